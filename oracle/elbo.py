@@ -1,0 +1,396 @@
+"""Oracle: posterior aggregation + reparameterisation + KL / IWAE + reconstruction NLL.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Plain torch-CPU restatement of
+  /root/reference/src/multivae/models/base/base_utils.py   (poe, stable_poe, kl_divergence, rsample, log-probs)
+  /root/reference/src/multivae/models/mopoe/mopoe_model.py (MoPoE.forward / inference / selection / divergence)
+  /root/reference/src/multivae/models/mvtcae/mvtcae_model.py (MVTCAE.forward)
+  /root/reference/src/multivae/models/mmvae/mmvae_model.py (MMVAE.forward / compute_k_lws / loosers)
+  /root/reference/src/multivae/models/jmvae/jmvae_model.py (JMVAE.forward)
+Noise (`eps`, `choice`, `u`) is always an explicit argument.
+"""
+import math
+from itertools import chain, combinations
+
+import torch
+import torch.nn.functional as F
+
+HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
+
+
+# ----------------------------------------------------------------------------------------------
+# a1-a5: helpers of base_utils.py
+# ----------------------------------------------------------------------------------------------
+def poe(mus, logvars, eps=1e-8):
+    """Gaussian product of experts over dim 0.  base_utils.py:122-130.
+
+    The 1e-8 is added to every expert's variance, also for single-expert stacks.
+    """
+    var = torch.exp(logvars) + eps
+    T = 1.0 / var
+    pd_mu = torch.sum(mus * T, dim=0) / torch.sum(T, dim=0)
+    pd_var = 1.0 / torch.sum(T, dim=0)
+    return pd_mu, torch.log(pd_var)
+
+
+def stable_poe(mus, logvars):
+    """log-sum-exp PoE without the variance epsilon.  base_utils.py:133-147."""
+    if len(mus) == 1:
+        return mus[0], logvars[0]
+    ln_inv = torch.stack([-l for l in logvars])
+    ln_var = -torch.logsumexp(ln_inv, dim=0)
+    mu = (torch.exp(ln_inv) * torch.stack(list(mus))).sum(dim=0) * torch.exp(ln_var)
+    return mu, ln_var
+
+
+def kl_divergence(mean, log_var, prior_mean, prior_log_var):
+    """General diagonal-Gaussian KL summed over the last dim.  base_utils.py:90-119."""
+    kl = 0.5 * (
+        prior_log_var
+        - log_var
+        + torch.exp(log_var - prior_log_var)
+        + ((mean - prior_mean) ** 2) / torch.exp(prior_log_var)
+        - 1
+    )
+    return kl.sum(dim=-1)
+
+
+def rsample(mu, log_var, eps):
+    """z = mu + exp(0.5*log_var) * eps.  base_utils.py:150-172 with the N(0,1) draw made explicit.
+
+    eps is [B,L] (N == 1) or [K,B,L] (N == K; `Normal.rsample([K])` broadcasts the same way).
+    """
+    return mu + torch.exp(0.5 * log_var) * eps
+
+
+def recon_log_prob(dist_name, recon, target, scale=1.0):
+    """Elementwise decoder log-probability.  base_utils.py:62-87 (torch.distributions formulas)."""
+    if dist_name == "normal":
+        # Normal(recon, scale).log_prob(target)
+        return -((target - recon) ** 2) / (2.0 * scale * scale) - math.log(scale) - HALF_LOG_2PI
+    if dist_name == "laplace":
+        # Laplace(recon, scale).log_prob(target)
+        return -math.log(2.0 * scale) - torch.abs(target - recon) / scale
+    if dist_name == "bernoulli":
+        # Bernoulli(logits=recon).log_prob(target) = -BCEWithLogits
+        return -F.binary_cross_entropy_with_logits(recon, target.expand_as(recon), reduction="none")
+    if dist_name == "categorical":
+        # base_utils.py:28-40: target * log_softmax(recon + 1e-6)
+        return target * F.log_softmax(recon + 1e-6, dim=-1)
+    raise ValueError(dist_name)
+
+
+def rescale_factors(input_dims, uses_likelihood_rescaling, given=None):
+    """base_ae_model.py:127-152."""
+    if not uses_likelihood_rescaling:
+        return {k: 1.0 for k in input_dims}
+    if given is not None:
+        return dict(given)
+    prods = {k: float(math.prod(v)) for k, v in input_dims.items()}
+    mx = max(prods.values())
+    return {k: mx / prods[k] for k in prods}
+
+
+def _row_nll(dist_name, recon, x, rescale, scale=1.0):
+    """-(log p(x|recon) * rescale) summed over everything but the leading batch dims of `x`.
+
+    recon is [B,*D] or [K,B,*D]; returns [B] or [K,B].
+    """
+    lp = recon_log_prob(dist_name, recon, x, scale)
+    lead = recon.dim() - (x.dim() - 1)
+    return (-lp * rescale).reshape(*recon.shape[:lead], -1).sum(-1)
+
+
+# ----------------------------------------------------------------------------------------------
+# a6-a10: MoPoE
+# ----------------------------------------------------------------------------------------------
+def mopoe_subsets(names):
+    """Non-empty subsets in the reference's enumeration order.  mopoe_model.py:71-106, :291-292.
+
+    `names` is the encoder-dict order.  Subsets come by increasing size, `itertools.combinations`
+    order; inside a subset the experts are in sorted-name order; key = "_".join(sorted(subset)).
+    """
+    names = list(names)
+    out = []
+    for combo in chain.from_iterable(combinations(names, n) for n in range(len(names) + 1)):
+        if len(combo) == 0:
+            continue  # the "" key exists in model.subsets but is skipped at :292
+        mods = sorted(combo)
+        out.append(("_".join(mods), mods))
+    return out
+
+
+def mopoe_row_bounds(B, S):
+    """Row-range assignment of subsets.  mopoe_model.py:435-465 with w = 1/S.
+
+    n = int(floor(B * (1/S))) computed in float32 like the reference's tensor arithmetic.
+    """
+    w = torch.tensor(1.0 / float(S), dtype=torch.float32)
+    n = int(torch.floor(B * w))
+    bounds = [0]
+    for k in range(S):
+        bounds.append(B if k == S - 1 else bounds[-1] + n)
+    bounds[-1] = B
+    return bounds
+
+
+def mopoe_inference(enc, names, masks=None, choice=None, subsets=None):
+    """mopoe_model.py:274-350.
+
+    enc: {name: (mu[B,L], logvar[B,L])}.  Returns dict(mus[S,B,L], logvars[S,B,L], weights[S,B],
+    joint_mu, joint_logvar, keys).  `choice` [B,S] one-hot (float/bool) replaces the
+    OneHotCategorical draw of :417-433 for masked inputs.
+    """
+    subsets = mopoe_subsets(names) if subsets is None else subsets
+    M = len(names)
+    mus, lvs, avail = [], [], []
+    for key, mods in subsets:
+        smu = torch.stack([enc[m][0] for m in mods])
+        slv = torch.stack([enc[m][1] for m in mods])
+        if smu.shape[0] == M:  # prior expert only on the full subset (:249-262)
+            smu = torch.cat([smu, torch.zeros_like(smu[:1])], 0)
+            slv = torch.cat([slv, torch.zeros_like(slv[:1])], 0)
+        mu_s, lv_s = poe(smu, slv)
+        mus.append(mu_s)
+        lvs.append(lv_s)
+        if masks is not None:
+            f = torch.ones_like(masks[mods[0]], dtype=torch.bool)
+            for m in mods:
+                f = torch.logical_and(f, masks[m].bool())
+            avail.append(f)
+    mus = torch.stack(mus)
+    lvs = torch.stack(lvs)
+    S, B = mus.shape[0], mus.shape[1]
+    if masks is not None:
+        a = torch.stack(avail).to(mus.dtype)
+        weights = a / a.sum(0)
+        sel = choice.bool()  # [B,S]
+        jm = mus.permute(1, 0, 2)[sel]
+        jl = lvs.permute(1, 0, 2)[sel]
+    else:
+        weights = torch.full((S, B), 1.0 / float(S), dtype=mus.dtype)
+        bnd = mopoe_row_bounds(B, S)
+        jm = torch.cat([mus[k, bnd[k] : bnd[k + 1]] for k in range(S)])
+        jl = torch.cat([lvs[k, bnd[k] : bnd[k + 1]] for k in range(S)])
+    return dict(mus=mus, logvars=lvs, weights=weights, joint_mu=jm, joint_logvar=jl,
+                keys=[k for k, _ in subsets])
+
+
+def mopoe_joint_divergence(mus, logvars, weights):
+    """mopoe_model.py:108-145: mean_b sum_s w[s,b] * KL(N(mu_s, var_s) || N(0, I))."""
+    klds = -0.5 * (1 - logvars.exp() - mus.pow(2) + logvars).sum(-1)  # [S,B]
+    return (weights * klds).sum(dim=0).mean(), klds
+
+
+def mopoe_forward(enc, data, decoders, eps, *, names, beta=1.0, rescale=None, dists=None,
+                  dist_scales=None, masks=None, choice=None, subsets=None):
+    """MoPoE.forward, one shared latent space.  mopoe_model.py:147-227 (Appendix A.1).
+
+    eps [B,L] reproduces the reference exactly; eps [K,B,L] is the K-sample Monte-Carlo extension
+    of SURVEY.md §0 D1: the reconstruction term is averaged over k, the analytic KL is unchanged.
+    decoders: {name: callable(z[...,L]) -> recon[...,*D]}.
+    """
+    rescale = rescale or {m: 1.0 for m in names}
+    dists = dists or {m: "normal" for m in names}
+    dist_scales = dist_scales or {}
+    inf = mopoe_inference(enc, names, masks=masks, choice=choice, subsets=subsets)
+    z = rsample(inf["joint_mu"], inf["joint_logvar"], eps)
+    B = inf["joint_mu"].shape[0]
+    kld, klds = mopoe_joint_divergence(inf["mus"], inf["logvars"], inf["weights"])
+    metrics = {"joint_divergence": kld}
+    rows = {}
+    loss = 0
+    for m in names:
+        recon = decoders[m](z)
+        r = _row_nll(dists[m], recon, data[m], rescale[m], dist_scales.get(m, 1.0))  # [B] or [K,B]
+        rows[m] = r
+        if r.dim() == 2:
+            r = r.mean(0)
+        if masks is not None:
+            r = r * masks[m].to(r.dtype)
+        metrics["recon_" + m] = r.mean()
+        loss = loss + metrics["recon_" + m]
+    loss = loss + beta * kld
+    out = dict(inf)
+    out.update(loss=loss, loss_sum=loss * B, metrics=metrics, z=z, klds=klds, rows=rows)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# a14: MVTCAE
+# ----------------------------------------------------------------------------------------------
+def mvtcae_forward(enc, data, decoders, eps, *, names, alpha=0.1, beta=2.5, rescale=None, dists=None,
+                   dist_scales=None, masks=None):
+    """MVTCAE.forward.  mvtcae_model.py:42-169 (Appendix A.3).  Metrics are SUMS over the batch."""
+    rescale = rescale or {m: 1.0 for m in names}
+    dists = dists or {m: "normal" for m in names}
+    dist_scales = dist_scales or {}
+    M = len(names)
+    mus = torch.stack([enc[m][0] for m in names])
+    lvs = []
+    for m in names:
+        lv = enc[m][1]
+        if masks is not None:  # :128-129  missing rows get +inf log-variance
+            lv = torch.where(masks[m].bool().unsqueeze(-1), lv, torch.full_like(lv, float("inf")))
+        lvs.append(lv)
+    lvs = torch.stack(lvs)
+    jmu, jlv = poe(mus, lvs)  # no prior expert (:163)
+    z = rsample(jmu, jlv, eps)
+    B = jmu.shape[0]
+    joint_kld = -0.5 * torch.sum(1 - jlv.exp() - jmu.pow(2) + jlv)
+    metrics = {"joint_divergence": joint_kld}
+    loss_rec = 0
+    rows = {}
+    for m in names:
+        recon = decoders[m](z)
+        r = _row_nll(dists[m], recon, data[m], rescale[m], dist_scales.get(m, 1.0))
+        rows[m] = r
+        if r.dim() == 2:
+            r = r.mean(0)
+        if masks is not None:
+            r = masks[m].to(r.dtype) * r
+        metrics[m] = r.sum()
+        loss_rec = loss_rec + r.sum()
+    kld_losses = 0.0
+    for i, m in enumerate(names):
+        mu, lv = mus[i], lvs[i]
+        k = -0.5 * (1 - jlv.exp() / lv.exp() - (jmu - mu).pow(2) / lv.exp() + jlv - lv)
+        k = k.reshape(B, -1).sum(-1)
+        if masks is not None:
+            k = torch.where(masks[m].bool(), k, torch.zeros_like(k))
+        metrics["kld_" + m] = k.sum()
+        kld_losses = kld_losses + k.sum()
+    rec_w = (M - alpha) / M
+    cvib_w = alpha / M
+    vib_w = 1 - alpha
+    total = rec_w * loss_rec + beta * (cvib_w * kld_losses + vib_w * joint_kld)
+    return dict(loss=total / B, loss_sum=total, metrics=metrics, joint_mu=jmu, joint_logvar=jlv, z=z,
+                rows=rows)
+
+
+# ----------------------------------------------------------------------------------------------
+# a11-a13: MMVAE
+# ----------------------------------------------------------------------------------------------
+def mmvae_std(log_var, family):
+    """mmvae_model.py:66-74."""
+    if family == "laplace_with_softmax":
+        return F.softmax(log_var, dim=-1) * log_var.size(-1) + 1e-6
+    return torch.exp(0.5 * log_var)
+
+
+def latent_log_prob(family, z, loc, scale):
+    """torch.distributions Normal / Laplace log_prob on the latent."""
+    if family == "normal":
+        return -((z - loc) ** 2) / (2 * scale * scale) - torch.log(scale) - HALF_LOG_2PI
+    return -torch.log(2 * scale) - torch.abs(z - loc) / scale
+
+
+def latent_rsample(family, loc, scale, noise):
+    """Normal.rsample: loc + scale*eps.  Laplace.rsample: u ~ U(eps_f32-1, 1);
+    loc - scale * sign(u) * log1p(-|u|)  (SURVEY.md Appendix B).  noise is [K,B,L]."""
+    if family == "normal":
+        return loc + scale * noise
+    return loc - scale * noise.sign() * torch.log1p(-noise.abs())
+
+
+def mmvae_forward(enc, data, decoders, noise, *, names, K, family="laplace_with_softmax",
+                  loss="dreg_looser", prior_mean=None, prior_log_var=None, rescale=None, dists=None,
+                  dist_scales=None, masks=None):
+    """MMVAE.forward + compute_k_lws + iwae_looser / dreg_looser.  mmvae_model.py:95-292 (A.2).
+
+    enc: {name: (mu, log_var)} for the modalities present; noise: {name: [K,B,L]}.
+    The DReG gradient hook (:263-266) is reproduced with `Tensor.register_hook` on z.
+    """
+    mods = [m for m in names if m in data]
+    rescale = rescale or {m: 1.0 for m in names}
+    dists = dists or {m: "normal" for m in names}
+    dist_scales = dist_scales or {}
+    L = enc[mods[0]][0].shape[-1]
+    ref = enc[mods[0]][0]
+    if prior_mean is None:
+        prior_mean = torch.zeros(1, L, dtype=ref.dtype)
+    if prior_log_var is None:
+        prior_log_var = torch.zeros(1, L, dtype=ref.dtype)
+    p_std = mmvae_std(prior_log_var, family)
+    post, post_det, zs, recons = {}, {}, {}, {}
+    for c in mods:
+        mu, lv = enc[c]
+        sig = mmvae_std(lv, family)
+        z = latent_rsample(family, mu, sig, noise[c])  # [K,B,L]
+        post[c] = (mu, sig)
+        post_det[c] = (mu.detach(), sig.detach())
+        zs[c] = z
+        flat = z.reshape(-1, L)
+        recons[c] = {}
+        for r in mods:
+            rec = decoders[r](flat)
+            recons[c][r] = rec.reshape(*z.shape[:-1], *rec.shape[1:])
+    q = post_det if loss == "dreg_looser" else post
+    if masks is not None:
+        n_avail = torch.stack([masks[m] for m in masks]).int().sum(0)
+    else:
+        n_avail = torch.tensor([len(names)])
+    lws = {}
+    for c in mods:
+        z = zs[c]
+        lpz = latent_log_prob(family, z, prior_mean, p_std).sum(-1)
+        lq = []
+        for m in mods:
+            v = latent_log_prob(family, z, q[m][0], q[m][1]).sum(-1)
+            if masks is not None:
+                v = torch.where(masks[m].bool().unsqueeze(0), v, torch.full_like(v, -float("inf")))
+            lq.append(v)
+        lq = torch.logsumexp(torch.stack(lq), dim=0) - torch.log(n_avail.to(z.dtype))
+        lpx = 0
+        for r in mods:
+            lp = recon_log_prob(dists[r], recons[c][r], data[r], dist_scales.get(r, 1.0))
+            lp = lp.reshape(z.shape[0], z.shape[1], -1).mul(rescale[r]).sum(-1)
+            if masks is not None:
+                lp = lp * masks[r].to(lp.dtype)
+            lpx = lpx + lp
+        lw = lpx + lpz - lq
+        if masks is not None:
+            lw = lw * masks[c].to(lw.dtype)
+        lws[c] = lw
+    if loss == "dreg_looser":
+        wk = {}
+        with torch.no_grad():
+            for c in mods:
+                wk[c] = (lws[c] - torch.logsumexp(lws[c], 0, keepdim=True)).exp()
+        tot = torch.stack([lws[c] * wk[c] for c in mods]).sum(1)
+        for c in mods:
+            if zs[c].requires_grad:
+                zs[c].register_hook(lambda g, w=wk[c]: w.unsqueeze(-1) * g)
+    else:
+        tot = torch.logsumexp(torch.stack([lws[c] for c in mods]), dim=1) - math.log(K)
+    tot = tot.sum(0) / n_avail.to(tot.dtype)
+    loss_v = -tot.sum()
+    return dict(loss=loss_v, loss_sum=loss_v, metrics={}, lws=lws, zs=zs)
+
+
+# ----------------------------------------------------------------------------------------------
+# a16: JMVAE (loss assembly only; the joint encoder is a network, see nets.py)
+# ----------------------------------------------------------------------------------------------
+def jmvae_forward(joint, enc, data, decoders, eps, *, names, alpha=0.1, beta=1.0, warmup=10, epoch=1,
+                  rescale=None, dists=None, dist_scales=None):
+    """JMVAE.forward.  jmvae_model.py:116-192 (Appendix A.4).  joint = (mu, log_var) of the joint encoder."""
+    rescale = rescale or {m: 1.0 for m in names}
+    dists = dists or {m: "normal" for m in names}
+    dist_scales = dist_scales or {}
+    mu, lv = joint
+    z = rsample(mu, lv, eps)
+    B = mu.shape[0]
+    rec = 0
+    for m in names:
+        recon = decoders[m](z)
+        rec = rec + _row_nll(dists[m], recon, data[m], rescale[m], dist_scales.get(m, 1.0)).sum()
+    kld = -0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp())
+    ljm = 0
+    for m in names:  # accumulated elementwise, then summed (:160-174)
+        mu_m, lv_m = enc[m]
+        ljm = ljm + 1 / 2 * (lv_m - lv + (torch.exp(lv) + (mu - mu_m) ** 2) / torch.exp(lv_m) - 1)
+    ljm = ljm.sum() * alpha
+    kld = kld * beta
+    a = 1.0 if epoch >= warmup else epoch / warmup
+    loss_sum = rec + a * (kld + ljm)
+    return dict(loss=loss_sum / B, loss_sum=loss_sum,
+                metrics=dict(loss_no_ponderation=rec + kld + ljm, beta=a, elbo=(rec + kld) / B), z=z)

@@ -1,0 +1,124 @@
+"""Oracle: the in-package encoder/decoder architectures as pure functions of a state dict.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Restates
+  /root/reference/src/multivae/models/nn/default_architectures.py:21-72   Encoder_VAE_MLP
+  /root/reference/src/multivae/models/nn/default_architectures.py:225-258 Decoder_AE_MLP
+  /root/reference/src/multivae/models/nn/svhn.py:7-38                     Encoder_VAE_SVHN
+  /root/reference/src/multivae/models/nn/svhn.py:41-70                    Decoder_VAE_SVHN
+  /root/reference/src/multivae/models/nn/default_architectures.py:261-322 MultipleHeadJointEncoder
+with the reference's parameter names (`<prefix>layers.0.0.weight`, `<prefix>enc.0.weight`, ...), on
+torch CPU ops (the reference itself is torch ops; F.linear / F.conv2d are the same aten kernels).
+`conv2d_np` / `conv_transpose2d_np` are independent numpy restatements of the two convolution
+definitions, used to pin the layout/stride/padding semantics without torch.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def mlp_encoder(sd, prefix, x, n_hidden=1):
+    """Encoder_VAE_MLP.forward: reshape(-1, prod D) -> [Linear+ReLU]*(1+n_hidden) -> two heads."""
+    w0 = sd[prefix + "layers.0.0.weight"]
+    h = x.reshape(-1, w0.shape[1])
+    for i in range(1 + n_hidden):
+        h = F.relu(F.linear(h, sd[f"{prefix}layers.{i}.0.weight"], sd[f"{prefix}layers.{i}.0.bias"]))
+    mu = F.linear(h, sd[prefix + "embedding.weight"], sd[prefix + "embedding.bias"])
+    lv = F.linear(h, sd[prefix + "log_var.weight"], sd[prefix + "log_var.bias"])
+    return mu, lv
+
+
+def mlp_decoder(sd, prefix, z, input_dim):
+    """Decoder_AE_MLP.forward: Linear(L,512)+ReLU -> Linear(512, prod D)+Sigmoid -> reshape(*z.shape[:-1], *D)."""
+    h = F.relu(F.linear(z, sd[prefix + "layers.0.0.weight"], sd[prefix + "layers.0.0.bias"]))
+    h = torch.sigmoid(F.linear(h, sd[prefix + "layers.1.0.weight"], sd[prefix + "layers.1.0.bias"]))
+    return h.reshape(*z.shape[:-1], *input_dim)
+
+
+def svhn_encoder(sd, prefix, x):
+    """Encoder_VAE_SVHN.forward: 3x Conv(4,2,1)+ReLU, two Conv(4,2,0) heads, `.squeeze()`.
+
+    `.squeeze()` removes ALL unit dims, so B == 1 collapses the batch dim like the reference (Appendix D).
+    """
+    h = x
+    for i in (0, 2, 4):
+        h = F.relu(F.conv2d(h, sd[f"{prefix}enc.{i}.weight"], sd[f"{prefix}enc.{i}.bias"], stride=2, padding=1))
+    mu = F.conv2d(h, sd[prefix + "c1.weight"], sd[prefix + "c1.bias"], stride=2, padding=0).squeeze()
+    lv = F.conv2d(h, sd[prefix + "c2.weight"], sd[prefix + "c2.bias"], stride=2, padding=0).squeeze()
+    return mu, lv
+
+
+def svhn_decoder(sd, prefix, z):
+    """Decoder_VAE_SVHN.forward: z[...,L] -> ConvT(4,1,0)+ReLU -> 2x ConvT(4,2,1)+ReLU -> ConvT(4,2,1)+Sigmoid."""
+    lead = z.shape[:-1]
+    h = z.reshape(-1, z.shape[-1], 1, 1)
+    h = F.relu(F.conv_transpose2d(h, sd[prefix + "dec.0.weight"], sd[prefix + "dec.0.bias"], stride=1, padding=0))
+    h = F.relu(F.conv_transpose2d(h, sd[prefix + "dec.2.weight"], sd[prefix + "dec.2.bias"], stride=2, padding=1))
+    h = F.relu(F.conv_transpose2d(h, sd[prefix + "dec.4.weight"], sd[prefix + "dec.4.bias"], stride=2, padding=1))
+    h = torch.sigmoid(F.conv_transpose2d(h, sd[prefix + "dec.6.weight"], sd[prefix + "dec.6.bias"], stride=2, padding=1))
+    return h.reshape(*lead, *h.shape[1:])
+
+
+def build_mnist_svhn(sd, latent_dim=20):
+    """Encoder / decoder callables for the MnistSvhn architecture of examples/distributed_training.py:42-50
+    (MLP for mnist, conv for svhn) bound to state dict `sd` with the BaseMultiVAE key prefixes."""
+    enc = {
+        "mnist": lambda x: mlp_encoder(sd, "encoders.mnist.", x),
+        "svhn": lambda x: svhn_encoder(sd, "encoders.svhn.", x),
+    }
+    dec = {
+        "mnist": lambda z: mlp_decoder(sd, "decoders.mnist.", z, (1, 28, 28)),
+        "svhn": lambda z: svhn_decoder(sd, "decoders.svhn.", z),
+    }
+    return enc, dec
+
+
+def build_default_mlp(sd, input_dims):
+    """Default architectures (BaseDictEncoders / BaseDictDecoders, default_architectures.py:143-222)."""
+    enc = {m: (lambda x, m=m: mlp_encoder(sd, f"encoders.{m}.", x)) for m in input_dims}
+    dec = {m: (lambda z, m=m: mlp_decoder(sd, f"decoders.{m}.", z, tuple(input_dims[m]))) for m in input_dims}
+    return enc, dec
+
+
+# ----------------------------------------------------------------------------------------------
+# numpy pins of the two convolution definitions (small inputs only: O(N*C*C*H*W*k*k) python-free einsum)
+# ----------------------------------------------------------------------------------------------
+def conv2d_np(x, w, b, stride, padding):
+    """out[n,co,oh,ow] = b[co] + sum_{ci,kh,kw} x[n,ci,oh*s-p+kh, ow*s-p+kw] * w[co,ci,kh,kw]."""
+    x = np.asarray(x, np.float64)
+    w = np.asarray(w, np.float64)
+    N, C, H, W = x.shape
+    CO, _, KH, KW = w.shape
+    xp = np.zeros((N, C, H + 2 * padding, W + 2 * padding))
+    xp[:, :, padding : padding + H, padding : padding + W] = x
+    OH = (H + 2 * padding - KH) // stride + 1
+    OW = (W + 2 * padding - KW) // stride + 1
+    out = np.zeros((N, CO, OH, OW))
+    for kh in range(KH):
+        for kw in range(KW):
+            patch = xp[:, :, kh : kh + stride * OH : stride, kw : kw + stride * OW : stride]
+            out += np.einsum("nchw,oc->nohw", patch, w[:, :, kh, kw])
+    return out + np.asarray(b, np.float64)[None, :, None, None]
+
+
+def conv_transpose2d_np(x, w, b, stride, padding):
+    """out[n,co,ih*s-p+kh, iw*s-p+kw] += x[n,ci,ih,iw] * w[ci,co,kh,kw]; weight layout [Cin,Cout,KH,KW]."""
+    x = np.asarray(x, np.float64)
+    w = np.asarray(w, np.float64)
+    N, C, H, W = x.shape
+    _, CO, KH, KW = w.shape
+    FH = (H - 1) * stride + KH
+    FW = (W - 1) * stride + KW
+    full = np.zeros((N, CO, FH, FW))
+    for kh in range(KH):
+        for kw in range(KW):
+            full[:, :, kh : kh + stride * H : stride, kw : kw + stride * W : stride] += np.einsum(
+                "nchw,co->nohw", x, w[:, :, kh, kw]
+            )
+    out = full[:, :, padding : FH - padding, padding : FW - padding]
+    return out + np.asarray(b, np.float64)[None, :, None, None]
+
+
+def count_params(sd):
+    return int(sum(math.prod(v.shape) for v in sd.values()))

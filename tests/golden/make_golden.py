@@ -1,0 +1,423 @@
+"""Generate the golden vectors under tests/golden/ by running the REAL reference.
+
+Run in the build container only (needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+For every case the script
+  1. builds the reference model (`multivae.models.*`) and loads procedurally generated weights
+     (tests/golden/procedural.py, bit-exact integer hash) through `load_state_dict`;
+  2. seeds the global torch generator, runs the reference forward + backward;
+  3. re-seeds and replays the reference's noise draws in the order of SURVEY.md Appendix B to record
+     the noise tensors the forward consumed;
+  4. checks that `oracle/` fed with that recorded noise reproduces the reference (printed), and
+  5. stores noise + expected outputs (loss, metrics, intermediates, gradient statistics and sampled
+     gradient entries) in a small .npz.  Weights and inputs are NOT stored: tests regenerate them.
+The fixtures contain arrays and JSON hyper-parameters only — no reference source, bytecode or pickles.
+"""
+import sys
+
+sys.dont_write_bytecode = True
+import json
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+import _reference_import as R
+
+R.install()
+import procedural as P
+from multivae.data.datasets.base import IncompleteDataset, MultimodalBaseDataset
+from multivae.models import (JMVAE, MMVAE, MVTCAE, JMVAEConfig, MMVAEConfig, MoPoE, MoPoEConfig,
+                             MVTCAEConfig)
+from multivae.models.base import base_utils as ref_utils
+from multivae.models.base.base_config import BaseAEConfig
+from multivae.models.nn.default_architectures import Decoder_AE_MLP, Encoder_VAE_MLP
+from multivae.models.nn.svhn import Decoder_VAE_SVHN, Encoder_VAE_SVHN
+
+import oracle
+from oracle import elbo, nets
+
+torch.set_num_threads(4)
+GRAD_SAMPLES = 48
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def grad_stats(named_grads):
+    """name -> (sum, abs_sum, sampled values) as flat arrays; sample positions come from procedural.hash_indices."""
+    out = {}
+    for i, (name, g) in enumerate(named_grads.items()):
+        g = g.detach().double().reshape(-1).numpy()
+        idx = P.hash_indices(g.size, GRAD_SAMPLES, P.name_seed(name))
+        out["gsum/" + name] = np.array([g.sum(), np.abs(g).sum()])
+        out["gval/" + name] = g[idx].astype(np.float32)
+    return out
+
+
+def load_weights(model, sd_np):
+    sd = {k: t(v) for k, v in sd_np.items()}
+    missing = model.load_state_dict(sd, strict=False)
+    extra = [k for k in missing.missing_keys if not k.startswith("prior_")]
+    assert not extra and not missing.unexpected_keys, (missing,)
+
+
+def ref_grads(model):
+    return {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in model.named_parameters()}
+
+
+def oracle_sd(sd_np, requires_grad=True):
+    return {k: t(v).clone().requires_grad_(requires_grad) for k, v in sd_np.items()}
+
+
+def save(name, cfg, arrays):
+    arrays = {k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()}
+    arrays["cfg_json"] = np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {name}.npz  {os.path.getsize(path)/1024:.1f} KiB")
+
+
+def report(tag, a, b):
+    a, b = float(a), float(b)
+    print(f"  {tag}: ref {a:.8g} oracle {b:.8g} rel {abs(a-b)/max(abs(a),1e-30):.2e}")
+    assert abs(a - b) <= 2e-6 * max(abs(a), 1.0), tag
+
+
+def cmp_grads(tag, gref, gor):
+    worst = 0.0
+    for k in gref:
+        a, b = gref[k].double(), gor[k].double()
+        worst = max(worst, float((a - b).abs().max() / (a.abs().max() + 1e-12)))
+    print(f"  {tag}: worst grad rel-to-max err {worst:.2e}")
+    assert worst < 5e-5, tag
+
+
+# ---------------------------------------------------------------------------------------------------
+TINY_DIMS = dict(mod1=(2,), mod2=(3,), mod3=(4,), mod4=(4,))  # tests/test_mopoe.py:23-43 shapes
+TINY_L = 5
+
+
+def tiny_data(B, seed, masked):
+    data = {m: P.uniform((B,) + d, seed + i) for i, (m, d) in enumerate(TINY_DIMS.items())}
+    masks = None
+    if masked:
+        masks = {}
+        for i, m in enumerate(TINY_DIMS):
+            mk = P.hash_uniform(B, seed + 50 + i) > 0.4
+            masks[m] = mk
+        masks["mod1"][:] = True  # at least one modality always present
+        masks["mod3"][0] = False
+    return data, masks
+
+
+def ref_dataset(data, masks):
+    d = {m: t(v) for m, v in data.items()}
+    if masks is None:
+        return MultimodalBaseDataset(data=d)
+    return IncompleteDataset(data=d, masks={m: t(v) for m, v in masks.items()})
+
+
+def mnist_svhn_data(B, seed):
+    return {"mnist": P.uniform((B, 1, 28, 28), seed), "svhn": P.uniform((B, 3, 32, 32), seed + 1)}
+
+
+def mnist_svhn_arch(L):
+    enc = dict(mnist=Encoder_VAE_MLP(BaseAEConfig(latent_dim=L, input_dim=(1, 28, 28))),
+               svhn=Encoder_VAE_SVHN(BaseAEConfig(latent_dim=L, input_dim=(3, 32, 32))))
+    dec = dict(mnist=Decoder_AE_MLP(BaseAEConfig(latent_dim=L, input_dim=(1, 28, 28))),
+               svhn=Decoder_VAE_SVHN(BaseAEConfig(latent_dim=L, input_dim=(3, 32, 32))))
+    return enc, dec
+
+
+# ---------------------------------------------------------------------------------------------------
+def unit_goldens():
+    print("unit_base_utils")
+    g = torch.Generator().manual_seed(11)
+    mus = torch.randn(3, 7, 5, generator=g)
+    lvs = torch.randn(3, 7, 5, generator=g)
+    lvs[1, 2] = float("inf")  # an "absent expert" row (MVTCAE masks, mvtcae_model.py:128)
+    out = {"mus": mus, "lvs": lvs}
+    pm, pl = ref_utils.poe(mus, lvs)
+    out["poe_mu"], out["poe_lv"] = pm, pl
+    fin = torch.randn(3, 7, 5, generator=g)
+    sm, sl = ref_utils.stable_poe(mus, fin)
+    out["fin_lvs"], out["spoe_mu"], out["spoe_lv"] = fin, sm, sl
+    out["kl"] = ref_utils.kl_divergence(mus[0], fin[0], mus[2], fin[2])
+    torch.manual_seed(5)
+    z1 = ref_utils.rsample_from_gaussian(mus[0], fin[0])
+    zK = ref_utils.rsample_from_gaussian(mus[0], fin[0], N=4)
+    zKf = ref_utils.rsample_from_gaussian(mus[0], fin[0], N=4, flatten=True)
+    torch.manual_seed(5)
+    e1 = torch.randn(7, 5)
+    eK = torch.randn(4, 7, 5)
+    eKf = torch.randn(4, 7, 5)
+    out.update(z1=z1, zK=zK, zKf=zKf, eps1=e1, epsK=eK, epsKf=eKf)
+    assert torch.equal(z1, elbo.rsample(mus[0], fin[0], e1))
+    recon = torch.randn(4, 7, 6, generator=g)
+    target = torch.rand(7, 6, generator=g)
+    out["recon"], out["target"] = recon, target
+    for name, params in (("normal", {}), ("normal", {"scale": 0.75}), ("laplace", {"scale": 0.75}),
+                         ("bernoulli", {})):
+        tag = name + ("_s" if params else "")
+        fn = ref_utils.set_decoder_dist(name, dict(params))
+        tgt = (target > 0.5).float() if name == "bernoulli" else target
+        out["lp_" + tag] = fn(recon, tgt)
+        mine = elbo.recon_log_prob(name, recon, tgt, params.get("scale", 1.0))
+        assert torch.allclose(out["lp_" + tag], mine, rtol=1e-6, atol=1e-6), tag
+    onehot = torch.nn.functional.one_hot(torch.randint(0, 6, (7,), generator=g), 6).float()
+    out["onehot"] = onehot
+    out["lp_categorical"] = ref_utils.set_decoder_dist("categorical", {})(recon, onehot)
+    assert torch.allclose(pm, elbo.poe(mus, lvs)[0]) and torch.allclose(sm, elbo.stable_poe(mus, fin)[0])
+    save("unit_base_utils", {}, out)
+
+
+def mopoe_case(name, *, arch, B, beta, rescaling, masked, seed, K=1, dists=None):
+    print(name)
+    L = TINY_L if arch == "tiny" else 20
+    if arch == "tiny":
+        dims = TINY_DIMS
+        shapes = P.default_mlp_shapes(dims, L)
+        data, masks = tiny_data(B, seed, masked)
+        for m, d in (dists or {}).items():
+            if d == "bernoulli":  # Bernoulli targets must be {0,1}
+                data[m] = (data[m] > 0.5).astype(np.float32)
+        cfg = MoPoEConfig(n_modalities=4, latent_dim=L, input_dims=dict(dims), beta=beta,
+                          uses_likelihood_rescaling=rescaling, decoders_dist=dists)
+        model = MoPoE(cfg)
+    else:
+        dims = dict(mnist=(1, 28, 28), svhn=(3, 32, 32))
+        shapes = P.mnist_svhn_shapes(L)
+        data, masks = mnist_svhn_data(B, seed), None
+        cfg = MoPoEConfig(n_modalities=2, latent_dim=L, input_dims=dict(dims), beta=beta,
+                          uses_likelihood_rescaling=rescaling, decoders_dist=dists)
+        enc, dec = mnist_svhn_arch(L)
+        model = MoPoE(cfg, enc, dec)
+    sd_np = P.make_state_dict(shapes, seed)
+    load_weights(model, sd_np)
+    names = list(model.encoders.keys())
+    S = len(names and elbo.mopoe_subsets(names))
+    inputs = ref_dataset(data, masks)
+    model.train()
+    # --- noise replay (Appendix B): masked -> OneHotCategorical first, then normal_[B,L] (or [K,B,L])
+    torch.manual_seed(seed)
+    choice = None
+    if masked:
+        with torch.no_grad():
+            lat = model.inference(inputs)
+        torch.manual_seed(seed)
+        choice = torch.distributions.OneHotCategorical(probs=lat["weights"].permute(1, 0)).sample()
+    eps = torch.randn(B, L) if K == 1 else torch.randn(K, B, L)
+    # --- reference run
+    torch.manual_seed(seed)
+    if K == 1:
+        out = model(inputs)
+        loss, metrics = out.loss, out.metrics
+        with torch.no_grad():
+            lat = {k: v for k, v in model.inference(inputs).items() if k in ("mus", "logvars", "weights")} \
+                if not masked else None
+    else:
+        # K-sample Monte-Carlo extension assembled from the reference's own pieces:
+        # inference + rsample_from_gaussian(N=K) + decoders + recon_log_probs + calc_joint_divergence.
+        lat = model.inference(inputs)
+        z = ref_utils.rsample_from_gaussian(lat["joint"][0], lat["joint"][1], N=K)
+        kld = model.calc_joint_divergence(lat["mus"], lat["logvars"], lat["weights"])["joint_divergence"]
+        metrics = {"joint_divergence": kld}
+        loss = 0
+        for m in names:
+            recon = model.decoders[m](z).reconstruction
+            lp = model.recon_log_probs[m](recon, inputs.data[m]) * model.rescale_factors[m]
+            r = (-lp).reshape(K, B, -1).sum(-1).mean(0)
+            metrics["recon_" + m] = r.mean()
+            loss = loss + metrics["recon_" + m]
+        loss = loss + cfg.beta * kld
+    model.zero_grad()
+    loss.backward()
+    gref = ref_grads(model)
+    # --- oracle on the recorded noise
+    osd = oracle_sd(sd_np)
+    if arch == "tiny":
+        enc_f, dec_f = nets.build_default_mlp(osd, dims)
+    else:
+        enc_f, dec_f = nets.build_mnist_svhn(osd, L)
+    tdata = {m: t(v) for m, v in data.items()}
+    tmasks = None if masks is None else {m: t(v) for m, v in masks.items()}
+    e = {m: enc_f[m](tdata[m]) for m in names}
+    o = elbo.mopoe_forward(e, tdata, dec_f, eps, names=names, beta=beta,
+                           rescale=elbo.rescale_factors(dims, rescaling), dists=dists, masks=tmasks,
+                           choice=choice)
+    o["loss"].backward()
+    report("loss", loss, o["loss"])
+    for k in metrics:
+        report(k, metrics[k], o["metrics"][k])
+    cmp_grads("grads", gref, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in osd.items()})
+    arrays = dict(eps=eps, loss=loss.detach(), loss_sum=(loss * B).detach(),
+                  mus=o["mus"].detach(), logvars=o["logvars"].detach(), weights=o["weights"],
+                  joint_mu=o["joint_mu"].detach(), joint_logvar=o["joint_logvar"].detach(), z=o["z"].detach())
+    if K == 1 and not masked:
+        assert torch.allclose(lat["mus"], o["mus"], atol=1e-6) and torch.allclose(lat["logvars"], o["logvars"], atol=1e-6)
+        arrays["mus"], arrays["logvars"] = lat["mus"], lat["logvars"]
+    if choice is not None:
+        arrays["choice"] = choice
+    for k, v in metrics.items():
+        arrays["metric/" + k] = v.detach()
+    for m in names:
+        arrays["rows/" + m] = o["rows"][m].detach()
+    if masks is not None:
+        for m, v in masks.items():
+            arrays["mask/" + m] = v
+    arrays.update(grad_stats(gref))
+    save(name, dict(model="MoPoE", arch=arch, B=B, L=L, K=K, beta=beta, rescaling=rescaling, masked=masked,
+                    seed=seed, names=names, dists=dists, subsets=[k for k, _ in elbo.mopoe_subsets(names)]), arrays)
+
+
+def mvtcae_case(name, *, arch, B, alpha, beta, rescaling, masked, seed):
+    print(name)
+    if arch == "tiny":
+        dims, L = TINY_DIMS, TINY_L
+        data, masks = tiny_data(B, seed, masked)
+    else:  # cfg1: default MLP enc/dec on MnistSvhn shapes
+        dims, L = dict(mnist=(1, 28, 28), svhn=(3, 32, 32)), 20
+        data, masks = mnist_svhn_data(B, seed), None
+    shapes = P.default_mlp_shapes(dims, L)
+    cfg = MVTCAEConfig(n_modalities=len(dims), latent_dim=L, input_dims=dict(dims), alpha=alpha, beta=beta,
+                       uses_likelihood_rescaling=rescaling)
+    model = MVTCAE(cfg)
+    sd_np = P.make_state_dict(shapes, seed)
+    load_weights(model, sd_np)
+    names = list(model.encoders.keys())
+    inputs = ref_dataset(data, masks)
+    model.train()
+    torch.manual_seed(seed)
+    eps = torch.randn(B, L)
+    torch.manual_seed(seed)
+    out = model(inputs)
+    model.zero_grad()
+    out.loss.backward()
+    gref = ref_grads(model)
+    osd = oracle_sd(sd_np)
+    enc_f, dec_f = nets.build_default_mlp(osd, dims)
+    tdata = {m: t(v) for m, v in data.items()}
+    tmasks = None if masks is None else {m: t(v) for m, v in masks.items()}
+    e = {m: enc_f[m](tdata[m]) for m in names}
+    o = elbo.mvtcae_forward(e, tdata, dec_f, eps, names=names, alpha=alpha, beta=beta,
+                            rescale=elbo.rescale_factors(dims, rescaling), masks=tmasks)
+    o["loss"].backward()
+    report("loss", out.loss, o["loss"])
+    for k in out.metrics:
+        report(k, out.metrics[k], o["metrics"][k])
+    cmp_grads("grads", gref, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in osd.items()})
+    arrays = dict(eps=eps, loss=out.loss.detach(), loss_sum=out.loss_sum.detach(),
+                  joint_mu=o["joint_mu"].detach(), joint_logvar=o["joint_logvar"].detach(), z=o["z"].detach())
+    for k, v in out.metrics.items():
+        arrays["metric/" + k] = v.detach()
+    if masks is not None:
+        for m, v in masks.items():
+            arrays["mask/" + m] = v
+    arrays.update(grad_stats(gref))
+    save(name, dict(model="MVTCAE", arch=arch, B=B, L=L, alpha=alpha, beta=beta, rescaling=rescaling,
+                    masked=masked, seed=seed, names=names), arrays)
+
+
+def mmvae_case(name, *, arch, B, K, family, loss, rescaling, masked, seed, learn_prior=True):
+    print(name)
+    if arch == "tiny":
+        dims, L = TINY_DIMS, TINY_L
+        data, masks = tiny_data(B, seed, masked)
+        shapes = P.default_mlp_shapes(dims, L)
+        cfg = MMVAEConfig(n_modalities=4, latent_dim=L, input_dims=dict(dims), K=K,
+                          prior_and_posterior_dist=family, loss=loss, uses_likelihood_rescaling=rescaling,
+                          learn_prior=learn_prior)
+        model = MMVAE(cfg)
+    else:
+        dims, L = dict(mnist=(1, 28, 28), svhn=(3, 32, 32)), 20
+        data, masks = mnist_svhn_data(B, seed), None
+        shapes = P.mnist_svhn_shapes(L)
+        cfg = MMVAEConfig(n_modalities=2, latent_dim=L, input_dims=dict(dims), K=K,
+                          prior_and_posterior_dist=family, loss=loss, uses_likelihood_rescaling=rescaling,
+                          learn_prior=learn_prior)
+        enc, dec = mnist_svhn_arch(L)
+        model = MMVAE(cfg, enc, dec)
+    sd_np = P.make_state_dict(shapes, seed)
+    load_weights(model, sd_np)
+    plv = P.uniform((1, L), seed + 999, -0.3, 0.3)  # non-trivial learnable prior log-variance
+    with torch.no_grad():
+        model.prior_log_var.copy_(t(plv))
+    names = list(model.encoders.keys())
+    inputs = ref_dataset(data, masks)
+    mods = list(inputs.data.keys())
+    model.train()
+    torch.manual_seed(seed)
+    noise = {}
+    for m in mods:
+        if family == "normal":
+            noise[m] = torch.randn(K, B, L)
+        else:
+            noise[m] = torch.empty(K, B, L).uniform_(torch.finfo(torch.float32).eps - 1, 1)
+    torch.manual_seed(seed)
+    out = model(inputs)
+    model.zero_grad()
+    out.loss.backward()
+    gref = ref_grads(model)
+    osd = oracle_sd(sd_np)
+    oplv = t(plv).clone().requires_grad_(learn_prior)
+    if arch == "tiny":
+        enc_f, dec_f = nets.build_default_mlp(osd, dims)
+    else:
+        enc_f, dec_f = nets.build_mnist_svhn(osd, L)
+    tdata = {m: t(v) for m, v in data.items()}
+    tmasks = None if masks is None else {m: t(v) for m, v in masks.items()}
+    e = {m: enc_f[m](tdata[m]) for m in mods}
+    o = elbo.mmvae_forward(e, tdata, dec_f, noise, names=names, K=K, family=family, loss=loss,
+                           prior_log_var=oplv, rescale=elbo.rescale_factors(dims, rescaling), masks=tmasks)
+    o["loss"].backward()
+    report("loss", out.loss, o["loss"])
+    gor = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in osd.items()}
+    gor["prior_log_var"] = oplv.grad if oplv.grad is not None else torch.zeros_like(oplv)
+    gor["prior_mean"] = torch.zeros(1, L)
+    cmp_grads("grads", gref, gor)
+    arrays = dict(loss=out.loss.detach(), prior_log_var=plv)
+    for m in mods:
+        arrays["noise/" + m] = noise[m]
+        arrays["lws/" + m] = o["lws"][m].detach()
+        arrays["zs/" + m] = o["zs"][m].detach()
+    if masks is not None:
+        for m, v in masks.items():
+            arrays["mask/" + m] = v
+    arrays.update(grad_stats(gref))
+    save(name, dict(model="MMVAE", arch=arch, B=B, L=L, K=K, family=family, loss=loss, rescaling=rescaling,
+                    masked=masked, seed=seed, names=names, learn_prior=learn_prior), arrays)
+
+
+def main():
+    unit_goldens()
+    mopoe_case("mopoe_tiny_complete", arch="tiny", B=6, beta=1.0, rescaling=False, masked=False, seed=101)
+    mopoe_case("mopoe_tiny_beta_rescale", arch="tiny", B=7, beta=2.5, rescaling=True, masked=False, seed=102,
+               dists=dict(mod1="normal", mod2="laplace", mod3="bernoulli", mod4="normal"))
+    mopoe_case("mopoe_tiny_masked", arch="tiny", B=9, beta=1.5, rescaling=False, masked=True, seed=103)
+    mopoe_case("mopoe_mnistsvhn_k1", arch="mnistsvhn", B=16, beta=1.0, rescaling=False, masked=False, seed=104)
+    mopoe_case("mopoe_mnistsvhn_k1_rescale", arch="mnistsvhn", B=5, beta=1.0, rescaling=True, masked=False, seed=105)
+    mopoe_case("mopoe_mnistsvhn_k10", arch="mnistsvhn", B=8, beta=1.0, rescaling=False, masked=False, seed=106, K=10)
+    mvtcae_case("mvtcae_tiny_complete", arch="tiny", B=6, alpha=0.1, beta=2.5, rescaling=False, masked=False, seed=201)
+    mvtcae_case("mvtcae_tiny_masked", arch="tiny", B=9, alpha=0.3, beta=1.0, rescaling=True, masked=True, seed=202)
+    mvtcae_case("mvtcae_mnistsvhn_mlp", arch="mnistsvhn", B=8, alpha=0.1, beta=2.5, rescaling=False, masked=False, seed=203)
+    for fam, loss, msk, sd in (("normal", "iwae_looser", False, 301), ("laplace_with_softmax", "dreg_looser", False, 302),
+                               ("normal", "dreg_looser", True, 303), ("laplace_with_softmax", "iwae_looser", True, 304)):
+        short = ("normal" if fam == "normal" else "laplace") + "_" + loss.split("_")[0] + ("_masked" if msk else "")
+        mmvae_case("mmvae_tiny_" + short, arch="tiny", B=6, K=3, family=fam, loss=loss, rescaling=False, masked=msk, seed=sd)
+    mmvae_case("mmvae_mnistsvhn_laplace_dreg_k1", arch="mnistsvhn", B=8, K=1, family="laplace_with_softmax",
+               loss="dreg_looser", rescaling=True, masked=False, seed=305)
+    mmvae_case("mmvae_mnistsvhn_normal_iwae_k10", arch="mnistsvhn", B=4, K=10, family="normal",
+               loss="iwae_looser", rescaling=False, masked=False, seed=306)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,111 @@
+"""Bit-exact procedural test data shared by the golden generator and the tests.
+
+Weights and inputs of the golden cases are NOT stored in the fixtures (a MnistSvhn state dict is
+6 MB); they are regenerated from an integer hash (splitmix64 on uint64, exact on every platform)
+so the committed fixtures only hold noise tensors and expected outputs.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+
+def hash_uniform(n, seed):
+    """n float64 values in [0,1), pure integer arithmetic (splitmix64 finaliser)."""
+    with np.errstate(over="ignore"):
+        z = (np.arange(n, dtype=np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z = z + np.uint64(seed) * np.uint64(0xD1B54A32D192ED03)
+        z ^= z >> np.uint64(30)
+        z *= np.uint64(0xBF58476D1CE4E5B9)
+        z ^= z >> np.uint64(27)
+        z *= np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def uniform(shape, seed, lo=0.0, hi=1.0):
+    n = int(np.prod(shape)) if len(shape) else 1
+    return (lo + (hi - lo) * hash_uniform(n, seed)).astype(np.float32).reshape(shape)
+
+
+def name_seed(name):
+    """Stable small integer derived from a parameter name (CRC32)."""
+    import zlib
+
+    return 777 + (zlib.crc32(name.encode()) % 100000)
+
+
+def hash_indices(n, count, seed):
+    """`count` pseudo-random flat indices into a tensor of n elements."""
+    return (hash_uniform(count, seed) * n).astype(np.int64) % max(n, 1)
+
+
+# ---- parameter shapes, reference key names -------------------------------
+def mlp_encoder_shapes(prefix, in_features, latent_dim, n_hidden=1):
+    s = OrderedDict()
+    s[prefix + "layers.0.0.weight"] = (512, in_features)
+    s[prefix + "layers.0.0.bias"] = (512,)
+    for i in range(1, 1 + n_hidden):
+        s[f"{prefix}layers.{i}.0.weight"] = (512, 512)
+        s[f"{prefix}layers.{i}.0.bias"] = (512,)
+    for h in ("embedding", "log_var"):
+        s[f"{prefix}{h}.weight"] = (latent_dim, 512)
+        s[f"{prefix}{h}.bias"] = (latent_dim,)
+    return s
+
+
+def mlp_decoder_shapes(prefix, latent_dim, out_features):
+    s = OrderedDict()
+    s[prefix + "layers.0.0.weight"] = (512, latent_dim)
+    s[prefix + "layers.0.0.bias"] = (512,)
+    s[prefix + "layers.1.0.weight"] = (out_features, 512)
+    s[prefix + "layers.1.0.bias"] = (out_features,)
+    return s
+
+
+def svhn_encoder_shapes(prefix, latent_dim):
+    s = OrderedDict()
+    for i, (co, ci) in zip((0, 2, 4), ((32, 3), (64, 32), (128, 64))):
+        s[f"{prefix}enc.{i}.weight"] = (co, ci, 4, 4)
+        s[f"{prefix}enc.{i}.bias"] = (co,)
+    for h in ("c1", "c2"):
+        s[f"{prefix}{h}.weight"] = (latent_dim, 128, 4, 4)
+        s[f"{prefix}{h}.bias"] = (latent_dim,)
+    return s
+
+
+def svhn_decoder_shapes(prefix, latent_dim):
+    s = OrderedDict()
+    for i, (ci, co) in zip((0, 2, 4, 6), ((latent_dim, 128), (128, 64), (64, 32), (32, 3))):
+        s[f"{prefix}dec.{i}.weight"] = (ci, co, 4, 4)
+        s[f"{prefix}dec.{i}.bias"] = (co,)
+    return s
+
+
+def mnist_svhn_shapes(latent_dim=20):
+    """Parameter order of BaseMultiVAE: decoders are registered before encoders (base_ae_model.py:86-87)."""
+    s = OrderedDict()
+    s.update(mlp_decoder_shapes("decoders.mnist.", latent_dim, 784))
+    s.update(svhn_decoder_shapes("decoders.svhn.", latent_dim))
+    s.update(mlp_encoder_shapes("encoders.mnist.", 784, latent_dim))
+    s.update(svhn_encoder_shapes("encoders.svhn.", latent_dim))
+    return s
+
+
+def default_mlp_shapes(input_dims, latent_dim):
+    s = OrderedDict()
+    for m, d in input_dims.items():
+        s.update(mlp_decoder_shapes(f"decoders.{m}.", latent_dim, int(np.prod(d))))
+    for m, d in input_dims.items():
+        s.update(mlp_encoder_shapes(f"encoders.{m}.", int(np.prod(d)), latent_dim))
+    return s
+
+
+def make_state_dict(shapes, seed, gain=1.0):
+    """name -> float32 ndarray, U(-b, b) with b = gain/sqrt(prod(shape[1:])) (bias: b of its weight)."""
+    sd = OrderedDict()
+    bound = 1.0
+    for i, (name, shape) in enumerate(shapes.items()):
+        if name.endswith(".weight"):
+            bound = gain / float(np.sqrt(np.prod(shape[1:])))
+        sd[name] = uniform(shape, seed * 1000 + i, -bound, bound)
+    return sd

@@ -1,0 +1,92 @@
+"""Helpers shared by the CPU oracle tests and the GPU parity tests: load a golden fixture and
+regenerate its (procedural) inputs and weights.  Nothing here touches /root/reference."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+if GOLDEN not in sys.path:
+    sys.path.insert(0, GOLDEN)
+import procedural as P  # noqa: E402
+
+TINY_DIMS = dict(mod1=(2,), mod2=(3,), mod3=(4,), mod4=(4,))
+MNIST_SVHN_DIMS = dict(mnist=(1, 28, 28), svhn=(3, 32, 32))
+
+MOPOE_CASES = ["mopoe_tiny_complete", "mopoe_tiny_beta_rescale", "mopoe_tiny_masked", "mopoe_mnistsvhn_k1",
+               "mopoe_mnistsvhn_k1_rescale", "mopoe_mnistsvhn_k10"]
+MVTCAE_CASES = ["mvtcae_tiny_complete", "mvtcae_tiny_masked", "mvtcae_mnistsvhn_mlp"]
+MMVAE_CASES = ["mmvae_tiny_normal_iwae", "mmvae_tiny_laplace_dreg", "mmvae_tiny_normal_dreg_masked",
+               "mmvae_tiny_laplace_iwae_masked", "mmvae_mnistsvhn_laplace_dreg_k1",
+               "mmvae_mnistsvhn_normal_iwae_k10"]
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    cfg = json.loads(bytes(z["cfg_json"]).decode())
+    arrays = {k: z[k] for k in z.files if k != "cfg_json"}
+    return cfg, arrays
+
+
+def tiny_data(B, seed, masked):
+    data = {m: P.uniform((B,) + d, seed + i) for i, (m, d) in enumerate(TINY_DIMS.items())}
+    masks = None
+    if masked:
+        masks = {}
+        for i, m in enumerate(TINY_DIMS):
+            masks[m] = P.hash_uniform(B, seed + 50 + i) > 0.4
+        masks["mod1"][:] = True
+        masks["mod3"][0] = False
+    return data, masks
+
+
+def build_inputs(cfg):
+    """-> dims, data{name: np}, masks{name: np}|None, state_dict{name: np} (procedural, bit-exact)."""
+    seed, B = cfg["seed"], cfg["B"]
+    if cfg["arch"] == "tiny":
+        dims = TINY_DIMS
+        data, masks = tiny_data(B, seed, cfg["masked"])
+        for m, d in (cfg.get("dists") or {}).items():
+            if d == "bernoulli":
+                data[m] = (data[m] > 0.5).astype(np.float32)
+        shapes = P.default_mlp_shapes(dims, cfg["L"])
+    else:
+        dims = MNIST_SVHN_DIMS
+        data = {"mnist": P.uniform((B, 1, 28, 28), seed), "svhn": P.uniform((B, 3, 32, 32), seed + 1)}
+        masks = None
+        if cfg["model"] == "MVTCAE":
+            shapes = P.default_mlp_shapes(dims, cfg["L"])
+        else:
+            shapes = P.mnist_svhn_shapes(cfg["L"])
+    sd = P.make_state_dict(shapes, seed)
+    return dims, data, masks, sd
+
+
+def check_grads(arrays, named_grads, rtol=2e-4, atol_frac=2e-5):
+    """Compare gradients with the golden statistics: sum / abs-sum and sampled entries.
+
+    Tolerance on sampled entries is relative to the tensor's mean |g| (atol_frac * abs_sum / n scaled up)
+    so near-zero entries of a large tensor do not dominate.
+    """
+    worst = 0.0
+    for i, (name, g) in enumerate(named_grads.items()):
+        if "gsum/" + name not in arrays:
+            continue
+        g = g.detach().double().cpu().reshape(-1).numpy()
+        ref_sum, ref_abs = arrays["gsum/" + name]
+        scale = max(ref_abs / max(g.size, 1), 1e-30)
+        assert abs(np.abs(g).sum() - ref_abs) <= rtol * max(ref_abs, 1e-12) + 1e-12, (name, np.abs(g).sum(), ref_abs)
+        assert abs(g.sum() - ref_sum) <= rtol * ref_abs + 1e-12, (name, g.sum(), ref_sum)
+        idx = P.hash_indices(g.size, len(arrays["gval/" + name]), P.name_seed(name))
+        err = np.abs(g[idx] - arrays["gval/" + name].astype(np.float64))
+        tol = rtol * np.abs(arrays["gval/" + name]) + 50 * atol_frac * scale
+        assert (err <= tol).all(), (name, float(err.max()), float(tol.min()))
+        worst = max(worst, float((err / (np.abs(arrays["gval/" + name]) + scale)).max()))
+    return worst

@@ -1,0 +1,141 @@
+"""The oracle (oracle/) against the golden vectors generated from the real reference
+(tests/golden/make_golden.py).  CPU only.  This is the pin that lets the GPU parity tests trust the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as G
+from oracle import elbo, nets
+
+RTOL = 2e-6  # the oracle is the same torch-CPU arithmetic as the reference: expect (near) bit equality
+
+
+def close(a, b, rtol=RTOL, atol=1e-6):
+    a = torch.as_tensor(np.asarray(a)).double()
+    b = torch.as_tensor(b.detach().numpy() if torch.is_tensor(b) else np.asarray(b)).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    both_inf = torch.isinf(a) & torch.isinf(b) & (a.sign() == b.sign())
+    a = torch.where(both_inf, torch.zeros_like(a), a)
+    b = torch.where(both_inf, torch.zeros_like(b), b)
+    assert torch.allclose(a, b, rtol=rtol, atol=atol, equal_nan=True), float((a - b).abs().max())
+
+
+def test_unit_base_utils():
+    _, a = G.load_case("unit_base_utils")
+    mus, lvs, fin = G.t(a["mus"]), G.t(a["lvs"]), G.t(a["fin_lvs"])
+    pm, pl = elbo.poe(mus, lvs)
+    close(a["poe_mu"], pm)
+    close(a["poe_lv"], pl)
+    sm, sl = elbo.stable_poe(mus, fin)
+    close(a["spoe_mu"], sm)
+    close(a["spoe_lv"], sl)
+    close(a["kl"], elbo.kl_divergence(mus[0], fin[0], mus[2], fin[2]))
+    close(a["z1"], elbo.rsample(mus[0], fin[0], G.t(a["eps1"])))
+    close(a["zK"], elbo.rsample(mus[0], fin[0], G.t(a["epsK"])))
+    close(a["zKf"], elbo.rsample(mus[0], fin[0], G.t(a["epsKf"])).reshape(-1, 5))
+    recon, target = G.t(a["recon"]), G.t(a["target"])
+    close(a["lp_normal"], elbo.recon_log_prob("normal", recon, target))
+    close(a["lp_normal_s"], elbo.recon_log_prob("normal", recon, target, 0.75))
+    close(a["lp_laplace_s"], elbo.recon_log_prob("laplace", recon, target, 0.75))
+    close(a["lp_bernoulli"], elbo.recon_log_prob("bernoulli", recon, (target > 0.5).float()))
+    close(a["lp_categorical"], elbo.recon_log_prob("categorical", recon, G.t(a["onehot"])))
+
+
+def _oracle_nets(cfg, dims, sd):
+    if cfg["arch"] == "tiny" or cfg["model"] == "MVTCAE":
+        return nets.build_default_mlp(sd, dims)
+    return nets.build_mnist_svhn(sd, cfg["L"])
+
+
+def _prep(name):
+    cfg, a = G.load_case(name)
+    dims, data, masks, sd_np = G.build_inputs(cfg)
+    sd = {k: G.t(v).clone().requires_grad_(True) for k, v in sd_np.items()}
+    data = {m: G.t(v) for m, v in data.items()}
+    masks = None if masks is None else {m: G.t(v) for m, v in masks.items()}
+    enc_f, dec_f = _oracle_nets(cfg, dims, sd)
+    return cfg, a, dims, data, masks, sd, enc_f, dec_f
+
+
+@pytest.mark.parametrize("name", G.MOPOE_CASES)
+def test_mopoe(name):
+    cfg, a, dims, data, masks, sd, enc_f, dec_f = _prep(name)
+    names = cfg["names"]
+    assert [k for k, _ in elbo.mopoe_subsets(names)] == cfg["subsets"]
+    e = {m: enc_f[m](data[m]) for m in names}
+    choice = G.t(a["choice"]) if "choice" in a else None
+    o = elbo.mopoe_forward(e, data, dec_f, G.t(a["eps"]), names=names, beta=cfg["beta"],
+                           rescale=elbo.rescale_factors(dims, cfg["rescaling"]), dists=cfg["dists"],
+                           masks=masks, choice=choice)
+    close(a["loss"], o["loss"])
+    close(a["loss_sum"], o["loss_sum"], rtol=1e-5)
+    for k in ("mus", "logvars", "weights", "joint_mu", "joint_logvar", "z"):
+        close(a[k], o[k])
+    for k, v in o["metrics"].items():
+        close(a["metric/" + k], v)
+    o["loss"].backward()
+    G.check_grads(a, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()},
+                  rtol=1e-5)
+
+
+def test_mopoe_row_bounds():
+    # B=512, S=3 -> [0,170,340,512]
+    assert elbo.mopoe_row_bounds(512, 3) == [0, 170, 340, 512]
+    assert elbo.mopoe_row_bounds(6, 15) == [0] * 15 + [6]
+    assert elbo.mopoe_row_bounds(16, 3) == [0, 5, 10, 16]
+
+
+@pytest.mark.parametrize("name", G.MVTCAE_CASES)
+def test_mvtcae(name):
+    cfg, a, dims, data, masks, sd, enc_f, dec_f = _prep(name)
+    names = cfg["names"]
+    e = {m: enc_f[m](data[m]) for m in names}
+    o = elbo.mvtcae_forward(e, data, dec_f, G.t(a["eps"]), names=names, alpha=cfg["alpha"], beta=cfg["beta"],
+                            rescale=elbo.rescale_factors(dims, cfg["rescaling"]), masks=masks)
+    close(a["loss"], o["loss"])
+    close(a["loss_sum"], o["loss_sum"])
+    for k in ("joint_mu", "joint_logvar", "z"):
+        close(a[k], o[k])
+    for k, v in o["metrics"].items():
+        close(a["metric/" + k], v)
+    o["loss"].backward()
+    G.check_grads(a, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()},
+                  rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", G.MMVAE_CASES)
+def test_mmvae(name):
+    cfg, a, dims, data, masks, sd, enc_f, dec_f = _prep(name)
+    names = cfg["names"]
+    mods = [m for m in names if ("noise/" + m) in a]
+    plv = G.t(a["prior_log_var"]).clone().requires_grad_(True)
+    e = {m: enc_f[m](data[m]) for m in mods}
+    noise = {m: G.t(a["noise/" + m]) for m in mods}
+    o = elbo.mmvae_forward(e, data, dec_f, noise, names=names, K=cfg["K"], family=cfg["family"], loss=cfg["loss"],
+                           prior_log_var=plv, rescale=elbo.rescale_factors(dims, cfg["rescaling"]), masks=masks)
+    close(a["loss"], o["loss"])
+    for m in mods:
+        close(a["lws/" + m], o["lws"][m], rtol=1e-5, atol=1e-4)
+        close(a["zs/" + m], o["zs"][m])
+    o["loss"].backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()}
+    grads["prior_log_var"] = plv.grad
+    G.check_grads(a, grads, rtol=2e-5)
+
+
+def test_numpy_conv_pins_match_torch():
+    """conv2d_np / conv_transpose2d_np (independent numpy restatements) agree with the aten ops the
+    reference calls, on the SVHN layer shapes."""
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 3, 8, 8, generator=g)
+    w = torch.randn(5, 3, 4, 4, generator=g)
+    b = torch.randn(5, generator=g)
+    close(nets.conv2d_np(x, w, b, 2, 1), F.conv2d(x, w, b, 2, 1), rtol=1e-5, atol=1e-5)
+    close(nets.conv2d_np(x[:, :, :4, :4], w, b, 2, 0), F.conv2d(x[:, :, :4, :4], w, b, 2, 0), rtol=1e-5, atol=1e-5)
+    wt = torch.randn(3, 6, 4, 4, generator=g)
+    bt = torch.randn(6, generator=g)
+    close(nets.conv_transpose2d_np(x, wt, bt, 2, 1), F.conv_transpose2d(x, wt, bt, 2, 1), rtol=1e-5, atol=1e-5)
+    z = torch.randn(4, 3, 1, 1, generator=g)
+    close(nets.conv_transpose2d_np(z, wt, bt, 1, 0), F.conv_transpose2d(z, wt, bt, 1, 0), rtol=1e-5, atol=1e-5)
