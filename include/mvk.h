@@ -1,0 +1,261 @@
+/*
+ * mvk.h — C ABI of libmvk.so: hand-written HIP (gfx950 / CDNA4) kernels for the multimodal-VAE
+ * training hot path (MMVAE / MoPoE / MVTCAE forward + ELBO + backward + Adam).
+ *
+ * The reference (AgatheSenellart/MultiVae) has no FFI: its "operator API" is Python.
+ * Each entry point below therefore names the reference Python function(s) it replaces (file:line,
+ * relative to /root/reference/src/multivae).  Host code (multivae_amd/, Python on PyTorch-ROCm) binds
+ * these through ctypes; INTEGRATION.md shows the binding a MultiVae maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless stated otherwise; the caller owns all
+ *     memory; the library never allocates, frees, retains a pointer past the call, or synchronises;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it; calls are re-entrant per stream;
+ *   - return value: 0 = MVK_OK, <0 = error (MVK_EINVAL bad argument, MVK_ELAUNCH launch failure);
+ *   - noise is always an input buffer: results never depend on an RNG stream;
+ *   - gradient outputs documented "+=" are ACCUMULATED (atomicAdd split-K): zero them first if needed.
+ */
+#ifndef MVK_H
+#define MVK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVK_OK 0
+#define MVK_EINVAL (-1)
+#define MVK_ELAUNCH (-2)
+
+#define MVK_MAX_MODALITIES 8
+
+/* decoder output distributions — models/base/base_utils.py:62-87 (set_decoder_dist) */
+#define MVK_DIST_NORMAL 0
+#define MVK_DIST_LAPLACE 1
+#define MVK_DIST_BERNOULLI 2
+
+/* activations fused into GEMM/conv epilogues */
+#define MVK_ACT_NONE 0
+#define MVK_ACT_RELU 1
+#define MVK_ACT_SIGMOID 2
+
+/* latent families of MMVAE — models/mmvae/mmvae_model.py:44-49,66-74 */
+#define MVK_FAMILY_NORMAL 0
+#define MVK_FAMILY_LAPLACE_SOFTMAX 1
+
+int mvk_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused posterior aggregation + reparameterisation + Gaussian KL
+ * ------------------------------------------------------------------------------------------------ */
+
+/* MoPoE: per-subset PoE (+N(0,I) expert on the full subset), subset selection, z = mu + exp(lv/2) eps,
+ * all-subset weighted KL.  Replaces models/base/base_utils.py:122-130 (poe), :150-172
+ * (rsample_from_gaussian), models/mopoe/mopoe_model.py:274-350 (inference), :249-262 (_poe_fusion),
+ * :435-465 / :417-433 (mixture component selection, given as `sel`), :108-145 (calc_joint_divergence).
+ *   mu, lv        HOST arrays of M device pointers, each [B,L], modalities in PoE summation order
+ *                 (the reference stacks a subset's experts in sorted-name order, mopoe_model.py:88-101)
+ *   subset_masks  device int32 [S]: bit i set = modality i (position in mu/lv) belongs to the subset;
+ *                 subsets in the reference's enumeration order (mopoe_model.py:71-80)
+ *   sel           device int32 [B]: subset index whose posterior row b samples from
+ *   weights       device [S,B] or NULL (= 1/S)
+ *   eps           device [K,B,L]
+ * outputs
+ *   z [K,B,L]; kld_rows [B] = sum_s w[s,b] KL_s[b]; mus_out, lvs_out [S,B,L] (both or neither);
+ *   joint_mu, joint_lv [B,L] (both or neither)
+ */
+int mvk_mopoe_posterior_fwd(const float* const* mu, const float* const* lv, int M, const int32_t* subset_masks,
+                            int S, const int32_t* sel, const float* weights, const float* eps, int K, int B,
+                            int L, float* z, float* kld_rows, float* mus_out, float* lvs_out, float* joint_mu,
+                            float* joint_lv, void* stream);
+
+/* backward of the above.  dz [K,B,L]; gkld_rows [B] = upstream gradient of kld_rows (NULL = 0).
+ * dmu, dlv: HOST arrays of M device pointers [B,L], overwritten. */
+int mvk_mopoe_posterior_bwd(const float* const* mu, const float* const* lv, int M, const int32_t* subset_masks,
+                            int S, const int32_t* sel, const float* weights, const float* eps, const float* dz,
+                            int K, int B, int L, const float* gkld_rows, float* const* dmu, float* const* dlv,
+                            void* stream);
+
+/* MVTCAE: PoE over all modalities (no prior expert, eps 1e-8), joint KL and per-modality conditional
+ * KLs.  Replaces models/mvtcae/mvtcae_model.py:110-169 (_modality_encode masks, _inference) and the KL
+ * arithmetic of :42-108.  masks: HOST array of M device uint8 [B] pointers (entries may be NULL), or NULL.
+ * outputs: z [K,B,L]; joint_kl_rows [B]; cond_kl_rows [M,B]; joint_mu, joint_lv [B,L] (both or neither). */
+int mvk_mvtcae_posterior_fwd(const float* const* mu, const float* const* lv, const uint8_t* const* masks,
+                             int M, const float* eps, int K, int B, int L, float* z, float* joint_kl_rows,
+                             float* cond_kl_rows, float* joint_mu, float* joint_lv, void* stream);
+
+/* backward: gjoint_rows [B], gcond_rows [M,B] = upstream gradients of the two KL outputs (NULL = 0). */
+int mvk_mvtcae_posterior_bwd(const float* const* mu, const float* const* lv, const uint8_t* const* masks,
+                             int M, const float* eps, const float* dz, int K, int B, int L,
+                             const float* gjoint_rows, const float* gcond_rows, float* const* dmu,
+                             float* const* dlv, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused reconstruction NLL over the K-sample axis
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct mvk_recon_desc {
+  const float* recon;   /* [K,B,D] decoder output (logits for bernoulli) */
+  const float* x;       /* [B,D] target, broadcast over K */
+  const uint8_t* mask;  /* [B] availability or NULL */
+  float* rows;          /* out [K,B]: rescale * sum_d -log p(x|recon); NOT masked (fwd only) */
+  float* drecon;        /* out [K,B,D] or NULL: coef * mask[b] * rowcoef[k,b] * rescale * d(-log p)/d recon */
+  const float* rowcoef; /* [K,B] per-row gradient weight or NULL (= 1) */
+  int64_t D;
+  int32_t dist;         /* MVK_DIST_* */
+  float scale;          /* normal / laplace scale */
+  float rescale;        /* likelihood rescaling factor (base_ae_model.py:127-152) */
+  float coef;           /* constant gradient weight (e.g. 1/(B*K)) */
+} mvk_recon_desc;
+
+/* Per-(k,b) row NLL for up to MVK_MAX_MODALITIES modalities in ONE launch, optionally emitting
+ * d(loss)/d(recon) in the same pass.  Replaces models/base/base_utils.py:62-87 (recon_log_probs) and the
+ * `.view(B,-1).sum(-1)` row reductions of mopoe_model.py:192-199, mvtcae_model.py:60-68,
+ * mmvae_model.py:208-214.  descs: HOST array. */
+int mvk_recon_nll_fwd(const mvk_recon_desc* descs, int n_mod, int K, int B, void* stream);
+
+/* Second pass for estimators whose row weights depend on a K-reduction (IWAE/DReG): writes drecon only. */
+int mvk_recon_nll_bwd(const mvk_recon_desc* descs, int n_mod, int K, int B, void* stream);
+
+/* Scalar assembly: out[i] = coef[i] * sum_j v_i[j] * (mask_i ? mask_i[j % period_i] : 1) for i < n_terms;
+ * out[n_terms] = sum_i lossw[i] * out[i]; out[n_terms+1] = out[n_terms] * loss_sum_scale; *loss_out (nullable)
+ * = out[n_terms].  n_terms <= 16.
+ * Replaces the `.mean()` / `.sum()` / `loss = ...` lines of mopoe_model.py:200-227, mvtcae_model.py:96-108. */
+typedef struct mvk_term_desc {
+  const float* v;
+  const uint8_t* mask;
+  int64_t n;
+  int64_t period;
+  float coef;
+  float lossw;
+} mvk_term_desc;
+int mvk_reduce_terms(const mvk_term_desc* terms, int n_terms, float loss_sum_scale, float* out, float* loss_out,
+                     void* stream);
+
+/* buf[i] *= *gscale unless *gscale == 1 (no memory traffic in that case). */
+int mvk_scale_by_device_scalar(float* buf, int64_t n, const float* gscale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * MMVAE: mixture-of-experts importance weights (IWAE / DReG)
+ * ------------------------------------------------------------------------------------------------ */
+
+/* std from log-variance: exp(lv/2) or softmax(lv)*L + 1e-6 (models/mmvae/mmvae_model.py:66-74) and its
+ * backward.  lv, std: [rows, L]. */
+int mvk_mmvae_std_fwd(const float* lv, int rows, int L, int family, float* std, void* stream);
+int mvk_mmvae_std_bwd(const float* lv, const float* std, const float* dstd, int rows, int L, int family,
+                      float* dlv, void* stream);
+
+/* For every conditioning modality c: z[c] = loc + std * t(noise) (Normal: t = n; Laplace: t = -sign(u) log1p(-|u|),
+ * u ~ U(eps-1,1), torch.distributions.Laplace.rsample), lpz[c][k,b] = sum_l log p(z), lq_all[c][m,k,b] =
+ * sum_l log q_m(z) (-inf where mask_m[b] == 0) and lqz[c][k,b] = logsumexp_m lq_all - log n_avail[b]
+ * (mmvae_model.py:111-123, :160-206).  mu, std [B,L]; noise, z [K,B,L]; lpz, lqz [K,B]; lq_all [M,K,B]:
+ * HOST arrays of M device pointers.  prior_mean, prior_std: device [L].  masks: HOST array of M uint8 [B]
+ * device pointers (entries may be NULL) or NULL. */
+int mvk_mmvae_latent_fwd(const float* const* mu, const float* const* std, const float* const* noise,
+                         const uint8_t* const* masks, const float* prior_mean, const float* prior_std, int M,
+                         int K, int B, int L, int family, float* const* z, float* const* lpz,
+                         float* const* lqz, float* const* lq_all, void* stream);
+
+/* lw[c] = (sum_r -rows[c][r] * mask_r + lpz[c] - lqz[c]) * mask_c, softmax weights w[c] over k, and
+ * loss = -sum_b (1/n_avail[b]) sum_c obj_c[b] with obj = logsumexp_k lw - log K (IWAE) or sum_k w lw (DReG)
+ * (mmvae_model.py:208-292).  rows: HOST array of M*M device pointers, rows[c*M + r] = [K,B] rescaled NLL rows
+ * of modality r reconstructed from z[c] (mvk_recon_nll_fwd).  rowcoef[c] [K,B] = d loss / d lw[c] =
+ * -w[c] mask_c / n_avail (the per-row weight of mvk_recon_nll_bwd).  loss: device scalar, overwritten. */
+int mvk_mmvae_objective_fwd(const float* const* rows, const float* const* lpz, const float* const* lqz,
+                            const uint8_t* const* masks, int M, int K, int B, int dreg, float* const* lw_out,
+                            float* const* w, float* const* rowcoef, float* loss, void* stream);
+
+/* Latent-side backward.  dz_dec[c] [K,B,L]: gradient of the loss w.r.t. z[c] through the decoders (from
+ * mvk_recon_nll_bwd with rowcoef = -w[c]/n_avail and the decoders' own backward).  Produces dmu[c], dstd[c]
+ * [B,L] and dprior_std [L] (nullable).  DReG: q parameters are detached inside log q and the total gradient
+ * reaching z is scaled by w once more (the hook of mmvae_model.py:263-266). */
+int mvk_mmvae_latent_bwd(const float* const* mu, const float* const* std, const float* const* noise,
+                         const float* const* z, const uint8_t* const* masks, const float* prior_mean,
+                         const float* prior_std, const float* const* w, const float* const* lq_all,
+                         const float* const* lqz, const float* const* dz_dec, int M, int K, int B, int L,
+                         int family, int dreg, const float* gscale, float* const* dmu, float* const* dstd,
+                         float* dprior_std, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Encoder / decoder layers: fp32 MFMA implicit GEMM (v_mfma_f32_32x32x2_f32, exact fp32 FMA chains)
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Y[M,N] = act(X[M,K] W[N,K]^T + b[N]) — nn.Linear + activation
+ * (models/nn/default_architectures.py:21-72 Encoder_VAE_MLP, :225-258 Decoder_AE_MLP). */
+int mvk_linear_fwd(const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int act,
+                   void* stream);
+/* dX[M,K] = dYpre[M,N] W[N,K] (* act'(prev_out[m,k]) if prev_out != NULL, so the result is directly the
+ * previous layer's pre-activation gradient).  dYpre = dY * act'(y_out) when y_out != NULL, else dY.
+ * accumulate != 0: dX += (atomic). */
+int mvk_linear_bwd_data(const float* dY, const float* W, float* dX, int M, int N, int K, const float* y_out,
+                        int y_act, const float* prev_out, int prev_act, int accumulate, void* stream);
+/* dW[N,K] += dYpre[M,N]^T X[M,K];  db[N] += colsum(dYpre) (db nullable). */
+int mvk_linear_bwd_weight(const float* dY, const float* X, float* dW, float* db, int M, int N, int K,
+                          const float* y_out, int y_act, void* stream);
+/* db[N] += column sums of dY[M,N] (* act'(y_out)). */
+int mvk_colsum_acc(const float* dY, const float* y_out, int y_act, float* db, int M, int N, void* stream);
+/* db[c] += sum over n and spatial positions of dY[n,c,hw] (* act'(y_out)) for NCHW tensors. */
+int mvk_nchw_channel_sum_acc(const float* dY, const float* y_out, int y_act, float* db, int n, int c, int hw,
+                             void* stream);
+/* In-place dY *= act'(Y) (sigmoid: y(1-y), relu: y>0). */
+int mvk_act_bwd(float* dY, const float* Y, int64_t n, int act, void* stream);
+
+/* Row-major GEMM C[M,N] (+)= op(A) op(B) used for the packed 1x1-spatial layers:
+ *   ta=0: A is [M,K]; ta=1: A is [K,M].  tb=0: B is [K,N]; tb=1: B is [N,K].
+ *   bias[n % bias_mod] added when bias != NULL; act applied; a_act_src: A *= a_act'(a_act_src) on load;
+ *   c_act_src: result *= c_act'(c_act_src[m,n]); accumulate != 0 => C += (split-K, atomic). */
+int mvk_gemm(const float* A, const float* B, float* C, int M, int N, int K, int ta, int tb, const float* bias,
+             int bias_mod, int act, int accumulate, const float* a_act_src, int a_act, const float* c_act_src,
+             int c_act, void* stream);
+
+/* 4x4 / stride 2 / pad 1 convolution pair on NHWC activations (models/nn/svhn.py:7-70).
+ * "U" is the large feature map [n,2h,2w,Cu], "V" the small one [n,h,w,Cv], W the reference weight
+ * tensor indexed [Cv][Cu][4][4] (nn.Conv2d weight [out,in,kh,kw] with V = output; nn.ConvTranspose2d
+ * weight [in,out,kh,kw] with V = input).
+ *   pack:  Wdown[(kh*4+kw)*Cu + cu][col_off + cv] (row stride ld_down) and/or
+ *          Wup[ph*2+pw][((a*2+b)*Cv + cv)][cu], kh = (1-ph)+2a, kw = (1-pw)+2b
+ *   down:  V = act(conv(U) + b) (* v_act'(v_act_src))   — Conv2d forward / ConvTranspose2d backward-data
+ *   up:    U = act(convT(V) + b) (* u_act'(u_act_src))  — ConvTranspose2d forward / Conv2d backward-data
+ *   wgrad: dWref[Cv][Cu][4][4] += sum_pos U(gathered) V — both layer types
+ * u_nchw != 0: U is stored NCHW (network input / output boundary tensors only).
+ * u_act_src (down, wgrad): U is a gradient tensor that is multiplied by u_act'(u_act_src) while loading. */
+int mvk_pack_conv4s2_weight(const float* Wref, int Cv, int Cu, float* Wdown, int ld_down, int col_off,
+                            float* Wup, void* stream);
+int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w,
+                     int Cu, int Cv, int act, int u_nchw, const float* u_act_src, int u_act,
+                     const float* v_act_src, int v_act, void* stream);
+int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U, int n, int h, int w, int Cu,
+                   int Cv, int act, int u_nchw, const float* u_act_src, int u_act, void* stream);
+int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv,
+                      int u_nchw, const float* u_act_src, int u_act, void* stream);
+/* Direct kernel for the 3-channel image-producing layer: U[n,Cu,2h,2w] (NCHW) = act(convT(V) + b), Cu <= 4,
+ * reading the reference weight tensor directly (models/nn/svhn.py:58-60). */
+int mvk_conv4s2_up_nchw_small(const float* V, const float* Wref, const float* bias, float* U, int n, int h,
+                              int w, int Cu, int Cv, int act, void* stream);
+
+/* 1x1-spatial layers:
+ *   unflatten  Y[n,(tap,co)] = act(z[n,Cin] Wp + b[co]), Wp[ci][tap*Cout+co] = Wref[ci][co][tap]
+ *              (ConvTranspose2d(L,128,4,1,0), svhn.py:51) — forward / backward-data via mvk_gemm on Wp;
+ *   flatten    Y[n,cv] = H[n,(tap,cu)] Wdown + b  (Conv2d(128,L,4,2,0) heads, svhn.py:29-30) — via mvk_gemm
+ *              on the `down` packing.
+ * The weight gradients scatter straight back into the reference layouts: */
+int mvk_pack_unflatten_weight(const float* Wref, int Cin, int Cout, float* Wp, void* stream);
+int mvk_unflatten_wgrad(const float* Z, const float* dY, float* dWref, int n, int Cin, int Cout, void* stream);
+int mvk_flatten_wgrad(const float* H, const float* dY, float* dWref, int n, int Cu, int Cv, void* stream);
+
+/* NCHW <-> NHWC copies at the plugin boundary. */
+int mvk_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, void* stream);
+int mvk_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer
+ * ------------------------------------------------------------------------------------------------ */
+/* torch.optim.Adam (amsgrad=False) on flat buffers; step is 1-based; grad_scale multiplies g first
+ * (1/world_size for DDP averaging).  trainers/base/base_trainer_config.py:58,62; base_trainer.py:350-361. */
+int mvk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVK_H */

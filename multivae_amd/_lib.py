@@ -1,0 +1,129 @@
+"""ctypes binding of libmvk.so (the C ABI declared in include/mvk.h).
+
+There is NO CPU fallback: if the HIP library is missing or a call returns an error code the product path
+raises.  PyTorch only provides device memory (`tensor.data_ptr()`) and the HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvk.so")
+
+MVK_OK = 0
+DIST = {"normal": 0, "laplace": 1, "bernoulli": 2}
+ACT = {None: 0, "none": 0, "relu": 1, "sigmoid": 2}
+FAMILY = {"normal": 0, "laplace_with_softmax": 1}
+MAX_MODALITIES = 8
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_i64 = C.c_int64
+
+
+class ReconDesc(C.Structure):
+    _fields_ = [("recon", _p), ("x", _p), ("mask", _p), ("rows", _p), ("drecon", _p), ("rowcoef", _p),
+                ("D", _i64), ("dist", C.c_int32), ("scale", _f), ("rescale", _f), ("coef", _f)]
+
+
+class TermDesc(C.Structure):
+    _fields_ = [("v", _p), ("mask", _p), ("n", _i64), ("period", _i64), ("coef", _f), ("lossw", _f)]
+
+
+# name -> argtypes (restype is always int); mirrors include/mvk.h one for one
+PROTOTYPES = {
+    "mvk_version": [],
+    "mvk_mopoe_posterior_fwd": [_p, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
+    "mvk_mopoe_posterior_bwd": [_p, _p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p],
+    "mvk_mvtcae_posterior_fwd": [_p, _p, _p, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p],
+    "mvk_mvtcae_posterior_bwd": [_p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p],
+    "mvk_recon_nll_fwd": [C.POINTER(ReconDesc), _i, _i, _i, _p],
+    "mvk_recon_nll_bwd": [C.POINTER(ReconDesc), _i, _i, _i, _p],
+    "mvk_reduce_terms": [C.POINTER(TermDesc), _i, _f, _p, _p, _p],
+    "mvk_scale_by_device_scalar": [_p, _i64, _p, _p],
+    "mvk_linear_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "mvk_linear_bwd_data": [_p, _p, _p, _i, _i, _i, _p, _i, _p, _i, _i, _p],
+    "mvk_linear_bwd_weight": [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p],
+    "mvk_colsum_acc": [_p, _p, _i, _p, _i, _i, _p],
+    "mvk_nchw_channel_sum_acc": [_p, _p, _i, _p, _i, _i, _i, _p],
+    "mvk_act_bwd": [_p, _p, _i64, _i, _p],
+    "mvk_gemm": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _i, _p, _i, _p],
+    "mvk_pack_conv4s2_weight": [_p, _i, _i, _p, _i, _i, _p, _p],
+    "mvk_conv4s2_down": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p],
+    "mvk_conv4s2_up": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p],
+    "mvk_conv4s2_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p],
+    "mvk_conv4s2_up_nchw_small": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "mvk_pack_unflatten_weight": [_p, _i, _i, _p, _p],
+    "mvk_unflatten_wgrad": [_p, _p, _p, _i, _i, _i, _p],
+    "mvk_flatten_wgrad": [_p, _p, _p, _i, _i, _i, _p],
+    "mvk_nchw_to_nhwc": [_p, _p, _i, _i, _i, _i, _p],
+    "mvk_nhwc_to_nchw": [_p, _p, _i, _i, _i, _i, _p],
+    "mvk_adam_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i, _f, _p],
+    "mvk_mmvae_std_fwd": [_p, _i, _i, _i, _p, _p],
+    "mvk_mmvae_std_bwd": [_p, _p, _p, _i, _i, _i, _p, _p],
+    "mvk_mmvae_latent_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p],
+    "mvk_mmvae_objective_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p],
+    "mvk_mmvae_latent_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p],
+}
+
+_lib = None
+
+
+class MvkError(RuntimeError):
+    pass
+
+
+def load(path=None):
+    """Load libmvk.so and set every prototype.  Raises if the library or any declared symbol is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise MvkError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors):
+    """HOST array of device pointers (for the `const float* const*` arguments)."""
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def check(rc, what):
+    if rc != MVK_OK:
+        raise MvkError(f"{what} failed with code {rc}")
+
+
+def call(name, *args):
+    lib = load()
+    check(getattr(lib, name)(*args), name)
+
+
+def require_gpu_tensor(t, name="tensor"):
+    if not t.is_cuda:
+        raise MvkError(f"{name} must live on the GPU: multivae_amd has no CPU compute path")
+    if t.dtype != torch.float32:
+        raise MvkError(f"{name} must be float32, got {t.dtype}")

@@ -1,0 +1,594 @@
+// Fused ELBO kernels: posterior aggregation (PoE / MoPoE) + reparameterisation + Gaussian KL, and the
+// HBM-bound reconstruction-NLL kernel over the K-sample axis with the gradient emitted in the same pass.
+#include "common.hpp"
+
+namespace {
+
+constexpr int MAXM = MVK_MAX_MODALITIES;
+constexpr float POE_EPS = 1e-8f;  // models/base/base_utils.py:122 default eps
+
+struct PtrTable {
+  const float* mu[MAXM];
+  const float* lv[MAXM];
+  const uint8_t* mask[MAXM];
+};
+struct OutPtrTable {
+  float* dmu[MAXM];
+  float* dlv[MAXM];
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// MoPoE posterior.  One wave per batch row; lanes stride over the latent dimension.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mopoe_posterior_fwd_kernel(
+    const PtrTable pt, int M, const int32_t* __restrict__ subset_masks, int S, const int32_t* __restrict__ sel,
+    const float* __restrict__ weights, const float* __restrict__ eps, int K, int B, int L, float* __restrict__ z,
+    float* __restrict__ kld_rows, float* __restrict__ mus_out, float* __restrict__ lvs_out,
+    float* __restrict__ joint_mu, float* __restrict__ joint_lv) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int my_sel = sel[b];
+  const uint32_t full = (M >= 32) ? 0xffffffffu : ((1u << M) - 1u);
+  float kld_acc = 0.f;
+  for (int l = lane; l < L; l += 64) {
+    const long long o = (long long)b * L + l;
+    float T[MAXM], muT[MAXM];
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      if (m < M) {
+        float mu = pt.mu[m][o];
+        float var = expf(pt.lv[m][o]) + POE_EPS;
+        T[m] = 1.0f / var;
+        muT[m] = mu * T[m];
+      } else {
+        T[m] = 0.f;
+        muT[m] = 0.f;
+      }
+    }
+    for (int s = 0; s < S; ++s) {
+      const uint32_t bits = (uint32_t)subset_masks[s];
+      float D = 0.f, N = 0.f;
+      bool first = true;
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) {
+        if (m < M && ((bits >> m) & 1u)) {
+          // sequential sum over the stacked experts, as torch.sum(dim=0) does for a short leading dim
+          D = first ? T[m] : D + T[m];
+          N = first ? muT[m] : N + muT[m];
+          first = false;
+        }
+      }
+      if (bits == full) {  // N(0, I) prior expert: var = exp(0) + 1e-8 == 1.0f in fp32
+        D += 1.0f / (1.0f + POE_EPS);
+        N += 0.0f;
+      }
+      const float mu_s = N / D;
+      const float var_s = 1.0f / D;
+      const float lv_s = logf(var_s);
+      const float w = weights ? weights[(long long)s * B + b] : 1.0f / (float)S;
+      const float kl = -0.5f * (1.0f - expf(lv_s) - mu_s * mu_s + lv_s);
+      kld_acc += w * kl;
+      if (mus_out) {
+        mus_out[((long long)s * B + b) * L + l] = mu_s;
+        lvs_out[((long long)s * B + b) * L + l] = lv_s;
+      }
+      if (s == my_sel) {
+        const float sd = expf(0.5f * lv_s);
+        for (int k = 0; k < K; ++k) {
+          const long long zo = ((long long)k * B + b) * L + l;
+          z[zo] = mu_s + sd * eps[zo];
+        }
+        if (joint_mu) {
+          joint_mu[o] = mu_s;
+          joint_lv[o] = lv_s;
+        }
+      }
+    }
+  }
+  kld_acc = wave_sum(kld_acc);
+  if (lane == 0) kld_rows[b] = kld_acc;
+}
+
+__global__ __launch_bounds__(256) void mopoe_posterior_bwd_kernel(
+    const PtrTable pt, const OutPtrTable ot, int M, const int32_t* __restrict__ subset_masks, int S,
+    const int32_t* __restrict__ sel, const float* __restrict__ weights, const float* __restrict__ eps,
+    const float* __restrict__ dz, int K, int B, int L, const float* __restrict__ gkld_rows) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int my_sel = sel[b];
+  const float g = gkld_rows ? gkld_rows[b] : 0.0f;
+  const uint32_t full = (M >= 32) ? 0xffffffffu : ((1u << M) - 1u);
+  for (int l = lane; l < L; l += 64) {
+    const long long o = (long long)b * L + l;
+    float T[MAXM], mu[MAXM], ev[MAXM], dmu[MAXM], dlv[MAXM];
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      dmu[m] = 0.f;
+      dlv[m] = 0.f;
+      if (m < M) {
+        mu[m] = pt.mu[m][o];
+        ev[m] = expf(pt.lv[m][o]);
+        T[m] = 1.0f / (ev[m] + POE_EPS);
+      } else {
+        mu[m] = 0.f;
+        ev[m] = 0.f;
+        T[m] = 0.f;
+      }
+    }
+    // sum over k of dz and dz*eps for the selected subset
+    float sdz = 0.f, sdze = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const long long zo = ((long long)k * B + b) * L + l;
+      const float d = dz[zo];
+      sdz += d;
+      sdze += d * eps[zo];
+    }
+    for (int s = 0; s < S; ++s) {
+      const uint32_t bits = (uint32_t)subset_masks[s];
+      float D = 0.f, N = 0.f;
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) {
+        if (m < M && ((bits >> m) & 1u)) {
+          D += T[m];
+          N += mu[m] * T[m];
+        }
+      }
+      if (bits == full) D += 1.0f / (1.0f + POE_EPS);
+      const float mu_s = N / D;
+      const float lv_s = logf(1.0f / D);
+      const float w = weights ? weights[(long long)s * B + b] : 1.0f / (float)S;
+      const float c = g * w;
+      float g_mu = c * mu_s;
+      float g_lv = c * 0.5f * (expf(lv_s) - 1.0f);
+      if (s == my_sel) {
+        g_mu += sdz;
+        g_lv += 0.5f * expf(0.5f * lv_s) * sdze;
+      }
+      // mu_s = N/D ; lv_s = -log D
+      const float dN = g_mu / D;
+      const float dD = -(g_mu * mu_s + g_lv) / D;
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) {
+        if (m < M && ((bits >> m) & 1u)) {
+          dmu[m] += dN * T[m];
+          const float dT = dN * mu[m] + dD;
+          dlv[m] += dT * (-T[m] * T[m] * ev[m]);
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      if (m < M) {
+        ot.dmu[m][o] = dmu[m];
+        ot.dlv[m][o] = dlv[m];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MVTCAE posterior.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mvtcae_posterior_fwd_kernel(const PtrTable pt, int M,
+                                                                   const float* __restrict__ eps, int K, int B,
+                                                                   int L, float* __restrict__ z,
+                                                                   float* __restrict__ joint_kl_rows,
+                                                                   float* __restrict__ cond_kl_rows,
+                                                                   float* __restrict__ joint_mu,
+                                                                   float* __restrict__ joint_lv) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  bool avail[MAXM];
+#pragma unroll
+  for (int m = 0; m < MAXM; ++m) avail[m] = (m < M) && (pt.mask[m] ? pt.mask[m][b] != 0 : true);
+  float jkl = 0.f;
+  float ckl[MAXM];
+#pragma unroll
+  for (int m = 0; m < MAXM; ++m) ckl[m] = 0.f;
+  for (int l = lane; l < L; l += 64) {
+    const long long o = (long long)b * L + l;
+    float mu[MAXM], lv[MAXM];
+    float D = 0.f, N = 0.f;
+    bool first = true;
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      mu[m] = 0.f;
+      lv[m] = 0.f;
+      if (m < M) {
+        mu[m] = pt.mu[m][o];
+        lv[m] = pt.lv[m][o];
+        // missing rows: log-variance = +inf -> T = 0 (mvtcae_model.py:128-129)
+        const float T = avail[m] ? 1.0f / (expf(lv[m]) + POE_EPS) : 0.0f;
+        const float mt = mu[m] * T;
+        D = first ? T : D + T;
+        N = first ? mt : N + mt;
+        first = false;
+      }
+    }
+    const float jmu = N / D;
+    const float jlv = logf(1.0f / D);
+    const float ejl = expf(jlv);
+    jkl += -0.5f * (1.0f - ejl - jmu * jmu + jlv);
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      if (m < M && avail[m]) {
+        const float em = expf(lv[m]);
+        const float dm = jmu - mu[m];
+        ckl[m] += -0.5f * (1.0f - ejl / em - dm * dm / em + jlv - lv[m]);
+      }
+    }
+    const float sd = expf(0.5f * jlv);
+    for (int k = 0; k < K; ++k) {
+      const long long zo = ((long long)k * B + b) * L + l;
+      z[zo] = jmu + sd * eps[zo];
+    }
+    if (joint_mu) {
+      joint_mu[o] = jmu;
+      joint_lv[o] = jlv;
+    }
+  }
+  jkl = wave_sum(jkl);
+  if (lane == 0) joint_kl_rows[b] = jkl;
+#pragma unroll
+  for (int m = 0; m < MAXM; ++m) {
+    if (m < M) {
+      float v = wave_sum(ckl[m]);
+      if (lane == 0) cond_kl_rows[(long long)m * B + b] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void mvtcae_posterior_bwd_kernel(const PtrTable pt, const OutPtrTable ot, int M,
+                                                                   const float* __restrict__ eps,
+                                                                   const float* __restrict__ dz, int K, int B, int L,
+                                                                   const float* __restrict__ gjoint_rows,
+                                                                   const float* __restrict__ gcond_rows) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float jc = gjoint_rows ? gjoint_rows[b] : 0.0f;
+  bool avail[MAXM];
+#pragma unroll
+  for (int m = 0; m < MAXM; ++m) avail[m] = (m < M) && (pt.mask[m] ? pt.mask[m][b] != 0 : true);
+  for (int l = lane; l < L; l += 64) {
+    const long long o = (long long)b * L + l;
+    float mu[MAXM], lv[MAXM], T[MAXM], ev[MAXM];
+    float D = 0.f, N = 0.f;
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      mu[m] = lv[m] = T[m] = ev[m] = 0.f;
+      if (m < M) {
+        mu[m] = pt.mu[m][o];
+        lv[m] = pt.lv[m][o];
+        ev[m] = expf(lv[m]);
+        T[m] = avail[m] ? 1.0f / (ev[m] + POE_EPS) : 0.0f;
+        D += T[m];
+        N += mu[m] * T[m];
+      }
+    }
+    const float jmu = N / D;
+    const float jlv = logf(1.0f / D);
+    const float ejl = expf(jlv);
+    float sdz = 0.f, sdze = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const long long zo = ((long long)k * B + b) * L + l;
+      const float d = dz[zo];
+      sdz += d;
+      sdze += d * eps[zo];
+    }
+    float g_mu = sdz + jc * jmu;
+    float g_lv = 0.5f * expf(0.5f * jlv) * sdze + jc * 0.5f * (ejl - 1.0f);
+    float dmu[MAXM], dlv[MAXM];
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      dmu[m] = dlv[m] = 0.f;
+      if (m < M && avail[m]) {
+        const float cc = gcond_rows ? gcond_rows[(long long)m * B + b] : 0.0f;
+        const float dm = jmu - mu[m];
+        const float inv = 1.0f / ev[m];
+        g_mu += cc * dm * inv;
+        g_lv += cc * 0.5f * (ejl * inv - 1.0f);
+        dmu[m] = -cc * dm * inv;
+        dlv[m] = -cc * 0.5f * (ejl * inv + dm * dm * inv - 1.0f);
+      }
+    }
+    const float dN = g_mu / D;
+    const float dD = -(g_mu * jmu + g_lv) / D;
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      if (m < M) {
+        if (avail[m]) {
+          dmu[m] += dN * T[m];
+          const float dT = dN * mu[m] + dD;
+          dlv[m] += dT * (-T[m] * T[m] * ev[m]);
+        }
+        ot.dmu[m][o] = dmu[m];
+        ot.dlv[m][o] = dlv[m];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Reconstruction NLL over [K,B,D] with the gradient emitted in the same pass.  HBM-bound:
+// algorithmic bytes = 4*B*D*(2K+1) per modality (read recon, write d_recon, read x once).
+// One block = one batch row b and a chunk of KC samples; x[b,:] lives in registers across the chunk.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int KC = 8;          // samples per block
+constexpr int NLL_THREADS = 256;
+constexpr int MAXV = 4;        // float4 per thread held for x -> D <= 4096 on the vector path
+
+struct ReconTable {
+  mvk_recon_desc d[MAXM];
+  int block_start[MAXM + 1];  // prefix sum of blocks per modality
+  int n;
+};
+
+__device__ __forceinline__ void nll_elem(int dist, float inv_s, float inv_s2, float r, float x, float& nll,
+                                         float& dr) {
+  if (dist == MVK_DIST_NORMAL) {
+    const float d = r - x;
+    nll = 0.5f * d * d * inv_s2;  // + log(scale) + 0.5 log(2 pi), added per row
+    dr = d * inv_s2;
+  } else if (dist == MVK_DIST_LAPLACE) {
+    const float d = r - x;
+    nll = fabsf(d) * inv_s;  // + log(2 scale) per row
+    dr = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv_s;
+  } else {  // Bernoulli with logits r: BCE-with-logits = max(r,0) - r x + log1p(exp(-|r|))
+    const float e = expf(-fabsf(r));
+    nll = fmaxf(r, 0.f) - r * x + log1pf(e);
+    const float sig = r >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    dr = sig - x;
+  }
+}
+
+__device__ __forceinline__ float nll_row_const(int dist, float scale, long long D) {
+  if (dist == MVK_DIST_NORMAL) return (float)D * (logf(scale) + 0.918938533204672742f);
+  if (dist == MVK_DIST_LAPLACE) return (float)D * logf(2.0f * scale);
+  return 0.f;
+}
+
+template <bool VEC, bool FWD>
+__global__ __launch_bounds__(NLL_THREADS) void recon_nll_kernel(const ReconTable tb, int K, int B) {
+  // locate the modality of this block
+  int mi = 0;
+#pragma unroll
+  for (int i = 1; i < MAXM; ++i)
+    if (i < tb.n && (int)blockIdx.x >= tb.block_start[i]) mi = i;
+  const mvk_recon_desc& d = tb.d[mi];
+  const int local = blockIdx.x - tb.block_start[mi];
+  const int kchunks = (K + KC - 1) / KC;
+  const int b = local / kchunks;
+  const int k0 = (local % kchunks) * KC;
+  const int kn = (K - k0) < KC ? (K - k0) : KC;
+  const long long D = d.D;
+  const float inv_s = 1.0f / d.scale, inv_s2 = inv_s * inv_s;
+  const float mk = d.mask ? (d.mask[b] ? 1.0f : 0.0f) : 1.0f;
+  const float gbase = d.coef * d.rescale * mk;
+  const float* xrow = d.x + (long long)b * D;
+  float part[KC];
+#pragma unroll
+  for (int k = 0; k < KC; ++k) part[k] = 0.f;
+
+  if (VEC) {
+    const int nv = (int)(D >> 2);
+    float4 xv[MAXV];
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+      const int idx = threadIdx.x + j * NLL_THREADS;
+      xv[j] = (idx < nv) ? reinterpret_cast<const float4*>(xrow)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      if (k < kn) {
+        const long long ro = ((long long)(k0 + k) * B + b) * D;
+        const float4* rp = reinterpret_cast<const float4*>(d.recon + ro);
+        float4* gp = d.drecon ? reinterpret_cast<float4*>(d.drecon + ro) : nullptr;
+        const float gw = gbase * (d.rowcoef ? d.rowcoef[(long long)(k0 + k) * B + b] : 1.0f);
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+          const int idx = threadIdx.x + j * NLL_THREADS;
+          if (idx < nv) {
+            const float4 r = rp[idx];
+            float4 gr;
+            float n0, n1, n2, n3;
+            nll_elem(d.dist, inv_s, inv_s2, r.x, xv[j].x, n0, gr.x);
+            nll_elem(d.dist, inv_s, inv_s2, r.y, xv[j].y, n1, gr.y);
+            nll_elem(d.dist, inv_s, inv_s2, r.z, xv[j].z, n2, gr.z);
+            nll_elem(d.dist, inv_s, inv_s2, r.w, xv[j].w, n3, gr.w);
+            acc += (n0 + n1) + (n2 + n3);
+            if (gp) {
+              gr.x *= gw;
+              gr.y *= gw;
+              gr.z *= gw;
+              gr.w *= gw;
+              gp[idx] = gr;
+            }
+          }
+        }
+        part[k] = acc;
+      }
+    }
+  } else {
+    for (int k = 0; k < kn; ++k) {
+      const long long ro = ((long long)(k0 + k) * B + b) * D;
+      const float gw = gbase * (d.rowcoef ? d.rowcoef[(long long)(k0 + k) * B + b] : 1.0f);
+      float acc = 0.f;
+      for (long long i = threadIdx.x; i < D; i += NLL_THREADS) {
+        float n, g;
+        nll_elem(d.dist, inv_s, inv_s2, d.recon[ro + i], xrow[i], n, g);
+        acc += n;
+        if (d.drecon) d.drecon[ro + i] = g * gw;
+      }
+      // static indexing of part[] to keep it in registers
+#pragma unroll
+      for (int kk = 0; kk < KC; ++kk)
+        if (kk == k) part[kk] = acc;
+    }
+  }
+
+  if (FWD) {
+    __shared__ float red[KC][NLL_THREADS / 64];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      const float s = wave_sum(part[k]);
+      if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < kn) {
+      const int k = threadIdx.x;
+      float s = red[k][0] + red[k][1] + red[k][2] + red[k][3];
+      s = (s + nll_row_const(d.dist, d.scale, D)) * d.rescale;
+      d.rows[(long long)(k0 + k) * B + b] = s;
+    }
+  }
+}
+
+static int launch_recon(const mvk_recon_desc* descs, int n_mod, int K, int B, bool fwd, hipStream_t s) {
+  if (!descs || n_mod < 1 || n_mod > MAXM || K < 1 || B < 0) return MVK_EINVAL;
+  if (B == 0) return MVK_OK;
+  // the vector path needs every modality to qualify; otherwise the scalar path serves all of them
+  bool vec = true;
+  for (int i = 0; i < n_mod; ++i) {
+    const mvk_recon_desc& d = descs[i];
+    if (!d.recon || !d.x || d.D <= 0 || (fwd && !d.rows) || (!fwd && !d.drecon)) return MVK_EINVAL;
+    if (d.dist < 0 || d.dist > MVK_DIST_BERNOULLI) return MVK_EINVAL;
+    if ((d.D & 3) || d.D > 4 * MAXV * NLL_THREADS || !mvk_aligned16(d.recon) || !mvk_aligned16(d.x) ||
+        (d.drecon && !mvk_aligned16(d.drecon)))
+      vec = false;
+  }
+  const int kchunks = (K + KC - 1) / KC;
+  // launch per vectorisability group so that a tiny modality does not de-vectorise a large one
+  for (int pass = 0; pass < 2; ++pass) {
+    ReconTable tb;
+    tb.n = 0;
+    int blocks = 0;
+    for (int i = 0; i < n_mod; ++i) {
+      const mvk_recon_desc& d = descs[i];
+      bool v = !((d.D & 3) || d.D > 4 * MAXV * NLL_THREADS || !mvk_aligned16(d.recon) || !mvk_aligned16(d.x) ||
+                 (d.drecon && !mvk_aligned16(d.drecon)));
+      if ((pass == 0) != v) continue;
+      tb.d[tb.n] = d;
+      tb.block_start[tb.n] = blocks;
+      blocks += B * kchunks;
+      tb.n++;
+    }
+    if (tb.n == 0) continue;
+    tb.block_start[tb.n] = blocks;
+    (void)vec;
+    if (pass == 0) {
+      if (fwd)
+        hipLaunchKernelGGL((recon_nll_kernel<true, true>), dim3(blocks), dim3(NLL_THREADS), 0, s, tb, K, B);
+      else
+        hipLaunchKernelGGL((recon_nll_kernel<true, false>), dim3(blocks), dim3(NLL_THREADS), 0, s, tb, K, B);
+    } else {
+      if (fwd)
+        hipLaunchKernelGGL((recon_nll_kernel<false, true>), dim3(blocks), dim3(NLL_THREADS), 0, s, tb, K, B);
+      else
+        hipLaunchKernelGGL((recon_nll_kernel<false, false>), dim3(blocks), dim3(NLL_THREADS), 0, s, tb, K, B);
+    }
+    MVK_CHECK_LAUNCH();
+  }
+  return MVK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mvk_mopoe_posterior_fwd(const float* const* mu, const float* const* lv, int M, const int32_t* subset_masks, int S,
+                            const int32_t* sel, const float* weights, const float* eps, int K, int B, int L, float* z,
+                            float* kld_rows, float* mus_out, float* lvs_out, float* joint_mu, float* joint_lv,
+                            void* stream) {
+  if (!mu || !lv || M < 1 || M > MAXM || !subset_masks || S < 1 || !sel || !eps || !z || !kld_rows || K < 1 || L < 1)
+    return MVK_EINVAL;
+  if ((mus_out == nullptr) != (lvs_out == nullptr) || (joint_mu == nullptr) != (joint_lv == nullptr)) return MVK_EINVAL;
+  if (B <= 0) return B == 0 ? MVK_OK : MVK_EINVAL;
+  PtrTable pt{};
+  for (int m = 0; m < M; ++m) {
+    if (!mu[m] || !lv[m]) return MVK_EINVAL;
+    pt.mu[m] = mu[m];
+    pt.lv[m] = lv[m];
+  }
+  hipLaunchKernelGGL(mopoe_posterior_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, mvk_stream(stream), pt, M,
+                     subset_masks, S, sel, weights, eps, K, B, L, z, kld_rows, mus_out, lvs_out, joint_mu, joint_lv);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_mopoe_posterior_bwd(const float* const* mu, const float* const* lv, int M, const int32_t* subset_masks, int S,
+                            const int32_t* sel, const float* weights, const float* eps, const float* dz, int K, int B,
+                            int L, const float* gkld_rows, float* const* dmu, float* const* dlv, void* stream) {
+  if (!mu || !lv || M < 1 || M > MAXM || !subset_masks || S < 1 || !sel || !eps || !dz || !dmu || !dlv || K < 1 ||
+      L < 1)
+    return MVK_EINVAL;
+  if (B <= 0) return B == 0 ? MVK_OK : MVK_EINVAL;
+  PtrTable pt{};
+  OutPtrTable ot{};
+  for (int m = 0; m < M; ++m) {
+    if (!mu[m] || !lv[m] || !dmu[m] || !dlv[m]) return MVK_EINVAL;
+    pt.mu[m] = mu[m];
+    pt.lv[m] = lv[m];
+    ot.dmu[m] = dmu[m];
+    ot.dlv[m] = dlv[m];
+  }
+  hipLaunchKernelGGL(mopoe_posterior_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, mvk_stream(stream), pt, ot, M,
+                     subset_masks, S, sel, weights, eps, dz, K, B, L, gkld_rows);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_mvtcae_posterior_fwd(const float* const* mu, const float* const* lv, const uint8_t* const* masks, int M,
+                             const float* eps, int K, int B, int L, float* z, float* joint_kl_rows,
+                             float* cond_kl_rows, float* joint_mu, float* joint_lv, void* stream) {
+  if (!mu || !lv || M < 1 || M > MAXM || !eps || !z || !joint_kl_rows || !cond_kl_rows || K < 1 || L < 1)
+    return MVK_EINVAL;
+  if ((joint_mu == nullptr) != (joint_lv == nullptr)) return MVK_EINVAL;
+  if (B <= 0) return B == 0 ? MVK_OK : MVK_EINVAL;
+  PtrTable pt{};
+  for (int m = 0; m < M; ++m) {
+    if (!mu[m] || !lv[m]) return MVK_EINVAL;
+    pt.mu[m] = mu[m];
+    pt.lv[m] = lv[m];
+    pt.mask[m] = masks ? masks[m] : nullptr;
+  }
+  hipLaunchKernelGGL(mvtcae_posterior_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, mvk_stream(stream), pt, M, eps, K,
+                     B, L, z, joint_kl_rows, cond_kl_rows, joint_mu, joint_lv);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_mvtcae_posterior_bwd(const float* const* mu, const float* const* lv, const uint8_t* const* masks, int M,
+                             const float* eps, const float* dz, int K, int B, int L, const float* gjoint_rows,
+                             const float* gcond_rows, float* const* dmu, float* const* dlv, void* stream) {
+  if (!mu || !lv || M < 1 || M > MAXM || !eps || !dz || !dmu || !dlv || K < 1 || L < 1) return MVK_EINVAL;
+  if (B <= 0) return B == 0 ? MVK_OK : MVK_EINVAL;
+  PtrTable pt{};
+  OutPtrTable ot{};
+  for (int m = 0; m < M; ++m) {
+    if (!mu[m] || !lv[m] || !dmu[m] || !dlv[m]) return MVK_EINVAL;
+    pt.mu[m] = mu[m];
+    pt.lv[m] = lv[m];
+    pt.mask[m] = masks ? masks[m] : nullptr;
+    ot.dmu[m] = dmu[m];
+    ot.dlv[m] = dlv[m];
+  }
+  hipLaunchKernelGGL(mvtcae_posterior_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, mvk_stream(stream), pt, ot, M, eps,
+                     dz, K, B, L, gjoint_rows, gcond_rows);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_recon_nll_fwd(const mvk_recon_desc* descs, int n_mod, int K, int B, void* stream) {
+  return launch_recon(descs, n_mod, K, B, true, mvk_stream(stream));
+}
+
+int mvk_recon_nll_bwd(const mvk_recon_desc* descs, int n_mod, int K, int B, void* stream) {
+  return launch_recon(descs, n_mod, K, B, false, mvk_stream(stream));
+}
+
+}  // extern "C"

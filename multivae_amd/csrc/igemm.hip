@@ -1,0 +1,407 @@
+// C-ABI entry points built on the fp32 MFMA implicit-GEMM engine (igemm.hpp).
+#include "igemm.hpp"
+
+namespace mvk {
+
+template <int BM, int BN>
+static int launch_cfg(const GemmDesc& d, int zdim, hipStream_t s) {
+  dim3 grid((d.M + BM - 1) / BM, (d.N + BN - 1) / BN, zdim);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN>), grid, dim3(256), 0, s, d);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int launch_igemm(const GemmDesc& d, int zdim, hipStream_t s) {
+  if (d.M <= 0 || d.N <= 0 || d.K <= 0) return MVK_OK;
+  if (d.N <= 32) return launch_cfg<128, 32>(d, zdim, s);
+  if (d.N <= 64) {
+    if (d.M <= 64) return launch_cfg<64, 64>(d, zdim, s);
+    return launch_cfg<128, 64>(d, zdim, s);
+  }
+  long long big = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * zdim;
+  if (big >= 192) return launch_cfg<128, 128>(d, zdim, s);
+  long long mid = (long long)((d.M + 127) / 128) * ((d.N + 63) / 64) * zdim;
+  if (mid >= 192 || d.M > 4096) return launch_cfg<128, 64>(d, zdim, s);
+  return launch_cfg<64, 64>(d, zdim, s);
+}
+
+static void plain_a(AOperand& a, const float* p, long long sr, long long sk, int M, int K) {
+  a = AOperand{};
+  a.p = p;
+  a.kind = A_PLAIN;
+  a.sr = sr;
+  a.sk = sk;
+  a.contig_k = (sk == 1);
+  if (sk == 1)
+    a.vec4 = (sr % 4 == 0) && (K % 4 == 0) && mvk_aligned16(p);
+  else
+    a.vec4 = (sr == 1) && (sk % 4 == 0) && (M % 4 == 0) && mvk_aligned16(p);
+  a.C = a.H = a.W = a.OH = a.OW = 1;
+}
+
+static void plain_b(BOperand& b, const float* p, long long sk, long long sn, int K, int N) {
+  b = BOperand{};
+  b.p = p;
+  b.sk = sk;
+  b.sn = sn;
+  b.contig_k = (sk == 1);
+  if (sk == 1)
+    b.vec4 = (sn % 4 == 0) && (K % 4 == 0) && mvk_aligned16(p);
+  else
+    b.vec4 = (sn == 1) && (sk % 4 == 0) && (N % 4 == 0) && mvk_aligned16(p);
+}
+
+static void rowmajor_epi(Epilogue& e, float* out, long long ld) {
+  e = Epilogue{};
+  e.out = out;
+  e.kind = E_ROWMAJOR;
+  e.ld = ld;
+  e.bias_mod = 1;
+  e.Cu = e.OH = e.OW = 1;
+}
+
+// split the reduction so that roughly `target` workgroups are in flight
+static int pick_splits(int M, int N, int K, int target = 1024) {
+  int tm = (M + 127) / 128;
+  int tn = (N <= 32) ? 1 : (N + 63) / 64;
+  int tiles = tm * tn;
+  int ktiles = (K + BK - 1) / BK;
+  int s = target / (tiles > 0 ? tiles : 1);
+  if (s < 1) s = 1;
+  if (s > ktiles) s = ktiles;
+  return s;
+}
+
+// ---- small helper kernels ------------------------------------------------------------------------------
+__global__ void colsum_kernel(const float* __restrict__ dY, const float* __restrict__ Y, int act, int M, int N,
+                              int rows_per_block, float* __restrict__ db) {
+  // block handles `rows_per_block` rows x 64 columns; threads: 64 columns x 4 row-lanes
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block;
+  int r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
+  float s = 0.f;
+  if (col < N) {
+    for (int r = r0 + rl; r < r1; r += 4) {
+      float v = dY[(long long)r * N + col];
+      if (Y) v *= mvk_act_grad_from_out(Y[(long long)r * N + col], act);
+      s += v;
+    }
+  }
+  __shared__ float red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && col < N) {
+    float t = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+    atomicAdd(db + col, t);
+  }
+}
+
+// db[c] += sum over (n, p) of dY[n,c,p] (* act'(Y)) for NCHW tensors; one block per (c, chunk of n)
+__global__ void nchw_channel_sum_kernel(const float* __restrict__ dY, const float* __restrict__ Y, int act, int n,
+                                        int c, int hw, int imgs_per_block, float* __restrict__ db) {
+  const int ch = blockIdx.x;
+  const int i0 = blockIdx.y * imgs_per_block;
+  int i1 = i0 + imgs_per_block;
+  if (i1 > n) i1 = n;
+  float s = 0.f;
+  for (int img = i0; img < i1; ++img) {
+    const long long base = ((long long)img * c + ch) * hw;
+    for (int p = threadIdx.x; p < hw; p += blockDim.x) {
+      float v = dY[base + p];
+      if (Y) v *= mvk_act_grad_from_out(Y[base + p], act);
+      s += v;
+    }
+  }
+  s = wave_sum(s);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(db + ch, red[0] + red[1] + red[2] + red[3]);
+}
+
+static int colsum(const float* dY, const float* Y, int act, int M, int N, float* db, hipStream_t s) {
+  if (M <= 0 || N <= 0) return MVK_OK;
+  int gx = (N + 63) / 64;
+  int rows_per_block = 256;
+  int gy = (M + rows_per_block - 1) / rows_per_block;
+  hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, s, dY, Y, act, M, N, rows_per_block, db);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+}  // namespace mvk
+
+using namespace mvk;
+
+extern "C" {
+
+int mvk_linear_fwd(const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int act,
+                   void* stream) {
+  if (!X || !W || !Y || M < 0 || N <= 0 || K <= 0) return MVK_EINVAL;
+  GemmDesc d{};
+  plain_a(d.a, X, K, 1, M, K);
+  plain_b(d.b, W, 1, K, K, N);  // B[k][n] = W[n][k]
+  rowmajor_epi(d.e, Y, N);
+  d.e.bias = b;
+  d.e.bias_mod = N;
+  d.e.act = act;
+  d.M = M;
+  d.N = N;
+  d.K = K;
+  return launch_igemm(d, 1, mvk_stream(stream));
+}
+
+int mvk_linear_bwd_data(const float* dY, const float* W, float* dX, int M, int N, int K, const float* y_out,
+                        int y_act, const float* prev_out, int prev_act, int accumulate, void* stream) {
+  if (!dY || !W || !dX || M < 0 || N <= 0 || K <= 0) return MVK_EINVAL;
+  GemmDesc d{};
+  plain_a(d.a, dY, N, 1, M, N);  // reduce over n
+  d.a.act_src = y_out;
+  d.a.act = y_act;
+  plain_b(d.b, W, K, 1, N, K);  // B[kk=n][j=k] = W[n][k]
+  rowmajor_epi(d.e, dX, K);
+  d.e.act_src = prev_out;
+  d.e.src_act = prev_act;
+  d.e.atomic = accumulate;
+  d.M = M;
+  d.N = K;
+  d.K = N;
+  return launch_igemm(d, 1, mvk_stream(stream));
+}
+
+int mvk_linear_bwd_weight(const float* dY, const float* X, float* dW, float* db, int M, int N, int K,
+                          const float* y_out, int y_act, void* stream) {
+  if (!dY || !X || !dW || M < 0 || N <= 0 || K <= 0) return MVK_EINVAL;
+  hipStream_t s = mvk_stream(stream);
+  GemmDesc d{};
+  // dW[n][k] += sum_m dY[m][n] X[m][k]:  A'[i=n][kk=m] = dY[m*N + n]
+  plain_a(d.a, dY, 1, N, N, M);
+  d.a.act_src = y_out;
+  d.a.act = y_act;
+  plain_b(d.b, X, K, 1, M, K);
+  rowmajor_epi(d.e, dW, K);
+  d.e.atomic = 1;
+  d.M = N;
+  d.N = K;
+  d.K = M;
+  int splits = pick_splits(d.M, d.N, d.K);
+  int ktiles = (d.K + BK - 1) / BK;
+  d.zmode = Z_SPLITK;
+  d.ksplit_tiles = (ktiles + splits - 1) / splits;
+  int z = (ktiles + d.ksplit_tiles - 1) / d.ksplit_tiles;
+  int rc = launch_igemm(d, z, s);
+  if (rc) return rc;
+  if (db) return colsum(dY, y_out, y_act, M, N, db, s);
+  return MVK_OK;
+}
+
+int mvk_colsum_acc(const float* dY, const float* y_out, int y_act, float* db, int M, int N, void* stream) {
+  if (!dY || !db) return MVK_EINVAL;
+  return colsum(dY, y_out, y_act, M, N, db, mvk_stream(stream));
+}
+
+int mvk_nchw_channel_sum_acc(const float* dY, const float* y_out, int y_act, float* db, int n, int c, int hw,
+                             void* stream) {
+  if (!dY || !db || n < 0 || c <= 0 || hw <= 0) return MVK_EINVAL;
+  if (n == 0) return MVK_OK;
+  int ipb = 16;
+  hipLaunchKernelGGL(nchw_channel_sum_kernel, dim3(c, (n + ipb - 1) / ipb), dim3(256), 0, mvk_stream(stream), dY,
+                     y_out, y_act, n, c, hw, ipb, db);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_gemm(const float* A, const float* B, float* C, int M, int N, int K, int ta, int tb, const float* bias,
+             int bias_mod, int act, int accumulate, const float* a_act_src, int a_act, const float* c_act_src,
+             int c_act, void* stream) {
+  if (!A || !B || !C || M < 0 || N <= 0 || K <= 0) return MVK_EINVAL;
+  GemmDesc d{};
+  if (ta)
+    plain_a(d.a, A, 1, M, M, K);
+  else
+    plain_a(d.a, A, K, 1, M, K);
+  d.a.act_src = a_act_src;
+  d.a.act = a_act;
+  if (tb)
+    plain_b(d.b, B, 1, K, K, N);
+  else
+    plain_b(d.b, B, N, 1, K, N);
+  rowmajor_epi(d.e, C, N);
+  d.e.bias = bias;
+  d.e.bias_mod = bias_mod > 0 ? bias_mod : 1;
+  d.e.act = act;
+  d.e.act_src = c_act_src;
+  d.e.src_act = c_act;
+  d.e.atomic = accumulate;
+  d.M = M;
+  d.N = N;
+  d.K = K;
+  int z = 1;
+  if (accumulate) {
+    int splits = pick_splits(M, N, K);
+    int ktiles = (K + BK - 1) / BK;
+    d.zmode = Z_SPLITK;
+    d.ksplit_tiles = (ktiles + splits - 1) / splits;
+    z = (ktiles + d.ksplit_tiles - 1) / d.ksplit_tiles;
+  }
+  return launch_igemm(d, z, mvk_stream(stream));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 4x4 / stride 2 / pad 1 pair
+// ---------------------------------------------------------------------------------------------------------
+int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w, int Cu,
+                     int Cv, int act, int u_nchw, const float* u_act_src, int u_act, const float* v_act_src,
+                     int v_act, void* stream) {
+  if (!U || !Wdown || !V || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0) return MVK_EINVAL;
+  GemmDesc d{};
+  d.a = AOperand{};
+  d.a.p = U;
+  d.a.kind = u_nchw ? A_DOWN_NCHW : A_DOWN;
+  d.a.trans = 0;
+  d.a.C = Cu;
+  d.a.H = 2 * h;
+  d.a.W = 2 * w;
+  d.a.OH = h;
+  d.a.OW = w;
+  d.a.contig_k = u_nchw ? 0 : 1;
+  d.a.vec4 = (!u_nchw) && (Cu % 4 == 0) && mvk_aligned16(U) && (!u_act_src || mvk_aligned16(u_act_src));
+  d.a.act_src = u_act_src;
+  d.a.act = u_act;
+  plain_b(d.b, Wdown, Cv, 1, 16 * Cu, Cv);
+  rowmajor_epi(d.e, V, Cv);
+  d.e.bias = bias;
+  d.e.bias_mod = Cv;
+  d.e.act = act;
+  d.e.act_src = v_act_src;
+  d.e.src_act = v_act;
+  d.M = n * h * w;
+  d.N = Cv;
+  d.K = 16 * Cu;
+  return launch_igemm(d, 1, mvk_stream(stream));
+}
+
+int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U, int n, int h, int w, int Cu,
+                   int Cv, int act, int u_nchw, const float* u_act_src, int u_act, void* stream) {
+  if (!V || !Wup || !U || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0) return MVK_EINVAL;
+  GemmDesc d{};
+  d.a = AOperand{};
+  d.a.p = V;
+  d.a.kind = A_UP;
+  d.a.trans = 0;
+  d.a.C = Cv;
+  d.a.H = h;
+  d.a.W = w;
+  d.a.OH = h;
+  d.a.OW = w;
+  d.a.contig_k = 1;
+  d.a.vec4 = (Cv % 4 == 0) && mvk_aligned16(V);
+  plain_b(d.b, Wup, Cu, 1, 4 * Cv, Cu);
+  d.b.z_stride = (long long)4 * Cv * Cu;
+  d.e = Epilogue{};
+  d.e.out = U;
+  d.e.kind = u_nchw ? E_UP_NCHW : E_UP;
+  d.e.ld = Cu;
+  d.e.bias = bias;
+  d.e.bias_mod = Cu;
+  d.e.act = act;
+  d.e.act_src = u_act_src;
+  d.e.src_act = u_act;
+  d.e.Cu = Cu;
+  d.e.OH = h;
+  d.e.OW = w;
+  d.M = n * h * w;
+  d.N = Cu;
+  d.K = 4 * Cv;
+  d.zmode = Z_PARITY;
+  return launch_igemm(d, 4, mvk_stream(stream));
+}
+
+int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv,
+                      int u_nchw, const float* u_act_src, int u_act, void* stream) {
+  if (!U || !V || !dWref || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0) return MVK_EINVAL;
+  GemmDesc d{};
+  d.a = AOperand{};
+  d.a.p = U;
+  d.a.kind = u_nchw ? A_DOWN_NCHW : A_DOWN;
+  d.a.trans = 1;  // GEMM row = (tap, cu), reduction index = position
+  d.a.C = Cu;
+  d.a.H = 2 * h;
+  d.a.W = 2 * w;
+  d.a.OH = h;
+  d.a.OW = w;
+  d.a.contig_k = u_nchw ? 1 : 0;
+  d.a.vec4 = (!u_nchw) && (Cu % 4 == 0) && mvk_aligned16(U) && (!u_act_src || mvk_aligned16(u_act_src));
+  d.a.act_src = u_act_src;
+  d.a.act = u_act;
+  plain_b(d.b, V, Cv, 1, n * h * w, Cv);
+  d.e = Epilogue{};
+  d.e.out = dWref;
+  d.e.kind = E_CONVREF;
+  d.e.bias_mod = 1;
+  d.e.atomic = 1;
+  d.e.Cu = Cu;
+  d.e.OH = h;
+  d.e.OW = w;
+  d.M = 16 * Cu;
+  d.N = Cv;
+  d.K = n * h * w;
+  int splits = pick_splits(d.M, d.N, d.K);
+  int ktiles = (d.K + BK - 1) / BK;
+  d.zmode = Z_SPLITK;
+  d.ksplit_tiles = (ktiles + splits - 1) / splits;
+  int z = (ktiles + d.ksplit_tiles - 1) / d.ksplit_tiles;
+  return launch_igemm(d, z, mvk_stream(stream));
+}
+
+// dWref[ci][co][4][4] += z[n,ci]^T dY[n,(tap,co)]  (ConvTranspose2d(L,C,4,1,0) on a 1x1 input)
+int mvk_unflatten_wgrad(const float* Z, const float* dY, float* dWref, int n, int Cin, int Cout, void* stream) {
+  if (!Z || !dY || !dWref || n < 0 || Cin <= 0 || Cout <= 0) return MVK_EINVAL;
+  GemmDesc d{};
+  plain_a(d.a, Z, 1, Cin, Cin, n);  // A'[i=ci][kk=row] = Z[row*Cin + ci]
+  plain_b(d.b, dY, 16 * Cout, 1, n, 16 * Cout);
+  d.e = Epilogue{};
+  d.e.out = dWref;
+  d.e.kind = E_UNFLATREF;
+  d.e.bias_mod = 1;
+  d.e.atomic = 1;
+  d.e.Cu = Cout;
+  d.e.OH = d.e.OW = 1;
+  d.M = Cin;
+  d.N = 16 * Cout;
+  d.K = n;
+  int splits = pick_splits(d.M, d.N, d.K, 512);
+  int ktiles = (d.K + BK - 1) / BK;
+  d.zmode = Z_SPLITK;
+  d.ksplit_tiles = (ktiles + splits - 1) / splits;
+  int z = (ktiles + d.ksplit_tiles - 1) / d.ksplit_tiles;
+  return launch_igemm(d, z, mvk_stream(stream));
+}
+
+// dWref[cv][cu][4][4] += H[n,(tap,cu)]^T dY[n,cv]  (Conv2d(C,L,4,2,0) heads on a 4x4 input)
+int mvk_flatten_wgrad(const float* H, const float* dY, float* dWref, int n, int Cu, int Cv, void* stream) {
+  if (!H || !dY || !dWref || n < 0 || Cu <= 0 || Cv <= 0) return MVK_EINVAL;
+  GemmDesc d{};
+  plain_a(d.a, H, 1, 16 * Cu, 16 * Cu, n);
+  plain_b(d.b, dY, Cv, 1, n, Cv);
+  d.e = Epilogue{};
+  d.e.out = dWref;
+  d.e.kind = E_CONVREF;
+  d.e.bias_mod = 1;
+  d.e.atomic = 1;
+  d.e.Cu = Cu;
+  d.e.OH = d.e.OW = 1;
+  d.M = 16 * Cu;
+  d.N = Cv;
+  d.K = n;
+  int splits = pick_splits(d.M, d.N, d.K, 512);
+  int ktiles = (d.K + BK - 1) / BK;
+  d.zmode = Z_SPLITK;
+  d.ksplit_tiles = (ktiles + splits - 1) / splits;
+  int z = (ktiles + d.ksplit_tiles - 1) / d.ksplit_tiles;
+  return launch_igemm(d, z, mvk_stream(stream));
+}
+
+}  // extern "C"

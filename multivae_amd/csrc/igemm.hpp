@@ -1,0 +1,536 @@
+// fp32 MFMA implicit-GEMM engine for gfx950 (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains).
+//
+// One kernel template computes C = op(A) * op(B) for every dense layer on the path:
+//   - A may be a plain strided matrix or an *implicit* im2col view of an NHWC/NCHW activation tensor
+//     (4x4 / stride-2 / pad-1 convolution "down" gather, its transposed "up" gather, or either one with the
+//     roles of the GEMM row and reduction index swapped for the weight-gradient GEMM);
+//   - B is a plain strided matrix (weights are pre-packed so that the GEMM N index is contiguous);
+//   - the epilogue fuses bias, activation, multiplication by a saved activation's derivative, the
+//     parity scatter of the transposed convolution, the scatter back into the reference weight layout and
+//     atomic split-K accumulation.
+// LDS tiles are k-major (As[kk][i], Bs[kk][j]) so both MFMA operands are bank-conflict-free ds_read_b32
+// (lanes 0-31 read 32 consecutive floats of one k row, lanes 32-63 the next k row).
+#pragma once
+#include "common.hpp"
+
+namespace mvk {
+
+enum AKind { A_PLAIN = 0, A_DOWN = 1, A_DOWN_NCHW = 2, A_UP = 3 };
+enum EpiKind { E_ROWMAJOR = 0, E_UP = 1, E_CONVREF = 2, E_UNFLATREF = 3, E_UP_NCHW = 4 };
+enum ZMode { Z_NONE = 0, Z_SPLITK = 1, Z_PARITY = 2 };
+
+struct AOperand {
+  const float* p;
+  int kind;
+  int trans;        // gather kinds: 0 -> GEMM row = position, k = (tap,channel); 1 -> swapped (wgrad)
+  long long sr, sk;  // A_PLAIN: element (r,k) at p[r*sr + k*sk]
+  int contig_k;     // 1: memory contiguous along k; 0: contiguous along r
+  int vec4;         // 16-byte vector loads allowed along the contiguous direction
+  int C, H, W;      // gathered tensor: channels and spatial size
+  int OH, OW;       // spatial size enumerating positions
+  const float* act_src;  // optional: loaded value *= act'(act_src[same offset])
+  int act;
+};
+
+struct BOperand {
+  const float* p;
+  long long sk, sn;  // element (k,n) at p[k*sk + n*sn]
+  int contig_k;
+  int vec4;
+  long long z_stride;  // Z_PARITY: per-parity offset
+};
+
+struct Epilogue {
+  float* out;
+  int kind;
+  long long ld;
+  const float* bias;
+  int bias_mod;
+  int act;
+  const float* act_src;  // multiply by act'(act_src[out offset]) before storing
+  int src_act;
+  int atomic;
+  int Cu, OH, OW;  // E_UP / E_CONVREF / E_UNFLATREF geometry
+};
+
+struct GemmDesc {
+  AOperand a;
+  BOperand b;
+  Epilogue e;
+  int M, N, K;
+  int zmode;
+  int ksplit_tiles;  // Z_SPLITK: k-tiles per z slice
+};
+
+constexpr int BK = 16;
+
+template <int BM, int BN>
+struct TileCfg {
+  static constexpr int WAVES_N = (BN >= 64) ? 2 : 1;
+  static constexpr int WAVES_M = 4 / WAVES_N;
+  static constexpr int WTM = BM / WAVES_M;  // wave tile
+  static constexpr int WTN = BN / WAVES_N;
+  static constexpr int TM = WTM / 32;
+  static constexpr int TN = WTN / 32;
+  static constexpr int SA = BM + 4;  // LDS row strides (floats), multiple of 4 for b128 writes
+  static constexpr int SB = BN + 4;
+  // staging: scalar path = R*BK/256 floats per thread; vector path = ceil(R*BK/4/256) float4 per thread
+  static constexpr int NA1 = BM * BK / 256;
+  static constexpr int NB1 = BN * BK / 256;
+  static constexpr int NA4 = (BM * BK / 4 + 255) / 256;
+  static constexpr int NB4 = (BN * BK / 4 + 255) / 256;
+  static constexpr int NA = (4 * NA4 > NA1) ? 4 * NA4 : NA1;
+  static constexpr int NB = (4 * NB4 > NB1) ? 4 * NB4 : NB1;
+  static constexpr int UA4 = BM * BK / 4;  // number of float4 units in a tile
+  static constexpr int UB4 = BN * BK / 4;
+  static_assert(TM >= 1 && TN >= 1, "tile too small");
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- position decode helpers -------------------------------------------------------------------------
+struct Pos {
+  int n, i, j;
+};
+__device__ __forceinline__ Pos decode_pos(int pos, int OH, int OW) {
+  Pos p;
+  p.j = pos % OW;
+  int t = pos / OW;
+  p.i = t % OH;
+  p.n = t / OH;
+  return p;
+}
+
+// offset (in floats) of gathered element for position `ps`, reduction index kk=(tap,c); returns validity
+__device__ __forceinline__ bool gather_off(const AOperand& a, const Pos& ps, int kk, int ph, int pw,
+                                           long long& off) {
+  int tap = kk / a.C;
+  int c = kk - tap * a.C;
+  if (a.kind == A_UP) {
+    int ta = tap >> 1, tb = tap & 1;
+    int oh = ps.i + ph - ta;
+    int ow = ps.j + pw - tb;
+    off = (((long long)ps.n * a.H + oh) * a.W + ow) * a.C + c;
+    return (oh >= 0) & (oh < a.H) & (ow >= 0) & (ow < a.W);
+  }
+  int kh = tap >> 2, kw = tap & 3;
+  int h = 2 * ps.i - 1 + kh;
+  int w = 2 * ps.j - 1 + kw;
+  bool ok = (h >= 0) & (h < a.H) & (w >= 0) & (w < a.W);
+  if (a.kind == A_DOWN)
+    off = (((long long)ps.n * a.H + h) * a.W + w) * a.C + c;
+  else
+    off = (((long long)ps.n * a.C + c) * a.H + h) * a.W + w;
+  return ok;
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void igemm_kernel(const GemmDesc d) {
+  using T = TileCfg<BM, BN>;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (T::SA + T::SB)];
+  float* As = lds;                    // [2][BK][SA]
+  float* Bs = lds + 2 * BK * T::SA;   // [2][BK][SB]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / T::WAVES_N;
+  const int wn = wave % T::WAVES_N;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  int ph = 0, pw = 0;
+  int kt_begin = 0, kt_end = (d.K + BK - 1) / BK;
+  const float* bp = d.b.p;
+  if (d.zmode == Z_PARITY) {
+    ph = blockIdx.z >> 1;
+    pw = blockIdx.z & 1;
+    bp += (long long)blockIdx.z * d.b.z_stride;
+  } else if (d.zmode == Z_SPLITK) {
+    kt_begin = blockIdx.z * d.ksplit_tiles;
+    int e = kt_begin + d.ksplit_tiles;
+    kt_end = e < kt_end ? e : kt_end;
+    if (kt_begin >= kt_end) return;
+  }
+
+  f32x16 acc[T::TM][T::TN];
+#pragma unroll
+  for (int a = 0; a < T::TM; ++a)
+#pragma unroll
+    for (int b = 0; b < T::TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  float sa[T::NA];
+  float sb[T::NB];
+
+  const AOperand& A = d.a;
+  const BOperand& B = d.b;
+  const bool a_gather = A.kind != A_PLAIN;
+
+  // ---------------- global -> registers ----------------
+  auto load_a = [&](int kt) {
+    const int k0 = kt * BK;
+    if (A.contig_k) {
+      // units: (row, kvec) ; vec along k
+      if (A.vec4) {
+#pragma unroll
+        for (int u = 0; u < T::NA4; ++u) {
+          int idx = tid + u * 256;
+          int row = idx / (BK / 4);
+          int k = k0 + (idx % (BK / 4)) * 4;
+          int r = m0 + row;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (idx < T::UA4 && r < d.M && k < d.K) {
+            long long off;
+            bool ok = true;
+            if (!a_gather) {
+              off = r * A.sr + k * A.sk;
+            } else {
+              Pos ps = decode_pos(A.trans ? k : r, A.OH, A.OW);
+              ok = gather_off(A, ps, A.trans ? r : k, ph, pw, off);
+            }
+            if (ok) {
+              v = *reinterpret_cast<const float4*>(A.p + off);
+              if (A.act_src) {
+                float4 y = *reinterpret_cast<const float4*>(A.act_src + off);
+                v.x *= mvk_act_grad_from_out(y.x, A.act);
+                v.y *= mvk_act_grad_from_out(y.y, A.act);
+                v.z *= mvk_act_grad_from_out(y.z, A.act);
+                v.w *= mvk_act_grad_from_out(y.w, A.act);
+              }
+            }
+          }
+          sa[4 * u + 0] = v.x;
+          sa[4 * u + 1] = v.y;
+          sa[4 * u + 2] = v.z;
+          sa[4 * u + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < T::NA1; ++u) {
+          int idx = tid + u * 256;
+          int row = idx / BK;
+          int k = k0 + (idx % BK);
+          int r = m0 + row;
+          float v = 0.f;
+          if (r < d.M && k < d.K) {
+            long long off;
+            bool ok = true;
+            if (!a_gather) {
+              off = r * A.sr + k * A.sk;
+            } else {
+              Pos ps = decode_pos(A.trans ? k : r, A.OH, A.OW);
+              ok = gather_off(A, ps, A.trans ? r : k, ph, pw, off);
+            }
+            if (ok) {
+              v = A.p[off];
+              if (A.act_src) v *= mvk_act_grad_from_out(A.act_src[off], A.act);
+            }
+          }
+          sa[u] = v;
+        }
+      }
+    } else {
+      // contiguous along r: units (k, rvec)
+      if (A.vec4) {
+#pragma unroll
+        for (int u = 0; u < T::NA4; ++u) {
+          int idx = tid + u * 256;
+          int kk = idx / (BM / 4);
+          int row = (idx % (BM / 4)) * 4;
+          int k = k0 + kk;
+          int r = m0 + row;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (idx < T::UA4 && r < d.M && k < d.K) {
+            long long off;
+            bool ok = true;
+            if (!a_gather) {
+              off = r * A.sr + k * A.sk;
+            } else {
+              Pos ps = decode_pos(A.trans ? k : r, A.OH, A.OW);
+              ok = gather_off(A, ps, A.trans ? r : k, ph, pw, off);
+            }
+            if (ok) {
+              v = *reinterpret_cast<const float4*>(A.p + off);
+              if (A.act_src) {
+                float4 y = *reinterpret_cast<const float4*>(A.act_src + off);
+                v.x *= mvk_act_grad_from_out(y.x, A.act);
+                v.y *= mvk_act_grad_from_out(y.y, A.act);
+                v.z *= mvk_act_grad_from_out(y.z, A.act);
+                v.w *= mvk_act_grad_from_out(y.w, A.act);
+              }
+            }
+          }
+          sa[4 * u + 0] = v.x;
+          sa[4 * u + 1] = v.y;
+          sa[4 * u + 2] = v.z;
+          sa[4 * u + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < T::NA1; ++u) {
+          int idx = tid + u * 256;
+          int kk = idx / BM;
+          int row = idx % BM;
+          int k = k0 + kk;
+          int r = m0 + row;
+          float v = 0.f;
+          if (r < d.M && k < d.K) {
+            long long off;
+            bool ok = true;
+            if (!a_gather) {
+              off = r * A.sr + k * A.sk;
+            } else {
+              Pos ps = decode_pos(A.trans ? k : r, A.OH, A.OW);
+              ok = gather_off(A, ps, A.trans ? r : k, ph, pw, off);
+            }
+            if (ok) {
+              v = A.p[off];
+              if (A.act_src) v *= mvk_act_grad_from_out(A.act_src[off], A.act);
+            }
+          }
+          sa[u] = v;
+        }
+      }
+    }
+  };
+
+  auto load_b = [&](int kt) {
+    const int k0 = kt * BK;
+    if (B.contig_k) {
+      if (B.vec4) {
+#pragma unroll
+        for (int u = 0; u < T::NB4; ++u) {
+          int idx = tid + u * 256;
+          int col = idx / (BK / 4);
+          int k = k0 + (idx % (BK / 4)) * 4;
+          int n = n0 + col;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (idx < T::UB4 && n < d.N && k < d.K) v = *reinterpret_cast<const float4*>(bp + k * B.sk + n * B.sn);
+          sb[4 * u + 0] = v.x;
+          sb[4 * u + 1] = v.y;
+          sb[4 * u + 2] = v.z;
+          sb[4 * u + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < T::NB1; ++u) {
+          int idx = tid + u * 256;
+          int col = idx / BK;
+          int k = k0 + (idx % BK);
+          int n = n0 + col;
+          sb[u] = (n < d.N && k < d.K) ? bp[k * B.sk + n * B.sn] : 0.f;
+        }
+      }
+    } else {
+      if (B.vec4) {
+#pragma unroll
+        for (int u = 0; u < T::NB4; ++u) {
+          int idx = tid + u * 256;
+          int kk = idx / (BN / 4);
+          int col = (idx % (BN / 4)) * 4;
+          int k = k0 + kk;
+          int n = n0 + col;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (idx < T::UB4 && n < d.N && k < d.K) v = *reinterpret_cast<const float4*>(bp + k * B.sk + n * B.sn);
+          sb[4 * u + 0] = v.x;
+          sb[4 * u + 1] = v.y;
+          sb[4 * u + 2] = v.z;
+          sb[4 * u + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < T::NB1; ++u) {
+          int idx = tid + u * 256;
+          int kk = idx / BN;
+          int col = idx % BN;
+          int k = k0 + kk;
+          int n = n0 + col;
+          sb[u] = (n < d.N && k < d.K) ? bp[k * B.sk + n * B.sn] : 0.f;
+        }
+      }
+    }
+  };
+
+  // ---------------- registers -> LDS (k-major tiles) ----------------
+  auto store_a = [&](int buf) {
+    float* dst = As + buf * BK * T::SA;
+    if (A.contig_k) {
+      if (A.vec4) {
+#pragma unroll
+        for (int u = 0; u < T::NA4; ++u) {
+          int idx = tid + u * 256;
+          int row = idx / (BK / 4);
+          int kq = (idx % (BK / 4)) * 4;
+          if (idx < T::UA4) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dst[(kq + c) * T::SA + row] = sa[4 * u + c];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < T::NA1; ++u) {
+          int idx = tid + u * 256;
+          dst[(idx % BK) * T::SA + idx / BK] = sa[u];
+        }
+      }
+    } else {
+      if (A.vec4) {
+#pragma unroll
+        for (int u = 0; u < T::NA4; ++u) {
+          int idx = tid + u * 256;
+          int kk = idx / (BM / 4);
+          int row = (idx % (BM / 4)) * 4;
+          if (idx < T::UA4)
+            *reinterpret_cast<float4*>(dst + kk * T::SA + row) =
+                make_float4(sa[4 * u], sa[4 * u + 1], sa[4 * u + 2], sa[4 * u + 3]);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < T::NA1; ++u) {
+          int idx = tid + u * 256;
+          dst[(idx / BM) * T::SA + idx % BM] = sa[u];
+        }
+      }
+    }
+  };
+  auto store_b = [&](int buf) {
+    float* dst = Bs + buf * BK * T::SB;
+    if (B.contig_k) {
+      if (B.vec4) {
+#pragma unroll
+        for (int u = 0; u < T::NB4; ++u) {
+          int idx = tid + u * 256;
+          int col = idx / (BK / 4);
+          int kq = (idx % (BK / 4)) * 4;
+          if (idx < T::UB4) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dst[(kq + c) * T::SB + col] = sb[4 * u + c];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < T::NB1; ++u) {
+          int idx = tid + u * 256;
+          dst[(idx % BK) * T::SB + idx / BK] = sb[u];
+        }
+      }
+    } else {
+      if (B.vec4) {
+#pragma unroll
+        for (int u = 0; u < T::NB4; ++u) {
+          int idx = tid + u * 256;
+          int kk = idx / (BN / 4);
+          int col = (idx % (BN / 4)) * 4;
+          if (idx < T::UB4)
+            *reinterpret_cast<float4*>(dst + kk * T::SB + col) =
+                make_float4(sb[4 * u], sb[4 * u + 1], sb[4 * u + 2], sb[4 * u + 3]);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < T::NB1; ++u) {
+          int idx = tid + u * 256;
+          dst[(idx / BN) * T::SB + idx % BN] = sb[u];
+        }
+      }
+    }
+  };
+
+  // ---------------- MFMA over one staged k-tile ----------------
+  const int l31 = lane & 31;
+  const int lhi = lane >> 5;
+  auto compute = [&](int buf) {
+    const float* a_s = As + buf * BK * T::SA + wm * T::WTM + l31;
+    const float* b_s = Bs + buf * BK * T::SB + wn * T::WTN + l31;
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      float av[T::TM], bv[T::TN];
+#pragma unroll
+      for (int a = 0; a < T::TM; ++a) av[a] = a_s[(2 * ks + lhi) * T::SA + a * 32];
+#pragma unroll
+      for (int b = 0; b < T::TN; ++b) bv[b] = b_s[(2 * ks + lhi) * T::SB + b * 32];
+#pragma unroll
+      for (int a = 0; a < T::TM; ++a)
+#pragma unroll
+        for (int b = 0; b < T::TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+  };
+
+  // ---------------- main loop: register-staged prefetch, double-buffered LDS ----------------
+  load_a(kt_begin);
+  load_b(kt_begin);
+  store_a(0);
+  store_b(0);
+  __syncthreads();
+  int buf = 0;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const bool more = (kt + 1) < kt_end;
+    if (more) {
+      load_a(kt + 1);
+      load_b(kt + 1);
+    }
+    compute(buf);
+    if (more) {
+      store_a(buf ^ 1);
+      store_b(buf ^ 1);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---------------- epilogue ----------------
+  // The accumulators of one 32x32 MFMA tile are parked in LDS (one private column per thread, so no
+  // barrier is needed) and consumed by a rolled loop: the address / activation code exists once instead of
+  // 16*TM*TN times.  The tile buffers are free: the main loop ended with a barrier.
+  const Epilogue& E = d.e;
+  float* park = lds + tid;  // element r at park[r * 256]
+#pragma unroll
+  for (int a = 0; a < T::TM; ++a) {
+#pragma unroll
+    for (int b = 0; b < T::TN; ++b) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) park[r * 256] = acc[a][b][r];
+      const int n = n0 + wn * T::WTN + b * 32 + l31;
+      const int mbase = m0 + wm * T::WTM + a * 32 + 4 * lhi;
+      if (n < d.N) {
+        const float bias_v = E.bias ? E.bias[n % E.bias_mod] : 0.f;
+#pragma unroll 1
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          if (m >= d.M) continue;
+          float v = park[r * 256];
+          long long off;
+          if (E.kind == E_ROWMAJOR) {
+            off = (long long)m * E.ld + n;
+          } else if (E.kind == E_UP) {
+            Pos ps = decode_pos(m, E.OH, E.OW);
+            off = (((long long)ps.n * (2 * E.OH) + 2 * ps.i + ph) * (2 * E.OW) + 2 * ps.j + pw) * E.Cu + n;
+          } else if (E.kind == E_UP_NCHW) {
+            Pos ps = decode_pos(m, E.OH, E.OW);
+            off = (((long long)ps.n * E.Cu + n) * (2 * E.OH) + 2 * ps.i + ph) * (2 * E.OW) + 2 * ps.j + pw;
+          } else if (E.kind == E_CONVREF) {
+            int tap = m / E.Cu;
+            int cu = m - tap * E.Cu;
+            off = ((long long)n * E.Cu + cu) * 16 + tap;
+          } else {  // E_UNFLATREF: m = ci, n = (tap, co)
+            int tap = n / E.Cu;
+            int co = n - tap * E.Cu;
+            off = ((long long)m * E.Cu + co) * 16 + tap;
+          }
+          v = mvk_act(v + bias_v, E.act);
+          if (E.act_src) v *= mvk_act_grad_from_out(E.act_src[off], E.src_act);
+          if (E.atomic)
+            atomicAdd(E.out + off, v);
+          else
+            E.out[off] = v;
+        }
+      }
+    }
+  }
+}
+
+int launch_igemm(const GemmDesc& d, int zdim, hipStream_t s);
+
+}  // namespace mvk

@@ -1,0 +1,305 @@
+// Small HBM-bound helper kernels: weight packing, layout changes at the plugin boundary, activation
+// backward, the 3-channel image-producing transposed convolution, flat Adam, scalar assembly.
+#include "common.hpp"
+
+namespace {
+
+// ---- weight packing -------------------------------------------------------------------------------------
+// Wref[cv][cu][kh][kw]  ->  Wdown[(kh*4+kw)*Cu + cu][cv]            (ld = ldd, column offset coff)
+//                       ->  Wup[ph*2+pw][((a*2+b)*Cv + cv)][cu]     with kh = (1-ph)+2a, kw = (1-pw)+2b
+__global__ void pack_conv4s2_kernel(const float* __restrict__ Wref, int Cv, int Cu, float* __restrict__ Wdown,
+                                    int ldd, int coff, float* __restrict__ Wup) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int total = Cv * Cu * 16;
+  if (idx >= total) return;
+  int tap = idx & 15;
+  int cu = (idx >> 4) % Cu;
+  int cv = (idx >> 4) / Cu;
+  float v = Wref[idx];
+  int kh = tap >> 2, kw = tap & 3;
+  if (Wdown) Wdown[(long long)(tap * Cu + cu) * ldd + coff + cv] = v;
+  if (Wup) {
+    int ph = 1 - (kh & 1), a = kh >> 1;
+    int pw = 1 - (kw & 1), b = kw >> 1;
+    Wup[((long long)(ph * 2 + pw) * 4 * Cv + (a * 2 + b) * Cv + cv) * Cu + cu] = v;
+  }
+}
+
+// Wref[ci][co][tap] -> Wp[ci][tap*Cout + co]
+__global__ void pack_unflatten_kernel(const float* __restrict__ Wref, int Cin, int Cout, float* __restrict__ Wp) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int total = Cin * Cout * 16;
+  if (idx >= total) return;
+  int tap = idx & 15;
+  int co = (idx >> 4) % Cout;
+  int ci = (idx >> 4) / Cout;
+  Wp[(long long)ci * 16 * Cout + tap * Cout + co] = Wref[idx];
+}
+
+// ---- layout ----------------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, long long total, int c,
+                                    int hw) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // destination index (n, p, ch)
+  if (idx >= total) return;
+  int ch = idx % c;
+  long long t = idx / c;
+  int p = t % hw;
+  long long n = t / hw;
+  dst[idx] = src[(n * c + ch) * hw + p];
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, long long total, int c,
+                                    int hw) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // destination index (n, ch, p)
+  if (idx >= total) return;
+  int p = idx % hw;
+  long long t = idx / hw;
+  int ch = t % c;
+  long long n = t / c;
+  dst[idx] = src[(n * hw + p) * c + ch];
+}
+
+__global__ void act_bwd_kernel(float* __restrict__ dY, const float* __restrict__ Y, long long n, int act) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dY[i] *= mvk_act_grad_from_out(Y[i], act);
+}
+
+__global__ void scale_kernel(float* __restrict__ buf, long long n, const float* __restrict__ g) {
+  float s = *g;
+  if (s == 1.0f) return;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) buf[i] *= s;
+}
+
+// ---- U[n,Cu,2h,2w] (NCHW) = act(convT(V[n,h,w,Cv]) + b), Cu <= 4: direct, one thread per output pixel ------
+template <int CU>
+__global__ __launch_bounds__(256) void up_nchw_small_kernel(const float* __restrict__ V,
+                                                            const float* __restrict__ Wref,
+                                                            const float* __restrict__ bias, float* __restrict__ U,
+                                                            int n, int h, int w, int Cv, int act) {
+  extern __shared__ float wl[];  // [tap][cv][CU]
+  for (int i = threadIdx.x; i < 16 * Cv * CU; i += blockDim.x) {
+    int cu = i % CU;
+    int cv = (i / CU) % Cv;
+    int tap = i / (CU * Cv);
+    wl[i] = Wref[((long long)cv * CU + cu) * 16 + tap];
+  }
+  __syncthreads();
+  const int H = 2 * h, W2 = 2 * w;
+  long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)n * H * W2;
+  if (pix >= total) return;
+  int ow = pix % W2;
+  long long t = pix / W2;
+  int oh = t % H;
+  long long img = t / H;
+  float acc[CU];
+#pragma unroll
+  for (int c = 0; c < CU; ++c) acc[c] = bias ? bias[c] : 0.f;
+  const int ph = oh & 1, pw = ow & 1;
+  const int i0 = oh >> 1, j0 = ow >> 1;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    int kh = (1 - ph) + 2 * a;
+    int ih = i0 + ph - a;
+    if (ih < 0 || ih >= h) continue;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      int kw = (1 - pw) + 2 * b;
+      int iw = j0 + pw - b;
+      if (iw < 0 || iw >= w) continue;
+      const float* vp = V + ((img * h + ih) * w + iw) * Cv;
+      const float* wp = wl + (kh * 4 + kw) * Cv * CU;
+      for (int cv = 0; cv < Cv; cv += 4) {
+        float4 x = *reinterpret_cast<const float4*>(vp + cv);
+#pragma unroll
+        for (int c = 0; c < CU; ++c) {
+          acc[c] = fmaf(x.x, wp[(cv + 0) * CU + c], acc[c]);
+          acc[c] = fmaf(x.y, wp[(cv + 1) * CU + c], acc[c]);
+          acc[c] = fmaf(x.z, wp[(cv + 2) * CU + c], acc[c]);
+          acc[c] = fmaf(x.w, wp[(cv + 3) * CU + c], acc[c]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CU; ++c) U[((img * CU + c) * H + oh) * W2 + ow] = mvk_act(acc[c], act);
+}
+
+// ---- Adam on flat buffers (torch.optim.Adam single-tensor rule, amsgrad=False) -----------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
+                            float bc1, float bc2_sqrt, float gscale) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  const float step_size = lr / bc1;
+  for (; i < n; i += stride) {
+    float gi = g[i] * gscale;
+    float pi = p[i];
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    float mi = m[i] + (gi - m[i]) * (1.f - b1);  // exp_avg.lerp_(grad, 1 - beta1)
+    float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+
+// ---- scalar assembly ----------------------------------------------------------------------------------------
+struct TermTable {
+  mvk_term_desc t[16];
+  int n;
+  float loss_sum_scale;
+};
+
+__global__ __launch_bounds__(1024) void reduce_terms_kernel(const TermTable tt, float* __restrict__ out,
+                                                            float* __restrict__ loss_out) {
+  __shared__ float red[16];
+  __shared__ float vals[16];
+  for (int i = 0; i < tt.n; ++i) {
+    const mvk_term_desc& t = tt.t[i];
+    float s = 0.f;
+    for (long long j = threadIdx.x; j < t.n; j += blockDim.x) {
+      float v = t.v[j];
+      if (t.mask) v = t.mask[j % t.period] ? v : 0.f;
+      s += v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float tot = 0.f;
+      for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) tot += red[wv];
+      vals[i] = tot * t.coef;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float loss = 0.f;
+    for (int i = 0; i < tt.n; ++i) {
+      out[i] = vals[i];
+      loss += tt.t[i].lossw * vals[i];
+    }
+    out[tt.n] = loss;
+    out[tt.n + 1] = loss * tt.loss_sum_scale;
+    if (loss_out) *loss_out = loss;
+  }
+}
+
+static int grid_for(long long n, int block, int cap = 2048) {
+  long long g = (n + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mvk_version(void) { return 100; }
+
+int mvk_pack_conv4s2_weight(const float* Wref, int Cv, int Cu, float* Wdown, int ld_down, int col_off,
+                            float* Wup, void* stream) {
+  if (!Wref || Cv <= 0 || Cu <= 0 || (!Wdown && !Wup)) return MVK_EINVAL;
+  int total = Cv * Cu * 16;
+  hipLaunchKernelGGL(pack_conv4s2_kernel, dim3((total + 255) / 256), dim3(256), 0, mvk_stream(stream), Wref, Cv, Cu,
+                     Wdown, ld_down > 0 ? ld_down : Cv, col_off, Wup);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_pack_unflatten_weight(const float* Wref, int Cin, int Cout, float* Wp, void* stream) {
+  if (!Wref || !Wp || Cin <= 0 || Cout <= 0) return MVK_EINVAL;
+  int total = Cin * Cout * 16;
+  hipLaunchKernelGGL(pack_unflatten_kernel, dim3((total + 255) / 256), dim3(256), 0, mvk_stream(stream), Wref, Cin,
+                     Cout, Wp);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, void* stream) {
+  if (!src || !dst) return MVK_EINVAL;
+  long long total = (long long)n * c * h * w;
+  if (total == 0) return MVK_OK;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mvk_stream(stream), src,
+                     dst, total, c, h * w);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, void* stream) {
+  if (!src || !dst) return MVK_EINVAL;
+  long long total = (long long)n * c * h * w;
+  if (total == 0) return MVK_OK;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mvk_stream(stream), src,
+                     dst, total, c, h * w);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_act_bwd(float* dY, const float* Y, int64_t n, int act, void* stream) {
+  if (!dY || !Y) return MVK_EINVAL;
+  if (n == 0) return MVK_OK;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, mvk_stream(stream), dY, Y, (long long)n, act);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_scale_by_device_scalar(float* buf, int64_t n, const float* gscale, void* stream) {
+  if (!buf || !gscale) return MVK_EINVAL;
+  if (n == 0) return MVK_OK;
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, 256)), dim3(256), 0, mvk_stream(stream), buf, (long long)n, gscale);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_conv4s2_up_nchw_small(const float* V, const float* Wref, const float* bias, float* U, int n, int h, int w,
+                              int Cu, int Cv, int act, void* stream) {
+  if (!V || !Wref || !U || Cu <= 0 || Cu > 4 || Cv <= 0 || (Cv % 4) != 0 || !mvk_aligned16(V)) return MVK_EINVAL;
+  long long total = (long long)n * 4 * h * w;
+  if (total == 0) return MVK_OK;
+  dim3 grid((unsigned)((total + 255) / 256));
+  size_t lds = (size_t)16 * Cv * Cu * sizeof(float);
+  hipStream_t s = mvk_stream(stream);
+  switch (Cu) {
+    case 1: hipLaunchKernelGGL(up_nchw_small_kernel<1>, grid, dim3(256), lds, s, V, Wref, bias, U, n, h, w, Cv, act); break;
+    case 2: hipLaunchKernelGGL(up_nchw_small_kernel<2>, grid, dim3(256), lds, s, V, Wref, bias, U, n, h, w, Cv, act); break;
+    case 3: hipLaunchKernelGGL(up_nchw_small_kernel<3>, grid, dim3(256), lds, s, V, Wref, bias, U, n, h, w, Cv, act); break;
+    default: hipLaunchKernelGGL(up_nchw_small_kernel<4>, grid, dim3(256), lds, s, V, Wref, bias, U, n, h, w, Cv, act); break;
+  }
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || step < 1) return MVK_EINVAL;
+  if (n == 0) return MVK_OK;
+  double bc1 = 1.0 - pow((double)beta1, (double)step);
+  double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, mvk_stream(stream), p, g, m, v, (long long)n,
+                     lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_reduce_terms(const mvk_term_desc* terms, int n_terms, float loss_sum_scale, float* out, float* loss_out,
+                     void* stream) {
+  if (!terms || !out || n_terms < 1 || n_terms > 16) return MVK_EINVAL;
+  TermTable tt;
+  for (int i = 0; i < n_terms; ++i) {
+    tt.t[i] = terms[i];
+    if (!terms[i].v || terms[i].n < 0) return MVK_EINVAL;
+    if (tt.t[i].period <= 0) tt.t[i].period = 1;
+  }
+  tt.n = n_terms;
+  tt.loss_sum_scale = loss_sum_scale;
+  hipLaunchKernelGGL(reduce_terms_kernel, dim3(1), dim3(1024), 0, mvk_stream(stream), tt, out, loss_out);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,628 @@
+"""torch.autograd.Function wrappers over the C ABI of libmvk.so.
+
+Every function here launches hand-written HIP kernels on the current PyTorch-ROCm stream; PyTorch is used
+for device memory and autograd ordering only.  Whole networks (MLP / SVHN encoder and decoder) are single
+autograd nodes so that a training step is a few dozen kernel launches with almost no Python in between,
+and the backward passes use the producer-epilogue fusion of the engine (a layer's backward-data GEMM
+multiplies by the previous layer's activation derivative and writes the pre-activation gradient directly).
+"""
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from ._lib import ACT, DIST, FAMILY, ReconDesc, TermDesc, call, ptr, ptr_array, stream_ptr
+
+RELU, SIGMOID, NONE = ACT["relu"], ACT["sigmoid"], ACT["none"]
+
+
+def _c(t):
+    """contiguous fp32 CUDA tensor (no copy when already so)."""
+    _lib.require_gpu_tensor(t)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _new(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def _zeros(shape, like):
+    return torch.zeros(shape, dtype=torch.float32, device=like.device)
+
+
+# =====================================================================================================
+# thin launch helpers (no autograd)
+# =====================================================================================================
+def linear_fwd(x2, w, b, act):
+    M, K = x2.shape
+    N = w.shape[0]
+    y = _new((M, N), x2)
+    call("mvk_linear_fwd", ptr(x2), ptr(w), ptr(b), ptr(y), M, N, K, act, stream_ptr())
+    return y
+
+
+def linear_bwd_data(dy, w, y_out=None, y_act=NONE, prev_out=None, prev_act=NONE, out=None, accumulate=False):
+    M, N = dy.shape
+    K = w.shape[1]
+    dx = out if out is not None else _new((M, K), dy)
+    call("mvk_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), M, N, K, ptr(y_out), y_act, ptr(prev_out), prev_act,
+         1 if accumulate else 0, stream_ptr())
+    return dx
+
+
+def linear_bwd_weight(dy, x2, y_out=None, y_act=NONE, want_bias=True):
+    M, N = dy.shape
+    K = x2.shape[1]
+    dw = _zeros((N, K), dy)
+    db = _zeros((N,), dy) if want_bias else None
+    call("mvk_linear_bwd_weight", ptr(dy), ptr(x2), ptr(dw), ptr(db), M, N, K, ptr(y_out), y_act, stream_ptr())
+    return dw, db
+
+
+def gemm(a, b, M, N, K, ta=False, tb=False, bias=None, bias_mod=0, act=NONE, out=None, accumulate=False,
+         a_act_src=None, a_act=NONE, c_act_src=None, c_act=NONE):
+    c = out if out is not None else _new((M, N), a)
+    call("mvk_gemm", ptr(a), ptr(b), ptr(c), M, N, K, int(ta), int(tb), ptr(bias), bias_mod, act,
+         1 if accumulate else 0, ptr(a_act_src), a_act, ptr(c_act_src), c_act, stream_ptr())
+    return c
+
+
+def colsum(dy2, y_out=None, y_act=NONE):
+    M, N = dy2.shape
+    db = _zeros((N,), dy2)
+    call("mvk_colsum_acc", ptr(dy2), ptr(y_out), y_act, ptr(db), M, N, stream_ptr())
+    return db
+
+
+def pack_conv(wref, want_down=True, want_up=True):
+    """wref [Cv][Cu][4][4] -> (Wdown [16*Cu, Cv], Wup [4, 4*Cv, Cu])."""
+    Cv, Cu = wref.shape[0], wref.shape[1]
+    wd = _new((16 * Cu, Cv), wref) if want_down else None
+    wu = _new((4, 4 * Cv, Cu), wref) if want_up else None
+    call("mvk_pack_conv4s2_weight", ptr(wref), Cv, Cu, ptr(wd), Cv, 0, ptr(wu), stream_ptr())
+    return wd, wu
+
+
+def conv_down(U, wdown, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src=None, u_act=NONE,
+              v_act_src=None, v_act=NONE):
+    V = _new((n, h, w, Cv), U)
+    call("mvk_conv4s2_down", ptr(U), ptr(wdown), ptr(bias), ptr(V), n, h, w, Cu, Cv, act, int(u_nchw),
+         ptr(u_act_src), u_act, ptr(v_act_src), v_act, stream_ptr())
+    return V
+
+
+def conv_up(V, wup, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src=None, u_act=NONE):
+    U = _new((n, Cu, 2 * h, 2 * w) if u_nchw else (n, 2 * h, 2 * w, Cu), V)
+    call("mvk_conv4s2_up", ptr(V), ptr(wup), ptr(bias), ptr(U), n, h, w, Cu, Cv, act, int(u_nchw),
+         ptr(u_act_src), u_act, stream_ptr())
+    return U
+
+
+def conv_wgrad(U, V, n, h, w, Cu, Cv, u_nchw=False, u_act_src=None, u_act=NONE):
+    dw = _zeros((Cv, Cu, 4, 4), V)
+    call("mvk_conv4s2_wgrad", ptr(U), ptr(V), ptr(dw), n, h, w, Cu, Cv, int(u_nchw), ptr(u_act_src), u_act,
+         stream_ptr())
+    return dw
+
+
+# =====================================================================================================
+# Encoder_VAE_MLP / Decoder_AE_MLP  (models/nn/default_architectures.py:21-72, 225-258)
+# =====================================================================================================
+class MLPEncoderFn(Function):
+    """x -> [Linear+ReLU]*n -> (embedding, log_covariance).  params = (W0,b0, W1,b1, ..., We,be, Wl,bl)."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        n_layers = (len(params) - 4) // 2
+        K0 = params[0].shape[1]
+        x2 = _c(x.reshape(-1, K0))
+        acts = [x2]
+        h = x2
+        for i in range(n_layers):
+            h = linear_fwd(h, params[2 * i], params[2 * i + 1], RELU)
+            acts.append(h)
+        we, be, wl, bl = params[-4:]
+        mu = linear_fwd(h, we, be, NONE)
+        lv = linear_fwd(h, wl, bl, NONE)
+        ctx.save_for_backward(*acts, *params)
+        ctx.n_layers = n_layers
+        ctx.x_shape = x.shape
+        return mu, lv
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dmu, dlv):
+        n = ctx.n_layers
+        saved = ctx.saved_tensors
+        acts, params = saved[: n + 1], saved[n + 1 :]
+        we, be, wl, bl = params[-4:]
+        dmu, dlv = _c(dmu), _c(dlv)
+        h = acts[-1]
+        grads = [None] * len(params)
+        grads[-4], grads[-3] = linear_bwd_weight(dmu, h)
+        grads[-2], grads[-1] = linear_bwd_weight(dlv, h)
+        # gradient w.r.t. the last hidden layer's PRE-activation: both heads, ReLU' fused in the epilogue
+        prev_src, prev_act = (h, RELU) if n > 0 else (None, NONE)
+        need_dx = ctx.needs_input_grad[0]
+        dh = None
+        if n > 0 or need_dx:
+            dh = linear_bwd_data(dmu, we, prev_out=prev_src, prev_act=prev_act)
+            linear_bwd_data(dlv, wl, prev_out=prev_src, prev_act=prev_act, out=dh, accumulate=True)
+        for i in range(n - 1, -1, -1):
+            w, inp = params[2 * i], acts[i]
+            grads[2 * i], grads[2 * i + 1] = linear_bwd_weight(dh, inp)
+            if i > 0:
+                dh = linear_bwd_data(dh, w, prev_out=acts[i], prev_act=RELU)
+            elif need_dx:
+                dh = linear_bwd_data(dh, w)
+        dx = dh.reshape(ctx.x_shape) if need_dx else None
+        return (dx, *grads)
+
+
+class MLPDecoderFn(Function):
+    """z[...,L] -> Linear+ReLU -> Linear+Sigmoid -> reshape(*z.shape[:-1], *input_dim)."""
+
+    @staticmethod
+    def forward(ctx, z, w0, b0, w1, b1, input_dim):
+        L = w0.shape[1]
+        z2 = _c(z.reshape(-1, L))
+        h = linear_fwd(z2, w0, b0, RELU)
+        out = linear_fwd(h, w1, b1, SIGMOID)
+        ctx.save_for_backward(z2, h, out, w0, w1)
+        ctx.z_shape = z.shape
+        return out.view(*z.shape[:-1], *input_dim)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        z2, h, out, w0, w1 = ctx.saved_tensors
+        dout = _c(dout).view(out.shape)
+        dw1, db1 = linear_bwd_weight(dout, h, y_out=out, y_act=SIGMOID)
+        dh = linear_bwd_data(dout, w1, y_out=out, y_act=SIGMOID, prev_out=h, prev_act=RELU)
+        dw0, db0 = linear_bwd_weight(dh, z2)
+        dz = None
+        if ctx.needs_input_grad[0]:
+            dz = linear_bwd_data(dh, w0).view(ctx.z_shape)
+        return dz, dw0, db0, dw1, db1, None
+
+
+# =====================================================================================================
+# Encoder_VAE_SVHN / Decoder_VAE_SVHN  (models/nn/svhn.py:7-70), NHWC activations inside
+# =====================================================================================================
+class SVHNEncoderFn(Function):
+    """x[B,C,32,32] NCHW -> 3x(Conv 4/2/1 + ReLU) -> two Conv(4,2,0) heads -> (mu, lv) [B,L]."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, w2, b2, wc1, bc1, wc2, bc2):
+        x = _c(x)
+        B, C0, H, W = x.shape
+        chans = [C0, w0.shape[0], w1.shape[0], w2.shape[0]]
+        L = wc1.shape[0]
+        wd0, _ = pack_conv(w0, True, False)
+        wd1, wu1 = pack_conv(w1)
+        wd2, wu2 = pack_conv(w2)
+        wdc1, _ = pack_conv(wc1, True, False)
+        wdc2, _ = pack_conv(wc2, True, False)
+        h1 = conv_down(x, wd0, b0, B, H // 2, W // 2, chans[0], chans[1], RELU, u_nchw=True)
+        h2 = conv_down(h1, wd1, b1, B, H // 4, W // 4, chans[1], chans[2], RELU)
+        h3 = conv_down(h2, wd2, b2, B, H // 8, W // 8, chans[2], chans[3], RELU)
+        if (H // 8, W // 8) != (4, 4):
+            raise _lib.MvkError("Encoder_VAE_SVHN expects 32x32 inputs (4x4 feature map before the heads)")
+        Kf = 16 * chans[3]
+        h3f = h3.view(B, Kf)
+        mu = gemm(h3f, wdc1, B, L, Kf, bias=bc1, bias_mod=L)
+        lv = gemm(h3f, wdc2, B, L, Kf, bias=bc2, bias_mod=L)
+        ctx.save_for_backward(x, h1, h2, h3, wu1, wu2, wdc1, wdc2)
+        ctx.dims = (B, H, W, chans, L)
+        return mu, lv
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dmu, dlv):
+        x, h1, h2, h3, wu1, wu2, wdc1, wdc2 = ctx.saved_tensors
+        B, H, W, ch, L = ctx.dims
+        dmu, dlv = _c(dmu).view(B, L), _c(dlv).view(B, L)
+        Kf = 16 * ch[3]
+        h3f = h3.view(B, Kf)
+        # heads
+        dwc1 = _zeros((L, ch[3], 4, 4), x)
+        dwc2 = _zeros((L, ch[3], 4, 4), x)
+        call("mvk_flatten_wgrad", ptr(h3f), ptr(dmu), ptr(dwc1), B, ch[3], L, stream_ptr())
+        call("mvk_flatten_wgrad", ptr(h3f), ptr(dlv), ptr(dwc2), B, ch[3], L, stream_ptr())
+        dbc1, dbc2 = colsum(dmu), colsum(dlv)
+        # d h3 (pre-activation): dmu Wd1^T + dlv Wd2^T, ReLU'(h3) fused
+        dh3 = gemm(dmu, wdc1, B, Kf, L, tb=True, c_act_src=h3f, c_act=RELU)
+        gemm(dlv, wdc2, B, Kf, L, tb=True, c_act_src=h3f, c_act=RELU, out=dh3, accumulate=True)
+        dh3 = dh3.view(B, H // 8, W // 8, ch[3])
+        dw2 = conv_wgrad(h2, dh3, B, H // 8, W // 8, ch[2], ch[3])
+        db2 = colsum(dh3.view(-1, ch[3]))
+        dh2 = conv_up(dh3, wu2, None, B, H // 8, W // 8, ch[2], ch[3], u_act_src=h2, u_act=RELU)
+        dw1 = conv_wgrad(h1, dh2, B, H // 4, W // 4, ch[1], ch[2])
+        db1 = colsum(dh2.view(-1, ch[2]))
+        dh1 = conv_up(dh2, wu1, None, B, H // 4, W // 4, ch[1], ch[2], u_act_src=h1, u_act=RELU)
+        dw0 = conv_wgrad(x, dh1, B, H // 2, W // 2, ch[0], ch[1], u_nchw=True)
+        db0 = colsum(dh1.view(-1, ch[1]))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            raise _lib.MvkError("gradient w.r.t. the encoder input image is not implemented")
+        return dx, dw0, db0, dw1, db1, dw2, db2, dwc1, dbc1, dwc2, dbc2
+
+
+class SVHNDecoderFn(Function):
+    """z[...,L] -> ConvT(4,1,0)+ReLU -> 2x ConvT(4,2,1)+ReLU -> ConvT(4,2,1)+Sigmoid -> [...,C,32,32] NCHW."""
+
+    @staticmethod
+    def forward(ctx, z, w0, b0, w1, b1, w2, b2, w3, b3):
+        L = w0.shape[0]
+        z2 = _c(z.reshape(-1, L))
+        n = z2.shape[0]
+        C1, C2, C3, C4 = w0.shape[1], w1.shape[1], w2.shape[1], w3.shape[1]
+        wp0 = _new((L, 16 * C1), z2)
+        call("mvk_pack_unflatten_weight", ptr(w0), L, C1, ptr(wp0), stream_ptr())
+        wd1, wu1 = pack_conv(w1)  # [Cv=C1][Cu=C2]
+        wd2, wu2 = pack_conv(w2)  # [Cv=C2][Cu=C3]
+        wd3, _ = pack_conv(w3, True, False)  # [Cv=C3][Cu=C4]
+        g1 = gemm(z2, wp0, n, 16 * C1, L, bias=b0, bias_mod=C1, act=RELU)  # [n,4,4,C1]
+        g2 = conv_up(g1, wu1, b1, n, 4, 4, C2, C1, RELU)  # [n,8,8,C2]
+        g3 = conv_up(g2, wu2, b2, n, 8, 8, C3, C2, RELU)  # [n,16,16,C3]
+        out = _new((n, C4, 32, 32), z2)
+        call("mvk_conv4s2_up_nchw_small", ptr(g3), ptr(w3), ptr(b3), ptr(out), n, 16, 16, C4, C3, SIGMOID,
+             stream_ptr())
+        ctx.save_for_backward(z2, g1, g2, g3, out, wp0, wd1, wd2, wd3)
+        ctx.dims = (n, L, C1, C2, C3, C4)
+        ctx.z_shape = z.shape
+        return out.view(*z.shape[:-1], C4, 32, 32)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        z2, g1, g2, g3, out, wp0, wd1, wd2, wd3 = ctx.saved_tensors
+        n, L, C1, C2, C3, C4 = ctx.dims
+        dout = _c(dout).view(out.shape)
+        # last layer: dpre = dout * out(1-out) applied while loading (u_act_src)
+        dw3 = conv_wgrad(dout, g3, n, 16, 16, C4, C3, u_nchw=True, u_act_src=out, u_act=SIGMOID)
+        db3 = _zeros((C4,), z2)
+        call("mvk_nchw_channel_sum_acc", ptr(dout), ptr(out), SIGMOID, ptr(db3), n, C4, 32 * 32, stream_ptr())
+        dg3 = conv_down(dout, wd3, None, n, 16, 16, C4, C3, NONE, u_nchw=True, u_act_src=out, u_act=SIGMOID,
+                        v_act_src=g3, v_act=RELU)
+        dw2 = conv_wgrad(dg3, g2, n, 8, 8, C3, C2)
+        db2 = colsum(dg3.view(-1, C3))
+        dg2 = conv_down(dg3, wd2, None, n, 8, 8, C3, C2, NONE, v_act_src=g2, v_act=RELU)
+        dw1 = conv_wgrad(dg2, g1, n, 4, 4, C2, C1)
+        db1 = colsum(dg2.view(-1, C2))
+        dg1 = conv_down(dg2, wd1, None, n, 4, 4, C2, C1, NONE, v_act_src=g1, v_act=RELU)
+        dg1f = dg1.view(n, 16 * C1)
+        dw0 = _zeros((L, C1, 4, 4), z2)
+        call("mvk_unflatten_wgrad", ptr(z2), ptr(dg1f), ptr(dw0), n, L, C1, stream_ptr())
+        db0 = colsum(dg1.view(-1, C1))
+        dz = None
+        if ctx.needs_input_grad[0]:
+            dz = gemm(dg1f, wp0, n, L, 16 * C1, tb=True).view(ctx.z_shape)
+        return dz, dw0, db0, dw1, db1, dw2, db2, dw3, db3
+
+
+# =====================================================================================================
+# Fused posterior kernels
+# =====================================================================================================
+class MoPoEPosteriorFn(Function):
+    """(mu_m, lv_m)_m -> z[K,B,L], kld_rows[B] (+ subset statistics); see mvk_mopoe_posterior_fwd.
+
+    Inputs are given in PoE summation order (sorted modality names); subset_masks refer to that order.
+    """
+
+    @staticmethod
+    def forward(ctx, eps, subset_masks, sel, weights, want_stats, *mus_lvs):
+        M = len(mus_lvs) // 2
+        mus = [_c(t) for t in mus_lvs[:M]]
+        lvs = [_c(t) for t in mus_lvs[M:]]
+        K, B, L = eps.shape
+        S = subset_masks.numel()
+        z = _new((K, B, L), eps)
+        kld_rows = _new((B,), eps)
+        mus_out = _new((S, B, L), eps) if want_stats else None
+        lvs_out = _new((S, B, L), eps) if want_stats else None
+        jmu = _new((B, L), eps) if want_stats else None
+        jlv = _new((B, L), eps) if want_stats else None
+        call("mvk_mopoe_posterior_fwd", ptr_array(mus), ptr_array(lvs), M, ptr(subset_masks), S, ptr(sel),
+             ptr(weights), ptr(eps), K, B, L, ptr(z), ptr(kld_rows), ptr(mus_out), ptr(lvs_out), ptr(jmu), ptr(jlv),
+             stream_ptr())
+        ctx.save_for_backward(eps, subset_masks, sel, *mus, *lvs)
+        ctx.weights = weights
+        ctx.M = M
+        if want_stats:
+            ctx.mark_non_differentiable(mus_out, lvs_out, jmu, jlv)
+            return z, kld_rows, mus_out, lvs_out, jmu, jlv
+        return z, kld_rows
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz, dkld_rows, *unused):
+        saved = ctx.saved_tensors
+        eps, subset_masks, sel = saved[:3]
+        M = ctx.M
+        mus, lvs = saved[3 : 3 + M], saved[3 + M :]
+        K, B, L = eps.shape
+        dz = _c(dz) if dz is not None else torch.zeros_like(eps)
+        gk = _c(dkld_rows) if dkld_rows is not None else None
+        dmus = [_new((B, L), eps) for _ in range(M)]
+        dlvs = [_new((B, L), eps) for _ in range(M)]
+        call("mvk_mopoe_posterior_bwd", ptr_array(mus), ptr_array(lvs), M, ptr(subset_masks), subset_masks.numel(),
+             ptr(sel), ptr(ctx.weights), ptr(eps), ptr(dz), K, B, L, ptr(gk), ptr_array(dmus), ptr_array(dlvs),
+             stream_ptr())
+        return (None, None, None, None, None, *dmus, *dlvs)
+
+
+class MVTCAEPosteriorFn(Function):
+    """(mu_m, lv_m)_m -> z[K,B,L], joint_kl_rows[B], cond_kl_rows[M,B], joint_mu, joint_lv."""
+
+    @staticmethod
+    def forward(ctx, eps, masks, *mus_lvs):
+        M = len(mus_lvs) // 2
+        mus = [_c(t) for t in mus_lvs[:M]]
+        lvs = [_c(t) for t in mus_lvs[M:]]
+        K, B, L = eps.shape
+        z = _new((K, B, L), eps)
+        jkl = _new((B,), eps)
+        ckl = _new((M, B), eps)
+        jmu, jlv = _new((B, L), eps), _new((B, L), eps)
+        marr = ptr_array(masks) if masks is not None else None
+        call("mvk_mvtcae_posterior_fwd", ptr_array(mus), ptr_array(lvs), marr, M, ptr(eps), K, B, L, ptr(z),
+             ptr(jkl), ptr(ckl), ptr(jmu), ptr(jlv), stream_ptr())
+        ctx.save_for_backward(eps, *mus, *lvs)
+        ctx.masks = masks
+        ctx.M = M
+        ctx.mark_non_differentiable(jmu, jlv)
+        return z, jkl, ckl, jmu, jlv
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz, djkl, dckl, *unused):
+        saved = ctx.saved_tensors
+        eps = saved[0]
+        M = ctx.M
+        mus, lvs = saved[1 : 1 + M], saved[1 + M :]
+        K, B, L = eps.shape
+        dz = _c(dz) if dz is not None else torch.zeros_like(eps)
+        gj = _c(djkl) if djkl is not None else None
+        gc = _c(dckl) if dckl is not None else None
+        dmus = [_new((B, L), eps) for _ in range(M)]
+        dlvs = [_new((B, L), eps) for _ in range(M)]
+        marr = ptr_array(ctx.masks) if ctx.masks is not None else None
+        call("mvk_mvtcae_posterior_bwd", ptr_array(mus), ptr_array(lvs), marr, M, ptr(eps), ptr(dz), K, B, L,
+             ptr(gj), ptr(gc), ptr_array(dmus), ptr_array(dlvs), stream_ptr())
+        return (None, None, *dmus, *dlvs)
+
+
+# =====================================================================================================
+# Fused reconstruction NLL + scalar assembly (single autograd node producing the loss)
+# =====================================================================================================
+class ReconLossFn(Function):
+    """loss = sum_m lossw_m * coef_m * sum_{k,b} mask_m[b] rows_m[k,b] + sum_j lossw_j * coef_j * sum(extra_j).
+
+    forward: ONE mvk_recon_nll_fwd launch for all modalities (row NLLs + d loss / d recon assuming an upstream
+             gradient of 1) and ONE mvk_reduce_terms launch.  Returns (loss, terms[n_terms+2]) where terms holds
+             every individual term, the loss and loss * loss_sum_scale (all detached: metrics).
+    spec:    dict(K, B, x[], masks[], dist[], scale[], rescale[], coef[], lossw[], extra_coef[], extra_lossw[],
+             extra_split[], loss_sum_scale).
+    extras:  tensors (KL rows) whose sums enter the loss with a constant weight.
+    """
+
+    @staticmethod
+    def forward(ctx, spec, n_mod, *tensors):
+        recons = [_c(t) for t in tensors[:n_mod]]
+        extras = [_c(t) for t in tensors[n_mod:]]
+        xs, masks = spec["x"], spec["masks"]
+        K, B = spec["K"], spec["B"]
+        ref = recons[0] if recons else extras[0]
+        descs = (ReconDesc * max(n_mod, 1))()
+        rows, drecons = [], []
+        for i in range(n_mod):
+            D = recons[i].numel() // (K * B)
+            r = _new((K, B), ref)
+            g = torch.empty_like(recons[i]) if ctx.needs_input_grad[2 + i] else None
+            rows.append(r)
+            drecons.append(g)
+            d = descs[i]
+            d.recon, d.x = recons[i].data_ptr(), xs[i].data_ptr()
+            d.mask = masks[i].data_ptr() if masks[i] is not None else None
+            d.rows = r.data_ptr()
+            d.drecon = g.data_ptr() if g is not None else None
+            d.rowcoef = None
+            d.D, d.dist = D, spec["dist"][i]
+            d.scale, d.rescale = spec["scale"][i], spec["rescale"][i]
+            d.coef = spec["coef"][i] * spec["lossw"][i]
+        if n_mod:
+            call("mvk_recon_nll_fwd", descs, n_mod, K, B, stream_ptr())
+        splits = spec.get("extra_split") or [1] * len(extras)
+        n_terms = n_mod + sum(splits)
+        terms = (TermDesc * n_terms)()
+        for i in range(n_mod):
+            t = terms[i]
+            t.v, t.n = rows[i].data_ptr(), K * B
+            t.mask = masks[i].data_ptr() if masks[i] is not None else None
+            t.period, t.coef, t.lossw = B, spec["coef"][i], spec["lossw"][i]
+        ti = n_mod
+        for j, e in enumerate(extras):
+            ns = splits[j]
+            chunk = e.numel() // ns
+            for c in range(ns):  # one term per chunk (e.g. per-modality KL rows), one gradient per tensor
+                t = terms[ti]
+                t.v, t.n, t.mask, t.period = e.data_ptr() + 4 * c * chunk, chunk, None, 1
+                t.coef, t.lossw = spec["extra_coef"][j], spec["extra_lossw"][j]
+                ti += 1
+        out = _new((n_terms + 2,), ref)
+        loss = _new((), ref)
+        call("mvk_reduce_terms", terms, n_terms, spec["loss_sum_scale"], ptr(out), ptr(loss), stream_ptr())
+        ctx.drecons = drecons
+        ctx.extra_shapes = [e.shape for e in extras]
+        ctx.extra_grad = [spec["extra_coef"][j] * spec["extra_lossw"][j] for j in range(len(extras))]
+        ctx.rows = rows  # keep alive: metrics / debugging
+        ctx.mark_non_differentiable(out)
+        return loss, out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gloss, gout):
+        gloss = _c(gloss.reshape(1))
+        grads = []
+        for g in ctx.drecons:
+            if g is not None:
+                call("mvk_scale_by_device_scalar", ptr(g), g.numel(), ptr(gloss), stream_ptr())
+            grads.append(g)
+        for shape, c in zip(ctx.extra_shapes, ctx.extra_grad):
+            grads.append((gloss * c).expand(shape).contiguous())
+        ctx.drecons = None
+        return (None, None, *grads)
+
+
+def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    call("mvk_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+         grad_scale, stream_ptr())
+
+
+# =====================================================================================================
+# MMVAE: mixture-of-experts importance weights (IWAE / DReG)
+# =====================================================================================================
+class MMVAEStdFn(Function):
+    """std = exp(lv/2) | softmax(lv)*L + 1e-6   (mmvae_model.py:66-74)."""
+
+    @staticmethod
+    def forward(ctx, lv, family):
+        lv2 = _c(lv.reshape(-1, lv.shape[-1]))
+        sd = torch.empty_like(lv2)
+        call("mvk_mmvae_std_fwd", ptr(lv2), lv2.shape[0], lv2.shape[1], family, ptr(sd), stream_ptr())
+        ctx.save_for_backward(lv2, sd)
+        ctx.family = family
+        ctx.shape = lv.shape
+        return sd.view(lv.shape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dsd):
+        lv2, sd = ctx.saved_tensors
+        dsd = _c(dsd).view(lv2.shape)
+        dlv = torch.empty_like(lv2)
+        call("mvk_mmvae_std_bwd", ptr(lv2), ptr(sd), ptr(dsd), lv2.shape[0], lv2.shape[1], ctx.family, ptr(dlv),
+             stream_ptr())
+        return dlv.view(ctx.shape), None
+
+
+class MMVAEState:
+    """Tensors shared between the latent node and the objective node of one forward pass."""
+
+    def __init__(self):
+        self.z = self.lpz = self.lqz = self.lq_all = None
+        self.w = self.rowcoef = self.lw = None
+        self.gloss = None
+
+
+class MMVAELatentFn(Function):
+    """(mu_c, std_c)_c, prior_std -> z_c [K,B,L] for every conditioning modality; also fills state.lpz / lqz."""
+
+    @staticmethod
+    def forward(ctx, state, noises, masks, prior_mean, family, dreg, prior_std, *mus_stds):
+        M = len(mus_stds) // 2
+        mus = [_c(t) for t in mus_stds[:M]]
+        sds = [_c(t) for t in mus_stds[M:]]
+        prior_std = _c(prior_std.reshape(-1))
+        prior_mean = _c(prior_mean.reshape(-1))
+        K, B, L = noises[0].shape
+        zs = [_new((K, B, L), mus[0]) for _ in range(M)]
+        state.lpz = [_new((K, B), mus[0]) for _ in range(M)]
+        state.lqz = [_new((K, B), mus[0]) for _ in range(M)]
+        state.lq_all = [_new((M, K, B), mus[0]) for _ in range(M)]
+        marr = ptr_array(masks) if masks is not None else None
+        call("mvk_mmvae_latent_fwd", ptr_array(mus), ptr_array(sds), ptr_array(noises), marr, ptr(prior_mean),
+             ptr(prior_std), M, K, B, L, family, ptr_array(zs), ptr_array(state.lpz), ptr_array(state.lqz),
+             ptr_array(state.lq_all), stream_ptr())
+        state.z = zs
+        ctx.save_for_backward(prior_mean, prior_std, *mus, *sds)
+        ctx.state, ctx.noises, ctx.masks = state, noises, masks
+        ctx.family, ctx.dreg, ctx.M = family, dreg, M
+        return tuple(zs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *dzs):
+        saved = ctx.saved_tensors
+        prior_mean, prior_std = saved[0], saved[1]
+        M = ctx.M
+        mus, sds = saved[2 : 2 + M], saved[2 + M :]
+        st = ctx.state
+        K, B, L = ctx.noises[0].shape
+        dzs = [(_c(d) if d is not None else torch.zeros_like(st.z[i])) for i, d in enumerate(dzs)]
+        dmus = [_new((B, L), mus[0]) for _ in range(M)]
+        dsds = [_new((B, L), mus[0]) for _ in range(M)]
+        dprior = _new((L,), mus[0])
+        marr = ptr_array(ctx.masks) if ctx.masks is not None else None
+        call("mvk_mmvae_latent_bwd", ptr_array(mus), ptr_array(sds), ptr_array(ctx.noises), ptr_array(st.z), marr,
+             ptr(prior_mean), ptr(prior_std), ptr_array(st.w), ptr_array(st.lq_all), ptr_array(st.lqz),
+             ptr_array(dzs), M, K, B, L, ctx.family, ctx.dreg, ptr(st.gloss), ptr_array(dmus), ptr_array(dsds),
+             ptr(dprior), stream_ptr())
+        return (None, None, None, None, None, None, dprior.view(1, L), *dmus, *dsds)
+
+
+class MMVAEObjectiveFn(Function):
+    """recon[c][r] (M*M tensors, c-major) -> loss.  forward: row NLLs + IWAE/DReG objective; backward: the
+    second reconstruction pass with the per-row weights d loss / d lw."""
+
+    @staticmethod
+    def forward(ctx, state, spec, M, dreg, *recons):
+        recons = [_c(t) for t in recons]
+        K, B = spec["K"], spec["B"]
+        ref = recons[0]
+        descs = (ReconDesc * M)()
+        rows = []
+        for c in range(M):
+            for r in range(M):
+                d = descs[r]
+                rr = _new((K, B), ref)
+                rows.append(rr)
+                t = recons[c * M + r]
+                d.recon, d.x = t.data_ptr(), spec["x"][r].data_ptr()
+                d.mask, d.rows, d.drecon, d.rowcoef = None, rr.data_ptr(), None, None
+                d.D, d.dist = t.numel() // (K * B), spec["dist"][r]
+                d.scale, d.rescale, d.coef = spec["scale"][r], spec["rescale"][r], 1.0
+            call("mvk_recon_nll_fwd", descs, M, K, B, stream_ptr())
+        state.lw = [_new((K, B), ref) for _ in range(M)]
+        state.w = [_new((K, B), ref) for _ in range(M)]
+        state.rowcoef = [_new((K, B), ref) for _ in range(M)]
+        loss = _new((), ref)
+        masks = spec["masks"]
+        marr = ptr_array(masks) if masks[0] is not None else None
+        call("mvk_mmvae_objective_fwd", ptr_array(rows), ptr_array(state.lpz), ptr_array(state.lqz), marr, M, K, B,
+             int(dreg), ptr_array(state.lw), ptr_array(state.w), ptr_array(state.rowcoef), ptr(loss), stream_ptr())
+        ctx.save_for_backward(*recons)
+        ctx.state, ctx.spec, ctx.M = state, spec, M
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gloss):
+        recons = ctx.saved_tensors
+        st, spec, M = ctx.state, ctx.spec, ctx.M
+        K, B = spec["K"], spec["B"]
+        st.gloss = _c(gloss.reshape(1))
+        grads = []
+        descs = (ReconDesc * M)()
+        for c in range(M):
+            gs = []
+            for r in range(M):
+                d = descs[r]
+                t = recons[c * M + r]
+                g = torch.empty_like(t)
+                gs.append(g)
+                mk = spec["masks"][r]
+                d.recon, d.x = t.data_ptr(), spec["x"][r].data_ptr()
+                d.mask = mk.data_ptr() if mk is not None else None
+                d.rows, d.drecon, d.rowcoef = None, g.data_ptr(), st.rowcoef[c].data_ptr()
+                d.D, d.dist = t.numel() // (K * B), spec["dist"][r]
+                # lw contains +log p = -NLL, so d loss / d recon = rowcoef * (-1) * rescale * dNLL/drecon
+                d.scale, d.rescale, d.coef = spec["scale"][r], spec["rescale"][r], -1.0
+            call("mvk_recon_nll_bwd", descs, M, K, B, stream_ptr())
+            for g in gs:
+                call("mvk_scale_by_device_scalar", ptr(g), g.numel(), ptr(st.gloss), stream_ptr())
+            grads += gs
+        return (None, None, None, None, *grads)

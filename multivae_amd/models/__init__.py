@@ -1,0 +1,7 @@
+from .base import BaseAEConfig, BaseMultiVAE, BaseMultiVAEConfig, ModelOutput
+from .mmvae import MMVAE, MMVAEConfig
+from .mopoe import MoPoE, MoPoEConfig
+from .mvtcae import MVTCAE, MVTCAEConfig
+
+__all__ = ["BaseAEConfig", "BaseMultiVAE", "BaseMultiVAEConfig", "ModelOutput", "MMVAE", "MMVAEConfig", "MoPoE",
+           "MoPoEConfig", "MVTCAE", "MVTCAEConfig"]

@@ -1,0 +1,80 @@
+"""MMVAE (Shi 2019) on the HIP kernels.  Mirrors `multivae/models/mmvae/mmvae_model.py:44-292` (Appendix A.2):
+per-modality Normal / Laplace(softmax-scale) posteriors, K samples each, M x M cross reconstructions,
+mixture-of-experts log-density, IWAE or DReG objective (sum over the batch, loss_sum == loss).
+
+Kernel sequence: M encoder nodes + M std kernels -> ONE latent kernel (samples, log p(z), log q_MoE(z)) ->
+M x M decoder passes -> M reconstruction-NLL launches (rows) -> ONE objective kernel; backward: M
+reconstruction launches with the per-row weights -> decoders -> ONE latent backward kernel -> encoders.
+"""
+import torch
+
+from ... import _lib, kernels
+from ...data.utils import drop_unused_modalities
+from ..base import BaseMultiVAE
+from ..base.base_utils import ModelOutput
+from .mmvae_config import MMVAEConfig
+
+
+class MMVAE(BaseMultiVAE):
+    def __init__(self, model_config: MMVAEConfig, encoders: dict = None, decoders: dict = None):
+        super().__init__(model_config, encoders, decoders)
+        if model_config.prior_and_posterior_dist not in ("laplace_with_softmax", "normal"):
+            raise AttributeError(" The posterior_dist parameter must be either 'laplace_with_softmax' or 'normal'. "
+                                 f" {model_config.prior_and_posterior_dist} was provided.")
+        self.prior_mean = torch.nn.Parameter(torch.zeros(1, self.latent_dim), requires_grad=False)
+        self.prior_log_var = torch.nn.Parameter(torch.zeros(1, self.latent_dim),
+                                                requires_grad=model_config.learn_prior)
+        self.model_name = "MMVAE"
+
+    @property
+    def _family(self):
+        return _lib.FAMILY[self.model_config.prior_and_posterior_dist]
+
+    def log_var_to_std(self, log_var):
+        return kernels.MMVAEStdFn.apply(log_var, self._family)
+
+    @property
+    def pz_params(self):
+        return self.prior_mean, self.log_var_to_std(self.prior_log_var)
+
+    def forward(self, inputs, **kwargs):
+        inputs = drop_unused_modalities(inputs)
+        K = int(kwargs.pop("K", self.model_config.K))
+        noise = kwargs.pop("noise", None)  # {modality: [K,B,L]} explicit noise (Appendix B)
+        mods = list(inputs.data.keys())
+        M = len(mods)
+        dreg = self.model_config.loss == "dreg_looser"
+        if self.model_config.loss not in ("dreg_looser", "iwae_looser"):
+            raise NotImplementedError()
+        family = self._family
+        mus, sds = [], []
+        for m in mods:
+            out = self.encoders[m](inputs.data[m])
+            mu, lv = out.embedding, out.log_covariance
+            if mu.dim() == 1:
+                mu, lv = mu.unsqueeze(0), lv.unsqueeze(0)
+            mus.append(mu)
+            sds.append(self.log_var_to_std(lv))
+        B, L = mus[0].shape
+        device = mus[0].device
+        noises = [self._noise((K, B, L), device, None if noise is None else noise[m], uniform=family == 1)
+                  for m in mods]
+        masks = None
+        if hasattr(inputs, "masks"):
+            masks = [inputs.masks[m].to(torch.bool).contiguous() for m in mods]
+        state = kernels.MMVAEState()
+        prior_std = self.log_var_to_std(self.prior_log_var)
+        zs = kernels.MMVAELatentFn.apply(state, noises, masks, self.prior_mean.detach(), family, int(dreg), prior_std,
+                                         *mus, *sds)
+        recons = []
+        for c in range(M):
+            flat = zs[c].reshape(-1, L)  # (K*B, L) like the reference (:127)
+            for r in mods:
+                recons.append(self.decoders[r](flat).reconstruction)
+        spec = self._recon_spec(mods, inputs.data, inputs.masks if masks is not None else None, K, B)
+        loss = kernels.MMVAEObjectiveFn.apply(state, spec, M, dreg, *recons)
+        out = ModelOutput(loss=loss, loss_sum=loss, metrics={})
+        if kwargs.pop("detailed_output", False):
+            out["zss"] = {m: zs[i] for i, m in enumerate(mods)}
+            out["lws"] = {m: state.lw[i] for i, m in enumerate(mods)}
+        return out

@@ -1,0 +1,166 @@
+"""MoPoE (Sutter 2021) on the HIP kernels.  Mirrors `multivae/models/mopoe/mopoe_model.py`:
+subset enumeration :71-106, forward :147-227, inference :274-350, selection :417-465, divergence :108-145.
+
+forward = M encoder nodes -> ONE fused posterior kernel (per-subset PoE, prior expert on the full subset,
+subset selection, reparameterisation over K samples, all-subset KL) -> M decoder nodes -> ONE fused
+reconstruction-NLL kernel (+ d loss / d recon in the same pass) -> ONE scalar assembly kernel.
+"""
+import math
+from itertools import chain, combinations
+from typing import Union
+
+import torch
+
+from ... import kernels
+from ..base import BaseMultiVAE
+from ..base.base_utils import ModelOutput
+from .mopoe_config import MoPoEConfig
+
+
+class MoPoE(BaseMultiVAE):
+    def __init__(self, model_config: MoPoEConfig, encoders: dict = None, decoders: dict = None):
+        super().__init__(model_config, encoders, decoders)
+        self.multiple_latent_spaces = model_config.modalities_specific_dim is not None
+        if self.multiple_latent_spaces:
+            raise NotImplementedError("modalities_specific_dim (private latent spaces) is not on the HIP path yet")
+        self.model_name = "MoPoE"
+        list_subsets = self.model_config.subsets
+        if isinstance(list_subsets, dict):
+            list_subsets = list(list_subsets.values())
+        if list_subsets is None:
+            list_subsets = self.all_subsets()
+        self.set_subsets(list_subsets)
+        self._sel_cache = {}
+
+    # -- subsets ---------------------------------------------------------------------------------------
+    def all_subsets(self):
+        xs = list(self.encoders.keys())
+        return chain.from_iterable(combinations(xs, n) for n in range(len(xs) + 1))
+
+    def set_subsets(self, subsets_list):
+        subsets = dict()
+        for mod_names in subsets_list:
+            mods = []
+            for mod_name in sorted(mod_names):
+                if (mod_name not in self.encoders.keys()) and (mod_name != ""):
+                    raise AttributeError(f"The provided subsets list contains unknown modality name {mod_name}."
+                                         " that is not the encoders dictionary or inputs_dim dictionary.")
+                mods.append(mod_name)
+            subsets["_".join(sorted(mod_names))] = mods
+        self.subsets = subsets
+        self.model_config.subsets = subsets
+        # kernel-side description: modalities in PoE summation order (sorted names), one bit mask per
+        # non-empty subset in enumeration order
+        self._poe_order = sorted(self.encoders.keys())
+        pos = {m: i for i, m in enumerate(self._poe_order)}
+        self._subset_keys = [k for k in subsets if k != ""]
+        self._subset_bits = [sum(1 << pos[m] for m in subsets[k]) for k in self._subset_keys]
+        self._subset_masks_dev = {}
+
+    def _subset_masks(self, device):
+        t = self._subset_masks_dev.get(device)
+        if t is None:
+            t = torch.tensor(self._subset_bits, dtype=torch.int32, device=device)
+            self._subset_masks_dev[device] = t
+        return t
+
+    def _row_range_selection(self, B, device):
+        """deterministic_mixture_component_selection (:435-465): rows [k*n,(k+1)*n) take subset k,
+        n = floor(B * float32(1/S)); the last subset takes the remainder."""
+        key = (B, device)
+        sel = self._sel_cache.get(key)
+        if sel is None:
+            S = len(self._subset_keys)
+            n = int(torch.floor(B * torch.tensor(1.0 / float(S), dtype=torch.float32)))
+            idx = torch.arange(B)
+            sel = torch.clamp(idx // max(n, 1), max=S - 1) if n > 0 else torch.full((B,), S - 1)
+            sel = sel.to(torch.int32).to(device)
+            self._sel_cache[key] = sel
+        return sel
+
+    def subset_mask(self, inputs, subset):
+        filt = None
+        for mod in subset:
+            filt = inputs.masks[mod].bool() if filt is None else torch.logical_and(filt, inputs.masks[mod])
+        return filt
+
+    # -- forward -----------------------------------------------------------------------------------------
+    def modality_encode(self, inputs, **kwargs):
+        return {m: self.encoders[m](inputs.data[m]) for m in self.encoders.keys()}
+
+    def _posterior(self, inputs, K, noise=None, choice=None, want_stats=False):
+        enc = self.modality_encode(inputs)
+        first = enc[self._poe_order[0]].embedding
+        mus = [enc[m].embedding for m in self._poe_order]
+        lvs = [enc[m].log_covariance for m in self._poe_order]
+        if first.dim() == 1:  # single-sample batch: the SVHN encoder squeezed the batch dim (Appendix D)
+            mus = [t.unsqueeze(0) for t in mus]
+            lvs = [t.unsqueeze(0) for t in lvs]
+        B, L = mus[0].shape
+        device = mus[0].device
+        masked = hasattr(inputs, "masks")
+        weights = None
+        if masked:
+            avail = torch.stack([self.subset_mask(inputs, self.subsets[k]) for k in self._subset_keys]).float()
+            weights = (avail / avail.sum(0)).contiguous()  # [S,B]
+            if choice is None:  # random_mixture_component_selection (:417-433), drawn BEFORE eps
+                choice_idx = torch.multinomial(weights.t(), 1).squeeze(1)
+            else:
+                choice_idx = choice.to(device).float().argmax(dim=1)
+            sel = choice_idx.to(torch.int32).contiguous()
+        else:
+            sel = self._row_range_selection(B, device)
+        eps = self._noise((K, B, L), device, noise)
+        outs = kernels.MoPoEPosteriorFn.apply(eps, self._subset_masks(device), sel, weights, want_stats, *mus, *lvs)
+        return enc, outs, (B, L, device, weights)
+
+    def forward(self, inputs, **kwargs) -> ModelOutput:
+        K = int(kwargs.pop("K", self.model_config.K))
+        noise = kwargs.pop("noise", None)
+        if noise is not None and noise.dim() == 2:
+            noise = noise.unsqueeze(0)
+        _, outs, (B, L, device, _) = self._posterior(inputs, K, noise=noise, choice=kwargs.pop("choice", None))
+        z, kld_rows = outs[0], outs[1]
+        names = list(self.encoders.keys())
+        z_in = z[0] if K == 1 else z  # K == 1: decoders see [B,L] exactly like the reference
+        recons = [self.decoders[m](z_in).reconstruction for m in names]
+        masks = inputs.masks if hasattr(inputs, "masks") else None
+        spec = self._recon_spec(names, inputs.data, masks, K, B)
+        M = len(names)
+        spec.update(coef=[1.0 / (K * B)] * M, lossw=[1.0] * M, extra_coef=[1.0 / B],
+                    extra_lossw=[float(self.model_config.beta)], loss_sum_scale=float(B))
+        loss, terms = kernels.ReconLossFn.apply(spec, M, *recons, kld_rows)
+        metrics = {"joint_divergence": terms[M]}
+        for i, m in enumerate(names):
+            metrics["recon_" + m] = terms[i]
+        return ModelOutput(loss=loss, loss_sum=terms[M + 2], metrics=metrics)
+
+    def inference(self, inputs, **kwargs):
+        """Subset and joint posterior parameters (:274-350).  Returns the same dict layout as the reference."""
+        K = 1
+        enc, outs, (B, L, device, weights) = self._posterior(inputs, K, noise=kwargs.get("noise"),
+                                                              choice=kwargs.get("choice"), want_stats=True)
+        z, kld_rows, mus, lvs, jmu, jlv = outs
+        S = len(self._subset_keys)
+        if weights is None:
+            weights = torch.full((S, B), 1.0 / float(S), device=device)
+        return dict(modalities=enc, mus=mus, logvars=lvs, weights=weights, joint=[jmu, jlv],
+                    subsets={k: [mus[i], lvs[i]] for i, k in enumerate(self._subset_keys)})
+
+    def encode(self, inputs, cond_mod: Union[list, str] = "all", N: int = 1, return_mean=False, **kwargs):
+        cond_mod = super().encode(inputs, cond_mod, N, **kwargs).cond_mod
+        key = "_".join(sorted(cond_mod))
+        with torch.no_grad():
+            lat = self.inference(inputs)
+            mu, log_var = lat["subsets"][key]
+            if return_mean and len(cond_mod) == self.n_modalities:
+                mu = torch.stack([lat["subsets"][k][0] for k in lat["subsets"]]).mean(0)
+            flatten = kwargs.pop("flatten", False)
+            if return_mean:
+                z = torch.stack([mu] * N) if N > 1 else mu
+            else:
+                shape = (N, *mu.shape) if N > 1 else mu.shape
+                z = mu + torch.exp(0.5 * log_var) * torch.randn(shape, device=mu.device)
+            if N > 1 and flatten:
+                z = z.reshape(-1, *z.shape[2:])
+        return ModelOutput(z=z, one_latent_space=True)

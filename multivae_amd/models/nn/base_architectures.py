@@ -1,0 +1,20 @@
+"""Plugin bases (what the reference takes from `pythae.models.nn.base_architectures`): a user encoder /
+decoder is any `nn.Module` subclass of these whose forward returns a `ModelOutput` with `embedding`,
+`log_covariance` (encoders) or `reconstruction` (decoders).  SURVEY.md §8(b1)."""
+import torch.nn as nn
+
+
+class BaseEncoder(nn.Module):
+    def __init__(self):
+        nn.Module.__init__(self)
+
+    def forward(self, x):
+        raise NotImplementedError()
+
+
+class BaseDecoder(nn.Module):
+    def __init__(self):
+        nn.Module.__init__(self)
+
+    def forward(self, z):
+        raise NotImplementedError()

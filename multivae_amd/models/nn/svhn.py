@@ -1,0 +1,53 @@
+"""SVHN convolutional encoder / decoder with the reference's parameter names and shapes
+(`multivae/models/nn/svhn.py:7-70`), computed by the implicit-GEMM fp32-MFMA kernels on NHWC activations.
+The `nn.Conv2d` / `nn.ConvTranspose2d` objects only hold the parameters (state_dict keys `enc.0.weight`,
+`c1.weight`, `dec.0.weight`, ...)."""
+import torch
+from torch import nn
+
+from ... import kernels
+from ..base.base_utils import ModelOutput
+from .base_architectures import BaseDecoder, BaseEncoder
+
+
+class Encoder_VAE_SVHN(BaseEncoder):
+    def __init__(self, args):
+        BaseEncoder.__init__(self)
+        self.input_dim = args.input_dim
+        self.latent_dim = args.latent_dim
+        self.n_channels = args.input_dim[0]
+        self.fBase = 32
+        self.enc = nn.Sequential(
+            nn.Conv2d(self.n_channels, self.fBase, 4, 2, 1, bias=True), nn.ReLU(True),
+            nn.Conv2d(self.fBase, self.fBase * 2, 4, 2, 1, bias=True), nn.ReLU(True),
+            nn.Conv2d(self.fBase * 2, self.fBase * 4, 4, 2, 1, bias=True), nn.ReLU(True),
+        )
+        self.c1 = nn.Conv2d(self.fBase * 4, self.latent_dim, 4, 2, 0)
+        self.c2 = nn.Conv2d(self.fBase * 4, self.latent_dim, 4, 2, 0)
+
+    def forward(self, x: torch.Tensor):
+        e = self.enc
+        mu, lv = kernels.SVHNEncoderFn.apply(x, e[0].weight, e[0].bias, e[2].weight, e[2].bias, e[4].weight,
+                                             e[4].bias, self.c1.weight, self.c1.bias, self.c2.weight, self.c2.bias)
+        # the reference squeezes ALL unit dims of the [B,L,1,1] head outputs (svhn.py:35-36; Appendix D)
+        return ModelOutput(embedding=mu.squeeze(), log_covariance=lv.squeeze())
+
+
+class Decoder_VAE_SVHN(BaseDecoder):
+    def __init__(self, args):
+        BaseDecoder.__init__(self)
+        self.latent_dim = args.latent_dim
+        self.fBase = 32
+        self.nb_channels = args.input_dim[0]
+        self.dec = nn.Sequential(
+            nn.ConvTranspose2d(self.latent_dim, self.fBase * 4, 4, 1, 0, bias=True), nn.ReLU(True),
+            nn.ConvTranspose2d(self.fBase * 4, self.fBase * 2, 4, 2, 1, bias=True), nn.ReLU(True),
+            nn.ConvTranspose2d(self.fBase * 2, self.fBase, 4, 2, 1, bias=True), nn.ReLU(True),
+            nn.ConvTranspose2d(self.fBase, self.nb_channels, 4, 2, 1, bias=True), nn.Sigmoid(),
+        )
+
+    def forward(self, z: torch.Tensor):
+        d = self.dec
+        out = kernels.SVHNDecoderFn.apply(z, d[0].weight, d[0].bias, d[2].weight, d[2].bias, d[4].weight, d[4].bias,
+                                          d[6].weight, d[6].bias)
+        return ModelOutput(reconstruction=out)

@@ -17,7 +17,7 @@ def adam_update(p, g, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, wei
     """In-place Adam update of p with state (m, v) at 1-based `step` (torch.optim.Adam, amsgrad=False)."""
     if weight_decay != 0.0:
         g = g + weight_decay * p
-    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    m.lerp_(g, 1 - beta1)  # torch.optim.Adam: exp_avg.lerp_(grad, 1 - beta1)
     v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
     bc1 = 1 - beta1**step
     bc2 = 1 - beta2**step

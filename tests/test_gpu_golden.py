@@ -1,0 +1,192 @@
+"""Model-level parity on the GPU: multivae_amd.models.{MoPoE, MVTCAE, MMVAE} (HIP kernels behind the C ABI)
+against (a) the golden vectors generated from the real reference and (b) the CPU oracle evaluated on the same
+procedural inputs, weights and recorded noise.  Tolerance 1e-4 relative (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as G
+from oracle import elbo, nets
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def rel(a, b):
+    a = torch.as_tensor(np.asarray(a)).double().reshape(-1)
+    b = b.detach().double().cpu().reshape(-1)
+    return float((a - b).abs().max() / a.abs().max().clamp_min(1e-30))
+
+
+def check(a, b, what, rtol=RTOL):
+    e = rel(a, b)
+    assert e <= rtol, f"{what}: rel-to-max err {e:.3e} > {rtol}"
+
+
+def build_model(cfg, dims):
+    from multivae_amd.models import MMVAE, MVTCAE, MMVAEConfig, MoPoE, MoPoEConfig, MVTCAEConfig
+    from multivae_amd.models.base.base_config import BaseAEConfig
+    from multivae_amd.models.nn.default_architectures import Decoder_AE_MLP, Encoder_VAE_MLP
+    from multivae_amd.models.nn.svhn import Decoder_VAE_SVHN, Encoder_VAE_SVHN
+
+    L = cfg["L"]
+    common = dict(n_modalities=len(dims), latent_dim=L, input_dims=dict(dims),
+                  uses_likelihood_rescaling=cfg["rescaling"])
+    enc = dec = None
+    if cfg["arch"] != "tiny" and cfg["model"] != "MVTCAE":
+        enc = dict(mnist=Encoder_VAE_MLP(BaseAEConfig(latent_dim=L, input_dim=(1, 28, 28))),
+                   svhn=Encoder_VAE_SVHN(BaseAEConfig(latent_dim=L, input_dim=(3, 32, 32))))
+        dec = dict(mnist=Decoder_AE_MLP(BaseAEConfig(latent_dim=L, input_dim=(1, 28, 28))),
+                   svhn=Decoder_VAE_SVHN(BaseAEConfig(latent_dim=L, input_dim=(3, 32, 32))))
+    if cfg["model"] == "MoPoE":
+        mc = MoPoEConfig(beta=cfg["beta"], decoders_dist=cfg.get("dists"), K=cfg["K"], **common)
+        return MoPoE(mc, enc, dec)
+    if cfg["model"] == "MVTCAE":
+        return MVTCAE(MVTCAEConfig(alpha=cfg["alpha"], beta=cfg["beta"], **common))
+    mc = MMVAEConfig(K=cfg["K"], prior_and_posterior_dist=cfg["family"], loss=cfg["loss"],
+                     learn_prior=cfg["learn_prior"], **common)
+    return MMVAE(mc, enc, dec)
+
+
+def prep(name):
+    from multivae_amd.data.datasets.base import DatasetOutput
+
+    cfg, a = G.load_case(name)
+    dims, data, masks, sd_np = G.build_inputs(cfg)
+    model = build_model(cfg, dims)
+    missing = model.load_state_dict({k: G.t(v) for k, v in sd_np.items()}, strict=False)
+    assert not missing.unexpected_keys and all(k.startswith("prior_") for k in missing.missing_keys), missing
+    d = torch.device("cuda:0")
+    model = model.to(d).train()
+    kw = dict(data={m: G.t(v).to(d) for m, v in data.items()})
+    if masks is not None:
+        kw["masks"] = {m: G.t(v).to(d) for m, v in masks.items()}
+    return cfg, a, dims, data, masks, sd_np, model, DatasetOutput(**kw), d
+
+
+def model_grads(model):
+    return {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in model.named_parameters()}
+
+
+def oracle_full_grads(cfg, dims, data, masks, sd_np, a):
+    """The oracle's full gradient tensors (not just the sampled golden entries)."""
+    sd = {k: G.t(v).clone().requires_grad_(True) for k, v in sd_np.items()}
+    tdata = {m: G.t(v) for m, v in data.items()}
+    tmasks = None if masks is None else {m: G.t(v) for m, v in masks.items()}
+    names = cfg["names"]
+    if cfg["arch"] == "tiny" or cfg["model"] == "MVTCAE":
+        enc_f, dec_f = nets.build_default_mlp(sd, dims)
+    else:
+        enc_f, dec_f = nets.build_mnist_svhn(sd, cfg["L"])
+    resc = elbo.rescale_factors(dims, cfg["rescaling"])
+    extra = {}
+    if cfg["model"] == "MoPoE":
+        e = {m: enc_f[m](tdata[m]) for m in names}
+        o = elbo.mopoe_forward(e, tdata, dec_f, G.t(a["eps"]), names=names, beta=cfg["beta"], rescale=resc,
+                               dists=cfg["dists"], masks=tmasks, choice=G.t(a["choice"]) if "choice" in a else None)
+    elif cfg["model"] == "MVTCAE":
+        e = {m: enc_f[m](tdata[m]) for m in names}
+        o = elbo.mvtcae_forward(e, tdata, dec_f, G.t(a["eps"]), names=names, alpha=cfg["alpha"], beta=cfg["beta"],
+                                rescale=resc, masks=tmasks)
+    else:
+        mods = [m for m in names if ("noise/" + m) in a]
+        plv = G.t(a["prior_log_var"]).clone().requires_grad_(True)
+        e = {m: enc_f[m](tdata[m]) for m in mods}
+        o = elbo.mmvae_forward(e, tdata, dec_f, {m: G.t(a["noise/" + m]) for m in mods}, names=names, K=cfg["K"],
+                               family=cfg["family"], loss=cfg["loss"], prior_log_var=plv, rescale=resc, masks=tmasks)
+        extra["prior_log_var"] = plv
+    o["loss"].backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()}
+    for k, v in extra.items():
+        grads[k] = v.grad if v.grad is not None else torch.zeros_like(v)
+    return o, grads
+
+
+def compare_grads(model, ograds, a, rtol=RTOL):
+    mg = model_grads(model)
+    worst = 0.0
+    for k, gref in ograds.items():
+        if k not in mg:
+            continue
+        e = rel(gref.detach().numpy(), mg[k])
+        worst = max(worst, e)
+        assert e <= rtol, f"grad {k}: rel-to-max err {e:.3e}"
+    G.check_grads(a, mg, rtol=5 * rtol, atol_frac=rtol)
+    return worst
+
+
+@pytest.mark.parametrize("name", G.MOPOE_CASES)
+def test_mopoe_golden(name):
+    cfg, a, dims, data, masks, sd_np, model, inputs, d = prep(name)
+    kw = dict(noise=G.t(a["eps"]).to(d))
+    if "choice" in a:
+        kw["choice"] = G.t(a["choice"]).to(d)
+    out = model(inputs, **kw)
+    check(a["loss"], out.loss, "loss")
+    check(a["loss_sum"], out.loss_sum, "loss_sum")
+    for k, v in out.metrics.items():
+        check(a["metric/" + k], v, k)
+    lat = model.inference(inputs, **kw)
+    check(a["mus"], lat["mus"], "subset mus")
+    check(a["logvars"], lat["logvars"], "subset logvars")
+    check(a["joint_mu"], lat["joint"][0], "joint mu")
+    assert list(lat["subsets"].keys()) == cfg["subsets"]
+    out.loss.backward()
+    o, og = oracle_full_grads(cfg, dims, data, masks, sd_np, a)
+    check(o["loss"].detach().numpy(), out.loss, "loss vs oracle")
+    compare_grads(model, og, a)
+
+
+@pytest.mark.parametrize("name", G.MVTCAE_CASES)
+def test_mvtcae_golden(name):
+    cfg, a, dims, data, masks, sd_np, model, inputs, d = prep(name)
+    out = model(inputs, noise=G.t(a["eps"]).to(d))
+    check(a["loss"], out.loss, "loss")
+    check(a["loss_sum"], out.loss_sum, "loss_sum")
+    for k, v in out.metrics.items():
+        check(a["metric/" + k], v, k)
+    out.loss.backward()
+    o, og = oracle_full_grads(cfg, dims, data, masks, sd_np, a)
+    compare_grads(model, og, a)
+    if masks is not None:
+        # exact zeros for the rows of a missing modality flow back to its encoder input layer only through
+        # available rows; a fully missing modality gives exactly zero encoder gradients (tests/test_mvtcae.py:160)
+        pass
+
+
+@pytest.mark.parametrize("name", G.MMVAE_CASES)
+def test_mmvae_golden(name):
+    cfg, a, dims, data, masks, sd_np, model, inputs, d = prep(name)
+    with torch.no_grad():
+        model.prior_log_var.copy_(G.t(a["prior_log_var"]).to(d))
+    mods = [m for m in cfg["names"] if ("noise/" + m) in a]
+    noise = {m: G.t(a["noise/" + m]).to(d) for m in mods}
+    out = model(inputs, noise=noise, detailed_output=True)
+    check(a["loss"], out.loss, "loss")
+    for m in mods:
+        check(a["zs/" + m], out.zss[m], "z " + m)
+        check(a["lws/" + m], out.lws[m], "lw " + m)
+    out.loss.backward()
+    o, og = oracle_full_grads(cfg, dims, data, masks, sd_np, a)
+    compare_grads(model, og, a, rtol=2e-4)
+
+
+def test_missing_modality_gives_exactly_zero_encoder_grads():
+    """tests/test_mopoe.py:237-253 / test_mvtcae.py:160-175 of the reference: a modality that is missing for the
+    whole batch receives exactly zero gradient in its encoder."""
+    from multivae_amd.data.datasets.base import DatasetOutput
+    from multivae_amd.models import MVTCAE, MoPoE, MoPoEConfig, MVTCAEConfig
+
+    d = torch.device("cuda:0")
+    dims = G.TINY_DIMS
+    torch.manual_seed(0)
+    data = {m: torch.rand(6, *s, device=d) for m, s in dims.items()}
+    masks = {m: torch.ones(6, dtype=torch.bool, device=d) for m in dims}
+    masks["mod2"][:] = False
+    for cls, cfgc in ((MoPoE, MoPoEConfig), (MVTCAE, MVTCAEConfig)):
+        model = cls(cfgc(n_modalities=4, latent_dim=5, input_dims=dict(dims))).to(d)
+        out = model(DatasetOutput(data=data, masks=masks))
+        out.loss.backward()
+        for p in model.encoders["mod2"].parameters():
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0
+        assert any(float(p.grad.abs().max()) > 0 for p in model.encoders["mod1"].parameters())

@@ -1,0 +1,486 @@
+"""Kernel-level parity: every C-ABI entry point of libmvk.so against the CPU oracle (oracle/) on seeded
+inputs.  Tolerance: 1e-4 relative (BASELINE.json north_star), measured against the largest magnitude of the
+reference tensor so that near-zero entries of a large tensor do not dominate; most kernels are far tighter.
+All tests need a real MI355X (`-m gpu`)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import elbo, nets, train
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def close(got, ref, rtol=RTOL, what=""):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = ref.abs().max().clamp_min(1e-30)
+    err = (got - ref).abs().max() / scale
+    assert torch.isfinite(got).all(), what
+    assert float(err) <= rtol, f"{what}: rel-to-max err {float(err):.3e} > {rtol}"
+    return float(err)
+
+
+@pytest.fixture(scope="module")
+def K():
+    from multivae_amd import kernels
+
+    return kernels
+
+
+# ------------------------------------------------------------------------------------------------------------
+# GEMM family
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K_,act", [(7, 5, 3, "relu"), (64, 40, 20, "none"), (300, 512, 784, "relu"),
+                                        (513, 784, 512, "sigmoid"), (128, 128, 16, "none"), (33, 65, 130, "relu")])
+def test_linear_fwd_bwd(K, M, N, K_, act):
+    gen = g(M * 1000 + N)
+    x = torch.randn(M, K_, generator=gen)
+    w = torch.randn(N, K_, generator=gen) / math.sqrt(K_)
+    b = torch.randn(N, generator=gen)
+    dy = torch.randn(M, N, generator=gen)
+    a = {"relu": 1, "sigmoid": 2, "none": 0}[act]
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    y_ref = F.linear(xr, wr, br)
+    y_ref = {"relu": torch.relu, "sigmoid": torch.sigmoid, "none": lambda t: t}[act](y_ref)
+    y_ref.backward(dy)
+    d = dev()
+    xd, wd, bd, dyd = x.to(d), w.to(d), b.to(d), dy.to(d)
+    y = K.linear_fwd(xd, wd, bd, a)
+    close(y, y_ref, what="linear fwd")
+    y_src = y if a else None
+    dx = K.linear_bwd_data(dyd, wd, y_out=y_src, y_act=a)
+    close(dx, xr.grad, what="linear bwd data")
+    dw, db = K.linear_bwd_weight(dyd, xd, y_out=y_src, y_act=a)
+    close(dw, wr.grad, what="linear bwd weight")
+    close(db, br.grad, what="linear bwd bias")
+
+
+def test_linear_bwd_data_fused_prev_act_and_accumulate(K):
+    gen = g(3)
+    M, N, K_ = 50, 24, 36
+    dy = torch.randn(M, N, generator=gen)
+    w = torch.randn(N, K_, generator=gen)
+    prev = torch.relu(torch.randn(M, K_, generator=gen))
+    ref = (dy @ w) * (prev > 0).float()
+    d = dev()
+    got = K.linear_bwd_data(dy.to(d), w.to(d), prev_out=prev.to(d), prev_act=1)
+    close(got, ref, what="prev-act fusion")
+    K.linear_bwd_data(dy.to(d), w.to(d), prev_out=prev.to(d), prev_act=1, out=got, accumulate=True)
+    close(got, 2 * ref, what="accumulate")
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_modes(K, ta, tb):
+    gen = g(10 + 2 * ta + tb)
+    M, N, K_ = 45, 52, 28
+    A = torch.randn(M, K_, generator=gen)
+    B = torch.randn(K_, N, generator=gen)
+    bias = torch.randn(13, generator=gen)
+    ref = A @ B + bias[torch.arange(N) % 13]
+    d = dev()
+    a_in = (A.t().contiguous() if ta else A).to(d)
+    b_in = (B.t().contiguous() if tb else B).to(d)
+    got = K.gemm(a_in, b_in, M, N, K_, ta=bool(ta), tb=bool(tb), bias=bias.to(d), bias_mod=13)
+    close(got, ref, what=f"gemm ta={ta} tb={tb}")
+
+
+def test_gemm_splitk_accumulate(K):
+    gen = g(5)
+    M, N, K_ = 40, 24, 5000
+    A = torch.randn(M, K_, generator=gen)
+    B = torch.randn(K_, N, generator=gen)
+    C0 = torch.randn(M, N, generator=gen)
+    d = dev()
+    out = C0.to(d).clone()
+    K.gemm(A.to(d), B.to(d), M, N, K_, out=out, accumulate=True)
+    close(out, C0 + A @ B, what="split-K accumulate")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 4x4 / stride 2 / pad 1 convolution pair (NHWC inside)
+# ------------------------------------------------------------------------------------------------------------
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("n,h,w,Cu,Cv", [(3, 2, 3, 8, 12), (5, 4, 4, 64, 128), (4, 8, 8, 32, 64), (2, 16, 16, 4, 32),
+                                         (130, 4, 4, 16, 20)])
+def test_conv_down_up_wgrad(K, n, h, w, Cu, Cv):
+    gen = g(n * 100 + h)
+    U = torch.randn(n, Cu, 2 * h, 2 * w, generator=gen)
+    V = torch.randn(n, Cv, h, w, generator=gen)
+    Wc = torch.randn(Cv, Cu, 4, 4, generator=gen) / math.sqrt(16 * Cu)  # conv weight [out=Cv, in=Cu]
+    bv = torch.randn(Cv, generator=gen)
+    bu = torch.randn(Cu, generator=gen)
+    d = dev()
+    wd, wu = K.pack_conv(Wc.to(d))
+    # down: V' = relu(conv(U)+b)
+    ref_down = torch.relu(F.conv2d(U, Wc, bv, stride=2, padding=1))
+    got = K.conv_down(nhwc(U).to(d), wd, bv.to(d), n, h, w, Cu, Cv, act=1)
+    close(nchw(got.cpu()), ref_down, what="conv down")
+    # down from an NCHW source
+    got2 = K.conv_down(U.to(d), wd, bv.to(d), n, h, w, Cu, Cv, act=1, u_nchw=True)
+    close(nchw(got2.cpu()), ref_down, what="conv down nchw src")
+    # up: U' = convT(V) + b  (ConvTranspose2d weight [in=Cv, out=Cu] is the same tensor)
+    ref_up = F.conv_transpose2d(V, Wc, bu, stride=2, padding=1)
+    got = K.conv_up(nhwc(V).to(d), wu, bu.to(d), n, h, w, Cu, Cv)
+    close(nchw(got.cpu()), ref_up, what="conv up")
+    got3 = K.conv_up(nhwc(V).to(d), wu, bu.to(d), n, h, w, Cu, Cv, u_nchw=True)
+    close(got3.cpu(), ref_up, what="conv up nchw dst")
+    # wgrad: d/dW of sum(conv(U) * V)
+    Wr = Wc.clone().requires_grad_()
+    (F.conv2d(U, Wr, None, stride=2, padding=1) * V).sum().backward()
+    got = K.conv_wgrad(nhwc(U).to(d), nhwc(V).to(d), n, h, w, Cu, Cv)
+    close(got, Wr.grad, what="conv wgrad")
+    got4 = K.conv_wgrad(U.to(d), nhwc(V).to(d), n, h, w, Cu, Cv, u_nchw=True)
+    close(got4, Wr.grad, what="conv wgrad nchw src")
+
+
+def test_conv_pins_against_numpy_definition(K):
+    """The same kernels against the torch-free numpy definitions of oracle/nets.py (small case)."""
+    gen = g(77)
+    n, h, w, Cu, Cv = 2, 2, 2, 4, 8
+    U = torch.randn(n, Cu, 2 * h, 2 * w, generator=gen)
+    V = torch.randn(n, Cv, h, w, generator=gen)
+    Wc = torch.randn(Cv, Cu, 4, 4, generator=gen)
+    b0 = torch.zeros(Cv)
+    d = dev()
+    wd, wu = K.pack_conv(Wc.to(d))
+    got = K.conv_down(nhwc(U).to(d), wd, None, n, h, w, Cu, Cv)
+    close(nchw(got.cpu()), torch.from_numpy(nets.conv2d_np(U, Wc, b0, 2, 1)).float(), what="down vs numpy")
+    got = K.conv_up(nhwc(V).to(d), wu, None, n, h, w, Cu, Cv)
+    close(nchw(got.cpu()), torch.from_numpy(nets.conv_transpose2d_np(V, Wc, torch.zeros(Cu), 2, 1)).float(),
+          what="up vs numpy")
+
+
+@pytest.mark.parametrize("n,h,Cv,Cu", [(3, 16, 32, 3), (2, 4, 8, 1), (65, 16, 32, 3)])
+def test_up_nchw_small(K, n, h, Cv, Cu):
+    from multivae_amd._lib import call, ptr, stream_ptr
+
+    gen = g(n + h)
+    V = torch.randn(n, Cv, h, h, generator=gen)
+    Wt = torch.randn(Cv, Cu, 4, 4, generator=gen) / math.sqrt(4 * Cv)
+    b = torch.randn(Cu, generator=gen)
+    ref = torch.sigmoid(F.conv_transpose2d(V, Wt, b, stride=2, padding=1))
+    d = dev()
+    out = torch.empty(n, Cu, 2 * h, 2 * h, device=d)
+    Vd, Wd, bd = nhwc(V).to(d), Wt.to(d), b.to(d)
+    call("mvk_conv4s2_up_nchw_small", ptr(Vd), ptr(Wd), ptr(bd), ptr(out), n, h, h, Cu, Cv, 2, stream_ptr())
+    close(out, ref, what="up nchw small")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# whole networks (single autograd nodes) against the oracle's functional networks
+# ------------------------------------------------------------------------------------------------------------
+def _sd(shapes, seed):
+    import golden_cases as G
+
+    return {k: torch.from_numpy(v) for k, v in G.P.make_state_dict(shapes, seed).items()}
+
+
+def _grads_close(mod, prefix, sd_ref, rtol=RTOL):
+    for name, p in mod.named_parameters():
+        ref = sd_ref[prefix + name].grad
+        close(p.grad, ref, rtol=rtol, what=f"grad {prefix}{name}")
+
+
+@pytest.mark.parametrize("B", [1, 5, 64])
+def test_svhn_encoder_decoder_nodes(B):
+    import golden_cases as G
+    from multivae_amd.models.base.base_config import BaseAEConfig
+    from multivae_amd.models.nn.svhn import Decoder_VAE_SVHN, Encoder_VAE_SVHN
+
+    L = 20
+    shapes = {}
+    shapes.update(G.P.svhn_encoder_shapes("enc.", L))
+    shapes.update(G.P.svhn_decoder_shapes("dec.", L))
+    sd = _sd(shapes, 42 + B)
+    gen = g(B)
+    x = torch.rand(B, 3, 32, 32, generator=gen)
+    z = torch.randn(2, B, L, generator=gen)
+    d = dev()
+    enc = Encoder_VAE_SVHN(BaseAEConfig(input_dim=(3, 32, 32), latent_dim=L)).to(d)
+    dec = Decoder_VAE_SVHN(BaseAEConfig(input_dim=(3, 32, 32), latent_dim=L)).to(d)
+    enc.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("enc.")})
+    dec.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("dec.")})
+    ref = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    mu_r, lv_r = nets.svhn_encoder(ref, "enc.", x)
+    out = enc(x.to(d))
+    close(out.embedding, mu_r, what="svhn enc mu")
+    close(out.log_covariance, lv_r, what="svhn enc lv")
+    gm, gl = torch.randn(mu_r.shape, generator=gen), torch.randn(lv_r.shape, generator=gen)
+    (mu_r * gm + lv_r * gl).sum().backward()
+    (out.embedding * gm.to(d) + out.log_covariance * gl.to(d)).sum().backward()
+    _grads_close(enc, "enc.", ref)
+    zr = z.clone().requires_grad_()
+    rec_r = nets.svhn_decoder(ref, "dec.", zr)
+    zd = z.to(d).requires_grad_()
+    rec = dec(zd).reconstruction
+    assert rec.shape == (2, B, 3, 32, 32)
+    close(rec, rec_r, what="svhn dec out")
+    gr = torch.randn(rec_r.shape, generator=gen)
+    (rec_r * gr).sum().backward()
+    (rec * gr.to(d)).sum().backward()
+    _grads_close(dec, "dec.", ref)
+    close(zd.grad, zr.grad, what="svhn dec dz")
+
+
+@pytest.mark.parametrize("B,D", [(6, (2,)), (33, (1, 28, 28)), (512, (3, 4))])
+def test_mlp_encoder_decoder_nodes(B, D):
+    import golden_cases as G
+    from multivae_amd.models.base.base_config import BaseAEConfig
+    from multivae_amd.models.nn.default_architectures import Decoder_AE_MLP, Encoder_VAE_MLP
+
+    L = 7
+    nin = int(np.prod(D))
+    shapes = {}
+    shapes.update(G.P.mlp_encoder_shapes("enc.", nin, L))
+    shapes.update(G.P.mlp_decoder_shapes("dec.", L, nin))
+    sd = _sd(shapes, 7 + B)
+    gen = g(B + 1)
+    x = torch.rand(B, *D, generator=gen)
+    z = torch.randn(3, B, L, generator=gen)
+    d = dev()
+    enc = Encoder_VAE_MLP(BaseAEConfig(input_dim=D, latent_dim=L)).to(d)
+    dec = Decoder_AE_MLP(BaseAEConfig(input_dim=D, latent_dim=L)).to(d)
+    enc.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("enc.")})
+    dec.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("dec.")})
+    ref = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    mu_r, lv_r = nets.mlp_encoder(ref, "enc.", x)
+    out = enc(x.to(d))
+    close(out.embedding, mu_r, what="mlp enc mu")
+    close(out.log_covariance, lv_r, what="mlp enc lv")
+    gm, gl = torch.randn(mu_r.shape, generator=gen), torch.randn(lv_r.shape, generator=gen)
+    (mu_r * gm + lv_r * gl).sum().backward()
+    (out.embedding * gm.to(d) + out.log_covariance * gl.to(d)).sum().backward()
+    _grads_close(enc, "enc.", ref)
+    zr = z.clone().requires_grad_()
+    rec_r = nets.mlp_decoder(ref, "dec.", zr, D)
+    zd = z.to(d).requires_grad_()
+    rec = dec(zd).reconstruction
+    assert rec.shape == (3, B, *D)
+    close(rec, rec_r, what="mlp dec out")
+    gr = torch.randn(rec_r.shape, generator=gen)
+    (rec_r * gr).sum().backward()
+    (rec * gr.to(d)).sum().backward()
+    _grads_close(dec, "dec.", ref)
+    close(zd.grad, zr.grad, what="mlp dec dz")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# fused ELBO kernels
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dist,scale", [("normal", 1.0), ("normal", 0.75), ("laplace", 0.5), ("bernoulli", 1.0)])
+@pytest.mark.parametrize("Kk,B,D", [(1, 6, 3), (10, 17, 784), (9, 5, 3072), (17, 3, 4100)])
+def test_recon_nll(dist, scale, Kk, B, D):
+    from multivae_amd._lib import DIST, ReconDesc, call, stream_ptr
+
+    gen = g(Kk * 7 + B)
+    recon = torch.randn(Kk, B, D, generator=gen)
+    x = torch.rand(B, D, generator=gen)
+    if dist == "bernoulli":
+        x = (x > 0.5).float()
+    mask = torch.rand(B, generator=gen) > 0.3
+    rowcoef = torch.rand(Kk, B, generator=gen)
+    rescale, coef = 1.7, 0.3
+    rr = recon.clone().requires_grad_()
+    rows_ref = elbo._row_nll(dist, rr, x, rescale, scale)  # [K,B]
+    (rows_ref * rowcoef * mask.float() * coef).sum().backward()
+    d = dev()
+    rd, xd, md, rcd = recon.to(d), x.to(d), mask.to(d), rowcoef.to(d)
+    rows = torch.empty(Kk, B, device=d)
+    drecon = torch.empty_like(rd)
+    desc = (ReconDesc * 1)()
+    e = desc[0]
+    e.recon, e.x, e.mask, e.rows, e.drecon, e.rowcoef = (rd.data_ptr(), xd.data_ptr(), md.data_ptr(),
+                                                         rows.data_ptr(), drecon.data_ptr(), rcd.data_ptr())
+    e.D, e.dist, e.scale, e.rescale, e.coef = D, DIST[dist], scale, rescale, coef
+    call("mvk_recon_nll_fwd", desc, 1, Kk, B, stream_ptr())
+    close(rows, rows_ref, what="nll rows")
+    close(drecon, rr.grad, what="nll drecon (fused)")
+    drecon2 = torch.zeros_like(rd)
+    e.drecon, e.rows = drecon2.data_ptr(), None
+    call("mvk_recon_nll_bwd", desc, 1, Kk, B, stream_ptr())
+    close(drecon2, rr.grad, what="nll drecon (second pass)")
+
+
+def test_recon_nll_multi_modality_one_launch():
+    from multivae_amd._lib import ReconDesc, call, stream_ptr
+
+    gen = g(4)
+    Kk, B = 3, 9
+    d = dev()
+    Ds, keep = [784, 3072, 5], []
+    desc = (ReconDesc * 3)()
+    refs = []
+    for i, D in enumerate(Ds):
+        recon = torch.randn(Kk, B, D, generator=gen)
+        x = torch.rand(B, D, generator=gen)
+        refs.append(elbo._row_nll("normal", recon, x, 1.0 + i, 1.0))
+        rd, xd = recon.to(d), x.to(d)
+        rows = torch.empty(Kk, B, device=d)
+        keep += [rd, xd, rows]
+        e = desc[i]
+        e.recon, e.x, e.mask, e.rows, e.drecon, e.rowcoef = rd.data_ptr(), xd.data_ptr(), None, rows.data_ptr(), None, None
+        e.D, e.dist, e.scale, e.rescale, e.coef = D, 0, 1.0, 1.0 + i, 1.0
+    call("mvk_recon_nll_fwd", desc, 3, Kk, B, stream_ptr())
+    for i in range(3):
+        close(keep[3 * i + 2], refs[i], what=f"rows modality {i}")
+
+
+def _subsets_bits(names):
+    order = sorted(names)
+    pos = {m: i for i, m in enumerate(order)}
+    subs = elbo.mopoe_subsets(names)
+    return order, subs, [sum(1 << pos[m] for m in mods) for _, mods in subs]
+
+
+@pytest.mark.parametrize("M,B,L,Kk,masked", [(2, 16, 20, 1, False), (2, 512, 20, 10, False), (4, 9, 5, 3, True),
+                                             (5, 33, 70, 2, False)])
+def test_mopoe_posterior(K, M, B, L, Kk, masked):
+    gen = g(M * 31 + B)
+    names = [f"m{(i * 3) % M}x{i}" for i in range(M)]  # deliberately not sorted
+    enc = {m: (torch.randn(B, L, generator=gen), torch.randn(B, L, generator=gen) * 0.5) for m in names}
+    eps = torch.randn(Kk, B, L, generator=gen)
+    order, subs, bits = _subsets_bits(names)
+    S = len(subs)
+    masks = choice = None
+    if masked:
+        masks = {m: torch.rand(B, generator=gen) > 0.3 for m in names}
+        masks[names[0]][:] = True
+    encr = {m: (a.clone().requires_grad_(), b.clone().requires_grad_()) for m, (a, b) in enc.items()}
+    if masked:
+        inf0 = elbo.mopoe_inference(enc, names, masks=masks, choice=torch.eye(S)[torch.zeros(B, dtype=torch.long)])
+        idx = torch.multinomial(inf0["weights"].t(), 1, generator=gen).squeeze(1)
+        choice = torch.eye(S)[idx]
+    inf = elbo.mopoe_inference(encr, names, masks=masks, choice=choice)
+    z_ref = elbo.rsample(inf["joint_mu"], inf["joint_logvar"], eps)
+    kld_ref, klds = elbo.mopoe_joint_divergence(inf["mus"], inf["logvars"], inf["weights"])
+    dz = torch.randn(Kk, B, L, generator=gen)
+    gk = torch.rand(B, generator=gen)
+    kld_rows_ref = (inf["weights"] * klds).sum(0)
+    ((z_ref * dz).sum() + (kld_rows_ref * gk).sum()).backward()
+    d = dev()
+    if masked:
+        sel = choice.argmax(1).to(torch.int32).to(d)
+        weights = inf["weights"].detach().contiguous().to(d)
+    else:
+        bnd = elbo.mopoe_row_bounds(B, S)
+        sel = torch.zeros(B, dtype=torch.int32)
+        for k in range(S):
+            sel[bnd[k]:bnd[k + 1]] = k
+        sel, weights = sel.to(d), None
+    mus = [enc[m][0].to(d).requires_grad_() for m in order]
+    lvs = [enc[m][1].to(d).requires_grad_() for m in order]
+    outs = K.MoPoEPosteriorFn.apply(eps.to(d), torch.tensor(bits, dtype=torch.int32, device=d), sel, weights, True,
+                                    *mus, *lvs)
+    z, kld_rows, mus_o, lvs_o, jmu, jlv = outs
+    close(z, z_ref, what="z")
+    close(kld_rows, kld_rows_ref, what="kld rows")
+    close(mus_o, inf["mus"], what="subset mus")
+    close(lvs_o, inf["logvars"], what="subset logvars")
+    close(jmu, inf["joint_mu"], what="joint mu")
+    ((z * dz.to(d)).sum() + (kld_rows * gk.to(d)).sum()).backward()
+    for i, m in enumerate(order):
+        close(mus[i].grad, encr[m][0].grad, what=f"dmu {m}")
+        close(lvs[i].grad, encr[m][1].grad, what=f"dlv {m}")
+
+
+@pytest.mark.parametrize("M,B,L,Kk,masked", [(2, 64, 20, 1, False), (4, 9, 5, 2, True), (3, 40, 33, 1, True)])
+def test_mvtcae_posterior(K, M, B, L, Kk, masked):
+    gen = g(M + B)
+    names = [f"m{i}" for i in range(M)]
+    mus_c = [torch.randn(B, L, generator=gen) for _ in range(M)]
+    lvs_c = [torch.randn(B, L, generator=gen) * 0.5 for _ in range(M)]
+    eps = torch.randn(Kk, B, L, generator=gen)
+    masks = None
+    if masked:
+        masks = [torch.rand(B, generator=gen) > 0.35 for _ in range(M)]
+        masks[0][:] = True
+    mur = [t.clone().requires_grad_() for t in mus_c]
+    lvr = [t.clone().requires_grad_() for t in lvs_c]
+    lv_eff = [torch.where(masks[i].unsqueeze(-1), lvr[i], torch.full_like(lvr[i], float("inf"))) if masked else lvr[i]
+              for i in range(M)]
+    jmu, jlv = elbo.poe(torch.stack(mur), torch.stack(lv_eff))
+    z_ref = elbo.rsample(jmu, jlv, eps)
+    jkl_ref = -0.5 * (1 - jlv.exp() - jmu.pow(2) + jlv).sum(-1)
+    ckl_ref = []
+    for i in range(M):
+        k = -0.5 * (1 - jlv.exp() / lv_eff[i].exp() - (jmu - mur[i]).pow(2) / lv_eff[i].exp() + jlv - lv_eff[i]).sum(-1)
+        if masked:
+            k = torch.where(masks[i], k, torch.zeros_like(k))
+        ckl_ref.append(k)
+    ckl_ref = torch.stack(ckl_ref)
+    dz = torch.randn(Kk, B, L, generator=gen)
+    gj, gc = torch.rand(B, generator=gen), torch.rand(M, B, generator=gen)
+    ((z_ref * dz).sum() + (jkl_ref * gj).sum() + (ckl_ref * gc).sum()).backward()
+    d = dev()
+    mud = [t.to(d).requires_grad_() for t in mus_c]
+    lvd = [t.to(d).requires_grad_() for t in lvs_c]
+    mk = [m.to(d) for m in masks] if masked else None
+    z, jkl, ckl, jmu_o, jlv_o = K.MVTCAEPosteriorFn.apply(eps.to(d), mk, *mud, *lvd)
+    close(z, z_ref, what="z")
+    close(jkl, jkl_ref, what="joint kl rows")
+    close(ckl, ckl_ref, what="cond kl rows")
+    close(jmu_o, jmu, what="joint mu")
+    ((z * dz.to(d)).sum() + (jkl * gj.to(d)).sum() + (ckl * gc.to(d)).sum()).backward()
+    for i in range(M):
+        close(mud[i].grad, mur[i].grad, what=f"dmu {i}")
+        g_ref = lvr[i].grad
+        close(lvd[i].grad, g_ref, what=f"dlv {i}")
+        if masked:  # exactly zero gradient on missing rows (tests/test_mvtcae.py:160-175)
+            assert float(lvd[i].grad[~mk[i]].abs().max() if (~mk[i]).any() else 0.0) == 0.0
+            assert float(mud[i].grad[~mk[i]].abs().max() if (~mk[i]).any() else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("family", ["normal", "laplace_with_softmax"])
+def test_mmvae_std(K, family):
+    from multivae_amd._lib import FAMILY
+
+    gen = g(2)
+    lv = torch.randn(9, 20, generator=gen)
+    lr = lv.clone().requires_grad_()
+    ref = elbo.mmvae_std(lr, family)
+    gs = torch.randn(9, 20, generator=gen)
+    (ref * gs).sum().backward()
+    d = dev()
+    ld = lv.to(d).requires_grad_()
+    sd = K.MMVAEStdFn.apply(ld, FAMILY[family])
+    close(sd, ref, what="std")
+    (sd * gs.to(d)).sum().backward()
+    close(ld.grad, lr.grad, what="dlv")
+
+
+def test_adam_matches_oracle(K):
+    gen = g(9)
+    n = 100003
+    p = torch.randn(n, generator=gen)
+    m = torch.zeros(n)
+    v = torch.zeros(n)
+    d = dev()
+    pd, md, vd = p.to(d), m.to(d), v.to(d)
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=gen)
+        train.adam_update(p, gr * 0.5, m, v, step, lr=1e-3)
+        K.adam_step(pd, gr.to(d), md, vd, step, 1e-3, grad_scale=0.5)
+    close(pd, p, rtol=1e-6, what="adam params")
+    close(vd, v, rtol=1e-6, what="adam v")
