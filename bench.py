@@ -1,0 +1,193 @@
+"""Headline benchmark: train samples/sec of one full MoPoE training step (forward + fused ELBO + backward +
+Adam [+ one RCCL gradient all-reduce]) on synthetic MnistSvhn-shaped batches, K = 10 importance samples,
+per-device batch 512 (weak scaling), one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     — the fused reconstruction-NLL kernel (HBM-bound): algorithmic bytes / HIP-event duration,
+  cpu_baseline — the CPU oracle (oracle/train.py, a port of the reference path) timed on the host cores.
+Nothing here reads /root/reference.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def build_model(K, L, device, seed=0):
+    from multivae_amd.models import MoPoE, MoPoEConfig
+    from multivae_amd.models.base.base_config import BaseAEConfig
+    from multivae_amd.models.nn.default_architectures import Decoder_AE_MLP, Encoder_VAE_MLP
+    from multivae_amd.models.nn.svhn import Decoder_VAE_SVHN, Encoder_VAE_SVHN
+
+    torch.manual_seed(seed)  # default nn.Linear / nn.Conv2d init
+    enc = dict(mnist=Encoder_VAE_MLP(BaseAEConfig(latent_dim=L, input_dim=(1, 28, 28))),
+               svhn=Encoder_VAE_SVHN(BaseAEConfig(latent_dim=L, input_dim=(3, 32, 32))))
+    dec = dict(mnist=Decoder_AE_MLP(BaseAEConfig(latent_dim=L, input_dim=(1, 28, 28))),
+               svhn=Decoder_VAE_SVHN(BaseAEConfig(latent_dim=L, input_dim=(3, 32, 32))))
+    cfg = MoPoEConfig(n_modalities=2, latent_dim=L, input_dims=dict(mnist=(1, 28, 28), svhn=(3, 32, 32)), beta=1.0, K=K)
+    return MoPoE(cfg, enc, dec).to(device).train()
+
+
+def synthetic_batch(B, device, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return {"mnist": torch.rand(B, 1, 28, 28, generator=g).to(device),
+            "svhn": torch.rand(B, 3, 32, 32, generator=g).to(device)}
+
+
+def cpu_baseline(model, data, K, L, budget_s=20.0):
+    """The oracle's training step (torch CPU, same architecture / batch / K) on the host cores."""
+    from oracle import train as otrain
+
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    st = otrain.AdamState(sd)
+    cdata = {m: v.cpu() for m, v in data.items()}
+    B = cdata["mnist"].shape[0]
+    g = torch.Generator().manual_seed(1234)
+
+    def step():
+        eps = torch.randn(K, B, L, generator=g)
+        otrain.train_step(sd, st, lambda s: otrain.mopoe_mnist_svhn_loss(s, cdata, eps), lr=1e-3)
+
+    step()  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 8:
+            break
+    return {"value": round(n * B / el, 2), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} full training steps (B={B}, K={K}) of oracle/train.py after 1 warm-up step, {el:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=512, help="per-device batch (reference: per_device_train_batch_size)")
+    ap.add_argument("--K", type=int, default=10)
+    ap.add_argument("--latent-dim", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: multivae_amd has no CPU compute path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)  # nccl == RCCL on ROCm
+
+    from multivae_amd import kernels
+    from multivae_amd.data.datasets.base import DatasetOutput
+    from multivae_amd.trainers import FlatParams, FusedAdam
+
+    B, K, L = args.batch, args.K, args.latent_dim
+    model = build_model(K, L, device, seed=0)
+    flat = FlatParams(model)
+    if world > 1:
+        flat.broadcast(0)  # C1: one parameter broadcast
+    opt = FusedAdam(flat, lr=1e-3)
+    data = synthetic_batch(B, device, seed=rank)
+    inputs = DatasetOutput(data=data)
+    gen = torch.Generator(device=device).manual_seed(1000 + rank)
+    grad_scale = 1.0 / world
+
+    def step():
+        eps = torch.randn(K, B, L, device=device, generator=gen)
+        opt.zero_grad()
+        out = model(inputs, noise=eps)
+        out.loss.backward()
+        if world > 1:
+            flat.all_reduce()  # C2: ONE all-reduce of the flat gradient buffer
+        opt.step(grad_scale=grad_scale)
+        return out
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kernels.PROFILE["recon_nll"] = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    events = kernels.PROFILE.pop("recon_nll")
+    loss = float(out.loss)
+    if loss != loss:
+        raise ArithmeticError("NaN detected in train loss")
+
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        D = 784 + 3072
+        alg_bytes = 4.0 * B * D * (2 * K + 1)  # read recon, write d_recon, read x
+        durs = [s.elapsed_time(e) * 1e-3 for s, e in events]
+        avg = sum(durs) / max(len(durs), 1)
+        achieved = alg_bytes / avg / 1e9 if avg > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "recon_nll_traffic.json")
+        if os.path.exists(tf):
+            with open(tf) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        res = {
+            "metric": "train samples/sec (ELBO step) MoPoE MnistSvhn K=10",
+            "value": round(world * B * args.steps / elapsed, 2),
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"MoPoE MnistSvhn (mnist MLP + svhn conv), K={K}, per-device batch {B}, "
+                                   f"latent_dim {L}, Adam lr 1e-3, fwd+ELBO+bwd+optimizer"
+                                   + (", 1 RCCL all-reduce/step" if world > 1 else ""),
+                       "global_batch": world * B, "K": K, "parallelism": f"dp{world}", "final_loss": round(loss, 4)},
+            "roofline": {"kernel": "recon_nll_kernel<vec,fwd> (fused reconstruction NLL + d_recon, both modalities)",
+                         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes": alg_bytes, "avg_launch_us": round(avg * 1e6, 2),
+                         "launches_timed": len(durs)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(model, data, K, L, args.cpu_budget)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

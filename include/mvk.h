@@ -252,8 +252,8 @@ int mvk_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, v
  * ------------------------------------------------------------------------------------------------ */
 /* torch.optim.Adam (amsgrad=False) on flat buffers; step is 1-based; grad_scale multiplies g first
  * (1/world_size for DDP averaging).  trainers/base/base_trainer_config.py:58,62; base_trainer.py:350-361. */
-int mvk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, int step, float grad_scale, void* stream);
+int mvk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, int step, double grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

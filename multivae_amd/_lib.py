@@ -20,6 +20,7 @@ MAX_MODALITIES = 8
 _p = C.c_void_p
 _i = C.c_int
 _f = C.c_float
+_d = C.c_double
 _i64 = C.c_int64
 
 
@@ -60,7 +61,7 @@ PROTOTYPES = {
     "mvk_flatten_wgrad": [_p, _p, _p, _i, _i, _i, _p],
     "mvk_nchw_to_nhwc": [_p, _p, _i, _i, _i, _i, _p],
     "mvk_nhwc_to_nchw": [_p, _p, _i, _i, _i, _i, _p],
-    "mvk_adam_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i, _f, _p],
+    "mvk_adam_step": [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _d, _p],
     "mvk_mmvae_std_fwd": [_p, _i, _i, _i, _p, _p],
     "mvk_mmvae_std_bwd": [_p, _p, _p, _i, _i, _i, _p, _p],
     "mvk_mmvae_latent_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p],

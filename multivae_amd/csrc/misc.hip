@@ -129,17 +129,16 @@ __global__ __launch_bounds__(256) void up_nchw_small_kernel(const float* __restr
 
 // ---- Adam on flat buffers (torch.optim.Adam single-tensor rule, amsgrad=False) -----------------------------
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
-                            float bc1, float bc2_sqrt, float gscale) {
+                            float* __restrict__ v, long long n, float step_size, float omb1, float b2, float omb2,
+                            float eps, float wd, float bc2_sqrt, float gscale) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
-  const float step_size = lr / bc1;
   for (; i < n; i += stride) {
     float gi = g[i] * gscale;
     float pi = p[i];
     if (wd != 0.f) gi = fmaf(wd, pi, gi);
-    float mi = m[i] + (gi - m[i]) * (1.f - b1);  // exp_avg.lerp_(grad, 1 - beta1)
-    float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    float mi = m[i] + (gi - m[i]) * omb1;  // exp_avg.lerp_(grad, 1 - beta1), weight < 0.5 branch
+    float vi = fmaf(omb2, gi * gi, v[i] * b2);  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
     m[i] = mi;
     v[i] = vi;
     float denom = sqrtf(vi) / bc2_sqrt + eps;
@@ -274,14 +273,16 @@ int mvk_conv4s2_up_nchw_small(const float* V, const float* Wref, const float* bi
   return MVK_OK;
 }
 
-int mvk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, int step, float grad_scale, void* stream) {
+int mvk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, int step, double grad_scale, void* stream) {
   if (!p || !g || !m || !v || step < 1) return MVK_EINVAL;
   if (n == 0) return MVK_OK;
-  double bc1 = 1.0 - pow((double)beta1, (double)step);
-  double bc2 = 1.0 - pow((double)beta2, (double)step);
+  // scalar arithmetic in double like the Python side of torch.optim.Adam, cast once
+  double bc1 = 1.0 - pow(beta1, (double)step);
+  double bc2 = 1.0 - pow(beta2, (double)step);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, mvk_stream(stream), p, g, m, v, (long long)n,
-                     lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+                     (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                     (float)weight_decay, (float)sqrt(bc2), (float)grad_scale);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }

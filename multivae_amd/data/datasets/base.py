@@ -3,7 +3,7 @@ items are `DatasetOutput(data={mod: tensor}, [masks={mod: bool}], [labels])` wit
 and `hasattr(inputs, "masks")` is the incompleteness test."""
 import torch
 
-from ...models.base.base_utils import ModelOutput
+from ..._output import ModelOutput
 
 
 class DatasetOutput(ModelOutput):

@@ -17,6 +17,10 @@ from ._lib import ACT, DIST, FAMILY, ReconDesc, TermDesc, call, ptr, ptr_array, 
 
 RELU, SIGMOID, NONE = ACT["relu"], ACT["sigmoid"], ACT["none"]
 
+# bench.py sets PROFILE["recon_nll"] = [] to collect (start, end) HIP events around the fused reconstruction-NLL
+# launch on the stream it is launched on (roofline measurement inside the timed region).
+PROFILE = {}
+
 
 def _c(t):
     """contiguous fp32 CUDA tensor (no copy when already so)."""
@@ -434,7 +438,14 @@ class ReconLossFn(Function):
             d.scale, d.rescale = spec["scale"][i], spec["rescale"][i]
             d.coef = spec["coef"][i] * spec["lossw"][i]
         if n_mod:
+            prof = PROFILE.get("recon_nll")
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             call("mvk_recon_nll_fwd", descs, n_mod, K, B, stream_ptr())
+            if prof is not None:
+                e1.record()
+                prof.append((e0, e1))
         splits = spec.get("extra_split") or [1] * len(extras)
         n_terms = n_mod + sum(splits)
         terms = (TermDesc * n_terms)()

@@ -4,41 +4,8 @@ Mirrors what the reference takes from pythae (`pythae.models.base.base_utils.Mod
 `multivae/models/base/base_utils.py:62-87` (set_decoder_dist validation).  The arithmetic of poe /
 kl_divergence / rsample lives in the HIP kernels (multivae_amd/csrc/elbo.hip).
 """
-from collections import OrderedDict
-
 from ... import _lib
-
-
-class ModelOutput(OrderedDict):
-    """Ordered dict whose items are also attributes; integer indexing returns the i-th value."""
-
-    def __init__(self, *args, **kwargs):
-        super().__init__()
-        for k, v in dict(*args, **kwargs).items():
-            self[k] = v
-
-    def __getitem__(self, k):
-        if isinstance(k, str):
-            return super().__getitem__(k)
-        return list(self.values())[k]
-
-    def __setitem__(self, key, value):
-        super().__setitem__(key, value)
-        super().__setattr__(key, value)
-
-    def __setattr__(self, name, value):
-        super().__setitem__(name, value)
-        super().__setattr__(name, value)
-
-    def __delitem__(self, key):
-        super().__delitem__(key)
-        if key in self.__dict__:
-            super().__delattr__(key)
-
-    def pop(self, key, *default):
-        if key in self.__dict__:
-            super().__delattr__(key)
-        return super().pop(key, *default)
+from ..._output import ModelOutput  # noqa: F401  (re-exported: `multivae.models.base.base_utils.ModelOutput`)
 
 
 def decoder_dist_code(dist_name):

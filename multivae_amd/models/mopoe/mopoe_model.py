@@ -138,7 +138,10 @@ class MoPoE(BaseMultiVAE):
     def inference(self, inputs, **kwargs):
         """Subset and joint posterior parameters (:274-350).  Returns the same dict layout as the reference."""
         K = 1
-        enc, outs, (B, L, device, weights) = self._posterior(inputs, K, noise=kwargs.get("noise"),
+        noise = kwargs.get("noise")
+        if noise is not None:  # only the first sample matters here: the posterior parameters do not depend on it
+            noise = (noise.unsqueeze(0) if noise.dim() == 2 else noise)[:1]
+        enc, outs, (B, L, device, weights) = self._posterior(inputs, K, noise=noise,
                                                               choice=kwargs.get("choice"), want_stats=True)
         z, kld_rows, mus, lvs, jmu, jlv = outs
         S = len(self._subset_keys)

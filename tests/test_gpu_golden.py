@@ -168,7 +168,9 @@ def test_mmvae_golden(name):
         check(a["lws/" + m], out.lws[m], "lw " + m)
     out.loss.backward()
     o, og = oracle_full_grads(cfg, dims, data, masks, sd_np, a)
-    compare_grads(model, og, a, rtol=2e-4)
+    # IWAE weights are exp(lw - lse) with |lw| ~ 4e3: one fp32 ulp of lw is 2.4e-4, so the weights (and the
+    # gradients they scale) carry ~1e-4 relative noise in ANY fp32 evaluation order
+    compare_grads(model, og, a, rtol=5e-4)
 
 
 def test_missing_modality_gives_exactly_zero_encoder_grads():
