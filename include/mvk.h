@@ -183,15 +183,21 @@ int mvk_mmvae_latent_bwd(const float* const* mu, const float* const* std, const 
 /* Y[M,N] = act(X[M,K] W[N,K]^T + b[N]) — nn.Linear + activation
  * (models/nn/default_architectures.py:21-72 Encoder_VAE_MLP, :225-258 Decoder_AE_MLP). */
 int mvk_linear_fwd(const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int act,
-                   void* stream);
+                   float* ws, int64_t ws_floats, void* stream);
 /* dX[M,K] = dYpre[M,N] W[N,K] (* act'(prev_out[m,k]) if prev_out != NULL, so the result is directly the
  * previous layer's pre-activation gradient).  dYpre = dY * act'(y_out) when y_out != NULL, else dY.
  * accumulate != 0: dX += (atomic). */
 int mvk_linear_bwd_data(const float* dY, const float* W, float* dX, int M, int N, int K, const float* y_out,
-                        int y_act, const float* prev_out, int prev_act, int accumulate, void* stream);
-/* dW[N,K] += dYpre[M,N]^T X[M,K];  db[N] += colsum(dYpre) (db nullable). */
+                        int y_act, const float* prev_out, int prev_act, int accumulate, float* ws,
+                        int64_t ws_floats, void* stream);
+/* dW[N,K] += dYpre[M,N]^T X[M,K];  db[N] += colsum(dYpre) (db nullable).
+ * Split-K workspace convention (all weight-gradient / accumulate entry points): `ws` is caller-owned scratch of
+ * `ws_floats` floats.  When it can hold one [rows x cols] slab per reduction slice the slices are summed by a
+ * second kernel in a fixed order (deterministic, no atomics); with ws == NULL or too small the slices fall
+ * back to fp32 atomicAdd.  mvk_splitk_workspace_floats() returns a size that is always sufficient. */
 int mvk_linear_bwd_weight(const float* dY, const float* X, float* dW, float* db, int M, int N, int K,
-                          const float* y_out, int y_act, void* stream);
+                          const float* y_out, int y_act, float* ws, int64_t ws_floats, void* stream);
+int64_t mvk_splitk_workspace_floats(int rows, int cols, int reduce_len);
 /* db[N] += column sums of dY[M,N] (* act'(y_out)). */
 int mvk_colsum_acc(const float* dY, const float* y_out, int y_act, float* db, int M, int N, void* stream);
 /* db[c] += sum over n and spatial positions of dY[n,c,hw] (* act'(y_out)) for NCHW tensors. */
@@ -206,7 +212,7 @@ int mvk_act_bwd(float* dY, const float* Y, int64_t n, int act, void* stream);
  *   c_act_src: result *= c_act'(c_act_src[m,n]); accumulate != 0 => C += (split-K, atomic). */
 int mvk_gemm(const float* A, const float* B, float* C, int M, int N, int K, int ta, int tb, const float* bias,
              int bias_mod, int act, int accumulate, const float* a_act_src, int a_act, const float* c_act_src,
-             int c_act, void* stream);
+             int c_act, float* ws, int64_t ws_floats, void* stream);
 
 /* 4x4 / stride 2 / pad 1 convolution pair on NHWC activations (models/nn/svhn.py:7-70).
  * "U" is the large feature map [n,2h,2w,Cu], "V" the small one [n,h,w,Cv], W the reference weight
@@ -227,11 +233,24 @@ int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, floa
 int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U, int n, int h, int w, int Cu,
                    int Cv, int act, int u_nchw, const float* u_act_src, int u_act, void* stream);
 int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv,
-                      int u_nchw, const float* u_act_src, int u_act, void* stream);
+                      int u_nchw, const float* u_act_src, int u_act, float* ws, int64_t ws_floats, void* stream);
 /* Direct kernel for the 3-channel image-producing layer: U[n,Cu,2h,2w] (NCHW) = act(convT(V) + b), Cu <= 4,
  * reading the reference weight tensor directly (models/nn/svhn.py:58-60). */
 int mvk_conv4s2_up_nchw_small(const float* V, const float* Wref, const float* bias, float* U, int n, int h,
                               int w, int Cu, int Cv, int act, void* stream);
+
+/* MFMA kernels for the same layer when h*w is a multiple of 64 (<= 256), Cu <= 4 and Cv in {16,32,64}
+ * (mvk_conv4s2_small_up_supported != 0): one workgroup per image computes the column matrix
+ * V[pos,:] . W[:,(cu,kh,kw)] on the matrix cores and gathers the output pixels from LDS (no wasted MFMA columns).
+ * The backward entry point fuses backward-data (dV = conv(dUpre) * v_act'(V)), backward-weight (dWref +=) and
+ * the bias gradient (db +=, nullable) with dUpre = dU * u_act'(Uout) applied while loading; ws is split-K style
+ * scratch (>= 512 * (16*Cu*Cv + Cu) floats for full parallelism). */
+int mvk_conv4s2_small_up_supported(int h, int w, int Cu, int Cv);
+int mvk_conv4s2_small_up_fwd(const float* V, const float* Wref, const float* bias, float* U, int n, int h, int w,
+                             int Cu, int Cv, int act, void* stream);
+int mvk_conv4s2_small_up_bwd(const float* dU, const float* Uout, int u_act, const float* V, int v_act,
+                             const float* Wref, float* dV, float* dWref, float* db, float* ws, int64_t ws_floats,
+                             int n, int h, int w, int Cu, int Cv, void* stream);
 
 /* 1x1-spatial layers:
  *   unflatten  Y[n,(tap,co)] = act(z[n,Cin] Wp + b[co]), Wp[ci][tap*Cout+co] = Wref[ci][co][tap]
@@ -240,8 +259,10 @@ int mvk_conv4s2_up_nchw_small(const float* V, const float* Wref, const float* bi
  *              on the `down` packing.
  * The weight gradients scatter straight back into the reference layouts: */
 int mvk_pack_unflatten_weight(const float* Wref, int Cin, int Cout, float* Wp, void* stream);
-int mvk_unflatten_wgrad(const float* Z, const float* dY, float* dWref, int n, int Cin, int Cout, void* stream);
-int mvk_flatten_wgrad(const float* H, const float* dY, float* dWref, int n, int Cu, int Cv, void* stream);
+int mvk_unflatten_wgrad(const float* Z, const float* dY, float* dWref, int n, int Cin, int Cout, float* ws,
+                        int64_t ws_floats, void* stream);
+int mvk_flatten_wgrad(const float* H, const float* dY, float* dWref, int n, int Cu, int Cv, float* ws,
+                      int64_t ws_floats, void* stream);
 
 /* NCHW <-> NHWC copies at the plugin boundary. */
 int mvk_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, void* stream);

@@ -44,21 +44,23 @@ PROTOTYPES = {
     "mvk_recon_nll_bwd": [C.POINTER(ReconDesc), _i, _i, _i, _p],
     "mvk_reduce_terms": [C.POINTER(TermDesc), _i, _f, _p, _p, _p],
     "mvk_scale_by_device_scalar": [_p, _i64, _p, _p],
-    "mvk_linear_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
-    "mvk_linear_bwd_data": [_p, _p, _p, _i, _i, _i, _p, _i, _p, _i, _i, _p],
-    "mvk_linear_bwd_weight": [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p],
+    "mvk_linear_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p, _i64, _p],
+    "mvk_linear_bwd_data": [_p, _p, _p, _i, _i, _i, _p, _i, _p, _i, _i, _p, _i64, _p],
+    "mvk_linear_bwd_weight": [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _i64, _p],
     "mvk_colsum_acc": [_p, _p, _i, _p, _i, _i, _p],
     "mvk_nchw_channel_sum_acc": [_p, _p, _i, _p, _i, _i, _i, _p],
     "mvk_act_bwd": [_p, _p, _i64, _i, _p],
-    "mvk_gemm": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _i, _p, _i, _p],
+    "mvk_gemm": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _i, _p, _i, _p, _i64, _p],
     "mvk_pack_conv4s2_weight": [_p, _i, _i, _p, _i, _i, _p, _p],
     "mvk_conv4s2_down": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p],
     "mvk_conv4s2_up": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p],
-    "mvk_conv4s2_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p],
+    "mvk_conv4s2_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _p],
     "mvk_conv4s2_up_nchw_small": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "mvk_conv4s2_small_up_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "mvk_conv4s2_small_up_bwd": [_p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p],
     "mvk_pack_unflatten_weight": [_p, _i, _i, _p, _p],
-    "mvk_unflatten_wgrad": [_p, _p, _p, _i, _i, _i, _p],
-    "mvk_flatten_wgrad": [_p, _p, _p, _i, _i, _i, _p],
+    "mvk_unflatten_wgrad": [_p, _p, _p, _i, _i, _i, _p, _i64, _p],
+    "mvk_flatten_wgrad": [_p, _p, _p, _i, _i, _i, _p, _i64, _p],
     "mvk_nchw_to_nhwc": [_p, _p, _i, _i, _i, _i, _p],
     "mvk_nhwc_to_nchw": [_p, _p, _i, _i, _i, _i, _p],
     "mvk_adam_step": [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _d, _p],
@@ -90,6 +92,10 @@ def load(path=None):
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    lib.mvk_conv4s2_small_up_supported.argtypes = [_i, _i, _i, _i]
+    lib.mvk_conv4s2_small_up_supported.restype = C.c_int
+    lib.mvk_splitk_workspace_floats.argtypes = [_i, _i, _i]
+    lib.mvk_splitk_workspace_floats.restype = C.c_int64
     _lib = lib
     return lib
 

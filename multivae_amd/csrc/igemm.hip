@@ -25,6 +25,31 @@ int launch_igemm(const GemmDesc& d, int zdim, hipStream_t s) {
   return launch_cfg<64, 64>(d, zdim, s);
 }
 
+int launch_splitk(GemmDesc& d, float* ws, long long ws_floats, int target_blocks, hipStream_t s) {
+  int tm = (d.M + 127) / 128;
+  int tn = (d.N <= 32) ? 1 : (d.N + 63) / 64;
+  int tiles = tm * tn;
+  int ktiles = (d.K + BK - 1) / BK;
+  int splits = target_blocks / (tiles > 0 ? tiles : 1);
+  if (splits < 1) splits = 1;
+  if (splits > ktiles) splits = ktiles;
+  d.zmode = Z_SPLITK;
+  d.ksplit_tiles = (ktiles + splits - 1) / splits;
+  int z = (ktiles + d.ksplit_tiles - 1) / d.ksplit_tiles;
+  const long long need = (long long)z * d.M * d.N;
+  if (z > 1 && ws && ws_floats >= need && d.e.kind != E_UP && d.e.kind != E_UP_NCHW) {
+    d.e.ws = ws;
+    int rc = launch_igemm(d, z, s);
+    if (rc) return rc;
+    long long total = (long long)d.M * d.N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d.e, d.M, d.N, z);
+    MVK_CHECK_LAUNCH();
+    return MVK_OK;
+  }
+  d.e.ws = nullptr;
+  return launch_igemm(d, z, s);
+}
+
 static void plain_a(AOperand& a, const float* p, long long sr, long long sk, int M, int K) {
   a = AOperand{};
   a.p = p;
@@ -58,18 +83,6 @@ static void rowmajor_epi(Epilogue& e, float* out, long long ld) {
   e.ld = ld;
   e.bias_mod = 1;
   e.Cu = e.OH = e.OW = 1;
-}
-
-// split the reduction so that roughly `target` workgroups are in flight
-static int pick_splits(int M, int N, int K, int target = 1024) {
-  int tm = (M + 127) / 128;
-  int tn = (N <= 32) ? 1 : (N + 63) / 64;
-  int tiles = tm * tn;
-  int ktiles = (K + BK - 1) / BK;
-  int s = target / (tiles > 0 ? tiles : 1);
-  if (s < 1) s = 1;
-  if (s > ktiles) s = ktiles;
-  return s;
 }
 
 // ---- small helper kernels ------------------------------------------------------------------------------
@@ -137,8 +150,15 @@ using namespace mvk;
 
 extern "C" {
 
+// tall-skinny / K-serial shapes: too few output tiles to fill 256 CUs -> split the reduction
+static int launch_auto(GemmDesc& d, float* ws, int64_t ws_floats, hipStream_t s) {
+  long long tiles = (long long)((d.M + 127) / 128) * ((d.N + 63) / 64);
+  if (d.e.atomic || (ws && tiles < 128 && d.K >= 256)) return launch_splitk(d, ws, ws_floats, 512, s);
+  return launch_igemm(d, 1, s);
+}
+
 int mvk_linear_fwd(const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int act,
-                   void* stream) {
+                   float* ws, int64_t ws_floats, void* stream) {
   if (!X || !W || !Y || M < 0 || N <= 0 || K <= 0) return MVK_EINVAL;
   GemmDesc d{};
   plain_a(d.a, X, K, 1, M, K);
@@ -150,11 +170,12 @@ int mvk_linear_fwd(const float* X, const float* W, const float* b, float* Y, int
   d.M = M;
   d.N = N;
   d.K = K;
-  return launch_igemm(d, 1, mvk_stream(stream));
+  return launch_auto(d, ws, ws_floats, mvk_stream(stream));
 }
 
 int mvk_linear_bwd_data(const float* dY, const float* W, float* dX, int M, int N, int K, const float* y_out,
-                        int y_act, const float* prev_out, int prev_act, int accumulate, void* stream) {
+                        int y_act, const float* prev_out, int prev_act, int accumulate, float* ws,
+                        int64_t ws_floats, void* stream) {
   if (!dY || !W || !dX || M < 0 || N <= 0 || K <= 0) return MVK_EINVAL;
   GemmDesc d{};
   plain_a(d.a, dY, N, 1, M, N);  // reduce over n
@@ -168,11 +189,11 @@ int mvk_linear_bwd_data(const float* dY, const float* W, float* dX, int M, int N
   d.M = M;
   d.N = K;
   d.K = N;
-  return launch_igemm(d, 1, mvk_stream(stream));
+  return launch_auto(d, ws, ws_floats, mvk_stream(stream));
 }
 
 int mvk_linear_bwd_weight(const float* dY, const float* X, float* dW, float* db, int M, int N, int K,
-                          const float* y_out, int y_act, void* stream) {
+                          const float* y_out, int y_act, float* ws, int64_t ws_floats, void* stream) {
   if (!dY || !X || !dW || M < 0 || N <= 0 || K <= 0) return MVK_EINVAL;
   hipStream_t s = mvk_stream(stream);
   GemmDesc d{};
@@ -186,12 +207,7 @@ int mvk_linear_bwd_weight(const float* dY, const float* X, float* dW, float* db,
   d.M = N;
   d.N = K;
   d.K = M;
-  int splits = pick_splits(d.M, d.N, d.K);
-  int ktiles = (d.K + BK - 1) / BK;
-  d.zmode = Z_SPLITK;
-  d.ksplit_tiles = (ktiles + splits - 1) / splits;
-  int z = (ktiles + d.ksplit_tiles - 1) / d.ksplit_tiles;
-  int rc = launch_igemm(d, z, s);
+  int rc = launch_splitk(d, ws, ws_floats, 1024, s);
   if (rc) return rc;
   if (db) return colsum(dY, y_out, y_act, M, N, db, s);
   return MVK_OK;
@@ -215,7 +231,7 @@ int mvk_nchw_channel_sum_acc(const float* dY, const float* y_out, int y_act, flo
 
 int mvk_gemm(const float* A, const float* B, float* C, int M, int N, int K, int ta, int tb, const float* bias,
              int bias_mod, int act, int accumulate, const float* a_act_src, int a_act, const float* c_act_src,
-             int c_act, void* stream) {
+             int c_act, float* ws, int64_t ws_floats, void* stream) {
   if (!A || !B || !C || M < 0 || N <= 0 || K <= 0) return MVK_EINVAL;
   GemmDesc d{};
   if (ta)
@@ -238,15 +254,7 @@ int mvk_gemm(const float* A, const float* B, float* C, int M, int N, int K, int 
   d.M = M;
   d.N = N;
   d.K = K;
-  int z = 1;
-  if (accumulate) {
-    int splits = pick_splits(M, N, K);
-    int ktiles = (K + BK - 1) / BK;
-    d.zmode = Z_SPLITK;
-    d.ksplit_tiles = (ktiles + splits - 1) / splits;
-    z = (ktiles + d.ksplit_tiles - 1) / d.ksplit_tiles;
-  }
-  return launch_igemm(d, z, mvk_stream(stream));
+  return launch_auto(d, ws, ws_floats, mvk_stream(stream));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -320,7 +328,7 @@ int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U
 }
 
 int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv,
-                      int u_nchw, const float* u_act_src, int u_act, void* stream) {
+                      int u_nchw, const float* u_act_src, int u_act, float* ws, int64_t ws_floats, void* stream) {
   if (!U || !V || !dWref || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0) return MVK_EINVAL;
   GemmDesc d{};
   d.a = AOperand{};
@@ -348,16 +356,12 @@ int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h
   d.M = 16 * Cu;
   d.N = Cv;
   d.K = n * h * w;
-  int splits = pick_splits(d.M, d.N, d.K);
-  int ktiles = (d.K + BK - 1) / BK;
-  d.zmode = Z_SPLITK;
-  d.ksplit_tiles = (ktiles + splits - 1) / splits;
-  int z = (ktiles + d.ksplit_tiles - 1) / d.ksplit_tiles;
-  return launch_igemm(d, z, mvk_stream(stream));
+  return launch_splitk(d, ws, ws_floats, 1024, mvk_stream(stream));
 }
 
 // dWref[ci][co][4][4] += z[n,ci]^T dY[n,(tap,co)]  (ConvTranspose2d(L,C,4,1,0) on a 1x1 input)
-int mvk_unflatten_wgrad(const float* Z, const float* dY, float* dWref, int n, int Cin, int Cout, void* stream) {
+int mvk_unflatten_wgrad(const float* Z, const float* dY, float* dWref, int n, int Cin, int Cout, float* ws,
+                        int64_t ws_floats, void* stream) {
   if (!Z || !dY || !dWref || n < 0 || Cin <= 0 || Cout <= 0) return MVK_EINVAL;
   GemmDesc d{};
   plain_a(d.a, Z, 1, Cin, Cin, n);  // A'[i=ci][kk=row] = Z[row*Cin + ci]
@@ -372,16 +376,12 @@ int mvk_unflatten_wgrad(const float* Z, const float* dY, float* dWref, int n, in
   d.M = Cin;
   d.N = 16 * Cout;
   d.K = n;
-  int splits = pick_splits(d.M, d.N, d.K, 512);
-  int ktiles = (d.K + BK - 1) / BK;
-  d.zmode = Z_SPLITK;
-  d.ksplit_tiles = (ktiles + splits - 1) / splits;
-  int z = (ktiles + d.ksplit_tiles - 1) / d.ksplit_tiles;
-  return launch_igemm(d, z, mvk_stream(stream));
+  return launch_splitk(d, ws, ws_floats, 512, mvk_stream(stream));
 }
 
 // dWref[cv][cu][4][4] += H[n,(tap,cu)]^T dY[n,cv]  (Conv2d(C,L,4,2,0) heads on a 4x4 input)
-int mvk_flatten_wgrad(const float* H, const float* dY, float* dWref, int n, int Cu, int Cv, void* stream) {
+int mvk_flatten_wgrad(const float* H, const float* dY, float* dWref, int n, int Cu, int Cv, float* ws,
+                      int64_t ws_floats, void* stream) {
   if (!H || !dY || !dWref || n < 0 || Cu <= 0 || Cv <= 0) return MVK_EINVAL;
   GemmDesc d{};
   plain_a(d.a, H, 1, 16 * Cu, 16 * Cu, n);
@@ -396,12 +396,14 @@ int mvk_flatten_wgrad(const float* H, const float* dY, float* dWref, int n, int 
   d.M = 16 * Cu;
   d.N = Cv;
   d.K = n;
-  int splits = pick_splits(d.M, d.N, d.K, 512);
-  int ktiles = (d.K + BK - 1) / BK;
-  d.zmode = Z_SPLITK;
-  d.ksplit_tiles = (ktiles + splits - 1) / splits;
-  int z = (ktiles + d.ksplit_tiles - 1) / d.ksplit_tiles;
-  return launch_igemm(d, z, mvk_stream(stream));
+  return launch_splitk(d, ws, ws_floats, 512, mvk_stream(stream));
 }
 
 }  // extern "C"
+
+extern "C" int64_t mvk_splitk_workspace_floats(int rows, int cols, int reduce_len) {
+  // at most `target` (<= 1024) slices, never more slices than k-tiles
+  long long ktiles = ((long long)reduce_len + mvk::BK - 1) / mvk::BK;
+  long long z = ktiles < 1024 ? ktiles : 1024;
+  return (int64_t)(z * (long long)rows * cols);
+}

@@ -51,6 +51,7 @@ struct Epilogue {
   int src_act;
   int atomic;
   int Cu, OH, OW;  // E_UP / E_CONVREF / E_UNFLATREF geometry
+  float* ws;       // Z_SPLITK: if set, raw partial tiles go to ws[z][m][n] and splitk_reduce_kernel finishes
 };
 
 struct GemmDesc {
@@ -485,6 +486,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmDesc d) {
   // barrier is needed) and consumed by a rolled loop: the address / activation code exists once instead of
   // 16*TM*TN times.  The tile buffers are free: the main loop ended with a barrier.
   const Epilogue& E = d.e;
+  if (E.ws) {
+    // split-K partial: plain coalesced stores of the raw accumulators into this slice's slab
+    float* slab = E.ws + (long long)blockIdx.z * d.M * d.N;
+#pragma unroll
+    for (int a = 0; a < T::TM; ++a) {
+#pragma unroll
+      for (int b = 0; b < T::TN; ++b) {
+        const int n = n0 + wn * T::WTN + b * 32 + l31;
+        const int mbase = m0 + wm * T::WTM + a * 32 + 4 * lhi;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          if (m < d.M && n < d.N) slab[(long long)m * d.N + n] = acc[a][b][r];
+        }
+      }
+    }
+    return;
+  }
   float* park = lds + tid;  // element r at park[r * 256]
 #pragma unroll
   for (int a = 0; a < T::TM; ++a) {
@@ -531,6 +550,37 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmDesc d) {
   }
 }
 
+// out[map(m,n)] (+)= epilogue(sum_z ws[z][m][n]) — deterministic split-K finish, one thread per (m,n)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const Epilogue E, int M, int N, int nz) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)M * N) return;
+  const int m = (int)(idx / N);
+  const int n = (int)(idx - (long long)m * N);
+  float v = 0.f;
+  for (int z = 0; z < nz; ++z) v += E.ws[(long long)z * M * N + idx];
+  long long off;
+  if (E.kind == E_ROWMAJOR) {
+    off = (long long)m * E.ld + n;
+  } else if (E.kind == E_CONVREF) {
+    int tap = m / E.Cu;
+    int cu = m - tap * E.Cu;
+    off = ((long long)n * E.Cu + cu) * 16 + tap;
+  } else {  // E_UNFLATREF
+    int tap = n / E.Cu;
+    int co = n - tap * E.Cu;
+    off = ((long long)m * E.Cu + co) * 16 + tap;
+  }
+  if (E.bias) v += E.bias[n % E.bias_mod];
+  v = mvk_act(v, E.act);
+  if (E.act_src) v *= mvk_act_grad_from_out(E.act_src[off], E.src_act);
+  if (E.atomic)
+    E.out[off] += v;  // "accumulate" semantics; every element is owned by exactly one thread
+  else
+    E.out[off] = v;
+}
+
 int launch_igemm(const GemmDesc& d, int zdim, hipStream_t s);
+// split-K launch: picks the slice count, uses the slab workspace when it is large enough (else atomics)
+int launch_splitk(GemmDesc& d, float* ws, long long ws_floats, int target_blocks, hipStream_t s);
 
 }  // namespace mvk

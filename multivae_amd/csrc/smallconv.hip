@@ -1,0 +1,353 @@
+// The image-producing transposed convolution (ConvTranspose2d(Cv, Cu<=4, 4, 2, 1) + Sigmoid, svhn.py:58-60) and
+// its whole backward as two per-image MFMA kernels.
+//
+// With only Cu = 3 output channels an output-stationary GEMM wastes 13/16 of every MFMA tile.  Instead each
+// workgroup takes one image and computes the *column* matrix cols[pos][(cu,kh,kw)] = V[pos][:] . W[:, (cu,kh,kw)]
+// (M = h*w positions, N = 16*Cu, K = Cv: every multiply is useful), parks it in LDS and gathers the 2x2 taps of
+// every output pixel from there (col2im without atomics).  The backward kernel stages the pre-activation
+// gradient tile once (sigmoid' applied while loading, zero halo for the padding) and runs both GEMMs that need
+// it — backward-data (im2col gather from LDS) and backward-weight (reduction over positions, accumulated in
+// registers across a persistent loop over images) — plus the bias gradient, so dU / U / V are read from HBM
+// exactly once.  v_mfma_f32_16x16x4_f32: exact fp32.
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int CU, int CV>
+struct SmallCfg {
+  static constexpr int NC = 16 * CU;   // columns (cu, kh, kw)
+  static constexpr int VS = CV + 4;    // V tile row stride in LDS (16-byte aligned rows)
+  static constexpr int CS = NC + 1;    // column-matrix row stride
+  static constexpr int WT = CV + 16;   // transposed-weight row stride (bank shift of 16 between k rows)
+  static constexpr int MT = 4;         // 16-row tiles per wave (64 positions)
+  static constexpr int NTV = CV / 16;  // 16-wide tiles over Cv
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// forward: U[n,Cu,2h,2w] = act(convT(V[n,h,w,Cv]) + b)
+// ---------------------------------------------------------------------------------------------------------
+template <int CU, int CV>
+__global__ __launch_bounds__(256) void small_up_fwd_kernel(const float* __restrict__ V, const float* __restrict__ Wref,
+                                                           const float* __restrict__ bias, float* __restrict__ U, int n,
+                                                           int h, int w, int act) {
+  using C = SmallCfg<CU, CV>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;                 // [CV][NC]  == Wref[cv][cu][tap] as is
+  float* buf = smem + CV * C::NC;   // V tile [P][VS], later the column matrix [P][CS]
+  const int P = h * w;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+  const long long img = blockIdx.x;
+  for (int i = tid; i < CV * C::NC; i += 256) Ws[i] = Wref[i];
+  const float4* src = reinterpret_cast<const float4*>(V + img * P * CV);
+  for (int idx = tid; idx < P * CV / 4; idx += 256) {
+    const int pos = idx / (CV / 4), q = idx - pos * (CV / 4);
+    *reinterpret_cast<float4*>(buf + pos * C::VS + 4 * q) = src[idx];
+  }
+  __syncthreads();
+  f32x4 acc[C::MT][CU];
+#pragma unroll
+  for (int a = 0; a < C::MT; ++a)
+#pragma unroll
+    for (int b = 0; b < CU; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool active = wave * 64 < P;
+  if (active) {
+#pragma unroll 2
+    for (int ks = 0; ks < CV / 4; ++ks) {
+      const int k = ks * 4 + lq;
+      float av[C::MT], bv[CU];
+#pragma unroll
+      for (int a = 0; a < C::MT; ++a) av[a] = buf[(wave * 64 + a * 16 + l15) * C::VS + k];
+#pragma unroll
+      for (int b = 0; b < CU; ++b) bv[b] = Ws[k * C::NC + b * 16 + l15];
+#pragma unroll
+      for (int a = 0; a < C::MT; ++a)
+#pragma unroll
+        for (int b = 0; b < CU; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+  }
+  __syncthreads();  // every wave is done with the V tile
+  if (active) {
+#pragma unroll
+    for (int a = 0; a < C::MT; ++a)
+#pragma unroll
+      for (int b = 0; b < CU; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) buf[(wave * 64 + a * 16 + lq * 4 + r) * C::CS + b * 16 + l15] = acc[a][b][r];
+  }
+  __syncthreads();
+  const int H2 = 2 * h, W2 = 2 * w;
+  const int per_img = CU * H2 * W2;
+  float* out = U + img * per_img;
+  for (int o = tid; o < per_img; o += 256) {
+    const int cu = o / (H2 * W2);
+    const int rem = o - cu * (H2 * W2);
+    const int oh = rem / W2, ow = rem - oh * W2;
+    const int ph = oh & 1, pw = ow & 1, i0 = oh >> 1, j0 = ow >> 1;
+    float s = bias ? bias[cu] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int ih = i0 + ph - a, kh = (1 - ph) + 2 * a;
+      if (ih < 0 || ih >= h) continue;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int iw = j0 + pw - b, kw = (1 - pw) + 2 * b;
+        if (iw < 0 || iw >= w) continue;
+        s += buf[(ih * w + iw) * C::CS + cu * 16 + kh * 4 + kw];
+      }
+    }
+    out[o] = mvk_act(s, act);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward: dV = down(dUpre) * act'(V),  partial dW / db per workgroup (persistent over images)
+// ---------------------------------------------------------------------------------------------------------
+template <int CU, int CV>
+__global__ __launch_bounds__(256) void small_up_bwd_kernel(const float* __restrict__ dU, const float* __restrict__ Uout,
+                                                           int u_act, const float* __restrict__ V, int v_act,
+                                                           const float* __restrict__ Wref, float* __restrict__ dV,
+                                                           float* __restrict__ partial, int n, int h, int w) {
+  using C = SmallCfg<CU, CV>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int P = h * w, DH = 2 * h + 2, DW = 2 * w + 2;
+  float* Wt = smem;                       // [NC][WT]: Wt[k=(cu,tap)][cv] = Wref[cv][k]
+  float* Ds = Wt + C::NC * C::WT;         // [CU][DH][DW] pre-activation gradient with zero halo
+  float* Vs = Ds + ((CU * DH * DW + 3) & ~3);  // [P][VS]
+  int* posoff = reinterpret_cast<int*>(Vs + P * C::VS);  // [P]: (2i)*DW + 2j
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+  for (int i = tid; i < CV * C::NC; i += 256) {
+    const int cv = i / C::NC, k = i - cv * C::NC;
+    Wt[k * C::WT + cv] = Wref[i];
+  }
+  for (int p = tid; p < P; p += 256) posoff[p] = (2 * (p / w)) * DW + 2 * (p % w);
+  const bool active = wave * 64 < P;
+
+  f32x4 accw[C::NTV][CU];
+#pragma unroll
+  for (int a = 0; a < C::NTV; ++a)
+#pragma unroll
+    for (int b = 0; b < CU; ++b) accw[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbl[CU];
+#pragma unroll
+  for (int c = 0; c < CU; ++c) dbl[c] = 0.f;
+
+  const int H2 = 2 * h, W2 = 2 * w;
+  for (long long img = blockIdx.x; img < n; img += gridDim.x) {
+    __syncthreads();  // previous image's tiles are no longer read
+    // --- stage dUpre (NCHW) with halo; sigmoid' (or any act') applied on the fly; bias-gradient partials
+    const float* du = dU + img * CU * H2 * W2;
+    const float* uo = Uout + img * CU * H2 * W2;
+    for (int idx = tid; idx < CU * DH * DW; idx += 256) {
+      const int cu = idx / (DH * DW);
+      const int rem = idx - cu * (DH * DW);
+      const int y = rem / DW, x = rem - y * DW;
+      const int oh = y - 1, ow = x - 1;
+      float v = 0.f;
+      if (oh >= 0 && oh < H2 && ow >= 0 && ow < W2) {
+        const int off = (cu * H2 + oh) * W2 + ow;
+        v = du[off] * mvk_act_grad_from_out(uo[off], u_act);
+      }
+      Ds[idx] = v;
+#pragma unroll
+      for (int c = 0; c < CU; ++c)
+        if (c == cu) dbl[c] += v;
+    }
+    const float4* src = reinterpret_cast<const float4*>(V + img * P * CV);
+    for (int idx = tid; idx < P * CV / 4; idx += 256) {
+      const int pos = idx / (CV / 4), q = idx - pos * (CV / 4);
+      *reinterpret_cast<float4*>(Vs + pos * C::VS + 4 * q) = src[idx];
+    }
+    __syncthreads();
+    if (!active) continue;
+    // --- backward data: dV[pos][cv] = sum_{k=(cu,kh,kw)} dUpre[cu][2i-1+kh][2j-1+kw] * W[cv][k]
+    f32x4 acc[C::MT][C::NTV];
+#pragma unroll
+    for (int a = 0; a < C::MT; ++a)
+#pragma unroll
+      for (int b = 0; b < C::NTV; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int po[C::MT];
+#pragma unroll
+    for (int a = 0; a < C::MT; ++a) po[a] = posoff[wave * 64 + a * 16 + l15];
+#pragma unroll 2
+    for (int ks = 0; ks < C::NC / 4; ++ks) {
+      const int k = ks * 4 + lq;
+      const int koff = (k >> 4) * DH * DW + ((k >> 2) & 3) * DW + (k & 3);
+      float av[C::MT], bv[C::NTV];
+#pragma unroll
+      for (int a = 0; a < C::MT; ++a) av[a] = Ds[koff + po[a]];
+#pragma unroll
+      for (int b = 0; b < C::NTV; ++b) bv[b] = Wt[k * C::WT + b * 16 + l15];
+#pragma unroll
+      for (int a = 0; a < C::MT; ++a)
+#pragma unroll
+        for (int b = 0; b < C::NTV; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+    float* dv = dV + img * P * CV;
+#pragma unroll
+    for (int a = 0; a < C::MT; ++a)
+#pragma unroll
+      for (int b = 0; b < C::NTV; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pos = wave * 64 + a * 16 + lq * 4 + r, cv = b * 16 + l15;
+          dv[pos * CV + cv] = acc[a][b][r] * mvk_act_grad_from_out(Vs[pos * C::VS + cv], v_act);
+        }
+    // --- backward weight: dW[cv][k] += sum_pos V[pos][cv] * dUpre(gathered)[pos][k]; this wave's 64 positions
+#pragma unroll 2
+    for (int ks = 0; ks < 16; ++ks) {
+      const int kpos = wave * 64 + ks * 4 + lq;
+      const int pbase = posoff[kpos];
+      float av[C::NTV], bv[CU];
+#pragma unroll
+      for (int a = 0; a < C::NTV; ++a) av[a] = Vs[kpos * C::VS + a * 16 + l15];
+#pragma unroll
+      for (int b = 0; b < CU; ++b) bv[b] = Ds[b * DH * DW + (l15 >> 2) * DW + (l15 & 3) + pbase];
+#pragma unroll
+      for (int a = 0; a < C::NTV; ++a)
+#pragma unroll
+        for (int b = 0; b < CU; ++b)
+          accw[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], accw[a][b], 0, 0, 0);
+    }
+  }
+  // --- cross-wave reduction of the weight / bias partials, one slab per workgroup
+  __syncthreads();
+  float* red = smem;  // [4 waves][CV*NC] — reuses Wt/Ds/Vs (needs 4*CV*NC floats)
+#pragma unroll
+  for (int a = 0; a < C::NTV; ++a)
+#pragma unroll
+    for (int b = 0; b < CU; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cv = a * 16 + lq * 4 + r, col = b * 16 + l15;
+        red[wave * CV * C::NC + cv * C::NC + col] = accw[a][b][r];
+      }
+  __syncthreads();
+  float* slab = partial + (long long)blockIdx.x * (CV * C::NC + CU);
+  for (int i = tid; i < CV * C::NC; i += 256)
+    slab[i] = red[i] + red[CV * C::NC + i] + red[2 * CV * C::NC + i] + red[3 * CV * C::NC + i];
+  __syncthreads();
+  // bias partials
+  float* bred = smem;
+#pragma unroll
+  for (int c = 0; c < CU; ++c) {
+    const float s = wave_sum(dbl[c]);
+    if (lane == 0) bred[c * 4 + wave] = s;
+  }
+  __syncthreads();
+  if (tid < CU) slab[CV * C::NC + tid] = bred[tid * 4] + bred[tid * 4 + 1] + bred[tid * 4 + 2] + bred[tid * 4 + 3];
+}
+
+// dWref += sum_b partial[b][0:CV*NC];  db += sum_b partial[b][CV*NC + cu]
+__global__ void small_up_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int nw, int ncu,
+                                           float* __restrict__ dWref, float* __restrict__ db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nw + ncu) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[(long long)b * (nw + ncu) + i];
+  if (i < nw)
+    dWref[i] += s;
+  else if (db)
+    db[i - nw] += s;
+}
+
+template <int CU, int CV>
+static size_t fwd_lds(int P) {
+  using C = SmallCfg<CU, CV>;
+  const size_t tile = (size_t)P * (C::VS > C::CS ? C::VS : C::CS);
+  return (CV * C::NC + tile) * sizeof(float);
+}
+template <int CU, int CV>
+static size_t bwd_lds(int h, int w) {
+  using C = SmallCfg<CU, CV>;
+  const int P = h * w, DH = 2 * h + 2, DW = 2 * w + 2;
+  size_t fl = (size_t)C::NC * C::WT + ((CU * DH * DW + 3) & ~3) + (size_t)P * C::VS + P;
+  const size_t red = (size_t)4 * CV * C::NC;
+  if (fl < red) fl = red;
+  return fl * sizeof(float);
+}
+
+static bool supported(int h, int w, int Cu, int Cv) {
+  const int P = h * w;
+  return Cu >= 1 && Cu <= 4 && (Cv == 16 || Cv == 32 || Cv == 64) && P % 64 == 0 && P <= 256;
+}
+
+template <int CU, int CV>
+static int launch_fwd(const float* V, const float* Wref, const float* bias, float* U, int n, int h, int w, int act,
+                      hipStream_t s) {
+  const size_t lds = fwd_lds<CU, CV>(h * w);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_fwd_kernel<CU, CV>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((small_up_fwd_kernel<CU, CV>), dim3(n), dim3(256), lds, s, V, Wref, bias, U, n, h, w, act);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+template <int CU, int CV>
+static int launch_bwd(const float* dU, const float* Uout, int u_act, const float* V, int v_act, const float* Wref,
+                      float* dV, float* dWref, float* db, float* ws, int64_t ws_floats, int n, int h, int w,
+                      hipStream_t s) {
+  using C = SmallCfg<CU, CV>;
+  const int slab = CV * C::NC + CU;
+  int grid = n < 512 ? n : 512;
+  if ((int64_t)grid * slab > ws_floats) grid = (int)(ws_floats / slab);
+  if (grid < 1) return MVK_EINVAL;
+  const size_t lds = bwd_lds<CU, CV>(h, w);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_bwd_kernel<CU, CV>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((small_up_bwd_kernel<CU, CV>), dim3(grid), dim3(256), lds, s, dU, Uout, u_act, V, v_act, Wref, dV,
+                     ws, n, h, w);
+  MVK_CHECK_LAUNCH();
+  const int total = CV * C::NC + CU;
+  hipLaunchKernelGGL(small_up_bwd_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, ws, grid, CV * C::NC, CU,
+                     dWref, db);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+#define MVK_SMALL_DISPATCH(FN, ...)                                  \
+  switch (Cu * 100 + Cv) {                                           \
+    case 116: return FN<1, 16>(__VA_ARGS__);                         \
+    case 132: return FN<1, 32>(__VA_ARGS__);                         \
+    case 164: return FN<1, 64>(__VA_ARGS__);                         \
+    case 216: return FN<2, 16>(__VA_ARGS__);                         \
+    case 232: return FN<2, 32>(__VA_ARGS__);                         \
+    case 264: return FN<2, 64>(__VA_ARGS__);                         \
+    case 316: return FN<3, 16>(__VA_ARGS__);                         \
+    case 332: return FN<3, 32>(__VA_ARGS__);                         \
+    case 364: return FN<3, 64>(__VA_ARGS__);                         \
+    case 416: return FN<4, 16>(__VA_ARGS__);                         \
+    case 432: return FN<4, 32>(__VA_ARGS__);                         \
+    case 464: return FN<4, 64>(__VA_ARGS__);                         \
+    default: return MVK_EINVAL;                                      \
+  }
+
+}  // namespace
+
+extern "C" {
+
+int mvk_conv4s2_small_up_supported(int h, int w, int Cu, int Cv) { return supported(h, w, Cu, Cv) ? 1 : 0; }
+
+int mvk_conv4s2_small_up_fwd(const float* V, const float* Wref, const float* bias, float* U, int n, int h, int w,
+                             int Cu, int Cv, int act, void* stream) {
+  if (!V || !Wref || !U || n < 0 || !supported(h, w, Cu, Cv) || !mvk_aligned16(V)) return MVK_EINVAL;
+  if (n == 0) return MVK_OK;
+  hipStream_t s = mvk_stream(stream);
+  MVK_SMALL_DISPATCH(launch_fwd, V, Wref, bias, U, n, h, w, act, s)
+}
+
+int mvk_conv4s2_small_up_bwd(const float* dU, const float* Uout, int u_act, const float* V, int v_act,
+                             const float* Wref, float* dV, float* dWref, float* db, float* ws, int64_t ws_floats,
+                             int n, int h, int w, int Cu, int Cv, void* stream) {
+  if (!dU || !Uout || !V || !Wref || !dV || !dWref || !ws || n < 0 || !supported(h, w, Cu, Cv) || !mvk_aligned16(V))
+    return MVK_EINVAL;
+  if (n == 0) return MVK_OK;
+  hipStream_t s = mvk_stream(stream);
+  MVK_SMALL_DISPATCH(launch_bwd, dU, Uout, u_act, V, v_act, Wref, dV, dWref, db, ws, ws_floats, n, h, w, s)
+}
+
+}  // extern "C"

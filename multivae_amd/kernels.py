@@ -20,6 +20,8 @@ RELU, SIGMOID, NONE = ACT["relu"], ACT["sigmoid"], ACT["none"]
 # bench.py sets PROFILE["recon_nll"] = [] to collect (start, end) HIP events around the fused reconstruction-NLL
 # launch on the stream it is launched on (roofline measurement inside the timed region).
 PROFILE = {}
+# accumulate parameter gradients directly into pre-existing .grad buffers (see _grad_target)
+DIRECT_GRAD = True
 
 
 def _c(t):
@@ -36,6 +38,20 @@ def _zeros(shape, like):
     return torch.zeros(shape, dtype=torch.float32, device=like.device)
 
 
+_WS = {}
+WS_FLOATS = 16 * 1024 * 1024  # 64 MB of split-K slab scratch per device (largest need on the path: 8.4M floats)
+
+
+def _ws(like):
+    """Caller-owned split-K scratch (see mvk.h): one persistent buffer per device, reused by every launch on
+    the stream (launches are stream-ordered, so reuse is safe)."""
+    t = _WS.get(like.device)
+    if t is None:
+        t = torch.empty(WS_FLOATS, dtype=torch.float32, device=like.device)
+        _WS[like.device] = t
+    return t
+
+
 # =====================================================================================================
 # thin launch helpers (no autograd)
 # =====================================================================================================
@@ -43,7 +59,8 @@ def linear_fwd(x2, w, b, act):
     M, K = x2.shape
     N = w.shape[0]
     y = _new((M, N), x2)
-    call("mvk_linear_fwd", ptr(x2), ptr(w), ptr(b), ptr(y), M, N, K, act, stream_ptr())
+    ws = _ws(x2)
+    call("mvk_linear_fwd", ptr(x2), ptr(w), ptr(b), ptr(y), M, N, K, act, ptr(ws), ws.numel(), stream_ptr())
     return y
 
 
@@ -51,33 +68,52 @@ def linear_bwd_data(dy, w, y_out=None, y_act=NONE, prev_out=None, prev_act=NONE,
     M, N = dy.shape
     K = w.shape[1]
     dx = out if out is not None else _new((M, K), dy)
+    ws = _ws(dy)
     call("mvk_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), M, N, K, ptr(y_out), y_act, ptr(prev_out), prev_act,
-         1 if accumulate else 0, stream_ptr())
+         1 if accumulate else 0, ptr(ws), ws.numel(), stream_ptr())
     return dx
 
 
-def linear_bwd_weight(dy, x2, y_out=None, y_act=NONE, want_bias=True):
+def _grad_target(p):
+    """Where a parameter's gradient is accumulated.  If the parameter already owns a contiguous fp32 .grad
+    (e.g. a view of the flat gradient buffer of trainers.FlatParams) the kernels accumulate straight into it
+    and autograd gets None for this input (no zero-fill, no extra add kernel); otherwise a fresh zero buffer is
+    returned to autograd as usual.  Both ways the visible semantics are `p.grad += dL/dp`."""
+    g = p.grad
+    if DIRECT_GRAD and g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.shape == p.shape \
+            and g.device == p.device:
+        return g, None
+    z = _zeros(p.shape, p)
+    return z, z
+
+
+def linear_bwd_weight(dy, x2, w, b, y_out=None, y_act=NONE):
+    """-> (grad to return for w, grad to return for b)"""
     M, N = dy.shape
     K = x2.shape[1]
-    dw = _zeros((N, K), dy)
-    db = _zeros((N,), dy) if want_bias else None
-    call("mvk_linear_bwd_weight", ptr(dy), ptr(x2), ptr(dw), ptr(db), M, N, K, ptr(y_out), y_act, stream_ptr())
-    return dw, db
+    dw, rw = _grad_target(w)
+    db, rb = _grad_target(b) if b is not None else (None, None)
+    ws = _ws(dy)
+    call("mvk_linear_bwd_weight", ptr(dy), ptr(x2), ptr(dw), ptr(db), M, N, K, ptr(y_out), y_act, ptr(ws),
+         ws.numel(), stream_ptr())
+    return rw, rb
 
 
 def gemm(a, b, M, N, K, ta=False, tb=False, bias=None, bias_mod=0, act=NONE, out=None, accumulate=False,
          a_act_src=None, a_act=NONE, c_act_src=None, c_act=NONE):
     c = out if out is not None else _new((M, N), a)
+    ws = _ws(a)
     call("mvk_gemm", ptr(a), ptr(b), ptr(c), M, N, K, int(ta), int(tb), ptr(bias), bias_mod, act,
-         1 if accumulate else 0, ptr(a_act_src), a_act, ptr(c_act_src), c_act, stream_ptr())
+         1 if accumulate else 0, ptr(a_act_src), a_act, ptr(c_act_src), c_act, ptr(ws), ws.numel(), stream_ptr())
     return c
 
 
-def colsum(dy2, y_out=None, y_act=NONE):
+def colsum(dy2, b, y_out=None, y_act=NONE):
+    """bias gradient: b.grad += column sums of dy2 [M,N]; returns what autograd should get for b."""
     M, N = dy2.shape
-    db = _zeros((N,), dy2)
+    db, rb = _grad_target(b)
     call("mvk_colsum_acc", ptr(dy2), ptr(y_out), y_act, ptr(db), M, N, stream_ptr())
-    return db
+    return rb
 
 
 def pack_conv(wref, want_down=True, want_up=True):
@@ -104,11 +140,12 @@ def conv_up(V, wup, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src=Non
     return U
 
 
-def conv_wgrad(U, V, n, h, w, Cu, Cv, u_nchw=False, u_act_src=None, u_act=NONE):
-    dw = _zeros((Cv, Cu, 4, 4), V)
+def conv_wgrad(U, V, wparam, n, h, w, Cu, Cv, u_nchw=False, u_act_src=None, u_act=NONE):
+    dw, rw = _grad_target(wparam)
+    ws = _ws(V)
     call("mvk_conv4s2_wgrad", ptr(U), ptr(V), ptr(dw), n, h, w, Cu, Cv, int(u_nchw), ptr(u_act_src), u_act,
-         stream_ptr())
-    return dw
+         ptr(ws), ws.numel(), stream_ptr())
+    return rw
 
 
 # =====================================================================================================
@@ -145,8 +182,8 @@ class MLPEncoderFn(Function):
         dmu, dlv = _c(dmu), _c(dlv)
         h = acts[-1]
         grads = [None] * len(params)
-        grads[-4], grads[-3] = linear_bwd_weight(dmu, h)
-        grads[-2], grads[-1] = linear_bwd_weight(dlv, h)
+        grads[-4], grads[-3] = linear_bwd_weight(dmu, h, we, be)
+        grads[-2], grads[-1] = linear_bwd_weight(dlv, h, wl, bl)
         # gradient w.r.t. the last hidden layer's PRE-activation: both heads, ReLU' fused in the epilogue
         prev_src, prev_act = (h, RELU) if n > 0 else (None, NONE)
         need_dx = ctx.needs_input_grad[0]
@@ -156,7 +193,7 @@ class MLPEncoderFn(Function):
             linear_bwd_data(dlv, wl, prev_out=prev_src, prev_act=prev_act, out=dh, accumulate=True)
         for i in range(n - 1, -1, -1):
             w, inp = params[2 * i], acts[i]
-            grads[2 * i], grads[2 * i + 1] = linear_bwd_weight(dh, inp)
+            grads[2 * i], grads[2 * i + 1] = linear_bwd_weight(dh, inp, w, params[2 * i + 1])
             if i > 0:
                 dh = linear_bwd_data(dh, w, prev_out=acts[i], prev_act=RELU)
             elif need_dx:
@@ -174,18 +211,18 @@ class MLPDecoderFn(Function):
         z2 = _c(z.reshape(-1, L))
         h = linear_fwd(z2, w0, b0, RELU)
         out = linear_fwd(h, w1, b1, SIGMOID)
-        ctx.save_for_backward(z2, h, out, w0, w1)
+        ctx.save_for_backward(z2, h, out, w0, b0, w1, b1)
         ctx.z_shape = z.shape
         return out.view(*z.shape[:-1], *input_dim)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
-        z2, h, out, w0, w1 = ctx.saved_tensors
+        z2, h, out, w0, b0, w1, b1 = ctx.saved_tensors
         dout = _c(dout).view(out.shape)
-        dw1, db1 = linear_bwd_weight(dout, h, y_out=out, y_act=SIGMOID)
+        dw1, db1 = linear_bwd_weight(dout, h, w1, b1, y_out=out, y_act=SIGMOID)
         dh = linear_bwd_data(dout, w1, y_out=out, y_act=SIGMOID, prev_out=h, prev_act=RELU)
-        dw0, db0 = linear_bwd_weight(dh, z2)
+        dw0, db0 = linear_bwd_weight(dh, z2, w0, b0)
         dz = None
         if ctx.needs_input_grad[0]:
             dz = linear_bwd_data(dh, w0).view(ctx.z_shape)
@@ -218,36 +255,37 @@ class SVHNEncoderFn(Function):
         h3f = h3.view(B, Kf)
         mu = gemm(h3f, wdc1, B, L, Kf, bias=bc1, bias_mod=L)
         lv = gemm(h3f, wdc2, B, L, Kf, bias=bc2, bias_mod=L)
-        ctx.save_for_backward(x, h1, h2, h3, wu1, wu2, wdc1, wdc2)
+        ctx.save_for_backward(x, h1, h2, h3, wu1, wu2, wdc1, wdc2, w0, b0, w1, b1, w2, b2, wc1, bc1, wc2, bc2)
         ctx.dims = (B, H, W, chans, L)
         return mu, lv
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dmu, dlv):
-        x, h1, h2, h3, wu1, wu2, wdc1, wdc2 = ctx.saved_tensors
+        x, h1, h2, h3, wu1, wu2, wdc1, wdc2, w0, b0, w1, b1, w2, b2, wc1, bc1, wc2, bc2 = ctx.saved_tensors
         B, H, W, ch, L = ctx.dims
         dmu, dlv = _c(dmu).view(B, L), _c(dlv).view(B, L)
         Kf = 16 * ch[3]
         h3f = h3.view(B, Kf)
         # heads
-        dwc1 = _zeros((L, ch[3], 4, 4), x)
-        dwc2 = _zeros((L, ch[3], 4, 4), x)
-        call("mvk_flatten_wgrad", ptr(h3f), ptr(dmu), ptr(dwc1), B, ch[3], L, stream_ptr())
-        call("mvk_flatten_wgrad", ptr(h3f), ptr(dlv), ptr(dwc2), B, ch[3], L, stream_ptr())
-        dbc1, dbc2 = colsum(dmu), colsum(dlv)
+        tw1, dwc1 = _grad_target(wc1)
+        tw2, dwc2 = _grad_target(wc2)
+        ws = _ws(x)
+        call("mvk_flatten_wgrad", ptr(h3f), ptr(dmu), ptr(tw1), B, ch[3], L, ptr(ws), ws.numel(), stream_ptr())
+        call("mvk_flatten_wgrad", ptr(h3f), ptr(dlv), ptr(tw2), B, ch[3], L, ptr(ws), ws.numel(), stream_ptr())
+        dbc1, dbc2 = colsum(dmu, bc1), colsum(dlv, bc2)
         # d h3 (pre-activation): dmu Wd1^T + dlv Wd2^T, ReLU'(h3) fused
         dh3 = gemm(dmu, wdc1, B, Kf, L, tb=True, c_act_src=h3f, c_act=RELU)
         gemm(dlv, wdc2, B, Kf, L, tb=True, c_act_src=h3f, c_act=RELU, out=dh3, accumulate=True)
         dh3 = dh3.view(B, H // 8, W // 8, ch[3])
-        dw2 = conv_wgrad(h2, dh3, B, H // 8, W // 8, ch[2], ch[3])
-        db2 = colsum(dh3.view(-1, ch[3]))
+        dw2 = conv_wgrad(h2, dh3, w2, B, H // 8, W // 8, ch[2], ch[3])
+        db2 = colsum(dh3.view(-1, ch[3]), b2)
         dh2 = conv_up(dh3, wu2, None, B, H // 8, W // 8, ch[2], ch[3], u_act_src=h2, u_act=RELU)
-        dw1 = conv_wgrad(h1, dh2, B, H // 4, W // 4, ch[1], ch[2])
-        db1 = colsum(dh2.view(-1, ch[2]))
+        dw1 = conv_wgrad(h1, dh2, w1, B, H // 4, W // 4, ch[1], ch[2])
+        db1 = colsum(dh2.view(-1, ch[2]), b1)
         dh1 = conv_up(dh2, wu1, None, B, H // 4, W // 4, ch[1], ch[2], u_act_src=h1, u_act=RELU)
-        dw0 = conv_wgrad(x, dh1, B, H // 2, W // 2, ch[0], ch[1], u_nchw=True)
-        db0 = colsum(dh1.view(-1, ch[1]))
+        dw0 = conv_wgrad(x, dh1, w0, B, H // 2, W // 2, ch[0], ch[1], u_nchw=True)
+        db0 = colsum(dh1.view(-1, ch[1]), b0)
         dx = None
         if ctx.needs_input_grad[0]:
             raise _lib.MvkError("gradient w.r.t. the encoder input image is not implemented")
@@ -272,9 +310,15 @@ class SVHNDecoderFn(Function):
         g2 = conv_up(g1, wu1, b1, n, 4, 4, C2, C1, RELU)  # [n,8,8,C2]
         g3 = conv_up(g2, wu2, b2, n, 8, 8, C3, C2, RELU)  # [n,16,16,C3]
         out = _new((n, C4, 32, 32), z2)
-        call("mvk_conv4s2_up_nchw_small", ptr(g3), ptr(w3), ptr(b3), ptr(out), n, 16, 16, C4, C3, SIGMOID,
-             stream_ptr())
-        ctx.save_for_backward(z2, g1, g2, g3, out, wp0, wd1, wd2, wd3)
+        small = bool(_lib.load().mvk_conv4s2_small_up_supported(16, 16, C4, C3))
+        if small:  # per-image MFMA column-matrix kernel (smallconv.hip)
+            call("mvk_conv4s2_small_up_fwd", ptr(g3), ptr(w3), ptr(b3), ptr(out), n, 16, 16, C4, C3, SIGMOID,
+                 stream_ptr())
+        else:
+            call("mvk_conv4s2_up_nchw_small", ptr(g3), ptr(w3), ptr(b3), ptr(out), n, 16, 16, C4, C3, SIGMOID,
+                 stream_ptr())
+        ctx.small = small
+        ctx.save_for_backward(z2, g1, g2, g3, out, wp0, wd1, wd2, wd3, w0, b0, w1, b1, w2, b2, w3, b3)
         ctx.dims = (n, L, C1, C2, C3, C4)
         ctx.z_shape = z.shape
         return out.view(*z.shape[:-1], C4, 32, 32)
@@ -282,25 +326,34 @@ class SVHNDecoderFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
-        z2, g1, g2, g3, out, wp0, wd1, wd2, wd3 = ctx.saved_tensors
+        z2, g1, g2, g3, out, wp0, wd1, wd2, wd3, w0, b0, w1, b1, w2, b2, w3, b3 = ctx.saved_tensors
         n, L, C1, C2, C3, C4 = ctx.dims
         dout = _c(dout).view(out.shape)
-        # last layer: dpre = dout * out(1-out) applied while loading (u_act_src)
-        dw3 = conv_wgrad(dout, g3, n, 16, 16, C4, C3, u_nchw=True, u_act_src=out, u_act=SIGMOID)
-        db3 = _zeros((C4,), z2)
-        call("mvk_nchw_channel_sum_acc", ptr(dout), ptr(out), SIGMOID, ptr(db3), n, C4, 32 * 32, stream_ptr())
-        dg3 = conv_down(dout, wd3, None, n, 16, 16, C4, C3, NONE, u_nchw=True, u_act_src=out, u_act=SIGMOID,
-                        v_act_src=g3, v_act=RELU)
-        dw2 = conv_wgrad(dg3, g2, n, 8, 8, C3, C2)
-        db2 = colsum(dg3.view(-1, C3))
+        # last layer: dpre = dout * out(1-out) applied while loading
+        if ctx.small:  # backward-data + backward-weight + bias gradient in ONE pass over dout / out / g3
+            tw3, dw3 = _grad_target(w3)
+            tb3, db3 = _grad_target(b3)
+            dg3 = _new((n, 16, 16, C3), z2)
+            ws = _ws(z2)
+            call("mvk_conv4s2_small_up_bwd", ptr(dout), ptr(out), SIGMOID, ptr(g3), RELU, ptr(w3), ptr(dg3), ptr(tw3),
+                 ptr(tb3), ptr(ws), ws.numel(), n, 16, 16, C4, C3, stream_ptr())
+        else:
+            dw3 = conv_wgrad(dout, g3, w3, n, 16, 16, C4, C3, u_nchw=True, u_act_src=out, u_act=SIGMOID)
+            tb3, db3 = _grad_target(b3)
+            call("mvk_nchw_channel_sum_acc", ptr(dout), ptr(out), SIGMOID, ptr(tb3), n, C4, 32 * 32, stream_ptr())
+            dg3 = conv_down(dout, wd3, None, n, 16, 16, C4, C3, NONE, u_nchw=True, u_act_src=out, u_act=SIGMOID,
+                            v_act_src=g3, v_act=RELU)
+        dw2 = conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2)
+        db2 = colsum(dg3.view(-1, C3), b2)
         dg2 = conv_down(dg3, wd2, None, n, 8, 8, C3, C2, NONE, v_act_src=g2, v_act=RELU)
-        dw1 = conv_wgrad(dg2, g1, n, 4, 4, C2, C1)
-        db1 = colsum(dg2.view(-1, C2))
+        dw1 = conv_wgrad(dg2, g1, w1, n, 4, 4, C2, C1)
+        db1 = colsum(dg2.view(-1, C2), b1)
         dg1 = conv_down(dg2, wd1, None, n, 4, 4, C2, C1, NONE, v_act_src=g1, v_act=RELU)
         dg1f = dg1.view(n, 16 * C1)
-        dw0 = _zeros((L, C1, 4, 4), z2)
-        call("mvk_unflatten_wgrad", ptr(z2), ptr(dg1f), ptr(dw0), n, L, C1, stream_ptr())
-        db0 = colsum(dg1.view(-1, C1))
+        tw0, dw0 = _grad_target(w0)
+        ws = _ws(z2)
+        call("mvk_unflatten_wgrad", ptr(z2), ptr(dg1f), ptr(tw0), n, L, C1, ptr(ws), ws.numel(), stream_ptr())
+        db0 = colsum(dg1.view(-1, C1), b0)
         dz = None
         if ctx.needs_input_grad[0]:
             dz = gemm(dg1f, wp0, n, L, 16 * C1, tb=True).view(ctx.z_shape)

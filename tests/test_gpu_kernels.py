@@ -65,9 +65,15 @@ def test_linear_fwd_bwd(K, M, N, K_, act):
     y_src = y if a else None
     dx = K.linear_bwd_data(dyd, wd, y_out=y_src, y_act=a)
     close(dx, xr.grad, what="linear bwd data")
-    dw, db = K.linear_bwd_weight(dyd, xd, y_out=y_src, y_act=a)
+    dw, db = K.linear_bwd_weight(dyd, xd, wd, bd, y_out=y_src, y_act=a)
     close(dw, wr.grad, what="linear bwd weight")
     close(db, br.grad, what="linear bwd bias")
+    # direct accumulation into a pre-existing .grad (flat-buffer views): p.grad += dL/dp, autograd gets None
+    wd.grad, bd.grad = torch.ones_like(wd), torch.ones_like(bd)
+    r = K.linear_bwd_weight(dyd, xd, wd, bd, y_out=y_src, y_act=a)
+    assert r == (None, None)
+    close(wd.grad - 1, wr.grad, rtol=2e-4, what="direct-accumulated weight grad")
+    close(bd.grad - 1, br.grad, rtol=2e-4, what="direct-accumulated bias grad")
 
 
 def test_linear_bwd_data_fused_prev_act_and_accumulate(K):
@@ -149,9 +155,10 @@ def test_conv_down_up_wgrad(K, n, h, w, Cu, Cv):
     # wgrad: d/dW of sum(conv(U) * V)
     Wr = Wc.clone().requires_grad_()
     (F.conv2d(U, Wr, None, stride=2, padding=1) * V).sum().backward()
-    got = K.conv_wgrad(nhwc(U).to(d), nhwc(V).to(d), n, h, w, Cu, Cv)
+    Wd = Wc.to(d)
+    got = K.conv_wgrad(nhwc(U).to(d), nhwc(V).to(d), Wd, n, h, w, Cu, Cv)
     close(got, Wr.grad, what="conv wgrad")
-    got4 = K.conv_wgrad(U.to(d), nhwc(V).to(d), n, h, w, Cu, Cv, u_nchw=True)
+    got4 = K.conv_wgrad(U.to(d), nhwc(V).to(d), Wd, n, h, w, Cu, Cv, u_nchw=True)
     close(got4, Wr.grad, what="conv wgrad nchw src")
 
 
@@ -484,3 +491,34 @@ def test_adam_matches_oracle(K):
         K.adam_step(pd, gr.to(d), md, vd, step, 1e-3, grad_scale=0.5)
     close(pd, p, rtol=1e-6, what="adam params")
     close(vd, v, rtol=1e-6, what="adam v")
+
+
+@pytest.mark.parametrize("n,h,w,Cu,Cv", [(3, 16, 16, 3, 32), (700, 16, 16, 3, 32), (5, 8, 8, 1, 16), (2, 16, 8, 4, 64)])
+def test_small_up_fwd_bwd(K, n, h, w, Cu, Cv):
+    """The per-image MFMA kernels of the image-producing layer (smallconv.hip) against torch CPU."""
+    from multivae_amd import _lib
+    from multivae_amd._lib import call, ptr, stream_ptr
+
+    assert _lib.load().mvk_conv4s2_small_up_supported(h, w, Cu, Cv)
+    gen = g(n + Cu)
+    V = torch.relu(torch.randn(n, Cv, h, w, generator=gen))
+    Wt = torch.randn(Cv, Cu, 4, 4, generator=gen) / math.sqrt(4 * Cv)
+    b = torch.randn(Cu, generator=gen)
+    dout = torch.randn(n, Cu, 2 * h, 2 * w, generator=gen)
+    Vr, Wr, br = V.clone().requires_grad_(), Wt.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = torch.sigmoid(F.conv_transpose2d(Vr, Wr, br, stride=2, padding=1))
+    ref.backward(dout)
+    d = dev()
+    Vd, Wd, bd, dod = nhwc(V).to(d), Wt.to(d), b.to(d), dout.to(d)
+    out = torch.empty(n, Cu, 2 * h, 2 * w, device=d)
+    call("mvk_conv4s2_small_up_fwd", ptr(Vd), ptr(Wd), ptr(bd), ptr(out), n, h, w, Cu, Cv, 2, stream_ptr())
+    close(out, ref, what="small up fwd")
+    dV = torch.empty(n, h, w, Cv, device=d)
+    dW = torch.zeros_like(Wd)
+    db = torch.zeros_like(bd)
+    ws = K._ws(Vd)
+    call("mvk_conv4s2_small_up_bwd", ptr(dod), ptr(out), 2, ptr(Vd), 1, ptr(Wd), ptr(dV), ptr(dW), ptr(db), ptr(ws),
+         ws.numel(), n, h, w, Cu, Cv, stream_ptr())
+    close(nchw(dV.cpu()), Vr.grad * (V > 0).float(), what="small up dV (relu mask fused)")
+    close(dW, Wr.grad, what="small up dW")
+    close(db, br.grad, what="small up db")
