@@ -361,9 +361,10 @@ __global__ __launch_bounds__(NLL_THREADS) void recon_nll_kernel(const ReconTable
   const mvk_recon_desc& d = tb.d[mi];
   const int local = blockIdx.x - tb.block_start[mi];
   const int kchunks = (K + KC - 1) / KC;
+  const int kper = (K + kchunks - 1) / kchunks;  // balanced chunks (K=10 -> 5+5, not 8+2)
   const int b = local / kchunks;
-  const int k0 = (local % kchunks) * KC;
-  const int kn = (K - k0) < KC ? (K - k0) : KC;
+  const int k0 = (local % kchunks) * kper;
+  const int kn = (K - k0) < kper ? (K - k0) : kper;
   const long long D = d.D;
   const float inv_s = 1.0f / d.scale, inv_s2 = inv_s * inv_s;
   const float mk = d.mask ? (d.mask[b] ? 1.0f : 0.0f) : 1.0f;

@@ -42,7 +42,7 @@ int launch_splitk(GemmDesc& d, float* ws, long long ws_floats, int target_blocks
     int rc = launch_igemm(d, z, s);
     if (rc) return rc;
     long long total = (long long)d.M * d.N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d.e, d.M, d.N, z);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, d.e, d.M, d.N, z);
     MVK_CHECK_LAUNCH();
     return MVK_OK;
   }
@@ -86,28 +86,58 @@ static void rowmajor_epi(Epilogue& e, float* out, long long ld) {
 }
 
 // ---- small helper kernels ------------------------------------------------------------------------------
-__global__ void colsum_kernel(const float* __restrict__ dY, const float* __restrict__ Y, int act, int M, int N,
-                              int rows_per_block, float* __restrict__ db) {
-  // block handles `rows_per_block` rows x 64 columns; threads: 64 columns x 4 row-lanes
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rl = threadIdx.x >> 6;
+// db[n] += sum_m dY[m][n] (* act'(Y)).  Threads = (N/vec column groups) x (row lanes); 16-byte coalesced loads when
+// N % 4 == 0; partials combined through LDS, one atomicAdd per column per workgroup.
+template <int VEC>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dY, const float* __restrict__ Y, int act,
+                                                     int M, int N, int rows_per_block, float* __restrict__ db) {
+  const int ncg = (N + VEC - 1) / VEC;            // column groups
+  const int cg_per_blk = ncg < 256 ? ncg : 256;   // column groups handled by this block (blockIdx.x strides them)
+  const int lanes_r = 256 / cg_per_blk;           // row lanes
+  const int cg = blockIdx.x * cg_per_blk + (threadIdx.x % cg_per_blk);
+  const int rl = threadIdx.x / cg_per_blk;
   const int r0 = blockIdx.y * rows_per_block;
   int r1 = r0 + rows_per_block;
   if (r1 > M) r1 = M;
-  float s = 0.f;
-  if (col < N) {
-    for (int r = r0 + rl; r < r1; r += 4) {
-      float v = dY[(long long)r * N + col];
-      if (Y) v *= mvk_act_grad_from_out(Y[(long long)r * N + col], act);
-      s += v;
+  float acc[VEC];
+#pragma unroll
+  for (int c = 0; c < VEC; ++c) acc[c] = 0.f;
+  if (cg < ncg && rl < lanes_r) {
+#pragma unroll 8
+    for (int r = r0 + rl; r < r1; r += lanes_r) {
+      const long long o = (long long)r * N + (long long)cg * VEC;
+      if (VEC == 4) {
+        float4 v = *reinterpret_cast<const float4*>(dY + o);
+        if (Y) {
+          float4 y = *reinterpret_cast<const float4*>(Y + o);
+          v.x *= mvk_act_grad_from_out(y.x, act);
+          v.y *= mvk_act_grad_from_out(y.y, act);
+          v.z *= mvk_act_grad_from_out(y.z, act);
+          v.w *= mvk_act_grad_from_out(y.w, act);
+        }
+        acc[0] += v.x;
+        acc[1 % VEC] += v.y;
+        acc[2 % VEC] += v.z;
+        acc[3 % VEC] += v.w;
+      } else {
+        float v = dY[o];
+        if (Y) v *= mvk_act_grad_from_out(Y[o], act);
+        acc[0] += v;
+      }
     }
   }
-  __shared__ float red[256];
-  red[threadIdx.x] = s;
+  __shared__ float red[256 * VEC];
+#pragma unroll
+  for (int c = 0; c < VEC; ++c) red[threadIdx.x * VEC + c] = acc[c];
   __syncthreads();
-  if (rl == 0 && col < N) {
-    float t = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
-    atomicAdd(db + col, t);
+  if (rl == 0 && cg < ncg) {
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      float t = 0.f;
+      for (int q = 0; q < lanes_r; ++q) t += red[(q * cg_per_blk + (threadIdx.x % cg_per_blk)) * VEC + c];
+      const int col = cg * VEC + c;
+      if (col < N) atomicAdd(db + col, t);
+    }
   }
 }
 
@@ -136,10 +166,18 @@ __global__ void nchw_channel_sum_kernel(const float* __restrict__ dY, const floa
 
 static int colsum(const float* dY, const float* Y, int act, int M, int N, float* db, hipStream_t s) {
   if (M <= 0 || N <= 0) return MVK_OK;
-  int gx = (N + 63) / 64;
-  int rows_per_block = 256;
-  int gy = (M + rows_per_block - 1) / rows_per_block;
-  hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, s, dY, Y, act, M, N, rows_per_block, db);
+  const bool vec = (N % 4 == 0) && mvk_aligned16(dY) && (!Y || mvk_aligned16(Y));
+  const int ncg = vec ? N / 4 : N;
+  const int cgb = ncg < 256 ? ncg : 256;
+  const int gx = (ncg + cgb - 1) / cgb;
+  // ~256 workgroups over the rows (few atomics per column), at least 64 rows each
+  int rows_per_block = (M + 255) / 256;
+  if (rows_per_block < 64) rows_per_block = 64;
+  const int gy = (M + rows_per_block - 1) / rows_per_block;
+  if (vec)
+    hipLaunchKernelGGL((colsum_kernel<4>), dim3(gx, gy), dim3(256), 0, s, dY, Y, act, M, N, rows_per_block, db);
+  else
+    hipLaunchKernelGGL((colsum_kernel<1>), dim3(gx, gy), dim3(256), 0, s, dY, Y, act, M, N, rows_per_block, db);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }

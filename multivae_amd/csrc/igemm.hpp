@@ -63,6 +63,9 @@ struct GemmDesc {
   int ksplit_tiles;  // Z_SPLITK: k-tiles per z slice
 };
 
+#ifndef MVK_MIN_WAVES
+#define MVK_MIN_WAVES 3
+#endif
 constexpr int BK = 16;
 
 template <int BM, int BN>
@@ -126,7 +129,7 @@ __device__ __forceinline__ bool gather_off(const AOperand& a, const Pos& ps, int
 }
 
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void igemm_kernel(const GemmDesc d) {
+__global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_kernel(const GemmDesc d) {
   using T = TileCfg<BM, BN>;
   __shared__ __attribute__((aligned(16))) float lds[2 * BK * (T::SA + T::SB)];
   float* As = lds;                    // [2][BK][SA]
@@ -169,9 +172,124 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmDesc d) {
   const BOperand& B = d.b;
   const bool a_gather = A.kind != A_PLAIN;
 
+  // ---------------- hoisted gather decode (fast paths) ----------------
+  // FAST_ROW: rows are positions, k = (tap, channel), NHWC, 16-byte loads along the channel, C % BK == 0:
+  //           the (n,i,j) of each staged row is decoded once; inside the K loop the tap is block-uniform.
+  // FAST_COL: weight-gradient view (rows = (tap, channel), k = position): tap/channel decoded once; the position
+  //           decode per tile uses shifts when OH, OW are powers of two.
+  const bool fast_row = a_gather && !A.trans && A.vec4 && A.contig_k && (A.C % BK == 0) && A.kind != A_DOWN_NCHW;
+  const bool fast_col = a_gather && A.trans && A.vec4 && !A.contig_k && A.kind == A_DOWN;
+  int pre_a[T::NA4], pre_b[T::NA4], pre_c[T::NA4];
+  if (fast_row) {
+#pragma unroll
+    for (int u = 0; u < T::NA4; ++u) {
+      const int idx = tid + u * 256;
+      const int r = m0 + idx / (BK / 4);
+      pre_a[u] = -1;
+      pre_b[u] = pre_c[u] = 0;
+      if (idx < T::UA4 && r < d.M) {
+        Pos ps = decode_pos(r, A.OH, A.OW);
+        pre_a[u] = ps.n;
+        pre_b[u] = ps.i;
+        pre_c[u] = ps.j;
+      }
+    }
+  } else if (fast_col) {
+#pragma unroll
+    for (int u = 0; u < T::NA4; ++u) {
+      const int idx = tid + u * 256;
+      const int r = m0 + (idx % (BM / 4)) * 4;
+      pre_a[u] = -1;
+      pre_b[u] = pre_c[u] = 0;
+      if (idx < T::UA4 && r < d.M) {
+        const int tap = r / A.C;
+        pre_a[u] = tap;           // kh*4 + kw
+        pre_b[u] = r - tap * A.C; // channel
+      }
+    }
+  }
+  const int ow_sh = ((A.OW & (A.OW - 1)) == 0) ? __builtin_ctz(A.OW > 0 ? A.OW : 1) : -1;
+  const int oh_sh = ((A.OH & (A.OH - 1)) == 0) ? __builtin_ctz(A.OH > 0 ? A.OH : 1) : -1;
+
   // ---------------- global -> registers ----------------
   auto load_a = [&](int kt) {
     const int k0 = kt * BK;
+    if (fast_row) {
+      const int tap = k0 / A.C;
+      const int c0 = k0 - tap * A.C;
+#pragma unroll
+      for (int u = 0; u < T::NA4; ++u) {
+        const int idx = tid + u * 256;
+        const int c = c0 + (idx % (BK / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pre_a[u] >= 0 && (k0 + (idx % (BK / 4)) * 4) < d.K) {
+          int hh, ww;
+          if (A.kind == A_UP) {
+            hh = pre_b[u] + ph - (tap >> 1);
+            ww = pre_c[u] + pw - (tap & 1);
+          } else {
+            hh = 2 * pre_b[u] - 1 + (tap >> 2);
+            ww = 2 * pre_c[u] - 1 + (tap & 3);
+          }
+          if (hh >= 0 && hh < A.H && ww >= 0 && ww < A.W) {
+            const long long off = (((long long)pre_a[u] * A.H + hh) * A.W + ww) * A.C + c;
+            v = *reinterpret_cast<const float4*>(A.p + off);
+            if (A.act_src) {
+              float4 y = *reinterpret_cast<const float4*>(A.act_src + off);
+              v.x *= mvk_act_grad_from_out(y.x, A.act);
+              v.y *= mvk_act_grad_from_out(y.y, A.act);
+              v.z *= mvk_act_grad_from_out(y.z, A.act);
+              v.w *= mvk_act_grad_from_out(y.w, A.act);
+            }
+          }
+        }
+        sa[4 * u + 0] = v.x;
+        sa[4 * u + 1] = v.y;
+        sa[4 * u + 2] = v.z;
+        sa[4 * u + 3] = v.w;
+      }
+      return;
+    }
+    if (fast_col) {
+#pragma unroll
+      for (int u = 0; u < T::NA4; ++u) {
+        const int idx = tid + u * 256;
+        const int pos = k0 + idx / (BM / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pre_a[u] >= 0 && pos < d.K) {
+          int pj, pi, pn;
+          if (ow_sh >= 0 && oh_sh >= 0) {
+            pj = pos & (A.OW - 1);
+            const int t = pos >> ow_sh;
+            pi = t & (A.OH - 1);
+            pn = t >> oh_sh;
+          } else {
+            pj = pos % A.OW;
+            const int t = pos / A.OW;
+            pi = t % A.OH;
+            pn = t / A.OH;
+          }
+          const int hh = 2 * pi - 1 + (pre_a[u] >> 2);
+          const int ww = 2 * pj - 1 + (pre_a[u] & 3);
+          if (hh >= 0 && hh < A.H && ww >= 0 && ww < A.W) {
+            const long long off = (((long long)pn * A.H + hh) * A.W + ww) * A.C + pre_b[u];
+            v = *reinterpret_cast<const float4*>(A.p + off);
+            if (A.act_src) {
+              float4 y = *reinterpret_cast<const float4*>(A.act_src + off);
+              v.x *= mvk_act_grad_from_out(y.x, A.act);
+              v.y *= mvk_act_grad_from_out(y.y, A.act);
+              v.z *= mvk_act_grad_from_out(y.z, A.act);
+              v.w *= mvk_act_grad_from_out(y.w, A.act);
+            }
+          }
+        }
+        sa[4 * u + 0] = v.x;
+        sa[4 * u + 1] = v.y;
+        sa[4 * u + 2] = v.z;
+        sa[4 * u + 3] = v.w;
+      }
+      return;
+    }
     if (A.contig_k) {
       // units: (row, kvec) ; vec along k
       if (A.vec4) {
@@ -550,14 +668,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmDesc d) {
   }
 }
 
-// out[map(m,n)] (+)= epilogue(sum_z ws[z][m][n]) — deterministic split-K finish, one thread per (m,n)
+// out[map(m,n)] (+)= epilogue(sum_z ws[z][m][n]) — deterministic split-K finish.
+// A workgroup owns 32 consecutive (m,n) elements; its 8 z-lanes each sum every 8th slab (128-byte coalesced
+// loads), then the 8 partials are combined in a fixed order through LDS.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const Epilogue E, int M, int N, int nz) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long long)M * N) return;
+  const int e = threadIdx.x & 31;
+  const int zl = threadIdx.x >> 5;
+  const long long total = (long long)M * N;
+  const long long idx = (long long)blockIdx.x * 32 + e;
+  float v = 0.f;
+  if (idx < total) {
+#pragma unroll 4
+    for (int z = zl; z < nz; z += 8) v += E.ws[(long long)z * total + idx];
+  }
+  __shared__ float red[8][33];
+  red[zl][e] = v;
+  __syncthreads();
+  if (zl != 0 || idx >= total) return;
+  v = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
   const int m = (int)(idx / N);
   const int n = (int)(idx - (long long)m * N);
-  float v = 0.f;
-  for (int z = 0; z < nz; ++z) v += E.ws[(long long)z * M * N + idx];
   long long off;
   if (E.kind == E_ROWMAJOR) {
     off = (long long)m * E.ld + n;

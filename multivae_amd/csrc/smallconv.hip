@@ -240,13 +240,23 @@ __global__ __launch_bounds__(256) void small_up_bwd_kernel(const float* __restri
   if (tid < CU) slab[CV * C::NC + tid] = bred[tid * 4] + bred[tid * 4 + 1] + bred[tid * 4 + 2] + bred[tid * 4 + 3];
 }
 
-// dWref += sum_b partial[b][0:CV*NC];  db += sum_b partial[b][CV*NC + cu]
-__global__ void small_up_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int nw, int ncu,
-                                           float* __restrict__ dWref, float* __restrict__ db) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nw + ncu) return;
+// dWref += sum_b partial[b][0:CV*NC];  db += sum_b partial[b][CV*NC + cu]   (32 elements x 8 slab lanes per block)
+__global__ __launch_bounds__(256) void small_up_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int nw,
+                                                                  int ncu, float* __restrict__ dWref,
+                                                                  float* __restrict__ db) {
+  const int e = threadIdx.x & 31, zl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + e;
+  const int total = nw + ncu;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(long long)b * (nw + ncu) + i];
+  if (i < total) {
+#pragma unroll 4
+    for (int b = zl; b < nblocks; b += 8) s += partial[(long long)b * total + i];
+  }
+  __shared__ float red[8][33];
+  red[zl][e] = s;
+  __syncthreads();
+  if (zl != 0 || i >= total) return;
+  s = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
   if (i < nw)
     dWref[i] += s;
   else if (db)
@@ -303,7 +313,7 @@ static int launch_bwd(const float* dU, const float* Uout, int u_act, const float
                      ws, n, h, w);
   MVK_CHECK_LAUNCH();
   const int total = CV * C::NC + CU;
-  hipLaunchKernelGGL(small_up_bwd_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, ws, grid, CV * C::NC, CU,
+  hipLaunchKernelGGL(small_up_bwd_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, s, ws, grid, CV * C::NC, CU,
                      dWref, db);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
