@@ -39,6 +39,9 @@ class CallbackHandler:
         for callback in self.callbacks:
             getattr(callback, event)(training_config, model=self.model, **kwargs)
 
+    def on_log(self, training_config, logs, **kwargs):
+        self.call_event("on_log", training_config, logs=logs, **kwargs)
+
     def __getattr__(self, name):
         if name.startswith("on_"):
             return lambda training_config=None, **kw: self.call_event(name, training_config, **kw)

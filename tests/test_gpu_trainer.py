@@ -1,0 +1,90 @@
+"""Whole-step parity (forward + ELBO + backward + fused Adam) against the CPU oracle, and the BaseTrainer loop
+(BASELINE.json configs[0]: MVTCAE, default MLP enc/dec, batch 64 — here on the GPU through the HIP kernels)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as G
+from oracle import elbo, nets
+from oracle import train as otrain
+
+pytestmark = pytest.mark.gpu
+
+
+def test_three_training_steps_match_oracle():
+    from multivae_amd.data.datasets.base import DatasetOutput
+    from multivae_amd.models import MoPoE, MoPoEConfig
+    from multivae_amd.trainers import FlatParams, FusedAdam
+
+    d = torch.device("cuda:0")
+    dims, L, B, K, lr = G.TINY_DIMS, 5, 12, 3, 1e-3
+    shapes = G.P.default_mlp_shapes(dims, L)
+    sd_np = G.P.make_state_dict(shapes, 321)
+    model = MoPoE(MoPoEConfig(n_modalities=4, latent_dim=L, input_dims=dict(dims), beta=2.0, K=K))
+    model.load_state_dict({k: G.t(v) for k, v in sd_np.items()})
+    model = model.to(d).train()
+    flat = FlatParams(model)
+    opt = FusedAdam(flat, lr=lr)
+    data = {m: G.t(G.P.uniform((B,) + s, 40 + i)) for i, (m, s) in enumerate(dims.items())}
+    inputs = DatasetOutput(data={m: v.to(d) for m, v in data.items()})
+    sd = {k: G.t(v).clone().requires_grad_(True) for k, v in sd_np.items()}
+    st = otrain.AdamState(sd)
+    names = list(dims)
+    gen = torch.Generator().manual_seed(5)
+    losses = []
+    for step in range(3):
+        eps = torch.randn(K, B, L, generator=gen)
+        opt.zero_grad()
+        out = model(inputs, noise=eps.to(d))
+        out.loss.backward()
+        opt.step()
+
+        def loss_fn(s):
+            enc_f, dec_f = nets.build_default_mlp(s, dims)
+            e = {m: enc_f[m](data[m]) for m in names}
+            return elbo.mopoe_forward(e, data, dec_f, eps, names=names, beta=2.0)
+
+        o = otrain.train_step(sd, st, loss_fn, lr=lr)
+        losses.append((float(out.loss.detach()), float(o["loss"].detach())))
+    for a, b in losses:
+        assert abs(a - b) <= 1e-4 * abs(b), losses
+    bad = total = 0
+    for k, p in model.named_parameters():
+        diff = (p.detach().cpu() - sd[k].detach()).abs()
+        bad += int((diff > 0.5 * lr).sum())
+        total += diff.numel()
+    assert bad <= 2e-3 * total, (bad, total)
+
+
+def test_base_trainer_mvtcae_cfg1(tmp_path):
+    """configs[0]: MVTCAE n_modalities=2, latent_dim=20, default MLP enc/dec, batch 64, BaseTrainer."""
+    from multivae_amd.data.datasets.base import MultimodalBaseDataset
+    from multivae_amd.models import MVTCAE, MVTCAEConfig
+    from multivae_amd.trainers import BaseTrainer, BaseTrainerConfig
+
+    torch.manual_seed(0)
+    n = 640
+    ds = MultimodalBaseDataset(data=dict(mnist=torch.rand(n, 1, 28, 28), svhn=torch.rand(n, 3, 32, 32)))
+    ev = MultimodalBaseDataset(data=dict(mnist=torch.rand(128, 1, 28, 28), svhn=torch.rand(128, 3, 32, 32)))
+    model = MVTCAE(MVTCAEConfig(n_modalities=2, latent_dim=20, input_dims=dict(mnist=(1, 28, 28), svhn=(3, 32, 32))))
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    cfg = BaseTrainerConfig(output_dir=str(tmp_path), per_device_train_batch_size=64, per_device_eval_batch_size=64,
+                            num_epochs=3, learning_rate=1e-3, steps_saving=2)
+    trainer = BaseTrainer(model, train_dataset=ds, eval_dataset=ev, training_config=cfg)
+    hist = trainer.train()
+    assert len(hist) == 3 and all(np.isfinite(h["train_epoch_loss"]) for h in hist)
+    assert hist[-1]["train_epoch_loss"] < hist[0]["train_epoch_loss"]
+    assert set(hist[0]) >= {"train_epoch_loss", "eval_epoch_loss", "train_joint_divergence", "train_mnist", "train_kld_svhn"}
+    after = trainer.model.state_dict()
+    assert any(not torch.equal(before[k].to(after[k].device), after[k]) for k in before)
+    tdir = trainer.training_dir
+    assert set(os.listdir(os.path.join(tdir, "final_model"))) >= {"model.pt", "model_config.json", "environment.json",
+                                                                  "training_config.json"}
+    ck = os.path.join(tdir, "checkpoint_epoch_2")
+    assert set(os.listdir(ck)) >= {"model.pt", "optimizer.pt", "model_config.json", "training_config.json",
+                                   "info_checkpoint.json"}
+    re = MVTCAE.load_from_folder(os.path.join(tdir, "final_model"))
+    best = trainer._best_model.state_dict()
+    assert all(torch.equal(v.cpu(), best[k].cpu()) for k, v in re.state_dict().items())

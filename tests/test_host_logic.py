@@ -1,0 +1,187 @@
+"""CPU tests of the host side: the drop-in surface (names, arguments, error behaviour of the reference's plugin
+API), the C-ABI library (loads, exports every symbol include/mvk.h declares), and that the product path refuses
+to compute on the CPU (no fallback)."""
+import json
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from multivae_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "mvk.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(mvk_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 35
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/mvk.h but not exported by libmvk.so"
+    bound = set(_lib.PROTOTYPES) | {"mvk_splitk_workspace_floats", "mvk_conv4s2_small_up_supported"}
+    assert declared == bound, (declared - bound, bound - declared)
+    assert lib.mvk_version() >= 100
+
+
+def test_argument_counts_match_header():
+    from multivae_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "mvk.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    for name, argtypes in _lib.PROTOTYPES.items():
+        m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", header, flags=re.S)
+        assert m, name
+        args = m.group(1).strip()
+        n = 0 if args in ("", "void") else len(args.split(","))
+        assert n == len(argtypes), (name, n, len(argtypes))
+
+
+def test_no_cpu_compute_path():
+    from multivae_amd import _lib, kernels
+
+    x = torch.randn(4, 3)
+    w = torch.randn(5, 3)
+    b = torch.zeros(5)
+    with pytest.raises(_lib.MvkError):
+        kernels.MLPDecoderFn.apply(x, w, b, torch.randn(2, 5), torch.zeros(2), (2,))
+    from multivae_amd.data.datasets.base import DatasetOutput
+    from multivae_amd.models import MoPoE, MoPoEConfig
+
+    model = MoPoE(MoPoEConfig(n_modalities=2, latent_dim=3, input_dims=dict(a=(2,), b=(3,))))
+    with pytest.raises(_lib.MvkError):
+        model(DatasetOutput(data=dict(a=torch.rand(4, 2), b=torch.rand(4, 3))))
+
+
+def test_model_output_and_dataset_contract():
+    from multivae_amd.data.datasets.base import DatasetOutput, IncompleteDataset, MultimodalBaseDataset
+    from multivae_amd.models.base.base_utils import ModelOutput
+
+    o = ModelOutput(loss=1.0, metrics={})
+    o.loss_sum = 2.0
+    o["extra"] = 3
+    assert (o.loss, o["loss_sum"], o.extra, o[0]) == (1.0, 2.0, 3, 1.0)
+    assert list(o.keys()) == ["loss", "metrics", "loss_sum", "extra"]
+    ds = MultimodalBaseDataset(data=dict(a=torch.rand(5, 2), b=torch.rand(5, 3)), labels=torch.arange(5))
+    assert len(ds) == 5 and set(ds[1].data) == {"a", "b"} and int(ds[1].labels) == 1 and not hasattr(ds[1], "masks")
+    with pytest.raises(AttributeError):
+        len(MultimodalBaseDataset(data=dict(a=torch.rand(5, 2), b=torch.rand(4, 3))))
+    inc = IncompleteDataset(data=dict(a=torch.rand(5, 2)), masks=dict(a=torch.ones(5, dtype=torch.bool)))
+    assert hasattr(inc[0], "masks") and isinstance(inc[0], DatasetOutput)
+    with pytest.raises(AttributeError):
+        IncompleteDataset(data=dict(a=torch.rand(5, 2)), masks=dict(a=torch.ones(4, dtype=torch.bool)))
+
+
+def test_config_json_round_trip(tmp_path):
+    from multivae_amd.models import MMVAEConfig, MoPoEConfig, MVTCAEConfig
+
+    c = MoPoEConfig(n_modalities=2, latent_dim=20, input_dims=dict(mnist=[1, 28, 28], svhn=[3, 32, 32]), beta=2.5)
+    assert c.name == "MoPoEConfig" and c.input_dims["mnist"] == (1, 28, 28)
+    c.save_json(str(tmp_path), "model_config")
+    d = json.load(open(tmp_path / "model_config.json"))
+    assert d["name"] == "MoPoEConfig" and d["beta"] == 2.5 and d["K"] == 1
+    c2 = MoPoEConfig.from_json_file(str(tmp_path / "model_config.json"))
+    assert c2.to_dict() == c.to_dict()
+    assert MVTCAEConfig(n_modalities=2).alpha == 0.1 and MVTCAEConfig(n_modalities=2).beta == 2.5
+    m = MMVAEConfig(n_modalities=2)
+    assert (m.K, m.prior_and_posterior_dist, m.loss, m.learn_prior) == (10, "laplace_with_softmax", "dreg_looser", True)
+
+
+def test_base_multivae_constructor_checks():
+    """Error behaviour of base_ae_model.py:42-99,154-180."""
+    from multivae_amd.models import MoPoE, MoPoEConfig
+    from multivae_amd.models.base.base_config import BaseAEConfig
+    from multivae_amd.models.nn.default_architectures import Decoder_AE_MLP, Encoder_VAE_MLP
+
+    with pytest.raises(AttributeError):  # n_modalities vs input_dims
+        MoPoE(MoPoEConfig(n_modalities=3, input_dims=dict(a=(2,), b=(3,))))
+    with pytest.raises(AttributeError):  # neither encoders nor input_dims
+        MoPoE(MoPoEConfig(n_modalities=2))
+    enc = dict(a=Encoder_VAE_MLP(BaseAEConfig(input_dim=(2,), latent_dim=4)),
+               b=Encoder_VAE_MLP(BaseAEConfig(input_dim=(3,), latent_dim=4)))
+    dec = dict(a=Decoder_AE_MLP(BaseAEConfig(input_dim=(2,), latent_dim=4)),
+               c=Decoder_AE_MLP(BaseAEConfig(input_dim=(3,), latent_dim=4)))
+    with pytest.raises(AttributeError):  # names differ between encoders and decoders
+        MoPoE(MoPoEConfig(n_modalities=2, latent_dim=4), enc, dec)
+    dec = dict(a=dec["a"], b=dec["c"])
+    with pytest.raises(KeyError):  # input_dims keys != encoder keys
+        MoPoE(MoPoEConfig(n_modalities=2, latent_dim=4, input_dims=dict(a=(2,), z=(3,))), enc, dec)
+    with pytest.raises(AttributeError):  # not a BaseEncoder
+        MoPoE(MoPoEConfig(n_modalities=2, latent_dim=4), dict(a=torch.nn.Linear(2, 2), b=enc["b"]), dec)
+    m = MoPoE(MoPoEConfig(n_modalities=2, latent_dim=4, input_dims=dict(a=(2,), b=(3,))), enc, dec)
+    assert m.model_config.custom_architectures == ["encoders", "decoders"]
+    # parameter order of the reference: decoders are registered before encoders
+    assert list(m.state_dict().keys())[0].startswith("decoders.")
+    with pytest.raises(ValueError):
+        MoPoE(MoPoEConfig(n_modalities=2, input_dims=dict(a=(2,), b=(3,)), decoders_dist=dict(a="normal", b="foo")))
+
+
+def test_rescale_factors_and_dists():
+    from multivae_amd.models import MVTCAE, MVTCAEConfig
+
+    dims = dict(mnist=(1, 28, 28), svhn=(3, 32, 32))
+    m = MVTCAE(MVTCAEConfig(n_modalities=2, latent_dim=20, input_dims=dims, uses_likelihood_rescaling=True,
+                            decoders_dist=dict(mnist="laplace", svhn="bernoulli"),
+                            decoder_dist_params=dict(mnist=dict(scale=0.75))))
+    assert abs(m.rescale_factors["mnist"] - 3072 / 784) < 1e-12 and m.rescale_factors["svhn"] == 1.0
+    assert m.recon_dists == {"mnist": (1, 0.75), "svhn": (2, 1.0)}
+    assert sum(p.numel() for p in m.parameters()) == 4541280  # SURVEY.md §2.3 C1 (MVTCAE MLP)
+
+
+def test_mopoe_subset_enumeration_and_selection():
+    from multivae_amd.models import MoPoE, MoPoEConfig
+    from oracle import elbo
+
+    dims = dict(zeta=(2,), alpha=(3,), mid=(4,))  # deliberately unsorted
+    m = MoPoE(MoPoEConfig(n_modalities=3, latent_dim=4, input_dims=dims))
+    assert list(m.subsets.keys()) == ["", "zeta", "alpha", "mid", "alpha_zeta", "mid_zeta", "alpha_mid",
+                                      "alpha_mid_zeta"]
+    assert m._subset_keys == [k for k, _ in elbo.mopoe_subsets(list(dims))]
+    assert m._poe_order == ["alpha", "mid", "zeta"]
+    assert m._subset_bits == [4, 1, 2, 5, 6, 3, 7]
+    for B in (1, 6, 16, 512, 513):
+        sel = m._row_range_selection(B, torch.device("cpu")).tolist()
+        bnd = elbo.mopoe_row_bounds(B, 7)
+        ref = [k for k in range(7) for _ in range(bnd[k + 1] - bnd[k])]
+        assert sel == ref
+    with pytest.raises(AttributeError):
+        MoPoE(MoPoEConfig(n_modalities=3, latent_dim=4, input_dims=dims, subsets=[["zeta", "nope"]]))
+
+
+def test_shard_indices_match_distributed_sampler():
+    from torch.utils.data import DistributedSampler
+
+    from multivae_amd.trainers.base import shard_indices
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 103
+
+        def __getitem__(self, i):
+            return i
+
+    for W in (2, 4, 8):
+        for r in range(W):
+            ref = list(DistributedSampler(DS(), num_replicas=W, rank=r))  # shuffle=True, seed=0, no set_epoch
+            assert shard_indices(103, W, r).tolist() == ref
+
+
+def test_trainer_config_validation(monkeypatch):
+    from multivae_amd.trainers import BaseTrainerConfig
+
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    c = BaseTrainerConfig()
+    assert (c.per_device_train_batch_size, c.learning_rate, c.optimizer_cls, c.seed, c.dist_backend) == \
+        (64, 1e-4, "Adam", 8, "nccl")
+    with pytest.raises(AttributeError):
+        BaseTrainerConfig(optimizer_cls="NotAnOptimizer")
+    with pytest.raises(TypeError):
+        BaseTrainerConfig(optimizer_params=dict(wrong_kw=1))
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("RANK", "3")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    c = BaseTrainerConfig()
+    assert (c.world_size, c.rank, c.local_rank) == (4, 3, 1)
