@@ -21,8 +21,8 @@ def main():
     rows = c.execute(q).fetchall()
     stats = {}
     for name, st, en in rows:
+        name = name.replace("(anonymous namespace)::", "").replace("void ", "")
         name = re.sub(r"\(.*", "", name)
-        name = name.replace("void ", "")
         d = (en - st) / 1e3
         s = stats.setdefault(name, [0, 0.0, 1e30, 0.0])
         s[0] += 1
