@@ -1,5 +1,5 @@
 // C-ABI entry points built on the fp32 MFMA implicit-GEMM engine (igemm.hpp).
-#include "igemm.hpp"
+#include "igemm_fast.hpp"
 
 namespace mvk {
 
@@ -11,8 +11,68 @@ static int launch_cfg(const GemmDesc& d, int zdim, hipStream_t s) {
   return MVK_OK;
 }
 
+// ---- mode-specialised kernels (igemm_fast.hpp) -------------------------------------------------------------------
+template <int BM, int BN, int BKT, int AMODE, int BMODE, bool AACT>
+static int launch_fast_cfg(const GemmDesc& d, int zdim, hipStream_t s) {
+  dim3 grid((d.M + BM - 1) / BM, (d.N + BN - 1) / BN, zdim);
+  hipLaunchKernelGGL((igemm_fast_kernel<BM, BN, BKT, AMODE, BMODE, AACT>), grid, dim3(256), 0, s, d);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+template <int BM, int BN, int BKT>
+static int launch_fast_tile(const GemmDesc& d, int zdim, hipStream_t s, int amode, int bmode, bool aact) {
+  if (amode == AM_PLAIN_K && bmode == BM_K && !aact) return launch_fast_cfg<BM, BN, BKT, AM_PLAIN_K, BM_K, false>(d, zdim, s);
+  if (amode == AM_PLAIN_K && bmode == BM_N && !aact) return launch_fast_cfg<BM, BN, BKT, AM_PLAIN_K, BM_N, false>(d, zdim, s);
+  if (amode == AM_PLAIN_K && bmode == BM_N && aact) return launch_fast_cfg<BM, BN, BKT, AM_PLAIN_K, BM_N, true>(d, zdim, s);
+  if (amode == AM_PLAIN_R && bmode == BM_N && !aact) return launch_fast_cfg<BM, BN, BKT, AM_PLAIN_R, BM_N, false>(d, zdim, s);
+  if (amode == AM_PLAIN_R && bmode == BM_N && aact) return launch_fast_cfg<BM, BN, BKT, AM_PLAIN_R, BM_N, true>(d, zdim, s);
+  if (amode == AM_ROW && bmode == BM_N && !aact) return launch_fast_cfg<BM, BN, BKT, AM_ROW, BM_N, false>(d, zdim, s);
+  if (amode == AM_COL && bmode == BM_N && !aact) return launch_fast_cfg<BM, BN, BKT, AM_COL, BM_N, false>(d, zdim, s);
+  return 1;  // combination not instantiated -> generic kernel
+}
+
+// returns 1 when no specialised kernel applies
+static int try_launch_fast(const GemmDesc& d, int zdim, hipStream_t s) {
+  const AOperand& A = d.a;
+  int amode = 0, bmode = 0;
+  const bool aact = A.act_src != nullptr;
+  if (A.kind == A_PLAIN) {
+    if (!A.vec4) return 1;
+    if (aact && !mvk_aligned16(A.act_src)) return 1;
+    amode = A.contig_k ? AM_PLAIN_K : AM_PLAIN_R;
+  } else if (!A.trans && A.vec4 && A.contig_k && A.kind != A_DOWN_NCHW && !aact) {
+    amode = AM_ROW;
+  } else if (A.trans && A.vec4 && !A.contig_k && A.kind == A_DOWN && !aact) {
+    amode = AM_COL;
+  } else {
+    return 1;
+  }
+  if (!d.b.vec4) return 1;
+  bmode = d.b.contig_k ? BM_K : BM_N;
+  if (d.zmode == Z_SPLITK && (d.ksplit_tiles & 1)) return 1;  // BKT = 32 needs 32-aligned slices
+  const bool c32 = (amode != AM_ROW) || (A.C % 32 == 0);
+  const bool c16 = (amode != AM_ROW) || (A.C % 16 == 0);
+  if (d.N <= 32) return c32 ? launch_fast_tile<128, 32, 32>(d, zdim, s, amode, bmode, aact) : 1;
+  if (d.N <= 64) {
+    if (!c32) return 1;
+    if (d.M <= 64) return launch_fast_tile<64, 64, 32>(d, zdim, s, amode, bmode, aact);
+    return launch_fast_tile<128, 64, 32>(d, zdim, s, amode, bmode, aact);
+  }
+  long long big = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * zdim;
+  if (big >= 192) return c16 ? launch_fast_tile<128, 128, 16>(d, zdim, s, amode, bmode, aact) : 1;
+  if (!c32) return 1;
+  long long mid = (long long)((d.M + 127) / 128) * ((d.N + 63) / 64) * zdim;
+  if (mid >= 192 || d.M > 4096) return launch_fast_tile<128, 64, 32>(d, zdim, s, amode, bmode, aact);
+  return launch_fast_tile<64, 64, 32>(d, zdim, s, amode, bmode, aact);
+}
+
 int launch_igemm(const GemmDesc& d, int zdim, hipStream_t s) {
   if (d.M <= 0 || d.N <= 0 || d.K <= 0) return MVK_OK;
+  {
+    const int rc = try_launch_fast(d, zdim, s);
+    if (rc != 1) return rc;
+  }
   if (d.N <= 32) return launch_cfg<128, 32>(d, zdim, s);
   if (d.N <= 64) {
     if (d.M <= 64) return launch_cfg<64, 64>(d, zdim, s);
@@ -35,6 +95,7 @@ int launch_splitk(GemmDesc& d, float* ws, long long ws_floats, int target_blocks
   if (splits > ktiles) splits = ktiles;
   d.zmode = Z_SPLITK;
   d.ksplit_tiles = (ktiles + splits - 1) / splits;
+  d.ksplit_tiles += d.ksplit_tiles & 1;  // 32-element aligned slices (BKT = 32 kernels)
   int z = (ktiles + d.ksplit_tiles - 1) / d.ksplit_tiles;
   const long long need = (long long)z * d.M * d.N;
   if (z > 1 && ws && ws_floats >= need && d.e.kind != E_UP && d.e.kind != E_UP_NCHW) {

@@ -128,6 +128,79 @@ __device__ __forceinline__ bool gather_off(const AOperand& a, const Pos& ps, int
   return ok;
 }
 
+// ---- shared epilogue -------------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ void run_epilogue(const GemmDesc& d, f32x16 (&acc)[T::TM][T::TN], float* lds, int tid, int m0,
+                                             int n0, int wm, int wn, int l31, int lhi, int ph, int pw) {
+  // ---------------- epilogue ----------------
+  // The accumulators of one 32x32 MFMA tile are parked in LDS (one private column per thread, so no
+  // barrier is needed) and consumed by a rolled loop: the address / activation code exists once instead of
+  // 16*TM*TN times.  The tile buffers are free: the main loop ended with a barrier.
+  const Epilogue& E = d.e;
+  if (E.ws) {
+    // split-K partial: plain coalesced stores of the raw accumulators into this slice's slab
+    float* slab = E.ws + (long long)blockIdx.z * d.M * d.N;
+#pragma unroll
+    for (int a = 0; a < T::TM; ++a) {
+#pragma unroll
+      for (int b = 0; b < T::TN; ++b) {
+        const int n = n0 + wn * T::WTN + b * 32 + l31;
+        const int mbase = m0 + wm * T::WTM + a * 32 + 4 * lhi;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          if (m < d.M && n < d.N) slab[(long long)m * d.N + n] = acc[a][b][r];
+        }
+      }
+    }
+    return;
+  }
+  float* park = lds + tid;  // element r at park[r * 256]
+#pragma unroll
+  for (int a = 0; a < T::TM; ++a) {
+#pragma unroll
+    for (int b = 0; b < T::TN; ++b) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) park[r * 256] = acc[a][b][r];
+      const int n = n0 + wn * T::WTN + b * 32 + l31;
+      const int mbase = m0 + wm * T::WTM + a * 32 + 4 * lhi;
+      if (n < d.N) {
+        const float bias_v = E.bias ? E.bias[n % E.bias_mod] : 0.f;
+#pragma unroll 1
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          if (m >= d.M) continue;
+          float v = park[r * 256];
+          long long off;
+          if (E.kind == E_ROWMAJOR) {
+            off = (long long)m * E.ld + n;
+          } else if (E.kind == E_UP) {
+            Pos ps = decode_pos(m, E.OH, E.OW);
+            off = (((long long)ps.n * (2 * E.OH) + 2 * ps.i + ph) * (2 * E.OW) + 2 * ps.j + pw) * E.Cu + n;
+          } else if (E.kind == E_UP_NCHW) {
+            Pos ps = decode_pos(m, E.OH, E.OW);
+            off = (((long long)ps.n * E.Cu + n) * (2 * E.OH) + 2 * ps.i + ph) * (2 * E.OW) + 2 * ps.j + pw;
+          } else if (E.kind == E_CONVREF) {
+            int tap = m / E.Cu;
+            int cu = m - tap * E.Cu;
+            off = ((long long)n * E.Cu + cu) * 16 + tap;
+          } else {  // E_UNFLATREF: m = ci, n = (tap, co)
+            int tap = n / E.Cu;
+            int co = n - tap * E.Cu;
+            off = ((long long)m * E.Cu + co) * 16 + tap;
+          }
+          v = mvk_act(v + bias_v, E.act);
+          if (E.act_src) v *= mvk_act_grad_from_out(E.act_src[off], E.src_act);
+          if (E.atomic)
+            atomicAdd(E.out + off, v);
+          else
+            E.out[off] = v;
+        }
+      }
+    }
+  }
+}
+
 template <int BM, int BN>
 __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_kernel(const GemmDesc d) {
   using T = TileCfg<BM, BN>;
@@ -599,73 +672,7 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_kernel(const GemmDes
     buf ^= 1;
   }
 
-  // ---------------- epilogue ----------------
-  // The accumulators of one 32x32 MFMA tile are parked in LDS (one private column per thread, so no
-  // barrier is needed) and consumed by a rolled loop: the address / activation code exists once instead of
-  // 16*TM*TN times.  The tile buffers are free: the main loop ended with a barrier.
-  const Epilogue& E = d.e;
-  if (E.ws) {
-    // split-K partial: plain coalesced stores of the raw accumulators into this slice's slab
-    float* slab = E.ws + (long long)blockIdx.z * d.M * d.N;
-#pragma unroll
-    for (int a = 0; a < T::TM; ++a) {
-#pragma unroll
-      for (int b = 0; b < T::TN; ++b) {
-        const int n = n0 + wn * T::WTN + b * 32 + l31;
-        const int mbase = m0 + wm * T::WTM + a * 32 + 4 * lhi;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mbase + (r & 3) + 8 * (r >> 2);
-          if (m < d.M && n < d.N) slab[(long long)m * d.N + n] = acc[a][b][r];
-        }
-      }
-    }
-    return;
-  }
-  float* park = lds + tid;  // element r at park[r * 256]
-#pragma unroll
-  for (int a = 0; a < T::TM; ++a) {
-#pragma unroll
-    for (int b = 0; b < T::TN; ++b) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) park[r * 256] = acc[a][b][r];
-      const int n = n0 + wn * T::WTN + b * 32 + l31;
-      const int mbase = m0 + wm * T::WTM + a * 32 + 4 * lhi;
-      if (n < d.N) {
-        const float bias_v = E.bias ? E.bias[n % E.bias_mod] : 0.f;
-#pragma unroll 1
-        for (int r = 0; r < 16; ++r) {
-          const int m = mbase + (r & 3) + 8 * (r >> 2);
-          if (m >= d.M) continue;
-          float v = park[r * 256];
-          long long off;
-          if (E.kind == E_ROWMAJOR) {
-            off = (long long)m * E.ld + n;
-          } else if (E.kind == E_UP) {
-            Pos ps = decode_pos(m, E.OH, E.OW);
-            off = (((long long)ps.n * (2 * E.OH) + 2 * ps.i + ph) * (2 * E.OW) + 2 * ps.j + pw) * E.Cu + n;
-          } else if (E.kind == E_UP_NCHW) {
-            Pos ps = decode_pos(m, E.OH, E.OW);
-            off = (((long long)ps.n * E.Cu + n) * (2 * E.OH) + 2 * ps.i + ph) * (2 * E.OW) + 2 * ps.j + pw;
-          } else if (E.kind == E_CONVREF) {
-            int tap = m / E.Cu;
-            int cu = m - tap * E.Cu;
-            off = ((long long)n * E.Cu + cu) * 16 + tap;
-          } else {  // E_UNFLATREF: m = ci, n = (tap, co)
-            int tap = n / E.Cu;
-            int co = n - tap * E.Cu;
-            off = ((long long)m * E.Cu + co) * 16 + tap;
-          }
-          v = mvk_act(v + bias_v, E.act);
-          if (E.act_src) v *= mvk_act_grad_from_out(E.act_src[off], E.src_act);
-          if (E.atomic)
-            atomicAdd(E.out + off, v);
-          else
-            E.out[off] = v;
-        }
-      }
-    }
-  }
+  run_epilogue<T>(d, acc, lds, tid, m0, n0, wm, wn, l31, lhi, ph, pw);
 }
 
 // out[map(m,n)] (+)= epilogue(sum_z ws[z][m][n]) — deterministic split-K finish.

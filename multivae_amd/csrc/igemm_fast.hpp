@@ -1,0 +1,288 @@
+// Mode-specialised, software-pipelined variant of the fp32 MFMA implicit-GEMM engine.
+//
+// igemm.hpp's generic kernel decides everything from runtime flags; the compiler then waits for every
+// conditional global load right where it is issued and the loads never overlap the MFMAs.  Here the operand
+// modes are template parameters, so one k-tile iteration is straight-line code:
+//     issue ALL global loads of tile t+1 (16-byte loads, addresses from hoisted per-thread bases)
+//     ds_read + MFMA over tile t                      <- loads in flight
+//     wait, (optional activation-derivative multiply), write tile t+1 to the other LDS buffer, barrier
+// BKT = 32 halves the number of barriers per MFMA where the LDS budget allows.
+#pragma once
+#include "igemm.hpp"
+
+namespace mvk {
+
+enum AMode { AM_PLAIN_K = 1, AM_PLAIN_R = 2, AM_ROW = 3, AM_COL = 4 };
+enum BMode { BM_K = 1, BM_N = 2 };
+
+template <int BM, int BN, int BKT>
+struct FastCfg {
+  static constexpr int WAVES_N = (BN >= 64) ? 2 : 1;
+  static constexpr int WAVES_M = 4 / WAVES_N;
+  static constexpr int WTM = BM / WAVES_M;
+  static constexpr int WTN = BN / WAVES_N;
+  static constexpr int TM = WTM / 32;
+  static constexpr int TN = WTN / 32;
+  static constexpr int SA = BM + 4;
+  static constexpr int SB = BN + 4;
+  static constexpr int UA4 = BM * BKT / 4;
+  static constexpr int UB4 = BN * BKT / 4;
+  static constexpr int NA4 = (UA4 + 255) / 256;
+  static constexpr int NB4 = (UB4 + 255) / 256;
+  static_assert(TM >= 1 && TN >= 1, "tile too small");
+};
+
+template <int BM, int BN, int BKT, int AMODE, int BMODE, bool AACT>
+__global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const GemmDesc d) {
+  using T = FastCfg<BM, BN, BKT>;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BKT * (T::SA + T::SB)];
+  float* As = lds;
+  float* Bs = lds + 2 * BKT * T::SA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / T::WAVES_N, wn = wave % T::WAVES_N;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const AOperand& A = d.a;
+  const BOperand& B = d.b;
+
+  int ph = 0, pw = 0;
+  int kbeg = 0, kend = d.K;
+  const float* bp = B.p;
+  if (d.zmode == Z_PARITY) {
+    ph = blockIdx.z >> 1;
+    pw = blockIdx.z & 1;
+    bp += (long long)blockIdx.z * B.z_stride;
+  } else if (d.zmode == Z_SPLITK) {
+    kbeg = blockIdx.z * d.ksplit_tiles * BK;  // ksplit_tiles counts 16-wide tiles; launch keeps it a multiple of 2
+    const int e = kbeg + d.ksplit_tiles * BK;
+    kend = e < kend ? e : kend;
+    if (kbeg >= kend) return;
+  }
+  const int ntiles = (kend - kbeg + BKT - 1) / BKT;
+
+  f32x16 acc[T::TM][T::TN];
+#pragma unroll
+  for (int a = 0; a < T::TM; ++a)
+#pragma unroll
+    for (int b = 0; b < T::TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // ------------------------------------------------------------------------------------------------
+  // hoisted per-unit state
+  // ------------------------------------------------------------------------------------------------
+  long long abase[T::NA4];  // PLAIN: element offset without the k0 term; -1 = row out of range
+  int pa[T::NA4], pb[T::NA4], pc[T::NA4];  // ROW: (n,i,j)  COL: (tap, channel, -)
+#pragma unroll
+  for (int u = 0; u < T::NA4; ++u) {
+    const int idx = tid + u * 256;
+    abase[u] = -1;
+    pa[u] = -1;
+    pb[u] = pc[u] = 0;
+    if (idx >= T::UA4) continue;
+    if (AMODE == AM_PLAIN_K) {
+      const int r = m0 + idx / (BKT / 4);
+      if (r < d.M) abase[u] = (long long)r * A.sr + (idx % (BKT / 4)) * 4;
+    } else if (AMODE == AM_PLAIN_R) {
+      const int r = m0 + (idx % (BM / 4)) * 4;
+      if (r < d.M) abase[u] = (long long)(idx / (BM / 4)) * A.sk + r;
+    } else if (AMODE == AM_ROW) {
+      const int r = m0 + idx / (BKT / 4);
+      if (r < d.M) {
+        Pos ps = decode_pos(r, A.OH, A.OW);
+        pa[u] = ps.n;
+        pb[u] = ps.i;
+        pc[u] = ps.j;
+      }
+    } else {  // AM_COL
+      const int r = m0 + (idx % (BM / 4)) * 4;
+      if (r < d.M) {
+        const int tap = r / A.C;
+        pa[u] = tap;
+        pb[u] = r - tap * A.C;
+      }
+    }
+  }
+  long long bbase[T::NB4];
+#pragma unroll
+  for (int u = 0; u < T::NB4; ++u) {
+    const int idx = tid + u * 256;
+    bbase[u] = -1;
+    if (idx >= T::UB4) continue;
+    if (BMODE == BM_K) {
+      const int n = n0 + idx / (BKT / 4);
+      if (n < d.N) bbase[u] = (long long)n * B.sn + (idx % (BKT / 4)) * 4;
+    } else {
+      const int n = n0 + (idx % (BN / 4)) * 4;
+      if (n < d.N) bbase[u] = (long long)(idx / (BN / 4)) * B.sk + n;
+    }
+  }
+  const int ow_sh = ((A.OW & (A.OW - 1)) == 0) ? __builtin_ctz(A.OW > 0 ? A.OW : 1) : -1;
+  const int oh_sh = ((A.OH & (A.OH - 1)) == 0) ? __builtin_ctz(A.OH > 0 ? A.OH : 1) : -1;
+
+  float4 ra[T::NA4], ya[AACT ? T::NA4 : 1], rb[T::NB4];
+
+  // ------------------------------------------------------------------------------------------------
+  // global -> registers (no dependent use: the loads stay in flight across the MFMAs)
+  // ------------------------------------------------------------------------------------------------
+  auto load_tiles = [&](int k0) {
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (AMODE == AM_PLAIN_K) {
+#pragma unroll
+      for (int u = 0; u < T::NA4; ++u) {
+        const int idx = tid + u * 256;
+        const bool ok = abase[u] >= 0 && (k0 + (idx % (BKT / 4)) * 4) < kend;
+        const long long off = abase[u] + k0;
+        ra[u] = ok ? *reinterpret_cast<const float4*>(A.p + off) : z4;
+        if (AACT) ya[u] = ok ? *reinterpret_cast<const float4*>(A.act_src + off) : z4;
+      }
+    } else if (AMODE == AM_PLAIN_R) {
+#pragma unroll
+      for (int u = 0; u < T::NA4; ++u) {
+        const int idx = tid + u * 256;
+        const bool ok = abase[u] >= 0 && (k0 + idx / (BM / 4)) < kend;
+        const long long off = abase[u] + (long long)k0 * A.sk;
+        ra[u] = ok ? *reinterpret_cast<const float4*>(A.p + off) : z4;
+        if (AACT) ya[u] = ok ? *reinterpret_cast<const float4*>(A.act_src + off) : z4;
+      }
+    } else if (AMODE == AM_ROW) {
+      const int tap = k0 / A.C;  // block-uniform: C % BKT == 0
+      const int c0 = k0 - tap * A.C;
+      int dh, dw;
+      if (A.kind == A_UP) {
+        dh = ph - (tap >> 1);
+        dw = pw - (tap & 1);
+      } else {
+        dh = (tap >> 2) - 1;
+        dw = (tap & 3) - 1;
+      }
+      const int mul = (A.kind == A_UP) ? 1 : 2;
+#pragma unroll
+      for (int u = 0; u < T::NA4; ++u) {
+        const int idx = tid + u * 256;
+        const int kq = (idx % (BKT / 4)) * 4;
+        const int hh = mul * pb[u] + dh, ww = mul * pc[u] + dw;
+        const bool ok = pa[u] >= 0 && (k0 + kq) < kend && hh >= 0 && hh < A.H && ww >= 0 && ww < A.W;
+        const long long off = (((long long)pa[u] * A.H + hh) * A.W + ww) * A.C + c0 + kq;
+        ra[u] = ok ? *reinterpret_cast<const float4*>(A.p + off) : z4;
+      }
+    } else {  // AM_COL: rows = (tap, channel), k = position
+#pragma unroll
+      for (int u = 0; u < T::NA4; ++u) {
+        const int idx = tid + u * 256;
+        const int pos = k0 + idx / (BM / 4);
+        int pj, pi, pn;
+        if (ow_sh >= 0 && oh_sh >= 0) {
+          pj = pos & (A.OW - 1);
+          const int t = pos >> ow_sh;
+          pi = t & (A.OH - 1);
+          pn = t >> oh_sh;
+        } else {
+          pj = pos % A.OW;
+          const int t = pos / A.OW;
+          pi = t % A.OH;
+          pn = t / A.OH;
+        }
+        const int hh = 2 * pi - 1 + (pa[u] >> 2), ww = 2 * pj - 1 + (pa[u] & 3);
+        const bool ok = pa[u] >= 0 && pos < kend && hh >= 0 && hh < A.H && ww >= 0 && ww < A.W;
+        const long long off = (((long long)pn * A.H + hh) * A.W + ww) * A.C + pb[u];
+        ra[u] = ok ? *reinterpret_cast<const float4*>(A.p + off) : z4;
+      }
+    }
+    if (BMODE == BM_K) {
+#pragma unroll
+      for (int u = 0; u < T::NB4; ++u) {
+        const int idx = tid + u * 256;
+        const bool ok = bbase[u] >= 0 && (k0 + (idx % (BKT / 4)) * 4) < kend;
+        rb[u] = ok ? *reinterpret_cast<const float4*>(bp + bbase[u] + k0) : z4;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < T::NB4; ++u) {
+        const int idx = tid + u * 256;
+        const bool ok = bbase[u] >= 0 && (k0 + idx / (BN / 4)) < kend;
+        rb[u] = ok ? *reinterpret_cast<const float4*>(bp + bbase[u] + (long long)k0 * B.sk) : z4;
+      }
+    }
+  };
+
+  // ------------------------------------------------------------------------------------------------
+  // registers -> LDS (k-major tiles)
+  // ------------------------------------------------------------------------------------------------
+  auto store_tiles = [&](int buf) {
+    float* da = As + buf * BKT * T::SA;
+    float* db = Bs + buf * BKT * T::SB;
+#pragma unroll
+    for (int u = 0; u < T::NA4; ++u) {
+      const int idx = tid + u * 256;
+      if (idx >= T::UA4) continue;
+      float4 v = ra[u];
+      if (AACT) {
+        v.x *= mvk_act_grad_from_out(ya[u].x, A.act);
+        v.y *= mvk_act_grad_from_out(ya[u].y, A.act);
+        v.z *= mvk_act_grad_from_out(ya[u].z, A.act);
+        v.w *= mvk_act_grad_from_out(ya[u].w, A.act);
+      }
+      if (AMODE == AM_PLAIN_K || AMODE == AM_ROW) {
+        const int row = idx / (BKT / 4), kq = (idx % (BKT / 4)) * 4;
+        da[(kq + 0) * T::SA + row] = v.x;
+        da[(kq + 1) * T::SA + row] = v.y;
+        da[(kq + 2) * T::SA + row] = v.z;
+        da[(kq + 3) * T::SA + row] = v.w;
+      } else {
+        const int kk = idx / (BM / 4), row = (idx % (BM / 4)) * 4;
+        *reinterpret_cast<float4*>(da + kk * T::SA + row) = v;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < T::NB4; ++u) {
+      const int idx = tid + u * 256;
+      if (idx >= T::UB4) continue;
+      const float4 v = rb[u];
+      if (BMODE == BM_K) {
+        const int col = idx / (BKT / 4), kq = (idx % (BKT / 4)) * 4;
+        db[(kq + 0) * T::SB + col] = v.x;
+        db[(kq + 1) * T::SB + col] = v.y;
+        db[(kq + 2) * T::SB + col] = v.z;
+        db[(kq + 3) * T::SB + col] = v.w;
+      } else {
+        const int kk = idx / (BN / 4), col = (idx % (BN / 4)) * 4;
+        *reinterpret_cast<float4*>(db + kk * T::SB + col) = v;
+      }
+    }
+  };
+
+  auto compute = [&](int buf) {
+    const float* a_s = As + buf * BKT * T::SA + wm * T::WTM + l31;
+    const float* b_s = Bs + buf * BKT * T::SB + wn * T::WTN + l31;
+#pragma unroll
+    for (int ks = 0; ks < BKT / 2; ++ks) {
+      float av[T::TM], bv[T::TN];
+#pragma unroll
+      for (int a = 0; a < T::TM; ++a) av[a] = a_s[(2 * ks + lhi) * T::SA + a * 32];
+#pragma unroll
+      for (int b = 0; b < T::TN; ++b) bv[b] = b_s[(2 * ks + lhi) * T::SB + b * 32];
+#pragma unroll
+      for (int a = 0; a < T::TM; ++a)
+#pragma unroll
+        for (int b = 0; b < T::TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+  };
+
+  load_tiles(kbeg);
+  store_tiles(0);
+  __syncthreads();
+  int buf = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const bool more = (t + 1) < ntiles;
+    if (more) load_tiles(kbeg + (t + 1) * BKT);
+    compute(buf);
+    if (more) store_tiles(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  run_epilogue<T>(d, acc, lds, tid, m0, n0, wm, wn, l31, lhi, ph, pw);
+}
+
+}  // namespace mvk
