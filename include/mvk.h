@@ -243,14 +243,15 @@ int mvk_conv4s2_up_nchw_small(const float* V, const float* Wref, const float* bi
  * (mvk_conv4s2_small_up_supported != 0): one workgroup per image computes the column matrix
  * V[pos,:] . W[:,(cu,kh,kw)] on the matrix cores and gathers the output pixels from LDS (no wasted MFMA columns).
  * The backward entry point fuses backward-data (dV = conv(dUpre) * v_act'(V)), backward-weight (dWref +=) and
- * the bias gradient (db +=, nullable) with dUpre = dU * u_act'(Uout) applied while loading; ws is split-K style
- * scratch (>= 512 * (16*Cu*Cv + Cu) floats for full parallelism). */
+ * the bias gradient (db +=, nullable) with dUpre = dU * u_act'(Uout) applied while loading; db_v (nullable) +=
+ * the per-channel sums of dV, i.e. the bias gradient of the layer that produced V; ws is split-K style scratch
+ * (>= 512 * (16*Cu*Cv + Cu + Cv) floats for full parallelism). */
 int mvk_conv4s2_small_up_supported(int h, int w, int Cu, int Cv);
 int mvk_conv4s2_small_up_fwd(const float* V, const float* Wref, const float* bias, float* U, int n, int h, int w,
                              int Cu, int Cv, int act, void* stream);
 int mvk_conv4s2_small_up_bwd(const float* dU, const float* Uout, int u_act, const float* V, int v_act,
-                             const float* Wref, float* dV, float* dWref, float* db, float* ws, int64_t ws_floats,
-                             int n, int h, int w, int Cu, int Cv, void* stream);
+                             const float* Wref, float* dV, float* dWref, float* db, float* db_v, float* ws,
+                             int64_t ws_floats, int n, int h, int w, int Cu, int Cv, void* stream);
 
 /* 1x1-spatial layers:
  *   unflatten  Y[n,(tap,co)] = act(z[n,Cin] Wp + b[co]), Wp[ci][tap*Cout+co] = Wref[ci][co][tap]

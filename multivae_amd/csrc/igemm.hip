@@ -1,5 +1,6 @@
 // C-ABI entry points built on the fp32 MFMA implicit-GEMM engine (igemm.hpp).
 #include "igemm_fast.hpp"
+#include <cstdlib>
 
 namespace mvk {
 
@@ -35,6 +36,17 @@ static int launch_fast_tile(const GemmDesc& d, int zdim, hipStream_t s, int amod
 // returns 1 when no specialised kernel applies
 static int try_launch_fast(const GemmDesc& d, int zdim, hipStream_t s) {
   const AOperand& A = d.a;
+  // buffer loads use 32-bit byte offsets: stay on the generic kernel for operands of 2 GiB or more
+  const long long lim = 1ll << 29;
+  if (A.kind == A_PLAIN) {
+    if ((long long)d.M * d.K >= lim) return 1;
+  } else if ((long long)d.a.H * d.a.W * d.a.C * ((long long)d.M / (d.a.OH * d.a.OW > 0 ? d.a.OH * d.a.OW : 1) + 1) >= lim &&
+             !d.a.trans) {
+    return 1;
+  } else if (d.a.trans && (long long)d.a.H * d.a.W * d.a.C * ((long long)d.K / (d.a.OH * d.a.OW > 0 ? d.a.OH * d.a.OW : 1) + 1) >= lim) {
+    return 1;
+  }
+  if ((long long)d.K * d.N >= lim) return 1;
   int amode = 0, bmode = 0;
   const bool aact = A.act_src != nullptr;
   if (A.kind == A_PLAIN) {
@@ -53,10 +65,14 @@ static int try_launch_fast(const GemmDesc& d, int zdim, hipStream_t s) {
   if (d.zmode == Z_SPLITK && (d.ksplit_tiles & 1)) return 1;  // BKT = 32 needs 32-aligned slices
   const bool c32 = (amode != AM_ROW) || (A.C % 32 == 0);
   const bool c16 = (amode != AM_ROW) || (A.C % 16 == 0);
-  if (d.N <= 32) return c32 ? launch_fast_tile<128, 32, 32>(d, zdim, s, amode, bmode, aact) : 1;
+  if (d.N <= 32) {
+    // tall-skinny: a 256-row tile lets every wave reuse its B fragment for two MFMA tiles
+    if (c16 && (long long)((d.M + 255) / 256) * zdim >= 512) return launch_fast_tile<256, 32, 16>(d, zdim, s, amode, bmode, aact);
+    return c32 ? launch_fast_tile<128, 32, 32>(d, zdim, s, amode, bmode, aact) : 1;
+  }
   if (d.N <= 64) {
     if (!c32) return 1;
-    if (d.M <= 64) return launch_fast_tile<64, 64, 32>(d, zdim, s, amode, bmode, aact);
+    if (d.M <= 64 || getenv("MVK_T64")) return launch_fast_tile<64, 64, 32>(d, zdim, s, amode, bmode, aact);
     return launch_fast_tile<128, 64, 32>(d, zdim, s, amode, bmode, aact);
   }
   long long big = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * zdim;
@@ -67,7 +83,12 @@ static int try_launch_fast(const GemmDesc& d, int zdim, hipStream_t s) {
   return launch_fast_tile<64, 64, 32>(d, zdim, s, amode, bmode, aact);
 }
 
-int launch_igemm(const GemmDesc& d, int zdim, hipStream_t s) {
+static unsigned long long* g_dbg = nullptr;
+extern "C" void mvk_debug_set_phase_buffer(unsigned long long* p) { g_dbg = p; }
+
+int launch_igemm(const GemmDesc& d_in, int zdim, hipStream_t s) {
+  GemmDesc d = d_in;
+  d.dbg = g_dbg;
   if (d.M <= 0 || d.N <= 0 || d.K <= 0) return MVK_OK;
   {
     const int rc = try_launch_fast(d, zdim, s);

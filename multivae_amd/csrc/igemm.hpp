@@ -61,6 +61,7 @@ struct GemmDesc {
   int M, N, K;
   int zmode;
   int ksplit_tiles;  // Z_SPLITK: k-tiles per z slice
+  unsigned long long* dbg;  // phase-cycle counters (debug builds with -DMVK_PHASES only)
 };
 
 #ifndef MVK_MIN_WAVES

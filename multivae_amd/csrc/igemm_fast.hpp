@@ -15,7 +15,7 @@ namespace mvk {
 enum AMode { AM_PLAIN_K = 1, AM_PLAIN_R = 2, AM_ROW = 3, AM_COL = 4 };
 enum BMode { BM_K = 1, BM_N = 2 };
 
-template <int BM, int BN, int BKT>
+template <int BM, int BN, int BKT, bool A_TRANSPOSED_WRITE = false, bool B_TRANSPOSED_WRITE = false>
 struct FastCfg {
   static constexpr int WAVES_N = (BN >= 64) ? 2 : 1;
   static constexpr int WAVES_M = 4 / WAVES_N;
@@ -23,8 +23,12 @@ struct FastCfg {
   static constexpr int WTN = BN / WAVES_N;
   static constexpr int TM = WTM / 32;
   static constexpr int TN = WTN / 32;
-  static constexpr int SA = BM + 4;
-  static constexpr int SB = BN + 4;
+  // k-major LDS tiles.  Operands whose memory is contiguous along k are written transposed (4 x ds_write_b32 per
+  // 16-byte unit): a row stride == 1 (mod 32) makes those writes bank-conflict-free (32 lanes = 8 k-groups x 4
+  // rows -> banks 4*kq + row).  Operands contiguous along the row index are written with ds_write_b128 and need
+  // a 16-byte aligned stride.  Fragment reads (32 consecutive rows of one k) are conflict-free for any stride.
+  static constexpr int SA = A_TRANSPOSED_WRITE ? BM + 1 : BM + 4;
+  static constexpr int SB = B_TRANSPOSED_WRITE ? BN + 1 : BN + 4;
   static constexpr int UA4 = BM * BKT / 4;
   static constexpr int UB4 = BN * BKT / 4;
   static constexpr int NA4 = (UA4 + 255) / 256;
@@ -34,10 +38,10 @@ struct FastCfg {
 
 template <int BM, int BN, int BKT, int AMODE, int BMODE, bool AACT>
 __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const GemmDesc d) {
-  using T = FastCfg<BM, BN, BKT>;
-  __shared__ __attribute__((aligned(16))) float lds[2 * BKT * (T::SA + T::SB)];
+  using T = FastCfg<BM, BN, BKT, (AMODE == AM_PLAIN_K || AMODE == AM_ROW), (BMODE == BM_K)>;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BKT * (T::SA + T::SB) + 8];
   float* As = lds;
-  float* Bs = lds + 2 * BKT * T::SA;
+  float* Bs = lds + ((2 * BKT * T::SA + 3) & ~3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / T::WAVES_N, wn = wave % T::WAVES_N;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -71,7 +75,17 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
   // ------------------------------------------------------------------------------------------------
   // hoisted per-unit state
   // ------------------------------------------------------------------------------------------------
-  long long abase[T::NA4];  // PLAIN: element offset without the k0 term; -1 = row out of range
+  // Operands are read through buffer descriptors with hardware bounds checking: an out-of-range byte offset
+  // (OOB) returns zeros, so padding / tile tails need neither branches nor pointer selects (a select between a
+  // real address and a constant zero makes hipcc emit flat_load, whose lgkmcnt use serialises the LDS waits
+  // of the MFMA phase with the global loads).  Offsets are 32-bit: every tensor on the path is < 2 GiB.
+  constexpr int OOB = 0x7fffffff;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A.p, 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsY =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(AACT ? A.act_src : A.p), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)bp, 0, 0x7ffffff0, 0x00020000);
+
+  int abase[T::NA4];  // PLAIN: element offset without the k0 term; -1 = row out of range
   int pa[T::NA4], pb[T::NA4], pc[T::NA4];  // ROW: (n,i,j)  COL: (tap, channel, -)
 #pragma unroll
   for (int u = 0; u < T::NA4; ++u) {
@@ -82,10 +96,10 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
     if (idx >= T::UA4) continue;
     if (AMODE == AM_PLAIN_K) {
       const int r = m0 + idx / (BKT / 4);
-      if (r < d.M) abase[u] = (long long)r * A.sr + (idx % (BKT / 4)) * 4;
+      if (r < d.M) abase[u] = r * (int)A.sr + (idx % (BKT / 4)) * 4;
     } else if (AMODE == AM_PLAIN_R) {
       const int r = m0 + (idx % (BM / 4)) * 4;
-      if (r < d.M) abase[u] = (long long)(idx / (BM / 4)) * A.sk + r;
+      if (r < d.M) abase[u] = (idx / (BM / 4)) * (int)A.sk + r;
     } else if (AMODE == AM_ROW) {
       const int r = m0 + idx / (BKT / 4);
       if (r < d.M) {
@@ -103,7 +117,7 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
       }
     }
   }
-  long long bbase[T::NB4];
+  int bbase[T::NB4];
 #pragma unroll
   for (int u = 0; u < T::NB4; ++u) {
     const int idx = tid + u * 256;
@@ -111,39 +125,39 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
     if (idx >= T::UB4) continue;
     if (BMODE == BM_K) {
       const int n = n0 + idx / (BKT / 4);
-      if (n < d.N) bbase[u] = (long long)n * B.sn + (idx % (BKT / 4)) * 4;
+      if (n < d.N) bbase[u] = n * (int)B.sn + (idx % (BKT / 4)) * 4;
     } else {
       const int n = n0 + (idx % (BN / 4)) * 4;
-      if (n < d.N) bbase[u] = (long long)(idx / (BN / 4)) * B.sk + n;
+      if (n < d.N) bbase[u] = (idx / (BN / 4)) * (int)B.sk + n;
     }
   }
   const int ow_sh = ((A.OW & (A.OW - 1)) == 0) ? __builtin_ctz(A.OW > 0 ? A.OW : 1) : -1;
   const int oh_sh = ((A.OH & (A.OH - 1)) == 0) ? __builtin_ctz(A.OH > 0 ? A.OH : 1) : -1;
 
-  float4 ra[T::NA4], ya[AACT ? T::NA4 : 1], rb[T::NB4];
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 ra[T::NA4], ya[AACT ? T::NA4 : 1], rb[T::NB4];
 
   // ------------------------------------------------------------------------------------------------
   // global -> registers (no dependent use: the loads stay in flight across the MFMAs)
   // ------------------------------------------------------------------------------------------------
   auto load_tiles = [&](int k0) {
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (AMODE == AM_PLAIN_K) {
 #pragma unroll
       for (int u = 0; u < T::NA4; ++u) {
         const int idx = tid + u * 256;
         const bool ok = abase[u] >= 0 && (k0 + (idx % (BKT / 4)) * 4) < kend;
-        const long long off = abase[u] + k0;
-        ra[u] = ok ? *reinterpret_cast<const float4*>(A.p + off) : z4;
-        if (AACT) ya[u] = ok ? *reinterpret_cast<const float4*>(A.act_src + off) : z4;
+        const int off = ok ? (abase[u] + k0) * 4 : OOB;
+        ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
+        if (AACT) ya[u] = __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0);
       }
     } else if (AMODE == AM_PLAIN_R) {
 #pragma unroll
       for (int u = 0; u < T::NA4; ++u) {
         const int idx = tid + u * 256;
         const bool ok = abase[u] >= 0 && (k0 + idx / (BM / 4)) < kend;
-        const long long off = abase[u] + (long long)k0 * A.sk;
-        ra[u] = ok ? *reinterpret_cast<const float4*>(A.p + off) : z4;
-        if (AACT) ya[u] = ok ? *reinterpret_cast<const float4*>(A.act_src + off) : z4;
+        const int off = ok ? (abase[u] + k0 * (int)A.sk) * 4 : OOB;
+        ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
+        if (AACT) ya[u] = __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0);
       }
     } else if (AMODE == AM_ROW) {
       const int tap = k0 / A.C;  // block-uniform: C % BKT == 0
@@ -163,8 +177,8 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
         const int kq = (idx % (BKT / 4)) * 4;
         const int hh = mul * pb[u] + dh, ww = mul * pc[u] + dw;
         const bool ok = pa[u] >= 0 && (k0 + kq) < kend && hh >= 0 && hh < A.H && ww >= 0 && ww < A.W;
-        const long long off = (((long long)pa[u] * A.H + hh) * A.W + ww) * A.C + c0 + kq;
-        ra[u] = ok ? *reinterpret_cast<const float4*>(A.p + off) : z4;
+        const int off = ok ? (((pa[u] * A.H + hh) * A.W + ww) * A.C + c0 + kq) * 4 : OOB;
+        ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
       }
     } else {  // AM_COL: rows = (tap, channel), k = position
 #pragma unroll
@@ -185,8 +199,8 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
         }
         const int hh = 2 * pi - 1 + (pa[u] >> 2), ww = 2 * pj - 1 + (pa[u] & 3);
         const bool ok = pa[u] >= 0 && pos < kend && hh >= 0 && hh < A.H && ww >= 0 && ww < A.W;
-        const long long off = (((long long)pn * A.H + hh) * A.W + ww) * A.C + pb[u];
-        ra[u] = ok ? *reinterpret_cast<const float4*>(A.p + off) : z4;
+        const int off = ok ? (((pn * A.H + hh) * A.W + ww) * A.C + pb[u]) * 4 : OOB;
+        ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
       }
     }
     if (BMODE == BM_K) {
@@ -194,14 +208,14 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
       for (int u = 0; u < T::NB4; ++u) {
         const int idx = tid + u * 256;
         const bool ok = bbase[u] >= 0 && (k0 + (idx % (BKT / 4)) * 4) < kend;
-        rb[u] = ok ? *reinterpret_cast<const float4*>(bp + bbase[u] + k0) : z4;
+        rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rsB, ok ? (bbase[u] + k0) * 4 : OOB, 0, 0);
       }
     } else {
 #pragma unroll
       for (int u = 0; u < T::NB4; ++u) {
         const int idx = tid + u * 256;
         const bool ok = bbase[u] >= 0 && (k0 + idx / (BN / 4)) < kend;
-        rb[u] = ok ? *reinterpret_cast<const float4*>(bp + bbase[u] + (long long)k0 * B.sk) : z4;
+        rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rsB, ok ? (bbase[u] + k0 * (int)B.sk) * 4 : OOB, 0, 0);
       }
     }
   };
@@ -216,12 +230,13 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
     for (int u = 0; u < T::NA4; ++u) {
       const int idx = tid + u * 256;
       if (idx >= T::UA4) continue;
-      float4 v = ra[u];
+      float4 v = make_float4(__uint_as_float(ra[u].x), __uint_as_float(ra[u].y), __uint_as_float(ra[u].z),
+                             __uint_as_float(ra[u].w));
       if (AACT) {
-        v.x *= mvk_act_grad_from_out(ya[u].x, A.act);
-        v.y *= mvk_act_grad_from_out(ya[u].y, A.act);
-        v.z *= mvk_act_grad_from_out(ya[u].z, A.act);
-        v.w *= mvk_act_grad_from_out(ya[u].w, A.act);
+        v.x *= mvk_act_grad_from_out(__uint_as_float(ya[u].x), A.act);
+        v.y *= mvk_act_grad_from_out(__uint_as_float(ya[u].y), A.act);
+        v.z *= mvk_act_grad_from_out(__uint_as_float(ya[u].z), A.act);
+        v.w *= mvk_act_grad_from_out(__uint_as_float(ya[u].w), A.act);
       }
       if (AMODE == AM_PLAIN_K || AMODE == AM_ROW) {
         const int row = idx / (BKT / 4), kq = (idx % (BKT / 4)) * 4;
@@ -238,7 +253,8 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
     for (int u = 0; u < T::NB4; ++u) {
       const int idx = tid + u * 256;
       if (idx >= T::UB4) continue;
-      const float4 v = rb[u];
+      const float4 v = make_float4(__uint_as_float(rb[u].x), __uint_as_float(rb[u].y), __uint_as_float(rb[u].z),
+                                   __uint_as_float(rb[u].w));
       if (BMODE == BM_K) {
         const int col = idx / (BKT / 4), kq = (idx % (BKT / 4)) * 4;
         db[(kq + 0) * T::SB + col] = v.x;
@@ -270,18 +286,42 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
     }
   };
 
+#ifdef MVK_PHASES
+  unsigned long long ph_t[5] = {0, 0, 0, 0, 0};
+  const unsigned long long tk0 = __builtin_readcyclecounter();
+#define MVK_TICK(i, prev) { unsigned long long now__ = __builtin_readcyclecounter(); ph_t[i] += now__ - prev; prev = now__; }
+#else
+#define MVK_TICK(i, prev)
+#endif
   load_tiles(kbeg);
   store_tiles(0);
   __syncthreads();
   int buf = 0;
+#ifdef MVK_PHASES
+  unsigned long long tk = __builtin_readcyclecounter();
+  ph_t[4] = tk - tk0;
+#endif
   for (int t = 0; t < ntiles; ++t) {
     const bool more = (t + 1) < ntiles;
     if (more) load_tiles(kbeg + (t + 1) * BKT);
+    MVK_TICK(0, tk)
     compute(buf);
+    MVK_TICK(1, tk)
     if (more) store_tiles(buf ^ 1);
+    MVK_TICK(2, tk)
     __syncthreads();
+    MVK_TICK(3, tk)
     buf ^= 1;
   }
+#ifdef MVK_PHASES
+  if (d.dbg && lane == 0) {
+    for (int i = 0; i < 5; ++i) atomicAdd(d.dbg + i, ph_t[i]);
+    atomicAdd(d.dbg + 5, (unsigned long long)ntiles);
+    unsigned long long te = __builtin_readcyclecounter();
+    atomicAdd(d.dbg + 6, te - tk0);
+    atomicAdd(d.dbg + 7, 1ull);
+  }
+#endif
   run_epilogue<T>(d, acc, lds, tid, m0, n0, wm, wn, l31, lhi, ph, pw);
 }
 

@@ -132,6 +132,9 @@ __global__ __launch_bounds__(256) void small_up_bwd_kernel(const float* __restri
   float dbl[CU];
 #pragma unroll
   for (int c = 0; c < CU; ++c) dbl[c] = 0.f;
+  float dbv[C::NTV];  // column sums of dV for this lane's channel cv = b*16 + l15 (rows: this lane's lq group)
+#pragma unroll
+  for (int b = 0; b < C::NTV; ++b) dbv[b] = 0.f;
 
   const int H2 = 2 * h, W2 = 2 * w;
   for (long long img = blockIdx.x; img < n; img += gridDim.x) {
@@ -193,7 +196,9 @@ __global__ __launch_bounds__(256) void small_up_bwd_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int pos = wave * 64 + a * 16 + lq * 4 + r, cv = b * 16 + l15;
-          dv[pos * CV + cv] = acc[a][b][r] * mvk_act_grad_from_out(Vs[pos * C::VS + cv], v_act);
+          const float g = acc[a][b][r] * mvk_act_grad_from_out(Vs[pos * C::VS + cv], v_act);
+          dv[pos * CV + cv] = g;
+          dbv[b] += g;
         }
     // --- backward weight: dW[cv][k] += sum_pos V[pos][cv] * dUpre(gathered)[pos][k]; this wave's 64 positions
 #pragma unroll 2
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(256) void small_up_bwd_kernel(const float* __restri
         red[wave * CV * C::NC + cv * C::NC + col] = accw[a][b][r];
       }
   __syncthreads();
-  float* slab = partial + (long long)blockIdx.x * (CV * C::NC + CU);
+  float* slab = partial + (long long)blockIdx.x * (CV * C::NC + CU + CV);
   for (int i = tid; i < CV * C::NC; i += 256)
     slab[i] = red[i] + red[CV * C::NC + i] + red[2 * CV * C::NC + i] + red[3 * CV * C::NC + i];
   __syncthreads();
@@ -238,15 +243,27 @@ __global__ __launch_bounds__(256) void small_up_bwd_kernel(const float* __restri
   }
   __syncthreads();
   if (tid < CU) slab[CV * C::NC + tid] = bred[tid * 4] + bred[tid * 4 + 1] + bred[tid * 4 + 2] + bred[tid * 4 + 3];
+  __syncthreads();
+  // column sums of dV: combine the 4 lq groups of each wave, then the 4 waves
+  float* vred = smem;  // [CV][16]
+#pragma unroll
+  for (int b = 0; b < C::NTV; ++b) vred[(b * 16 + l15) * 16 + wave * 4 + lq] = dbv[b];
+  __syncthreads();
+  if (tid < CV) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += vred[tid * 16 + q];
+    slab[CV * C::NC + CU + tid] = t;
+  }
 }
 
-// dWref += sum_b partial[b][0:CV*NC];  db += sum_b partial[b][CV*NC + cu]   (32 elements x 8 slab lanes per block)
+// dWref += sum_b partial[b][0:CV*NC];  db += sum_b partial[b][CV*NC + cu];  db_v += sum_b partial[b][CV*NC+CU+cv]
 __global__ __launch_bounds__(256) void small_up_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int nw,
-                                                                  int ncu, float* __restrict__ dWref,
-                                                                  float* __restrict__ db) {
+                                                                  int ncu, int ncv, float* __restrict__ dWref,
+                                                                  float* __restrict__ db, float* __restrict__ db_v) {
   const int e = threadIdx.x & 31, zl = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + e;
-  const int total = nw + ncu;
+  const int total = nw + ncu + ncv;
   float s = 0.f;
   if (i < total) {
 #pragma unroll 4
@@ -259,8 +276,11 @@ __global__ __launch_bounds__(256) void small_up_bwd_reduce_kernel(const float* _
   s = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
   if (i < nw)
     dWref[i] += s;
-  else if (db)
-    db[i - nw] += s;
+  else if (i < nw + ncu) {
+    if (db) db[i - nw] += s;
+  } else if (db_v) {
+    db_v[i - nw - ncu] += s;
+  }
 }
 
 template <int CU, int CV>
@@ -298,10 +318,10 @@ static int launch_fwd(const float* V, const float* Wref, const float* bias, floa
 
 template <int CU, int CV>
 static int launch_bwd(const float* dU, const float* Uout, int u_act, const float* V, int v_act, const float* Wref,
-                      float* dV, float* dWref, float* db, float* ws, int64_t ws_floats, int n, int h, int w,
-                      hipStream_t s) {
+                      float* dV, float* dWref, float* db, float* db_v, float* ws, int64_t ws_floats, int n, int h,
+                      int w, hipStream_t s) {
   using C = SmallCfg<CU, CV>;
-  const int slab = CV * C::NC + CU;
+  const int slab = CV * C::NC + CU + CV;
   int grid = n < 512 ? n : 512;
   if ((int64_t)grid * slab > ws_floats) grid = (int)(ws_floats / slab);
   if (grid < 1) return MVK_EINVAL;
@@ -312,9 +332,9 @@ static int launch_bwd(const float* dU, const float* Uout, int u_act, const float
   hipLaunchKernelGGL((small_up_bwd_kernel<CU, CV>), dim3(grid), dim3(256), lds, s, dU, Uout, u_act, V, v_act, Wref, dV,
                      ws, n, h, w);
   MVK_CHECK_LAUNCH();
-  const int total = CV * C::NC + CU;
-  hipLaunchKernelGGL(small_up_bwd_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, s, ws, grid, CV * C::NC, CU,
-                     dWref, db);
+  const int total = CV * C::NC + CU + CV;
+  hipLaunchKernelGGL(small_up_bwd_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, s, ws, grid, CV * C::NC, CU, CV,
+                     dWref, db, db_v);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }
@@ -351,13 +371,13 @@ int mvk_conv4s2_small_up_fwd(const float* V, const float* Wref, const float* bia
 }
 
 int mvk_conv4s2_small_up_bwd(const float* dU, const float* Uout, int u_act, const float* V, int v_act,
-                             const float* Wref, float* dV, float* dWref, float* db, float* ws, int64_t ws_floats,
-                             int n, int h, int w, int Cu, int Cv, void* stream) {
+                             const float* Wref, float* dV, float* dWref, float* db, float* db_v, float* ws,
+                             int64_t ws_floats, int n, int h, int w, int Cu, int Cv, void* stream) {
   if (!dU || !Uout || !V || !Wref || !dV || !dWref || !ws || n < 0 || !supported(h, w, Cu, Cv) || !mvk_aligned16(V))
     return MVK_EINVAL;
   if (n == 0) return MVK_OK;
   hipStream_t s = mvk_stream(stream);
-  MVK_SMALL_DISPATCH(launch_bwd, dU, Uout, u_act, V, v_act, Wref, dV, dWref, db, ws, ws_floats, n, h, w, s)
+  MVK_SMALL_DISPATCH(launch_bwd, dU, Uout, u_act, V, v_act, Wref, dV, dWref, db, db_v, ws, ws_floats, n, h, w, s)
 }
 
 }  // extern "C"

@@ -335,8 +335,9 @@ class SVHNDecoderFn(Function):
             tb3, db3 = _grad_target(b3)
             dg3 = _new((n, 16, 16, C3), z2)
             ws = _ws(z2)
+            tb2, db2 = _grad_target(b2)  # bias gradient of the layer below = channel sums of dg3: fused
             call("mvk_conv4s2_small_up_bwd", ptr(dout), ptr(out), SIGMOID, ptr(g3), RELU, ptr(w3), ptr(dg3), ptr(tw3),
-                 ptr(tb3), ptr(ws), ws.numel(), n, 16, 16, C4, C3, stream_ptr())
+                 ptr(tb3), ptr(tb2), ptr(ws), ws.numel(), n, 16, 16, C4, C3, stream_ptr())
         else:
             dw3 = conv_wgrad(dout, g3, w3, n, 16, 16, C4, C3, u_nchw=True, u_act_src=out, u_act=SIGMOID)
             tb3, db3 = _grad_target(b3)
@@ -344,7 +345,8 @@ class SVHNDecoderFn(Function):
             dg3 = conv_down(dout, wd3, None, n, 16, 16, C4, C3, NONE, u_nchw=True, u_act_src=out, u_act=SIGMOID,
                             v_act_src=g3, v_act=RELU)
         dw2 = conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2)
-        db2 = colsum(dg3.view(-1, C3), b2)
+        if not ctx.small:
+            db2 = colsum(dg3.view(-1, C3), b2)
         dg2 = conv_down(dg3, wd2, None, n, 8, 8, C3, C2, NONE, v_act_src=g2, v_act=RELU)
         dw1 = conv_wgrad(dg2, g1, w1, n, 4, 4, C2, C1)
         db1 = colsum(dg2.view(-1, C2), b1)

@@ -517,8 +517,10 @@ def test_small_up_fwd_bwd(K, n, h, w, Cu, Cv):
     dW = torch.zeros_like(Wd)
     db = torch.zeros_like(bd)
     ws = K._ws(Vd)
-    call("mvk_conv4s2_small_up_bwd", ptr(dod), ptr(out), 2, ptr(Vd), 1, ptr(Wd), ptr(dV), ptr(dW), ptr(db), ptr(ws),
-         ws.numel(), n, h, w, Cu, Cv, stream_ptr())
+    dbv = torch.zeros(Cv, device=d)
+    call("mvk_conv4s2_small_up_bwd", ptr(dod), ptr(out), 2, ptr(Vd), 1, ptr(Wd), ptr(dV), ptr(dW), ptr(db), ptr(dbv),
+         ptr(ws), ws.numel(), n, h, w, Cu, Cv, stream_ptr())
+    close(dbv, (Vr.grad * (V > 0).float()).sum(dim=(0, 2, 3)), what="small up channel sums of dV")
     close(nchw(dV.cpu()), Vr.grad * (V > 0).float(), what="small up dV (relu mask fused)")
     close(dW, Wr.grad, what="small up dW")
     close(db, br.grad, what="small up db")
