@@ -39,4 +39,5 @@ __device__ __forceinline__ float mvk_act_grad_from_out(float y, int act) {
   return 1.f;
 }
 
+__device__ __forceinline__ bool mvk_dev_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline bool mvk_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

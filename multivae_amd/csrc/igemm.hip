@@ -84,11 +84,15 @@ static int try_launch_fast(const GemmDesc& d, int zdim, hipStream_t s) {
 }
 
 static unsigned long long* g_dbg = nullptr;
+static int g_dbg_flags = 0;
 extern "C" void mvk_debug_set_phase_buffer(unsigned long long* p) { g_dbg = p; }
+extern "C" void mvk_debug_set_flags(int f) { g_dbg_flags = f; }
 
 int launch_igemm(const GemmDesc& d_in, int zdim, hipStream_t s) {
   GemmDesc d = d_in;
   d.dbg = g_dbg;
+  d.dbg_flags = g_dbg_flags;
+  { static int stg = -1; if (stg < 0) { const char* e = getenv("MVK_STAGGER"); stg = e ? atoi(e) : 0; } d.stagger = stg; }
   if (d.M <= 0 || d.N <= 0 || d.K <= 0) return MVK_OK;
   {
     const int rc = try_launch_fast(d, zdim, s);

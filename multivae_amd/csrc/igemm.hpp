@@ -62,6 +62,8 @@ struct GemmDesc {
   int zmode;
   int ksplit_tiles;  // Z_SPLITK: k-tiles per z slice
   unsigned long long* dbg;  // phase-cycle counters (debug builds with -DMVK_PHASES only)
+  int dbg_flags;            // experiment switches (debug builds only)
+  int stagger;              // start-up de-phasing of co-resident workgroups (units of 32*64 cycles)
 };
 
 #ifndef MVK_MIN_WAVES
@@ -200,6 +202,86 @@ __device__ __forceinline__ void run_epilogue(const GemmDesc& d, f32x16 (&acc)[T:
       }
     }
   }
+}
+
+// ---- vectorised epilogue ------------------------------------------------------------------------------------------
+// For row-major / NHWC-parity outputs with N % 4 == 0: the accumulators of `RP` tile rows at a time are parked in
+// LDS as a [RP][BN+4] slab, then every thread emits whole float4 row segments: one address computation, one
+// bias / activation-mask float4 load and one 16-byte store per 4 outputs, all mask loads independent (the scalar
+// epilogue above does a dependent 4-byte load + address decode per element).
+template <class T, int BM, int BN, int LDS_FLOATS>
+__device__ __forceinline__ bool run_epilogue_vec(const GemmDesc& d, f32x16 (&acc)[T::TM][T::TN], float* lds, int tid,
+                                                 int m0, int n0, int wm, int wn, int l31, int lhi, int ph, int pw) {
+  const Epilogue& E = d.e;
+  constexpr int CS = BN + 4;
+  // rows per pass: a multiple of 32 (one MFMA tile row block per wave row) that fits the LDS budget
+  constexpr int RP_MAX = LDS_FLOATS / CS;
+  constexpr int RP = (RP_MAX >= BM) ? BM : ((RP_MAX >= T::WTM && T::WAVES_M > 1) ? T::WTM : (RP_MAX >= 32 ? 32 : 0));
+  if (RP == 0) return false;
+  const bool vec_ok = !E.ws && !E.atomic && (E.kind == E_ROWMAJOR || E.kind == E_UP) && (d.N % 4 == 0) &&
+                      mvk_dev_aligned16(E.out) && (!E.act_src || mvk_dev_aligned16(E.act_src)) &&
+                      (E.kind == E_UP ? (E.Cu % 4 == 0) : (E.ld % 4 == 0)) &&
+                      (!E.bias || (E.bias_mod % 4 == 0 && mvk_dev_aligned16(E.bias)));
+  if (!vec_ok) return false;
+  constexpr int NPASS = BM / RP;
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    const int r_lo = p * RP;
+    // park: each lane writes its accumulator elements that fall into rows [r_lo, r_lo + RP)
+#pragma unroll
+    for (int a = 0; a < T::TM; ++a) {
+      const int rbase = wm * T::WTM + a * 32;  // tile-local row of this 32-row block
+      if (rbase >= r_lo && rbase < r_lo + RP) {
+#pragma unroll
+        for (int b = 0; b < T::TN; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            lds[(rbase - r_lo + (r & 3) + 8 * (r >> 2) + 4 * lhi) * CS + wn * T::WTN + b * 32 + l31] = acc[a][b][r];
+      }
+    }
+    __syncthreads();
+    constexpr int UNITS = RP * BN / 4;
+#pragma unroll
+    for (int u = 0; u < (UNITS + 255) / 256; ++u) {
+      const int idx = tid + u * 256;
+      if (idx < UNITS) {
+        const int row = idx / (BN / 4);
+        const int c4 = (idx - row * (BN / 4)) * 4;
+        const int m = m0 + r_lo + row, n = n0 + c4;
+        if (m < d.M && n < d.N) {
+          long long off;
+          if (E.kind == E_ROWMAJOR) {
+            off = (long long)m * E.ld + n;
+          } else {
+            Pos ps = decode_pos(m, E.OH, E.OW);
+            off = (((long long)ps.n * (2 * E.OH) + 2 * ps.i + ph) * (2 * E.OW) + 2 * ps.j + pw) * E.Cu + n;
+          }
+          float4 v = *reinterpret_cast<const float4*>(lds + row * CS + c4);
+          if (E.bias) {
+            const float4 bb = *reinterpret_cast<const float4*>(E.bias + (n % E.bias_mod));
+            v.x += bb.x;
+            v.y += bb.y;
+            v.z += bb.z;
+            v.w += bb.w;
+          }
+          v.x = mvk_act(v.x, E.act);
+          v.y = mvk_act(v.y, E.act);
+          v.z = mvk_act(v.z, E.act);
+          v.w = mvk_act(v.w, E.act);
+          if (E.act_src) {
+            const float4 y = *reinterpret_cast<const float4*>(E.act_src + off);
+            v.x *= mvk_act_grad_from_out(y.x, E.src_act);
+            v.y *= mvk_act_grad_from_out(y.y, E.src_act);
+            v.z *= mvk_act_grad_from_out(y.z, E.src_act);
+            v.w *= mvk_act_grad_from_out(y.w, E.src_act);
+          }
+          *reinterpret_cast<float4*>(E.out + off) = v;
+        }
+      }
+    }
+    if (p + 1 < NPASS) __syncthreads();
+  }
+  return true;
 }
 
 template <int BM, int BN>

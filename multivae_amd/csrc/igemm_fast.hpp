@@ -141,6 +141,12 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
   // global -> registers (no dependent use: the loads stay in flight across the MFMAs)
   // ------------------------------------------------------------------------------------------------
   auto load_tiles = [&](int k0) {
+#if defined(MVK_PHASES) || defined(MVK_EXPER)
+    if (d.dbg_flags & 1) {  // experiment: no A traffic
+      for (int u = 0; u < T::NA4; ++u) ra[u] = u32x4{0, 0, 0, 0};
+      goto load_b_only;
+    }
+#endif
     if (AMODE == AM_PLAIN_K) {
 #pragma unroll
       for (int u = 0; u < T::NA4; ++u) {
@@ -177,7 +183,12 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
         const int kq = (idx % (BKT / 4)) * 4;
         const int hh = mul * pb[u] + dh, ww = mul * pc[u] + dw;
         const bool ok = pa[u] >= 0 && (k0 + kq) < kend && hh >= 0 && hh < A.H && ww >= 0 && ww < A.W;
-        const int off = ok ? (((pa[u] * A.H + hh) * A.W + ww) * A.C + c0 + kq) * 4 : OOB;
+#if defined(MVK_PHASES) || defined(MVK_EXPER)
+        const int img = (d.dbg_flags & 4) ? (pa[u] & 7) : pa[u];  // experiment: all blocks read 8 images (cache hits)
+#else
+        const int img = pa[u];
+#endif
+        const int off = ok ? (((img * A.H + hh) * A.W + ww) * A.C + c0 + kq) * 4 : OOB;
         ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
       }
     } else {  // AM_COL: rows = (tap, channel), k = position
@@ -203,6 +214,13 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
         ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
       }
     }
+#if defined(MVK_PHASES) || defined(MVK_EXPER)
+  load_b_only:
+    if (d.dbg_flags & 2) {  // experiment: no B traffic
+      for (int u = 0; u < T::NB4; ++u) rb[u] = u32x4{0, 0, 0, 0};
+      return;
+    }
+#endif
     if (BMODE == BM_K) {
 #pragma unroll
       for (int u = 0; u < T::NB4; ++u) {
@@ -224,6 +242,9 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
   // registers -> LDS (k-major tiles)
   // ------------------------------------------------------------------------------------------------
   auto store_tiles = [&](int buf) {
+#if defined(MVK_PHASES) || defined(MVK_EXPER)
+    if (d.dbg_flags & 16) return;  // experiment: no LDS writes
+#endif
     float* da = As + buf * BKT * T::SA;
     float* db = Bs + buf * BKT * T::SB;
 #pragma unroll
@@ -269,6 +290,7 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
   };
 
   auto compute = [&](int buf) {
+    if (d.stagger == 2) __builtin_amdgcn_s_setprio(3);
     const float* a_s = As + buf * BKT * T::SA + wm * T::WTM + l31;
     const float* b_s = Bs + buf * BKT * T::SB + wn * T::WTN + l31;
 #pragma unroll
@@ -284,6 +306,7 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
         for (int b = 0; b < T::TN; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
     }
+    if (d.stagger == 2) __builtin_amdgcn_s_setprio(0);
   };
 
 #ifdef MVK_PHASES
@@ -293,6 +316,15 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
 #else
 #define MVK_TICK(i, prev)
 #endif
+  // De-phase the workgroups that share a CU (EXPERIMENT): identical blocks started together issue their tile
+  // loads in global bursts and then all sit in the MFMA phase with the memory system idle.
+  if (d.stagger == 1) {  // EXPERIMENT: static priority per co-resident workgroup -> same MFMA arbitration on all SIMDs
+    const int phs = (blockIdx.x / 256) % 3;
+    if (phs == 0) __builtin_amdgcn_s_setprio(3);
+    else if (phs == 1) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(1);
+  } else if (d.stagger == 2) {  // EXPERIMENT: priority raised only around the MFMA section (see compute)
+  }
   load_tiles(kbeg);
   store_tiles(0);
   __syncthreads();
@@ -307,6 +339,10 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
     MVK_TICK(0, tk)
     compute(buf);
     MVK_TICK(1, tk)
+#ifdef MVK_PHASES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MVK_TICK(4, tk)   // pure global-load wait (ph_t[4] also holds the prologue time; subtract it when reading)
+#endif
     if (more) store_tiles(buf ^ 1);
     MVK_TICK(2, tk)
     __syncthreads();
@@ -322,6 +358,15 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
     atomicAdd(d.dbg + 7, 1ull);
   }
 #endif
+#if defined(MVK_PHASES) || defined(MVK_EXPER)
+  if (d.dbg_flags & 8) {  // experiment: no epilogue (keep the accumulators alive)
+    float s = 0.f;
+    for (int a = 0; a < T::TM; ++a) for (int b = 0; b < T::TN; ++b) for (int r = 0; r < 16; ++r) s += acc[a][b][r];
+    if (s == 12345.678f) d.e.out[0] = s;
+    return;
+  }
+#endif
+  if (run_epilogue_vec<T, BM, BN, 2 * BKT * (T::SA + T::SB)>(d, acc, lds, tid, m0, n0, wm, wn, l31, lhi, ph, pw)) return;
   run_epilogue<T>(d, acc, lds, tid, m0, n0, wm, wn, l31, lhi, ph, pw);
 }
 
