@@ -70,16 +70,11 @@ static int try_launch_fast(const GemmDesc& d, int zdim, hipStream_t s) {
     if (c16 && (long long)((d.M + 255) / 256) * zdim >= 512) return launch_fast_tile<256, 32, 16>(d, zdim, s, amode, bmode, aact);
     return c32 ? launch_fast_tile<128, 32, 32>(d, zdim, s, amode, bmode, aact) : 1;
   }
-  if (d.N <= 64) {
-    if (!c32) return 1;
-    if (d.M <= 64 || getenv("MVK_T64")) return launch_fast_tile<64, 64, 32>(d, zdim, s, amode, bmode, aact);
-    return launch_fast_tile<128, 64, 32>(d, zdim, s, amode, bmode, aact);
-  }
-  long long big = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * zdim;
-  if (big >= 192) return c16 ? launch_fast_tile<128, 128, 16>(d, zdim, s, amode, bmode, aact) : 1;
+  // pick the largest tile that still gives >= 1.5 workgroups per CU (384); small problems take 64x64
+  auto nblk = [&](int bm, int bn) { return (long long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * zdim; };
+  if (d.N > 64 && c16 && nblk(128, 128) >= 384) return launch_fast_tile<128, 128, 16>(d, zdim, s, amode, bmode, aact);
   if (!c32) return 1;
-  long long mid = (long long)((d.M + 127) / 128) * ((d.N + 63) / 64) * zdim;
-  if (mid >= 192 || d.M > 4096) return launch_fast_tile<128, 64, 32>(d, zdim, s, amode, bmode, aact);
+  if (nblk(128, 64) >= 384) return launch_fast_tile<128, 64, 32>(d, zdim, s, amode, bmode, aact);
   return launch_fast_tile<64, 64, 32>(d, zdim, s, amode, bmode, aact);
 }
 

@@ -38,66 +38,86 @@ __global__ __launch_bounds__(256) void small_up_fwd_kernel(const float* __restri
   float* buf = smem + CV * C::NC;   // V tile [P][VS], later the column matrix [P][CS]
   const int P = h * w;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
-  const long long img = blockIdx.x;
   for (int i = tid; i < CV * C::NC; i += 256) Ws[i] = Wref[i];
-  const float4* src = reinterpret_cast<const float4*>(V + img * P * CV);
-  for (int idx = tid; idx < P * CV / 4; idx += 256) {
-    const int pos = idx / (CV / 4), q = idx - pos * (CV / 4);
-    *reinterpret_cast<float4*>(buf + pos * C::VS + 4 * q) = src[idx];
-  }
-  __syncthreads();
-  f32x4 acc[C::MT][CU];
+  constexpr int NV = 256 * CV / 4 / 256;  // float4 per thread for a full 256-position tile
+  const int n4 = P * CV / 4;
+  f32x4 pre[NV];  // ext-vector type: HIP's float4 struct arrays are not promoted to registers here
+  auto prefetch = [&](long long img) __attribute__((always_inline)) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(V + img * P * CV);
 #pragma unroll
-  for (int a = 0; a < C::MT; ++a)
-#pragma unroll
-    for (int b = 0; b < CU; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool active = wave * 64 < P;
-  if (active) {
-#pragma unroll 2
-    for (int ks = 0; ks < CV / 4; ++ks) {
-      const int k = ks * 4 + lq;
-      float av[C::MT], bv[CU];
-#pragma unroll
-      for (int a = 0; a < C::MT; ++a) av[a] = buf[(wave * 64 + a * 16 + l15) * C::VS + k];
-#pragma unroll
-      for (int b = 0; b < CU; ++b) bv[b] = Ws[k * C::NC + b * 16 + l15];
-#pragma unroll
-      for (int a = 0; a < C::MT; ++a)
-#pragma unroll
-        for (int b = 0; b < CU; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    for (int u = 0; u < NV; ++u) {
+      const int idx = tid + u * 256;
+      pre[u] = src[idx < n4 ? idx : n4 - 1];  // clamped: unconditional loads keep pre[] in registers
     }
-  }
-  __syncthreads();  // every wave is done with the V tile
-  if (active) {
+  };
+  const bool active = wave * 64 < P;
+  const int H2 = 2 * h, W2 = 2 * w;
+  const int per_img = CU * H2 * W2;
+  long long img = blockIdx.x;
+  if (img < n) prefetch(img);
+  for (; img < n; img += gridDim.x) {
+    // stage this image's V tile (prefetched one iteration ago), then start fetching the next image
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int idx = tid + u * 256;
+      if (idx < n4) {
+        const int pos = idx / (CV / 4), q = idx - pos * (CV / 4);
+        *reinterpret_cast<f32x4*>(buf + pos * C::VS + 4 * q) = pre[u];
+      }
+    }
+    __syncthreads();
+    if (img + gridDim.x < n) prefetch(img + gridDim.x);
+    f32x4 acc[C::MT][CU];
 #pragma unroll
     for (int a = 0; a < C::MT; ++a)
 #pragma unroll
-      for (int b = 0; b < CU; ++b)
+      for (int b = 0; b < CU; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (active) {
+#pragma unroll 2
+      for (int ks = 0; ks < CV / 4; ++ks) {
+        const int k = ks * 4 + lq;
+        float av[C::MT], bv[CU];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) buf[(wave * 64 + a * 16 + lq * 4 + r) * C::CS + b * 16 + l15] = acc[a][b][r];
-  }
-  __syncthreads();
-  const int H2 = 2 * h, W2 = 2 * w;
-  const int per_img = CU * H2 * W2;
-  float* out = U + img * per_img;
-  for (int o = tid; o < per_img; o += 256) {
-    const int cu = o / (H2 * W2);
-    const int rem = o - cu * (H2 * W2);
-    const int oh = rem / W2, ow = rem - oh * W2;
-    const int ph = oh & 1, pw = ow & 1, i0 = oh >> 1, j0 = ow >> 1;
-    float s = bias ? bias[cu] : 0.f;
+        for (int a = 0; a < C::MT; ++a) av[a] = buf[(wave * 64 + a * 16 + l15) * C::VS + k];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int ih = i0 + ph - a, kh = (1 - ph) + 2 * a;
-      if (ih < 0 || ih >= h) continue;
+        for (int b = 0; b < CU; ++b) bv[b] = Ws[k * C::NC + b * 16 + l15];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int iw = j0 + pw - b, kw = (1 - pw) + 2 * b;
-        if (iw < 0 || iw >= w) continue;
-        s += buf[(ih * w + iw) * C::CS + cu * 16 + kh * 4 + kw];
+        for (int a = 0; a < C::MT; ++a)
+#pragma unroll
+          for (int b = 0; b < CU; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
       }
     }
-    out[o] = mvk_act(s, act);
+    __syncthreads();  // every wave is done with the V tile
+    if (active) {
+#pragma unroll
+      for (int a = 0; a < C::MT; ++a)
+#pragma unroll
+        for (int b = 0; b < CU; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) buf[(wave * 64 + a * 16 + lq * 4 + r) * C::CS + b * 16 + l15] = acc[a][b][r];
+    }
+    __syncthreads();
+    float* out = U + img * per_img;
+    for (int o = tid; o < per_img; o += 256) {
+      const int cu = o / (H2 * W2);
+      const int rem = o - cu * (H2 * W2);
+      const int oh = rem / W2, ow = rem - oh * W2;
+      const int ph = oh & 1, pw = ow & 1, i0 = oh >> 1, j0 = ow >> 1;
+      float s = bias ? bias[cu] : 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int ih = i0 + ph - a, kh = (1 - ph) + 2 * a;
+        if (ih < 0 || ih >= h) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int iw = j0 + pw - b, kw = (1 - pw) + 2 * b;
+          if (iw < 0 || iw >= w) continue;
+          s += buf[(ih * w + iw) * C::CS + cu * 16 + kh * 4 + kw];
+        }
+      }
+      out[o] = mvk_act(s, act);
+    }
+    __syncthreads();  // the column matrix is overwritten by the next image's V tile
   }
 }
 
@@ -137,32 +157,63 @@ __global__ __launch_bounds__(256) void small_up_bwd_kernel(const float* __restri
   for (int b = 0; b < C::NTV; ++b) dbv[b] = 0.f;
 
   const int H2 = 2 * h, W2 = 2 * w;
-  for (long long img = blockIdx.x; img < n; img += gridDim.x) {
-    __syncthreads();  // previous image's tiles are no longer read
-    // --- stage dUpre (NCHW) with halo; sigmoid' (or any act') applied on the fly; bias-gradient partials
+  // register prefetch of the NEXT image's three tiles (dU, Uout with halo indexing; V as float4)
+  constexpr int ND = (CU * 34 * 34 + 255) / 256;  // halo-tile elements per thread (h, w <= 16)
+  constexpr int NV = 256 * CV / 4 / 256;
+  const int nd = CU * DH * DW, n4 = P * CV / 4;
+  float pdu[ND], puo[ND];
+  f32x4 pv[NV];
+  auto prefetch = [&](long long img) __attribute__((always_inline)) {
     const float* du = dU + img * CU * H2 * W2;
     const float* uo = Uout + img * CU * H2 * W2;
-    for (int idx = tid; idx < CU * DH * DW; idx += 256) {
-      const int cu = idx / (DH * DW);
-      const int rem = idx - cu * (DH * DW);
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int idx = tid + u * 256;
+      const int idc = idx < nd ? idx : nd - 1;
+      const int cu = idc / (DH * DW);
+      const int rem = idc - cu * (DH * DW);
       const int y = rem / DW, x = rem - y * DW;
       const int oh = y - 1, ow = x - 1;
-      float v = 0.f;
-      if (oh >= 0 && oh < H2 && ow >= 0 && ow < W2) {
-        const int off = (cu * H2 + oh) * W2 + ow;
-        v = du[off] * mvk_act_grad_from_out(uo[off], u_act);
-      }
-      Ds[idx] = v;
-#pragma unroll
-      for (int c = 0; c < CU; ++c)
-        if (c == cu) dbl[c] += v;
+      const bool in = idx < nd && oh >= 0 && oh < H2 && ow >= 0 && ow < W2;
+      const int ohc = oh < 0 ? 0 : (oh >= H2 ? H2 - 1 : oh), owc = ow < 0 ? 0 : (ow >= W2 ? W2 - 1 : ow);
+      const int off = (cu * H2 + ohc) * W2 + owc;  // clamped address: the load is unconditional, the halo is zeroed below
+      const float a = du[off], b = uo[off];
+      pdu[u] = in ? a : 0.f;
+      puo[u] = in ? b : 0.f;
     }
-    const float4* src = reinterpret_cast<const float4*>(V + img * P * CV);
-    for (int idx = tid; idx < P * CV / 4; idx += 256) {
-      const int pos = idx / (CV / 4), q = idx - pos * (CV / 4);
-      *reinterpret_cast<float4*>(Vs + pos * C::VS + 4 * q) = src[idx];
+    const f32x4* src = reinterpret_cast<const f32x4*>(V + img * P * CV);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int idx = tid + u * 256;
+      pv[u] = src[idx < n4 ? idx : n4 - 1];
+    }
+  };
+  if ((long long)blockIdx.x < n) prefetch(blockIdx.x);
+  for (long long img = blockIdx.x; img < n; img += gridDim.x) {
+    __syncthreads();  // previous image's tiles are no longer read
+    // --- stage dUpre with halo (sigmoid' applied here), bias-gradient partials, and the V tile
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int idx = tid + u * 256;
+      if (idx < nd) {
+        const float v = pdu[u] * mvk_act_grad_from_out(puo[u], u_act);  // halo: 0 * act'(0) = 0
+        Ds[idx] = v;
+        const int cu = idx / (DH * DW);
+#pragma unroll
+        for (int c = 0; c < CU; ++c)
+          if (c == cu) dbl[c] += v;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int idx = tid + u * 256;
+      if (idx < n4) {
+        const int pos = idx / (CV / 4), q = idx - pos * (CV / 4);
+        *reinterpret_cast<f32x4*>(Vs + pos * C::VS + 4 * q) = pv[u];
+      }
     }
     __syncthreads();
+    if (img + gridDim.x < n) prefetch(img + gridDim.x);
     if (!active) continue;
     // --- backward data: dV[pos][cv] = sum_{k=(cu,kh,kw)} dUpre[cu][2i-1+kh][2j-1+kw] * W[cv][k]
     f32x4 acc[C::MT][C::NTV];
@@ -311,7 +362,8 @@ static int launch_fwd(const float* V, const float* Wref, const float* bias, floa
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_fwd_kernel<CU, CV>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((small_up_fwd_kernel<CU, CV>), dim3(n), dim3(256), lds, s, V, Wref, bias, U, n, h, w, act);
+  const int grid = n < 512 ? n : 512;  // persistent: 2 workgroups per CU, each loops over images with prefetch
+  hipLaunchKernelGGL((small_up_fwd_kernel<CU, CV>), dim3(grid), dim3(256), lds, s, V, Wref, bias, U, n, h, w, act);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }
