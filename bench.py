@@ -50,7 +50,17 @@ def cpu_baseline(model, data, K, L, budget_s=20.0):
     """The oracle's training step (torch CPU, same architecture / batch / K) on the host cores."""
     from oracle import train as otrain
 
+    # torch's intra-op pool scales poorly on these small convolutions.  Measured on the GPU box's host (2 x EPYC
+    # 9575F, 128 cores / 256 threads), samples/s by thread count: 16 -> 542, 32 -> 524, 64 -> 331, 128 -> 173,
+    # 256 -> 12.  The baseline uses the best setting (16); MVK_CPU_THREADS overrides it.
     ncores = os.cpu_count() or 1
+    try:
+        import psutil
+
+        ncores = psutil.cpu_count(logical=False) or ncores
+    except Exception:
+        pass
+    ncores = max(1, min(ncores, int(os.environ.get("MVK_CPU_THREADS", "16"))))
     torch.set_num_threads(ncores)
     sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
     st = otrain.AdamState(sd)
@@ -95,7 +105,8 @@ def main():
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
 
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("MVK_FORCE_DIST") == "1"  # the latter exercises the RCCL path on 1 GPU
+    if use_dist:
         dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)  # nccl == RCCL on ROCm
 
     from multivae_amd import kernels
@@ -105,7 +116,7 @@ def main():
     B, K, L = args.batch, args.K, args.latent_dim
     model = build_model(K, L, device, seed=0)
     flat = FlatParams(model)
-    if world > 1:
+    if use_dist:
         flat.broadcast(0)  # C1: one parameter broadcast
     opt = FusedAdam(flat, lr=1e-3)
     data = synthetic_batch(B, device, seed=rank)
@@ -118,7 +129,7 @@ def main():
         opt.zero_grad()
         out = model(inputs, noise=eps)
         out.loss.backward()
-        if world > 1:
+        if use_dist:
             flat.all_reduce()  # C2: ONE all-reduce of the flat gradient buffer
         opt.step(grad_scale=grad_scale)
         return out
@@ -126,7 +137,7 @@ def main():
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     kernels.PROFILE["recon_nll"] = []
@@ -134,7 +145,7 @@ def main():
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -144,7 +155,7 @@ def main():
         raise ArithmeticError("NaN detected in train loss")
 
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -185,7 +196,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(model, data, K, L, args.cpu_budget)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
