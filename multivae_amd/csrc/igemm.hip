@@ -1,5 +1,5 @@
 // C-ABI entry points built on the fp32 MFMA implicit-GEMM engine (igemm.hpp).
-#include "igemm_fast.hpp"
+#include "igemm_bf.hpp"
 #include <cstdlib>
 
 namespace mvk {
@@ -31,6 +31,36 @@ static int launch_fast_tile(const GemmDesc& d, int zdim, hipStream_t s, int amod
   if (amode == AM_ROW && bmode == BM_N && !aact) return launch_fast_cfg<BM, BN, BKT, AM_ROW, BM_N, false>(d, zdim, s);
   if (amode == AM_COL && bmode == BM_N && !aact) return launch_fast_cfg<BM, BN, BKT, AM_COL, BM_N, false>(d, zdim, s);
   return 1;  // combination not instantiated -> generic kernel
+}
+
+// ---- split-precision kernels (igemm_bf.hpp) ----------------------------------------------------------------------
+template <int BM, int BN, int AMODE, int BMODE, bool AACT>
+static int launch_bf_cfg(const GemmDesc& d, int zdim, hipStream_t s) {
+  dim3 grid((d.M + BM - 1) / BM, (d.N + BN - 1) / BN, zdim);
+  hipLaunchKernelGGL((igemm_bf_kernel<BM, BN, AMODE, BMODE, AACT>), grid, dim3(256), 0, s, d);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+template <int BM, int BN>
+static int launch_bf_tile(const GemmDesc& d, int zdim, hipStream_t s, int amode, int bmode, bool aact) {
+  if (amode == AM_PLAIN_K && bmode == BM_K && !aact) return launch_bf_cfg<BM, BN, AM_PLAIN_K, BM_K, false>(d, zdim, s);
+  if (amode == AM_PLAIN_K && bmode == BM_N && !aact) return launch_bf_cfg<BM, BN, AM_PLAIN_K, BM_N, false>(d, zdim, s);
+  if (amode == AM_PLAIN_K && bmode == BM_N && aact) return launch_bf_cfg<BM, BN, AM_PLAIN_K, BM_N, true>(d, zdim, s);
+  if (amode == AM_PLAIN_R && bmode == BM_N && !aact) return launch_bf_cfg<BM, BN, AM_PLAIN_R, BM_N, false>(d, zdim, s);
+  if (amode == AM_PLAIN_R && bmode == BM_N && aact) return launch_bf_cfg<BM, BN, AM_PLAIN_R, BM_N, true>(d, zdim, s);
+  if (amode == AM_ROW && bmode == BM_N && !aact) return launch_bf_cfg<BM, BN, AM_ROW, BM_N, false>(d, zdim, s);
+  if (amode == AM_COL && bmode == BM_N && !aact) return launch_bf_cfg<BM, BN, AM_COL, BM_N, false>(d, zdim, s);
+  return 1;
+}
+
+static int g_engine = -1;  // 0 = fp32 MFMA, 1 = split-bf16 MFMA (MVK_ENGINE=f32|bf3)
+static int engine() {
+  if (g_engine < 0) {
+    const char* e = getenv("MVK_ENGINE");
+    g_engine = (e && e[0] == 'b') ? 1 : 0;
+  }
+  return g_engine;
 }
 
 // returns 1 when no specialised kernel applies
@@ -65,6 +95,19 @@ static int try_launch_fast(const GemmDesc& d, int zdim, hipStream_t s) {
   if (d.zmode == Z_SPLITK && (d.ksplit_tiles & 1)) return 1;  // BKT = 32 needs 32-aligned slices
   const bool c32 = (amode != AM_ROW) || (A.C % 32 == 0);
   const bool c16 = (amode != AM_ROW) || (A.C % 16 == 0);
+  if (engine() == 1 && c32) {
+    auto nb = [&](int bm, int bn) { return (long long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * zdim; };
+    int rc = 1;
+    if (d.N <= 32) {
+      if (nb(256, 32) >= 512) rc = launch_bf_tile<256, 32>(d, zdim, s, amode, bmode, aact);
+      else rc = launch_bf_tile<128, 32>(d, zdim, s, amode, bmode, aact);
+    } else if (d.N > 64 && nb(128, 128) >= 384) {
+      rc = launch_bf_tile<128, 128>(d, zdim, s, amode, bmode, aact);
+    } else if (nb(128, 64) >= 384) {
+      rc = launch_bf_tile<128, 64>(d, zdim, s, amode, bmode, aact);
+    }
+    if (rc != 1) return rc;
+  }
   if (d.N <= 32) {
     // tall-skinny: a 256-row tile lets every wave reuse its B fragment for two MFMA tiles
     if (c16 && (long long)((d.M + 255) / 256) * zdim >= 512) return launch_fast_tile<256, 32, 16>(d, zdim, s, amode, bmode, aact);
