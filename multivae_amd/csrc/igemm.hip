@@ -37,7 +37,8 @@ static int launch_fast_tile(const GemmDesc& d, int zdim, hipStream_t s, int amod
 template <int BM, int BN, int AMODE, int BMODE, bool AACT>
 static int launch_bf_cfg(const GemmDesc& d, int zdim, hipStream_t s) {
   dim3 grid((d.M + BM - 1) / BM, (d.N + BN - 1) / BN, zdim);
-  hipLaunchKernelGGL((igemm_bf_kernel<BM, BN, AMODE, BMODE, AACT>), grid, dim3(256), 0, s, d);
+  constexpr int DEPTH = 2;
+  hipLaunchKernelGGL((igemm_bf_kernel<BM, BN, AMODE, BMODE, AACT, DEPTH>), grid, dim3(256), 0, s, d);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }
@@ -54,11 +55,11 @@ static int launch_bf_tile(const GemmDesc& d, int zdim, hipStream_t s, int amode,
   return 1;
 }
 
-static int g_engine = -1;  // 0 = fp32 MFMA, 1 = split-bf16 MFMA (MVK_ENGINE=f32|bf3)
+static int g_engine = -1;  // 1 = split-bf16 MFMA (default), 0 = fp32 MFMA (MVK_ENGINE=f32)
 static int engine() {
   if (g_engine < 0) {
     const char* e = getenv("MVK_ENGINE");
-    g_engine = (e && e[0] == 'b') ? 1 : 0;
+    g_engine = (e && e[0] == 'f') ? 0 : 1;
   }
   return g_engine;
 }
@@ -99,10 +100,7 @@ static int try_launch_fast(const GemmDesc& d, int zdim, hipStream_t s) {
     auto nb = [&](int bm, int bn) { return (long long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * zdim; };
     int rc = 1;
     if (d.N <= 32) {
-      if (nb(256, 32) >= 512) rc = launch_bf_tile<256, 32>(d, zdim, s, amode, bmode, aact);
-      else rc = launch_bf_tile<128, 32>(d, zdim, s, amode, bmode, aact);
-    } else if (d.N > 64 && nb(128, 128) >= 384) {
-      rc = launch_bf_tile<128, 128>(d, zdim, s, amode, bmode, aact);
+      rc = launch_bf_tile<128, 32>(d, zdim, s, amode, bmode, aact);
     } else if (nb(128, 64) >= 384) {
       rc = launch_bf_tile<128, 64>(d, zdim, s, amode, bmode, aact);
     }
@@ -124,7 +122,12 @@ static int try_launch_fast(const GemmDesc& d, int zdim, hipStream_t s) {
 static unsigned long long* g_dbg = nullptr;
 static int g_dbg_flags = 0;
 extern "C" void mvk_debug_set_phase_buffer(unsigned long long* p) { g_dbg = p; }
-extern "C" void mvk_debug_set_flags(int f) { g_dbg_flags = f; }
+extern "C" void mvk_debug_set_flags(int f) {
+  g_dbg_flags = f;
+#ifdef MVK_EXPER
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bf_flags), &f, sizeof(int));
+#endif
+}
 
 int launch_igemm(const GemmDesc& d_in, int zdim, hipStream_t s) {
   GemmDesc d = d_in;

@@ -50,66 +50,108 @@ struct BfCfg {
 };
 
 // two fp32 values -> three dwords, each holding the (lo = x, hi = y) pair of one bf16 piece
+#ifdef MVK_EXPER
+__device__ int g_bf_flags;
+#endif
 __device__ __forceinline__ void bf_split3(float x, float y, unsigned& p0, unsigned& p1, unsigned& p2) {
-  const f32x2 v = {x, y};
-  const bf16x2 a0 = __builtin_convertvector(v, bf16x2);
-  const f32x2 r1 = v - __builtin_convertvector(a0, f32x2);
-  const bf16x2 a1 = __builtin_convertvector(r1, bf16x2);
-  const f32x2 r2 = r1 - __builtin_convertvector(a1, f32x2);
-  const bf16x2 a2 = __builtin_convertvector(r2, bf16x2);
+#ifdef MVK_EXPER
+  if (g_bf_flags & 1) {  // experiment: no conversion arithmetic
+    p0 = __builtin_amdgcn_perm(__float_as_uint(y), __float_as_uint(x), 0x07060302u);
+    p1 = p0;
+    p2 = p0;
+    return;
+  }
+#endif
+  // scalar subtractions on purpose (built with -fno-slp-vectorize): v_pk_add_f32 needs aligned register pairs,
+  // which costs copies of freshly loaded registers (and the waits that go with them) beside the MFMAs
+  const bf16x2 a0 = __builtin_convertvector(f32x2{x, y}, bf16x2);
   p0 = __builtin_bit_cast(unsigned, a0);
+  const float rx1 = x - __uint_as_float(p0 << 16), ry1 = y - __uint_as_float(p0 & 0xffff0000u);
+  const bf16x2 a1 = __builtin_convertvector(f32x2{rx1, ry1}, bf16x2);
   p1 = __builtin_bit_cast(unsigned, a1);
+  const float rx2 = rx1 - __uint_as_float(p1 << 16), ry2 = ry1 - __uint_as_float(p1 & 0xffff0000u);
+  const bf16x2 a2 = __builtin_convertvector(f32x2{rx2, ry2}, bf16x2);
   p2 = __builtin_bit_cast(unsigned, a2);
 }
 
-// Stage the N4 float4 units of one thread (row-contiguous operand: unit u = k index kg*N4+u, 4 consecutive rows)
-// into the LDS image: for each of the 4 rows, N4 consecutive k values per piece.
-template <int N4, int G, int PIECE>
-__device__ __forceinline__ void bf_store_rows(char* base, const f32x4 (&v)[N4], int row4, int kg) {
+// ---- staging: fp32 registers -> bf16 piece registers -> LDS ----------------------------------------------------
+// One thread owns N4 float4 units of an operand tile.
+//   k-contiguous operand (KC):   unit u = 4 k values of one row           -> pair j = (u = j/2, half j%2)
+//   row-contiguous operand:      unit u = k index kg*N4+u of 4 rows       -> pair j = (row i = j/(N4/2), k pair j%(N4/2))
+//                                (N4 == 1: four single values, one per row)
+// A "pair" is two k-adjacent values of one row = one dword of each bf16 piece.
+template <int N4, bool KC>
+struct BfStage {
+  static constexpr int NP = (KC || N4 >= 2) ? 2 * N4 : 4;  // pairs (dwords per piece) per thread
+};
+
+template <int N4, bool KC, bool ACT>
+__device__ __forceinline__ void bf_convert_pair(int j, const u32x4 (&raw)[N4], const u32x4 (&yraw)[ACT ? N4 : 1], int act,
+                                                unsigned (&pc)[3][BfStage<N4, KC>::NP]) {
+  float x, y = 0.f, gx = 1.f, gy = 1.f;
+  if (KC) {
+    const int u = j / 2, h = j % 2;
+    x = __uint_as_float(raw[u][2 * h]);
+    y = __uint_as_float(raw[u][2 * h + 1]);
+    if (ACT) {
+      gx = mvk_act_grad_from_out(__uint_as_float(yraw[ACT ? u : 0][2 * h]), act);
+      gy = mvk_act_grad_from_out(__uint_as_float(yraw[ACT ? u : 0][2 * h + 1]), act);
+    }
+  } else if (N4 >= 2) {
+    constexpr int H = N4 / 2 > 0 ? N4 / 2 : 1;
+    const int i = j / H, jj = j % H;
+    x = __uint_as_float(raw[(2 * jj) % N4][i]);
+    y = __uint_as_float(raw[(2 * jj + 1) % N4][i]);
+    if (ACT) {
+      gx = mvk_act_grad_from_out(__uint_as_float(yraw[ACT ? (2 * jj) % N4 : 0][i]), act);
+      gy = mvk_act_grad_from_out(__uint_as_float(yraw[ACT ? (2 * jj + 1) % N4 : 0][i]), act);
+    }
+  } else {
+    x = __uint_as_float(raw[0][j]);
+    if (ACT) gx = mvk_act_grad_from_out(__uint_as_float(yraw[0][j]), act);
+  }
+  if (ACT) {
+    x *= gx;
+    y *= gy;
+  }
+  bf_split3(x, y, pc[0][j], pc[1][j], pc[2][j]);
+}
+
+template <int N4, bool KC, int G, int PIECE>
+__device__ __forceinline__ void bf_write_pieces(char* base, const unsigned (&pc)[3][BfStage<N4, KC>::NP], int tid, int row4,
+                                                int kg) {
+  if (KC) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    char* dst = base + i * G + row4 * 80 + kg * N4 * 2;
-    if (N4 == 1) {
-      unsigned p0, p1, p2;
-      bf_split3(v[0][i], 0.f, p0, p1, p2);
-      *reinterpret_cast<unsigned short*>(dst) = (unsigned short)p0;
-      *reinterpret_cast<unsigned short*>(dst + PIECE) = (unsigned short)p1;
-      *reinterpret_cast<unsigned short*>(dst + 2 * PIECE) = (unsigned short)p2;
-    } else {
-      constexpr int NP = N4 / 2 > 0 ? N4 / 2 : 1;
-      unsigned q0[NP], q1[NP], q2[NP];
+    for (int u = 0; u < N4; ++u) {
+      const int idx = tid + u * 256;
+      const int row = idx / 8, kq = (idx % 8) * 4;
+      char* dst = base + (row & 3) * G + (row >> 2) * 80 + kq * 2;
 #pragma unroll
-      for (int j = 0; j < N4 / 2; ++j) bf_split3(v[2 * j][i], v[(2 * j + 1) % N4][i], q0[j], q1[j], q2[j]);
-      if (N4 == 2) {
-        *reinterpret_cast<unsigned*>(dst) = q0[0];
-        *reinterpret_cast<unsigned*>(dst + PIECE) = q1[0];
-        *reinterpret_cast<unsigned*>(dst + 2 * PIECE) = q2[0];
-      } else if (N4 == 4) {
-        *reinterpret_cast<u32x2*>(dst) = u32x2{q0[0], q0[1 % NP]};
-        *reinterpret_cast<u32x2*>(dst + PIECE) = u32x2{q1[0], q1[1 % NP]};
-        *reinterpret_cast<u32x2*>(dst + 2 * PIECE) = u32x2{q2[0], q2[1 % NP]};
-      } else {  // 8
-        *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1 % NP], q0[2 % NP], q0[3 % NP]};
-        *reinterpret_cast<u32x4*>(dst + PIECE) = u32x4{q1[0], q1[1 % NP], q1[2 % NP], q1[3 % NP]};
-        *reinterpret_cast<u32x4*>(dst + 2 * PIECE) = u32x4{q2[0], q2[1 % NP], q2[2 % NP], q2[3 % NP]};
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(dst + p * PIECE) = u32x2{pc[p][2 * u], pc[p][2 * u + 1]};
+    }
+  } else {
+    constexpr int H = N4 / 2 > 0 ? N4 / 2 : 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      char* dst = base + i * G + row4 * 80 + kg * N4 * 2;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        if (N4 == 1) {
+          *reinterpret_cast<unsigned short*>(dst + p * PIECE) = (unsigned short)pc[p][i];
+        } else if (N4 == 2) {
+          *reinterpret_cast<unsigned*>(dst + p * PIECE) = pc[p][i * H];
+        } else if (N4 == 4) {
+          *reinterpret_cast<u32x2*>(dst + p * PIECE) = u32x2{pc[p][i * H], pc[p][i * H + 1 % H]};
+        } else {
+          *reinterpret_cast<u32x4*>(dst + p * PIECE) =
+              u32x4{pc[p][i * H], pc[p][i * H + 1 % H], pc[p][i * H + 2 % H], pc[p][i * H + 3 % H]};
+        }
       }
     }
   }
 }
 
-// k-contiguous operand: one float4 = 4 k values of one row
-template <int G, int PIECE>
-__device__ __forceinline__ void bf_store_k4(char* base, const f32x4& v, int row, int kq) {
-  unsigned a0, a1, a2, b0, b1, b2;
-  bf_split3(v[0], v[1], a0, a1, a2);
-  bf_split3(v[2], v[3], b0, b1, b2);
-  char* dst = base + (row & 3) * G + (row >> 2) * 80 + kq * 2;
-  *reinterpret_cast<u32x2*>(dst) = u32x2{a0, b0};
-  *reinterpret_cast<u32x2*>(dst + PIECE) = u32x2{a1, b1};
-  *reinterpret_cast<u32x2*>(dst + 2 * PIECE) = u32x2{a2, b2};
-}
-
-template <int BM, int BN, int AMODE, int BMODE, bool AACT>
+template <int BM, int BN, int AMODE, int BMODE, bool AACT, int DEPTH>
 __global__ __launch_bounds__(256, 2) void igemm_bf_kernel(const GemmDesc d) {
   using T = BfCfg<BM, BN>;
   constexpr int BKT = T::BKT;
@@ -147,6 +189,9 @@ __global__ __launch_bounds__(256, 2) void igemm_bf_kernel(const GemmDesc d) {
     for (int b = 0; b < T::TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  f32x16 acc2;  // second accumulator of single-tile waves (see step)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
 
   constexpr int OOB = 0x7fffffff;  // buffer loads past num_records return 0 (see igemm_fast.hpp)
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A.p, 0, 0x7ffffff0, 0x00020000);
@@ -160,6 +205,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf_kernel(const GemmDesc d) {
   const int a_row4 = tid % (BM / 4), a_kg = tid / (BM / 4);
   const int b_row4 = tid % (BN / 4), b_kg = tid / (BN / 4);
   int abase[T::NA4], pa[T::NA4], pb[T::NA4], pc[T::NA4];
+  int col_th = -(1 << 20), col_tw = 0, col_ch = 0;  // AM_COL: tap row / column offset and channel of this thread's rows
 #pragma unroll
   for (int u = 0; u < T::NA4; ++u) {
     const int idx = tid + u * 256;
@@ -173,12 +219,15 @@ __global__ __launch_bounds__(256, 2) void igemm_bf_kernel(const GemmDesc d) {
       const int r = m0 + a_row4 * 4;
       if (r < d.M) abase[u] = (a_kg * T::NA4 + u) * (int)A.sk + r;
     } else if (AMODE == AM_ROW) {
+      // hoisted gather geometry: pa = byte offset of tap (0,0) at this unit's k quad, pb / pc = mul*i, mul*j
       const int r = m0 + idx / 8;
+      pb[u] = -(1 << 20);  // invalid row: every bounds test fails
       if (r < d.M) {
         Pos ps = decode_pos(r, A.OH, A.OW);
-        pa[u] = ps.n;
-        pb[u] = ps.i;
-        pc[u] = ps.j;
+        const int mul = (A.kind == A_UP) ? 1 : 2;
+        pb[u] = mul * ps.i;
+        pc[u] = mul * ps.j;
+        pa[u] = (((ps.n * A.H + pb[u]) * A.W + pc[u]) * A.C + (idx % 8) * 4) * 4;
       }
     } else {  // AM_COL: rows = (tap, channel)
       const int r = m0 + a_row4 * 4;
@@ -186,6 +235,9 @@ __global__ __launch_bounds__(256, 2) void igemm_bf_kernel(const GemmDesc d) {
         const int tap = r / A.C;
         pa[u] = tap;
         pb[u] = r - tap * A.C;
+        col_th = (tap >> 2) - 1;
+        col_tw = (tap & 3) - 1;
+        col_ch = pb[u];
       }
     }
   }
@@ -204,16 +256,29 @@ __global__ __launch_bounds__(256, 2) void igemm_bf_kernel(const GemmDesc d) {
   }
   const int ow_sh = ((A.OW & (A.OW - 1)) == 0) ? __builtin_ctz(A.OW > 0 ? A.OW : 1) : -1;
   const int oh_sh = ((A.OH & (A.OH - 1)) == 0) ? __builtin_ctz(A.OH > 0 ? A.OH : 1) : -1;
+  const bool col_fast = ow_sh >= 0 && oh_sh >= 0 && (A.OW % T::NA4) == 0;
 
-  u32x4 ra[T::NA4], ya[AACT ? T::NA4 : 1], rb[T::NB4];
+  constexpr int NYA = AACT ? T::NA4 : 1;
+  // DEPTH raw (fp32) register stages: the loads run DEPTH k-tiles ahead of the MFMAs.  They are issued
+  // unconditionally (past the end of K they are out-of-range = zero-fill, no traffic): a conditional load would
+  // make the compiler's vmcnt bookkeeping fall back to waiting for the newest stage.
+  u32x4 ra[DEPTH][T::NA4], ya[DEPTH][NYA], rb[DEPTH][T::NB4];
 
-  auto load_tiles = [&](int k0) {
+  auto load_tiles = [&](int k0, u32x4 (&ra)[T::NA4], u32x4 (&ya)[NYA], u32x4 (&rb)[T::NB4]) {
+    auto sel = [](bool ok, int off) { return __builtin_unpredictable(ok) ? off : 0x7fffffff; };  // keep it a v_cndmask
+#ifdef MVK_EXPER
+    if (d.dbg_flags & 2) {  // experiment: no global traffic
+      for (int u = 0; u < T::NA4; ++u) ra[u] = u32x4{1, 2, 3, 4};
+      for (int u = 0; u < T::NB4; ++u) rb[u] = u32x4{1, 2, 3, 4};
+      return;
+    }
+#endif
     if (AMODE == AM_PLAIN_K) {
 #pragma unroll
       for (int u = 0; u < T::NA4; ++u) {
         const int idx = tid + u * 256;
         const bool ok = abase[u] >= 0 && (k0 + (idx % 8) * 4) < kend;
-        const int off = ok ? (abase[u] + k0) * 4 : OOB;
+        const int off = sel(ok, (abase[u] + k0) * 4);
         ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
         if (AACT) ya[u] = __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0);
       }
@@ -221,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf_kernel(const GemmDesc d) {
 #pragma unroll
       for (int u = 0; u < T::NA4; ++u) {
         const bool ok = abase[u] >= 0 && (k0 + a_kg * T::NA4 + u) < kend;
-        const int off = ok ? (abase[u] + k0 * (int)A.sk) * 4 : OOB;
+        const int off = sel(ok, (abase[u] + k0 * (int)A.sk) * 4);
         ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
         if (AACT) ya[u] = __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0);
       }
@@ -236,36 +301,39 @@ __global__ __launch_bounds__(256, 2) void igemm_bf_kernel(const GemmDesc d) {
         dh = (tap >> 2) - 1;
         dw = (tap & 3) - 1;
       }
-      const int mul = (A.kind == A_UP) ? 1 : 2;
+      if (k0 >= kend) dh = -(1 << 20);  // prefetch past the end: all out of range
+      const int delta = ((dh * A.W + dw) * A.C + c0) * 4;
 #pragma unroll
       for (int u = 0; u < T::NA4; ++u) {
-        const int idx = tid + u * 256;
-        const int kq = (idx % 8) * 4;
-        const int hh = mul * pb[u] + dh, ww = mul * pc[u] + dw;
-        const bool ok = pa[u] >= 0 && (k0 + kq) < kend && hh >= 0 && hh < A.H && ww >= 0 && ww < A.W;
-        const int off = ok ? (((pa[u] * A.H + hh) * A.W + ww) * A.C + c0 + kq) * 4 : OOB;
-        ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
+        const bool ok = (unsigned)(pb[u] + dh) < (unsigned)A.H && (unsigned)(pc[u] + dw) < (unsigned)A.W;
+        ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sel(ok, pa[u] + delta), 0, 0);
       }
-    } else {  // AM_COL: k = output position
+    } else {  // AM_COL: k = output position; this thread's units are NA4 consecutive positions
+      const int pos0 = k0 + a_kg * T::NA4;
+      if (col_fast) {  // all of them in one output row: decode once
+        const int pj0 = pos0 & (A.OW - 1);
+        const int t = pos0 >> ow_sh;
+        const int pi = t & (A.OH - 1), pn = t >> oh_sh;
+        const int hh = 2 * pi + col_th;
+        const bool hok = (unsigned)hh < (unsigned)A.H;
+        const int rowoff = (pn * A.H + hh) * A.W * A.C + col_ch;
 #pragma unroll
-      for (int u = 0; u < T::NA4; ++u) {
-        const int pos = k0 + a_kg * T::NA4 + u;
-        int pj, pi, pn;
-        if (ow_sh >= 0 && oh_sh >= 0) {
-          pj = pos & (A.OW - 1);
-          const int t = pos >> ow_sh;
-          pi = t & (A.OH - 1);
-          pn = t >> oh_sh;
-        } else {
-          pj = pos % A.OW;
-          const int t = pos / A.OW;
-          pi = t % A.OH;
-          pn = t / A.OH;
+        for (int u = 0; u < T::NA4; ++u) {
+          const int ww = 2 * (pj0 + u) + col_tw;
+          const bool ok = hok && (unsigned)ww < (unsigned)A.W && (pos0 + u) < kend;
+          ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sel(ok, (rowoff + ww * A.C) * 4), 0, 0);
         }
-        const int hh = 2 * pi - 1 + (pa[u] >> 2), ww = 2 * pj - 1 + (pa[u] & 3);
-        const bool ok = pa[u] >= 0 && pos < kend && hh >= 0 && hh < A.H && ww >= 0 && ww < A.W;
-        const int off = ok ? (((pn * A.H + hh) * A.W + ww) * A.C + pb[u]) * 4 : OOB;
-        ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
+      } else {
+#pragma unroll
+        for (int u = 0; u < T::NA4; ++u) {
+          const int pos = pos0 + u;
+          const int pj = pos % A.OW;
+          const int t = pos / A.OW;
+          const int pi = t % A.OH, pn = t / A.OH;
+          const int hh = 2 * pi + col_th, ww = 2 * pj + col_tw;
+          const bool ok = pos < kend && (unsigned)hh < (unsigned)A.H && (unsigned)ww < (unsigned)A.W;
+          ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sel(ok, (((pn * A.H + hh) * A.W + ww) * A.C + col_ch) * 4), 0, 0);
+        }
       }
     }
     if (BMODE == BM_K) {
@@ -273,49 +341,14 @@ __global__ __launch_bounds__(256, 2) void igemm_bf_kernel(const GemmDesc d) {
       for (int u = 0; u < T::NB4; ++u) {
         const int idx = tid + u * 256;
         const bool ok = bbase[u] >= 0 && (k0 + (idx % 8) * 4) < kend;
-        rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rsB, ok ? (bbase[u] + k0) * 4 : OOB, 0, 0);
+        rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rsB, sel(ok, (bbase[u] + k0) * 4), 0, 0);
       }
     } else {
 #pragma unroll
       for (int u = 0; u < T::NB4; ++u) {
         const bool ok = bbase[u] >= 0 && (k0 + b_kg * T::NB4 + u) < kend;
-        rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rsB, ok ? (bbase[u] + k0 * (int)B.sk) * 4 : OOB, 0, 0);
+        rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rsB, sel(ok, (bbase[u] + k0 * (int)B.sk) * 4), 0, 0);
       }
-    }
-  };
-
-  // registers -> three bf16 pieces -> LDS
-  auto store_tiles = [&]() {
-    f32x4 va[T::NA4];
-#pragma unroll
-    for (int u = 0; u < T::NA4; ++u) {
-      va[u] = __builtin_bit_cast(f32x4, ra[u]);
-      if (AACT) {
-        const f32x4 y = __builtin_bit_cast(f32x4, ya[u]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) va[u][i] *= mvk_act_grad_from_out(y[i], A.act);
-      }
-    }
-    if (A_KC) {
-#pragma unroll
-      for (int u = 0; u < T::NA4; ++u) {
-        const int idx = tid + u * 256;
-        bf_store_k4<T::GA, T::A_PIECE>(As, va[u], idx / 8, (idx % 8) * 4);
-      }
-    } else {
-      bf_store_rows<T::NA4, T::GA, T::A_PIECE>(As, va, a_row4, a_kg);
-    }
-    f32x4 vb[T::NB4];
-#pragma unroll
-    for (int u = 0; u < T::NB4; ++u) vb[u] = __builtin_bit_cast(f32x4, rb[u]);
-    if (B_KC) {
-#pragma unroll
-      for (int u = 0; u < T::NB4; ++u) {
-        const int idx = tid + u * 256;
-        bf_store_k4<T::GB, T::B_PIECE>(Bs, vb[u], idx / 8, (idx % 8) * 4);
-      }
-    } else {
-      bf_store_rows<T::NB4, T::GB, T::B_PIECE>(Bs, vb, b_row4, b_kg);
     }
   };
 
@@ -323,43 +356,123 @@ __global__ __launch_bounds__(256, 2) void igemm_bf_kernel(const GemmDesc d) {
   const char* a_frag = As + (l31 & 3) * T::GA + ((wm * T::WTM + l31) >> 2) * 80 + lhi * 16;
   const char* b_frag = Bs + (l31 & 3) * T::GB + ((wn * T::WTN + l31) >> 2) * 80 + lhi * 16;
 
-  auto compute = [&]() {
+  using SA_ = BfStage<T::NA4, A_KC>;
+  using SB_ = BfStage<T::NB4, B_KC>;
+  constexpr int NPAIR = SA_::NP + SB_::NP;  // conversion work items per thread and k-tile
+  constexpr int NSLOT = (BKT / 16) * 6;     // MFMA groups per k-tile
+  unsigned pca[3][SA_::NP], pcb[3][SB_::NP];
+  const u32x4 ynul[1] = {u32x4{0, 0, 0, 0}};
+
+  auto convert_range = [&](int lo, int hi, const u32x4 (&ra)[T::NA4], const u32x4 (&ya)[NYA], const u32x4 (&rb)[T::NB4]) {
 #pragma unroll
-    for (int ks = 0; ks < BKT / 16; ++ks) {
-      bf16x8 af[T::TM][3], bfr[T::TN][3];
+    for (int j = lo; j < hi; ++j) {
+      if (j < SA_::NP) bf_convert_pair<T::NA4, A_KC, AACT>(j, ra, ya, A.act, pca);
+      else bf_convert_pair<T::NB4, B_KC, false>(j - SA_::NP, rb, ynul, 0, pcb);
+    }
+  };
+  auto write_pieces = [&]() {
+    bf_write_pieces<T::NA4, A_KC, T::GA, T::A_PIECE>(As, pca, tid, a_row4, a_kg);
+    bf_write_pieces<T::NB4, B_KC, T::GB, T::B_PIECE>(Bs, pcb, tid, b_row4, b_kg);
+  };
+
+  // One k-tile: MFMAs over the tile in LDS, with the split of the NEXT tile's registers spread between the MFMA
+  // groups (VALU work runs beside the matrix pipe), then barrier / piece write / barrier.
+  auto step = [&](const u32x4 (&ra)[T::NA4], const u32x4 (&ya)[NYA], const u32x4 (&rb)[T::NB4]) {
+#ifdef MVK_EXPER
+    const bool no_mfma = d.dbg_flags & 32, no_write = d.dbg_flags & 16;
+#else
+    constexpr bool no_mfma = false, no_write = false;
+#endif
+    constexpr int PA[6] = {0, 1, 2, 0, 1, 0};  // smallest terms first
+    constexpr int PB[6] = {2, 1, 0, 1, 0, 0};
+    if (T::TM * T::TN == 1) {
+      // one MFMA tile per wave: alternate the two k-steps on two accumulators so consecutive MFMAs are independent
+      bf16x8 af[2][3], bfr[2][3];
+      if (!no_mfma) {
 #pragma unroll
-      for (int a = 0; a < T::TM; ++a)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-          af[a][p] = *reinterpret_cast<const bf16x8*>(a_frag + p * T::A_PIECE + a * 8 * 80 + ks * 32);
-#pragma unroll
-      for (int b = 0; b < T::TN; ++b)
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          bfr[b][p] = *reinterpret_cast<const bf16x8*>(b_frag + p * T::B_PIECE + b * 8 * 80 + ks * 32);
-      // smallest terms first; consecutive MFMAs go to different accumulators
-      constexpr int PA[6] = {0, 1, 2, 0, 1, 0};
-      constexpr int PB[6] = {2, 1, 0, 1, 0, 0};
+          for (int p = 0; p < 3; ++p) {
+            af[ks][p] = *reinterpret_cast<const bf16x8*>(a_frag + p * T::A_PIECE + ks * 32);
+            bfr[ks][p] = *reinterpret_cast<const bf16x8*>(b_frag + p * T::B_PIECE + ks * 32);
+          }
+      }
 #pragma unroll
       for (int q = 0; q < 6; ++q)
 #pragma unroll
-        for (int a = 0; a < T::TM; ++a)
+        for (int ks = 0; ks < 2; ++ks) {
+          if (!no_mfma) {
+            if (ks == 0) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][PA[q]], bfr[0][PB[q]], acc[0][0], 0, 0, 0);
+            else acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][PA[q]], bfr[1][PB[q]], acc2, 0, 0, 0);
+          }
+          const int slot = q * 2 + ks;
+          if (!no_write) convert_range(slot * NPAIR / NSLOT, (slot + 1) * NPAIR / NSLOT, ra, ya, rb);
+        }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < BKT / 16; ++ks) {
+        bf16x8 af[T::TM][3], bfr[T::TN][3];
+        if (!no_mfma) {
+#pragma unroll
+          for (int a = 0; a < T::TM; ++a)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+              af[a][p] = *reinterpret_cast<const bf16x8*>(a_frag + p * T::A_PIECE + a * 8 * 80 + ks * 32);
 #pragma unroll
           for (int b = 0; b < T::TN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA[q]], bfr[b][PB[q]], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+              bfr[b][p] = *reinterpret_cast<const bf16x8*>(b_frag + p * T::B_PIECE + b * 8 * 80 + ks * 32);
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          if (!no_mfma) {
+#pragma unroll
+            for (int a = 0; a < T::TM; ++a)
+#pragma unroll
+              for (int b = 0; b < T::TN; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA[q]], bfr[b][PB[q]], acc[a][b], 0, 0, 0);
+          }
+          const int slot = ks * 6 + q;
+          if (!no_write) convert_range(slot * NPAIR / NSLOT, (slot + 1) * NPAIR / NSLOT, ra, ya, rb);
+        }
+      }
     }
+    __syncthreads();  // every wave is done reading the tile
+    if (!no_write) write_pieces();
+#ifdef MVK_EXPER
+    if (no_write) {  // keep the loads alive
+      unsigned s_ = 0;
+      for (int u = 0; u < T::NA4; ++u) s_ += ra[u].x ^ ra[u].y ^ ra[u].z ^ ra[u].w;
+      for (int u = 0; u < T::NB4; ++u) s_ += rb[u].x ^ rb[u].y ^ rb[u].z ^ rb[u].w;
+      if (s_ == 0x12345677u) As[tid] = 1;
+    }
+#endif
+    __syncthreads();
   };
 
-  load_tiles(kbeg);
-  store_tiles();
+  // prologue: tile 0 -> LDS, tiles 1 .. DEPTH-1 -> registers (in flight)
+#pragma unroll
+  for (int i = 0; i < DEPTH; ++i) load_tiles(kbeg + i * BKT, ra[i], ya[i], rb[i]);
+  convert_range(0, NPAIR, ra[0], ya[0], rb[0]);
+  write_pieces();
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    const bool more = (t + 1) < ntiles;
-    if (more) load_tiles(kbeg + (t + 1) * BKT);  // in flight across the MFMAs
-    compute();
-    __syncthreads();                            // every wave is done reading the tile
-    if (more) store_tiles();
-    __syncthreads();
+  int t = 0;
+  for (; t + DEPTH <= ntiles; t += DEPTH) {  // full groups only: no exit inside the unrolled body (keeps the
+#pragma unroll                               // register stages static: no copies, no waits on the back edge)
+    for (int i = 0; i < DEPTH; ++i) {
+      // LDS: tile t+i.  Stage i is free: fetch tile t+i+DEPTH into it; split tile t+i+1 (stage i+1) beside the MFMAs.
+      load_tiles(kbeg + (t + i + DEPTH) * BKT, ra[i], ya[i], rb[i]);
+      __builtin_amdgcn_sched_barrier(0);  // keep the loads at the top of the step: the scheduler would sink them
+      step(ra[(i + 1) % DEPTH], ya[(i + 1) % DEPTH], rb[(i + 1) % DEPTH]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < DEPTH - 1; ++i)  // remaining ntiles % DEPTH tiles (their successors are zero tiles)
+    if (t + i < ntiles) step(ra[(i + 1) % DEPTH], ya[(i + 1) % DEPTH], rb[(i + 1) % DEPTH]);
+  if (T::TM * T::TN == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] += acc2[r];
   }
   float* lds = reinterpret_cast<float*>(lds_raw);
   if (run_epilogue_vec<T, BM, BN, T::LDS_BYTES / 4>(d, acc, lds, tid, m0, n0, wm, wn, l31, lhi, ph, pw)) return;
