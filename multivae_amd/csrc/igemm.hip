@@ -45,6 +45,10 @@ static int launch_bf_cfg(const GemmDesc& d, int zdim, hipStream_t s) {
 
 template <int BM, int BN>
 static int launch_bf_tile(const GemmDesc& d, int zdim, hipStream_t s, int amode, int bmode, bool aact) {
+  if (BM * BN > 128 * 64) {  // large tile: weight-gradient GEMMs only
+    if (amode == AM_COL && bmode == BM_N && !aact) return launch_bf_cfg<BM, BN, AM_COL, BM_N, false>(d, zdim, s);
+    return 1;
+  }
   if (amode == AM_PLAIN_K && bmode == BM_K && !aact) return launch_bf_cfg<BM, BN, AM_PLAIN_K, BM_K, false>(d, zdim, s);
   if (amode == AM_PLAIN_K && bmode == BM_N && !aact) return launch_bf_cfg<BM, BN, AM_PLAIN_K, BM_N, false>(d, zdim, s);
   if (amode == AM_PLAIN_K && bmode == BM_N && aact) return launch_bf_cfg<BM, BN, AM_PLAIN_K, BM_N, true>(d, zdim, s);
@@ -99,8 +103,12 @@ static int try_launch_fast(const GemmDesc& d, int zdim, hipStream_t s) {
   if (engine() == 1 && c32) {
     auto nb = [&](int bm, int bn) { return (long long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * zdim; };
     int rc = 1;
+    // measured on the step's convolutions: 128x128 only pays for the weight-gradient GEMMs (both operands staged
+    // through the register transpose), 256x32 never beats 128x32 (one MFMA tile per wave, two accumulators)
     if (d.N <= 32) {
       rc = launch_bf_tile<128, 32>(d, zdim, s, amode, bmode, aact);
+    } else if (d.N > 64 && amode == AM_COL && nb(128, 128) >= 384) {
+      rc = launch_bf_tile<128, 128>(d, zdim, s, amode, bmode, aact);
     } else if (nb(128, 64) >= 384) {
       rc = launch_bf_tile<128, 64>(d, zdim, s, amode, bmode, aact);
     }
