@@ -53,6 +53,32 @@ __global__ __launch_bounds__(256) void small_up_fwd_kernel(const float* __restri
   const bool active = wave * 64 < P;
   const int H2 = 2 * h, W2 = 2 * w;
   const int per_img = CU * H2 * W2;
+  // Output geometry is the same for every image: this thread's outputs o = tid + 256 t and, for each, the LDS
+  // word of its (up to) 2x2 contributing column-matrix entries.  Missing taps (image border) point at a zero word.
+  constexpr int NO = (CU * 32 * 32 + 255) / 256;  // h, w <= 16
+  const int zidx = P * (C::VS > C::CS ? C::VS : C::CS);  // one float past both uses of buf, kept at 0
+  int tap[NO][4];
+  float bia[NO];
+#pragma unroll
+  for (int t = 0; t < NO; ++t) {
+    const int o = tid + t * 256;
+    const int oc = o < per_img ? o : 0;
+    const int cu = oc / (H2 * W2);
+    const int rem = oc - cu * (H2 * W2);
+    const int oh = rem / W2, ow = rem - oh * W2;
+    const int ph = oh & 1, pw = ow & 1, i0 = oh >> 1, j0 = ow >> 1;
+    bia[t] = bias ? bias[cu] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int ih = i0 + ph - a, kh = (1 - ph) + 2 * a;
+        const int iw = j0 + pw - b, kw = (1 - pw) + 2 * b;
+        const bool ok = ih >= 0 && ih < h && iw >= 0 && iw < w;
+        tap[t][a * 2 + b] = ok ? (ih * w + iw) * C::CS + cu * 16 + kh * 4 + kw : zidx;
+      }
+  }
+  if (tid == 0) buf[zidx] = 0.f;
   long long img = blockIdx.x;
   if (img < n) prefetch(img);
   for (; img < n; img += gridDim.x) {
@@ -98,24 +124,13 @@ __global__ __launch_bounds__(256) void small_up_fwd_kernel(const float* __restri
     }
     __syncthreads();
     float* out = U + img * per_img;
-    for (int o = tid; o < per_img; o += 256) {
-      const int cu = o / (H2 * W2);
-      const int rem = o - cu * (H2 * W2);
-      const int oh = rem / W2, ow = rem - oh * W2;
-      const int ph = oh & 1, pw = ow & 1, i0 = oh >> 1, j0 = ow >> 1;
-      float s = bias ? bias[cu] : 0.f;
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const int ih = i0 + ph - a, kh = (1 - ph) + 2 * a;
-        if (ih < 0 || ih >= h) continue;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int iw = j0 + pw - b, kw = (1 - pw) + 2 * b;
-          if (iw < 0 || iw >= w) continue;
-          s += buf[(ih * w + iw) * C::CS + cu * 16 + kh * 4 + kw];
-        }
+    for (int t = 0; t < NO; ++t) {
+      const int o = tid + t * 256;
+      if (o < per_img) {
+        const float sum = ((buf[tap[t][0]] + buf[tap[t][1]]) + (buf[tap[t][2]] + buf[tap[t][3]])) + bia[t];
+        out[o] = mvk_act(sum, act);
       }
-      out[o] = mvk_act(s, act);
     }
     __syncthreads();  // the column matrix is overwritten by the next image's V tile
   }
@@ -163,20 +178,27 @@ __global__ __launch_bounds__(256) void small_up_bwd_kernel(const float* __restri
   const int nd = CU * DH * DW, n4 = P * CV / 4;
   float pdu[ND], puo[ND];
   f32x4 pv[NV];
+  // halo-tile geometry is image independent: source offset (clamped), validity and channel of every element
+  int hoff[ND];   // bits 0..27 offset into the image, 28..29 channel, 30 inside the image
+#pragma unroll
+  for (int u = 0; u < ND; ++u) {
+    const int idx = tid + u * 256;
+    const int idc = idx < nd ? idx : nd - 1;
+    const int cu = idc / (DH * DW);
+    const int rem = idc - cu * (DH * DW);
+    const int y = rem / DW, x = rem - y * DW;
+    const int oh = y - 1, ow = x - 1;
+    const bool in = idx < nd && oh >= 0 && oh < H2 && ow >= 0 && ow < W2;
+    const int ohc = oh < 0 ? 0 : (oh >= H2 ? H2 - 1 : oh), owc = ow < 0 ? 0 : (ow >= W2 ? W2 - 1 : ow);
+    hoff[u] = ((cu * H2 + ohc) * W2 + owc) | (cu << 28) | ((int)in << 30);
+  }
   auto prefetch = [&](long long img) __attribute__((always_inline)) {
     const float* du = dU + img * CU * H2 * W2;
     const float* uo = Uout + img * CU * H2 * W2;
 #pragma unroll
     for (int u = 0; u < ND; ++u) {
-      const int idx = tid + u * 256;
-      const int idc = idx < nd ? idx : nd - 1;
-      const int cu = idc / (DH * DW);
-      const int rem = idc - cu * (DH * DW);
-      const int y = rem / DW, x = rem - y * DW;
-      const int oh = y - 1, ow = x - 1;
-      const bool in = idx < nd && oh >= 0 && oh < H2 && ow >= 0 && ow < W2;
-      const int ohc = oh < 0 ? 0 : (oh >= H2 ? H2 - 1 : oh), owc = ow < 0 ? 0 : (ow >= W2 ? W2 - 1 : ow);
-      const int off = (cu * H2 + ohc) * W2 + owc;  // clamped address: the load is unconditional, the halo is zeroed below
+      const int off = hoff[u] & 0x0fffffff;  // clamped address: the load is unconditional, the halo is zeroed
+      const bool in = (hoff[u] >> 30) & 1;
       const float a = du[off], b = uo[off];
       pdu[u] = in ? a : 0.f;
       puo[u] = in ? b : 0.f;
@@ -198,7 +220,7 @@ __global__ __launch_bounds__(256) void small_up_bwd_kernel(const float* __restri
       if (idx < nd) {
         const float v = pdu[u] * mvk_act_grad_from_out(puo[u], u_act);  // halo: 0 * act'(0) = 0
         Ds[idx] = v;
-        const int cu = idx / (DH * DW);
+        const int cu = (hoff[u] >> 28) & 3;
 #pragma unroll
         for (int c = 0; c < CU; ++c)
           if (c == cu) dbl[c] += v;
@@ -338,7 +360,7 @@ template <int CU, int CV>
 static size_t fwd_lds(int P) {
   using C = SmallCfg<CU, CV>;
   const size_t tile = (size_t)P * (C::VS > C::CS ? C::VS : C::CS);
-  return (CV * C::NC + tile) * sizeof(float);
+  return (CV * C::NC + tile + 4) * sizeof(float);  // + the zero word of the output gather
 }
 template <int CU, int CV>
 static size_t bwd_lds(int h, int w) {

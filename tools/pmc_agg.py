@@ -14,7 +14,7 @@ rows = c.execute(f"select s.display_name, d.start, d.end, d.grid_size_x, d.grid_
 agg = collections.OrderedDict()
 for name, st, en, gx, gy, gz, wx, eid in rows:
     if sub not in name: continue
-    nm = re.sub(r"\(.*", "", name.replace("void ", ""))[:60]
+    nm = re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", "").replace("void ", ""))[:60]
     key = (nm, gx // wx, gy, gz)
     a = agg.setdefault(key, {"n": 0, "dur": 0.0, "c": collections.Counter()})
     a["n"] += 1; a["dur"] += (en - st) / 1e3
