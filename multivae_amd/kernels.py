@@ -8,6 +8,8 @@ multiplies by the previous layer's activation derivative and writes the pre-acti
 """
 import ctypes as C
 
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -43,13 +45,68 @@ WS_FLOATS = 16 * 1024 * 1024  # 64 MB of split-K slab scratch per device (larges
 
 
 def _ws(like):
-    """Caller-owned split-K scratch (see mvk.h): one persistent buffer per device, reused by every launch on
-    the stream (launches are stream-ordered, so reuse is safe)."""
-    t = _WS.get(like.device)
+    """Caller-owned split-K scratch (see mvk.h): one persistent buffer per (device, stream), reused by every launch
+    on that stream (launches are stream-ordered, so reuse is safe; two streams must not share one)."""
+    key = (like.device, torch.cuda.current_stream(like.device).cuda_stream)
+    t = _WS.get(key)
     if t is None:
         t = torch.empty(WS_FLOATS, dtype=torch.float32, device=like.device)
-        _WS[like.device] = t
+        _WS[key] = t
     return t
+
+
+# -----------------------------------------------------------------------------------------------------
+# modality branches on separate HIP streams
+# -----------------------------------------------------------------------------------------------------
+# The encoders (and the decoders) of different modalities are independent until the posterior (resp. the
+# reconstruction loss) joins them.  The small-modality branch is a string of short, launch-latency-bound
+# kernels; on its own stream it runs beside the large modality's convolutions instead of in front of them.
+# Autograd replays each node's backward on the stream its forward ran on, so the backward overlaps too.
+BRANCH_STREAMS = os.environ.get("MVK_BRANCH_STREAMS", "1") != "0"
+_SIDE = {}
+
+
+def _side_stream(device, i):
+    key = (device, i)
+    st = _SIDE.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SIDE[key] = st
+    return st
+
+
+def _tensors_of(obj):
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors_of(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors_of(v)
+
+
+def run_branches(names, fn, device):
+    """{m: fn(m)} with every branch but the first on its own stream; joined before returning."""
+    names = list(names)
+    if not BRANCH_STREAMS or len(names) < 2 or device.type != "cuda":
+        return {m: fn(m) for m in names}
+    main = torch.cuda.current_stream(device)
+    fork = main.record_event()
+    outs = {}
+    sides = []
+    for i, m in enumerate(names[1:], start=1):  # enqueue the side branches first, then the main one
+        st = _side_stream(device, i)
+        st.wait_event(fork)
+        with torch.cuda.stream(st):
+            outs[m] = fn(m)
+        for t in _tensors_of(outs[m]):
+            t.record_stream(main)
+        sides.append(st)
+    outs[names[0]] = fn(names[0])
+    for st in sides:
+        main.wait_stream(st)
+    return {m: outs[m] for m in names}
 
 
 # =====================================================================================================

@@ -56,6 +56,24 @@ class BaseMultiVAE(BaseModel):
         self.set_decoders_dist(model_config.decoders_dist, deepcopy(model_config.decoder_dist_params))
 
     # -- configuration -------------------------------------------------------------------------------
+
+    def _branch_order(self, inputs=None, names=None):
+        """Modalities by decreasing input size: the first one keeps the caller's stream, the others get side streams
+        (kernels.run_branches), so the large modality's kernels are never queued behind the small ones."""
+        names = list(self.encoders.keys()) if names is None else list(names)
+        dims = self.input_dims or {}
+
+        def size(m):
+            d = dims.get(m)
+            if d is None and inputs is not None and m in inputs.data:
+                d = tuple(inputs.data[m].shape[1:])
+            n = 1
+            for v in (d or ()):
+                n *= int(v)
+            return n
+
+        return sorted(names, key=lambda m: -size(m))
+
     def set_decoders_dist(self, recon_dict, dist_params_dict):
         """Per-modality (distribution code, scale) consumed by mvk_recon_nll_* (base_utils.py:62-87)."""
         self.recon_dists = {}

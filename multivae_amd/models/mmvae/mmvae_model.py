@@ -47,14 +47,17 @@ class MMVAE(BaseMultiVAE):
         if self.model_config.loss not in ("dreg_looser", "iwae_looser"):
             raise NotImplementedError()
         family = self._family
-        mus, sds = [], []
-        for m in mods:
+        def encode_one(m):
             out = self.encoders[m](inputs.data[m])
             mu, lv = out.embedding, out.log_covariance
             if mu.dim() == 1:
                 mu, lv = mu.unsqueeze(0), lv.unsqueeze(0)
-            mus.append(mu)
-            sds.append(self.log_var_to_std(lv))
+            return mu, self.log_var_to_std(lv)
+
+        order = self._branch_order(inputs, mods)
+        enc = kernels.run_branches(order, encode_one, inputs.data[order[0]].device)
+        mus = [enc[m][0] for m in mods]
+        sds = [enc[m][1] for m in mods]
         B, L = mus[0].shape
         device = mus[0].device
         noises = [self._noise((K, B, L), device, None if noise is None else noise[m], uniform=family == 1)
@@ -66,11 +69,10 @@ class MMVAE(BaseMultiVAE):
         prior_std = self.log_var_to_std(self.prior_log_var)
         zs = kernels.MMVAELatentFn.apply(state, noises, masks, self.prior_mean.detach(), family, int(dreg), prior_std,
                                          *mus, *sds)
-        recons = []
-        for c in range(M):
-            flat = zs[c].reshape(-1, L)  # (K*B, L) like the reference (:127)
-            for r in mods:
-                recons.append(self.decoders[r](flat).reconstruction)
+        flats = [zs[c].reshape(-1, L) for c in range(M)]  # (K*B, L) like the reference (:127)
+        dec = kernels.run_branches(self._branch_order(inputs, mods),
+                                   lambda r: [self.decoders[r](flats[c]).reconstruction for c in range(M)], device)
+        recons = [dec[r][c] for c in range(M) for r in mods]
         spec = self._recon_spec(mods, inputs.data, inputs.masks if masks is not None else None, K, B)
         loss = kernels.MMVAEObjectiveFn.apply(state, spec, M, dreg, *recons)
         out = ModelOutput(loss=loss, loss_sum=loss, metrics={})

@@ -86,7 +86,9 @@ class MoPoE(BaseMultiVAE):
 
     # -- forward -----------------------------------------------------------------------------------------
     def modality_encode(self, inputs, **kwargs):
-        return {m: self.encoders[m](inputs.data[m]) for m in self.encoders.keys()}
+        names = self._branch_order(inputs)
+        enc = kernels.run_branches(names, lambda m: self.encoders[m](inputs.data[m]), inputs.data[names[0]].device)
+        return {m: enc[m] for m in self.encoders.keys()}
 
     def _posterior(self, inputs, K, noise=None, choice=None, want_stats=False):
         enc = self.modality_encode(inputs)
@@ -123,7 +125,8 @@ class MoPoE(BaseMultiVAE):
         z, kld_rows = outs[0], outs[1]
         names = list(self.encoders.keys())
         z_in = z[0] if K == 1 else z  # K == 1: decoders see [B,L] exactly like the reference
-        recons = [self.decoders[m](z_in).reconstruction for m in names]
+        rec = kernels.run_branches(self._branch_order(inputs), lambda m: self.decoders[m](z_in).reconstruction, device)
+        recons = [rec[m] for m in names]
         masks = inputs.masks if hasattr(inputs, "masks") else None
         spec = self._recon_spec(names, inputs.data, masks, K, B)
         M = len(names)

@@ -21,7 +21,8 @@ class MVTCAE(BaseMultiVAE):
 
     def _posterior(self, inputs, K, noise=None, mods=None):
         mods = list(inputs.data.keys()) if mods is None else mods
-        enc = {m: self.encoders[m](inputs.data[m]) for m in mods}
+        order = self._branch_order(inputs, mods)
+        enc = kernels.run_branches(order, lambda m: self.encoders[m](inputs.data[m]), inputs.data[order[0]].device)
         mus = [enc[m].embedding for m in mods]
         lvs = [enc[m].log_covariance for m in mods]
         if mus[0].dim() == 1:
@@ -46,7 +47,8 @@ class MVTCAE(BaseMultiVAE):
         z, jkl, ckl = outs[0], outs[1], outs[2]
         names = list(self.encoders.keys())
         z_in = z[0] if K == 1 else z
-        recons = [self.decoders[m](z_in).reconstruction for m in names]
+        rec = kernels.run_branches(self._branch_order(inputs, names), lambda m: self.decoders[m](z_in).reconstruction, device)
+        recons = [rec[m] for m in names]
         masks = inputs.masks if hasattr(inputs, "masks") else None
         spec = self._recon_spec(names, inputs.data, masks, K, B)
         M, Mn = len(mods), len(names)
