@@ -524,3 +524,23 @@ def test_small_up_fwd_bwd(K, n, h, w, Cu, Cv):
     close(nchw(dV.cpu()), Vr.grad * (V > 0).float(), what="small up dV (relu mask fused)")
     close(dW, Wr.grad, what="small up dW")
     close(db, br.grad, what="small up db")
+
+
+@pytest.mark.parametrize("M,N,Kd", [(40960, 128, 1024), (4096, 64, 2048), (65536, 32, 512), (8192, 64, 96)])
+def test_split_bf16_engine_has_fp32_accuracy(K, M, N, Kd):
+    """The default GEMM engine (igemm_bf.hpp: every fp32 operand split into 3 bf16 pieces, 6 bf16 MFMAs per product)
+    must be as accurate as an fp32 GEMM: error against an fp64 product no worse than 1.5x torch's fp32 matmul
+    (rocBLAS), in max and rms norm."""
+    torch.manual_seed(5)
+    x = torch.randn(M, Kd, device=dev()) * torch.rand(M, 1, device=dev()) * 4
+    w = torch.randn(N, Kd, device=dev()) / Kd ** 0.5
+    ref = x.double() @ w.double().t()
+    y = K.linear_fwd(x, w, None, 0)
+    yt = x @ w.t()
+    den = ref.abs().max().item()
+    e_mvk = (y.double() - ref).abs().max().item() / den
+    e_t = (yt.double() - ref).abs().max().item() / den
+    r_mvk = (y.double() - ref).pow(2).mean().sqrt().item()
+    r_t = (yt.double() - ref).pow(2).mean().sqrt().item()
+    assert e_mvk <= 1.5 * e_t + 1e-7, (e_mvk, e_t)
+    assert r_mvk <= 1.5 * r_t + 1e-9, (r_mvk, r_t)

@@ -88,3 +88,75 @@ def test_base_trainer_mvtcae_cfg1(tmp_path):
     re = MVTCAE.load_from_folder(os.path.join(tdir, "final_model"))
     best = trainer._best_model.state_dict()
     assert all(torch.equal(v.cpu(), best[k].cpu()) for k, v in re.state_dict().items())
+
+
+def _mnist_svhn_mopoe(d, K=3, L=8, seed=0):
+    from multivae_amd.models import MoPoE, MoPoEConfig
+    from multivae_amd.models.base.base_config import BaseAEConfig
+    from multivae_amd.models.nn.default_architectures import Decoder_AE_MLP, Encoder_VAE_MLP
+    from multivae_amd.models.nn.svhn import Decoder_VAE_SVHN, Encoder_VAE_SVHN
+
+    torch.manual_seed(seed)
+    dims = dict(mnist=(1, 28, 28), svhn=(3, 32, 32))
+    enc = dict(mnist=Encoder_VAE_MLP(BaseAEConfig(latent_dim=L, input_dim=dims["mnist"])),
+               svhn=Encoder_VAE_SVHN(BaseAEConfig(latent_dim=L, input_dim=dims["svhn"])))
+    dec = dict(mnist=Decoder_AE_MLP(BaseAEConfig(latent_dim=L, input_dim=dims["mnist"])),
+               svhn=Decoder_VAE_SVHN(BaseAEConfig(latent_dim=L, input_dim=dims["svhn"])))
+    cfg = MoPoEConfig(n_modalities=2, latent_dim=L, input_dims=dims, beta=1.0, K=K)
+    return MoPoE(cfg, enc, dec).to(d).train()
+
+
+def _run_steps(d, steps, graphed, branch_streams=True, B=64, K=3, L=8):
+    """Losses and final parameters of `steps` Adam steps; the two modality branches on separate streams or not,
+    launches enqueued from Python or replayed from one hipGraph."""
+    from multivae_amd import kernels
+    from multivae_amd.data.datasets.base import DatasetOutput
+    from multivae_amd.trainers import FlatParams, FusedAdam, GraphedStep
+
+    old = kernels.BRANCH_STREAMS
+    kernels.BRANCH_STREAMS = branch_streams
+    try:
+        model = _mnist_svhn_mopoe(d, K=K, L=L)
+        flat = FlatParams(model)
+        opt = FusedAdam(flat, lr=1e-3)
+        g = torch.Generator().manual_seed(3)
+        inputs = DatasetOutput(data=dict(mnist=torch.rand(B, 1, 28, 28, generator=g).to(d),
+                                         svhn=torch.rand(B, 3, 32, 32, generator=g).to(d)))
+        gs = GraphedStep(model, flat, inputs, noise=torch.zeros(K, B, L, device=d)) if graphed else None
+        losses = []
+        for _ in range(steps):
+            eps = torch.randn(K, B, L, generator=g).to(d)
+            if gs is not None:
+                out = gs(inputs, eps)
+            else:
+                opt.zero_grad()
+                out = model(inputs, noise=eps)
+                out.loss.backward()
+            opt.step()
+            losses.append(float(out.loss.detach()))
+        torch.cuda.synchronize()
+        return losses, flat.flat.detach().cpu().clone()
+    finally:
+        kernels.BRANCH_STREAMS = old
+
+
+def _same_training(r1, r2, lr=1e-3):
+    """Same kernels on the same data: only the order of the bias-gradient atomics may differ (1e-8 relative on a
+    gradient), which Adam's g / sqrt(v) can turn into a different step for parameters whose gradient is ~0."""
+    (l1, p1), (l2, p2) = r1, r2
+    for a, b in zip(l1, l2):
+        assert abs(a - b) <= 1e-6 * abs(a), (l1, l2)
+    diff = (p1 - p2).abs()
+    assert int((diff > 0.5 * lr).sum()) <= 1e-3 * diff.numel(), float(diff.max())
+
+
+def test_branch_streams_do_not_change_the_result():
+    """Encoders / decoders of the two modalities on separate HIP streams (kernels.run_branches) vs one stream."""
+    d = torch.device("cuda:0")
+    _same_training(_run_steps(d, 4, graphed=False, branch_streams=False), _run_steps(d, 4, graphed=False, branch_streams=True))
+
+
+def test_graph_replay_matches_eager():
+    """GraphedStep (zero_grad + forward + backward as one hipGraph replay) vs launches enqueued from Python."""
+    d = torch.device("cuda:0")
+    _same_training(_run_steps(d, 5, graphed=False), _run_steps(d, 5, graphed=True))
