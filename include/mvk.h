@@ -177,7 +177,9 @@ int mvk_mmvae_latent_bwd(const float* const* mu, const float* const* std, const 
                          float* dprior_std, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Encoder / decoder layers: fp32 MFMA implicit GEMM (v_mfma_f32_32x32x2_f32, exact fp32 FMA chains)
+ * Encoder / decoder layers: implicit GEMM with fp32 operands and results.  Default engine: split-bf16 MFMA
+ * (3 bf16 pieces per operand, 6 piece products, fp32 accumulate: fp32-level error); MVK_ENGINE=f32 selects
+ * v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains), which also serves small / irregular shapes.
  * ------------------------------------------------------------------------------------------------ */
 
 /* Y[M,N] = act(X[M,K] W[N,K]^T + b[N]) — nn.Linear + activation
@@ -186,10 +188,12 @@ int mvk_linear_fwd(const float* X, const float* W, const float* b, float* Y, int
                    float* ws, int64_t ws_floats, void* stream);
 /* dX[M,K] = dYpre[M,N] W[N,K] (* act'(prev_out[m,k]) if prev_out != NULL, so the result is directly the
  * previous layer's pre-activation gradient).  dYpre = dY * act'(y_out) when y_out != NULL, else dY.
- * accumulate != 0: dX += (atomic). */
+ * accumulate != 0: dX += (atomic).
+ * colsum_acc (may be NULL; requires accumulate == 0): colsum_acc[k] += sum_m dX[m,k] — the previous layer's bias
+ * gradient, fused into this launch's epilogue. */
 int mvk_linear_bwd_data(const float* dY, const float* W, float* dX, int M, int N, int K, const float* y_out,
-                        int y_act, const float* prev_out, int prev_act, int accumulate, float* ws,
-                        int64_t ws_floats, void* stream);
+                        int y_act, const float* prev_out, int prev_act, int accumulate, float* colsum_acc,
+                        float* ws, int64_t ws_floats, void* stream);
 /* dW[N,K] += dYpre[M,N]^T X[M,K];  db[N] += colsum(dYpre) (db nullable).
  * Split-K workspace convention (all weight-gradient / accumulate entry points): `ws` is caller-owned scratch of
  * `ws_floats` floats.  When it can hold one [rows x cols] slab per reduction slice the slices are summed by a
@@ -224,14 +228,19 @@ int mvk_gemm(const float* A, const float* B, float* C, int M, int N, int K, int 
  *   up:    U = act(convT(V) + b) (* u_act'(u_act_src))  — ConvTranspose2d forward / Conv2d backward-data
  *   wgrad: dWref[Cv][Cu][4][4] += sum_pos U(gathered) V — both layer types
  * u_nchw != 0: U is stored NCHW (network input / output boundary tensors only).
- * u_act_src (down, wgrad): U is a gradient tensor that is multiplied by u_act'(u_act_src) while loading. */
+ * u_act_src (down, wgrad): U is a gradient tensor that is multiplied by u_act'(u_act_src) while loading.
+ * colsum_acc (down, up; may be NULL): colsum_acc[c] += sum over positions of the stored output — the bias gradient
+ *   of the layer whose output gradient this launch produces (replaces a separate pass over that tensor; uses the
+ *   caller-owned scratch ws for per-workgroup partials, reduced in a fixed order). */
 int mvk_pack_conv4s2_weight(const float* Wref, int Cv, int Cu, float* Wdown, int ld_down, int col_off,
                             float* Wup, void* stream);
 int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w,
                      int Cu, int Cv, int act, int u_nchw, const float* u_act_src, int u_act,
-                     const float* v_act_src, int v_act, void* stream);
+                     const float* v_act_src, int v_act, float* colsum_acc, float* ws, int64_t ws_floats,
+                     void* stream);
 int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U, int n, int h, int w, int Cu,
-                   int Cv, int act, int u_nchw, const float* u_act_src, int u_act, void* stream);
+                   int Cv, int act, int u_nchw, const float* u_act_src, int u_act, float* colsum_acc, float* ws,
+                   int64_t ws_floats, void* stream);
 int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv,
                       int u_nchw, const float* u_act_src, int u_act, float* ws, int64_t ws_floats, void* stream);
 /* Direct kernel for the 3-channel image-producing layer: U[n,Cu,2h,2w] (NCHW) = act(convT(V) + b), Cu <= 4,

@@ -45,15 +45,15 @@ PROTOTYPES = {
     "mvk_reduce_terms": [C.POINTER(TermDesc), _i, _f, _p, _p, _p],
     "mvk_scale_by_device_scalar": [_p, _i64, _p, _p],
     "mvk_linear_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p, _i64, _p],
-    "mvk_linear_bwd_data": [_p, _p, _p, _i, _i, _i, _p, _i, _p, _i, _i, _p, _i64, _p],
+    "mvk_linear_bwd_data": [_p, _p, _p, _i, _i, _i, _p, _i, _p, _i, _i, _p, _p, _i64, _p],
     "mvk_linear_bwd_weight": [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _i64, _p],
     "mvk_colsum_acc": [_p, _p, _i, _p, _i, _i, _p],
     "mvk_nchw_channel_sum_acc": [_p, _p, _i, _p, _i, _i, _i, _p],
     "mvk_act_bwd": [_p, _p, _i64, _i, _p],
     "mvk_gemm": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _i, _p, _i, _p, _i64, _p],
     "mvk_pack_conv4s2_weight": [_p, _i, _i, _p, _i, _i, _p, _p],
-    "mvk_conv4s2_down": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p],
-    "mvk_conv4s2_up": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p],
+    "mvk_conv4s2_down": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i64, _p],
+    "mvk_conv4s2_up": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i64, _p],
     "mvk_conv4s2_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _p],
     "mvk_conv4s2_up_nchw_small": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "mvk_conv4s2_small_up_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],

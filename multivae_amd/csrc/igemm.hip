@@ -13,8 +13,11 @@ static int launch_cfg(const GemmDesc& d, int zdim, hipStream_t s) {
 }
 
 // ---- mode-specialised kernels (igemm_fast.hpp) -------------------------------------------------------------------
+static thread_local int g_last_bm = 0;  // tile rows of the last specialised launch (LaunchInfo)
+
 template <int BM, int BN, int BKT, int AMODE, int BMODE, bool AACT>
 static int launch_fast_cfg(const GemmDesc& d, int zdim, hipStream_t s) {
+  g_last_bm = BM;
   dim3 grid((d.M + BM - 1) / BM, (d.N + BN - 1) / BN, zdim);
   hipLaunchKernelGGL((igemm_fast_kernel<BM, BN, BKT, AMODE, BMODE, AACT>), grid, dim3(256), 0, s, d);
   MVK_CHECK_LAUNCH();
@@ -36,6 +39,7 @@ static int launch_fast_tile(const GemmDesc& d, int zdim, hipStream_t s, int amod
 // ---- split-precision kernels (igemm_bf.hpp) ----------------------------------------------------------------------
 template <int BM, int BN, int AMODE, int BMODE, bool AACT>
 static int launch_bf_cfg(const GemmDesc& d, int zdim, hipStream_t s) {
+  g_last_bm = BM;
   dim3 grid((d.M + BM - 1) / BM, (d.N + BN - 1) / BN, zdim);
   constexpr int DEPTH = 2;
   hipLaunchKernelGGL((igemm_bf_kernel<BM, BN, AMODE, BMODE, AACT, DEPTH>), grid, dim3(256), 0, s, d);
@@ -137,15 +141,21 @@ extern "C" void mvk_debug_set_flags(int f) {
 #endif
 }
 
-int launch_igemm(const GemmDesc& d_in, int zdim, hipStream_t s) {
+int launch_igemm(const GemmDesc& d_in, int zdim, hipStream_t s, LaunchInfo* info) {
   GemmDesc d = d_in;
+  if (info) info->bm = 0;
   d.dbg = g_dbg;
   d.dbg_flags = g_dbg_flags;
   { static int stg = -1; if (stg < 0) { const char* e = getenv("MVK_STAGGER"); stg = e ? atoi(e) : 0; } d.stagger = stg; }
   if (d.M <= 0 || d.N <= 0 || d.K <= 0) return MVK_OK;
   {
+    g_last_bm = 0;
     const int rc = try_launch_fast(d, zdim, s);
-    if (rc != 1) return rc;
+    if (rc != 1) {
+      if (info) info->bm = g_last_bm;
+      return rc;
+    }
+    d.e.colsum_part = nullptr;  // generic kernels: the caller falls back to a separate column-sum launch
   }
   if (d.N <= 32) return launch_cfg<128, 32>(d, zdim, s);
   if (d.N <= 64) {
@@ -307,7 +317,7 @@ static int colsum(const float* dY, const float* Y, int act, int M, int N, float*
   const int gx = (ncg + cgb - 1) / cgb;
   // ~256 workgroups over the rows (few atomics per column), at least 64 rows each
   int rows_per_block = (M + 255) / 256;
-  if (rows_per_block < 64) rows_per_block = 64;
+  if (rows_per_block < 16) rows_per_block = 16;
   const int gy = (M + rows_per_block - 1) / rows_per_block;
   if (vec)
     hipLaunchKernelGGL((colsum_kernel<4>), dim3(gx, gy), dim3(256), 0, s, dY, Y, act, M, N, rows_per_block, db);
@@ -315,6 +325,70 @@ static int colsum(const float* dY, const float* Y, int act, int M, int N, float*
     hipLaunchKernelGGL((colsum_kernel<1>), dim3(gx, gy), dim3(256), 0, s, dY, Y, act, M, N, rows_per_block, db);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
+}
+
+// db[n] += sum_r part[r][n] in a fixed order: 64 row lanes x 4 column quads per workgroup (float4 loads), LDS tree.
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int rows, int N,
+                                                            float* __restrict__ db) {
+  const int q = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int c = (blockIdx.x * 4 + q) * 4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < N) {
+#pragma unroll 8
+    for (int r = rl; r < rows; r += 64) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (long long)r * N + c);
+      a.x += v.x;
+      a.y += v.y;
+      a.z += v.z;
+      a.w += v.w;
+    }
+  }
+  __shared__ float4 red[64][4];
+  red[rl][q] = a;
+  __syncthreads();
+  for (int st = 32; st >= 1; st >>= 1) {
+    if (rl < st) {
+      const float4 o = red[rl + st][q];
+      float4 m = red[rl][q];
+      m.x += o.x;
+      m.y += o.y;
+      m.z += o.z;
+      m.w += o.w;
+      red[rl][q] = m;
+    }
+    __syncthreads();
+  }
+  if (rl == 0 && c < N) {
+    const float4 t = red[0][q];
+    db[c] += t.x;
+    db[c + 1] += t.y;
+    db[c + 2] += t.z;
+    db[c + 3] += t.w;
+  }
+}
+
+int colsum_finish(const float* part, int rows, int N, float* db, hipStream_t s) {
+  // N % 4 == 0 and 16-byte aligned partials are guaranteed by epilogue_vec_ok + the scratch allocation
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 15) / 16), dim3(256), 0, s, part, rows, N, db);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+// GEMM launch + `db[n] += column sums of the stored output` (bias gradient of the layer that produced the GEMM's
+// input gradient).  Fused into the epilogue when the vectorised epilogue applies and the partials fit in ws;
+// otherwise a separate pass over the output.
+static int launch_with_colsum(GemmDesc& d, int zdim, float* db, float* ws, int64_t ws_floats, const float* out,
+                              long long out_rows, hipStream_t s) {
+  if (!db) return launch_igemm(d, zdim, s);
+  const long long max_rows = (long long)((d.M + 63) / 64) * zdim;
+  const bool fuse = ws && mvk_aligned16(ws) && epilogue_vec_ok(d.e, d.N) && max_rows * d.N <= ws_floats;
+  LaunchInfo info{};
+  d.e.colsum_part = fuse ? ws : nullptr;
+  int rc = launch_igemm(d, zdim, s, &info);
+  d.e.colsum_part = nullptr;
+  if (rc != MVK_OK) return rc;
+  if (fuse && info.bm > 0) return colsum_finish(ws, ((d.M + info.bm - 1) / info.bm) * zdim, d.N, db, s);
+  return colsum(out, nullptr, 0, (int)out_rows, d.N, db, s);
 }
 
 }  // namespace mvk
@@ -347,9 +421,9 @@ int mvk_linear_fwd(const float* X, const float* W, const float* b, float* Y, int
 }
 
 int mvk_linear_bwd_data(const float* dY, const float* W, float* dX, int M, int N, int K, const float* y_out,
-                        int y_act, const float* prev_out, int prev_act, int accumulate, float* ws,
+                        int y_act, const float* prev_out, int prev_act, int accumulate, float* colsum_acc, float* ws,
                         int64_t ws_floats, void* stream) {
-  if (!dY || !W || !dX || M < 0 || N <= 0 || K <= 0) return MVK_EINVAL;
+  if (!dY || !W || !dX || M < 0 || N <= 0 || K <= 0 || (colsum_acc && accumulate)) return MVK_EINVAL;
   GemmDesc d{};
   plain_a(d.a, dY, N, 1, M, N);  // reduce over n
   d.a.act_src = y_out;
@@ -362,7 +436,13 @@ int mvk_linear_bwd_data(const float* dY, const float* W, float* dX, int M, int N
   d.M = M;
   d.N = K;
   d.K = N;
-  return launch_auto(d, ws, ws_floats, mvk_stream(stream));
+  hipStream_t s = mvk_stream(stream);
+  if (!colsum_acc) return launch_auto(d, ws, ws_floats, s);
+  // bias gradient of the previous layer = column sums of dX: fused into the epilogue unless the launch splits K
+  const long long tiles = (long long)((d.M + 127) / 128) * ((d.N + 63) / 64);
+  if (!(ws && tiles < 128 && d.K >= 256)) return launch_with_colsum(d, 1, colsum_acc, ws, ws_floats, dX, M, s);
+  const int rc = launch_auto(d, ws, ws_floats, s);
+  return rc != MVK_OK ? rc : colsum(dX, nullptr, 0, M, K, colsum_acc, s);
 }
 
 int mvk_linear_bwd_weight(const float* dY, const float* X, float* dW, float* db, int M, int N, int K,
@@ -435,7 +515,7 @@ int mvk_gemm(const float* A, const float* B, float* C, int M, int N, int K, int 
 // ---------------------------------------------------------------------------------------------------------
 int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w, int Cu,
                      int Cv, int act, int u_nchw, const float* u_act_src, int u_act, const float* v_act_src,
-                     int v_act, void* stream) {
+                     int v_act, float* colsum_acc, float* ws, int64_t ws_floats, void* stream) {
   if (!U || !Wdown || !V || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0) return MVK_EINVAL;
   GemmDesc d{};
   d.a = AOperand{};
@@ -461,12 +541,13 @@ int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, floa
   d.M = n * h * w;
   d.N = Cv;
   d.K = 16 * Cu;
-  return launch_igemm(d, 1, mvk_stream(stream));
+  return launch_with_colsum(d, 1, colsum_acc, ws, ws_floats, V, (long long)n * h * w, mvk_stream(stream));
 }
 
 int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U, int n, int h, int w, int Cu,
-                   int Cv, int act, int u_nchw, const float* u_act_src, int u_act, void* stream) {
-  if (!V || !Wup || !U || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0) return MVK_EINVAL;
+                   int Cv, int act, int u_nchw, const float* u_act_src, int u_act, float* colsum_acc, float* ws,
+                   int64_t ws_floats, void* stream) {
+  if (!V || !Wup || !U || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0 || (colsum_acc && u_nchw)) return MVK_EINVAL;
   GemmDesc d{};
   d.a = AOperand{};
   d.a.p = V;
@@ -497,7 +578,7 @@ int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U
   d.N = Cu;
   d.K = 4 * Cv;
   d.zmode = Z_PARITY;
-  return launch_igemm(d, 4, mvk_stream(stream));
+  return launch_with_colsum(d, 4, colsum_acc, ws, ws_floats, U, (long long)n * 4 * h * w, mvk_stream(stream));
 }
 
 int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv,

@@ -52,7 +52,8 @@ struct Epilogue {
   int atomic;
   int Cu, OH, OW;  // E_UP / E_CONVREF / E_UNFLATREF geometry
   float* ws;       // Z_SPLITK: if set, raw partial tiles go to ws[z][m][n] and splitk_reduce_kernel finishes
-};
+  float* colsum_part;  // optional: per-workgroup column sums of the stored values -> colsum_part[(z*gridDim.x + bx)*N + n]
+};                     // (vectorised epilogue only; the host finishes them with an ordered reduce: bias gradients)
 
 struct GemmDesc {
   AOperand a;
@@ -129,6 +130,15 @@ __device__ __forceinline__ bool gather_off(const AOperand& a, const Pos& ps, int
   else
     off = (((long long)ps.n * a.C + c) * a.H + h) * a.W + w;
   return ok;
+}
+
+// Conditions of the float4 LDS-staged epilogue (host and device agree on them: the host decides on fusing the
+// bias-gradient column sums into the launch).
+__host__ __device__ inline bool epilogue_vec_ok(const Epilogue& E, int N) {
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+  return !E.ws && !E.atomic && (E.kind == E_ROWMAJOR || E.kind == E_UP) && (N % 4 == 0) && al16(E.out) &&
+         (!E.act_src || al16(E.act_src)) && (E.kind == E_UP ? (E.Cu % 4 == 0) : (E.ld % 4 == 0)) &&
+         (!E.bias || (E.bias_mod % 4 == 0 && al16(E.bias)));
 }
 
 // ---- shared epilogue -------------------------------------------------------------------------------------------
@@ -218,12 +228,10 @@ __device__ __forceinline__ bool run_epilogue_vec(const GemmDesc& d, f32x16 (&acc
   constexpr int RP_MAX = LDS_FLOATS / CS;
   constexpr int RP = (RP_MAX >= BM) ? BM : ((RP_MAX >= T::WTM && T::WAVES_M > 1) ? T::WTM : (RP_MAX >= 32 ? 32 : 0));
   if (RP == 0) return false;
-  const bool vec_ok = !E.ws && !E.atomic && (E.kind == E_ROWMAJOR || E.kind == E_UP) && (d.N % 4 == 0) &&
-                      mvk_dev_aligned16(E.out) && (!E.act_src || mvk_dev_aligned16(E.act_src)) &&
-                      (E.kind == E_UP ? (E.Cu % 4 == 0) : (E.ld % 4 == 0)) &&
-                      (!E.bias || (E.bias_mod % 4 == 0 && mvk_dev_aligned16(E.bias)));
+  const bool vec_ok = epilogue_vec_ok(E, d.N);
   if (!vec_ok) return false;
   constexpr int NPASS = BM / RP;
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);  // this thread's column quad (fixed: 256 % (BN/4) == 0)
 #pragma unroll
   for (int p = 0; p < NPASS; ++p) {
     const int r_lo = p * RP;
@@ -276,10 +284,28 @@ __device__ __forceinline__ bool run_epilogue_vec(const GemmDesc& d, f32x16 (&acc
             v.w *= mvk_act_grad_from_out(y.w, E.src_act);
           }
           *reinterpret_cast<float4*>(E.out + off) = v;
+          csum.x += v.x;
+          csum.y += v.y;
+          csum.z += v.z;
+          csum.w += v.w;
         }
       }
     }
     if (p + 1 < NPASS) __syncthreads();
+  }
+  if (E.colsum_part) {
+    // fixed-order block reduction of the per-thread column quads: 256/(BN/4) row groups -> one value per column
+    constexpr int QN = BN / 4, RG = 256 / QN;
+    static_assert(256 % QN == 0 && RG * BN <= LDS_FLOATS, "column-sum scratch");
+    __syncthreads();
+    *reinterpret_cast<float4*>(lds + (tid / QN) * BN + (tid % QN) * 4) = csum;
+    __syncthreads();
+    if (tid < BN && n0 + tid < d.N) {
+      float t = 0.f;
+#pragma unroll 4
+      for (int g = 0; g < RG; ++g) t += lds[g * BN + tid];
+      E.colsum_part[((long long)blockIdx.z * gridDim.x + blockIdx.x) * d.N + n0 + tid] = t;
+    }
   }
   return true;
 }
@@ -799,7 +825,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const Epilogue E, in
     E.out[off] = v;
 }
 
-int launch_igemm(const GemmDesc& d, int zdim, hipStream_t s);
+// what the launcher chose (needed to finish fused column sums): rows of one tile; 0 = generic kernel
+struct LaunchInfo {
+  int bm;
+};
+int launch_igemm(const GemmDesc& d, int zdim, hipStream_t s, LaunchInfo* info = nullptr);
+// db[n] += sum over `rows` partial rows (ordered, deterministic)
+int colsum_finish(const float* part, int rows, int N, float* db, hipStream_t s);
 // split-K launch: picks the slice count, uses the slab workspace when it is large enough (else atomics)
 int launch_splitk(GemmDesc& d, float* ws, long long ws_floats, int target_blocks, hipStream_t s);
 

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf_kernel(const GemmDesc d) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
 
-  constexpr int OOB = 0x7fffffff;  // buffer loads past num_records return 0 (see igemm_fast.hpp)
+  // buffer loads with byte offset 0x7fffffff are past num_records and return 0 (see igemm_fast.hpp)
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A.p, 0, 0x7ffffff0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsY =
       __builtin_amdgcn_make_buffer_rsrc((void*)(AACT ? A.act_src : A.p), 0, 0x7ffffff0, 0x00020000);

@@ -93,9 +93,12 @@ def run_branches(names, fn, device):
         return {m: fn(m) for m in names}
     main = torch.cuda.current_stream(device)
     fork = main.record_event()
-    outs = {}
+    # The first branch stays on the caller's stream and is enqueued FIRST: autograd runs backward nodes in reverse
+    # creation order, so the side branches' backward is enqueued (and, in a captured graph, ordered) before the long
+    # backward of the main branch instead of behind it.
+    outs = {names[0]: fn(names[0])}
     sides = []
-    for i, m in enumerate(names[1:], start=1):  # enqueue the side branches first, then the main one
+    for i, m in enumerate(names[1:], start=1):
         st = _side_stream(device, i)
         st.wait_event(fork)
         with torch.cuda.stream(st):
@@ -103,7 +106,6 @@ def run_branches(names, fn, device):
         for t in _tensors_of(outs[m]):
             t.record_stream(main)
         sides.append(st)
-    outs[names[0]] = fn(names[0])
     for st in sides:
         main.wait_stream(st)
     return {m: outs[m] for m in names}
@@ -121,14 +123,25 @@ def linear_fwd(x2, w, b, act):
     return y
 
 
-def linear_bwd_data(dy, w, y_out=None, y_act=NONE, prev_out=None, prev_act=NONE, out=None, accumulate=False):
+def _bias_target(bias_param):
+    """(buffer the kernel accumulates the bias gradient into, what autograd gets for the bias)."""
+    if bias_param is None:
+        return None, None
+    return _grad_target(bias_param)
+
+
+def linear_bwd_data(dy, w, y_out=None, y_act=NONE, prev_out=None, prev_act=NONE, out=None, accumulate=False,
+                    prev_bias=None):
+    """dx (the previous layer's pre-activation gradient when prev_out is given).  prev_bias: that layer's bias
+    parameter — its gradient (column sums of dx) is produced by the same launch; returns (dx, grad for autograd)."""
     M, N = dy.shape
     K = w.shape[1]
     dx = out if out is not None else _new((M, K), dy)
     ws = _ws(dy)
+    tb, rb = _bias_target(prev_bias)
     call("mvk_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), M, N, K, ptr(y_out), y_act, ptr(prev_out), prev_act,
-         1 if accumulate else 0, ptr(ws), ws.numel(), stream_ptr())
-    return dx
+         1 if accumulate else 0, ptr(tb), ptr(ws), ws.numel(), stream_ptr())
+    return dx if prev_bias is None else (dx, rb)
 
 
 def _grad_target(p):
@@ -183,18 +196,24 @@ def pack_conv(wref, want_down=True, want_up=True):
 
 
 def conv_down(U, wdown, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src=None, u_act=NONE,
-              v_act_src=None, v_act=NONE):
+              v_act_src=None, v_act=NONE, out_bias=None):
+    """out_bias: bias parameter whose gradient is the per-channel sum of the result (backward-data use): fused into
+    the launch; returns (V, grad for autograd) then."""
     V = _new((n, h, w, Cv), U)
+    ws = _ws(U)
+    tb, rb = _bias_target(out_bias)
     call("mvk_conv4s2_down", ptr(U), ptr(wdown), ptr(bias), ptr(V), n, h, w, Cu, Cv, act, int(u_nchw),
-         ptr(u_act_src), u_act, ptr(v_act_src), v_act, stream_ptr())
-    return V
+         ptr(u_act_src), u_act, ptr(v_act_src), v_act, ptr(tb), ptr(ws), ws.numel(), stream_ptr())
+    return V if out_bias is None else (V, rb)
 
 
-def conv_up(V, wup, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src=None, u_act=NONE):
+def conv_up(V, wup, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src=None, u_act=NONE, out_bias=None):
     U = _new((n, Cu, 2 * h, 2 * w) if u_nchw else (n, 2 * h, 2 * w, Cu), V)
+    ws = _ws(V)
+    tb, rb = _bias_target(out_bias)
     call("mvk_conv4s2_up", ptr(V), ptr(wup), ptr(bias), ptr(U), n, h, w, Cu, Cv, act, int(u_nchw),
-         ptr(u_act_src), u_act, stream_ptr())
-    return U
+         ptr(u_act_src), u_act, ptr(tb), ptr(ws), ws.numel(), stream_ptr())
+    return U if out_bias is None else (U, rb)
 
 
 def conv_wgrad(U, V, wparam, n, h, w, Cu, Cv, u_nchw=False, u_act_src=None, u_act=NONE):
@@ -248,11 +267,16 @@ class MLPEncoderFn(Function):
         if n > 0 or need_dx:
             dh = linear_bwd_data(dmu, we, prev_out=prev_src, prev_act=prev_act)
             linear_bwd_data(dlv, wl, prev_out=prev_src, prev_act=prev_act, out=dh, accumulate=True)
+        bias_done = False  # bias gradient of layer i already produced by the backward-data launch of layer i+1
         for i in range(n - 1, -1, -1):
             w, inp = params[2 * i], acts[i]
-            grads[2 * i], grads[2 * i + 1] = linear_bwd_weight(dh, inp, w, params[2 * i + 1])
+            gb = grads[2 * i + 1]
+            grads[2 * i], gb2 = linear_bwd_weight(dh, inp, w, None if bias_done else params[2 * i + 1])
+            grads[2 * i + 1] = gb if bias_done else gb2
+            bias_done = False
             if i > 0:
-                dh = linear_bwd_data(dh, w, prev_out=acts[i], prev_act=RELU)
+                dh, grads[2 * i - 1] = linear_bwd_data(dh, w, prev_out=acts[i], prev_act=RELU, prev_bias=params[2 * i - 1])
+                bias_done = True
             elif need_dx:
                 dh = linear_bwd_data(dh, w)
         dx = dh.reshape(ctx.x_shape) if need_dx else None
@@ -278,8 +302,8 @@ class MLPDecoderFn(Function):
         z2, h, out, w0, b0, w1, b1 = ctx.saved_tensors
         dout = _c(dout).view(out.shape)
         dw1, db1 = linear_bwd_weight(dout, h, w1, b1, y_out=out, y_act=SIGMOID)
-        dh = linear_bwd_data(dout, w1, y_out=out, y_act=SIGMOID, prev_out=h, prev_act=RELU)
-        dw0, db0 = linear_bwd_weight(dh, z2, w0, b0)
+        dh, db0 = linear_bwd_data(dout, w1, y_out=out, y_act=SIGMOID, prev_out=h, prev_act=RELU, prev_bias=b0)
+        dw0, _ = linear_bwd_weight(dh, z2, w0, None)
         dz = None
         if ctx.needs_input_grad[0]:
             dz = linear_bwd_data(dh, w0).view(ctx.z_shape)
@@ -337,12 +361,11 @@ class SVHNEncoderFn(Function):
         dh3 = dh3.view(B, H // 8, W // 8, ch[3])
         dw2 = conv_wgrad(h2, dh3, w2, B, H // 8, W // 8, ch[2], ch[3])
         db2 = colsum(dh3.view(-1, ch[3]), b2)
-        dh2 = conv_up(dh3, wu2, None, B, H // 8, W // 8, ch[2], ch[3], u_act_src=h2, u_act=RELU)
+        # each backward-data launch also emits the bias gradient of the layer it lands in (column sums of its output)
+        dh2, db1 = conv_up(dh3, wu2, None, B, H // 8, W // 8, ch[2], ch[3], u_act_src=h2, u_act=RELU, out_bias=b1)
         dw1 = conv_wgrad(h1, dh2, w1, B, H // 4, W // 4, ch[1], ch[2])
-        db1 = colsum(dh2.view(-1, ch[2]), b1)
-        dh1 = conv_up(dh2, wu1, None, B, H // 4, W // 4, ch[1], ch[2], u_act_src=h1, u_act=RELU)
+        dh1, db0 = conv_up(dh2, wu1, None, B, H // 4, W // 4, ch[1], ch[2], u_act_src=h1, u_act=RELU, out_bias=b0)
         dw0 = conv_wgrad(x, dh1, w0, B, H // 2, W // 2, ch[0], ch[1], u_nchw=True)
-        db0 = colsum(dh1.view(-1, ch[1]), b0)
         dx = None
         if ctx.needs_input_grad[0]:
             raise _lib.MvkError("gradient w.r.t. the encoder input image is not implemented")
@@ -404,15 +427,13 @@ class SVHNDecoderFn(Function):
         dw2 = conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2)
         if not ctx.small:
             db2 = colsum(dg3.view(-1, C3), b2)
-        dg2 = conv_down(dg3, wd2, None, n, 8, 8, C3, C2, NONE, v_act_src=g2, v_act=RELU)
+        dg2, db1 = conv_down(dg3, wd2, None, n, 8, 8, C3, C2, NONE, v_act_src=g2, v_act=RELU, out_bias=b1)
         dw1 = conv_wgrad(dg2, g1, w1, n, 4, 4, C2, C1)
-        db1 = colsum(dg2.view(-1, C2), b1)
-        dg1 = conv_down(dg2, wd1, None, n, 4, 4, C2, C1, NONE, v_act_src=g1, v_act=RELU)
+        dg1, db0 = conv_down(dg2, wd1, None, n, 4, 4, C2, C1, NONE, v_act_src=g1, v_act=RELU, out_bias=b0)
         dg1f = dg1.view(n, 16 * C1)
         tw0, dw0 = _grad_target(w0)
         ws = _ws(z2)
         call("mvk_unflatten_wgrad", ptr(z2), ptr(dg1f), ptr(tw0), n, L, C1, ptr(ws), ws.numel(), stream_ptr())
-        db0 = colsum(dg1.view(-1, C1), b0)
         dz = None
         if ctx.needs_input_grad[0]:
             dz = gemm(dg1f, wp0, n, L, 16 * C1, tb=True).view(ctx.z_shape)
