@@ -218,6 +218,13 @@ int mvk_gemm(const float* A, const float* B, float* C, int M, int N, int K, int 
              int bias_mod, int act, int accumulate, const float* a_act_src, int a_act, const float* c_act_src,
              int c_act, float* ws, int64_t ws_floats, void* stream);
 
+/* Pre-split ("bf3") tensor format of the split-bf16 GEMM engine: x = p0 + p1 + p2 with p0 = bf16(x),
+ * p1 = bf16(x - p0), p2 = bf16(x - p0 - p1) (round to nearest); stored as three planes of n bf16 values,
+ * plane i at byte offset i * 2 * n.  A producer writes it once; every consuming GEMM saves the per-k-tile split. */
+#define MVK_FMT_IN_BF3 1
+int mvk_f32_to_bf3(const float* x, int64_t n, void* planes, void* stream);
+int mvk_bf3_to_f32(const void* planes, int64_t n, float* x, void* stream);
+
 /* 4x4 / stride 2 / pad 1 convolution pair on NHWC activations (models/nn/svhn.py:7-70).
  * "U" is the large feature map [n,2h,2w,Cu], "V" the small one [n,h,w,Cv], W the reference weight
  * tensor indexed [Cv][Cu][4][4] (nn.Conv2d weight [out,in,kh,kw] with V = output; nn.ConvTranspose2d
@@ -229,6 +236,8 @@ int mvk_gemm(const float* A, const float* B, float* C, int M, int N, int K, int 
  *   wgrad: dWref[Cv][Cu][4][4] += sum_pos U(gathered) V — both layer types
  * u_nchw != 0: U is stored NCHW (network input / output boundary tensors only).
  * u_act_src (down, wgrad): U is a gradient tensor that is multiplied by u_act'(u_act_src) while loading.
+ * fmt (down, up): MVK_FMT_IN_BF3 — the gathered input (U for down, V for up) is a pre-split tensor (see
+ *   mvk_f32_to_bf3): three bf16 planes [3][n*H*W*C]; the GEMM then stages it without any conversion work.
  * colsum_acc (down, up; may be NULL): colsum_acc[c] += sum over positions of the stored output — the bias gradient
  *   of the layer whose output gradient this launch produces (replaces a separate pass over that tensor; uses the
  *   caller-owned scratch ws for per-workgroup partials, reduced in a fixed order). */
@@ -236,11 +245,11 @@ int mvk_pack_conv4s2_weight(const float* Wref, int Cv, int Cu, float* Wdown, int
                             float* Wup, void* stream);
 int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w,
                      int Cu, int Cv, int act, int u_nchw, const float* u_act_src, int u_act,
-                     const float* v_act_src, int v_act, float* colsum_acc, float* ws, int64_t ws_floats,
+                     const float* v_act_src, int v_act, float* colsum_acc, float* ws, int64_t ws_floats, int fmt,
                      void* stream);
 int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U, int n, int h, int w, int Cu,
                    int Cv, int act, int u_nchw, const float* u_act_src, int u_act, float* colsum_acc, float* ws,
-                   int64_t ws_floats, void* stream);
+                   int64_t ws_floats, int fmt, void* stream);
 int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv,
                       int u_nchw, const float* u_act_src, int u_act, float* ws, int64_t ws_floats, void* stream);
 /* Direct kernel for the 3-channel image-producing layer: U[n,Cu,2h,2w] (NCHW) = act(convT(V) + b), Cu <= 4,

@@ -52,8 +52,10 @@ PROTOTYPES = {
     "mvk_act_bwd": [_p, _p, _i64, _i, _p],
     "mvk_gemm": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _i, _p, _i, _p, _i64, _p],
     "mvk_pack_conv4s2_weight": [_p, _i, _i, _p, _i, _i, _p, _p],
-    "mvk_conv4s2_down": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i64, _p],
-    "mvk_conv4s2_up": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i64, _p],
+    "mvk_conv4s2_down": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i64, _i, _p],
+    "mvk_conv4s2_up": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i64, _i, _p],
+    "mvk_f32_to_bf3": [_p, _i64, _p, _p],
+    "mvk_bf3_to_f32": [_p, _i64, _p, _p],
     "mvk_conv4s2_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _p],
     "mvk_conv4s2_up_nchw_small": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "mvk_conv4s2_small_up_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],

@@ -60,6 +60,7 @@ static int launch_bf_tile(const GemmDesc& d, int zdim, hipStream_t s, int amode,
   if (amode == AM_PLAIN_R && bmode == BM_N && aact) return launch_bf_cfg<BM, BN, AM_PLAIN_R, BM_N, true>(d, zdim, s);
   if (amode == AM_ROW && bmode == BM_N && !aact) return launch_bf_cfg<BM, BN, AM_ROW, BM_N, false>(d, zdim, s);
   if (amode == AM_COL && bmode == BM_N && !aact) return launch_bf_cfg<BM, BN, AM_COL, BM_N, false>(d, zdim, s);
+  if (amode == AM_ROW3 && bmode == BM_N && !aact) return launch_bf_cfg<BM, BN, AM_ROW3, BM_N, false>(d, zdim, s);
   return 1;
 }
 
@@ -92,6 +93,12 @@ static int try_launch_fast(const GemmDesc& d, int zdim, hipStream_t s) {
     if (!A.vec4) return 1;
     if (aact && !mvk_aligned16(A.act_src)) return 1;
     amode = A.contig_k ? AM_PLAIN_K : AM_PLAIN_R;
+  } else if (A.bf3) {
+    // pre-split operand: only the split engine reads it (row gather, 32-channel k-tiles, 16-byte aligned planes)
+    if (A.trans || !A.contig_k || A.kind == A_DOWN_NCHW || aact || A.C % 32 != 0 || !mvk_aligned16(A.p) ||
+        A.plane_bytes % 16 != 0)
+      return MVK_EINVAL;
+    amode = AM_ROW3;
   } else if (!A.trans && A.vec4 && A.contig_k && A.kind != A_DOWN_NCHW && !aact) {
     amode = AM_ROW;
   } else if (A.trans && A.vec4 && !A.contig_k && A.kind == A_DOWN && !aact) {
@@ -104,7 +111,8 @@ static int try_launch_fast(const GemmDesc& d, int zdim, hipStream_t s) {
   if (d.zmode == Z_SPLITK && (d.ksplit_tiles & 1)) return 1;  // BKT = 32 needs 32-aligned slices
   const bool c32 = (amode != AM_ROW) || (A.C % 32 == 0);
   const bool c16 = (amode != AM_ROW) || (A.C % 16 == 0);
-  if (engine() == 1 && c32) {
+  if (amode == AM_ROW3 && !d.b.vec4) return MVK_EINVAL;
+  if ((engine() == 1 || amode == AM_ROW3) && c32) {
     auto nb = [&](int bm, int bn) { return (long long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * zdim; };
     int rc = 1;
     // measured on the step's convolutions: 128x128 only pays for the weight-gradient GEMMs (both operands staged
@@ -113,11 +121,12 @@ static int try_launch_fast(const GemmDesc& d, int zdim, hipStream_t s) {
       rc = launch_bf_tile<128, 32>(d, zdim, s, amode, bmode, aact);
     } else if (d.N > 64 && amode == AM_COL && nb(128, 128) >= 384) {
       rc = launch_bf_tile<128, 128>(d, zdim, s, amode, bmode, aact);
-    } else if (nb(128, 64) >= 384) {
+    } else if (nb(128, 64) >= 384 || amode == AM_ROW3) {
       rc = launch_bf_tile<128, 64>(d, zdim, s, amode, bmode, aact);
     }
     if (rc != 1) return rc;
   }
+  if (amode == AM_ROW3) return MVK_EINVAL;  // no exact-fp32 kernel reads pre-split operands
   if (d.N <= 32) {
     // tall-skinny: a 256-row tile lets every wave reuse its B fragment for two MFMA tiles
     if (c16 && (long long)((d.M + 255) / 256) * zdim >= 512) return launch_fast_tile<256, 32, 16>(d, zdim, s, amode, bmode, aact);
@@ -515,8 +524,9 @@ int mvk_gemm(const float* A, const float* B, float* C, int M, int N, int K, int 
 // ---------------------------------------------------------------------------------------------------------
 int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w, int Cu,
                      int Cv, int act, int u_nchw, const float* u_act_src, int u_act, const float* v_act_src,
-                     int v_act, float* colsum_acc, float* ws, int64_t ws_floats, void* stream) {
+                     int v_act, float* colsum_acc, float* ws, int64_t ws_floats, int fmt, void* stream) {
   if (!U || !Wdown || !V || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0) return MVK_EINVAL;
+  if ((fmt & ~MVK_FMT_IN_BF3) || ((fmt & MVK_FMT_IN_BF3) && (u_nchw || u_act_src))) return MVK_EINVAL;
   GemmDesc d{};
   d.a = AOperand{};
   d.a.p = U;
@@ -531,6 +541,8 @@ int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, floa
   d.a.vec4 = (!u_nchw) && (Cu % 4 == 0) && mvk_aligned16(U) && (!u_act_src || mvk_aligned16(u_act_src));
   d.a.act_src = u_act_src;
   d.a.act = u_act;
+  d.a.bf3 = (fmt & MVK_FMT_IN_BF3) ? 1 : 0;
+  d.a.plane_bytes = (long long)n * 4 * h * w * Cu * 2;
   plain_b(d.b, Wdown, Cv, 1, 16 * Cu, Cv);
   rowmajor_epi(d.e, V, Cv);
   d.e.bias = bias;
@@ -546,8 +558,9 @@ int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, floa
 
 int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U, int n, int h, int w, int Cu,
                    int Cv, int act, int u_nchw, const float* u_act_src, int u_act, float* colsum_acc, float* ws,
-                   int64_t ws_floats, void* stream) {
+                   int64_t ws_floats, int fmt, void* stream) {
   if (!V || !Wup || !U || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0 || (colsum_acc && u_nchw)) return MVK_EINVAL;
+  if (fmt & ~MVK_FMT_IN_BF3) return MVK_EINVAL;
   GemmDesc d{};
   d.a = AOperand{};
   d.a.p = V;
@@ -560,6 +573,8 @@ int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U
   d.a.OW = w;
   d.a.contig_k = 1;
   d.a.vec4 = (Cv % 4 == 0) && mvk_aligned16(V);
+  d.a.bf3 = (fmt & MVK_FMT_IN_BF3) ? 1 : 0;
+  d.a.plane_bytes = (long long)n * h * w * Cv * 2;
   plain_b(d.b, Wup, Cu, 1, 4 * Cv, Cu);
   d.b.z_stride = (long long)4 * Cv * Cu;
   d.e = Epilogue{};

@@ -30,6 +30,8 @@ struct AOperand {
   int OH, OW;       // spatial size enumerating positions
   const float* act_src;  // optional: loaded value *= act'(act_src[same offset])
   int act;
+  int bf3;               // operand is stored pre-split: 3 bf16 planes [piece][element], p -> plane 0
+  long long plane_bytes; // bytes between planes
 };
 
 struct BOperand {

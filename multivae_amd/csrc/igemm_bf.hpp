@@ -152,7 +152,7 @@ __device__ __forceinline__ void bf_write_pieces(char* base, const unsigned (&pc)
 }
 
 template <int BM, int BN, int AMODE, int BMODE, bool AACT, int DEPTH>
-__global__ __launch_bounds__(256, 2) void igemm_bf_kernel(const GemmDesc d) {
+__global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 3 : 2) void igemm_bf_kernel(const GemmDesc d) {
   using T = BfCfg<BM, BN>;
   constexpr int BKT = T::BKT;
   __shared__ __attribute__((aligned(16))) char lds_raw[T::LDS_BYTES];
@@ -165,6 +165,11 @@ __global__ __launch_bounds__(256, 2) void igemm_bf_kernel(const GemmDesc d) {
   const AOperand& A = d.a;
   const BOperand& B = d.b;
   constexpr bool A_KC = (AMODE == AM_PLAIN_K || AMODE == AM_ROW);  // memory contiguous along k
+  // Pre-split A operand (AM_ROW3): the tensor is stored as 3 bf16 planes, written once by its producer; a unit is
+  // 8 consecutive k (16 bytes) of one row per plane and goes to LDS as loaded — no VALU work in the loop.
+  constexpr bool A_PRE = (AMODE == AM_ROW3);
+  constexpr int NA8 = (BM * BKT / 8 / 256) > 0 ? (BM * BKT / 8 / 256) : 1;
+  constexpr int NRA = A_PRE ? 3 * NA8 : T::NA4;  // raw A registers (16 bytes each) per stage
   constexpr bool B_KC = (BMODE == BM_K);
 
   int ph = 0, pw = 0;
@@ -198,6 +203,11 @@ __global__ __launch_bounds__(256, 2) void igemm_bf_kernel(const GemmDesc d) {
   const __amdgpu_buffer_rsrc_t rsY =
       __builtin_amdgcn_make_buffer_rsrc((void*)(AACT ? A.act_src : A.p), 0, 0x7ffffff0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)bp, 0, 0x7ffffff0, 0x00020000);
+  const char* a_bytes = reinterpret_cast<const char*>(A.p);
+  const __amdgpu_buffer_rsrc_t rsA1 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a_bytes + (A_PRE ? A.plane_bytes : 0)), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA2 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a_bytes + (A_PRE ? 2 * A.plane_bytes : 0)), 0, 0x7ffffff0, 0x00020000);
 
   // ---- per-thread unit geometry ---------------------------------------------------------------------------
   // k-contiguous operand: unit idx = tid + 256 u -> row idx / 8, k quad (idx % 8) * 4
@@ -218,6 +228,18 @@ __global__ __launch_bounds__(256, 2) void igemm_bf_kernel(const GemmDesc d) {
     } else if (AMODE == AM_PLAIN_R) {
       const int r = m0 + a_row4 * 4;
       if (r < d.M) abase[u] = (a_kg * T::NA4 + u) * (int)A.sk + r;
+    } else if (AMODE == AM_ROW3) {
+      pb[u] = -(1 << 20);
+      if (u < NA8) {
+        const int r = m0 + idx / 4;  // unit = (row, k octet)
+        if (r < d.M) {
+          Pos ps = decode_pos(r, A.OH, A.OW);
+          const int mul = (A.kind == A_UP) ? 1 : 2;
+          pb[u] = mul * ps.i;
+          pc[u] = mul * ps.j;
+          pa[u] = (((ps.n * A.H + pb[u]) * A.W + pc[u]) * A.C + (idx % 4) * 8) * 2;  // bytes (bf16)
+        }
+      }
     } else if (AMODE == AM_ROW) {
       // hoisted gather geometry: pa = byte offset of tap (0,0) at this unit's k quad, pb / pc = mul*i, mul*j
       const int r = m0 + idx / 8;
@@ -262,18 +284,37 @@ __global__ __launch_bounds__(256, 2) void igemm_bf_kernel(const GemmDesc d) {
   // DEPTH raw (fp32) register stages: the loads run DEPTH k-tiles ahead of the MFMAs.  They are issued
   // unconditionally (past the end of K they are out-of-range = zero-fill, no traffic): a conditional load would
   // make the compiler's vmcnt bookkeeping fall back to waiting for the newest stage.
-  u32x4 ra[DEPTH][T::NA4], ya[DEPTH][NYA], rb[DEPTH][T::NB4];
+  u32x4 ra[DEPTH][NRA], ya[DEPTH][NYA], rb[DEPTH][T::NB4];
 
-  auto load_tiles = [&](int k0, u32x4 (&ra)[T::NA4], u32x4 (&ya)[NYA], u32x4 (&rb)[T::NB4]) {
+  auto load_tiles = [&](int k0, u32x4 (&ra)[NRA], u32x4 (&ya)[NYA], u32x4 (&rb)[T::NB4]) {
     auto sel = [](bool ok, int off) { return __builtin_unpredictable(ok) ? off : 0x7fffffff; };  // keep it a v_cndmask
 #ifdef MVK_EXPER
     if (d.dbg_flags & 2) {  // experiment: no global traffic
-      for (int u = 0; u < T::NA4; ++u) ra[u] = u32x4{1, 2, 3, 4};
+      for (int u = 0; u < NRA; ++u) ra[u] = u32x4{1, 2, 3, 4};
       for (int u = 0; u < T::NB4; ++u) rb[u] = u32x4{1, 2, 3, 4};
       return;
     }
+    const bool skip_a = d.dbg_flags & 64, skip_b = d.dbg_flags & 128;
+    if (skip_a) for (int u = 0; u < NRA; ++u) ra[u] = u32x4{1, 2, 3, 4};
+    if (skip_b) for (int u = 0; u < T::NB4; ++u) rb[u] = u32x4{1, 2, 3, 4};
+#elif defined(MVK_X_NOA) || defined(MVK_X_NOB)  // compile-time experiments (tools/build_variants.sh): schedule undisturbed
+#ifdef MVK_X_NOA
+    constexpr bool skip_a = true;
+    for (int u = 0; u < NRA; ++u) ra[u] = u32x4{1, 2, 3, 4};
+#else
+    constexpr bool skip_a = false;
 #endif
-    if (AMODE == AM_PLAIN_K) {
+#ifdef MVK_X_NOB
+    constexpr bool skip_b = true;
+    for (int u = 0; u < T::NB4; ++u) rb[u] = u32x4{1, 2, 3, 4};
+#else
+    constexpr bool skip_b = false;
+#endif
+#else
+    constexpr bool skip_a = false, skip_b = false;
+#endif
+    if (skip_a) {
+    } else if (AMODE == AM_PLAIN_K) {
 #pragma unroll
       for (int u = 0; u < T::NA4; ++u) {
         const int idx = tid + u * 256;
@@ -289,6 +330,27 @@ __global__ __launch_bounds__(256, 2) void igemm_bf_kernel(const GemmDesc d) {
         const int off = sel(ok, (abase[u] + k0 * (int)A.sk) * 4);
         ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
         if (AACT) ya[u] = __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0);
+      }
+    } else if (AMODE == AM_ROW3) {
+      const int tap = k0 / A.C;  // block-uniform: C % 32 == 0
+      const int c0 = k0 - tap * A.C;
+      int dh, dw;
+      if (A.kind == A_UP) {
+        dh = ph - (tap >> 1);
+        dw = pw - (tap & 1);
+      } else {
+        dh = (tap >> 2) - 1;
+        dw = (tap & 3) - 1;
+      }
+      if (k0 >= kend) dh = -(1 << 20);
+      const int delta = ((dh * A.W + dw) * A.C + c0) * 2;
+#pragma unroll
+      for (int u = 0; u < NA8; ++u) {
+        const bool ok = (unsigned)(pb[u] + dh) < (unsigned)A.H && (unsigned)(pc[u] + dw) < (unsigned)A.W;
+        const int off = sel(ok, pa[u] + delta);
+        ra[(3 * u) % NRA] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
+        ra[(3 * u + 1) % NRA] = __builtin_amdgcn_raw_buffer_load_b128(rsA1, off, 0, 0);
+        ra[(3 * u + 2) % NRA] = __builtin_amdgcn_raw_buffer_load_b128(rsA2, off, 0, 0);
       }
     } else if (AMODE == AM_ROW) {
       const int tap = k0 / A.C;  // block-uniform: C % 32 == 0
@@ -336,7 +398,8 @@ __global__ __launch_bounds__(256, 2) void igemm_bf_kernel(const GemmDesc d) {
         }
       }
     }
-    if (BMODE == BM_K) {
+    if (skip_b) {
+    } else if (BMODE == BM_K) {
 #pragma unroll
       for (int u = 0; u < T::NB4; ++u) {
         const int idx = tid + u * 256;
@@ -358,26 +421,50 @@ __global__ __launch_bounds__(256, 2) void igemm_bf_kernel(const GemmDesc d) {
 
   using SA_ = BfStage<T::NA4, A_KC>;
   using SB_ = BfStage<T::NB4, B_KC>;
-  constexpr int NPAIR = SA_::NP + SB_::NP;  // conversion work items per thread and k-tile
+  constexpr int SA_NP = A_PRE ? 0 : SA_::NP;
+  constexpr int NPAIR = SA_NP + SB_::NP;  // conversion work items per thread and k-tile
   constexpr int NSLOT = (BKT / 16) * 6;     // MFMA groups per k-tile
-  unsigned pca[3][SA_::NP], pcb[3][SB_::NP];
+  unsigned pca[3][SA_::NP], pcb[3][SB_::NP];  // pca unused for a pre-split A
   const u32x4 ynul[1] = {u32x4{0, 0, 0, 0}};
 
-  auto convert_range = [&](int lo, int hi, const u32x4 (&ra)[T::NA4], const u32x4 (&ya)[NYA], const u32x4 (&rb)[T::NB4]) {
+  auto convert_range = [&](int lo, int hi, const u32x4 (&ra)[NRA], const u32x4 (&ya)[NYA], const u32x4 (&rb)[T::NB4]) {
 #pragma unroll
     for (int j = lo; j < hi; ++j) {
-      if (j < SA_::NP) bf_convert_pair<T::NA4, A_KC, AACT>(j, ra, ya, A.act, pca);
-      else bf_convert_pair<T::NB4, B_KC, false>(j - SA_::NP, rb, ynul, 0, pcb);
+      if (j < SA_NP) {
+        if (!A_PRE) bf_convert_pair<T::NA4, A_KC, AACT>(j, reinterpret_cast<const u32x4(&)[T::NA4]>(ra), ya, A.act, pca);
+      } else {
+        bf_convert_pair<T::NB4, B_KC, false>(j - SA_NP, rb, ynul, 0, pcb);
+      }
     }
   };
-  auto write_pieces = [&]() {
-    bf_write_pieces<T::NA4, A_KC, T::GA, T::A_PIECE>(As, pca, tid, a_row4, a_kg);
+  auto write_pieces = [&](const u32x4 (&ra)[NRA]) {
+    if (A_PRE) {
+#pragma unroll
+      for (int u = 0; u < NA8; ++u) {
+        const int idx = tid + u * 256;
+        const int row = idx / 4;
+        char* dst = As + (row & 3) * T::GA + (row >> 2) * 80 + (idx % 4) * 16;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(dst + p * T::A_PIECE) = ra[(3 * u + p) % NRA];
+      }
+    } else {
+      bf_write_pieces<T::NA4, A_KC, T::GA, T::A_PIECE>(As, pca, tid, a_row4, a_kg);
+    }
     bf_write_pieces<T::NB4, B_KC, T::GB, T::B_PIECE>(Bs, pcb, tid, b_row4, b_kg);
   };
 
   // One k-tile: MFMAs over the tile in LDS, with the split of the NEXT tile's registers spread between the MFMA
   // groups (VALU work runs beside the matrix pipe), then barrier / piece write / barrier.
-  auto step = [&](const u32x4 (&ra)[T::NA4], const u32x4 (&ya)[NYA], const u32x4 (&rb)[T::NB4]) {
+#ifdef MVK_PHASES
+  unsigned long long tphase[5] = {0, 0, 0, 0, 0};
+#define MVK_T(i) { const unsigned long long now_ = __builtin_readcyclecounter(); tphase[i] += now_ - tlast; tlast = now_; }
+#else
+#define MVK_T(i)
+#endif
+  auto step = [&](const u32x4 (&ra)[NRA], const u32x4 (&ya)[NYA], const u32x4 (&rb)[T::NB4]) {
+#ifdef MVK_PHASES
+    unsigned long long tlast = __builtin_readcyclecounter();
+#endif
 #ifdef MVK_EXPER
     const bool no_mfma = d.dbg_flags & 32, no_write = d.dbg_flags & 16;
 #else
@@ -438,8 +525,11 @@ __global__ __launch_bounds__(256, 2) void igemm_bf_kernel(const GemmDesc d) {
         }
       }
     }
+    MVK_T(0)
     __syncthreads();  // every wave is done reading the tile
-    if (!no_write) write_pieces();
+    MVK_T(1)
+    if (!no_write) write_pieces(ra);
+    MVK_T(2)
 #ifdef MVK_EXPER
     if (no_write) {  // keep the loads alive
       unsigned s_ = 0;
@@ -449,13 +539,14 @@ __global__ __launch_bounds__(256, 2) void igemm_bf_kernel(const GemmDesc d) {
     }
 #endif
     __syncthreads();
+    MVK_T(3)
   };
 
   // prologue: tile 0 -> LDS, tiles 1 .. DEPTH-1 -> registers (in flight)
 #pragma unroll
   for (int i = 0; i < DEPTH; ++i) load_tiles(kbeg + i * BKT, ra[i], ya[i], rb[i]);
   convert_range(0, NPAIR, ra[0], ya[0], rb[0]);
-  write_pieces();
+  write_pieces(ra[0]);
   __syncthreads();
   int t = 0;
   for (; t + DEPTH <= ntiles; t += DEPTH) {  // full groups only: no exit inside the unrolled body (keeps the
@@ -474,6 +565,13 @@ __global__ __launch_bounds__(256, 2) void igemm_bf_kernel(const GemmDesc d) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] += acc2[r];
   }
+#ifdef MVK_PHASES
+  if (d.dbg && lane == 0) {
+    for (int i = 0; i < 4; ++i) atomicAdd(d.dbg + i, tphase[i]);
+    atomicAdd(d.dbg + 5, (unsigned long long)ntiles);
+    atomicAdd(d.dbg + 7, 1ull);
+  }
+#endif
   float* lds = reinterpret_cast<float*>(lds_raw);
   if (run_epilogue_vec<T, BM, BN, T::LDS_BYTES / 4>(d, acc, lds, tid, m0, n0, wm, wn, l31, lhi, ph, pw)) return;
   run_epilogue<T>(d, acc, lds, tid, m0, n0, wm, wn, l31, lhi, ph, pw);

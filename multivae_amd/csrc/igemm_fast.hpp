@@ -12,7 +12,7 @@
 
 namespace mvk {
 
-enum AMode { AM_PLAIN_K = 1, AM_PLAIN_R = 2, AM_ROW = 3, AM_COL = 4 };
+enum AMode { AM_PLAIN_K = 1, AM_PLAIN_R = 2, AM_ROW = 3, AM_COL = 4, AM_ROW3 = 5 };  // ROW3: AM_ROW on a pre-split (3 x bf16) tensor
 enum BMode { BM_K = 1, BM_N = 2 };
 
 template <int BM, int BN, int BKT, bool A_TRANSPOSED_WRITE = false, bool B_TRANSPOSED_WRITE = false>

@@ -304,3 +304,65 @@ int mvk_reduce_terms(const mvk_term_desc* terms, int n_terms, float loss_sum_sca
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// pre-split tensor format (three bf16 planes), see mvk.h
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+typedef __bf16 mvk_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float mvk_f32x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void f32_to_bf3_kernel(const float* __restrict__ x, long long n,
+                                                         unsigned short* __restrict__ planes) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= n) return;
+  const float a = x[i], b = (i + 1 < n) ? x[i + 1] : 0.f;
+  const mvk_bf16x2 p0 = __builtin_convertvector(mvk_f32x2{a, b}, mvk_bf16x2);
+  const unsigned u0 = __builtin_bit_cast(unsigned, p0);
+  const float ra = a - __uint_as_float(u0 << 16), rb = b - __uint_as_float(u0 & 0xffff0000u);
+  const mvk_bf16x2 p1 = __builtin_convertvector(mvk_f32x2{ra, rb}, mvk_bf16x2);
+  const unsigned u1 = __builtin_bit_cast(unsigned, p1);
+  const float sa = ra - __uint_as_float(u1 << 16), sb = rb - __uint_as_float(u1 & 0xffff0000u);
+  const mvk_bf16x2 p2 = __builtin_convertvector(mvk_f32x2{sa, sb}, mvk_bf16x2);
+  const unsigned u2 = __builtin_bit_cast(unsigned, p2);
+  const unsigned u[3] = {u0, u1, u2};
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    unsigned short* dst = planes + (long long)p * n + i;
+    dst[0] = (unsigned short)(u[p] & 0xffffu);
+    if (i + 1 < n) dst[1] = (unsigned short)(u[p] >> 16);
+  }
+}
+
+__global__ __launch_bounds__(256) void bf3_to_f32_kernel(const unsigned short* __restrict__ planes, long long n,
+                                                         float* __restrict__ x) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float a = __uint_as_float((unsigned)planes[i] << 16), b = __uint_as_float((unsigned)planes[n + i] << 16),
+              c = __uint_as_float((unsigned)planes[2 * n + i] << 16);
+  x[i] = a + (b + c);
+}
+}  // namespace
+
+extern "C" {
+
+int mvk_f32_to_bf3(const float* x, int64_t n, void* planes, void* stream) {
+  if (!x || !planes || n < 0) return MVK_EINVAL;
+  if (n == 0) return MVK_OK;
+  hipLaunchKernelGGL(f32_to_bf3_kernel, dim3((unsigned)((n / 2 + 256) / 256)), dim3(256), 0, mvk_stream(stream), x,
+                     (long long)n, static_cast<unsigned short*>(planes));
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_bf3_to_f32(const void* planes, int64_t n, float* x, void* stream) {
+  if (!x || !planes || n < 0) return MVK_EINVAL;
+  if (n == 0) return MVK_OK;
+  hipLaunchKernelGGL(bf3_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, mvk_stream(stream),
+                     static_cast<const unsigned short*>(planes), (long long)n, x);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+}  // extern "C"
+

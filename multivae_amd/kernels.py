@@ -40,6 +40,17 @@ def _zeros(shape, like):
     return torch.zeros(shape, dtype=torch.float32, device=like.device)
 
 
+FMT_IN_BF3 = 1  # mvk.h MVK_FMT_IN_BF3
+
+
+def to_bf3(x):
+    """fp32 tensor -> pre-split tensor [3, *x.shape] of bf16 (mvk_f32_to_bf3)."""
+    x = x.contiguous()
+    out = torch.empty((3,) + tuple(x.shape), dtype=torch.bfloat16, device=x.device)
+    call("mvk_f32_to_bf3", ptr(x), x.numel(), out.data_ptr(), stream_ptr())
+    return out
+
+
 _WS = {}
 WS_FLOATS = 16 * 1024 * 1024  # 64 MB of split-K slab scratch per device (largest need on the path: 8.4M floats)
 
@@ -196,23 +207,25 @@ def pack_conv(wref, want_down=True, want_up=True):
 
 
 def conv_down(U, wdown, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src=None, u_act=NONE,
-              v_act_src=None, v_act=NONE, out_bias=None):
+              v_act_src=None, v_act=NONE, out_bias=None, in_bf3=False):
     """out_bias: bias parameter whose gradient is the per-channel sum of the result (backward-data use): fused into
     the launch; returns (V, grad for autograd) then."""
-    V = _new((n, h, w, Cv), U)
-    ws = _ws(U)
+    V = torch.empty((n, h, w, Cv), dtype=torch.float32, device=U.device)
+    ws = _ws(V)
     tb, rb = _bias_target(out_bias)
     call("mvk_conv4s2_down", ptr(U), ptr(wdown), ptr(bias), ptr(V), n, h, w, Cu, Cv, act, int(u_nchw),
-         ptr(u_act_src), u_act, ptr(v_act_src), v_act, ptr(tb), ptr(ws), ws.numel(), stream_ptr())
+         ptr(u_act_src), u_act, ptr(v_act_src), v_act, ptr(tb), ptr(ws), ws.numel(), FMT_IN_BF3 if in_bf3 else 0,
+         stream_ptr())
     return V if out_bias is None else (V, rb)
 
 
-def conv_up(V, wup, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src=None, u_act=NONE, out_bias=None):
-    U = _new((n, Cu, 2 * h, 2 * w) if u_nchw else (n, 2 * h, 2 * w, Cu), V)
-    ws = _ws(V)
+def conv_up(V, wup, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src=None, u_act=NONE, out_bias=None,
+            in_bf3=False):
+    U = torch.empty((n, Cu, 2 * h, 2 * w) if u_nchw else (n, 2 * h, 2 * w, Cu), dtype=torch.float32, device=V.device)
+    ws = _ws(U)
     tb, rb = _bias_target(out_bias)
     call("mvk_conv4s2_up", ptr(V), ptr(wup), ptr(bias), ptr(U), n, h, w, Cu, Cv, act, int(u_nchw),
-         ptr(u_act_src), u_act, ptr(tb), ptr(ws), ws.numel(), stream_ptr())
+         ptr(u_act_src), u_act, ptr(tb), ptr(ws), ws.numel(), FMT_IN_BF3 if in_bf3 else 0, stream_ptr())
     return U if out_bias is None else (U, rb)
 
 

@@ -544,3 +544,25 @@ def test_split_bf16_engine_has_fp32_accuracy(K, M, N, Kd):
     r_t = (yt.double() - ref).pow(2).mean().sqrt().item()
     assert e_mvk <= 1.5 * e_t + 1e-7, (e_mvk, e_t)
     assert r_mvk <= 1.5 * r_t + 1e-9, (r_mvk, r_t)
+
+
+@pytest.mark.parametrize("n,h,w,Cu,Cv", [(96, 4, 4, 64, 128), (40, 8, 8, 32, 64)])
+def test_conv_reads_pre_split_input(K, n, h, w, Cu, Cv):
+    """MVK_FMT_IN_BF3: a convolution whose gathered input is stored pre-split (three bf16 planes, mvk_f32_to_bf3)
+    computes what the launch computes from the fp32 tensor (same arithmetic when both run on the split engine; small
+    problems take the exact-fp32 engine for fp32 inputs, hence a tolerance), and the planes reconstruct the values."""
+    torch.manual_seed(11)
+    wt = torch.randn(Cv, Cu, 4, 4, device=dev()) * 0.05
+    wd, wu = K.pack_conv(wt)
+    V = torch.relu(torch.randn(n, h, w, Cv, device=dev()))
+    U = torch.randn(n, 2 * h, 2 * w, Cu, device=dev())
+    V3, U3 = K.to_bf3(V), K.to_bf3(U)
+    assert V3.shape == (3,) + tuple(V.shape) and V3.dtype == torch.bfloat16
+    back = V3.float().sum(0)
+    assert float((back - V).abs().max()) <= 2e-7 * float(V.abs().max())
+    up_ref = K.conv_up(V, wu, None, n, h, w, Cu, Cv, 1)
+    up_pre = K.conv_up(V3, wu, None, n, h, w, Cu, Cv, 1, in_bf3=True)
+    close(up_pre, up_ref, 2e-6, "up from pre-split input")
+    dn_ref = K.conv_down(U, wd, None, n, h, w, Cu, Cv, 0, v_act_src=V, v_act=1)
+    dn_pre = K.conv_down(U3, wd, None, n, h, w, Cu, Cv, 0, v_act_src=V, v_act=1, in_bf3=True)
+    close(dn_pre, dn_ref, 2e-6, "down from pre-split input")
