@@ -243,6 +243,16 @@ int mvk_bf3_to_f32(const void* planes, int64_t n, float* x, void* stream);
  *   caller-owned scratch ws for per-workgroup partials, reduced in a fixed order). */
 int mvk_pack_conv4s2_weight(const float* Wref, int Cv, int Cu, float* Wdown, int ld_down, int col_off,
                             float* Wup, void* stream);
+/* All weight packs of one network in ONE launch.  kind 0: as mvk_pack_conv4s2_weight (Wdown and/or Wup, ld_down
+ * <= 0 means Cv); kind 1: as mvk_pack_unflatten_weight with Cv = Cin, Cu = Cout, destination in Wup. */
+#define MVK_PACK_MAX 8
+typedef struct mvk_pack_desc {
+  const float* Wref;
+  float* Wdown;
+  float* Wup;
+  int Cv, Cu, ld_down, col_off, kind;
+} mvk_pack_desc;
+int mvk_pack_weights(const mvk_pack_desc* jobs, int n, void* stream);
 int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w,
                      int Cu, int Cv, int act, int u_nchw, const float* u_act_src, int u_act,
                      const float* v_act_src, int v_act, float* colsum_acc, float* ws, int64_t ws_floats, int fmt,

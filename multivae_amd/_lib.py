@@ -29,6 +29,11 @@ class ReconDesc(C.Structure):
                 ("D", _i64), ("dist", C.c_int32), ("scale", _f), ("rescale", _f), ("coef", _f)]
 
 
+class PackDesc(C.Structure):  # mvk_pack_desc
+    _fields_ = [("Wref", _p), ("Wdown", _p), ("Wup", _p), ("Cv", C.c_int32), ("Cu", C.c_int32),
+                ("ld_down", C.c_int32), ("col_off", C.c_int32), ("kind", C.c_int32)]
+
+
 class TermDesc(C.Structure):
     _fields_ = [("v", _p), ("mask", _p), ("n", _i64), ("period", _i64), ("coef", _f), ("lossw", _f)]
 
@@ -54,6 +59,7 @@ PROTOTYPES = {
     "mvk_pack_conv4s2_weight": [_p, _i, _i, _p, _i, _i, _p, _p],
     "mvk_conv4s2_down": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i64, _i, _p],
     "mvk_conv4s2_up": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i64, _i, _p],
+    "mvk_pack_weights": [C.POINTER(PackDesc), _i, _p],
     "mvk_f32_to_bf3": [_p, _i64, _p, _p],
     "mvk_bf3_to_f32": [_p, _i64, _p, _p],
     "mvk_conv4s2_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _p],

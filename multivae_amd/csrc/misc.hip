@@ -25,6 +25,33 @@ __global__ void pack_conv4s2_kernel(const float* __restrict__ Wref, int Cv, int 
   }
 }
 
+// All weights of one network in ONE launch: blockIdx.y selects the descriptor (kind 0: 4x4/stride-2 pack as
+// above, kind 1: 1x1-spatial "unflatten" pack Wref[ci][co][tap] -> Wup[ci][tap*Cu + co] with Cv = Cin, Cu = Cout).
+struct PackJobs {
+  mvk_pack_desc j[MVK_PACK_MAX];
+};
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs jobs) {
+  const mvk_pack_desc& d = jobs.j[blockIdx.y];
+  const int total = d.Cv * d.Cu * 16;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int tap = idx & 15;
+    const int cu = (idx >> 4) % d.Cu;
+    const int cv = (idx >> 4) / d.Cu;
+    const float v = d.Wref[idx];
+    if (d.kind == 1) {
+      d.Wup[(long long)cv * 16 * d.Cu + tap * d.Cu + cu] = v;
+      continue;
+    }
+    const int kh = tap >> 2, kw = tap & 3;
+    if (d.Wdown) d.Wdown[(long long)(tap * d.Cu + cu) * d.ld_down + d.col_off + cv] = v;
+    if (d.Wup) {
+      const int ph = 1 - (kh & 1), a = kh >> 1;
+      const int pw = 1 - (kw & 1), b = kw >> 1;
+      d.Wup[((long long)(ph * 2 + pw) * 4 * d.Cv + (a * 2 + b) * d.Cv + cv) * d.Cu + cu] = v;
+    }
+  }
+}
+
 // Wref[ci][co][tap] -> Wp[ci][tap*Cout + co]
 __global__ void pack_unflatten_kernel(const float* __restrict__ Wref, int Cin, int Cout, float* __restrict__ Wp) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -206,6 +233,27 @@ int mvk_pack_conv4s2_weight(const float* Wref, int Cv, int Cu, float* Wdown, int
   int total = Cv * Cu * 16;
   hipLaunchKernelGGL(pack_conv4s2_kernel, dim3((total + 255) / 256), dim3(256), 0, mvk_stream(stream), Wref, Cv, Cu,
                      Wdown, ld_down > 0 ? ld_down : Cv, col_off, Wup);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_pack_weights(const mvk_pack_desc* jobs, int n, void* stream) {
+  if (!jobs || n <= 0 || n > MVK_PACK_MAX) return MVK_EINVAL;
+  PackJobs pj{};
+  int maxtot = 0;
+  for (int i = 0; i < n; ++i) {
+    const mvk_pack_desc& d = jobs[i];
+    if (!d.Wref || d.Cv <= 0 || d.Cu <= 0 || (d.kind != 0 && d.kind != 1) || (!d.Wdown && !d.Wup) ||
+        (d.kind == 1 && !d.Wup))
+      return MVK_EINVAL;
+    pj.j[i] = d;
+    if (pj.j[i].ld_down <= 0) pj.j[i].ld_down = d.Cv;
+    const int tot = d.Cv * d.Cu * 16;
+    if (tot > maxtot) maxtot = tot;
+  }
+  int gx = (maxtot + 255) / 256;
+  if (gx > 256) gx = 256;  // grid-stride inside
+  hipLaunchKernelGGL(pack_multi_kernel, dim3(gx, n), dim3(256), 0, mvk_stream(stream), pj);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }

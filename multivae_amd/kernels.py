@@ -15,7 +15,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import _lib
-from ._lib import ACT, DIST, FAMILY, ReconDesc, TermDesc, call, ptr, ptr_array, stream_ptr
+from ._lib import ACT, DIST, FAMILY, PackDesc, ReconDesc, TermDesc, call, ptr, ptr_array, stream_ptr
 
 RELU, SIGMOID, NONE = ACT["relu"], ACT["sigmoid"], ACT["none"]
 
@@ -206,6 +206,32 @@ def pack_conv(wref, want_down=True, want_up=True):
     return wd, wu
 
 
+def pack_weights(jobs):
+    """All weight packs of a network in ONE launch.  jobs: list of (wref, want_down, want_up) for 4x4/stride-2
+    layers ([Cv][Cu][4][4] -> (Wdown [16*Cu, Cv], Wup [4, 4*Cv, Cu])) or (wref, "unflatten") for the 1x1-spatial
+    transposed convolution ([Cin][Cout][4][4] -> [Cin, 16*Cout]).  Returns the packed tensors in job order."""
+    descs = (PackDesc * len(jobs))()
+    outs = []
+    for i, job in enumerate(jobs):
+        wref = job[0]
+        Cv, Cu = wref.shape[0], wref.shape[1]
+        d = descs[i]
+        d.Wref, d.Cv, d.Cu, d.ld_down, d.col_off = wref.data_ptr(), Cv, Cu, Cv, 0
+        if job[1] == "unflatten":
+            wp = _new((Cv, 16 * Cu), wref)
+            d.kind, d.Wdown, d.Wup = 1, None, wp.data_ptr()
+            outs.append(wp)
+        else:
+            wd = _new((16 * Cu, Cv), wref) if job[1] else None
+            wu = _new((4, 4 * Cv, Cu), wref) if job[2] else None
+            d.kind = 0
+            d.Wdown = wd.data_ptr() if wd is not None else None
+            d.Wup = wu.data_ptr() if wu is not None else None
+            outs.append((wd, wu))
+    call("mvk_pack_weights", descs, len(jobs), stream_ptr())
+    return outs
+
+
 def conv_down(U, wdown, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src=None, u_act=NONE,
               v_act_src=None, v_act=NONE, out_bias=None, in_bf3=False):
     """out_bias: bias parameter whose gradient is the per-channel sum of the result (backward-data use): fused into
@@ -335,11 +361,8 @@ class SVHNEncoderFn(Function):
         B, C0, H, W = x.shape
         chans = [C0, w0.shape[0], w1.shape[0], w2.shape[0]]
         L = wc1.shape[0]
-        wd0, _ = pack_conv(w0, True, False)
-        wd1, wu1 = pack_conv(w1)
-        wd2, wu2 = pack_conv(w2)
-        wdc1, _ = pack_conv(wc1, True, False)
-        wdc2, _ = pack_conv(wc2, True, False)
+        (wd0, _), (wd1, wu1), (wd2, wu2), (wdc1, _), (wdc2, _) = pack_weights(
+            [(w0, True, False), (w1, True, True), (w2, True, True), (wc1, True, False), (wc2, True, False)])
         h1 = conv_down(x, wd0, b0, B, H // 2, W // 2, chans[0], chans[1], RELU, u_nchw=True)
         h2 = conv_down(h1, wd1, b1, B, H // 4, W // 4, chans[1], chans[2], RELU)
         h3 = conv_down(h2, wd2, b2, B, H // 8, W // 8, chans[2], chans[3], RELU)
@@ -394,11 +417,9 @@ class SVHNDecoderFn(Function):
         z2 = _c(z.reshape(-1, L))
         n = z2.shape[0]
         C1, C2, C3, C4 = w0.shape[1], w1.shape[1], w2.shape[1], w3.shape[1]
-        wp0 = _new((L, 16 * C1), z2)
-        call("mvk_pack_unflatten_weight", ptr(w0), L, C1, ptr(wp0), stream_ptr())
-        wd1, wu1 = pack_conv(w1)  # [Cv=C1][Cu=C2]
-        wd2, wu2 = pack_conv(w2)  # [Cv=C2][Cu=C3]
-        wd3, _ = pack_conv(w3, True, False)  # [Cv=C3][Cu=C4]
+        # [L][C1] unflatten pack; [Cv=C1][Cu=C2]; [Cv=C2][Cu=C3]; [Cv=C3][Cu=C4] — one launch
+        wp0, (wd1, wu1), (wd2, wu2), (wd3, _) = pack_weights(
+            [(w0, "unflatten"), (w1, True, True), (w2, True, True), (w3, True, False)])
         g1 = gemm(z2, wp0, n, 16 * C1, L, bias=b0, bias_mod=C1, act=RELU)  # [n,4,4,C1]
         g2 = conv_up(g1, wu1, b1, n, 4, 4, C2, C1, RELU)  # [n,8,8,C2]
         g3 = conv_up(g2, wu2, b2, n, 8, 8, C3, C2, RELU)  # [n,16,16,C3]
