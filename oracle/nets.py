@@ -74,6 +74,19 @@ def build_mnist_svhn(sd, latent_dim=20):
     return enc, dec
 
 
+def joint_mlp_encoder(sd, input_dims, data, prefix="joint_encoder."):
+    """MultipleHeadJointEncoder.forward (default_architectures.py:303-322): embeddings of the copied unimodal encoders,
+    concatenated in modality order -> [Linear+ReLU]* -> fc1 / fc2 heads.  -> (mu, log_var)."""
+    embs = [mlp_encoder(sd, f"{prefix}encoders.{m}.", data[m])[0] for m in input_dims]
+    h = torch.cat(embs, dim=1)
+    i = 0
+    while f"{prefix}enc.{i}.0.weight" in sd:
+        h = F.relu(F.linear(h, sd[f"{prefix}enc.{i}.0.weight"], sd[f"{prefix}enc.{i}.0.bias"]))
+        i += 1
+    return (F.linear(h, sd[prefix + "fc1.weight"], sd[prefix + "fc1.bias"]),
+            F.linear(h, sd[prefix + "fc2.weight"], sd[prefix + "fc2.bias"]))
+
+
 def build_default_mlp(sd, input_dims):
     """Default architectures (BaseDictEncoders / BaseDictDecoders, default_architectures.py:143-222)."""
     enc = {m: (lambda x, m=m: mlp_encoder(sd, f"encoders.{m}.", x)) for m in input_dims}

@@ -327,6 +327,56 @@ def mvtcae_case(name, *, arch, B, alpha, beta, rescaling, masked, seed):
                     masked=masked, seed=seed, names=names), arrays)
 
 
+def jmvae_case(name, *, arch, B, alpha, beta, warmup, epoch, rescaling, seed, dists=None):
+    """JMVAE with all-default architectures (MLP encoders / decoders, MultipleHeadJointEncoder), complete data."""
+    print(name)
+    if arch == "tiny":
+        dims, L = TINY_DIMS, TINY_L
+        data, _ = tiny_data(B, seed, False)
+    else:
+        dims, L = dict(mnist=(1, 28, 28), svhn=(3, 32, 32)), 20
+        data = mnist_svhn_data(B, seed)
+    for m, d in (dists or {}).items():
+        if d == "bernoulli":
+            data[m] = (data[m] > 0.5).astype(np.float32)
+    shapes = P.jmvae_mlp_shapes(dims, L)
+    cfg = JMVAEConfig(n_modalities=len(dims), latent_dim=L, input_dims=dict(dims), alpha=alpha, beta=beta,
+                      warmup=warmup, uses_likelihood_rescaling=rescaling,
+                      decoders_dist=dists if dists else None)
+    model = JMVAE(cfg)
+    sd_np = P.make_state_dict(shapes, seed)
+    load_weights(model, sd_np)
+    names = list(model.encoders.keys())
+    inputs = ref_dataset(data, None)
+    model.train()
+    torch.manual_seed(seed)
+    eps = torch.randn(B, L)  # Normal(mu, sigma).rsample() draws one standard normal of mu's shape
+    torch.manual_seed(seed)
+    out = model(inputs, epoch=epoch)
+    model.zero_grad()
+    out.loss.backward()
+    gref = ref_grads(model)
+    osd = oracle_sd(sd_np)
+    enc_f, dec_f = nets.build_default_mlp(osd, dims)
+    tdata = {m: t(v) for m, v in data.items()}
+    e = {m: enc_f[m](tdata[m]) for m in names}
+    joint = nets.joint_mlp_encoder(osd, dims, tdata)
+    o = elbo.jmvae_forward(joint, e, tdata, dec_f, eps, names=names, alpha=alpha, beta=beta, warmup=warmup, epoch=epoch,
+                           rescale=elbo.rescale_factors(dims, rescaling), dists=dists)
+    o["loss"].backward()
+    report("loss", out.loss, o["loss"])
+    for k in out.metrics:
+        report(k, torch.as_tensor(out.metrics[k]), torch.as_tensor(o["metrics"][k]))
+    cmp_grads("grads", gref, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in osd.items()})
+    arrays = dict(eps=eps, loss=out.loss.detach(), loss_sum=out.loss_sum.detach(), z=o["z"].detach(),
+                  joint_mu=joint[0].detach(), joint_logvar=joint[1].detach())
+    for k, v in out.metrics.items():
+        arrays["metric/" + k] = torch.as_tensor(v).detach()
+    arrays.update(grad_stats(gref))
+    save(name, dict(model="JMVAE", arch=arch, B=B, L=L, alpha=alpha, beta=beta, warmup=warmup, epoch=epoch,
+                    rescaling=rescaling, masked=False, seed=seed, names=names, dists=dists), arrays)
+
+
 def mmvae_case(name, *, arch, B, K, family, loss, rescaling, masked, seed, learn_prior=True):
     print(name)
     if arch == "tiny":
@@ -419,5 +469,17 @@ def main():
                loss="iwae_looser", rescaling=False, masked=False, seed=306)
 
 
+def jmvae_main():
+    jmvae_case("jmvae_tiny_warmup", arch="tiny", B=6, alpha=0.1, beta=1.0, warmup=10, epoch=3, rescaling=False, seed=401)
+    jmvae_case("jmvae_tiny_beta_rescale", arch="tiny", B=7, alpha=0.3, beta=2.0, warmup=5, epoch=8, rescaling=True,
+               seed=402, dists=dict(mod1="normal", mod2="laplace", mod3="bernoulli", mod4="normal"))
+    jmvae_case("jmvae_mnistsvhn_mlp", arch="mnistsvhn", B=8, alpha=0.1, beta=1.0, warmup=10, epoch=20, rescaling=False,
+               seed=403)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "jmvae":  # only the JMVAE cases (the others are unchanged)
+        jmvae_main()
+    else:
+        main()
+        jmvae_main()

@@ -100,6 +100,30 @@ def default_mlp_shapes(input_dims, latent_dim):
     return s
 
 
+def joint_mlp_encoder_shapes(input_dims, latent_dim, hidden_dim=512, n_hidden_layers=2):
+    """MultipleHeadJointEncoder built from default MLP encoders (default_architectures.py:261-322): copies of the
+    unimodal encoders, the unifying MLP and its two heads, in state_dict order."""
+    s = OrderedDict()
+    for m, d in input_dims.items():
+        s.update(mlp_encoder_shapes(f"joint_encoder.encoders.{m}.", int(np.prod(d)), latent_dim))
+    s["joint_encoder.enc.0.0.weight"] = (hidden_dim, latent_dim * len(input_dims))
+    s["joint_encoder.enc.0.0.bias"] = (hidden_dim,)
+    for i in range(1, n_hidden_layers):
+        s[f"joint_encoder.enc.{i}.0.weight"] = (hidden_dim, hidden_dim)
+        s[f"joint_encoder.enc.{i}.0.bias"] = (hidden_dim,)
+    for h in ("fc1", "fc2"):
+        s[f"joint_encoder.{h}.weight"] = (latent_dim, hidden_dim)
+        s[f"joint_encoder.{h}.bias"] = (latent_dim,)
+    return s
+
+
+def jmvae_mlp_shapes(input_dims, latent_dim):
+    """JMVAE with all-default architectures: decoders, encoders, joint encoder (BaseJointModel registration order)."""
+    s = default_mlp_shapes(input_dims, latent_dim)
+    s.update(joint_mlp_encoder_shapes(input_dims, latent_dim))
+    return s
+
+
 def make_state_dict(shapes, seed, gain=1.0):
     """name -> float32 ndarray, U(-b, b) with b = gain/sqrt(prod(shape[1:])) (bias: b of its weight)."""
     sd = OrderedDict()

@@ -42,7 +42,7 @@ def test_unit_base_utils():
 
 
 def _oracle_nets(cfg, dims, sd):
-    if cfg["arch"] == "tiny" or cfg["model"] == "MVTCAE":
+    if cfg["arch"] == "tiny" or cfg["model"] in ("MVTCAE", "JMVAE"):
         return nets.build_default_mlp(sd, dims)
     return nets.build_mnist_svhn(sd, cfg["L"])
 
@@ -98,6 +98,28 @@ def test_mvtcae(name):
         close(a[k], o[k])
     for k, v in o["metrics"].items():
         close(a["metric/" + k], v)
+    o["loss"].backward()
+    G.check_grads(a, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()},
+                  rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", G.JMVAE_CASES)
+def test_jmvae(name):
+    """JMVAE.forward (jmvae_model.py:116-192) with the default MultipleHeadJointEncoder, annealing on and off."""
+    cfg, a, dims, data, masks, sd, enc_f, dec_f = _prep(name)
+    names = cfg["names"]
+    e = {m: enc_f[m](data[m]) for m in names}
+    joint = nets.joint_mlp_encoder(sd, dims, data)
+    close(a["joint_mu"], joint[0])
+    close(a["joint_logvar"], joint[1])
+    o = elbo.jmvae_forward(joint, e, data, dec_f, G.t(a["eps"]), names=names, alpha=cfg["alpha"], beta=cfg["beta"],
+                           warmup=cfg["warmup"], epoch=cfg["epoch"],
+                           rescale=elbo.rescale_factors(dims, cfg["rescaling"]), dists=cfg.get("dists"))
+    close(a["loss"], o["loss"])
+    close(a["loss_sum"], o["loss_sum"])
+    close(a["z"], o["z"])
+    for k, v in o["metrics"].items():
+        close(a["metric/" + k], torch.as_tensor(v))
     o["loss"].backward()
     G.check_grads(a, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()},
                   rtol=1e-5)
