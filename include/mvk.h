@@ -91,6 +91,19 @@ int mvk_mvtcae_posterior_bwd(const float* const* mu, const float* const* lv, con
                              const float* gjoint_rows, const float* gcond_rows, float* const* dmu,
                              float* const* dlv, void* stream);
 
+/* JMVAE (models/jmvae/jmvae_model.py:133-174): reparameterised sample(s) of the joint encoder's posterior
+ * z[k] = joint_mu + exp(joint_lv/2) * eps[k], kld_rows[b] = KL(q(z|X) || N(0,I)) summed over L, and
+ * ljm_rows[b] = sum_m KL(q(z|X) || q(z|x_m)) with (mu[m], lv[m]) the unimodal encoders' outputs.
+ * bwd: gradients w.r.t. the joint and the unimodal parameters given dz [K,B,L] (may be NULL) and the per-row
+ * gradients of the two KL terms (may be NULL = 0). */
+int mvk_jmvae_posterior_fwd(const float* joint_mu, const float* joint_lv, const float* const* mu,
+                            const float* const* lv, int M, const float* eps, int K, int B, int L, float* z,
+                            float* kld_rows, float* ljm_rows, void* stream);
+int mvk_jmvae_posterior_bwd(const float* joint_mu, const float* joint_lv, const float* const* mu,
+                            const float* const* lv, int M, const float* eps, const float* dz, int K, int B, int L,
+                            const float* gkld_rows, const float* gljm_rows, float* djoint_mu, float* djoint_lv,
+                            float* const* dmu, float* const* dlv, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused reconstruction NLL over the K-sample axis
  * ------------------------------------------------------------------------------------------------ */

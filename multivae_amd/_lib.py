@@ -45,6 +45,8 @@ PROTOTYPES = {
     "mvk_mopoe_posterior_bwd": [_p, _p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p],
     "mvk_mvtcae_posterior_fwd": [_p, _p, _p, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     "mvk_mvtcae_posterior_bwd": [_p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p],
+    "mvk_jmvae_posterior_fwd": [_p, _p, _p, _p, _i, _p, _i, _i, _i, _p, _p, _p, _p],
+    "mvk_jmvae_posterior_bwd": [_p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "mvk_recon_nll_fwd": [C.POINTER(ReconDesc), _i, _i, _i, _p],
     "mvk_recon_nll_bwd": [C.POINTER(ReconDesc), _i, _i, _i, _p],
     "mvk_reduce_terms": [C.POINTER(TermDesc), _i, _f, _p, _p, _p],

@@ -497,6 +497,90 @@ static int launch_recon(const mvk_recon_desc* descs, int n_mod, int K, int B, bo
   return MVK_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// JMVAE posterior (jmvae_model.py:133-174): z = mu + exp(lv/2) eps of the JOINT encoder, KL(q(z|X) || N(0,I)) rows
+// and the rows of LJM = sum_m KL(q(z|X) || q(z|x_m)) = sum_m 1/2 (lv_m - lv + (e^lv + (mu - mu_m)^2) / e^lv_m - 1).
+// pt.mu / pt.lv hold the unimodal encoders' outputs.  One wave per batch row.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void jmvae_posterior_fwd_kernel(const float* __restrict__ jmu,
+                                                                  const float* __restrict__ jlv, const PtrTable pt,
+                                                                  int M, const float* __restrict__ eps, int K, int B,
+                                                                  int L, float* __restrict__ z,
+                                                                  float* __restrict__ kld_rows,
+                                                                  float* __restrict__ ljm_rows) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float kld = 0.f, ljm = 0.f;
+  for (int l = lane; l < L; l += 64) {
+    const long long o = (long long)b * L + l;
+    const float mu = jmu[o], lv = jlv[o];
+    const float ev = expf(lv);
+    kld += -0.5f * (1.0f + lv - mu * mu - ev);
+    float acc = 0.f;  // summed over the modalities per element first, like the reference (:160-172)
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      if (m < M) {
+        const float um = pt.mu[m][o], ul = pt.lv[m][o];
+        const float d = mu - um;
+        acc += 0.5f * (ul - lv + (ev + d * d) / expf(ul) - 1.0f);
+      }
+    }
+    ljm += acc;
+    const float sd = expf(0.5f * lv);
+    for (int k = 0; k < K; ++k) {
+      const long long zo = ((long long)k * B + b) * L + l;
+      z[zo] = mu + sd * eps[zo];
+    }
+  }
+  kld = wave_sum(kld);
+  ljm = wave_sum(ljm);
+  if (lane == 0) {
+    kld_rows[b] = kld;
+    ljm_rows[b] = ljm;
+  }
+}
+
+__global__ __launch_bounds__(256) void jmvae_posterior_bwd_kernel(const float* __restrict__ jmu,
+                                                                  const float* __restrict__ jlv, const PtrTable pt,
+                                                                  const OutPtrTable ot, int M,
+                                                                  const float* __restrict__ eps,
+                                                                  const float* __restrict__ dz, int K, int B, int L,
+                                                                  const float* __restrict__ gkld_rows,
+                                                                  const float* __restrict__ gljm_rows,
+                                                                  float* __restrict__ djmu, float* __restrict__ djlv) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * L) return;
+  const int b = (int)(i / L);
+  const float mu = jmu[i], lv = jlv[i];
+  const float ev = expf(lv), sd = expf(0.5f * lv);
+  const float gk = gkld_rows ? gkld_rows[b] : 0.f, gj = gljm_rows ? gljm_rows[b] : 0.f;
+  float gmu = gk * mu, glv = gk * (-0.5f) * (1.0f - ev);
+  if (dz) {
+    for (int k = 0; k < K; ++k) {
+      const long long zo = (long long)k * B * L + i;
+      const float g = dz[zo];
+      gmu += g;
+      glv += g * 0.5f * sd * eps[zo];
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MAXM; ++m) {
+    if (m < M) {
+      const float um = pt.mu[m][i], ul = pt.lv[m][i];
+      const float iv = 1.0f / expf(ul);
+      const float d = mu - um;
+      gmu += gj * d * iv;
+      glv += gj * 0.5f * (ev * iv - 1.0f);
+      ot.dmu[m][i] = -gj * d * iv;
+      ot.dlv[m][i] = gj * 0.5f * (1.0f - (ev + d * d) * iv);
+    }
+  }
+  djmu[i] = gmu;
+  djlv[i] = glv;
+}
+
 }  // namespace
 
 extern "C" {
@@ -580,6 +664,49 @@ int mvk_mvtcae_posterior_bwd(const float* const* mu, const float* const* lv, con
   }
   hipLaunchKernelGGL(mvtcae_posterior_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, mvk_stream(stream), pt, ot, M, eps,
                      dz, K, B, L, gjoint_rows, gcond_rows);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_jmvae_posterior_fwd(const float* joint_mu, const float* joint_lv, const float* const* mu, const float* const* lv,
+                            int M, const float* eps, int K, int B, int L, float* z, float* kld_rows, float* ljm_rows,
+                            void* stream) {
+  if (!joint_mu || !joint_lv || !mu || !lv || M < 1 || M > MAXM || !eps || !z || !kld_rows || !ljm_rows || K < 1 ||
+      L < 1)
+    return MVK_EINVAL;
+  if (B <= 0) return B == 0 ? MVK_OK : MVK_EINVAL;
+  PtrTable pt{};
+  for (int m = 0; m < M; ++m) {
+    if (!mu[m] || !lv[m]) return MVK_EINVAL;
+    pt.mu[m] = mu[m];
+    pt.lv[m] = lv[m];
+  }
+  hipLaunchKernelGGL(jmvae_posterior_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, mvk_stream(stream), joint_mu,
+                     joint_lv, pt, M, eps, K, B, L, z, kld_rows, ljm_rows);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_jmvae_posterior_bwd(const float* joint_mu, const float* joint_lv, const float* const* mu, const float* const* lv,
+                            int M, const float* eps, const float* dz, int K, int B, int L, const float* gkld_rows,
+                            const float* gljm_rows, float* djoint_mu, float* djoint_lv, float* const* dmu,
+                            float* const* dlv, void* stream) {
+  if (!joint_mu || !joint_lv || !mu || !lv || M < 1 || M > MAXM || !eps || !djoint_mu || !djoint_lv || !dmu || !dlv ||
+      K < 1 || L < 1)
+    return MVK_EINVAL;
+  if (B <= 0) return B == 0 ? MVK_OK : MVK_EINVAL;
+  PtrTable pt{};
+  OutPtrTable ot{};
+  for (int m = 0; m < M; ++m) {
+    if (!mu[m] || !lv[m] || !dmu[m] || !dlv[m]) return MVK_EINVAL;
+    pt.mu[m] = mu[m];
+    pt.lv[m] = lv[m];
+    ot.dmu[m] = dmu[m];
+    ot.dlv[m] = dlv[m];
+  }
+  const long long n = (long long)B * L;
+  hipLaunchKernelGGL(jmvae_posterior_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, mvk_stream(stream),
+                     joint_mu, joint_lv, pt, ot, M, eps, dz, K, B, L, gkld_rows, gljm_rows, djoint_mu, djoint_lv);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }

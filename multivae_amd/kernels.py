@@ -566,6 +566,43 @@ class MVTCAEPosteriorFn(Function):
         return (None, None, *dmus, *dlvs)
 
 
+class JMVAEPosteriorFn(Function):
+    """joint (mu, lv), unimodal (mu_m, lv_m)_m -> z[K,B,L], kld_rows[B], ljm_rows[B]  (jmvae_model.py:133-174)."""
+
+    @staticmethod
+    def forward(ctx, eps, jmu, jlv, *mus_lvs):
+        M = len(mus_lvs) // 2
+        jmu, jlv = _c(jmu), _c(jlv)
+        mus = [_c(t) for t in mus_lvs[:M]]
+        lvs = [_c(t) for t in mus_lvs[M:]]
+        K, B, L = eps.shape
+        z = _new((K, B, L), eps)
+        kld, ljm = _new((B,), eps), _new((B,), eps)
+        call("mvk_jmvae_posterior_fwd", ptr(jmu), ptr(jlv), ptr_array(mus), ptr_array(lvs), M, ptr(eps), K, B, L,
+             ptr(z), ptr(kld), ptr(ljm), stream_ptr())
+        ctx.save_for_backward(eps, jmu, jlv, *mus, *lvs)
+        ctx.M = M
+        return z, kld, ljm
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz, dkld, dljm):
+        saved = ctx.saved_tensors
+        eps, jmu, jlv = saved[:3]
+        M = ctx.M
+        mus, lvs = saved[3 : 3 + M], saved[3 + M :]
+        K, B, L = eps.shape
+        dz = _c(dz) if dz is not None else None
+        gk = _c(dkld) if dkld is not None else None
+        gj = _c(dljm) if dljm is not None else None
+        djmu, djlv = _new((B, L), eps), _new((B, L), eps)
+        dmus = [_new((B, L), eps) for _ in range(M)]
+        dlvs = [_new((B, L), eps) for _ in range(M)]
+        call("mvk_jmvae_posterior_bwd", ptr(jmu), ptr(jlv), ptr_array(mus), ptr_array(lvs), M, ptr(eps), ptr(dz), K, B,
+             L, ptr(gk), ptr(gj), ptr(djmu), ptr(djlv), ptr_array(dmus), ptr_array(dlvs), stream_ptr())
+        return (None, djmu, djlv, *dmus, *dlvs)
+
+
 # =====================================================================================================
 # Fused reconstruction NLL + scalar assembly (single autograd node producing the loss)
 # =====================================================================================================

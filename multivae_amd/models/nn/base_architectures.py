@@ -18,3 +18,15 @@ class BaseDecoder(nn.Module):
 
     def forward(self, z):
         raise NotImplementedError()
+
+
+class BaseJointEncoder(nn.Module):
+    """Joint encoder plugin base (`multivae/models/nn/base_architectures.py`): forward(x: dict of modality tensors)
+    returns a ModelOutput with `embedding` and `log_covariance`."""
+
+    def __init__(self):
+        nn.Module.__init__(self)
+        self.latent_dim = None
+
+    def forward(self, x: dict):
+        raise NotImplementedError()

@@ -14,7 +14,7 @@ from torch import nn
 from ... import kernels
 from ..base.base_config import BaseAEConfig
 from ..base.base_utils import ModelOutput
-from .base_architectures import BaseDecoder, BaseEncoder
+from .base_architectures import BaseDecoder, BaseEncoder, BaseJointEncoder
 
 
 class Encoder_VAE_MLP(BaseEncoder):
@@ -58,6 +58,42 @@ class Decoder_AE_MLP(BaseDecoder):
         l0, l1 = self.layers[0][0], self.layers[1][0]
         out = kernels.MLPDecoderFn.apply(z, l0.weight, l0.bias, l1.weight, l1.bias, self.input_dim)
         return ModelOutput(reconstruction=out)
+
+
+class MultipleHeadJointEncoder(BaseJointEncoder):
+    """`default_architectures.py:261-322`: deep copies of the unimodal encoders, their embeddings concatenated in
+    modality order, a unifying MLP ([Linear+ReLU] x n_hidden_layers) and two linear heads.  The MLP and the heads run
+    as ONE autograd node on the GEMM engine (kernels.MLPEncoderFn); the concatenation is a device copy."""
+
+    def __init__(self, dict_encoders: dict, args, hidden_dim=512, n_hidden_layers=2, **kwargs):
+        BaseJointEncoder.__init__(self)
+        from copy import deepcopy
+
+        self.encoders = nn.ModuleDict()
+        self.joint_input_dim = 0
+        for modality in dict_encoders:
+            self.encoders[modality] = deepcopy(dict_encoders[modality])
+            self.joint_input_dim += self.encoders[modality].latent_dim
+        modules = [nn.Sequential(nn.Linear(self.joint_input_dim, hidden_dim), nn.ReLU(True))]
+        for _ in range(n_hidden_layers - 1):
+            modules.append(nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nn.ReLU(True)))
+        self.enc = nn.Sequential(*modules)
+        self.fc1 = nn.Linear(hidden_dim, args.latent_dim)
+        self.fc2 = nn.Linear(hidden_dim, args.latent_dim)
+        self.latent_dim = args.latent_dim
+
+    def forward(self, x: dict):
+        assert list(x.keys()) == list(self.encoders.keys())
+        names = list(self.encoders.keys())
+        dev = x[names[0]].device
+        outs = kernels.run_branches(names, lambda m: self.encoders[m](x[m])["embedding"], dev)
+        h = torch.cat([outs[m] for m in names], dim=1)
+        params = []
+        for seq in self.enc:
+            params += [seq[0].weight, seq[0].bias]
+        params += [self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias]
+        mu, lv = kernels.MLPEncoderFn.apply(h, *params)
+        return ModelOutput(embedding=mu, log_covariance=lv)
 
 
 def BaseDictEncoders(input_dims: dict, latent_dim: int):

@@ -24,7 +24,8 @@ def check(a, b, what, rtol=RTOL):
 
 
 def build_model(cfg, dims):
-    from multivae_amd.models import MMVAE, MVTCAE, MMVAEConfig, MoPoE, MoPoEConfig, MVTCAEConfig
+    from multivae_amd.models import (JMVAE, MMVAE, MVTCAE, JMVAEConfig, MMVAEConfig, MoPoE, MoPoEConfig,
+                                     MVTCAEConfig)
     from multivae_amd.models.base.base_config import BaseAEConfig
     from multivae_amd.models.nn.default_architectures import Decoder_AE_MLP, Encoder_VAE_MLP
     from multivae_amd.models.nn.svhn import Decoder_VAE_SVHN, Encoder_VAE_SVHN
@@ -33,7 +34,7 @@ def build_model(cfg, dims):
     common = dict(n_modalities=len(dims), latent_dim=L, input_dims=dict(dims),
                   uses_likelihood_rescaling=cfg["rescaling"])
     enc = dec = None
-    if cfg["arch"] != "tiny" and cfg["model"] != "MVTCAE":
+    if cfg["arch"] != "tiny" and cfg["model"] not in ("MVTCAE", "JMVAE"):
         enc = dict(mnist=Encoder_VAE_MLP(BaseAEConfig(latent_dim=L, input_dim=(1, 28, 28))),
                    svhn=Encoder_VAE_SVHN(BaseAEConfig(latent_dim=L, input_dim=(3, 32, 32))))
         dec = dict(mnist=Decoder_AE_MLP(BaseAEConfig(latent_dim=L, input_dim=(1, 28, 28))),
@@ -43,6 +44,9 @@ def build_model(cfg, dims):
         return MoPoE(mc, enc, dec)
     if cfg["model"] == "MVTCAE":
         return MVTCAE(MVTCAEConfig(alpha=cfg["alpha"], beta=cfg["beta"], **common))
+    if cfg["model"] == "JMVAE":
+        return JMVAE(JMVAEConfig(alpha=cfg["alpha"], beta=cfg["beta"], warmup=cfg["warmup"],
+                                 decoders_dist=cfg.get("dists"), **common))
     mc = MMVAEConfig(K=cfg["K"], prior_and_posterior_dist=cfg["family"], loss=cfg["loss"],
                      learn_prior=cfg["learn_prior"], **common)
     return MMVAE(mc, enc, dec)
@@ -74,7 +78,7 @@ def oracle_full_grads(cfg, dims, data, masks, sd_np, a):
     tdata = {m: G.t(v) for m, v in data.items()}
     tmasks = None if masks is None else {m: G.t(v) for m, v in masks.items()}
     names = cfg["names"]
-    if cfg["arch"] == "tiny" or cfg["model"] == "MVTCAE":
+    if cfg["arch"] == "tiny" or cfg["model"] in ("MVTCAE", "JMVAE"):
         enc_f, dec_f = nets.build_default_mlp(sd, dims)
     else:
         enc_f, dec_f = nets.build_mnist_svhn(sd, cfg["L"])
@@ -84,6 +88,11 @@ def oracle_full_grads(cfg, dims, data, masks, sd_np, a):
         e = {m: enc_f[m](tdata[m]) for m in names}
         o = elbo.mopoe_forward(e, tdata, dec_f, G.t(a["eps"]), names=names, beta=cfg["beta"], rescale=resc,
                                dists=cfg["dists"], masks=tmasks, choice=G.t(a["choice"]) if "choice" in a else None)
+    elif cfg["model"] == "JMVAE":
+        e = {m: enc_f[m](tdata[m]) for m in names}
+        o = elbo.jmvae_forward(nets.joint_mlp_encoder(sd, dims, tdata), e, tdata, dec_f, G.t(a["eps"]), names=names,
+                               alpha=cfg["alpha"], beta=cfg["beta"], warmup=cfg["warmup"], epoch=cfg["epoch"],
+                               rescale=resc, dists=cfg.get("dists"))
     elif cfg["model"] == "MVTCAE":
         e = {m: enc_f[m](tdata[m]) for m in names}
         o = elbo.mvtcae_forward(e, tdata, dec_f, G.t(a["eps"]), names=names, alpha=cfg["alpha"], beta=cfg["beta"],
@@ -154,6 +163,27 @@ def test_mvtcae_golden(name):
         pass
 
 
+@pytest.mark.parametrize("name", G.JMVAE_CASES)
+def test_jmvae_golden(name):
+    """JMVAE.forward (jmvae_model.py:116-192): default joint encoder, annealing on / off, mixed decoder distributions."""
+    cfg, a, dims, data, masks, sd_np, model, inputs, d = prep(name)
+    out = model(inputs, noise=G.t(a["eps"]).to(d), epoch=cfg["epoch"])
+    check(a["loss"], out.loss, "loss")
+    check(a["loss_sum"], out.loss_sum, "loss_sum")
+    for k, v in out.metrics.items():
+        check(a["metric/" + k], torch.as_tensor(v), k)
+    out.loss.backward()
+    o, og = oracle_full_grads(cfg, dims, data, masks, sd_np, a)
+    check(o["loss"].detach().numpy(), out.loss, "loss vs oracle")
+    compare_grads(model, og, a)
+    # masks are rejected like in the reference (joint_model.py:69-73)
+    from multivae_amd.data.datasets.base import DatasetOutput
+
+    bad = DatasetOutput(data=inputs.data, masks={m: torch.ones(cfg["B"], dtype=torch.bool, device=d) for m in dims})
+    with pytest.raises(AttributeError):
+        model(bad)
+
+
 @pytest.mark.parametrize("name", G.MMVAE_CASES)
 def test_mmvae_golden(name):
     cfg, a, dims, data, masks, sd_np, model, inputs, d = prep(name)
@@ -192,3 +222,28 @@ def test_missing_modality_gives_exactly_zero_encoder_grads():
         for p in model.encoders["mod2"].parameters():
             assert p.grad is None or float(p.grad.abs().max()) == 0.0
         assert any(float(p.grad.abs().max()) > 0 for p in model.encoders["mod1"].parameters())
+
+
+def test_jmvae_encode_paths():
+    """JMVAE.encode (jmvae_model.py:58-114): joint encoder for all modalities, product of the unimodal experts
+    (stable_poe) for a strict subset, the unimodal encoder for one modality; N samples, return_mean, flatten."""
+    from multivae_amd.data.datasets.base import DatasetOutput
+    from multivae_amd.models import JMVAE, JMVAEConfig
+
+    d = torch.device("cuda:0")
+    dims = dict(a=(2, 3), b=(7,), c=(4,))
+    torch.manual_seed(0)
+    model = JMVAE(JMVAEConfig(n_modalities=3, latent_dim=6, input_dims=dims)).to(d)
+    inputs = DatasetOutput(data={m: torch.rand((5,) + s, device=d) for m, s in dims.items()})
+    assert model.encode(inputs).z.shape == (5, 6)
+    assert model.encode(inputs, cond_mod=["a", "c"], N=4).z.shape == (4, 5, 6)
+    assert model.encode(inputs, cond_mod="b", N=3, flatten=True).z.shape == (15, 6)
+    joint = model.joint_encoder(inputs.data)
+    assert torch.equal(model.encode(inputs, return_mean=True).z, joint.embedding)
+    # subset posterior = stable_poe of the unimodal posteriors
+    ea, ec = model.encoders["a"](inputs.data["a"]), model.encoders["c"](inputs.data["c"])
+    mu, lv = elbo.stable_poe(torch.stack([ea.embedding, ec.embedding]).detach().cpu(),
+                             torch.stack([ea.log_covariance, ec.log_covariance]).detach().cpu())
+    check(mu.numpy(), model.encode(inputs, cond_mod=["a", "c"], return_mean=True).z, "subset mean")
+    with pytest.raises(AttributeError):
+        model.encode(inputs, cond_mod="zzz")

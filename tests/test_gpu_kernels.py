@@ -566,3 +566,33 @@ def test_conv_reads_pre_split_input(K, n, h, w, Cu, Cv):
     dn_ref = K.conv_down(U, wd, None, n, h, w, Cu, Cv, 0, v_act_src=V, v_act=1)
     dn_pre = K.conv_down(U3, wd, None, n, h, w, Cu, Cv, 0, v_act_src=V, v_act=1, in_bf3=True)
     close(dn_pre, dn_ref, 2e-6, "down from pre-split input")
+
+
+@pytest.mark.parametrize("M,B,L,Kk", [(2, 9, 20, 1), (3, 5, 70, 4)])
+def test_jmvae_posterior(K, M, B, L, Kk):
+    """mvk_jmvae_posterior_fwd/bwd vs the formulas of jmvae_model.py:133-174 in torch (L > 64 and K > 1 included)."""
+    gen = g(21)
+    jmu = torch.randn(B, L, generator=gen).requires_grad_(True)
+    jlv = (0.3 * torch.randn(B, L, generator=gen)).requires_grad_(True)
+    mus = [torch.randn(B, L, generator=gen).requires_grad_(True) for _ in range(M)]
+    lvs = [(0.3 * torch.randn(B, L, generator=gen)).requires_grad_(True) for _ in range(M)]
+    eps = torch.randn(Kk, B, L, generator=gen)
+    z_ref = jmu + torch.exp(0.5 * jlv) * eps
+    kld_ref = (-0.5 * (1 + jlv - jmu.pow(2) - jlv.exp())).sum(-1)
+    ljm_ref = sum(0.5 * (lvs[m] - jlv + (jlv.exp() + (jmu - mus[m]) ** 2) / lvs[m].exp() - 1) for m in range(M)).sum(-1)
+    wz, wk, wj = torch.randn(Kk, B, L, generator=gen), torch.randn(B, generator=gen), torch.randn(B, generator=gen)
+    ((z_ref * wz).sum() + (kld_ref * wk).sum() + (ljm_ref * wj).sum()).backward()
+    d = dev()
+    leaf = lambda t: t.detach().to(d).requires_grad_(True)
+    djmu, djlv = leaf(jmu), leaf(jlv)
+    dmus, dlvs = [leaf(t) for t in mus], [leaf(t) for t in lvs]
+    z, kld, ljm = K.JMVAEPosteriorFn.apply(eps.to(d), djmu, djlv, *dmus, *dlvs)
+    close(z, z_ref, what="z")
+    close(kld, kld_ref, what="kld rows")
+    close(ljm, ljm_ref, what="ljm rows")
+    ((z * wz.to(d)).sum() + (kld * wk.to(d)).sum() + (ljm * wj.to(d)).sum()).backward()
+    close(djmu.grad, jmu.grad, what="d joint mu")
+    close(djlv.grad, jlv.grad, what="d joint lv")
+    for m in range(M):
+        close(dmus[m].grad, mus[m].grad, what=f"d mu[{m}]")
+        close(dlvs[m].grad, lvs[m].grad, what=f"d lv[{m}]")
