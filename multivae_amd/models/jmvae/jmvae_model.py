@@ -21,6 +21,10 @@ class JMVAE(BaseJointModel):
         self.start_keep_best_epoch = model_config.warmup + 1
         self.beta = model_config.beta
 
+    def graph_key(self, epoch=1, **kwargs):
+        """What a captured training graph of this model depends on besides the batch shape: the annealing factor."""
+        return min(int(epoch), int(self.warmup))
+
     def forward(self, inputs, **kwargs) -> ModelOutput:
         """kwargs: epoch (annealing factor = min(1, epoch / warmup)), noise [B,L] (explicit eps of the joint sample)."""
         super().forward(inputs)

@@ -252,11 +252,12 @@ class BaseTrainer:
         self._best_model = deepcopy(self.model)
 
     # -- one optimizer step -------------------------------------------------------------------------------------
-    def _optimizers_step(self, model_output):
+    def _optimizers_step(self, model_output, backward_done=False):
         """zero_grad -> backward -> [one all-reduce] -> step  (base_trainer.py:350-361)."""
-        loss = model_output.loss
-        self.optimizer.zero_grad()
-        loss.backward()
+        if not backward_done:
+            loss = model_output.loss
+            self.optimizer.zero_grad()
+            loss.backward()
         if isinstance(self.optimizer, FusedAdam):
             if self.distributed:
                 self.flat.all_reduce()  # C2: ONE sum all-reduce of the flat gradient buffer
@@ -266,6 +267,29 @@ class BaseTrainer:
                 self.flat.all_reduce()
                 self.flat.grad.mul_(1.0 / self.world_size)
             self.optimizer.step()
+
+    # -- hipGraph replay of the fixed-shape part of a step (training_config.use_hip_graph) ----------------------
+    def _graphed_forward_backward(self, inputs, epoch, fwd_kwargs):
+        """zero_grad + forward + backward through a captured hipGraph when this batch shape (and the model's
+        graph_key, e.g. JMVAE's annealing epoch) has one; returns None when the step has to run eagerly."""
+        if not (self.training_config.use_hip_graph and isinstance(self.optimizer, FusedAdam)
+                and self.device.type == "cuda" and not hasattr(inputs, "masks")):
+            return None
+        from ..graph import GraphedStep
+
+        key_fn = getattr(self.model, "graph_key", None)
+        key = (tuple((m, tuple(v.shape)) for m, v in inputs.data.items()), key_fn(epoch=epoch) if key_fn else None)
+        graphs = self.__dict__.setdefault("_graphs", {})
+        gs = graphs.get(key)
+        if gs is None and key not in graphs:
+            try:
+                gs = GraphedStep(self.model, self.flat, inputs, noise=None,
+                                 capture_error_mode="thread_local" if self.distributed else "global", **fwd_kwargs)
+            except Exception as e:  # not capturable (host sync inside the model, ...): stay eager for this shape
+                logger.warning(f"hipGraph capture failed ({type(e).__name__}: {e}); running this batch shape eagerly")
+                gs = None
+            graphs[key] = gs
+        return gs(inputs) if gs is not None else None
 
     def train_step(self, epoch: int):
         self.callback_handler.on_train_step_begin(training_config=self.training_config, train_loader=self.train_loader,
@@ -278,9 +302,14 @@ class BaseTrainer:
         n_batches = len(self.train_loader)
         for batch_idx, inputs in enumerate(self.train_loader):
             beta_epoch = cfg.beta_schedule[epoch - 1] if hasattr(cfg, "beta_schedule") else 1
-            model_output = self.model(inputs, epoch=epoch, dataset_size=len(self.train_dataset),
-                                      uses_ddp=self.distributed, batch_ratio=batch_idx / n_batches, beta=beta_epoch)
-            self._optimizers_step(model_output)
+            fwd_kwargs = dict(epoch=epoch, dataset_size=len(self.train_dataset), uses_ddp=self.distributed,
+                              batch_ratio=batch_idx / n_batches, beta=beta_epoch)
+            model_output = self._graphed_forward_backward(inputs, epoch, fwd_kwargs)
+            if model_output is not None:  # gradients are already in the flat buffer
+                self._optimizers_step(model_output, backward_done=True)
+            else:
+                model_output = self.model(inputs, **fwd_kwargs)
+                self._optimizers_step(model_output)
             loss = model_output.loss_sum if hasattr(model_output, "loss_sum") else model_output.loss
             if sync:
                 epoch_loss += loss.item()

@@ -39,6 +39,7 @@ class BaseTrainerConfig(BaseConfig):
     # --- multivae_amd extensions -----------------------------------------------------------------
     use_fused_adam: bool = True     # optimizer_cls == "Adam": one mvk_adam_step launch over the flat buffer
     sync_every_step: bool = False   # True reproduces the reference's per-step `.item()` host sync
+    use_hip_graph: bool = False     # replay zero_grad+forward+backward of full-size batches as ONE hipGraph launch
 
     def __post_init__(self):
         super().__post_init__()
