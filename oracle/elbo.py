@@ -271,10 +271,17 @@ def mvtcae_forward(enc, data, decoders, eps, *, names, alpha=0.1, beta=2.5, resc
 # a11-a13: MMVAE
 # ----------------------------------------------------------------------------------------------
 def mmvae_std(log_var, family):
-    """mmvae_model.py:66-74."""
+    """mmvae_model.py:66-74; mmvaePlus_model.py:110-120 adds 'normal_with_softplus'."""
     if family == "laplace_with_softmax":
         return F.softmax(log_var, dim=-1) * log_var.size(-1) + 1e-6
+    if family == "normal_with_softplus":
+        return F.softplus(log_var) + 1e-6
     return torch.exp(0.5 * log_var)
+
+
+def _latent_family(family):
+    """Distribution family of the latent for the log-prob / rsample helpers."""
+    return "laplace_with_softmax" if family == "laplace_with_softmax" else "normal"
 
 
 def latent_log_prob(family, z, loc, scale):
@@ -365,6 +372,95 @@ def mmvae_forward(enc, data, decoders, noise, *, names, K, family="laplace_with_
     tot = tot.sum(0) / n_avail.to(tot.dtype)
     loss_v = -tot.sum()
     return dict(loss=loss_v, loss_sum=loss_v, metrics={}, lws=lws, zs=zs)
+
+
+# ----------------------------------------------------------------------------------------------
+# a15: MMVAE+ (shared latent u, one private latent w per modality)
+# ----------------------------------------------------------------------------------------------
+def mmvaeplus_forward(enc, data, decoders, noise, *, names, K, family="laplace_with_softmax", loss="dreg_looser",
+                      beta=1.0, prior_logvars=None, rescale=None, dists=None, dist_scales=None, masks=None):
+    """MMVAEPlus.forward: _compute_posteriors_and_embeddings + _compute_k_lws + iwae / dreg looser.
+    mmvaePlus_model.py:122-360.
+
+    enc: {name: (mu, lv, mu_style, lv_style)}; noise: {cond: {"u": [K,B,L], "w": [K,B,S], recon != cond: [K,B,S]}} in the
+    reference's draw order (u, w, then one prior draw per other modality); prior_logvars: {"shared": [1,L+S],
+    name: [1,S]} (the prior means are fixed zeros)."""
+    mods = [m for m in names if m in data]
+    rescale = rescale or {m: 1.0 for m in names}
+    dists = dists or {m: "normal" for m in names}
+    dist_scales = dist_scales or {}
+    fam = _latent_family(family)
+    L = enc[mods[0]][0].shape[-1]
+    S = enc[mods[0]][2].shape[-1]
+    ref = enc[mods[0]][0]
+    if prior_logvars is None:
+        prior_logvars = {"shared": torch.zeros(1, L + S, dtype=ref.dtype)}
+        prior_logvars.update({m: torch.zeros(1, S, dtype=ref.dtype) for m in names})
+    post, post_det, emb, recons = {}, {}, {}, {}
+    for c in mods:
+        mu, lv, mus, lvs = enc[c]
+        sig, sigs = mmvae_std(lv, family), mmvae_std(lvs, family)
+        u = latent_rsample(fam, mu, sig, noise[c]["u"])
+        w = latent_rsample(fam, mus, sigs, noise[c]["w"])
+        post[c] = ((mu, sig), (mus, sigs))
+        post_det[c] = ((mu.detach(), sig.detach()), (mus.detach(), sigs.detach()))
+        emb[c] = (u, w)
+        recons[c] = {}
+        for r in mods:
+            if r == c:
+                z = torch.cat([u, w], dim=-1)
+            else:
+                p_sig = mmvae_std(prior_logvars[r], family).expand(mu.shape[0], S)
+                wp = latent_rsample(fam, torch.zeros_like(p_sig), p_sig, noise[c][r])
+                z = torch.cat([u, wp], dim=-1)
+            rec = decoders[r](z.reshape(-1, z.shape[-1]))
+            recons[c][r] = rec.reshape(*z.shape[:-1], *rec.shape[1:])
+    q = post_det if loss == "dreg_looser" else post
+    if masks is not None:
+        n_avail = torch.stack([masks[m] for m in masks]).int().sum(0)
+    else:
+        n_avail = torch.tensor([len(names)])
+    pz_std = mmvae_std(prior_logvars["shared"], family)
+    lws = {}
+    for c in mods:
+        u, w = emb[c]
+        z = torch.cat([u, w], dim=-1)
+        lpz = latent_log_prob(fam, z, torch.zeros_like(pz_std), pz_std).sum(-1)
+        lqu = []
+        for m in mods:
+            v = latent_log_prob(fam, u, q[m][0][0], q[m][0][1]).sum(-1)
+            if masks is not None:
+                v = torch.where(masks[m].bool().unsqueeze(0), v, torch.full_like(v, -float("inf")))
+            lqu.append(v)
+        lqu = torch.logsumexp(torch.stack(lqu), dim=0) - torch.log(n_avail.to(z.dtype))
+        lqw = latent_log_prob(fam, w, q[c][1][0], q[c][1][1]).sum(-1)
+        lpx = 0
+        for r in mods:
+            lp = recon_log_prob(dists[r], recons[c][r], data[r], dist_scales.get(r, 1.0))
+            lp = lp.reshape(z.shape[0], z.shape[1], -1).mul(rescale[r]).sum(-1)
+            if masks is not None:
+                lp = lp * masks[r].to(lp.dtype)
+            lpx = lpx + lp
+        lw = lpx + beta * (lpz - lqu - lqw)
+        if masks is not None:
+            lw = lw * masks[c].to(lw.dtype)
+        lws[c] = lw
+    if loss == "dreg_looser":
+        wk = {}
+        with torch.no_grad():
+            for c in mods:
+                wk[c] = (lws[c] - torch.logsumexp(lws[c], 0, keepdim=True)).exp()
+        tot = torch.stack([lws[c] * wk[c] for c in mods]).sum(1)
+        for c in mods:
+            for tns in emb[c]:
+                if tns.requires_grad:
+                    tns.register_hook(lambda g, w_=wk[c]: w_.unsqueeze(-1) * g)
+    else:
+        tot = torch.logsumexp(torch.stack([lws[c] for c in mods]), dim=1) - math.log(K)
+    tot = tot.sum(0) / n_avail.to(tot.dtype)
+    loss_v = -tot.sum()
+    return dict(loss=loss_v, loss_sum=loss_v, metrics={}, lws=lws, us={c: emb[c][0] for c in mods},
+                ws={c: emb[c][1] for c in mods})
 
 
 # ----------------------------------------------------------------------------------------------

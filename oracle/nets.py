@@ -29,6 +29,22 @@ def mlp_encoder(sd, prefix, x, n_hidden=1):
     return mu, lv
 
 
+def mlp_style_encoder(sd, prefix, x):
+    """Encoder_VAE_MLP_Style.forward (default_architectures.py:75-141): Linear+ReLU -> four heads
+    (embedding, log_var, style_embedding, style_log_var)."""
+    w0 = sd[prefix + "layers.0.0.weight"]
+    h = F.relu(F.linear(x.reshape(-1, w0.shape[1]), w0, sd[prefix + "layers.0.0.bias"]))
+    head = lambda n: F.linear(h, sd[f"{prefix}{n}.weight"], sd[f"{prefix}{n}.bias"])
+    return head("embedding"), head("log_var"), head("style_embedding"), head("style_log_var")
+
+
+def build_default_mlp_multilatent(sd, input_dims):
+    """BaseDictEncoders_MultiLatents / BaseDictDecodersMultiLatents (default_architectures.py:161-221)."""
+    enc = {m: (lambda x, m=m: mlp_style_encoder(sd, f"encoders.{m}.", x)) for m in input_dims}
+    dec = {m: (lambda z, m=m: mlp_decoder(sd, f"decoders.{m}.", z, tuple(input_dims[m]))) for m in input_dims}
+    return enc, dec
+
+
 def mlp_decoder(sd, prefix, z, input_dim):
     """Decoder_AE_MLP.forward: Linear(L,512)+ReLU -> Linear(512, prod D)+Sigmoid -> reshape(*z.shape[:-1], *D)."""
     h = F.relu(F.linear(z, sd[prefix + "layers.0.0.weight"], sd[prefix + "layers.0.0.bias"]))

@@ -34,8 +34,8 @@ import _reference_import as R
 R.install()
 import procedural as P
 from multivae.data.datasets.base import IncompleteDataset, MultimodalBaseDataset
-from multivae.models import (JMVAE, MMVAE, MVTCAE, JMVAEConfig, MMVAEConfig, MoPoE, MoPoEConfig,
-                             MVTCAEConfig)
+from multivae.models import (JMVAE, MMVAE, MVTCAE, JMVAEConfig, MMVAEConfig, MMVAEPlus, MMVAEPlusConfig, MoPoE,
+                             MoPoEConfig, MVTCAEConfig)
 from multivae.models.base import base_utils as ref_utils
 from multivae.models.base.base_config import BaseAEConfig
 from multivae.models.nn.default_architectures import Decoder_AE_MLP, Encoder_VAE_MLP
@@ -469,6 +469,103 @@ def main():
                loss="iwae_looser", rescaling=False, masked=False, seed=306)
 
 
+def mmvaeplus_case(name, *, arch, B, K, S, family, loss, beta, rescaling, masked, seed, learn_shared_prior=False):
+    """MMVAEPlus with the default multi-latent MLP encoders / decoders."""
+    print(name)
+    if arch == "tiny":
+        dims, L = TINY_DIMS, TINY_L
+        data, masks = tiny_data(B, seed, masked)
+    else:
+        dims, L = dict(mnist=(1, 28, 28), svhn=(3, 32, 32)), 20
+        data, masks = mnist_svhn_data(B, seed), None
+    shapes = P.mmvaeplus_mlp_shapes(dims, L, S)
+    cfg = MMVAEPlusConfig(n_modalities=len(dims), latent_dim=L, input_dims=dict(dims), K=K, modalities_specific_dim=S,
+                          prior_and_posterior_dist=family, loss=loss, beta=beta, uses_likelihood_rescaling=rescaling,
+                          learn_shared_prior=learn_shared_prior, learn_modality_prior=True)
+    model = MMVAEPlus(cfg)
+    sd_np = P.make_state_dict(shapes, seed)
+    load_weights_plus(model, sd_np)
+    names = list(model.encoders.keys())
+    plv = {"shared": P.uniform((1, L + S), seed + 998, -0.3, 0.3)}
+    for i, m in enumerate(names):
+        plv[m] = P.uniform((1, S), seed + 900 + i, -0.3, 0.3)
+    with torch.no_grad():
+        for k, v in plv.items():
+            model.logvars_priors[k].copy_(t(v))
+    inputs = ref_dataset(data, masks)
+    mods = list(inputs.data.keys())
+    model.train()
+
+    def draw(shape):
+        if family == "laplace_with_softmax":
+            return torch.empty(shape).uniform_(torch.finfo(torch.float32).eps - 1, 1)
+        return torch.randn(shape)
+
+    torch.manual_seed(seed)
+    noise = {}
+    for c in mods:  # draw order of _compute_posteriors_and_embeddings: u, w, then one prior draw per other modality
+        noise[c] = {"u": draw((K, B, L)), "w": draw((K, B, S))}
+        for r in mods:
+            if r != c:
+                noise[c][r] = draw((K, B, S))
+    torch.manual_seed(seed)
+    out = model(inputs)
+    model.zero_grad()
+    out.loss.backward()
+    gref = ref_grads(model)
+    osd = oracle_sd(sd_np)
+    oplv = {k: t(v).clone().requires_grad_(k != "shared" or learn_shared_prior) for k, v in plv.items()}
+    enc_f, dec_f = nets.build_default_mlp_multilatent(osd, dims)
+    tdata = {m: t(v) for m, v in data.items()}
+    tmasks = None if masks is None else {m: t(v) for m, v in masks.items()}
+    e = {m: enc_f[m](tdata[m]) for m in mods}
+    o = elbo.mmvaeplus_forward(e, tdata, dec_f, noise, names=names, K=K, family=family, loss=loss, beta=beta,
+                               prior_logvars=oplv, rescale=elbo.rescale_factors(dims, rescaling), masks=tmasks)
+    o["loss"].backward()
+    report("loss", out.loss, o["loss"])
+    gor = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in osd.items()}
+    for k, v in oplv.items():
+        gor["logvars_priors." + k] = v.grad if v.grad is not None else torch.zeros_like(v)
+        gor["mean_priors." + k] = torch.zeros_like(v)
+    cmp_grads("grads", gref, gor)
+    arrays = dict(loss=out.loss.detach())
+    for k, v in plv.items():
+        arrays["prior_logvar/" + k] = v
+    for c in mods:
+        for k, v in noise[c].items():
+            arrays[f"noise/{c}/{k}"] = v
+        arrays["lws/" + c] = o["lws"][c].detach()
+        arrays["us/" + c] = o["us"][c].detach()
+        arrays["ws/" + c] = o["ws"][c].detach()
+    if masks is not None:
+        for m, v in masks.items():
+            arrays["mask/" + m] = v
+    arrays.update(grad_stats(gref))
+    save(name, dict(model="MMVAEPlus", arch=arch, B=B, L=L, S=S, K=K, family=family, loss=loss, beta=beta,
+                    rescaling=rescaling, masked=masked, seed=seed, names=names,
+                    learn_shared_prior=learn_shared_prior), arrays)
+
+
+def load_weights_plus(model, sd_np):
+    sd = {k: t(v) for k, v in sd_np.items()}
+    missing = model.load_state_dict(sd, strict=False)
+    extra = [k for k in missing.missing_keys if not (k.startswith("mean_priors.") or k.startswith("logvars_priors."))]
+    assert not extra and not missing.unexpected_keys, (missing,)
+
+
+def mmvaeplus_main():
+    mmvaeplus_case("mmvaeplus_tiny_laplace_dreg", arch="tiny", B=6, K=3, S=3, family="laplace_with_softmax",
+                   loss="dreg_looser", beta=1.0, rescaling=False, masked=False, seed=501)
+    mmvaeplus_case("mmvaeplus_tiny_normal_iwae_beta", arch="tiny", B=5, K=4, S=2, family="normal", loss="iwae_looser",
+                   beta=2.5, rescaling=True, masked=False, seed=502, learn_shared_prior=True)
+    mmvaeplus_case("mmvaeplus_tiny_softplus_dreg_masked", arch="tiny", B=7, K=3, S=3, family="normal_with_softplus",
+                   loss="dreg_looser", beta=1.0, rescaling=False, masked=True, seed=503)
+    mmvaeplus_case("mmvaeplus_tiny_laplace_iwae_masked", arch="tiny", B=6, K=2, S=4, family="laplace_with_softmax",
+                   loss="iwae_looser", beta=0.5, rescaling=False, masked=True, seed=504)
+    mmvaeplus_case("mmvaeplus_mnistsvhn_mlp_k10", arch="mnistsvhn", B=4, K=10, S=8, family="laplace_with_softmax",
+                   loss="dreg_looser", beta=2.5, rescaling=False, masked=False, seed=505)
+
+
 def jmvae_main():
     jmvae_case("jmvae_tiny_warmup", arch="tiny", B=6, alpha=0.1, beta=1.0, warmup=10, epoch=3, rescaling=False, seed=401)
     jmvae_case("jmvae_tiny_beta_rescale", arch="tiny", B=7, alpha=0.3, beta=2.0, warmup=5, epoch=8, rescaling=True,
@@ -480,6 +577,9 @@ def jmvae_main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "jmvae":  # only the JMVAE cases (the others are unchanged)
         jmvae_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "mmvaeplus":
+        mmvaeplus_main()
     else:
         main()
         jmvae_main()
+        mmvaeplus_main()

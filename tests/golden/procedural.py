@@ -124,6 +124,27 @@ def jmvae_mlp_shapes(input_dims, latent_dim):
     return s
 
 
+def mlp_style_encoder_shapes(prefix, in_features, latent_dim, style_dim):
+    s = OrderedDict()
+    s[prefix + "layers.0.0.weight"] = (512, in_features)
+    s[prefix + "layers.0.0.bias"] = (512,)
+    for h, d in (("embedding", latent_dim), ("log_var", latent_dim), ("style_embedding", style_dim),
+                 ("style_log_var", style_dim)):
+        s[f"{prefix}{h}.weight"] = (d, 512)
+        s[f"{prefix}{h}.bias"] = (d,)
+    return s
+
+
+def mmvaeplus_mlp_shapes(input_dims, latent_dim, style_dim):
+    """MMVAEPlus with default architectures: decoders take latent_dim + style_dim inputs, encoders have four heads."""
+    s = OrderedDict()
+    for m, d in input_dims.items():
+        s.update(mlp_decoder_shapes(f"decoders.{m}.", latent_dim + style_dim, int(np.prod(d))))
+    for m, d in input_dims.items():
+        s.update(mlp_style_encoder_shapes(f"encoders.{m}.", int(np.prod(d)), latent_dim, style_dim))
+    return s
+
+
 def make_state_dict(shapes, seed, gain=1.0):
     """name -> float32 ndarray, U(-b, b) with b = gain/sqrt(prod(shape[1:])) (bias: b of its weight)."""
     sd = OrderedDict()

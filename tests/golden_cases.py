@@ -20,6 +20,9 @@ MOPOE_CASES = ["mopoe_tiny_complete", "mopoe_tiny_beta_rescale", "mopoe_tiny_mas
                "mopoe_mnistsvhn_k1_rescale", "mopoe_mnistsvhn_k10"]
 MVTCAE_CASES = ["mvtcae_tiny_complete", "mvtcae_tiny_masked", "mvtcae_mnistsvhn_mlp"]
 JMVAE_CASES = ["jmvae_tiny_warmup", "jmvae_tiny_beta_rescale", "jmvae_mnistsvhn_mlp"]
+MMVAEPLUS_CASES = ["mmvaeplus_tiny_laplace_dreg", "mmvaeplus_tiny_normal_iwae_beta",
+                   "mmvaeplus_tiny_softplus_dreg_masked", "mmvaeplus_tiny_laplace_iwae_masked",
+                   "mmvaeplus_mnistsvhn_mlp_k10"]
 MMVAE_CASES = ["mmvae_tiny_normal_iwae", "mmvae_tiny_laplace_dreg", "mmvae_tiny_normal_dreg_masked",
                "mmvae_tiny_laplace_iwae_masked", "mmvae_mnistsvhn_laplace_dreg_k1",
                "mmvae_mnistsvhn_normal_iwae_k10"]
@@ -57,13 +60,20 @@ def build_inputs(cfg):
         for m, d in (cfg.get("dists") or {}).items():
             if d == "bernoulli":
                 data[m] = (data[m] > 0.5).astype(np.float32)
-        shapes = P.jmvae_mlp_shapes(dims, cfg["L"]) if cfg["model"] == "JMVAE" else P.default_mlp_shapes(dims, cfg["L"])
+        if cfg["model"] == "JMVAE":
+            shapes = P.jmvae_mlp_shapes(dims, cfg["L"])
+        elif cfg["model"] == "MMVAEPlus":
+            shapes = P.mmvaeplus_mlp_shapes(dims, cfg["L"], cfg["S"])
+        else:
+            shapes = P.default_mlp_shapes(dims, cfg["L"])
     else:
         dims = MNIST_SVHN_DIMS
         data = {"mnist": P.uniform((B, 1, 28, 28), seed), "svhn": P.uniform((B, 3, 32, 32), seed + 1)}
         masks = None
         if cfg["model"] == "JMVAE":
             shapes = P.jmvae_mlp_shapes(dims, cfg["L"])
+        elif cfg["model"] == "MMVAEPlus":
+            shapes = P.mmvaeplus_mlp_shapes(dims, cfg["L"], cfg["S"])
         elif cfg["model"] == "MVTCAE":
             shapes = P.default_mlp_shapes(dims, cfg["L"])
         else:

@@ -42,6 +42,8 @@ def test_unit_base_utils():
 
 
 def _oracle_nets(cfg, dims, sd):
+    if cfg["model"] == "MMVAEPlus":
+        return nets.build_default_mlp_multilatent(sd, dims)
     if cfg["arch"] == "tiny" or cfg["model"] in ("MVTCAE", "JMVAE"):
         return nets.build_default_mlp(sd, dims)
     return nets.build_mnist_svhn(sd, cfg["L"])
@@ -142,6 +144,35 @@ def test_mmvae(name):
     o["loss"].backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()}
     grads["prior_log_var"] = plv.grad
+    G.check_grads(a, grads, rtol=2e-5)
+
+
+def mmvaeplus_noise(a, mods):
+    return {c: {k.split("/")[2]: G.t(v) for k, v in a.items() if k.startswith(f"noise/{c}/")} for c in mods}
+
+
+@pytest.mark.parametrize("name", G.MMVAEPLUS_CASES)
+def test_mmvaeplus(name):
+    """MMVAEPlus.forward (mmvaePlus_model.py:122-360): shared + private latents, prior-sampled private latents for the
+    cross reconstructions, beta, IWAE / DReG, the three posterior families, incomplete data."""
+    cfg, a, dims, data, masks, sd, enc_f, dec_f = _prep(name)
+    names = cfg["names"]
+    mods = [m for m in names if ("lws/" + m) in a]
+    plv = {k.split("/")[1]: G.t(v).clone().requires_grad_(True) for k, v in a.items() if k.startswith("prior_logvar/")}
+    e = {m: enc_f[m](data[m]) for m in mods}
+    o = elbo.mmvaeplus_forward(e, data, dec_f, mmvaeplus_noise(a, mods), names=names, K=cfg["K"], family=cfg["family"],
+                               loss=cfg["loss"], beta=cfg["beta"], prior_logvars=plv,
+                               rescale=elbo.rescale_factors(dims, cfg["rescaling"]), masks=masks)
+    close(a["loss"], o["loss"])
+    for m in mods:
+        close(a["lws/" + m], o["lws"][m], rtol=1e-5, atol=1e-4)
+        close(a["us/" + m], o["us"][m])
+        close(a["ws/" + m], o["ws"][m])
+    o["loss"].backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()}
+    for k, v in plv.items():
+        if k != "shared" or cfg["learn_shared_prior"]:
+            grads["logvars_priors." + k] = v.grad if v.grad is not None else torch.zeros_like(v)
     G.check_grads(a, grads, rtol=2e-5)
 
 
