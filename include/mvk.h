@@ -43,6 +43,7 @@ extern "C" {
 /* latent families of MMVAE — models/mmvae/mmvae_model.py:44-49,66-74 */
 #define MVK_FAMILY_NORMAL 0
 #define MVK_FAMILY_LAPLACE_SOFTMAX 1
+#define MVK_FAMILY_NORMAL_SOFTPLUS 2 /* std kernels only (MMVAE+): std = softplus(lv) + 1e-6, density = Normal */
 
 int mvk_version(void);
 
@@ -152,8 +153,8 @@ int mvk_scale_by_device_scalar(float* buf, int64_t n, const float* gscale, void*
  * MMVAE: mixture-of-experts importance weights (IWAE / DReG)
  * ------------------------------------------------------------------------------------------------ */
 
-/* std from log-variance: exp(lv/2) or softmax(lv)*L + 1e-6 (models/mmvae/mmvae_model.py:66-74) and its
- * backward.  lv, std: [rows, L]. */
+/* std from log-variance: exp(lv/2), softmax(lv)*L + 1e-6 (models/mmvae/mmvae_model.py:66-74) or
+ * softplus(lv) + 1e-6 (models/mmvaePlus/mmvaePlus_model.py:110-120) and its backward.  lv, std: [rows, L]. */
 int mvk_mmvae_std_fwd(const float* lv, int rows, int L, int family, float* std, void* stream);
 int mvk_mmvae_std_bwd(const float* lv, const float* std, const float* dstd, int rows, int L, int family,
                       float* dlv, void* stream);
@@ -163,20 +164,27 @@ int mvk_mmvae_std_bwd(const float* lv, const float* std, const float* dstd, int 
  * sum_l log q_m(z) (-inf where mask_m[b] == 0) and lqz[c][k,b] = logsumexp_m lq_all - log n_avail[b]
  * (mmvae_model.py:111-123, :160-206).  mu, std [B,L]; noise, z [K,B,L]; lpz, lqz [K,B]; lq_all [M,K,B]:
  * HOST arrays of M device pointers.  prior_mean, prior_std: device [L].  masks: HOST array of M uint8 [B]
- * device pointers (entries may be NULL) or NULL. */
+ * device pointers (entries may be NULL) or NULL.
+ *
+ * MMVAE+ (mmvaePlus_model.py:122-262): the latent of a modality is [u (shared_dims), w (L - shared_dims)]; only the
+ * first shared_dims dimensions enter the mixture (lq_all, lqz), the rest is scored by the conditioning modality's own
+ * posterior: lqw[c][k,b] = sum_{l >= shared_dims} log q_c(z).  MMVAE: shared_dims = L, lqw = NULL. */
 int mvk_mmvae_latent_fwd(const float* const* mu, const float* const* std, const float* const* noise,
                          const uint8_t* const* masks, const float* prior_mean, const float* prior_std, int M,
                          int K, int B, int L, int family, float* const* z, float* const* lpz,
-                         float* const* lqz, float* const* lq_all, void* stream);
+                         float* const* lqz, float* const* lq_all, int shared_dims, float* const* lqw, void* stream);
 
 /* lw[c] = (sum_r -rows[c][r] * mask_r + lpz[c] - lqz[c]) * mask_c, softmax weights w[c] over k, and
  * loss = -sum_b (1/n_avail[b]) sum_c obj_c[b] with obj = logsumexp_k lw - log K (IWAE) or sum_k w lw (DReG)
  * (mmvae_model.py:208-292).  rows: HOST array of M*M device pointers, rows[c*M + r] = [K,B] rescaled NLL rows
  * of modality r reconstructed from z[c] (mvk_recon_nll_fwd).  rowcoef[c] [K,B] = d loss / d lw[c] =
  * -w[c] mask_c / n_avail (the per-row weight of mvk_recon_nll_bwd).  loss: device scalar, overwritten. */
+/* MMVAE+: lw[c] = (sum_r ... + beta * (lpz[c] - lqz[c] - lqw[c])) * mask_c (mmvaePlus_model.py:262); MMVAE passes
+ * lqw = NULL, beta = 1. */
 int mvk_mmvae_objective_fwd(const float* const* rows, const float* const* lpz, const float* const* lqz,
                             const uint8_t* const* masks, int M, int K, int B, int dreg, float* const* lw_out,
-                            float* const* w, float* const* rowcoef, float* loss, void* stream);
+                            float* const* w, float* const* rowcoef, float* loss, const float* const* lqw, float beta,
+                            void* stream);
 
 /* Latent-side backward.  dz_dec[c] [K,B,L]: gradient of the loss w.r.t. z[c] through the decoders (from
  * mvk_recon_nll_bwd with rowcoef = -w[c]/n_avail and the decoders' own backward).  Produces dmu[c], dstd[c]
@@ -187,7 +195,17 @@ int mvk_mmvae_latent_bwd(const float* const* mu, const float* const* std, const 
                          const float* prior_std, const float* const* w, const float* const* lq_all,
                          const float* const* lqz, const float* const* dz_dec, int M, int K, int B, int L,
                          int family, int dreg, const float* gscale, float* const* dmu, float* const* dstd,
-                         float* dprior_std, void* stream);
+                         float* dprior_std, int shared_dims, float beta,
+                         void* stream);
+
+/* MMVAE+ cross-modal decoder input (mmvaePlus_model.py:152-172): zc[r, :Ls] = z[r, :Ls] (the shared latent of the
+ * conditioning modality) and zc[r, Ls + j] = prior_std[j] * t(noise[r, j]) (a reparameterised sample of the TARGET
+ * modality's private prior, mean 0).  rows = K*B, z / zc [rows, D], noise [rows, D - Ls], prior_std [D - Ls].
+ * bwd: dz [rows, D] (zero in the private dims) and dprior_std [D - Ls] (nullable), overwritten. */
+int mvk_mmvaeplus_cross_latent_fwd(const float* z, const float* prior_std, const float* noise, int64_t rows, int D,
+                                   int Ls, int family, float* zc, void* stream);
+int mvk_mmvaeplus_cross_latent_bwd(const float* dzc, const float* noise, int64_t rows, int D, int Ls, int family,
+                                   float* dz, float* dprior_std, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Encoder / decoder layers: implicit GEMM with fp32 operands and results.  Default engine: split-bf16 MFMA

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libmvk.so")
 MVK_OK = 0
 DIST = {"normal": 0, "laplace": 1, "bernoulli": 2}
 ACT = {None: 0, "none": 0, "relu": 1, "sigmoid": 2}
-FAMILY = {"normal": 0, "laplace_with_softmax": 1}
+FAMILY = {"normal": 0, "laplace_with_softmax": 1, "normal_with_softplus": 2}  # 2: std kernels only (density = normal)
 MAX_MODALITIES = 8
 
 _p = C.c_void_p
@@ -76,9 +76,11 @@ PROTOTYPES = {
     "mvk_adam_step": [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _d, _p],
     "mvk_mmvae_std_fwd": [_p, _i, _i, _i, _p, _p],
     "mvk_mmvae_std_bwd": [_p, _p, _p, _i, _i, _i, _p, _p],
-    "mvk_mmvae_latent_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p],
-    "mvk_mmvae_objective_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p],
-    "mvk_mmvae_latent_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p],
+    "mvk_mmvae_latent_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p],
+    "mvk_mmvae_objective_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p],
+    "mvk_mmvae_latent_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _f, _p],
+    "mvk_mmvaeplus_cross_latent_fwd": [_p, _p, _p, _i64, _i, _i, _i, _p, _p],
+    "mvk_mmvaeplus_cross_latent_bwd": [_p, _p, _i64, _i, _i, _i, _p, _p, _p],
 }
 
 _lib = None

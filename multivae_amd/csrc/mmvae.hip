@@ -1,6 +1,10 @@
 // MMVAE mixture-of-experts importance weights (IWAE / DReG), Normal and Laplace(softmax-scale) families.
 // Follows models/mmvae/mmvae_model.py:66-74 (log_var_to_std), :95-158 (forward), :160-236 (compute_k_lws),
-// :238-292 (dreg_looser / iwae_looser).  All tensors are small ([K,B,L], L ~ 20-64): these kernels are
+// :238-292 (dreg_looser / iwae_looser).
+// MMVAE+ (models/mmvaePlus/mmvaePlus_model.py:110-360) runs on the same kernels: the latent of a modality is the
+// concatenation [u (shared, Ls dims), w (private)], the mixture density covers the shared dims only, the private dims
+// are scored by the modality's own posterior (lqw), the prior terms are weighted by beta, and the private part of a
+// cross-modal decoder input is sampled from the target modality's prior (cross_latent kernels).  All tensors are small ([K,B,L], L ~ 20-64): these kernels are
 // latency-bound; the design goal is few launches and deterministic reductions.
 #include "common.hpp"
 
@@ -18,6 +22,7 @@ struct MmPtrs {
   float* lpz[MAXM];
   float* lqz[MAXM];
   float* lq_all[MAXM];
+  float* lqw[MAXM];  // MMVAE+: log q_c(w_c) rows (NULL for MMVAE)
 };
 
 __device__ __forceinline__ float lat_logp(int family, float z, float loc, float sd) {
@@ -57,6 +62,10 @@ __global__ __launch_bounds__(256) void std_fwd_kernel(const float* __restrict__ 
     for (int l = lane; l < L; l += 64) y[l] = expf(0.5f * x[l]);
     return;
   }
+  if (family == MVK_FAMILY_NORMAL_SOFTPLUS) {  // F.softplus (threshold 20) + 1e-6, mmvaePlus_model.py:117-118
+    for (int l = lane; l < L; l += 64) y[l] = (x[l] > 20.f ? x[l] : log1pf(expf(x[l]))) + 1e-6f;
+    return;
+  }
   float mx = -INFINITY;
   for (int l = lane; l < L; l += 64) mx = fmaxf(mx, x[l]);
   mx = wave_max(mx);
@@ -77,6 +86,13 @@ __global__ __launch_bounds__(256) void std_bwd_kernel(const float* __restrict__ 
     for (int l = lane; l < L; l += 64) dlv[o + l] = dsd[o + l] * 0.5f * sd[o + l];
     return;
   }
+  if (family == MVK_FAMILY_NORMAL_SOFTPLUS) {  // d softplus = sigmoid
+    for (int l = lane; l < L; l += 64) {
+      const float x = lv[o + l];
+      dlv[o + l] = dsd[o + l] * (x > 20.f ? 1.0f : 1.0f / (1.0f + expf(-x)));
+    }
+    return;
+  }
   // sd = softmax * L + 1e-6  ->  d lv_i = L * p_i * (dsd_i - sum_j dsd_j p_j)
   const float invL = 1.0f / (float)L;
   float dot = 0.f;
@@ -93,7 +109,7 @@ __global__ __launch_bounds__(256) void std_bwd_kernel(const float* __restrict__ 
 // one wave per (c, k, b); lanes over l
 __global__ __launch_bounds__(256) void latent_fwd_kernel(const MmPtrs p, const float* __restrict__ prior_mean,
                                                          const float* __restrict__ prior_sd, int M, int K, int B,
-                                                         int L, int family) {
+                                                         int L, int Ls, int family) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long total = (long long)M * K * B;
@@ -101,7 +117,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(const MmPtrs p, const f
   const int c = (int)(row / ((long long)K * B));
   const int kb = (int)(row % ((long long)K * B));
   const int b = kb % B;
-  float lp = 0.f;
+  float lp = 0.f, lqw = 0.f;
   float lq[MAXM];
 #pragma unroll
   for (int m = 0; m < MAXM; ++m) lq[m] = 0.f;
@@ -124,11 +140,16 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(const MmPtrs p, const f
     const float z = mu_c[o] + sd_c[o] * lat_t(family, nz_c[zo]);
     z_c[zo] = z;
     lp += lat_logp(family, z, prior_mean[l], prior_sd[l]);
+    if (l < Ls) {  // shared dims: every modality's posterior enters the mixture
 #pragma unroll
-    for (int m = 0; m < MAXM; ++m)
-      if (m < M) lq[m] += lat_logp(family, z, p.mu[m][o], p.sd[m][o]);
+      for (int m = 0; m < MAXM; ++m)
+        if (m < M) lq[m] += lat_logp(family, z, p.mu[m][o], p.sd[m][o]);
+    } else {  // private dims (MMVAE+): the conditioning modality's own posterior
+      lqw += lat_logp(family, z, mu_c[o], sd_c[o]);
+    }
   }
   lp = wave_sum(lp);
+  lqw = wave_sum(lqw);
   int navail = 0;
   float mx = -INFINITY;
 #pragma unroll
@@ -152,6 +173,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(const MmPtrs p, const f
       if (m == c) {
         p.lpz[m][kb] = lp;
         p.lqz[m][kb] = lse - logf((float)navail);
+        if (p.lqw[m]) p.lqw[m][kb] = lqw;
         for (int mm = 0; mm < M; ++mm) {
           float v = 0.f;
 #pragma unroll
@@ -169,13 +191,14 @@ struct ObjPtrs {
   const float* rows[MAXM * MAXM];  // [c][r]: rescaled NLL rows of modality r decoded from z_c
   const float* lpz[MAXM];
   const float* lqz[MAXM];
+  const float* lqw[MAXM];  // MMVAE+ (may be NULL)
   const uint8_t* mask[MAXM];
   float* lw[MAXM];
   float* w[MAXM];
   float* rowcoef[MAXM];
 };
 
-__global__ __launch_bounds__(1024) void objective_kernel(const ObjPtrs p, int M, int K, int B, int dreg,
+__global__ __launch_bounds__(1024) void objective_kernel(const ObjPtrs p, int M, int K, int B, int dreg, float beta,
                                                          float* __restrict__ loss) {
   float local = 0.f;
   for (int idx = threadIdx.x; idx < M * B; idx += blockDim.x) {
@@ -203,7 +226,8 @@ __global__ __launch_bounds__(1024) void objective_kernel(const ObjPtrs p, int M,
         const float mr = p.mask[r] ? (p.mask[r][b] ? 1.f : 0.f) : 1.f;
         lpx += -p.rows[c * MAXM + r][o] * mr;
       }
-      const float v = (lpx + lpz[o] - lqz[o]) * mc;
+      const float lqw = p.lqw[c] ? p.lqw[c][o] : 0.f;
+      const float v = (lpx + beta * (lpz[o] - lqz[o] - lqw)) * mc;  // mmvaePlus_model.py:262
       lw[o] = v;
       mx = fmaxf(mx, v);
     }
@@ -250,7 +274,8 @@ struct BwdPtrs {
 // one wave per batch row b; lanes over l; loops over conditioning modality c and sample k
 __global__ __launch_bounds__(256) void latent_bwd_kernel(const BwdPtrs p, const float* __restrict__ prior_mean,
                                                          const float* __restrict__ prior_sd, int M, int K, int B,
-                                                         int L, int family, int dreg, const float* __restrict__ gscale,
+                                                         int L, int Ls, float beta, int family, int dreg,
+                                                         const float* __restrict__ gscale,
                                                          float* __restrict__ dprior_sd) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -283,7 +308,7 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const BwdPtrs p, const 
           const long long kb = (long long)k * B + b;
           const long long zo = kb * L + l;
           const float wk = p.w[c][kb];
-          const float g = -gs * inv_n * wk;  // dLoss / d lw[c][k,b]
+          const float g = -gs * inv_n * wk * beta;  // dLoss / d lw[c][k,b] times the weight of the latent terms
           const float z = p.z[c][zo];
           // prior
           float gz = g * lat_dlogp_dz(family, z, pm, ps);
@@ -292,8 +317,10 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const BwdPtrs p, const 
           const float lse = p.lqz[c][kb] + logf((float)navail);
 #pragma unroll
           for (int m = 0; m < MAXM; ++m) {
-            if (m < M && avail[m]) {
-              const float r = expf(p.lq_all[c][(long long)m * K * B + kb] - lse);
+            // shared dims: responsibilities of the mixture; private dims: the own posterior with weight 1
+            const bool own = (m == c);
+            if (m < M && avail[m] && (l < Ls || own)) {
+              const float r = (l < Ls) ? expf(p.lq_all[c][(long long)m * K * B + kb] - lse) : 1.0f;
               const float dz_q = lat_dlogp_dz(family, z, mu[m], sd[m]);
               gz -= g * r * dz_q;
               if (!dreg) {  // IWAE differentiates the q parameters directly as well
@@ -327,12 +354,70 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const BwdPtrs p, const 
   }
 }
 
+// ---- MMVAE+ cross-modal decoder input: [u_c (first Ls dims of z_c), w ~ prior of the target modality] ----------
+// mmvaePlus_model.py:152-172.  zc[k,b,:Ls] = z[k,b,:Ls];  zc[k,b,Ls+j] = prior_sd[j] * t(noise[k,b,j])  (prior mean 0).
+__global__ __launch_bounds__(256) void cross_latent_fwd_kernel(const float* __restrict__ z,
+                                                               const float* __restrict__ prior_sd,
+                                                               const float* __restrict__ noise, long long rows, int D,
+                                                               int Ls, int family, float* __restrict__ zc) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * D) return;
+  const long long r = i / D;
+  const int l = (int)(i - r * D);
+  zc[i] = l < Ls ? z[i] : prior_sd[l - Ls] * lat_t(family, noise[r * (D - Ls) + (l - Ls)]);
+}
+
+// dz[k,b,:Ls] = dzc[k,b,:Ls], 0 elsewhere; dprior_sd[j] = sum_{k,b} dzc[k,b,Ls+j] * t(noise)   (one block per j)
+__global__ __launch_bounds__(256) void cross_latent_bwd_kernel(const float* __restrict__ dzc,
+                                                               const float* __restrict__ noise, long long rows, int D,
+                                                               int Ls, int family, float* __restrict__ dz,
+                                                               float* __restrict__ dprior_sd) {
+  const int S = D - Ls;
+  if ((int)blockIdx.x < S) {
+    const int j = blockIdx.x;
+    float acc = 0.f;
+    for (long long r = threadIdx.x; r < rows; r += 256) acc += dzc[r * D + Ls + j] * lat_t(family, noise[r * S + j]);
+    __shared__ float red[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && dprior_sd) dprior_sd[j] = (red[0] + red[1]) + (red[2] + red[3]);
+    return;
+  }
+  const long long i = ((long long)blockIdx.x - S) * 256 + threadIdx.x;
+  if (i >= rows * D) return;
+  const int l = (int)(i % D);
+  dz[i] = l < Ls ? dzc[i] : 0.f;
+}
+
 }  // namespace
 
 extern "C" {
 
+int mvk_mmvaeplus_cross_latent_fwd(const float* z, const float* prior_sd, const float* noise, int64_t rows, int D,
+                                   int Ls, int family, float* zc, void* stream) {
+  if (!z || !prior_sd || !noise || !zc || rows < 0 || D < 2 || Ls < 1 || Ls >= D || family < 0 || family > 1)
+    return MVK_EINVAL;
+  if (rows == 0) return MVK_OK;
+  hipLaunchKernelGGL(cross_latent_fwd_kernel, dim3((unsigned)((rows * D + 255) / 256)), dim3(256), 0,
+                     mvk_stream(stream), z, prior_sd, noise, (long long)rows, D, Ls, family, zc);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_mmvaeplus_cross_latent_bwd(const float* dzc, const float* noise, int64_t rows, int D, int Ls, int family,
+                                   float* dz, float* dprior_sd, void* stream) {
+  if (!dzc || !noise || !dz || rows < 0 || D < 2 || Ls < 1 || Ls >= D || family < 0 || family > 1) return MVK_EINVAL;
+  if (rows == 0) return MVK_OK;
+  const unsigned blocks = (unsigned)(D - Ls) + (unsigned)((rows * D + 255) / 256);
+  hipLaunchKernelGGL(cross_latent_bwd_kernel, dim3(blocks), dim3(256), 0, mvk_stream(stream), dzc, noise,
+                     (long long)rows, D, Ls, family, dz, dprior_sd);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
 int mvk_mmvae_std_fwd(const float* lv, int rows, int L, int family, float* sd, void* stream) {
-  if (!lv || !sd || rows < 0 || L < 1 || family < 0 || family > 1) return MVK_EINVAL;
+  if (!lv || !sd || rows < 0 || L < 1 || family < 0 || family > 2) return MVK_EINVAL;
   if (rows == 0) return MVK_OK;
   hipLaunchKernelGGL(std_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, mvk_stream(stream), lv, rows, L, family, sd);
   MVK_CHECK_LAUNCH();
@@ -341,7 +426,7 @@ int mvk_mmvae_std_fwd(const float* lv, int rows, int L, int family, float* sd, v
 
 int mvk_mmvae_std_bwd(const float* lv, const float* sd, const float* dsd, int rows, int L, int family, float* dlv,
                       void* stream) {
-  if (!lv || !sd || !dsd || !dlv || rows < 0 || L < 1 || family < 0 || family > 1) return MVK_EINVAL;
+  if (!lv || !sd || !dsd || !dlv || rows < 0 || L < 1 || family < 0 || family > 2) return MVK_EINVAL;
   if (rows == 0) return MVK_OK;
   hipLaunchKernelGGL(std_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, mvk_stream(stream), lv, sd, dsd, rows, L,
                      family, dlv);
@@ -352,9 +437,9 @@ int mvk_mmvae_std_bwd(const float* lv, const float* sd, const float* dsd, int ro
 int mvk_mmvae_latent_fwd(const float* const* mu, const float* const* sd, const float* const* noise,
                          const uint8_t* const* masks, const float* prior_mean, const float* prior_sd, int M, int K,
                          int B, int L, int family, float* const* z, float* const* lpz, float* const* lqz,
-                         float* const* lq_all, void* stream) {
+                         float* const* lq_all, int shared_dims, float* const* lqw, void* stream) {
   if (!mu || !sd || !noise || !prior_mean || !prior_sd || !z || !lpz || !lqz || !lq_all || M < 1 || M > MAXM ||
-      K < 1 || L < 1 || family < 0 || family > 1)
+      K < 1 || L < 1 || family < 0 || family > 1 || shared_dims < 1 || shared_dims > L || (shared_dims < L && !lqw))
     return MVK_EINVAL;
   if (B <= 0) return B == 0 ? MVK_OK : MVK_EINVAL;
   MmPtrs p{};
@@ -368,17 +453,19 @@ int mvk_mmvae_latent_fwd(const float* const* mu, const float* const* sd, const f
     p.lpz[m] = lpz[m];
     p.lqz[m] = lqz[m];
     p.lq_all[m] = lq_all[m];
+    p.lqw[m] = lqw ? lqw[m] : nullptr;
   }
   long long rows = (long long)M * K * B;
   hipLaunchKernelGGL(latent_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, mvk_stream(stream), p,
-                     prior_mean, prior_sd, M, K, B, L, family);
+                     prior_mean, prior_sd, M, K, B, L, shared_dims, family);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }
 
 int mvk_mmvae_objective_fwd(const float* const* rows, const float* const* lpz, const float* const* lqz,
                             const uint8_t* const* masks, int M, int K, int B, int dreg, float* const* lw_out,
-                            float* const* w, float* const* rowcoef, float* loss, void* stream) {
+                            float* const* w, float* const* rowcoef, float* loss, const float* const* lqw, float beta,
+                            void* stream) {
   if (!rows || !lpz || !lqz || !lw_out || !w || !rowcoef || !loss || M < 1 || M > MAXM || K < 1 || B < 1) return MVK_EINVAL;
   ObjPtrs p{};
   for (int m = 0; m < M; ++m) {
@@ -390,11 +477,12 @@ int mvk_mmvae_objective_fwd(const float* const* rows, const float* const* lpz, c
     }
     p.lpz[m] = lpz[m];
     p.lqz[m] = lqz[m];
+    p.lqw[m] = lqw ? lqw[m] : nullptr;
     p.mask[m] = masks ? masks[m] : nullptr;
     p.lw[m] = lw_out[m];
     p.w[m] = w[m];
   }
-  hipLaunchKernelGGL(objective_kernel, dim3(1), dim3(1024), 0, mvk_stream(stream), p, M, K, B, dreg, loss);
+  hipLaunchKernelGGL(objective_kernel, dim3(1), dim3(1024), 0, mvk_stream(stream), p, M, K, B, dreg, beta, loss);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }
@@ -404,9 +492,9 @@ int mvk_mmvae_latent_bwd(const float* const* mu, const float* const* sd, const f
                          const float* prior_sd, const float* const* w, const float* const* lq_all,
                          const float* const* lqz, const float* const* dz_dec, int M, int K, int B, int L, int family,
                          int dreg, const float* gscale, float* const* dmu, float* const* dsd, float* dprior_sd,
-                         void* stream) {
+                         int shared_dims, float beta, void* stream) {
   if (!mu || !sd || !noise || !z || !prior_mean || !prior_sd || !w || !lq_all || !lqz || !dz_dec || !dmu || !dsd ||
-      M < 1 || M > MAXM || K < 1 || L < 1 || family < 0 || family > 1)
+      M < 1 || M > MAXM || K < 1 || L < 1 || family < 0 || family > 1 || shared_dims < 1 || shared_dims > L)
     return MVK_EINVAL;
   if (B <= 0) return B == 0 ? MVK_OK : MVK_EINVAL;
   BwdPtrs p{};
@@ -430,7 +518,7 @@ int mvk_mmvae_latent_bwd(const float* const* mu, const float* const* sd, const f
     if (hipMemsetAsync(dprior_sd, 0, sizeof(float) * L, s) != hipSuccess) return MVK_ELAUNCH;
   }
   hipLaunchKernelGGL(latent_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, s, p, prior_mean, prior_sd, M, K, B, L,
-                     family, dreg, gscale, dprior_sd);
+                     shared_dims, beta, family, dreg, gscale, dprior_sd);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }

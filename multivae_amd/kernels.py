@@ -322,6 +322,58 @@ class MLPEncoderFn(Function):
         return (dx, *grads)
 
 
+class MLPHeadsFn(Function):
+    """x -> [Linear+ReLU]*n -> n_heads linear heads (Encoder_VAE_MLP_Style: embedding, log_var, style_embedding,
+    style_log_var; default_architectures.py:75-141).  params = (W0,b0, ..., Wh1,bh1, ..., Whn,bhn)."""
+
+    @staticmethod
+    def forward(ctx, x, n_heads, *params):
+        n_layers = (len(params) - 2 * n_heads) // 2
+        K0 = params[0].shape[1]
+        x2 = _c(x.reshape(-1, K0))
+        acts = [x2]
+        h = x2
+        for i in range(n_layers):
+            h = linear_fwd(h, params[2 * i], params[2 * i + 1], RELU)
+            acts.append(h)
+        outs = tuple(linear_fwd(h, params[2 * (n_layers + j)], params[2 * (n_layers + j) + 1], NONE)
+                     for j in range(n_heads))
+        ctx.save_for_backward(*acts, *params)
+        ctx.n_layers, ctx.n_heads = n_layers, n_heads
+        ctx.x_shape = x.shape
+        return outs
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *douts):
+        n, nh = ctx.n_layers, ctx.n_heads
+        saved = ctx.saved_tensors
+        acts, params = saved[: n + 1], saved[n + 1 :]
+        h = acts[-1]
+        grads = [None] * len(params)
+        prev_src, prev_act = (h, RELU) if n > 0 else (None, NONE)
+        need_dx = ctx.needs_input_grad[0]
+        dh = None
+        for j in range(nh):
+            w, b = params[2 * (n + j)], params[2 * (n + j) + 1]
+            dy = _c(douts[j])
+            grads[2 * (n + j)], grads[2 * (n + j) + 1] = linear_bwd_weight(dy, h, w, b)
+            if n > 0 or need_dx:  # pre-activation gradient of the last hidden layer: all heads, ReLU' in the epilogue
+                if dh is None:
+                    dh = linear_bwd_data(dy, w, prev_out=prev_src, prev_act=prev_act)
+                else:
+                    linear_bwd_data(dy, w, prev_out=prev_src, prev_act=prev_act, out=dh, accumulate=True)
+        for i in range(n - 1, -1, -1):
+            w, inp = params[2 * i], acts[i]
+            grads[2 * i], grads[2 * i + 1] = linear_bwd_weight(dh, inp, w, params[2 * i + 1])
+            if i > 0:
+                dh = linear_bwd_data(dh, w, prev_out=acts[i], prev_act=RELU)
+            elif need_dx:
+                dh = linear_bwd_data(dh, w)
+        dx = dh.reshape(ctx.x_shape) if need_dx else None
+        return (dx, None, *grads)
+
+
 class MLPDecoderFn(Function):
     """z[...,L] -> Linear+ReLU -> Linear+Sigmoid -> reshape(*z.shape[:-1], *input_dim)."""
 
@@ -731,6 +783,9 @@ class MMVAEState:
         self.z = self.lpz = self.lqz = self.lq_all = None
         self.w = self.rowcoef = self.lw = None
         self.gloss = None
+        self.lqw = None          # MMVAE+: log q_c(w_c) rows
+        self.shared_dims = None  # MMVAE+: leading latent dims that enter the mixture (None = all)
+        self.beta = 1.0          # MMVAE+: weight of the latent terms of lw
 
 
 class MMVAELatentFn(Function):
@@ -748,10 +803,12 @@ class MMVAELatentFn(Function):
         state.lpz = [_new((K, B), mus[0]) for _ in range(M)]
         state.lqz = [_new((K, B), mus[0]) for _ in range(M)]
         state.lq_all = [_new((M, K, B), mus[0]) for _ in range(M)]
+        Ls = L if state.shared_dims is None else int(state.shared_dims)
+        state.lqw = [_new((K, B), mus[0]) for _ in range(M)] if Ls < L else None
         marr = ptr_array(masks) if masks is not None else None
         call("mvk_mmvae_latent_fwd", ptr_array(mus), ptr_array(sds), ptr_array(noises), marr, ptr(prior_mean),
              ptr(prior_std), M, K, B, L, family, ptr_array(zs), ptr_array(state.lpz), ptr_array(state.lqz),
-             ptr_array(state.lq_all), stream_ptr())
+             ptr_array(state.lq_all), Ls, ptr_array(state.lqw) if state.lqw is not None else None, stream_ptr())
         state.z = zs
         ctx.save_for_backward(prior_mean, prior_std, *mus, *sds)
         ctx.state, ctx.noises, ctx.masks = state, noises, masks
@@ -775,8 +832,39 @@ class MMVAELatentFn(Function):
         call("mvk_mmvae_latent_bwd", ptr_array(mus), ptr_array(sds), ptr_array(ctx.noises), ptr_array(st.z), marr,
              ptr(prior_mean), ptr(prior_std), ptr_array(st.w), ptr_array(st.lq_all), ptr_array(st.lqz),
              ptr_array(dzs), M, K, B, L, ctx.family, ctx.dreg, ptr(st.gloss), ptr_array(dmus), ptr_array(dsds),
-             ptr(dprior), stream_ptr())
+             ptr(dprior), L if st.shared_dims is None else int(st.shared_dims), float(st.beta), stream_ptr())
         return (None, None, None, None, None, None, dprior.view(1, L), *dmus, *dsds)
+
+
+class MMVAEPlusCrossLatentFn(Function):
+    """z_c [K,B,D] (= [u_c, w_c]), the target modality's private prior std [S], noise [K,B,S] -> [u_c, w ~ prior_r]
+    (mmvaePlus_model.py:152-172)."""
+
+    @staticmethod
+    def forward(ctx, z, prior_std, noise, Ls, family):
+        z = _c(z)
+        prior_std = _c(prior_std.reshape(-1))
+        noise = _c(noise)
+        K, B, D = z.shape
+        zc = torch.empty_like(z)
+        call("mvk_mmvaeplus_cross_latent_fwd", ptr(z), ptr(prior_std), ptr(noise), K * B, D, Ls, family, ptr(zc),
+             stream_ptr())
+        ctx.save_for_backward(noise)
+        ctx.dims = (K, B, D, Ls, family)
+        ctx.prior_shape = None
+        return zc
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dzc):
+        (noise,) = ctx.saved_tensors
+        K, B, D, Ls, family = ctx.dims
+        dzc = _c(dzc)
+        dz = torch.empty_like(dzc)
+        dprior = _new((1, D - Ls), dzc)
+        call("mvk_mmvaeplus_cross_latent_bwd", ptr(dzc), ptr(noise), K * B, D, Ls, family, ptr(dz), ptr(dprior),
+             stream_ptr())
+        return dz, dprior, None, None, None
 
 
 class MMVAEObjectiveFn(Function):
@@ -808,7 +896,8 @@ class MMVAEObjectiveFn(Function):
         masks = spec["masks"]
         marr = ptr_array(masks) if masks[0] is not None else None
         call("mvk_mmvae_objective_fwd", ptr_array(rows), ptr_array(state.lpz), ptr_array(state.lqz), marr, M, K, B,
-             int(dreg), ptr_array(state.lw), ptr_array(state.w), ptr_array(state.rowcoef), ptr(loss), stream_ptr())
+             int(dreg), ptr_array(state.lw), ptr_array(state.w), ptr_array(state.rowcoef), ptr(loss),
+             ptr_array(state.lqw) if state.lqw is not None else None, float(state.beta), stream_ptr())
         ctx.save_for_backward(*recons)
         ctx.state, ctx.spec, ctx.M = state, spec, M
         return loss

@@ -2,8 +2,9 @@ from .base import BaseAEConfig, BaseMultiVAE, BaseMultiVAEConfig, ModelOutput
 from .jmvae import JMVAE, JMVAEConfig
 from .joint_models import BaseJointModel, BaseJointModelConfig
 from .mmvae import MMVAE, MMVAEConfig
+from .mmvaePlus import MMVAEPlus, MMVAEPlusConfig
 from .mopoe import MoPoE, MoPoEConfig
 from .mvtcae import MVTCAE, MVTCAEConfig
 
 __all__ = ["BaseAEConfig", "BaseMultiVAE", "BaseMultiVAEConfig", "ModelOutput", "MMVAE", "MMVAEConfig", "MoPoE",
-           "MoPoEConfig", "MVTCAE", "MVTCAEConfig", "JMVAE", "JMVAEConfig", "BaseJointModel", "BaseJointModelConfig"]
+           "MoPoEConfig", "MVTCAE", "MVTCAEConfig", "JMVAE", "JMVAEConfig", "BaseJointModel", "BaseJointModelConfig", "MMVAEPlus", "MMVAEPlusConfig"]

@@ -30,3 +30,13 @@ class BaseJointEncoder(nn.Module):
 
     def forward(self, x: dict):
         raise NotImplementedError()
+
+
+class BaseMultilatentEncoder(BaseEncoder):
+    """Encoder plugin base for models with a shared and a private latent per modality (MMVAE+): forward returns a
+    ModelOutput with `embedding`, `log_covariance`, `style_embedding`, `style_log_covariance`."""
+
+    def __init__(self):
+        BaseEncoder.__init__(self)
+        self.latent_dim = None
+        self.style_dim = None

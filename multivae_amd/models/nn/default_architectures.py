@@ -14,7 +14,7 @@ from torch import nn
 from ... import kernels
 from ..base.base_config import BaseAEConfig
 from ..base.base_utils import ModelOutput
-from .base_architectures import BaseDecoder, BaseEncoder, BaseJointEncoder
+from .base_architectures import BaseDecoder, BaseEncoder, BaseJointEncoder, BaseMultilatentEncoder
 
 
 class Encoder_VAE_MLP(BaseEncoder):
@@ -58,6 +58,51 @@ class Decoder_AE_MLP(BaseDecoder):
         l0, l1 = self.layers[0][0], self.layers[1][0]
         out = kernels.MLPDecoderFn.apply(z, l0.weight, l0.bias, l1.weight, l1.bias, self.input_dim)
         return ModelOutput(reconstruction=out)
+
+
+class Encoder_VAE_MLP_Style(BaseMultilatentEncoder):
+    """`default_architectures.py:75-141`: Linear(prod D, 512)+ReLU and four linear heads, one autograd node."""
+
+    def __init__(self, args):
+        BaseMultilatentEncoder.__init__(self)
+        self.input_dim = args.input_dim
+        self.latent_dim = args.latent_dim
+        self.style_dim = args.style_dim
+        layers = nn.ModuleList()
+        layers.append(nn.Sequential(nn.Linear(int(np.prod(args.input_dim)), 512), nn.ReLU()))
+        self.layers = layers
+        self.depth = len(layers)
+        self.embedding = nn.Linear(512, self.latent_dim)
+        self.log_var = nn.Linear(512, self.latent_dim)
+        self.style_embedding = nn.Linear(512, self.style_dim)
+        self.style_log_var = nn.Linear(512, self.style_dim)
+
+    def forward(self, x, output_layer_levels: List[int] = None):
+        if output_layer_levels is not None:
+            raise NotImplementedError("output_layer_levels is not supported on the fused HIP path")
+        params = []
+        for seq in self.layers:
+            params += [seq[0].weight, seq[0].bias]
+        for head in (self.embedding, self.log_var, self.style_embedding, self.style_log_var):
+            params += [head.weight, head.bias]
+        mu, lv, smu, slv = kernels.MLPHeadsFn.apply(x, 4, *params)
+        return ModelOutput(embedding=mu, log_covariance=lv, style_embedding=smu, style_log_covariance=slv)
+
+
+def BaseDictEncoders_MultiLatents(input_dims: dict, latent_dim: int, modality_dims: dict):
+    encoders = nn.ModuleDict()
+    for mod in input_dims:
+        encoders[mod] = Encoder_VAE_MLP_Style(BaseAEConfig(input_dim=input_dims[mod], latent_dim=latent_dim,
+                                                           style_dim=modality_dims[mod]))
+    return encoders
+
+
+def BaseDictDecodersMultiLatents(input_dims: dict, latent_dim: int, modality_dims: dict):
+    decoders = nn.ModuleDict()
+    for mod in input_dims:
+        decoders[mod] = Decoder_AE_MLP(BaseAEConfig(input_dim=input_dims[mod],
+                                                    latent_dim=latent_dim + modality_dims[mod]))
+    return decoders
 
 
 class MultipleHeadJointEncoder(BaseJointEncoder):

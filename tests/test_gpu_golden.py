@@ -24,8 +24,8 @@ def check(a, b, what, rtol=RTOL):
 
 
 def build_model(cfg, dims):
-    from multivae_amd.models import (JMVAE, MMVAE, MVTCAE, JMVAEConfig, MMVAEConfig, MoPoE, MoPoEConfig,
-                                     MVTCAEConfig)
+    from multivae_amd.models import (JMVAE, MMVAE, MVTCAE, JMVAEConfig, MMVAEConfig, MMVAEPlus, MMVAEPlusConfig,
+                                     MoPoE, MoPoEConfig, MVTCAEConfig)
     from multivae_amd.models.base.base_config import BaseAEConfig
     from multivae_amd.models.nn.default_architectures import Decoder_AE_MLP, Encoder_VAE_MLP
     from multivae_amd.models.nn.svhn import Decoder_VAE_SVHN, Encoder_VAE_SVHN
@@ -34,7 +34,7 @@ def build_model(cfg, dims):
     common = dict(n_modalities=len(dims), latent_dim=L, input_dims=dict(dims),
                   uses_likelihood_rescaling=cfg["rescaling"])
     enc = dec = None
-    if cfg["arch"] != "tiny" and cfg["model"] not in ("MVTCAE", "JMVAE"):
+    if cfg["arch"] != "tiny" and cfg["model"] not in ("MVTCAE", "JMVAE", "MMVAEPlus"):
         enc = dict(mnist=Encoder_VAE_MLP(BaseAEConfig(latent_dim=L, input_dim=(1, 28, 28))),
                    svhn=Encoder_VAE_SVHN(BaseAEConfig(latent_dim=L, input_dim=(3, 32, 32))))
         dec = dict(mnist=Decoder_AE_MLP(BaseAEConfig(latent_dim=L, input_dim=(1, 28, 28))),
@@ -44,6 +44,10 @@ def build_model(cfg, dims):
         return MoPoE(mc, enc, dec)
     if cfg["model"] == "MVTCAE":
         return MVTCAE(MVTCAEConfig(alpha=cfg["alpha"], beta=cfg["beta"], **common))
+    if cfg["model"] == "MMVAEPlus":
+        return MMVAEPlus(MMVAEPlusConfig(K=cfg["K"], modalities_specific_dim=cfg["S"], beta=cfg["beta"],
+                                         prior_and_posterior_dist=cfg["family"], loss=cfg["loss"],
+                                         learn_shared_prior=cfg["learn_shared_prior"], **common))
     if cfg["model"] == "JMVAE":
         return JMVAE(JMVAEConfig(alpha=cfg["alpha"], beta=cfg["beta"], warmup=cfg["warmup"],
                                  decoders_dist=cfg.get("dists"), **common))
@@ -59,7 +63,8 @@ def prep(name):
     dims, data, masks, sd_np = G.build_inputs(cfg)
     model = build_model(cfg, dims)
     missing = model.load_state_dict({k: G.t(v) for k, v in sd_np.items()}, strict=False)
-    assert not missing.unexpected_keys and all(k.startswith("prior_") for k in missing.missing_keys), missing
+    assert not missing.unexpected_keys and all(k.startswith(("prior_", "mean_priors.", "logvars_priors."))
+                                               for k in missing.missing_keys), missing
     d = torch.device("cuda:0")
     model = model.to(d).train()
     kw = dict(data={m: G.t(v).to(d) for m, v in data.items()})
@@ -78,7 +83,9 @@ def oracle_full_grads(cfg, dims, data, masks, sd_np, a):
     tdata = {m: G.t(v) for m, v in data.items()}
     tmasks = None if masks is None else {m: G.t(v) for m, v in masks.items()}
     names = cfg["names"]
-    if cfg["arch"] == "tiny" or cfg["model"] in ("MVTCAE", "JMVAE"):
+    if cfg["model"] == "MMVAEPlus":
+        enc_f, dec_f = nets.build_default_mlp_multilatent(sd, dims)
+    elif cfg["arch"] == "tiny" or cfg["model"] in ("MVTCAE", "JMVAE"):
         enc_f, dec_f = nets.build_default_mlp(sd, dims)
     else:
         enc_f, dec_f = nets.build_mnist_svhn(sd, cfg["L"])
@@ -88,6 +95,17 @@ def oracle_full_grads(cfg, dims, data, masks, sd_np, a):
         e = {m: enc_f[m](tdata[m]) for m in names}
         o = elbo.mopoe_forward(e, tdata, dec_f, G.t(a["eps"]), names=names, beta=cfg["beta"], rescale=resc,
                                dists=cfg["dists"], masks=tmasks, choice=G.t(a["choice"]) if "choice" in a else None)
+    elif cfg["model"] == "MMVAEPlus":
+        mods = [m for m in names if ("lws/" + m) in a]
+        plv = {k.split("/")[1]: G.t(v).clone().requires_grad_(True) for k, v in a.items()
+               if k.startswith("prior_logvar/")}
+        e = {m: enc_f[m](tdata[m]) for m in mods}
+        noise = {c: {k.split("/")[2]: G.t(v) for k, v in a.items() if k.startswith(f"noise/{c}/")} for c in mods}
+        o = elbo.mmvaeplus_forward(e, tdata, dec_f, noise, names=names, K=cfg["K"], family=cfg["family"],
+                                   loss=cfg["loss"], beta=cfg["beta"], prior_logvars=plv, rescale=resc, masks=tmasks)
+        for k, v in plv.items():
+            if k != "shared" or cfg["learn_shared_prior"]:
+                extra["logvars_priors." + k] = v
     elif cfg["model"] == "JMVAE":
         e = {m: enc_f[m](tdata[m]) for m in names}
         o = elbo.jmvae_forward(nets.joint_mlp_encoder(sd, dims, tdata), e, tdata, dec_f, G.t(a["eps"]), names=names,
@@ -161,6 +179,30 @@ def test_mvtcae_golden(name):
         # exact zeros for the rows of a missing modality flow back to its encoder input layer only through
         # available rows; a fully missing modality gives exactly zero encoder gradients (tests/test_mvtcae.py:160)
         pass
+
+
+@pytest.mark.parametrize("name", G.MMVAEPLUS_CASES)
+def test_mmvaeplus_golden(name):
+    """MMVAEPlus.forward (mmvaePlus_model.py:122-362) on the MMVAE kernels with a split latent: loss, importance
+    weights, the shared / private samples, every parameter gradient including the learnable prior log-variances."""
+    cfg, a, dims, data, masks, sd_np, model, inputs, d = prep(name)
+    L = cfg["L"]
+    with torch.no_grad():
+        for k, v in a.items():
+            if k.startswith("prior_logvar/"):
+                model.logvars_priors[k.split("/")[1]].copy_(G.t(v).to(d))
+    mods = [m for m in cfg["names"] if ("lws/" + m) in a]
+    noise = {c: {k.split("/")[2]: G.t(v).to(d) for k, v in a.items() if k.startswith(f"noise/{c}/")} for c in mods}
+    out = model(inputs, noise=noise, detailed_output=True)
+    check(a["loss"], out.loss, "loss")
+    for m in mods:
+        check(a["us/" + m], out.zss[m][..., :L], "u " + m)
+        check(a["ws/" + m], out.zss[m][..., L:], "w " + m)
+        check(a["lws/" + m], out.lws[m], "lw " + m)
+    out.loss.backward()
+    o, og = oracle_full_grads(cfg, dims, data, masks, sd_np, a)
+    check(o["loss"].detach().numpy(), out.loss, "loss vs oracle")
+    compare_grads(model, og, a, rtol=5e-4 if cfg["K"] >= 10 else RTOL)  # K=10: see test_mmvae_golden
 
 
 @pytest.mark.parametrize("name", G.JMVAE_CASES)
@@ -247,3 +289,28 @@ def test_jmvae_encode_paths():
     check(mu.numpy(), model.encode(inputs, cond_mod=["a", "c"], return_mean=True).z, "subset mean")
     with pytest.raises(AttributeError):
         model.encode(inputs, cond_mod="zzz")
+
+
+def test_mmvaeplus_encode_paths():
+    """MMVAEPlus.encode (mmvaePlus_model.py:364-456): shared latent + one private latent per modality (own posterior for
+    the conditioning modalities, prior for the others)."""
+    from multivae_amd.data.datasets.base import DatasetOutput
+    from multivae_amd.models import MMVAEPlus, MMVAEPlusConfig
+
+    d = torch.device("cuda:0")
+    dims = dict(a=(2, 3), b=(7,), c=(4,))
+    torch.manual_seed(0)
+    model = MMVAEPlus(MMVAEPlusConfig(n_modalities=3, latent_dim=6, input_dims=dims, modalities_specific_dim=4)).to(d)
+    inputs = DatasetOutput(data={m: torch.rand((5,) + s, device=d) for m, s in dims.items()})
+    out = model.encode(inputs)
+    assert out.z.shape == (5, 6) and not out.one_latent_space
+    assert set(out.modalities_z) == set(dims) and all(v.shape == (5, 4) for v in out.modalities_z.values())
+    out = model.encode(inputs, cond_mod=["a"], N=3)
+    assert out.z.shape == (3, 5, 6) and out.modalities_z["c"].shape == (3, 5, 4)
+    out = model.encode(inputs, cond_mod="b", N=2, flatten=True)
+    assert out.z.shape == (10, 6) and out.modalities_z["a"].shape == (10, 4)
+    mean = model.encode(inputs, cond_mod=["a", "b"], return_mean=True)
+    ea, eb = model.encoders["a"](inputs.data["a"]), model.encoders["b"](inputs.data["b"])
+    assert torch.allclose(mean.z, 0.5 * (ea.embedding + eb.embedding), atol=1e-6)
+    with pytest.raises(AttributeError):
+        MMVAEPlus(MMVAEPlusConfig(n_modalities=3, latent_dim=6, input_dims=dims))  # modalities_specific_dim missing
