@@ -39,6 +39,7 @@ extern "C" {
 #define MVK_ACT_NONE 0
 #define MVK_ACT_RELU 1
 #define MVK_ACT_SIGMOID 2
+#define MVK_ACT_LEAKY02 3 /* LeakyReLU(0.2) (models/nn/mmnist.py:222-246, cub.py:250-293) */
 
 /* latent families of MMVAE — models/mmvae/mmvae_model.py:44-49,66-74 */
 #define MVK_FAMILY_NORMAL 0
@@ -275,7 +276,9 @@ int mvk_bf3_to_f32(const void* planes, int64_t n, float* x, void* stream);
 int mvk_pack_conv4s2_weight(const float* Wref, int Cv, int Cu, float* Wdown, int ld_down, int col_off,
                             float* Wup, void* stream);
 /* All weight packs of one network in ONE launch.  kind 0: as mvk_pack_conv4s2_weight (Wdown and/or Wup, ld_down
- * <= 0 means Cv); kind 1: as mvk_pack_unflatten_weight with Cv = Cin, Cu = Cout, destination in Wup. */
+ * <= 0 means Cv); kind 1: as mvk_pack_unflatten_weight with Cv = Cin, Cu = Cout, destination in Wup; kind 2: 3x3
+ * convolution weight Wref[Cv = Cout][Cu = Cin][3][3] -> Wdown[(tap*Cu + cu)][cv] (forward operand of mvk_conv3x3) and/or
+ * Wup[((8-tap)*Cv + cv)][cu] (its backward-data operand: flipped window, channels swapped). */
 #define MVK_PACK_MAX 8
 typedef struct mvk_pack_desc {
   const float* Wref;
@@ -293,6 +296,23 @@ int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U
                    int64_t ws_floats, int fmt, void* stream);
 int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv,
                       int u_nchw, const float* u_act_src, int u_act, float* ws, int64_t ws_floats, void* stream);
+
+/* 3x3 / stride 1 / pad 1 convolution on NHWC activations — the ResNet blocks of models/nn/mmnist.py:214-366 and
+ * models/nn/cub.py:144-293.  Y[n,H,W,Cout] = act(conv(X[n,H,W,Cin]) + bias) (* src_act'(y_act_src) elementwise), with
+ * Wp the kind-2 pack of mvk_pack_weights.  Backward data is the same launch on the output gradient with the Wup pack
+ * (Cin / Cout swapped); colsum_acc as in mvk_conv4s2_down.  wgrad: dWref[Cout][Cin][3][3] += sum_pos X(gathered) dY. */
+int mvk_conv3x3(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout,
+                int act, const float* y_act_src, int y_src_act, float* colsum_acc, float* ws, int64_t ws_floats,
+                void* stream);
+int mvk_conv3x3_wgrad(const float* X, const float* dY, float* dWref, int n, int H, int W, int Cin, int Cout,
+                      float* ws, int64_t ws_floats, void* stream);
+/* nn.AvgPool2d(3, stride=2, padding=1) (count_include_pad: every window divides by 9) and nn.Upsample(scale_factor=2)
+ * (nearest) on NHWC tensors, forward and backward; out = act(a*x + b*y) (x or y may be NULL). */
+int mvk_avgpool3s2_fwd(const float* x, float* y, int n, int H, int W, int C, void* stream);
+int mvk_avgpool3s2_bwd(const float* dy, float* dx, int n, int H, int W, int C, void* stream);
+int mvk_upsample2_fwd(const float* x, float* y, int n, int H, int W, int C, void* stream);
+int mvk_upsample2_bwd(const float* dy, float* dx, int n, int H, int W, int C, void* stream);
+int mvk_axpby(const float* x, float a, const float* y, float b, int64_t n, int act, float* out, void* stream);
 /* Direct kernel for the 3-channel image-producing layer: U[n,Cu,2h,2w] (NCHW) = act(convT(V) + b), Cu <= 4,
  * reading the reference weight tensor directly (models/nn/svhn.py:58-60). */
 int mvk_conv4s2_up_nchw_small(const float* V, const float* Wref, const float* bias, float* U, int n, int h,

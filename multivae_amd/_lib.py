@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmvk.so")
 
 MVK_OK = 0
 DIST = {"normal": 0, "laplace": 1, "bernoulli": 2}
-ACT = {None: 0, "none": 0, "relu": 1, "sigmoid": 2}
+ACT = {None: 0, "none": 0, "relu": 1, "sigmoid": 2, "leaky_relu_0.2": 3}
 FAMILY = {"normal": 0, "laplace_with_softmax": 1, "normal_with_softplus": 2}  # 2: std kernels only (density = normal)
 MAX_MODALITIES = 8
 
@@ -64,6 +64,13 @@ PROTOTYPES = {
     "mvk_pack_weights": [C.POINTER(PackDesc), _i, _p],
     "mvk_f32_to_bf3": [_p, _i64, _p, _p],
     "mvk_bf3_to_f32": [_p, _i64, _p, _p],
+    "mvk_conv3x3": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i64, _p],
+    "mvk_conv3x3_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i64, _p],
+    "mvk_avgpool3s2_fwd": [_p, _p, _i, _i, _i, _i, _p],
+    "mvk_avgpool3s2_bwd": [_p, _p, _i, _i, _i, _i, _p],
+    "mvk_upsample2_fwd": [_p, _p, _i, _i, _i, _i, _p],
+    "mvk_upsample2_bwd": [_p, _p, _i, _i, _i, _i, _p],
+    "mvk_axpby": [_p, _f, _p, _f, _i64, _i, _p, _p],
     "mvk_conv4s2_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _p],
     "mvk_conv4s2_up_nchw_small": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "mvk_conv4s2_small_up_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],

@@ -31,11 +31,13 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float mvk_act(float v, int act) {
   if (act == MVK_ACT_RELU) return v > 0.f ? v : 0.f;
   if (act == MVK_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+  if (act == MVK_ACT_LEAKY02) return v > 0.f ? v : 0.2f * v;
   return v;
 }
 __device__ __forceinline__ float mvk_act_grad_from_out(float y, int act) {
   if (act == MVK_ACT_RELU) return y > 0.f ? 1.f : 0.f;
   if (act == MVK_ACT_SIGMOID) return y * (1.f - y);
+  if (act == MVK_ACT_LEAKY02) return y > 0.f ? 1.f : 0.2f;  // sign(y) == sign(pre-activation)
   return 1.f;
 }
 

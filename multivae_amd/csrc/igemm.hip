@@ -596,6 +596,74 @@ int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U
   return launch_with_colsum(d, 4, colsum_acc, ws, ws_floats, U, (long long)n * 4 * h * w, mvk_stream(stream));
 }
 
+// ---- 3x3 / stride 1 / pad 1 convolution on NHWC activations (ResNet blocks) --------------------------------------
+// Y[n,H,W,Cout] = act(conv3x3(X[n,H,W,Cin]) + b) (* src_act'(y_act_src));  Wp[(kh*3+kw)*Cin + ci][co].
+// The same launch is the backward-data pass when it is fed the output gradient and the flipped / transposed pack.
+int mvk_conv3x3(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout,
+                int act, const float* y_act_src, int y_src_act, float* colsum_acc, float* ws, int64_t ws_floats,
+                void* stream) {
+  if (!X || !Wp || !Y || n < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return MVK_EINVAL;
+  GemmDesc d{};
+  d.a = AOperand{};
+  d.a.p = X;
+  d.a.kind = A_DOWN;
+  d.a.tw = 3;
+  d.a.mul = 1;
+  d.a.trans = 0;
+  d.a.C = Cin;
+  d.a.H = H;
+  d.a.W = W;
+  d.a.OH = H;
+  d.a.OW = W;
+  d.a.contig_k = 1;
+  d.a.vec4 = (Cin % 4 == 0) && mvk_aligned16(X);
+  plain_b(d.b, Wp, Cout, 1, 9 * Cin, Cout);
+  rowmajor_epi(d.e, Y, Cout);
+  d.e.bias = bias;
+  d.e.bias_mod = Cout;
+  d.e.act = act;
+  d.e.act_src = y_act_src;
+  d.e.src_act = y_src_act;
+  d.M = n * H * W;
+  d.N = Cout;
+  d.K = 9 * Cin;
+  return launch_with_colsum(d, 1, colsum_acc, ws, ws_floats, Y, (long long)n * H * W, mvk_stream(stream));
+}
+
+// dWref[Cout][Cin][3][3] += sum_pos X(gathered) dY
+int mvk_conv3x3_wgrad(const float* X, const float* dY, float* dWref, int n, int H, int W, int Cin, int Cout, float* ws,
+                      int64_t ws_floats, void* stream) {
+  if (!X || !dY || !dWref || n < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return MVK_EINVAL;
+  GemmDesc d{};
+  d.a = AOperand{};
+  d.a.p = X;
+  d.a.kind = A_DOWN;
+  d.a.tw = 3;
+  d.a.mul = 1;
+  d.a.trans = 1;  // GEMM row = (tap, ci), reduction index = position
+  d.a.C = Cin;
+  d.a.H = H;
+  d.a.W = W;
+  d.a.OH = H;
+  d.a.OW = W;
+  d.a.contig_k = 0;
+  d.a.vec4 = (Cin % 4 == 0) && mvk_aligned16(X);
+  plain_b(d.b, dY, Cout, 1, n * H * W, Cout);
+  d.e = Epilogue{};
+  d.e.out = dWref;
+  d.e.kind = E_CONVREF;
+  d.e.taps = 9;
+  d.e.bias_mod = 1;
+  d.e.atomic = 1;
+  d.e.Cu = Cin;
+  d.e.OH = H;
+  d.e.OW = W;
+  d.M = 9 * Cin;
+  d.N = Cout;
+  d.K = n * H * W;
+  return launch_splitk(d, ws, ws_floats, 1024, mvk_stream(stream));
+}
+
 int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv,
                       int u_nchw, const float* u_act_src, int u_act, float* ws, int64_t ws_floats, void* stream) {
   if (!U || !V || !dWref || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0) return MVK_EINVAL;

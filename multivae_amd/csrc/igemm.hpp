@@ -16,6 +16,8 @@
 namespace mvk {
 
 enum AKind { A_PLAIN = 0, A_DOWN = 1, A_DOWN_NCHW = 2, A_UP = 3 };
+// A_DOWN also covers every "same grid or strided, zero padded by 1" window through (tw, mul): 4x4/stride 2 (tw = 4,
+// mul = 2) and 3x3/stride 1 (tw = 3, mul = 1): input row = mul * i - 1 + kh, kh = tap / tw, kw = tap % tw.
 enum EpiKind { E_ROWMAJOR = 0, E_UP = 1, E_CONVREF = 2, E_UNFLATREF = 3, E_UP_NCHW = 4 };
 enum ZMode { Z_NONE = 0, Z_SPLITK = 1, Z_PARITY = 2 };
 
@@ -30,6 +32,7 @@ struct AOperand {
   int OH, OW;       // spatial size enumerating positions
   const float* act_src;  // optional: loaded value *= act'(act_src[same offset])
   int act;
+  int tw, mul;           // A_DOWN / A_DOWN_NCHW window: taps per window row and stride (0 = the 4x4/stride-2 default)
   int bf3;               // operand is stored pre-split: 3 bf16 planes [piece][element], p -> plane 0
   long long plane_bytes; // bytes between planes
 };
@@ -53,6 +56,7 @@ struct Epilogue {
   int src_act;
   int atomic;
   int Cu, OH, OW;  // E_UP / E_CONVREF / E_UNFLATREF geometry
+  int taps;        // E_CONVREF: window size of the reference weight layout (0 = 16)
   float* ws;       // Z_SPLITK: if set, raw partial tiles go to ws[z][m][n] and splitk_reduce_kernel finishes
   float* colsum_part;  // optional: per-workgroup column sums of the stored values -> colsum_part[(z*gridDim.x + bx)*N + n]
 };                     // (vectorised epilogue only; the host finishes them with an ordered reduce: bias gradients)
@@ -111,6 +115,18 @@ __device__ __forceinline__ Pos decode_pos(int pos, int OH, int OW) {
   return p;
 }
 
+// window geometry of the A_DOWN kinds
+__device__ __forceinline__ int a_mul(const AOperand& a) { return a.mul > 0 ? a.mul : 2; }
+__device__ __forceinline__ void a_tap(const AOperand& a, int tap, int& kh, int& kw) {
+  if (a.tw == 3) {
+    kh = tap / 3;
+    kw = tap - 3 * kh;
+  } else {
+    kh = tap >> 2;
+    kw = tap & 3;
+  }
+}
+
 // offset (in floats) of gathered element for position `ps`, reduction index kk=(tap,c); returns validity
 __device__ __forceinline__ bool gather_off(const AOperand& a, const Pos& ps, int kk, int ph, int pw,
                                            long long& off) {
@@ -123,9 +139,10 @@ __device__ __forceinline__ bool gather_off(const AOperand& a, const Pos& ps, int
     off = (((long long)ps.n * a.H + oh) * a.W + ow) * a.C + c;
     return (oh >= 0) & (oh < a.H) & (ow >= 0) & (ow < a.W);
   }
-  int kh = tap >> 2, kw = tap & 3;
-  int h = 2 * ps.i - 1 + kh;
-  int w = 2 * ps.j - 1 + kw;
+  int kh, kw;
+  a_tap(a, tap, kh, kw);
+  int h = a_mul(a) * ps.i - 1 + kh;
+  int w = a_mul(a) * ps.j - 1 + kw;
   bool ok = (h >= 0) & (h < a.H) & (w >= 0) & (w < a.W);
   if (a.kind == A_DOWN)
     off = (((long long)ps.n * a.H + h) * a.W + w) * a.C + c;
@@ -198,7 +215,7 @@ __device__ __forceinline__ void run_epilogue(const GemmDesc& d, f32x16 (&acc)[T:
           } else if (E.kind == E_CONVREF) {
             int tap = m / E.Cu;
             int cu = m - tap * E.Cu;
-            off = ((long long)n * E.Cu + cu) * 16 + tap;
+            off = ((long long)n * E.Cu + cu) * (E.taps > 0 ? E.taps : 16) + tap;
           } else {  // E_UNFLATREF: m = ci, n = (tap, co)
             int tap = n / E.Cu;
             int co = n - tap * E.Cu;
@@ -412,8 +429,10 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_kernel(const GemmDes
             hh = pre_b[u] + ph - (tap >> 1);
             ww = pre_c[u] + pw - (tap & 1);
           } else {
-            hh = 2 * pre_b[u] - 1 + (tap >> 2);
-            ww = 2 * pre_c[u] - 1 + (tap & 3);
+            int kh, kw;
+            a_tap(A, tap, kh, kw);
+            hh = a_mul(A) * pre_b[u] - 1 + kh;
+            ww = a_mul(A) * pre_c[u] - 1 + kw;
           }
           if (hh >= 0 && hh < A.H && ww >= 0 && ww < A.W) {
             const long long off = (((long long)pre_a[u] * A.H + hh) * A.W + ww) * A.C + c;
@@ -453,8 +472,10 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_kernel(const GemmDes
             pi = t % A.OH;
             pn = t / A.OH;
           }
-          const int hh = 2 * pi - 1 + (pre_a[u] >> 2);
-          const int ww = 2 * pj - 1 + (pre_a[u] & 3);
+          int kh, kw;
+          a_tap(A, pre_a[u], kh, kw);
+          const int hh = a_mul(A) * pi - 1 + kh;
+          const int ww = a_mul(A) * pj - 1 + kw;
           if (hh >= 0 && hh < A.H && ww >= 0 && ww < A.W) {
             const long long off = (((long long)pn * A.H + hh) * A.W + ww) * A.C + pre_b[u];
             v = *reinterpret_cast<const float4*>(A.p + off);
@@ -812,7 +833,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const Epilogue E, in
   } else if (E.kind == E_CONVREF) {
     int tap = m / E.Cu;
     int cu = m - tap * E.Cu;
-    off = ((long long)n * E.Cu + cu) * 16 + tap;
+    off = ((long long)n * E.Cu + cu) * (E.taps > 0 ? E.taps : 16) + tap;
   } else {  // E_UNFLATREF
     int tap = n / E.Cu;
     int co = n - tap * E.Cu;

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 3 : 2) void igemm_bf_k
         const int r = m0 + idx / 4;  // unit = (row, k octet)
         if (r < d.M) {
           Pos ps = decode_pos(r, A.OH, A.OW);
-          const int mul = (A.kind == A_UP) ? 1 : 2;
+          const int mul = (A.kind == A_UP) ? 1 : a_mul(A);
           pb[u] = mul * ps.i;
           pc[u] = mul * ps.j;
           pa[u] = (((ps.n * A.H + pb[u]) * A.W + pc[u]) * A.C + (idx % 4) * 8) * 2;  // bytes (bf16)
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 3 : 2) void igemm_bf_k
       pb[u] = -(1 << 20);  // invalid row: every bounds test fails
       if (r < d.M) {
         Pos ps = decode_pos(r, A.OH, A.OW);
-        const int mul = (A.kind == A_UP) ? 1 : 2;
+        const int mul = (A.kind == A_UP) ? 1 : a_mul(A);
         pb[u] = mul * ps.i;
         pc[u] = mul * ps.j;
         pa[u] = (((ps.n * A.H + pb[u]) * A.W + pc[u]) * A.C + (idx % 8) * 4) * 4;
@@ -257,8 +257,10 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 3 : 2) void igemm_bf_k
         const int tap = r / A.C;
         pa[u] = tap;
         pb[u] = r - tap * A.C;
-        col_th = (tap >> 2) - 1;
-        col_tw = (tap & 3) - 1;
+        int kh, kw;
+        a_tap(A, tap, kh, kw);
+        col_th = kh - 1;
+        col_tw = kw - 1;
         col_ch = pb[u];
       }
     }
@@ -339,8 +341,10 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 3 : 2) void igemm_bf_k
         dh = ph - (tap >> 1);
         dw = pw - (tap & 1);
       } else {
-        dh = (tap >> 2) - 1;
-        dw = (tap & 3) - 1;
+        int kh_, kw_;
+        a_tap(A, tap, kh_, kw_);
+        dh = kh_ - 1;
+        dw = kw_ - 1;
       }
       if (k0 >= kend) dh = -(1 << 20);
       const int delta = ((dh * A.W + dw) * A.C + c0) * 2;
@@ -360,8 +364,10 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 3 : 2) void igemm_bf_k
         dh = ph - (tap >> 1);
         dw = pw - (tap & 1);
       } else {
-        dh = (tap >> 2) - 1;
-        dw = (tap & 3) - 1;
+        int kh_, kw_;
+        a_tap(A, tap, kh_, kw_);
+        dh = kh_ - 1;
+        dw = kw_ - 1;
       }
       if (k0 >= kend) dh = -(1 << 20);  // prefetch past the end: all out of range
       const int delta = ((dh * A.W + dw) * A.C + c0) * 4;
@@ -376,12 +382,12 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 3 : 2) void igemm_bf_k
         const int pj0 = pos0 & (A.OW - 1);
         const int t = pos0 >> ow_sh;
         const int pi = t & (A.OH - 1), pn = t >> oh_sh;
-        const int hh = 2 * pi + col_th;
+        const int hh = a_mul(A) * pi + col_th;
         const bool hok = (unsigned)hh < (unsigned)A.H;
         const int rowoff = (pn * A.H + hh) * A.W * A.C + col_ch;
 #pragma unroll
         for (int u = 0; u < T::NA4; ++u) {
-          const int ww = 2 * (pj0 + u) + col_tw;
+          const int ww = a_mul(A) * (pj0 + u) + col_tw;
           const bool ok = hok && (unsigned)ww < (unsigned)A.W && (pos0 + u) < kend;
           ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sel(ok, (rowoff + ww * A.C) * 4), 0, 0);
         }
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 3 : 2) void igemm_bf_k
           const int pj = pos % A.OW;
           const int t = pos / A.OW;
           const int pi = t % A.OH, pn = t / A.OH;
-          const int hh = 2 * pi + col_th, ww = 2 * pj + col_tw;
+          const int hh = a_mul(A) * pi + col_th, ww = a_mul(A) * pj + col_tw;
           const bool ok = pos < kend && (unsigned)hh < (unsigned)A.H && (unsigned)ww < (unsigned)A.W;
           ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sel(ok, (((pn * A.H + hh) * A.W + ww) * A.C + col_ch) * 4), 0, 0);
         }

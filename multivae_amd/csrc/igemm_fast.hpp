@@ -173,10 +173,12 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
         dh = ph - (tap >> 1);
         dw = pw - (tap & 1);
       } else {
-        dh = (tap >> 2) - 1;
-        dw = (tap & 3) - 1;
+        int kh, kw;
+        a_tap(A, tap, kh, kw);
+        dh = kh - 1;
+        dw = kw - 1;
       }
-      const int mul = (A.kind == A_UP) ? 1 : 2;
+      const int mul = (A.kind == A_UP) ? 1 : a_mul(A);
 #pragma unroll
       for (int u = 0; u < T::NA4; ++u) {
         const int idx = tid + u * 256;
@@ -208,7 +210,9 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
           pi = t % A.OH;
           pn = t / A.OH;
         }
-        const int hh = 2 * pi - 1 + (pa[u] >> 2), ww = 2 * pj - 1 + (pa[u] & 3);
+        int kh, kw;
+        a_tap(A, pa[u], kh, kw);
+        const int hh = a_mul(A) * pi - 1 + kh, ww = a_mul(A) * pj - 1 + kw;
         const bool ok = pa[u] >= 0 && pos < kend && hh >= 0 && hh < A.H && ww >= 0 && ww < A.W;
         const int off = ok ? (((pn * A.H + hh) * A.W + ww) * A.C + pb[u]) * 4 : OOB;
         ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);

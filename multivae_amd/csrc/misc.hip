@@ -32,6 +32,18 @@ struct PackJobs {
 };
 __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs jobs) {
   const mvk_pack_desc& d = jobs.j[blockIdx.y];
+  if (d.kind == 2) {  // 3x3: Wref[cv][cu][3][3] -> Wdown[(tap*Cu + cu)][cv] (forward), Wup[((8-tap)*Cv + cv)][cu] (bwd data)
+    const int total9 = d.Cv * d.Cu * 9;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total9; idx += gridDim.x * 256) {
+      const int tap = idx % 9;
+      const int cu = (idx / 9) % d.Cu;
+      const int cv = (idx / 9) / d.Cu;
+      const float v = d.Wref[idx];
+      if (d.Wdown) d.Wdown[(long long)(tap * d.Cu + cu) * d.ld_down + d.col_off + cv] = v;
+      if (d.Wup) d.Wup[(long long)((8 - tap) * d.Cv + cv) * d.Cu + cu] = v;
+    }
+    return;
+  }
   const int total = d.Cv * d.Cu * 16;
   for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
     const int tap = idx & 15;
@@ -243,7 +255,7 @@ int mvk_pack_weights(const mvk_pack_desc* jobs, int n, void* stream) {
   int maxtot = 0;
   for (int i = 0; i < n; ++i) {
     const mvk_pack_desc& d = jobs[i];
-    if (!d.Wref || d.Cv <= 0 || d.Cu <= 0 || (d.kind != 0 && d.kind != 1) || (!d.Wdown && !d.Wup) ||
+    if (!d.Wref || d.Cv <= 0 || d.Cu <= 0 || d.kind < 0 || d.kind > 2 || (!d.Wdown && !d.Wup) ||
         (d.kind == 1 && !d.Wup))
       return MVK_EINVAL;
     pj.j[i] = d;
@@ -408,6 +420,148 @@ int mvk_bf3_to_f32(const void* planes, int64_t n, float* x, void* stream) {
   if (n == 0) return MVK_OK;
   hipLaunchKernelGGL(bf3_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, mvk_stream(stream),
                      static_cast<const unsigned short*>(planes), (long long)n, x);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// ResNet helpers on NHWC tensors: AvgPool2d(3, 2, 1) (count_include_pad), nearest Upsample(2), out = a x + b y
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void avgpool3s2_fwd_kernel(const float* __restrict__ x, int n, int H, int W, int C,
+                                                             float* __restrict__ y) {
+  const int OH = (H + 1) / 2, OW = (W + 1) / 2;  // floor((H + 2 - 3) / 2) + 1
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)n * OH * OW * C) return;
+  const int c = (int)(i % C);
+  long long t = i / C;
+  const int ow = (int)(t % OW);
+  t /= OW;
+  const int oh = (int)(t % OH);
+  const long long b = t / OH;
+  float s = 0.f;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int h = 2 * oh - 1 + kh;
+    if (h < 0 || h >= H) continue;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int w = 2 * ow - 1 + kw;
+      if (w < 0 || w >= W) continue;
+      s += x[((b * H + h) * W + w) * C + c];
+    }
+  }
+  y[i] = s * (1.0f / 9.0f);
+}
+
+// dx[b,h,w,c] = (1/9) sum over the output windows that contain (h,w)
+__global__ __launch_bounds__(256) void avgpool3s2_bwd_kernel(const float* __restrict__ dy, int n, int H, int W, int C,
+                                                             float* __restrict__ dx) {
+  const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)n * H * W * C) return;
+  const int c = (int)(i % C);
+  long long t = i / C;
+  const int w = (int)(t % W);
+  t /= W;
+  const int h = (int)(t % H);
+  const long long b = t / H;
+  float s = 0.f;
+  for (int oh = h / 2; oh <= (h + 1) / 2; ++oh) {  // windows rows 2*oh-1 .. 2*oh+1
+    if (oh >= OH) continue;
+    for (int ow = w / 2; ow <= (w + 1) / 2; ++ow) {
+      if (ow >= OW) continue;
+      s += dy[((b * OH + oh) * OW + ow) * C + c];
+    }
+  }
+  dx[i] = s * (1.0f / 9.0f);
+}
+
+__global__ __launch_bounds__(256) void upsample2_fwd_kernel(const float* __restrict__ x, int n, int H, int W, int C,
+                                                            float* __restrict__ y) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)n * 4 * H * W * C) return;
+  const int c = (int)(i % C);
+  long long t = i / C;
+  const int ow = (int)(t % (2 * W));
+  t /= 2 * W;
+  const int oh = (int)(t % (2 * H));
+  const long long b = t / (2 * H);
+  y[i] = x[((b * H + (oh >> 1)) * W + (ow >> 1)) * C + c];
+}
+
+__global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restrict__ dy, int n, int H, int W, int C,
+                                                            float* __restrict__ dx) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)n * H * W * C) return;
+  const int c = (int)(i % C);
+  long long t = i / C;
+  const int w = (int)(t % W);
+  t /= W;
+  const int h = (int)(t % H);
+  const long long b = t / H;
+  const float* p = dy + ((b * 2 * H + 2 * h) * 2 * W + 2 * w) * C + c;
+  dx[i] = (p[0] + p[C]) + (p[(long long)2 * W * C] + p[(long long)2 * W * C + C]);
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, float a, const float* __restrict__ y,
+                                                    float b, long long n, int act, float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  out[i] = mvk_act(a * (x ? x[i] : 0.f) + b * (y ? y[i] : 0.f), act);
+}
+}  // namespace
+
+extern "C" {
+
+int mvk_avgpool3s2_fwd(const float* x, float* y, int n, int H, int W, int C, void* stream) {
+  if (!x || !y || n < 0 || H <= 0 || W <= 0 || C <= 0) return MVK_EINVAL;
+  const long long total = (long long)n * ((H + 1) / 2) * ((W + 1) / 2) * C;
+  if (total == 0) return MVK_OK;
+  hipLaunchKernelGGL(avgpool3s2_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mvk_stream(stream), x,
+                     n, H, W, C, y);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_avgpool3s2_bwd(const float* dy, float* dx, int n, int H, int W, int C, void* stream) {
+  if (!dy || !dx || n < 0 || H <= 0 || W <= 0 || C <= 0) return MVK_EINVAL;
+  const long long total = (long long)n * H * W * C;
+  if (total == 0) return MVK_OK;
+  hipLaunchKernelGGL(avgpool3s2_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mvk_stream(stream), dy,
+                     n, H, W, C, dx);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_upsample2_fwd(const float* x, float* y, int n, int H, int W, int C, void* stream) {
+  if (!x || !y || n < 0 || H <= 0 || W <= 0 || C <= 0) return MVK_EINVAL;
+  const long long total = (long long)n * 4 * H * W * C;
+  if (total == 0) return MVK_OK;
+  hipLaunchKernelGGL(upsample2_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mvk_stream(stream), x, n,
+                     H, W, C, y);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_upsample2_bwd(const float* dy, float* dx, int n, int H, int W, int C, void* stream) {
+  if (!dy || !dx || n < 0 || H <= 0 || W <= 0 || C <= 0) return MVK_EINVAL;
+  const long long total = (long long)n * H * W * C;
+  if (total == 0) return MVK_OK;
+  hipLaunchKernelGGL(upsample2_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mvk_stream(stream), dy,
+                     n, H, W, C, dx);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_axpby(const float* x, float a, const float* y, float b, int64_t n, int act, float* out, void* stream) {
+  if (!out || n < 0 || (!x && !y)) return MVK_EINVAL;
+  if (n == 0) return MVK_OK;
+  hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, mvk_stream(stream), x, a, y, b,
+                     (long long)n, act, out);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }

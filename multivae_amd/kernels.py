@@ -221,6 +221,13 @@ def pack_weights(jobs):
             wp = _new((Cv, 16 * Cu), wref)
             d.kind, d.Wdown, d.Wup = 1, None, wp.data_ptr()
             outs.append(wp)
+        elif job[1] == "c3":  # 3x3 convolution [Cout][Cin][3][3] -> (forward [9*Cin, Cout], backward-data [9*Cout, Cin])
+            wf = _new((9 * Cu, Cv), wref) if job[2] else None
+            wb = _new((9 * Cv, Cu), wref) if job[3] else None
+            d.kind = 2
+            d.Wdown = wf.data_ptr() if wf is not None else None
+            d.Wup = wb.data_ptr() if wb is not None else None
+            outs.append((wf, wb))
         else:
             wd = _new((16 * Cu, Cv), wref) if job[1] else None
             wu = _new((4, 4 * Cv, Cu), wref) if job[2] else None
@@ -253,6 +260,59 @@ def conv_up(V, wup, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src=Non
     call("mvk_conv4s2_up", ptr(V), ptr(wup), ptr(bias), ptr(U), n, h, w, Cu, Cv, act, int(u_nchw),
          ptr(u_act_src), u_act, ptr(tb), ptr(ws), ws.numel(), FMT_IN_BF3 if in_bf3 else 0, stream_ptr())
     return U if out_bias is None else (U, rb)
+
+
+LEAKY = ACT["leaky_relu_0.2"]
+
+
+def conv3x3(X, wpack, bias, n, H, W, Cin, Cout, act=NONE, y_act_src=None, y_src_act=NONE, out_bias=None):
+    """3x3/1/1 convolution on NHWC (forward with the forward pack; backward data with the backward pack and Cin/Cout
+    swapped, y_act_src = the activation whose derivative multiplies the result, out_bias = the bias whose gradient is
+    the channel sum of the result)."""
+    Y = _new((n, H, W, Cout), X)
+    ws = _ws(X)
+    tb, rb = _bias_target(out_bias)
+    call("mvk_conv3x3", ptr(X), ptr(wpack), ptr(bias), ptr(Y), n, H, W, Cin, Cout, act, ptr(y_act_src), y_src_act,
+         ptr(tb), ptr(ws), ws.numel(), stream_ptr())
+    return Y if out_bias is None else (Y, rb)
+
+
+def conv3x3_wgrad(X, dY, wparam, n, H, W, Cin, Cout):
+    dw, rw = _grad_target(wparam)
+    ws = _ws(X)
+    call("mvk_conv3x3_wgrad", ptr(X), ptr(dY), ptr(dw), n, H, W, Cin, Cout, ptr(ws), ws.numel(), stream_ptr())
+    return rw
+
+
+def avgpool(x, n, H, W, C):
+    y = _new((n, (H + 1) // 2, (W + 1) // 2, C), x)
+    call("mvk_avgpool3s2_fwd", ptr(x), ptr(y), n, H, W, C, stream_ptr())
+    return y
+
+
+def avgpool_bwd(dy, n, H, W, C):
+    dx = _new((n, H, W, C), dy)
+    call("mvk_avgpool3s2_bwd", ptr(dy), ptr(dx), n, H, W, C, stream_ptr())
+    return dx
+
+
+def upsample2(x, n, H, W, C):
+    y = _new((n, 2 * H, 2 * W, C), x)
+    call("mvk_upsample2_fwd", ptr(x), ptr(y), n, H, W, C, stream_ptr())
+    return y
+
+
+def upsample2_bwd(dy, n, H, W, C):
+    dx = _new((n, H, W, C), dy)
+    call("mvk_upsample2_bwd", ptr(dy), ptr(dx), n, H, W, C, stream_ptr())
+    return dx
+
+
+def axpby(x, a, y, b, act=NONE, out=None):
+    ref = x if x is not None else y
+    out = torch.empty_like(ref) if out is None else out
+    call("mvk_axpby", ptr(x), float(a), ptr(y), float(b), ref.numel(), act, ptr(out), stream_ptr())
+    return out
 
 
 def conv_wgrad(U, V, wparam, n, h, w, Cu, Cv, u_nchw=False, u_act_src=None, u_act=NONE):

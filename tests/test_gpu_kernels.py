@@ -596,3 +596,59 @@ def test_jmvae_posterior(K, M, B, L, Kk):
     for m in range(M):
         close(dmus[m].grad, mus[m].grad, what=f"d mu[{m}]")
         close(dlvs[m].grad, lvs[m].grad, what=f"d lv[{m}]")
+
+
+@pytest.mark.parametrize("n,H,W,Cin,Cout", [(3, 7, 7, 64, 128), (2, 14, 14, 128, 64), (5, 28, 28, 3, 64), (2, 28, 28, 64, 3),
+                                          (40, 16, 16, 64, 64)])
+def test_conv3x3_fwd_bwd(K, n, H, W, Cin, Cout):
+    """mvk_conv3x3 / mvk_conv3x3_wgrad (+ kind-2 weight pack) vs F.conv2d(3, 1, 1) + LeakyReLU(0.2): forward, backward
+    data with the fused activation derivative and bias-gradient column sums, backward weight in the reference layout."""
+    gen = g(31)
+    x = torch.randn(n, Cin, H, W, generator=gen)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=gen) / (3 * Cin ** 0.5)).requires_grad_(True)
+    b = (0.1 * torch.randn(Cout, generator=gen)).requires_grad_(True)
+    xin = F.leaky_relu(x, 0.2).requires_grad_(True)  # x itself is a LeakyReLU output: its derivative multiplies dx
+    y = F.leaky_relu(F.conv2d(xin, w, b, 1, 1), 0.2)
+    dy = torch.randn(n, Cout, H, W, generator=gen)
+    y.backward(dy)
+    dxin_pre = xin.grad * torch.where(xin > 0, 1.0, 0.2)  # gradient w.r.t. the pre-activation of xin
+    d = dev()
+    nhwc = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(d)
+    wd = w.detach().to(d)
+    (wf, wb), = K.pack_weights([(wd, "c3", True, True)])
+    X = nhwc(xin)
+    Y = K.conv3x3(X, wf, b.detach().to(d), n, H, W, Cin, Cout, act=K.LEAKY)
+    close(Y, nhwc(y), what="conv3x3 forward")
+    dpre = nhwc(dy) * torch.where(Y > 0, 1.0, 0.2)
+    bparam = torch.zeros(Cin, device=d).requires_grad_(True)  # stands for the bias of the layer that produced xin
+    bparam.grad = torch.zeros(Cin, device=d)
+    dX, _ = K.conv3x3(dpre, wb, None, n, H, W, Cout, Cin, y_act_src=X, y_src_act=K.LEAKY, out_bias=bparam)
+    close(dX, nhwc(dxin_pre), what="conv3x3 backward data")
+    close(bparam.grad, dxin_pre.sum((0, 2, 3)), what="fused bias-gradient column sums")
+    wparam = wd.clone().requires_grad_(True)
+    wparam.grad = torch.zeros_like(wparam)
+    K.conv3x3_wgrad(X, dpre, wparam, n, H, W, Cin, Cout)
+    close(wparam.grad, w.grad, what="conv3x3 backward weight")
+
+
+@pytest.mark.parametrize("n,H,W,C", [(3, 28, 28, 64), (2, 7, 7, 20), (4, 14, 14, 128), (2, 5, 9, 3)])
+def test_avgpool_upsample_axpby(K, n, H, W, C):
+    """nn.AvgPool2d(3, 2, 1), nn.Upsample(scale_factor=2) forward / backward and the residual combination on NHWC."""
+    gen = g(41)
+    x = torch.randn(n, C, H, W, generator=gen, requires_grad=True)
+    d = dev()
+    nhwc = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(d)
+    y = F.avg_pool2d(x, 3, 2, 1)
+    gy = torch.randn(y.shape, generator=gen)
+    y.backward(gy)
+    close(K.avgpool(nhwc(x), n, H, W, C), nhwc(y), what="avgpool fwd")
+    close(K.avgpool_bwd(nhwc(gy), n, H, W, C), nhwc(x.grad), what="avgpool bwd")
+    x.grad = None
+    u = F.interpolate(x, scale_factor=2)
+    gu = torch.randn(u.shape, generator=gen)
+    u.backward(gu)
+    close(K.upsample2(nhwc(x), n, H, W, C), nhwc(u), what="upsample fwd")
+    close(K.upsample2_bwd(nhwc(gu), n, H, W, C), nhwc(x.grad), what="upsample bwd")
+    a, b = nhwc(x), torch.randn(n, H, W, C, generator=gen).to(d)
+    close(K.axpby(a, 1.0, b, 0.1), a + 0.1 * b, what="axpby")
+    close(K.axpby(a, 1.0, None, 0.0, act=K.LEAKY), F.leaky_relu(a, 0.2), what="leaky relu")
