@@ -587,6 +587,140 @@ class SVHNDecoderFn(Function):
 
 
 # =====================================================================================================
+# ResNet stacks (models/nn/mmnist.py:214-366, models/nn/cub.py:144-293), NHWC activations
+# =====================================================================================================
+class ResnetStackFn(Function):
+    """x [n,H,W,C] NHWC -> a static program of layers -> y NHWC, one autograd node.
+
+    program: list of tuples (static Python data; parameter references are indices into `params`)
+      ("conv", iw, ib, act)                      3x3/1/1 convolution (+ bias, + activation)
+      ("block", order, iw1, ib1, iw2, ib2, isc)  ResnetBlock; order "post": xs + 0.1*lrelu(conv2(lrelu(conv1(x))))
+                                                 (mmnist.py:229-246), "pre": xs + 0.1*conv2(lrelu(conv1(lrelu(x))))
+                                                 (cub.py:274-280); isc = 1x1 shortcut weight index or None
+      ("pool",)                                  AvgPool2d(3, 2, 1)
+      ("up",)                                    Upsample(scale_factor=2), nearest
+    """
+
+    @staticmethod
+    def forward(ctx, x, program, *params):
+        x = _c(x)
+        n, H, W, C = x.shape
+        tape = []  # per layer: what backward needs
+        packs = {}
+        jobs, order = [], []
+        for op in program:
+            idxs = [op[1]] if op[0] == "conv" else ([op[2], op[4]] if op[0] == "block" else [])
+            for i in idxs:
+                if i not in packs:
+                    packs[i] = None
+                    jobs.append((params[i], "c3", True, True))
+                    order.append(i)
+        for i0 in range(0, len(jobs), 8):  # MVK_PACK_MAX descriptors per launch
+            for i, pk in zip(order[i0:i0 + 8], pack_weights(jobs[i0:i0 + 8])):
+                packs[i] = pk
+        h = x
+        for op in program:
+            if op[0] == "conv":
+                _, iw, ib, act = op
+                Cout = params[iw].shape[0]
+                y = conv3x3(h, packs[iw][0], params[ib] if ib is not None else None, n, H, W, C, Cout, act=act)
+                tape.append((h, y, (H, W, C, Cout)))
+                h, C = y, Cout
+            elif op[0] == "block":
+                _, order_, iw1, ib1, iw2, ib2, isc = op
+                Chid, Cout = params[iw1].shape[0], params[iw2].shape[0]
+                b1 = params[ib1] if ib1 is not None else None
+                b2 = params[ib2] if ib2 is not None else None
+                if order_ == "post":
+                    a0 = h
+                    a1 = conv3x3(a0, packs[iw1][0], b1, n, H, W, C, Chid, act=LEAKY)
+                    y2 = conv3x3(a1, packs[iw2][0], b2, n, H, W, Chid, Cout, act=LEAKY)
+                else:
+                    a0 = axpby(h, 1.0, None, 0.0, act=LEAKY)
+                    a1 = conv3x3(a0, packs[iw1][0], b1, n, H, W, C, Chid, act=LEAKY)
+                    y2 = conv3x3(a1, packs[iw2][0], b2, n, H, W, Chid, Cout, act=NONE)
+                xs = h if isc is None else linear_fwd(h.view(-1, C), params[isc].view(Cout, C), None, NONE).view(n, H, W, Cout)
+                out = axpby(xs, 1.0, y2, 0.1)
+                tape.append((h, a0, a1, y2, (H, W, C, Chid, Cout)))
+                h, C = out, Cout
+            elif op[0] == "pool":
+                y = avgpool(h, n, H, W, C)
+                tape.append((H, W, C))
+                h, H, W = y, (H + 1) // 2, (W + 1) // 2
+            elif op[0] == "up":
+                y = upsample2(h, n, H, W, C)
+                tape.append((H, W, C))
+                h, H, W = y, 2 * H, 2 * W
+            else:
+                raise _lib.MvkError(f"unknown ResNet op {op[0]!r}")
+        ctx.tape, ctx.packs, ctx.program, ctx.n = tape, packs, program, n
+        ctx.save_for_backward(*params)
+        return h
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        params = ctx.saved_tensors
+        n, packs = ctx.n, ctx.packs
+        grads = [None] * len(params)
+        g = _c(dout)
+        need_dx = ctx.needs_input_grad[0]
+        for li in range(len(ctx.program) - 1, -1, -1):
+            op, rec = ctx.program[li], ctx.tape[li]
+            first = li == 0
+            if op[0] == "conv":
+                _, iw, ib, act = op
+                xin, y, (H, W, C, Cout) = rec
+                dpre = g
+                if act != NONE:
+                    dpre = g.clone() if g is dout else g
+                    call("mvk_act_bwd", ptr(dpre), ptr(y), dpre.numel(), act, stream_ptr())
+                grads[iw] = conv3x3_wgrad(xin, dpre, params[iw], n, H, W, C, Cout)
+                if ib is not None:
+                    grads[ib] = colsum(dpre.view(-1, Cout), params[ib])
+                if not first or need_dx:
+                    g = conv3x3(dpre, packs[iw][1], None, n, H, W, Cout, C)
+            elif op[0] == "block":
+                _, order_, iw1, ib1, iw2, ib2, isc = op
+                xin, a0, a1, y2, (H, W, C, Chid, Cout) = rec
+                gout = g
+                d2 = axpby(gout, 0.1, None, 0.0)  # gradient w.r.t. y2
+                if order_ == "post":
+                    call("mvk_act_bwd", ptr(d2), ptr(y2), d2.numel(), LEAKY, stream_ptr())
+                grads[iw2] = conv3x3_wgrad(a1, d2, params[iw2], n, H, W, Chid, Cout)
+                if ib2 is not None:
+                    grads[ib2] = colsum(d2.view(-1, Cout), params[ib2])
+                # backward data of conv2 with lrelu'(a1) fused; its channel sums are conv1's bias gradient
+                if ib1 is not None:
+                    d1, grads[ib1] = conv3x3(d2, packs[iw2][1], None, n, H, W, Cout, Chid, y_act_src=a1, y_src_act=LEAKY,
+                                             out_bias=params[ib1])
+                else:
+                    d1 = conv3x3(d2, packs[iw2][1], None, n, H, W, Cout, Chid, y_act_src=a1, y_src_act=LEAKY)
+                grads[iw1] = conv3x3_wgrad(a0, d1, params[iw1], n, H, W, C, Chid)
+                if isc is not None:
+                    grads[isc], _ = linear_bwd_weight(gout.view(-1, Cout), xin.view(-1, C), params[isc].view(Cout, C), None)
+                    if grads[isc] is not None:
+                        grads[isc] = grads[isc].view(params[isc].shape)
+                if not first or need_dx:
+                    if order_ == "post":
+                        dx = conv3x3(d1, packs[iw1][1], None, n, H, W, Chid, C)
+                    else:  # through the leading LeakyReLU: multiply by lrelu'(x) = lrelu'(a0)
+                        dx = conv3x3(d1, packs[iw1][1], None, n, H, W, Chid, C, y_act_src=a0, y_src_act=LEAKY)
+                    if isc is None:
+                        axpby(dx, 1.0, gout, 1.0, out=dx)
+                    else:
+                        linear_bwd_data(gout.view(-1, Cout), params[isc].view(Cout, C), out=dx.view(-1, C), accumulate=True)
+                    g = dx
+            elif op[0] == "pool":
+                H, W, C = rec
+                g = avgpool_bwd(g, n, H, W, C)
+            else:
+                H, W, C = rec
+                g = upsample2_bwd(g, n, H, W, C)
+        return (g if need_dx else None, None, *grads)
+
+
+# =====================================================================================================
 # Fused posterior kernels
 # =====================================================================================================
 class MoPoEPosteriorFn(Function):

@@ -6,6 +6,7 @@ TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Restates
   /root/reference/src/multivae/models/nn/svhn.py:7-38                     Encoder_VAE_SVHN
   /root/reference/src/multivae/models/nn/svhn.py:41-70                    Decoder_VAE_SVHN
   /root/reference/src/multivae/models/nn/default_architectures.py:261-322 MultipleHeadJointEncoder
+  /root/reference/src/multivae/models/nn/mmnist.py:214-366                ResnetBlock, Encoder/DecoderResnetMMNIST
 with the reference's parameter names (`<prefix>layers.0.0.weight`, `<prefix>enc.0.weight`, ...), on
 torch CPU ops (the reference itself is torch ops; F.linear / F.conv2d are the same aten kernels).
 `conv2d_np` / `conv_transpose2d_np` are independent numpy restatements of the two convolution
@@ -101,6 +102,45 @@ def joint_mlp_encoder(sd, input_dims, data, prefix="joint_encoder."):
         i += 1
     return (F.linear(h, sd[prefix + "fc1.weight"], sd[prefix + "fc1.bias"]),
             F.linear(h, sd[prefix + "fc2.weight"], sd[prefix + "fc2.bias"]))
+
+
+def resnet_block(sd, prefix, x, order="post"):
+    """ResnetBlock.  "post" (mmnist.py:229-246): x_s + 0.1 * lrelu(conv2(lrelu(conv1(x)))); "pre" (cub.py:274-280):
+    x_s + 0.1 * conv2(lrelu(conv1(lrelu(x)))).  x_s = 1x1 shortcut convolution when the channel counts differ."""
+    lr = lambda t: F.leaky_relu(t, 0.2)
+    c1 = lambda t: F.conv2d(t, sd[prefix + "conv_layers.0.weight"], sd[prefix + "conv_layers.0.bias"], 1, 1)
+    c2 = lambda t: F.conv2d(t, sd[prefix + "conv_layers.2.weight"], sd.get(prefix + "conv_layers.2.bias"), 1, 1)
+    xs = F.conv2d(x, sd[prefix + "shortcut_layer.weight"]) if (prefix + "shortcut_layer.weight") in sd else x
+    dx = lr(c2(lr(c1(x)))) if order == "post" else c2(lr(c1(lr(x))))
+    return xs + 0.1 * dx
+
+
+def mmnist_resnet_encoder(sd, prefix, x):
+    """EncoderResnetMMNIST.forward (mmnist.py:296-321) -> (mu_u, lv_u, mu_w, lv_w) (the last two None without w)."""
+    outs = {}
+    for tag in ("u", "w"):
+        if f"{prefix}conv_img_{tag}.weight" not in sd:
+            outs[tag] = (None, None)
+            continue
+        h = F.conv2d(x, sd[f"{prefix}conv_img_{tag}.weight"], sd[f"{prefix}conv_img_{tag}.bias"], 1, 1)
+        h = resnet_block(sd, f"{prefix}resnet_{tag}.0.", h)
+        h = resnet_block(sd, f"{prefix}resnet_{tag}.2.", F.avg_pool2d(h, 3, 2, 1))
+        h = resnet_block(sd, f"{prefix}resnet_{tag}.4.", F.avg_pool2d(h, 3, 2, 1))
+        h = h.reshape(h.shape[0], -1)
+        outs[tag] = (F.linear(h, sd[f"{prefix}fc_mu_{tag}.weight"], sd[f"{prefix}fc_mu_{tag}.bias"]),
+                     F.linear(h, sd[f"{prefix}fc_lv_{tag}.weight"], sd[f"{prefix}fc_lv_{tag}.bias"]))
+    return outs["u"][0], outs["u"][1], outs["w"][0], outs["w"][1]
+
+
+def mmnist_resnet_decoder(sd, prefix, z):
+    """DecoderResnetMMNIST.forward (mmnist.py:355-366)."""
+    lead = z.shape[:-1]
+    h = F.linear(z.reshape(-1, z.shape[-1]), sd[prefix + "fc.weight"], sd[prefix + "fc.bias"]).view(-1, 256, 7, 7)
+    h = F.interpolate(resnet_block(sd, prefix + "resnet.0.", h), scale_factor=2)
+    h = F.interpolate(resnet_block(sd, prefix + "resnet.2.", h), scale_factor=2)
+    h = resnet_block(sd, prefix + "resnet.4.", h)
+    h = F.leaky_relu(F.conv2d(h, sd[prefix + "conv_img.0.weight"], sd[prefix + "conv_img.0.bias"], 1, 1), 0.2)
+    return h.reshape(*lead, *h.shape[1:])
 
 
 def build_default_mlp(sd, input_dims):

@@ -566,6 +566,52 @@ def mmvaeplus_main():
                    loss="dreg_looser", beta=2.5, rescaling=False, masked=False, seed=505)
 
 
+def resnet_mmnist_case(name, *, B, K, private_dim, shared_dim, seed):
+    """The PolyMNIST ResNet encoder / decoder alone: outputs and gradients of a fixed random projection loss."""
+    from multivae.models.nn.mmnist import DecoderResnetMMNIST, EncoderResnetMMNIST
+
+    print(name)
+    L = private_dim + shared_dim
+    enc, dec = EncoderResnetMMNIST(private_dim, shared_dim), DecoderResnetMMNIST(L)
+    esd = P.make_state_dict(P.mmnist_resnet_encoder_shapes(private_dim, shared_dim), seed)
+    dsd = P.make_state_dict(P.mmnist_resnet_decoder_shapes(L), seed + 1)
+    enc.load_state_dict({k: t(v) for k, v in esd.items()})
+    dec.load_state_dict({k: t(v) for k, v in dsd.items()})
+    x = t(P.uniform((B, 3, 28, 28), seed + 2))
+    z = t(P.uniform((K, B, L), seed + 3, -1.0, 1.0)).requires_grad_(True)
+    pe = [t(P.uniform((B, d), seed + 10 + i, -1.0, 1.0)) for i, d in enumerate((shared_dim, shared_dim, private_dim, private_dim))]
+    pd = t(P.uniform((K, B, 3, 28, 28), seed + 20, -1.0, 1.0))
+    eo = enc(x)
+    outs = [eo.embedding, eo.log_covariance, eo.style_embedding, eo.style_log_covariance]
+    le = sum((o * p).sum() for o, p in zip(outs, pe))
+    le.backward()
+    rec = dec(z).reconstruction
+    ld = (rec * pd).sum()
+    ld.backward()
+    oe, od = oracle_sd(esd), oracle_sd(dsd)
+    oo = nets.mmnist_resnet_encoder(oe, "", x)
+    sum((o * p).sum() for o, p in zip(oo, pe)).backward()
+    zo = z.detach().clone().requires_grad_(True)
+    orec = nets.mmnist_resnet_decoder(od, "", zo)
+    (orec * pd).sum().backward()
+    for a_, b_, nme in zip(outs, oo, ("mu_u", "lv_u", "mu_w", "lv_w")):
+        report(nme, a_.abs().sum(), b_.abs().sum())
+    report("recon", rec.abs().sum(), orec.abs().sum())
+    cmp_grads("enc grads", {k: p.grad for k, p in enc.named_parameters()}, {k: v.grad for k, v in oe.items()})
+    cmp_grads("dec grads", {k: p.grad for k, p in dec.named_parameters()}, {k: v.grad for k, v in od.items()})
+    arrays = dict(mu_u=outs[0].detach(), lv_u=outs[1].detach(), mu_w=outs[2].detach(), lv_w=outs[3].detach(),
+                  recon_sample=rec.detach().reshape(-1)[P.hash_indices(rec.numel(), 512, 77)],
+                  recon_sum=np.array([float(rec.detach().double().sum()), float(rec.detach().double().abs().sum())]),
+                  dz=z.grad.detach())
+    arrays.update(grad_stats({"enc." + k: p.grad for k, p in enc.named_parameters()}))
+    arrays.update(grad_stats({"dec." + k: p.grad for k, p in dec.named_parameters()}))
+    save(name, dict(model="ResnetMMNIST", B=B, K=K, private_dim=private_dim, shared_dim=shared_dim, seed=seed), arrays)
+
+
+def resnet_main():
+    resnet_mmnist_case("resnet_mmnist_nets", B=3, K=2, private_dim=4, shared_dim=6, seed=601)
+
+
 def jmvae_main():
     jmvae_case("jmvae_tiny_warmup", arch="tiny", B=6, alpha=0.1, beta=1.0, warmup=10, epoch=3, rescaling=False, seed=401)
     jmvae_case("jmvae_tiny_beta_rescale", arch="tiny", B=7, alpha=0.3, beta=2.0, warmup=5, epoch=8, rescaling=True,
@@ -579,7 +625,10 @@ if __name__ == "__main__":
         jmvae_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "mmvaeplus":
         mmvaeplus_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "resnet":
+        resnet_main()
     else:
         main()
         jmvae_main()
         mmvaeplus_main()
+        resnet_main()

@@ -145,6 +145,49 @@ def mmvaeplus_mlp_shapes(input_dims, latent_dim, style_dim):
     return s
 
 
+def resnet_block_shapes(prefix, cin, cout, chid=None):
+    """ResnetBlock (mmnist.py:214-252 / cub.py:250-293): conv_layers.0, conv_layers.2 (3x3), optional 1x1 shortcut."""
+    chid = min(cin, cout) if chid is None else chid
+    s = OrderedDict()
+    s[prefix + "conv_layers.0.weight"] = (chid, cin, 3, 3)
+    s[prefix + "conv_layers.0.bias"] = (chid,)
+    s[prefix + "conv_layers.2.weight"] = (cout, chid, 3, 3)
+    s[prefix + "conv_layers.2.bias"] = (cout,)
+    if cin != cout:
+        s[prefix + "shortcut_layer.weight"] = (cout, cin, 1, 1)
+    return s
+
+
+def mmnist_resnet_encoder_shapes(private_dim, shared_dim, prefix=""):
+    """EncoderResnetMMNIST (mmnist.py:255-321) in state_dict order: w branch (if any) first, then u."""
+    s = OrderedDict()
+    for tag, dim in (("w", private_dim), ("u", shared_dim)):
+        if tag == "w" and private_dim <= 0:
+            continue
+        s[f"{prefix}conv_img_{tag}.weight"] = (64, 3, 3, 3)
+        s[f"{prefix}conv_img_{tag}.bias"] = (64,)
+        s.update(resnet_block_shapes(f"{prefix}resnet_{tag}.0.", 64, 64))
+        s.update(resnet_block_shapes(f"{prefix}resnet_{tag}.2.", 64, 128))
+        s.update(resnet_block_shapes(f"{prefix}resnet_{tag}.4.", 128, 256))
+        for h in ("fc_mu", "fc_lv"):
+            s[f"{prefix}{h}_{tag}.weight"] = (dim, 256 * 49)
+            s[f"{prefix}{h}_{tag}.bias"] = (dim,)
+    return s
+
+
+def mmnist_resnet_decoder_shapes(latent_dim, prefix=""):
+    """DecoderResnetMMNIST (mmnist.py:324-366)."""
+    s = OrderedDict()
+    s[prefix + "fc.weight"] = (256 * 49, latent_dim)
+    s[prefix + "fc.bias"] = (256 * 49,)
+    s.update(resnet_block_shapes(prefix + "resnet.0.", 256, 128))
+    s.update(resnet_block_shapes(prefix + "resnet.2.", 128, 64))
+    s.update(resnet_block_shapes(prefix + "resnet.4.", 64, 64))
+    s[prefix + "conv_img.0.weight"] = (3, 64, 3, 3)
+    s[prefix + "conv_img.0.bias"] = (3,)
+    return s
+
+
 def make_state_dict(shapes, seed, gain=1.0):
     """name -> float32 ndarray, U(-b, b) with b = gain/sqrt(prod(shape[1:])) (bias: b of its weight)."""
     sd = OrderedDict()

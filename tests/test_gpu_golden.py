@@ -314,3 +314,43 @@ def test_mmvaeplus_encode_paths():
     assert torch.allclose(mean.z, 0.5 * (ea.embedding + eb.embedding), atol=1e-6)
     with pytest.raises(AttributeError):
         MMVAEPlus(MMVAEPlusConfig(n_modalities=3, latent_dim=6, input_dims=dims))  # modalities_specific_dim missing
+
+
+def test_resnet_mmnist_nets_golden():
+    """EncoderResnetMMNIST / DecoderResnetMMNIST on the HIP kernels (3x3 convolutions, pooling, upsampling, residuals,
+    one autograd node per stack) vs the reference golden and the oracle's full gradients."""
+    from test_oracle_golden import resnet_case
+
+    from multivae_amd.models.nn.mmnist import DecoderResnetMMNIST, EncoderResnetMMNIST
+
+    cfg, a, esd, dsd, x, z, pe, pdec = resnet_case()
+    d = torch.device("cuda:0")
+    enc = EncoderResnetMMNIST(cfg["private_dim"], cfg["shared_dim"])
+    dec = DecoderResnetMMNIST(cfg["private_dim"] + cfg["shared_dim"])
+    enc.load_state_dict({k: G.t(v) for k, v in esd.items()})
+    dec.load_state_dict({k: G.t(v) for k, v in dsd.items()})
+    enc, dec = enc.to(d), dec.to(d)
+    eo = enc(x.to(d))
+    outs = [eo.embedding, eo.log_covariance, eo.style_embedding, eo.style_log_covariance]
+    for k, o in zip(("mu_u", "lv_u", "mu_w", "lv_w"), outs):
+        check(a[k], o, k)
+    sum((o * p.to(d)).sum() for o, p in zip(outs, pe)).backward()
+    zz = z.to(d).requires_grad_(True)
+    rec = dec(zz).reconstruction
+    assert rec.shape == (cfg["K"], cfg["B"], 3, 28, 28)
+    check(a["recon_sample"], rec.reshape(-1)[torch.as_tensor(G.P.hash_indices(rec.numel(), 512, 77), device=d)], "recon")
+    (rec * pdec.to(d)).sum().backward()
+    check(a["dz"], zz.grad, "dz")
+    # full gradients vs the oracle
+    oe = {k: G.t(v).clone().requires_grad_(True) for k, v in esd.items()}
+    od = {k: G.t(v).clone().requires_grad_(True) for k, v in dsd.items()}
+    sum((o * p).sum() for o, p in zip(nets.mmnist_resnet_encoder(oe, "", x), pe)).backward()
+    (nets.mmnist_resnet_decoder(od, "", z) * pdec).sum().backward()
+    mg = {"enc." + k: p.grad for k, p in enc.named_parameters()}
+    mg.update({"dec." + k: p.grad for k, p in dec.named_parameters()})
+    for k, v in list(oe.items()) + []:
+        check(v.grad.numpy(), mg["enc." + k], "grad enc." + k)
+    for k, v in od.items():
+        check(v.grad.numpy(), mg["dec." + k], "grad dec." + k)
+    G.check_grads(a, mg, rtol=5 * RTOL, atol_frac=RTOL)
+    assert dec(zz[0].detach()).reconstruction.shape == (cfg["B"], 3, 28, 28)  # 2-D latent input

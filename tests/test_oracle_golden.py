@@ -176,6 +176,40 @@ def test_mmvaeplus(name):
     G.check_grads(a, grads, rtol=2e-5)
 
 
+def resnet_case():
+    """Inputs of the resnet_mmnist_nets golden: (cfg, arrays, encoder sd, decoder sd, x, z, projections)."""
+    cfg, a = G.load_case("resnet_mmnist_nets")
+    P = G.P
+    seed, B, K, pd_, sd_ = cfg["seed"], cfg["B"], cfg["K"], cfg["private_dim"], cfg["shared_dim"]
+    L = pd_ + sd_
+    esd = P.make_state_dict(P.mmnist_resnet_encoder_shapes(pd_, sd_), seed)
+    dsd = P.make_state_dict(P.mmnist_resnet_decoder_shapes(L), seed + 1)
+    x = G.t(P.uniform((B, 3, 28, 28), seed + 2))
+    z = G.t(P.uniform((K, B, L), seed + 3, -1.0, 1.0))
+    pe = [G.t(P.uniform((B, d), seed + 10 + i, -1.0, 1.0)) for i, d in enumerate((sd_, sd_, pd_, pd_))]
+    pdec = G.t(P.uniform((K, B, 3, 28, 28), seed + 20, -1.0, 1.0))
+    return cfg, a, esd, dsd, x, z, pe, pdec
+
+
+def test_resnet_mmnist_nets():
+    """PolyMNIST ResNet encoder / decoder (mmnist.py:214-366): outputs and gradients vs the reference's."""
+    cfg, a, esd, dsd, x, z, pe, pdec = resnet_case()
+    oe = {k: G.t(v).clone().requires_grad_(True) for k, v in esd.items()}
+    od = {k: G.t(v).clone().requires_grad_(True) for k, v in dsd.items()}
+    outs = nets.mmnist_resnet_encoder(oe, "", x)
+    for k, o in zip(("mu_u", "lv_u", "mu_w", "lv_w"), outs):
+        close(a[k], o)
+    sum((o * p).sum() for o, p in zip(outs, pe)).backward()
+    zz = z.clone().requires_grad_(True)
+    rec = nets.mmnist_resnet_decoder(od, "", zz)
+    close(a["recon_sample"], rec.reshape(-1)[G.P.hash_indices(rec.numel(), 512, 77)])
+    (rec * pdec).sum().backward()
+    close(a["dz"], zz.grad, rtol=1e-5, atol=1e-5)
+    grads = {"enc." + k: v.grad for k, v in oe.items()}
+    grads.update({"dec." + k: v.grad for k, v in od.items()})
+    G.check_grads(a, grads, rtol=1e-5)
+
+
 def test_numpy_conv_pins_match_torch():
     """conv2d_np / conv_transpose2d_np (independent numpy restatements) agree with the aten ops the
     reference calls, on the SVHN layer shapes."""
