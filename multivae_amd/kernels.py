@@ -599,6 +599,7 @@ class ResnetStackFn(Function):
                                                  (cub.py:274-280); isc = 1x1 shortcut weight index or None
       ("pool",)                                  AvgPool2d(3, 2, 1)
       ("up",)                                    Upsample(scale_factor=2), nearest
+      ("act", code)                              elementwise activation (cub.py: fc(actvn(out)), conv_img(actvn(out)))
     """
 
     @staticmethod
@@ -651,6 +652,10 @@ class ResnetStackFn(Function):
                 y = upsample2(h, n, H, W, C)
                 tape.append((H, W, C))
                 h, H, W = y, 2 * H, 2 * W
+            elif op[0] == "act":
+                y = axpby(h, 1.0, None, 0.0, act=op[1])
+                tape.append((y,))
+                h = y
             else:
                 raise _lib.MvkError(f"unknown ResNet op {op[0]!r}")
         ctx.tape, ctx.packs, ctx.program, ctx.n = tape, packs, program, n
@@ -714,6 +719,9 @@ class ResnetStackFn(Function):
             elif op[0] == "pool":
                 H, W, C = rec
                 g = avgpool_bwd(g, n, H, W, C)
+            elif op[0] == "act":
+                g = g.clone() if g is dout else g
+                call("mvk_act_bwd", ptr(g), ptr(rec[0]), g.numel(), op[1], stream_ptr())
             else:
                 H, W, C = rec
                 g = upsample2_bwd(g, n, H, W, C)

@@ -49,7 +49,10 @@ def _add_conv(prog, params, conv, act):
 
 
 def _add_block(prog, params, blk):
-    c1, c2 = blk.conv_layers[0], blk.conv_layers[2]
+    if hasattr(blk, "conv_layers"):  # mmnist.py naming
+        c1, c2, sc = blk.conv_layers[0], blk.conv_layers[2], getattr(blk, "shortcut_layer", None)
+    else:  # cub.py naming
+        c1, c2, sc = blk.conv_0, blk.conv_1, getattr(blk, "conv_s", None)
     idx = []
     for t in (c1.weight, c1.bias, c2.weight, c2.bias):
         if t is None:
@@ -58,15 +61,15 @@ def _add_block(prog, params, blk):
             params.append(t)
             idx.append(len(params) - 1)
     isc = None
-    if blk.learn_shortcut:
-        params.append(blk.shortcut_layer.weight)
+    if sc is not None:
+        params.append(sc.weight)
         isc = len(params) - 1
     prog.append(("block", blk.order, idx[0], idx[1], idx[2], idx[3], isc))
 
 
 def _add_sequential(prog, params, seq):
     for m in seq:
-        if isinstance(m, ResnetBlock):
+        if hasattr(m, "order") and (hasattr(m, "conv_layers") or hasattr(m, "conv_0")):
             _add_block(prog, params, m)
         elif isinstance(m, nn.AvgPool2d):
             prog.append(("pool",))

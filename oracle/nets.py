@@ -7,6 +7,7 @@ TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Restates
   /root/reference/src/multivae/models/nn/svhn.py:41-70                    Decoder_VAE_SVHN
   /root/reference/src/multivae/models/nn/default_architectures.py:261-322 MultipleHeadJointEncoder
   /root/reference/src/multivae/models/nn/mmnist.py:214-366                ResnetBlock, Encoder/DecoderResnetMMNIST
+  /root/reference/src/multivae/models/nn/cub.py:144-293                   CUB_Resnet_Encoder / Decoder, ResnetBlock
 with the reference's parameter names (`<prefix>layers.0.0.weight`, `<prefix>enc.0.weight`, ...), on
 torch CPU ops (the reference itself is torch ops; F.linear / F.conv2d are the same aten kernels).
 `conv2d_np` / `conv_transpose2d_np` are independent numpy restatements of the two convolution
@@ -140,6 +141,37 @@ def mmnist_resnet_decoder(sd, prefix, z):
     h = F.interpolate(resnet_block(sd, prefix + "resnet.2.", h), scale_factor=2)
     h = resnet_block(sd, prefix + "resnet.4.", h)
     h = F.leaky_relu(F.conv2d(h, sd[prefix + "conv_img.0.weight"], sd[prefix + "conv_img.0.bias"], 1, 1), 0.2)
+    return h.reshape(*lead, *h.shape[1:])
+
+
+def _cub_block(sd, prefix, x):
+    """cub.py ResnetBlock (conv_0 / conv_1 / conv_s naming, pre-activation order :274-280)."""
+    lr = lambda t: F.leaky_relu(t, 0.2)
+    xs = F.conv2d(x, sd[prefix + "conv_s.weight"]) if (prefix + "conv_s.weight") in sd else x
+    dx = F.conv2d(lr(x), sd[prefix + "conv_0.weight"], sd[prefix + "conv_0.bias"], 1, 1)
+    dx = F.conv2d(lr(dx), sd[prefix + "conv_1.weight"], sd[prefix + "conv_1.bias"], 1, 1)
+    return xs + 0.1 * dx
+
+
+def cub_resnet_encoder(sd, prefix, x):
+    """CUB_Resnet_Encoder.forward (cub.py:186-196), default s0 = 16."""
+    h = F.conv2d(x, sd[prefix + "conv_img.weight"], sd[prefix + "conv_img.bias"], 1, 1)
+    h = _cub_block(sd, prefix + "resnet.0.", h)
+    h = _cub_block(sd, prefix + "resnet.2.", F.avg_pool2d(h, 3, 2, 1))
+    h = _cub_block(sd, prefix + "resnet.4.", F.avg_pool2d(h, 3, 2, 1))
+    h = F.leaky_relu(h.reshape(h.shape[0], -1), 0.2)
+    return (F.linear(h, sd[prefix + "fc_mu.weight"], sd[prefix + "fc_mu.bias"]),
+            F.linear(h, sd[prefix + "fc_logvar.weight"], sd[prefix + "fc_logvar.bias"]))
+
+
+def cub_resnet_decoder(sd, prefix, z):
+    """CUB_Resnet_Decoder.forward (cub.py:238-247); leading dims flattened (the reference takes [B, L] only)."""
+    lead = z.shape[:-1]
+    h = F.linear(z.reshape(-1, z.shape[-1]), sd[prefix + "fc.weight"], sd[prefix + "fc.bias"]).view(-1, 256, 16, 16)
+    h = F.interpolate(_cub_block(sd, prefix + "resnet.0.", h), scale_factor=2)
+    h = F.interpolate(_cub_block(sd, prefix + "resnet.2.", h), scale_factor=2)
+    h = _cub_block(sd, prefix + "resnet.4.", h)
+    h = F.conv2d(F.leaky_relu(h, 0.2), sd[prefix + "conv_img.weight"], sd[prefix + "conv_img.bias"], 1, 1)
     return h.reshape(*lead, *h.shape[1:])
 
 

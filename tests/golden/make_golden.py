@@ -608,8 +608,46 @@ def resnet_mmnist_case(name, *, B, K, private_dim, shared_dim, seed):
     save(name, dict(model="ResnetMMNIST", B=B, K=K, private_dim=private_dim, shared_dim=shared_dim, seed=seed), arrays)
 
 
+def resnet_cub_case(name, *, B, L, seed):
+    """CUB_Resnet_Encoder / Decoder (defaults: 64x64 images, s0 = 16)."""
+    from multivae.models.nn.cub import CUB_Resnet_Decoder, CUB_Resnet_Encoder
+
+    print(name)
+    enc, dec = CUB_Resnet_Encoder(L), CUB_Resnet_Decoder(L)
+    esd = P.make_state_dict(P.cub_resnet_encoder_shapes(L), seed)
+    dsd = P.make_state_dict(P.cub_resnet_decoder_shapes(L), seed + 1)
+    enc.load_state_dict({k: t(v) for k, v in esd.items()})
+    dec.load_state_dict({k: t(v) for k, v in dsd.items()})
+    x = t(P.uniform((B, 3, 64, 64), seed + 2))
+    z = t(P.uniform((B, L), seed + 3, -1.0, 1.0)).requires_grad_(True)
+    pe = [t(P.uniform((B, L), seed + 10 + i, -1.0, 1.0)) for i in range(2)]
+    pd = t(P.uniform((B, 3, 64, 64), seed + 20, -1.0, 1.0))
+    eo = enc(x)
+    outs = [eo.embedding, eo.log_covariance]
+    sum((o * p).sum() for o, p in zip(outs, pe)).backward()
+    rec = dec(z).reconstruction
+    (rec * pd).sum().backward()
+    oe, od = oracle_sd(esd), oracle_sd(dsd)
+    oo = nets.cub_resnet_encoder(oe, "", x)
+    sum((o * p).sum() for o, p in zip(oo, pe)).backward()
+    zo = z.detach().clone().requires_grad_(True)
+    orec = nets.cub_resnet_decoder(od, "", zo)
+    (orec * pd).sum().backward()
+    report("mu", outs[0].abs().sum(), oo[0].abs().sum())
+    report("lv", outs[1].abs().sum(), oo[1].abs().sum())
+    report("recon", rec.abs().sum(), orec.abs().sum())
+    cmp_grads("enc grads", {k: p.grad for k, p in enc.named_parameters()}, {k: v.grad for k, v in oe.items()})
+    cmp_grads("dec grads", {k: p.grad for k, p in dec.named_parameters()}, {k: v.grad for k, v in od.items()})
+    arrays = dict(mu=outs[0].detach(), lv=outs[1].detach(),
+                  recon_sample=rec.detach().reshape(-1)[P.hash_indices(rec.numel(), 512, 78)], dz=z.grad.detach())
+    arrays.update(grad_stats({"enc." + k: p.grad for k, p in enc.named_parameters()}))
+    arrays.update(grad_stats({"dec." + k: p.grad for k, p in dec.named_parameters()}))
+    save(name, dict(model="ResnetCUB", B=B, L=L, seed=seed), arrays)
+
+
 def resnet_main():
     resnet_mmnist_case("resnet_mmnist_nets", B=3, K=2, private_dim=4, shared_dim=6, seed=601)
+    resnet_cub_case("resnet_cub_nets", B=2, L=12, seed=602)
 
 
 def jmvae_main():

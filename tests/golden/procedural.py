@@ -188,6 +188,45 @@ def mmnist_resnet_decoder_shapes(latent_dim, prefix=""):
     return s
 
 
+def cub_block_shapes(prefix, fin, fout):
+    s = OrderedDict()
+    fh = min(fin, fout)
+    s[prefix + "conv_0.weight"] = (fh, fin, 3, 3)
+    s[prefix + "conv_0.bias"] = (fh,)
+    s[prefix + "conv_1.weight"] = (fout, fh, 3, 3)
+    s[prefix + "conv_1.bias"] = (fout,)
+    if fin != fout:
+        s[prefix + "conv_s.weight"] = (fout, fin, 1, 1)
+    return s
+
+
+def cub_resnet_encoder_shapes(latent_dim, prefix=""):
+    """CUB_Resnet_Encoder (cub.py:144-196), defaults s0=16, nfilter=64: blocks (64,64) (64,128) (128,256)."""
+    s = OrderedDict()
+    s[prefix + "conv_img.weight"] = (64, 3, 3, 3)
+    s[prefix + "conv_img.bias"] = (64,)
+    s.update(cub_block_shapes(prefix + "resnet.0.", 64, 64))
+    s.update(cub_block_shapes(prefix + "resnet.2.", 64, 128))
+    s.update(cub_block_shapes(prefix + "resnet.4.", 128, 256))
+    for h in ("fc_mu", "fc_logvar"):
+        s[f"{prefix}{h}.weight"] = (latent_dim, 256 * 256)
+        s[f"{prefix}{h}.bias"] = (latent_dim,)
+    return s
+
+
+def cub_resnet_decoder_shapes(latent_dim, prefix=""):
+    """CUB_Resnet_Decoder (cub.py:199-247), defaults."""
+    s = OrderedDict()
+    s[prefix + "fc.weight"] = (256 * 256, latent_dim)
+    s[prefix + "fc.bias"] = (256 * 256,)
+    s.update(cub_block_shapes(prefix + "resnet.0.", 256, 128))
+    s.update(cub_block_shapes(prefix + "resnet.2.", 128, 64))
+    s.update(cub_block_shapes(prefix + "resnet.4.", 64, 64))
+    s[prefix + "conv_img.weight"] = (3, 64, 3, 3)
+    s[prefix + "conv_img.bias"] = (3,)
+    return s
+
+
 def make_state_dict(shapes, seed, gain=1.0):
     """name -> float32 ndarray, U(-b, b) with b = gain/sqrt(prod(shape[1:])) (bias: b of its weight)."""
     sd = OrderedDict()

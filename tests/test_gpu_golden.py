@@ -354,3 +354,39 @@ def test_resnet_mmnist_nets_golden():
         check(v.grad.numpy(), mg["dec." + k], "grad dec." + k)
     G.check_grads(a, mg, rtol=5 * RTOL, atol_frac=RTOL)
     assert dec(zz[0].detach()).reconstruction.shape == (cfg["B"], 3, 28, 28)  # 2-D latent input
+
+
+def test_resnet_cub_nets_golden():
+    """CUB_Resnet_Encoder / Decoder (64x64 images, pre-activation blocks, lrelu before the heads / the image conv) on the
+    HIP kernels vs the reference golden and the oracle's full gradients; 3-D latents decode too."""
+    from test_oracle_golden import resnet_cub_case
+
+    from multivae_amd.models.nn.cub import CUB_Resnet_Decoder, CUB_Resnet_Encoder
+
+    cfg, a, esd, dsd, x, z, pe, pdec = resnet_cub_case()
+    d = torch.device("cuda:0")
+    enc, dec = CUB_Resnet_Encoder(cfg["L"]), CUB_Resnet_Decoder(cfg["L"])
+    enc.load_state_dict({k: G.t(v) for k, v in esd.items()})
+    dec.load_state_dict({k: G.t(v) for k, v in dsd.items()})
+    enc, dec = enc.to(d), dec.to(d)
+    eo = enc(x.to(d))
+    check(a["mu"], eo.embedding, "mu")
+    check(a["lv"], eo.log_covariance, "lv")
+    ((eo.embedding * pe[0].to(d)).sum() + (eo.log_covariance * pe[1].to(d)).sum()).backward()
+    zz = z.to(d).requires_grad_(True)
+    rec = dec(zz).reconstruction
+    check(a["recon_sample"], rec.reshape(-1)[torch.as_tensor(G.P.hash_indices(rec.numel(), 512, 78), device=d)], "recon")
+    (rec * pdec.to(d)).sum().backward()
+    check(a["dz"], zz.grad, "dz")
+    oe = {k: G.t(v).clone().requires_grad_(True) for k, v in esd.items()}
+    od = {k: G.t(v).clone().requires_grad_(True) for k, v in dsd.items()}
+    sum((o * p).sum() for o, p in zip(nets.cub_resnet_encoder(oe, "", x), pe)).backward()
+    (nets.cub_resnet_decoder(od, "", z) * pdec).sum().backward()
+    mg = {"enc." + k: p.grad for k, p in enc.named_parameters()}
+    mg.update({"dec." + k: p.grad for k, p in dec.named_parameters()})
+    for k, v in oe.items():
+        check(v.grad.numpy(), mg["enc." + k], "grad enc." + k)
+    for k, v in od.items():
+        check(v.grad.numpy(), mg["dec." + k], "grad dec." + k)
+    G.check_grads(a, mg, rtol=5 * RTOL, atol_frac=RTOL)
+    assert dec(zz.detach().unsqueeze(0)).reconstruction.shape == (1, cfg["B"], 3, 64, 64)

@@ -193,3 +193,47 @@ def test_trainer_with_hip_graph(tmp_path, model_name):
     assert all(np.isfinite(v) for v in graphed) and graphed[-1] < graphed[0]
     for a, b in zip(eager, graphed):  # same data order and initial weights, different noise stream
         assert abs(a - b) <= 0.05 * abs(a), (eager, graphed)
+
+
+def test_cfg4_cfg5_architectures_take_training_steps():
+    """BASELINE.json configs[3] / configs[4] in miniature: MMVAE+ with the PolyMNIST ResNets (K samples, iwae_looser,
+    laplace, beta 2.5) and JMVAE with the 64x64 CUB ResNet + the default MLP for a Bernoulli attribute vector: a few
+    Adam steps on the flat buffers run, the loss is finite and goes down."""
+    from multivae_amd.data.datasets.base import DatasetOutput
+    from multivae_amd.models import JMVAE, JMVAEConfig, MMVAEPlus, MMVAEPlusConfig
+    from multivae_amd.models.base.base_config import BaseAEConfig
+    from multivae_amd.models.nn.cub import CUB_Resnet_Decoder, CUB_Resnet_Encoder
+    from multivae_amd.models.nn.default_architectures import Decoder_AE_MLP, Encoder_VAE_MLP
+    from multivae_amd.models.nn.mmnist import DecoderResnetMMNIST, EncoderResnetMMNIST
+    from multivae_amd.trainers import FlatParams, FusedAdam
+
+    d = torch.device("cuda:0")
+    torch.manual_seed(0)
+    mods = ["m0", "m1", "m2"]
+    cfg4 = MMVAEPlusConfig(n_modalities=3, latent_dim=32, input_dims={m: (3, 28, 28) for m in mods}, K=2,
+                           modalities_specific_dim=32, beta=2.5, loss="iwae_looser",
+                           prior_and_posterior_dist="laplace_with_softmax",
+                           decoders_dist={m: "laplace" for m in mods}, decoder_dist_params={m: dict(scale=0.75) for m in mods})
+    m4 = MMVAEPlus(cfg4, {m: EncoderResnetMMNIST(32, 32) for m in mods}, {m: DecoderResnetMMNIST(64) for m in mods}).to(d)
+    in4 = DatasetOutput(data={m: torch.rand(6, 3, 28, 28, device=d) for m in mods})
+    cfg5 = JMVAEConfig(n_modalities=2, latent_dim=16, input_dims=dict(image=(3, 64, 64), attributes=(18,)),
+                       decoders_dist=dict(image="normal", attributes="bernoulli"))
+    enc5 = dict(image=CUB_Resnet_Encoder(16), attributes=Encoder_VAE_MLP(BaseAEConfig(latent_dim=16, input_dim=(18,))))
+    dec5 = dict(image=CUB_Resnet_Decoder(16), attributes=Decoder_AE_MLP(BaseAEConfig(latent_dim=16, input_dim=(18,))))
+    m5 = JMVAE(cfg5, enc5, dec5).to(d)
+    in5 = DatasetOutput(data=dict(image=torch.rand(4, 3, 64, 64, device=d),
+                                  attributes=(torch.rand(4, 18, device=d) > 0.5).float()))
+    for model, inputs in ((m4, in4), (m5, in5)):
+        model.train()
+        flat = FlatParams(model)
+        opt = FusedAdam(flat, lr=1e-3)
+        losses = []
+        for _ in range(4):
+            opt.zero_grad()
+            out = model(inputs, epoch=20)
+            out.loss.backward()
+            opt.step()
+            losses.append(float(out.loss.detach()))
+        assert all(np.isfinite(v) for v in losses), losses
+        assert losses[-1] < losses[0], losses
+        assert float(flat.grad.abs().max()) > 0

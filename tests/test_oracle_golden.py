@@ -210,6 +210,38 @@ def test_resnet_mmnist_nets():
     G.check_grads(a, grads, rtol=1e-5)
 
 
+def resnet_cub_case():
+    cfg, a = G.load_case("resnet_cub_nets")
+    P = G.P
+    seed, B, L = cfg["seed"], cfg["B"], cfg["L"]
+    esd = P.make_state_dict(P.cub_resnet_encoder_shapes(L), seed)
+    dsd = P.make_state_dict(P.cub_resnet_decoder_shapes(L), seed + 1)
+    x = G.t(P.uniform((B, 3, 64, 64), seed + 2))
+    z = G.t(P.uniform((B, L), seed + 3, -1.0, 1.0))
+    pe = [G.t(P.uniform((B, L), seed + 10 + i, -1.0, 1.0)) for i in range(2)]
+    pdec = G.t(P.uniform((B, 3, 64, 64), seed + 20, -1.0, 1.0))
+    return cfg, a, esd, dsd, x, z, pe, pdec
+
+
+def test_resnet_cub_nets():
+    """CUB_Resnet_Encoder / Decoder (cub.py:144-293, pre-activation ResnetBlock): outputs and gradients."""
+    cfg, a, esd, dsd, x, z, pe, pdec = resnet_cub_case()
+    oe = {k: G.t(v).clone().requires_grad_(True) for k, v in esd.items()}
+    od = {k: G.t(v).clone().requires_grad_(True) for k, v in dsd.items()}
+    outs = nets.cub_resnet_encoder(oe, "", x)
+    close(a["mu"], outs[0])
+    close(a["lv"], outs[1])
+    sum((o * p).sum() for o, p in zip(outs, pe)).backward()
+    zz = z.clone().requires_grad_(True)
+    rec = nets.cub_resnet_decoder(od, "", zz)
+    close(a["recon_sample"], rec.reshape(-1)[G.P.hash_indices(rec.numel(), 512, 78)])
+    (rec * pdec).sum().backward()
+    close(a["dz"], zz.grad, rtol=1e-5, atol=1e-5)
+    grads = {"enc." + k: v.grad for k, v in oe.items()}
+    grads.update({"dec." + k: v.grad for k, v in od.items()})
+    G.check_grads(a, grads, rtol=1e-5)
+
+
 def test_numpy_conv_pins_match_torch():
     """conv2d_np / conv_transpose2d_np (independent numpy restatements) agree with the aten ops the
     reference calls, on the SVHN layer shapes."""
