@@ -356,6 +356,11 @@ int mvk_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, v
 int mvk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                   double eps, double weight_decay, int step, double grad_scale, void* stream);
 
+/* Measurement hooks for experiment builds of the library (-DMVK_PHASES: per-phase cycle counters of the GEMM main
+ * loop accumulated into an 8-entry device buffer; -DMVK_EXPER: ablation switches).  Inert in the shipped build. */
+void mvk_debug_set_phase_buffer(unsigned long long* device_counters);
+void mvk_debug_set_flags(int flags);
+
 #ifdef __cplusplus
 }
 #endif

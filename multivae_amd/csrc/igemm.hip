@@ -142,6 +142,8 @@ static int try_launch_fast(const GemmDesc& d, int zdim, hipStream_t s) {
 
 static unsigned long long* g_dbg = nullptr;
 static int g_dbg_flags = 0;
+// Measurement hooks (declared in mvk.h): only experiment builds (-DMVK_PHASES / -DMVK_EXPER, tools/build_exper.sh,
+// tools/build_variants.sh) read what they set; in the shipped library they are inert.
 extern "C" void mvk_debug_set_phase_buffer(unsigned long long* p) { g_dbg = p; }
 extern "C" void mvk_debug_set_flags(int f) {
   g_dbg_flags = f;
@@ -155,7 +157,6 @@ int launch_igemm(const GemmDesc& d_in, int zdim, hipStream_t s, LaunchInfo* info
   if (info) info->bm = 0;
   d.dbg = g_dbg;
   d.dbg_flags = g_dbg_flags;
-  { static int stg = -1; if (stg < 0) { const char* e = getenv("MVK_STAGGER"); stg = e ? atoi(e) : 0; } d.stagger = stg; }
   if (d.M <= 0 || d.N <= 0 || d.K <= 0) return MVK_OK;
   {
     g_last_bm = 0;

@@ -70,7 +70,6 @@ struct GemmDesc {
   int ksplit_tiles;  // Z_SPLITK: k-tiles per z slice
   unsigned long long* dbg;  // phase-cycle counters (debug builds with -DMVK_PHASES only)
   int dbg_flags;            // experiment switches (debug builds only)
-  int stagger;              // start-up de-phasing of co-resident workgroups (units of 32*64 cycles)
 };
 
 #ifndef MVK_MIN_WAVES

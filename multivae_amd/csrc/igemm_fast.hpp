@@ -294,7 +294,6 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
   };
 
   auto compute = [&](int buf) {
-    if (d.stagger == 2) __builtin_amdgcn_s_setprio(3);
     const float* a_s = As + buf * BKT * T::SA + wm * T::WTM + l31;
     const float* b_s = Bs + buf * BKT * T::SB + wn * T::WTN + l31;
 #pragma unroll
@@ -310,7 +309,6 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
         for (int b = 0; b < T::TN; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
     }
-    if (d.stagger == 2) __builtin_amdgcn_s_setprio(0);
   };
 
 #ifdef MVK_PHASES
@@ -320,15 +318,6 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_fast_kernel(const Ge
 #else
 #define MVK_TICK(i, prev)
 #endif
-  // De-phase the workgroups that share a CU (EXPERIMENT): identical blocks started together issue their tile
-  // loads in global bursts and then all sit in the MFMA phase with the memory system idle.
-  if (d.stagger == 1) {  // EXPERIMENT: static priority per co-resident workgroup -> same MFMA arbitration on all SIMDs
-    const int phs = (blockIdx.x / 256) % 3;
-    if (phs == 0) __builtin_amdgcn_s_setprio(3);
-    else if (phs == 1) __builtin_amdgcn_s_setprio(2);
-    else __builtin_amdgcn_s_setprio(1);
-  } else if (d.stagger == 2) {  // EXPERIMENT: priority raised only around the MFMA section (see compute)
-  }
   load_tiles(kbeg);
   store_tiles(0);
   __syncthreads();
