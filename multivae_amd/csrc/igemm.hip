@@ -64,6 +64,15 @@ static int launch_bf_tile(const GemmDesc& d, int zdim, hipStream_t s, int amode,
   return 1;
 }
 
+static int bf_min_blocks() {  // smallest grid that still goes to the split engine (MVK_BF_MIN_BLOCKS overrides)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MVK_BF_MIN_BLOCKS");
+    v = e ? atoi(e) : 256;  // measured on the MnistSvhn step: 160-256 best, 384 and < 100 1-2 % slower
+  }
+  return v;
+}
+
 static int g_engine = -1;  // 1 = split-bf16 MFMA (default), 0 = fp32 MFMA (MVK_ENGINE=f32)
 static int engine() {
   if (g_engine < 0) {
@@ -121,7 +130,7 @@ static int try_launch_fast(const GemmDesc& d, int zdim, hipStream_t s) {
       rc = launch_bf_tile<128, 32>(d, zdim, s, amode, bmode, aact);
     } else if (d.N > 64 && amode == AM_COL && nb(128, 128) >= 384) {
       rc = launch_bf_tile<128, 128>(d, zdim, s, amode, bmode, aact);
-    } else if (nb(128, 64) >= 384 || amode == AM_ROW3) {
+    } else if (nb(128, 64) >= bf_min_blocks() || amode == AM_ROW3) {
       rc = launch_bf_tile<128, 64>(d, zdim, s, amode, bmode, aact);
     }
     if (rc != 1) return rc;
