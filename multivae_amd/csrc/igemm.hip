@@ -393,6 +393,22 @@ int colsum_finish(const float* part, int rows, int N, float* db, hipStream_t s) 
   return MVK_OK;
 }
 
+int convref_reduce(const float* slab, int nz, int Cu, int Cv, int taps, float* dWref, hipStream_t s) {
+  Epilogue e{};
+  e.out = dWref;
+  e.kind = E_CONVREF;
+  e.taps = taps;
+  e.bias_mod = 1;
+  e.atomic = 1;  // accumulate
+  e.Cu = Cu;
+  e.OH = e.OW = 1;
+  e.ws = const_cast<float*>(slab);
+  const int M = taps * Cu;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((M * Cv + 31) / 32), dim3(256), 0, s, e, M, Cv, nz);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
 // GEMM launch + `db[n] += column sums of the stored output` (bias gradient of the layer that produced the GEMM's
 // input gradient).  Fused into the epilogue when the vectorised epilogue applies and the partials fit in ws;
 // otherwise a separate pass over the output.
@@ -537,6 +553,8 @@ int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, floa
                      int v_act, float* colsum_acc, float* ws, int64_t ws_floats, int fmt, void* stream) {
   if (!U || !Wdown || !V || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0) return MVK_EINVAL;
   if ((fmt & ~MVK_FMT_IN_BF3) || ((fmt & MVK_FMT_IN_BF3) && (u_nchw || u_act_src))) return MVK_EINVAL;
+  if (u_nchw && !u_act_src && !v_act_src && !colsum_acc && smallcin_supported(Cu, Cv))  // the network-input layer
+    return smallcin_fwd(U, Wdown, bias, V, n, h, w, Cu, Cv, act, mvk_stream(stream));
   GemmDesc d{};
   d.a = AOperand{};
   d.a.p = U;
@@ -677,6 +695,10 @@ int mvk_conv3x3_wgrad(const float* X, const float* dY, float* dWref, int n, int 
 int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv,
                       int u_nchw, const float* u_act_src, int u_act, float* ws, int64_t ws_floats, void* stream) {
   if (!U || !V || !dWref || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0) return MVK_EINVAL;
+  if (u_nchw && !u_act_src && smallcin_supported(Cu, Cv)) {
+    const int rc = smallcin_wgrad(U, V, dWref, n, h, w, Cu, Cv, ws, ws_floats, mvk_stream(stream));
+    if (rc != 1) return rc;  // 1: scratch too small -> the implicit GEMM below
+  }
   GemmDesc d{};
   d.a = AOperand{};
   d.a.p = U;

@@ -854,6 +854,14 @@ struct LaunchInfo {
 int launch_igemm(const GemmDesc& d, int zdim, hipStream_t s, LaunchInfo* info = nullptr);
 // db[n] += sum over `rows` partial rows (ordered, deterministic)
 int colsum_finish(const float* part, int rows, int N, float* db, hipStream_t s);
+
+int convref_reduce(const float* slab, int nz, int Cu, int Cv, int taps, float* dWref, hipStream_t s);
+// smallcin.hip: direct kernels for the 4x4/stride-2 convolution of an NCHW image with <= 4 channels
+bool smallcin_supported(int Cu, int Cv);
+int smallcin_fwd(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w, int Cu, int Cv,
+                 int act, hipStream_t s);
+int smallcin_wgrad(const float* U, const float* dV, float* dWref, int n, int h, int w, int Cu, int Cv, float* ws,
+                   long long ws_floats, hipStream_t s);
 // split-K launch: picks the slice count, uses the slab workspace when it is large enough (else atomics)
 int launch_splitk(GemmDesc& d, float* ws, long long ws_floats, int target_blocks, hipStream_t s);
 

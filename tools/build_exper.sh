@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../multivae_amd/csrc"
 mkdir -p /tmp/mvk_exper
-for f in igemm smallconv elbo mmvae misc; do
+for f in igemm smallconv smallcin elbo mmvae misc; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DMVK_EXPER -c $f.hip -o /tmp/mvk_exper/$f.o &
 done
 wait

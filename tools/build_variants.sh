@@ -7,6 +7,6 @@ make -s >/dev/null
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize $flags -c igemm.hip -o /tmp/igemm_$name.o &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/igemm_$name.o smallconv.o elbo.o mmvae.o misc.o -o ../libmvk_$name.so ) &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/igemm_$name.o smallconv.o smallcin.o elbo.o mmvae.o misc.o -o ../libmvk_$name.so ) &
 done
 wait
