@@ -1,6 +1,7 @@
 // Fused ELBO kernels: posterior aggregation (PoE / MoPoE) + reparameterisation + Gaussian KL, and the
 // HBM-bound reconstruction-NLL kernel over the K-sample axis with the gradient emitted in the same pass.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -324,6 +325,7 @@ constexpr int MAXV = 4;        // float4 per thread held for x -> D <= 4096 on t
 struct ReconTable {
   mvk_recon_desc d[MAXM];
   int block_start[MAXM + 1];  // prefix sum of blocks per modality
+  int kchunks[MAXM];          // sample chunks per batch row (large rows are cut finer: load balance, see launch_recon)
   int n;
 };
 
@@ -351,6 +353,80 @@ __device__ __forceinline__ float nll_row_const(int dist, float scale, long long 
   return 0.f;
 }
 
+// Vector path of one block: row b, samples k0 .. k0+kn-1.  x[b,:] stays in registers; the 16-byte loads of sample k+1
+// are issued before the arithmetic of sample k (two register stages), so every thread keeps 2 * ceil(D/1024) loads in
+// flight.  Loads are unconditional (lanes past the row end re-read element 0 and are masked in the arithmetic): a
+// predicated HIP float4 load is scalarised into four branchy dword loads.
+typedef float nll_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int DIST>
+__device__ __forceinline__ void recon_vec_body(const mvk_recon_desc& d, int B, int b, int k0, int kn, float gbase,
+                                               float inv_s, float inv_s2, const float* __restrict__ xrow,
+                                               float (&part)[KC]) {
+  const long long D = d.D;
+  const int nv = (int)(D >> 2);
+  nll_f32x4 xv[MAXV], cur[MAXV], nxt[MAXV];
+  bool live[MAXV];
+  int off[MAXV];
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) {
+    const int idx = threadIdx.x + j * NLL_THREADS;
+    live[j] = idx < nv;
+    off[j] = live[j] ? idx : 0;
+    xv[j] = reinterpret_cast<const nll_f32x4*>(xrow)[off[j]];
+  }
+  auto load_sample = [&](int k, nll_f32x4 (&dst)[MAXV]) __attribute__((always_inline)) {
+    const nll_f32x4* rp = reinterpret_cast<const nll_f32x4*>(d.recon + ((long long)(k0 + k) * B + b) * D);
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) dst[j] = __builtin_nontemporal_load(rp + off[j]);  // streamed once
+  };
+  load_sample(0, cur);
+#pragma unroll
+  for (int k = 0; k < KC; ++k) {
+    if (k < kn) {
+      if (k + 1 < kn) load_sample(k + 1, nxt);
+      nll_f32x4* gp = d.drecon ? reinterpret_cast<nll_f32x4*>(d.drecon + ((long long)(k0 + k) * B + b) * D) : nullptr;
+      const float gw = gbase * (d.rowcoef ? d.rowcoef[(long long)(k0 + k) * B + b] : 1.0f);
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXV; ++j) {
+        nll_f32x4 gr;
+        float n0, n1, n2, n3, g0, g1, g2, g3;
+        nll_elem(DIST, inv_s, inv_s2, cur[j][0], xv[j][0], n0, g0);
+        nll_elem(DIST, inv_s, inv_s2, cur[j][1], xv[j][1], n1, g1);
+        nll_elem(DIST, inv_s, inv_s2, cur[j][2], xv[j][2], n2, g2);
+        nll_elem(DIST, inv_s, inv_s2, cur[j][3], xv[j][3], n3, g3);
+        acc += live[j] ? (n0 + n1) + (n2 + n3) : 0.f;
+        gr[0] = g0 * gw;
+        gr[1] = g1 * gw;
+        gr[2] = g2 * gw;
+        gr[3] = g3 * gw;
+        if (gp && live[j]) gp[threadIdx.x + j * NLL_THREADS] = gr;
+      }
+      part[k] = acc;
+#pragma unroll
+      for (int j = 0; j < MAXV; ++j) cur[j] = nxt[j];
+    }
+  }
+}
+
+// Sample chunks per batch row: at least ceil(K / KC) (the registers hold KC partial sums), balanced.  MVK_RECON_CHUNK
+// caps the chunk length of rows with more than 1024 values (experiment hook: finer chunks re-read x and measured slower).
+static int recon_max_chunk() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MVK_RECON_CHUNK");
+    v = e ? atoi(e) : KC;  // measured (MnistSvhn, K=10): 5-sample chunks 43.7 us, 3: 46.4, 2: 45.7, 1: 49.9 -> no finer cut
+    if (v < 1) v = 1;
+    if (v > KC) v = KC;
+  }
+  return v;
+}
+static int recon_kchunks(int K, long long D) {
+  const int cap = D > 1024 ? recon_max_chunk() : KC;
+  return (K + cap - 1) / cap;
+}
+
 template <bool VEC, bool FWD>
 __global__ __launch_bounds__(NLL_THREADS) void recon_nll_kernel(const ReconTable tb, int K, int B) {
   // locate the modality of this block
@@ -360,7 +436,7 @@ __global__ __launch_bounds__(NLL_THREADS) void recon_nll_kernel(const ReconTable
     if (i < tb.n && (int)blockIdx.x >= tb.block_start[i]) mi = i;
   const mvk_recon_desc& d = tb.d[mi];
   const int local = blockIdx.x - tb.block_start[mi];
-  const int kchunks = (K + KC - 1) / KC;
+  const int kchunks = tb.kchunks[mi];
   const int kper = (K + kchunks - 1) / kchunks;  // balanced chunks (K=10 -> 5+5, not 8+2)
   const int b = local / kchunks;
   const int k0 = (local % kchunks) * kper;
@@ -375,45 +451,10 @@ __global__ __launch_bounds__(NLL_THREADS) void recon_nll_kernel(const ReconTable
   for (int k = 0; k < KC; ++k) part[k] = 0.f;
 
   if (VEC) {
-    const int nv = (int)(D >> 2);
-    float4 xv[MAXV];
-#pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
-      const int idx = threadIdx.x + j * NLL_THREADS;
-      xv[j] = (idx < nv) ? reinterpret_cast<const float4*>(xrow)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      if (k < kn) {
-        const long long ro = ((long long)(k0 + k) * B + b) * D;
-        const float4* rp = reinterpret_cast<const float4*>(d.recon + ro);
-        float4* gp = d.drecon ? reinterpret_cast<float4*>(d.drecon + ro) : nullptr;
-        const float gw = gbase * (d.rowcoef ? d.rowcoef[(long long)(k0 + k) * B + b] : 1.0f);
-        float acc = 0.f;
-#pragma unroll
-        for (int j = 0; j < MAXV; ++j) {
-          const int idx = threadIdx.x + j * NLL_THREADS;
-          if (idx < nv) {
-            const float4 r = rp[idx];
-            float4 gr;
-            float n0, n1, n2, n3;
-            nll_elem(d.dist, inv_s, inv_s2, r.x, xv[j].x, n0, gr.x);
-            nll_elem(d.dist, inv_s, inv_s2, r.y, xv[j].y, n1, gr.y);
-            nll_elem(d.dist, inv_s, inv_s2, r.z, xv[j].z, n2, gr.z);
-            nll_elem(d.dist, inv_s, inv_s2, r.w, xv[j].w, n3, gr.w);
-            acc += (n0 + n1) + (n2 + n3);
-            if (gp) {
-              gr.x *= gw;
-              gr.y *= gw;
-              gr.z *= gw;
-              gr.w *= gw;
-              gp[idx] = gr;
-            }
-          }
-        }
-        part[k] = acc;
-      }
-    }
+    // distribution resolved once per block: the element loops below are branch-free
+    if (d.dist == MVK_DIST_NORMAL) recon_vec_body<MVK_DIST_NORMAL>(d, B, b, k0, kn, gbase, inv_s, inv_s2, xrow, part);
+    else if (d.dist == MVK_DIST_LAPLACE) recon_vec_body<MVK_DIST_LAPLACE>(d, B, b, k0, kn, gbase, inv_s, inv_s2, xrow, part);
+    else recon_vec_body<MVK_DIST_BERNOULLI>(d, B, b, k0, kn, gbase, inv_s, inv_s2, xrow, part);
   } else {
     for (int k = 0; k < kn; ++k) {
       const long long ro = ((long long)(k0 + k) * B + b) * D;
@@ -462,7 +503,6 @@ static int launch_recon(const mvk_recon_desc* descs, int n_mod, int K, int B, bo
         (d.drecon && !mvk_aligned16(d.drecon)))
       vec = false;
   }
-  const int kchunks = (K + KC - 1) / KC;
   // launch per vectorisability group so that a tiny modality does not de-vectorise a large one
   for (int pass = 0; pass < 2; ++pass) {
     ReconTable tb;
@@ -475,7 +515,8 @@ static int launch_recon(const mvk_recon_desc* descs, int n_mod, int K, int B, bo
       if ((pass == 0) != v) continue;
       tb.d[tb.n] = d;
       tb.block_start[tb.n] = blocks;
-      blocks += B * kchunks;
+      tb.kchunks[tb.n] = recon_kchunks(K, d.D);
+      blocks += B * tb.kchunks[tb.n];
       tb.n++;
     }
     if (tb.n == 0) continue;
