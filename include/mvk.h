@@ -149,6 +149,18 @@ int mvk_reduce_terms(const mvk_term_desc* terms, int n_terms, float loss_sum_sca
 
 /* buf[i] *= *gscale unless *gscale == 1 (no memory traffic in that case). */
 int mvk_scale_by_device_scalar(float* buf, int64_t n, const float* gscale, void* stream);
+/* Backward of the loss assembly in one launch (what autograd does for `loss = sum_i w_i * term_i` given d loss):
+ * buffers with fill == 0 (the d loss / d recon tensors written by mvk_recon_nll_fwd for an upstream gradient of 1) are
+ * multiplied in place by *gscale — skipped on the device when it is 1; buffers with fill != 0 (gradients of KL row
+ * tensors) are set to *gscale * coef. */
+#define MVK_SEED_MAX 12
+typedef struct mvk_seed_desc {
+  float* buf;
+  int64_t n;
+  float coef;
+  int32_t fill;
+} mvk_seed_desc;
+int mvk_loss_backward_seed(const mvk_seed_desc* jobs, int n, const float* gscale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * MMVAE: mixture-of-experts importance weights (IWAE / DReG)

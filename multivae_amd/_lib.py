@@ -34,6 +34,10 @@ class PackDesc(C.Structure):  # mvk_pack_desc
                 ("ld_down", C.c_int32), ("col_off", C.c_int32), ("kind", C.c_int32)]
 
 
+class SeedDesc(C.Structure):  # mvk_seed_desc
+    _fields_ = [("buf", _p), ("n", _i64), ("coef", _f), ("fill", C.c_int32)]
+
+
 class TermDesc(C.Structure):
     _fields_ = [("v", _p), ("mask", _p), ("n", _i64), ("period", _i64), ("coef", _f), ("lossw", _f)]
 
@@ -62,6 +66,7 @@ PROTOTYPES = {
     "mvk_conv4s2_down": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i64, _i, _p],
     "mvk_conv4s2_up": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i64, _i, _p],
     "mvk_pack_weights": [C.POINTER(PackDesc), _i, _p],
+    "mvk_loss_backward_seed": [C.POINTER(SeedDesc), _i, _p, _p],
     "mvk_f32_to_bf3": [_p, _i64, _p, _p],
     "mvk_bf3_to_f32": [_p, _i64, _p, _p],
     "mvk_conv3x3": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i64, _p],

@@ -111,6 +111,21 @@ __global__ void scale_kernel(float* __restrict__ buf, long long n, const float* 
   for (; i < n; i += stride) buf[i] *= s;
 }
 
+// Backward of the loss assembly in ONE launch: buffers with fill == 0 are multiplied in place by the upstream gradient
+// g (skipped when g == 1, the loss.backward() default); buffers with fill != 0 are set to g * coef (the gradient of a
+// row-sum term that entered the loss with a constant weight).  blockIdx.y selects the buffer.
+struct SeedJobs {
+  mvk_seed_desc j[MVK_SEED_MAX];
+};
+__global__ __launch_bounds__(256) void loss_seed_kernel(const SeedJobs jobs, const float* __restrict__ g) {
+  const mvk_seed_desc& d = jobs.j[blockIdx.y];
+  const float s = *g;
+  if (!d.fill && s == 1.0f) return;
+  const float v = s * d.coef;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < d.n; i += stride) d.buf[i] = d.fill ? v : d.buf[i] * s;
+}
+
 // ---- U[n,Cu,2h,2w] (NCHW) = act(convT(V[n,h,w,Cv]) + b), Cu <= 4: direct, one thread per output pixel ------
 template <int CU>
 __global__ __launch_bounds__(256) void up_nchw_small_kernel(const float* __restrict__ V,
@@ -311,6 +326,23 @@ int mvk_scale_by_device_scalar(float* buf, int64_t n, const float* gscale, void*
   if (!buf || !gscale) return MVK_EINVAL;
   if (n == 0) return MVK_OK;
   hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, 256)), dim3(256), 0, mvk_stream(stream), buf, (long long)n, gscale);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_loss_backward_seed(const mvk_seed_desc* jobs, int n, const float* gscale, void* stream) {
+  if (!jobs || !gscale || n <= 0 || n > MVK_SEED_MAX) return MVK_EINVAL;
+  SeedJobs sj{};
+  long long maxn = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!jobs[i].buf || jobs[i].n < 0) return MVK_EINVAL;
+    sj.j[i] = jobs[i];
+    if (jobs[i].n > maxn) maxn = jobs[i].n;
+  }
+  if (maxn == 0) return MVK_OK;
+  long long gx = (maxn + 255) / 256;
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(loss_seed_kernel, dim3((unsigned)gx, n), dim3(256), 0, mvk_stream(stream), sj, gscale);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }

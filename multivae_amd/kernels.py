@@ -15,7 +15,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import _lib
-from ._lib import ACT, DIST, FAMILY, PackDesc, ReconDesc, TermDesc, call, ptr, ptr_array, stream_ptr
+from ._lib import ACT, DIST, FAMILY, PackDesc, ReconDesc, SeedDesc, TermDesc, call, ptr, ptr_array, stream_ptr
 
 RELU, SIGMOID, NONE = ACT["relu"], ACT["sigmoid"], ACT["none"]
 
@@ -935,15 +935,17 @@ class ReconLossFn(Function):
     @once_differentiable
     def backward(ctx, gloss, gout):
         gloss = _c(gloss.reshape(1))
-        grads = []
-        for g in ctx.drecons:
-            if g is not None:
-                call("mvk_scale_by_device_scalar", ptr(g), g.numel(), ptr(gloss), stream_ptr())
-            grads.append(g)
-        for shape, c in zip(ctx.extra_shapes, ctx.extra_grad):
-            grads.append((gloss * c).expand(shape).contiguous())
+        grads = list(ctx.drecons)
+        extras = [_new(shape, gloss) for shape in ctx.extra_shapes]
+        jobs = [(g, 1.0, 0) for g in ctx.drecons if g is not None] + [(e, c, 1) for e, c in zip(extras, ctx.extra_grad)]
+        for i0 in range(0, len(jobs), 12):  # MVK_SEED_MAX buffers per launch: normally ONE launch
+            chunk = jobs[i0:i0 + 12]
+            descs = (SeedDesc * len(chunk))()
+            for d, (t, c, fill) in zip(descs, chunk):
+                d.buf, d.n, d.coef, d.fill = t.data_ptr(), t.numel(), float(c), fill
+            call("mvk_loss_backward_seed", descs, len(chunk), ptr(gloss), stream_ptr())
         ctx.drecons = None
-        return (None, None, *grads)
+        return (None, None, *grads, *extras)
 
 
 def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
