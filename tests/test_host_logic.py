@@ -186,3 +186,28 @@ def test_trainer_config_validation(monkeypatch):
     monkeypatch.setenv("LOCAL_RANK", "1")
     c = BaseTrainerConfig()
     assert (c.world_size, c.rank, c.local_rank) == (4, 3, 1)
+
+
+def test_jmvae_and_mmvaeplus_save_load_roundtrip(tmp_path):
+    """The reference folder layout (model.pt / model_config.json / environment.json) for the joint-encoder and the
+    split-latent models; state_dict keys follow the reference's module tree (joint_encoder.*, mean_priors.*, ...)."""
+    from multivae_amd.models import JMVAE, JMVAEConfig, MMVAEPlus, MMVAEPlusConfig
+
+    dims = dict(a=(2, 3), b=(7,))
+    jm = JMVAE(JMVAEConfig(n_modalities=2, latent_dim=5, input_dims=dims, alpha=0.3, warmup=4))
+    assert {"joint_encoder.fc1.weight", "joint_encoder.encoders.a.embedding.weight", "joint_encoder.enc.1.0.bias"} <= set(
+        jm.state_dict())
+    jm.save(str(tmp_path / "jm"))
+    jm2 = JMVAE.load_from_folder(str(tmp_path / "jm"))
+    assert jm2.model_config.alpha == 0.3 and jm2.warmup == 4
+    assert all(torch.equal(v, jm2.state_dict()[k]) for k, v in jm.state_dict().items())
+    mp = MMVAEPlus(MMVAEPlusConfig(n_modalities=2, latent_dim=5, input_dims=dims, modalities_specific_dim=3, beta=2.5))
+    assert {"logvars_priors.shared", "mean_priors.a", "encoders.b.style_log_var.bias"} <= set(mp.state_dict())
+    assert mp.logvars_priors["a"].requires_grad and not mp.logvars_priors["shared"].requires_grad
+    assert mp.state_dict()["decoders.a.layers.0.0.weight"].shape == (512, 8)  # shared + private latent
+    mp.save(str(tmp_path / "mp"))
+    mp2 = MMVAEPlus.load_from_folder(str(tmp_path / "mp"))
+    assert mp2.beta == 2.5 and mp2.modalities_specific_dim == 3
+    assert all(torch.equal(v, mp2.state_dict()[k]) for k, v in mp.state_dict().items())
+    with pytest.raises(AttributeError):
+        JMVAE(JMVAEConfig(n_modalities=2, latent_dim=5, input_dims=dims), joint_encoder=torch.nn.Linear(2, 2))
