@@ -246,6 +246,10 @@ int mvk_linear_bwd_data(const float* dY, const float* W, float* dX, int M, int N
 int mvk_linear_bwd_weight(const float* dY, const float* X, float* dW, float* db, int M, int N, int K,
                           const float* y_out, int y_act, float* ws, int64_t ws_floats, void* stream);
 int64_t mvk_splitk_workspace_floats(int rows, int cols, int reduce_len);
+/* dPre[M,N] = dY * act'(Y) and, if db != NULL, db[n] += sum_m dPre[m,n], in one pass over dY and Y (ordered
+ * per-workgroup partials in the caller-owned scratch ws).  The output-layer backward of the MLP decoders. */
+int mvk_act_bwd_colsum(const float* dY, const float* Y, int act, int M, int N, float* dPre, float* db, float* ws,
+                       int64_t ws_floats, void* stream);
 /* db[N] += column sums of dY[M,N] (* act'(y_out)). */
 int mvk_colsum_acc(const float* dY, const float* y_out, int y_act, float* db, int M, int N, void* stream);
 /* db[c] += sum over n and spatial positions of dY[n,c,hw] (* act'(y_out)) for NCHW tensors. */

@@ -58,6 +58,7 @@ PROTOTYPES = {
     "mvk_linear_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p, _i64, _p],
     "mvk_linear_bwd_data": [_p, _p, _p, _i, _i, _i, _p, _i, _p, _i, _i, _p, _p, _i64, _p],
     "mvk_linear_bwd_weight": [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _i64, _p],
+    "mvk_act_bwd_colsum": [_p, _p, _i, _i, _i, _p, _p, _p, _i64, _p],
     "mvk_colsum_acc": [_p, _p, _i, _p, _i, _i, _p],
     "mvk_nchw_channel_sum_acc": [_p, _p, _i, _p, _i, _i, _i, _p],
     "mvk_act_bwd": [_p, _p, _i64, _i, _p],

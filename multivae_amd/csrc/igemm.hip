@@ -409,6 +409,43 @@ int convref_reduce(const float* slab, int nz, int Cu, int Cv, int taps, float* d
   return MVK_OK;
 }
 
+// dPre[m][n] = dY[m][n] * act'(Y[m][n]) and per-workgroup column sums of dPre in ONE pass over dY / Y (the output-layer
+// backward of the MLP decoders: the pre-activation gradient is needed by the weight- and data-gradient GEMMs and its
+// column sums are the bias gradient).  part[(block)][N]; rows_per_block rows per workgroup; N % 4 == 0.
+__global__ void act_bwd_plain_kernel(float* __restrict__ dY, const float* __restrict__ Y, long long n, int act) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    dY[i] *= mvk_act_grad_from_out(Y[i], act);
+}
+
+__global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
+                                                             int act, int M, int N, int rows_per_block,
+                                                             float* __restrict__ dPre, float* __restrict__ part) {
+  const int nq = N >> 2;
+  const int r0 = blockIdx.x * rows_per_block;
+  int r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
+  for (int q = threadIdx.x; q < nq; q += 256) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int r = r0; r < r1; ++r) {
+      const long long o = (long long)r * N + 4 * q;
+      float4 v = *reinterpret_cast<const float4*>(dY + o);
+      const float4 y = *reinterpret_cast<const float4*>(Y + o);
+      v.x *= mvk_act_grad_from_out(y.x, act);
+      v.y *= mvk_act_grad_from_out(y.y, act);
+      v.z *= mvk_act_grad_from_out(y.z, act);
+      v.w *= mvk_act_grad_from_out(y.w, act);
+      *reinterpret_cast<float4*>(dPre + o) = v;
+      acc.x += v.x;
+      acc.y += v.y;
+      acc.z += v.z;
+      acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(part + (long long)blockIdx.x * N + 4 * q) = acc;
+  }
+}
+
 // GEMM launch + `db[n] += column sums of the stored output` (bias gradient of the layer that produced the GEMM's
 // input gradient).  Fused into the epilogue when the vectorised epilogue applies and the partials fit in ws;
 // otherwise a separate pass over the output.
@@ -499,6 +536,30 @@ int mvk_linear_bwd_weight(const float* dY, const float* X, float* dW, float* db,
   if (rc) return rc;
   if (db) return colsum(dY, y_out, y_act, M, N, db, s);
   return MVK_OK;
+}
+
+int mvk_act_bwd_colsum(const float* dY, const float* Y, int act, int M, int N, float* dPre, float* db, float* ws,
+                       int64_t ws_floats, void* stream) {
+  if (!dY || !Y || !dPre || M < 0 || N <= 0) return MVK_EINVAL;
+  if (M == 0) return MVK_OK;
+  hipStream_t s = mvk_stream(stream);
+  int rpb = (M + 1023) / 1024;  // ~1024 workgroups
+  if (rpb < 4) rpb = 4;
+  const int blocks = (M + rpb - 1) / rpb;
+  const bool fused = (N % 4 == 0) && mvk_aligned16(dY) && mvk_aligned16(Y) && mvk_aligned16(dPre) && ws &&
+                     mvk_aligned16(ws) && (!db || (long long)blocks * N <= ws_floats);
+  if (!fused) {  // generic route: elementwise pass, then the column-sum kernel
+    if (dPre != dY && hipMemcpyAsync(dPre, dY, sizeof(float) * (size_t)M * N, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      return MVK_ELAUNCH;
+    const long long n = (long long)M * N;
+    hipLaunchKernelGGL(act_bwd_plain_kernel, dim3((unsigned)((n + 255) / 256 > 65535 ? 65535 : (n + 255) / 256)), dim3(256),
+                       0, s, dPre, Y, n, act);
+    MVK_CHECK_LAUNCH();
+    return db ? colsum(dPre, nullptr, 0, M, N, db, s) : MVK_OK;
+  }
+  hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3(blocks), dim3(256), 0, s, dY, Y, act, M, N, rpb, dPre, ws);
+  MVK_CHECK_LAUNCH();
+  return db ? colsum_finish(ws, blocks, N, db, s) : MVK_OK;
 }
 
 int mvk_colsum_acc(const float* dY, const float* y_out, int y_act, float* db, int M, int N, void* stream) {

@@ -452,8 +452,15 @@ class MLPDecoderFn(Function):
     def backward(ctx, dout):
         z2, h, out, w0, b0, w1, b1 = ctx.saved_tensors
         dout = _c(dout).view(out.shape)
-        dw1, db1 = linear_bwd_weight(dout, h, w1, b1, y_out=out, y_act=SIGMOID)
-        dh, db0 = linear_bwd_data(dout, w1, y_out=out, y_act=SIGMOID, prev_out=h, prev_act=RELU, prev_bias=b0)
+        # pre-activation gradient of the output layer + its bias gradient in one pass; the two GEMMs then read it
+        # plainly (instead of re-deriving it from dout and out on every operand load, and a third time for the bias)
+        dpre = torch.empty_like(dout)
+        tb1, db1 = _grad_target(b1)
+        ws = _ws(dout)
+        call("mvk_act_bwd_colsum", ptr(dout), ptr(out), SIGMOID, dout.shape[0], dout.shape[1], ptr(dpre), ptr(tb1),
+             ptr(ws), ws.numel(), stream_ptr())
+        dw1, _ = linear_bwd_weight(dpre, h, w1, None)
+        dh, db0 = linear_bwd_data(dpre, w1, prev_out=h, prev_act=RELU, prev_bias=b0)
         dw0, _ = linear_bwd_weight(dh, z2, w0, None)
         dz = None
         if ctx.needs_input_grad[0]:
