@@ -11,6 +11,16 @@
 // exactly once.  v_mfma_f32_16x16x4_f32: exact fp32.
 #include "common.hpp"
 
+#ifndef MVK_SMALL_FWD_THREADS
+// Threads per workgroup (LDS allows 2 workgroups per CU either way).  Measured inside the MoPoE step (B=512, 3x32 ch):
+// forward 89 us at 256 threads -> 67 us at 512 (more loads in flight); backward 152 us at 256 -> 188 us at 512 (the
+// per-wave weight-gradient accumulators are replicated over twice the waves), so the two kernels differ.
+#define MVK_SMALL_FWD_THREADS 512
+#endif
+#ifndef MVK_SMALL_BWD_THREADS
+#define MVK_SMALL_BWD_THREADS 256
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -28,40 +38,42 @@ struct SmallCfg {
 // ---------------------------------------------------------------------------------------------------------
 // forward: U[n,Cu,2h,2w] = act(convT(V[n,h,w,Cv]) + b)
 // ---------------------------------------------------------------------------------------------------------
-template <int CU, int CV>
-__global__ __launch_bounds__(256) void small_up_fwd_kernel(const float* __restrict__ V, const float* __restrict__ Wref,
+template <int CU, int CV, int NT>
+__global__ __launch_bounds__(NT) void small_up_fwd_kernel(const float* __restrict__ V, const float* __restrict__ Wref,
                                                            const float* __restrict__ bias, float* __restrict__ U, int n,
                                                            int h, int w, int act) {
   using C = SmallCfg<CU, CV>;
+  constexpr int WP = 256 / (NT / 64);  // positions per wave (NT = 256: 64, NT = 512: 32)
+  constexpr int MT = WP / 16;          // 16-row MFMA tiles per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ws = smem;                 // [CV][NC]  == Wref[cv][cu][tap] as is
   float* buf = smem + CV * C::NC;   // V tile [P][VS], later the column matrix [P][CS]
   const int P = h * w;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
-  for (int i = tid; i < CV * C::NC; i += 256) Ws[i] = Wref[i];
-  constexpr int NV = 256 * CV / 4 / 256;  // float4 per thread for a full 256-position tile
+  for (int i = tid; i < CV * C::NC; i += NT) Ws[i] = Wref[i];
+  constexpr int NV = 256 * CV / 4 / NT;  // float4 per thread for a full 256-position tile
   const int n4 = P * CV / 4;
   f32x4 pre[NV];  // ext-vector type: HIP's float4 struct arrays are not promoted to registers here
   auto prefetch = [&](long long img) __attribute__((always_inline)) {
     const f32x4* src = reinterpret_cast<const f32x4*>(V + img * P * CV);
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
-      const int idx = tid + u * 256;
+      const int idx = tid + u * NT;
       pre[u] = src[idx < n4 ? idx : n4 - 1];  // clamped: unconditional loads keep pre[] in registers
     }
   };
-  const bool active = wave * 64 < P;
+  const bool active = wave * WP < P;
   const int H2 = 2 * h, W2 = 2 * w;
   const int per_img = CU * H2 * W2;
   // Output geometry is the same for every image: this thread's outputs o = tid + 256 t and, for each, the LDS
   // word of its (up to) 2x2 contributing column-matrix entries.  Missing taps (image border) point at a zero word.
-  constexpr int NO = (CU * 32 * 32 + 255) / 256;  // h, w <= 16
+  constexpr int NO = (CU * 32 * 32 + NT - 1) / NT;  // h, w <= 16
   const int zidx = P * (C::VS > C::CS ? C::VS : C::CS);  // one float past both uses of buf, kept at 0
   int tap[NO][4];
   float bia[NO];
 #pragma unroll
   for (int t = 0; t < NO; ++t) {
-    const int o = tid + t * 256;
+    const int o = tid + t * NT;
     const int oc = o < per_img ? o : 0;
     const int cu = oc / (H2 * W2);
     const int rem = oc - cu * (H2 * W2);
@@ -85,7 +97,7 @@ __global__ __launch_bounds__(256) void small_up_fwd_kernel(const float* __restri
     // stage this image's V tile (prefetched one iteration ago), then start fetching the next image
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
-      const int idx = tid + u * 256;
+      const int idx = tid + u * NT;
       if (idx < n4) {
         const int pos = idx / (CV / 4), q = idx - pos * (CV / 4);
         *reinterpret_cast<f32x4*>(buf + pos * C::VS + 4 * q) = pre[u];
@@ -93,22 +105,22 @@ __global__ __launch_bounds__(256) void small_up_fwd_kernel(const float* __restri
     }
     __syncthreads();
     if (img + gridDim.x < n) prefetch(img + gridDim.x);
-    f32x4 acc[C::MT][CU];
+    f32x4 acc[MT][CU];
 #pragma unroll
-    for (int a = 0; a < C::MT; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
       for (int b = 0; b < CU; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (active) {
 #pragma unroll 2
       for (int ks = 0; ks < CV / 4; ++ks) {
         const int k = ks * 4 + lq;
-        float av[C::MT], bv[CU];
+        float av[MT], bv[CU];
 #pragma unroll
-        for (int a = 0; a < C::MT; ++a) av[a] = buf[(wave * 64 + a * 16 + l15) * C::VS + k];
+        for (int a = 0; a < MT; ++a) av[a] = buf[(wave * WP + a * 16 + l15) * C::VS + k];
 #pragma unroll
         for (int b = 0; b < CU; ++b) bv[b] = Ws[k * C::NC + b * 16 + l15];
 #pragma unroll
-        for (int a = 0; a < C::MT; ++a)
+        for (int a = 0; a < MT; ++a)
 #pragma unroll
           for (int b = 0; b < CU; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
       }
@@ -116,17 +128,17 @@ __global__ __launch_bounds__(256) void small_up_fwd_kernel(const float* __restri
     __syncthreads();  // every wave is done with the V tile
     if (active) {
 #pragma unroll
-      for (int a = 0; a < C::MT; ++a)
+      for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < CU; ++b)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) buf[(wave * 64 + a * 16 + lq * 4 + r) * C::CS + b * 16 + l15] = acc[a][b][r];
+          for (int r = 0; r < 4; ++r) buf[(wave * WP + a * 16 + lq * 4 + r) * C::CS + b * 16 + l15] = acc[a][b][r];
     }
     __syncthreads();
     float* out = U + img * per_img;
 #pragma unroll
     for (int t = 0; t < NO; ++t) {
-      const int o = tid + t * 256;
+      const int o = tid + t * NT;
       if (o < per_img) {
         const float sum = ((buf[tap[t][0]] + buf[tap[t][1]]) + (buf[tap[t][2]] + buf[tap[t][3]])) + bia[t];
         out[o] = mvk_act(sum, act);
@@ -139,12 +151,15 @@ __global__ __launch_bounds__(256) void small_up_fwd_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------------------
 // backward: dV = down(dUpre) * act'(V),  partial dW / db per workgroup (persistent over images)
 // ---------------------------------------------------------------------------------------------------------
-template <int CU, int CV>
-__global__ __launch_bounds__(256) void small_up_bwd_kernel(const float* __restrict__ dU, const float* __restrict__ Uout,
+template <int CU, int CV, int NT>
+__global__ __launch_bounds__(NT) void small_up_bwd_kernel(const float* __restrict__ dU, const float* __restrict__ Uout,
                                                            int u_act, const float* __restrict__ V, int v_act,
                                                            const float* __restrict__ Wref, float* __restrict__ dV,
                                                            float* __restrict__ partial, int n, int h, int w) {
   using C = SmallCfg<CU, CV>;
+  constexpr int NW = NT / 64;    // waves per workgroup
+  constexpr int WP = 256 / NW;   // positions per wave
+  constexpr int MT = WP / 16;    // 16-row MFMA tiles per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int P = h * w, DH = 2 * h + 2, DW = 2 * w + 2;
   float* Wt = smem;                       // [NC][WT]: Wt[k=(cu,tap)][cv] = Wref[cv][k]
@@ -152,12 +167,12 @@ __global__ __launch_bounds__(256) void small_up_bwd_kernel(const float* __restri
   float* Vs = Ds + ((CU * DH * DW + 3) & ~3);  // [P][VS]
   int* posoff = reinterpret_cast<int*>(Vs + P * C::VS);  // [P]: (2i)*DW + 2j
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
-  for (int i = tid; i < CV * C::NC; i += 256) {
+  for (int i = tid; i < CV * C::NC; i += NT) {
     const int cv = i / C::NC, k = i - cv * C::NC;
     Wt[k * C::WT + cv] = Wref[i];
   }
-  for (int p = tid; p < P; p += 256) posoff[p] = (2 * (p / w)) * DW + 2 * (p % w);
-  const bool active = wave * 64 < P;
+  for (int p = tid; p < P; p += NT) posoff[p] = (2 * (p / w)) * DW + 2 * (p % w);
+  const bool active = wave * WP < P;
 
   f32x4 accw[C::NTV][CU];
 #pragma unroll
@@ -173,8 +188,8 @@ __global__ __launch_bounds__(256) void small_up_bwd_kernel(const float* __restri
 
   const int H2 = 2 * h, W2 = 2 * w;
   // register prefetch of the NEXT image's three tiles (dU, Uout with halo indexing; V as float4)
-  constexpr int ND = (CU * 34 * 34 + 255) / 256;  // halo-tile elements per thread (h, w <= 16)
-  constexpr int NV = 256 * CV / 4 / 256;
+  constexpr int ND = (CU * 34 * 34 + NT - 1) / NT;  // halo-tile elements per thread (h, w <= 16)
+  constexpr int NV = 256 * CV / 4 / NT;
   const int nd = CU * DH * DW, n4 = P * CV / 4;
   float pdu[ND], puo[ND];
   f32x4 pv[NV];
@@ -182,7 +197,7 @@ __global__ __launch_bounds__(256) void small_up_bwd_kernel(const float* __restri
   int hoff[ND];   // bits 0..27 offset into the image, 28..29 channel, 30 inside the image
 #pragma unroll
   for (int u = 0; u < ND; ++u) {
-    const int idx = tid + u * 256;
+    const int idx = tid + u * NT;
     const int idc = idx < nd ? idx : nd - 1;
     const int cu = idc / (DH * DW);
     const int rem = idc - cu * (DH * DW);
@@ -206,7 +221,7 @@ __global__ __launch_bounds__(256) void small_up_bwd_kernel(const float* __restri
     const f32x4* src = reinterpret_cast<const f32x4*>(V + img * P * CV);
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
-      const int idx = tid + u * 256;
+      const int idx = tid + u * NT;
       pv[u] = src[idx < n4 ? idx : n4 - 1];
     }
   };
@@ -216,7 +231,7 @@ __global__ __launch_bounds__(256) void small_up_bwd_kernel(const float* __restri
     // --- stage dUpre with halo (sigmoid' applied here), bias-gradient partials, and the V tile
 #pragma unroll
     for (int u = 0; u < ND; ++u) {
-      const int idx = tid + u * 256;
+      const int idx = tid + u * NT;
       if (idx < nd) {
         const float v = pdu[u] * mvk_act_grad_from_out(puo[u], u_act);  // halo: 0 * act'(0) = 0
         Ds[idx] = v;
@@ -228,7 +243,7 @@ __global__ __launch_bounds__(256) void small_up_bwd_kernel(const float* __restri
     }
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
-      const int idx = tid + u * 256;
+      const int idx = tid + u * NT;
       if (idx < n4) {
         const int pos = idx / (CV / 4), q = idx - pos * (CV / 4);
         *reinterpret_cast<f32x4*>(Vs + pos * C::VS + 4 * q) = pv[u];
@@ -238,45 +253,45 @@ __global__ __launch_bounds__(256) void small_up_bwd_kernel(const float* __restri
     if (img + gridDim.x < n) prefetch(img + gridDim.x);
     if (!active) continue;
     // --- backward data: dV[pos][cv] = sum_{k=(cu,kh,kw)} dUpre[cu][2i-1+kh][2j-1+kw] * W[cv][k]
-    f32x4 acc[C::MT][C::NTV];
+    f32x4 acc[MT][C::NTV];
 #pragma unroll
-    for (int a = 0; a < C::MT; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
       for (int b = 0; b < C::NTV; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int po[C::MT];
+    int po[MT];
 #pragma unroll
-    for (int a = 0; a < C::MT; ++a) po[a] = posoff[wave * 64 + a * 16 + l15];
+    for (int a = 0; a < MT; ++a) po[a] = posoff[wave * WP + a * 16 + l15];
 #pragma unroll 2
     for (int ks = 0; ks < C::NC / 4; ++ks) {
       const int k = ks * 4 + lq;
       const int koff = (k >> 4) * DH * DW + ((k >> 2) & 3) * DW + (k & 3);
-      float av[C::MT], bv[C::NTV];
+      float av[MT], bv[C::NTV];
 #pragma unroll
-      for (int a = 0; a < C::MT; ++a) av[a] = Ds[koff + po[a]];
+      for (int a = 0; a < MT; ++a) av[a] = Ds[koff + po[a]];
 #pragma unroll
       for (int b = 0; b < C::NTV; ++b) bv[b] = Wt[k * C::WT + b * 16 + l15];
 #pragma unroll
-      for (int a = 0; a < C::MT; ++a)
+      for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < C::NTV; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
     }
     float* dv = dV + img * P * CV;
 #pragma unroll
-    for (int a = 0; a < C::MT; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
       for (int b = 0; b < C::NTV; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int pos = wave * 64 + a * 16 + lq * 4 + r, cv = b * 16 + l15;
+          const int pos = wave * WP + a * 16 + lq * 4 + r, cv = b * 16 + l15;
           const float g = acc[a][b][r] * mvk_act_grad_from_out(Vs[pos * C::VS + cv], v_act);
           dv[pos * CV + cv] = g;
           dbv[b] += g;
         }
-    // --- backward weight: dW[cv][k] += sum_pos V[pos][cv] * dUpre(gathered)[pos][k]; this wave's 64 positions
+    // --- backward weight: dW[cv][k] += sum_pos V[pos][cv] * dUpre(gathered)[pos][k]; this wave's WP positions
 #pragma unroll 2
-    for (int ks = 0; ks < 16; ++ks) {
-      const int kpos = wave * 64 + ks * 4 + lq;
+    for (int ks = 0; ks < WP / 4; ++ks) {
+      const int kpos = wave * WP + ks * 4 + lq;
       const int pbase = posoff[kpos];
       float av[C::NTV], bv[CU];
 #pragma unroll
@@ -292,19 +307,25 @@ __global__ __launch_bounds__(256) void small_up_bwd_kernel(const float* __restri
   }
   // --- cross-wave reduction of the weight / bias partials, one slab per workgroup
   __syncthreads();
-  float* red = smem;  // [4 waves][CV*NC] — reuses Wt/Ds/Vs (needs 4*CV*NC floats)
+  float* red = smem;  // [4][CV*NC] — reuses Wt/Ds/Vs (needs 4*CV*NC floats); waves 4.. add into the slab of wave-4
+#pragma unroll 1
+  for (int pass = 0; pass < NW / 4; ++pass) {
+    if ((wave >> 2) == pass) {
 #pragma unroll
-  for (int a = 0; a < C::NTV; ++a)
+      for (int a = 0; a < C::NTV; ++a)
 #pragma unroll
-    for (int b = 0; b < CU; ++b)
+        for (int b = 0; b < CU; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int cv = a * 16 + lq * 4 + r, col = b * 16 + l15;
-        red[wave * CV * C::NC + cv * C::NC + col] = accw[a][b][r];
-      }
-  __syncthreads();
+          for (int r = 0; r < 4; ++r) {
+            const int cv = a * 16 + lq * 4 + r, col = b * 16 + l15;
+            float* dst = red + (wave & 3) * CV * C::NC + cv * C::NC + col;
+            *dst = pass == 0 ? accw[a][b][r] : *dst + accw[a][b][r];
+          }
+    }
+    __syncthreads();
+  }
   float* slab = partial + (long long)blockIdx.x * (CV * C::NC + CU + CV);
-  for (int i = tid; i < CV * C::NC; i += 256)
+  for (int i = tid; i < CV * C::NC; i += NT)
     slab[i] = red[i] + red[CV * C::NC + i] + red[2 * CV * C::NC + i] + red[3 * CV * C::NC + i];
   __syncthreads();
   // bias partials
@@ -312,20 +333,25 @@ __global__ __launch_bounds__(256) void small_up_bwd_kernel(const float* __restri
 #pragma unroll
   for (int c = 0; c < CU; ++c) {
     const float s = wave_sum(dbl[c]);
-    if (lane == 0) bred[c * 4 + wave] = s;
+    if (lane == 0) bred[c * NW + wave] = s;
   }
   __syncthreads();
-  if (tid < CU) slab[CV * C::NC + tid] = bred[tid * 4] + bred[tid * 4 + 1] + bred[tid * 4 + 2] + bred[tid * 4 + 3];
+  if (tid < CU) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) t += bred[tid * NW + q];
+    slab[CV * C::NC + tid] = t;
+  }
   __syncthreads();
   // column sums of dV: combine the 4 lq groups of each wave, then the 4 waves
-  float* vred = smem;  // [CV][16]
+  float* vred = smem;  // [CV][NW*4]
 #pragma unroll
-  for (int b = 0; b < C::NTV; ++b) vred[(b * 16 + l15) * 16 + wave * 4 + lq] = dbv[b];
+  for (int b = 0; b < C::NTV; ++b) vred[(b * 16 + l15) * (NW * 4) + wave * 4 + lq] = dbv[b];
   __syncthreads();
   if (tid < CV) {
     float t = 0.f;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) t += vred[tid * 16 + q];
+    for (int q = 0; q < NW * 4; ++q) t += vred[tid * (NW * 4) + q];
     slab[CV * C::NC + CU + tid] = t;
   }
 }
@@ -381,11 +407,12 @@ template <int CU, int CV>
 static int launch_fwd(const float* V, const float* Wref, const float* bias, float* U, int n, int h, int w, int act,
                       hipStream_t s) {
   const size_t lds = fwd_lds<CU, CV>(h * w);
+  constexpr int NT = MVK_SMALL_FWD_THREADS;
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_fwd_kernel<CU, CV>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_fwd_kernel<CU, CV, NT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int grid = n < 512 ? n : 512;  // persistent: 2 workgroups per CU, each loops over images with prefetch
-  hipLaunchKernelGGL((small_up_fwd_kernel<CU, CV>), dim3(grid), dim3(256), lds, s, V, Wref, bias, U, n, h, w, act);
+  hipLaunchKernelGGL((small_up_fwd_kernel<CU, CV, NT>), dim3(grid), dim3(NT), lds, s, V, Wref, bias, U, n, h, w, act);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }
@@ -400,10 +427,11 @@ static int launch_bwd(const float* dU, const float* Uout, int u_act, const float
   if ((int64_t)grid * slab > ws_floats) grid = (int)(ws_floats / slab);
   if (grid < 1) return MVK_EINVAL;
   const size_t lds = bwd_lds<CU, CV>(h, w);
+  constexpr int NT = MVK_SMALL_BWD_THREADS;
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_bwd_kernel<CU, CV>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_bwd_kernel<CU, CV, NT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((small_up_bwd_kernel<CU, CV>), dim3(grid), dim3(256), lds, s, dU, Uout, u_act, V, v_act, Wref, dV,
+  hipLaunchKernelGGL((small_up_bwd_kernel<CU, CV, NT>), dim3(grid), dim3(NT), lds, s, dU, Uout, u_act, V, v_act, Wref, dV,
                      ws, n, h, w);
   MVK_CHECK_LAUNCH();
   const int total = CV * C::NC + CU + CV;
