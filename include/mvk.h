@@ -29,6 +29,7 @@ extern "C" {
 #define MVK_ELAUNCH (-2)
 
 #define MVK_MAX_MODALITIES 8
+#define MVK_IWAE_MAX_EXPERTS 32 /* experts of the mixture posterior in mvk_iwae_logw (MoPoE: 2^5 - 1 subsets) */
 
 /* decoder output distributions — models/base/base_utils.py:62-87 (set_decoder_dist) */
 #define MVK_DIST_NORMAL 0
@@ -219,6 +220,32 @@ int mvk_mmvaeplus_cross_latent_fwd(const float* z, const float* prior_std, const
                                    int Ls, int family, float* zc, void* stream);
 int mvk_mmvaeplus_cross_latent_bwd(const float* dzc, const float* noise, int64_t rows, int D, int Ls, int family,
                                    float* dz, float* dprior_std, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Importance-sampled joint likelihood (compute_joint_nll; metrics/likelihoods/likelihoods.py:39-56 is the caller)
+ * ------------------------------------------------------------------------------------------------ */
+
+/* z[k,b,:] = loc[b,:] + sd[b,:] * t(noise[k,b,:]) (t as in mvk_mmvae_latent_fwd): the K importance samples of every
+ * data point, `rsample_from_gaussian(mu, lv, N=K)` (base_utils.py:150-172) / `post_dist(mu, sd).rsample([K])`.
+ * loc, sd [B,L]; noise, z [K,B,L]. */
+int mvk_iwae_sample(const float* loc, const float* sd, const float* noise, int K, int B, int L, int family, float* z,
+                    void* stream);
+
+/* lw[k,b] = -sum_r rows[r][k,b] + sum_l log p(z[k,b,l]) - (logsumexp_e sum_l log q_e(z[k,b,l]) - log E)
+ * with q_e = family(loc[e][b,:], sd[e][b,:]) and the prior family(prior_loc, prior_sd) (NULL: 0 / 1).  Replaces the
+ * per-data-point, per-chunk bodies of mopoe_model.py:524-588, mmvae_model.py:400-437, mvtcae_model.py:250-284 and
+ * joint_model.py:113-148.  rows: HOST array of n_rows device pointers to [K,B] UNRESCALED NLL rows
+ * (mvk_recon_nll_fwd with rescale = 1); loc, sd: HOST arrays of E <= MVK_IWAE_MAX_EXPERTS device pointers [B,L];
+ * z [K,B,L]; lw [K,B]. */
+int mvk_iwae_logw(const float* z, const float* const* rows, int n_rows, const float* const* loc,
+                  const float* const* sd, int E, const float* prior_loc, const float* prior_sd, int K, int B, int L,
+                  int family, float* lw, void* stream);
+
+/* ll[b] = logsumexp over the n arrays lw[j][k,b] (k < K) - log(n K): the log-mean-exp of the importance weights
+ * (the two-level logsumexp over K-chunks of the reference is the same number; MMVAE+ concatenates the weights of its
+ * M conditioning modalities, mmvaePlus_model.py:521-525).  lw: HOST array of n <= MVK_MAX_MODALITIES device
+ * pointers [K,B]; ll [B]. */
+int mvk_iwae_reduce(const float* const* lw, int n, int K, int B, float* ll, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Encoder / decoder layers: implicit GEMM with fp32 operands and results.  Default engine: split-bf16 MFMA

@@ -390,6 +390,79 @@ __global__ __launch_bounds__(256) void cross_latent_bwd_kernel(const float* __re
   dz[i] = l < Ls ? dzc[i] : 0.f;
 }
 
+// ---- importance-sampled joint likelihood (compute_joint_nll) -------------------------------------------------
+// ln p(x_b) ~= logsumexp_k [ sum_m ln p(x_m | z_kb) + ln p(z_kb) - ln q(z_kb | x_b) ] - ln K with q a uniform mixture
+// of E experts (the S subset posteriors of MoPoE, mopoe_model.py:467-594; the M unimodal posteriors of MMVAE,
+// mmvae_model.py:365-443; a single joint posterior for MVTCAE, mvtcae_model.py:213-291, and JMVAE,
+// joint_model.py:82-154).  The reference walks data points and K-chunks in Python; here the K axis is the leading
+// axis of one [K,B] problem (the decoders and mvk_recon_nll_fwd produce the likelihood rows).
+constexpr int MAXE = MVK_IWAE_MAX_EXPERTS;
+struct IwaePtrs {
+  const float* rows[MAXM];
+  const float* loc[MAXE];
+  const float* sd[MAXE];
+};
+
+__global__ __launch_bounds__(256) void iwae_sample_kernel(const float* __restrict__ loc, const float* __restrict__ sd,
+                                                          const float* __restrict__ noise, long long n, int BL,
+                                                          int family, float* __restrict__ z) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int j = (int)(i % BL);
+  z[i] = loc[j] + sd[j] * lat_t(family, noise[i]);
+}
+
+// one thread per (k,b): the expert parameters of row b are shared by the K threads of that column (L1 / L2 hits)
+__global__ __launch_bounds__(256) void iwae_logw_kernel(IwaePtrs a, const float* __restrict__ z,
+                                                        const float* __restrict__ prior_loc,
+                                                        const float* __restrict__ prior_sd, int K, int B, int L, int E,
+                                                        int R, int family, float* __restrict__ lw) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)K * B) return;
+  const int b = (int)(i % B);
+  const float* zr = z + i * L;
+  float lpz = 0.f;
+  for (int l = 0; l < L; ++l)
+    lpz += lat_logp(family, zr[l], prior_loc ? prior_loc[l] : 0.f, prior_sd ? prior_sd[l] : 1.f);
+  float m = -INFINITY, s = 0.f;  // running logsumexp over the experts
+  for (int e = 0; e < E; ++e) {
+    const float* lo = a.loc[e] + (long long)b * L;
+    const float* sd = a.sd[e] + (long long)b * L;
+    float lq = 0.f;
+    for (int l = 0; l < L; ++l) lq += lat_logp(family, zr[l], lo[l], sd[l]);
+    if (lq > m) {
+      s = s * expf(m - lq) + 1.f;
+      m = lq;
+    } else if (lq > -INFINITY) {
+      s += expf(lq - m);
+    }
+  }
+  const float lqz = m + logf(s) - logf((float)E);
+  float lpx = 0.f;
+  for (int r = 0; r < R; ++r) lpx -= a.rows[r][i];
+  lw[i] = lpx + lpz - lqz;
+}
+
+// ll[b] = logsumexp over the n arrays x K samples of lw[.][k,b] - ln(n K); one wave per data point
+struct IwaeLw {
+  const float* lw[MAXM];
+};
+__global__ __launch_bounds__(256) void iwae_reduce_kernel(IwaeLw a, int n, int K, int B, float* __restrict__ ll) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float m = -INFINITY;
+  for (int j = 0; j < n; ++j)
+    for (int k = lane; k < K; k += 64) m = fmaxf(m, a.lw[j][(long long)k * B + b]);
+  m = wave_max(m);
+  float s = 0.f;
+  if (m > -INFINITY)
+    for (int j = 0; j < n; ++j)
+      for (int k = lane; k < K; k += 64) s += expf(a.lw[j][(long long)k * B + b] - m);
+  s = wave_sum(s);
+  if (lane == 0) ll[b] = m + logf(s) - logf((float)n * (float)K);
+}
+
 }  // namespace
 
 extern "C" {
@@ -519,6 +592,55 @@ int mvk_mmvae_latent_bwd(const float* const* mu, const float* const* sd, const f
   }
   hipLaunchKernelGGL(latent_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, s, p, prior_mean, prior_sd, M, K, B, L,
                      shared_dims, beta, family, dreg, gscale, dprior_sd);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_iwae_sample(const float* loc, const float* sd, const float* noise, int K, int B, int L, int family, float* z,
+                    void* stream) {
+  if (!loc || !sd || !noise || !z || K < 0 || B < 0 || L < 1 || family < 0 || family > 2) return MVK_EINVAL;
+  const long long n = (long long)K * B * L;
+  if (n == 0) return MVK_OK;
+  hipLaunchKernelGGL(iwae_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, mvk_stream(stream), loc, sd,
+                     noise, n, B * L, family == MVK_FAMILY_LAPLACE_SOFTMAX ? MVK_FAMILY_LAPLACE_SOFTMAX : MVK_FAMILY_NORMAL, z);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_iwae_logw(const float* z, const float* const* rows, int n_rows, const float* const* loc,
+                  const float* const* sd, int E, const float* prior_loc, const float* prior_sd, int K, int B, int L,
+                  int family, float* lw, void* stream) {
+  if (!z || !loc || !sd || !lw || (n_rows > 0 && !rows) || n_rows < 0 || n_rows > MAXM || E < 1 || E > MAXE || K < 0 ||
+      B < 0 || L < 1 || family < 0 || family > 2)
+    return MVK_EINVAL;
+  IwaePtrs a{};
+  for (int r = 0; r < n_rows; ++r) {
+    if (!rows[r]) return MVK_EINVAL;
+    a.rows[r] = rows[r];
+  }
+  for (int e = 0; e < E; ++e) {
+    if (!loc[e] || !sd[e]) return MVK_EINVAL;
+    a.loc[e] = loc[e];
+    a.sd[e] = sd[e];
+  }
+  const long long n = (long long)K * B;
+  if (n == 0) return MVK_OK;
+  hipLaunchKernelGGL(iwae_logw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, mvk_stream(stream), a, z,
+                     prior_loc, prior_sd, K, B, L, E, n_rows,
+                     family == MVK_FAMILY_LAPLACE_SOFTMAX ? MVK_FAMILY_LAPLACE_SOFTMAX : MVK_FAMILY_NORMAL, lw);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_iwae_reduce(const float* const* lw, int n, int K, int B, float* ll, void* stream) {
+  if (!lw || !ll || n < 1 || n > MAXM || K < 1 || B < 0) return MVK_EINVAL;
+  IwaeLw a{};
+  for (int j = 0; j < n; ++j) {
+    if (!lw[j]) return MVK_EINVAL;
+    a.lw[j] = lw[j];
+  }
+  if (B == 0) return MVK_OK;
+  hipLaunchKernelGGL(iwae_reduce_kernel, dim3((B + 3) / 4), dim3(256), 0, mvk_stream(stream), a, n, K, B, ll);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }

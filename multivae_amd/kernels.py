@@ -1141,3 +1141,84 @@ class MMVAEObjectiveFn(Function):
                 call("mvk_scale_by_device_scalar", ptr(g), g.numel(), ptr(st.gloss), stream_ptr())
             grads += gs
         return (None, None, None, None, *grads)
+
+
+# =====================================================================================================
+# Importance-sampled joint likelihood (compute_joint_nll)
+# =====================================================================================================
+IWAE_ROWS_BUDGET = 1 << 16  # decoder rows (K * data points) per pass of joint_nll
+
+
+def std_from_logvar(lv, family=FAMILY["normal"]):
+    """exp(lv/2) (or the MMVAE scale parametrisations) without an autograd node."""
+    lv2 = _c(lv.reshape(-1, lv.shape[-1]))
+    sd = torch.empty_like(lv2)
+    call("mvk_mmvae_std_fwd", ptr(lv2), lv2.shape[0], lv2.shape[1], family, ptr(sd), stream_ptr())
+    return sd.view(lv.shape)
+
+
+def iwae_sample(loc, sd, noise, family=FAMILY["normal"]):
+    """z [K,B,L] = loc + sd * t(noise)."""
+    loc, sd, noise = _c(loc), _c(sd), _c(noise)
+    K, B, L = noise.shape
+    z = torch.empty_like(noise)
+    call("mvk_iwae_sample", ptr(loc), ptr(sd), ptr(noise), K, B, L, family, ptr(z), stream_ptr())
+    return z
+
+
+def recon_nll_rows(recons, xs, dists, scales, K, B):
+    """Unrescaled, unmasked NLL rows [K,B] of every modality in one mvk_recon_nll_fwd launch (no gradient)."""
+    n = len(recons)
+    recons = [_c(r) for r in recons]
+    descs = (ReconDesc * n)()
+    rows = []
+    for i in range(n):
+        r = _new((K, B), recons[i])
+        rows.append(r)
+        d = descs[i]
+        d.recon, d.x, d.mask, d.rows, d.drecon, d.rowcoef = recons[i].data_ptr(), xs[i].data_ptr(), None, r.data_ptr(), None, None
+        d.D, d.dist, d.scale, d.rescale, d.coef = recons[i].numel() // (K * B), dists[i], scales[i], 1.0, 1.0
+    call("mvk_recon_nll_fwd", descs, n, K, B, stream_ptr())
+    return rows
+
+
+def iwae_logw(z, rows, locs, sds, family=FAMILY["normal"], prior_loc=None, prior_sd=None):
+    """lw [K,B] = -sum rows + log p(z) - log mean_e q_e(z)   (mvk_iwae_logw)."""
+    z = _c(z)
+    K, B, L = z.shape
+    locs, sds = [_c(t) for t in locs], [_c(t) for t in sds]
+    lw = _new((K, B), z)
+    pl = _c(prior_loc.reshape(-1)) if prior_loc is not None else None
+    ps = _c(prior_sd.reshape(-1)) if prior_sd is not None else None
+    call("mvk_iwae_logw", ptr(z), ptr_array(rows) if rows else None, len(rows), ptr_array(locs), ptr_array(sds),
+         len(locs), ptr(pl) if pl is not None else None, ptr(ps) if ps is not None else None, K, B, L, family,
+         ptr(lw), stream_ptr())
+    return lw
+
+
+def iwae_reduce(lws, out=None):
+    """ll [B] = log-mean-exp over the K rows of every array in lws (mvk_iwae_reduce)."""
+    lws = [_c(t) for t in lws]
+    K, B = lws[0].shape
+    ll = _new((B,), lws[0]) if out is None else out
+    call("mvk_iwae_reduce", ptr_array(lws), len(lws), K, B, ptr(ll), stream_ptr())
+    return ll
+
+
+def joint_nll(decode_rows, z, locs, sds, family=FAMILY["normal"], prior_loc=None, prior_sd=None):
+    """-sum_b log-mean-exp_k [ log p(x_b | z_kb) + log p(z_kb) - log mean_e q_e(z_kb | x_b) ].
+
+    decode_rows(z_chunk [K,b,L], b0, b1) -> list of [K,b] NLL rows (decoders + recon_nll_rows on data rows b0:b1).
+    The data axis is processed in chunks of IWAE_ROWS_BUDGET // K points so that the decoder activations of
+    K = 1000 samples stay bounded; every chunk is independent (the estimate is per data point).
+    """
+    K, B, L = z.shape
+    ll = _new((B,), z)
+    step = max(1, IWAE_ROWS_BUDGET // max(K, 1))
+    for b0 in range(0, B, step):
+        b1 = min(B, b0 + step)
+        zc = z[:, b0:b1].contiguous()
+        rows = decode_rows(zc, b0, b1)
+        lw = iwae_logw(zc, rows, [t[b0:b1] for t in locs], [t[b0:b1] for t in sds], family, prior_loc, prior_sd)
+        iwae_reduce([lw], out=ll[b0:b1])
+    return -ll.sum()

@@ -11,6 +11,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from ... import kernels
 from ..nn.base_architectures import BaseDecoder, BaseEncoder
 from ..nn.default_architectures import BaseDictDecoders, BaseDictEncoders
 from .base_config import BaseMultiVAEConfig
@@ -201,6 +202,30 @@ class BaseMultiVAE(BaseModel):
 
     def compute_joint_nll(self, inputs, K: int = 1000, batch_size_K: int = 100):
         raise NotImplementedError
+
+    _NLL_INCOMPLETE = "The compute_joint_nll method is not yet implemented for incomplete datasets."
+
+    def _joint_nll(self, inputs, z, locs, sds, family=0, prior_loc=None, prior_sd=None):
+        """Importance-sampled -ln p(x) summed over the batch: the shared body of the reference's `compute_joint_nll`
+        methods (mopoe_model.py:522-592, mmvae_model.py:399-441, mvtcae_model.py:249-289, joint_model.py:111-152).
+        z [K,B,L] importance samples; q = uniform mixture of the experts (locs[e], sds[e]) [B,L].  The K axis is a
+        kernel axis here (decoders on [K,b,L], one mvk_recon_nll_fwd, mvk_iwae_logw, mvk_iwae_reduce per chunk of
+        data points) instead of a Python loop per data point and per `batch_size_K` samples; the likelihoods are
+        NOT rescaled, as in the reference."""
+        names = list(inputs.data.keys())
+        xs = [inputs.data[m].float().contiguous() for m in names]
+        dists = [self.recon_dists[m][0] for m in names]
+        scales = [self.recon_dists[m][1] for m in names]
+        device = z.device
+        order = self._branch_order(inputs, names)
+
+        def decode_rows(zc, b0, b1):
+            K, b = zc.shape[0], zc.shape[1]
+            rec = kernels.run_branches(order, lambda m: self.decoders[m](zc).reconstruction, device)
+            return kernels.recon_nll_rows([rec[m] for m in names], [x[b0:b1] for x in xs], dists, scales, K, b)
+
+        with torch.no_grad():
+            return kernels.joint_nll(decode_rows, z, locs, sds, family, prior_loc, prior_sd)
 
     def generate_from_prior(self, n_samples, **kwargs):
         shape = [n_samples, self.latent_dim] if n_samples > 1 else [self.latent_dim]

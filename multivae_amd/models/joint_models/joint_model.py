@@ -1,6 +1,9 @@
 """Base class of the models with a joint encoder (`multivae/models/joint_models/joint_model.py:20-84`)."""
 from typing import Union
 
+import torch
+
+from ... import kernels
 from ..base import BaseMultiVAE
 from ..nn.base_architectures import BaseJointEncoder
 from ..nn.default_architectures import MultipleHeadJointEncoder
@@ -34,3 +37,17 @@ class BaseJointModel(BaseMultiVAE):
         if hasattr(inputs, "masks"):
             raise AttributeError("The inputs have masks but this model is not compatible with incomplete dataset.")
         return super().encode(inputs, cond_mod, N, **kwargs)
+
+    def compute_joint_nll(self, inputs, K: int = 1000, batch_size_K: int = 100, **kwargs):
+        """-sum_b ln p(x_b) by importance sampling from the joint encoder's Gaussian (joint_model.py:82-154).
+        kwargs: noise [K,B,L]."""
+        self.eval()
+        if hasattr(inputs, "masks"):
+            raise AttributeError("The inputs contains masks but this model is not compatible with incomplete dataset.")
+        with torch.no_grad():
+            out = self.joint_encoder(inputs.data)
+            mu, lv = out.embedding, out.log_covariance
+            B, L = mu.shape
+            sd = kernels.std_from_logvar(lv)
+            z = kernels.iwae_sample(mu, sd, self._noise((int(K), B, L), mu.device, kwargs.get("noise")))
+            return self._joint_nll(inputs, z, [mu], [sd])

@@ -6,6 +6,9 @@ Kernel sequence: M encoder nodes + M std kernels -> ONE latent kernel (samples, 
 M x M decoder passes -> M reconstruction-NLL launches (rows) -> ONE objective kernel; backward: M
 reconstruction launches with the per-row weights -> decoders -> ONE latent backward kernel -> encoders.
 """
+from typing import Union
+
+import numpy as np
 import torch
 
 from ... import _lib, kernels
@@ -80,3 +83,54 @@ class MMVAE(BaseMultiVAE):
             out["zss"] = {m: zs[i] for i, m in enumerate(mods)}
             out["lws"] = {m: state.lw[i] for i, m in enumerate(mods)}
         return out
+
+    def _unimodal_posteriors(self, inputs, mods):
+        def encode_one(m):
+            out = self.encoders[m](inputs.data[m])
+            mu, lv = out.embedding, out.log_covariance
+            if mu.dim() == 1:
+                mu, lv = mu.unsqueeze(0), lv.unsqueeze(0)
+            return mu, kernels.std_from_logvar(lv, self._family)
+
+        order = self._branch_order(inputs, mods)
+        return kernels.run_branches(order, encode_one, inputs.data[order[0]].device)
+
+    def encode(self, inputs, cond_mod: Union[list, str] = "all", N: int = 1, return_mean=False, **kwargs):
+        """mmvae_model.py:312-363: the mean of the conditioning posteriors' means, or N samples from ONE conditioning
+        modality's posterior picked with `np.random.choice`.  kwargs: noise [N,B,L] (or [B,L] for N == 1)."""
+        cond_mod = super().encode(inputs, cond_mod, N, **kwargs).cond_mod
+        flatten = kwargs.pop("flatten", False)
+        with torch.no_grad():
+            if return_mean:
+                post = self._unimodal_posteriors(inputs, list(cond_mod))
+                emb = torch.stack([post[m][0] for m in cond_mod]).mean(0)
+                z = torch.stack([emb] * N) if N > 1 else emb
+            else:
+                mod = kwargs.pop("sampled", None) or str(np.random.choice(cond_mod))
+                mu, sd = self._unimodal_posteriors(inputs, [mod])[mod]
+                B, L = mu.shape
+                noise = kwargs.pop("noise", None)
+                if noise is not None and noise.dim() == 2:
+                    noise = noise.unsqueeze(0)
+                z = kernels.iwae_sample(mu, sd, self._noise((N, B, L), mu.device, noise, uniform=self._family == 1),
+                                        self._family)
+                if N == 1:
+                    z = z[0]
+            if flatten:
+                z = z.reshape(-1, self.latent_dim)
+        return ModelOutput(z=z, one_latent_space=True)
+
+    def compute_joint_nll(self, inputs, K: int = 1000, batch_size_K: int = 100, **kwargs):
+        """-sum_b ln p(x_b) by importance sampling (mmvae_model.py:365-443): the K samples of every data point come
+        from one modality's posterior (`encode`), the weights use the mixture of the M unimodal posteriors and the
+        learnable prior.  kwargs: noise [K,B,L], sampled (modality name; default np.random.choice as the reference)."""
+        self.eval()
+        if hasattr(inputs, "masks"):
+            raise AttributeError(self._NLL_INCOMPLETE)
+        names = list(self.encoders.keys())
+        with torch.no_grad():
+            post = self._unimodal_posteriors(inputs, names)
+            z = self.encode(inputs, N=int(K), noise=kwargs.get("noise"), sampled=kwargs.get("sampled")).z
+            prior_sd = kernels.std_from_logvar(self.prior_log_var, self._family)
+            return self._joint_nll(inputs, z, [post[m][0] for m in names], [post[m][1] for m in names],
+                                   family=self._family, prior_loc=self.prior_mean, prior_sd=prior_sd)

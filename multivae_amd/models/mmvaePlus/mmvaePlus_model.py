@@ -171,3 +171,48 @@ class MMVAEPlus(BaseMultiVAE):
                 z = z.reshape(-1, z.shape[-1])
                 style = {m: v.reshape(-1, v.shape[-1]) for m, v in style.items()}
         return ModelOutput(z=z, one_latent_space=False, modalities_z=style)
+
+    def compute_joint_nll(self, inputs, K: int = 1000, batch_size_K: int = 100, **kwargs):
+        """-sum_b ln p(x_b) from the pooled importance weights of the forward pass (mmvaePlus_model.py:477-531):
+        K // n_modalities samples per conditioning modality, rescale factors and beta forced to 1, and
+        ln p(x_b) ~= logsumexp over all conditioning modalities and samples - ln(count).
+
+        The reference evaluates this on the inputs WITHOUT their last modality (`inputs.data.popitem()`, :497, also
+        removes it from the caller's dataset) while the mixture normaliser stays ln(n_modalities); the default here
+        returns that number (without touching the caller's inputs).  kwargs: all_modalities=True conditions on and
+        scores every modality instead; noise as in forward() with K -> K // n_modalities."""
+        self.eval()
+        if hasattr(inputs, "masks"):
+            raise AttributeError(self._NLL_INCOMPLETE)
+        from ...data.datasets.base import DatasetOutput
+        import math
+
+        mods = list(inputs.data.keys())
+        if not kwargs.get("all_modalities", False):
+            mods = mods[:-1]
+        if not mods:
+            raise AttributeError("compute_joint_nll needs at least two modalities (the reference drops the last one).")
+        k = int(K) // self.n_modalities
+        noise = kwargs.get("noise")
+        B = inputs.data[mods[0]].shape[0]
+        device = inputs.data[mods[0]].device
+        ll = torch.empty(B, dtype=torch.float32, device=device)
+        step = max(1, kernels.IWAE_ROWS_BUDGET // max(k, 1))
+        rescale, beta = self.rescale_factors, self.beta
+        self.rescale_factors, self.beta = {m: 1.0 for m in rescale}, 1.0
+        try:
+            with torch.no_grad():
+                for b0 in range(0, B, step):
+                    b1 = min(B, b0 + step)
+                    part = DatasetOutput(data={m: inputs.data[m][b0:b1] for m in mods})
+                    nz = None
+                    if noise is not None:
+                        nz = {c: {key: v[:, b0:b1] for key, v in noise[c].items()} for c in mods}
+                    out = self.forward(part, K=k, noise=nz, detailed_output=True)
+                    kernels.iwae_reduce([out["lws"][m] for m in mods], out=ll[b0:b1])
+        finally:
+            self.rescale_factors, self.beta = rescale, beta
+        # the latent kernel normalises the mixture by the number of modalities it was given; the reference by
+        # n_modalities (mmvaePlus_model.py:239): a constant shift of every log-weight
+        shift = math.log(self.n_modalities) - math.log(len(mods))
+        return -(ll.sum() + B * shift)

@@ -153,6 +153,38 @@ class MoPoE(BaseMultiVAE):
         return dict(modalities=enc, mus=mus, logvars=lvs, weights=weights, joint=[jmu, jlv],
                     subsets={k: [mus[i], lvs[i]] for i, k in enumerate(self._subset_keys)})
 
+    def compute_joint_nll(self, inputs, K: int = 1000, batch_size_K: int = 100, **kwargs):
+        """-sum_b ln p(x_b) by importance sampling (mopoe_model.py:467-594): K samples per data point from the
+        selected subset posterior (`inference()["joint"]`), weighted against the uniform mixture of all subset
+        posteriors.  `batch_size_K` is accepted for compatibility: the reference's chunked logsumexp is the same
+        number.  kwargs: noise [K,B,L]."""
+        self.eval()
+        if hasattr(inputs, "masks"):
+            raise AttributeError(self._NLL_INCOMPLETE)
+        with torch.no_grad():
+            _, outs, _ = self._posterior(inputs, int(K), noise=kwargs.get("noise"), want_stats=True)
+            z, mus, lvs = outs[0], outs[2], outs[3]
+            sds = kernels.std_from_logvar(lvs)
+            S = mus.shape[0]
+            return self._joint_nll(inputs, z, [mus[i] for i in range(S)], [sds[i] for i in range(S)])
+
+    def _compute_joint_nll_from_subset_encoding(self, subset, inputs, K: int = 1000, batch_size_K: int = 100, **kwargs):
+        """Joint NLL with ONE subset posterior as the importance distribution (mopoe_model.py:596-701): samples and
+        density both come from `inference()["subsets"]["_".join(sorted(subset))]`.  kwargs: noise [K,B,L]."""
+        self.eval()
+        if hasattr(inputs, "masks"):
+            raise AttributeError(self._NLL_INCOMPLETE)
+        idx = self._subset_keys.index("_".join(sorted(subset)))
+        with torch.no_grad():
+            _, outs, (B, L, device, _) = self._posterior(inputs, 1, want_stats=True)
+            mu, sd = outs[2][idx], kernels.std_from_logvar(outs[3][idx])
+            z = kernels.iwae_sample(mu, sd, self._noise((int(K), B, L), device, kwargs.get("noise")))
+            return self._joint_nll(inputs, z, [mu], [sd])
+
+    def compute_joint_nll_paper(self, inputs, K: int = 1000, batch_size_K: int = 100, **kwargs):
+        """The original paper's estimator: the PoE of all modalities as importance distribution (:703-718)."""
+        return self._compute_joint_nll_from_subset_encoding(list(self.encoders.keys()), inputs, K, batch_size_K, **kwargs)
+
     def encode(self, inputs, cond_mod: Union[list, str] = "all", N: int = 1, return_mean=False, **kwargs):
         cond_mod = super().encode(inputs, cond_mod, N, **kwargs).cond_mod
         key = "_".join(sorted(cond_mod))

@@ -67,6 +67,17 @@ class MVTCAE(BaseMultiVAE):
         n_terms = Mn + 1 + M
         return ModelOutput(loss=loss, loss_sum=terms[n_terms + 1], metrics=metrics)
 
+    def compute_joint_nll(self, inputs, K: int = 1000, batch_size_K: int = 100, **kwargs):
+        """-sum_b ln p(x_b) by importance sampling from the PoE joint posterior (mvtcae_model.py:213-291).
+        kwargs: noise [K,B,L]."""
+        self.eval()
+        if hasattr(inputs, "masks"):
+            raise AttributeError(self._NLL_INCOMPLETE)
+        with torch.no_grad():
+            _, outs, _ = self._posterior(inputs, int(K), noise=kwargs.get("noise"))
+            z, mu, lv = outs[0], outs[3], outs[4]
+            return self._joint_nll(inputs, z, [mu], [kernels.std_from_logvar(lv)])
+
     def encode(self, inputs, cond_mod: Union[list, str] = "all", N: int = 1, return_mean=False, **kwargs):
         cond_mod = super().encode(inputs, cond_mod, N, **kwargs).cond_mod
         from ...data.datasets.base import MultimodalBaseDataset

@@ -490,3 +490,133 @@ def jmvae_forward(joint, enc, data, decoders, eps, *, names, alpha=0.1, beta=1.0
     loss_sum = rec + a * (kld + ljm)
     return dict(loss=loss_sum / B, loss_sum=loss_sum,
                 metrics=dict(loss_no_ponderation=rec + kld + ljm, beta=a, elbo=(rec + kld) / B), z=z)
+
+
+# ----------------------------------------------------------------------------------------------
+# importance-sampled joint likelihood (compute_joint_nll)
+# ----------------------------------------------------------------------------------------------
+def iwae_joint_nll(z, data, decoders, experts, *, names, dists=None, scales=None, family="normal", prior=None,
+                   batch_size_K=100):
+    """-sum_i [ logsumexp_k ( sum_m ln p(x_m,i | z_ik) + ln p(z_ik) - ln q(z_ik | x_i) ) - ln K ].
+
+    Follows the per-data-point / per-K-chunk loops shared by mopoe_model.py:522-592, mmvae_model.py:399-441,
+    mvtcae_model.py:249-289 and joint_model.py:111-152:
+      * z [K,B,L] are the importance samples (the reference permutes them to [B,K,L]);
+      * the likelihood terms use `recon_log_probs[m]` WITHOUT the rescale factors;
+      * q is the uniform mixture of `experts` = [(loc [B,L], scale [B,L]), ...]:
+        logsumexp_e sum_l log q_e(z) - ln E (a single expert gives the plain log-density);
+      * the K samples are visited in chunks of batch_size_K, the chunk logsumexps are collected in a float32
+        `torch.Tensor(lnpxs)` and combined by a second logsumexp minus ln K.
+    prior: None = N(0, I) (`dist.Normal(0, 1)`), or (loc [1,L], scale [1,L]) of the latent family (MMVAE).
+    Returns (nll scalar, ll [B], lw [K,B]) -- the last two are intermediates for the kernel tests.
+    """
+    K, B, L = z.shape
+    dists = dists or {}
+    scales = scales or {}
+    fam = _latent_family(family)
+    ll, lws = [], []
+    for i in range(B):
+        lnpxs, lw_i = [], []
+        start = 0
+        while start < K:
+            stop = min(start + batch_size_K, K)
+            latents = z[start:stop, i]  # [k, L]
+            lpx = 0
+            for m in names:
+                recon = decoders[m](latents)
+                x_m = data[m][i]
+                lp = recon_log_prob(dists.get(m, "normal"), recon, torch.stack([x_m] * len(recon)), scales.get(m, 1.0))
+                lpx = lpx + lp.reshape(recon.size(0), -1).sum(-1)
+            if prior is None:
+                lpz = latent_log_prob("normal", latents, torch.zeros(()), torch.ones(())).sum(-1)
+            else:
+                lpz = latent_log_prob(fam, latents, prior[0], prior[1]).sum(-1)
+            lqs = torch.stack([latent_log_prob(fam, latents, loc[i], scale[i]).sum(-1) for loc, scale in experts])
+            lqz = torch.logsumexp(lqs, dim=0) - math.log(len(experts))
+            w = lpx + lpz - lqz
+            lw_i.append(w)
+            lnpxs.append(torch.logsumexp(w, dim=0))
+            start = stop
+        ll.append(torch.logsumexp(torch.Tensor([float(v) for v in lnpxs]), dim=0) - math.log(K))
+        lws.append(torch.cat(lw_i))
+    ll = torch.stack(ll)
+    return -ll.sum(), ll, torch.stack(lws, dim=1)
+
+
+def mopoe_joint_nll(enc, data, decoders, eps, *, names, dists=None, batch_size_K=100):
+    """MoPoE.compute_joint_nll, mopoe_model.py:467-594 (complete data, one latent space): samples from the
+    row-range-selected subset posterior (`inference()["joint"]`), scores them under the uniform mixture of all
+    subset posteriors.  eps [K,B,L]."""
+    inf = mopoe_inference(enc, names)
+    z = rsample(inf["joint_mu"], inf["joint_logvar"], eps)
+    experts = [(inf["mus"][s], torch.exp(0.5 * inf["logvars"][s])) for s in range(inf["mus"].shape[0])]
+    return iwae_joint_nll(z, data, decoders, experts, names=names, dists=dists, batch_size_K=batch_size_K)
+
+
+def mvtcae_joint_nll(enc, data, decoders, eps, *, names, batch_size_K=100):
+    """MVTCAE.compute_joint_nll, mvtcae_model.py:213-291: q = the product of the unimodal experts (`poe`, no prior
+    expert, mvtcae_model.py:134-169)."""
+    mu, lv = poe(torch.stack([enc[m][0] for m in names]), torch.stack([enc[m][1] for m in names]))
+    sd = torch.exp(0.5 * lv)
+    z = mu + sd * eps
+    return iwae_joint_nll(z, data, decoders, [(mu, sd)], names=names, batch_size_K=batch_size_K)
+
+
+def jmvae_joint_nll(joint, data, decoders, eps, *, names, dists=None, batch_size_K=100):
+    """BaseJointModel.compute_joint_nll, joint_model.py:82-154: q = the joint encoder's Gaussian."""
+    mu, lv = joint
+    sd = torch.exp(0.5 * lv)
+    z = mu + sd * eps
+    return iwae_joint_nll(z, data, decoders, [(mu, sd)], names=names, dists=dists, batch_size_K=batch_size_K)
+
+
+def mmvae_joint_nll(enc, data, decoders, noise, *, names, sampled, family="laplace_with_softmax", prior_log_var=None,
+                    dists=None, batch_size_K=100):
+    """MMVAE.compute_joint_nll, mmvae_model.py:365-443: the samples come from ONE modality's posterior (`encode`,
+    :341-351, `np.random.choice(cond_mod)` = `sampled`) and are scored under the mixture of the M unimodal
+    posteriors; the prior is `prior_dist(*pz_params)` (:76-93).  noise [K,B,L] (normal or uniform, Appendix B)."""
+    fam = _latent_family(family)
+    L = enc[names[0]][0].shape[-1]
+    experts = [(enc[m][0], mmvae_std(enc[m][1], family)) for m in names]
+    loc, scale = experts[names.index(sampled)]
+    z = latent_rsample(fam, loc, scale, noise)
+    plv = torch.zeros(1, L) if prior_log_var is None else prior_log_var
+    prior = (torch.zeros(1, L), mmvae_std(plv, family))
+    return iwae_joint_nll(z, data, decoders, experts, names=names, dists=dists, family=family, prior=prior,
+                          batch_size_K=batch_size_K)
+
+
+def mmvaeplus_joint_nll(enc, data, decoders, noise, *, names, K, family="laplace_with_softmax", prior_logvars=None,
+                        dists=None):
+    """MMVAEPlus.compute_joint_nll, mmvaePlus_model.py:477-531, as the reference executes it:
+      * `n_data = len(inputs.data.popitem()[1])` (:497) REMOVES the last modality from the inputs, so the loop below
+        conditions on and reconstructs the first M-1 modalities only, while the mixture normaliser of
+        `_compute_k_lws` stays ln(n_modalities) (:239) and k = K // n_modalities (:511);
+      * rescale factors and beta are forced to 1 (:502-506);
+      * per data point: the forward's importance weights lws[c] [k,1] of every conditioning modality are concatenated
+        and reduced by logsumexp - ln(size) (:521-525).
+    enc: {name: (mu, lv, mu_style, lv_style)} on the whole batch; noise as in mmvaeplus_forward with K -> k.
+    Returns (nll, ll [B])."""
+    kept = list(data.keys())[:-1]
+    k = K // len(names)
+    B = data[kept[0]].shape[0]
+    ll = []
+    for i in range(B):
+        data_i = {m: data[m][i].unsqueeze(0) for m in kept}
+        enc_i = {m: tuple(t[i : i + 1] for t in enc[m]) for m in kept}
+        noise_i = {c: {key: v[:, i : i + 1] for key, v in noise[c].items()} for c in kept}
+        o = mmvaeplus_forward(enc_i, data_i, decoders, noise_i, names=names, K=k, family=family, loss="iwae_looser",
+                              beta=1.0, prior_logvars=prior_logvars, rescale={m: 1.0 for m in names}, dists=dists)
+        lws = torch.cat([o["lws"][c] for c in kept], dim=0)  # [(M-1) k, 1]
+        ll.append(torch.logsumexp(lws, dim=0) - math.log(lws.size(0)))
+    ll = torch.cat(ll)
+    return -ll.sum(), ll
+
+
+def mopoe_subset_joint_nll(enc, data, decoders, eps, *, names, subset, dists=None, batch_size_K=100):
+    """MoPoE._compute_joint_nll_from_subset_encoding, mopoe_model.py:596-701 (compute_joint_nll_paper :703-718 passes
+    the full subset): samples AND density from the posterior of `subset` alone."""
+    inf = mopoe_inference(enc, names)
+    s = inf["keys"].index("_".join(sorted(subset)))
+    mu, sd = inf["mus"][s], torch.exp(0.5 * inf["logvars"][s])
+    return iwae_joint_nll(mu + sd * eps, data, decoders, [(mu, sd)], names=names, dists=dists, batch_size_K=batch_size_K)

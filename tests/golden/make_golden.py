@@ -658,6 +658,176 @@ def jmvae_main():
                seed=403)
 
 
+def nll_case(name, *, kind, arch, B, K, batch_size_K, seed, dists=None, family="normal", subset=None):
+    """compute_joint_nll of the reference (K importance samples per data point, chunks of batch_size_K) against
+    oracle.elbo.*_joint_nll on the replayed noise.  Stores the noise, the reference's NLL and the oracle's per-point
+    log-likelihoods / importance weights (verified here to reproduce the reference's total)."""
+    print(name)
+    if arch == "tiny":
+        dims, L = TINY_DIMS, TINY_L
+        data, _ = tiny_data(B, seed, False)
+        for m, d in (dists or {}).items():
+            if d == "bernoulli":
+                data[m] = (data[m] > 0.5).astype(np.float32)
+        shapes = P.jmvae_mlp_shapes(dims, L) if kind == "jmvae" else P.default_mlp_shapes(dims, L)
+        enc = dec = None
+    else:
+        dims, L = dict(mnist=(1, 28, 28), svhn=(3, 32, 32)), 20
+        data = mnist_svhn_data(B, seed)
+        shapes = P.mnist_svhn_shapes(L)
+        enc, dec = mnist_svhn_arch(L)
+    common = dict(n_modalities=len(dims), latent_dim=L, input_dims=dict(dims), decoders_dist=dists if dists else None)
+    if kind == "mopoe":
+        model = MoPoE(MoPoEConfig(**common), enc, dec)
+    elif kind == "mvtcae":
+        model = MVTCAE(MVTCAEConfig(**common), enc, dec)
+    elif kind == "jmvae":
+        model = JMVAE(JMVAEConfig(**common))
+    else:
+        model = MMVAE(MMVAEConfig(K=1, prior_and_posterior_dist=family, **common), enc, dec)
+    sd_np = P.make_state_dict(shapes, seed)
+    load_weights(model, sd_np)
+    plv = None
+    if kind == "mmvae":
+        plv = P.uniform((1, L), seed + 999, -0.3, 0.3)
+        with torch.no_grad():
+            model.prior_log_var.copy_(t(plv))
+    names = list(model.encoders.keys())
+    inputs = ref_dataset(data, None)
+    # --- noise replay: the only draws are the [K,B,L] importance samples (and MMVAE's np.random.choice of the
+    # modality the samples come from, mmvae_model.py:343)
+    sampled = None
+    if kind == "mmvae":
+        np.random.seed(seed)
+        sampled = str(np.random.choice(names))
+    torch.manual_seed(seed)
+    if kind == "mmvae" and family != "normal":
+        noise = torch.empty(K, B, L).uniform_(torch.finfo(torch.float32).eps - 1, 1)
+    else:
+        noise = torch.randn(K, B, L)
+    # --- reference
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if subset == "paper":
+        nll = model.compute_joint_nll_paper(inputs, K=K, batch_size_K=batch_size_K)
+    elif subset is not None:
+        nll = model._compute_joint_nll_from_subset_encoding(subset, inputs, K=K, batch_size_K=batch_size_K)
+    else:
+        nll = model.compute_joint_nll(inputs, K=K, batch_size_K=batch_size_K)
+    # --- oracle
+    osd = oracle_sd(sd_np, requires_grad=False)
+    if arch == "tiny":
+        enc_f, dec_f = nets.build_default_mlp(osd, dims)
+    else:
+        enc_f, dec_f = nets.build_mnist_svhn(osd, L)
+    tdata = {m: t(v) for m, v in data.items()}
+    with torch.no_grad():
+        e = {m: enc_f[m](tdata[m]) for m in names}
+        if kind == "mopoe" and subset is not None:
+            o = elbo.mopoe_subset_joint_nll(e, tdata, dec_f, noise, names=names, dists=dists, batch_size_K=batch_size_K,
+                                            subset=names if subset == "paper" else subset)
+        elif kind == "mopoe":
+            o = elbo.mopoe_joint_nll(e, tdata, dec_f, noise, names=names, dists=dists, batch_size_K=batch_size_K)
+        elif kind == "mvtcae":
+            o = elbo.mvtcae_joint_nll(e, tdata, dec_f, noise, names=names, batch_size_K=batch_size_K)
+        elif kind == "jmvae":
+            joint = nets.joint_mlp_encoder(osd, dims, tdata)
+            o = elbo.jmvae_joint_nll(joint, tdata, dec_f, noise, names=names, dists=dists, batch_size_K=batch_size_K)
+        else:
+            o = elbo.mmvae_joint_nll(e, tdata, dec_f, noise, names=names, sampled=sampled, family=family,
+                                     prior_log_var=t(plv), dists=dists, batch_size_K=batch_size_K)
+    report("nll", nll, o[0])
+    arrays = dict(noise=noise, nll=torch.as_tensor(nll).detach(), ll=o[1], lw=o[2])
+    if plv is not None:
+        arrays["prior_log_var"] = plv
+    # model-construction keys as in the forward cases, so that tests build the model the same way
+    cfg = dict(model=dict(mopoe="MoPoE", mvtcae="MVTCAE", jmvae="JMVAE", mmvae="MMVAE")[kind], arch=arch, B=B, L=L,
+               K=1, nll_K=K, batch_size_K=batch_size_K, seed=seed, names=names, dists=dists, family=family,
+               sampled=sampled, subset=subset, masked=False, rescaling=False, beta=1.0, alpha=0.1, warmup=10,
+               loss="dreg_looser", learn_prior=True)
+    save(name, cfg, arrays)
+
+
+def nll_mmvaeplus_case(name, *, B, K, S, family, seed):
+    """MMVAEPlus.compute_joint_nll (mmvaePlus_model.py:477-531) incl. its dropped-last-modality behaviour."""
+    print(name)
+    dims, L = TINY_DIMS, TINY_L
+    data, _ = tiny_data(B, seed, False)
+    shapes = P.mmvaeplus_mlp_shapes(dims, L, S)
+    cfg = MMVAEPlusConfig(n_modalities=len(dims), latent_dim=L, input_dims=dict(dims), K=1, modalities_specific_dim=S,
+                          prior_and_posterior_dist=family, beta=2.5, uses_likelihood_rescaling=True,
+                          learn_shared_prior=True, learn_modality_prior=True)
+    model = MMVAEPlus(cfg)
+    sd_np = P.make_state_dict(shapes, seed)
+    load_weights_plus(model, sd_np)
+    names = list(model.encoders.keys())
+    plv = {"shared": P.uniform((1, L + S), seed + 998, -0.3, 0.3)}
+    for i, m in enumerate(names):
+        plv[m] = P.uniform((1, S), seed + 900 + i, -0.3, 0.3)
+    with torch.no_grad():
+        for k_, v in plv.items():
+            model.logvars_priors[k_].copy_(t(v))
+    kept = names[:-1]
+    k = K // len(names)
+
+    def draw(shape):
+        if family == "laplace_with_softmax":
+            return torch.empty(shape).uniform_(torch.finfo(torch.float32).eps - 1, 1)
+        return torch.randn(shape)
+
+    # noise replay: one forward per data point (batch of 1) over the kept modalities
+    torch.manual_seed(seed)
+    per_point = []
+    for i in range(B):
+        n_i = {}
+        for c in kept:
+            n_i[c] = {"u": draw((k, 1, L)), "w": draw((k, 1, S))}
+            for r in kept:
+                if r != c:
+                    n_i[c][r] = draw((k, 1, S))
+        per_point.append(n_i)
+    noise = {c: {key: torch.cat([p[c][key] for p in per_point], dim=1) for key in per_point[0][c]} for c in kept}
+    inputs = ref_dataset(data, None)
+    torch.manual_seed(seed)
+    nll = model.compute_joint_nll(inputs, K=K)
+    assert list(inputs.data.keys()) == kept  # the reference popped the last modality from the caller's inputs
+    assert model.beta == 2.5 and model.rescale_factors["mod1"] != 1
+    osd = oracle_sd(sd_np, requires_grad=False)
+    enc_f, dec_f = nets.build_default_mlp_multilatent(osd, dims)
+    tdata = {m: t(v) for m, v in data.items()}
+    with torch.no_grad():
+        e = {m: enc_f[m](tdata[m]) for m in names}
+        o = elbo.mmvaeplus_joint_nll(e, tdata, dec_f, noise, names=names, K=K, family=family,
+                                     prior_logvars={k_: t(v) for k_, v in plv.items()})
+    report("nll", nll, o[0])
+    arrays = dict(nll=torch.as_tensor(nll).detach(), ll=o[1])
+    for k_, v in plv.items():
+        arrays["prior_logvar/" + k_] = v
+    for c in kept:
+        for key, v in noise[c].items():
+            arrays[f"noise/{c}/{key}"] = v
+    save(name, dict(model="MMVAEPlus", arch="tiny", B=B, L=L, S=S, K=1, nll_K=K, family=family, loss="iwae_looser",
+                    beta=2.5, rescaling=True, masked=False, seed=seed, names=names, kept=kept,
+                    learn_shared_prior=True), arrays)
+
+
+def nll_main():
+    nll_case("nll_mopoe_tiny", kind="mopoe", arch="tiny", B=5, K=7, batch_size_K=3, seed=701,
+             dists=dict(mod1="normal", mod2="laplace", mod3="bernoulli", mod4="normal"))
+    nll_case("nll_mopoe_mnistsvhn", kind="mopoe", arch="mnistsvhn", B=3, K=12, batch_size_K=5, seed=702)
+    nll_case("nll_mopoe_tiny_subset", kind="mopoe", arch="tiny", B=4, K=9, batch_size_K=6, seed=710, subset=["mod3", "mod1"])
+    nll_case("nll_mopoe_mnistsvhn_paper", kind="mopoe", arch="mnistsvhn", B=2, K=8, batch_size_K=3, seed=711, subset="paper")
+    nll_case("nll_mvtcae_tiny", kind="mvtcae", arch="tiny", B=4, K=6, batch_size_K=100, seed=703)
+    nll_case("nll_jmvae_tiny", kind="jmvae", arch="tiny", B=4, K=5, batch_size_K=2, seed=704)
+    nll_case("nll_mmvae_tiny_normal", kind="mmvae", arch="tiny", B=4, K=6, batch_size_K=4, seed=705, family="normal")
+    nll_case("nll_mmvae_tiny_laplace", kind="mmvae", arch="tiny", B=3, K=8, batch_size_K=3, seed=706,
+             family="laplace_with_softmax")
+    nll_case("nll_mmvae_mnistsvhn_laplace", kind="mmvae", arch="mnistsvhn", B=2, K=10, batch_size_K=10, seed=707,
+             family="laplace_with_softmax")
+    nll_mmvaeplus_case("nll_mmvaeplus_tiny_laplace", B=4, K=14, S=3, family="laplace_with_softmax", seed=708)
+    nll_mmvaeplus_case("nll_mmvaeplus_tiny_softplus", B=3, K=9, S=2, family="normal_with_softplus", seed=709)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "jmvae":  # only the JMVAE cases (the others are unchanged)
         jmvae_main()
@@ -665,8 +835,11 @@ if __name__ == "__main__":
         mmvaeplus_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "resnet":
         resnet_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "nll":
+        nll_main()
     else:
         main()
         jmvae_main()
         mmvaeplus_main()
         resnet_main()
+        nll_main()

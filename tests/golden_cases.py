@@ -26,6 +26,9 @@ MMVAEPLUS_CASES = ["mmvaeplus_tiny_laplace_dreg", "mmvaeplus_tiny_normal_iwae_be
 MMVAE_CASES = ["mmvae_tiny_normal_iwae", "mmvae_tiny_laplace_dreg", "mmvae_tiny_normal_dreg_masked",
                "mmvae_tiny_laplace_iwae_masked", "mmvae_mnistsvhn_laplace_dreg_k1",
                "mmvae_mnistsvhn_normal_iwae_k10"]
+NLL_CASES = ["nll_mopoe_tiny", "nll_mopoe_mnistsvhn", "nll_mopoe_tiny_subset", "nll_mopoe_mnistsvhn_paper", "nll_mvtcae_tiny", "nll_jmvae_tiny", "nll_mmvae_tiny_normal",
+             "nll_mmvae_tiny_laplace", "nll_mmvae_mnistsvhn_laplace"]
+NLL_MMVAEPLUS_CASES = ["nll_mmvaeplus_tiny_laplace", "nll_mmvaeplus_tiny_softplus"]
 
 
 def t(a):

@@ -390,3 +390,75 @@ def test_resnet_cub_nets_golden():
         check(v.grad.numpy(), mg["dec." + k], "grad dec." + k)
     G.check_grads(a, mg, rtol=5 * RTOL, atol_frac=RTOL)
     assert dec(zz.detach().unsqueeze(0)).reconstruction.shape == (1, cfg["B"], 3, 64, 64)
+
+
+@pytest.mark.parametrize("name", G.NLL_CASES)
+def test_joint_nll_golden(name):
+    """compute_joint_nll on the HIP path (decoders over the K axis + mvk_recon_nll_fwd + mvk_iwae_logw +
+    mvk_iwae_reduce) against the reference's number and the oracle's per-point log-likelihoods."""
+    from multivae_amd import kernels
+
+    cfg, a, dims, data, masks, sd_np, model, inputs, d = prep(name)
+    if cfg["model"] == "MMVAE":
+        with torch.no_grad():
+            model.prior_log_var.copy_(G.t(a["prior_log_var"]).to(d))
+    kw = dict(noise=G.t(a["noise"]).to(d))
+    if cfg["model"] == "MMVAE":
+        kw["sampled"] = cfg["sampled"]
+    if cfg.get("subset") == "paper":
+        run = model.compute_joint_nll_paper
+    elif cfg.get("subset") is not None:
+        run = lambda *args, **kwargs: model._compute_joint_nll_from_subset_encoding(cfg["subset"], *args, **kwargs)
+    else:
+        run = model.compute_joint_nll
+    nll = run(inputs, K=cfg["nll_K"], batch_size_K=cfg["batch_size_K"], **kw)
+    assert not model.training  # the reference switches to eval()
+    assert isinstance(nll, torch.Tensor) and nll.size() == torch.Size([]) and nll >= 0  # tests/test_mopoe.py:505-548
+    check(a["nll"], nll, "nll")
+    # same number when the data axis is processed one point at a time (chunking of joint_nll)
+    old = kernels.IWAE_ROWS_BUDGET
+    kernels.IWAE_ROWS_BUDGET = cfg["nll_K"]
+    try:
+        nll1 = run(inputs, K=cfg["nll_K"], **kw)
+    finally:
+        kernels.IWAE_ROWS_BUDGET = old
+    check(a["nll"], nll1, "nll (one data point per pass)")
+
+
+def test_joint_nll_rejects_incomplete_data():
+    from multivae_amd.data.datasets.base import DatasetOutput
+
+    cfg, a, dims, data, masks, sd_np, model, inputs, d = prep("nll_mopoe_tiny")
+    B = cfg["B"]
+    bad = DatasetOutput(data=inputs.data, masks={m: torch.ones(B, dtype=torch.bool, device=d) for m in inputs.data})
+    with pytest.raises(AttributeError):
+        model.compute_joint_nll(bad, K=4)
+
+
+@pytest.mark.parametrize("name", G.NLL_MMVAEPLUS_CASES)
+def test_joint_nll_mmvaeplus_golden(name):
+    """MMVAEPlus.compute_joint_nll on the HIP path against the reference's number (which leaves out the last
+    modality, mmvaePlus_model.py:497) and the oracle's per-point log-likelihoods; the caller's inputs and the model's
+    beta / rescale factors are left as they were."""
+    from multivae_amd import kernels
+
+    cfg, a, dims, data, masks, sd_np, model, inputs, d = prep(name)
+    with torch.no_grad():
+        for k in a:
+            if k.startswith("prior_logvar/"):
+                model.logvars_priors[k.split("/")[1]].copy_(G.t(a[k]).to(d))
+    kept = cfg["kept"]
+    noise = {c: {k.split("/")[2]: G.t(a[k]).to(d) for k in a if k.startswith(f"noise/{c}/")} for c in kept}
+    before = dict(model.rescale_factors)
+    nll = model.compute_joint_nll(inputs, K=cfg["nll_K"], noise=noise)
+    check(a["nll"], nll, "nll")
+    assert list(inputs.data.keys()) == cfg["names"] and model.beta == cfg["beta"] and model.rescale_factors == before
+    old = kernels.IWAE_ROWS_BUDGET
+    kernels.IWAE_ROWS_BUDGET = 1
+    try:
+        nll1 = model.compute_joint_nll(inputs, K=cfg["nll_K"], noise=noise)
+    finally:
+        kernels.IWAE_ROWS_BUDGET = old
+    check(a["nll"], nll1, "nll (one data point per pass)")
+    full = model.compute_joint_nll(inputs, K=cfg["nll_K"], all_modalities=True)
+    assert torch.isfinite(full) and float(full) > float(nll)  # one more modality to explain

@@ -652,3 +652,53 @@ def test_avgpool_upsample_axpby(K, n, H, W, C):
     a, b = nhwc(x), torch.randn(n, H, W, C, generator=gen).to(d)
     close(K.axpby(a, 1.0, b, 0.1), a + 0.1 * b, what="axpby")
     close(K.axpby(a, 1.0, None, 0.0, act=K.LEAKY), F.leaky_relu(a, 0.2), what="leaky relu")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# importance-sampled joint likelihood kernels (compute_joint_nll)
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("family,Kk,B,L,E,R,prior", [("normal", 7, 5, 5, 1, 2, False), ("normal", 33, 9, 20, 3, 2, False),
+                                                     ("laplace_with_softmax", 12, 4, 20, 2, 2, True),
+                                                     ("normal", 1000, 3, 64, 31, 5, True), ("normal", 2, 1, 3, 32, 0, False)])
+def test_iwae_sample_logw_reduce(K, family, Kk, B, L, E, R, prior):
+    """mvk_iwae_sample / mvk_iwae_logw / mvk_iwae_reduce against the torch.distributions formulas the reference's
+    compute_joint_nll bodies use (oracle.elbo.latent_log_prob / latent_rsample), up to 32 experts."""
+    from multivae_amd._lib import FAMILY
+
+    gen = g(31)
+    fam = "normal" if family == "normal" else "laplace_with_softmax"
+    locs = [torch.randn(B, L, generator=gen) for _ in range(E)]
+    sds = [torch.rand(B, L, generator=gen) * 0.8 + 0.3 for _ in range(E)]
+    noise = torch.randn(Kk, B, L, generator=gen) if fam == "normal" else torch.rand(Kk, B, L, generator=gen) * 1.98 - 0.99
+    rows = [torch.rand(Kk, B, generator=gen) * 50 for _ in range(R)]
+    ploc = torch.randn(1, L, generator=gen) * 0.1 if prior else None
+    psd = torch.rand(1, L, generator=gen) + 0.5 if prior else None
+    z_ref = elbo.latent_rsample(fam, locs[0], sds[0], noise)
+    lpz = elbo.latent_log_prob(fam, z_ref, ploc if prior else torch.zeros(()), psd if prior else torch.ones(())).sum(-1)
+    lq = torch.stack([elbo.latent_log_prob(fam, z_ref, locs[e], sds[e]).sum(-1) for e in range(E)])
+    lw_ref = -sum(rows) + lpz - (torch.logsumexp(lq, 0) - math.log(E)) if R else lpz - (torch.logsumexp(lq, 0) - math.log(E))
+    ll_ref = torch.logsumexp(lw_ref, 0) - math.log(Kk)
+    d = dev()
+    z = K.iwae_sample(locs[0].to(d), sds[0].to(d), noise.to(d), FAMILY[family])
+    close(z, z_ref, rtol=1e-6, what="z")
+    lw = K.iwae_logw(z, [r.to(d) for r in rows], [t.to(d) for t in locs], [t.to(d) for t in sds], FAMILY[family],
+                     None if ploc is None else ploc.to(d), None if psd is None else psd.to(d))
+    close(lw, lw_ref, rtol=1e-5, what="lw")
+    ll = K.iwae_reduce([lw])
+    close(ll, ll_ref, rtol=1e-5, what="ll")
+    # several weight arrays are pooled (MMVAE+ concatenates its M conditioning modalities)
+    lw2 = lw_ref + torch.randn(Kk, B, generator=gen)
+    ll2 = K.iwae_reduce([lw, lw2.to(d)])
+    close(ll2, torch.logsumexp(torch.cat([lw_ref, lw2]), 0) - math.log(2 * Kk), rtol=1e-5, what="ll pooled")
+
+
+def test_iwae_entry_points_reject_bad_arguments(K):
+    from multivae_amd._lib import MvkError
+
+    d = dev()
+    z = torch.zeros(2, 3, 4, device=d)
+    loc = [torch.zeros(3, 4, device=d)] * 33
+    with pytest.raises(MvkError):
+        K.iwae_logw(z, [], loc, loc)  # more than MVK_IWAE_MAX_EXPERTS experts
+    with pytest.raises(MvkError):
+        K.iwae_reduce([torch.zeros(2, 3, device=d)] * 9)  # more than MVK_MAX_MODALITIES arrays

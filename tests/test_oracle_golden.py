@@ -147,6 +147,61 @@ def test_mmvae(name):
     G.check_grads(a, grads, rtol=2e-5)
 
 
+def oracle_joint_nll(cfg, a, dims, data, sd, enc_f, dec_f, batch_size_K=None):
+    """The oracle's compute_joint_nll for a golden NLL case -> (nll, ll [B], lw [K,B])."""
+    names = cfg["names"]
+    bsk = cfg["batch_size_K"] if batch_size_K is None else batch_size_K
+    noise = G.t(a["noise"])
+    with torch.no_grad():
+        e = {m: enc_f[m](data[m]) for m in names}
+        if cfg["model"] == "MoPoE" and cfg.get("subset") is not None:
+            subset = names if cfg["subset"] == "paper" else cfg["subset"]
+            return elbo.mopoe_subset_joint_nll(e, data, dec_f, noise, names=names, subset=subset,
+                                               dists=cfg.get("dists"), batch_size_K=bsk)
+        if cfg["model"] == "MoPoE":
+            return elbo.mopoe_joint_nll(e, data, dec_f, noise, names=names, dists=cfg.get("dists"), batch_size_K=bsk)
+        if cfg["model"] == "MVTCAE":
+            return elbo.mvtcae_joint_nll(e, data, dec_f, noise, names=names, batch_size_K=bsk)
+        if cfg["model"] == "JMVAE":
+            joint = nets.joint_mlp_encoder(sd, dims, data)
+            return elbo.jmvae_joint_nll(joint, data, dec_f, noise, names=names, dists=cfg.get("dists"), batch_size_K=bsk)
+        return elbo.mmvae_joint_nll(e, data, dec_f, noise, names=names, sampled=cfg["sampled"], family=cfg["family"],
+                                    prior_log_var=G.t(a["prior_log_var"]), dists=cfg.get("dists"), batch_size_K=bsk)
+
+
+@pytest.mark.parametrize("name", G.NLL_CASES)
+def test_joint_nll(name):
+    """compute_joint_nll (mopoe_model.py:467-594, mmvae_model.py:365-443, mvtcae_model.py:213-291,
+    joint_model.py:82-154): the oracle reproduces the reference's importance-sampled NLL on the recorded noise, and
+    the number does not depend on the K-chunk size (the property the HIP path relies on)."""
+    cfg, a, dims, data, masks, sd, enc_f, dec_f = _prep(name)
+    nll, ll, lw = oracle_joint_nll(cfg, a, dims, data, sd, enc_f, dec_f)
+    close(a["nll"], nll, rtol=1e-6)
+    close(a["ll"], ll, rtol=1e-6)
+    close(a["lw"], lw, rtol=1e-6, atol=1e-4)
+    nll_one_chunk, _, _ = oracle_joint_nll(cfg, a, dims, data, sd, enc_f, dec_f, batch_size_K=cfg["nll_K"])
+    close(a["nll"], nll_one_chunk, rtol=2e-6)
+
+
+def nll_plus_noise(a, kept):
+    return {c: {k.split("/")[2]: G.t(a[k]) for k in a if k.startswith(f"noise/{c}/")} for c in kept}
+
+
+@pytest.mark.parametrize("name", G.NLL_MMVAEPLUS_CASES)
+def test_joint_nll_mmvaeplus(name):
+    """MMVAEPlus.compute_joint_nll (mmvaePlus_model.py:477-531), including the last modality the reference drops."""
+    cfg, a, dims, data, masks, sd, enc_f, dec_f = _prep(name)
+    names, kept = cfg["names"], cfg["kept"]
+    assert kept == names[:-1]
+    plv = {k.split("/")[1]: G.t(a[k]) for k in a if k.startswith("prior_logvar/")}
+    with torch.no_grad():
+        e = {m: enc_f[m](data[m]) for m in names}
+        nll, ll = elbo.mmvaeplus_joint_nll(e, data, dec_f, nll_plus_noise(a, kept), names=names, K=cfg["nll_K"],
+                                           family=cfg["family"], prior_logvars=plv)
+    close(a["nll"], nll, rtol=1e-6)
+    close(a["ll"], ll, rtol=1e-6)
+
+
 def mmvaeplus_noise(a, mods):
     return {c: {k.split("/")[2]: G.t(v) for k, v in a.items() if k.startswith(f"noise/{c}/")} for c in mods}
 
