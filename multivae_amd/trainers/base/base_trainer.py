@@ -140,6 +140,7 @@ class BaseTrainer:
         self.training_config = training_config
         self.model_config = model.model_config
         self.model_name = model.model_name
+        self.start_keep_best_epoch = getattr(model, "start_keep_best_epoch", 0)  # base_trainer.py:138
         self.world_size = training_config.world_size
         self.local_rank = training_config.local_rank
         self.rank = training_config.rank
@@ -247,8 +248,34 @@ class BaseTrainer:
         self._set_output_dir()
         self.callback_handler = CallbackHandler(callbacks=self.callbacks, model=self.model)
         self.callback_handler.add_callback(MetricConsolePrinterCallback())
-        self.best_train_loss = 1e10
-        self.best_eval_loss = 1e10
+        self.trained_epochs = 0
+        self.best_train_loss = float("inf")
+        self.best_eval_loss = float("inf")
+        self.metrics_best_model = {}
+        self._best_model = deepcopy(self.model)
+
+    def resume_training(self, checkpoint):
+        """Continue from a `checkpoint_epoch_N` folder (base_trainer.py:402-440), written by this trainer or by the
+        reference's: optimizer / scheduler state, best losses, trained epochs and the training directory."""
+        with open(os.path.join(checkpoint, "info_checkpoint.json"), "r") as fp:
+            info = json.load(fp)
+        with open(os.path.join(checkpoint, "metrics_best_model.json"), "r") as fp:
+            self.metrics_best_model = json.load(fp)
+        set_seed(self.training_config.seed)
+        self.set_optimizer()
+        self.optimizer.load_state_dict(torch.load(os.path.join(checkpoint, "optimizer.pt"), map_location=self.device))
+        self.set_scheduler()
+        if self.scheduler is not None:
+            self.scheduler.load_state_dict(torch.load(os.path.join(checkpoint, "scheduler.pt"),
+                                                      map_location=self.device))
+        self.training_dir = info["training_dir"]
+        if self.is_main_process:
+            os.makedirs(self.training_dir, exist_ok=True)
+        self.callback_handler = CallbackHandler(callbacks=self.callbacks, model=self.model)
+        self.callback_handler.add_callback(MetricConsolePrinterCallback())
+        self.trained_epochs = info["trained_epochs"]
+        self.best_train_loss = info["best_train_loss"]
+        self.best_eval_loss = info["best_eval_loss"]
         self._best_model = deepcopy(self.model)
 
     # -- one optimizer step -------------------------------------------------------------------------------------
@@ -352,12 +379,14 @@ class BaseTrainer:
 
     # -- main loop -----------------------------------------------------------------------------------------------
     def train(self):
-        self.prepare_training()
+        if self.checkpoint is None:
+            self.prepare_training()
+        else:
+            self.resume_training(self.checkpoint)
         cfg = self.training_config
         self.callback_handler.on_train_begin(training_config=cfg, model_config=self.model_config)
-        best_train_loss, best_eval_loss = self.best_train_loss, self.best_eval_loss
         history = []
-        for epoch in range(1, cfg.num_epochs + 1):
+        for epoch in range(self.trained_epochs + 1, cfg.num_epochs + 1):
             self.callback_handler.on_epoch_begin(training_config=cfg, epoch=epoch)
             metrics = {}
             epoch_train_loss, epoch_metrics = self.train_step(epoch)
@@ -372,12 +401,19 @@ class BaseTrainer:
                     self._schedulers_step(epoch_eval_loss)
             elif self.scheduler is not None:
                 self._schedulers_step(epoch_train_loss)
-            if epoch_eval_loss is not None and epoch_eval_loss < best_eval_loss and not cfg.keep_best_on_train:
-                best_eval_loss = epoch_eval_loss
+            if epoch_eval_loss is None:
+                epoch_eval_loss = self.best_eval_loss  # base_trainer.py:528
+            if epoch <= self.start_keep_best_epoch:  # e.g. JMVAE's warm-up: keep the latest model (:534-539)
                 self._best_model = deepcopy(self.model)
-            elif epoch_train_loss < best_train_loss and cfg.keep_best_on_train:
-                best_train_loss = epoch_train_loss
+                self.metrics_best_model = metrics
+            elif epoch_eval_loss < self.best_eval_loss and not cfg.keep_best_on_train:
+                self.best_eval_loss = epoch_eval_loss
                 self._best_model = deepcopy(self.model)
+                self.metrics_best_model = metrics
+            elif epoch_train_loss < self.best_train_loss and cfg.keep_best_on_train:
+                self.best_train_loss = epoch_train_loss
+                self._best_model = deepcopy(self.model)
+                self.metrics_best_model = metrics
             self.callback_handler.on_epoch_end(training_config=cfg)
             if cfg.steps_saving is not None and epoch % cfg.steps_saving == 0 and self.is_main_process:
                 self.save_checkpoint(model=self._best_model, dir_path=self.training_dir, epoch=epoch)
@@ -406,11 +442,14 @@ class BaseTrainer:
         os.makedirs(dir_path, exist_ok=True)
         model.save(dir_path)
         self.training_config.save_json(dir_path, "training_config")
+        with open(os.path.join(dir_path, "metrics_best_model.json"), "w") as fp:
+            json.dump(self.metrics_best_model, fp)
         self.callback_handler.on_save(self.training_config)
 
     def save_checkpoint(self, model: BaseModel, dir_path, epoch: int):
-        """checkpoint_epoch_N/{model.pt, optimizer.pt, model_config.json, training_config.json, environment.json,
-        info_checkpoint.json} (base_trainer.py:777-828)."""
+        """checkpoint_epoch_N/{model.pt, optimizer.pt [, scheduler.pt], model_config.json, training_config.json,
+        environment.json, metrics_best_model.json, info_checkpoint.json} (base_trainer.py:777-828), same keys and
+        layouts, so a checkpoint resumes in either trainer."""
         ckpt = os.path.join(dir_path, f"checkpoint_epoch_{epoch}")
         os.makedirs(ckpt, exist_ok=True)
         torch.save(deepcopy(self.optimizer.state_dict()), os.path.join(ckpt, "optimizer.pt"))
@@ -418,5 +457,9 @@ class BaseTrainer:
             torch.save(deepcopy(self.scheduler.state_dict()), os.path.join(ckpt, "scheduler.pt"))
         model.save(ckpt)
         self.training_config.save_json(ckpt, "training_config")
+        with open(os.path.join(ckpt, "metrics_best_model.json"), "w") as fp:
+            json.dump(self.metrics_best_model, fp)
+        info = dict(training_dir=self.training_dir, trained_epochs=epoch, best_train_loss=self.best_train_loss,
+                    best_eval_loss=self.best_eval_loss)
         with open(os.path.join(ckpt, "info_checkpoint.json"), "w") as fp:
-            json.dump({"epoch": epoch, "best_train_loss": self.best_train_loss, "best_eval_loss": self.best_eval_loss}, fp)
+            json.dump(info, fp, sort_keys=True, indent=4)

@@ -12,7 +12,8 @@ from .. import kernels
 
 class FlatParams:
     def __init__(self, model: torch.nn.Module):
-        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.all_params = list(model.parameters())  # torch.optim indexes its state by position in this list
+        self.params = [p for p in self.all_params if p.requires_grad]
         if not self.params:
             raise ValueError("model has no trainable parameters")
         dev = self.params[0].device
@@ -77,10 +78,45 @@ class FusedAdam:
                           self.betas[1], self.eps, self.weight_decay, grad_scale)
 
     def state_dict(self):
-        return {"m": self.m, "v": self.v, "step": self.step_count, "lr": self.lr, "betas": self.betas,
-                "eps": self.eps, "weight_decay": self.weight_decay}
+        """The layout of `torch.optim.Adam(model.parameters()).state_dict()` (what the reference writes to
+        `optimizer.pt`, base_trainer.py:790-793, and reads back in `resume_training`, :413-419): per-parameter
+        `step` / `exp_avg` / `exp_avg_sq` keyed by the parameter's position in `model.parameters()`, one param group."""
+        pos = {id(p): i for i, p in enumerate(self.flat.all_params)}
+        state, off = {}, 0
+        for p in self.flat.params:
+            k = p.numel()
+            if self.step_count > 0:  # torch creates the state lazily at the first step
+                state[pos[id(p)]] = {"step": torch.tensor(float(self.step_count)),
+                                     "exp_avg": self.m[off:off + k].view(p.shape).clone(),
+                                     "exp_avg_sq": self.v[off:off + k].view(p.shape).clone()}
+            off += k
+        group = dict(lr=self.lr, betas=tuple(self.betas), eps=self.eps, weight_decay=self.weight_decay, amsgrad=False,
+                     maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                     decoupled_weight_decay=False, params=list(range(len(self.flat.all_params))))
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self.m.copy_(sd["m"])
-        self.v.copy_(sd["v"])
-        self.step_count = int(sd["step"])
+        """Accepts the torch.optim.Adam layout above (also an `optimizer.pt` written by the reference)."""
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.flat.all_params):
+            raise ValueError("loaded state dict has a different number of parameter groups / parameters")
+        if groups[0].get("amsgrad", False):
+            raise ValueError("the fused Adam has no amsgrad state: use use_fused_adam=False")
+        g = groups[0]
+        self.lr, self.betas = float(g["lr"]), tuple(g["betas"])
+        self.eps, self.weight_decay = float(g["eps"]), float(g["weight_decay"])
+        pos = {id(p): i for i, p in enumerate(self.flat.all_params)}
+        self.m.zero_()
+        self.v.zero_()
+        steps, off = set(), 0
+        for p in self.flat.params:
+            k = p.numel()
+            st = sd["state"].get(pos[id(p)])
+            if st is not None:
+                self.m[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                self.v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
+            off += k
+        if len(steps) > 1:
+            raise ValueError(f"parameters with different step counts {sorted(steps)}: not representable by one fused step")
+        self.step_count = steps.pop() if steps else 0

@@ -90,9 +90,13 @@ class BaseConfig:
         return cls(**d)
 
     @classmethod
-    def from_json_file(cls, path):
+    def _dict_from_json(cls, path):  # pythae.config.BaseConfig._dict_from_json (used by multivae's AutoConfig)
         with open(path) as f:
-            return cls.from_dict(json.load(f))
+            return json.load(f)
+
+    @classmethod
+    def from_json_file(cls, path):
+        return cls.from_dict(cls._dict_from_json(path))
 
     def to_dict(self):
         return dataclasses.asdict(self)

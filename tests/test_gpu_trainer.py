@@ -237,3 +237,46 @@ def test_cfg4_cfg5_architectures_take_training_steps():
         assert all(np.isfinite(v) for v in losses), losses
         assert losses[-1] < losses[0], losses
         assert float(flat.grad.abs().max()) > 0
+
+
+def test_resume_from_checkpoint_continues_the_same_training(tmp_path):
+    """checkpoint_epoch_N (model.pt + optimizer.pt in torch.optim.Adam layout + info_checkpoint.json +
+    metrics_best_model.json, base_trainer.py:777-828) -> BaseTrainer(checkpoint=...) resumes at epoch N+1 with the
+    optimizer moments and step count of the interrupted run (resume_training, :402-440)."""
+    import json
+
+    from multivae_amd.data.datasets.base import MultimodalBaseDataset
+    from multivae_amd.models import MVTCAE, MVTCAEConfig
+    from multivae_amd.trainers import BaseTrainer, BaseTrainerConfig
+
+    torch.manual_seed(0)
+    dims = dict(a=(6,), b=(2, 5))
+    ds = MultimodalBaseDataset(data=dict(a=torch.rand(96, 6), b=torch.rand(96, 2, 5)))
+
+    def make():
+        torch.manual_seed(1)
+        return MVTCAE(MVTCAEConfig(n_modalities=2, latent_dim=4, input_dims=dims))
+
+    def cfg(out, epochs):
+        return BaseTrainerConfig(output_dir=str(out), per_device_train_batch_size=32, num_epochs=epochs,
+                                 learning_rate=1e-3, steps_saving=1, use_hip_graph=False)
+
+    t1 = BaseTrainer(make(), train_dataset=ds, training_config=cfg(tmp_path / "a", 1))
+    t1.train()
+    ck = os.path.join(t1.training_dir, "checkpoint_epoch_1")
+    with open(os.path.join(ck, "info_checkpoint.json")) as f:
+        info = json.load(f)
+    assert set(info) == {"training_dir", "trained_epochs", "best_train_loss", "best_eval_loss"} and info["trained_epochs"] == 1
+    with open(os.path.join(ck, "metrics_best_model.json")) as f:
+        assert "train_epoch_loss" in json.load(f)
+    osd = torch.load(os.path.join(ck, "optimizer.pt"), map_location="cpu")
+    assert set(osd) == {"state", "param_groups"} and float(osd["state"][0]["step"]) == 3.0
+    m_after_1 = {k: v.clone() for k, v in t1._best_model.state_dict().items()}
+    t2 = BaseTrainer(make(), train_dataset=ds, training_config=cfg(tmp_path / "b", 3), checkpoint=ck)
+    assert all(torch.equal(v.cpu(), m_after_1[k].cpu()) for k, v in t2.model.state_dict().items())
+    hist = t2.train()
+    assert len(hist) == 2  # epochs 2 and 3 only
+    assert t2.optimizer.step_count == 9
+    assert t2.training_dir == info["training_dir"]
+    assert os.path.isdir(os.path.join(t2.training_dir, "checkpoint_epoch_3"))
+    assert hist[-1]["train_epoch_loss"] < float(json.load(open(os.path.join(ck, "metrics_best_model.json")))["train_epoch_loss"])

@@ -211,3 +211,66 @@ def test_jmvae_and_mmvaeplus_save_load_roundtrip(tmp_path):
     assert all(torch.equal(v, mp2.state_dict()[k]) for k, v in mp.state_dict().items())
     with pytest.raises(AttributeError):
         JMVAE(JMVAEConfig(n_modalities=2, latent_dim=5, input_dims=dims), joint_encoder=torch.nn.Linear(2, 2))
+
+
+def test_fused_adam_state_dict_is_torch_adam_layout():
+    """`optimizer.pt` compatibility (base_trainer.py:790-793 writes torch.optim.Adam.state_dict(), :413-419 reads it):
+    the fused Adam's state loads into torch.optim.Adam and back, parameter by parameter, including parameters that do
+    not require grad (they keep their index, they have no state)."""
+    from multivae_amd.models import MMVAE, MMVAEConfig
+    from multivae_amd.trainers.flat import FlatParams, FusedAdam
+
+    torch.manual_seed(0)
+    model = MMVAE(MMVAEConfig(n_modalities=2, latent_dim=4, input_dims=dict(a=(3,), b=(2, 2)), learn_prior=True))
+    assert not model.prior_mean.requires_grad  # a frozen parameter in the middle of model.parameters()
+    ref_opt = torch.optim.Adam(model.parameters(), lr=3e-4, betas=(0.8, 0.95), eps=1e-7)
+    for _ in range(2):
+        for p in model.parameters():
+            p.grad = torch.randn_like(p) if p.requires_grad else None
+        ref_opt.step()
+    sd = ref_opt.state_dict()
+    for p in model.parameters():
+        p.grad = None
+    flat = FlatParams(model)
+    opt = FusedAdam(flat, lr=1.0)
+    opt.load_state_dict(sd)
+    assert opt.step_count == 2 and opt.lr == 3e-4 and opt.betas == (0.8, 0.95) and opt.eps == 1e-7
+    mine = opt.state_dict()
+    assert mine["param_groups"][0]["params"] == sd["param_groups"][0]["params"]
+    assert set(mine["state"]) == set(sd["state"])
+    for i, st in sd["state"].items():
+        assert torch.equal(mine["state"][i]["exp_avg"], st["exp_avg"])
+        assert torch.equal(mine["state"][i]["exp_avg_sq"], st["exp_avg_sq"])
+        assert float(mine["state"][i]["step"]) == 2.0
+    fresh = torch.optim.Adam(model.parameters(), lr=1.0)
+    fresh.load_state_dict(mine)  # torch validates group sizes and casts the state
+    assert fresh.state_dict()["param_groups"][0]["lr"] == 3e-4
+    assert FusedAdam(flat).state_dict()["state"] == {}  # like torch: no state before the first step
+    bad = {"state": {}, "param_groups": [dict(sd["param_groups"][0], params=[0, 1])]}
+    with pytest.raises(ValueError):
+        opt.load_state_dict(bad)
+
+
+def test_auto_model_and_auto_config(tmp_path):
+    """AutoModel / AutoConfig pick the class from the `name` field of model_config.json (auto_model.py:41-98)."""
+    import json
+
+    from multivae_amd.models import AutoConfig, AutoModel, MoPoE, MoPoEConfig, MVTCAE, MVTCAEConfig
+
+    dims = dict(a=(2, 3), b=(7,))
+    m = MoPoE(MoPoEConfig(n_modalities=2, latent_dim=5, input_dims=dims, beta=2.0))
+    m.save(str(tmp_path / "mopoe"))
+    with open(tmp_path / "mopoe" / "model_config.json") as f:
+        d = json.load(f)
+    assert d["name"] == "MoPoEConfig" and d["input_dims"] == {"a": [2, 3], "b": [7]} and d["subsets"]["a_b"] == ["a", "b"]
+    back = AutoModel.load_from_folder(str(tmp_path / "mopoe"))
+    assert isinstance(back, MoPoE) and back.model_config.beta == 2.0
+    assert all(torch.equal(v, back.state_dict()[k]) for k, v in m.state_dict().items())
+    MVTCAE(MVTCAEConfig(n_modalities=2, latent_dim=5, input_dims=dims, alpha=0.4)).save(str(tmp_path / "mvt"))
+    cfg = AutoConfig.from_json_file(str(tmp_path / "mvt" / "model_config.json"))
+    assert isinstance(cfg, MVTCAEConfig) and cfg.alpha == 0.4
+    d["name"] = "SomethingElseConfig"
+    with open(tmp_path / "mopoe" / "model_config.json", "w") as f:
+        json.dump(d, f)
+    with pytest.raises(NameError):
+        AutoModel.load_from_folder(str(tmp_path / "mopoe"))
