@@ -29,6 +29,7 @@ extern "C" {
 #define MVK_ELAUNCH (-2)
 
 #define MVK_MAX_MODALITIES 8
+#define MVK_MVAE_MAX_SUBSETS 32  /* subsets of one MVAE objective (joint + unimodal + k random ones) */
 #define MVK_IWAE_MAX_EXPERTS 32 /* experts of the mixture posterior in mvk_iwae_logw (MoPoE: 2^5 - 1 subsets) */
 
 /* decoder output distributions — models/base/base_utils.py:62-87 (set_decoder_dist) */
@@ -94,6 +95,22 @@ int mvk_mvtcae_posterior_bwd(const float* const* mu, const float* const* lv, con
                              const float* gjoint_rows, const float* gcond_rows, float* const* dmu,
                              float* const* dlv, void* stream);
 
+/* MVAE (models/mvae/mvae_model.py:56-118): for each of the S subsets of the objective (subset_bits: HOST array, bit m
+ * = modality m), the product of the AVAILABLE experts of the subset and the N(0,I) prior in the log-sum-exp form of
+ * `stable_poe` (base_utils.py:133-147; a missing modality has log-variance +inf, mvae_model.py:71-75), one sample
+ * z_s = mu_s + exp(lv_s / 2) eps[s] per row and kld_rows[s,b] = -1/2 sum_l (1 + lv_s - mu_s^2 - exp(lv_s)) (:100).
+ * z_s is written into the decoder input of every modality of s: zm[m] is [K_m, B, L] with K_m = number of subsets
+ * holding m, slab index = rank of s among them (HOST array of M device pointers; so each decoder runs once for all
+ * its subsets).  eps [S,B,L]; sub_mu, sub_lv [S,B,L] optional outputs (both or neither).  Rows with no available
+ * modality in s give the prior (kld 0, no gradient).  bwd: dzm[m] [K_m,B,L] (entries may be NULL), gkld_rows [S,B]
+ * (nullable) -> dmu[m], dlv[m] [B,L] (overwritten). */
+int mvk_mvae_posterior_fwd(const float* const* mu, const float* const* lv, const uint8_t* const* masks, int M,
+                           const int32_t* subset_bits, int S, const float* eps, int B, int L, float* const* zm,
+                           float* kld_rows, float* sub_mu, float* sub_lv, void* stream);
+int mvk_mvae_posterior_bwd(const float* const* mu, const float* const* lv, const uint8_t* const* masks, int M,
+                           const int32_t* subset_bits, int S, const float* eps, const float* const* dzm, int B, int L,
+                           const float* gkld_rows, float* const* dmu, float* const* dlv, void* stream);
+
 /* JMVAE (models/jmvae/jmvae_model.py:133-174): reparameterised sample(s) of the joint encoder's posterior
  * z[k] = joint_mu + exp(joint_lv/2) * eps[k], kld_rows[b] = KL(q(z|X) || N(0,I)) summed over L, and
  * ljm_rows[b] = sum_m KL(q(z|X) || q(z|x_m)) with (mu[m], lv[m]) the unimodal encoders' outputs.
@@ -135,8 +152,9 @@ int mvk_recon_nll_bwd(const mvk_recon_desc* descs, int n_mod, int K, int B, void
 
 /* Scalar assembly: out[i] = coef[i] * sum_j v_i[j] * (mask_i ? mask_i[j % period_i] : 1) for i < n_terms;
  * out[n_terms] = sum_i lossw[i] * out[i]; out[n_terms+1] = out[n_terms] * loss_sum_scale; *loss_out (nullable)
- * = out[n_terms].  n_terms <= 16.
+ * = out[n_terms].  n_terms <= MVK_MAX_TERMS.
  * Replaces the `.mean()` / `.sum()` / `loss = ...` lines of mopoe_model.py:200-227, mvtcae_model.py:96-108. */
+#define MVK_MAX_TERMS 64
 typedef struct mvk_term_desc {
   const float* v;
   const uint8_t* mask;

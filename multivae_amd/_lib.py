@@ -94,6 +94,8 @@ PROTOTYPES = {
     "mvk_mmvae_latent_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _f, _p],
     "mvk_mmvaeplus_cross_latent_fwd": [_p, _p, _p, _i64, _i, _i, _i, _p, _p],
     "mvk_mmvaeplus_cross_latent_bwd": [_p, _p, _i64, _i, _i, _i, _p, _p, _p],
+    "mvk_mvae_posterior_fwd": [_p, _p, _p, _i, _p, _i, _p, _i, _i, _p, _p, _p, _p, _p],
+    "mvk_mvae_posterior_bwd": [_p, _p, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p, _p],
     "mvk_iwae_sample": [_p, _p, _p, _i, _i, _i, _i, _p, _p],
     "mvk_iwae_logw": [_p, _p, _i, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p, _p],
     "mvk_iwae_reduce": [_p, _i, _i, _i, _p, _p],

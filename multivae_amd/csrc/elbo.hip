@@ -622,6 +622,146 @@ __global__ __launch_bounds__(256) void jmvae_posterior_bwd_kernel(const float* _
   djlv[i] = glv;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// MVAE posterior (models/mvae/mvae_model.py:56-118): for every subset s of the objective, the product of the available
+// experts of s AND the N(0,I) prior, in the log-sum-exp form of `stable_poe` (base_utils.py:133-147), one
+// reparameterised sample per subset and row, and the KL to the prior.  One wave per batch row, lanes over the latent.
+// The sample of subset s is written once per modality of s, into that modality's decoder input zm[m][slot(s,m)]
+// ([K_m, B, L], K_m = number of subsets holding m), so every decoder runs once over all its subsets.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int MAXS = MVK_MVAE_MAX_SUBSETS;
+struct MvaeTable {
+  uint32_t bits[MAXS];
+  signed char slot[MAXS][MAXM];  // slab of zm[m] that holds subset s (-1: m not in s)
+  float* zm[MAXM];
+  const float* dzm[MAXM];
+};
+
+__global__ __launch_bounds__(256) void mvae_posterior_fwd_kernel(const PtrTable pt, const MvaeTable tb, int M, int S,
+                                                                 const float* __restrict__ eps, int B, int L,
+                                                                 float* __restrict__ kld_rows,
+                                                                 float* __restrict__ sub_mu,
+                                                                 float* __restrict__ sub_lv) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  bool avail[MAXM];
+#pragma unroll
+  for (int m = 0; m < MAXM; ++m) avail[m] = (m < M) && (pt.mask[m] ? pt.mask[m][b] != 0 : true);
+  for (int s = 0; s < S; ++s) {
+    const uint32_t bits = tb.bits[s];
+    float kld = 0.f;
+    for (int l = lane; l < L; l += 64) {
+      const long long o = (long long)b * L + l;
+      float a[MAXM], mu[MAXM];
+      float amax = 0.f;  // the prior expert: ln(1/var) = 0
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) {
+        a[m] = -INFINITY;  // missing rows: log-variance = +inf (mvae_model.py:71-75)
+        mu[m] = 0.f;
+        if (m < M && ((bits >> m) & 1u) && avail[m]) {
+          a[m] = -pt.lv[m][o];
+          mu[m] = pt.mu[m][o];
+          amax = fmaxf(amax, a[m]);
+        }
+      }
+      float se = expf(-amax), num = 0.f;  // prior: exp(0 - amax), mean 0
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) {
+        if (a[m] > -INFINITY) {
+          se += expf(a[m] - amax);
+          num += expf(a[m]) * mu[m];  // (exp(ln_inv_vars) * mus).sum(0)
+        }
+      }
+      const float lnv = -(amax + logf(se));
+      const float mus = num * expf(lnv);
+      kld += -0.5f * (1.0f + lnv - mus * mus - expf(lnv));
+      const long long so = ((long long)s * B + b) * L + l;
+      const float zz = mus + expf(0.5f * lnv) * eps[so];
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) {
+        if (m < M && tb.slot[s][m] >= 0) tb.zm[m][((long long)tb.slot[s][m] * B + b) * L + l] = zz;
+      }
+      if (sub_mu) {
+        sub_mu[so] = mus;
+        sub_lv[so] = lnv;
+      }
+    }
+    kld = wave_sum(kld);
+    if (lane == 0) kld_rows[(long long)s * B + b] = kld;
+  }
+}
+
+// d mu_e = g_mu w_e, d lv_e = w_e (g_lnv - g_mu (mu_e - mu_s)) with w_e = exp(-lv_e) / sum_e' exp(-lv_e') the
+// precision weights (softmax of -lv over the experts and the prior): no division by a possibly tiny variance.
+__global__ __launch_bounds__(256) void mvae_posterior_bwd_kernel(const PtrTable pt, const OutPtrTable ot,
+                                                                 const MvaeTable tb, int M, int S,
+                                                                 const float* __restrict__ eps, int B, int L,
+                                                                 const float* __restrict__ gkld_rows) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  bool avail[MAXM];
+#pragma unroll
+  for (int m = 0; m < MAXM; ++m) avail[m] = (m < M) && (pt.mask[m] ? pt.mask[m][b] != 0 : true);
+  for (int l = lane; l < L; l += 64) {
+    const long long o = (long long)b * L + l;
+    float dmu[MAXM], dlv[MAXM], mu[MAXM], nlv[MAXM];
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      dmu[m] = dlv[m] = mu[m] = nlv[m] = 0.f;
+      if (m < M) {
+        mu[m] = pt.mu[m][o];
+        nlv[m] = -pt.lv[m][o];
+      }
+    }
+    for (int s = 0; s < S; ++s) {
+      const uint32_t bits = tb.bits[s];
+      float amax = 0.f;
+      bool in[MAXM];
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) {
+        in[m] = m < M && ((bits >> m) & 1u) && avail[m];
+        if (in[m]) amax = fmaxf(amax, nlv[m]);
+      }
+      float se = expf(-amax), num = 0.f;
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) {
+        if (in[m]) {
+          se += expf(nlv[m] - amax);
+          num += expf(nlv[m]) * mu[m];
+        }
+      }
+      const float lnv = -(amax + logf(se));
+      const float mus = num * expf(lnv);
+      const long long so = ((long long)s * B + b) * L + l;
+      float dz = 0.f;
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) {
+        if (m < M && tb.slot[s][m] >= 0 && tb.dzm[m]) dz += tb.dzm[m][((long long)tb.slot[s][m] * B + b) * L + l];
+      }
+      const float gk = gkld_rows ? gkld_rows[(long long)s * B + b] : 0.f;
+      const float g_mu = dz + gk * mus;
+      const float g_lnv = dz * 0.5f * expf(0.5f * lnv) * eps[so] - 0.5f * gk * (1.0f - expf(lnv));
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) {
+        if (in[m]) {
+          const float w = expf(nlv[m] - amax) / se;
+          dmu[m] += g_mu * w;
+          dlv[m] += w * (g_lnv - g_mu * (mu[m] - mus));
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      if (m < M) {
+        ot.dmu[m][o] = dmu[m];
+        ot.dlv[m][o] = dlv[m];
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -705,6 +845,74 @@ int mvk_mvtcae_posterior_bwd(const float* const* mu, const float* const* lv, con
   }
   hipLaunchKernelGGL(mvtcae_posterior_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, mvk_stream(stream), pt, ot, M, eps,
                      dz, K, B, L, gjoint_rows, gcond_rows);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+static int mvae_table(const int32_t* subset_bits, int S, int M, MvaeTable* tb) {
+  if (!subset_bits || S < 1 || S > MAXS) return MVK_EINVAL;
+  int count[MAXM] = {0};
+  const uint32_t full = (M >= 32) ? 0xffffffffu : ((1u << M) - 1u);
+  for (int s = 0; s < S; ++s) {
+    const uint32_t bits = (uint32_t)subset_bits[s];
+    if (bits == 0 || (bits & ~full)) return MVK_EINVAL;
+    tb->bits[s] = bits;
+    for (int m = 0; m < MAXM; ++m) {
+      tb->slot[s][m] = -1;
+      if (m < M && ((bits >> m) & 1u)) {
+        if (count[m] > 127) return MVK_EINVAL;
+        tb->slot[s][m] = (signed char)count[m]++;
+      }
+    }
+  }
+  return MVK_OK;
+}
+
+int mvk_mvae_posterior_fwd(const float* const* mu, const float* const* lv, const uint8_t* const* masks, int M,
+                           const int32_t* subset_bits, int S, const float* eps, int B, int L, float* const* zm,
+                           float* kld_rows, float* sub_mu, float* sub_lv, void* stream) {
+  if (!mu || !lv || M < 1 || M > MAXM || !eps || !zm || !kld_rows || L < 1) return MVK_EINVAL;
+  if ((sub_mu == nullptr) != (sub_lv == nullptr)) return MVK_EINVAL;
+  MvaeTable tb{};
+  if (mvae_table(subset_bits, S, M, &tb) != MVK_OK) return MVK_EINVAL;
+  if (B <= 0) return B == 0 ? MVK_OK : MVK_EINVAL;
+  PtrTable pt{};
+  for (int m = 0; m < M; ++m) {
+    if (!mu[m] || !lv[m]) return MVK_EINVAL;
+    pt.mu[m] = mu[m];
+    pt.lv[m] = lv[m];
+    pt.mask[m] = masks ? masks[m] : nullptr;
+    tb.zm[m] = zm[m];
+    bool used = false;
+    for (int s = 0; s < S; ++s) used = used || tb.slot[s][m] >= 0;
+    if (used && !zm[m]) return MVK_EINVAL;
+  }
+  hipLaunchKernelGGL(mvae_posterior_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, mvk_stream(stream), pt, tb, M, S, eps,
+                     B, L, kld_rows, sub_mu, sub_lv);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_mvae_posterior_bwd(const float* const* mu, const float* const* lv, const uint8_t* const* masks, int M,
+                           const int32_t* subset_bits, int S, const float* eps, const float* const* dzm, int B, int L,
+                           const float* gkld_rows, float* const* dmu, float* const* dlv, void* stream) {
+  if (!mu || !lv || M < 1 || M > MAXM || !eps || !dzm || !dmu || !dlv || L < 1) return MVK_EINVAL;
+  MvaeTable tb{};
+  if (mvae_table(subset_bits, S, M, &tb) != MVK_OK) return MVK_EINVAL;
+  if (B <= 0) return B == 0 ? MVK_OK : MVK_EINVAL;
+  PtrTable pt{};
+  OutPtrTable ot{};
+  for (int m = 0; m < M; ++m) {
+    if (!mu[m] || !lv[m] || !dmu[m] || !dlv[m]) return MVK_EINVAL;
+    pt.mu[m] = mu[m];
+    pt.lv[m] = lv[m];
+    pt.mask[m] = masks ? masks[m] : nullptr;
+    ot.dmu[m] = dmu[m];
+    ot.dlv[m] = dlv[m];
+    tb.dzm[m] = dzm[m];
+  }
+  hipLaunchKernelGGL(mvae_posterior_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, mvk_stream(stream), pt, ot, tb, M, S,
+                     eps, B, L, gkld_rows);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }

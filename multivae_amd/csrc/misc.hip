@@ -202,7 +202,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 // ---- scalar assembly ----------------------------------------------------------------------------------------
 struct TermTable {
-  mvk_term_desc t[16];
+  mvk_term_desc t[MVK_MAX_TERMS];
   int n;
   float loss_sum_scale;
 };
@@ -210,7 +210,7 @@ struct TermTable {
 __global__ __launch_bounds__(1024) void reduce_terms_kernel(const TermTable tt, float* __restrict__ out,
                                                             float* __restrict__ loss_out) {
   __shared__ float red[16];
-  __shared__ float vals[16];
+  __shared__ float vals[MVK_MAX_TERMS];
   for (int i = 0; i < tt.n; ++i) {
     const mvk_term_desc& t = tt.t[i];
     float s = 0.f;
@@ -381,7 +381,7 @@ int mvk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, doubl
 
 int mvk_reduce_terms(const mvk_term_desc* terms, int n_terms, float loss_sum_scale, float* out, float* loss_out,
                      void* stream) {
-  if (!terms || !out || n_terms < 1 || n_terms > 16) return MVK_EINVAL;
+  if (!terms || !out || n_terms < 1 || n_terms > MVK_MAX_TERMS) return MVK_EINVAL;
   TermTable tt;
   for (int i = 0; i < n_terms; ++i) {
     tt.t[i] = terms[i];

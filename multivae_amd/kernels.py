@@ -868,14 +868,19 @@ class JMVAEPosteriorFn(Function):
 # Fused reconstruction NLL + scalar assembly (single autograd node producing the loss)
 # =====================================================================================================
 class ReconLossFn(Function):
-    """loss = sum_m lossw_m * coef_m * sum_{k,b} mask_m[b] rows_m[k,b] + sum_j lossw_j * coef_j * sum(extra_j).
+    """loss = sum_i lossw_i * coef_i * sum_{k,b} mask_i[b] rows_i[k,b] + sum_j lossw_j * coef_j * sum(extra_j).
 
     forward: ONE mvk_recon_nll_fwd launch for all modalities (row NLLs + d loss / d recon assuming an upstream
              gradient of 1) and ONE mvk_reduce_terms launch.  Returns (loss, terms[n_terms+2]) where terms holds
              every individual term, the loss and loss * loss_sum_scale (all detached: metrics).
     spec:    dict(K, B, x[], masks[], dist[], scale[], rescale[], coef[], lossw[], extra_coef[], extra_lossw[],
              extra_split[], loss_sum_scale).
-    extras:  tensors (KL rows) whose sums enter the loss with a constant weight.
+    extras:  tensors (KL rows) whose sums enter the loss with a constant weight; with extra_split[j] = n the tensor is
+             n equal chunks, one term each, and extra_coef[j] may be a list of n per-chunk coefficients.
+    pairs:   optional spec["pairs"] = [(tensor index, slab)]: reconstruction term i scores ONE [B, D] slab of the
+             decoder output tensors[tensor index] ([K_t, B, D]) against x[i] with its own mask / coefficient (MVAE: a
+             decoder runs once over the samples of all its subsets, every (modality, subset) pair is a term).  The
+             per-entry lists of spec are then indexed by pair; gradients are still one buffer per decoder output.
     """
 
     @staticmethod
@@ -884,56 +889,74 @@ class ReconLossFn(Function):
         extras = [_c(t) for t in tensors[n_mod:]]
         xs, masks = spec["x"], spec["masks"]
         K, B = spec["K"], spec["B"]
+        pairs = spec.get("pairs")
         ref = recons[0] if recons else extras[0]
-        descs = (ReconDesc * max(n_mod, 1))()
-        rows, drecons = [], []
-        for i in range(n_mod):
-            D = recons[i].numel() // (K * B)
-            r = _new((K, B), ref)
-            g = torch.empty_like(recons[i]) if ctx.needs_input_grad[2 + i] else None
+        drecons = [torch.empty_like(r) if ctx.needs_input_grad[2 + i] else None for i, r in enumerate(recons)]
+        if pairs is not None:  # every term is one slab: K = 1 launches; untouched slabs of a buffer get no gradient
+            used = {}
+            for j, k in pairs:
+                used.setdefault(j, set()).add(k)
+            for j, g in enumerate(drecons):
+                if g is not None and len(used.get(j, ())) != g.shape[0]:
+                    g.zero_()
+        n_rec = len(pairs) if pairs is not None else n_mod
+        descs = (ReconDesc * max(n_rec, 1))()
+        rows = []
+        for i in range(n_rec):
+            j, k = pairs[i] if pairs is not None else (i, None)
+            Kt = recons[j].shape[0] if pairs is not None else K
+            D = recons[j].numel() // (Kt * B)
+            off = 0 if k is None else 4 * k * B * D
+            r = _new((1 if pairs is not None else K, B), ref)
             rows.append(r)
-            drecons.append(g)
             d = descs[i]
-            d.recon, d.x = recons[i].data_ptr(), xs[i].data_ptr()
+            d.recon, d.x = recons[j].data_ptr() + off, xs[i].data_ptr()
             d.mask = masks[i].data_ptr() if masks[i] is not None else None
             d.rows = r.data_ptr()
-            d.drecon = g.data_ptr() if g is not None else None
+            d.drecon = drecons[j].data_ptr() + off if drecons[j] is not None else None
             d.rowcoef = None
             d.D, d.dist = D, spec["dist"][i]
             d.scale, d.rescale = spec["scale"][i], spec["rescale"][i]
             d.coef = spec["coef"][i] * spec["lossw"][i]
-        if n_mod:
+        if n_rec:
             prof = PROFILE.get("recon_nll")
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            call("mvk_recon_nll_fwd", descs, n_mod, K, B, stream_ptr())
+            Kl = 1 if pairs is not None else K
+            for i0 in range(0, n_rec, _lib.MAX_MODALITIES):  # MVK_MAX_MODALITIES descriptors per launch
+                n = min(_lib.MAX_MODALITIES, n_rec - i0)
+                call("mvk_recon_nll_fwd", C.cast(C.byref(descs[i0]), C.POINTER(ReconDesc)), n, Kl, B, stream_ptr())
             if prof is not None:
                 e1.record()
                 prof.append((e0, e1))
         splits = spec.get("extra_split") or [1] * len(extras)
-        n_terms = n_mod + sum(splits)
+        n_terms = n_rec + sum(splits)
         terms = (TermDesc * n_terms)()
-        for i in range(n_mod):
+        for i in range(n_rec):
             t = terms[i]
-            t.v, t.n = rows[i].data_ptr(), K * B
+            t.v, t.n = rows[i].data_ptr(), rows[i].numel()
             t.mask = masks[i].data_ptr() if masks[i] is not None else None
             t.period, t.coef, t.lossw = B, spec["coef"][i], spec["lossw"][i]
-        ti = n_mod
+        ti = n_rec
+        extra_grad = []  # (byte offset, numel, coefficient) per chunk of every extra tensor
         for j, e in enumerate(extras):
             ns = splits[j]
             chunk = e.numel() // ns
+            cj = spec["extra_coef"][j]
             for c in range(ns):  # one term per chunk (e.g. per-modality KL rows), one gradient per tensor
                 t = terms[ti]
+                cc = cj[c] if isinstance(cj, (list, tuple)) else cj
                 t.v, t.n, t.mask, t.period = e.data_ptr() + 4 * c * chunk, chunk, None, 1
-                t.coef, t.lossw = spec["extra_coef"][j], spec["extra_lossw"][j]
+                t.coef, t.lossw = cc, spec["extra_lossw"][j]
+                extra_grad.append((j, 4 * c * chunk, chunk, cc * spec["extra_lossw"][j]))
                 ti += 1
         out = _new((n_terms + 2,), ref)
         loss = _new((), ref)
         call("mvk_reduce_terms", terms, n_terms, spec["loss_sum_scale"], ptr(out), ptr(loss), stream_ptr())
         ctx.drecons = drecons
         ctx.extra_shapes = [e.shape for e in extras]
-        ctx.extra_grad = [spec["extra_coef"][j] * spec["extra_lossw"][j] for j in range(len(extras))]
+        ctx.extra_grad = extra_grad
         ctx.rows = rows  # keep alive: metrics / debugging
         ctx.mark_non_differentiable(out)
         return loss, out
@@ -944,15 +967,64 @@ class ReconLossFn(Function):
         gloss = _c(gloss.reshape(1))
         grads = list(ctx.drecons)
         extras = [_new(shape, gloss) for shape in ctx.extra_shapes]
-        jobs = [(g, 1.0, 0) for g in ctx.drecons if g is not None] + [(e, c, 1) for e, c in zip(extras, ctx.extra_grad)]
+        jobs = [(g.data_ptr(), g.numel(), 1.0, 0) for g in ctx.drecons if g is not None]
+        jobs += [(extras[j].data_ptr() + off, n, c, 1) for j, off, n, c in ctx.extra_grad]
         for i0 in range(0, len(jobs), 12):  # MVK_SEED_MAX buffers per launch: normally ONE launch
             chunk = jobs[i0:i0 + 12]
             descs = (SeedDesc * len(chunk))()
-            for d, (t, c, fill) in zip(descs, chunk):
-                d.buf, d.n, d.coef, d.fill = t.data_ptr(), t.numel(), float(c), fill
+            for d, (p, n, c, fill) in zip(descs, chunk):
+                d.buf, d.n, d.coef, d.fill = p, n, float(c), fill
             call("mvk_loss_backward_seed", descs, len(chunk), ptr(gloss), stream_ptr())
         ctx.drecons = None
         return (None, None, *grads, *extras)
+
+
+class MVAEPosteriorFn(Function):
+    """(mu_m, lv_m)_m, eps [S,B,L] -> z of every subset written into its modalities' decoder inputs zm[m] [K_m,B,L],
+    kld_rows [S,B] (mvk_mvae_posterior_fwd/bwd; mvae_model.py:56-118)."""
+
+    @staticmethod
+    def forward(ctx, eps, masks, subset_bits, want_stats, *mus_lvs):
+        M = len(mus_lvs) // 2
+        mus = [_c(t) for t in mus_lvs[:M]]
+        lvs = [_c(t) for t in mus_lvs[M:]]
+        eps = _c(eps)
+        S, B, L = eps.shape
+        bits = (C.c_int32 * S)(*subset_bits)
+        counts = [sum((b >> m) & 1 for b in subset_bits) for m in range(M)]
+        zm = [_new((counts[m], B, L), eps) if counts[m] else None for m in range(M)]
+        kld = _new((S, B), eps)
+        smu = _new((S, B, L), eps) if want_stats else None
+        slv = _new((S, B, L), eps) if want_stats else None
+        marr = ptr_array(masks) if masks is not None else None
+        call("mvk_mvae_posterior_fwd", ptr_array(mus), ptr_array(lvs), marr, M, bits, S, ptr(eps), B, L, ptr_array(zm),
+             ptr(kld), ptr(smu) if want_stats else None, ptr(slv) if want_stats else None, stream_ptr())
+        ctx.save_for_backward(eps, *mus, *lvs)
+        ctx.masks, ctx.bits, ctx.M, ctx.n_z = masks, bits, M, sum(1 for t in zm if t is not None)
+        ctx.has_z = [t is not None for t in zm]
+        outs = [t for t in zm if t is not None] + [kld]
+        if want_stats:
+            outs += [smu, slv]
+            ctx.mark_non_differentiable(smu, slv)
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        saved = ctx.saved_tensors
+        eps, M = saved[0], ctx.M
+        mus, lvs = list(saved[1:1 + M]), list(saved[1 + M:1 + 2 * M])
+        S, B, L = eps.shape
+        gz = iter(grads[:ctx.n_z])
+        dzm = [(_c(next(gz)) if has else None) for has in ctx.has_z]
+        gk = grads[ctx.n_z]
+        gk = _c(gk) if gk is not None else None
+        dmu = [torch.empty_like(t) for t in mus]
+        dlv = [torch.empty_like(t) for t in lvs]
+        marr = ptr_array(ctx.masks) if ctx.masks is not None else None
+        call("mvk_mvae_posterior_bwd", ptr_array(mus), ptr_array(lvs), marr, M, ctx.bits, S, ptr(eps), ptr_array(dzm), B,
+             L, ptr(gk) if gk is not None else None, ptr_array(dmu), ptr_array(dlv), stream_ptr())
+        return (None, None, None, None, *dmu, *dlv)
 
 
 def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):

@@ -4,8 +4,9 @@ from .joint_models import BaseJointModel, BaseJointModelConfig
 from .mmvae import MMVAE, MMVAEConfig
 from .mmvaePlus import MMVAEPlus, MMVAEPlusConfig
 from .mopoe import MoPoE, MoPoEConfig
+from .mvae import MVAE, MVAEConfig
 from .mvtcae import MVTCAE, MVTCAEConfig
 from .auto_model import AutoConfig, AutoModel  # noqa: E402  (needs the model classes above)
 
 __all__ = ["BaseAEConfig", "BaseMultiVAE", "BaseMultiVAEConfig", "ModelOutput", "MMVAE", "MMVAEConfig", "MoPoE",
-           "MoPoEConfig", "MVTCAE", "MVTCAEConfig", "JMVAE", "JMVAEConfig", "BaseJointModel", "BaseJointModelConfig", "MMVAEPlus", "MMVAEPlusConfig", "AutoModel", "AutoConfig"]
+           "MoPoEConfig", "MVTCAE", "MVTCAEConfig", "JMVAE", "JMVAEConfig", "BaseJointModel", "BaseJointModelConfig", "MMVAEPlus", "MMVAEPlusConfig", "AutoModel", "AutoConfig", "MVAE", "MVAEConfig"]

@@ -305,7 +305,10 @@ class BaseTrainer:
         from ..graph import GraphedStep
 
         key_fn = getattr(self.model, "graph_key", None)
-        key = (tuple((m, tuple(v.shape)) for m, v in inputs.data.items()), key_fn(epoch=epoch) if key_fn else None)
+        model_key = key_fn(**fwd_kwargs) if key_fn else None
+        if model_key is False:  # this step is not replayable (e.g. MVAE while its KL weight changes every batch)
+            return None
+        key = (tuple((m, tuple(v.shape)) for m, v in inputs.data.items()), model_key)
         graphs = self.__dict__.setdefault("_graphs", {})
         gs = graphs.get(key)
         if gs is None and key not in graphs:

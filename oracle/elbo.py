@@ -620,3 +620,93 @@ def mopoe_subset_joint_nll(enc, data, decoders, eps, *, names, subset, dists=Non
     s = inf["keys"].index("_".join(sorted(subset)))
     mu, sd = inf["mus"][s], torch.exp(0.5 * inf["logvars"][s])
     return iwae_joint_nll(mu + sd * eps, data, decoders, [(mu, sd)], names=names, dists=dists, batch_size_K=batch_size_K)
+
+
+# ----------------------------------------------------------------------------------------------
+# MVAE (sub-sampled product-of-experts ELBOs)
+# ----------------------------------------------------------------------------------------------
+def mvae_subsets(names, use_subsampling=True, random_subsets=()):
+    """Subsets of one MVAE objective in evaluation order, mvae_model.py:176-191: the joint one, then (sub-sampling)
+    the unimodal ones, then the k randomly drawn ones (`random_subsets`: lists of names, the np.random.choice result)."""
+    out = [list(names)]
+    if use_subsampling:
+        out += [[m] for m in names]
+        out += [list(s) for s in random_subsets]
+    return out
+
+
+def mvae_annealing(epoch, batch_ratio, warmup, beta):
+    """mvae_model.py:166-171."""
+    return 1 * beta if epoch >= warmup else (epoch - 1 + batch_ratio) / warmup * beta
+
+
+def mvae_forward(enc, data, decoders, eps, *, names, subsets, beta=1.0, rescale=None, dists=None, dist_scales=None,
+                 masks=None):
+    """MVAE.forward, mvae_model.py:145-228 with _compute_elbo_subset :86-118, compute_mu_log_var_subset :53-84 and
+    _filter_inputs_with_masks :120-143.
+
+    enc: {name: (mu [B,L], logvar [B,L])} on the whole batch (the reference re-runs the encoders on the filtered
+    batch of every subset; the default networks are row-independent).  eps [S,B,L]: row b of eps[s] is the noise of
+    data point b in subset s (the reference draws one [n_s, L] tensor per subset for the rows it keeps).
+    beta: the annealed KL weight (mvae_annealing).  Returns loss, loss_sum, metrics and per-subset intermediates."""
+    rescale = rescale or {m: 1.0 for m in names}
+    dists = dists or {}
+    dist_scales = dist_scales or {}
+    total, metrics, zs, sub = 0, {}, [], []
+    len_batch = 0.0
+    for si, s in enumerate(subsets):
+        if masks is not None:
+            filt = torch.zeros_like(masks[s[0]], dtype=torch.bool)
+            for m in s:
+                filt = torch.logical_or(filt, masks[m].bool())
+            if not bool(filt.any()):
+                len_batch = 0.0
+                zs.append(None)
+                sub.append(None)
+                continue
+        else:
+            filt = torch.ones(eps.shape[1], dtype=torch.bool)
+        mus, lvs = [], []
+        for m in names:
+            if m in s:
+                mu_m, lv_m = enc[m][0][filt], enc[m][1][filt].clone()
+                if masks is not None:
+                    lv_m[~masks[m].bool()[filt]] = float("inf")
+                mus.append(mu_m)
+                lvs.append(lv_m)
+        mus.append(torch.zeros_like(mus[0]))
+        lvs.append(torch.zeros_like(lvs[0]))
+        sub_mu, sub_lv = stable_poe(torch.stack(mus), torch.stack(lvs))
+        z = rsample(sub_mu, sub_lv, eps[si][filt])
+        recon_sum = 0
+        for m in names:
+            if m in s:
+                rec = decoders[m](z)
+                r = _row_nll(dists.get(m, "normal"), rec, data[m][filt], rescale[m], dist_scales.get(m, 1.0))
+                if masks is not None:
+                    r = masks[m][filt].float() * r
+                recon_sum = recon_sum + r.sum()
+        kld = -0.5 * torch.sum(1 + sub_lv - sub_mu.pow(2) - sub_lv.exp())
+        n = len(sub_mu)
+        elbo = (recon_sum + kld * beta) / n
+        key = "_".join(sorted(s))
+        metrics[key] = elbo
+        metrics["beta"] = beta
+        metrics["kld" + key] = kld / n
+        # `recon = elbo_sub` (:99) aliases the tensor that `elbo_sub += KLD * beta` (:102) then updates in place: the
+        # reference's "recon" metric IS the subset ELBO.  Reproduced.
+        metrics["recon" + key] = elbo
+        total = total + elbo
+        len_batch = n
+        zs.append(z)
+        sub.append((sub_mu, sub_lv))
+    return dict(loss=total, loss_sum=total * len_batch, metrics=metrics, zs=zs, subs=sub)
+
+
+def mvae_joint_nll(enc, data, decoders, eps, *, names, dists=None, batch_size_K=100):
+    """MVAE.compute_joint_nll, mvae_model.py:266-340: q = stable_poe of all experts and the prior."""
+    mus = [enc[m][0] for m in names] + [torch.zeros_like(enc[names[0]][0])]
+    lvs = [enc[m][1] for m in names] + [torch.zeros_like(enc[names[0]][1])]
+    mu, lv = stable_poe(torch.stack(mus), torch.stack(lvs))
+    sd = torch.exp(0.5 * lv)
+    return iwae_joint_nll(mu + sd * eps, data, decoders, [(mu, sd)], names=names, dists=dists, batch_size_K=batch_size_K)

@@ -34,8 +34,8 @@ import _reference_import as R
 R.install()
 import procedural as P
 from multivae.data.datasets.base import IncompleteDataset, MultimodalBaseDataset
-from multivae.models import (JMVAE, MMVAE, MVTCAE, JMVAEConfig, MMVAEConfig, MMVAEPlus, MMVAEPlusConfig, MoPoE,
-                             MoPoEConfig, MVTCAEConfig)
+from multivae.models import (JMVAE, MMVAE, MVAE, MVTCAE, JMVAEConfig, MMVAEConfig, MMVAEPlus, MMVAEPlusConfig, MoPoE,
+                             MoPoEConfig, MVAEConfig, MVTCAEConfig)
 from multivae.models.base import base_utils as ref_utils
 from multivae.models.base.base_config import BaseAEConfig
 from multivae.models.nn.default_architectures import Decoder_AE_MLP, Encoder_VAE_MLP
@@ -658,6 +658,113 @@ def jmvae_main():
                seed=403)
 
 
+def mvae_case(name, *, arch, B, beta, warmup, epoch, batch_ratio, rescaling, masked, seed, k=0, subsampling=True,
+              dists=None, nll_K=0):
+    """MVAE.forward (+ backward) in training mode; the k random subsets are replayed from np.random's seed.  With nll_K
+    the case also records compute_joint_nll (complete data only)."""
+    print(name)
+    if arch == "tiny":
+        dims, L = TINY_DIMS, TINY_L
+        data, masks = tiny_data(B, seed, masked)
+        for m, d in (dists or {}).items():
+            if d == "bernoulli":
+                data[m] = (data[m] > 0.5).astype(np.float32)
+        shapes = P.default_mlp_shapes(dims, L)
+        enc = dec = None
+    else:
+        dims, L = dict(mnist=(1, 28, 28), svhn=(3, 32, 32)), 20
+        data, masks = mnist_svhn_data(B, seed), None
+        shapes = P.mnist_svhn_shapes(L)
+        enc, dec = mnist_svhn_arch(L)
+    cfg = MVAEConfig(n_modalities=len(dims), latent_dim=L, input_dims=dict(dims), beta=beta, warmup=warmup, k=k,
+                     use_subsampling=subsampling, uses_likelihood_rescaling=rescaling, decoders_dist=dists)
+    model = MVAE(cfg, enc, dec)
+    sd_np = P.make_state_dict(shapes, seed)
+    load_weights(model, sd_np)
+    names = list(model.encoders.keys())
+    inputs = ref_dataset(data, masks)
+    model.train()
+    # --- replay: np.random.choice of the k random subsets, then one [n_s, L] normal per evaluated subset
+    random_idx = []
+    if subsampling and model.k > 0:
+        np.random.seed(seed)
+        random_idx = [int(i) for i in np.random.choice(np.arange(len(model.subsets)), size=model.k, replace=False)]
+    subsets = elbo.mvae_subsets(names, subsampling, [model.subsets[i] for i in random_idx])
+    tmasks = None if masks is None else {m: t(v) for m, v in masks.items()}
+    torch.manual_seed(seed)
+    eps = torch.zeros(len(subsets), B, L)
+    for si, s in enumerate(subsets):
+        filt = torch.ones(B, dtype=torch.bool)
+        if tmasks is not None:
+            filt = torch.zeros(B, dtype=torch.bool)
+            for m in s:
+                filt = torch.logical_or(filt, tmasks[m])
+        if bool(filt.any()):
+            eps[si][filt] = torch.randn(int(filt.sum()), L)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    out = model(inputs, epoch=epoch, batch_ratio=batch_ratio)
+    model.zero_grad()
+    out.loss.backward()
+    gref = ref_grads(model)
+    osd = oracle_sd(sd_np)
+    if arch == "tiny":
+        enc_f, dec_f = nets.build_default_mlp(osd, dims)
+    else:
+        enc_f, dec_f = nets.build_mnist_svhn(osd, L)
+    tdata = {m: t(v) for m, v in data.items()}
+    e = {m: enc_f[m](tdata[m]) for m in names}
+    b_eff = elbo.mvae_annealing(epoch, batch_ratio, warmup, beta)
+    o = elbo.mvae_forward(e, tdata, dec_f, eps, names=names, subsets=subsets, beta=b_eff,
+                          rescale=elbo.rescale_factors(dims, rescaling), dists=dists, masks=tmasks)
+    o["loss"].backward()
+    report("loss", out.loss, o["loss"])
+    report("loss_sum", out.loss_sum, o["loss_sum"])
+    assert set(out.metrics) == set(o["metrics"]), (set(out.metrics) ^ set(o["metrics"]))
+    for k_ in out.metrics:
+        report(k_, torch.as_tensor(out.metrics[k_]), torch.as_tensor(o["metrics"][k_]))
+    cmp_grads("grads", gref, {k_: (v.grad if v.grad is not None else torch.zeros_like(v)) for k_, v in osd.items()})
+    arrays = dict(eps=eps, loss=out.loss.detach(), loss_sum=torch.as_tensor(out.loss_sum).detach())
+    for k_, v in out.metrics.items():
+        arrays["metric/" + k_] = torch.as_tensor(v).detach()
+    for si in range(len(subsets)):
+        if o["zs"][si] is not None and masks is None:
+            arrays[f"z/{si}"] = o["zs"][si].detach()
+            arrays[f"sub_mu/{si}"] = o["subs"][si][0].detach()
+            arrays[f"sub_lv/{si}"] = o["subs"][si][1].detach()
+    if masks is not None:
+        for m, v in masks.items():
+            arrays["mask/" + m] = v
+    arrays.update(grad_stats(gref))
+    if nll_K:
+        torch.manual_seed(seed + 1)
+        nz = torch.randn(nll_K, B, L)
+        torch.manual_seed(seed + 1)
+        nll = model.compute_joint_nll(inputs, K=nll_K, batch_size_K=4)
+        with torch.no_grad():
+            e2 = {m: enc_f[m](tdata[m]) for m in names}
+            on = elbo.mvae_joint_nll(e2, tdata, dec_f, nz, names=names, dists=dists, batch_size_K=4)
+        report("nll", nll, on[0])
+        arrays.update(nll_noise=nz, nll=torch.as_tensor(nll).detach(), nll_ll=on[1])
+    save(name, dict(model="MVAE", arch=arch, B=B, L=L, beta=beta, warmup=warmup, epoch=epoch, batch_ratio=batch_ratio,
+                    rescaling=rescaling, masked=masked, seed=seed, names=names, k=k, subsampling=subsampling,
+                    dists=dists, random_idx=random_idx, subsets=subsets, nll_K=nll_K), arrays)
+
+
+def mvae_main():
+    mvae_case("mvae_tiny_subsampling_k2", arch="tiny", B=6, beta=1.0, warmup=10, epoch=3, batch_ratio=0.25,
+              rescaling=False, masked=False, seed=801, k=2, nll_K=9)
+    mvae_case("mvae_tiny_joint_only_rescale", arch="tiny", B=5, beta=2.5, warmup=4, epoch=7, batch_ratio=0.5,
+              rescaling=True, masked=False, seed=802, subsampling=False,
+              dists=dict(mod1="normal", mod2="laplace", mod3="bernoulli", mod4="normal"))
+    mvae_case("mvae_tiny_masked", arch="tiny", B=9, beta=1.5, warmup=10, epoch=20, batch_ratio=0.0, rescaling=False,
+              masked=True, seed=803, k=1)
+    mvae_case("mvae_tiny_masked_joint_only", arch="tiny", B=8, beta=1.0, warmup=10, epoch=2, batch_ratio=0.75,
+              rescaling=True, masked=True, seed=804, subsampling=False)
+    mvae_case("mvae_mnistsvhn", arch="mnistsvhn", B=8, beta=1.0, warmup=10, epoch=12, batch_ratio=0.0, rescaling=False,
+              masked=False, seed=805, nll_K=6)
+
+
 def nll_case(name, *, kind, arch, B, K, batch_size_K, seed, dists=None, family="normal", subset=None):
     """compute_joint_nll of the reference (K importance samples per data point, chunks of batch_size_K) against
     oracle.elbo.*_joint_nll on the replayed noise.  Stores the noise, the reference's NLL and the oracle's per-point
@@ -837,9 +944,12 @@ if __name__ == "__main__":
         resnet_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "nll":
         nll_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "mvae":
+        mvae_main()
     else:
         main()
         jmvae_main()
         mmvaeplus_main()
         resnet_main()
         nll_main()
+        mvae_main()

@@ -28,6 +28,8 @@ MMVAE_CASES = ["mmvae_tiny_normal_iwae", "mmvae_tiny_laplace_dreg", "mmvae_tiny_
                "mmvae_mnistsvhn_normal_iwae_k10"]
 NLL_CASES = ["nll_mopoe_tiny", "nll_mopoe_mnistsvhn", "nll_mopoe_tiny_subset", "nll_mopoe_mnistsvhn_paper", "nll_mvtcae_tiny", "nll_jmvae_tiny", "nll_mmvae_tiny_normal",
              "nll_mmvae_tiny_laplace", "nll_mmvae_mnistsvhn_laplace"]
+MVAE_CASES = ["mvae_tiny_subsampling_k2", "mvae_tiny_joint_only_rescale", "mvae_tiny_masked",
+              "mvae_tiny_masked_joint_only", "mvae_mnistsvhn"]
 NLL_MMVAEPLUS_CASES = ["nll_mmvaeplus_tiny_laplace", "nll_mmvaeplus_tiny_softplus"]
 
 

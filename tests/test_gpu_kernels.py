@@ -702,3 +702,98 @@ def test_iwae_entry_points_reject_bad_arguments(K):
         K.iwae_logw(z, [], loc, loc)  # more than MVK_IWAE_MAX_EXPERTS experts
     with pytest.raises(MvkError):
         K.iwae_reduce([torch.zeros(2, 3, device=d)] * 9)  # more than MVK_MAX_MODALITIES arrays
+
+
+@pytest.mark.parametrize("M,B,L,bits,masked", [(2, 7, 5, [3, 1, 2], False), (4, 9, 20, [15, 1, 2, 4, 8, 6, 13], True),
+                                               (3, 5, 70, [7], False), (8, 3, 4, [255, 128, 129], True)])
+def test_mvae_posterior(K, M, B, L, bits, masked):
+    """mvk_mvae_posterior_fwd/bwd against stable_poe (+ prior expert, +inf log-variance for missing rows), rsample
+    and the closed-form KL of the oracle, with autograd gradients; z lands in every member modality's slab."""
+    gen = g(41)
+    S = len(bits)
+    mus = [torch.randn(B, L, generator=gen) for _ in range(M)]
+    lvs = [torch.randn(B, L, generator=gen) * 0.7 for _ in range(M)]
+    eps = torch.randn(S, B, L, generator=gen)
+    masks = None
+    if masked:
+        masks = [torch.rand(B, generator=gen) > 0.4 for _ in range(M)]
+        masks[0][:] = True
+        masks[-1][0] = False
+    gz = [torch.randn(sum((b >> m) & 1 for b in bits), B, L, generator=gen) for m in range(M)]
+    gk = torch.randn(S, B, generator=gen)
+    # --- reference formulas
+    rm = [t.clone().requires_grad_() for t in mus]
+    rl = [t.clone().requires_grad_() for t in lvs]
+    total = 0
+    zs_ref, klds, stats = [], [], []
+    slot = [0] * M
+    for si, bt in enumerate(bits):
+        ms, ls = [], []
+        for m in range(M):
+            if (bt >> m) & 1:
+                lv = rl[m]
+                if masks is not None:
+                    lv = torch.where(masks[m].unsqueeze(1), lv, torch.full_like(lv, float("inf")))
+                ms.append(rm[m])
+                ls.append(lv)
+        ms.append(torch.zeros(B, L))
+        ls.append(torch.zeros(B, L))
+        mu_s, lv_s = elbo.stable_poe(torch.stack(ms), torch.stack(ls))
+        z = elbo.rsample(mu_s, lv_s, eps[si])
+        kld = -0.5 * (1 + lv_s - mu_s.pow(2) - lv_s.exp()).sum(-1)
+        zs_ref.append(z)
+        klds.append(kld)
+        stats.append((mu_s, lv_s))
+        total = total + (kld * gk[si]).sum()
+        for m in range(M):
+            if (bt >> m) & 1:
+                total = total + (z * gz[m][slot[m]]).sum()
+                slot[m] += 1
+    total.backward()
+    # --- kernels
+    d = dev()
+    dm = [t.to(d).requires_grad_() for t in mus]
+    dl = [t.to(d).requires_grad_() for t in lvs]
+    dmasks = None if masks is None else [t.to(d) for t in masks]
+    outs = K.MVAEPosteriorFn.apply(eps.to(d), dmasks, bits, True, *dm, *dl)
+    nz = sum(1 for m in range(M) if any((b >> m) & 1 for b in bits))
+    zm, kld, smu, slv = outs[:nz], outs[nz], outs[nz + 1], outs[nz + 2]
+    slot = [0] * M
+    present = [m for m in range(M) if any((b >> m) & 1 for b in bits)]
+    for si, bt in enumerate(bits):
+        close(kld[si], klds[si], what=f"kld {si}")
+        close(smu[si], stats[si][0], what=f"mu {si}")
+        close(slv[si], stats[si][1], what=f"lv {si}")
+        for m in range(M):
+            if (bt >> m) & 1:
+                close(zm[present.index(m)][slot[m]], zs_ref[si], what=f"z {si} in slab of modality {m}")
+                slot[m] += 1
+    loss = (kld * gk.to(d)).sum()
+    for i, m in enumerate(present):
+        loss = loss + (zm[i] * gz[m].to(d)).sum()
+    loss.backward()
+    for m in range(M):
+        if m in present:
+            close(dm[m].grad, rm[m].grad, what=f"dmu {m}")
+            close(dl[m].grad, rl[m].grad, what=f"dlv {m}")
+        else:
+            assert float(dm[m].grad.abs().max()) == 0.0
+
+
+def test_reduce_terms_handles_more_than_sixteen_terms(K):
+    """mvk_reduce_terms with MVK_MAX_TERMS = 64 terms (MVAE: one per (modality, subset) pair plus the KL rows)."""
+    from multivae_amd._lib import TermDesc, call, ptr, stream_ptr
+
+    d = dev()
+    n = 40
+    vals = [torch.arange(i + 1, dtype=torch.float32, device=d) for i in range(n)]
+    terms = (TermDesc * n)()
+    for i, t in enumerate(terms):
+        t.v, t.n, t.mask, t.period, t.coef, t.lossw = vals[i].data_ptr(), i + 1, None, 1, 0.5, 2.0
+    out = torch.empty(n + 2, device=d)
+    loss = torch.empty((), device=d)
+    call("mvk_reduce_terms", terms, n, 3.0, ptr(out), ptr(loss), stream_ptr())
+    exp = torch.tensor([0.5 * i * (i + 1) / 2 for i in range(n)])
+    close(out[:n], exp, rtol=1e-6, what="terms")
+    close(loss, 2.0 * exp.sum(), rtol=1e-6, what="loss")
+    close(out[n + 1], 6.0 * exp.sum(), rtol=1e-6, what="loss_sum")

@@ -162,13 +162,13 @@ def test_graph_replay_matches_eager():
     _same_training(_run_steps(d, 5, graphed=False), _run_steps(d, 5, graphed=True))
 
 
-@pytest.mark.parametrize("model_name", ["MoPoE", "JMVAE"])
+@pytest.mark.parametrize("model_name", ["MoPoE", "JMVAE", "MVAE"])
 def test_trainer_with_hip_graph(tmp_path, model_name):
     """BaseTrainerConfig.use_hip_graph: every batch shape gets one captured graph (the full batches and the short last
     one; fresh noise on every replay through the registered default generator), JMVAE re-captures while its annealing
     factor changes.  The loss goes down like in the eager run of the same seed."""
     from multivae_amd.data.datasets.base import MultimodalBaseDataset
-    from multivae_amd.models import JMVAE, JMVAEConfig, MoPoE, MoPoEConfig
+    from multivae_amd.models import JMVAE, MVAE, JMVAEConfig, MoPoE, MoPoEConfig, MVAEConfig
     from multivae_amd.trainers import BaseTrainer, BaseTrainerConfig
 
     def run(use_graph):
@@ -178,6 +178,8 @@ def test_trainer_with_hip_graph(tmp_path, model_name):
         dims = dict(a=(1, 28, 28), b=(40,))
         if model_name == "MoPoE":
             model = MoPoE(MoPoEConfig(n_modalities=2, latent_dim=12, input_dims=dims))
+        elif model_name == "MVAE":  # epoch 1: the KL weight changes every batch -> eager (graph_key is False)
+            model = MVAE(MVAEConfig(n_modalities=2, latent_dim=12, input_dims=dims, warmup=2))
         else:
             model = JMVAE(JMVAEConfig(n_modalities=2, latent_dim=12, input_dims=dims, warmup=2))
         cfg = BaseTrainerConfig(output_dir=str(tmp_path), per_device_train_batch_size=64, num_epochs=4,
@@ -189,7 +191,7 @@ def test_trainer_with_hip_graph(tmp_path, model_name):
     eager, _ = run(False)
     graphed, tr = run(True)
     graphs = [g for g in tr._graphs.values() if g is not None]
-    assert len(graphs) == (2 if model_name == "MoPoE" else 4), tr._graphs.keys()  # JMVAE: x2 for epochs 1 and >= 2
+    assert len(graphs) == (4 if model_name == "JMVAE" else 2), tr._graphs.keys()  # JMVAE: x2 for epochs 1 and >= 2
     assert all(np.isfinite(v) for v in graphed) and graphed[-1] < graphed[0]
     for a, b in zip(eager, graphed):  # same data order and initial weights, different noise stream
         assert abs(a - b) <= 0.05 * abs(a), (eager, graphed)

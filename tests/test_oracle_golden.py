@@ -202,6 +202,38 @@ def test_joint_nll_mmvaeplus(name):
     close(a["ll"], ll, rtol=1e-6)
 
 
+def oracle_mvae(cfg, a, dims, data, masks, enc_f, dec_f):
+    names = cfg["names"]
+    e = {m: enc_f[m](data[m]) for m in names}
+    beta = elbo.mvae_annealing(cfg["epoch"], cfg["batch_ratio"], cfg["warmup"], cfg["beta"])
+    return elbo.mvae_forward(e, data, dec_f, G.t(a["eps"]), names=names, subsets=cfg["subsets"], beta=beta,
+                             rescale=elbo.rescale_factors(dims, cfg["rescaling"]), dists=cfg.get("dists"), masks=masks)
+
+
+@pytest.mark.parametrize("name", G.MVAE_CASES)
+def test_mvae(name):
+    """MVAE.forward (mvae_model.py:145-228): joint / unimodal / random subsets, annealing, incomplete data, and
+    compute_joint_nll (:266-340) where the case holds one."""
+    cfg, a, dims, data, masks, sd, enc_f, dec_f = _prep(name)
+    assert cfg["subsets"] == elbo.mvae_subsets(cfg["names"], cfg["subsampling"], cfg["subsets"][1 + len(cfg["names"]):]
+                                               if cfg["subsampling"] else ())
+    o = oracle_mvae(cfg, a, dims, data, masks, enc_f, dec_f)
+    close(a["loss"], o["loss"])
+    close(a["loss_sum"], torch.as_tensor(o["loss_sum"]))
+    assert {k[7:] for k in a if k.startswith("metric/")} == set(o["metrics"])
+    for k, v in o["metrics"].items():
+        close(a["metric/" + k], torch.as_tensor(v))
+    o["loss"].backward()
+    G.check_grads(a, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()}, rtol=1e-5)
+    if cfg["nll_K"]:
+        with torch.no_grad():
+            e = {m: enc_f[m](data[m]) for m in cfg["names"]}
+            nll, ll, _ = elbo.mvae_joint_nll(e, data, dec_f, G.t(a["nll_noise"]), names=cfg["names"],
+                                             dists=cfg.get("dists"), batch_size_K=4)
+        close(a["nll"], nll, rtol=1e-6)
+        close(a["nll_ll"], ll, rtol=1e-6)
+
+
 def mmvaeplus_noise(a, mods):
     return {c: {k.split("/")[2]: G.t(v) for k, v in a.items() if k.startswith(f"noise/{c}/")} for c in mods}
 
