@@ -36,6 +36,7 @@ extern "C" {
 #define MVK_DIST_NORMAL 0
 #define MVK_DIST_LAPLACE 1
 #define MVK_DIST_BERNOULLI 2
+#define MVK_DIST_CATEGORICAL 3 /* x * log_softmax(recon + 1e-6) over the last dimension (base_utils.py:28-57) */
 
 /* activations fused into GEMM/conv epilogues */
 #define MVK_ACT_NONE 0
@@ -95,6 +96,15 @@ int mvk_mvtcae_posterior_bwd(const float* const* mu, const float* const* lv, con
                              const float* gjoint_rows, const float* gcond_rows, float* const* dmu,
                              float* const* dlv, void* stream);
 
+/* Diagonal Gaussian q = N(mu, exp(lv)): w[k,b,:] = mu[b,:] + exp(lv[b,:] / 2) eps[k,b,:] and kl_rows[b] =
+ * -1/2 sum_l (1 - exp(lv) - mu^2 + lv) = KL(q || N(0,I)): the modality-specific ("style") latents of MoPoE
+ * (mopoe_model.py:171-178 rsample, :212-221 style_kld).  mu, lv [B,L]; eps, w [K,B,L].  bwd: dw [K,B,L] (nullable),
+ * gkl [B] (nullable) -> dmu, dlv [B,L] (overwritten). */
+int mvk_gauss_sample_kl_fwd(const float* mu, const float* lv, const float* eps, int K, int B, int L, float* w,
+                            float* kl_rows, void* stream);
+int mvk_gauss_sample_kl_bwd(const float* mu, const float* lv, const float* eps, const float* dw, const float* gkl,
+                            int K, int B, int L, float* dmu, float* dlv, void* stream);
+
 /* MVAE (models/mvae/mvae_model.py:56-118): for each of the S subsets of the objective (subset_bits: HOST array, bit m
  * = modality m), the product of the AVAILABLE experts of the subset and the N(0,I) prior in the log-sum-exp form of
  * `stable_poe` (base_utils.py:133-147; a missing modality has log-variance +inf, mvae_model.py:71-75), one sample
@@ -139,6 +149,7 @@ typedef struct mvk_recon_desc {
   float scale;          /* normal / laplace scale */
   float rescale;        /* likelihood rescaling factor (base_ae_model.py:127-152) */
   float coef;           /* constant gradient weight (e.g. 1/(B*K)) */
+  int32_t n_classes;    /* MVK_DIST_CATEGORICAL: size of the last (class) dimension, D % n_classes == 0; else ignored */
 } mvk_recon_desc;
 
 /* Per-(k,b) row NLL for up to MVK_MAX_MODALITIES modalities in ONE launch, optionally emitting

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmvk.so")
 
 MVK_OK = 0
-DIST = {"normal": 0, "laplace": 1, "bernoulli": 2}
+DIST = {"normal": 0, "laplace": 1, "bernoulli": 2, "categorical": 3}
 ACT = {None: 0, "none": 0, "relu": 1, "sigmoid": 2, "leaky_relu_0.2": 3}
 FAMILY = {"normal": 0, "laplace_with_softmax": 1, "normal_with_softplus": 2}  # 2: std kernels only (density = normal)
 MAX_MODALITIES = 8
@@ -26,7 +26,8 @@ _i64 = C.c_int64
 
 class ReconDesc(C.Structure):
     _fields_ = [("recon", _p), ("x", _p), ("mask", _p), ("rows", _p), ("drecon", _p), ("rowcoef", _p),
-                ("D", _i64), ("dist", C.c_int32), ("scale", _f), ("rescale", _f), ("coef", _f)]
+                ("D", _i64), ("dist", C.c_int32), ("scale", _f), ("rescale", _f), ("coef", _f),
+                ("n_classes", C.c_int32)]
 
 
 class PackDesc(C.Structure):  # mvk_pack_desc
@@ -96,6 +97,8 @@ PROTOTYPES = {
     "mvk_mmvaeplus_cross_latent_bwd": [_p, _p, _i64, _i, _i, _i, _p, _p, _p],
     "mvk_mvae_posterior_fwd": [_p, _p, _p, _i, _p, _i, _p, _i, _i, _p, _p, _p, _p, _p],
     "mvk_mvae_posterior_bwd": [_p, _p, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p, _p],
+    "mvk_gauss_sample_kl_fwd": [_p, _p, _p, _i, _i, _i, _p, _p, _p],
+    "mvk_gauss_sample_kl_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p],
     "mvk_iwae_sample": [_p, _p, _p, _i, _i, _i, _i, _p, _p],
     "mvk_iwae_logw": [_p, _p, _i, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p, _p],
     "mvk_iwae_reduce": [_p, _i, _i, _i, _p, _p],

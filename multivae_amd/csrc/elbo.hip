@@ -490,6 +490,55 @@ __global__ __launch_bounds__(NLL_THREADS) void recon_nll_kernel(const ReconTable
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Categorical decoder distribution (base_utils.py:28-57 `cross_entropy`): log p = x * log_softmax(r + 1e-6) over the
+// LAST dimension (n_classes), summed over the positions of the sample.  One block per (k, b); every wave walks class
+// rows (positions) of length C: max, sum-exp, then the gradient  d(-log p)/dr_c = softmax_c * sum_c' x_c' - x_c.
+// ---------------------------------------------------------------------------------------------------------
+template <bool FWD>
+__global__ __launch_bounds__(NLL_THREADS) void recon_categorical_kernel(const mvk_recon_desc d, int K, int B) {
+  const int kb = blockIdx.x;
+  const int b = kb % B;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = d.n_classes;
+  const long long P = d.D / C;
+  const float mk = d.mask ? (d.mask[b] ? 1.0f : 0.0f) : 1.0f;
+  const float gw = d.coef * d.rescale * mk * (d.rowcoef ? d.rowcoef[kb] : 1.0f);
+  const float* r0 = d.recon + (long long)kb * d.D;
+  const float* x0 = d.x + (long long)b * d.D;
+  float* g0 = d.drecon ? d.drecon + (long long)kb * d.D : nullptr;
+  float nll = 0.f;
+  for (long long p = wave; p < P; p += NLL_THREADS / 64) {
+    const float* r = r0 + p * C;
+    const float* x = x0 + p * C;
+    float mx = -INFINITY;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, r[c] + 1e-6f);
+    mx = wave_max(mx);
+    float se = 0.f, sxr = 0.f, sx = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float v = r[c] + 1e-6f;
+      se += expf(v - mx);
+      sxr += x[c] * v;
+      sx += x[c];
+    }
+    se = wave_sum(se);
+    sxr = wave_sum(sxr);
+    sx = wave_sum(sx);
+    const float lse = mx + logf(se);
+    nll += -(sxr - lse * sx);
+    if (g0) {
+      float* g = g0 + p * C;
+      for (int c = lane; c < C; c += 64) g[c] = gw * (expf(r[c] + 1e-6f - lse) * sx - x[c]);
+    }
+  }
+  if (FWD) {
+    __shared__ float red[NLL_THREADS / 64];
+    if (lane == 0) red[wave] = nll;  // every lane of a wave holds the wave's total
+    __syncthreads();
+    if (threadIdx.x == 0) d.rows[kb] = (red[0] + red[1] + red[2] + red[3]) * d.rescale;
+  }
+}
+
 static int launch_recon(const mvk_recon_desc* descs, int n_mod, int K, int B, bool fwd, hipStream_t s) {
   if (!descs || n_mod < 1 || n_mod > MAXM || K < 1 || B < 0) return MVK_EINVAL;
   if (B == 0) return MVK_OK;
@@ -498,10 +547,19 @@ static int launch_recon(const mvk_recon_desc* descs, int n_mod, int K, int B, bo
   for (int i = 0; i < n_mod; ++i) {
     const mvk_recon_desc& d = descs[i];
     if (!d.recon || !d.x || d.D <= 0 || (fwd && !d.rows) || (!fwd && !d.drecon)) return MVK_EINVAL;
-    if (d.dist < 0 || d.dist > MVK_DIST_BERNOULLI) return MVK_EINVAL;
+    if (d.dist < 0 || d.dist > MVK_DIST_CATEGORICAL) return MVK_EINVAL;
+    if (d.dist == MVK_DIST_CATEGORICAL && (d.n_classes < 1 || d.D % d.n_classes)) return MVK_EINVAL;
     if ((d.D & 3) || d.D > 4 * MAXV * NLL_THREADS || !mvk_aligned16(d.recon) || !mvk_aligned16(d.x) ||
         (d.drecon && !mvk_aligned16(d.drecon)))
       vec = false;
+  }
+  for (int i = 0; i < n_mod; ++i) {  // categorical terms: class-row kernel, one launch per term
+    if (descs[i].dist != MVK_DIST_CATEGORICAL) continue;
+    if (fwd)
+      hipLaunchKernelGGL((recon_categorical_kernel<true>), dim3(K * B), dim3(NLL_THREADS), 0, s, descs[i], K, B);
+    else
+      hipLaunchKernelGGL((recon_categorical_kernel<false>), dim3(K * B), dim3(NLL_THREADS), 0, s, descs[i], K, B);
+    MVK_CHECK_LAUNCH();
   }
   // launch per vectorisability group so that a tiny modality does not de-vectorise a large one
   for (int pass = 0; pass < 2; ++pass) {
@@ -510,6 +568,7 @@ static int launch_recon(const mvk_recon_desc* descs, int n_mod, int K, int B, bo
     int blocks = 0;
     for (int i = 0; i < n_mod; ++i) {
       const mvk_recon_desc& d = descs[i];
+      if (d.dist == MVK_DIST_CATEGORICAL) continue;
       bool v = !((d.D & 3) || d.D > 4 * MAXV * NLL_THREADS || !mvk_aligned16(d.recon) || !mvk_aligned16(d.x) ||
                  (d.drecon && !mvk_aligned16(d.drecon)));
       if ((pass == 0) != v) continue;
@@ -762,6 +821,57 @@ __global__ __launch_bounds__(256) void mvae_posterior_bwd_kernel(const PtrTable 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Diagonal Gaussian: K reparameterised samples and the KL to N(0, I) per row (the modality-specific "style" latents of
+// MoPoE, mopoe_model.py:171-178 and :212-221).  One wave per row.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gauss_sample_kl_fwd_kernel(const float* __restrict__ mu,
+                                                                  const float* __restrict__ lv,
+                                                                  const float* __restrict__ eps, int K, int B, int L,
+                                                                  float* __restrict__ w, float* __restrict__ kl_rows) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float kl = 0.f;
+  for (int l = lane; l < L; l += 64) {
+    const long long o = (long long)b * L + l;
+    const float m = mu[o], v = lv[o];
+    kl += -0.5f * (1.0f - expf(v) - m * m + v);
+    const float sd = expf(0.5f * v);
+    for (int k = 0; k < K; ++k) {
+      const long long zo = ((long long)k * B + b) * L + l;
+      w[zo] = m + sd * eps[zo];
+    }
+  }
+  kl = wave_sum(kl);
+  if (lane == 0) kl_rows[b] = kl;
+}
+
+__global__ __launch_bounds__(256) void gauss_sample_kl_bwd_kernel(const float* __restrict__ mu,
+                                                                  const float* __restrict__ lv,
+                                                                  const float* __restrict__ eps,
+                                                                  const float* __restrict__ dw,
+                                                                  const float* __restrict__ gkl, int K, int B, int L,
+                                                                  float* __restrict__ dmu, float* __restrict__ dlv) {
+  const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (o >= (long long)B * L) return;
+  const int b = (int)(o / L);
+  const float m = mu[o], v = lv[o];
+  const float sd = expf(0.5f * v);
+  float sdw = 0.f, sdwe = 0.f;
+  if (dw) {
+    for (int k = 0; k < K; ++k) {
+      const long long zo = (long long)k * B * L + o;
+      const float g = dw[zo];
+      sdw += g;
+      sdwe += g * eps[zo];
+    }
+  }
+  const float gk = gkl ? gkl[b] : 0.f;
+  dmu[o] = sdw + gk * m;
+  dlv[o] = 0.5f * sd * sdwe + gk * 0.5f * (expf(v) - 1.0f);
+}
+
 }  // namespace
 
 extern "C" {
@@ -913,6 +1023,27 @@ int mvk_mvae_posterior_bwd(const float* const* mu, const float* const* lv, const
   }
   hipLaunchKernelGGL(mvae_posterior_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, mvk_stream(stream), pt, ot, tb, M, S,
                      eps, B, L, gkld_rows);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_gauss_sample_kl_fwd(const float* mu, const float* lv, const float* eps, int K, int B, int L, float* w,
+                            float* kl_rows, void* stream) {
+  if (!mu || !lv || !eps || !w || !kl_rows || K < 1 || L < 1) return MVK_EINVAL;
+  if (B <= 0) return B == 0 ? MVK_OK : MVK_EINVAL;
+  hipLaunchKernelGGL(gauss_sample_kl_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, mvk_stream(stream), mu, lv, eps, K, B,
+                     L, w, kl_rows);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_gauss_sample_kl_bwd(const float* mu, const float* lv, const float* eps, const float* dw, const float* gkl,
+                            int K, int B, int L, float* dmu, float* dlv, void* stream) {
+  if (!mu || !lv || !eps || !dmu || !dlv || K < 1 || L < 1) return MVK_EINVAL;
+  if (B <= 0) return B == 0 ? MVK_OK : MVK_EINVAL;
+  const long long n = (long long)B * L;
+  hipLaunchKernelGGL(gauss_sample_kl_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, mvk_stream(stream),
+                     mu, lv, eps, dw, gkl, K, B, L, dmu, dlv);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }

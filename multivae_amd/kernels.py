@@ -915,7 +915,7 @@ class ReconLossFn(Function):
             d.rows = r.data_ptr()
             d.drecon = drecons[j].data_ptr() + off if drecons[j] is not None else None
             d.rowcoef = None
-            d.D, d.dist = D, spec["dist"][i]
+            d.D, d.dist, d.n_classes = D, spec["dist"][i], recons[j].shape[-1]
             d.scale, d.rescale = spec["scale"][i], spec["rescale"][i]
             d.coef = spec["coef"][i] * spec["lossw"][i]
         if n_rec:
@@ -977,6 +977,32 @@ class ReconLossFn(Function):
             call("mvk_loss_backward_seed", descs, len(chunk), ptr(gloss), stream_ptr())
         ctx.drecons = None
         return (None, None, *grads, *extras)
+
+
+class GaussSampleKLFn(Function):
+    """(mu, lv) [B,S], eps [K,B,S] -> w [K,B,S], kl_rows [B]  (mvk_gauss_sample_kl_fwd/bwd; MoPoE style latents)."""
+
+    @staticmethod
+    def forward(ctx, eps, mu, lv):
+        eps, mu, lv = _c(eps), _c(mu), _c(lv)
+        K, B, L = eps.shape
+        w = torch.empty_like(eps)
+        kl = _new((B,), eps)
+        call("mvk_gauss_sample_kl_fwd", ptr(mu), ptr(lv), ptr(eps), K, B, L, ptr(w), ptr(kl), stream_ptr())
+        ctx.save_for_backward(eps, mu, lv)
+        return w, kl
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dw, dkl):
+        eps, mu, lv = ctx.saved_tensors
+        K, B, L = eps.shape
+        dw = _c(dw) if dw is not None else None
+        dkl = _c(dkl) if dkl is not None else None
+        dmu, dlv = torch.empty_like(mu), torch.empty_like(lv)
+        call("mvk_gauss_sample_kl_bwd", ptr(mu), ptr(lv), ptr(eps), ptr(dw), ptr(dkl), K, B, L, ptr(dmu), ptr(dlv),
+             stream_ptr())
+        return None, dmu, dlv
 
 
 class MVAEPosteriorFn(Function):
@@ -1169,7 +1195,7 @@ class MMVAEObjectiveFn(Function):
                 t = recons[c * M + r]
                 d.recon, d.x = t.data_ptr(), spec["x"][r].data_ptr()
                 d.mask, d.rows, d.drecon, d.rowcoef = None, rr.data_ptr(), None, None
-                d.D, d.dist = t.numel() // (K * B), spec["dist"][r]
+                d.D, d.dist, d.n_classes = t.numel() // (K * B), spec["dist"][r], t.shape[-1]
                 d.scale, d.rescale, d.coef = spec["scale"][r], spec["rescale"][r], 1.0
             call("mvk_recon_nll_fwd", descs, M, K, B, stream_ptr())
         state.lw = [_new((K, B), ref) for _ in range(M)]
@@ -1205,7 +1231,7 @@ class MMVAEObjectiveFn(Function):
                 d.recon, d.x = t.data_ptr(), spec["x"][r].data_ptr()
                 d.mask = mk.data_ptr() if mk is not None else None
                 d.rows, d.drecon, d.rowcoef = None, g.data_ptr(), st.rowcoef[c].data_ptr()
-                d.D, d.dist = t.numel() // (K * B), spec["dist"][r]
+                d.D, d.dist, d.n_classes = t.numel() // (K * B), spec["dist"][r], t.shape[-1]
                 # lw contains +log p = -NLL, so d loss / d recon = rowcoef * (-1) * rescale * dNLL/drecon
                 d.scale, d.rescale, d.coef = spec["scale"][r], spec["rescale"][r], -1.0
             call("mvk_recon_nll_bwd", descs, M, K, B, stream_ptr())
@@ -1250,6 +1276,7 @@ def recon_nll_rows(recons, xs, dists, scales, K, B):
         d = descs[i]
         d.recon, d.x, d.mask, d.rows, d.drecon, d.rowcoef = recons[i].data_ptr(), xs[i].data_ptr(), None, r.data_ptr(), None, None
         d.D, d.dist, d.scale, d.rescale, d.coef = recons[i].numel() // (K * B), dists[i], scales[i], 1.0, 1.0
+        d.n_classes = recons[i].shape[-1]
     call("mvk_recon_nll_fwd", descs, n, K, B, stream_ptr())
     return rows
 

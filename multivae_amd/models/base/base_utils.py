@@ -9,10 +9,9 @@ from ..._output import ModelOutput  # noqa: F401  (re-exported: `multivae.models
 
 
 def decoder_dist_code(dist_name):
-    """'normal' | 'laplace' | 'bernoulli' -> MVK_DIST_*; anything else is rejected like the reference
-    (`set_decoder_dist` raises ValueError, base_utils.py:84-85).  'categorical' is not on the HIP path yet."""
+    """'normal' | 'laplace' | 'bernoulli' | 'categorical' -> MVK_DIST_*; anything else is rejected like the reference
+    (`set_decoder_dist` raises ValueError, base_utils.py:84-85).  'categorical' takes tensors: logits [..., n_classes]
+    against one-hot (or probability) targets of the same trailing shape."""
     if dist_name in _lib.DIST:
         return _lib.DIST[dist_name]
-    if dist_name == "categorical":
-        raise NotImplementedError("decoder distribution 'categorical' has no HIP kernel yet")
     raise ValueError("The distribution type 'dist' is not supported")

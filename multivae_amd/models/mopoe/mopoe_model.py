@@ -21,8 +21,6 @@ class MoPoE(BaseMultiVAE):
     def __init__(self, model_config: MoPoEConfig, encoders: dict = None, decoders: dict = None):
         super().__init__(model_config, encoders, decoders)
         self.multiple_latent_spaces = model_config.modalities_specific_dim is not None
-        if self.multiple_latent_spaces:
-            raise NotImplementedError("modalities_specific_dim (private latent spaces) is not on the HIP path yet")
         self.model_name = "MoPoE"
         list_subsets = self.model_config.subsets
         if isinstance(list_subsets, dict):
@@ -31,6 +29,18 @@ class MoPoE(BaseMultiVAE):
             list_subsets = self.all_subsets()
         self.set_subsets(list_subsets)
         self._sel_cache = {}
+        if self.multiple_latent_spaces:  # default multi-latent MLPs (mopoe_model.py:58-75)
+            from ..nn.default_architectures import BaseDictDecodersMultiLatents, BaseDictEncoders_MultiLatents
+
+            self.style_dims = model_config.modalities_specific_dim
+            if encoders is None:
+                self.set_encoders(BaseDictEncoders_MultiLatents(input_dims=model_config.input_dims,
+                                                                latent_dim=model_config.latent_dim,
+                                                                modality_dims=model_config.modalities_specific_dim))
+            if decoders is None:
+                self.set_decoders(BaseDictDecodersMultiLatents(input_dims=model_config.input_dims,
+                                                               latent_dim=model_config.latent_dim,
+                                                               modality_dims=model_config.modalities_specific_dim))
 
     # -- subsets ---------------------------------------------------------------------------------------
     def all_subsets(self):
@@ -121,22 +131,57 @@ class MoPoE(BaseMultiVAE):
         noise = kwargs.pop("noise", None)
         if noise is not None and noise.dim() == 2:
             noise = noise.unsqueeze(0)
-        _, outs, (B, L, device, _) = self._posterior(inputs, K, noise=noise, choice=kwargs.pop("choice", None))
+        style_noise = kwargs.pop("style_noise", None)  # {modality: [K,B,S_m]} (drawn after the shared noise, in encoder order)
+        enc, outs, (B, L, device, _) = self._posterior(inputs, K, noise=noise, choice=kwargs.pop("choice", None))
         z, kld_rows = outs[0], outs[1]
         names = list(self.encoders.keys())
         z_in = z[0] if K == 1 else z  # K == 1: decoders see [B,L] exactly like the reference
-        rec = kernels.run_branches(self._branch_order(inputs), lambda m: self.decoders[m](z_in).reconstruction, device)
-        recons = [rec[m] for m in names]
         masks = inputs.masks if hasattr(inputs, "masks") else None
+        style_kl = []
+        if self.multiple_latent_spaces:  # z_m = [shared, style_m], style_m ~ q(w_m | x_m)  (mopoe_model.py:171-178)
+            z_ins = {}
+            for m in names:
+                try:
+                    smu, slv = enc[m].style_embedding, enc[m].style_log_covariance
+                except (AttributeError, KeyError):
+                    raise AttributeError(" model_config.modality_specific_dims is not None, but encoder output for "
+                                         f"modality {m} doesn't have a style_embedding attribute. When using multiple "
+                                         "latent spaces, the encoders' output should be of the form : ModelOuput("
+                                         "embedding = ...,style_embedding = ...,log_covariance = ..., "
+                                         "style_log_covariance = ...)")
+                if smu.dim() == 1:
+                    smu, slv = smu.unsqueeze(0), slv.unsqueeze(0)
+                sn = None if style_noise is None else style_noise[m]
+                if sn is not None and sn.dim() == 2:
+                    sn = sn.unsqueeze(0)
+                w, kl = kernels.GaussSampleKLFn.apply(self._noise((K, B, smu.shape[-1]), device, sn), smu, slv)
+                style_kl.append(kl)
+                zw = torch.cat([z, w], dim=-1)
+                z_ins[m] = zw[0] if K == 1 else zw
+            decode = lambda m: self.decoders[m](z_ins[m]).reconstruction
+        else:
+            decode = lambda m: self.decoders[m](z_in).reconstruction
+        rec = kernels.run_branches(self._branch_order(inputs), decode, device)
+        recons = [rec[m] for m in names]
         spec = self._recon_spec(names, inputs.data, masks, K, B)
         M = len(names)
-        spec.update(coef=[1.0 / (K * B)] * M, lossw=[1.0] * M, extra_coef=[1.0 / B],
-                    extra_lossw=[float(self.model_config.beta)], loss_sum_scale=float(B))
-        loss, terms = kernels.ReconLossFn.apply(spec, M, *recons, kld_rows)
-        metrics = {"joint_divergence": terms[M]}
+        beta = float(self.model_config.beta)
+        spec.update(coef=[1.0 / (K * B)] * M, lossw=[1.0] * M, extra_coef=[1.0 / B] * (1 + len(style_kl)),
+                    extra_lossw=[beta] + [beta * float(self.model_config.beta_style)] * len(style_kl),
+                    loss_sum_scale=float(B))
+        if style_kl and masks is not None:  # style_kld *= mask (:217-218), still averaged over the whole batch
+            style_kl = [kl * masks[m].to(kl.dtype) for kl, m in zip(style_kl, names)]
+        loss, terms = kernels.ReconLossFn.apply(spec, M, *recons, kld_rows, *style_kl)
+        jd = terms[M]
+        if style_kl:
+            # `kld = results["joint_divergence"]` is updated in place by `kld += style_kld.mean() * beta_style`
+            # (:164, :221): the reference's metric includes the style terms
+            jd = jd + float(self.model_config.beta_style) * terms[M + 1:M + 1 + len(style_kl)].sum()
+        metrics = {"joint_divergence": jd}
         for i, m in enumerate(names):
             metrics["recon_" + m] = terms[i]
-        return ModelOutput(loss=loss, loss_sum=terms[M + 2], metrics=metrics)
+        n_terms = M + 1 + len(style_kl)
+        return ModelOutput(loss=loss, loss_sum=terms[n_terms + 1], metrics=metrics)
 
     def inference(self, inputs, **kwargs):
         """Subset and joint posterior parameters (:274-350).  Returns the same dict layout as the reference."""
@@ -161,6 +206,8 @@ class MoPoE(BaseMultiVAE):
         self.eval()
         if hasattr(inputs, "masks"):
             raise AttributeError(self._NLL_INCOMPLETE)
+        if self.multiple_latent_spaces:
+            raise NotImplementedError("compute_joint_nll with modality-specific latent spaces is not on the HIP path yet")
         with torch.no_grad():
             _, outs, _ = self._posterior(inputs, int(K), noise=kwargs.get("noise"), want_stats=True)
             z, mus, lvs = outs[0], outs[2], outs[3]

@@ -182,12 +182,16 @@ def mopoe_joint_divergence(mus, logvars, weights):
 
 
 def mopoe_forward(enc, data, decoders, eps, *, names, beta=1.0, rescale=None, dists=None,
-                  dist_scales=None, masks=None, choice=None, subsets=None):
-    """MoPoE.forward, one shared latent space.  mopoe_model.py:147-227 (Appendix A.1).
+                  dist_scales=None, masks=None, choice=None, subsets=None, style_eps=None, beta_style=1.0):
+    """MoPoE.forward.  mopoe_model.py:147-227 (Appendix A.1).
 
     eps [B,L] reproduces the reference exactly; eps [K,B,L] is the K-sample Monte-Carlo extension
     of SURVEY.md §0 D1: the reconstruction term is averaged over k, the analytic KL is unchanged.
     decoders: {name: callable(z[...,L]) -> recon[...,*D]}.
+    Modality-specific latent spaces (:171-178, :212-221): enc[m] = (mu, lv, style_mu, style_lv), style_eps[m] [B,S_m]
+    (drawn per modality inside the decoder loop, after the shared noise); the decoders see [z, w_m]; the style KLs
+    (masked, averaged over the whole batch, x beta_style) are added IN PLACE to the tensor that is also the
+    "joint_divergence" metric (:164, :221), so the metric includes them.
     """
     rescale = rescale or {m: 1.0 for m in names}
     dists = dists or {m: "normal" for m in names}
@@ -199,8 +203,14 @@ def mopoe_forward(enc, data, decoders, eps, *, names, beta=1.0, rescale=None, di
     metrics = {"joint_divergence": kld}
     rows = {}
     loss = 0
+    ws = {}
     for m in names:
-        recon = decoders[m](z)
+        z_m = z
+        if style_eps is not None:
+            smu, slv = enc[m][2], enc[m][3]
+            ws[m] = rsample(smu, slv, style_eps[m])
+            z_m = torch.cat([z.expand(*ws[m].shape[:-1], z.shape[-1]) if z.dim() != ws[m].dim() else z, ws[m]], dim=-1)
+        recon = decoders[m](z_m)
         r = _row_nll(dists[m], recon, data[m], rescale[m], dist_scales.get(m, 1.0))  # [B] or [K,B]
         rows[m] = r
         if r.dim() == 2:
@@ -209,8 +219,15 @@ def mopoe_forward(enc, data, decoders, eps, *, names, beta=1.0, rescale=None, di
             r = r * masks[m].to(r.dtype)
         metrics["recon_" + m] = r.mean()
         loss = loss + metrics["recon_" + m]
+        if style_eps is not None:
+            skl = -0.5 * (1 - slv.exp() - smu.pow(2) + slv).reshape(smu.size(0), -1).sum(-1)
+            if masks is not None:
+                skl = skl * masks[m].to(skl.dtype)
+            kld = kld + skl.mean() * beta_style
+    metrics["joint_divergence"] = kld
     loss = loss + beta * kld
     out = dict(inf)
+    out["ws"] = ws
     out.update(loss=loss, loss_sum=loss * B, metrics=metrics, z=z, klds=klds, rows=rows)
     return out
 

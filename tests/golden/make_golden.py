@@ -190,6 +190,8 @@ def mopoe_case(name, *, arch, B, beta, rescaling, masked, seed, K=1, dists=None)
         for m, d in (dists or {}).items():
             if d == "bernoulli":  # Bernoulli targets must be {0,1}
                 data[m] = (data[m] > 0.5).astype(np.float32)
+            if d == "categorical":  # one-hot targets over the last dimension
+                data[m] = np.eye(data[m].shape[-1], dtype=np.float32)[data[m].argmax(-1)]
         cfg = MoPoEConfig(n_modalities=4, latent_dim=L, input_dims=dict(dims), beta=beta,
                           uses_likelihood_rescaling=rescaling, decoders_dist=dists)
         model = MoPoE(cfg)
@@ -277,6 +279,11 @@ def mopoe_case(name, *, arch, B, beta, rescaling, masked, seed, K=1, dists=None)
     arrays.update(grad_stats(gref))
     save(name, dict(model="MoPoE", arch=arch, B=B, L=L, K=K, beta=beta, rescaling=rescaling, masked=masked,
                     seed=seed, names=names, dists=dists, subsets=[k for k, _ in elbo.mopoe_subsets(names)]), arrays)
+
+
+def mopoe_categorical():
+    mopoe_case("mopoe_tiny_categorical", arch="tiny", B=7, beta=1.0, rescaling=True, masked=True, seed=107,
+               dists=dict(mod1="normal", mod2="categorical", mod3="categorical", mod4="laplace"))
 
 
 def mvtcae_case(name, *, arch, B, alpha, beta, rescaling, masked, seed):
@@ -453,6 +460,7 @@ def main():
     mopoe_case("mopoe_tiny_beta_rescale", arch="tiny", B=7, beta=2.5, rescaling=True, masked=False, seed=102,
                dists=dict(mod1="normal", mod2="laplace", mod3="bernoulli", mod4="normal"))
     mopoe_case("mopoe_tiny_masked", arch="tiny", B=9, beta=1.5, rescaling=False, masked=True, seed=103)
+    mopoe_categorical()
     mopoe_case("mopoe_mnistsvhn_k1", arch="mnistsvhn", B=16, beta=1.0, rescaling=False, masked=False, seed=104)
     mopoe_case("mopoe_mnistsvhn_k1_rescale", arch="mnistsvhn", B=5, beta=1.0, rescaling=True, masked=False, seed=105)
     mopoe_case("mopoe_mnistsvhn_k10", arch="mnistsvhn", B=8, beta=1.0, rescaling=False, masked=False, seed=106, K=10)
@@ -656,6 +664,69 @@ def jmvae_main():
                seed=402, dists=dict(mod1="normal", mod2="laplace", mod3="bernoulli", mod4="normal"))
     jmvae_case("jmvae_mnistsvhn_mlp", arch="mnistsvhn", B=8, alpha=0.1, beta=1.0, warmup=10, epoch=20, rescaling=False,
                seed=403)
+
+
+def mopoe_style_case(name, *, B, beta, beta_style, S, rescaling, masked, seed):
+    """MoPoE with modality-specific latent spaces (default multi-latent MLPs), mopoe_model.py:171-178 / :212-221."""
+    print(name)
+    dims, L = TINY_DIMS, TINY_L
+    data, masks = tiny_data(B, seed, masked)
+    sdims = {m: S + i for i, m in enumerate(dims)}  # a different private dimension per modality
+    shapes = P.mopoe_style_mlp_shapes(dims, L, sdims)
+    cfg = MoPoEConfig(n_modalities=4, latent_dim=L, input_dims=dict(dims), beta=beta, beta_style=beta_style,
+                      modalities_specific_dim=sdims, uses_likelihood_rescaling=rescaling)
+    model = MoPoE(cfg)
+    sd_np = P.make_state_dict(shapes, seed)
+    load_weights(model, sd_np)
+    names = list(model.encoders.keys())
+    inputs = ref_dataset(data, masks)
+    model.train()
+    torch.manual_seed(seed)
+    choice = None
+    if masked:
+        with torch.no_grad():
+            lat = model.inference(inputs)
+        torch.manual_seed(seed)
+        choice = torch.distributions.OneHotCategorical(probs=lat["weights"].permute(1, 0)).sample()
+    eps = torch.randn(B, L)
+    style_eps = {m: torch.randn(B, sdims[m]) for m in names}
+    torch.manual_seed(seed)
+    out = model(inputs)
+    model.zero_grad()
+    out.loss.backward()
+    gref = ref_grads(model)
+    osd = oracle_sd(sd_np)
+    enc_f, dec_f = nets.build_default_mlp_multilatent(osd, dims)
+    tdata = {m: t(v) for m, v in data.items()}
+    tmasks = None if masks is None else {m: t(v) for m, v in masks.items()}
+    e = {m: enc_f[m](tdata[m]) for m in names}
+    o = elbo.mopoe_forward(e, tdata, dec_f, eps, names=names, beta=beta, rescale=elbo.rescale_factors(dims, rescaling),
+                           masks=tmasks, choice=choice, style_eps=style_eps, beta_style=beta_style)
+    o["loss"].backward()
+    report("loss", out.loss, o["loss"])
+    for k_ in out.metrics:
+        report(k_, out.metrics[k_], o["metrics"][k_])
+    cmp_grads("grads", gref, {k_: (v.grad if v.grad is not None else torch.zeros_like(v)) for k_, v in osd.items()})
+    arrays = dict(eps=eps, loss=out.loss.detach(), loss_sum=out.loss_sum.detach(), z=o["z"].detach())
+    for m in names:
+        arrays["style_eps/" + m] = style_eps[m]
+        arrays["w/" + m] = o["ws"][m].detach()
+    if choice is not None:
+        arrays["choice"] = choice
+    for k_, v in out.metrics.items():
+        arrays["metric/" + k_] = v.detach()
+    if masks is not None:
+        for m, v in masks.items():
+            arrays["mask/" + m] = v
+    arrays.update(grad_stats(gref))
+    save(name, dict(model="MoPoE", arch="tiny", B=B, L=L, K=1, beta=beta, beta_style=beta_style, style_dims=sdims,
+                    rescaling=rescaling, masked=masked, seed=seed, names=names, dists=None,
+                    subsets=[k_ for k_, _ in elbo.mopoe_subsets(names)]), arrays)
+
+
+def mopoe_style_main():
+    mopoe_style_case("mopoe_tiny_style", B=6, beta=2.5, beta_style=0.7, S=2, rescaling=True, masked=False, seed=901)
+    mopoe_style_case("mopoe_tiny_style_masked", B=9, beta=1.0, beta_style=2.0, S=3, rescaling=False, masked=True, seed=902)
 
 
 def mvae_case(name, *, arch, B, beta, warmup, epoch, batch_ratio, rescaling, masked, seed, k=0, subsampling=True,
@@ -946,6 +1017,10 @@ if __name__ == "__main__":
         nll_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "mvae":
         mvae_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "categorical":
+        mopoe_categorical()
+    elif len(sys.argv) > 1 and sys.argv[1] == "style":
+        mopoe_style_main()
     else:
         main()
         jmvae_main()
@@ -953,3 +1028,4 @@ if __name__ == "__main__":
         resnet_main()
         nll_main()
         mvae_main()
+        mopoe_style_main()

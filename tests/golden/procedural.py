@@ -145,6 +145,17 @@ def mmvaeplus_mlp_shapes(input_dims, latent_dim, style_dim):
     return s
 
 
+def mopoe_style_mlp_shapes(input_dims, latent_dim, style_dims):
+    """MoPoE with modality-specific latent spaces and default architectures (mopoe_model.py:58-75): like MMVAEPlus but
+    with one private dimension per modality (`style_dims`: {modality: dim})."""
+    s = OrderedDict()
+    for m, d in input_dims.items():
+        s.update(mlp_decoder_shapes(f"decoders.{m}.", latent_dim + style_dims[m], int(np.prod(d))))
+    for m, d in input_dims.items():
+        s.update(mlp_style_encoder_shapes(f"encoders.{m}.", int(np.prod(d)), latent_dim, style_dims[m]))
+    return s
+
+
 def resnet_block_shapes(prefix, cin, cout, chid=None):
     """ResnetBlock (mmnist.py:214-252 / cub.py:250-293): conv_layers.0, conv_layers.2 (3x3), optional 1x1 shortcut."""
     chid = min(cin, cout) if chid is None else chid

@@ -16,7 +16,8 @@ import procedural as P  # noqa: E402
 TINY_DIMS = dict(mod1=(2,), mod2=(3,), mod3=(4,), mod4=(4,))
 MNIST_SVHN_DIMS = dict(mnist=(1, 28, 28), svhn=(3, 32, 32))
 
-MOPOE_CASES = ["mopoe_tiny_complete", "mopoe_tiny_beta_rescale", "mopoe_tiny_masked", "mopoe_mnistsvhn_k1",
+MOPOE_CASES = ["mopoe_tiny_complete", "mopoe_tiny_beta_rescale", "mopoe_tiny_masked", "mopoe_tiny_categorical",
+               "mopoe_mnistsvhn_k1",
                "mopoe_mnistsvhn_k1_rescale", "mopoe_mnistsvhn_k10"]
 MVTCAE_CASES = ["mvtcae_tiny_complete", "mvtcae_tiny_masked", "mvtcae_mnistsvhn_mlp"]
 JMVAE_CASES = ["jmvae_tiny_warmup", "jmvae_tiny_beta_rescale", "jmvae_mnistsvhn_mlp"]
@@ -28,6 +29,7 @@ MMVAE_CASES = ["mmvae_tiny_normal_iwae", "mmvae_tiny_laplace_dreg", "mmvae_tiny_
                "mmvae_mnistsvhn_normal_iwae_k10"]
 NLL_CASES = ["nll_mopoe_tiny", "nll_mopoe_mnistsvhn", "nll_mopoe_tiny_subset", "nll_mopoe_mnistsvhn_paper", "nll_mvtcae_tiny", "nll_jmvae_tiny", "nll_mmvae_tiny_normal",
              "nll_mmvae_tiny_laplace", "nll_mmvae_mnistsvhn_laplace"]
+MOPOE_STYLE_CASES = ["mopoe_tiny_style", "mopoe_tiny_style_masked"]
 MVAE_CASES = ["mvae_tiny_subsampling_k2", "mvae_tiny_joint_only_rescale", "mvae_tiny_masked",
               "mvae_tiny_masked_joint_only", "mvae_mnistsvhn"]
 NLL_MMVAEPLUS_CASES = ["nll_mmvaeplus_tiny_laplace", "nll_mmvaeplus_tiny_softplus"]
@@ -65,10 +67,14 @@ def build_inputs(cfg):
         for m, d in (cfg.get("dists") or {}).items():
             if d == "bernoulli":
                 data[m] = (data[m] > 0.5).astype(np.float32)
+            if d == "categorical":
+                data[m] = np.eye(data[m].shape[-1], dtype=np.float32)[data[m].argmax(-1)]
         if cfg["model"] == "JMVAE":
             shapes = P.jmvae_mlp_shapes(dims, cfg["L"])
         elif cfg["model"] == "MMVAEPlus":
             shapes = P.mmvaeplus_mlp_shapes(dims, cfg["L"], cfg["S"])
+        elif cfg.get("style_dims"):
+            shapes = P.mopoe_style_mlp_shapes(dims, cfg["L"], cfg["style_dims"])
         else:
             shapes = P.default_mlp_shapes(dims, cfg["L"])
     else:

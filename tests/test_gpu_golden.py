@@ -40,7 +40,8 @@ def build_model(cfg, dims):
         dec = dict(mnist=Decoder_AE_MLP(BaseAEConfig(latent_dim=L, input_dim=(1, 28, 28))),
                    svhn=Decoder_VAE_SVHN(BaseAEConfig(latent_dim=L, input_dim=(3, 32, 32))))
     if cfg["model"] == "MoPoE":
-        mc = MoPoEConfig(beta=cfg["beta"], decoders_dist=cfg.get("dists"), K=cfg["K"], **common)
+        mc = MoPoEConfig(beta=cfg["beta"], decoders_dist=cfg.get("dists"), K=cfg["K"],
+                         beta_style=cfg.get("beta_style", 1.0), modalities_specific_dim=cfg.get("style_dims"), **common)
         return MoPoE(mc, enc, dec)
     if cfg["model"] == "MVAE":
         return MVAE(MVAEConfig(beta=cfg["beta"], warmup=cfg["warmup"], k=cfg["k"], use_subsampling=cfg["subsampling"],
@@ -86,7 +87,7 @@ def oracle_full_grads(cfg, dims, data, masks, sd_np, a):
     tdata = {m: G.t(v) for m, v in data.items()}
     tmasks = None if masks is None else {m: G.t(v) for m, v in masks.items()}
     names = cfg["names"]
-    if cfg["model"] == "MMVAEPlus":
+    if cfg["model"] == "MMVAEPlus" or cfg.get("style_dims"):
         enc_f, dec_f = nets.build_default_mlp_multilatent(sd, dims)
     elif cfg["arch"] == "tiny" or cfg["model"] in ("MVTCAE", "JMVAE"):
         enc_f, dec_f = nets.build_default_mlp(sd, dims)
@@ -96,8 +97,12 @@ def oracle_full_grads(cfg, dims, data, masks, sd_np, a):
     extra = {}
     if cfg["model"] == "MoPoE":
         e = {m: enc_f[m](tdata[m]) for m in names}
+        style = None
+        if cfg.get("style_dims"):
+            style = dict(style_eps={m: G.t(a["style_eps/" + m]) for m in names}, beta_style=cfg["beta_style"])
         o = elbo.mopoe_forward(e, tdata, dec_f, G.t(a["eps"]), names=names, beta=cfg["beta"], rescale=resc,
-                               dists=cfg["dists"], masks=tmasks, choice=G.t(a["choice"]) if "choice" in a else None)
+                               dists=cfg["dists"], masks=tmasks, choice=G.t(a["choice"]) if "choice" in a else None,
+                               **(style or {}))
     elif cfg["model"] == "MMVAEPlus":
         mods = [m for m in names if ("lws/" + m) in a]
         plv = {k.split("/")[1]: G.t(v).clone().requires_grad_(True) for k, v in a.items()
@@ -524,3 +529,29 @@ def test_mvae_encode_and_missing_modality_gradients():
     g = model_grads(model)
     assert all(float(v.abs().max()) == 0.0 for k, v in g.items() if k.startswith(("encoders.mod3", "decoders.mod3")))
     assert any(float(v.abs().max()) > 0.0 for k, v in g.items() if k.startswith("encoders.mod1"))
+
+
+@pytest.mark.parametrize("name", G.MOPOE_STYLE_CASES)
+def test_mopoe_style_golden(name):
+    """MoPoE with modality-specific latent spaces on the HIP path (mvk_gauss_sample_kl_fwd/bwd for the style latents)."""
+    cfg, a, dims, data, masks, sd_np, model, inputs, d = prep(name)
+    names = cfg["names"]
+    kw = dict(noise=G.t(a["eps"]).to(d), style_noise={m: G.t(a["style_eps/" + m]).to(d) for m in names})
+    if "choice" in a:
+        kw["choice"] = G.t(a["choice"]).to(d)
+    out = model(inputs, **kw)
+    check(a["loss"], out.loss, "loss")
+    check(a["loss_sum"], out.loss_sum, "loss_sum")
+    for k, v in out.metrics.items():
+        check(a["metric/" + k], v, k)
+    out.loss.backward()
+    o, og = oracle_full_grads(cfg, dims, data, masks, sd_np, a)
+    check(o["loss"].detach().numpy(), out.loss, "loss vs oracle")
+    compare_grads(model, og, a)
+    # a plain encoder (no style outputs) is rejected like in the reference (:179-188)
+    from multivae_amd.models.nn.default_architectures import Encoder_VAE_MLP
+    from multivae_amd.models.base.base_config import BaseAEConfig
+
+    model.encoders["mod1"] = Encoder_VAE_MLP(BaseAEConfig(latent_dim=cfg["L"], input_dim=(2,))).to(d)
+    with pytest.raises(AttributeError):
+        model(inputs)

@@ -797,3 +797,65 @@ def test_reduce_terms_handles_more_than_sixteen_terms(K):
     close(out[:n], exp, rtol=1e-6, what="terms")
     close(loss, 2.0 * exp.sum(), rtol=1e-6, what="loss")
     close(out[n + 1], 6.0 * exp.sum(), rtol=1e-6, what="loss_sum")
+
+
+@pytest.mark.parametrize("Kk,B,L", [(1, 7, 3), (4, 9, 70)])
+def test_gauss_sample_kl(K, Kk, B, L):
+    gen = g(51)
+    mu, lv = torch.randn(B, L, generator=gen), torch.randn(B, L, generator=gen) * 0.6
+    eps = torch.randn(Kk, B, L, generator=gen)
+    gw, gk = torch.randn(Kk, B, L, generator=gen), torch.randn(B, generator=gen)
+    rm, rl = mu.clone().requires_grad_(), lv.clone().requires_grad_()
+    w_ref = elbo.rsample(rm, rl, eps)
+    kl_ref = -0.5 * (1 - rl.exp() - rm.pow(2) + rl).sum(-1)
+    ((w_ref * gw).sum() + (kl_ref * gk).sum()).backward()
+    d = dev()
+    dm, dl = mu.to(d).requires_grad_(), lv.to(d).requires_grad_()
+    w, kl = K.GaussSampleKLFn.apply(eps.to(d), dm, dl)
+    close(w, w_ref, what="w")
+    close(kl, kl_ref, what="kl")
+    ((w * gw.to(d)).sum() + (kl * gk.to(d)).sum()).backward()
+    close(dm.grad, rm.grad, what="dmu")
+    close(dl.grad, rl.grad, what="dlv")
+
+
+@pytest.mark.parametrize("Kk,B,shape", [(1, 5, (4,)), (3, 7, (6, 10)), (2, 3, (32, 1590)), (4, 2, (3, 5, 130))])
+def test_recon_nll_categorical(Kk, B, shape):
+    """MVK_DIST_CATEGORICAL: x * log_softmax(recon + 1e-6) over the last dimension (base_utils.py:28-57), rows, fused
+    gradient and second-pass gradient; one-hot and soft targets; CUB-sentence sized rows (32 positions x 1590 words)."""
+    from multivae_amd._lib import DIST, ReconDesc, call, stream_ptr
+
+    gen = g(61 + Kk)
+    C = shape[-1]
+    D = int(np.prod(shape))
+    recon = torch.randn(Kk, B, *shape, generator=gen) * 2
+    idx = torch.randint(0, C, (B, *shape[:-1]), generator=gen)
+    x = F.one_hot(idx, C).float()
+    x[0] = torch.softmax(torch.randn(*shape, generator=gen), -1)  # a soft target row
+    mask = torch.rand(B, generator=gen) > 0.3
+    rowcoef = torch.rand(Kk, B, generator=gen)
+    rescale, coef = 1.3, 0.4
+    rr = recon.clone().requires_grad_()
+    rows_ref = elbo._row_nll("categorical", rr, x, rescale)
+    (rows_ref * rowcoef * mask.float() * coef).sum().backward()
+    d = dev()
+    rd, xd, md, rcd = recon.to(d), x.to(d), mask.to(d), rowcoef.to(d)
+    rows = torch.empty(Kk, B, device=d)
+    drecon = torch.empty_like(rd)
+    desc = (ReconDesc * 1)()
+    e = desc[0]
+    e.recon, e.x, e.mask, e.rows, e.drecon, e.rowcoef = (rd.data_ptr(), xd.data_ptr(), md.data_ptr(),
+                                                         rows.data_ptr(), drecon.data_ptr(), rcd.data_ptr())
+    e.D, e.dist, e.scale, e.rescale, e.coef, e.n_classes = D, DIST["categorical"], 1.0, rescale, coef, C
+    call("mvk_recon_nll_fwd", desc, 1, Kk, B, stream_ptr())
+    close(rows, rows_ref, what="categorical rows")
+    close(drecon, rr.grad, what="categorical drecon (fused)")
+    drecon2 = torch.zeros_like(rd)
+    e.drecon, e.rows = drecon2.data_ptr(), None
+    call("mvk_recon_nll_bwd", desc, 1, Kk, B, stream_ptr())
+    close(drecon2, rr.grad, what="categorical drecon (second pass)")
+    from multivae_amd._lib import MvkError
+
+    e.n_classes = C + 1 if D % (C + 1) else 0
+    with pytest.raises(MvkError):
+        call("mvk_recon_nll_bwd", desc, 1, Kk, B, stream_ptr())

@@ -42,7 +42,7 @@ def test_unit_base_utils():
 
 
 def _oracle_nets(cfg, dims, sd):
-    if cfg["model"] == "MMVAEPlus":
+    if cfg["model"] == "MMVAEPlus" or cfg.get("style_dims"):
         return nets.build_default_mlp_multilatent(sd, dims)
     if cfg["arch"] == "tiny" or cfg["model"] in ("MVTCAE", "JMVAE"):
         return nets.build_default_mlp(sd, dims)
@@ -200,6 +200,27 @@ def test_joint_nll_mmvaeplus(name):
                                            family=cfg["family"], prior_logvars=plv)
     close(a["nll"], nll, rtol=1e-6)
     close(a["ll"], ll, rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", G.MOPOE_STYLE_CASES)
+def test_mopoe_style(name):
+    """MoPoE with modality-specific latent spaces (mopoe_model.py:171-178, :212-221): [shared, style] decoder inputs,
+    masked style KLs x beta_style, and the joint_divergence metric that includes them."""
+    cfg, a, dims, data, masks, sd, enc_f, dec_f = _prep(name)
+    names = cfg["names"]
+    e = {m: enc_f[m](data[m]) for m in names}
+    o = elbo.mopoe_forward(e, data, dec_f, G.t(a["eps"]), names=names, beta=cfg["beta"],
+                           rescale=elbo.rescale_factors(dims, cfg["rescaling"]), masks=masks,
+                           choice=G.t(a["choice"]) if "choice" in a else None,
+                           style_eps={m: G.t(a["style_eps/" + m]) for m in names}, beta_style=cfg["beta_style"])
+    close(a["loss"], o["loss"])
+    close(a["loss_sum"], o["loss_sum"])
+    for k, v in o["metrics"].items():
+        close(a["metric/" + k], v)
+    for m in names:
+        close(a["w/" + m], o["ws"][m])
+    o["loss"].backward()
+    G.check_grads(a, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()}, rtol=1e-5)
 
 
 def oracle_mvae(cfg, a, dims, data, masks, enc_f, dec_f):
