@@ -318,9 +318,9 @@ __global__ __launch_bounds__(256) void mvtcae_posterior_bwd_kernel(const PtrTabl
 // algorithmic bytes = 4*B*D*(2K+1) per modality (read recon, write d_recon, read x once).
 // One block = one batch row b and a chunk of KC samples; x[b,:] lives in registers across the chunk.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int KC = 8;          // samples per block
+constexpr int KC = 16;         // max samples per block (LDS partial sums)
 constexpr int NLL_THREADS = 256;
-constexpr int MAXV = 4;        // float4 per thread held for x -> D <= 4096 on the vector path
+constexpr int NLL_NV = 3;      // float4 per thread and column tile on the long-row vector path (SVHN: 3072 = 3 * 1024)
 
 struct ReconTable {
   mvk_recon_desc d[MAXM];
@@ -353,43 +353,46 @@ __device__ __forceinline__ float nll_row_const(int dist, float scale, long long 
   return 0.f;
 }
 
-// Vector path of one block: row b, samples k0 .. k0+kn-1.  x[b,:] stays in registers; the 16-byte loads of sample k+1
-// are issued before the arithmetic of sample k (two register stages), so every thread keeps 2 * ceil(D/1024) loads in
-// flight.  Loads are unconditional (lanes past the row end re-read element 0 and are masked in the arithmetic): a
-// predicated HIP float4 load is scalarised into four branchy dword loads.
+// Vector path of one block: row b, samples k0 .. k0+kn-1.  The row is walked in column tiles of NV * 256 float4; the
+// x tile stays in registers while the tile of every sample streams past it, and the 16-byte loads of sample k+1 are
+// issued before the arithmetic of sample k (two register stages).  NV is a compile-time constant per launch group
+// (1: rows up to 1024 values, 3: longer rows -- SVHN's 3072 values are exactly one tile), so there are no dummy loads
+// and the register count stays low enough for 8 waves per SIMD; partial sums go to LDS per (sample, wave), so the
+// sample loop is a plain loop.  Loads are unconditional (lanes past the row end re-read element 0 and are masked in
+// the arithmetic): a predicated HIP float4 load is scalarised into four branchy dword loads.
 typedef float nll_f32x4 __attribute__((ext_vector_type(4)));
 
-template <int DIST>
+template <int DIST, int NV>
 __device__ __forceinline__ void recon_vec_body(const mvk_recon_desc& d, int B, int b, int k0, int kn, float gbase,
                                                float inv_s, float inv_s2, const float* __restrict__ xrow,
-                                               float (&part)[KC]) {
+                                               float (*red)[NLL_THREADS / 64]) {
   const long long D = d.D;
   const int nv = (int)(D >> 2);
-  nll_f32x4 xv[MAXV], cur[MAXV], nxt[MAXV];
-  bool live[MAXV];
-  int off[MAXV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t0 = 0; t0 < nv; t0 += NV * NLL_THREADS) {
+    nll_f32x4 xv[NV], cur[NV], nxt[NV];
+    bool live[NV];
+    int off[NV];
 #pragma unroll
-  for (int j = 0; j < MAXV; ++j) {
-    const int idx = threadIdx.x + j * NLL_THREADS;
-    live[j] = idx < nv;
-    off[j] = live[j] ? idx : 0;
-    xv[j] = reinterpret_cast<const nll_f32x4*>(xrow)[off[j]];
-  }
-  auto load_sample = [&](int k, nll_f32x4 (&dst)[MAXV]) __attribute__((always_inline)) {
-    const nll_f32x4* rp = reinterpret_cast<const nll_f32x4*>(d.recon + ((long long)(k0 + k) * B + b) * D);
+    for (int j = 0; j < NV; ++j) {
+      const int idx = t0 + threadIdx.x + j * NLL_THREADS;
+      live[j] = idx < nv;
+      off[j] = live[j] ? idx : 0;
+      xv[j] = reinterpret_cast<const nll_f32x4*>(xrow)[off[j]];
+    }
+    auto load_sample = [&](int k, nll_f32x4 (&dst)[NV]) __attribute__((always_inline)) {
+      const nll_f32x4* rp = reinterpret_cast<const nll_f32x4*>(d.recon + ((long long)(k0 + k) * B + b) * D);
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j) dst[j] = __builtin_nontemporal_load(rp + off[j]);  // streamed once
-  };
-  load_sample(0, cur);
-#pragma unroll
-  for (int k = 0; k < KC; ++k) {
-    if (k < kn) {
+      for (int j = 0; j < NV; ++j) dst[j] = __builtin_nontemporal_load(rp + off[j]);  // streamed once (plain loads: +1 us in the step)
+    };
+    load_sample(0, cur);
+    for (int k = 0; k < kn; ++k) {
       if (k + 1 < kn) load_sample(k + 1, nxt);
       nll_f32x4* gp = d.drecon ? reinterpret_cast<nll_f32x4*>(d.drecon + ((long long)(k0 + k) * B + b) * D) : nullptr;
       const float gw = gbase * (d.rowcoef ? d.rowcoef[(long long)(k0 + k) * B + b] : 1.0f);
       float acc = 0.f;
 #pragma unroll
-      for (int j = 0; j < MAXV; ++j) {
+      for (int j = 0; j < NV; ++j) {
         nll_f32x4 gr;
         float n0, n1, n2, n3, g0, g1, g2, g3;
         nll_elem(DIST, inv_s, inv_s2, cur[j][0], xv[j][0], n0, g0);
@@ -401,22 +404,24 @@ __device__ __forceinline__ void recon_vec_body(const mvk_recon_desc& d, int B, i
         gr[1] = g1 * gw;
         gr[2] = g2 * gw;
         gr[3] = g3 * gw;
-        if (gp && live[j]) gp[threadIdx.x + j * NLL_THREADS] = gr;
+        if (gp && live[j]) gp[off[j]] = gr;
       }
-      part[k] = acc;
+      acc = wave_sum(acc);
+      if (lane == 0) red[k][wave] += acc;
 #pragma unroll
-      for (int j = 0; j < MAXV; ++j) cur[j] = nxt[j];
+      for (int j = 0; j < NV; ++j) cur[j] = nxt[j];
     }
   }
 }
 
-// Sample chunks per batch row: at least ceil(K / KC) (the registers hold KC partial sums), balanced.  MVK_RECON_CHUNK
-// caps the chunk length of rows with more than 1024 values (experiment hook: finer chunks re-read x and measured slower).
+// Sample chunks per batch row: one block walks up to KC samples of its row (x is read once).  MVK_RECON_CHUNK caps the
+// chunk length (experiment hook).  Measured in the MoPoE step (MnistSvhn, K=10, B=512): 10 samples per block 28.5 us,
+// 5: 30.3, 3: 34.0, 2: 31.8 -- the coarsest cut wins.
 static int recon_max_chunk() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("MVK_RECON_CHUNK");
-    v = e ? atoi(e) : KC;  // measured (MnistSvhn, K=10): 5-sample chunks 43.7 us, 3: 46.4, 2: 45.7, 1: 49.9 -> no finer cut
+    v = e ? atoi(e) : KC;
     if (v < 1) v = 1;
     if (v > KC) v = KC;
   }
@@ -427,7 +432,10 @@ static int recon_kchunks(int K, long long D) {
   return (K + cap - 1) / cap;
 }
 
-template <bool VEC, bool FWD>
+// MODE 0: scalar path (unaligned rows / row length not a multiple of 4); 1: vector path, Normal / Laplace rows; 2: vector
+// path, Bernoulli rows (a separate instantiation: its exp / log1p temporaries cost 24 more registers, i.e. 2 waves per
+// SIMD that the streaming Normal / Laplace rows would lose)
+template <int MODE, bool FWD>
 __global__ __launch_bounds__(NLL_THREADS) void recon_nll_kernel(const ReconTable tb, int K, int B) {
   // locate the modality of this block
   int mi = 0;
@@ -446,15 +454,25 @@ __global__ __launch_bounds__(NLL_THREADS) void recon_nll_kernel(const ReconTable
   const float mk = d.mask ? (d.mask[b] ? 1.0f : 0.0f) : 1.0f;
   const float gbase = d.coef * d.rescale * mk;
   const float* xrow = d.x + (long long)b * D;
-  float part[KC];
+  __shared__ float red[KC][NLL_THREADS / 64];  // partial row sums per (sample, wave); only lane 0 of a wave touches it
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
 #pragma unroll
-  for (int k = 0; k < KC; ++k) part[k] = 0.f;
+    for (int k = 0; k < KC; ++k) red[k][wave] = 0.f;
+  }
 
-  if (VEC) {
-    // distribution resolved once per block: the element loops below are branch-free
-    if (d.dist == MVK_DIST_NORMAL) recon_vec_body<MVK_DIST_NORMAL>(d, B, b, k0, kn, gbase, inv_s, inv_s2, xrow, part);
-    else if (d.dist == MVK_DIST_LAPLACE) recon_vec_body<MVK_DIST_LAPLACE>(d, B, b, k0, kn, gbase, inv_s, inv_s2, xrow, part);
-    else recon_vec_body<MVK_DIST_BERNOULLI>(d, B, b, k0, kn, gbase, inv_s, inv_s2, xrow, part);
+  if (MODE > 0) {
+    // distribution and tile width resolved once per block: the element loops below are branch-free
+    const bool small = D <= 4 * NLL_THREADS;
+#define MVK_RECON_BODY(DIST)                                                                              \
+  do {                                                                                                    \
+    if (small) recon_vec_body<DIST, 1>(d, B, b, k0, kn, gbase, inv_s, inv_s2, xrow, red);                  \
+    else recon_vec_body<DIST, NLL_NV>(d, B, b, k0, kn, gbase, inv_s, inv_s2, xrow, red);                   \
+  } while (0)
+    if (MODE == 2) MVK_RECON_BODY(MVK_DIST_BERNOULLI);
+    else if (d.dist == MVK_DIST_NORMAL) MVK_RECON_BODY(MVK_DIST_NORMAL);
+    else MVK_RECON_BODY(MVK_DIST_LAPLACE);
+#undef MVK_RECON_BODY
   } else {
     for (int k = 0; k < kn; ++k) {
       const long long ro = ((long long)(k0 + k) * B + b) * D;
@@ -466,20 +484,12 @@ __global__ __launch_bounds__(NLL_THREADS) void recon_nll_kernel(const ReconTable
         acc += n;
         if (d.drecon) d.drecon[ro + i] = g * gw;
       }
-      // static indexing of part[] to keep it in registers
-#pragma unroll
-      for (int kk = 0; kk < KC; ++kk)
-        if (kk == k) part[kk] = acc;
+      acc = wave_sum(acc);
+      if (lane == 0) red[k][wave] += acc;
     }
   }
 
   if (FWD) {
-    __shared__ float red[KC][NLL_THREADS / 64];
-#pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      const float s = wave_sum(part[k]);
-      if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s;
-    }
     __syncthreads();
     if ((int)threadIdx.x < kn) {
       const int k = threadIdx.x;
@@ -542,16 +552,11 @@ __global__ __launch_bounds__(NLL_THREADS) void recon_categorical_kernel(const mv
 static int launch_recon(const mvk_recon_desc* descs, int n_mod, int K, int B, bool fwd, hipStream_t s) {
   if (!descs || n_mod < 1 || n_mod > MAXM || K < 1 || B < 0) return MVK_EINVAL;
   if (B == 0) return MVK_OK;
-  // the vector path needs every modality to qualify; otherwise the scalar path serves all of them
-  bool vec = true;
   for (int i = 0; i < n_mod; ++i) {
     const mvk_recon_desc& d = descs[i];
     if (!d.recon || !d.x || d.D <= 0 || (fwd && !d.rows) || (!fwd && !d.drecon)) return MVK_EINVAL;
     if (d.dist < 0 || d.dist > MVK_DIST_CATEGORICAL) return MVK_EINVAL;
     if (d.dist == MVK_DIST_CATEGORICAL && (d.n_classes < 1 || d.D % d.n_classes)) return MVK_EINVAL;
-    if ((d.D & 3) || d.D > 4 * MAXV * NLL_THREADS || !mvk_aligned16(d.recon) || !mvk_aligned16(d.x) ||
-        (d.drecon && !mvk_aligned16(d.drecon)))
-      vec = false;
   }
   for (int i = 0; i < n_mod; ++i) {  // categorical terms: class-row kernel, one launch per term
     if (descs[i].dist != MVK_DIST_CATEGORICAL) continue;
@@ -561,17 +566,18 @@ static int launch_recon(const mvk_recon_desc* descs, int n_mod, int K, int B, bo
       hipLaunchKernelGGL((recon_categorical_kernel<false>), dim3(K * B), dim3(NLL_THREADS), 0, s, descs[i], K, B);
     MVK_CHECK_LAUNCH();
   }
-  // launch per vectorisability group so that a tiny modality does not de-vectorise a large one
-  for (int pass = 0; pass < 2; ++pass) {
+  // launch per group (scalar rows, Normal / Laplace vector rows, Bernoulli vector rows) so that an odd-sized or
+  // register-hungry modality does not slow the others down
+  for (int pass = 0; pass < 3; ++pass) {
     ReconTable tb;
     tb.n = 0;
     int blocks = 0;
     for (int i = 0; i < n_mod; ++i) {
       const mvk_recon_desc& d = descs[i];
       if (d.dist == MVK_DIST_CATEGORICAL) continue;
-      bool v = !((d.D & 3) || d.D > 4 * MAXV * NLL_THREADS || !mvk_aligned16(d.recon) || !mvk_aligned16(d.x) ||
-                 (d.drecon && !mvk_aligned16(d.drecon)));
-      if ((pass == 0) != v) continue;
+      const bool v = !((d.D & 3) || !mvk_aligned16(d.recon) || !mvk_aligned16(d.x) || (d.drecon && !mvk_aligned16(d.drecon)));
+      const int group = !v ? 0 : (d.dist == MVK_DIST_BERNOULLI ? 2 : 1);
+      if (group != pass) continue;
       tb.d[tb.n] = d;
       tb.block_start[tb.n] = blocks;
       tb.kchunks[tb.n] = recon_kchunks(K, d.D);
@@ -580,17 +586,16 @@ static int launch_recon(const mvk_recon_desc* descs, int n_mod, int K, int B, bo
     }
     if (tb.n == 0) continue;
     tb.block_start[tb.n] = blocks;
-    (void)vec;
+    const dim3 g(blocks), t(NLL_THREADS);
     if (pass == 0) {
-      if (fwd)
-        hipLaunchKernelGGL((recon_nll_kernel<true, true>), dim3(blocks), dim3(NLL_THREADS), 0, s, tb, K, B);
-      else
-        hipLaunchKernelGGL((recon_nll_kernel<true, false>), dim3(blocks), dim3(NLL_THREADS), 0, s, tb, K, B);
+      if (fwd) hipLaunchKernelGGL((recon_nll_kernel<0, true>), g, t, 0, s, tb, K, B);
+      else hipLaunchKernelGGL((recon_nll_kernel<0, false>), g, t, 0, s, tb, K, B);
+    } else if (pass == 1) {
+      if (fwd) hipLaunchKernelGGL((recon_nll_kernel<1, true>), g, t, 0, s, tb, K, B);
+      else hipLaunchKernelGGL((recon_nll_kernel<1, false>), g, t, 0, s, tb, K, B);
     } else {
-      if (fwd)
-        hipLaunchKernelGGL((recon_nll_kernel<false, true>), dim3(blocks), dim3(NLL_THREADS), 0, s, tb, K, B);
-      else
-        hipLaunchKernelGGL((recon_nll_kernel<false, false>), dim3(blocks), dim3(NLL_THREADS), 0, s, tb, K, B);
+      if (fwd) hipLaunchKernelGGL((recon_nll_kernel<2, true>), g, t, 0, s, tb, K, B);
+      else hipLaunchKernelGGL((recon_nll_kernel<2, false>), g, t, 0, s, tb, K, B);
     }
     MVK_CHECK_LAUNCH();
   }

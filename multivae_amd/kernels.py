@@ -921,6 +921,10 @@ class ReconLossFn(Function):
         if n_rec:
             prof = PROFILE.get("recon_nll")
             if prof is not None:
+                # measurement only: a short spin kernel ahead of the first event lets the host finish enqueueing the
+                # launch while the GPU is busy, so the event pair brackets the kernel and not the launch latency
+                if PROFILE.get("presleep_cycles"):
+                    torch.cuda._sleep(int(PROFILE["presleep_cycles"]))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             Kl = 1 if pairs is not None else K

@@ -23,4 +23,4 @@ cols = sorted({k for a in agg.values() for k in a["c"]})
 print("n dur_us grid | " + " | ".join(cols))
 for (nm, gx, gy, gz), a in agg.items():
     n = a["n"]
-    print(f"{n:3d} {a['dur']/n:8.1f} ({gx},{gy},{gz}) " + " ".join(f"{a['c'][k]/n/1e6:9.3f}M" for k in cols) + "  " + nm)
+    print(f"{n:3d} {a['dur']/n:8.1f} ({gx},{gy},{gz}) " + " ".join(f"{a['c'][k]/n/1e6:11.6f}M" for k in cols) + "  " + nm)

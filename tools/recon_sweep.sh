@@ -1,6 +1,6 @@
 #!/bin/bash
-# recon-NLL workgroup granularity sweep (run on the GPU box)
-for c in 8 5 3 2 1; do
+# recon-NLL workgroup granularity sweep (run on the GPU box): samples per block
+for c in 16 5 3 2; do
   MVK_RECON_CHUNK=$c python bench.py --steps 30 --warmup 10 --no-cpu-baseline 2>&1 | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
