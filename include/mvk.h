@@ -397,6 +397,11 @@ int mvk_conv4s2_up_nchw_small(const float* V, const float* Wref, const float* bi
  * the bias gradient (db +=, nullable) with dUpre = dU * u_act'(Uout) applied while loading; db_v (nullable) +=
  * the per-channel sums of dV, i.e. the bias gradient of the layer that produced V; ws is split-K style scratch
  * (>= 512 * (16*Cu*Cv + Cu + Cv) floats for full parallelism). */
+/* Forward of the image-CONSUMING layer (svhn.py:13-15, the encoder's first Conv2d(Cu <= 4, Cv, 4, 2, 1) on the NCHW
+ * network input): V[n,h,w,Cv] = act(conv(U[n,Cu,2h,2w]) + bias), Wdown = the packed [16 Cu][Cv] weight of
+ * mvk_pack_conv4s2_weight.  Same support set as mvk_conv4s2_small_up_supported; mvk_conv4s2_down routes here. */
+int mvk_conv4s2_small_down_fwd(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w,
+                               int Cu, int Cv, int act, void* stream);
 int mvk_conv4s2_small_up_supported(int h, int w, int Cu, int Cv);
 int mvk_conv4s2_small_up_fwd(const float* V, const float* Wref, const float* bias, float* U, int n, int h, int w,
                              int Cu, int Cv, int act, void* stream);

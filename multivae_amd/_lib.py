@@ -81,6 +81,7 @@ PROTOTYPES = {
     "mvk_conv4s2_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _p],
     "mvk_conv4s2_up_nchw_small": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "mvk_conv4s2_small_up_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "mvk_conv4s2_small_down_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "mvk_conv4s2_small_up_bwd": [_p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p],
     "mvk_pack_unflatten_weight": [_p, _i, _i, _p, _p],
     "mvk_unflatten_wgrad": [_p, _p, _p, _i, _i, _i, _p, _i64, _p],

@@ -614,8 +614,11 @@ int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, floa
                      int v_act, float* colsum_acc, float* ws, int64_t ws_floats, int fmt, void* stream) {
   if (!U || !Wdown || !V || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0) return MVK_EINVAL;
   if ((fmt & ~MVK_FMT_IN_BF3) || ((fmt & MVK_FMT_IN_BF3) && (u_nchw || u_act_src))) return MVK_EINVAL;
-  if (u_nchw && !u_act_src && !v_act_src && !colsum_acc && smallcin_supported(Cu, Cv))  // the network-input layer
-    return smallcin_fwd(U, Wdown, bias, V, n, h, w, Cu, Cv, act, mvk_stream(stream));
+  if (u_nchw && !u_act_src && !v_act_src && !colsum_acc) {  // the network-input layer
+    if (mvk_conv4s2_small_up_supported(h, w, Cu, Cv))
+      return mvk_conv4s2_small_down_fwd(U, Wdown, bias, V, n, h, w, Cu, Cv, act, stream);  // LDS-staged image, MFMA
+    if (smallcin_supported(Cu, Cv)) return smallcin_fwd(U, Wdown, bias, V, n, h, w, Cu, Cv, act, mvk_stream(stream));
+  }
   GemmDesc d{};
   d.a = AOperand{};
   d.a.p = U;

@@ -19,6 +19,9 @@
 #pragma once
 #include "igemm_fast.hpp"
 
+#ifndef MVK_BF_OCC_SMALL
+#define MVK_BF_OCC_SMALL 3  // 4 (<= 128 VGPRs) spills 92-240 bytes per lane in every 128x32 variant
+#endif
 namespace mvk {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -152,7 +155,7 @@ __device__ __forceinline__ void bf_write_pieces(char* base, const unsigned (&pc)
 }
 
 template <int BM, int BN, int AMODE, int BMODE, bool AACT, int DEPTH>
-__global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 3 : 2) void igemm_bf_kernel(const GemmDesc d) {
+__global__ __launch_bounds__(256, (BM * BN <= 128 * 32) ? MVK_BF_OCC_SMALL : ((BM * BN <= 128 * 64) ? 3 : 2)) void igemm_bf_kernel(const GemmDesc d) {
   using T = BfCfg<BM, BN>;
   constexpr int BKT = T::BKT;
   __shared__ __attribute__((aligned(16))) char lds_raw[T::LDS_BYTES];

@@ -17,6 +17,9 @@
 // per-wave weight-gradient accumulators are replicated over twice the waves), so the two kernels differ.
 #define MVK_SMALL_FWD_THREADS 512
 #endif
+#ifndef MVK_SMALL_DOWN_THREADS
+#define MVK_SMALL_DOWN_THREADS 256
+#endif
 #ifndef MVK_SMALL_BWD_THREADS
 #define MVK_SMALL_BWD_THREADS 256
 #endif
@@ -356,6 +359,105 @@ __global__ __launch_bounds__(NT) void small_up_bwd_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// forward of the image-CONSUMING layer: V[n,h,w,Cv] = act(conv4s2(U[n,Cu,2h,2w]) + b), Cu <= 4 (svhn.py:13-15 first
+// Conv2d).  Same tile algebra as the backward-data part above (the gradient of the image-producing ConvTranspose IS this
+// convolution): the NCHW image with a zero halo is staged in LDS with coalesced loads (persistent workgroups, next
+// image prefetched in registers), the 16 Cu window of every position is gathered from LDS into the A operand of
+// v_mfma_f32_16x16x4_f32 (exact fp32), the packed weight [16 Cu][Cv] sits in LDS for the whole launch.
+// ---------------------------------------------------------------------------------------------------------
+template <int CU, int CV, int NT>
+__global__ __launch_bounds__(NT) void small_down_fwd_kernel(const float* __restrict__ U, const float* __restrict__ Wdown,
+                                                            const float* __restrict__ bias, float* __restrict__ V, int n,
+                                                            int h, int w, int act) {
+  using C = SmallCfg<CU, CV>;
+  constexpr int NW = NT / 64, WP = 256 / NW, MT = WP / 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int P = h * w, DH = 2 * h + 2, DW = 2 * w + 2;
+  float* Wt = smem;                                       // [NC][WT]: Wt[k = tap*CU + cu][cv] (the packed down layout)
+  float* Ds = Wt + C::NC * C::WT;                         // [CU][DH][DW] image with zero halo
+  int* posoff = reinterpret_cast<int*>(Ds + ((CU * DH * DW + 3) & ~3));  // [P]: (2i)*DW + 2j
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+  for (int i = tid; i < C::NC * CV; i += NT) Wt[(i / CV) * C::WT + (i % CV)] = Wdown[i];
+  for (int p = tid; p < P; p += NT) posoff[p] = (2 * (p / w)) * DW + 2 * (p % w);
+  const bool active = wave * WP < P;
+  float bv0[C::NTV];
+#pragma unroll
+  for (int b = 0; b < C::NTV; ++b) bv0[b] = bias ? bias[b * 16 + l15] : 0.f;
+
+  const int H2 = 2 * h, W2 = 2 * w;
+  constexpr int ND = (CU * 34 * 34 + NT - 1) / NT;  // halo-tile elements per thread (h, w <= 16)
+  const int nd = CU * DH * DW;
+  float pu[ND];
+  int hoff[ND];  // bits 0..27 offset into the image (clamped), 30 inside the image
+#pragma unroll
+  for (int u = 0; u < ND; ++u) {
+    const int idx = tid + u * NT;
+    const int idc = idx < nd ? idx : nd - 1;
+    const int cu = idc / (DH * DW);
+    const int rem = idc - cu * (DH * DW);
+    const int y = rem / DW, x = rem - y * DW;
+    const int oh = y - 1, ow = x - 1;
+    const bool in = idx < nd && oh >= 0 && oh < H2 && ow >= 0 && ow < W2;
+    const int ohc = oh < 0 ? 0 : (oh >= H2 ? H2 - 1 : oh), owc = ow < 0 ? 0 : (ow >= W2 ? W2 - 1 : ow);
+    hoff[u] = ((cu * H2 + ohc) * W2 + owc) | ((int)in << 30);
+  }
+  auto prefetch = [&](long long img) __attribute__((always_inline)) {
+    const float* src = U + img * CU * H2 * W2;
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const float a = src[hoff[u] & 0x0fffffff];  // unconditional clamped load, the halo is zeroed
+      pu[u] = ((hoff[u] >> 30) & 1) ? a : 0.f;
+    }
+  };
+  if ((long long)blockIdx.x < n) prefetch(blockIdx.x);
+  for (long long img = blockIdx.x; img < n; img += gridDim.x) {
+    __syncthreads();  // the previous image's tile is no longer read
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int idx = tid + u * NT;
+      if (idx < nd) Ds[idx] = pu[u];
+    }
+    __syncthreads();
+    if (img + gridDim.x < n) prefetch(img + gridDim.x);
+    if (!active) continue;
+    f32x4 acc[MT][C::NTV];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < C::NTV; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int po[MT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) po[a] = posoff[wave * WP + a * 16 + l15];
+#pragma unroll 2
+    for (int ks = 0; ks < C::NC / 4; ++ks) {
+      const int k = ks * 4 + lq;
+      const int tap = k / CU, cu = k - tap * CU;
+      const int koff = cu * DH * DW + (tap >> 2) * DW + (tap & 3);
+      float av[MT], bv[C::NTV];
+#pragma unroll
+      for (int a = 0; a < MT; ++a) av[a] = Ds[koff + po[a]];
+#pragma unroll
+      for (int b = 0; b < C::NTV; ++b) bv[b] = Wt[k * C::WT + b * 16 + l15];
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < C::NTV; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+    float* out = V + img * P * CV;
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < C::NTV; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pos = wave * WP + a * 16 + lq * 4 + r, cv = b * 16 + l15;
+          out[pos * CV + cv] = mvk_act(acc[a][b][r] + bv0[b], act);
+        }
+  }
+}
+
 // dWref += sum_b partial[b][0:CV*NC];  db += sum_b partial[b][CV*NC + cu];  db_v += sum_b partial[b][CV*NC+CU+cv]
 __global__ __launch_bounds__(256) void small_up_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int nw,
                                                                   int ncu, int ncv, float* __restrict__ dWref,
@@ -441,6 +543,19 @@ static int launch_bwd(const float* dU, const float* Uout, int u_act, const float
   return MVK_OK;
 }
 
+template <int CU, int CV>
+static int launch_down_fwd(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w, int act,
+                           hipStream_t s) {
+  using C = SmallCfg<CU, CV>;
+  constexpr int NT = MVK_SMALL_DOWN_THREADS;
+  const int P = h * w, DH = 2 * h + 2, DW = 2 * w + 2;
+  const size_t lds = ((size_t)C::NC * C::WT + ((CU * DH * DW + 3) & ~3) + P) * sizeof(float);
+  const int grid = n < 1024 ? n : 1024;  // persistent: up to 4 workgroups per CU, each loops over images with prefetch
+  hipLaunchKernelGGL((small_down_fwd_kernel<CU, CV, NT>), dim3(grid), dim3(NT), lds, s, U, Wdown, bias, V, n, h, w, act);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
 #define MVK_SMALL_DISPATCH(FN, ...)                                  \
   switch (Cu * 100 + Cv) {                                           \
     case 116: return FN<1, 16>(__VA_ARGS__);                         \
@@ -470,6 +585,14 @@ int mvk_conv4s2_small_up_fwd(const float* V, const float* Wref, const float* bia
   if (n == 0) return MVK_OK;
   hipStream_t s = mvk_stream(stream);
   MVK_SMALL_DISPATCH(launch_fwd, V, Wref, bias, U, n, h, w, act, s)
+}
+
+int mvk_conv4s2_small_down_fwd(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w,
+                               int Cu, int Cv, int act, void* stream) {
+  if (!U || !Wdown || !V || n < 0 || !supported(h, w, Cu, Cv)) return MVK_EINVAL;
+  if (n == 0) return MVK_OK;
+  hipStream_t s = mvk_stream(stream);
+  MVK_SMALL_DISPATCH(launch_down_fwd, U, Wdown, bias, V, n, h, w, act, s)
 }
 
 int mvk_conv4s2_small_up_bwd(const float* dU, const float* Uout, int u_act, const float* V, int v_act,

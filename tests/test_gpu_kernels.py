@@ -859,3 +859,29 @@ def test_recon_nll_categorical(Kk, B, shape):
     e.n_classes = C + 1 if D % (C + 1) else 0
     with pytest.raises(MvkError):
         call("mvk_recon_nll_bwd", desc, 1, Kk, B, stream_ptr())
+
+
+@pytest.mark.parametrize("n,h,w,Cu,Cv,act", [(1030, 16, 16, 3, 32, 1), (5, 8, 8, 3, 16, 0), (3, 16, 16, 1, 64, 1),
+                                             (7, 8, 8, 2, 32, 3), (2, 16, 16, 4, 64, 1)])
+def test_small_down_fwd(K, n, h, w, Cu, Cv, act):
+    """mvk_conv4s2_small_down_fwd (LDS-staged NCHW image, fp32 MFMA) = Conv2d(Cu, Cv, 4, 2, 1) + bias + activation, also
+    through mvk_conv4s2_down's routing for the network-input layer; more images than persistent workgroups."""
+    from multivae_amd._lib import call, ptr, stream_ptr
+
+    gen = g(71 + n)
+    U = torch.randn(n, Cu, 2 * h, 2 * w, generator=gen)
+    Wc = torch.randn(Cv, Cu, 4, 4, generator=gen) / math.sqrt(16 * Cu)
+    b = torch.randn(Cv, generator=gen)
+    ref = F.conv2d(U, Wc, b, stride=2, padding=1)
+    ref = {0: ref, 1: torch.relu(ref), 3: F.leaky_relu(ref, 0.2)}[act]
+    d = dev()
+    wd, _ = K.pack_conv(Wc.to(d))
+    Ud, bd = U.to(d), b.to(d)
+    V = torch.empty(n, h, w, Cv, device=d)
+    call("mvk_conv4s2_small_down_fwd", ptr(Ud), ptr(wd), ptr(bd), ptr(V), n, h, w, Cu, Cv, act, stream_ptr())
+    close(nchw(V.cpu()), ref, rtol=2e-6, what="small down fwd")  # exact fp32 MFMA
+    got = K.conv_down(Ud, wd, bd, n, h, w, Cu, Cv, act=act, u_nchw=True)
+    assert torch.equal(got, V)
+    V2 = torch.empty_like(V)
+    call("mvk_conv4s2_small_down_fwd", ptr(Ud), ptr(wd), None, ptr(V2), n, h, w, Cu, Cv, 0, stream_ptr())
+    close(nchw(V2.cpu()), F.conv2d(U, Wc, None, stride=2, padding=1), rtol=2e-6, what="no bias")
