@@ -188,7 +188,20 @@ int launch_igemm(const GemmDesc& d_in, int zdim, hipStream_t s, LaunchInfo* info
   return launch_cfg<64, 64>(d, zdim, s);
 }
 
+// experiment hook: MVK_SPLITK_TARGET_1024 / _512 replace the two block targets of the split-K launches
+static int splitk_target(int t) {
+  static int t1024 = -1, t512 = -1;
+  if (t1024 < 0) {
+    const char* a = getenv("MVK_SPLITK_TARGET_1024");
+    const char* b = getenv("MVK_SPLITK_TARGET_512");
+    t1024 = a ? atoi(a) : 768;  // one full wave of 3 workgroups per CU (A/B in the step: 1.955 vs 1.969 ms at 1024)
+    t512 = b ? atoi(b) : 512;
+  }
+  return t == 1024 ? t1024 : (t == 512 ? t512 : t);
+}
+
 int launch_splitk(GemmDesc& d, float* ws, long long ws_floats, int target_blocks, hipStream_t s) {
+  target_blocks = splitk_target(target_blocks);
   int tm = (d.M + 127) / 128;
   int tn = (d.N <= 32) ? 1 : (d.N + 63) / 64;
   int tiles = tm * tn;

@@ -9,6 +9,8 @@ the distributed step is: copy batch -> replay -> all_reduce(flat.grad) -> adam.
 Capture needs static shapes and addresses: the batch and the noise are copied into buffers owned by this object;
 a batch of another shape (the last one of an epoch) must go through the eager path.
 """
+import os
+
 import torch
 
 from .. import kernels
@@ -41,6 +43,8 @@ class GraphedStep:
             cur.wait_stream(side)
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
+            # (stream priorities were tried: capturing the main branch, or the side branches, on a priority -1 stream
+            # makes the replayed step 3.0-3.1 ms instead of 1.9)
             with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
                 self.out = self._body()
         finally:
