@@ -6,7 +6,8 @@ from .mmvaePlus import MMVAEPlus, MMVAEPlusConfig
 from .mopoe import MoPoE, MoPoEConfig
 from .mvae import MVAE, MVAEConfig
 from .mvtcae import MVTCAE, MVTCAEConfig
+from .crmvae import CRMVAE, CRMVAEConfig
 from .auto_model import AutoConfig, AutoModel  # noqa: E402  (needs the model classes above)
 
 __all__ = ["BaseAEConfig", "BaseMultiVAE", "BaseMultiVAEConfig", "ModelOutput", "MMVAE", "MMVAEConfig", "MoPoE",
-           "MoPoEConfig", "MVTCAE", "MVTCAEConfig", "JMVAE", "JMVAEConfig", "BaseJointModel", "BaseJointModelConfig", "MMVAEPlus", "MMVAEPlusConfig", "AutoModel", "AutoConfig", "MVAE", "MVAEConfig"]
+           "MoPoEConfig", "MVTCAE", "MVTCAEConfig", "JMVAE", "JMVAEConfig", "BaseJointModel", "BaseJointModelConfig", "MMVAEPlus", "MMVAEPlusConfig", "AutoModel", "AutoConfig", "MVAE", "MVAEConfig", "CRMVAE", "CRMVAEConfig"]

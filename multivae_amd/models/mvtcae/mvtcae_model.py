@@ -79,7 +79,7 @@ class MVTCAE(BaseMultiVAE):
             return self._joint_nll(inputs, z, [mu], [kernels.std_from_logvar(lv)])
 
     def encode(self, inputs, cond_mod: Union[list, str] = "all", N: int = 1, return_mean=False, **kwargs):
-        cond_mod = super().encode(inputs, cond_mod, N, **kwargs).cond_mod
+        cond_mod = BaseMultiVAE.encode(self, inputs, cond_mod, N, **kwargs).cond_mod  # (CRMVAE borrows this method)
         from ...data.datasets.base import MultimodalBaseDataset
 
         cond_inputs = MultimodalBaseDataset(data={k: inputs.data[k] for k in cond_mod})

@@ -727,3 +727,49 @@ def mvae_joint_nll(enc, data, decoders, eps, *, names, dists=None, batch_size_K=
     mu, lv = stable_poe(torch.stack(mus), torch.stack(lvs))
     sd = torch.exp(0.5 * lv)
     return iwae_joint_nll(mu + sd * eps, data, decoders, [(mu, sd)], names=names, dists=dists, batch_size_K=batch_size_K)
+
+
+# ----------------------------------------------------------------------------------------------
+# CRMVAE
+# ----------------------------------------------------------------------------------------------
+def crmvae_forward(enc, data, decoders, eps, mod_eps, *, names, beta=2.5, rescale=None, dists=None, dist_scales=None,
+                   masks=None):
+    """CRMVAE.forward, crmvae_model.py:37-105 (+ _infer_all_latent_parameters :133-165): PoE of the available experts
+    (`poe`, +inf log-variance for missing rows, no prior expert), KL(joint || N(0,I)) and KL(joint || q_m) (masked) via
+    `kl_divergence` (base_utils.py:90-119), every modality reconstructed from the joint sample AND from a sample of its
+    own (unmasked) posterior; per-sample loss = sum recon / (2 (M+1)) + beta (sum KL) / (M+1), summed over the batch.
+    eps [B,L]: joint noise; mod_eps {m: [B,L]}: unimodal noise (drawn after the joint one, in data order)."""
+    rescale = rescale or {m: 1.0 for m in names}
+    dists = dists or {}
+    dist_scales = dist_scales or {}
+    M = len(names)
+    mus = torch.stack([enc[m][0] for m in names])
+    lvs = []
+    for m in names:
+        lv = enc[m][1]
+        if masks is not None:
+            lv = torch.where(masks[m].bool().unsqueeze(-1), lv, torch.full_like(lv, float("inf")))
+        lvs.append(lv)
+    jmu, jlv = poe(mus, torch.stack(lvs))
+    zs = {"joint": rsample(jmu, jlv, eps)}
+    joint_kld = kl_divergence(jmu, jlv, torch.zeros_like(jmu), torch.zeros_like(jlv))
+    metrics = {"joint_divergence": joint_kld.mean()}
+    divergence = joint_kld
+    for m in names:
+        mu, lv = enc[m]
+        zs[m] = rsample(mu, lv, mod_eps[m])
+        kl = kl_divergence(jmu, jlv, mu, lv)
+        if masks is not None:
+            kl = kl * masks[m].float()
+        divergence = divergence + kl
+        metrics[f"kl_{m}"] = kl.mean()
+    loss_rec = 0
+    for g in names:
+        for src in ("joint", g):
+            r = _row_nll(dists.get(g, "normal"), decoders[g](zs[src]), data[g], rescale[g], dist_scales.get(g, 1.0))
+            if masks is not None:
+                r = masks[g].float() * r
+            loss_rec = loss_rec + r
+            metrics[f"recon_{g}_from_{src}"] = r.mean()
+    total = loss_rec / (2 * (M + 1)) + beta * divergence / (M + 1)
+    return dict(loss=total.sum(), loss_sum=total.sum(), metrics=metrics, zs=zs, joint_mu=jmu, joint_logvar=jlv)

@@ -34,7 +34,7 @@ import _reference_import as R
 R.install()
 import procedural as P
 from multivae.data.datasets.base import IncompleteDataset, MultimodalBaseDataset
-from multivae.models import (JMVAE, MMVAE, MVAE, MVTCAE, JMVAEConfig, MMVAEConfig, MMVAEPlus, MMVAEPlusConfig, MoPoE,
+from multivae.models import (CRMVAE, JMVAE, MMVAE, MVAE, MVTCAE, CRMVAEConfig, JMVAEConfig, MMVAEConfig, MMVAEPlus, MMVAEPlusConfig, MoPoE,
                              MoPoEConfig, MVAEConfig, MVTCAEConfig)
 from multivae.models.base import base_utils as ref_utils
 from multivae.models.base.base_config import BaseAEConfig
@@ -836,6 +836,76 @@ def mvae_main():
               masked=False, seed=805, nll_K=6)
 
 
+def crmvae_case(name, *, arch, B, beta, rescaling, masked, seed, dists=None):
+    print(name)
+    if arch == "tiny":
+        dims, L = TINY_DIMS, TINY_L
+        data, masks = tiny_data(B, seed, masked)
+        for m, d in (dists or {}).items():
+            if d == "bernoulli":
+                data[m] = (data[m] > 0.5).astype(np.float32)
+        shapes = P.default_mlp_shapes(dims, L)
+        enc = dec = None
+    else:
+        dims, L = dict(mnist=(1, 28, 28), svhn=(3, 32, 32)), 20
+        data, masks = mnist_svhn_data(B, seed), None
+        shapes = P.mnist_svhn_shapes(L)
+        enc, dec = mnist_svhn_arch(L)
+    cfg = CRMVAEConfig(n_modalities=len(dims), latent_dim=L, input_dims=dict(dims), beta=beta,
+                       uses_likelihood_rescaling=rescaling, decoders_dist=dists)
+    model = CRMVAE(cfg, enc, dec)
+    sd_np = P.make_state_dict(shapes, seed)
+    load_weights(model, sd_np)
+    names = list(model.encoders.keys())
+    inputs = ref_dataset(data, masks)
+    model.train()
+    torch.manual_seed(seed)
+    eps = torch.randn(B, L)
+    mod_eps = {m: torch.randn(B, L) for m in inputs.data}
+    torch.manual_seed(seed)
+    out = model(inputs)
+    model.zero_grad()
+    out.loss.backward()
+    gref = ref_grads(model)
+    osd = oracle_sd(sd_np)
+    if arch == "tiny":
+        enc_f, dec_f = nets.build_default_mlp(osd, dims)
+    else:
+        enc_f, dec_f = nets.build_mnist_svhn(osd, L)
+    tdata = {m: t(v) for m, v in data.items()}
+    tmasks = None if masks is None else {m: t(v) for m, v in masks.items()}
+    e = {m: enc_f[m](tdata[m]) for m in names}
+    o = elbo.crmvae_forward(e, tdata, dec_f, eps, mod_eps, names=names, beta=beta,
+                            rescale=elbo.rescale_factors(dims, rescaling), dists=dists, masks=tmasks)
+    o["loss"].backward()
+    report("loss", out.loss, o["loss"])
+    assert set(out.metrics) == set(o["metrics"])
+    for k_ in out.metrics:
+        report(k_, out.metrics[k_], o["metrics"][k_])
+    cmp_grads("grads", gref, {k_: (v.grad if v.grad is not None else torch.zeros_like(v)) for k_, v in osd.items()})
+    arrays = dict(eps=eps, loss=out.loss.detach(), loss_sum=out.loss_sum.detach(), joint_mu=o["joint_mu"].detach(),
+                  joint_logvar=o["joint_logvar"].detach())
+    for m in names:
+        arrays["mod_eps/" + m] = mod_eps[m]
+    for k_, v in o["zs"].items():
+        arrays["z/" + k_] = v.detach()
+    for k_, v in out.metrics.items():
+        arrays["metric/" + k_] = v.detach()
+    if masks is not None:
+        for m, v in masks.items():
+            arrays["mask/" + m] = v
+    arrays.update(grad_stats(gref))
+    save(name, dict(model="CRMVAE", arch=arch, B=B, L=L, beta=beta, rescaling=rescaling, masked=masked, seed=seed,
+                    names=names, dists=dists), arrays)
+
+
+def crmvae_main():
+    crmvae_case("crmvae_tiny_complete", arch="tiny", B=6, beta=2.5, rescaling=False, masked=False, seed=1001)
+    crmvae_case("crmvae_tiny_masked_rescale", arch="tiny", B=9, beta=1.0, rescaling=True, masked=True, seed=1002,
+                dists=dict(mod1="normal", mod2="laplace", mod3="bernoulli", mod4="normal"))
+    crmvae_case("crmvae_mnistsvhn", arch="mnistsvhn", B=8, beta=2.5, rescaling=False, masked=False, seed=1003)
+
+
 def nll_case(name, *, kind, arch, B, K, batch_size_K, seed, dists=None, family="normal", subset=None):
     """compute_joint_nll of the reference (K importance samples per data point, chunks of batch_size_K) against
     oracle.elbo.*_joint_nll on the replayed noise.  Stores the noise, the reference's NLL and the oracle's per-point
@@ -1017,6 +1087,8 @@ if __name__ == "__main__":
         nll_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "mvae":
         mvae_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "crmvae":
+        crmvae_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "categorical":
         mopoe_categorical()
     elif len(sys.argv) > 1 and sys.argv[1] == "style":
@@ -1029,3 +1101,4 @@ if __name__ == "__main__":
         nll_main()
         mvae_main()
         mopoe_style_main()
+        crmvae_main()

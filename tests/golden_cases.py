@@ -32,6 +32,7 @@ NLL_CASES = ["nll_mopoe_tiny", "nll_mopoe_mnistsvhn", "nll_mopoe_tiny_subset", "
 MOPOE_STYLE_CASES = ["mopoe_tiny_style", "mopoe_tiny_style_masked"]
 MVAE_CASES = ["mvae_tiny_subsampling_k2", "mvae_tiny_joint_only_rescale", "mvae_tiny_masked",
               "mvae_tiny_masked_joint_only", "mvae_mnistsvhn"]
+CRMVAE_CASES = ["crmvae_tiny_complete", "crmvae_tiny_masked_rescale", "crmvae_mnistsvhn"]
 NLL_MMVAEPLUS_CASES = ["nll_mmvaeplus_tiny_laplace", "nll_mmvaeplus_tiny_softplus"]
 
 

@@ -24,7 +24,7 @@ def check(a, b, what, rtol=RTOL):
 
 
 def build_model(cfg, dims):
-    from multivae_amd.models import (JMVAE, MMVAE, MVAE, MVTCAE, JMVAEConfig, MMVAEConfig, MMVAEPlus, MMVAEPlusConfig,
+    from multivae_amd.models import (CRMVAE, JMVAE, MMVAE, MVAE, MVTCAE, CRMVAEConfig, JMVAEConfig, MMVAEConfig, MMVAEPlus, MMVAEPlusConfig,
                                      MoPoE, MoPoEConfig, MVAEConfig, MVTCAEConfig)
     from multivae_amd.models.base.base_config import BaseAEConfig
     from multivae_amd.models.nn.default_architectures import Decoder_AE_MLP, Encoder_VAE_MLP
@@ -43,6 +43,8 @@ def build_model(cfg, dims):
         mc = MoPoEConfig(beta=cfg["beta"], decoders_dist=cfg.get("dists"), K=cfg["K"],
                          beta_style=cfg.get("beta_style", 1.0), modalities_specific_dim=cfg.get("style_dims"), **common)
         return MoPoE(mc, enc, dec)
+    if cfg["model"] == "CRMVAE":
+        return CRMVAE(CRMVAEConfig(beta=cfg["beta"], decoders_dist=cfg.get("dists"), **common), enc, dec)
     if cfg["model"] == "MVAE":
         return MVAE(MVAEConfig(beta=cfg["beta"], warmup=cfg["warmup"], k=cfg["k"], use_subsampling=cfg["subsampling"],
                                decoders_dist=cfg.get("dists"), **common), enc, dec)
@@ -119,6 +121,10 @@ def oracle_full_grads(cfg, dims, data, masks, sd_np, a):
         o = elbo.jmvae_forward(nets.joint_mlp_encoder(sd, dims, tdata), e, tdata, dec_f, G.t(a["eps"]), names=names,
                                alpha=cfg["alpha"], beta=cfg["beta"], warmup=cfg["warmup"], epoch=cfg["epoch"],
                                rescale=resc, dists=cfg.get("dists"))
+    elif cfg["model"] == "CRMVAE":
+        e = {m: enc_f[m](tdata[m]) for m in names}
+        o = elbo.crmvae_forward(e, tdata, dec_f, G.t(a["eps"]), {m: G.t(a["mod_eps/" + m]) for m in names}, names=names,
+                                beta=cfg["beta"], rescale=resc, dists=cfg.get("dists"), masks=tmasks)
     elif cfg["model"] == "MVAE":
         e = {m: enc_f[m](tdata[m]) for m in names}
         o = elbo.mvae_forward(e, tdata, dec_f, G.t(a["eps"]), names=names, subsets=cfg["subsets"],
@@ -555,3 +561,25 @@ def test_mopoe_style_golden(name):
     model.encoders["mod1"] = Encoder_VAE_MLP(BaseAEConfig(latent_dim=cfg["L"], input_dim=(2,))).to(d)
     with pytest.raises(AttributeError):
         model(inputs)
+
+
+@pytest.mark.parametrize("name", G.CRMVAE_CASES)
+def test_crmvae_golden(name):
+    """CRMVAE on the HIP path (MVTCAE posterior kernel + unimodal samples + two reconstruction slabs per decoder)."""
+    cfg, a, dims, data, masks, sd_np, model, inputs, d = prep(name)
+    names = cfg["names"]
+    out = model(inputs, noise=G.t(a["eps"]).to(d), modality_noise={m: G.t(a["mod_eps/" + m]).to(d) for m in names})
+    check(a["loss"], out.loss, "loss")
+    check(a["loss_sum"], out.loss_sum, "loss_sum")
+    assert set(out.metrics) == {k[7:] for k in a if k.startswith("metric/")}
+    for k, v in out.metrics.items():
+        check(a["metric/" + k], v, k)
+    out.loss.backward()
+    o, og = oracle_full_grads(cfg, dims, data, masks, sd_np, a)
+    check(o["loss"].detach().numpy(), out.loss, "loss vs oracle")
+    compare_grads(model, og, a)
+    if masks is None:
+        z = model.encode(inputs, return_mean=True).z
+        check(a["joint_mu"], z, "joint mean")
+        nll = model.compute_joint_nll(inputs, K=6)
+        assert nll.size() == torch.Size([]) and torch.isfinite(nll)

@@ -223,6 +223,25 @@ def test_mopoe_style(name):
     G.check_grads(a, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()}, rtol=1e-5)
 
 
+@pytest.mark.parametrize("name", G.CRMVAE_CASES)
+def test_crmvae(name):
+    """CRMVAE.forward (crmvae_model.py:37-105): PoE joint, KL(joint || prior) + masked KL(joint || q_m), reconstructions
+    from the joint and from the unimodal samples."""
+    cfg, a, dims, data, masks, sd, enc_f, dec_f = _prep(name)
+    names = cfg["names"]
+    e = {m: enc_f[m](data[m]) for m in names}
+    o = elbo.crmvae_forward(e, data, dec_f, G.t(a["eps"]), {m: G.t(a["mod_eps/" + m]) for m in names}, names=names,
+                            beta=cfg["beta"], rescale=elbo.rescale_factors(dims, cfg["rescaling"]),
+                            dists=cfg.get("dists"), masks=masks)
+    close(a["loss"], o["loss"])
+    close(a["loss_sum"], o["loss_sum"])
+    assert {k[7:] for k in a if k.startswith("metric/")} == set(o["metrics"])
+    for k, v in o["metrics"].items():
+        close(a["metric/" + k], v)
+    o["loss"].backward()
+    G.check_grads(a, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()}, rtol=1e-5)
+
+
 def oracle_mvae(cfg, a, dims, data, masks, enc_f, dec_f):
     names = cfg["names"]
     e = {m: enc_f[m](data[m]) for m in names}
