@@ -4,11 +4,11 @@ reference load here and folders written by `BaseModel.save` load in the referenc
 import json
 import os
 
-from .. import CRMVAE, JMVAE, MMVAE, MVAE, MVTCAE, CRMVAEConfig, JMVAEConfig, MVAEConfig, MMVAEConfig, MMVAEPlus, MMVAEPlusConfig, MoPoE, MoPoEConfig, MVTCAEConfig
+from .. import CRMVAE, DMVAE, DMVAEConfig, JMVAE, MMVAE, MVAE, MVTCAE, CRMVAEConfig, JMVAEConfig, MVAEConfig, MMVAEConfig, MMVAEPlus, MMVAEPlusConfig, MoPoE, MoPoEConfig, MVTCAEConfig
 from ..base import BaseMultiVAEConfig
 
 _MODELS = {"JMVAEConfig": (JMVAE, JMVAEConfig), "MMVAEConfig": (MMVAE, MMVAEConfig), "MoPoEConfig": (MoPoE, MoPoEConfig),
-           "MVTCAEConfig": (MVTCAE, MVTCAEConfig), "MVAEConfig": (MVAE, MVAEConfig), "CRMVAEConfig": (CRMVAE, CRMVAEConfig), "MMVAEPlusConfig": (MMVAEPlus, MMVAEPlusConfig)}
+           "MVTCAEConfig": (MVTCAE, MVTCAEConfig), "MVAEConfig": (MVAE, MVAEConfig), "CRMVAEConfig": (CRMVAE, CRMVAEConfig), "DMVAEConfig": (DMVAE, DMVAEConfig), "MMVAEPlusConfig": (MMVAEPlus, MMVAEPlusConfig)}
 
 
 def _name(json_path):

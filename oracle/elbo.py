@@ -773,3 +773,59 @@ def crmvae_forward(enc, data, decoders, eps, mod_eps, *, names, beta=2.5, rescal
             metrics[f"recon_{g}_from_{src}"] = r.mean()
     total = loss_rec / (2 * (M + 1)) + beta * divergence / (M + 1)
     return dict(loss=total.sum(), loss_sum=total.sum(), metrics=metrics, zs=zs, joint_mu=jmu, joint_logvar=jlv)
+
+
+# ----------------------------------------------------------------------------------------------
+# DMVAE
+# ----------------------------------------------------------------------------------------------
+def dmvae_forward(enc, data, decoders, noise, *, names, beta=1.0, private_betas=None, rescale=None, dists=None,
+                  dist_scales=None, masks=None):
+    """DMVAE.forward, dmvae_model.py:152-240: M + 1 negative ELBOs per sample -- q(shared) = stable_poe of the available
+    shared experts and the prior (:131-148), then every modality's own shared posterior (x its mask) -- each with fresh
+    private samples; -sum_m mask_m log p(x_m | [z, w_m]) + beta KL(q(shared) || N(0,I)) + sum_m beta_m mask_m KL(q(w_m) ||
+    N(0,I)); loss = mean over the batch of the sum of the ELBOs.
+    enc: {m: (mu, lv, style_mu, style_lv)}; noise = {"shared": [M+1,B,L], "private": {m: [M+1,B,S_m]}} (slab 0: joint
+    ELBO, slab 1+k: ELBO of the k-th modality)."""
+    rescale = rescale or {m: 1.0 for m in names}
+    private_betas = private_betas or {m: 1.0 for m in names}
+    dists = dists or {}
+    dist_scales = dist_scales or {}
+    mus = [enc[m][0] for m in names]
+    lvs = []
+    for m in names:
+        lv = enc[m][1]
+        if masks is not None:
+            lv = torch.where(masks[m].bool().unsqueeze(-1), lv, torch.full_like(lv, float("inf")))
+        lvs.append(lv)
+    mus.append(torch.zeros_like(mus[0]))
+    lvs.append(torch.zeros_like(lvs[0]))
+    jmu, jlv = stable_poe(torch.stack(mus), torch.stack(lvs))
+
+    def neg_elbo(e, q_mu, q_lv):
+        shared_z = rsample(q_mu, q_lv, noise["shared"][e])
+        recon = 0
+        for m in names:
+            z_mod = rsample(enc[m][2], enc[m][3], noise["private"][m][e])
+            rec = decoders[m](torch.cat([shared_z, z_mod], dim=1))
+            lp = -_row_nll(dists.get(m, "normal"), rec, data[m], rescale[m], dist_scales.get(m, 1.0))
+            if masks is not None:
+                lp = masks[m].float() * lp
+            recon = recon + lp
+        kl = kl_divergence(q_mu, q_lv, torch.zeros_like(q_mu), torch.zeros_like(q_lv)) * beta
+        for m in names:
+            kl_mod = kl_divergence(enc[m][2], enc[m][3], torch.zeros_like(enc[m][2]), torch.zeros_like(enc[m][3]))
+            if masks is not None:
+                kl_mod = masks[m].float() * kl_mod
+            kl = kl + kl_mod * private_betas[m]
+        return -recon + kl
+
+    joint = neg_elbo(0, jmu, jlv)
+    metrics = {"joint": joint.mean()}
+    loss = joint
+    for k, m in enumerate(names):
+        mod = neg_elbo(1 + k, enc[m][0], enc[m][1])
+        if masks is not None:
+            mod = masks[m] * mod
+        loss = loss + mod
+        metrics[m] = mod.mean()
+    return dict(loss=loss.mean(), metrics=metrics, joint_mu=jmu, joint_logvar=jlv)

@@ -34,7 +34,7 @@ import _reference_import as R
 R.install()
 import procedural as P
 from multivae.data.datasets.base import IncompleteDataset, MultimodalBaseDataset
-from multivae.models import (CRMVAE, JMVAE, MMVAE, MVAE, MVTCAE, CRMVAEConfig, JMVAEConfig, MMVAEConfig, MMVAEPlus, MMVAEPlusConfig, MoPoE,
+from multivae.models import (CRMVAE, DMVAE, DMVAEConfig, JMVAE, MMVAE, MVAE, MVTCAE, CRMVAEConfig, JMVAEConfig, MMVAEConfig, MMVAEPlus, MMVAEPlusConfig, MoPoE,
                              MoPoEConfig, MVAEConfig, MVTCAEConfig)
 from multivae.models.base import base_utils as ref_utils
 from multivae.models.base.base_config import BaseAEConfig
@@ -906,6 +906,72 @@ def crmvae_main():
     crmvae_case("crmvae_mnistsvhn", arch="mnistsvhn", B=8, beta=2.5, rescaling=False, masked=False, seed=1003)
 
 
+def dmvae_case(name, *, B, beta, S, rescaling, masked, seed, private_betas=None, dists=None):
+    """DMVAE with the default multi-latent MLPs."""
+    print(name)
+    dims, L = TINY_DIMS, TINY_L
+    data, masks = tiny_data(B, seed, masked)
+    for m, d in (dists or {}).items():
+        if d == "bernoulli":
+            data[m] = (data[m] > 0.5).astype(np.float32)
+    sdims = {m: S + i for i, m in enumerate(dims)}
+    shapes = P.mopoe_style_mlp_shapes(dims, L, sdims)
+    cfg = DMVAEConfig(n_modalities=4, latent_dim=L, input_dims=dict(dims), beta=beta, modalities_specific_dim=sdims,
+                      modalities_specific_betas=private_betas, uses_likelihood_rescaling=rescaling, decoders_dist=dists)
+    model = DMVAE(cfg)
+    sd_np = P.make_state_dict(shapes, seed)
+    load_weights(model, sd_np)
+    names = list(model.encoders.keys())
+    inputs = ref_dataset(data, masks)
+    model.train()
+    E = len(names) + 1
+    torch.manual_seed(seed)
+    noise = {"shared": torch.zeros(E, B, L), "private": {m: torch.zeros(E, B, sdims[m]) for m in names}}
+    for e in range(E):  # per ELBO: the shared draw, then one private draw per modality (dmvae_model.py:198-206)
+        noise["shared"][e] = torch.randn(B, L)
+        for m in names:
+            noise["private"][m][e] = torch.randn(B, sdims[m])
+    torch.manual_seed(seed)
+    out = model(inputs)
+    model.zero_grad()
+    out.loss.backward()
+    gref = ref_grads(model)
+    osd = oracle_sd(sd_np)
+    enc_f, dec_f = nets.build_default_mlp_multilatent(osd, dims)
+    tdata = {m: t(v) for m, v in data.items()}
+    tmasks = None if masks is None else {m: t(v) for m, v in masks.items()}
+    e_ = {m: enc_f[m](tdata[m]) for m in names}
+    o = elbo.dmvae_forward(e_, tdata, dec_f, noise, names=names, beta=beta, private_betas=private_betas,
+                           rescale=elbo.rescale_factors(dims, rescaling), dists=dists, masks=tmasks)
+    o["loss"].backward()
+    report("loss", out.loss, o["loss"])
+    assert set(out.metrics) == set(o["metrics"])
+    for k_ in out.metrics:
+        report(k_, out.metrics[k_], o["metrics"][k_])
+    cmp_grads("grads", gref, {k_: (v.grad if v.grad is not None else torch.zeros_like(v)) for k_, v in osd.items()})
+    arrays = dict(loss=out.loss.detach(), joint_mu=o["joint_mu"].detach(), joint_logvar=o["joint_logvar"].detach())
+    arrays["noise/shared"] = noise["shared"]
+    for m in names:
+        arrays["noise/private/" + m] = noise["private"][m]
+    for k_, v in out.metrics.items():
+        arrays["metric/" + k_] = v.detach()
+    if masks is not None:
+        for m, v in masks.items():
+            arrays["mask/" + m] = v
+    arrays.update(grad_stats(gref))
+    save(name, dict(model="DMVAE", arch="tiny", B=B, L=L, beta=beta, style_dims=sdims, private_betas=private_betas,
+                    rescaling=rescaling, masked=masked, seed=seed, names=names, dists=dists), arrays)
+
+
+def dmvae_main():
+    dmvae_case("dmvae_tiny_complete", B=6, beta=1.0, S=2, rescaling=False, masked=False, seed=1101)
+    dmvae_case("dmvae_tiny_betas_rescale", B=5, beta=2.5, S=3, rescaling=True, masked=False, seed=1102,
+               private_betas=dict(mod1=0.5, mod2=2.0, mod3=1.0, mod4=1.5),
+               dists=dict(mod1="normal", mod2="laplace", mod3="bernoulli", mod4="normal"))
+    dmvae_case("dmvae_tiny_masked", B=9, beta=1.5, S=2, rescaling=False, masked=True, seed=1103,
+               private_betas=dict(mod1=1.0, mod2=0.7, mod3=2.0, mod4=1.0))
+
+
 def nll_case(name, *, kind, arch, B, K, batch_size_K, seed, dists=None, family="normal", subset=None):
     """compute_joint_nll of the reference (K importance samples per data point, chunks of batch_size_K) against
     oracle.elbo.*_joint_nll on the replayed noise.  Stores the noise, the reference's NLL and the oracle's per-point
@@ -1087,6 +1153,8 @@ if __name__ == "__main__":
         nll_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "mvae":
         mvae_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "dmvae":
+        dmvae_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "crmvae":
         crmvae_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "categorical":
@@ -1102,3 +1170,4 @@ if __name__ == "__main__":
         mvae_main()
         mopoe_style_main()
         crmvae_main()
+        dmvae_main()

@@ -242,6 +242,27 @@ def test_crmvae(name):
     G.check_grads(a, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()}, rtol=1e-5)
 
 
+def dmvae_noise(a, names):
+    return {"shared": G.t(a["noise/shared"]), "private": {m: G.t(a["noise/private/" + m]) for m in names}}
+
+
+@pytest.mark.parametrize("name", G.DMVAE_CASES)
+def test_dmvae(name):
+    """DMVAE.forward (dmvae_model.py:152-240): joint + unimodal ELBOs with private latents, private betas, masks."""
+    cfg, a, dims, data, masks, sd, enc_f, dec_f = _prep(name)
+    names = cfg["names"]
+    e = {m: enc_f[m](data[m]) for m in names}
+    o = elbo.dmvae_forward(e, data, dec_f, dmvae_noise(a, names), names=names, beta=cfg["beta"],
+                           private_betas=cfg.get("private_betas"), rescale=elbo.rescale_factors(dims, cfg["rescaling"]),
+                           dists=cfg.get("dists"), masks=masks)
+    close(a["loss"], o["loss"])
+    close(a["joint_mu"], o["joint_mu"])
+    for k, v in o["metrics"].items():
+        close(a["metric/" + k], v)
+    o["loss"].backward()
+    G.check_grads(a, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()}, rtol=1e-5)
+
+
 def oracle_mvae(cfg, a, dims, data, masks, enc_f, dec_f):
     names = cfg["names"]
     e = {m: enc_f[m](data[m]) for m in names}
