@@ -205,13 +205,15 @@ class BaseMultiVAE(BaseModel):
 
     _NLL_INCOMPLETE = "The compute_joint_nll method is not yet implemented for incomplete datasets."
 
-    def _joint_nll(self, inputs, z, locs, sds, family=0, prior_loc=None, prior_sd=None):
+    def _joint_nll(self, inputs, z, locs, sds, family=0, prior_loc=None, prior_sd=None, private=None):
         """Importance-sampled -ln p(x) summed over the batch: the shared body of the reference's `compute_joint_nll`
         methods (mopoe_model.py:522-592, mmvae_model.py:399-441, mvtcae_model.py:249-289, joint_model.py:111-152).
         z [K,B,L] importance samples; q = uniform mixture of the experts (locs[e], sds[e]) [B,L].  The K axis is a
         kernel axis here (decoders on [K,b,L], one mvk_recon_nll_fwd, mvk_iwae_logw, mvk_iwae_reduce per chunk of
         data points) instead of a Python loop per data point and per `batch_size_K` samples; the likelihoods are
-        NOT rescaled, as in the reference."""
+        NOT rescaled, as in the reference.
+        private = {m: (w [K,B,S_m], loc [B,S_m], sd [B,S_m])}: modality-specific latents (mopoe_model.py:507-521,
+        :560-567): decoder m sees [z, w_m], and ln N(w_m; 0, I) - ln q(w_m | x_m) joins the log-weight."""
         names = list(inputs.data.keys())
         xs = [inputs.data[m].float().contiguous() for m in names]
         dists = [self.recon_dists[m][0] for m in names]
@@ -221,8 +223,17 @@ class BaseMultiVAE(BaseModel):
 
         def decode_rows(zc, b0, b1):
             K, b = zc.shape[0], zc.shape[1]
-            rec = kernels.run_branches(order, lambda m: self.decoders[m](zc).reconstruction, device)
-            return kernels.recon_nll_rows([rec[m] for m in names], [x[b0:b1] for x in xs], dists, scales, K, b)
+            if private is None:
+                rec = kernels.run_branches(order, lambda m: self.decoders[m](zc).reconstruction, device)
+                return kernels.recon_nll_rows([rec[m] for m in names], [x[b0:b1] for x in xs], dists, scales, K, b)
+            ws = {m: private[m][0][:, b0:b1].contiguous() for m in names}
+            rec = kernels.run_branches(order, lambda m: self.decoders[m](torch.cat([zc, ws[m]], dim=-1)).reconstruction,
+                                       device)
+            rows = kernels.recon_nll_rows([rec[m] for m in names], [x[b0:b1] for x in xs], dists, scales, K, b)
+            for m in names:  # -(ln p(w_m) - ln q(w_m | x_m)) as one more "row" of the log-weight
+                ratio = kernels.iwae_logw(ws[m], [], [private[m][1][b0:b1]], [private[m][2][b0:b1]])
+                rows.append(kernels.axpby(ratio, -1.0, None, 0.0))
+            return rows
 
         with torch.no_grad():
             return kernels.joint_nll(decode_rows, z, locs, sds, family, prior_loc, prior_sd)

@@ -206,14 +206,21 @@ class MoPoE(BaseMultiVAE):
         self.eval()
         if hasattr(inputs, "masks"):
             raise AttributeError(self._NLL_INCOMPLETE)
-        if self.multiple_latent_spaces:
-            raise NotImplementedError("compute_joint_nll with modality-specific latent spaces is not on the HIP path yet")
         with torch.no_grad():
-            _, outs, _ = self._posterior(inputs, int(K), noise=kwargs.get("noise"), want_stats=True)
+            enc, outs, (B, L, device, _) = self._posterior(inputs, int(K), noise=kwargs.get("noise"), want_stats=True)
             z, mus, lvs = outs[0], outs[2], outs[3]
             sds = kernels.std_from_logvar(lvs)
             S = mus.shape[0]
-            return self._joint_nll(inputs, z, [mus[i] for i in range(S)], [sds[i] for i in range(S)])
+            private = None
+            if self.multiple_latent_spaces:  # K private samples per modality too (:507-521); kwargs: style_noise
+                style_noise = kwargs.get("style_noise")
+                private = {}
+                for m in inputs.data:
+                    smu, slv = enc[m].style_embedding, enc[m].style_log_covariance
+                    ssd = kernels.std_from_logvar(slv)
+                    nz = self._noise((int(K), B, smu.shape[-1]), device, None if style_noise is None else style_noise[m])
+                    private[m] = (kernels.iwae_sample(smu, ssd, nz), smu, ssd)
+            return self._joint_nll(inputs, z, [mus[i] for i in range(S)], [sds[i] for i in range(S)], private=private)
 
     def _compute_joint_nll_from_subset_encoding(self, subset, inputs, K: int = 1000, batch_size_K: int = 100, **kwargs):
         """Joint NLL with ONE subset posterior as the importance distribution (mopoe_model.py:596-701): samples and

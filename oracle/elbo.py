@@ -513,7 +513,7 @@ def jmvae_forward(joint, enc, data, decoders, eps, *, names, alpha=0.1, beta=1.0
 # importance-sampled joint likelihood (compute_joint_nll)
 # ----------------------------------------------------------------------------------------------
 def iwae_joint_nll(z, data, decoders, experts, *, names, dists=None, scales=None, family="normal", prior=None,
-                   batch_size_K=100):
+                   batch_size_K=100, private=None):
     """-sum_i [ logsumexp_k ( sum_m ln p(x_m,i | z_ik) + ln p(z_ik) - ln q(z_ik | x_i) ) - ln K ].
 
     Follows the per-data-point / per-K-chunk loops shared by mopoe_model.py:522-592, mmvae_model.py:399-441,
@@ -525,6 +525,8 @@ def iwae_joint_nll(z, data, decoders, experts, *, names, dists=None, scales=None
       * the K samples are visited in chunks of batch_size_K, the chunk logsumexps are collected in a float32
         `torch.Tensor(lnpxs)` and combined by a second logsumexp minus ln K.
     prior: None = N(0, I) (`dist.Normal(0, 1)`), or (loc [1,L], scale [1,L]) of the latent family (MMVAE).
+    private: {m: (w [K,B,S_m], mu [B,S_m], logvar [B,S_m])} modality-specific latents of MoPoE (mopoe_model.py:507-521,
+    :543-567): decoder m sees [z, w_m]; ln N(w_m; 0, 1) joins ln p(z) and ln q(w_m | x_m) joins ln q.
     Returns (nll scalar, ll [B], lw [K,B]) -- the last two are intermediates for the kernel tests.
     """
     K, B, L = z.shape
@@ -539,8 +541,16 @@ def iwae_joint_nll(z, data, decoders, experts, *, names, dists=None, scales=None
             stop = min(start + batch_size_K, K)
             latents = z[start:stop, i]  # [k, L]
             lpx = 0
+            lpz_priv, lq_priv = 0, 0
             for m in names:
-                recon = decoders[m](latents)
+                full = latents
+                if private is not None:
+                    w_m = private[m][0][start:stop, i]
+                    full = torch.cat([latents, w_m], dim=-1)
+                    sd_m = torch.exp(0.5 * private[m][2][i])
+                    lpz_priv = lpz_priv + latent_log_prob("normal", w_m, torch.zeros(()), torch.ones(())).sum(-1)
+                    lq_priv = lq_priv + latent_log_prob("normal", w_m, private[m][1][i], sd_m).sum(-1)
+                recon = decoders[m](full)
                 x_m = data[m][i]
                 lp = recon_log_prob(dists.get(m, "normal"), recon, torch.stack([x_m] * len(recon)), scales.get(m, 1.0))
                 lpx = lpx + lp.reshape(recon.size(0), -1).sum(-1)
@@ -550,6 +560,7 @@ def iwae_joint_nll(z, data, decoders, experts, *, names, dists=None, scales=None
                 lpz = latent_log_prob(fam, latents, prior[0], prior[1]).sum(-1)
             lqs = torch.stack([latent_log_prob(fam, latents, loc[i], scale[i]).sum(-1) for loc, scale in experts])
             lqz = torch.logsumexp(lqs, dim=0) - math.log(len(experts))
+            lpz, lqz = lpz_priv + lpz, lq_priv + lqz
             w = lpx + lpz - lqz
             lw_i.append(w)
             lnpxs.append(torch.logsumexp(w, dim=0))
@@ -560,14 +571,18 @@ def iwae_joint_nll(z, data, decoders, experts, *, names, dists=None, scales=None
     return -ll.sum(), ll, torch.stack(lws, dim=1)
 
 
-def mopoe_joint_nll(enc, data, decoders, eps, *, names, dists=None, batch_size_K=100):
-    """MoPoE.compute_joint_nll, mopoe_model.py:467-594 (complete data, one latent space): samples from the
-    row-range-selected subset posterior (`inference()["joint"]`), scores them under the uniform mixture of all
-    subset posteriors.  eps [K,B,L]."""
+def mopoe_joint_nll(enc, data, decoders, eps, *, names, dists=None, batch_size_K=100, style_eps=None):
+    """MoPoE.compute_joint_nll, mopoe_model.py:467-594 (complete data): samples from the row-range-selected subset
+    posterior (`inference()["joint"]`), scores them under the uniform mixture of all subset posteriors.  eps [K,B,L];
+    style_eps {m: [K,B,S_m]} with modality-specific latent spaces (enc[m] = (mu, lv, style_mu, style_lv))."""
     inf = mopoe_inference(enc, names)
     z = rsample(inf["joint_mu"], inf["joint_logvar"], eps)
     experts = [(inf["mus"][s], torch.exp(0.5 * inf["logvars"][s])) for s in range(inf["mus"].shape[0])]
-    return iwae_joint_nll(z, data, decoders, experts, names=names, dists=dists, batch_size_K=batch_size_K)
+    private = None
+    if style_eps is not None:
+        private = {m: (rsample(enc[m][2], enc[m][3], style_eps[m]), enc[m][2], enc[m][3]) for m in names}
+    return iwae_joint_nll(z, data, decoders, experts, names=names, dists=dists, batch_size_K=batch_size_K,
+                          private=private)
 
 
 def mvtcae_joint_nll(enc, data, decoders, eps, *, names, batch_size_K=100):

@@ -1125,6 +1125,38 @@ def nll_mmvaeplus_case(name, *, B, K, S, family, seed):
                     learn_shared_prior=True), arrays)
 
 
+def nll_mopoe_style_case(name, *, B, K, batch_size_K, S, seed):
+    """MoPoE.compute_joint_nll with modality-specific latent spaces (mopoe_model.py:507-521, :543-567)."""
+    print(name)
+    dims, L = TINY_DIMS, TINY_L
+    data, _ = tiny_data(B, seed, False)
+    sdims = {m: S + i for i, m in enumerate(dims)}
+    shapes = P.mopoe_style_mlp_shapes(dims, L, sdims)
+    model = MoPoE(MoPoEConfig(n_modalities=4, latent_dim=L, input_dims=dict(dims), modalities_specific_dim=sdims))
+    sd_np = P.make_state_dict(shapes, seed)
+    load_weights(model, sd_np)
+    names = list(model.encoders.keys())
+    inputs = ref_dataset(data, None)
+    torch.manual_seed(seed)
+    noise = torch.randn(K, B, L)
+    style_eps = {m: torch.randn(K, B, sdims[m]) for m in inputs.data}
+    torch.manual_seed(seed)
+    nll = model.compute_joint_nll(inputs, K=K, batch_size_K=batch_size_K)
+    osd = oracle_sd(sd_np, requires_grad=False)
+    enc_f, dec_f = nets.build_default_mlp_multilatent(osd, dims)
+    tdata = {m: t(v) for m, v in data.items()}
+    with torch.no_grad():
+        e = {m: enc_f[m](tdata[m]) for m in names}
+        o = elbo.mopoe_joint_nll(e, tdata, dec_f, noise, names=names, batch_size_K=batch_size_K, style_eps=style_eps)
+    report("nll", nll, o[0])
+    arrays = dict(noise=noise, nll=torch.as_tensor(nll).detach(), ll=o[1], lw=o[2])
+    for m in names:
+        arrays["style_eps/" + m] = style_eps[m]
+    save(name, dict(model="MoPoE", arch="tiny", B=B, L=L, K=1, nll_K=K, batch_size_K=batch_size_K, seed=seed, names=names,
+                    dists=None, family="normal", sampled=None, subset=None, masked=False, rescaling=False, beta=1.0,
+                    beta_style=1.0, style_dims=sdims), arrays)
+
+
 def nll_main():
     nll_case("nll_mopoe_tiny", kind="mopoe", arch="tiny", B=5, K=7, batch_size_K=3, seed=701,
              dists=dict(mod1="normal", mod2="laplace", mod3="bernoulli", mod4="normal"))
@@ -1138,6 +1170,7 @@ def nll_main():
              family="laplace_with_softmax")
     nll_case("nll_mmvae_mnistsvhn_laplace", kind="mmvae", arch="mnistsvhn", B=2, K=10, batch_size_K=10, seed=707,
              family="laplace_with_softmax")
+    nll_mopoe_style_case("nll_mopoe_tiny_style", B=4, K=7, batch_size_K=3, S=2, seed=712)
     nll_mmvaeplus_case("nll_mmvaeplus_tiny_laplace", B=4, K=14, S=3, family="laplace_with_softmax", seed=708)
     nll_mmvaeplus_case("nll_mmvaeplus_tiny_softplus", B=3, K=9, S=2, family="normal_with_softplus", seed=709)
 

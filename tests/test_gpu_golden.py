@@ -619,3 +619,14 @@ def test_dmvae_golden(name):
         assert enc.modalities_z["mod1"].shape == (3, cfg["B"], cfg["style_dims"]["mod1"])
         gen = model.generate_from_prior(5)
         assert gen.z.shape == (5, cfg["L"]) and gen.modalities_z["mod3"].shape == (5, cfg["style_dims"]["mod3"])
+
+
+@pytest.mark.parametrize("name", G.NLL_STYLE_CASES)
+def test_joint_nll_mopoe_private_latents_golden(name):
+    """MoPoE.compute_joint_nll with modality-specific latent spaces on the HIP path: decoders on [z, w_m], the private
+    log-density ratios as extra rows of mvk_iwae_logw."""
+    cfg, a, dims, data, masks, sd_np, model, inputs, d = prep(name)
+    names = cfg["names"]
+    nll = model.compute_joint_nll(inputs, K=cfg["nll_K"], noise=G.t(a["noise"]).to(d),
+                                  style_noise={m: G.t(a["style_eps/" + m]).to(d) for m in names})
+    check(a["nll"], nll, "nll")

@@ -183,6 +183,19 @@ def test_joint_nll(name):
     close(a["nll"], nll_one_chunk, rtol=2e-6)
 
 
+@pytest.mark.parametrize("name", G.NLL_STYLE_CASES)
+def test_joint_nll_mopoe_private_latents(name):
+    """MoPoE.compute_joint_nll with modality-specific latent spaces (mopoe_model.py:507-521, :543-567)."""
+    cfg, a, dims, data, masks, sd, enc_f, dec_f = _prep(name)
+    names = cfg["names"]
+    with torch.no_grad():
+        e = {m: enc_f[m](data[m]) for m in names}
+        nll, ll, lw = elbo.mopoe_joint_nll(e, data, dec_f, G.t(a["noise"]), names=names, batch_size_K=cfg["batch_size_K"],
+                                           style_eps={m: G.t(a["style_eps/" + m]) for m in names})
+    close(a["nll"], nll, rtol=1e-6)
+    close(a["ll"], ll, rtol=1e-6)
+
+
 def nll_plus_noise(a, kept):
     return {c: {k.split("/")[2]: G.t(a[k]) for k in a if k.startswith(f"noise/{c}/")} for c in kept}
 
