@@ -282,3 +282,42 @@ def test_resume_from_checkpoint_continues_the_same_training(tmp_path):
     assert t2.training_dir == info["training_dir"]
     assert os.path.isdir(os.path.join(t2.training_dir, "checkpoint_epoch_3"))
     assert hist[-1]["train_epoch_loss"] < float(json.load(open(os.path.join(ck, "metrics_best_model.json")))["train_epoch_loss"])
+
+
+@pytest.mark.parametrize("model_name", ["MVAE", "CRMVAE", "DMVAE"])
+@pytest.mark.parametrize("masked", [False, True])
+def test_trainer_runs_the_poe_family(tmp_path, model_name, masked):
+    """MVAE / CRMVAE / DMVAE through BaseTrainer on complete and incomplete data: finite decreasing loss, metrics
+    averaged over batches, checkpoint reloadable through AutoModel."""
+    from multivae_amd.data.datasets.base import IncompleteDataset, MultimodalBaseDataset
+    from multivae_amd.models import (CRMVAE, DMVAE, MVAE, AutoModel, CRMVAEConfig, DMVAEConfig, MVAEConfig)
+    from multivae_amd.trainers import BaseTrainer, BaseTrainerConfig
+
+    torch.manual_seed(0)
+    n = 160
+    dims = dict(a=(12,), b=(2, 5), c=(7,))
+    data = {m: torch.rand(n, *d) for m, d in dims.items()}
+    if masked:
+        masks = {m: torch.rand(n) > 0.3 for m in dims}
+        masks["a"][:] = True
+        ds = IncompleteDataset(data=data, masks=masks)
+    else:
+        ds = MultimodalBaseDataset(data=data)
+    common = dict(n_modalities=3, latent_dim=6, input_dims=dims)
+    if model_name == "MVAE":
+        model = MVAE(MVAEConfig(k=1, warmup=2, **common))
+    elif model_name == "CRMVAE":
+        model = CRMVAE(CRMVAEConfig(**common))
+    else:
+        model = DMVAE(DMVAEConfig(modalities_specific_dim=dict(a=2, b=3, c=2), **common))
+    cfg = BaseTrainerConfig(output_dir=str(tmp_path), per_device_train_batch_size=32, num_epochs=4, learning_rate=2e-3,
+                            steps_saving=4)
+    trainer = BaseTrainer(model, train_dataset=ds, training_config=cfg)
+    hist = trainer.train()
+    losses = [h["train_epoch_loss"] for h in hist]
+    assert all(np.isfinite(v) for v in losses), losses
+    if model_name != "MVAE":  # MVAE's KL weight rises during its warm-up epochs
+        assert losses[-1] < losses[0], losses
+    assert all(np.isfinite(float(v)) for h in hist for v in h.values())
+    back = AutoModel.load_from_folder(os.path.join(trainer.training_dir, "final_model"))
+    assert type(back) is type(model)
