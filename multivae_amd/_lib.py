@@ -158,9 +158,15 @@ def check(rc, what):
         raise MvkError(f"{what} failed with code {rc}")
 
 
+_SYNC_DEBUG = os.environ.get("MVK_SYNC_DEBUG", "")  # debugging aid: "1" = device sync after every launch, or a
+# comma list of entry-point names to sync after
+
+
 def call(name, *args):
     lib = load()
     check(getattr(lib, name)(*args), name)
+    if _SYNC_DEBUG and (_SYNC_DEBUG == "1" or name in _SYNC_DEBUG.split(",")):
+        torch.cuda.synchronize()
 
 
 def require_gpu_tensor(t, name="tensor"):

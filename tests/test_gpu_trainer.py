@@ -321,3 +321,58 @@ def test_trainer_runs_the_poe_family(tmp_path, model_name, masked):
     assert all(np.isfinite(float(v)) for h in hist for v in h.values())
     back = AutoModel.load_from_folder(os.path.join(trainer.training_dir, "final_model"))
     assert type(back) is type(model)
+
+
+def test_full_size_step_properties():
+    """BASELINE.json headline size (MoPoE MnistSvhn, B = 512, K = 10), where the oracle would need minutes: properties
+    that do not depend on the size.
+      * K-linearity: the K-sample loss is the mean over k of the single-sample losses on the same noise rows (same
+        analytic KL);
+      * K-linearity of every parameter gradient, checked with IDENTICAL launch shapes (sample k repeated K times): a
+        K = 1 run takes other kernels, whose last-bit differences flip the ReLU mask of a unit with a ~1e-10
+        pre-activation now and then, which moves a cancelling gradient sum by a whole sample's contribution (measured:
+        one flip in 8.4 M units changes decoders.svhn.dec.0.weight by 2 % of its largest entry -- in fp32 on any device);
+      * the K axis is a batch axis of the decoders and of the reconstruction kernel: permuting the K noise slabs leaves
+        loss and gradients unchanged (up to summation order);
+      * hipGraph replay = eager launches, bit for bit in the loss."""
+    from multivae_amd.data.datasets.base import DatasetOutput
+    from multivae_amd.trainers import FlatParams, GraphedStep
+
+    d = torch.device("cuda:0")
+    B, K, L = 512, 10, 20
+    model = _mnist_svhn_mopoe(d, K=K, L=L)
+    g = torch.Generator().manual_seed(5)
+    inputs = DatasetOutput(data=dict(mnist=torch.rand(B, 1, 28, 28, generator=g).to(d),
+                                     svhn=torch.rand(B, 3, 32, 32, generator=g).to(d)))
+    eps = torch.randn(K, B, L, generator=g).to(d)
+
+    def run(noise, Kk):
+        model.zero_grad(set_to_none=True)
+        out = model(inputs, noise=noise, K=Kk)
+        out.loss.backward()
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        return float(out.loss.detach()), grads, out
+
+    def worst(ga, gb):
+        return max(float((ga[n] - gb[n]).abs().max() / gb[n].abs().max().clamp_min(1e-30)) for n in ga)
+
+    loss_k, grads_k, out_k = run(eps, K)
+    single = sum(run(eps[k:k + 1].contiguous(), 1)[0] for k in range(K)) / K
+    assert abs(loss_k - single) <= 2e-6 * abs(loss_k), (loss_k, single)
+    acc_loss, acc = 0.0, None
+    for k in range(K):
+        lk, gk, _ = run(eps[k:k + 1].expand(K, B, L).contiguous(), K)
+        acc_loss += lk / K
+        acc = gk if acc is None else {n: acc[n] + gk[n] for n in acc}
+    assert abs(loss_k - acc_loss) <= 2e-6 * abs(loss_k), (loss_k, acc_loss)
+    assert worst(grads_k, {n: v / K for n, v in acc.items()}) <= 2e-5
+    perm = torch.randperm(K, generator=g)
+    loss_p, grads_p, _ = run(eps[perm].contiguous(), K)
+    assert abs(loss_p - loss_k) <= 1e-6 * abs(loss_k)
+    assert worst(grads_p, grads_k) <= 2e-5
+    # graph replay on the same noise
+    flat = FlatParams(model)
+    gs = GraphedStep(model, flat, inputs, noise=eps)
+    out_g = gs(inputs, eps)
+    assert float(out_g.loss.detach()) == loss_k
+    assert float(out_g.metrics["joint_divergence"]) == float(out_k.metrics["joint_divergence"])
