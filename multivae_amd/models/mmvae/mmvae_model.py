@@ -134,3 +134,15 @@ class MMVAE(BaseMultiVAE):
             prior_sd = kernels.std_from_logvar(self.prior_log_var, self._family)
             return self._joint_nll(inputs, z, [post[m][0] for m in names], [post[m][1] for m in names],
                                    family=self._family, prior_loc=self.prior_mean, prior_sd=prior_sd)
+
+    def generate_from_prior(self, n_samples, **kwargs):
+        """n samples of the (learnable) prior `prior_dist(*pz_params)` (mmvae_model.py:470-474).  kwargs: noise [n, D]."""
+        with torch.no_grad():
+            mean, std = self.pz_params
+            D = mean.shape[-1]
+            n = max(int(n_samples), 1)
+            noise = kwargs.get("noise")
+            noise = self._noise((n, 1, D), mean.device, None if noise is None else noise.reshape(n, 1, D),
+                                uniform=self._family == 1)
+            z = kernels.iwae_sample(mean.detach().reshape(1, D), std.detach().reshape(1, D), noise, self._family)
+        return ModelOutput(z=z.reshape(n, D).squeeze() if n_samples > 1 else z.reshape(D), one_latent_space=True)

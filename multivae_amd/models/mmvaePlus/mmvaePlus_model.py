@@ -216,3 +216,15 @@ class MMVAEPlus(BaseMultiVAE):
         # n_modalities (mmvaePlus_model.py:239): a constant shift of every log-weight
         shift = math.log(self.n_modalities) - math.log(len(mods))
         return -(ll.sum() + B * shift)
+
+    def generate_from_prior(self, n_samples, **kwargs):
+        """n samples of the (learnable) prior `prior_dist(*pz_params)` (mmvaePlus_model.py:453-456).  kwargs: noise [n, D]."""
+        with torch.no_grad():
+            mean, std = self.pz_params
+            D = mean.shape[-1]
+            n = max(int(n_samples), 1)
+            noise = kwargs.get("noise")
+            noise = self._noise((n, 1, D), mean.device, None if noise is None else noise.reshape(n, 1, D),
+                                uniform=self._family == 1)
+            z = kernels.iwae_sample(mean.detach().reshape(1, D), std.detach().reshape(1, D), noise, self._family)
+        return ModelOutput(z=z.reshape(n, D).squeeze() if n_samples > 1 else z.reshape(D), one_latent_space=True)
