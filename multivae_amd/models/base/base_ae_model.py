@@ -203,6 +203,34 @@ class BaseMultiVAE(BaseModel):
     def compute_joint_nll(self, inputs, K: int = 1000, batch_size_K: int = 100):
         raise NotImplementedError
 
+    def compute_cond_nll(self, inputs, subset, pred_mods, k_iwae=1000, **kwargs):
+        """-mean_b [ logsumexp_k ln p(x_pred,b | z_kb) - ln K ], z_kb ~ q(z | x_subset,b), per modality of pred_mods
+        (base_ae_model.py:396-442).  The reference calls encode() + decode() k_iwae times; here the k_iwae samples of
+        encode(N = k_iwae) are the leading axis of one decoder pass per chunk of data points (mvk_recon_nll_fwd rows,
+        mvk_iwae_reduce).  kwargs: noise [K,B,L] (forwarded to encode)."""
+        if isinstance(pred_mods, str):
+            pred_mods = [pred_mods]
+        K = int(k_iwae)
+        with torch.no_grad():
+            enc = self.encode(inputs, subset, N=K, **kwargs)
+            z = enc.z if K > 1 else enc.z.unsqueeze(0)
+            B = z.shape[1]
+            xs = {m: inputs.data[m].float().contiguous() for m in pred_mods}
+            ll = {m: torch.empty(B, dtype=torch.float32, device=z.device) for m in pred_mods}
+            step = max(1, kernels.IWAE_ROWS_BUDGET // K)
+            for b0 in range(0, B, step):
+                b1 = min(B, b0 + step)
+                for m in pred_mods:
+                    zc = z[:, b0:b1]
+                    if not enc.one_latent_space:
+                        w = enc.modalities_z[m] if K > 1 else enc.modalities_z[m].unsqueeze(0)
+                        zc = torch.cat([zc, w[:, b0:b1]], dim=-1)
+                    rec = self.decoders[m](zc.contiguous()).reconstruction
+                    rows = kernels.recon_nll_rows([rec], [xs[m][b0:b1]], [self.recon_dists[m][0]],
+                                                  [self.recon_dists[m][1]], K, b1 - b0)
+                    kernels.iwae_reduce([kernels.axpby(rows[0], -1.0, None, 0.0)], out=ll[m][b0:b1])
+            return {m: -ll[m].sum() / B for m in pred_mods}
+
     _NLL_INCOMPLETE = "The compute_joint_nll method is not yet implemented for incomplete datasets."
 
     def _joint_nll(self, inputs, z, locs, sds, family=0, prior_loc=None, prior_sd=None, private=None):
@@ -244,6 +272,22 @@ class BaseMultiVAE(BaseModel):
         return ModelOutput(z=torch.randn(shape, device=dev), one_latent_space=True)
 
     # -- shared helpers for the HIP forward passes ------------------------------------------------------------
+    def _gaussian_encoding(self, mu, log_var, N, return_mean, flatten, noise=None):
+        """`rsample_from_gaussian(mu, log_var, N, return_mean, flatten)` (base_utils.py:150-172) for the encode()
+        helpers, on mvk_iwae_sample; noise [N,B,L] (or [B,L] for N == 1) replaces the N(0,1) draw."""
+        if return_mean:
+            z = torch.stack([mu] * N) if N > 1 else mu
+        else:
+            B, L = mu.shape
+            if noise is not None and noise.dim() == 2:
+                noise = noise.unsqueeze(0)
+            z = kernels.iwae_sample(mu, kernels.std_from_logvar(log_var), self._noise((N, B, L), mu.device, noise))
+            if N == 1:
+                z = z[0]
+        if N > 1 and flatten:
+            z = z.reshape(-1, *z.shape[2:])
+        return z
+
     @staticmethod
     def _noise(shape, device, noise=None, uniform=False):
         """Noise is an explicit kernel input; by default it is drawn from torch's generator."""

@@ -69,13 +69,7 @@ class JMVAE(BaseJointModel):
             else:
                 out = self.encoders[cond_mod[0]](inputs.data[cond_mod[0]])
                 mu, lv = out.embedding, out.log_covariance
-            if return_mean:
-                z = torch.stack([mu] * N) if N > 1 else mu
-            else:
-                shape = (N, *mu.shape) if N > 1 else mu.shape
-                z = mu + torch.exp(0.5 * lv) * torch.randn(shape, device=mu.device)
-            if N > 1 and flatten:
-                z = z.reshape(-1, *z.shape[2:])
+            z = self._gaussian_encoding(mu, lv, N, return_mean, flatten, kwargs.get("noise"))
         return ModelOutput(z=z, one_latent_space=True)
 
     def _poe_subset(self, subset, data):

@@ -153,13 +153,7 @@ class MVAE(BaseMultiVAE):
         flatten = kwargs.pop("flatten", False)
         with torch.no_grad():
             mu, log_var = self.compute_mu_log_var_subset(inputs, cond_mod)
-            if return_mean:
-                z = torch.stack([mu] * N) if N > 1 else mu
-            else:
-                shape = (N, *mu.shape) if N > 1 else mu.shape
-                z = mu + torch.exp(0.5 * log_var) * torch.randn(shape, device=mu.device)
-            if N > 1 and flatten:
-                z = z.reshape(-1, *z.shape[2:])
+            z = self._gaussian_encoding(mu, log_var, N, return_mean, flatten, kwargs.get("noise"))
         return ModelOutput(z=z, one_latent_space=True)
 
     def compute_joint_nll(self, inputs, K: int = 1000, batch_size_K: int = 100, **kwargs):

@@ -86,12 +86,5 @@ class MVTCAE(BaseMultiVAE):
         with torch.no_grad():
             _, outs, _ = self._posterior(cond_inputs, 1, mods=list(cond_mod))
             mu, log_var = outs[3], outs[4]
-            flatten = kwargs.pop("flatten", False)
-            if return_mean:
-                z = torch.stack([mu] * N) if N > 1 else mu
-            else:
-                shape = (N, *mu.shape) if N > 1 else mu.shape
-                z = mu + torch.exp(0.5 * log_var) * torch.randn(shape, device=mu.device)
-            if N > 1 and flatten:
-                z = z.reshape(-1, *z.shape[2:])
+            z = self._gaussian_encoding(mu, log_var, N, return_mean, kwargs.pop("flatten", False), kwargs.get("noise"))
         return ModelOutput(z=z, one_latent_space=True)

@@ -844,3 +844,19 @@ def dmvae_forward(enc, data, decoders, noise, *, names, beta=1.0, private_betas=
         loss = loss + mod
         metrics[m] = mod.mean()
     return dict(loss=loss.mean(), metrics=metrics, joint_mu=jmu, joint_logvar=jlv)
+
+
+def cond_nll(z, data, decoders, *, pred_mods, dists=None, scales=None):
+    """BaseMultiVAE.compute_cond_nll, base_ae_model.py:396-442: z [K,B,L] are the K conditional encodings (one
+    `encode(inputs, subset)` call per k in the reference); per predicted modality
+    -(1/B) sum_b [ logsumexp_k sum_d log p(x_b | dec(z_kb)) - ln K ]  (unrescaled log-probabilities)."""
+    dists = dists or {}
+    scales = scales or {}
+    K = z.shape[0]
+    out = {}
+    for m in pred_mods:
+        lp = torch.stack([-_row_nll(dists.get(m, "normal"), decoders[m](z[k]), data[m], 1.0, scales.get(m, 1.0))
+                          for k in range(K)])
+        ll = torch.logsumexp(lp, dim=0) - math.log(K)
+        out[m] = -torch.sum(ll) / len(ll)
+    return out

@@ -972,6 +972,53 @@ def dmvae_main():
                private_betas=dict(mod1=1.0, mod2=0.7, mod3=2.0, mod4=1.0))
 
 
+def cond_nll_case(name, *, kind, B, K, subset, pred, seed, dists=None):
+    """compute_cond_nll of the reference (base_ae_model.py:396-442): K encode() + decode() rounds."""
+    print(name)
+    dims, L = TINY_DIMS, TINY_L
+    data, _ = tiny_data(B, seed, False)
+    for m, d in (dists or {}).items():
+        if d == "bernoulli":
+            data[m] = (data[m] > 0.5).astype(np.float32)
+    shapes = P.jmvae_mlp_shapes(dims, L) if kind == "jmvae" else P.default_mlp_shapes(dims, L)
+    common = dict(n_modalities=4, latent_dim=L, input_dims=dict(dims), decoders_dist=dists)
+    model = dict(mopoe=lambda: MoPoE(MoPoEConfig(**common)), mvtcae=lambda: MVTCAE(MVTCAEConfig(**common)),
+                 jmvae=lambda: JMVAE(JMVAEConfig(**common)), mvae=lambda: MVAE(MVAEConfig(**common)))[kind]()
+    sd_np = P.make_state_dict(shapes, seed)
+    load_weights(model, sd_np)
+    names = list(model.encoders.keys())
+    inputs = ref_dataset(data, None)
+    model.eval()
+    torch.manual_seed(seed)
+    noise = torch.stack([torch.randn(B, L) for _ in range(K)])  # one rsample per encode() call
+    torch.manual_seed(seed)
+    cn = model.compute_cond_nll(inputs, subset, pred, k_iwae=K)
+    osd = oracle_sd(sd_np, requires_grad=False)
+    enc_f, dec_f = nets.build_default_mlp(osd, dims)
+    tdata = {m: t(v) for m, v in data.items()}
+    with torch.no_grad():
+        z = model.encode(inputs, subset, return_mean=True).z  # posterior mean from the reference ...
+        torch.manual_seed(seed)
+        zs = torch.stack([model.encode(inputs, subset).z for _ in range(K)])  # ... and the K samples it drew
+        o = elbo.cond_nll(zs, tdata, dec_f, pred_mods=pred, dists=dists)
+    for m in pred:
+        report("cond_nll " + m, cn[m], o[m])
+    arrays = dict(noise=noise, z=zs, z_mean=z)
+    for m in pred:
+        arrays["cnll/" + m] = torch.as_tensor(cn[m]).detach()
+    save(name, dict(model=dict(mopoe="MoPoE", mvtcae="MVTCAE", jmvae="JMVAE", mvae="MVAE")[kind], arch="tiny", B=B, L=L,
+                    K=1, cond_K=K, subset=subset, pred=pred, seed=seed, names=names, dists=dists, masked=False,
+                    rescaling=False, beta=1.0, alpha=0.1, warmup=10, k=0, subsampling=True), arrays)
+
+
+def cond_nll_main():
+    cond_nll_case("cnll_mopoe_tiny", kind="mopoe", B=5, K=6, subset=["mod1", "mod3"], pred=["mod2", "mod4"], seed=1201,
+                  dists=dict(mod1="normal", mod2="laplace", mod3="bernoulli", mod4="normal"))
+    cond_nll_case("cnll_mvtcae_tiny", kind="mvtcae", B=4, K=5, subset=["mod2"], pred=["mod1"], seed=1202)
+    cond_nll_case("cnll_jmvae_tiny", kind="jmvae", B=4, K=4, subset=["mod1", "mod2", "mod3", "mod4"], pred=["mod3"], seed=1203)
+    cond_nll_case("cnll_mvae_tiny", kind="mvae", B=6, K=5, subset=["mod4", "mod2"], pred=["mod1", "mod2"], seed=1204)
+
+
 def nll_case(name, *, kind, arch, B, K, batch_size_K, seed, dists=None, family="normal", subset=None):
     """compute_joint_nll of the reference (K importance samples per data point, chunks of batch_size_K) against
     oracle.elbo.*_joint_nll on the replayed noise.  Stores the noise, the reference's NLL and the oracle's per-point
@@ -1186,6 +1233,8 @@ if __name__ == "__main__":
         nll_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "mvae":
         mvae_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "cnll":
+        cond_nll_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "dmvae":
         dmvae_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "crmvae":
@@ -1204,3 +1253,4 @@ if __name__ == "__main__":
         mopoe_style_main()
         crmvae_main()
         dmvae_main()
+        cond_nll_main()

@@ -35,6 +35,7 @@ MVAE_CASES = ["mvae_tiny_subsampling_k2", "mvae_tiny_joint_only_rescale", "mvae_
 CRMVAE_CASES = ["crmvae_tiny_complete", "crmvae_tiny_masked_rescale", "crmvae_mnistsvhn"]
 DMVAE_CASES = ["dmvae_tiny_complete", "dmvae_tiny_betas_rescale", "dmvae_tiny_masked"]
 NLL_STYLE_CASES = ["nll_mopoe_tiny_style"]
+COND_NLL_CASES = ["cnll_mopoe_tiny", "cnll_mvtcae_tiny", "cnll_jmvae_tiny", "cnll_mvae_tiny"]
 NLL_MMVAEPLUS_CASES = ["nll_mmvaeplus_tiny_laplace", "nll_mmvaeplus_tiny_softplus"]
 
 

@@ -653,3 +653,31 @@ def test_mmvae_generate_from_prior_uses_the_learned_prior():
         ref = E.latent_rsample("laplace_with_softmax" if lap else "normal", torch.zeros(1, D), E.mmvae_std(plv, fam), noise)
         check(ref.numpy(), z, f"{name} prior samples")
         assert model.generate_from_prior(1).z.shape == (D,)
+
+
+@pytest.mark.parametrize("name", G.COND_NLL_CASES)
+def test_cond_nll_golden(name):
+    """compute_cond_nll on the HIP path: encode(N = K) on the recorded noise reproduces the reference's K encodings, the
+    conditional likelihood of every predicted modality matches, also with one data point per pass."""
+    from multivae_amd import kernels
+
+    cfg, a, dims, data, masks, sd_np, model, inputs, d = prep(name)
+    model.eval()
+    K = cfg["cond_K"]
+    noise = G.t(a["noise"]).to(d)
+    check(a["z"], model.encode(inputs, cfg["subset"], N=K, noise=noise).z, "K conditional encodings")
+    check(a["z_mean"], model.encode(inputs, cfg["subset"], return_mean=True).z, "posterior mean")
+    cn = model.compute_cond_nll(inputs, cfg["subset"], cfg["pred"], k_iwae=K, noise=noise)
+    assert set(cn) == set(cfg["pred"])
+    for m in cfg["pred"]:
+        check(a["cnll/" + m], cn[m], "cond nll " + m)
+    old = kernels.IWAE_ROWS_BUDGET
+    kernels.IWAE_ROWS_BUDGET = K
+    try:
+        cn1 = model.compute_cond_nll(inputs, cfg["subset"], cfg["pred"], k_iwae=K, noise=noise)
+    finally:
+        kernels.IWAE_ROWS_BUDGET = old
+    for m in cfg["pred"]:
+        check(a["cnll/" + m], cn1[m], "cond nll (one point per pass) " + m)
+    one = model.compute_cond_nll(inputs, cfg["subset"], cfg["pred"][0], k_iwae=1)
+    assert torch.isfinite(one[cfg["pred"][0]])

@@ -196,6 +196,16 @@ def test_joint_nll_mopoe_private_latents(name):
     close(a["ll"], ll, rtol=1e-6)
 
 
+@pytest.mark.parametrize("name", G.COND_NLL_CASES)
+def test_cond_nll(name):
+    """compute_cond_nll (base_ae_model.py:396-442) restated on the K encodings the reference drew."""
+    cfg, a, dims, data, masks, sd, enc_f, dec_f = _prep(name)
+    with torch.no_grad():
+        o = elbo.cond_nll(G.t(a["z"]), data, dec_f, pred_mods=cfg["pred"], dists=cfg.get("dists"))
+    for m in cfg["pred"]:
+        close(a["cnll/" + m], o[m], rtol=1e-6)
+
+
 def nll_plus_noise(a, kept):
     return {c: {k.split("/")[2]: G.t(a[k]) for k in a if k.startswith(f"noise/{c}/")} for c in kept}
 
