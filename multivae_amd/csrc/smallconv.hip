@@ -13,9 +13,9 @@
 
 #ifndef MVK_SMALL_FWD_THREADS
 // Threads per workgroup (LDS allows 2 workgroups per CU either way).  Measured inside the MoPoE step (B=512, 3x32 ch):
-// forward 89 us at 256 threads -> 67 us at 512 (more loads in flight); backward 152 us at 256 -> 188 us at 512 (the
+// forward 89 us at 256 threads -> 67 us at 512 -> 62 us at 1024 (more loads in flight, 56 VGPRs); backward 152 us at 256 -> 188 us at 512 (the
 // per-wave weight-gradient accumulators are replicated over twice the waves), so the two kernels differ.
-#define MVK_SMALL_FWD_THREADS 512
+#define MVK_SMALL_FWD_THREADS 1024
 #endif
 #ifndef MVK_SMALL_DOWN_THREADS
 #define MVK_SMALL_DOWN_THREADS 256
