@@ -1034,8 +1034,8 @@ int mvk_mvae_posterior_bwd(const float* const* mu, const float* const* lv, const
 
 int mvk_gauss_sample_kl_fwd(const float* mu, const float* lv, const float* eps, int K, int B, int L, float* w,
                             float* kl_rows, void* stream) {
-  if (!mu || !lv || !eps || !w || !kl_rows || K < 1 || L < 1) return MVK_EINVAL;
-  if (B <= 0) return B == 0 ? MVK_OK : MVK_EINVAL;
+  if (B == 0) return MVK_OK;
+  if (!mu || !lv || !eps || !w || !kl_rows || K < 1 || L < 1 || B < 0) return MVK_EINVAL;
   hipLaunchKernelGGL(gauss_sample_kl_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, mvk_stream(stream), mu, lv, eps, K, B,
                      L, w, kl_rows);
   MVK_CHECK_LAUNCH();

@@ -491,6 +491,7 @@ static int launch_auto(GemmDesc& d, float* ws, int64_t ws_floats, hipStream_t s)
 
 int mvk_linear_fwd(const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int act,
                    float* ws, int64_t ws_floats, void* stream) {
+  if (M == 0) return MVK_OK;  // empty batch: nothing to launch (torch hands out NULL for empty tensors)
   if (!X || !W || !Y || M < 0 || N <= 0 || K <= 0) return MVK_EINVAL;
   GemmDesc d{};
   plain_a(d.a, X, K, 1, M, K);
@@ -508,6 +509,7 @@ int mvk_linear_fwd(const float* X, const float* W, const float* b, float* Y, int
 int mvk_linear_bwd_data(const float* dY, const float* W, float* dX, int M, int N, int K, const float* y_out,
                         int y_act, const float* prev_out, int prev_act, int accumulate, float* colsum_acc, float* ws,
                         int64_t ws_floats, void* stream) {
+  if (M == 0) return MVK_OK;  // empty batch: nothing to launch (torch hands out NULL for empty tensors)
   if (!dY || !W || !dX || M < 0 || N <= 0 || K <= 0 || (colsum_acc && accumulate)) return MVK_EINVAL;
   GemmDesc d{};
   plain_a(d.a, dY, N, 1, M, N);  // reduce over n
@@ -625,6 +627,7 @@ int mvk_gemm(const float* A, const float* B, float* C, int M, int N, int K, int 
 int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w, int Cu,
                      int Cv, int act, int u_nchw, const float* u_act_src, int u_act, const float* v_act_src,
                      int v_act, float* colsum_acc, float* ws, int64_t ws_floats, int fmt, void* stream) {
+  if (n == 0) return MVK_OK;  // empty batch: nothing to launch (torch hands out NULL for empty tensors)
   if (!U || !Wdown || !V || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0) return MVK_EINVAL;
   if ((fmt & ~MVK_FMT_IN_BF3) || ((fmt & MVK_FMT_IN_BF3) && (u_nchw || u_act_src))) return MVK_EINVAL;
   if (u_nchw && !u_act_src && !v_act_src && !colsum_acc) {  // the network-input layer
@@ -664,6 +667,7 @@ int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, floa
 int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U, int n, int h, int w, int Cu,
                    int Cv, int act, int u_nchw, const float* u_act_src, int u_act, float* colsum_acc, float* ws,
                    int64_t ws_floats, int fmt, void* stream) {
+  if (n == 0) return MVK_OK;  // empty batch: nothing to launch (torch hands out NULL for empty tensors)
   if (!V || !Wup || !U || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0 || (colsum_acc && u_nchw)) return MVK_EINVAL;
   if (fmt & ~MVK_FMT_IN_BF3) return MVK_EINVAL;
   GemmDesc d{};

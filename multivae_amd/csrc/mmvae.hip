@@ -598,9 +598,9 @@ int mvk_mmvae_latent_bwd(const float* const* mu, const float* const* sd, const f
 
 int mvk_iwae_sample(const float* loc, const float* sd, const float* noise, int K, int B, int L, int family, float* z,
                     void* stream) {
+  if (K == 0 || B == 0) return MVK_OK;
   if (!loc || !sd || !noise || !z || K < 0 || B < 0 || L < 1 || family < 0 || family > 2) return MVK_EINVAL;
   const long long n = (long long)K * B * L;
-  if (n == 0) return MVK_OK;
   hipLaunchKernelGGL(iwae_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, mvk_stream(stream), loc, sd,
                      noise, n, B * L, family == MVK_FAMILY_LAPLACE_SOFTMAX ? MVK_FAMILY_LAPLACE_SOFTMAX : MVK_FAMILY_NORMAL, z);
   MVK_CHECK_LAUNCH();

@@ -18,7 +18,7 @@
 #define MVK_SMALL_FWD_THREADS 1024
 #endif
 #ifndef MVK_SMALL_DOWN_THREADS
-#define MVK_SMALL_DOWN_THREADS 256
+#define MVK_SMALL_DOWN_THREADS 512
 #endif
 #ifndef MVK_SMALL_BWD_THREADS
 #define MVK_SMALL_BWD_THREADS 256
@@ -589,8 +589,8 @@ int mvk_conv4s2_small_up_fwd(const float* V, const float* Wref, const float* bia
 
 int mvk_conv4s2_small_down_fwd(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w,
                                int Cu, int Cv, int act, void* stream) {
-  if (!U || !Wdown || !V || n < 0 || !supported(h, w, Cu, Cv)) return MVK_EINVAL;
   if (n == 0) return MVK_OK;
+  if (!U || !Wdown || !V || n < 0 || !supported(h, w, Cu, Cv)) return MVK_EINVAL;
   hipStream_t s = mvk_stream(stream);
   MVK_SMALL_DISPATCH(launch_down_fwd, U, Wdown, bias, V, n, h, w, act, s)
 }

@@ -885,3 +885,30 @@ def test_small_down_fwd(K, n, h, w, Cu, Cv, act):
     V2 = torch.empty_like(V)
     call("mvk_conv4s2_small_down_fwd", ptr(Ud), ptr(wd), None, ptr(V2), n, h, w, Cu, Cv, 0, stream_ptr())
     close(nchw(V2.cpu()), F.conv2d(U, Wc, None, stride=2, padding=1), rtol=2e-6, what="no bias")
+
+
+def test_zero_row_launches_are_no_ops(K):
+    """Empty inputs: every row-parallel entry point accepts 0 rows, launches nothing and leaves its outputs alone."""
+    from multivae_amd._lib import DIST, ReconDesc, call, ptr, stream_ptr
+
+    d = dev()
+    w = torch.randn(8, 6, device=d)
+    y = K.linear_fwd(torch.empty(0, 6, device=d), w, torch.zeros(8, device=d), 0)
+    assert y.shape == (0, 8)
+    z = torch.empty(3, 0, 5, device=d)
+    assert K.iwae_sample(torch.empty(0, 5, device=d), torch.empty(0, 5, device=d), z).shape == (3, 0, 5)
+    sentinel = torch.full((4,), 7.0, device=d)
+    desc = (ReconDesc * 1)()
+    e = desc[0]
+    e.recon, e.x, e.rows, e.D, e.dist, e.scale, e.rescale, e.coef = (sentinel.data_ptr(), sentinel.data_ptr(),
+                                                                    sentinel.data_ptr(), 4, DIST["normal"], 1.0, 1.0, 1.0)
+    call("mvk_recon_nll_fwd", desc, 1, 2, 0, stream_ptr())  # B = 0
+    V = torch.empty(0, 8, 8, 32, device=d)
+    call("mvk_conv4s2_small_down_fwd", ptr(sentinel), ptr(torch.zeros(48 * 32, device=d)), None, ptr(V), 0, 8, 8, 3, 32, 1,
+         stream_ptr())
+    call("mvk_gauss_sample_kl_fwd", ptr(sentinel), ptr(sentinel), ptr(sentinel), 1, 0, 4, ptr(sentinel), ptr(sentinel),
+         stream_ptr())
+    call("mvk_adam_step", ptr(sentinel), ptr(sentinel), ptr(sentinel), ptr(sentinel), 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0,
+         stream_ptr())
+    torch.cuda.synchronize()
+    assert bool((sentinel == 7.0).all())
