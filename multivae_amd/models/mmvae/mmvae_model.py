@@ -146,3 +146,24 @@ class MMVAE(BaseMultiVAE):
                                 uniform=self._family == 1)
             z = kernels.iwae_sample(mean.detach().reshape(1, D), std.detach().reshape(1, D), noise, self._family)
         return ModelOutput(z=z.reshape(n, D).squeeze() if n_samples > 1 else z.reshape(D), one_latent_space=True)
+
+    def compute_joint_nll_paper(self, inputs, K: int = 1000, batch_size_K: int = 10, **kwargs):
+        """The original implementation's estimator (mmvae_model.py:444-468): for every chunk of batch_size_K samples
+        per modality, the forward pass's (rescaled) importance weights of all modalities are pooled per data point
+        (`iwae`, :294-311: logsumexp over samples and modalities - ln(n M)), SUMMED over the batch, shifted by
+        ln(n M), and the chunk values are combined by one more logsumexp - ln(K M).  Unlike compute_joint_nll the
+        result depends on the chunk size (the logsumexp acts on batch sums).  kwargs: noise = list (one entry per
+        chunk) of {modality: [n,B,L]}."""
+        self.eval()
+        noise = kwargs.get("noise")
+        M = self.n_modalities
+        vals, done, c = [], 0, 0
+        with torch.no_grad():
+            while done < K:
+                n = min(int(batch_size_K), int(K) - done)
+                done += n
+                out = self.forward(inputs, K=n, detailed_output=True, noise=None if noise is None else noise[c])
+                ll = kernels.iwae_reduce([out["lws"][m] for m in out["lws"]])  # [B]: pooled over modalities and samples
+                vals.append(ll.sum() + float(np.log(n * M)))
+                c += 1
+            return -(torch.logsumexp(torch.stack(vals), dim=0) - float(np.log(done * M)))

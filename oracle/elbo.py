@@ -860,3 +860,22 @@ def cond_nll(z, data, decoders, *, pred_mods, dists=None, scales=None):
         ll = torch.logsumexp(lp, dim=0) - math.log(K)
         out[m] = -torch.sum(ll) / len(ll)
     return out
+
+
+def mmvae_joint_nll_paper(enc, data, decoders, noises, *, names, K, batch_size_K, family="laplace_with_softmax",
+                          prior_log_var=None, rescale=None, dists=None):
+    """MMVAE.compute_joint_nll_paper, mmvae_model.py:444-468, with `iwae` :294-311.  noises: one {modality: [n,B,L]} per
+    chunk of n = min(batch_size_K, remaining) samples (a forward pass per chunk)."""
+    M = len(names)
+    vals, done, c = [], 0, 0
+    while done < K:
+        n = min(batch_size_K, K - done)
+        done += n
+        o = mmvae_forward(enc, data, decoders, noises[c], names=names, K=n, family=family, loss="iwae_looser",
+                          prior_log_var=prior_log_var, rescale=rescale, dists=dists)
+        lws = torch.stack([o["lws"][m] for m in names], dim=0)  # [M, n, B]
+        l = torch.logsumexp(lws, dim=1) - math.log(lws.size(1))
+        l = torch.logsumexp(l, dim=0) - math.log(M)
+        vals.append(l.sum() + math.log(n * M))
+        c += 1
+    return -(torch.logsumexp(torch.stack(vals), dim=0) - math.log(done * M))

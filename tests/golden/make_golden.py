@@ -1204,6 +1204,49 @@ def nll_mopoe_style_case(name, *, B, K, batch_size_K, S, seed):
                     beta_style=1.0, style_dims=sdims), arrays)
 
 
+def nll_mmvae_paper_case(name, *, B, K, batch_size_K, family, rescaling, seed):
+    """MMVAE.compute_joint_nll_paper (mmvae_model.py:444-468): chunked, rescaled, batch-summed estimator."""
+    print(name)
+    dims, L = TINY_DIMS, TINY_L
+    data, _ = tiny_data(B, seed, False)
+    shapes = P.default_mlp_shapes(dims, L)
+    model = MMVAE(MMVAEConfig(n_modalities=4, latent_dim=L, input_dims=dict(dims), K=1, prior_and_posterior_dist=family,
+                              uses_likelihood_rescaling=rescaling))
+    sd_np = P.make_state_dict(shapes, seed)
+    load_weights(model, sd_np)
+    plv = P.uniform((1, L), seed + 999, -0.3, 0.3)
+    with torch.no_grad():
+        model.prior_log_var.copy_(t(plv))
+    names = list(model.encoders.keys())
+    inputs = ref_dataset(data, None)
+    torch.manual_seed(seed)
+    noises, done = [], 0
+    while done < K:
+        n = min(batch_size_K, K - done)
+        done += n
+        if family == "normal":
+            noises.append({m: torch.randn(n, B, L) for m in names})
+        else:
+            noises.append({m: torch.empty(n, B, L).uniform_(torch.finfo(torch.float32).eps - 1, 1) for m in names})
+    torch.manual_seed(seed)
+    nll = model.compute_joint_nll_paper(inputs, K=K, batch_size_K=batch_size_K)
+    osd = oracle_sd(sd_np, requires_grad=False)
+    enc_f, dec_f = nets.build_default_mlp(osd, dims)
+    tdata = {m: t(v) for m, v in data.items()}
+    with torch.no_grad():
+        e = {m: enc_f[m](tdata[m]) for m in names}
+        o = elbo.mmvae_joint_nll_paper(e, tdata, dec_f, noises, names=names, K=K, batch_size_K=batch_size_K, family=family,
+                                       prior_log_var=t(plv), rescale=elbo.rescale_factors(dims, rescaling))
+    report("nll_paper", nll, o)
+    arrays = dict(nll=torch.as_tensor(nll).detach(), prior_log_var=plv)
+    for c, nz in enumerate(noises):
+        for m in names:
+            arrays[f"noise/{c}/{m}"] = nz[m]
+    save(name, dict(model="MMVAE", arch="tiny", B=B, L=L, K=1, nll_K=K, batch_size_K=batch_size_K, seed=seed, names=names,
+                    family=family, loss="iwae_looser", learn_prior=True, rescaling=rescaling, masked=False,
+                    chunks=len(noises)), arrays)
+
+
 def nll_main():
     nll_case("nll_mopoe_tiny", kind="mopoe", arch="tiny", B=5, K=7, batch_size_K=3, seed=701,
              dists=dict(mod1="normal", mod2="laplace", mod3="bernoulli", mod4="normal"))
@@ -1217,6 +1260,9 @@ def nll_main():
              family="laplace_with_softmax")
     nll_case("nll_mmvae_mnistsvhn_laplace", kind="mmvae", arch="mnistsvhn", B=2, K=10, batch_size_K=10, seed=707,
              family="laplace_with_softmax")
+    nll_mmvae_paper_case("nll_mmvae_paper_normal", B=4, K=7, batch_size_K=3, family="normal", rescaling=True, seed=713)
+    nll_mmvae_paper_case("nll_mmvae_paper_laplace", B=3, K=6, batch_size_K=2, family="laplace_with_softmax", rescaling=False,
+                         seed=714)
     nll_mopoe_style_case("nll_mopoe_tiny_style", B=4, K=7, batch_size_K=3, S=2, seed=712)
     nll_mmvaeplus_case("nll_mmvaeplus_tiny_laplace", B=4, K=14, S=3, family="laplace_with_softmax", seed=708)
     nll_mmvaeplus_case("nll_mmvaeplus_tiny_softplus", B=3, K=9, S=2, family="normal_with_softplus", seed=709)

@@ -681,3 +681,15 @@ def test_cond_nll_golden(name):
         check(a["cnll/" + m], cn1[m], "cond nll (one point per pass) " + m)
     one = model.compute_cond_nll(inputs, cfg["subset"], cfg["pred"][0], k_iwae=1)
     assert torch.isfinite(one[cfg["pred"][0]])
+
+
+@pytest.mark.parametrize("name", G.NLL_PAPER_CASES)
+def test_joint_nll_paper_mmvae_golden(name):
+    """MMVAE.compute_joint_nll_paper on the HIP path (forward importance weights per chunk, pooled by mvk_iwae_reduce)."""
+    cfg, a, dims, data, masks, sd_np, model, inputs, d = prep(name)
+    with torch.no_grad():
+        model.prior_log_var.copy_(G.t(a["prior_log_var"]).to(d))
+    noise = [{m: G.t(a[f"noise/{c}/{m}"]).to(d) for m in cfg["names"]} for c in range(cfg["chunks"])]
+    nll = model.compute_joint_nll_paper(inputs, K=cfg["nll_K"], batch_size_K=cfg["batch_size_K"], noise=noise)
+    assert nll.size() == torch.Size([]) and nll >= 0  # tests/test_mmvae_model.py:443-446
+    check(a["nll"], nll, "nll (paper)")

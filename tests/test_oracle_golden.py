@@ -206,6 +206,23 @@ def test_cond_nll(name):
         close(a["cnll/" + m], o[m], rtol=1e-6)
 
 
+def paper_noises(cfg, a):
+    return [{m: G.t(a[f"noise/{c}/{m}"]) for m in cfg["names"]} for c in range(cfg["chunks"])]
+
+
+@pytest.mark.parametrize("name", G.NLL_PAPER_CASES)
+def test_joint_nll_paper_mmvae(name):
+    """MMVAE.compute_joint_nll_paper (mmvae_model.py:444-468): chunked, rescaled, batch-summed estimator."""
+    cfg, a, dims, data, masks, sd, enc_f, dec_f = _prep(name)
+    with torch.no_grad():
+        e = {m: enc_f[m](data[m]) for m in cfg["names"]}
+        nll = elbo.mmvae_joint_nll_paper(e, data, dec_f, paper_noises(cfg, a), names=cfg["names"], K=cfg["nll_K"],
+                                         batch_size_K=cfg["batch_size_K"], family=cfg["family"],
+                                         prior_log_var=G.t(a["prior_log_var"]),
+                                         rescale=elbo.rescale_factors(dims, cfg["rescaling"]))
+    close(a["nll"], nll, rtol=1e-6)
+
+
 def nll_plus_noise(a, kept):
     return {c: {k.split("/")[2]: G.t(a[k]) for k in a if k.startswith(f"noise/{c}/")} for c in kept}
 
