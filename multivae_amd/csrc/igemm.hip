@@ -480,6 +480,28 @@ static int launch_with_colsum(GemmDesc& d, int zdim, float* db, float* ws, int64
 
 using namespace mvk;
 
+namespace mvk {
+// imgconv.hip: register-stationary-weight kernels for the 4x4/stride-2 layer pairs (1 = shape not covered)
+int imgconv_up(const float* V, const float* Wup, const float* bias, float* U, int n, int h, int w, int Cu, int Cv,
+               int act, const float* u_act_src, int u_act, float* colsum_part, int* part_rows, hipStream_t s);
+int imgconv_down(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w, int Cu, int Cv,
+                 int act, const float* v_act_src, int v_act, float* colsum_part, int* part_rows, hipStream_t s);
+// MVK_IMGCONV=0 disables the kernels, MVK_IMGCONV=<n> sets the smallest batch that takes them (default 256 images);
+// mvk_debug_set_flags: bit 0x100 disables them, bit 0x200 takes them for every batch size (tests, A/B probes)
+static int imgconv_min_images() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MVK_IMGCONV");
+    v = e ? atoi(e) : 256;
+    if (v == 0) v = 1 << 30;
+  }
+  if (g_dbg_flags & 0x100) return 1 << 30;
+  if (g_dbg_flags & 0x200) return 1;
+  return v;
+}
+static bool imgconv_act_ok(int a) { return a == MVK_ACT_NONE || a == MVK_ACT_RELU; }
+}  // namespace mvk
+
 extern "C" {
 
 // tall-skinny / K-serial shapes: too few output tiles to fill 256 CUs -> split the reduction
@@ -635,6 +657,14 @@ int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, floa
       return mvk_conv4s2_small_down_fwd(U, Wdown, bias, V, n, h, w, Cu, Cv, act, stream);  // LDS-staged image, MFMA
     if (smallcin_supported(Cu, Cv)) return smallcin_fwd(U, Wdown, bias, V, n, h, w, Cu, Cv, act, mvk_stream(stream));
   }
+  if (!u_nchw && !u_act_src && fmt == 0 && n >= imgconv_min_images() && imgconv_act_ok(act) &&
+      imgconv_act_ok(v_act) && (!colsum_acc || (ws && ws_floats >= 256 * (int64_t)Cv)) && mvk_aligned16(U)) {
+    int rows = 0;
+    const int rc = imgconv_down(U, Wdown, bias, V, n, h, w, Cu, Cv, act, v_act_src, v_act, colsum_acc ? ws : nullptr,
+                                &rows, mvk_stream(stream));
+    if (rc == MVK_OK && colsum_acc) return colsum_finish(ws, rows, Cv, colsum_acc, mvk_stream(stream));
+    if (rc != 1) return rc;
+  }
   GemmDesc d{};
   d.a = AOperand{};
   d.a.p = U;
@@ -670,6 +700,14 @@ int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U
   if (n == 0) return MVK_OK;  // empty batch: nothing to launch (torch hands out NULL for empty tensors)
   if (!V || !Wup || !U || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0 || (colsum_acc && u_nchw)) return MVK_EINVAL;
   if (fmt & ~MVK_FMT_IN_BF3) return MVK_EINVAL;
+  if (!u_nchw && fmt == 0 && n >= imgconv_min_images() && imgconv_act_ok(act) && imgconv_act_ok(u_act) &&
+      (!colsum_acc || (ws && ws_floats >= 256 * (int64_t)Cu)) && mvk_aligned16(V)) {
+    int rows = 0;
+    const int rc = imgconv_up(V, Wup, bias, U, n, h, w, Cu, Cv, act, u_act_src, u_act, colsum_acc ? ws : nullptr, &rows,
+                              mvk_stream(stream));
+    if (rc == MVK_OK && colsum_acc) return colsum_finish(ws, rows, Cu, colsum_acc, mvk_stream(stream));
+    if (rc != 1) return rc;
+  }
   GemmDesc d{};
   d.a = AOperand{};
   d.a.p = V;

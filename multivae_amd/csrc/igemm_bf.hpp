@@ -17,6 +17,7 @@
 //   * row-contiguous operands (one float4 = 4 rows of one k per lane) transpose in registers over the lane's
 //     consecutive k values and write one (row&3) group per instruction at an 80-byte lane stride.
 #pragma once
+#include "bf3.hpp"
 #include "igemm_fast.hpp"
 
 #ifndef MVK_BF_OCC_SMALL
@@ -24,12 +25,6 @@
 #endif
 namespace mvk {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 template <int BM, int BN>
 struct BfCfg {

@@ -1,0 +1,418 @@
+// Register-stationary-weight convolution kernels for the 4x4 / stride-2 / pad-1 layer pairs of the SVHN networks
+// (reference: models/nn/svhn.py:19-28 Conv2d stack, :52-60 ConvTranspose2d stack).
+//
+// The implicit-GEMM engine (igemm_bf.hpp) re-gathers every activation element 16 times (once per kernel tap) from
+// L2 and re-splits it into bf16 pieces each time: its big launches are bound by the vector-memory path, not by the
+// matrix cores.  These kernels turn the data flow round for gfx950's 512-register unified
+// VGPR/AGPR file:
+//
+//   * one workgroup per CU, 4 waves, ONE wave per SIMD, up to 512 registers per lane;
+//   * WEIGHTS ARE STATIONARY IN REGISTERS: every wave loads its [256 k][32 n] slice of the layer's GEMM weight
+//     once per launch, splits it into the three bf16 pieces (x = x0 + x1 + x2, igemm_bf.hpp) and keeps the
+//     16 k-steps x 3 pieces x 4 registers = 192 VGPRs as MFMA B operands for the whole launch.  4 waves x 48 KB
+//     hold the whole weight of the 64<->32 channel layer pair (196 KB as pieces: more than the 160 KB of LDS); the
+//     128<->64 pair (786 KB) takes 4 workgroup types;
+//   * IMAGES STREAM THROUGH LDS: each activation image is read from HBM/L2 once per workgroup type with coalesced
+//     16-byte loads, split once, and written as three bf16 planes [pixel][channel] (padded rows, one zero row for
+//     the halo); every (tap, class) use is a ds_read_b128 A fragment from LDS.  Double buffered; the conversion of
+//     the next unit is spread over the k-steps of the current one;
+//   * a product is the 6 piece products of order <= 2 on v_mfma_f32_32x32x16_bf16, alternating between two
+//     accumulators (two independent chains per wave);
+//   * waves that split the reduction dimension exchange accumulator slices through LDS (each wave finishes a
+//     slice of the 32 x 32 tile): one s_barrier per tile;
+//   * the epilogue adds the bias, applies the activation / the activation derivative of the layer the result
+//     lands in, stores whole 128-byte rows and keeps per-column sums (bias gradient) in registers; per-workgroup
+//     partials are reduced in a fixed order (deterministic).
+//
+// Per 32-row tile a wave issues 96 MFMAs (3072 matrix-pipe cycles) against 48 ds_read_b128, <= 8 global loads and
+// ~100-200 VALU: the loop is MFMA-bound by construction.
+#include "bf3.hpp"
+
+namespace mvk {
+
+enum { IC_UP = 0, IC_DOWN = 1 };
+
+struct ImgConvArgs {
+  const float* A;        // input images [n][APIX][CIN] (NHWC)
+  const float* Wp;       // fp32 GEMM pack: Wup[class][(a,b,cv)][cu] or Wdown[(kh,kw,cu)][cv]
+  const float* bias;     // [COUT] or null
+  float* out;            // output images (NHWC)
+  const float* act_src;  // tensor of the output's shape whose activation derivative multiplies the result, or null
+  float* colsum_part;    // [rows][COUT] per-workgroup column sums of the stored result, or null
+  int n;                 // images
+  int act, src_act;
+};
+
+template <int KIND, int HS, int CIN, int COUT>
+struct ICfg {
+  static constexpr int PIX = HS * HS;                          // output rows per image (per parity class for UP)
+  static constexpr int APIX = KIND == IC_UP ? PIX : 4 * PIX;   // input pixels per image
+  static constexpr int AW = KIND == IC_UP ? HS : 2 * HS;       // input image width
+  static constexpr int CHUNKS = CIN / 16;                      // 16-channel k-steps per tap
+  static constexpr int NTAPS = 16 / CHUNKS;                    // taps per wave (16 k-steps = 192 B registers)
+  static constexpr int TAPS_ALL = KIND == IC_UP ? 4 : 16;      // taps of one output element
+  static constexpr int KSPLIT = TAPS_ALL / NTAPS;              // waves sharing one output tile
+  static constexpr int NCT = COUT / 32;                        // 32-column tiles
+  static constexpr int ROLES = (KIND == IC_UP ? 4 : 1) * NCT * KSPLIT;
+  static constexpr int WG_TYPES = ROLES / 4;
+  static constexpr int SU = PIX >= 32 ? 1 : 32 / PIX;          // images per stage unit
+  static constexpr int TPU = PIX >= 32 ? PIX / 32 : 1;         // 32-row tiles per stage unit (and class)
+  static constexpr int AROWS = SU * APIX;                      // LDS rows per unit
+  static constexpr int S = CIN * 2 + 16;                       // bytes per LDS row (bf16 channels + pad)
+  static constexpr int PLANE = (AROWS + 1) * S;                // + the zero row
+  static constexpr int BUF = 3 * PLANE;
+  static constexpr int NF4 = AROWS * CIN / 4 / 256;            // float4 units per thread per stage unit
+  static constexpr int OWN = 16 / KSPLIT;                      // accumulator registers a wave finishes
+  static constexpr int XWAVE = (KSPLIT - 1) * OWN * 64 * 4;    // exchange bytes received per wave
+  static constexpr int XBUF = KSPLIT > 1 ? 4 * XWAVE : 0;
+  static constexpr int LDS_BYTES = 2 * BUF + 2 * XBUF + 4 * 32 * 4;
+  static_assert(CIN % 16 == 0 && 16 % CHUNKS == 0 && TAPS_ALL % NTAPS == 0, "k split");
+  static_assert(ROLES % 4 == 0 && COUT % 32 == 0, "roles");
+  static_assert((AROWS * CIN / 4) % 256 == 0, "stage unit must split evenly over 256 threads");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+__device__ __forceinline__ bf16x8 ic_pack8(const unsigned (&d)[4]) {
+  u32x4 v = {d[0], d[1], d[2], d[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int KIND, int HS, int CIN, int COUT, bool HAS_SRC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void imgconv_kernel(const ImgConvArgs g) {
+  using T = ICfg<KIND, HS, CIN, COUT>;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, kg = lane >> 5;
+  const int wgtype = blockIdx.x % T::WG_TYPES;
+  const int worker = blockIdx.x / T::WG_TYPES, workers = gridDim.x / T::WG_TYPES;
+
+  // ---- role of this wave ----------------------------------------------------------------------------------
+  int cls = 0, ct = 0, ks = 0;
+  if (KIND == IC_UP) {
+    const int role = wgtype * 4 + wave;  // (class, ks, ct)
+    cls = role / (T::KSPLIT * T::NCT);
+    ks = (role / T::NCT) % T::KSPLIT;
+    ct = role % T::NCT;
+  } else if (T::WG_TYPES == 1) {
+    ks = wave / T::NCT;
+    ct = wave % T::NCT;
+  } else {  // one column tile per workgroup type, the waves split the taps
+    ct = wgtype;
+    ks = wave;
+  }
+  const int py = cls >> 1, px = cls & 1;
+  const int ncol = ct * 32 + col;
+
+  // ---- weights: 16 k-steps x 3 pieces, resident for the whole launch ---------------------------------------------
+  bf16x8 Bw[T::NTAPS][T::CHUNKS][3];
+#pragma unroll
+  for (int q = 0; q < T::NTAPS; ++q) {
+    const int tap = ks * T::NTAPS + q;
+    const long long rowbase = KIND == IC_UP ? (long long)(cls * 4 + tap) * CIN : (long long)tap * CIN;
+#pragma unroll
+    for (int c = 0; c < T::CHUNKS; ++c) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = g.Wp[(rowbase + c * 16 + kg * 8 + e) * COUT + ncol];
+      unsigned p[3][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bf3_split(v[2 * e], v[2 * e + 1], p[0][e], p[1][e], p[2][e]);
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) Bw[q][c][pc] = ic_pack8(p[pc]);
+    }
+  }
+
+  // ---- LDS geometry -----------------------------------------------------------------------------------------------
+  char* const xbase = lds + 2 * T::BUF;
+  float* const csred = reinterpret_cast<float*>(lds + 2 * T::BUF + 2 * T::XBUF);
+  // zero rows (row AROWS of every plane of both buffers)
+  for (int i = tid; i < 2 * 3 * (T::S / 4); i += 256) {
+    const int pl = i / (T::S / 4), w = i % (T::S / 4);
+    *reinterpret_cast<unsigned*>(lds + (pl / 3) * T::BUF + (pl % 3) * T::PLANE + T::AROWS * T::S + w * 4) = 0u;
+  }
+  // A-fragment byte offsets of this lane, per (tile of the unit, tap of this wave): row * S + kg * 16
+  int aoff[T::TPU][T::NTAPS];
+#pragma unroll
+  for (int tt = 0; tt < T::TPU; ++tt) {
+    const int gr = tt * 32 + col;
+    const int img = gr / T::PIX, p = gr % T::PIX, i = p / HS, j = p % HS;
+#pragma unroll
+    for (int q = 0; q < T::NTAPS; ++q) {
+      const int tap = ks * T::NTAPS + q;
+      int y, x;
+      if (KIND == IC_UP) {
+        y = i + py - (tap >> 1);
+        x = j + px - (tap & 1);
+      } else {
+        y = 2 * i - 1 + (tap >> 2);
+        x = 2 * j - 1 + (tap & 3);
+      }
+      const bool ok = y >= 0 && y < T::AW && x >= 0 && x < T::AW;
+      const int row = ok ? img * T::APIX + y * T::AW + x : T::AROWS;
+      aoff[tt][q] = row * T::S + kg * 16;
+    }
+  }
+  // staging: float4 unit f = tid + u*256 of the unit's [AROWS][CIN] matrix -> row f / (CIN/4), 4 channels
+  int soff[T::NF4];
+#pragma unroll
+  for (int u = 0; u < T::NF4; ++u) {
+    const int f = tid + u * 256;
+    soff[u] = (f / (CIN / 4)) * T::S + (f % (CIN / 4)) * 8;
+  }
+  // output rows this wave finishes: accumulator registers [ks*OWN, ks*OWN+OWN).  The element offset of row
+  // R = (r & 3) + 8 (r >> 2) + 4 kg of tile tt inside the unit's output block is additive over (tt, r, kg) (no
+  // carries between the bit fields for the supported shapes): lane part + compile-time part.
+  auto out_off = [&](int tt, int r, int kgv) -> int {
+    const int R = (r & 3) + 8 * (r >> 2) + 4 * kgv;
+    const int gr = tt * 32 + R;
+    const int img = gr / T::PIX, p = gr % T::PIX, i = p / HS, j = p % HS;
+    if (KIND == IC_UP) return ((img * 2 * HS + 2 * i) * 2 * HS + 2 * j) * COUT;
+    return (img * T::PIX + p) * COUT;
+  };
+  const int obase = out_off(0, ks * T::OWN, kg) + (KIND == IC_UP ? (py * 2 * HS + px) * COUT : 0) + ncol;
+  constexpr long long OUT_UNIT = (long long)T::SU * (KIND == IC_UP ? 4 * T::PIX : T::PIX) * COUT;
+  constexpr long long IN_UNIT = (long long)T::AROWS * CIN;
+
+  const float bias = g.bias ? g.bias[ncol] : 0.f;
+  const float act_lo = g.act == MVK_ACT_RELU ? 0.f : -__builtin_inff();
+  const float src_lo = g.src_act == MVK_ACT_RELU ? 0.f : -__builtin_inff();
+  float csum = 0.f;
+
+  const long long units = g.n / T::SU;
+  const long long u0 = units * worker / workers, u1 = units * (worker + 1) / workers;
+
+  f32x4 raw[T::NF4];
+  auto unit_src = [&](long long u) {  // clamped: the tail re-reads the last unit instead of branching
+    const long long uc = u < u1 ? u : u1 - 1;
+    return reinterpret_cast<const f32x4*>(g.A + uc * IN_UNIT) + tid;
+  };
+  auto write_f4 = [&](char* buf, int k) {
+    unsigned a0, a1, a2, b0, b1, b2;
+    bf3_split(raw[k][0], raw[k][1], a0, a1, a2);
+    bf3_split(raw[k][2], raw[k][3], b0, b1, b2);
+    *reinterpret_cast<u32x2*>(buf + soff[k]) = u32x2{a0, b0};
+    *reinterpret_cast<u32x2*>(buf + T::PLANE + soff[k]) = u32x2{a1, b1};
+    *reinterpret_cast<u32x2*>(buf + 2 * T::PLANE + soff[k]) = u32x2{a2, b2};
+  };
+
+  if (u0 < u1) {
+    const f32x4* s0 = unit_src(u0);
+#pragma unroll
+    for (int k = 0; k < T::NF4; ++k) raw[k] = s0[k * 256];
+#pragma unroll
+    for (int k = 0; k < T::NF4; ++k) write_f4(lds, k);
+    const f32x4* s1 = unit_src(u0 + 1);
+#pragma unroll
+    for (int k = 0; k < T::NF4; ++k) raw[k] = s1[k * 256];
+  }
+  __syncthreads();
+
+  // ---- main loop: a software pipeline over 32-row tiles -----------------------------------------------------------
+  // Inside the k-loop of tile t (8 pairs of k-steps, 12 MFMAs each) run, in slices between the MFMA groups:
+  //   * the A fragments of the NEXT pair (ds_read_b128, one pair ahead),
+  //   * the conversion of the next unit into the other LDS buffer + the reload of its registers (first tile of a unit),
+  //   * the loads of the activation-derivative source of tile t (consumed one tile later),
+  //   * the epilogue of tile t-1 (bias, activation, mask, store, column sums).
+  // After the k-loop: accumulator exchange (waves that split the taps), ONE barrier, first fragments of tile t+1.
+  auto read_pair = [&](bf16x8 (&dst)[2][3], const char* buf, int tt, int pr) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int q = (2 * pr + h) / T::CHUNKS, c = (2 * pr + h) % T::CHUNKS;
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        dst[h][pc] = *reinterpret_cast<const bf16x8*>(buf + aoff[tt][q] + pc * T::PLANE + c * 32);
+    }
+  };
+  float res_prev[T::OWN], msk_prev[T::OWN], msk_cur[T::OWN];
+#pragma unroll
+  for (int o = 0; o < T::OWN; ++o) res_prev[o] = msk_prev[o] = msk_cur[o] = 0.f;
+  auto epilogue_row = [&](float* outp, int ptt, int o, float validf) {
+    const int off = obase + out_off(ptt, o, 0);
+    float v = fmaxf(res_prev[o] + bias, act_lo);          // NONE / RELU
+    if (HAS_SRC) v = (msk_prev[o] > src_lo) ? v : 0.f;    // x ReLU'(y) of the layer the result lands in (or x 1)
+    outp[off] = v;
+    csum = fmaf(v, validf, csum);
+  };
+  bf16x8 a_cur[2][3];
+  if (u0 < u1) read_pair(a_cur, lds, 0, 0);
+  bool first = true;
+  int xpar = 0;
+  for (long long u = u0; u < u1; ++u) {
+    const int cur = (int)((u - u0) & 1);
+    const char* const abuf = lds + cur * T::BUF;
+    char* const nbuf = lds + (cur ^ 1) * T::BUF;
+    const f32x4* const src2 = unit_src(u + 2);
+    float* const outp_cur = g.out + u * OUT_UNIT;
+    const float* const srcp_cur = HAS_SRC ? g.act_src + u * OUT_UNIT : nullptr;
+#pragma unroll
+    for (int tt = 0; tt < T::TPU; ++tt) {
+      const int ptt = (tt + T::TPU - 1) % T::TPU;  // tile whose epilogue runs inside this k-loop
+      // the very first tile has no predecessor: its slices store act(bias) into rows of this unit that the real
+      // epilogue of those rows overwrites later (same lane, same address, program order) and add 0 to the column sums
+      float* const outp_prev = (tt > 0 || first) ? outp_cur : outp_cur - OUT_UNIT;
+      const float validf = first ? 0.f : 1.f;
+      f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) {
+        bf16x8 a_nxt[2][3];
+        if (pr < 7) read_pair(a_nxt, abuf, tt, pr + 1);
+        if (tt == 0) {
+          constexpr int PER = T::NF4 >= 8 ? T::NF4 / 8 : 1;
+          if (T::NF4 >= 8) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+              write_f4(nbuf, pr * PER + k);
+              raw[pr * PER + k] = src2[(pr * PER + k) * 256];
+            }
+          } else if (pr % (8 / T::NF4) == 0) {
+            write_f4(nbuf, pr / (8 / T::NF4));
+            raw[pr / (8 / T::NF4)] = src2[(pr / (8 / T::NF4)) * 256];
+          }
+        }
+        // rows o of this pair's slice: OWN rows over 8 pairs
+#pragma unroll
+        for (int o = 0; o < T::OWN; ++o) {
+          if (o * 8 / T::OWN != pr) continue;
+          if (HAS_SRC) msk_cur[o] = srcp_cur[obase + out_off(tt, o, 0)];
+          epilogue_row(outp_prev, ptt, o, validf);
+        }
+        constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {2, 1, 0, 1, 0, 0};  // small terms first
+        const int q0 = (2 * pr) / T::CHUNKS, c0 = (2 * pr) % T::CHUNKS;
+        const int q1 = (2 * pr + 1) / T::CHUNKS, c1 = (2 * pr + 1) % T::CHUNKS;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][PA[m]], Bw[q0][c0][PB[m]], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][PA[m]], Bw[q1][c1][PB[m]], acc1, 0, 0, 0);
+        }
+        if (pr < 7) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) a_cur[h][pc] = a_nxt[h][pc];
+        }
+      }
+      acc0 += acc1;
+      // next tile: same unit and buffer, or the first tile of the next unit in the other buffer (complete after the
+      // barrier below; the last unit of the workgroup re-reads a converted copy of itself, unused)
+      const char* const next_buf = (tt + 1 < T::TPU) ? abuf : nbuf;
+      const int ntt = (tt + 1) % T::TPU;
+      if (T::KSPLIT > 1) {
+        // accumulator exchange: registers [r*OWN, r*OWN+OWN) go to the wave of rank r of this tile's group
+        char* const xb = xbase + xpar * T::XBUF;
+#pragma unroll
+        for (int r = 0; r < T::KSPLIT; ++r) {
+          if (r == ks) continue;
+          const int dwave = T::WG_TYPES == 1 || KIND == IC_UP ? r * T::NCT + ct : r;
+          const int slot = ks < r ? ks : ks - 1;
+          float* dst = reinterpret_cast<float*>(xb + dwave * T::XWAVE + slot * T::OWN * 256);
+#pragma unroll
+          for (int o = 0; o < T::OWN; ++o) dst[o * 64 + lane] = acc0[r * T::OWN + o];
+        }
+        __syncthreads();
+        read_pair(a_cur, next_buf, ntt, 0);
+        const float* src = reinterpret_cast<const float*>(xb + wave * T::XWAVE);
+#pragma unroll
+        for (int o = 0; o < T::OWN; ++o) {
+          float v = 0.f;
+#pragma unroll
+          for (int r = 0; r < T::KSPLIT; ++r) {  // fixed order over the ranks: deterministic
+            if (r == ks) {
+              float mine = 0.f;
+#pragma unroll
+              for (int rr = 0; rr < T::KSPLIT; ++rr)
+                if (rr == ks) mine = acc0[rr * T::OWN + o];
+              v += mine;
+            } else {
+              const int slot = r < ks ? r : r - 1;
+              v += src[(slot * T::OWN + o) * 64 + lane];
+            }
+          }
+          res_prev[o] = v;
+        }
+        xpar ^= 1;
+      } else {
+#pragma unroll
+        for (int o = 0; o < T::OWN; ++o) res_prev[o] = acc0[o];
+        if (tt == T::TPU - 1) __syncthreads();
+        read_pair(a_cur, next_buf, ntt, 0);
+      }
+#pragma unroll
+      for (int o = 0; o < T::OWN; ++o) msk_prev[o] = msk_cur[o];
+      first = false;
+    }
+  }
+  if (u0 < u1) {  // epilogue of the last tile
+    float* const outp_last = g.out + (u1 - 1) * OUT_UNIT;
+#pragma unroll
+    for (int o = 0; o < T::OWN; ++o) epilogue_row(outp_last, T::TPU - 1, o, 1.f);
+  }
+
+  if (g.colsum_part) {  // fixed-order sum over the waves that share a column tile
+    csum += __shfl_xor(csum, 32, 64);
+    if (kg == 0) csred[wave * 32 + col] = csum;
+    __syncthreads();
+    if (KIND == IC_DOWN && T::WG_TYPES > 1) {  // all four waves hold column tile `wgtype`
+      if (tid < 32) {
+        float s = 0.f;
+        for (int w = 0; w < 4; ++w) s += csred[w * 32 + tid];
+        g.colsum_part[(long long)worker * COUT + wgtype * 32 + tid] = s;
+      }
+    } else if (tid < COUT) {
+      const int c_t = tid / 32, c_l = tid % 32;
+      float s = 0.f;
+      for (int w = 0; w < 4; ++w) {
+        const int wct = KIND == IC_UP ? (wgtype * 4 + w) % T::NCT : w % T::NCT;
+        if (wct == c_t) s += csred[w * 32 + c_l];
+      }
+      g.colsum_part[(long long)blockIdx.x * COUT + tid] = s;
+    }
+  }
+}
+
+template <int KIND, int HS, int CIN, int COUT>
+static int imgconv_launch(const ImgConvArgs& a, int* part_rows, hipStream_t s) {
+  using T = ICfg<KIND, HS, CIN, COUT>;
+  static bool attr_done = false;
+  auto kern = a.act_src ? imgconv_kernel<KIND, HS, CIN, COUT, true> : imgconv_kernel<KIND, HS, CIN, COUT, false>;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(imgconv_kernel<KIND, HS, CIN, COUT, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess)
+      return MVK_ELAUNCH;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(imgconv_kernel<KIND, HS, CIN, COUT, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess)
+      return MVK_ELAUNCH;
+    attr_done = true;
+  }
+  if (false) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            T::LDS_BYTES) != hipSuccess)
+      return MVK_ELAUNCH;
+    attr_done = true;
+  }
+  const int grid = 256;
+  if (part_rows) *part_rows = (KIND == IC_DOWN && T::WG_TYPES > 1) ? grid / T::WG_TYPES : grid;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), T::LDS_BYTES, s, a);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+// 1: shape not covered (the caller falls back to the implicit-GEMM engine)
+int imgconv_up(const float* V, const float* Wup, const float* bias, float* U, int n, int h, int w, int Cu, int Cv,
+               int act, const float* u_act_src, int u_act, float* colsum_part, int* part_rows, hipStream_t s) {
+  if (h != w) return 1;
+  ImgConvArgs a{V, Wup, bias, U, u_act_src, colsum_part, n, act, u_act};
+  if (h == 8 && Cv == 64 && Cu == 32) return imgconv_launch<IC_UP, 8, 64, 32>(a, part_rows, s);
+  if (h == 4 && Cv == 128 && Cu == 64 && n % 2 == 0) return imgconv_launch<IC_UP, 4, 128, 64>(a, part_rows, s);
+  return 1;
+}
+
+int imgconv_down(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w, int Cu, int Cv,
+                 int act, const float* v_act_src, int v_act, float* colsum_part, int* part_rows, hipStream_t s) {
+  if (h != w) return 1;
+  ImgConvArgs a{U, Wdown, bias, V, v_act_src, colsum_part, n, act, v_act};
+  if (h == 8 && Cu == 32 && Cv == 64) return imgconv_launch<IC_DOWN, 8, 32, 64>(a, part_rows, s);
+  if (h == 4 && Cu == 64 && Cv == 128 && n % 2 == 0) return imgconv_launch<IC_DOWN, 4, 64, 128>(a, part_rows, s);
+  return 1;
+}
+
+}  // namespace mvk
