@@ -195,6 +195,56 @@ def test_up_nchw_small(K, n, h, Cv, Cu):
     close(out, ref, what="up nchw small")
 
 
+def _debug_flags(f):
+    import ctypes
+
+    from multivae_amd import _lib
+
+    lib = _lib.load()
+    lib.mvk_debug_set_flags.argtypes = [ctypes.c_int]
+    lib.mvk_debug_set_flags(f)
+
+
+@pytest.mark.parametrize("n", [2, 6, 130, 700])
+@pytest.mark.parametrize("h,Cu,Cv", [(8, 32, 64), (4, 64, 128)])
+def test_imgconv_register_stationary_kernels(K, n, h, Cu, Cv):
+    """csrc/imgconv.hip (weights resident in registers, images streamed through LDS) against a float64 convolution:
+    forward form (bias + ReLU) and backward-data form (x ReLU'(saved activation), bias-gradient column sums), for both
+    directions of both SVHN layer pairs; batches smaller and larger than the 256 workgroups, odd and even."""
+    gen = g(h * 1000 + n)
+    U = torch.randn(n, Cu, 2 * h, 2 * h, generator=gen)
+    V = torch.randn(n, Cv, h, h, generator=gen)
+    Wc = torch.randn(Cv, Cu, 4, 4, generator=gen) / math.sqrt(16 * Cu)
+    bu, bv = torch.randn(Cu, generator=gen), torch.randn(Cv, generator=gen)
+    Us, Vs = torch.randn(n, Cu, 2 * h, 2 * h, generator=gen), torch.randn(n, Cv, h, h, generator=gen)
+    d = dev()
+    wd, wu = K.pack_conv(Wc.to(d))
+    pb_u, pb_v = torch.nn.Parameter(torch.zeros(Cu, device=d)), torch.nn.Parameter(torch.zeros(Cv, device=d))
+    Ud, Vd = nhwc(U).to(d), nhwc(V).to(d)
+    direct = K.DIRECT_GRAD
+    K.DIRECT_GRAD = False
+    _debug_flags(0x200)  # take the kernels for every batch size
+    try:
+        up = K.conv_up(Vd, wu, bu.to(d), n, h, h, Cu, Cv, act=1)
+        up2, gb_u = K.conv_up(Vd, wu, None, n, h, h, Cu, Cv, u_act_src=nhwc(Us).to(d), u_act=1, out_bias=pb_u)
+        dn = K.conv_down(Ud, wd, bv.to(d), n, h, h, Cu, Cv, act=1)
+        dn2, gb_v = K.conv_down(Ud, wd, None, n, h, h, Cu, Cv, v_act_src=nhwc(Vs).to(d), v_act=1, out_bias=pb_v)
+        torch.cuda.synchronize()
+    finally:
+        _debug_flags(0)
+        K.DIRECT_GRAD = direct
+    ref_up = F.conv_transpose2d(V.double(), Wc.double(), None, stride=2, padding=1)
+    ref_dn = F.conv2d(U.double(), Wc.double(), None, stride=2, padding=1)
+    close(nchw(up.cpu()), torch.relu(ref_up + bu.double().view(1, -1, 1, 1)), rtol=2e-6, what="imgconv up")
+    close(nchw(dn.cpu()), torch.relu(ref_dn + bv.double().view(1, -1, 1, 1)), rtol=2e-6, what="imgconv down")
+    ref_up2 = ref_up * (Us > 0)
+    ref_dn2 = ref_dn * (Vs > 0)
+    close(nchw(up2.cpu()), ref_up2, rtol=2e-6, what="imgconv up x mask")
+    close(nchw(dn2.cpu()), ref_dn2, rtol=2e-6, what="imgconv down x mask")
+    close(gb_u, ref_up2.sum((0, 2, 3)), rtol=1e-5, what="imgconv up column sums")
+    close(gb_v, ref_dn2.sum((0, 2, 3)), rtol=1e-5, what="imgconv down column sums")
+
+
 # ------------------------------------------------------------------------------------------------------------
 # whole networks (single autograd nodes) against the oracle's functional networks
 # ------------------------------------------------------------------------------------------------------------
