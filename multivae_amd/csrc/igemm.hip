@@ -488,6 +488,8 @@ int imgconv_down(const float* U, const float* Wdown, const float* bias, float* V
                  int act, const float* v_act_src, int v_act, float* colsum_part, int* part_rows, hipStream_t s);
 // MVK_IMGCONV=0 disables the kernels, MVK_IMGCONV=<n> sets the smallest batch that takes them (default 256 images);
 // mvk_debug_set_flags: bit 0x100 disables them, bit 0x200 takes them for every batch size (tests, A/B probes)
+int imgconv_wgrad(const float* U, const float* V, float* slab, long long slab_floats, int n, int h, int w, int Cu, int Cv,
+                  int* nz, hipStream_t s);
 static int imgconv_min_images() {
   static int v = -1;
   if (v < 0) {
@@ -817,6 +819,13 @@ int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h
   if (u_nchw && !u_act_src && smallcin_supported(Cu, Cv)) {
     const int rc = smallcin_wgrad(U, V, dWref, n, h, w, Cu, Cv, ws, ws_floats, mvk_stream(stream));
     if (rc != 1) return rc;  // 1: scratch too small -> the implicit GEMM below
+  }
+  if (!u_nchw && !u_act_src && ws && n / 4 >= imgconv_min_images() && mvk_aligned16(U) && mvk_aligned16(V) &&
+      mvk_aligned16(ws)) {
+    int nz = 0;
+    const int rc = imgconv_wgrad(U, V, ws, ws_floats, n, h, w, Cu, Cv, &nz, mvk_stream(stream));
+    if (rc == MVK_OK) return convref_reduce(ws, nz, Cu, Cv, 16, dWref, mvk_stream(stream));
+    if (rc != 1) return rc;
   }
   GemmDesc d{};
   d.a = AOperand{};

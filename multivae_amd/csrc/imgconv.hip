@@ -396,6 +396,255 @@ static int imgconv_launch(const ImgConvArgs& a, int* part_rows, hipStream_t s) {
   return MVK_OK;
 }
 
+// =====================================================================================================================
+// Weight gradient of the same layer pairs:  dW[cv][cu][kh][kw] += sum_{n,i,j} V[n,i,j,cv] U[n,2i-1+kh,2j-1+kw,cu]
+// =====================================================================================================================
+// The reduction index of this GEMM is the pixel, and both operands are stored channel-contiguous ([pixel][channel]),
+// i.e. transposed for the matrix cores.  gfx950's ds_read_b64_tr_b16 transposes on the way out of LDS (16 lanes read
+// a [4 pixels][16 channels] block as 8-byte row pieces and receive 4 pixels of one channel each), so the images are
+// staged exactly as in the kernels above (one coalesced pass, one split, three bf16 planes [pixel][channel]) and every
+// (tap, channel tile) use is a pair of transposing reads at per-lane gathered pixel addresses (halo -> zero row).
+//   * OUTPUT-stationary: a wave keeps 8 accumulator tiles (128 registers) for the whole launch: the 4 waves of a
+//     workgroup hold the 16 taps x 32 x 64 gradient of the 64<->32 layer (one kernel row per wave); the 128<->64 layer
+//     takes one kernel row per workgroup type, one tap per wave;
+//   * a workgroup walks its share of the images once, one s_barrier per stage unit, and writes its partial gradient
+//     as one slab; the slabs are summed in a fixed order (deterministic) into the reference layout.
+template <int HS, int CU, int CV>
+struct WCfg {
+  static constexpr int PIX = HS * HS, AW = 2 * HS;
+  static constexpr bool SPLIT_KH = (CU * CV > 32 * 64);          // one kernel row per workgroup type
+  static constexpr int WG_TYPES = SPLIT_KH ? 4 : 1;
+  static constexpr int NKW = SPLIT_KH ? 1 : 4;                   // taps (kw) per wave
+  static constexpr int MT = SPLIT_KH ? CU / 32 : 4;              // A fragments per k-step: cu tiles, or the 4 kw taps
+  static constexpr int NT = CV / 32;
+  static constexpr int SU = PIX >= 32 ? 1 : 2;                   // images per stage unit
+  static constexpr int KS = SU * PIX / 16;                       // 16-pixel k-steps per unit
+  static constexpr int UROWS_IMG = SPLIT_KH ? HS * AW : 4 * PIX; // staged input rows per image (one row per (i, x))
+  static constexpr int UROWS = SU * UROWS_IMG, VROWS = SU * PIX;
+  static constexpr int PAD = SPLIT_KH ? 16 : 0;
+  static constexpr int SUB = CU * 2 + PAD, SVB = CV * 2 + PAD;   // bytes per LDS row
+  static constexpr int PLANE_U = (UROWS + 1) * SUB, PLANE_V = VROWS * SVB;
+  static constexpr int OFF_V = 3 * PLANE_U;
+  static constexpr int BUF = 3 * (PLANE_U + PLANE_V);
+  static constexpr int NFU = UROWS * CU / 4 / 256, NFV = VROWS * CV / 4 / 256;
+  static constexpr int NF = NFU + NFV;
+  static constexpr int LDS_BYTES = 2 * BUF;
+  static_assert(MT * NT == 8, "8 accumulator tiles per wave");
+  static_assert(SPLIT_KH || CU == 32, "the 4 taps of a kernel row are the 4 row tiles");
+  static_assert(UROWS * CU / 4 % 256 == 0 && VROWS * CV / 4 % 256 == 0 && NF % KS == 0, "staging split");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 ic_tr_pair(const char* p0, const char* p1) {
+  typedef __attribute__((address_space(3))) bf16x4* lp;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p0));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p1));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+struct ImgWgradArgs {
+  const float* U;  // [n][2h][2w][CU]
+  const float* V;  // [n][h][w][CV]
+  float* slab;     // [workers][16 * CU][CV] partial gradients
+  int n;
+};
+
+template <int HS, int CU, int CV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void imgwgrad_kernel(const ImgWgradArgs g) {
+  using T = WCfg<HS, CU, CV>;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wgtype = blockIdx.x % T::WG_TYPES;
+  const int worker = blockIdx.x / T::WG_TYPES, workers = gridDim.x / T::WG_TYPES;
+  const int kh = T::SPLIT_KH ? wgtype : wave;
+
+  // zero rows of the three U planes of both buffers
+  for (int i = tid; i < 2 * 3 * (T::SUB / 4); i += 256) {
+    const int pl = i / (T::SUB / 4), w = i % (T::SUB / 4);
+    *reinterpret_cast<unsigned*>(lds + (pl / 3) * T::BUF + (pl % 3) * T::PLANE_U + T::UROWS * T::SUB + w * 4) = 0u;
+  }
+  // transposing-read addresses: 16-lane group gq reads [4 pixels][16 channels]; lane lp supplies pixel (lp >> 2),
+  // channels 4 (lp & 3) .. +3 and receives channel lp of the block, pixels 0..3
+  const int gq = lane >> 4, lp = lane & 15;
+  const int kbase = 8 * (gq >> 1) + (lp >> 2);
+  const int cch = 16 * (gq & 1) + 4 * (lp & 3);
+  int uaddr[T::KS][2][T::NKW], vaddr[T::KS][2];
+#pragma unroll
+  for (int s = 0; s < T::KS; ++s)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int p = s * 16 + kbase + 4 * t;
+      const int img = p / T::PIX, pp = p % T::PIX, i = pp / HS, j = pp % HS;
+      vaddr[s][t] = T::OFF_V + p * T::SVB + cch * 2;
+      const int y = 2 * i - 1 + kh;
+#pragma unroll
+      for (int q = 0; q < T::NKW; ++q) {
+        const int kw = T::SPLIT_KH ? wave : q;
+        const int x = 2 * j - 1 + kw;
+        const bool ok = y >= 0 && y < T::AW && x >= 0 && x < T::AW;
+        const int row = img * T::UROWS_IMG + (T::SPLIT_KH ? i * T::AW + x : y * T::AW + x);
+        uaddr[s][t][q] = (ok ? row : T::UROWS) * T::SUB + cch * 2;
+      }
+    }
+  // staging: NFU float4 units of U, NFV of V per thread and unit
+  int sdst[T::NF], ssrc[T::NF];  // LDS byte offset (plane 0), float4 offset inside the unit's source block
+#pragma unroll
+  for (int k = 0; k < T::NFU; ++k) {
+    const int f = tid + k * 256;
+    const int row = f / (CU / 4), c4 = f % (CU / 4);
+    sdst[k] = row * T::SUB + c4 * 8;
+    if (T::SPLIT_KH) {  // row = (img, i, x): source pixel (2i-1+kh, x), clamped (a clamped row is never read)
+      const int img = row / T::UROWS_IMG, r = row % T::UROWS_IMG, i = r / T::AW, x = r % T::AW;
+      int y = 2 * i - 1 + kh;
+      y = y < 0 ? 0 : (y >= T::AW ? T::AW - 1 : y);
+      ssrc[k] = ((img * T::AW + y) * T::AW + x) * (CU / 4) + c4;
+    } else {
+      ssrc[k] = f;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < T::NFV; ++k) {
+    const int f = tid + k * 256;
+    sdst[T::NFU + k] = T::OFF_V + (f / (CV / 4)) * T::SVB + (f % (CV / 4)) * 8;
+    ssrc[T::NFU + k] = f;
+  }
+  constexpr long long U_UNIT = (long long)T::SU * 4 * T::PIX * CU / 4, V_UNIT = (long long)T::SU * T::PIX * CV / 4;  // float4s
+
+  const long long units = g.n / T::SU;
+  const long long u0 = units * worker / workers, u1 = units * (worker + 1) / workers;
+  f32x4 raw[T::NF];
+  auto load_f4 = [&](long long u, int k) {
+    const long long uc = u < u1 ? u : u1 - 1;
+    const f32x4* base = k < T::NFU ? reinterpret_cast<const f32x4*>(g.U) + uc * U_UNIT
+                                   : reinterpret_cast<const f32x4*>(g.V) + uc * V_UNIT;
+    raw[k] = base[ssrc[k]];
+  };
+  auto write_f4 = [&](char* buf, int k) {
+    unsigned a0, a1, a2, b0, b1, b2;
+    bf3_split(raw[k][0], raw[k][1], a0, a1, a2);
+    bf3_split(raw[k][2], raw[k][3], b0, b1, b2);
+    const int pl = k < T::NFU ? T::PLANE_U : T::PLANE_V;
+    *reinterpret_cast<u32x2*>(buf + sdst[k]) = u32x2{a0, b0};
+    *reinterpret_cast<u32x2*>(buf + pl + sdst[k]) = u32x2{a1, b1};
+    *reinterpret_cast<u32x2*>(buf + 2 * pl + sdst[k]) = u32x2{a2, b2};
+  };
+
+  f32x16 acc[T::MT][T::NT];
+#pragma unroll
+  for (int a = 0; a < T::MT; ++a)
+#pragma unroll
+    for (int b = 0; b < T::NT; ++b) acc[a][b] = f32x16{0};
+
+  if (u0 < u1) {
+#pragma unroll
+    for (int k = 0; k < T::NF; ++k) load_f4(u0, k);
+#pragma unroll
+    for (int k = 0; k < T::NF; ++k) write_f4(lds, k);
+#pragma unroll
+    for (int k = 0; k < T::NF; ++k) load_f4(u0 + 1, k);
+  }
+  __syncthreads();
+
+  bf16x8 Af[T::MT][3], Bf[T::NT][3];
+  auto read_frags = [&](bf16x8 (&A)[T::MT][3], bf16x8 (&B)[T::NT][3], const char* buf, int s) {
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+      for (int b = 0; b < T::NT; ++b)
+        B[b][pc] = ic_tr_pair(buf + vaddr[s][0] + pc * T::PLANE_V + b * 64, buf + vaddr[s][1] + pc * T::PLANE_V + b * 64);
+#pragma unroll
+      for (int a = 0; a < T::MT; ++a) {
+        const int q = T::SPLIT_KH ? 0 : a, co = T::SPLIT_KH ? a * 64 : 0;
+        A[a][pc] = ic_tr_pair(buf + uaddr[s][0][q] + pc * T::PLANE_U + co, buf + uaddr[s][1][q] + pc * T::PLANE_U + co);
+      }
+    }
+  };
+  if (u0 < u1) read_frags(Af, Bf, lds, 0);
+
+  for (long long u = u0; u < u1; ++u) {
+    const int cur = (int)((u - u0) & 1);
+    const char* const abuf = lds + cur * T::BUF;
+    char* const nbuf = lds + (cur ^ 1) * T::BUF;
+#pragma unroll
+    for (int s = 0; s < T::KS; ++s) {
+      bf16x8 An[T::MT][3], Bn[T::NT][3];
+      if (s + 1 < T::KS) read_frags(An, Bn, abuf, s + 1);
+      constexpr int PER = T::NF / T::KS;
+#pragma unroll
+      for (int k = s * PER; k < (s + 1) * PER; ++k) {  // conversion of the next unit + reload with the one after it
+        write_f4(nbuf, k);
+        load_f4(u + 2, k);
+      }
+      constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {2, 1, 0, 1, 0, 0};  // small terms first
+#pragma unroll
+      for (int m = 0; m < 6; ++m)
+#pragma unroll
+        for (int a = 0; a < T::MT; ++a)
+#pragma unroll
+          for (int b = 0; b < T::NT; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[a][PA[m]], Bf[b][PB[m]], acc[a][b], 0, 0, 0);
+      if (s + 1 < T::KS) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+          for (int a = 0; a < T::MT; ++a) Af[a][pc] = An[a][pc];
+#pragma unroll
+          for (int b = 0; b < T::NT; ++b) Bf[b][pc] = Bn[b][pc];
+        }
+      }
+    }
+    __syncthreads();
+    read_frags(Af, Bf, nbuf, 0);
+  }
+
+  // partial gradient of this workgroup: slab[worker][(tap * CU + cu)][cv]
+  float* const slab = g.slab + (long long)worker * 16 * CU * CV;
+  const int col = lane & 31, kg = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < T::MT; ++a) {
+    const int kw = T::SPLIT_KH ? wave : a, cut = T::SPLIT_KH ? a : 0;
+    const int tap = kh * 4 + kw;
+#pragma unroll
+    for (int b = 0; b < T::NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cu = cut * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        slab[(long long)(tap * CU + cu) * CV + b * 32 + col] = acc[a][b][r];
+      }
+  }
+}
+
+template <int HS, int CU, int CV>
+static int imgwgrad_launch(const ImgWgradArgs& a, int* nz, hipStream_t s) {
+  using T = WCfg<HS, CU, CV>;
+  static bool attr_done = false;
+  auto kern = imgwgrad_kernel<HS, CU, CV>;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            T::LDS_BYTES) != hipSuccess)
+      return MVK_ELAUNCH;
+    attr_done = true;
+  }
+  const int grid = 256;
+  *nz = grid / T::WG_TYPES;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), T::LDS_BYTES, s, a);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+// slab: [*nz][16 Cu][Cv] partial gradients (needs 256 / types * 16 Cu Cv floats); 1: shape not covered
+int imgconv_wgrad(const float* U, const float* V, float* slab, long long slab_floats, int n, int h, int w, int Cu, int Cv,
+                  int* nz, hipStream_t s) {
+  if (h != w) return 1;
+  ImgWgradArgs a{U, V, slab, n};
+  if (h == 8 && Cu == 32 && Cv == 64 && slab_floats >= 256ll * 16 * Cu * Cv) return imgwgrad_launch<8, 32, 64>(a, nz, s);
+  if (h == 4 && Cu == 64 && Cv == 128 && n % 2 == 0 && slab_floats >= 64ll * 16 * Cu * Cv)
+    return imgwgrad_launch<4, 64, 128>(a, nz, s);
+  return 1;
+}
+
 // 1: shape not covered (the caller falls back to the implicit-GEMM engine)
 int imgconv_up(const float* V, const float* Wup, const float* bias, float* U, int n, int h, int w, int Cu, int Cv,
                int act, const float* u_act_src, int u_act, float* colsum_part, int* part_rows, hipStream_t s) {

@@ -229,6 +229,7 @@ def test_imgconv_register_stationary_kernels(K, n, h, Cu, Cv):
         up2, gb_u = K.conv_up(Vd, wu, None, n, h, h, Cu, Cv, u_act_src=nhwc(Us).to(d), u_act=1, out_bias=pb_u)
         dn = K.conv_down(Ud, wd, bv.to(d), n, h, h, Cu, Cv, act=1)
         dn2, gb_v = K.conv_down(Ud, wd, None, n, h, h, Cu, Cv, v_act_src=nhwc(Vs).to(d), v_act=1, out_bias=pb_v)
+        wg = K.conv_wgrad(Ud, Vd, Wc.to(d), n, h, h, Cu, Cv)  # transposing-read weight-gradient kernel for n >= 4
         torch.cuda.synchronize()
     finally:
         _debug_flags(0)
@@ -243,6 +244,9 @@ def test_imgconv_register_stationary_kernels(K, n, h, Cu, Cv):
     close(nchw(dn2.cpu()), ref_dn2, rtol=2e-6, what="imgconv down x mask")
     close(gb_u, ref_up2.sum((0, 2, 3)), rtol=1e-5, what="imgconv up column sums")
     close(gb_v, ref_dn2.sum((0, 2, 3)), rtol=1e-5, what="imgconv down column sums")
+    Wr = Wc.double().clone().requires_grad_()
+    (F.conv2d(U.double(), Wr, None, stride=2, padding=1) * V.double()).sum().backward()
+    close(wg, Wr.grad, rtol=2e-6, what="imgconv wgrad")
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ P2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTI
 i=1
 for P in "$P1" "$P2"; do
   rocprofv3 --pmc $P --kernel-trace -d $OUT/${W}_p$i -o p -- python tools/imgconv_probe.py prof $W > $OUT/${W}_p$i.log 2>&1
-  python tools/pmc_agg.py $OUT/${W}_p$i/p_results.db | grep -E "n dur_us|imgconv|igemm_bf" > $OUT/${W}_p$i.txt
+  python tools/pmc_agg.py $OUT/${W}_p$i/p_results.db | grep -E "n dur_us|imgconv|imgwgrad|splitk|igemm_bf" > $OUT/${W}_p$i.txt
   i=$((i+1))
 done
 cat $OUT/${W}_p*.txt

@@ -54,10 +54,11 @@ def check(n):
             up2, gb_u = K.conv_up(Vd, wu, None, n, h, h, Cu, Cv, u_act_src=Us, u_act=1, out_bias=pb_u)
             dn = K.conv_down(Ud, wd, bv.to(d), n, h, h, Cu, Cv, act=1)
             dn2, gb_v = K.conv_down(Ud, wd, None, n, h, h, Cu, Cv, v_act_src=Vs, v_act=1, out_bias=pb_v)
+            wg = K.conv_wgrad(Ud, Vd, Wc.to(d), n, h, h, Cu, Cv)
             torch.cuda.synchronize()
-            outs[name] = [t.clone() for t in (up, up2, gb_u, dn, dn2, gb_v)]
+            outs[name] = [t.clone() for t in (up, up2, gb_u, dn, dn2, gb_v, wg)]
         flags(0)
-        names = ["up+bias+relu", "up*mask", "up colsum", "down+bias+relu", "down*mask", "down colsum"]
+        names = ["up+bias+relu", "up*mask", "up colsum", "down+bias+relu", "down*mask", "down colsum", "wgrad"]
         for nm, a, b in zip(names, outs["new"], outs["old"]):
             print(f"  h={h} n={n} {nm:16s} new vs engine {relerr(a, b):.2e}", flush=True)
         if n <= 64:
@@ -67,6 +68,10 @@ def check(n):
                   f"engine {relerr(nchw(outs['old'][0].cpu()), ref_up):.2e}")
             print(f"  h={h} n={n} down vs float64: new {relerr(nchw(outs['new'][3].cpu()), ref_dn):.2e} "
                   f"engine {relerr(nchw(outs['old'][3].cpu()), ref_dn):.2e}")
+            Wr = Wc.double().clone().requires_grad_()
+            (F.conv2d(U.double(), Wr, None, stride=2, padding=1) * V.double()).sum().backward()
+            print(f"  h={h} n={n} wgrad vs float64: new {relerr(outs['new'][6].cpu(), Wr.grad):.2e} "
+                  f"engine {relerr(outs['old'][6].cpu(), Wr.grad):.2e}")
 
 
 def bench(n, rounds):
@@ -80,6 +85,7 @@ def bench(n, rounds):
         pb = torch.nn.Parameter(torch.zeros(Cv, device=d))
         K.DIRECT_GRAD = False
         cases = {
+            "wgrd": lambda: K.conv_wgrad(Ud, Vd, Wc, n, h, h, Cu, Cv),
             "up  ": lambda: K.conv_up(Vd, wu, bu, n, h, h, Cu, Cv, act=1),
             "down": lambda: K.conv_down(Ud, wd, None, n, h, h, Cu, Cv, v_act_src=Vd, v_act=1, out_bias=pb),
         }
@@ -118,6 +124,7 @@ def prof(which, n=5120, reps=5):
         for _ in range(reps):
             K.conv_up(Vd, wu, bu, n, h, h, Cu, Cv, act=1)
             K.conv_down(Ud, wd, None, n, h, h, Cu, Cv, v_act_src=Vd, v_act=1, out_bias=pb)
+            K.conv_wgrad(Ud, Vd, Wc, n, h, h, Cu, Cv)
         torch.cuda.synchronize()
 
 
