@@ -1,17 +1,23 @@
-"""Headline benchmark: train samples/sec of one full MoPoE training step (forward + fused ELBO + backward +
-Adam [+ one RCCL gradient all-reduce]) on synthetic MnistSvhn-shaped batches, K = 10 importance samples,
-per-device batch 512 (weak scaling), one process per GPU.
+"""Benchmark of one full training step (forward + fused ELBO + backward + Adam [+ one RCCL gradient all-reduce]) on
+synthetic batches of the BASELINE.json configurations, one process per GPU.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 20 --warmup 5                       # headline: MoPoE MnistSvhn K=10, batch 512
+    python bench.py --config cfg2|cfg3k1|cfg4|cfg5 ...                    # the other BASELINE configurations
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     — the fused reconstruction-NLL kernel (HBM-bound): algorithmic bytes / HIP-event duration,
-  cpu_baseline — the CPU oracle (oracle/train.py, a port of the reference path) timed on the host cores.
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline       the fused reconstruction-NLL kernel (HBM-bound): algorithmic bytes / device-clock duration,
+  roofline_mfma  the register-stationary convolution kernels (MFMA-bound) and the whole step's GEMM FLOP rate,
+  roofline_image the 3-channel image-layer kernels (HBM-bound),
+  cpu_baseline   the CPU oracle (oracle/, a port of the reference path) timed on the host cores.
+Kernel durations come from the library's device-timestamp profiler (mvk_prof_enable: first workgroup in to last
+workgroup out on the constant-rate clock, the quantity a kernel trace reports) in eager steps of the same workload
+right after the graph-replayed timed region; a HIP-event bracket of the same launch is reported beside it.
 Nothing here reads /root/reference.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -22,32 +28,161 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F32_TFLOPS = 157.3    # fp32-input MFMA = the fp32 vector rate
+MFMA_BF16_TFLOPS = 2500.0  # dense bf16 MFMA; an fp32 product on the split-bf16 path costs 6 bf16 products
+PROF_KINDS = {1: "recon_nll", 2: "imgconv_up", 3: "imgconv_down", 4: "imgconv_wgrad", 5: "image_layer_fwd",
+              6: "image_layer_bwd"}
 
 
-def build_model(K, L, device, seed=0):
-    from multivae_amd.models import MoPoE, MoPoEConfig
+# ---- workloads --------------------------------------------------------------------------------------------------------
+def mnist_svhn_nets(L):
     from multivae_amd.models.base.base_config import BaseAEConfig
     from multivae_amd.models.nn.default_architectures import Decoder_AE_MLP, Encoder_VAE_MLP
     from multivae_amd.models.nn.svhn import Decoder_VAE_SVHN, Encoder_VAE_SVHN
 
-    torch.manual_seed(seed)  # default nn.Linear / nn.Conv2d init
     enc = dict(mnist=Encoder_VAE_MLP(BaseAEConfig(latent_dim=L, input_dim=(1, 28, 28))),
                svhn=Encoder_VAE_SVHN(BaseAEConfig(latent_dim=L, input_dim=(3, 32, 32))))
     dec = dict(mnist=Decoder_AE_MLP(BaseAEConfig(latent_dim=L, input_dim=(1, 28, 28))),
                svhn=Decoder_VAE_SVHN(BaseAEConfig(latent_dim=L, input_dim=(3, 32, 32))))
-    cfg = MoPoEConfig(n_modalities=2, latent_dim=L, input_dims=dict(mnist=(1, 28, 28), svhn=(3, 32, 32)), beta=1.0, K=K)
-    return MoPoE(cfg, enc, dec).to(device).train()
+    return enc, dec
 
 
-def synthetic_batch(B, device, seed=0):
+def mnist_svhn_batch(B, device, seed):
     g = torch.Generator().manual_seed(seed)
     return {"mnist": torch.rand(B, 1, 28, 28, generator=g).to(device),
             "svhn": torch.rand(B, 3, 32, 32, generator=g).to(device)}
 
 
-def cpu_baseline(model, data, K, L, budget_s=20.0):
-    """The oracle's training step (torch CPU, same architecture / batch / K) on the host cores."""
+def build_workload(name, args, device, rank):
+    """-> dict(model, data, B, K, noise (callable(gen) -> noise tensor for forward, or None), adam (kwargs), text)"""
+    from multivae_amd import models as M
+
+    torch.manual_seed(0)  # default nn.Linear / nn.Conv2d initialisation (SURVEY.md section 8d)
+    w = dict(noise=None, adam=dict(lr=1e-3), fwd_kwargs={})
+    if name in ("cfg3", "cfg3k1"):
+        K = args.K if name == "cfg3" else 1
+        B, L = args.batch or 512, args.latent_dim
+        enc, dec = mnist_svhn_nets(L)
+        cfg = M.MoPoEConfig(n_modalities=2, latent_dim=L, input_dims=dict(mnist=(1, 28, 28), svhn=(3, 32, 32)), beta=1.0, K=K)
+        w.update(model=M.MoPoE(cfg, enc, dec), data=mnist_svhn_batch(B, device, rank), B=B, K=K,
+                 noise=lambda gen: torch.randn(K, B, L, device=device, generator=gen),
+                 metric=f"train samples/sec (ELBO step) MoPoE MnistSvhn K={K}",
+                 text=f"MoPoE MnistSvhn (mnist MLP + svhn conv), K={K}, per-device batch {B}, latent_dim {L}, Adam lr 1e-3, "
+                      "fwd+ELBO+bwd+optimizer")
+    elif name == "cfg2":
+        B, L, K = args.batch or 256, args.latent_dim, 1
+        enc, dec = mnist_svhn_nets(L)
+        cfg = M.MMVAEConfig(n_modalities=2, latent_dim=L, input_dims=dict(mnist=(1, 28, 28), svhn=(3, 32, 32)), K=K,
+                            prior_and_posterior_dist=args.family, loss=args.loss)
+        w.update(model=M.MMVAE(cfg, enc, dec), data=mnist_svhn_batch(B, device, rank), B=B, K=K,
+                 metric="train samples/sec (ELBO step) MMVAE MnistSvhn K=1",
+                 text=f"MMVAE MnistSvhn (mnist MLP + svhn conv), K=1, {args.family}, {args.loss}, per-device batch {B}, "
+                      f"latent_dim {L}, Adam lr 1e-3, fwd+ELBO+bwd+optimizer")
+    elif name == "cfg4":
+        from multivae_amd.models.nn.mmnist import DecoderResnetMMNIST, EncoderResnetMMNIST
+
+        B, K = args.batch or 32, 10  # global batch 256 = 8 GPUs x 32 (the reference example's per-device batch)
+        names = [f"m{i}" for i in range(5)]
+        cfg = M.MMVAEPlusConfig(n_modalities=5, latent_dim=32, input_dims={m: (3, 28, 28) for m in names}, K=K,
+                                modalities_specific_dim=32, prior_and_posterior_dist="laplace_with_softmax",
+                                loss="iwae_looser", beta=2.5, decoders_dist={m: "laplace" for m in names},
+                                decoder_dist_params={m: dict(scale=0.75) for m in names}, learn_shared_prior=False,
+                                learn_modality_prior=True)
+        model = M.MMVAEPlus(cfg, {m: EncoderResnetMMNIST(32, 32) for m in names},
+                            {m: DecoderResnetMMNIST(64) for m in names})
+        g = torch.Generator().manual_seed(rank)
+        data = {m: torch.rand(B, 3, 28, 28, generator=g).to(device) for m in names}
+        w.update(model=model, data=data, B=B, K=K, adam=dict(lr=1e-3, amsgrad=True),  # examples/mmvae_plus/mmnist.py:61-62
+                 metric="train samples/sec (ELBO step) MMVAE+ PolyMNIST 5 modalities K=10",
+                 text=f"MMVAE+ PolyMNIST-shaped (5 x 3x28x28, ResNet enc/dec), K=10, latent 32+32, laplace_with_softmax, "
+                      f"iwae_looser, beta 2.5, per-device batch {B}, Adam(amsgrad) lr 1e-3, fwd+ELBO+bwd+optimizer")
+    elif name == "cfg5":
+        from multivae_amd.models.base.base_config import BaseAEConfig
+        from multivae_amd.models.nn.cub import CUB_Resnet_Decoder, CUB_Resnet_Encoder
+        from multivae_amd.models.nn.default_architectures import Decoder_AE_MLP, Encoder_VAE_MLP
+
+        B, L, K = args.batch or 128, 64, 1
+        cfg = M.JMVAEConfig(n_modalities=2, latent_dim=L, input_dims=dict(image=(3, 64, 64), attributes=(40,)),
+                            decoders_dist=dict(image="normal", attributes="bernoulli"))
+        enc = dict(image=CUB_Resnet_Encoder(L), attributes=Encoder_VAE_MLP(BaseAEConfig(latent_dim=L, input_dim=(40,))))
+        dec = dict(image=CUB_Resnet_Decoder(L), attributes=Decoder_AE_MLP(BaseAEConfig(latent_dim=L, input_dim=(40,))))
+        g = torch.Generator().manual_seed(rank)
+        data = dict(image=torch.rand(B, 3, 64, 64, generator=g).to(device),
+                    attributes=(torch.rand(B, 40, generator=g) > 0.5).float().to(device))
+        w.update(model=M.JMVAE(cfg, enc, dec), data=data, B=B, K=K, fwd_kwargs=dict(epoch=20),
+                 metric="train samples/sec (ELBO step) JMVAE CelebA-shaped 64x64 + attributes",
+                 text=f"JMVAE CelebA-shaped (3x64x64 image: CUB ResNet enc/dec, 40 binary attributes: MLP), latent {L}, "
+                      f"per-device batch {B}, Adam lr 1e-3, fwd+ELBO+bwd+optimizer")
+    else:
+        raise SystemExit(f"unknown --config {name}")
+    w["model"] = w["model"].to(device).train()
+    w["name"], w["L"] = name, args.latent_dim
+    return w
+
+
+# ---- CPU baseline (oracle port of the reference path) -------------------------------------------------------------------
+def oracle_loss_fn(w, B):
+    """-> (state_dict of fp32 leaves, loss_fn(sd) drawing fresh noise) for the workload, on `B` samples of its batch."""
+    from oracle import elbo, nets
+    from oracle import train as otrain
+
+    name, model = w["name"], w["model"]
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.requires_grad) for k, v in model.named_parameters()}
+    data = {m: v[:B].cpu() for m, v in w["data"].items()}
+    g = torch.Generator().manual_seed(1234)
+    K = w["K"]
+    if name in ("cfg3", "cfg3k1"):
+        L = w["L"]
+        shape = (K, B, L) if name == "cfg3" else (B, L)
+        return sd, lambda s: otrain.mopoe_mnist_svhn_loss(s, data, torch.randn(*shape, generator=g))
+    if name == "cfg2":
+        L = w["L"]
+        fam, loss = model.model_config.prior_and_posterior_dist, model.model_config.loss
+        names = ["mnist", "svhn"]
+
+        def f(s):
+            enc, dec = nets.build_mnist_svhn(s)
+            e = {m: enc[m](data[m]) for m in names}
+            if fam == "laplace_with_softmax":
+                noise = {m: torch.empty(K, B, L).uniform_(torch.finfo(torch.float32).eps - 1, 1, generator=g) for m in names}
+            else:
+                noise = {m: torch.randn(K, B, L, generator=g) for m in names}
+            return elbo.mmvae_forward(e, data, dec, noise, names=names, K=K, family=fam, loss=loss,
+                                      prior_log_var=s["prior_log_var"] if "prior_log_var" in s else None)
+        return sd, f
+    if name == "cfg4":
+        names = list(data.keys())
+        L = S = 32
+        lo = torch.finfo(torch.float32).eps - 1
+
+        def f(s):
+            e = {m: nets.mmnist_resnet_encoder(s, f"encoders.{m}.", data[m]) for m in names}
+            dec = {m: (lambda z, m=m: nets.mmnist_resnet_decoder(s, f"decoders.{m}.", z)) for m in names}
+            noise = {c: dict(u=torch.empty(K, B, L).uniform_(lo, 1, generator=g), w=torch.empty(K, B, S).uniform_(lo, 1, generator=g),
+                             **{r: torch.empty(K, B, S).uniform_(lo, 1, generator=g) for r in names if r != c}) for c in names}
+            plv = {"shared": s["logvars_priors.shared"], **{m: s["logvars_priors." + m] for m in names}}
+            return elbo.mmvaeplus_forward(e, data, dec, noise, names=names, K=K, family="laplace_with_softmax",
+                                          loss="iwae_looser", beta=2.5, prior_logvars=plv,
+                                          dists={m: "laplace" for m in names}, dist_scales={m: 0.75 for m in names})
+        return sd, f
+    if name == "cfg5":
+        names = ["image", "attributes"]
+        fns = dict(image=nets.cub_resnet_encoder, attributes=nets.mlp_encoder)
+
+        def f(s):
+            e = {m: fns[m](s, f"encoders.{m}.", data[m]) for m in names}
+            dec = dict(image=lambda z: nets.cub_resnet_decoder(s, "decoders.image.", z),
+                       attributes=lambda z: nets.mlp_decoder(s, "decoders.attributes.", z, (40,)))
+            joint = nets.joint_encoder_generic(s, fns, data)
+            return elbo.jmvae_forward(joint, e, data, dec, torch.randn(B, 64, generator=g), names=names, epoch=20,
+                                      dists=dict(image="normal", attributes="bernoulli"))
+        return sd, f
+    raise ValueError(name)
+
+
+def cpu_baseline(w, budget_s=20.0):
+    """The oracle's training step (torch CPU, same architecture / K) on the host cores, on a bounded sample."""
     from oracle import train as otrain
 
     # torch's intra-op pool scales poorly on these small convolutions.  Measured on the GPU box's host (2 x EPYC
@@ -62,15 +197,13 @@ def cpu_baseline(model, data, K, L, budget_s=20.0):
         pass
     ncores = max(1, min(ncores, int(os.environ.get("MVK_CPU_THREADS", "16"))))
     torch.set_num_threads(ncores)
-    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    B = w["B"]
+    Bc = B if w["name"] in ("cfg3", "cfg3k1", "cfg2") else min(B, 8)  # ResNet configurations: a reduced batch
+    sd, loss_fn = oracle_loss_fn(w, Bc)
     st = otrain.AdamState(sd)
-    cdata = {m: v.cpu() for m, v in data.items()}
-    B = cdata["mnist"].shape[0]
-    g = torch.Generator().manual_seed(1234)
 
     def step():
-        eps = torch.randn(K, B, L, generator=g)
-        otrain.train_step(sd, st, lambda s: otrain.mopoe_mnist_svhn_loss(s, cdata, eps), lr=1e-3)
+        otrain.train_step(sd, st, loss_fn, lr=1e-3)
 
     step()  # warm-up
     n, t0 = 0, time.perf_counter()
@@ -80,8 +213,81 @@ def cpu_baseline(model, data, K, L, budget_s=20.0):
         el = time.perf_counter() - t0
         if el > budget_s or n >= 8:
             break
-    return {"value": round(n * B / el, 2), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} full training steps (B={B}, K={K}) of oracle/train.py after 1 warm-up step, {el:.1f}s"}
+    note = "" if Bc == B else f" at a reduced batch of {Bc} (per-sample cost taken as batch-independent)"
+    return {"value": round(n * Bc / el, 2), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} full training steps (B={Bc}, K={w['K']}) of the oracle after 1 warm-up step, {el:.1f}s{note}"}
+
+
+# ---- device-timestamp profiler ----------------------------------------------------------------------------------------
+class DeviceProfiler:
+    """Records of the library's device-timestamp profiler: one per instrumented launch (eager) or per captured launch
+    (hipGraph: a record accumulates one duration per replay)."""
+
+    def __init__(self, device, nslots=2048):
+        from multivae_amd import _lib
+
+        self.lib = _lib.load()
+        self.n = nslots
+        self.slots = torch.zeros((nslots, 520), dtype=torch.int64, device=device)  # MVK_PROF_SLOT_U64 (include/mvk.h)
+        self.slots[:, 8:264:8] = -1  # 0xFFFF... as unsigned: the armed start stamps
+        self.kinds = (ctypes.c_int32 * nslots)()
+        self.work = (ctypes.c_double * nslots)()
+        self.khz = self.lib.mvk_prof_clock_khz()
+        self.count = 0
+
+    def start(self):
+        torch.cuda.synchronize()
+        self.lib.mvk_prof_enable(ctypes.c_void_p(self.slots.data_ptr()), self.n, ctypes.cast(self.kinds, ctypes.c_void_p),
+                                 ctypes.cast(self.work, ctypes.c_void_p))
+        self.active = True
+
+    def stop(self):
+        torch.cuda.synchronize()
+        if self.active:
+            self.count = self.lib.mvk_prof_count()
+            self.lib.mvk_prof_enable(None, 0, None, None)
+            self.active = False
+
+    def boundary_seconds(self, n=64):
+        """The dependent-kernel boundary on this stream (median gap between back-to-back one-wave kernels)."""
+        from multivae_amd._lib import stream_ptr
+
+        ticks = torch.zeros((n, 2), dtype=torch.int64, device=self.slots.device)
+        torch.cuda._sleep(200_000)  # let the host enqueue all of them behind a short spin
+        self.lib.mvk_prof_calibrate(ctypes.c_void_p(ticks.data_ptr()), n, stream_ptr())
+        torch.cuda.synchronize()
+        d = (ticks[1:, 0] - ticks[:-1, 1]).double()  # last instruction of one -> first instruction of the next
+        return float(d.median()) / (self.khz * 1e3) if self.khz > 0 else 0.0
+
+    def reset_sums(self):
+        """Forget what the records accumulated so far (warm-up launches); they stay armed."""
+        torch.cuda.synchronize()
+        self.slots[:, :3] = 0
+
+    def records(self):
+        """[(kind name, work per launch, launches, total seconds (first workgroup in -> the launch has retired),
+        total seconds (first workgroup in -> last workgroup out))]"""
+        n = self.count
+        s = self.slots[:n, :3].cpu()
+        out = []
+        for i in range(n):
+            cnt = int(s[i, 1])
+            if cnt and self.khz > 0:
+                out.append((PROF_KINDS.get(self.kinds[i], str(self.kinds[i])), self.work[i], cnt,
+                            int(s[i, 2]) / (self.khz * 1e3), int(s[i, 0]) / (self.khz * 1e3)))
+        return out
+
+
+def summarise(recs, kinds, boundary_s=0.0):
+    """Durations per launch = (first workgroup in -> next kernel's first instruction) - one kernel boundary."""
+    sel = [r for r in recs if r[0] in kinds]
+    if not sel:
+        return None
+    n = sum(r[2] for r in sel)
+    work, outer, inner = sum(r[1] * r[2] for r in sel), sum(r[3] for r in sel), sum(r[4] for r in sel)
+    dur = max(outer - n * boundary_s, inner)
+    return dict(launches=n, work=work, seconds=dur, avg_us=1e6 * dur / n, inner_avg_us=1e6 * inner / n,
+                outer_avg_us=1e6 * outer / n)
 
 
 def main():
@@ -89,9 +295,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=512, help="per-device batch (reference: per_device_train_batch_size)")
+    ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg3k1", "cfg4", "cfg5"],
+                    help="BASELINE.json configuration (cfg3 = configs[2], the headline; cfg3k1 = the same with the "
+                         "reference's single sample)")
+    ap.add_argument("--batch", type=int, default=0, help="per-device batch (default: the configuration's)")
     ap.add_argument("--K", type=int, default=10)
     ap.add_argument("--latent-dim", type=int, default=20)
+    ap.add_argument("--family", default="normal", choices=["normal", "laplace_with_softmax"], help="cfg2 posterior family")
+    ap.add_argument("--loss", default="iwae_looser", choices=["iwae_looser", "dreg_looser"], help="cfg2 objective")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every launch from Python instead of replaying a hipGraph")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -110,47 +321,49 @@ def main():
     if use_dist:
         dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)  # nccl == RCCL on ROCm
 
-    from multivae_amd import kernels
+    from multivae_amd import _lib, kernels
     from multivae_amd.data.datasets.base import DatasetOutput
     from multivae_amd.trainers import FlatParams, FusedAdam
 
-    B, K, L = args.batch, args.K, args.latent_dim
-    model = build_model(K, L, device, seed=0)
+    w = build_workload(args.config, args, device, rank)
+    model, B, K = w["model"], w["B"], w["K"]
     flat = FlatParams(model)
     if use_dist:
-        flat.broadcast(0)  # C1: one parameter broadcast (SURVEY.md §2.3)
-    opt = FusedAdam(flat, lr=1e-3)
-    data = synthetic_batch(B, device, seed=rank)
-    inputs = DatasetOutput(data=data)
+        flat.broadcast(0)  # C1: one parameter broadcast (SURVEY.md section 2.3)
+    opt = FusedAdam(flat, **w["adam"])
+    inputs = DatasetOutput(data=w["data"])
     gen = torch.Generator(device=device).manual_seed(1000 + rank)
     grad_scale = 1.0 / world
+    draw = w["noise"]
+    fkw = w["fwd_kwargs"]
 
     def eager_step():
-        eps = torch.randn(K, B, L, device=device, generator=gen)
+        kw = dict(fkw)
+        if draw is not None:
+            kw["noise"] = draw(gen)
         opt.zero_grad()
-        out = model(inputs, noise=eps)
+        out = model(inputs, **kw)
         out.loss.backward()
         if use_dist:
             flat.all_reduce()  # C2: ONE all-reduce of the flat gradient buffer
         opt.step(grad_scale=grad_scale)
         return out
 
-    # zero_grad + forward + backward replayed as ONE hipGraph launch (the host needs ~1.9 ms to enqueue the ~100
-    # launches of a step, about what the GPU needs to run them); all-reduce and the fused Adam launch stay outside.
+    # zero_grad + forward + backward replayed as ONE hipGraph launch (the host needs about as long to enqueue the
+    # launches of a step as the GPU needs to run them); all-reduce and the fused Adam launch stay outside.
     graphed = None
     if not args.no_graph:
         from multivae_amd.trainers import GraphedStep
 
         try:
-            graphed = GraphedStep(model, flat, inputs, noise=torch.zeros(K, B, L, device=device),
-                                  capture_error_mode="thread_local" if use_dist else "global")
+            graphed = GraphedStep(model, flat, inputs, noise=torch.zeros_like(draw(gen)) if draw is not None else None,
+                                  capture_error_mode="thread_local" if use_dist else "global", **fkw)
         except Exception as e:  # capture is an optimisation, not a requirement
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graphed = None
 
     def graph_step():
-        eps = torch.randn(K, B, L, device=device, generator=gen)
-        out = graphed(inputs, eps)
+        out = graphed(inputs, draw(gen) if draw is not None else None)
         if use_dist:
             flat.all_reduce()
         opt.step(grad_scale=grad_scale)
@@ -163,8 +376,6 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    if graphed is None:
-        kernels.PROFILE["recon_nll"] = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -176,28 +387,53 @@ def main():
     loss = float(out.loss.detach())
     if loss != loss:
         raise ArithmeticError("NaN detected in train loss")
-    timed_in = "timed region"
-    if graphed is not None and rank == 0:
-        # a graph replay carries no host-visible events: time the dominant kernel with HIP events in eager steps of
-        # the same workload right after the timed region (the rocprof summary under profiles/ covers both)
-        kernels.PROFILE["recon_nll"] = []
-        kernels.PROFILE["presleep_cycles"] = 200_000  # ~0.1 ms GPU spin before the bracketed launch (see kernels.py)
-        for _ in range(min(args.steps, 10)):
+
+    recs, events, step_flops, ms_instr, boundary = [], [], 0.0, None, 0.0
+    if rank == 0:
+        # Kernel durations: the same step again with the library's device-timestamp records switched on (captured into a
+        # second graph: every replay accumulates into the records), `steps` replays right after the timed region.  The
+        # stamps and the one-wave fold kernels behind the instrumented launches cost ~2 % of the step, which is why the
+        # headline number above is measured without them.
+        prof = DeviceProfiler(device)
+        prof.start()
+        step2 = eager_step
+        if graphed is not None:
+            try:
+                g2 = GraphedStep(model, flat, inputs, noise=torch.zeros_like(draw(gen)) if draw is not None else None,
+                                 capture_error_mode="thread_local" if use_dist else "global", **fkw)
+                prof.stop()  # the captured launches keep their records; nothing else is stamped from here on
+
+                def step2():
+                    o = g2(inputs, draw(gen) if draw is not None else None)
+                    if use_dist:
+                        flat.all_reduce()
+                    opt.step(grad_scale=grad_scale)
+                    return o
+            except Exception as e:
+                print(f"[bench] instrumented capture failed ({type(e).__name__}: {e}); profiling eagerly", file=sys.stderr)
+        for _ in range(2):
+            step2()
+        prof.reset_sums()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step2()
+        torch.cuda.synchronize()
+        ms_instr = 1e3 * (time.perf_counter() - t1) / args.steps
+        prof.stop()
+        recs = prof.records()
+        boundary = prof.boundary_seconds()
+        # beside it: the HIP-event bracket of the NLL launch in eager steps, and the GEMM FLOP count of one step
+        kernels.PROFILE["recon_nll"] = events
+        kernels.PROFILE["presleep_cycles"] = 200_000  # ~0.1 ms GPU spin: the host enqueues the launch meanwhile
+        for _ in range(3):
             eager_step()
         torch.cuda.synchronize()
+        kernels.PROFILE.pop("recon_nll", None)
         kernels.PROFILE.pop("presleep_cycles", None)
-        timed_in = "eager steps after the graph-replayed timed region"
-    # what an event pair with nothing in between reads on this stream (the timer's own cost, subtracted below)
-    empty = []
-    if rank == 0:
-        for _ in range(20):
-            torch.cuda._sleep(200_000)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            e1.record()
-            empty.append((e0, e1))
+        _lib.COUNT_FLOPS = [0.0]  # GEMM-shaped FLOP of one step (every mvk_linear / gemm / conv entry point)
+        eager_step()
         torch.cuda.synchronize()
-    events = kernels.PROFILE.pop("recon_nll", [])
+        step_flops, _lib.COUNT_FLOPS = _lib.COUNT_FLOPS[0], None
 
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if use_dist:
@@ -205,45 +441,73 @@ def main():
     elapsed = float(t.item())
 
     if rank == 0:
-        D = 784 + 3072
-        alg_bytes = 4.0 * B * D * (2 * K + 1)  # read recon, write d_recon, read x
-        durs = [s.elapsed_time(e) * 1e-3 for s, e in events]
-        raw = sum(durs) / max(len(durs), 1)
-        overhead = sum(s.elapsed_time(e) * 1e-3 for s, e in empty) / max(len(empty), 1)
-        avg = max(raw - overhead, 0.0)
-        achieved = alg_bytes / avg / 1e9 if avg > 0 else 0.0
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "recon_nll_traffic.json")
-        if os.path.exists(tf):
-            with open(tf) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+        ms = 1e3 * elapsed / args.steps
         res = {
-            "metric": "train samples/sec (ELBO step) MoPoE MnistSvhn K=10",
+            "metric": w["metric"],
             "value": round(world * B * args.steps / elapsed, 2),
             "unit": "samples/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "ms_per_step": round(ms, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"MoPoE MnistSvhn (mnist MLP + svhn conv), K={K}, per-device batch {B}, "
-                                   f"latent_dim {L}, Adam lr 1e-3, fwd+ELBO+bwd+optimizer"
-                                   + (", 1 RCCL all-reduce/step" if world > 1 else ""),
-                       "global_batch": world * B, "K": K, "parallelism": f"dp{world}", "final_loss": round(loss, 4),
+            "config": {"workload": w["text"] + (", 1 RCCL all-reduce/step" if world > 1 else ""),
+                       "baseline_config": args.config, "global_batch": world * B, "K": K, "parallelism": f"dp{world}",
+                       "final_loss": round(loss, 4),
                        "launch": "hipGraph replay (fwd+bwd) + all-reduce + Adam" if graphed is not None else "eager"},
-            "roofline": {"kernel": "recon_nll_kernel<vec,fwd> (fused reconstruction NLL + d_recon, both modalities)",
-                         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes": alg_bytes, "avg_launch_us": round(avg * 1e6, 2),
-                         "event_pair_us": round(raw * 1e6, 2), "empty_event_pair_us": round(overhead * 1e6, 2),
-                         "launches_timed": len(durs), "timed_in": timed_in},
         }
+        nll = summarise(recs, {"recon_nll"}, boundary)
+        if nll:
+            ev = [s.elapsed_time(e) * 1e-3 for s, e in events]
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "recon_nll_traffic.json")
+            if args.config == "cfg3" and os.path.exists(tf):
+                with open(tf) as f:
+                    traffic = json.load(f).get("hbm_bytes_per_launch")
+            ach = nll["work"] / nll["seconds"] / 1e9
+            res["roofline"] = {
+                "kernel": "recon_nll_kernel<vec,fwd> (fused reconstruction NLL + d_recon, all modalities, one launch)",
+                "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": "profiles/recon_nll_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
+                "algorithmic_bytes": nll["work"] / nll["launches"], "avg_launch_us": round(nll["avg_us"], 2),
+                "launches_timed": nll["launches"],
+                "first_in_last_out_us": round(nll["inner_avg_us"], 2), "retire_bracket_us": round(nll["outer_avg_us"], 2),
+                "kernel_boundary_us": round(1e6 * boundary, 2),
+                "method": "device timestamps (mvk_prof_enable, constant-rate clock): first workgroup in -> first "
+                          "instruction of the one-wave kernel queued behind the launch (its stores have drained), minus "
+                          "one dependent-kernel boundary calibrated in the same run; accumulated over `steps` replays of "
+                          "the instrumented step right after the timed region",
+                "instrumented_ms_per_step": round(ms_instr, 4),
+                "hip_event_pair_us": round(1e6 * sum(ev) / len(ev), 2) if ev else None}
+        conv = summarise(recs, {"imgconv_up", "imgconv_down", "imgconv_wgrad"}, boundary)
+        mf = {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F32_TFLOPS,
+              "peak_split_bf16": round(MFMA_BF16_TFLOPS / 6, 1),
+              "step_gemm_gflop": round(step_flops / 1e9, 2),
+              "step_achieved": round(step_flops / (ms * 1e-3) / 1e12, 2),
+              "step_frac": round(step_flops / (ms * 1e-3) / 1e12 / MFMA_F32_TFLOPS, 4),
+              "note": "fp32 products on the split-bf16 engine (6 bf16 MFMAs each): peak = the fp32-input MFMA rate, "
+                      "peak_split_bf16 = 2500 / 6; step_* = every GEMM-shaped FLOP of the step / ms_per_step"}
+        if conv:
+            ach = conv["work"] / conv["seconds"] / 1e12
+            mf.update({"kernel": "imgconv_kernel / imgwgrad_kernel (register-stationary 4x4/stride-2 convolutions)",
+                       "achieved": round(ach, 1), "frac": round(ach / MFMA_F32_TFLOPS, 4),
+                       "frac_split_bf16": round(ach / (MFMA_BF16_TFLOPS / 6), 4),
+                       "gflop_per_step": round(conv["work"] / args.steps / 1e9, 2),
+                       "us_per_step": round(1e6 * conv["seconds"] / args.steps, 1), "launches_timed": conv["launches"]})
+        res["roofline_mfma"] = mf
+        img = {k: summarise(recs, {k}, boundary) for k in ("image_layer_fwd", "image_layer_bwd")}
+        if any(img.values()):
+            res["roofline_image"] = {k: {"bound": "hbm", "achieved": round(v["work"] / v["seconds"] / 1e9, 1),
+                                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": round(v["work"] / v["seconds"] / 1e9 / HBM_PEAK_GBS, 4),
+                                         "avg_launch_us": round(v["avg_us"], 2)} for k, v in img.items() if v}
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(model, data, K, L, args.cpu_budget)
+            res["cpu_baseline"] = cpu_baseline(w, args.cpu_budget)
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.destroy_process_group()

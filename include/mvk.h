@@ -306,11 +306,13 @@ int64_t mvk_splitk_workspace_floats(int rows, int cols, int reduce_len);
  * per-workgroup partials in the caller-owned scratch ws).  The output-layer backward of the MLP decoders. */
 int mvk_act_bwd_colsum(const float* dY, const float* Y, int act, int M, int N, float* dPre, float* db, float* ws,
                        int64_t ws_floats, void* stream);
-/* db[N] += column sums of dY[M,N] (* act'(y_out)). */
-int mvk_colsum_acc(const float* dY, const float* y_out, int y_act, float* db, int M, int N, void* stream);
+/* db[N] += column sums of dY[M,N] (* act'(y_out)): per-workgroup partials in the caller-owned scratch ws, summed in a
+ * fixed order (bit-reproducible); ws == NULL (or too small) falls back to fp32 atomics. */
+int mvk_colsum_acc(const float* dY, const float* y_out, int y_act, float* db, int M, int N, float* ws, int64_t ws_floats,
+                   void* stream);
 /* db[c] += sum over n and spatial positions of dY[n,c,hw] (* act'(y_out)) for NCHW tensors. */
 int mvk_nchw_channel_sum_acc(const float* dY, const float* y_out, int y_act, float* db, int n, int c, int hw,
-                             void* stream);
+                             float* ws, int64_t ws_floats, void* stream);
 /* In-place dY *= act'(Y) (sigmoid: y(1-y), relu: y>0). */
 int mvk_act_bwd(float* dY, const float* Y, int64_t n, int act, void* stream);
 
@@ -432,6 +434,31 @@ int mvk_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, v
  * (1/world_size for DDP averaging).  trainers/base/base_trainer_config.py:58,62; base_trainer.py:350-361. */
 int mvk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                   double eps, double weight_decay, int step, double grad_scale, void* stream);
+/* torch.optim.Adam(amsgrad=True) (the reference's MMVAE+ PolyMNIST setting, examples/mmvae_plus/mmnist.py:61-62): vmax is
+ * the running maximum of exp_avg_sq (`max_exp_avg_sq`), updated in place and used in the denominator; vmax == NULL is
+ * mvk_adam_step.  lr is a host scalar per call, so learning-rate schedulers (base_trainer_config.py:60) cost nothing. */
+int mvk_adam_step_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1,
+                          double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream);
+
+/* Device-timestamp profiler (bench.py's roofline objects).  device_slots: nslots records of MVK_PROF_SLOT_U64 = 520
+ * uint64 each: [0] sum of durations (clock ticks, first workgroup in -> last workgroup out), [1] launches accumulated,
+ * [2] sum of (first workgroup in -> start of the one-wave fold kernel queued behind the launch: the launch has drained
+ * its stores by then; this bracket contains what a kernel trace reports), [8 + 8 e] start stamps, [264 + 8 e] end stamps
+ * (e < 32); the caller initialises the start stamps to ~0 and everything else to 0.  Every instrumented launch
+ * (kind 1: fused reconstruction NLL forward, 2: imgconv up, 3: imgconv down, 4: imgconv weight gradient, 5 / 6: image-
+ * layer forward / backward) takes the next record: its workgroups stamp the constant-rate clock on entry (min) and exit
+ * (max), and a one-wave kernel behind it adds max(end) - min(start) to the sum and re-arms the record, so a launch
+ * captured into a hipGraph accumulates one duration per replay.  host_kinds / host_work (nslots entries, may be NULL)
+ * receive the kind and the algorithmic work of the launch (bytes for the HBM-bound kinds 1, 5, 6, FLOP for the
+ * others).  device_slots == NULL switches the profiler off (later launches are not stamped; captured ones keep their
+ * record). */
+int mvk_prof_enable(void* device_slots, int nslots, int32_t* host_kinds, double* host_work);
+int mvk_prof_count(void);     /* records taken since mvk_prof_enable */
+/* n one-wave kernels back to back, each storing the clock at its first and last instruction into device_ticks[2 i],
+ * device_ticks[2 i + 1] (uint64): first[i + 1] - last[i] is the dependent-kernel boundary that the retire bracket of a
+ * record contains once. */
+int mvk_prof_calibrate(void* device_ticks, int n, void* stream);
+int mvk_prof_clock_khz(void); /* rate of the stamped clock */
 
 /* Measurement hooks for experiment builds of the library (-DMVK_PHASES: per-phase cycle counters of the GEMM main
  * loop accumulated into an 8-entry device buffer; -DMVK_EXPER: ablation switches).  Inert in the shipped build. */

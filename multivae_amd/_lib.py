@@ -60,8 +60,8 @@ PROTOTYPES = {
     "mvk_linear_bwd_data": [_p, _p, _p, _i, _i, _i, _p, _i, _p, _i, _i, _p, _p, _i64, _p],
     "mvk_linear_bwd_weight": [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _i64, _p],
     "mvk_act_bwd_colsum": [_p, _p, _i, _i, _i, _p, _p, _p, _i64, _p],
-    "mvk_colsum_acc": [_p, _p, _i, _p, _i, _i, _p],
-    "mvk_nchw_channel_sum_acc": [_p, _p, _i, _p, _i, _i, _i, _p],
+    "mvk_colsum_acc": [_p, _p, _i, _p, _i, _i, _p, _i64, _p],
+    "mvk_nchw_channel_sum_acc": [_p, _p, _i, _p, _i, _i, _i, _p, _i64, _p],
     "mvk_act_bwd": [_p, _p, _i64, _i, _p],
     "mvk_gemm": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _i, _p, _i, _p, _i64, _p],
     "mvk_pack_conv4s2_weight": [_p, _i, _i, _p, _i, _i, _p, _p],
@@ -89,6 +89,7 @@ PROTOTYPES = {
     "mvk_nchw_to_nhwc": [_p, _p, _i, _i, _i, _i, _p],
     "mvk_nhwc_to_nchw": [_p, _p, _i, _i, _i, _i, _p],
     "mvk_adam_step": [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _d, _p],
+    "mvk_adam_step_amsgrad": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _d, _p],
     "mvk_mmvae_std_fwd": [_p, _i, _i, _i, _p, _p],
     "mvk_mmvae_std_bwd": [_p, _p, _p, _i, _i, _i, _p, _p],
     "mvk_mmvae_latent_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p],
@@ -128,6 +129,14 @@ def load(path=None):
         fn.restype = C.c_int
     lib.mvk_conv4s2_small_up_supported.argtypes = [_i, _i, _i, _i]
     lib.mvk_conv4s2_small_up_supported.restype = C.c_int
+    lib.mvk_prof_enable.argtypes = [_p, _i, _p, _p]
+    lib.mvk_prof_enable.restype = C.c_int
+    lib.mvk_prof_calibrate.argtypes = [_p, _i, _p]
+    lib.mvk_prof_calibrate.restype = C.c_int
+    lib.mvk_prof_count.argtypes = []
+    lib.mvk_prof_count.restype = C.c_int
+    lib.mvk_prof_clock_khz.argtypes = []
+    lib.mvk_prof_clock_khz.restype = C.c_int
     lib.mvk_splitk_workspace_floats.argtypes = [_i, _i, _i]
     lib.mvk_splitk_workspace_floats.restype = C.c_int64
     _lib = lib
@@ -162,9 +171,34 @@ _SYNC_DEBUG = os.environ.get("MVK_SYNC_DEBUG", "")  # debugging aid: "1" = devic
 # comma list of entry-point names to sync after
 
 
+# GEMM-shaped entry points -> algorithmic FLOP of one call (2 x multiply-adds) from its positional arguments; used by
+# bench.py (COUNT_FLOPS = [0.0] switches the count on for one eager step).  Everything else on the path is
+# elementwise / reduction work (a few FLOP per byte) and is not counted.
+GEMM_FLOPS = {
+    "mvk_linear_fwd": lambda a: 2.0 * a[4] * a[5] * a[6],
+    "mvk_linear_bwd_data": lambda a: 2.0 * a[3] * a[4] * a[5],
+    "mvk_linear_bwd_weight": lambda a: 2.0 * a[4] * a[5] * a[6],
+    "mvk_gemm": lambda a: 2.0 * a[3] * a[4] * a[5],
+    "mvk_conv4s2_down": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
+    "mvk_conv4s2_up": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
+    "mvk_conv4s2_wgrad": lambda a: 2.0 * a[3] * a[4] * a[5] * 16 * a[6] * a[7],
+    "mvk_conv3x3": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
+    "mvk_conv3x3_wgrad": lambda a: 2.0 * a[3] * a[4] * a[5] * 9 * a[6] * a[7],
+    "mvk_conv4s2_up_nchw_small": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
+    "mvk_conv4s2_small_up_fwd": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
+    "mvk_conv4s2_small_down_fwd": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
+    "mvk_conv4s2_small_up_bwd": lambda a: 2.0 * 2.0 * a[12] * a[13] * a[14] * 16 * a[15] * a[16],  # data + weight
+    "mvk_unflatten_wgrad": lambda a: 2.0 * a[3] * a[4] * 16 * a[5],
+    "mvk_flatten_wgrad": lambda a: 2.0 * a[3] * 16 * a[4] * a[5],
+}
+COUNT_FLOPS = None
+
+
 def call(name, *args):
     lib = load()
     check(getattr(lib, name)(*args), name)
+    if COUNT_FLOPS is not None and name in GEMM_FLOPS:
+        COUNT_FLOPS[0] += GEMM_FLOPS[name](args)
     if _SYNC_DEBUG and (_SYNC_DEBUG == "1" or name in _SYNC_DEBUG.split(",")):
         torch.cuda.synchronize()
 

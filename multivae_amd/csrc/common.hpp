@@ -43,3 +43,35 @@ __device__ __forceinline__ float mvk_act_grad_from_out(float y, int act) {
 
 __device__ __forceinline__ bool mvk_dev_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline bool mvk_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- device-timestamp profiler (mvk_prof_enable, mvk.h) --------------------------------------------------------------
+// An instrumented launch takes the next record of the caller's device array; thread 0 of every workgroup stamps the
+// constant-rate clock (s_memrealtime) on entry (min) and exit (max) into one of 32 entries of the record (64 bytes apart:
+// the ~1000 workgroups of a streaming kernel leave within a few microseconds, one address would serialise their atomics
+// for longer than that); a one-wave fold kernel behind the launch adds max(end) - min(start) (first workgroup's first
+// instruction to last workgroup's last one: what a kernel trace reports) to the record's running sum and re-arms it, so a
+// record captured into a hipGraph accumulates one duration per replay.  A null record costs one scalar compare.
+#define MVK_PROF_ENTRIES 32
+#define MVK_PROF_SLOT_U64 (8 + 2 * 8 * MVK_PROF_ENTRIES)  // header {sum, count, ...} + start entries + end entries
+struct mvk_prof_slot {
+  unsigned long long w[MVK_PROF_SLOT_U64];
+};
+namespace mvk {
+mvk_prof_slot* prof_next(int kind, double work);      // host side (misc.hip): nullptr while the profiler is off
+void prof_fold(mvk_prof_slot* slot, hipStream_t s);    // enqueue the fold kernel behind an instrumented launch
+}
+__device__ __forceinline__ void mvk_prof_begin(mvk_prof_slot* s) {
+  if (s && threadIdx.x == 0) {
+    const unsigned long long t = (unsigned long long)wall_clock64();
+    unsigned long long* e = &s->w[8 + 8 * ((blockIdx.x + blockIdx.y + blockIdx.z) & (MVK_PROF_ENTRIES - 1))];
+    if (t < __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(e, t);
+  }
+}
+__device__ __forceinline__ void mvk_prof_end(mvk_prof_slot* s) {
+  if (s) {
+    __syncthreads();
+    if (threadIdx.x == 0)
+      atomicMax(&s->w[8 + 8 * MVK_PROF_ENTRIES + 8 * ((blockIdx.x + blockIdx.y + blockIdx.z) & (MVK_PROF_ENTRIES - 1))],
+                (unsigned long long)wall_clock64());
+  }
+}

@@ -327,6 +327,7 @@ struct ReconTable {
   int block_start[MAXM + 1];  // prefix sum of blocks per modality
   int kchunks[MAXM];          // sample chunks per batch row (large rows are cut finer: load balance, see launch_recon)
   int n;
+  mvk_prof_slot* prof;        // device-timestamp record of this launch (null: profiler off)
 };
 
 __device__ __forceinline__ void nll_elem(int dist, float inv_s, float inv_s2, float r, float x, float& nll,
@@ -437,6 +438,7 @@ static int recon_kchunks(int K, long long D) {
 // SIMD that the streaming Normal / Laplace rows would lose)
 template <int MODE, bool FWD>
 __global__ __launch_bounds__(NLL_THREADS) void recon_nll_kernel(const ReconTable tb, int K, int B) {
+  mvk_prof_begin(tb.prof);
   // locate the modality of this block
   int mi = 0;
 #pragma unroll
@@ -498,6 +500,7 @@ __global__ __launch_bounds__(NLL_THREADS) void recon_nll_kernel(const ReconTable
       d.rows[(long long)(k0 + k) * B + b] = s;
     }
   }
+  mvk_prof_end(tb.prof);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -586,6 +589,10 @@ static int launch_recon(const mvk_recon_desc* descs, int n_mod, int K, int B, bo
     }
     if (tb.n == 0) continue;
     tb.block_start[tb.n] = blocks;
+    double bytes = 0.0;  // algorithmic HBM bytes: reconstructions read once, gradients written once, x once
+    for (int i = 0; i < tb.n; ++i)
+      bytes += 4.0 * B * (double)tb.d[i].D * (K + (tb.d[i].drecon ? K : 0) + 1);
+    tb.prof = (fwd && pass == 1) ? mvk::prof_next(1, bytes) : nullptr;
     const dim3 g(blocks), t(NLL_THREADS);
     if (pass == 0) {
       if (fwd) hipLaunchKernelGGL((recon_nll_kernel<0, true>), g, t, 0, s, tb, K, B);
@@ -598,6 +605,7 @@ static int launch_recon(const mvk_recon_desc* descs, int n_mod, int K, int B, bo
       else hipLaunchKernelGGL((recon_nll_kernel<2, false>), g, t, 0, s, tb, K, B);
     }
     MVK_CHECK_LAUNCH();
+    mvk::prof_fold(tb.prof, s);
   }
   return MVK_OK;
 }

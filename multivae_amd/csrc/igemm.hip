@@ -264,10 +264,13 @@ static void rowmajor_epi(Epilogue& e, float* out, long long ld) {
 
 // ---- small helper kernels ------------------------------------------------------------------------------
 // db[n] += sum_m dY[m][n] (* act'(Y)).  Threads = (N/vec column groups) x (row lanes); 16-byte coalesced loads when
-// N % 4 == 0; partials combined through LDS, one atomicAdd per column per workgroup.
+// N % 4 == 0; partials combined through LDS.  With `part` every workgroup row writes its partial sums to
+// part[blockIdx.y][N] and an ordered finish adds them to db (deterministic); without scratch: one atomicAdd per column
+// per workgroup.
 template <int VEC>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dY, const float* __restrict__ Y, int act,
-                                                     int M, int N, int rows_per_block, float* __restrict__ db) {
+                                                     int M, int N, int rows_per_block, float* __restrict__ db,
+                                                     float* __restrict__ part) {
   const int ncg = (N + VEC - 1) / VEC;            // column groups
   const int cg_per_blk = ncg < 256 ? ncg : 256;   // column groups handled by this block (blockIdx.x strides them)
   const int lanes_r = 256 / cg_per_blk;           // row lanes
@@ -313,14 +316,28 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
       float t = 0.f;
       for (int q = 0; q < lanes_r; ++q) t += red[(q * cg_per_blk + (threadIdx.x % cg_per_blk)) * VEC + c];
       const int col = cg * VEC + c;
-      if (col < N) atomicAdd(db + col, t);
+      if (col < N) {
+        if (part) part[(long long)blockIdx.y * N + col] = t;
+        else atomicAdd(db + col, t);
+      }
     }
   }
 }
 
+// db[n] += sum_r part[r][n], r in order: one thread per column (any N)
+__global__ __launch_bounds__(256) void colsum_finish_scalar_kernel(const float* __restrict__ part, int rows, int N,
+                                                                   float* __restrict__ db) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  float t = 0.f;
+  for (int r = 0; r < rows; ++r) t += part[(long long)r * N + c];
+  db[c] += t;
+}
+
 // db[c] += sum over (n, p) of dY[n,c,p] (* act'(Y)) for NCHW tensors; one block per (c, chunk of n)
 __global__ void nchw_channel_sum_kernel(const float* __restrict__ dY, const float* __restrict__ Y, int act, int n,
-                                        int c, int hw, int imgs_per_block, float* __restrict__ db) {
+                                        int c, int hw, int imgs_per_block, float* __restrict__ db,
+                                        float* __restrict__ part) {
   const int ch = blockIdx.x;
   const int i0 = blockIdx.y * imgs_per_block;
   int i1 = i0 + imgs_per_block;
@@ -338,10 +355,19 @@ __global__ void nchw_channel_sum_kernel(const float* __restrict__ dY, const floa
   __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(db + ch, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    const float t = red[0] + red[1] + red[2] + red[3];
+    if (part) part[(long long)blockIdx.y * c + ch] = t;
+    else atomicAdd(db + ch, t);
+  }
 }
 
-static int colsum(const float* dY, const float* Y, int act, int M, int N, float* db, hipStream_t s) {
+int colsum_finish(const float* part, int rows, int N, float* db, hipStream_t s);
+static int colsum_finish_any(const float* part, int rows, int N, float* db, hipStream_t s);
+
+// ws: scratch for the per-workgroup partial sums (deterministic ordered finish); without it: fp32 atomics
+static int colsum(const float* dY, const float* Y, int act, int M, int N, float* db, float* ws, long long ws_floats,
+                  hipStream_t s) {
   if (M <= 0 || N <= 0) return MVK_OK;
   const bool vec = (N % 4 == 0) && mvk_aligned16(dY) && (!Y || mvk_aligned16(Y));
   const int ncg = vec ? N / 4 : N;
@@ -351,12 +377,13 @@ static int colsum(const float* dY, const float* Y, int act, int M, int N, float*
   int rows_per_block = (M + 255) / 256;
   if (rows_per_block < 16) rows_per_block = 16;
   const int gy = (M + rows_per_block - 1) / rows_per_block;
+  float* part = (ws && (long long)gy * N <= ws_floats) ? ws : nullptr;
   if (vec)
-    hipLaunchKernelGGL((colsum_kernel<4>), dim3(gx, gy), dim3(256), 0, s, dY, Y, act, M, N, rows_per_block, db);
+    hipLaunchKernelGGL((colsum_kernel<4>), dim3(gx, gy), dim3(256), 0, s, dY, Y, act, M, N, rows_per_block, db, part);
   else
-    hipLaunchKernelGGL((colsum_kernel<1>), dim3(gx, gy), dim3(256), 0, s, dY, Y, act, M, N, rows_per_block, db);
+    hipLaunchKernelGGL((colsum_kernel<1>), dim3(gx, gy), dim3(256), 0, s, dY, Y, act, M, N, rows_per_block, db, part);
   MVK_CHECK_LAUNCH();
-  return MVK_OK;
+  return part ? colsum_finish_any(part, gy, N, db, s) : MVK_OK;
 }
 
 // db[n] += sum_r part[r][n] in a fixed order: 64 row lanes x 4 column quads per workgroup (float4 loads), LDS tree.
@@ -402,6 +429,13 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
 int colsum_finish(const float* part, int rows, int N, float* db, hipStream_t s) {
   // N % 4 == 0 and 16-byte aligned partials are guaranteed by epilogue_vec_ok + the scratch allocation
   hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 15) / 16), dim3(256), 0, s, part, rows, N, db);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+static int colsum_finish_any(const float* part, int rows, int N, float* db, hipStream_t s) {
+  if (N % 4 == 0 && mvk_aligned16(part)) return colsum_finish(part, rows, N, db, s);
+  hipLaunchKernelGGL(colsum_finish_scalar_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, rows, N, db);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }
@@ -473,7 +507,7 @@ static int launch_with_colsum(GemmDesc& d, int zdim, float* db, float* ws, int64
   d.e.colsum_part = nullptr;
   if (rc != MVK_OK) return rc;
   if (fuse && info.bm > 0) return colsum_finish(ws, ((d.M + info.bm - 1) / info.bm) * zdim, d.N, db, s);
-  return colsum(out, nullptr, 0, (int)out_rows, d.N, db, s);
+  return colsum(out, nullptr, 0, (int)out_rows, d.N, db, ws, ws_floats, s);
 }
 
 }  // namespace mvk
@@ -553,7 +587,7 @@ int mvk_linear_bwd_data(const float* dY, const float* W, float* dX, int M, int N
   const long long tiles = (long long)((d.M + 127) / 128) * ((d.N + 63) / 64);
   if (!(ws && tiles < 128 && d.K >= 256)) return launch_with_colsum(d, 1, colsum_acc, ws, ws_floats, dX, M, s);
   const int rc = launch_auto(d, ws, ws_floats, s);
-  return rc != MVK_OK ? rc : colsum(dX, nullptr, 0, M, K, colsum_acc, s);
+  return rc != MVK_OK ? rc : colsum(dX, nullptr, 0, M, K, colsum_acc, ws, ws_floats, s);
 }
 
 int mvk_linear_bwd_weight(const float* dY, const float* X, float* dW, float* db, int M, int N, int K,
@@ -573,7 +607,7 @@ int mvk_linear_bwd_weight(const float* dY, const float* X, float* dW, float* db,
   d.K = M;
   int rc = launch_splitk(d, ws, ws_floats, 1024, s);
   if (rc) return rc;
-  if (db) return colsum(dY, y_out, y_act, M, N, db, s);
+  if (db) return colsum(dY, y_out, y_act, M, N, db, ws, ws_floats, s);
   return MVK_OK;
 }
 
@@ -594,27 +628,30 @@ int mvk_act_bwd_colsum(const float* dY, const float* Y, int act, int M, int N, f
     hipLaunchKernelGGL(act_bwd_plain_kernel, dim3((unsigned)((n + 255) / 256 > 65535 ? 65535 : (n + 255) / 256)), dim3(256),
                        0, s, dPre, Y, n, act);
     MVK_CHECK_LAUNCH();
-    return db ? colsum(dPre, nullptr, 0, M, N, db, s) : MVK_OK;
+    return db ? colsum(dPre, nullptr, 0, M, N, db, ws, ws_floats, s) : MVK_OK;
   }
   hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3(blocks), dim3(256), 0, s, dY, Y, act, M, N, rpb, dPre, ws);
   MVK_CHECK_LAUNCH();
   return db ? colsum_finish(ws, blocks, N, db, s) : MVK_OK;
 }
 
-int mvk_colsum_acc(const float* dY, const float* y_out, int y_act, float* db, int M, int N, void* stream) {
+int mvk_colsum_acc(const float* dY, const float* y_out, int y_act, float* db, int M, int N, float* ws, int64_t ws_floats,
+                   void* stream) {
   if (!dY || !db) return MVK_EINVAL;
-  return colsum(dY, y_out, y_act, M, N, db, mvk_stream(stream));
+  return colsum(dY, y_out, y_act, M, N, db, ws, ws_floats, mvk_stream(stream));
 }
 
 int mvk_nchw_channel_sum_acc(const float* dY, const float* y_out, int y_act, float* db, int n, int c, int hw,
-                             void* stream) {
+                             float* ws, int64_t ws_floats, void* stream) {
   if (!dY || !db || n < 0 || c <= 0 || hw <= 0) return MVK_EINVAL;
   if (n == 0) return MVK_OK;
   int ipb = 16;
-  hipLaunchKernelGGL(nchw_channel_sum_kernel, dim3(c, (n + ipb - 1) / ipb), dim3(256), 0, mvk_stream(stream), dY,
-                     y_out, y_act, n, c, hw, ipb, db);
+  const int gy = (n + ipb - 1) / ipb;
+  float* part = (ws && (long long)gy * c <= ws_floats) ? ws : nullptr;
+  hipLaunchKernelGGL(nchw_channel_sum_kernel, dim3(c, gy), dim3(256), 0, mvk_stream(stream), dY, y_out, y_act, n, c, hw,
+                     ipb, db, part);
   MVK_CHECK_LAUNCH();
-  return MVK_OK;
+  return part ? colsum_finish_any(part, gy, c, db, mvk_stream(stream)) : MVK_OK;
 }
 
 int mvk_gemm(const float* A, const float* B, float* C, int M, int N, int K, int ta, int tb, const float* bias,

@@ -41,6 +41,7 @@ struct ImgConvArgs {
   float* colsum_part;    // [rows][COUT] per-workgroup column sums of the stored result, or null
   int n;                 // images
   int act, src_act;
+  mvk_prof_slot* prof;   // device-timestamp record of this launch (null: profiler off)
 };
 
 template <int KIND, int HS, int CIN, int COUT>
@@ -81,6 +82,7 @@ template <int KIND, int HS, int CIN, int COUT, bool HAS_SRC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void imgconv_kernel(const ImgConvArgs g) {
   using T = ICfg<KIND, HS, CIN, COUT>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  mvk_prof_begin(g.prof);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, kg = lane >> 5;
   const int wgtype = blockIdx.x % T::WG_TYPES;
@@ -367,6 +369,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       g.colsum_part[(long long)blockIdx.x * COUT + tid] = s;
     }
   }
+  mvk_prof_end(g.prof);
 }
 
 template <int KIND, int HS, int CIN, int COUT>
@@ -391,8 +394,11 @@ static int imgconv_launch(const ImgConvArgs& a, int* part_rows, hipStream_t s) {
   }
   const int grid = 256;
   if (part_rows) *part_rows = (KIND == IC_DOWN && T::WG_TYPES > 1) ? grid / T::WG_TYPES : grid;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), T::LDS_BYTES, s, a);
+  ImgConvArgs ap = a;
+  ap.prof = prof_next(KIND == IC_UP ? 2 : 3, 2.0 * a.n * HS * HS * 16.0 * CIN * COUT);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), T::LDS_BYTES, s, ap);
   MVK_CHECK_LAUNCH();
+  prof_fold(ap.prof, s);
   return MVK_OK;
 }
 
@@ -449,12 +455,14 @@ struct ImgWgradArgs {
   const float* V;  // [n][h][w][CV]
   float* slab;     // [workers][16 * CU][CV] partial gradients
   int n;
+  mvk_prof_slot* prof;
 };
 
 template <int HS, int CU, int CV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void imgwgrad_kernel(const ImgWgradArgs g) {
   using T = WCfg<HS, CU, CV>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  mvk_prof_begin(g.prof);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wgtype = blockIdx.x % T::WG_TYPES;
   const int worker = blockIdx.x / T::WG_TYPES, workers = gridDim.x / T::WG_TYPES;
@@ -614,6 +622,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         slab[(long long)(tap * CU + cu) * CV + b * 32 + col] = acc[a][b][r];
       }
   }
+  mvk_prof_end(g.prof);
 }
 
 template <int HS, int CU, int CV>
@@ -629,8 +638,11 @@ static int imgwgrad_launch(const ImgWgradArgs& a, int* nz, hipStream_t s) {
   }
   const int grid = 256;
   *nz = grid / T::WG_TYPES;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), T::LDS_BYTES, s, a);
+  ImgWgradArgs ap = a;
+  ap.prof = prof_next(4, 2.0 * a.n * HS * HS * 16.0 * CU * CV);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), T::LDS_BYTES, s, ap);
   MVK_CHECK_LAUNCH();
+  prof_fold(ap.prof, s);
   return MVK_OK;
 }
 
@@ -638,7 +650,7 @@ static int imgwgrad_launch(const ImgWgradArgs& a, int* nz, hipStream_t s) {
 int imgconv_wgrad(const float* U, const float* V, float* slab, long long slab_floats, int n, int h, int w, int Cu, int Cv,
                   int* nz, hipStream_t s) {
   if (h != w) return 1;
-  ImgWgradArgs a{U, V, slab, n};
+  ImgWgradArgs a{U, V, slab, n, nullptr};
   if (h == 8 && Cu == 32 && Cv == 64 && slab_floats >= 256ll * 16 * Cu * Cv) return imgwgrad_launch<8, 32, 64>(a, nz, s);
   if (h == 4 && Cu == 64 && Cv == 128 && n % 2 == 0 && slab_floats >= 64ll * 16 * Cu * Cv)
     return imgwgrad_launch<4, 64, 128>(a, nz, s);
@@ -649,7 +661,7 @@ int imgconv_wgrad(const float* U, const float* V, float* slab, long long slab_fl
 int imgconv_up(const float* V, const float* Wup, const float* bias, float* U, int n, int h, int w, int Cu, int Cv,
                int act, const float* u_act_src, int u_act, float* colsum_part, int* part_rows, hipStream_t s) {
   if (h != w) return 1;
-  ImgConvArgs a{V, Wup, bias, U, u_act_src, colsum_part, n, act, u_act};
+  ImgConvArgs a{V, Wup, bias, U, u_act_src, colsum_part, n, act, u_act, nullptr};
   if (h == 8 && Cv == 64 && Cu == 32) return imgconv_launch<IC_UP, 8, 64, 32>(a, part_rows, s);
   if (h == 4 && Cv == 128 && Cu == 64 && n % 2 == 0) return imgconv_launch<IC_UP, 4, 128, 64>(a, part_rows, s);
   return 1;
@@ -658,7 +670,7 @@ int imgconv_up(const float* V, const float* Wup, const float* bias, float* U, in
 int imgconv_down(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w, int Cu, int Cv,
                  int act, const float* v_act_src, int v_act, float* colsum_part, int* part_rows, hipStream_t s) {
   if (h != w) return 1;
-  ImgConvArgs a{U, Wdown, bias, V, v_act_src, colsum_part, n, act, v_act};
+  ImgConvArgs a{U, Wdown, bias, V, v_act_src, colsum_part, n, act, v_act, nullptr};
   if (h == 8 && Cu == 32 && Cv == 64) return imgconv_launch<IC_DOWN, 8, 32, 64>(a, part_rows, s);
   if (h == 4 && Cu == 64 && Cv == 128 && n % 2 == 0) return imgconv_launch<IC_DOWN, 4, 64, 128>(a, part_rows, s);
   return 1;

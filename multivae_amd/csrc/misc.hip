@@ -182,9 +182,10 @@ __global__ __launch_bounds__(256) void up_nchw_small_kernel(const float* __restr
 }
 
 // ---- Adam on flat buffers (torch.optim.Adam single-tensor rule, amsgrad=False) -----------------------------
+template <bool AMSGRAD>
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long long n, float step_size, float omb1, float b2, float omb2,
-                            float eps, float wd, float bc2_sqrt, float gscale) {
+                            float* __restrict__ v, float* __restrict__ vmax, long long n, float step_size, float omb1,
+                            float b2, float omb2, float eps, float wd, float bc2_sqrt, float gscale) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
@@ -195,6 +196,10 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     float vi = fmaf(omb2, gi * gi, v[i] * b2);  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
     m[i] = mi;
     v[i] = vi;
+    if (AMSGRAD) {  // max_exp_avg_sq = max(max_exp_avg_sq, exp_avg_sq); the denominator uses the running maximum
+      vi = fmaxf(vmax[i], vi);
+      vmax[i] = vi;
+    }
     float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] = pi - step_size * (mi / denom);
   }
@@ -250,9 +255,77 @@ static int grid_for(long long n, int block, int cap = 2048) {
 
 }  // namespace
 
+// ---- device-timestamp profiler ---------------------------------------------------------------------------------------
+static mvk_prof_slot* g_prof_slots = nullptr;
+static int g_prof_n = 0, g_prof_used = 0;
+static int32_t* g_prof_kinds = nullptr;
+static double* g_prof_work = nullptr;
+__global__ __launch_bounds__(64) void prof_fold_kernel(mvk_prof_slot* s) {
+  const unsigned long long now = (unsigned long long)wall_clock64();  // the launch in front has fully retired
+  const int l = threadIdx.x & (MVK_PROF_ENTRIES - 1);
+  unsigned long long t0 = s->w[8 + 8 * l], t1 = s->w[8 + 8 * MVK_PROF_ENTRIES + 8 * l];
+#pragma unroll
+  for (int off = MVK_PROF_ENTRIES / 2; off > 0; off >>= 1) {
+    const unsigned long long a = __shfl_xor(t0, off, 64), b = __shfl_xor(t1, off, 64);
+    t0 = a < t0 ? a : t0;
+    t1 = b > t1 ? b : t1;
+  }
+  if (threadIdx.x == 0 && t1 > t0) {
+    s->w[0] += t1 - t0;   // first workgroup in -> last workgroup out
+    s->w[1] += 1;
+    s->w[2] += now - t0;  // ... -> first instruction of the next kernel on the stream (stores drained, + one boundary)
+  }
+  if (threadIdx.x < MVK_PROF_ENTRIES) {  // re-arm
+    s->w[8 + 8 * l] = ~0ull;
+    s->w[8 + 8 * MVK_PROF_ENTRIES + 8 * l] = 0ull;
+  }
+}
+__global__ __launch_bounds__(64) void prof_stamp_kernel(unsigned long long* out) {
+  const unsigned long long t = (unsigned long long)wall_clock64();
+  if (threadIdx.x == 0) {
+    out[0] = t;                                      // first instruction
+    out[1] = (unsigned long long)wall_clock64();     // last instruction (as mvk_prof_end stamps it)
+  }
+}
+namespace mvk {
+mvk_prof_slot* prof_next(int kind, double work) {
+  if (!g_prof_slots || g_prof_used >= g_prof_n) return nullptr;
+  const int i = g_prof_used++;
+  if (g_prof_kinds) g_prof_kinds[i] = kind;
+  if (g_prof_work) g_prof_work[i] = work;
+  return g_prof_slots + i;
+}
+void prof_fold(mvk_prof_slot* slot, hipStream_t s) {
+  if (slot) hipLaunchKernelGGL(prof_fold_kernel, dim3(1), dim3(64), 0, s, slot);
+}
+}  // namespace mvk
+
 extern "C" {
 
 int mvk_version(void) { return 100; }
+
+int mvk_prof_enable(void* device_slots, int nslots, int32_t* host_kinds, double* host_work) {
+  g_prof_slots = static_cast<mvk_prof_slot*>(device_slots);
+  g_prof_n = device_slots ? nslots : 0;
+  g_prof_used = 0;
+  g_prof_kinds = host_kinds;
+  g_prof_work = host_work;
+  return MVK_OK;
+}
+int mvk_prof_count(void) { return g_prof_used; }
+int mvk_prof_calibrate(void* device_ticks, int n, void* stream) {
+  if (!device_ticks || n < 2) return MVK_EINVAL;
+  unsigned long long* out = static_cast<unsigned long long*>(device_ticks);
+  for (int i = 0; i < n; ++i) hipLaunchKernelGGL(prof_stamp_kernel, dim3(1), dim3(64), 0, mvk_stream(stream), out + 2 * i);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+int mvk_prof_clock_khz(void) {
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return 0;
+  return khz;
+}
 
 int mvk_pack_conv4s2_weight(const float* Wref, int Cv, int Cu, float* Wdown, int ld_down, int col_off,
                             float* Wup, void* stream) {
@@ -365,18 +438,28 @@ int mvk_conv4s2_up_nchw_small(const float* V, const float* Wref, const float* bi
   return MVK_OK;
 }
 
-int mvk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
-                  double eps, double weight_decay, int step, double grad_scale, void* stream) {
+int mvk_adam_step_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1,
+                          double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream) {
   if (!p || !g || !m || !v || step < 1) return MVK_EINVAL;
   if (n == 0) return MVK_OK;
   // scalar arithmetic in double like the Python side of torch.optim.Adam, cast once
   double bc1 = 1.0 - pow(beta1, (double)step);
   double bc2 = 1.0 - pow(beta2, (double)step);
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, mvk_stream(stream), p, g, m, v, (long long)n,
-                     (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-                     (float)weight_decay, (float)sqrt(bc2), (float)grad_scale);
+  if (vmax)
+    hipLaunchKernelGGL(adam_kernel<true>, dim3(grid_for(n, 256)), dim3(256), 0, mvk_stream(stream), p, g, m, v, vmax,
+                       (long long)n, (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                       (float)eps, (float)weight_decay, (float)sqrt(bc2), (float)grad_scale);
+  else
+    hipLaunchKernelGGL(adam_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, mvk_stream(stream), p, g, m, v, vmax,
+                       (long long)n, (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                       (float)eps, (float)weight_decay, (float)sqrt(bc2), (float)grad_scale);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
+}
+
+int mvk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, int step, double grad_scale, void* stream) {
+  return mvk_adam_step_amsgrad(p, g, m, v, nullptr, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, stream);
 }
 
 int mvk_reduce_terms(const mvk_term_desc* terms, int n_terms, float loss_sum_scale, float* out, float* loss_out,

@@ -44,7 +44,8 @@ struct SmallCfg {
 template <int CU, int CV, int NT>
 __global__ __launch_bounds__(NT) void small_up_fwd_kernel(const float* __restrict__ V, const float* __restrict__ Wref,
                                                            const float* __restrict__ bias, float* __restrict__ U, int n,
-                                                           int h, int w, int act) {
+                                                           int h, int w, int act, mvk_prof_slot* prof) {
+  mvk_prof_begin(prof);
   using C = SmallCfg<CU, CV>;
   constexpr int WP = 256 / (NT / 64);  // positions per wave (NT = 256: 64, NT = 512: 32)
   constexpr int MT = WP / 16;          // 16-row MFMA tiles per wave
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(NT) void small_up_fwd_kernel(const float* __restric
     }
     __syncthreads();  // the column matrix is overwritten by the next image's V tile
   }
+  mvk_prof_end(prof);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -158,7 +160,9 @@ template <int CU, int CV, int NT>
 __global__ __launch_bounds__(NT) void small_up_bwd_kernel(const float* __restrict__ dU, const float* __restrict__ Uout,
                                                            int u_act, const float* __restrict__ V, int v_act,
                                                            const float* __restrict__ Wref, float* __restrict__ dV,
-                                                           float* __restrict__ partial, int n, int h, int w) {
+                                                           float* __restrict__ partial, int n, int h, int w,
+                                                           mvk_prof_slot* prof) {
+  mvk_prof_begin(prof);
   using C = SmallCfg<CU, CV>;
   constexpr int NW = NT / 64;    // waves per workgroup
   constexpr int WP = 256 / NW;   // positions per wave
@@ -357,6 +361,7 @@ __global__ __launch_bounds__(NT) void small_up_bwd_kernel(const float* __restric
     for (int q = 0; q < NW * 4; ++q) t += vred[tid * (NW * 4) + q];
     slab[CV * C::NC + CU + tid] = t;
   }
+  mvk_prof_end(prof);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -514,8 +519,11 @@ static int launch_fwd(const float* V, const float* Wref, const float* bias, floa
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_fwd_kernel<CU, CV, NT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int grid = n < 512 ? n : 512;  // persistent: 2 workgroups per CU, each loops over images with prefetch
-  hipLaunchKernelGGL((small_up_fwd_kernel<CU, CV, NT>), dim3(grid), dim3(NT), lds, s, V, Wref, bias, U, n, h, w, act);
+  // algorithmic bytes: the input map read once, the image written once
+  mvk_prof_slot* prof = mvk::prof_next(5, 4.0 * n * h * w * (CV + 4.0 * CU));
+  hipLaunchKernelGGL((small_up_fwd_kernel<CU, CV, NT>), dim3(grid), dim3(NT), lds, s, V, Wref, bias, U, n, h, w, act, prof);
   MVK_CHECK_LAUNCH();
+  mvk::prof_fold(prof, s);
   return MVK_OK;
 }
 
@@ -533,9 +541,12 @@ static int launch_bwd(const float* dU, const float* Uout, int u_act, const float
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_bwd_kernel<CU, CV, NT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // algorithmic bytes: image gradient + image read once, the saved input map read once, its gradient written once
+  mvk_prof_slot* prof = mvk::prof_next(6, 4.0 * n * h * w * (2.0 * CV + 8.0 * CU));
   hipLaunchKernelGGL((small_up_bwd_kernel<CU, CV, NT>), dim3(grid), dim3(NT), lds, s, dU, Uout, u_act, V, v_act, Wref, dV,
-                     ws, n, h, w);
+                     ws, n, h, w, prof);
   MVK_CHECK_LAUNCH();
+  mvk::prof_fold(prof, s);
   const int total = CV * C::NC + CU + CV;
   hipLaunchKernelGGL(small_up_bwd_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, s, ws, grid, CV * C::NC, CU, CV,
                      dWref, db, db_v);

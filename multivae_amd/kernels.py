@@ -193,7 +193,8 @@ def colsum(dy2, b, y_out=None, y_act=NONE):
     """bias gradient: b.grad += column sums of dy2 [M,N]; returns what autograd should get for b."""
     M, N = dy2.shape
     db, rb = _grad_target(b)
-    call("mvk_colsum_acc", ptr(dy2), ptr(y_out), y_act, ptr(db), M, N, stream_ptr())
+    ws = _ws(dy2)
+    call("mvk_colsum_acc", ptr(dy2), ptr(y_out), y_act, ptr(db), M, N, ptr(ws), ws.numel(), stream_ptr())
     return rb
 
 
@@ -574,7 +575,9 @@ class SVHNDecoderFn(Function):
         else:
             dw3 = conv_wgrad(dout, g3, w3, n, 16, 16, C4, C3, u_nchw=True, u_act_src=out, u_act=SIGMOID)
             tb3, db3 = _grad_target(b3)
-            call("mvk_nchw_channel_sum_acc", ptr(dout), ptr(out), SIGMOID, ptr(tb3), n, C4, 32 * 32, stream_ptr())
+            ws = _ws(dout)
+            call("mvk_nchw_channel_sum_acc", ptr(dout), ptr(out), SIGMOID, ptr(tb3), n, C4, 32 * 32, ptr(ws), ws.numel(),
+                 stream_ptr())
             dg3 = conv_down(dout, wd3, None, n, 16, 16, C4, C3, NONE, u_nchw=True, u_act_src=out, u_act=SIGMOID,
                             v_act_src=g3, v_act=RELU)
         dw2 = conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2)
@@ -1057,9 +1060,10 @@ class MVAEPosteriorFn(Function):
         return (None, None, None, None, *dmu, *dlv)
 
 
-def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
-    call("mvk_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
-         grad_scale, stream_ptr())
+def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0, vmax=None):
+    """torch.optim.Adam on flat buffers, one launch; vmax = the amsgrad running maximum of exp_avg_sq (or None)."""
+    call("mvk_adam_step_amsgrad", ptr(p), ptr(g), ptr(m), ptr(v), ptr(vmax), p.numel(), lr, beta1, beta2, eps,
+         weight_decay, step, grad_scale, stream_ptr())
 
 
 # =====================================================================================================

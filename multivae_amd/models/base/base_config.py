@@ -20,6 +20,9 @@ class BaseConfig:
     def from_dict(cls, config_dict):
         d = dict(config_dict)
         d.pop("name", None)
+        # a null in the file means "the default" (fields like `output_dir: str = None` do not validate an explicit None)
+        defaults = {f.name: f.default for f in dataclasses.fields(cls)}
+        d = {k: v for k, v in d.items() if not (v is None and defaults.get(k, 0) is None)}
         return cls(**d)
 
     @classmethod

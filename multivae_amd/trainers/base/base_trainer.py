@@ -43,8 +43,13 @@ def set_seed(seed: int):
 
 
 def update_dict(dict1, dict2):
+    """Running sums of the batch metrics.  The first value is COPIED: under hipGraph replay the model output's tensors
+    are static buffers that the next replay overwrites."""
     for k in dict2.keys():
-        dict1[k] = dict1[k] + dict2[k] if k in dict1 else dict2[k]
+        if k in dict1:
+            dict1[k] = dict1[k] + dict2[k]
+        else:
+            dict1[k] = dict2[k].clone() if torch.is_tensor(dict2[k]) else dict2[k]
 
 
 def shard_indices(n: int, world_size: int, rank: int, seed: int = 0, epoch: int = 0) -> torch.Tensor:
@@ -77,7 +82,13 @@ class _BatchIterator:
             self.index_map = torch.as_tensor(dataset.indices)
             base = dataset.dataset
         self.base = base
-        self.fast = isinstance(getattr(base, "data", None), dict) and all(torch.is_tensor(v) for v in base.data.values())
+        # device-resident gather only for the stock datasets: a subclass that overrides __getitem__ (transforms,
+        # normalisation, dtype conversion) goes through its own __getitem__ below
+        from ...data.datasets.base import IncompleteDataset, MultimodalBaseDataset
+
+        stock = type(base).__getitem__ in (MultimodalBaseDataset.__getitem__, IncompleteDataset.__getitem__)
+        self.fast = stock and isinstance(getattr(base, "data", None), dict) and \
+            all(torch.is_tensor(v) for v in base.data.values())
         if self.fast:
             self.data = {m: v.to(device) for m, v in base.data.items()}
             self.masks = None
@@ -128,6 +139,8 @@ class _BatchIterator:
                 if "masks" in items[0]:
                     out["masks"] = {m: torch.stack([torch.as_tensor(it["masks"][m]) for it in items]).to(self.device)
                                     for m in items[0]["masks"]}
+                if "labels" in items[0] and items[0]["labels"] is not None:
+                    out["labels"] = torch.stack([torch.as_tensor(it["labels"]) for it in items]).to(self.device)
                 yield DatasetOutput(**out)
 
 
@@ -136,7 +149,10 @@ class BaseTrainer:
                  training_config: Optional[BaseTrainerConfig] = None, callbacks: List[TrainingCallback] = None,
                  checkpoint: str = None):
         if training_config is None:
-            training_config = BaseTrainerConfig()
+            # resuming: the configuration saved with the checkpoint (base_trainer.py:71-75), else the defaults
+            cfg_file = os.path.join(checkpoint, "training_config.json") if checkpoint is not None else None
+            training_config = BaseTrainerConfig.from_json_file(cfg_file) if cfg_file and os.path.exists(cfg_file) \
+                else BaseTrainerConfig()
         self.training_config = training_config
         self.model_config = model.model_config
         self.model_name = model.model_name
@@ -148,7 +164,9 @@ class BaseTrainer:
         self.distributed = self.world_size > 1
         self.device = self._setup_devices() if self.distributed else (
             "cuda" if torch.cuda.is_available() and not training_config.no_cuda else "cpu")
-        if str(self.device) == "cpu":
+        # MVK_TRAINER_ALLOW_CPU=1: host-logic tests of THIS loop with plain-PyTorch plugin models (gloo, no GPU); the
+        # multivae_amd models themselves still refuse CPU tensors (their arithmetic lives in HIP kernels)
+        if str(self.device) == "cpu" and os.environ.get("MVK_TRAINER_ALLOW_CPU") != "1":
             raise RuntimeError("multivae_amd trains on MI355X GPUs only: the model's arithmetic lives in HIP kernels "
                                "(no CPU compute path)")
         self.device = torch.device(self.device) if not isinstance(self.device, torch.device) else self.device
@@ -167,8 +185,9 @@ class BaseTrainer:
                                            self.device, W, r, training_config.drop_last)
         self.eval_loader = None
         if eval_dataset is not None:
+            # the reference's eval DataLoader never drops the last batch (base_trainer.py:213-232)
             self.eval_loader = _BatchIterator(eval_dataset, training_config.per_device_eval_batch_size, False,
-                                              self.device, W, r, training_config.drop_last)
+                                              self.device, W, r, False)
         self.callbacks = [TrainingCallback()] if callbacks is None else callbacks
         self.is_main_process = self.rank in (-1, 0)
         self.optimizer = None
@@ -209,11 +228,12 @@ class BaseTrainer:
         self.flat = FlatParams(self.model)
         if self.distributed:
             self.flat.broadcast(0)  # C1: one parameter broadcast from rank 0 (DDP.__init__ in the reference)
-        fused_ok = cfg.optimizer_cls == "Adam" and cfg.use_fused_adam and not params.get("amsgrad", False) and \
+        fused_ok = cfg.optimizer_cls == "Adam" and cfg.use_fused_adam and \
             set(params.keys()) <= {"betas", "eps", "weight_decay", "amsgrad"}
-        if fused_ok:
+        if fused_ok:  # amsgrad and every torch lr scheduler stay on the one-launch path
             self.optimizer = FusedAdam(self.flat, lr=cfg.learning_rate, betas=tuple(params.get("betas", (0.9, 0.999))),
-                                       eps=params.get("eps", 1e-8), weight_decay=params.get("weight_decay", 0.0))
+                                       eps=params.get("eps", 1e-8), weight_decay=params.get("weight_decay", 0.0),
+                                       amsgrad=params.get("amsgrad", False))
         else:
             import torch.optim as optim
 
@@ -224,8 +244,6 @@ class BaseTrainer:
         if cfg.scheduler_cls is None:
             self.scheduler = None
             return
-        if isinstance(self.optimizer, FusedAdam):
-            raise NotImplementedError("learning-rate schedulers need use_fused_adam=False (torch.optim optimizer)")
         import torch.optim.lr_scheduler as lr_scheduler
 
         self.scheduler = getattr(lr_scheduler, cfg.scheduler_cls)(self.optimizer, **(cfg.scheduler_params or {}))
@@ -283,8 +301,12 @@ class BaseTrainer:
         """zero_grad -> backward -> [one all-reduce] -> step  (base_trainer.py:350-361)."""
         if not backward_done:
             loss = model_output.loss
-            self.optimizer.zero_grad()
+            # always through the flat buffer: torch's own zero_grad() sets .grad to None, backward() would then
+            # allocate gradients OUTSIDE the buffer the all-reduce below exchanges
+            self.flat.zero_grad()
             loss.backward()
+            if not isinstance(self.optimizer, FusedAdam):
+                self.flat.ensure_attached()
         if isinstance(self.optimizer, FusedAdam):
             if self.distributed:
                 self.flat.all_reduce()  # C2: ONE sum all-reduce of the flat gradient buffer

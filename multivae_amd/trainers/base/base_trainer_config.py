@@ -41,6 +41,36 @@ class BaseTrainerConfig(BaseConfig):
     sync_every_step: bool = False   # True reproduces the reference's per-step `.item()` host sync
     use_hip_graph: bool = False     # replay zero_grad+forward+backward of full-size batches as ONE hipGraph launch
 
+    # the reference's BaseTrainerConfig.from_json_file rejects unknown fields: the extension fields go to a side file
+    _EXTENSION_FIELDS = ("use_fused_adam", "sync_every_step", "use_hip_graph")
+
+    def save_json(self, dir_path, filename):
+        """`<filename>.json` holds exactly the reference's fields (loads in either trainer); the multivae_amd switches
+        go to `<filename>_mvk.json` beside it."""
+        import json
+
+        d = self.to_dict()
+        ext = {k: d.pop(k) for k in self._EXTENSION_FIELDS}
+        with open(os.path.join(dir_path, f"{filename}.json"), "w", encoding="utf-8") as f:
+            f.write(json.dumps(d))
+        with open(os.path.join(dir_path, f"{filename}_mvk.json"), "w", encoding="utf-8") as f:
+            f.write(json.dumps(ext))
+
+    @classmethod
+    def from_json_file(cls, json_path):
+        import json
+
+        with open(json_path) as f:
+            d = json.load(f)
+        name = d.pop("name", None)
+        if name is not None and name != cls.__name__:
+            raise ValueError(f"config file is for {name}, not {cls.__name__}")
+        side = json_path[:-5] + "_mvk.json" if json_path.endswith(".json") else None
+        if side and os.path.exists(side):
+            with open(side) as f:
+                d.update(json.load(f))
+        return cls.from_dict(d)
+
     def __post_init__(self):
         super().__post_init__()
         env_local_rank = int(os.environ.get("LOCAL_RANK", -1))

@@ -37,6 +37,14 @@ class FlatParams:
                 self._reattach()
                 break
 
+    def ensure_attached(self):
+        """After a backward pass: fold any gradient that landed outside the flat buffer back into it."""
+        lo, hi = self.grad.data_ptr(), self.grad.data_ptr() + 4 * self.numel
+        for p in self.params:
+            if p.grad is None or not (lo <= p.grad.data_ptr() < hi):
+                self._reattach()
+                return
+
     def _reattach(self):
         off = 0
         for p in self.params:
@@ -59,40 +67,68 @@ class FlatParams:
         dist.broadcast(self.flat, src=src, group=group)
 
 
-class FusedAdam:
-    """torch.optim.Adam (amsgrad=False) semantics on FlatParams, one HIP launch per step."""
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (amsgrad on or off) on FlatParams, one HIP launch per step (mvk_adam_step_amsgrad).
 
-    def __init__(self, flat: FlatParams, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    A real `torch.optim.Optimizer` with ONE parameter group, so `torch.optim.lr_scheduler.*` drive it unchanged (the
+    learning rate is a host scalar handed to the kernel at every step) and `state_dict()` / `load_state_dict()` speak
+    the layout of `torch.optim.Adam(model.parameters())` — what the reference writes to / reads from `optimizer.pt`."""
+
+    def __init__(self, flat: FlatParams, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False):
         self.flat = flat
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=bool(amsgrad))
+        super().__init__(flat.all_params, defaults)
         self.m = torch.zeros_like(flat.flat)
         self.v = torch.zeros_like(flat.flat)
+        self.vmax = torch.zeros_like(flat.flat) if amsgrad else None
         self.step_count = 0
 
-    def zero_grad(self):
-        self.flat.zero_grad()
+    # the hyper-parameters live in the parameter group (schedulers write `lr` there)
+    def _g(self):
+        return self.param_groups[0]
 
-    def step(self, grad_scale=1.0):
+    lr = property(lambda self: self._g()["lr"], lambda self, v: self._g().__setitem__("lr", v))
+    betas = property(lambda self: tuple(self._g()["betas"]), lambda self, v: self._g().__setitem__("betas", tuple(v)))
+    eps = property(lambda self: self._g()["eps"], lambda self, v: self._g().__setitem__("eps", v))
+    weight_decay = property(lambda self: self._g()["weight_decay"],
+                            lambda self, v: self._g().__setitem__("weight_decay", v))
+    amsgrad = property(lambda self: bool(self._g().get("amsgrad", False)))
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat.zero_grad()  # gradients stay views of the flat buffer (never None)
+
+    def step(self, closure=None, grad_scale=1.0):
+        loss = closure() if closure is not None else None
         self.step_count += 1
-        kernels.adam_step(self.flat.flat, self.flat.grad, self.m, self.v, self.step_count, self.lr, self.betas[0],
-                          self.betas[1], self.eps, self.weight_decay, grad_scale)
+        g = self._g()
+        kernels.adam_step(self.flat.flat, self.flat.grad, self.m, self.v, self.step_count, float(g["lr"]),
+                          float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                          grad_scale, vmax=self.vmax)
+        return loss
 
     def state_dict(self):
         """The layout of `torch.optim.Adam(model.parameters()).state_dict()` (what the reference writes to
         `optimizer.pt`, base_trainer.py:790-793, and reads back in `resume_training`, :413-419): per-parameter
-        `step` / `exp_avg` / `exp_avg_sq` keyed by the parameter's position in `model.parameters()`, one param group."""
+        `step` / `exp_avg` / `exp_avg_sq` (/ `max_exp_avg_sq`) keyed by the parameter's position in
+        `model.parameters()`, one param group."""
         pos = {id(p): i for i, p in enumerate(self.flat.all_params)}
         state, off = {}, 0
         for p in self.flat.params:
             k = p.numel()
             if self.step_count > 0:  # torch creates the state lazily at the first step
-                state[pos[id(p)]] = {"step": torch.tensor(float(self.step_count)),
-                                     "exp_avg": self.m[off:off + k].view(p.shape).clone(),
-                                     "exp_avg_sq": self.v[off:off + k].view(p.shape).clone()}
+                st = {"step": torch.tensor(float(self.step_count)),
+                      "exp_avg": self.m[off:off + k].view(p.shape).clone(),
+                      "exp_avg_sq": self.v[off:off + k].view(p.shape).clone()}
+                if self.vmax is not None:
+                    st["max_exp_avg_sq"] = self.vmax[off:off + k].view(p.shape).clone()
+                state[pos[id(p)]] = st
             off += k
-        group = dict(lr=self.lr, betas=tuple(self.betas), eps=self.eps, weight_decay=self.weight_decay, amsgrad=False,
-                     maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
-                     decoupled_weight_decay=False, params=list(range(len(self.flat.all_params))))
+        g = self._g()
+        group = dict(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"],
+                     amsgrad=self.amsgrad, maximize=False, foreach=None, capturable=False, differentiable=False,
+                     fused=None, decoupled_weight_decay=False, params=list(range(len(self.flat.all_params))))
+        if "initial_lr" in g:  # written by lr schedulers
+            group["initial_lr"] = g["initial_lr"]
         return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
@@ -100,14 +136,22 @@ class FusedAdam:
         groups = sd["param_groups"]
         if len(groups) != 1 or len(groups[0]["params"]) != len(self.flat.all_params):
             raise ValueError("loaded state dict has a different number of parameter groups / parameters")
-        if groups[0].get("amsgrad", False):
-            raise ValueError("the fused Adam has no amsgrad state: use use_fused_adam=False")
         g = groups[0]
-        self.lr, self.betas = float(g["lr"]), tuple(g["betas"])
-        self.eps, self.weight_decay = float(g["eps"]), float(g["weight_decay"])
+        if bool(g.get("amsgrad", False)) and self.vmax is None:
+            self.vmax = torch.zeros_like(self.flat.flat)
+        if not g.get("amsgrad", False):
+            self.vmax = None
+        mine = self._g()
+        mine["lr"], mine["betas"] = float(g["lr"]), tuple(g["betas"])
+        mine["eps"], mine["weight_decay"] = float(g["eps"]), float(g["weight_decay"])
+        mine["amsgrad"] = bool(g.get("amsgrad", False))
+        if "initial_lr" in g:
+            mine["initial_lr"] = g["initial_lr"]
         pos = {id(p): i for i, p in enumerate(self.flat.all_params)}
         self.m.zero_()
         self.v.zero_()
+        if self.vmax is not None:
+            self.vmax.zero_()
         steps, off = set(), 0
         for p in self.flat.params:
             k = p.numel()
@@ -115,6 +159,8 @@ class FusedAdam:
             if st is not None:
                 self.m[off:off + k].copy_(st["exp_avg"].reshape(-1))
                 self.v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                if self.vmax is not None and "max_exp_avg_sq" in st:
+                    self.vmax[off:off + k].copy_(st["max_exp_avg_sq"].reshape(-1))
                 steps.add(int(float(st["step"])))
             off += k
         if len(steps) > 1:

@@ -105,6 +105,20 @@ def joint_mlp_encoder(sd, input_dims, data, prefix="joint_encoder."):
             F.linear(h, sd[prefix + "fc2.weight"], sd[prefix + "fc2.bias"]))
 
 
+def joint_encoder_generic(sd, enc_fns, data, prefix="joint_encoder."):
+    """MultipleHeadJointEncoder.forward (default_architectures.py:303-322) over arbitrary unimodal encoders:
+    enc_fns = {modality: f(sd, prefix, x) -> (mu, log_var, ...)} evaluated on the joint encoder's own copies
+    (`joint_encoder.encoders.<m>.`), embeddings concatenated in modality order -> MLP -> fc1 / fc2."""
+    embs = [enc_fns[m](sd, f"{prefix}encoders.{m}.", data[m])[0] for m in enc_fns]
+    h = torch.cat(embs, dim=1)
+    i = 0
+    while f"{prefix}enc.{i}.0.weight" in sd:
+        h = F.relu(F.linear(h, sd[f"{prefix}enc.{i}.0.weight"], sd[f"{prefix}enc.{i}.0.bias"]))
+        i += 1
+    return (F.linear(h, sd[prefix + "fc1.weight"], sd[prefix + "fc1.bias"]),
+            F.linear(h, sd[prefix + "fc2.weight"], sd[prefix + "fc2.bias"]))
+
+
 def resnet_block(sd, prefix, x, order="post"):
     """ResnetBlock.  "post" (mmnist.py:229-246): x_s + 0.1 * lrelu(conv2(lrelu(conv1(x)))); "pre" (cub.py:274-280):
     x_s + 0.1 * conv2(lrelu(conv1(lrelu(x)))).  x_s = 1x1 shortcut convolution when the channel counts differ."""

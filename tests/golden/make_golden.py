@@ -653,6 +653,139 @@ def resnet_cub_case(name, *, B, L, seed):
     save(name, dict(model="ResnetCUB", B=B, L=L, seed=seed), arrays)
 
 
+def mmvaeplus_resnet_case(name, *, M, B, K, S, L, loss, beta, scale, seed):
+    """BASELINE configs[3] assembled (MMVAE+ on PolyMNIST-shaped data, examples/mmvae_plus/mmnist.py:19-45): M
+    modalities of 3x28x28, EncoderResnetMMNIST / DecoderResnetMMNIST, laplace_with_softmax posteriors, Laplace
+    decoders with scale 0.75, learnable private priors, K importance samples."""
+    from multivae.models.nn.mmnist import DecoderResnetMMNIST, EncoderResnetMMNIST
+
+    print(name)
+    names = [f"m{i}" for i in range(M)]
+    dims = {m: (3, 28, 28) for m in names}
+    family = "laplace_with_softmax"
+    cfg = MMVAEPlusConfig(n_modalities=M, latent_dim=L, input_dims=dict(dims), K=K, modalities_specific_dim=S,
+                          prior_and_posterior_dist=family, loss=loss, beta=beta,
+                          decoders_dist={m: "laplace" for m in names},
+                          decoder_dist_params={m: dict(scale=scale) for m in names},
+                          learn_shared_prior=False, learn_modality_prior=True)
+    model = MMVAEPlus(cfg, {m: EncoderResnetMMNIST(S, L) for m in names}, {m: DecoderResnetMMNIST(L + S) for m in names})
+    sd_np = P.make_state_dict(P.mmvaeplus_resnet_shapes(names, S, L), seed)
+    load_weights_plus(model, sd_np)
+    plv = {"shared": P.uniform((1, L + S), seed + 998, -0.3, 0.3)}
+    for i, m in enumerate(names):
+        plv[m] = P.uniform((1, S), seed + 900 + i, -0.3, 0.3)
+    with torch.no_grad():
+        for k, v in plv.items():
+            model.logvars_priors[k].copy_(t(v))
+    data = {m: P.uniform((B, 3, 28, 28), seed + 50 + i) for i, m in enumerate(names)}
+    inputs = ref_dataset(data, None)
+    mods = list(inputs.data.keys())
+    model.train()
+
+    def draw(shape):
+        return torch.empty(shape).uniform_(torch.finfo(torch.float32).eps - 1, 1)
+
+    torch.manual_seed(seed)
+    noise = {}
+    for c in mods:
+        noise[c] = {"u": draw((K, B, L)), "w": draw((K, B, S))}
+        for r in mods:
+            if r != c:
+                noise[c][r] = draw((K, B, S))
+    torch.manual_seed(seed)
+    out = model(inputs)
+    model.zero_grad()
+    out.loss.backward()
+    gref = ref_grads(model)
+    osd = oracle_sd(sd_np)
+    oplv = {k: t(v).clone().requires_grad_(k != "shared") for k, v in plv.items()}
+    tdata = {m: t(v) for m, v in data.items()}
+    e = {m: nets.mmnist_resnet_encoder(osd, f"encoders.{m}.", tdata[m]) for m in mods}
+    dec_f = {m: (lambda z, m=m: nets.mmnist_resnet_decoder(osd, f"decoders.{m}.", z)) for m in mods}
+    o = elbo.mmvaeplus_forward(e, tdata, dec_f, noise, names=names, K=K, family=family, loss=loss, beta=beta,
+                               prior_logvars=oplv, rescale=elbo.rescale_factors(dims, False),
+                               dists={m: "laplace" for m in names}, dist_scales={m: scale for m in names})
+    o["loss"].backward()
+    report("loss", out.loss, o["loss"])
+    gor = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in osd.items()}
+    for k, v in oplv.items():
+        gor["logvars_priors." + k] = v.grad if v.grad is not None else torch.zeros_like(v)
+        gor["mean_priors." + k] = torch.zeros_like(v)
+    cmp_grads("grads", gref, gor)
+    arrays = dict(loss=out.loss.detach())
+    for k, v in plv.items():
+        arrays["prior_logvar/" + k] = v
+    for c in mods:
+        for k, v in noise[c].items():
+            arrays[f"noise/{c}/{k}"] = v
+        arrays["lws/" + c] = o["lws"][c].detach()
+        arrays["us/" + c] = o["us"][c].detach()
+        arrays["ws/" + c] = o["ws"][c].detach()
+    arrays.update(grad_stats(gref))
+    save(name, dict(model="MMVAEPlusResnet", M=M, B=B, L=L, S=S, K=K, family=family, loss=loss, beta=beta, scale=scale,
+                    seed=seed, names=names), arrays)
+
+
+def jmvae_cub_case(name, *, B, L, n_attr, alpha, beta, warmup, epoch, seed):
+    """BASELINE configs[4] assembled: JMVAE on a 64x64 image (CUB_Resnet_Encoder / Decoder, cub.py:144-246) and a binary
+    attribute vector (default MLPs, Bernoulli likelihood), default MultipleHeadJointEncoder (copies of both encoders)."""
+    from multivae.models.nn.cub import CUB_Resnet_Decoder, CUB_Resnet_Encoder
+
+    print(name)
+    dims = dict(image=(3, 64, 64), attributes=(n_attr,))
+    dists = dict(image="normal", attributes="bernoulli")
+    cfg = JMVAEConfig(n_modalities=2, latent_dim=L, input_dims=dict(dims), alpha=alpha, beta=beta, warmup=warmup,
+                      decoders_dist=dists)
+    enc = dict(image=CUB_Resnet_Encoder(L), attributes=Encoder_VAE_MLP(BaseAEConfig(latent_dim=L, input_dim=(n_attr,))))
+    dec = dict(image=CUB_Resnet_Decoder(L), attributes=Decoder_AE_MLP(BaseAEConfig(latent_dim=L, input_dim=(n_attr,))))
+    model = JMVAE(cfg, enc, dec)
+    sd_np = P.make_state_dict(P.jmvae_cub_shapes(L, n_attr), seed)
+    load_weights(model, sd_np)
+    names = list(model.encoders.keys())
+    data = dict(image=P.uniform((B, 3, 64, 64), seed + 2),
+                attributes=(P.uniform((B, n_attr), seed + 3) > 0.5).astype(np.float32))
+    inputs = ref_dataset(data, None)
+    model.train()
+    torch.manual_seed(seed)
+    eps = torch.randn(B, L)
+    torch.manual_seed(seed)
+    out = model(inputs, epoch=epoch)
+    model.zero_grad()
+    out.loss.backward()
+    gref = ref_grads(model)
+    osd = oracle_sd(sd_np)
+    tdata = {m: t(v) for m, v in data.items()}
+    enc_fns = dict(image=nets.cub_resnet_encoder, attributes=nets.mlp_encoder)
+    e = {m: enc_fns[m](osd, f"encoders.{m}.", tdata[m]) for m in names}
+    dec_f = dict(image=lambda z: nets.cub_resnet_decoder(osd, "decoders.image.", z),
+                 attributes=lambda z: nets.mlp_decoder(osd, "decoders.attributes.", z, (n_attr,)))
+    joint = nets.joint_encoder_generic(osd, {m: enc_fns[m] for m in names}, tdata)
+    o = elbo.jmvae_forward(joint, e, tdata, dec_f, eps, names=names, alpha=alpha, beta=beta, warmup=warmup, epoch=epoch,
+                           rescale=elbo.rescale_factors(dims, False), dists=dists)
+    o["loss"].backward()
+    report("loss", out.loss, o["loss"])
+    for k in out.metrics:
+        report(k, torch.as_tensor(out.metrics[k]), torch.as_tensor(o["metrics"][k]))
+    cmp_grads("grads", gref, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in osd.items()})
+    arrays = dict(eps=eps, loss=out.loss.detach(), loss_sum=out.loss_sum.detach(), z=o["z"].detach(),
+                  joint_mu=joint[0].detach(), joint_logvar=joint[1].detach())
+    for k, v in out.metrics.items():
+        arrays["metric/" + k] = torch.as_tensor(v).detach()
+    arrays.update(grad_stats(gref))
+    save(name, dict(model="JMVAECub", B=B, L=L, n_attr=n_attr, alpha=alpha, beta=beta, warmup=warmup, epoch=epoch,
+                    seed=seed, names=names, dists=dists), arrays)
+
+
+def assembled_main():
+    """BASELINE configs[3] / configs[4] in miniature (networks + ELBO together, from the real reference)."""
+    mmvaeplus_resnet_case("mmvaeplus_polymnist_resnet_k10", M=5, B=3, K=10, S=32, L=32, loss="iwae_looser", beta=2.5,
+                          scale=0.75, seed=701)
+    mmvaeplus_resnet_case("mmvaeplus_polymnist_resnet_dreg", M=3, B=4, K=3, S=8, L=16, loss="dreg_looser", beta=1.0,
+                          scale=0.75, seed=702)
+    jmvae_cub_case("jmvae_celeba_cub_resnet", B=3, L=64, n_attr=40, alpha=0.1, beta=1.0, warmup=10, epoch=4, seed=703)
+    jmvae_cub_case("jmvae_celeba_cub_resnet_trained", B=2, L=16, n_attr=18, alpha=0.5, beta=2.0, warmup=3, epoch=7, seed=704)
+
+
 def resnet_main():
     resnet_mmnist_case("resnet_mmnist_nets", B=3, K=2, private_dim=4, shared_dim=6, seed=601)
     resnet_cub_case("resnet_cub_nets", B=2, L=12, seed=602)
@@ -1275,6 +1408,8 @@ if __name__ == "__main__":
         mmvaeplus_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "resnet":
         resnet_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "assembled":
+        assembled_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "nll":
         nll_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "mvae":
@@ -1294,6 +1429,7 @@ if __name__ == "__main__":
         jmvae_main()
         mmvaeplus_main()
         resnet_main()
+        assembled_main()
         nll_main()
         mvae_main()
         mopoe_style_main()

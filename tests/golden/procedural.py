@@ -247,3 +247,34 @@ def make_state_dict(shapes, seed, gain=1.0):
             bound = gain / float(np.sqrt(np.prod(shape[1:])))
         sd[name] = uniform(shape, seed * 1000 + i, -bound, bound)
     return sd
+
+
+def mmvaeplus_resnet_shapes(names, private_dim, shared_dim):
+    """MMVAEPlus with the PolyMNIST ResNets (BASELINE configs[3]): decoders first, then encoders (base_ae_model.py:86-87)."""
+    s = OrderedDict()
+    for m in names:
+        s.update(mmnist_resnet_decoder_shapes(private_dim + shared_dim, f"decoders.{m}."))
+    for m in names:
+        s.update(mmnist_resnet_encoder_shapes(private_dim, shared_dim, f"encoders.{m}."))
+    return s
+
+
+def jmvae_cub_shapes(latent_dim, n_attr, hidden_dim=512, n_hidden_layers=2):
+    """JMVAE on (image 3x64x64: CUB ResNets, attributes [n_attr]: default MLPs) with the default joint encoder
+    (BASELINE configs[4]): decoders, encoders, then the joint encoder's copies + MLP + heads."""
+    s = OrderedDict()
+    s.update(cub_resnet_decoder_shapes(latent_dim, "decoders.image."))
+    s.update(mlp_decoder_shapes("decoders.attributes.", latent_dim, n_attr))
+    s.update(cub_resnet_encoder_shapes(latent_dim, "encoders.image."))
+    s.update(mlp_encoder_shapes("encoders.attributes.", n_attr, latent_dim))
+    s.update(cub_resnet_encoder_shapes(latent_dim, "joint_encoder.encoders.image."))
+    s.update(mlp_encoder_shapes("joint_encoder.encoders.attributes.", n_attr, latent_dim))
+    s["joint_encoder.enc.0.0.weight"] = (hidden_dim, 2 * latent_dim)
+    s["joint_encoder.enc.0.0.bias"] = (hidden_dim,)
+    for i in range(1, n_hidden_layers):
+        s[f"joint_encoder.enc.{i}.0.weight"] = (hidden_dim, hidden_dim)
+        s[f"joint_encoder.enc.{i}.0.bias"] = (hidden_dim,)
+    for h in ("fc1", "fc2"):
+        s[f"joint_encoder.{h}.weight"] = (latent_dim, hidden_dim)
+        s[f"joint_encoder.{h}.bias"] = (latent_dim,)
+    return s

@@ -547,6 +547,28 @@ def test_adam_matches_oracle(K):
     close(vd, v, rtol=1e-6, what="adam v")
 
 
+def test_adam_amsgrad_matches_torch(K):
+    """mvk_adam_step_amsgrad against torch.optim.Adam(amsgrad=True) on the CPU (the reference's MMVAE+ setting,
+    examples/mmvae_plus/mmnist.py:61-62) over 4 steps with weight decay and a changing learning rate."""
+    gen = g(10)
+    n = 50021
+    p0 = torch.randn(n, generator=gen)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=2e-3, betas=(0.85, 0.97), eps=1e-7, weight_decay=0.01, amsgrad=True)
+    d = dev()
+    pd, md, vd, xd = p0.to(d), torch.zeros(n, device=d), torch.zeros(n, device=d), torch.zeros(n, device=d)
+    for step in range(1, 5):
+        gr = torch.randn(n, generator=gen) * (3.0 if step == 1 else 0.3)  # a large first step: the maximum matters
+        lr = 2e-3 * 0.5 ** (step - 1)
+        opt.param_groups[0]["lr"] = lr
+        ref.grad = gr.clone()
+        opt.step()
+        K.adam_step(pd, gr.to(d), md, vd, step, lr, 0.85, 0.97, 1e-7, 0.01, vmax=xd)
+    close(pd, ref.detach(), rtol=2e-6, what="amsgrad params")
+    close(xd, opt.state[ref]["max_exp_avg_sq"], rtol=1e-6, what="max_exp_avg_sq")
+    close(vd, opt.state[ref]["exp_avg_sq"], rtol=1e-6, what="exp_avg_sq")
+
+
 @pytest.mark.parametrize("n,h,w,Cu,Cv", [(3, 16, 16, 3, 32), (700, 16, 16, 3, 32), (5, 8, 8, 1, 16), (2, 16, 8, 4, 64)])
 def test_small_up_fwd_bwd(K, n, h, w, Cu, Cv):
     """The per-image MFMA kernels of the image-producing layer (smallconv.hip) against torch CPU."""

@@ -186,10 +186,18 @@ def test_trainer_with_hip_graph(tmp_path, model_name):
                                 learning_rate=1e-3, use_hip_graph=use_graph)
         trainer = BaseTrainer(model, train_dataset=ds, training_config=cfg)
         hist = trainer.train()
+        metrics.append([{k: v for k, v in h.items() if k.startswith("train_") and k != "train_epoch_loss"} for h in hist])
         return [h["train_epoch_loss"] for h in hist], trainer
 
+    metrics = []
     eager, _ = run(False)
     graphed, tr = run(True)
+    # epoch metrics are means over the batches in both modes (a replayed graph overwrites its output tensors in
+    # place: the running sums must not alias them)
+    for me, mg in zip(*metrics):
+        for k, v in me.items():
+            if isinstance(v, float) and np.isfinite(v) and abs(v) > 1e-6:
+                assert abs(mg[k] - v) <= 0.1 * abs(v), (k, v, mg[k])
     graphs = [g for g in tr._graphs.values() if g is not None]
     assert len(graphs) == (4 if model_name == "JMVAE" else 2), tr._graphs.keys()  # JMVAE: x2 for epochs 1 and >= 2
     assert all(np.isfinite(v) for v in graphed) and graphed[-1] < graphed[0]
@@ -376,3 +384,60 @@ def test_full_size_step_properties():
     out_g = gs(inputs, eps)
     assert float(out_g.loss.detach()) == loss_k
     assert float(out_g.metrics["joint_divergence"]) == float(out_k.metrics["joint_divergence"])
+
+
+def test_fused_adam_amsgrad_and_scheduler_in_the_trainer(tmp_path):
+    """The reference's MMVAE+ optimizer setting (`optimizer_params=dict(amsgrad=True)`, examples/mmvae_plus/mmnist.py:61-62)
+    and an lr scheduler stay on the fused one-launch Adam; the run matches torch.optim.Adam(amsgrad) + StepLR on the same
+    model / seed (use_fused_adam=False) and the checkpoint carries max_exp_avg_sq and scheduler.pt."""
+    from multivae_amd.data.datasets.base import MultimodalBaseDataset
+    from multivae_amd.models import MVTCAE, MVTCAEConfig
+    from multivae_amd.trainers import BaseTrainer, BaseTrainerConfig, FusedAdam
+
+    def run(fused):
+        torch.manual_seed(0)
+        ds = MultimodalBaseDataset(data=dict(a=torch.rand(96, 12), b=torch.rand(96, 7)))
+        model = MVTCAE(MVTCAEConfig(n_modalities=2, latent_dim=4, input_dims=dict(a=(12,), b=(7,))))
+        cfg = BaseTrainerConfig(output_dir=str(tmp_path / ("f" if fused else "t")), per_device_train_batch_size=32,
+                                num_epochs=3, learning_rate=2e-3, optimizer_params=dict(amsgrad=True, weight_decay=0.01),
+                                scheduler_cls="StepLR", scheduler_params=dict(step_size=1, gamma=0.5), steps_saving=3,
+                                use_fused_adam=fused, seed=3)
+        tr = BaseTrainer(model, train_dataset=ds, training_config=cfg)
+        hist = tr.train()
+        return tr, [h["train_epoch_loss"] for h in hist], {k: v.detach().cpu().clone() for k, v in model.named_parameters()}
+
+    tf, lf, pf = run(True)
+    tt, lt, pt = run(False)
+    assert isinstance(tf.optimizer, FusedAdam) and tf.optimizer.amsgrad and not isinstance(tt.optimizer, FusedAdam)
+    assert tf.optimizer.lr == pytest.approx(2e-3 * 0.5 ** 3) and tf.optimizer.step_count == 9
+    for a, b in zip(lf, lt):
+        assert abs(a - b) <= 1e-4 * abs(b), (lf, lt)
+    for k in pf:
+        assert float((pf[k] - pt[k]).abs().max()) <= 2e-4 * float(pt[k].abs().max()) + 1e-6, k
+    ck = os.path.join(tf.training_dir, "checkpoint_epoch_3")
+    sd = torch.load(os.path.join(ck, "optimizer.pt"), map_location="cpu")
+    assert sd["param_groups"][0]["amsgrad"] is True and "max_exp_avg_sq" in next(iter(sd["state"].values()))
+    assert os.path.exists(os.path.join(ck, "scheduler.pt"))
+    ref_opt = torch.optim.Adam(tt.model.parameters(), lr=1.0, amsgrad=True)
+    ref_opt.load_state_dict(sd)  # loads into the reference's optimizer class
+
+
+def test_rccl_path_on_one_gpu_matches_the_plain_step(tmp_path):
+    """bench.py with MVK_FORCE_DIST=1: RCCL initialisation, the parameter broadcast, ONE all-reduce of the flat gradient
+    buffer per step and the 1/world_size folded into Adam on a single GPU (world_size 1) give the loss of the plain run."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--batch", "64"]
+    outs = []
+    for force in ("0", "1"):
+        env = dict(os.environ, MVK_FORCE_DIST=force, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0",
+                   WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        outs.append(json.loads(line))
+    assert outs[0]["config"]["final_loss"] == pytest.approx(outs[1]["config"]["final_loss"], rel=1e-6)
+    assert outs[1]["n_gpus"] == 1

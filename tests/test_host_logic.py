@@ -22,7 +22,8 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/mvk.h but not exported by libmvk.so"
     bound = set(_lib.PROTOTYPES) | {"mvk_splitk_workspace_floats", "mvk_conv4s2_small_up_supported",
-                                    "mvk_debug_set_phase_buffer", "mvk_debug_set_flags"}  # void hooks, bound ad hoc
+                                    "mvk_debug_set_phase_buffer", "mvk_debug_set_flags",  # void hooks, bound ad hoc
+                                    "mvk_prof_enable", "mvk_prof_count", "mvk_prof_clock_khz", "mvk_prof_calibrate"}
     assert declared == bound, (declared - bound, bound - declared)
     assert lib.mvk_version() >= 100
 
@@ -249,6 +250,63 @@ def test_fused_adam_state_dict_is_torch_adam_layout():
     bad = {"state": {}, "param_groups": [dict(sd["param_groups"][0], params=[0, 1])]}
     with pytest.raises(ValueError):
         opt.load_state_dict(bad)
+
+
+def test_fused_adam_is_a_torch_optimizer_with_schedulers_and_amsgrad_state():
+    """FusedAdam is a torch.optim.Optimizer with one parameter group: lr schedulers drive it unchanged (the trainer
+    accepts `scheduler_cls` with the fused optimizer), and the amsgrad state round-trips in torch.optim.Adam's layout."""
+    from multivae_amd.models import MVTCAE, MVTCAEConfig
+    from multivae_amd.trainers.flat import FlatParams, FusedAdam
+
+    torch.manual_seed(0)
+    model = MVTCAE(MVTCAEConfig(n_modalities=2, latent_dim=3, input_dims=dict(a=(4,), b=(5,))))
+    flat = FlatParams(model)
+    opt = FusedAdam(flat, lr=1e-2, amsgrad=True, weight_decay=0.1)
+    assert isinstance(opt, torch.optim.Optimizer) and len(opt.param_groups) == 1
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.5)
+    opt.step_count = 1  # (no GPU here: pretend a step happened; the kernel launch itself is covered by the GPU tests)
+    sched.step()
+    assert opt.lr == pytest.approx(5e-3)
+    plateau = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.1, patience=0)
+    plateau.step(1.0)
+    plateau.step(2.0)
+    assert opt.lr == pytest.approx(5e-4)
+    # amsgrad state in torch's layout, both directions
+    ref = torch.optim.Adam(model.parameters(), lr=1e-3, amsgrad=True)
+    for p in model.parameters():
+        p.grad = torch.randn_like(p)
+    ref.step()
+    sd = ref.state_dict()
+    opt.load_state_dict(sd)
+    assert opt.amsgrad and opt.vmax is not None and opt.step_count == 1
+    mine = opt.state_dict()
+    assert mine["param_groups"][0]["amsgrad"] is True
+    for i, st in sd["state"].items():
+        assert torch.equal(mine["state"][i]["max_exp_avg_sq"], st["max_exp_avg_sq"])
+    fresh = torch.optim.Adam(model.parameters(), lr=1.0, amsgrad=True)
+    fresh.load_state_dict(mine)
+    plain = FusedAdam(flat, lr=1e-3)
+    plain.load_state_dict(torch.optim.Adam(model.parameters(), lr=1e-3).state_dict())
+    assert plain.vmax is None and not plain.amsgrad
+
+
+def test_training_config_json_is_reference_compatible(tmp_path):
+    """training_config.json holds the reference's fields only (its from_json_file rejects unknown keys); the
+    multivae_amd switches live in a side file and come back on load."""
+    import json
+
+    from multivae_amd.trainers import BaseTrainerConfig
+
+    cfg = BaseTrainerConfig(num_epochs=3, use_hip_graph=True, sync_every_step=True, scheduler_cls="StepLR",
+                            scheduler_params=dict(step_size=2))
+    cfg.save_json(str(tmp_path), "training_config")
+    with open(tmp_path / "training_config.json") as f:
+        d = json.load(f)
+    assert not ({"use_fused_adam", "sync_every_step", "use_hip_graph"} & set(d)) and d["num_epochs"] == 3
+    back = BaseTrainerConfig.from_json_file(str(tmp_path / "training_config.json"))
+    assert back.use_hip_graph and back.sync_every_step and back.scheduler_cls == "StepLR"
+    (tmp_path / "training_config_mvk.json").unlink()
+    assert BaseTrainerConfig.from_json_file(str(tmp_path / "training_config.json")).use_hip_graph is False
 
 
 def test_auto_model_and_auto_config(tmp_path):
