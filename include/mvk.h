@@ -428,6 +428,34 @@ int mvk_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, v
 int mvk_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The reference's public helper functions (multivae/models/base/base_utils.py) for user code that imports them
+ * ------------------------------------------------------------------------------------------------ */
+/* poe(mus, logvars, eps) (base_utils.py:122-130; stable = 0) and stable_poe (:133-147; stable = 1, no eps, an expert with
+ * logvar = +inf has weight exactly 0, a single expert is returned as is): mus, lvs [E, n] -> mu, lv [n]; backward from
+ * the gradients of both outputs (either may be NULL) to dmus, dlvs [E, n]. */
+int mvk_poe_fwd(const float* mus, const float* lvs, int E, int64_t n, float eps, int stable, float* mu, float* lv,
+                void* stream);
+int mvk_poe_bwd(const float* mus, const float* lvs, int E, int64_t n, float eps, int stable, const float* gmu,
+                const float* glv, float* dmus, float* dlvs, void* stream);
+/* kl_divergence(mean, log_var, prior_mean, prior_log_var).sum(-1) (base_utils.py:90-119): kl [rows]; every operand holds
+ * n_* elements and is indexed modulo that count (trailing-dimension broadcasting: a [1, L] prior under [rows, L]
+ * posteriors).  Backward writes FULL-shape [rows, L] partial derivatives (NULL outputs are skipped); the caller column-
+ * sums those of broadcast operands (mvk_colsum_acc). */
+int mvk_kl_gauss_fwd(const float* mean, int64_t n_mean, const float* lv, int64_t n_lv, const float* pmean, int64_t n_pmean,
+                     const float* plv, int64_t n_plv, int64_t rows, int L, float* kl, void* stream);
+int mvk_kl_gauss_bwd(const float* mean, int64_t n_mean, const float* lv, int64_t n_lv, const float* pmean, int64_t n_pmean,
+                     const float* plv, int64_t n_plv, int64_t rows, int L, const float* g, float* dmean, float* dlv,
+                     float* dpmean, float* dplv, void* stream);
+/* set_decoder_dist(dist, params)(recon, target) (base_utils.py:62-87) and cross_entropy (:28-57): ELEMENT-WISE log-
+ * probabilities lp [n] of recon [n] against target [n_target] (indexed modulo n_target: a [B, D] target under [K, B, D]
+ * reconstructions); dist = MVK_DIST_*; scale for normal / laplace; categorical: x * log_softmax(recon + eps) over the last
+ * dimension C.  Backward: drecon = g * d lp / d recon. */
+int mvk_logprob_fwd(const float* recon, const float* target, int64_t n, int64_t n_target, int dist, float scale, int C,
+                    float eps, float* lp, void* stream);
+int mvk_logprob_bwd(const float* recon, const float* target, int64_t n, int64_t n_target, int dist, float scale, int C,
+                    float eps, const float* g, float* drecon, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Optimizer
  * ------------------------------------------------------------------------------------------------ */
 /* torch.optim.Adam (amsgrad=False) on flat buffers; step is 1-based; grad_scale multiplies g first

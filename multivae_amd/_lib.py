@@ -104,6 +104,12 @@ PROTOTYPES = {
     "mvk_iwae_sample": [_p, _p, _p, _i, _i, _i, _i, _p, _p],
     "mvk_iwae_logw": [_p, _p, _i, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p, _p],
     "mvk_iwae_reduce": [_p, _i, _i, _i, _p, _p],
+    "mvk_poe_fwd": [_p, _p, _i, _i64, _f, _i, _p, _p, _p],
+    "mvk_poe_bwd": [_p, _p, _i, _i64, _f, _i, _p, _p, _p, _p, _p],
+    "mvk_kl_gauss_fwd": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i, _p, _p],
+    "mvk_kl_gauss_bwd": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p],
+    "mvk_logprob_fwd": [_p, _p, _i64, _i64, _i, _f, _i, _f, _p, _p],
+    "mvk_logprob_bwd": [_p, _p, _i64, _i64, _i, _f, _i, _f, _p, _p, _p],
 }
 
 _lib = None

@@ -79,9 +79,6 @@ class JMVAE(BaseJointModel):
             o = self.encoders[mod](data[mod])
             mus.append(o.embedding)
             lvs.append(o.log_covariance)
-        mus, lvs = torch.stack(mus), torch.stack(lvs)
-        if len(subset) == 1:
-            return mus[0], lvs[0]
-        ln_inv_vars = -lvs
-        ln_var = -torch.logsumexp(ln_inv_vars, dim=0)
-        return (torch.exp(ln_inv_vars) * mus).sum(dim=0) * torch.exp(ln_var), ln_var
+        from ..base.base_utils import stable_poe
+
+        return stable_poe(mus, lvs)  # mvk_poe_fwd (csrc/utils.hip)

@@ -85,12 +85,22 @@ class _BatchIterator:
         # device-resident gather only for the stock datasets: a subclass that overrides __getitem__ (transforms,
         # normalisation, dtype conversion) goes through its own __getitem__ below
         from ...data.datasets.base import IncompleteDataset, MultimodalBaseDataset
+        from ...data.datasets.mmnist import MMNISTDataset
+        from ...data.datasets.utils import ResampleDataset
 
-        stock = type(base).__getitem__ in (MultimodalBaseDataset.__getitem__, IncompleteDataset.__getitem__)
-        self.fast = stock and isinstance(getattr(base, "data", None), dict) and \
-            all(torch.is_tensor(v) for v in base.data.values())
+        stock = type(base).__getitem__ in (MultimodalBaseDataset.__getitem__, IncompleteDataset.__getitem__,
+                                           MMNISTDataset.__getitem__)
+        plain = lambda v: torch.is_tensor(v) or (isinstance(v, ResampleDataset) and v.transform is None)
+        self.fast = stock and isinstance(getattr(base, "data", None), dict) and all(plain(v) for v in base.data.values())
+        self.resample = {}
         if self.fast:
-            self.data = {m: v.to(device) for m, v in base.data.items()}
+            self.data = {}
+            for m, v in base.data.items():
+                if isinstance(v, ResampleDataset):  # base[index[i]]: the base set and the index live on the device
+                    self.data[m] = v.base.to(device)
+                    self.resample[m] = v.index.to(device)
+                else:
+                    self.data[m] = v.to(device)
             self.masks = None
             if getattr(base, "masks", None) is not None:
                 self.masks = {m: torch.as_tensor(v).to(device) for m, v in base.masks.items()}
@@ -126,7 +136,8 @@ class _BatchIterator:
             if self.fast:
                 gi = idx if self.index_map is None else self.index_map[idx]
                 gi = gi.to(self.device)
-                out = {"data": {m: v.index_select(0, gi) for m, v in self.data.items()}}
+                out = {"data": {m: v.index_select(0, self.resample[m].index_select(0, gi) if m in self.resample else gi)
+                                for m, v in self.data.items()}}
                 if self.masks is not None:
                     out["masks"] = {m: v.index_select(0, gi) for m, v in self.masks.items()}
                 if self.labels is not None:
