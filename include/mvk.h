@@ -359,15 +359,18 @@ typedef struct mvk_pack_desc {
   float* Wdown;
   float* Wup;
   int Cv, Cu, ld_down, col_off, kind;
-} mvk_pack_desc;
+  void* Fdown; /* kind 0, optional: the weights as bf16-piece MFMA fragments in the order the register-stationary */
+  void* Fup;   /* convolution kernels (csrc/imgconv.hip) load them: [role][k-step 16][piece 3][lane 64][8 bf16],  */
+} mvk_pack_desc; /* mvk_imgconv_frag_bytes(Cu, Cv) bytes each; passed to mvk_conv4s2_down / _up as `wfrag` */
+int64_t mvk_imgconv_frag_bytes(int Cu, int Cv); /* 0: this channel pair has no register-stationary kernel */
 int mvk_pack_weights(const mvk_pack_desc* jobs, int n, void* stream);
 int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w,
                      int Cu, int Cv, int act, int u_nchw, const float* u_act_src, int u_act,
                      const float* v_act_src, int v_act, float* colsum_acc, float* ws, int64_t ws_floats, int fmt,
-                     void* stream);
+                     const void* wfrag, void* stream);
 int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U, int n, int h, int w, int Cu,
                    int Cv, int act, int u_nchw, const float* u_act_src, int u_act, float* colsum_acc, float* ws,
-                   int64_t ws_floats, int fmt, void* stream);
+                   int64_t ws_floats, int fmt, const void* wfrag, void* stream);
 int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv,
                       int u_nchw, const float* u_act_src, int u_act, float* ws, int64_t ws_floats, void* stream);
 

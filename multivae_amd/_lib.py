@@ -32,7 +32,7 @@ class ReconDesc(C.Structure):
 
 class PackDesc(C.Structure):  # mvk_pack_desc
     _fields_ = [("Wref", _p), ("Wdown", _p), ("Wup", _p), ("Cv", C.c_int32), ("Cu", C.c_int32),
-                ("ld_down", C.c_int32), ("col_off", C.c_int32), ("kind", C.c_int32)]
+                ("ld_down", C.c_int32), ("col_off", C.c_int32), ("kind", C.c_int32), ("Fdown", _p), ("Fup", _p)]
 
 
 class SeedDesc(C.Structure):  # mvk_seed_desc
@@ -65,8 +65,8 @@ PROTOTYPES = {
     "mvk_act_bwd": [_p, _p, _i64, _i, _p],
     "mvk_gemm": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _i, _p, _i, _p, _i64, _p],
     "mvk_pack_conv4s2_weight": [_p, _i, _i, _p, _i, _i, _p, _p],
-    "mvk_conv4s2_down": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i64, _i, _p],
-    "mvk_conv4s2_up": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i64, _i, _p],
+    "mvk_conv4s2_down": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i64, _i, _p, _p],
+    "mvk_conv4s2_up": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i64, _i, _p, _p],
     "mvk_pack_weights": [C.POINTER(PackDesc), _i, _p],
     "mvk_loss_backward_seed": [C.POINTER(SeedDesc), _i, _p, _p],
     "mvk_f32_to_bf3": [_p, _i64, _p, _p],
@@ -143,6 +143,8 @@ def load(path=None):
     lib.mvk_prof_count.restype = C.c_int
     lib.mvk_prof_clock_khz.argtypes = []
     lib.mvk_prof_clock_khz.restype = C.c_int
+    lib.mvk_imgconv_frag_bytes.argtypes = [_i, _i]
+    lib.mvk_imgconv_frag_bytes.restype = C.c_int64
     lib.mvk_splitk_workspace_floats.argtypes = [_i, _i, _i]
     lib.mvk_splitk_workspace_floats.restype = C.c_int64
     _lib = lib

@@ -516,10 +516,11 @@ using namespace mvk;
 
 namespace mvk {
 // imgconv.hip: register-stationary-weight kernels for the 4x4/stride-2 layer pairs (1 = shape not covered)
-int imgconv_up(const float* V, const float* Wup, const float* bias, float* U, int n, int h, int w, int Cu, int Cv,
-               int act, const float* u_act_src, int u_act, float* colsum_part, int* part_rows, hipStream_t s);
-int imgconv_down(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w, int Cu, int Cv,
-                 int act, const float* v_act_src, int v_act, float* colsum_part, int* part_rows, hipStream_t s);
+int imgconv_up(const float* V, const float* Wup, const void* wfrag, const float* bias, float* U, int n, int h, int w, int Cu,
+               int Cv, int act, const float* u_act_src, int u_act, float* colsum_part, int* part_rows, hipStream_t s);
+int imgconv_down(const float* U, const float* Wdown, const void* wfrag, const float* bias, float* V, int n, int h, int w,
+                 int Cu, int Cv, int act, const float* v_act_src, int v_act, float* colsum_part, int* part_rows,
+                 hipStream_t s);
 // MVK_IMGCONV=0 disables the kernels, MVK_IMGCONV=<n> sets the smallest batch that takes them (default 256 images);
 // mvk_debug_set_flags: bit 0x100 disables them, bit 0x200 takes them for every batch size (tests, A/B probes)
 int imgconv_wgrad(const float* U, const float* V, float* slab, long long slab_floats, int n, int h, int w, int Cu, int Cv,
@@ -687,7 +688,7 @@ int mvk_gemm(const float* A, const float* B, float* C, int M, int N, int K, int 
 // ---------------------------------------------------------------------------------------------------------
 int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w, int Cu,
                      int Cv, int act, int u_nchw, const float* u_act_src, int u_act, const float* v_act_src,
-                     int v_act, float* colsum_acc, float* ws, int64_t ws_floats, int fmt, void* stream) {
+                     int v_act, float* colsum_acc, float* ws, int64_t ws_floats, int fmt, const void* wfrag, void* stream) {
   if (n == 0) return MVK_OK;  // empty batch: nothing to launch (torch hands out NULL for empty tensors)
   if (!U || !Wdown || !V || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0) return MVK_EINVAL;
   if ((fmt & ~MVK_FMT_IN_BF3) || ((fmt & MVK_FMT_IN_BF3) && (u_nchw || u_act_src))) return MVK_EINVAL;
@@ -699,7 +700,7 @@ int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, floa
   if (!u_nchw && !u_act_src && fmt == 0 && n >= imgconv_min_images() && imgconv_act_ok(act) &&
       imgconv_act_ok(v_act) && (!colsum_acc || (ws && ws_floats >= 256 * (int64_t)Cv)) && mvk_aligned16(U)) {
     int rows = 0;
-    const int rc = imgconv_down(U, Wdown, bias, V, n, h, w, Cu, Cv, act, v_act_src, v_act, colsum_acc ? ws : nullptr,
+    const int rc = imgconv_down(U, Wdown, wfrag, bias, V, n, h, w, Cu, Cv, act, v_act_src, v_act, colsum_acc ? ws : nullptr,
                                 &rows, mvk_stream(stream));
     if (rc == MVK_OK && colsum_acc) return colsum_finish(ws, rows, Cv, colsum_acc, mvk_stream(stream));
     if (rc != 1) return rc;
@@ -735,14 +736,14 @@ int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, floa
 
 int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U, int n, int h, int w, int Cu,
                    int Cv, int act, int u_nchw, const float* u_act_src, int u_act, float* colsum_acc, float* ws,
-                   int64_t ws_floats, int fmt, void* stream) {
+                   int64_t ws_floats, int fmt, const void* wfrag, void* stream) {
   if (n == 0) return MVK_OK;  // empty batch: nothing to launch (torch hands out NULL for empty tensors)
   if (!V || !Wup || !U || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0 || (colsum_acc && u_nchw)) return MVK_EINVAL;
   if (fmt & ~MVK_FMT_IN_BF3) return MVK_EINVAL;
   if (!u_nchw && fmt == 0 && n >= imgconv_min_images() && imgconv_act_ok(act) && imgconv_act_ok(u_act) &&
       (!colsum_acc || (ws && ws_floats >= 256 * (int64_t)Cu)) && mvk_aligned16(V)) {
     int rows = 0;
-    const int rc = imgconv_up(V, Wup, bias, U, n, h, w, Cu, Cv, act, u_act_src, u_act, colsum_acc ? ws : nullptr, &rows,
+    const int rc = imgconv_up(V, Wup, wfrag, bias, U, n, h, w, Cu, Cv, act, u_act_src, u_act, colsum_acc ? ws : nullptr, &rows,
                               mvk_stream(stream));
     if (rc == MVK_OK && colsum_acc) return colsum_finish(ws, rows, Cu, colsum_acc, mvk_stream(stream));
     if (rc != 1) return rc;

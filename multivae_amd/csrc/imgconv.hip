@@ -35,6 +35,7 @@ enum { IC_UP = 0, IC_DOWN = 1 };
 struct ImgConvArgs {
   const float* A;        // input images [n][APIX][CIN] (NHWC)
   const float* Wp;       // fp32 GEMM pack: Wup[class][(a,b,cv)][cu] or Wdown[(kh,kw,cu)][cv]
+  const void* wfrag;     // the same weights as bf16-piece fragments [role][k-step][piece][lane][8] (mvk_pack_weights), or null
   const float* bias;     // [COUT] or null
   float* out;            // output images (NHWC)
   const float* act_src;  // tensor of the output's shape whose activation derivative multiplies the result, or null
@@ -107,6 +108,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   // ---- weights: 16 k-steps x 3 pieces, resident for the whole launch ---------------------------------------------
   bf16x8 Bw[T::NTAPS][T::CHUNKS][3];
+  if (g.wfrag) {  // 48 coalesced 16-byte loads per lane
+    const bf16x8* f = reinterpret_cast<const bf16x8*>(g.wfrag) + (long long)(wgtype * 4 + wave) * 16 * 3 * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < T::NTAPS; ++q)
+#pragma unroll
+      for (int c = 0; c < T::CHUNKS; ++c)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) Bw[q][c][pc] = f[((q * T::CHUNKS + c) * 3 + pc) * 64];
+  } else
 #pragma unroll
   for (int q = 0; q < T::NTAPS; ++q) {
     const int tap = ks * T::NTAPS + q;
@@ -658,19 +668,20 @@ int imgconv_wgrad(const float* U, const float* V, float* slab, long long slab_fl
 }
 
 // 1: shape not covered (the caller falls back to the implicit-GEMM engine)
-int imgconv_up(const float* V, const float* Wup, const float* bias, float* U, int n, int h, int w, int Cu, int Cv,
-               int act, const float* u_act_src, int u_act, float* colsum_part, int* part_rows, hipStream_t s) {
+int imgconv_up(const float* V, const float* Wup, const void* wfrag, const float* bias, float* U, int n, int h, int w, int Cu,
+               int Cv, int act, const float* u_act_src, int u_act, float* colsum_part, int* part_rows, hipStream_t s) {
   if (h != w) return 1;
-  ImgConvArgs a{V, Wup, bias, U, u_act_src, colsum_part, n, act, u_act, nullptr};
+  ImgConvArgs a{V, Wup, wfrag, bias, U, u_act_src, colsum_part, n, act, u_act, nullptr};
   if (h == 8 && Cv == 64 && Cu == 32) return imgconv_launch<IC_UP, 8, 64, 32>(a, part_rows, s);
   if (h == 4 && Cv == 128 && Cu == 64 && n % 2 == 0) return imgconv_launch<IC_UP, 4, 128, 64>(a, part_rows, s);
   return 1;
 }
 
-int imgconv_down(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w, int Cu, int Cv,
-                 int act, const float* v_act_src, int v_act, float* colsum_part, int* part_rows, hipStream_t s) {
+int imgconv_down(const float* U, const float* Wdown, const void* wfrag, const float* bias, float* V, int n, int h, int w,
+                 int Cu, int Cv, int act, const float* v_act_src, int v_act, float* colsum_part, int* part_rows,
+                 hipStream_t s) {
   if (h != w) return 1;
-  ImgConvArgs a{U, Wdown, bias, V, v_act_src, colsum_part, n, act, v_act, nullptr};
+  ImgConvArgs a{U, Wdown, wfrag, bias, V, v_act_src, colsum_part, n, act, v_act, nullptr};
   if (h == 8 && Cu == 32 && Cv == 64) return imgconv_launch<IC_DOWN, 8, 32, 64>(a, part_rows, s);
   if (h == 4 && Cu == 64 && Cv == 128 && n % 2 == 0) return imgconv_launch<IC_DOWN, 4, 64, 128>(a, part_rows, s);
   return 1;

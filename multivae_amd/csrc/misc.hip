@@ -1,6 +1,6 @@
 // Small HBM-bound helper kernels: weight packing, layout changes at the plugin boundary, activation
 // backward, the 3-channel image-producing transposed convolution, flat Adam, scalar assembly.
-#include "common.hpp"
+#include "bf3.hpp"
 
 namespace {
 
@@ -56,10 +56,33 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs jobs) {
     }
     const int kh = tap >> 2, kw = tap & 3;
     if (d.Wdown) d.Wdown[(long long)(tap * d.Cu + cu) * d.ld_down + d.col_off + cv] = v;
-    if (d.Wup) {
-      const int ph = 1 - (kh & 1), a = kh >> 1;
-      const int pw = 1 - (kw & 1), b = kw >> 1;
-      d.Wup[((long long)(ph * 2 + pw) * 4 * d.Cv + (a * 2 + b) * d.Cv + cv) * d.Cu + cu] = v;
+    const int ph = 1 - (kh & 1), a = kh >> 1;
+    const int pw = 1 - (kw & 1), b = kw >> 1;
+    if (d.Wup) d.Wup[((long long)(ph * 2 + pw) * 4 * d.Cv + (a * 2 + b) * d.Cv + cv) * d.Cu + cu] = v;
+    if (d.Fdown || d.Fup) {
+      // bf16-piece MFMA B fragments of the register-stationary convolution kernels (imgconv.hip): element (k, n) of
+      // the slice of wave `role` sits at [role][k-step][piece][lane = (k % 16 / 8) * 32 + n % 32][k % 8]
+      unsigned p0, p1, p2;
+      mvk::bf3_split(v, 0.f, p0, p1, p2);
+      const unsigned short pc[3] = {(unsigned short)p0, (unsigned short)p1, (unsigned short)p2};
+      if (d.Fdown) {  // GEMM k = (tap, cu), n = cv
+        const int chunks = d.Cu / 16, ntaps = 16 / chunks, ksplit = 16 / ntaps, nct = d.Cv / 32;
+        const int ks = tap / ntaps, q = tap % ntaps, ct = cv / 32;
+        const int role = nct * ksplit <= 4 ? ks * nct + ct : ct * 4 + ks;
+        const int kk = q * chunks + cu / 16, lane = ((cu % 16) / 8) * 32 + cv % 32;
+        unsigned short* f = static_cast<unsigned short*>(d.Fdown);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) f[((((long long)role * 16 + kk) * 3 + p) * 64 + lane) * 8 + cu % 8] = pc[p];
+      }
+      if (d.Fup) {  // per output parity class: k = (tap (a, b), cv), n = cu
+        const int chunks = d.Cv / 16, ntaps = 16 / chunks, ksplit = 4 / ntaps, nct = d.Cu / 32;
+        const int t4 = a * 2 + b, ks = t4 / ntaps, q = t4 % ntaps, ct = cu / 32;
+        const int role = (ph * 2 + pw) * (ksplit * nct) + ks * nct + ct;
+        const int kk = q * chunks + cv / 16, lane = ((cv % 16) / 8) * 32 + cu % 32;
+        unsigned short* f = static_cast<unsigned short*>(d.Fup);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) f[((((long long)role * 16 + kk) * 3 + p) * 64 + lane) * 8 + cv % 8] = pc[p];
+      }
     }
   }
 }
@@ -337,15 +360,21 @@ int mvk_pack_conv4s2_weight(const float* Wref, int Cv, int Cu, float* Wdown, int
   return MVK_OK;
 }
 
+int64_t mvk_imgconv_frag_bytes(int Cu, int Cv) {
+  if ((Cu == 32 && Cv == 64) || (Cu == 64 && Cv == 128)) return (int64_t)16 * Cu * Cv * 3 * 2;  // every element, 3 bf16 pieces
+  return 0;
+}
+
 int mvk_pack_weights(const mvk_pack_desc* jobs, int n, void* stream) {
   if (!jobs || n <= 0 || n > MVK_PACK_MAX) return MVK_EINVAL;
   PackJobs pj{};
   int maxtot = 0;
   for (int i = 0; i < n; ++i) {
     const mvk_pack_desc& d = jobs[i];
-    if (!d.Wref || d.Cv <= 0 || d.Cu <= 0 || d.kind < 0 || d.kind > 2 || (!d.Wdown && !d.Wup) ||
+    if (!d.Wref || d.Cv <= 0 || d.Cu <= 0 || d.kind < 0 || d.kind > 2 || (!d.Wdown && !d.Wup && !d.Fdown && !d.Fup) ||
         (d.kind == 1 && !d.Wup))
       return MVK_EINVAL;
+    if ((d.Fdown || d.Fup) && (d.kind != 0 || mvk_imgconv_frag_bytes(d.Cu, d.Cv) == 0)) return MVK_EINVAL;
     pj.j[i] = d;
     if (pj.j[i].ld_down <= 0) pj.j[i].ld_down = d.Cv;
     const int tot = d.Cv * d.Cu * 16;

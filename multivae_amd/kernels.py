@@ -200,11 +200,19 @@ def colsum(dy2, b, y_out=None, y_act=NONE):
 
 def pack_conv(wref, want_down=True, want_up=True):
     """wref [Cv][Cu][4][4] -> (Wdown [16*Cu, Cv], Wup [4, 4*Cv, Cu])."""
-    Cv, Cu = wref.shape[0], wref.shape[1]
-    wd = _new((16 * Cu, Cv), wref) if want_down else None
-    wu = _new((4, 4 * Cv, Cu), wref) if want_up else None
-    call("mvk_pack_conv4s2_weight", ptr(wref), Cv, Cu, ptr(wd), Cv, 0, ptr(wu), stream_ptr())
+    (wd, wu), = pack_weights([(wref, want_down, want_up)])
     return wd, wu
+
+
+def _frag(like, Cu, Cv):
+    """Buffer for the bf16-piece fragment pack of a 4x4/stride-2 layer the register-stationary kernels cover, else None."""
+    nb = _lib.load().mvk_imgconv_frag_bytes(Cu, Cv)
+    return torch.empty(nb, dtype=torch.uint8, device=like.device) if nb else None
+
+
+def wfrag(w):
+    """The fragment pack that travels with a packed weight (attached by pack_weights), or None."""
+    return getattr(w, "mvk_frag", None)
 
 
 def pack_weights(jobs):
@@ -235,13 +243,20 @@ def pack_weights(jobs):
             d.kind = 0
             d.Wdown = wd.data_ptr() if wd is not None else None
             d.Wup = wu.data_ptr() if wu is not None else None
+            # bf16-piece MFMA fragments for the register-stationary kernels travel with the packs (same launch)
+            if wd is not None:
+                wd.mvk_frag = _frag(wref, Cu, Cv)
+                d.Fdown = wd.mvk_frag.data_ptr() if wd.mvk_frag is not None else None
+            if wu is not None:
+                wu.mvk_frag = _frag(wref, Cu, Cv)
+                d.Fup = wu.mvk_frag.data_ptr() if wu.mvk_frag is not None else None
             outs.append((wd, wu))
     call("mvk_pack_weights", descs, len(jobs), stream_ptr())
     return outs
 
 
 def conv_down(U, wdown, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src=None, u_act=NONE,
-              v_act_src=None, v_act=NONE, out_bias=None, in_bf3=False):
+              v_act_src=None, v_act=NONE, out_bias=None, in_bf3=False, frag=None):
     """out_bias: bias parameter whose gradient is the per-channel sum of the result (backward-data use): fused into
     the launch; returns (V, grad for autograd) then."""
     V = torch.empty((n, h, w, Cv), dtype=torch.float32, device=U.device)
@@ -249,17 +264,18 @@ def conv_down(U, wdown, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src
     tb, rb = _bias_target(out_bias)
     call("mvk_conv4s2_down", ptr(U), ptr(wdown), ptr(bias), ptr(V), n, h, w, Cu, Cv, act, int(u_nchw),
          ptr(u_act_src), u_act, ptr(v_act_src), v_act, ptr(tb), ptr(ws), ws.numel(), FMT_IN_BF3 if in_bf3 else 0,
-         stream_ptr())
+         ptr(frag if frag is not None else wfrag(wdown)), stream_ptr())
     return V if out_bias is None else (V, rb)
 
 
 def conv_up(V, wup, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src=None, u_act=NONE, out_bias=None,
-            in_bf3=False):
+            in_bf3=False, frag=None):
     U = torch.empty((n, Cu, 2 * h, 2 * w) if u_nchw else (n, 2 * h, 2 * w, Cu), dtype=torch.float32, device=V.device)
     ws = _ws(U)
     tb, rb = _bias_target(out_bias)
     call("mvk_conv4s2_up", ptr(V), ptr(wup), ptr(bias), ptr(U), n, h, w, Cu, Cv, act, int(u_nchw),
-         ptr(u_act_src), u_act, ptr(tb), ptr(ws), ws.numel(), FMT_IN_BF3 if in_bf3 else 0, stream_ptr())
+         ptr(u_act_src), u_act, ptr(tb), ptr(ws), ws.numel(), FMT_IN_BF3 if in_bf3 else 0,
+         ptr(frag if frag is not None else wfrag(wup)), stream_ptr())
     return U if out_bias is None else (U, rb)
 
 
@@ -493,6 +509,7 @@ class SVHNEncoderFn(Function):
         mu = gemm(h3f, wdc1, B, L, Kf, bias=bc1, bias_mod=L)
         lv = gemm(h3f, wdc2, B, L, Kf, bias=bc2, bias_mod=L)
         ctx.save_for_backward(x, h1, h2, h3, wu1, wu2, wdc1, wdc2, w0, b0, w1, b1, w2, b2, wc1, bc1, wc2, bc2)
+        ctx.frags = (wfrag(wu1), wfrag(wu2))  # saved tensors come back without Python attributes
         ctx.dims = (B, H, W, chans, L)
         return mu, lv
 
@@ -518,9 +535,11 @@ class SVHNEncoderFn(Function):
         dw2 = conv_wgrad(h2, dh3, w2, B, H // 8, W // 8, ch[2], ch[3])
         db2 = colsum(dh3.view(-1, ch[3]), b2)
         # each backward-data launch also emits the bias gradient of the layer it lands in (column sums of its output)
-        dh2, db1 = conv_up(dh3, wu2, None, B, H // 8, W // 8, ch[2], ch[3], u_act_src=h2, u_act=RELU, out_bias=b1)
+        dh2, db1 = conv_up(dh3, wu2, None, B, H // 8, W // 8, ch[2], ch[3], u_act_src=h2, u_act=RELU, out_bias=b1,
+                           frag=ctx.frags[1])
         dw1 = conv_wgrad(h1, dh2, w1, B, H // 4, W // 4, ch[1], ch[2])
-        dh1, db0 = conv_up(dh2, wu1, None, B, H // 4, W // 4, ch[1], ch[2], u_act_src=h1, u_act=RELU, out_bias=b0)
+        dh1, db0 = conv_up(dh2, wu1, None, B, H // 4, W // 4, ch[1], ch[2], u_act_src=h1, u_act=RELU, out_bias=b0,
+                           frag=ctx.frags[0])
         dw0 = conv_wgrad(x, dh1, w0, B, H // 2, W // 2, ch[0], ch[1], u_nchw=True)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -552,6 +571,7 @@ class SVHNDecoderFn(Function):
             call("mvk_conv4s2_up_nchw_small", ptr(g3), ptr(w3), ptr(b3), ptr(out), n, 16, 16, C4, C3, SIGMOID,
                  stream_ptr())
         ctx.small = small
+        ctx.frags = (wfrag(wd1), wfrag(wd2))
         ctx.save_for_backward(z2, g1, g2, g3, out, wp0, wd1, wd2, wd3, w0, b0, w1, b1, w2, b2, w3, b3)
         ctx.dims = (n, L, C1, C2, C3, C4)
         ctx.z_shape = z.shape
@@ -583,9 +603,11 @@ class SVHNDecoderFn(Function):
         dw2 = conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2)
         if not ctx.small:
             db2 = colsum(dg3.view(-1, C3), b2)
-        dg2, db1 = conv_down(dg3, wd2, None, n, 8, 8, C3, C2, NONE, v_act_src=g2, v_act=RELU, out_bias=b1)
+        dg2, db1 = conv_down(dg3, wd2, None, n, 8, 8, C3, C2, NONE, v_act_src=g2, v_act=RELU, out_bias=b1,
+                             frag=ctx.frags[1])
         dw1 = conv_wgrad(dg2, g1, w1, n, 4, 4, C2, C1)
-        dg1, db0 = conv_down(dg2, wd1, None, n, 4, 4, C2, C1, NONE, v_act_src=g1, v_act=RELU, out_bias=b0)
+        dg1, db0 = conv_down(dg2, wd1, None, n, 4, 4, C2, C1, NONE, v_act_src=g1, v_act=RELU, out_bias=b0,
+                             frag=ctx.frags[0])
         dg1f = dg1.view(n, 16 * C1)
         tw0, dw0 = _grad_target(w0)
         ws = _ws(z2)
