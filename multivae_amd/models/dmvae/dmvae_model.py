@@ -196,7 +196,62 @@ class DMVAE(BaseMultiVAE):
             modalities_z[k] = torch.randn([n_samples, int(dim)] if n_samples > 1 else [int(dim)], device=dev)
         return ModelOutput(z=torch.randn(shape, device=dev), one_latent_space=False, modalities_z=modalities_z)
 
-    def compute_joint_nll(self, inputs, K: int = 1000, batch_size_K: int = 100):
-        # The reference accumulates ln_prior / ln_posterior ACROSS data points and K-chunks (dmvae_model.py:352, :395-408
-        # never reset them), so its number depends on the batch order and the chunk size; not reproduced.
-        raise NotImplementedError("DMVAE.compute_joint_nll is not on the HIP path")
+    def compute_joint_nll(self, inputs, K: int = 1000, batch_size_K: int = 100, **kwargs):
+        """The reference's estimator (dmvae_model.py:311-412), quirk included: K shared samples per data point from the
+        joint posterior, fresh private samples of every modality per chunk of `batch_size_K`, and `ln_prior` /
+        `ln_posterior` that are NEVER reset (:352, :385-403 accumulate them over the K-chunks AND over the data points), so
+        the log-weight of sample r of chunk c of data point i carries the prior / posterior log-densities of sample r of
+        every earlier (data point, chunk).  Here the K axis is a kernel axis (mvk_iwae_sample, one decoder pass per
+        modality and chunk of data points, mvk_recon_nll_fwd rows, mvk_iwae_logw for ln p - ln q of the concatenated
+        [shared, private...] latent, mvk_iwae_reduce); the running sums are one cumulative sum over the (data point,
+        chunk) sequence.  kwargs: noise = {"shared": [K,B,L], "private": {m: [K,B,S_m]}} (sample k = c * batch_size_K + r)."""
+        self.eval()
+        if hasattr(inputs, "masks"):
+            raise AttributeError(self._NLL_INCOMPLETE)
+        K, bK = int(K), min(int(batch_size_K), int(K))
+        if K % bK:  # the reference adds a [K % bK] chunk to its [bK] running sums and fails
+            raise RuntimeError(f"K = {K} is not a multiple of batch_size_K = {bK}: the running prior / posterior sums of "
+                               "the reference's estimator have one entry per sample of a chunk")
+        noise = kwargs.get("noise") or {}
+        with torch.no_grad():
+            mu, lv, _, private = self._infer_latent_parameters(inputs)
+            B, L = mu.shape
+            dev = mu.device
+            names = list(inputs.data.keys())
+            z = kernels.iwae_sample(mu, kernels.std_from_logvar(lv), self._noise((K, B, L), dev, noise.get("shared")))
+            ws, locs, sds = {}, [mu], [kernels.std_from_logvar(lv)]
+            for m in names:
+                pm, pl = private[m]
+                psd = kernels.std_from_logvar(pl)
+                ws[m] = kernels.iwae_sample(pm, psd, self._noise((K, B, pm.shape[-1]), dev,
+                                                                   (noise.get("private") or {}).get(m)))
+                locs.append(pm)
+                sds.append(psd)
+            loc_all, sd_all = torch.cat(locs, dim=-1).contiguous(), torch.cat(sds, dim=-1).contiguous()
+            xs = [inputs.data[m].float().contiguous() for m in names]
+            dists = [self.recon_dists[m][0] for m in names]
+            scales = [self.recon_dists[m][1] for m in names]
+            order = self._branch_order(inputs, names)
+            nc = K // bK
+            ll = torch.empty(B, dtype=torch.float32, device=dev)
+            carry = torch.zeros(bK, dtype=torch.float32, device=dev)
+            step = max(1, kernels.IWAE_ROWS_BUDGET // K)
+            for b0 in range(0, B, step):
+                b1 = min(B, b0 + step)
+                b = b1 - b0
+                zc = z[:, b0:b1]
+                wc = {m: ws[m][:, b0:b1] for m in names}
+                rec = kernels.run_branches(order, lambda m: self.decoders[m](
+                    torch.cat([zc, wc[m]], dim=-1).contiguous()).reconstruction, dev)
+                rows = kernels.recon_nll_rows([rec[m] for m in names], [x[b0:b1] for x in xs], dists, scales, K, b)
+                z_all = torch.cat([zc] + [wc[m] for m in names], dim=-1).contiguous()
+                ratio = kernels.iwae_logw(z_all, [], [loc_all[b0:b1]], [sd_all[b0:b1]])  # ln p - ln q, [K, b]
+                # running sums over the (data point, chunk) sequence, per sample slot r of a chunk
+                t = ratio.view(nc, bK, b).permute(2, 0, 1).reshape(b * nc, bK)
+                run = torch.cumsum(t, dim=0) + carry
+                carry = run[-1].clone()
+                lw = run.view(b, nc, bK).permute(1, 2, 0).reshape(K, b).contiguous()
+                for r in rows:
+                    lw = kernels.axpby(lw, 1.0, r, -1.0)
+                kernels.iwae_reduce([lw], out=ll[b0:b1])
+            return -ll.sum()

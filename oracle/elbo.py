@@ -879,3 +879,43 @@ def mmvae_joint_nll_paper(enc, data, decoders, noises, *, names, K, batch_size_K
         vals.append(l.sum() + math.log(n * M))
         c += 1
     return -(torch.logsumexp(torch.stack(vals), dim=0) - math.log(done * M))
+
+
+def dmvae_joint_nll(enc, data, decoders, noise, *, names, batch_size_K=100, dists=None, scales=None):
+    """DMVAE.compute_joint_nll (dmvae_model.py:311-412) as written: K samples of the shared latent from the joint posterior
+    (stable_poe of the shared experts and the prior), fresh private samples of every modality per chunk of batch_size_K, and
+    `ln_prior` / `ln_posterior` initialised ONCE before the loop over the data points (:352) and only ever added to
+    (:385-403): the importance weights of a chunk carry the log-densities of every earlier chunk and data point.
+    enc: {m: (mu, lv, mu_private, lv_private)}; noise: {"shared": [K,B,L], "private": {m: [K,B,S_m]}} with sample
+    k = chunk * batch_size_K + r.  -> (nll, ll [B])"""
+    dists, scales = dists or {}, scales or {}
+    K, B, L = noise["shared"].shape
+    mus = torch.stack([enc[m][0] for m in names] + [torch.zeros_like(enc[names[0]][0])])
+    lvs = torch.stack([enc[m][1] for m in names] + [torch.zeros_like(enc[names[0]][1])])
+    mu, lv = stable_poe(mus, lvs)
+    sigma = torch.exp(0.5 * lv)
+    z_joint = mu + sigma * noise["shared"]  # [K,B,L]
+    ln_prior, ln_posterior = 0, 0
+    lls = []
+    for i in range(B):
+        lnpxs = []
+        start = 0
+        while start < K:
+            stop = min(start + batch_size_K, K)
+            shared = z_joint[start:stop, i]
+            lpx = 0
+            for m in names:
+                mu_p, sd_p = enc[m][2][i], torch.exp(0.5 * enc[m][3][i])
+                priv = mu_p + sd_p * noise["private"][m][start:stop, i]
+                recon = decoders[m](torch.cat([shared, priv], dim=-1))
+                lp = recon_log_prob(dists.get(m, "normal"), recon, torch.stack([data[m][i]] * len(recon)), scales.get(m, 1.0))
+                lpx = lpx + lp.reshape(recon.size(0), -1).sum(-1)
+                ln_prior = ln_prior + latent_log_prob("normal", priv, torch.zeros(()), torch.ones(())).sum(-1)
+                ln_posterior = ln_posterior + latent_log_prob("normal", priv, mu_p, sd_p).sum(-1)
+            ln_prior = ln_prior + latent_log_prob("normal", shared, torch.zeros(()), torch.ones(())).sum(-1)
+            ln_posterior = ln_posterior + latent_log_prob("normal", shared, mu[i], sigma[i]).sum(-1)
+            lnpxs.append(torch.logsumexp(lpx + ln_prior - ln_posterior, dim=0))
+            start = stop
+        lls.append(torch.logsumexp(torch.Tensor([float(v) for v in lnpxs]), dim=0) - math.log(K))
+    ll = torch.stack(lls)
+    return -ll.sum(), ll

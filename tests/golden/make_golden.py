@@ -1096,6 +1096,53 @@ def dmvae_case(name, *, B, beta, S, rescaling, masked, seed, private_betas=None,
                     rescaling=rescaling, masked=masked, seed=seed, names=names, dists=dists), arrays)
 
 
+def nll_dmvae_case(name, *, B, K, batch_size_K, S, seed, dists=None):
+    """DMVAE.compute_joint_nll of the reference (dmvae_model.py:311-412), running prior / posterior sums included."""
+    print(name)
+    dims, L = TINY_DIMS, TINY_L
+    data, _ = tiny_data(B, seed, False)
+    for m, d in (dists or {}).items():
+        if d == "bernoulli":
+            data[m] = (data[m] > 0.5).astype(np.float32)
+    sdims = {m: S + i for i, m in enumerate(dims)}
+    cfg = DMVAEConfig(n_modalities=4, latent_dim=L, input_dims=dict(dims), modalities_specific_dim=sdims,
+                      decoders_dist=dists)
+    model = DMVAE(cfg)
+    sd_np = P.make_state_dict(P.mopoe_style_mlp_shapes(dims, L, sdims), seed)
+    load_weights(model, sd_np)
+    names = list(model.encoders.keys())
+    inputs = ref_dataset(data, None)
+    # noise replay: rsample([K]) of the shared latent first, then per data point, per chunk, per modality one
+    # rsample([chunk]) of the private latent (:340, :366-372)
+    torch.manual_seed(seed)
+    noise = {"shared": torch.randn(K, B, L), "private": {m: torch.zeros(K, B, sdims[m]) for m in names}}
+    for i in range(B):
+        for c0 in range(0, K, batch_size_K):
+            for m in names:
+                noise["private"][m][c0:c0 + batch_size_K, i] = torch.randn(min(batch_size_K, K - c0), sdims[m])
+    torch.manual_seed(seed)
+    nll = model.compute_joint_nll(inputs, K=K, batch_size_K=batch_size_K)
+    osd = oracle_sd(sd_np, requires_grad=False)
+    enc_f, dec_f = nets.build_default_mlp_multilatent(osd, dims)
+    tdata = {m: t(v) for m, v in data.items()}
+    with torch.no_grad():
+        e_ = {m: enc_f[m](tdata[m]) for m in names}
+        on, oll = elbo.dmvae_joint_nll(e_, tdata, dec_f, noise, names=names, batch_size_K=batch_size_K, dists=dists)
+    report("nll", nll, on)
+    arrays = dict(nll=torch.as_tensor(nll).detach(), ll=oll)
+    arrays["noise/shared"] = noise["shared"]
+    for m in names:
+        arrays["noise/private/" + m] = noise["private"][m]
+    save(name, dict(model="DMVAE", arch="tiny", B=B, L=L, K=K, batch_size_K=batch_size_K, style_dims=sdims, seed=seed,
+                    names=names, dists=dists, masked=False, rescaling=False, beta=1.0, private_betas=None), arrays)
+
+
+def nll_dmvae_main():
+    nll_dmvae_case("nll_dmvae_tiny", B=5, K=12, batch_size_K=4, S=2, seed=1201)
+    nll_dmvae_case("nll_dmvae_tiny_one_chunk", B=4, K=6, batch_size_K=100, S=3, seed=1202,
+                   dists=dict(mod1="normal", mod2="laplace", mod3="bernoulli", mod4="normal"))
+
+
 def dmvae_main():
     dmvae_case("dmvae_tiny_complete", B=6, beta=1.0, S=2, rescaling=False, masked=False, seed=1101)
     dmvae_case("dmvae_tiny_betas_rescale", B=5, beta=2.5, S=3, rescaling=True, masked=False, seed=1102,
@@ -1418,6 +1465,8 @@ if __name__ == "__main__":
         cond_nll_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "dmvae":
         dmvae_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "nll_dmvae":
+        nll_dmvae_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "crmvae":
         crmvae_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "categorical":
@@ -1435,4 +1484,5 @@ if __name__ == "__main__":
         mopoe_style_main()
         crmvae_main()
         dmvae_main()
+        nll_dmvae_main()
         cond_nll_main()

@@ -37,6 +37,7 @@ DMVAE_CASES = ["dmvae_tiny_complete", "dmvae_tiny_betas_rescale", "dmvae_tiny_ma
 NLL_STYLE_CASES = ["nll_mopoe_tiny_style"]
 COND_NLL_CASES = ["cnll_mopoe_tiny", "cnll_mvtcae_tiny", "cnll_jmvae_tiny", "cnll_mvae_tiny"]
 NLL_PAPER_CASES = ["nll_mmvae_paper_normal", "nll_mmvae_paper_laplace"]
+NLL_DMVAE_CASES = ["nll_dmvae_tiny", "nll_dmvae_tiny_one_chunk"]
 NLL_MMVAEPLUS_CASES = ["nll_mmvaeplus_tiny_laplace", "nll_mmvaeplus_tiny_softplus"]
 
 

@@ -693,3 +693,17 @@ def test_joint_nll_paper_mmvae_golden(name):
     nll = model.compute_joint_nll_paper(inputs, K=cfg["nll_K"], batch_size_K=cfg["batch_size_K"], noise=noise)
     assert nll.size() == torch.Size([]) and nll >= 0  # tests/test_mmvae_model.py:443-446
     check(a["nll"], nll, "nll (paper)")
+
+
+@pytest.mark.parametrize("name", G.NLL_DMVAE_CASES)
+def test_dmvae_joint_nll_golden(name):
+    """DMVAE.compute_joint_nll on the HIP path (K as a kernel axis; the reference's never-reset prior / posterior sums as
+    one cumulative sum over the (data point, chunk) sequence) against the reference's number."""
+    cfg, a, dims, data, masks, sd_np, model, inputs, d = prep(name)
+    names = cfg["names"]
+    noise = {"shared": G.t(a["noise/shared"]).to(d), "private": {m: G.t(a["noise/private/" + m]).to(d) for m in names}}
+    nll = model.compute_joint_nll(inputs, K=cfg["K"], batch_size_K=cfg["batch_size_K"], noise=noise)
+    check(a["nll"], nll, "nll")
+    assert np.isfinite(float(model.compute_joint_nll(inputs, K=8, batch_size_K=4)))  # fresh noise
+    with pytest.raises(RuntimeError):
+        model.compute_joint_nll(inputs, K=10, batch_size_K=4)

@@ -446,3 +446,22 @@ def test_numpy_conv_pins_match_torch():
     close(nets.conv_transpose2d_np(x, wt, bt, 2, 1), F.conv_transpose2d(x, wt, bt, 2, 1), rtol=1e-5, atol=1e-5)
     z = torch.randn(4, 3, 1, 1, generator=g)
     close(nets.conv_transpose2d_np(z, wt, bt, 1, 0), F.conv_transpose2d(z, wt, bt, 1, 0), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", G.NLL_DMVAE_CASES)
+def test_dmvae_joint_nll(name):
+    """DMVAE.compute_joint_nll of the reference (dmvae_model.py:311-412): its running ln_prior / ln_posterior sums over the
+    K-chunks and the data points are part of the number."""
+    cfg, a = G.load_case(name)
+    dims, data, _, sd_np = G.build_inputs(cfg)
+    sd = {k: G.t(v) for k, v in sd_np.items()}
+    enc_f, dec_f = nets.build_default_mlp_multilatent(sd, dims)
+    names = cfg["names"]
+    tdata = {m: G.t(v) for m, v in data.items()}
+    noise = {"shared": G.t(a["noise/shared"]), "private": {m: G.t(a["noise/private/" + m]) for m in names}}
+    with torch.no_grad():
+        e = {m: enc_f[m](tdata[m]) for m in names}
+        nll, ll = elbo.dmvae_joint_nll(e, tdata, dec_f, noise, names=names, batch_size_K=cfg["batch_size_K"],
+                                       dists=cfg.get("dists"))
+    close(a["nll"], nll)
+    close(a["ll"], ll)
