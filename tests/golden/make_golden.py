@@ -220,23 +220,26 @@ def mopoe_case(name, *, arch, B, beta, rescaling, masked, seed, K=1, dists=None)
     eps = torch.randn(B, L) if K == 1 else torch.randn(K, B, L)
     # --- reference run
     torch.manual_seed(seed)
+    ref_z, ref_rows = None, {}
     if K == 1:
         out = model(inputs)
         loss, metrics = out.loss, out.metrics
-        with torch.no_grad():
-            lat = {k: v for k, v in model.inference(inputs).items() if k in ("mus", "logvars", "weights")} \
-                if not masked else None
+        with torch.no_grad():  # the reference's own intermediates: same seed -> same subset draw for incomplete data
+            torch.manual_seed(seed)
+            lat = model.inference(inputs)
     else:
         # K-sample Monte-Carlo extension assembled from the reference's own pieces:
         # inference + rsample_from_gaussian(N=K) + decoders + recon_log_probs + calc_joint_divergence.
         lat = model.inference(inputs)
         z = ref_utils.rsample_from_gaussian(lat["joint"][0], lat["joint"][1], N=K)
+        ref_z = z.detach()
         kld = model.calc_joint_divergence(lat["mus"], lat["logvars"], lat["weights"])["joint_divergence"]
         metrics = {"joint_divergence": kld}
         loss = 0
         for m in names:
             recon = model.decoders[m](z).reconstruction
             lp = model.recon_log_probs[m](recon, inputs.data[m]) * model.rescale_factors[m]
+            ref_rows[m] = (-lp).reshape(K, B, -1).sum(-1).detach()
             r = (-lp).reshape(K, B, -1).sum(-1).mean(0)
             metrics["recon_" + m] = r.mean()
             loss = loss + metrics["recon_" + m]
@@ -264,15 +267,32 @@ def mopoe_case(name, *, arch, B, beta, rescaling, masked, seed, K=1, dists=None)
     arrays = dict(eps=eps, loss=loss.detach(), loss_sum=(loss * B).detach(),
                   mus=o["mus"].detach(), logvars=o["logvars"].detach(), weights=o["weights"],
                   joint_mu=o["joint_mu"].detach(), joint_logvar=o["joint_logvar"].detach(), z=o["z"].detach())
-    if K == 1 and not masked:
-        assert torch.allclose(lat["mus"], o["mus"], atol=1e-6) and torch.allclose(lat["logvars"], o["logvars"], atol=1e-6)
-        arrays["mus"], arrays["logvars"] = lat["mus"], lat["logvars"]
+    # intermediates of the REFERENCE wherever it exposes them (inference(): subset and joint posterior parameters, subset
+    # weights; K > 1: the samples and the per-sample reconstruction rows); the oracle's only for what stays internal to
+    # the reference's forward (z and rows at K = 1)
+    def same(a_, b_, what):
+        fin = torch.isfinite(b_)
+        assert bool((fin | (a_ == b_)).all()) and torch.allclose(a_[fin], b_[fin], rtol=1e-6, atol=1e-6), what
+
+    same(lat["mus"].detach(), o["mus"].detach(), "mus")
+    same(lat["logvars"].detach(), o["logvars"].detach(), "logvars")
+    same(lat["joint"][0].detach(), o["joint_mu"].detach(), "joint mu")
+    same(lat["joint"][1].detach(), o["joint_logvar"].detach(), "joint logvar")
+    arrays["mus"], arrays["logvars"] = lat["mus"].detach(), lat["logvars"].detach()
+    arrays["joint_mu"], arrays["joint_logvar"] = lat["joint"][0].detach(), lat["joint"][1].detach()
+    arrays["weights"] = lat["weights"].detach()
+    if ref_z is not None:
+        same(ref_z, o["z"].detach(), "z")
+        arrays["z"] = ref_z
     if choice is not None:
         arrays["choice"] = choice
     for k, v in metrics.items():
         arrays["metric/" + k] = v.detach()
     for m in names:
         arrays["rows/" + m] = o["rows"][m].detach()
+        if m in ref_rows:
+            same(ref_rows[m], o["rows"][m].detach(), "rows " + m)
+            arrays["rows/" + m] = ref_rows[m]
     if masks is not None:
         for m, v in masks.items():
             arrays["mask/" + m] = v
@@ -454,8 +474,7 @@ def mmvae_case(name, *, arch, B, K, family, loss, rescaling, masked, seed, learn
                     masked=masked, seed=seed, names=names, learn_prior=learn_prior), arrays)
 
 
-def main():
-    unit_goldens()
+def mopoe_main():
     mopoe_case("mopoe_tiny_complete", arch="tiny", B=6, beta=1.0, rescaling=False, masked=False, seed=101)
     mopoe_case("mopoe_tiny_beta_rescale", arch="tiny", B=7, beta=2.5, rescaling=True, masked=False, seed=102,
                dists=dict(mod1="normal", mod2="laplace", mod3="bernoulli", mod4="normal"))
@@ -464,6 +483,11 @@ def main():
     mopoe_case("mopoe_mnistsvhn_k1", arch="mnistsvhn", B=16, beta=1.0, rescaling=False, masked=False, seed=104)
     mopoe_case("mopoe_mnistsvhn_k1_rescale", arch="mnistsvhn", B=5, beta=1.0, rescaling=True, masked=False, seed=105)
     mopoe_case("mopoe_mnistsvhn_k10", arch="mnistsvhn", B=8, beta=1.0, rescaling=False, masked=False, seed=106, K=10)
+
+
+def main():
+    unit_goldens()
+    mopoe_main()
     mvtcae_case("mvtcae_tiny_complete", arch="tiny", B=6, alpha=0.1, beta=2.5, rescaling=False, masked=False, seed=201)
     mvtcae_case("mvtcae_tiny_masked", arch="tiny", B=9, alpha=0.3, beta=1.0, rescaling=True, masked=True, seed=202)
     mvtcae_case("mvtcae_mnistsvhn_mlp", arch="mnistsvhn", B=8, alpha=0.1, beta=2.5, rescaling=False, masked=False, seed=203)
@@ -1471,6 +1495,8 @@ if __name__ == "__main__":
         crmvae_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "categorical":
         mopoe_categorical()
+    elif len(sys.argv) > 1 and sys.argv[1] == "mopoe":
+        mopoe_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "style":
         mopoe_style_main()
     else:

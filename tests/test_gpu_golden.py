@@ -1,6 +1,8 @@
 """Model-level parity on the GPU: multivae_amd.models.{MoPoE, MVTCAE, MMVAE} (HIP kernels behind the C ABI)
 against (a) the golden vectors generated from the real reference and (b) the CPU oracle evaluated on the same
 procedural inputs, weights and recorded noise.  Tolerance 1e-4 relative (BASELINE.json north_star)."""
+import re
+
 import numpy as np
 import pytest
 import torch
@@ -18,9 +20,22 @@ def rel(a, b):
     return float((a - b).abs().max() / a.abs().max().clamp_min(1e-30))
 
 
+ELEMENTWISE = re.compile(r"^(z\b|zs|z |kld|kl\b|joint|mus|logvars|mu\b|lv\b|lw\b|u |w |us|ws|lws|rows)")
+
+
 def check(a, b, what, rtol=RTOL):
     e = rel(a, b)
     assert e <= rtol, f"{what}: rel-to-max err {e:.3e} > {rtol}"
+    if ELEMENTWISE.match(what):  # latents, posterior parameters, KL rows, importance weights: entry by entry
+        ref = torch.as_tensor(np.asarray(a)).double().reshape(-1)
+        got = b.detach().double().cpu().reshape(-1)
+        fin = torch.isfinite(ref)
+        assert bool((fin | (got == ref)).all()), what
+        if bool(fin.any()):
+            tol = min(rtol, 1e-4) * ref[fin].abs() + 1e-6 * ref[fin].abs().max()
+            bad = (got[fin] - ref[fin]).abs() > tol
+            assert not bool(bad.any()), (f"{what}: {int(bad.sum())} of {bad.numel()} entries outside rtol 1e-4 + 1e-6 max; "
+                                         f"worst excess {float(((got[fin] - ref[fin]).abs() / tol).max()):.2f}x")
 
 
 def build_model(cfg, dims):

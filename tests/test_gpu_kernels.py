@@ -3,6 +3,7 @@ inputs.  Tolerance: 1e-4 relative (BASELINE.json north_star), measured against t
 reference tensor so that near-zero entries of a large tensor do not dominate; most kernels are far tighter.
 All tests need a real MI355X (`-m gpu`)."""
 import math
+import re
 
 import numpy as np
 import pytest
@@ -25,13 +26,35 @@ def g(seed):
     return torch.Generator().manual_seed(seed)
 
 
+ELEMENTWISE = re.compile(r"^(z\b|zs|kld|kl\b|joint|cond kl|subset|mu\b|lv\b|lw\b|u\b|w\b)")
+
+
+def close_elementwise(got, ref, what, rtol=1e-4, atol_frac=1e-6):
+    """|got - ref| <= rtol |ref| + atol_frac max|ref| for EVERY entry (latents, posterior parameters, KL rows, importance
+    weights): small entries of a tensor are checked on their own scale, not against the tensor's maximum.  Matching
+    infinities (log-variances of missing modalities) are equal."""
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    same_inf = torch.isinf(ref) & (got == ref)
+    fin = torch.isfinite(ref)
+    assert bool((fin | same_inf).all()) and bool(torch.isfinite(got[fin]).all()), what
+    if not bool(fin.any()):
+        return
+    tol = rtol * ref[fin].abs() + atol_frac * ref[fin].abs().max()
+    bad = (got[fin] - ref[fin]).abs() > tol
+    assert not bool(bad.any()), (f"{what}: {int(bad.sum())} of {bad.numel()} entries outside rtol {rtol} + "
+                                 f"{atol_frac} max; worst excess {float(((got[fin] - ref[fin]).abs() / tol).max()):.2f}x")
+
+
 def close(got, ref, rtol=RTOL, what=""):
     got = got.detach().double().cpu()
     ref = ref.detach().double().cpu()
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
-    scale = ref.abs().max().clamp_min(1e-30)
-    err = (got - ref).abs().max() / scale
-    assert torch.isfinite(got).all(), what
+    if ELEMENTWISE.match(what):
+        close_elementwise(got, ref, what, rtol=min(rtol, 1e-4))
+    fin = torch.isfinite(ref)
+    scale = ref[fin].abs().max().clamp_min(1e-30) if bool(fin.any()) else torch.tensor(1.0)
+    err = ((got - ref).abs()[fin].max() if bool(fin.any()) else torch.tensor(0.0)) / scale
+    assert torch.isfinite(got[fin]).all(), what
     assert float(err) <= rtol, f"{what}: rel-to-max err {float(err):.3e} > {rtol}"
     return float(err)
 
