@@ -279,15 +279,16 @@ class DeviceProfiler:
 
 
 def summarise(recs, kinds, boundary_s=0.0):
-    """Durations per launch = (first workgroup in -> next kernel's first instruction) - one kernel boundary."""
+    """Duration per launch = first workgroup in -> first instruction of the one-wave kernel queued behind it (what
+    rocprofv3's begin -> end of the dispatch shows, within ~1 %); `busy_avg_us` takes one calibrated kernel boundary off."""
     sel = [r for r in recs if r[0] in kinds]
     if not sel:
         return None
     n = sum(r[2] for r in sel)
     work, outer, inner = sum(r[1] * r[2] for r in sel), sum(r[3] for r in sel), sum(r[4] for r in sel)
-    dur = max(outer - n * boundary_s, inner)
-    return dict(launches=n, work=work, seconds=dur, avg_us=1e6 * dur / n, inner_avg_us=1e6 * inner / n,
-                outer_avg_us=1e6 * outer / n)
+    busy = max(outer - n * min(boundary_s, 2.5e-6), inner)
+    return dict(launches=n, work=work, seconds=outer, avg_us=1e6 * outer / n, inner_avg_us=1e6 * inner / n,
+                busy_avg_us=1e6 * busy / n)
 
 
 def main():
@@ -476,12 +477,14 @@ def main():
                 "traffic_source": "profiles/recon_nll_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
                 "algorithmic_bytes": nll["work"] / nll["launches"], "avg_launch_us": round(nll["avg_us"], 2),
                 "launches_timed": nll["launches"],
-                "first_in_last_out_us": round(nll["inner_avg_us"], 2), "retire_bracket_us": round(nll["outer_avg_us"], 2),
-                "kernel_boundary_us": round(1e6 * boundary, 2),
+                "first_in_last_out_us": round(nll["inner_avg_us"], 2),
+                "minus_kernel_boundary_us": round(nll["busy_avg_us"], 2), "kernel_boundary_us": round(1e6 * boundary, 2),
+                "frac_minus_kernel_boundary": round(nll["work"] / nll["launches"] / nll["busy_avg_us"] / 1e3 / HBM_PEAK_GBS, 4),
                 "method": "device timestamps (mvk_prof_enable, constant-rate clock): first workgroup in -> first "
-                          "instruction of the one-wave kernel queued behind the launch (its stores have drained), minus "
-                          "one dependent-kernel boundary calibrated in the same run; accumulated over `steps` replays of "
-                          "the instrumented step right after the timed region",
+                          "instruction of the one-wave kernel queued behind the launch (its stores have drained) = the "
+                          "begin -> end rocprofv3 reports for the dispatch (profiles/r02_kernel_stats.md); accumulated over "
+                          "`steps` replays of the instrumented step right after the timed region.  minus_kernel_boundary_us "
+                          "takes off one dependent-kernel boundary calibrated in the same run",
                 "instrumented_ms_per_step": round(ms_instr, 4),
                 "hip_event_pair_us": round(1e6 * sum(ev) / len(ev), 2) if ev else None}
         conv = summarise(recs, {"imgconv_up", "imgconv_down", "imgconv_wgrad"}, boundary)

@@ -231,7 +231,8 @@ int mvk_mmvae_objective_fwd(const float* const* rows, const float* const* lpz, c
 
 /* Latent-side backward.  dz_dec[c] [K,B,L]: gradient of the loss w.r.t. z[c] through the decoders (from
  * mvk_recon_nll_bwd with rowcoef = -w[c]/n_avail and the decoders' own backward).  Produces dmu[c], dstd[c]
- * [B,L] and dprior_std [L] (nullable).  DReG: q parameters are detached inside log q and the total gradient
+ * [B,L] and dprior_std [B,L] (nullable): the per-row terms of d loss / d prior_std, which the caller sums over the rows
+ * (mvk_colsum_acc: fixed order, bit-reproducible).  DReG: q parameters are detached inside log q and the total gradient
  * reaching z is scaled by w once more (the hook of mmvae_model.py:263-266). */
 int mvk_mmvae_latent_bwd(const float* const* mu, const float* const* std, const float* const* noise,
                          const float* const* z, const uint8_t* const* masks, const float* prior_mean,

@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const BwdPtrs p, const 
         p.dsd[m][o] = dsd[m];
       }
     }
-    if (dprior_sd) atomicAdd(dprior_sd + l, dps);
+    if (dprior_sd) dprior_sd[o] = dps;  // per-row term [B, L]: the caller sums the rows in a fixed order
   }
 }
 
@@ -587,9 +587,6 @@ int mvk_mmvae_latent_bwd(const float* const* mu, const float* const* sd, const f
     p.dsd[m] = dsd[m];
   }
   hipStream_t s = mvk_stream(stream);
-  if (dprior_sd) {
-    if (hipMemsetAsync(dprior_sd, 0, sizeof(float) * L, s) != hipSuccess) return MVK_ELAUNCH;
-  }
   hipLaunchKernelGGL(latent_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, s, p, prior_mean, prior_sd, M, K, B, L,
                      shared_dims, beta, family, dreg, gscale, dprior_sd);
   MVK_CHECK_LAUNCH();

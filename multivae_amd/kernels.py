@@ -1166,12 +1166,15 @@ class MMVAELatentFn(Function):
         dzs = [(_c(d) if d is not None else torch.zeros_like(st.z[i])) for i, d in enumerate(dzs)]
         dmus = [_new((B, L), mus[0]) for _ in range(M)]
         dsds = [_new((B, L), mus[0]) for _ in range(M)]
-        dprior = _new((L,), mus[0])
+        dprior_rows = _new((B, L), mus[0])  # per-row terms of d loss / d prior_std, summed below in a fixed order
         marr = ptr_array(ctx.masks) if ctx.masks is not None else None
         call("mvk_mmvae_latent_bwd", ptr_array(mus), ptr_array(sds), ptr_array(ctx.noises), ptr_array(st.z), marr,
              ptr(prior_mean), ptr(prior_std), ptr_array(st.w), ptr_array(st.lq_all), ptr_array(st.lqz),
              ptr_array(dzs), M, K, B, L, ctx.family, ctx.dreg, ptr(st.gloss), ptr_array(dmus), ptr_array(dsds),
-             ptr(dprior), L if st.shared_dims is None else int(st.shared_dims), float(st.beta), stream_ptr())
+             ptr(dprior_rows), L if st.shared_dims is None else int(st.shared_dims), float(st.beta), stream_ptr())
+        dprior = _zeros((L,), mus[0])
+        ws = _ws(dprior_rows)
+        call("mvk_colsum_acc", ptr(dprior_rows), None, NONE, ptr(dprior), B, L, ptr(ws), ws.numel(), stream_ptr())
         return (None, None, None, None, None, None, dprior.view(1, L), *dmus, *dsds)
 
 

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Runs ON the GPU box (via gpurun): every measurement behind profiles/r02_* in one call.
+#   bash tools/gpu_profile_r02.sh [TAG]      -> gpurun_out/<TAG>/...
+TAG=${1:-r02}; OUT=gpurun_out/$TAG
+export TMPDIR=/tmp; mkdir -p $OUT
+# 1. kernel trace of the default bench command (the JSON line of the same run beside it)
+rocprofv3 --kernel-trace --stats -d $OUT -o trace -- python bench.py --steps 20 --warmup 5 > $OUT/bench_under_rocprof.log 2>&1
+# 2. the unprofiled bench lines: headline + the other BASELINE configurations
+for c in cfg3 cfg3k1 cfg2 cfg5 cfg4; do
+  timeout 900 python bench.py --config $c --steps 20 --warmup 5 2> $OUT/bench_$c.err | tail -1 > $OUT/bench_$c.json
+done
+timeout 600 python bench.py --config cfg2 --family laplace_with_softmax --loss dreg_looser --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_cfg2_laplace_dreg.json
+timeout 900 python bench.py --config cfg4 --batch 128 --no-graph --steps 5 --warmup 2 --no-cpu-baseline 2> $OUT/bench_cfg4_b128_eager.err | grep '^{' | tail -1 > $OUT/bench_cfg4_b128_eager.json
+# 3. trainer loop throughput
+timeout 300 python tools/trainer_bench.py cfg3 5 2>/dev/null | tail -1 > $OUT/trainer_cfg3.json
+timeout 300 python tools/trainer_bench.py cfg1 4 2>/dev/null | tail -1 > $OUT/trainer_cfg1.json
+# 4. SQ / LDS counters of the convolution kernels (two passes, kernel-trace only)
+bash tools/imgconv_pmc.sh $OUT/pmc_conv new > $OUT/pmc_conv.txt 2>&1
+# 5. HBM traffic counters of the headline step (separate passes)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace -d $OUT/pmc_$c -o p -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline > $OUT/pmc_$c.log 2>&1
+  python tools/pmc_agg.py $OUT/pmc_$c/p_results.db | grep -E "n dur_us|recon_nll|small_up|imgconv|imgwgrad" > $OUT/pmc_$c.txt
+done
+# 6. the single-GPU RCCL path
+MVK_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $OUT/bench_force_dist.json
+ls -la $OUT | head -40
