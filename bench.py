@@ -343,8 +343,9 @@ def main():
         if draw is not None:
             kw["noise"] = draw(gen)
         opt.zero_grad()
-        out = model(inputs, **kw)
-        out.loss.backward()
+        with kernels.deferred_reductions(flat):
+            out = model(inputs, **kw)
+            out.loss.backward()
         if use_dist:
             flat.all_reduce()  # C2: ONE all-reduce of the flat gradient buffer
         opt.step(grad_scale=grad_scale)

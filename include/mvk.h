@@ -472,6 +472,24 @@ int mvk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, doubl
 int mvk_adam_step_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1,
                           double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream);
 
+/* Deferred leaf reductions.  Parameter gradients are leaves of the backward pass (reference: autograd accumulates them
+ * into `.grad`, nothing reads them before `optimizer.step()`, trainers/base/base_trainer.py:405-420), so the ordered
+ * finishes that complete them - split-K slabs of the weight-gradient GEMMs, per-workgroup column sums of the bias
+ * gradients, the slabs of the convolution weight-gradient kernels - need not run one launch each behind their producer.
+ * Between mvk_defer_begin and mvk_defer_end every entry point whose result ACCUMULATES into [grad, grad + grad_floats)
+ * (the flat gradient buffer of trainers.FlatParams) writes its partial results into a private region of `arena` instead
+ * of the caller's shared scratch and queues the finish; mvk_defer_flush(stream) orders `stream` behind every stream such a
+ * producer ran on and runs all queued finishes in ONE launch per 24 (same fixed summation order per element as the
+ * immediate kernels: results are bit-reproducible run to run).  A producer that does not fit (arena full, a second
+ * accumulation into the same parameter while one is queued, a target outside the gradient buffer) finishes immediately
+ * as without deferral.  The caller must flush before anything reads the gradient buffer (all-reduce, optimizer step) and
+ * must keep `arena` alive and unused by others until then.  mvk_defer_begin returns MVK_EINVAL while finishes are
+ * pending; mvk_defer_end = flush + off; mvk_defer_pending = number of queued finishes. */
+int mvk_defer_begin(float* arena, int64_t arena_floats, const float* grad, int64_t grad_floats);
+int mvk_defer_flush(void* stream);
+int mvk_defer_end(void* stream);
+int mvk_defer_pending(void);
+
 /* Device-timestamp profiler (bench.py's roofline objects).  device_slots: nslots records of MVK_PROF_SLOT_U64 = 520
  * uint64 each: [0] sum of durations (clock ticks, first workgroup in -> last workgroup out), [1] launches accumulated,
  * [2] sum of (first workgroup in -> start of the one-wave fold kernel queued behind the launch: the launch has drained

@@ -89,6 +89,9 @@ PROTOTYPES = {
     "mvk_nchw_to_nhwc": [_p, _p, _i, _i, _i, _i, _p],
     "mvk_nhwc_to_nchw": [_p, _p, _i, _i, _i, _i, _p],
     "mvk_adam_step": [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _d, _p],
+    "mvk_defer_begin": [_p, _i64, _p, _i64],
+    "mvk_defer_flush": [_p],
+    "mvk_defer_end": [_p],
     "mvk_adam_step_amsgrad": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _d, _p],
     "mvk_mmvae_std_fwd": [_p, _i, _i, _i, _p, _p],
     "mvk_mmvae_std_bwd": [_p, _p, _p, _i, _i, _i, _p, _p],
@@ -135,6 +138,8 @@ def load(path=None):
         fn.restype = C.c_int
     lib.mvk_conv4s2_small_up_supported.argtypes = [_i, _i, _i, _i]
     lib.mvk_conv4s2_small_up_supported.restype = C.c_int
+    lib.mvk_defer_pending.argtypes = []
+    lib.mvk_defer_pending.restype = C.c_int
     lib.mvk_prof_enable.argtypes = [_p, _i, _p, _p]
     lib.mvk_prof_enable.restype = C.c_int
     lib.mvk_prof_calibrate.argtypes = [_p, _i, _p]

@@ -44,6 +44,21 @@ __device__ __forceinline__ float mvk_act_grad_from_out(float y, int act) {
 __device__ __forceinline__ bool mvk_dev_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline bool mvk_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// ---- deferred leaf reductions (mvk_defer_begin, mvk.h; implemented in igemm.hip) ---------------------------------------
+// Parameter gradients are leaves of the backward pass: nobody reads them before the optimizer.  While deferral is on, a
+// producer whose result accumulates into the registered gradient buffer writes its partial results (split-K slabs,
+// per-workgroup column sums, weight-gradient slabs) into a private region of the caller's arena instead of the shared
+// scratch and queues the ordered finish; mvk_defer_flush runs every queued finish in one launch.
+namespace mvk {
+// arena region of `floats` floats for a producer whose finish targets `out` on stream `s`; nullptr = not deferred
+// (deferral off, `out` outside the gradient buffer, another queued finish targets `out`, arena full): finish immediately
+float* defer_scratch(const void* out, long long floats, hipStream_t s);
+// true when `out` is null, or could be the target of a queued finish right now (no scratch is taken)
+bool defer_free(const void* out);
+// queue out[i] += sum_{z < nz} part[z * zstride + i], i < count (z in a fixed order); part from defer_scratch
+int defer_push_plain(float* out, const float* part, long long count, int nz, long long zstride, hipStream_t s);
+}  // namespace mvk
+
 // ---- device-timestamp profiler (mvk_prof_enable, mvk.h) --------------------------------------------------------------
 // An instrumented launch takes the next record of the caller's device array; thread 0 of every workgroup stamps the
 // constant-rate clock (s_memrealtime) on entry (min) and exit (max) into one of 32 entries of the record (64 bytes apart:

@@ -1,5 +1,152 @@
 // C-ABI entry points built on the fp32 MFMA implicit-GEMM engine (igemm.hpp).
 #include "igemm_bf.hpp"
+#include <mutex>
+#include <vector>
+
+// ---- deferred leaf reductions ------------------------------------------------------------------------------------------
+namespace mvk {
+namespace {
+struct DeferState {
+  std::mutex mu;
+  bool active = false;
+  float* arena = nullptr;
+  long long cap = 0, used = 0;
+  const char* g0 = nullptr;
+  const char* g1 = nullptr;
+  std::vector<DeferItem> items;
+  std::vector<hipStream_t> streams;  // every stream a gradient producer ran on since the last flush
+  std::vector<hipEvent_t> events;
+};
+DeferState g_defer;
+
+void defer_note_stream(hipStream_t s) {
+  for (hipStream_t t : g_defer.streams)
+    if (t == s) return;
+  g_defer.streams.push_back(s);
+}
+}  // namespace
+
+float* defer_scratch(const void* out, long long floats, hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_defer.mu);
+  const char* o = static_cast<const char*>(out);
+  if (!g_defer.active || !out || o < g_defer.g0 || o >= g_defer.g1 || floats <= 0) return nullptr;
+  defer_note_stream(s);  // also when declined: the flush orders itself behind every producer of the gradient buffer
+  for (const DeferItem& it : g_defer.items)
+    if (it.e.out == out) return nullptr;
+  const long long need = (floats + 63) & ~63LL;  // 256-byte aligned regions
+  if (g_defer.used + need > g_defer.cap) return nullptr;
+  float* p = g_defer.arena + g_defer.used;
+  g_defer.used += need;
+  return p;
+}
+
+bool defer_free(const void* out) {
+  if (!out) return true;
+  std::lock_guard<std::mutex> lock(g_defer.mu);
+  const char* o = static_cast<const char*>(out);
+  if (!g_defer.active || o < g_defer.g0 || o >= g_defer.g1) return false;
+  for (const DeferItem& it : g_defer.items)
+    if (it.e.out == out) return false;
+  return true;
+}
+
+static int defer_push(const Epilogue& e, int M, int N, int nz, long long zstride) {
+  std::lock_guard<std::mutex> lock(g_defer.mu);
+  DeferItem it{};
+  it.e = e;
+  it.M = M;
+  it.N = N;
+  it.nz = nz;
+  it.zstride = zstride;
+  it.vec4 = ((long long)M * N) % 4 == 0 && zstride % 4 == 0 && mvk_aligned16(e.ws);
+  it.zl_bits = nz > 64 ? 5 : 3;
+  g_defer.items.push_back(it);
+  return MVK_OK;
+}
+
+int defer_push_plain(float* out, const float* part, long long count, int nz, long long zstride, hipStream_t) {
+  if (count > 0x7fffffffLL) return MVK_EINVAL;
+  Epilogue e{};
+  e.out = out;
+  e.kind = E_ROWMAJOR;
+  e.ld = count;
+  e.bias_mod = 1;
+  e.atomic = 1;
+  e.Cu = e.OH = e.OW = 1;
+  e.ws = const_cast<float*>(part);
+  return defer_push(e, 1, (int)count, nz, zstride);
+}
+}  // namespace mvk
+
+extern "C" int mvk_defer_begin(float* arena, int64_t arena_floats, const float* grad, int64_t grad_floats) {
+  using namespace mvk;
+  std::lock_guard<std::mutex> lock(g_defer.mu);
+  if (!g_defer.items.empty()) return MVK_EINVAL;  // pending finishes: flush first
+  if (!arena || arena_floats <= 0 || !grad || grad_floats <= 0 || !mvk_aligned16(arena)) return MVK_EINVAL;
+  g_defer.active = true;
+  g_defer.arena = arena;
+  g_defer.cap = arena_floats;
+  g_defer.used = 0;
+  g_defer.g0 = reinterpret_cast<const char*>(grad);
+  g_defer.g1 = g_defer.g0 + sizeof(float) * (size_t)grad_floats;
+  g_defer.streams.clear();
+  return MVK_OK;
+}
+
+extern "C" int mvk_defer_flush(void* stream) {
+  using namespace mvk;
+  hipStream_t s = mvk_stream(stream);
+  std::lock_guard<std::mutex> lock(g_defer.mu);
+  if (!g_defer.active) return MVK_OK;
+  // order this stream behind every stream a gradient producer ran on (autograd replays a branch's backward on the
+  // stream of its forward)
+  size_t ev = 0;
+  for (hipStream_t t : g_defer.streams) {
+    if (t == s) continue;
+    if (ev == g_defer.events.size()) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return MVK_ELAUNCH;
+      g_defer.events.push_back(e);
+    }
+    if (hipEventRecord(g_defer.events[ev], t) != hipSuccess) return MVK_ELAUNCH;
+    if (hipStreamWaitEvent(s, g_defer.events[ev], 0) != hipSuccess) return MVK_ELAUNCH;
+    ++ev;
+  }
+  g_defer.streams.clear();
+  for (size_t i0 = 0; i0 < g_defer.items.size(); i0 += DEFER_BATCH) {
+    DeferTable T{};
+    unsigned blocks = 0;
+    for (size_t i = i0; i < g_defer.items.size() && i < i0 + DEFER_BATCH; ++i) {
+      DeferItem& it = T.it[T.n++];
+      it = g_defer.items[i];
+      it.blk0 = blocks;
+      const int per = (256 >> it.zl_bits) * (it.vec4 ? 4 : 1);
+      blocks += (unsigned)(((long long)it.M * it.N + per - 1) / per);
+    }
+    hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3(blocks), dim3(256), 0, s, T);
+    if (hipGetLastError() != hipSuccess) {
+      g_defer.items.clear();
+      g_defer.used = 0;
+      return MVK_ELAUNCH;
+    }
+  }
+  g_defer.items.clear();
+  g_defer.used = 0;
+  return MVK_OK;
+}
+
+extern "C" int mvk_defer_end(void* stream) {
+  const int rc = mvk_defer_flush(stream);
+  std::lock_guard<std::mutex> lock(mvk::g_defer.mu);
+  mvk::g_defer.active = false;
+  return rc;
+}
+
+extern "C" int mvk_defer_pending(void) {
+  std::lock_guard<std::mutex> lock(mvk::g_defer.mu);
+  return (int)mvk::g_defer.items.size();
+}
+
 #include <cstdlib>
 
 namespace mvk {
@@ -214,6 +361,14 @@ int launch_splitk(GemmDesc& d, float* ws, long long ws_floats, int target_blocks
   d.ksplit_tiles += d.ksplit_tiles & 1;  // 32-element aligned slices (BKT = 32 kernels)
   int z = (ktiles + d.ksplit_tiles - 1) / d.ksplit_tiles;
   const long long need = (long long)z * d.M * d.N;
+  if (z > 1 && d.e.atomic && d.e.kind != E_UP && d.e.kind != E_UP_NCHW) {
+    // a gradient accumulated into the registered buffer: private slabs, the ordered finish is queued (mvk_defer_flush)
+    if (float* dws = defer_scratch(d.e.out, need, s)) {
+      d.e.ws = dws;
+      const int rc = launch_igemm(d, z, s);
+      return rc ? rc : defer_push(d.e, d.M, d.N, z, (long long)d.M * d.N);
+    }
+  }
   if (z > 1 && ws && ws_floats >= need && d.e.kind != E_UP && d.e.kind != E_UP_NCHW) {
     d.e.ws = ws;
     int rc = launch_igemm(d, z, s);
@@ -377,12 +532,14 @@ static int colsum(const float* dY, const float* Y, int act, int M, int N, float*
   int rows_per_block = (M + 255) / 256;
   if (rows_per_block < 16) rows_per_block = 16;
   const int gy = (M + rows_per_block - 1) / rows_per_block;
-  float* part = (ws && (long long)gy * N <= ws_floats) ? ws : nullptr;
+  float* dpart = defer_scratch(db, (long long)gy * N, s);
+  float* part = dpart ? dpart : ((ws && (long long)gy * N <= ws_floats) ? ws : nullptr);
   if (vec)
     hipLaunchKernelGGL((colsum_kernel<4>), dim3(gx, gy), dim3(256), 0, s, dY, Y, act, M, N, rows_per_block, db, part);
   else
     hipLaunchKernelGGL((colsum_kernel<1>), dim3(gx, gy), dim3(256), 0, s, dY, Y, act, M, N, rows_per_block, db, part);
   MVK_CHECK_LAUNCH();
+  if (dpart) return defer_push_plain(db, dpart, N, gy, N, s);
   return part ? colsum_finish_any(part, gy, N, db, s) : MVK_OK;
 }
 
@@ -440,7 +597,7 @@ static int colsum_finish_any(const float* part, int rows, int N, float* db, hipS
   return MVK_OK;
 }
 
-int convref_reduce(const float* slab, int nz, int Cu, int Cv, int taps, float* dWref, hipStream_t s) {
+int convref_reduce(const float* slab, int nz, int Cu, int Cv, int taps, float* dWref, hipStream_t s, bool deferred) {
   Epilogue e{};
   e.out = dWref;
   e.kind = E_CONVREF;
@@ -451,6 +608,7 @@ int convref_reduce(const float* slab, int nz, int Cu, int Cv, int taps, float* d
   e.OH = e.OW = 1;
   e.ws = const_cast<float*>(slab);
   const int M = taps * Cu;
+  if (deferred) return defer_push(e, M, Cv, nz, (long long)M * Cv);  // slab from defer_scratch(dWref, ...)
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((M * Cv + 31) / 32), dim3(256), 0, s, e, M, Cv, nz);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
@@ -500,13 +658,18 @@ static int launch_with_colsum(GemmDesc& d, int zdim, float* db, float* ws, int64
                               long long out_rows, hipStream_t s) {
   if (!db) return launch_igemm(d, zdim, s);
   const long long max_rows = (long long)((d.M + 63) / 64) * zdim;
-  const bool fuse = ws && mvk_aligned16(ws) && epilogue_vec_ok(d.e, d.N) && max_rows * d.N <= ws_floats;
+  float* dpart = epilogue_vec_ok(d.e, d.N) ? defer_scratch(db, max_rows * d.N, s) : nullptr;
+  float* cws = dpart ? dpart : ws;
+  const bool fuse = cws && mvk_aligned16(cws) && epilogue_vec_ok(d.e, d.N) && (dpart || max_rows * d.N <= ws_floats);
   LaunchInfo info{};
-  d.e.colsum_part = fuse ? ws : nullptr;
+  d.e.colsum_part = fuse ? cws : nullptr;
   int rc = launch_igemm(d, zdim, s, &info);
   d.e.colsum_part = nullptr;
   if (rc != MVK_OK) return rc;
-  if (fuse && info.bm > 0) return colsum_finish(ws, ((d.M + info.bm - 1) / info.bm) * zdim, d.N, db, s);
+  if (fuse && info.bm > 0) {
+    const int rows = ((d.M + info.bm - 1) / info.bm) * zdim;
+    return dpart ? defer_push_plain(db, dpart, d.N, rows, d.N, s) : colsum_finish(cws, rows, d.N, db, s);
+  }
   return colsum(out, nullptr, 0, (int)out_rows, d.N, db, ws, ws_floats, s);
 }
 
@@ -631,8 +794,10 @@ int mvk_act_bwd_colsum(const float* dY, const float* Y, int act, int M, int N, f
     MVK_CHECK_LAUNCH();
     return db ? colsum(dPre, nullptr, 0, M, N, db, ws, ws_floats, s) : MVK_OK;
   }
-  hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3(blocks), dim3(256), 0, s, dY, Y, act, M, N, rpb, dPre, ws);
+  float* dpart = db ? defer_scratch(db, (long long)blocks * N, s) : nullptr;
+  hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3(blocks), dim3(256), 0, s, dY, Y, act, M, N, rpb, dPre, dpart ? dpart : ws);
   MVK_CHECK_LAUNCH();
+  if (dpart) return defer_push_plain(db, dpart, N, blocks, N, s);
   return db ? colsum_finish(ws, blocks, N, db, s) : MVK_OK;
 }
 
@@ -648,10 +813,12 @@ int mvk_nchw_channel_sum_acc(const float* dY, const float* y_out, int y_act, flo
   if (n == 0) return MVK_OK;
   int ipb = 16;
   const int gy = (n + ipb - 1) / ipb;
-  float* part = (ws && (long long)gy * c <= ws_floats) ? ws : nullptr;
+  float* dpart = defer_scratch(db, (long long)gy * c, mvk_stream(stream));
+  float* part = dpart ? dpart : ((ws && (long long)gy * c <= ws_floats) ? ws : nullptr);
   hipLaunchKernelGGL(nchw_channel_sum_kernel, dim3(c, gy), dim3(256), 0, mvk_stream(stream), dY, y_out, y_act, n, c, hw,
                      ipb, db, part);
   MVK_CHECK_LAUNCH();
+  if (dpart) return defer_push_plain(db, dpart, c, gy, c, mvk_stream(stream));
   return part ? colsum_finish_any(part, gy, c, db, mvk_stream(stream)) : MVK_OK;
 }
 
@@ -700,8 +867,11 @@ int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, floa
   if (!u_nchw && !u_act_src && fmt == 0 && n >= imgconv_min_images() && imgconv_act_ok(act) &&
       imgconv_act_ok(v_act) && (!colsum_acc || (ws && ws_floats >= 256 * (int64_t)Cv)) && mvk_aligned16(U)) {
     int rows = 0;
-    const int rc = imgconv_down(U, Wdown, wfrag, bias, V, n, h, w, Cu, Cv, act, v_act_src, v_act, colsum_acc ? ws : nullptr,
+    float* dpart = colsum_acc ? defer_scratch(colsum_acc, 256 * (long long)Cv, mvk_stream(stream)) : nullptr;
+    float* cpart = dpart ? dpart : ws;
+    const int rc = imgconv_down(U, Wdown, wfrag, bias, V, n, h, w, Cu, Cv, act, v_act_src, v_act, colsum_acc ? cpart : nullptr,
                                 &rows, mvk_stream(stream));
+    if (rc == MVK_OK && dpart) return defer_push_plain(colsum_acc, dpart, Cv, rows, Cv, mvk_stream(stream));
     if (rc == MVK_OK && colsum_acc) return colsum_finish(ws, rows, Cv, colsum_acc, mvk_stream(stream));
     if (rc != 1) return rc;
   }
@@ -743,8 +913,11 @@ int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U
   if (!u_nchw && fmt == 0 && n >= imgconv_min_images() && imgconv_act_ok(act) && imgconv_act_ok(u_act) &&
       (!colsum_acc || (ws && ws_floats >= 256 * (int64_t)Cu)) && mvk_aligned16(V)) {
     int rows = 0;
-    const int rc = imgconv_up(V, Wup, wfrag, bias, U, n, h, w, Cu, Cv, act, u_act_src, u_act, colsum_acc ? ws : nullptr, &rows,
-                              mvk_stream(stream));
+    float* dpart = colsum_acc ? defer_scratch(colsum_acc, 256 * (long long)Cu, mvk_stream(stream)) : nullptr;
+    float* cpart = dpart ? dpart : ws;
+    const int rc = imgconv_up(V, Wup, wfrag, bias, U, n, h, w, Cu, Cv, act, u_act_src, u_act, colsum_acc ? cpart : nullptr,
+                              &rows, mvk_stream(stream));
+    if (rc == MVK_OK && dpart) return defer_push_plain(colsum_acc, dpart, Cu, rows, Cu, mvk_stream(stream));
     if (rc == MVK_OK && colsum_acc) return colsum_finish(ws, rows, Cu, colsum_acc, mvk_stream(stream));
     if (rc != 1) return rc;
   }
@@ -861,8 +1034,11 @@ int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h
   if (!u_nchw && !u_act_src && ws && n / 4 >= imgconv_min_images() && mvk_aligned16(U) && mvk_aligned16(V) &&
       mvk_aligned16(ws)) {
     int nz = 0;
-    const int rc = imgconv_wgrad(U, V, ws, ws_floats, n, h, w, Cu, Cv, &nz, mvk_stream(stream));
-    if (rc == MVK_OK) return convref_reduce(ws, nz, Cu, Cv, 16, dWref, mvk_stream(stream));
+    const long long slab_floats = 256ll * 16 * Cu * Cv;
+    float* dslab = defer_scratch(dWref, slab_floats, mvk_stream(stream));
+    const int rc = imgconv_wgrad(U, V, dslab ? dslab : ws, dslab ? slab_floats : ws_floats, n, h, w, Cu, Cv, &nz,
+                                 mvk_stream(stream));
+    if (rc == MVK_OK) return convref_reduce(dslab ? dslab : ws, nz, Cu, Cv, 16, dWref, mvk_stream(stream), dslab != nullptr);
     if (rc != 1) return rc;
   }
   GemmDesc d{};

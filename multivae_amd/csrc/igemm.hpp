@@ -806,24 +806,10 @@ __global__ __launch_bounds__(256, MVK_MIN_WAVES) void igemm_kernel(const GemmDes
   run_epilogue<T>(d, acc, lds, tid, m0, n0, wm, wn, l31, lhi, ph, pw);
 }
 
-// out[map(m,n)] (+)= epilogue(sum_z ws[z][m][n]) — deterministic split-K finish.
+// out[map(m,n)] (+)= epilogue(sum_z ws[z * zstride + m*N + n]) — deterministic split-K finish.
 // A workgroup owns 32 consecutive (m,n) elements; its 8 z-lanes each sum every 8th slab (128-byte coalesced
 // loads), then the 8 partials are combined in a fixed order through LDS.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const Epilogue E, int M, int N, int nz) {
-  const int e = threadIdx.x & 31;
-  const int zl = threadIdx.x >> 5;
-  const long long total = (long long)M * N;
-  const long long idx = (long long)blockIdx.x * 32 + e;
-  float v = 0.f;
-  if (idx < total) {
-#pragma unroll 4
-    for (int z = zl; z < nz; z += 8) v += E.ws[(long long)z * total + idx];
-  }
-  __shared__ float red[8][33];
-  red[zl][e] = v;
-  __syncthreads();
-  if (zl != 0 || idx >= total) return;
-  v = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
+__device__ __forceinline__ void splitk_store(const Epilogue& E, int N, long long idx, float v) {
   const int m = (int)(idx / N);
   const int n = (int)(idx - (long long)m * N);
   long long off;
@@ -847,6 +833,102 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const Epilogue E, in
     E.out[off] = v;
 }
 
+__device__ __forceinline__ void splitk_reduce_body(const Epilogue& E, int M, int N, int nz, long long zstride,
+                                                   unsigned block, float (*red)[33]) {
+  const int e = threadIdx.x & 31;
+  const int zl = threadIdx.x >> 5;
+  const long long total = (long long)M * N;
+  const long long idx = (long long)block * 32 + e;
+  float v = 0.f;
+  if (idx < total) {
+#pragma unroll 4
+    for (int z = zl; z < nz; z += 8) v += E.ws[(long long)z * zstride + idx];
+  }
+  red[zl][e] = v;
+  __syncthreads();
+  if (zl != 0 || idx >= total) return;
+  v = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
+  splitk_store(E, N, idx, v);
+}
+
+// The batched finish (mvk_defer_flush): V = 4 floats per thread with 16-byte loads when total and zstride are multiples
+// of 4 and the slabs 16-byte aligned; ZL = 8 or 32 z-lanes (32 for long reductions: a thread's serial chain is nz / ZL
+// loads).  A workgroup owns (256 / ZL) * V consecutive elements; per element the additions run in a fixed order: every
+// z-lane over its slabs z = zl, zl + ZL, ..., then the lanes in groups of 8 as a balanced tree, then the groups in order.
+template <int V>
+__device__ __forceinline__ void splitk_reduce_bodyv(const Epilogue& E, int M, int N, int nz, long long zstride,
+                                                    unsigned block, int zl_bits, float* red /* [ZL][EL*V + 1] */) {
+  const int ZL = 1 << zl_bits, EL = 256 >> zl_bits;
+  const int e = threadIdx.x & (EL - 1);
+  const int zl = threadIdx.x >> (8 - zl_bits);
+  const long long total = (long long)M * N;
+  const long long idx = ((long long)block * EL + e) * V;
+  float v[V];
+#pragma unroll
+  for (int c = 0; c < V; ++c) v[c] = 0.f;
+  if (idx < total) {
+#pragma unroll 8
+    for (int z = zl; z < nz; z += ZL) {
+      const float* src = E.ws + (long long)z * zstride + idx;
+      if (V == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(src);
+        v[0] += t.x;
+        v[1 % V] += t.y;
+        v[2 % V] += t.z;
+        v[3 % V] += t.w;
+      } else {
+        v[0] += *src;
+      }
+    }
+  }
+  const int ld = EL * V + 1;
+#pragma unroll
+  for (int c = 0; c < V; ++c) red[zl * ld + e * V + c] = v[c];
+  __syncthreads();
+  if (zl != 0 || idx >= total) return;
+#pragma unroll
+  for (int c = 0; c < V; ++c) {
+    float acc = 0.f;
+    for (int g = 0; g < ZL; g += 8) {
+      const float* r = red + g * ld + e * V + c;
+      acc += ((r[0] + r[ld]) + (r[2 * ld] + r[3 * ld])) + ((r[4 * ld] + r[5 * ld]) + (r[6 * ld] + r[7 * ld]));
+    }
+    splitk_store(E, N, idx + c, acc);
+  }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const Epilogue E, int M, int N, int nz) {
+  __shared__ float red[8][33];
+  splitk_reduce_body(E, M, N, nz, (long long)M * N, blockIdx.x, red);
+}
+
+// The same finish for a whole table of pending reductions in ONE launch (deferred leaf reductions, mvk_defer_begin):
+// workgroups [blk0, next blk0) belong to item i.
+struct DeferItem {
+  Epilogue e;
+  int M, N, nz;
+  unsigned blk0;
+  long long zstride;
+  int vec4;     // 16-byte loads, 4 elements per thread
+  int zl_bits;  // 3 or 5: 8 or 32 z-lanes
+};
+constexpr int DEFER_BATCH = 24;
+struct DeferTable {
+  int n;
+  DeferItem it[DEFER_BATCH];
+};
+__global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const DeferTable T) {
+  __shared__ float red[32 * 33];  // [ZL][EL * V + 1]: (8, 129) or (32, 33) at most
+  int i = 0;
+  for (int j = 1; j < T.n; ++j)
+    if (blockIdx.x >= T.it[j].blk0) i = j;
+  const DeferItem& it = T.it[i];
+  if (it.vec4)
+    splitk_reduce_bodyv<4>(it.e, it.M, it.N, it.nz, it.zstride, blockIdx.x - it.blk0, it.zl_bits, red);
+  else
+    splitk_reduce_bodyv<1>(it.e, it.M, it.N, it.nz, it.zstride, blockIdx.x - it.blk0, it.zl_bits, red);
+}
+
 // what the launcher chose (needed to finish fused column sums): rows of one tile; 0 = generic kernel
 struct LaunchInfo {
   int bm;
@@ -855,7 +937,7 @@ int launch_igemm(const GemmDesc& d, int zdim, hipStream_t s, LaunchInfo* info = 
 // db[n] += sum over `rows` partial rows (ordered, deterministic)
 int colsum_finish(const float* part, int rows, int N, float* db, hipStream_t s);
 
-int convref_reduce(const float* slab, int nz, int Cu, int Cv, int taps, float* dWref, hipStream_t s);
+int convref_reduce(const float* slab, int nz, int Cu, int Cv, int taps, float* dWref, hipStream_t s, bool deferred = false);
 // smallcin.hip: direct kernels for the 4x4/stride-2 convolution of an NCHW image with <= 4 channels
 bool smallcin_supported(int Cu, int Cv);
 int smallcin_fwd(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w, int Cu, int Cv,

@@ -7,7 +7,7 @@
 namespace mvk {
 
 // igemm.hip: dWref[Cv][Cu][taps] += sum_z slab[z][(tap*Cu + cu)][cv] (ordered reduce into the reference weight layout)
-int convref_reduce(const float* slab, int nz, int Cu, int Cv, int taps, float* dWref, hipStream_t s);
+int convref_reduce(const float* slab, int nz, int Cu, int Cv, int taps, float* dWref, hipStream_t s, bool deferred = false);
 
 constexpr int SC_MAXC = 4;
 
@@ -157,7 +157,9 @@ int smallcin_wgrad(const float* U, const float* dV, float* dWref, int n, int h, 
   const int nout = 16 * Cu * Cv;
   int blocks = (int)((npos + 255) / 256);
   if (blocks > 1024) blocks = 1024;
-  if (!ws || (long long)blocks * nout > ws_floats) return 1;
+  float* dslab = defer_scratch(dWref, (long long)blocks * nout, s);
+  if (dslab) ws = dslab;
+  else if (!ws || (long long)blocks * nout > ws_floats) return 1;
   int ppb = (int)((npos + blocks - 1) / blocks);
   ppb = (ppb + 63) / 64 * 64;
   blocks = (int)((npos + ppb - 1) / ppb);
@@ -177,7 +179,7 @@ int smallcin_wgrad(const float* U, const float* dV, float* dWref, int n, int h, 
 #undef MVK_SCW_C
 #undef MVK_SCW
   MVK_CHECK_LAUNCH();
-  return convref_reduce(ws, blocks, Cu, Cv, 16, dWref, s);
+  return convref_reduce(ws, blocks, Cu, Cv, 16, dWref, s, dslab != nullptr);
 }
 
 }  // namespace mvk

@@ -534,7 +534,9 @@ static int launch_bwd(const float* dU, const float* Uout, int u_act, const float
   using C = SmallCfg<CU, CV>;
   const int slab = CV * C::NC + CU + CV;
   int grid = n < 512 ? n : 512;
-  if ((int64_t)grid * slab > ws_floats) grid = (int)(ws_floats / slab);
+  float* dslab = (mvk::defer_free(db) && mvk::defer_free(db_v)) ? mvk::defer_scratch(dWref, (long long)grid * slab, s) : nullptr;
+  if (dslab) ws = dslab;
+  else if ((int64_t)grid * slab > ws_floats) grid = (int)(ws_floats / slab);
   if (grid < 1) return MVK_EINVAL;
   const size_t lds = bwd_lds<CU, CV>(h, w);
   constexpr int NT = MVK_SMALL_BWD_THREADS;
@@ -548,6 +550,12 @@ static int launch_bwd(const float* dU, const float* Uout, int u_act, const float
   MVK_CHECK_LAUNCH();
   mvk::prof_fold(prof, s);
   const int total = CV * C::NC + CU + CV;
+  if (dslab) {  // the three ordered sums over the per-workgroup slabs are queued (mvk_defer_flush)
+    int rc = mvk::defer_push_plain(dWref, dslab, CV * C::NC, grid, total, s);
+    if (rc == MVK_OK && db) rc = mvk::defer_push_plain(db, dslab + CV * C::NC, CU, grid, total, s);
+    if (rc == MVK_OK && db_v) rc = mvk::defer_push_plain(db_v, dslab + CV * C::NC + CU, CV, grid, total, s);
+    return rc;
+  }
   hipLaunchKernelGGL(small_up_bwd_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, s, ws, grid, CV * C::NC, CU, CV,
                      dWref, db, db_v);
   MVK_CHECK_LAUNCH();

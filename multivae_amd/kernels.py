@@ -67,6 +67,42 @@ def _ws(like):
 
 
 # -----------------------------------------------------------------------------------------------------
+# deferred leaf reductions (mvk_defer_begin, include/mvk.h)
+# -----------------------------------------------------------------------------------------------------
+# Weight / bias gradients are leaves: between `deferred_reductions(flat)` and its exit the ordered finishes of every
+# gradient that accumulates into the flat buffer (split-K slabs, column-sum partials, convolution weight-gradient slabs)
+# are queued and run in ONE launch at exit instead of one small launch each in the middle of the backward chain.
+DEFER = os.environ.get("MVK_DEFER", "1") != "0"
+DEFER_ARENA_FLOATS = int(os.environ.get("MVK_DEFER_MB", "512")) * (1 << 18)
+_ARENA = {}
+
+
+class deferred_reductions:
+    """with deferred_reductions(flat): forward + backward.  On exit the queued finishes run on the current stream; the
+    gradient buffer is complete after that (before: NOT).  A no-op on CPU tensors or with MVK_DEFER=0."""
+
+    def __init__(self, flat):
+        g = getattr(flat, "grad", None)
+        self.on = DEFER and g is not None and g.is_cuda and g.numel() > 0
+        self.grad = g
+
+    def __enter__(self):
+        if self.on:
+            dev = self.grad.device
+            arena = _ARENA.get(dev)
+            if arena is None:
+                arena = torch.empty(DEFER_ARENA_FLOATS, dtype=torch.float32, device=dev)
+                _ARENA[dev] = arena
+            call("mvk_defer_begin", ptr(arena), arena.numel(), ptr(self.grad), self.grad.numel())
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.on:
+            call("mvk_defer_end", stream_ptr())
+        return False
+
+
+# -----------------------------------------------------------------------------------------------------
 # modality branches on separate HIP streams
 # -----------------------------------------------------------------------------------------------------
 # The encoders (and the decoders) of different modalities are independent until the posterior (resp. the

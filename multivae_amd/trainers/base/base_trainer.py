@@ -21,6 +21,7 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
+from ... import kernels
 from ...data.datasets.base import DatasetOutput
 from ...models.base.base_model import BaseModel
 from ..flat import FlatParams, FusedAdam
@@ -315,7 +316,8 @@ class BaseTrainer:
             # always through the flat buffer: torch's own zero_grad() sets .grad to None, backward() would then
             # allocate gradients OUTSIDE the buffer the all-reduce below exchanges
             self.flat.zero_grad()
-            loss.backward()
+            with kernels.deferred_reductions(self.flat):  # one launch finishes every weight / bias gradient
+                loss.backward()
             if not isinstance(self.optimizer, FusedAdam):
                 self.flat.ensure_attached()
         if isinstance(self.optimizer, FusedAdam):

@@ -64,8 +64,9 @@ class GraphedStep:
         kw = dict(self.fwd_kwargs)
         if self.noise is not None:
             kw["noise"] = self.noise
-        out = self.model(self.inputs, **kw)
-        out.loss.backward()
+        with kernels.deferred_reductions(self.flat):
+            out = self.model(self.inputs, **kw)
+            out.loss.backward()
         return out
 
     def matches(self, inputs):

@@ -162,6 +162,53 @@ def test_graph_replay_matches_eager():
     _same_training(_run_steps(d, 5, graphed=False), _run_steps(d, 5, graphed=True))
 
 
+def test_deferred_reductions_match_immediate_finishes():
+    """kernels.deferred_reductions (mvk_defer_begin / _end): every ordered finish of a weight / bias gradient queued and
+    run in one launch at the end of the backward pass vs one launch each behind its producer.  Same partial results, a
+    different (fixed) summation tree for the column-sum finishes; bit-identical from run to run; nothing left pending.
+    n = K * B = 2560 images: the register-stationary convolution kernels and their slabs are on the path."""
+    from multivae_amd import _lib, kernels
+    from multivae_amd.data.datasets.base import DatasetOutput
+    from multivae_amd.trainers import FlatParams
+
+    d = torch.device("cuda:0")
+    B, K, L = 256, 10, 20
+    model = _mnist_svhn_mopoe(d, K=K, L=L)
+    flat = FlatParams(model)
+    g = torch.Generator().manual_seed(11)
+    inputs = DatasetOutput(data=dict(mnist=torch.rand(B, 1, 28, 28, generator=g).to(d),
+                                     svhn=torch.rand(B, 3, 32, 32, generator=g).to(d)))
+    eps = torch.randn(K, B, L, generator=g).to(d)
+
+    def run(deferred):
+        flat.zero_grad()
+        if deferred:
+            with kernels.deferred_reductions(flat) as ctx:
+                assert ctx.on
+                out = model(inputs, noise=eps)
+                out.loss.backward()
+                assert _lib.load().mvk_defer_pending() >= 10  # the finishes are queued, not run
+        else:
+            out = model(inputs, noise=eps)
+            out.loss.backward()
+        assert _lib.load().mvk_defer_pending() == 0
+        torch.cuda.synchronize()
+        return float(out.loss.detach()), flat.grad.detach().clone()
+
+    l0, g0 = run(False)
+    l1, g1 = run(True)
+    l2, g2 = run(True)
+    assert l0 == l1 == l2
+    assert torch.equal(g1, g2), "deferred finishes are not reproducible"
+    off = 0
+    for name, p in model.named_parameters():  # FlatParams lays the gradients out in this order
+        n = p.numel()
+        a, b = g1[off:off + n], g0[off:off + n]
+        off += n
+        scale = float(b.abs().max().clamp_min(1e-30))
+        assert float((a - b).abs().max()) <= 2e-6 * scale, (name, float((a - b).abs().max()), scale)
+
+
 @pytest.mark.parametrize("model_name", ["MoPoE", "JMVAE", "MVAE"])
 def test_trainer_with_hip_graph(tmp_path, model_name):
     """BaseTrainerConfig.use_hip_graph: every batch shape gets one captured graph (the full batches and the short last
