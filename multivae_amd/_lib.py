@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmvk.so")
+LIB_PATH = os.environ.get("MVK_LIB_PATH") or os.path.join(_HERE, "libmvk.so")  # MVK_LIB_PATH: A/B builds (tools/)
 
 MVK_OK = 0
 DIST = {"normal": 0, "laplace": 1, "bernoulli": 2, "categorical": 3}

@@ -9,6 +9,8 @@
 // it — backward-data (im2col gather from LDS) and backward-weight (reduction over positions, accumulated in
 // registers across a persistent loop over images) — plus the bias gradient, so dU / U / V are read from HBM
 // exactly once.  v_mfma_f32_16x16x4_f32: exact fp32.
+#include <cstdlib>
+
 #include "common.hpp"
 
 #ifndef MVK_SMALL_FWD_THREADS
@@ -156,21 +158,38 @@ __global__ __launch_bounds__(NT) void small_up_fwd_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------------------
 // backward: dV = down(dUpre) * act'(V),  partial dW / db per workgroup (persistent over images)
 // ---------------------------------------------------------------------------------------------------------
-template <int CU, int CV, int NT>
-__global__ __launch_bounds__(NT) void small_up_bwd_kernel(const float* __restrict__ dU, const float* __restrict__ Uout,
-                                                           int u_act, const float* __restrict__ V, int v_act,
+// A work unit is an image (PU = 256 positions) or, for 16x16 inputs, half an image (PU = 128: rows [8 half, 8 half + 8);
+// the gradient tile then carries the neighbouring half's two rows as halo instead of zeros).  Half units need 35 KB of LDS
+// and ~120 registers instead of 61 KB and 252: four workgroups per CU instead of two, which is what this latency-bound
+// kernel lacks (measured with whole images: matrix pipe 42 % busy, 47 % of the wave cycles waiting to issue).
+// UACT / VACT >= 0: the activations are compile-time constants (sigmoid image, ReLU input map: the SVHN decoder); the
+// run-time codes cost a compare / select chain per element in a kernel that is bound by instruction issue.
+template <int CU, int CV, int NT, int PU, int OCC, int UACT, int VACT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void small_up_bwd_kernel(const float* __restrict__ dU, const float* __restrict__ Uout,
+                                                           int u_act_rt, const float* __restrict__ V, int v_act_rt,
                                                            const float* __restrict__ Wref, float* __restrict__ dV,
-                                                           float* __restrict__ partial, int n, int h, int w,
+                                                           float* __restrict__ partial, int n, int h, int w, int units,
                                                            mvk_prof_slot* prof) {
   mvk_prof_begin(prof);
   using C = SmallCfg<CU, CV>;
+  const int u_act = UACT >= 0 ? UACT : u_act_rt, v_act = VACT >= 0 ? VACT : v_act_rt;
+#ifdef MVK_ABLATE  // tools/smallup_ablate.sh: which part of the kernel bounds it (wrong results by construction)
+  const int abl = (units >> 8) & 0xff;
+  const int dephase = units >> 16;  // experiment: the second half of the grid starts `dephase` x ~0.4 us late
+  units &= 0xff;
+  if (blockIdx.x >= gridDim.x / 2)
+    for (int q = 0; q < dephase; ++q) __builtin_amdgcn_s_sleep(100);
+#else
+  constexpr int abl = 0;
+#endif
   constexpr int NW = NT / 64;    // waves per workgroup
-  constexpr int WP = 256 / NW;   // positions per wave
+  constexpr int WP = PU / NW;    // positions per wave
   constexpr int MT = WP / 16;    // 16-row MFMA tiles per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int P = h * w, DH = 2 * h + 2, DW = 2 * w + 2;
+  const int hu = h / units;      // input rows per unit
+  const int P = hu * w, DH = 2 * hu + 2, DW = 2 * w + 2;
   float* Wt = smem;                       // [NC][WT]: Wt[k=(cu,tap)][cv] = Wref[cv][k]
-  float* Ds = Wt + C::NC * C::WT;         // [CU][DH][DW] pre-activation gradient with zero halo
+  float* Ds = Wt + C::NC * C::WT;         // [CU][DH][DW] pre-activation gradient with halo
   float* Vs = Ds + ((CU * DH * DW + 3) & ~3);  // [P][VS]
   int* posoff = reinterpret_cast<int*>(Vs + P * C::VS);  // [P]: (2i)*DW + 2j
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
@@ -186,22 +205,23 @@ __global__ __launch_bounds__(NT) void small_up_bwd_kernel(const float* __restric
   for (int a = 0; a < C::NTV; ++a)
 #pragma unroll
     for (int b = 0; b < CU; ++b) accw[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float dbl[CU];
+  f32x4 dbv[C::NTV];  // column sums of dV for this lane's channels cv = b*16 + 4*lq + r (positions: this lane's l15 group)
 #pragma unroll
-  for (int c = 0; c < CU; ++c) dbl[c] = 0.f;
-  float dbv[C::NTV];  // column sums of dV for this lane's channel cv = b*16 + l15 (rows: this lane's lq group)
-#pragma unroll
-  for (int b = 0; b < C::NTV; ++b) dbv[b] = 0.f;
+  for (int b = 0; b < C::NTV; ++b) dbv[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int H2 = 2 * h, W2 = 2 * w;
-  // register prefetch of the NEXT image's three tiles (dU, Uout with halo indexing; V as float4)
-  constexpr int ND = (CU * 34 * 34 + NT - 1) / NT;  // halo-tile elements per thread (h, w <= 16)
-  constexpr int NV = 256 * CV / 4 / NT;
+  // register prefetch of the NEXT unit's three tiles (dU, Uout with halo indexing; V as float4)
+  constexpr int ND = (CU * (PU / 8 + 2) * 34 + NT - 1) / NT;  // halo-tile elements per thread (w <= 16, hu <= PU / 16)
+  constexpr int NV = PU * CV / 4 / NT;
   const int nd = CU * DH * DW, n4 = P * CV / 4;
   float pdu[ND], puo[ND];
   f32x4 pv[NV];
-  // halo-tile geometry is image independent: source offset (clamped), validity and channel of every element
-  int hoff[ND];   // bits 0..27 offset into the image, 28..29 channel, 30 inside the image
+  float dslot[ND];  // bias-gradient partial of tile slot u (a slot always holds the same channel)
+#pragma unroll
+  for (int u = 0; u < ND; ++u) dslot[u] = 0.f;
+  // halo-tile geometry is unit independent up to the row offset of the unit: offset of tile element (cu, y, x) for a
+  // unit starting at output row 0 (may be negative), its tile row y, channel, and whether its column is inside the image
+  int tinfo[ND];  // bits 0..7 y, 8..9 channel, 10 column inside the image and idx < nd, 12.. offset + W2 (>= 0)
 #pragma unroll
   for (int u = 0; u < ND; ++u) {
     const int idx = tid + u * NT;
@@ -209,55 +229,58 @@ __global__ __launch_bounds__(NT) void small_up_bwd_kernel(const float* __restric
     const int cu = idc / (DH * DW);
     const int rem = idc - cu * (DH * DW);
     const int y = rem / DW, x = rem - y * DW;
-    const int oh = y - 1, ow = x - 1;
-    const bool in = idx < nd && oh >= 0 && oh < H2 && ow >= 0 && ow < W2;
-    const int ohc = oh < 0 ? 0 : (oh >= H2 ? H2 - 1 : oh), owc = ow < 0 ? 0 : (ow >= W2 ? W2 - 1 : ow);
-    hoff[u] = ((cu * H2 + ohc) * W2 + owc) | (cu << 28) | ((int)in << 30);
+    const int ow = x - 1;
+    const bool colin = idx < nd && ow >= 0 && ow < W2;
+    tinfo[u] = y | (cu << 8) | ((int)colin << 10) | (((cu * H2 + y) * W2 + (colin ? ow : 0)) << 12);
   }
-  auto prefetch = [&](long long img) __attribute__((always_inline)) {
+  const long long nunits = (long long)n * units;
+  auto prefetch = [&](long long unit) __attribute__((always_inline)) {
+    const long long img = unit >> (units - 1);           // units is 1 or 2
+    const int r2 = 2 * (int)(unit & (units - 1)) * hu;  // first output row of the unit
     const float* du = dU + img * CU * H2 * W2;
     const float* uo = Uout + img * CU * H2 * W2;
 #pragma unroll
     for (int u = 0; u < ND; ++u) {
-      const int off = hoff[u] & 0x0fffffff;  // clamped address: the load is unconditional, the halo is zeroed
-      const bool in = (hoff[u] >> 30) & 1;
-      const float a = du[off], b = uo[off];
-      pdu[u] = in ? a : 0.f;
-      puo[u] = in ? b : 0.f;
+      const int oh = r2 + (tinfo[u] & 255) - 1;
+      const bool in = ((tinfo[u] >> 10) & 1) && oh >= 0 && oh < H2;
+      const int off = in ? (tinfo[u] >> 12) + (r2 - 1) * W2 : 0;  // clamped: the load is unconditional, the padding zeroed
+      pdu[u] = du[off];  // raw: the padding mask is applied when the tile is staged, so nothing waits on these loads
+      puo[u] = uo[off];  // before the MFMA phase of the current unit
     }
-    const f32x4* src = reinterpret_cast<const f32x4*>(V + img * P * CV);
+    const f32x4* src = reinterpret_cast<const f32x4*>(V + (img * h * w + (long long)(r2 >> 1) * w) * CV);
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       const int idx = tid + u * NT;
       pv[u] = src[idx < n4 ? idx : n4 - 1];
     }
   };
-  if ((long long)blockIdx.x < n) prefetch(blockIdx.x);
-  for (long long img = blockIdx.x; img < n; img += gridDim.x) {
-    __syncthreads();  // previous image's tiles are no longer read
+  if ((long long)blockIdx.x < nunits) prefetch(blockIdx.x);
+  for (long long unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+    __syncthreads();  // previous unit's tiles are no longer read
     // --- stage dUpre with halo (sigmoid' applied here), bias-gradient partials, and the V tile
+    const int r2s = 2 * (int)(unit & (units - 1)) * hu;  // first output row of the unit being staged
 #pragma unroll
     for (int u = 0; u < ND; ++u) {
       const int idx = tid + u * NT;
-      if (idx < nd) {
-        const float v = pdu[u] * mvk_act_grad_from_out(puo[u], u_act);  // halo: 0 * act'(0) = 0
+      if (idx < nd && !(abl & 16)) {
+        const int oh = r2s + (tinfo[u] & 255) - 1;
+        const bool in = ((tinfo[u] >> 10) & 1) && oh >= 0 && oh < H2;
+        const float v = in ? pdu[u] * mvk_act_grad_from_out(puo[u], u_act) : 0.f;  // zero padding outside the image
         Ds[idx] = v;
-        const int cu = (hoff[u] >> 28) & 3;
-#pragma unroll
-        for (int c = 0; c < CU; ++c)
-          if (c == cu) dbl[c] += v;
+        const int y = tinfo[u] & 255;
+        dslot[u] += (y >= 1 && y <= 2 * hu) ? v : 0.f;  // halo rows belong to the neighbouring unit (or are padding)
       }
     }
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       const int idx = tid + u * NT;
-      if (idx < n4) {
+      if (idx < n4 && !(abl & 32)) {
         const int pos = idx / (CV / 4), q = idx - pos * (CV / 4);
         *reinterpret_cast<f32x4*>(Vs + pos * C::VS + 4 * q) = pv[u];
       }
     }
     __syncthreads();
-    if (img + gridDim.x < n) prefetch(img + gridDim.x);
+    if (unit + gridDim.x < nunits && !(abl & 8)) prefetch(unit + gridDim.x);
     if (!active) continue;
     // --- backward data: dV[pos][cv] = sum_{k=(cu,kh,kw)} dUpre[cu][2i-1+kh][2j-1+kw] * W[cv][k]
     f32x4 acc[MT][C::NTV];
@@ -269,7 +292,7 @@ __global__ __launch_bounds__(NT) void small_up_bwd_kernel(const float* __restric
 #pragma unroll
     for (int a = 0; a < MT; ++a) po[a] = posoff[wave * WP + a * 16 + l15];
 #pragma unroll 2
-    for (int ks = 0; ks < C::NC / 4; ++ks) {
+    for (int ks = 0; ks < ((abl & 1) ? 1 : C::NC / 4); ++ks) {
       const int k = ks * 4 + lq;
       const int koff = (k >> 4) * DH * DW + ((k >> 2) & 3) * DW + (k & 3);
       float av[MT], bv[C::NTV];
@@ -281,23 +304,31 @@ __global__ __launch_bounds__(NT) void small_up_bwd_kernel(const float* __restric
       for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < C::NTV; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[b], av[a], acc[a][b], 0, 0, 0);  // transposed tile
     }
-    float* dv = dV + img * P * CV;
+    if (!(abl & 64)) {
+      // operands swapped: this lane holds dV[pos = a*16 + l15][cv = b*16 + 4*lq .. +3] -> 16-byte mask reads and stores
+      const long long img = unit >> (units - 1);
+      const int r0 = (int)(unit & (units - 1)) * hu;
+      float* dv = dV + (img * h * w + (long long)r0 * w) * CV;
 #pragma unroll
-    for (int a = 0; a < MT; ++a)
+      for (int a = 0; a < MT; ++a)
 #pragma unroll
-      for (int b = 0; b < C::NTV; ++b)
+        for (int b = 0; b < C::NTV; ++b) {
+          const int pos = wave * WP + a * 16 + l15, cv = b * 16 + lq * 4;
+          const f32x4 vin = *reinterpret_cast<const f32x4*>(Vs + pos * C::VS + cv);
+          f32x4 g;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int pos = wave * WP + a * 16 + lq * 4 + r, cv = b * 16 + l15;
-          const float g = acc[a][b][r] * mvk_act_grad_from_out(Vs[pos * C::VS + cv], v_act);
-          dv[pos * CV + cv] = g;
-          dbv[b] += g;
+          for (int r = 0; r < 4; ++r) {
+            g[r] = acc[a][b][r] * mvk_act_grad_from_out(vin[r], v_act);
+            dbv[b][r] += g[r];
+          }
+          if (!(abl & 4)) *reinterpret_cast<f32x4*>(dv + pos * CV + cv) = g;
         }
+    }
     // --- backward weight: dW[cv][k] += sum_pos V[pos][cv] * dUpre(gathered)[pos][k]; this wave's WP positions
 #pragma unroll 2
-    for (int ks = 0; ks < WP / 4; ++ks) {
+    for (int ks = 0; ks < ((abl & 2) ? 1 : WP / 4); ++ks) {
       const int kpos = wave * WP + ks * 4 + lq;
       const int pbase = posoff[kpos];
       float av[C::NTV], bv[CU];
@@ -336,6 +367,14 @@ __global__ __launch_bounds__(NT) void small_up_bwd_kernel(const float* __restric
     slab[i] = red[i] + red[CV * C::NC + i] + red[2 * CV * C::NC + i] + red[3 * CV * C::NC + i];
   __syncthreads();
   // bias partials
+  float dbl[CU];
+#pragma unroll
+  for (int c = 0; c < CU; ++c) dbl[c] = 0.f;
+#pragma unroll
+  for (int u = 0; u < ND; ++u)
+#pragma unroll
+    for (int c = 0; c < CU; ++c)
+      if (c == ((tinfo[u] >> 8) & 3)) dbl[c] += dslot[u];
   float* bred = smem;
 #pragma unroll
   for (int c = 0; c < CU; ++c) {
@@ -350,15 +389,17 @@ __global__ __launch_bounds__(NT) void small_up_bwd_kernel(const float* __restric
     slab[CV * C::NC + tid] = t;
   }
   __syncthreads();
-  // column sums of dV: combine the 4 lq groups of each wave, then the 4 waves
-  float* vred = smem;  // [CV][NW*4]
+  // column sums of dV: combine the 16 position groups of each wave, then the waves (fixed order)
+  float* vred = smem;  // [CV][NW*16]
 #pragma unroll
-  for (int b = 0; b < C::NTV; ++b) vred[(b * 16 + l15) * (NW * 4) + wave * 4 + lq] = dbv[b];
+  for (int b = 0; b < C::NTV; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vred[(b * 16 + lq * 4 + r) * (NW * 16) + wave * 16 + l15] = dbv[b][r];
   __syncthreads();
   if (tid < CV) {
     float t = 0.f;
 #pragma unroll
-    for (int q = 0; q < NW * 4; ++q) t += vred[tid * (NW * 4) + q];
+    for (int q = 0; q < NW * 16; ++q) t += vred[tid * (NW * 16) + q];
     slab[CV * C::NC + CU + tid] = t;
   }
   mvk_prof_end(prof);
@@ -533,20 +574,50 @@ static int launch_bwd(const float* dU, const float* Uout, int u_act, const float
                       int w, hipStream_t s) {
   using C = SmallCfg<CU, CV>;
   const int slab = CV * C::NC + CU + CV;
-  int grid = n < 512 ? n : 512;
+  // MVK_SMALL_BWD_UNITS=2: half-image work units for 16x16 inputs (3 workgroups per CU instead of 2).  Measured at
+  // n = 5120: 142.7 us vs 146.0 us alone, 162-166 us vs 137-139 us inside the MoPoE step (same step time): off by default.
+  static const int units_env = getenv("MVK_SMALL_BWD_UNITS") ? atoi(getenv("MVK_SMALL_BWD_UNITS")) : 1;
+  const int units = (h == 16 && w == 16 && units_env == 2) ? 2 : 1;
+  const long long nunits = (long long)n * units;
+  const int gmax = units == 2 ? 1024 : 512;
+  int grid = nunits < gmax ? (int)nunits : gmax;
   float* dslab = (mvk::defer_free(db) && mvk::defer_free(db_v)) ? mvk::defer_scratch(dWref, (long long)grid * slab, s) : nullptr;
   if (dslab) ws = dslab;
   else if ((int64_t)grid * slab > ws_floats) grid = (int)(ws_floats / slab);
   if (grid < 1) return MVK_EINVAL;
-  const size_t lds = bwd_lds<CU, CV>(h, w);
+  const size_t lds = bwd_lds<CU, CV>(h / units, w);
   constexpr int NT = MVK_SMALL_BWD_THREADS;
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_bwd_kernel<CU, CV, NT>),
+  if (lds > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_bwd_kernel<CU, CV, NT, 256, 2, -1, -1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(
+        reinterpret_cast<const void*>(small_up_bwd_kernel<CU, CV, NT, 256, 2, MVK_ACT_SIGMOID, MVK_ACT_RELU>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
   // algorithmic bytes: image gradient + image read once, the saved input map read once, its gradient written once
   mvk_prof_slot* prof = mvk::prof_next(6, 4.0 * n * h * w * (2.0 * CV + 8.0 * CU));
-  hipLaunchKernelGGL((small_up_bwd_kernel<CU, CV, NT>), dim3(grid), dim3(NT), lds, s, dU, Uout, u_act, V, v_act, Wref, dV,
-                     ws, n, h, w, prof);
+  static const int occ_env = getenv("MVK_SMALL_BWD_OCC") ? atoi(getenv("MVK_SMALL_BWD_OCC")) : 3;
+  const bool spec = u_act == MVK_ACT_SIGMOID && v_act == MVK_ACT_RELU;
+#ifdef MVK_ABLATE
+  const int abl_bits = ((getenv("MVK_ABLATE") ? atoi(getenv("MVK_ABLATE")) : 0) << 8) |
+                       ((getenv("MVK_DEPHASE") ? atoi(getenv("MVK_DEPHASE")) : 0) << 16);
+#else
+  constexpr int abl_bits = 0;
+#endif
+#define MVK_SUB_LAUNCH(PU_, OCC_, UA_, VA_, UNITS_)                                                                          \
+  hipLaunchKernelGGL((small_up_bwd_kernel<CU, CV, NT, PU_, OCC_, UA_, VA_>), dim3(grid), dim3(NT), lds, s, dU, Uout, u_act, V, \
+                     v_act, Wref, dV, ws, n, h, w, (UNITS_) | abl_bits, prof)
+  if (units == 2 && occ_env == 4) {
+    if (spec) MVK_SUB_LAUNCH(128, 4, MVK_ACT_SIGMOID, MVK_ACT_RELU, 2);
+    else MVK_SUB_LAUNCH(128, 4, -1, -1, 2);
+  } else if (units == 2) {
+    if (spec) MVK_SUB_LAUNCH(128, 3, MVK_ACT_SIGMOID, MVK_ACT_RELU, 2);
+    else MVK_SUB_LAUNCH(128, 3, -1, -1, 2);
+  } else {
+    if (spec) MVK_SUB_LAUNCH(256, 2, MVK_ACT_SIGMOID, MVK_ACT_RELU, 1);
+    else MVK_SUB_LAUNCH(256, 2, -1, -1, 1);
+  }
+#undef MVK_SUB_LAUNCH
   MVK_CHECK_LAUNCH();
   mvk::prof_fold(prof, s);
   const int total = CV * C::NC + CU + CV;
