@@ -472,6 +472,15 @@ int mvk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, doubl
 int mvk_adam_step_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1,
                           double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream);
 
+/* The encoder heads in ONE launch: Y_h[m][n] = sum_k X[m][k] W_h(k, n) + b_h[n] for h = 0 (and 1 when W1 != NULL),
+ * n < N <= 32, W_h(k, n) = W_h[k * w_sk + n * w_sn] (a torch Linear weight [N][K]: w_sk = 1, w_sn = K; the packed
+ * Conv2d(C, L, 4, 2, 0) head [(kh,kw,c)][L]: w_sk = L, w_sn = 1).  Replaces `self.embedding(h)`, `self.log_var(h)` of
+ * Encoder_VAE_MLP (models/nn/default_architectures.py:40-56) and `self.c1(e)`, `self.c2(e)` of Encoder_VAE_SVHN
+ * (models/nn/svhn.py:29-34).  K % 4 == 0, X 16-byte aligned; exact fp32 (v_mfma_f32_16x16x4_f32), fixed summation
+ * order.  b_h may be NULL. */
+int mvk_heads_fwd(const float* X, const float* W0, const float* b0, float* Y0, const float* W1, const float* b1,
+                  float* Y1, int M, int N, int K, int64_t w_sk, int64_t w_sn, void* stream);
+
 /* Deferred leaf reductions.  Parameter gradients are leaves of the backward pass (reference: autograd accumulates them
  * into `.grad`, nothing reads them before `optimizer.step()`, trainers/base/base_trainer.py:405-420), so the ordered
  * finishes that complete them - split-K slabs of the weight-gradient GEMMs, per-workgroup column sums of the bias

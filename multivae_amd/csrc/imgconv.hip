@@ -61,7 +61,23 @@ struct ICfg {
   static constexpr int TPU = PIX >= 32 ? PIX / 32 : 1;         // 32-row tiles per stage unit (and class)
   static constexpr int AROWS = SU * APIX;                      // LDS rows per unit
   static constexpr int S = CIN * 2 + 16;                       // bytes per LDS row (bf16 channels + pad)
-  static constexpr int PLANE = (AROWS + 1) * S;                // + the zero row
+  // Pixel (img, y, x) of a unit sits at img * IMGB + y * LINEB + xrow(x) * S.  An A fragment (ds_read_b128, four groups of
+  // 16 lanes, each reading 256 bytes = 16 slots of 16 B per LDS cycle) takes the pixels of 32 consecutive outputs at one
+  // tap: for UP that is a stride of one pixel per output and plain rows are conflict-free; for DOWN the stride is two
+  // pixels (2 S = 160 or 288 bytes: only even slots / every other slot pair are hit -> 2-way for 16 -> 8 output columns,
+  // 4-way for 8 -> 4).  Storing the even and the odd input columns of a line in separate half lines (16 -> 8) makes the
+  // stride one row again, and LPAD / IPAD shift the lines (and the second image of a 2-image unit) onto the slots the
+  // first line of a lane group leaves free: every group then covers 16 distinct slots (checked exhaustively offline).
+  static constexpr bool XPERM = KIND == IC_DOWN && HS == 8;
+  static constexpr int LPAD = KIND == IC_DOWN ? 64 : 0;
+  static constexpr int IPAD = (KIND == IC_DOWN && HS == 4) ? 16 : 0;
+  static constexpr int LINEB = AW * S + LPAD;
+  static constexpr int IMGB = AW * LINEB + IPAD;
+  static constexpr int ZOFF = SU * IMGB;                       // the zero row (halo)
+  static constexpr int PLANE = SU * IMGB + S;
+  __host__ __device__ static constexpr int pix_off(int img, int y, int x) {
+    return img * IMGB + y * LINEB + (XPERM ? (x & 1) * (AW / 2) + (x >> 1) : x) * S;
+  }
   static constexpr int BUF = 3 * PLANE;
   static constexpr int NF4 = AROWS * CIN / 4 / 256;            // float4 units per thread per stage unit
   static constexpr int OWN = 16 / KSPLIT;                      // accumulator registers a wave finishes
@@ -137,10 +153,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // ---- LDS geometry -----------------------------------------------------------------------------------------------
   char* const xbase = lds + 2 * T::BUF;
   float* const csred = reinterpret_cast<float*>(lds + 2 * T::BUF + 2 * T::XBUF);
-  // zero rows (row AROWS of every plane of both buffers)
+  // zero rows (at ZOFF of every plane of both buffers)
   for (int i = tid; i < 2 * 3 * (T::S / 4); i += 256) {
     const int pl = i / (T::S / 4), w = i % (T::S / 4);
-    *reinterpret_cast<unsigned*>(lds + (pl / 3) * T::BUF + (pl % 3) * T::PLANE + T::AROWS * T::S + w * 4) = 0u;
+    *reinterpret_cast<unsigned*>(lds + (pl / 3) * T::BUF + (pl % 3) * T::PLANE + T::ZOFF + w * 4) = 0u;
   }
   // A-fragment byte offsets of this lane, per (tile of the unit, tap of this wave): row * S + kg * 16
   int aoff[T::TPU][T::NTAPS];
@@ -160,8 +176,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         x = 2 * j - 1 + (tap & 3);
       }
       const bool ok = y >= 0 && y < T::AW && x >= 0 && x < T::AW;
-      const int row = ok ? img * T::APIX + y * T::AW + x : T::AROWS;
-      aoff[tt][q] = row * T::S + kg * 16;
+      aoff[tt][q] = (ok ? T::pix_off(img, y, x) : T::ZOFF) + kg * 16;
     }
   }
   // staging: float4 unit f = tid + u*256 of the unit's [AROWS][CIN] matrix -> row f / (CIN/4), 4 channels
@@ -169,7 +184,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int u = 0; u < T::NF4; ++u) {
     const int f = tid + u * 256;
-    soff[u] = (f / (CIN / 4)) * T::S + (f % (CIN / 4)) * 8;
+    const int r = f / (CIN / 4), img = r / T::APIX, p = r % T::APIX;
+    soff[u] = T::pix_off(img, p / T::AW, p % T::AW) + (f % (CIN / 4)) * 8;
   }
   // output rows this wave finishes: accumulator registers [ks*OWN, ks*OWN+OWN).  The element offset of row
   // R = (r & 3) + 8 (r >> 2) + 4 kg of tile tt inside the unit's output block is additive over (tt, r, kg) (no

@@ -225,6 +225,17 @@ def gemm(a, b, M, N, K, ta=False, tb=False, bias=None, bias_mod=0, act=NONE, out
     return c
 
 
+def heads_fwd(h2, w_mu, b_mu, w_lv, b_lv, N, w_sk, w_sn):
+    """(mu, lv) = h2 @ W_mu + b_mu, h2 @ W_lv + b_lv in one launch (mvk_heads_fwd); W(k, n) = W[k * w_sk + n * w_sn]."""
+    M, K = h2.shape
+    if N > 32 or K % 4 != 0:
+        return None
+    mu, lv = _new((M, N), h2), _new((M, N), h2)
+    call("mvk_heads_fwd", ptr(h2), ptr(w_mu), ptr(b_mu), ptr(mu), ptr(w_lv), ptr(b_lv), ptr(lv), M, N, K, w_sk, w_sn,
+         stream_ptr())
+    return mu, lv
+
+
 def colsum(dy2, b, y_out=None, y_act=NONE):
     """bias gradient: b.grad += column sums of dy2 [M,N]; returns what autograd should get for b."""
     M, N = dy2.shape
@@ -393,8 +404,12 @@ class MLPEncoderFn(Function):
             h = linear_fwd(h, params[2 * i], params[2 * i + 1], RELU)
             acts.append(h)
         we, be, wl, bl = params[-4:]
-        mu = linear_fwd(h, we, be, NONE)
-        lv = linear_fwd(h, wl, bl, NONE)
+        heads = heads_fwd(h, we, be, wl, bl, we.shape[0], 1, we.shape[1]) if we.shape == wl.shape else None
+        if heads is not None:
+            mu, lv = heads
+        else:
+            mu = linear_fwd(h, we, be, NONE)
+            lv = linear_fwd(h, wl, bl, NONE)
         ctx.save_for_backward(*acts, *params)
         ctx.n_layers = n_layers
         ctx.x_shape = x.shape
@@ -542,8 +557,12 @@ class SVHNEncoderFn(Function):
             raise _lib.MvkError("Encoder_VAE_SVHN expects 32x32 inputs (4x4 feature map before the heads)")
         Kf = 16 * chans[3]
         h3f = h3.view(B, Kf)
-        mu = gemm(h3f, wdc1, B, L, Kf, bias=bc1, bias_mod=L)
-        lv = gemm(h3f, wdc2, B, L, Kf, bias=bc2, bias_mod=L)
+        heads = heads_fwd(h3f, wdc1, bc1, wdc2, bc2, L, L, 1)
+        if heads is not None:
+            mu, lv = heads
+        else:
+            mu = gemm(h3f, wdc1, B, L, Kf, bias=bc1, bias_mod=L)
+            lv = gemm(h3f, wdc2, B, L, Kf, bias=bc2, bias_mod=L)
         ctx.save_for_backward(x, h1, h2, h3, wu1, wu2, wdc1, wdc2, w0, b0, w1, b1, w2, b2, wc1, bc1, wc2, bc2)
         ctx.frags = (wfrag(wu1), wfrag(wu2))  # saved tensors come back without Python attributes
         ctx.dims = (B, H, W, chans, L)
@@ -1024,11 +1043,14 @@ class ReconLossFn(Function):
         ctx.extra_grad = extra_grad
         ctx.rows = rows  # keep alive: metrics / debugging
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)  # no zero-fill launch for the gradient of `out` (never used)
         return loss, out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gloss, gout):
+        if gloss is None:  # only the (non-differentiable) terms were used
+            return (None, None) + (None,) * (len(ctx.drecons) + len(ctx.extra_shapes))
         gloss = _c(gloss.reshape(1))
         grads = list(ctx.drecons)
         extras = [_new(shape, gloss) for shape in ctx.extra_shapes]

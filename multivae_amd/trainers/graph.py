@@ -23,6 +23,7 @@ class GraphedStep:
         if dev.type != "cuda":
             raise RuntimeError("GraphedStep needs a GPU")
         self.model, self.flat, self.fwd_kwargs = model, flat, fwd_kwargs
+        self._seed = None
         self.data = {m: v.detach().clone() for m, v in inputs.data.items()}
         extra = {}
         if hasattr(inputs, "masks"):
@@ -66,7 +67,9 @@ class GraphedStep:
             kw["noise"] = self.noise
         with kernels.deferred_reductions(self.flat):
             out = self.model(self.inputs, **kw)
-            out.loss.backward()
+            if self._seed is None or self._seed.shape != out.loss.shape:
+                self._seed = torch.ones_like(out.loss)  # the backward seed, filled once (not one launch per replay)
+            out.loss.backward(gradient=self._seed)
         return out
 
     def matches(self, inputs):

@@ -1095,3 +1095,23 @@ def test_public_base_utils_helpers_match_reference_goldens():
         rr = recon.detach().cpu().clone().requires_grad_(True)
         (elbo.recon_log_prob(name, rr, tgt.cpu(), params.get("scale", 1.0)) * wgt.cpu()).sum().backward()
         close(rg.grad, rr.grad, rtol=1e-4, what="d log_prob " + name)
+
+
+@pytest.mark.parametrize("M,N,K,layout", [(512, 20, 2048, "kn"), (512, 20, 400, "nk"), (37, 5, 12, "nk"), (1, 32, 64, "kn"),
+                                          (130, 17, 100, "kn")])
+def test_heads_fwd_matches_float64(M, N, K, layout):
+    """mvk_heads_fwd: both encoder heads in one launch (exact fp32 MFMA, K split over 4 waves) vs float64 on the CPU;
+    `nk` = torch Linear weights [N][K], `kn` = the packed convolution heads [K][N]; ragged M / N / K tails."""
+    from multivae_amd import kernels as K_
+
+    DEV = dev()
+    gen = g(M * 7 + N)
+    x = torch.randn(M, K, generator=gen)
+    w = [torch.randn(N, K, generator=gen) / K ** 0.5 for _ in range(2)]
+    b = [torch.randn(N, generator=gen) for _ in range(2)]
+    wd = [(wi if layout == "nk" else wi.t().contiguous()).to(DEV) for wi in w]
+    sk, sn = (1, K) if layout == "nk" else (N, 1)
+    mu, lv = K_.heads_fwd(x.to(DEV), wd[0], b[0].to(DEV), wd[1], b[1].to(DEV), N, sk, sn)
+    for got, wi, bi in ((mu, w[0], b[0]), (lv, w[1], b[1])):
+        ref = (x.double() @ wi.double().t() + bi.double()).float()
+        close_elementwise(got.cpu(), ref, "heads_fwd", rtol=2e-6, atol_frac=2e-6)
