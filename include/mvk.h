@@ -492,8 +492,11 @@ int mvk_heads_fwd(const float* X, const float* W0, const float* b0, float* Y0, c
  * immediate kernels: results are bit-reproducible run to run).  A producer that does not fit (arena full, a second
  * accumulation into the same parameter while one is queued, a target outside the gradient buffer) finishes immediately
  * as without deferral.  The caller must flush before anything reads the gradient buffer (all-reduce, optimizer step) and
- * must keep `arena` alive and unused by others until then.  mvk_defer_begin returns MVK_EINVAL while finishes are
- * pending; mvk_defer_end = flush + off; mvk_defer_pending = number of queued finishes. */
+ * must keep `arena` alive and unused by others until then.  mvk_defer_flush may be called on ANY stream in the middle of
+ * the backward pass (e.g. a side stream, once the decoders are done: the finishes then run beside the latency-bound
+ * encoder backward); the arena regions it reads stay reserved and the next flush waits for it.  mvk_defer_end(stream) =
+ * final flush on `stream` + off: after it (in stream order) the gradient buffer is complete.  mvk_defer_begin returns
+ * MVK_EINVAL while finishes are pending; mvk_defer_pending = number of queued finishes. */
 int mvk_defer_begin(float* arena, int64_t arena_floats, const float* grad, int64_t grad_floats);
 int mvk_defer_flush(void* stream);
 int mvk_defer_end(void* stream);

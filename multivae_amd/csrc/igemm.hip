@@ -59,7 +59,8 @@ static int defer_push(const Epilogue& e, int M, int N, int nz, long long zstride
   it.nz = nz;
   it.zstride = zstride;
   it.vec4 = ((long long)M * N) % 4 == 0 && zstride % 4 == 0 && mvk_aligned16(e.ws);
-  it.zl_bits = nz > 64 ? 5 : 3;
+  static const int zl_env = getenv("MVK_DEFER_ZL") ? atoi(getenv("MVK_DEFER_ZL")) : 5;  // z-lanes of long reductions (A/B)
+  it.zl_bits = nz > 64 ? zl_env : 3;
   g_defer.items.push_back(it);
   return MVK_OK;
 }
@@ -93,13 +94,10 @@ extern "C" int mvk_defer_begin(float* arena, int64_t arena_floats, const float* 
   return MVK_OK;
 }
 
-extern "C" int mvk_defer_flush(void* stream) {
+static int defer_flush_locked(hipStream_t s, bool last) {
   using namespace mvk;
-  hipStream_t s = mvk_stream(stream);
-  std::lock_guard<std::mutex> lock(g_defer.mu);
-  if (!g_defer.active) return MVK_OK;
   // order this stream behind every stream a gradient producer ran on (autograd replays a branch's backward on the
-  // stream of its forward)
+  // stream of its forward; an earlier partial flush counts as a producer)
   size_t ev = 0;
   for (hipStream_t t : g_defer.streams) {
     if (t == s) continue;
@@ -113,7 +111,8 @@ extern "C" int mvk_defer_flush(void* stream) {
     ++ev;
   }
   g_defer.streams.clear();
-  for (size_t i0 = 0; i0 < g_defer.items.size(); i0 += DEFER_BATCH) {
+  int rc = MVK_OK;
+  for (size_t i0 = 0; i0 < g_defer.items.size() && rc == MVK_OK; i0 += DEFER_BATCH) {
     DeferTable T{};
     unsigned blocks = 0;
     for (size_t i = i0; i < g_defer.items.size() && i < i0 + DEFER_BATCH; ++i) {
@@ -124,20 +123,26 @@ extern "C" int mvk_defer_flush(void* stream) {
       blocks += (unsigned)(((long long)it.M * it.N + per - 1) / per);
     }
     hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3(blocks), dim3(256), 0, s, T);
-    if (hipGetLastError() != hipSuccess) {
-      g_defer.items.clear();
-      g_defer.used = 0;
-      return MVK_ELAUNCH;
-    }
+    if (hipGetLastError() != hipSuccess) rc = MVK_ELAUNCH;
   }
   g_defer.items.clear();
-  g_defer.used = 0;
-  return MVK_OK;
+  if (last)
+    g_defer.used = 0;
+  else
+    defer_note_stream(s);  // the arena regions stay reserved (this launch may still read them) and the next flush waits for it
+  return rc;
+}
+
+extern "C" int mvk_defer_flush(void* stream) {
+  std::lock_guard<std::mutex> lock(mvk::g_defer.mu);
+  if (!mvk::g_defer.active) return MVK_OK;
+  return defer_flush_locked(mvk_stream(stream), false);
 }
 
 extern "C" int mvk_defer_end(void* stream) {
-  const int rc = mvk_defer_flush(stream);
   std::lock_guard<std::mutex> lock(mvk::g_defer.mu);
+  if (!mvk::g_defer.active) return MVK_OK;
+  const int rc = defer_flush_locked(mvk_stream(stream), true);
   mvk::g_defer.active = false;
   return rc;
 }
@@ -678,6 +683,9 @@ static int launch_with_colsum(GemmDesc& d, int zdim, float* db, float* ws, int64
 using namespace mvk;
 
 namespace mvk {
+// skinny.hip: short-reduction linear layer (K <= 32): 1 = shape not covered
+int smallk_fwd(const float* X, const float* W, long long w_sk, long long w_sn, const float* bias, int bias_mod, int act,
+               float* Y, int M, int N, int K, hipStream_t s);
 // imgconv.hip: register-stationary-weight kernels for the 4x4/stride-2 layer pairs (1 = shape not covered)
 int imgconv_up(const float* V, const float* Wup, const void* wfrag, const float* bias, float* U, int n, int h, int w, int Cu,
                int Cv, int act, const float* u_act_src, int u_act, float* colsum_part, int* part_rows, hipStream_t s);
@@ -715,6 +723,10 @@ int mvk_linear_fwd(const float* X, const float* W, const float* b, float* Y, int
                    float* ws, int64_t ws_floats, void* stream) {
   if (M == 0) return MVK_OK;  // empty batch: nothing to launch (torch hands out NULL for empty tensors)
   if (!X || !W || !Y || M < 0 || N <= 0 || K <= 0) return MVK_EINVAL;
+  if (K <= 32) {
+    const int rc = smallk_fwd(X, W, 1, K, b, N, act, Y, M, N, K, mvk_stream(stream));
+    if (rc != 1) return rc;
+  }
   GemmDesc d{};
   plain_a(d.a, X, K, 1, M, K);
   plain_b(d.b, W, 1, K, K, N);  // B[k][n] = W[n][k]
@@ -826,6 +838,10 @@ int mvk_gemm(const float* A, const float* B, float* C, int M, int N, int K, int 
              int bias_mod, int act, int accumulate, const float* a_act_src, int a_act, const float* c_act_src,
              int c_act, float* ws, int64_t ws_floats, void* stream) {
   if (!A || !B || !C || M < 0 || N <= 0 || K <= 0) return MVK_EINVAL;
+  if (K <= 32 && !ta && !accumulate && !a_act_src && !c_act_src && M > 0) {
+    const int rc = smallk_fwd(A, B, tb ? 1 : N, tb ? K : 1, bias, bias_mod, act, C, M, N, K, mvk_stream(stream));
+    if (rc != 1) return rc;
+  }
   GemmDesc d{};
   if (ta)
     plain_a(d.a, A, 1, M, M, K);

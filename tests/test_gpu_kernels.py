@@ -1115,3 +1115,30 @@ def test_heads_fwd_matches_float64(M, N, K, layout):
     for got, wi, bi in ((mu, w[0], b[0]), (lv, w[1], b[1])):
         ref = (x.double() @ wi.double().t() + bi.double()).float()
         close_elementwise(got.cpu(), ref, "heads_fwd", rtol=2e-6, atol_frac=2e-6)
+
+
+@pytest.mark.parametrize("M,N,K,tb,act,bias_mod", [(5120, 2048, 20, False, "relu", 128), (5120, 400, 20, True, "relu", 400),
+                                                   (37, 8, 5, True, "none", 8), (9, 1028, 32, False, "sigmoid", 4),
+                                                   (1, 4, 1, False, "none", 0), (600, 64, 13, True, "leaky", 64)])
+def test_short_reduction_linear_matches_float64(M, N, K, tb, act, bias_mod):
+    """K <= 32: mvk_gemm / mvk_linear_fwd take the register-resident-weight kernel (skinny.hip, exact fp32 FMA chains)
+    instead of the tiled MFMA engine; both weight layouts, every activation, bias period, ragged tails; vs float64."""
+    from multivae_amd import kernels as K_
+
+    d = dev()
+    gen = g(M + 3 * N + K)
+    x = torch.randn(M, K, generator=gen)
+    w = torch.randn(K, N, generator=gen) / K ** 0.5          # B[k][n]
+    b = torch.randn(bias_mod, generator=gen) if bias_mod else None
+    code = dict(none=K_.NONE, relu=K_.RELU, sigmoid=K_.SIGMOID, leaky=K_.ACT["leaky_relu_0.2"])[act]
+    ref = x.double() @ w.double()
+    if b is not None:
+        ref = ref + b.double().repeat(N // bias_mod)
+    ref = dict(none=lambda t: t, relu=torch.relu, sigmoid=torch.sigmoid,
+               leaky=lambda t: torch.nn.functional.leaky_relu(t, 0.2))[act](ref)
+    wd = (w.t().contiguous() if tb else w).to(d)
+    got = K_.gemm(x.to(d), wd, M, N, K, tb=tb, bias=None if b is None else b.to(d), bias_mod=bias_mod, act=code)
+    close_elementwise(got, ref.float(), "short-reduction linear", rtol=2e-6, atol_frac=2e-6)
+    if tb and bias_mod == N:  # the same through mvk_linear_fwd (torch Linear layout)
+        got2 = K_.linear_fwd(x.to(d), wd, b.to(d), code)
+        assert torch.equal(got2, got)
