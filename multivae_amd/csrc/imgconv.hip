@@ -30,6 +30,11 @@
 
 namespace mvk {
 
+#ifdef MVK_ICPROF  // tools/imgconv_phase.py: per-wave cycle counters (total, waiting at the tile barrier, k-loops)
+__device__ unsigned long long* g_ic_dbg = nullptr;
+#define IC_CLK() __builtin_readcyclecounter()
+#endif
+
 enum { IC_UP = 0, IC_DOWN = 1 };
 
 struct ImgConvArgs {
@@ -100,6 +105,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   using T = ICfg<KIND, HS, CIN, COUT>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   mvk_prof_begin(g.prof);
+#ifdef MVK_ICPROF
+  const unsigned long long ic_t0 = IC_CLK();
+  unsigned long long ic_bar = 0, ic_k = 0, ic_pre = 0, ic_post = 0, ic_tend = 0;
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, kg = lane >> 5;
   const int wgtype = blockIdx.x % T::WG_TYPES;
@@ -280,6 +289,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       float* const outp_prev = (tt > 0 || first) ? outp_cur : outp_cur - OUT_UNIT;
       const float validf = first ? 0.f : 1.f;
       f32x16 acc0 = {0}, acc1 = {0};
+#ifdef MVK_ICPROF
+      const unsigned long long ic_k0 = IC_CLK();
+#endif
 #pragma unroll
       for (int pr = 0; pr < 8; ++pr) {
         bf16x8 a_nxt[2][3];
@@ -310,7 +322,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int m = 0; m < 6; ++m) {
           acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][PA[m]], Bw[q0][c0][PB[m]], acc0, 0, 0, 0);
+#ifdef MVK_IC_ONECHAIN
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][PA[m]], Bw[q1][c1][PB[m]], acc0, 0, 0, 0);
+#else
           acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][PA[m]], Bw[q1][c1][PB[m]], acc1, 0, 0, 0);
+#endif
         }
         if (pr < 7) {
 #pragma unroll
@@ -318,8 +334,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) a_cur[h][pc] = a_nxt[h][pc];
         }
+#ifndef MVK_IC_SCHED
+#define MVK_IC_SCHED (HS == 8 ? 5 : 6)
+#endif
+        // One wave per SIMD: the ~28 idle issue cycles behind an MFMA hide about five single-issue instructions, a cluster
+        // of MFMAs hides none — and hipcc clusters the 12 MFMAs of a k-step pair (108 of 191 MFMA-to-MFMA gaps empty,
+        // the VALU / LDS / memory work in bursts of 7-20 between the clusters).  Ask the scheduler for the pipeline
+        // "1 MFMA, N others" instead (N = 4 ... 10 measured: 5-6 is best; cycles per wave at n = 5120:
+        // down 8x8 254 k -> 214 k, down 4x4 262 k -> 222 k, up 4x4 218 k -> 197 k, up 8x8 174 k -> 168 k).
+        if (MVK_IC_SCHED > 0) {
+#pragma unroll
+          for (int m = 0; m < 12; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x496, MVK_IC_SCHED > 0 ? MVK_IC_SCHED : 1, 0);  // VALU | SALU | VMEM | DS | TRANS
+          }
+        }
       }
+#ifdef MVK_ICPROF
+      ic_k += IC_CLK() - ic_k0;
+      const unsigned long long ic_p0 = IC_CLK();
+#endif
+#ifndef MVK_IC_ONECHAIN
       acc0 += acc1;
+#endif
       // next tile: same unit and buffer, or the first tile of the next unit in the other buffer (complete after the
       // barrier below; the last unit of the workgroup re-reads a converted copy of itself, unused)
       const char* const next_buf = (tt + 1 < T::TPU) ? abuf : nbuf;
@@ -336,7 +373,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int o = 0; o < T::OWN; ++o) dst[o * 64 + lane] = acc0[r * T::OWN + o];
         }
+#ifdef MVK_ICPROF
+        const unsigned long long ic_b0 = IC_CLK();
+        ic_pre += ic_b0 - ic_p0;
         __syncthreads();
+        ic_tend = IC_CLK();
+        ic_bar += ic_tend - ic_b0;
+#else
+        __syncthreads();
+#endif
         read_pair(a_cur, next_buf, ntt, 0);
         const float* src = reinterpret_cast<const float*>(xb + wave * T::XWAVE);
 #pragma unroll
@@ -361,12 +406,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       } else {
 #pragma unroll
         for (int o = 0; o < T::OWN; ++o) res_prev[o] = acc0[o];
+#ifdef MVK_ICPROF
+        const unsigned long long ic_b0 = IC_CLK();
+        ic_pre += ic_b0 - ic_p0;
         if (tt == T::TPU - 1) __syncthreads();
+        ic_tend = IC_CLK();
+        ic_bar += ic_tend - ic_b0;
+#else
+        if (tt == T::TPU - 1) __syncthreads();
+#endif
         read_pair(a_cur, next_buf, ntt, 0);
       }
 #pragma unroll
       for (int o = 0; o < T::OWN; ++o) msk_prev[o] = msk_cur[o];
       first = false;
+#ifdef MVK_ICPROF
+      ic_post += IC_CLK() - ic_tend;
+#endif
     }
   }
   if (u0 < u1) {  // epilogue of the last tile
@@ -395,6 +451,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       g.colsum_part[(long long)blockIdx.x * COUT + tid] = s;
     }
   }
+#ifdef MVK_ICPROF
+  if (g_ic_dbg && lane == 0) {
+    unsigned long long* o = g_ic_dbg + (blockIdx.x * 4 + wave) * 4;
+    o[0] = IC_CLK() - ic_t0;
+    o[1] = ic_bar;
+    o[2] = ic_k;
+    o[3] = (ic_pre << 32) | (ic_post & 0xffffffffull);
+  }
+#endif
   mvk_prof_end(g.prof);
 }
 
@@ -619,6 +684,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int b = 0; b < T::NT; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[a][PA[m]], Bf[b][PB[m]], acc[a][b], 0, 0, 0);
+#ifndef MVK_IW_SCHED
+#define MVK_IW_SCHED 4
+#endif
+      if (MVK_IW_SCHED > 0) {  // "1 MFMA, N others" instead of hipcc's MFMA clusters (see imgconv_kernel)
+#pragma unroll
+        for (int m = 0; m < 6 * T::MT * T::NT; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x496, MVK_IW_SCHED > 0 ? MVK_IW_SCHED : 1, 0);
+        }
+      }
       if (s + 1 < T::KS) {
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) {
@@ -704,3 +779,9 @@ int imgconv_down(const float* U, const float* Wdown, const void* wfrag, const fl
 }
 
 }  // namespace mvk
+
+#ifdef MVK_ICPROF
+extern "C" int mvk_imgconv_debug_buffer(unsigned long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(mvk::g_ic_dbg), &p, sizeof(p)) == hipSuccess ? 0 : -2;
+}
+#endif
