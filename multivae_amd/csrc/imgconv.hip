@@ -26,7 +26,14 @@
 //
 // Per 32-row tile a wave issues 96 MFMAs (3072 matrix-pipe cycles) against 48 ds_read_b128, <= 8 global loads and
 // ~100-200 VALU: the loop is MFMA-bound by construction.
+#include <cstdlib>
+#include <type_traits>
+
 #include "bf3.hpp"
+
+#ifndef MVK_IC_SCHED
+#define MVK_IC_SCHED (HS == 8 ? 5 : 4)  // "others" per MFMA of the scheduling pipeline in imgconv_kernel (0 = hipcc's own order)
+#endif
 
 namespace mvk {
 
@@ -100,7 +107,7 @@ __device__ __forceinline__ bf16x8 ic_pack8(const unsigned (&d)[4]) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int KIND, int HS, int CIN, int COUT, bool HAS_SRC>
+template <int KIND, int HS, int CIN, int COUT, bool HAS_SRC, bool PIPE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void imgconv_kernel(const ImgConvArgs g) {
   using T = ICfg<KIND, HS, CIN, COUT>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -158,6 +165,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int pc = 0; pc < 3; ++pc) Bw[q][c][pc] = ic_pack8(p[pc]);
     }
   }
+
+  // The 192 weight registers live in the ACCUMULATOR half of the register file: gfx950's MFMA takes its A / B operands from
+  // AGPRs as well as VGPRs, and an empty asm with an "=a" output makes the value an AGPR citizen for hipcc (its MFMA
+  // builtin then reads a[...] directly).  Without this the kernel needs ~330 architectural VGPRs, hipcc parks ~100 of
+  // the weight registers in AGPRs as SPILLS and pays one v_accvgpr_read per MFMA to bring them back (203 reads per 192
+  // MFMAs in the 32 -> 64 channel kernel) — in a loop whose budget is ~5 non-MFMA instructions per MFMA.
+#pragma unroll
+  for (int q = 0; q < T::NTAPS; ++q)
+#pragma unroll
+    for (int c = 0; c < T::CHUNKS; ++c)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+        bf16x8 t = Bw[q][c][pc];
+        asm volatile("" : "=a"(Bw[q][c][pc]) : "0"(t));
+      }
 
   // ---- LDS geometry -----------------------------------------------------------------------------------------------
   char* const xbase = lds + 2 * T::BUF;
@@ -272,6 +294,180 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
   bf16x8 a_cur[2][3];
   if (u0 < u1) read_pair(a_cur, lds, 0, 0);
+  if (PIPE) {
+    // ---- main loop, two-tile latency (default) --------------------------------------------------------------------
+    // With one barrier at the END of every tile the waves spend a third of their cycles between k-loops (measured with
+    // the in-kernel counters of tools/imgconv_phase.sh: accumulator read-out + exchange writes before the barrier, first
+    // fragments + exchange reads behind it, the matrix pipe idle meanwhile).  Here tile T carries, inside its k-loop:
+    //   pair 0    : the sum of tile T-1's two accumulator chains and (tap-split kernels) its exchange slices -> LDS
+    //   pairs 0-7 : the epilogue slices of tile T-2 and the mask loads of tile T-1
+    //   pairs 0-6 : the conversion of the next unit (first tile of a unit)
+    //   after pair 6: THE barrier (publishes the exchange slices and the converted unit; the other buffer is free)
+    //   pair 7    : the first fragments of tile T+1 and the exchange read of tile T-1 (result of T-1, consumed by T+1)
+    // so nothing but the barrier itself stands between the MFMAs of consecutive tiles.  Same sums in the same order as the
+    // one-tile-latency loop below (bit-identical results).
+    // The main loop is instantiated once per tap-split rank of the wave (KSC): every "is this my slice" test of the
+    // exchange is then a compile-time fact.  With a run-time rank hipcc emits exec-masked branches for them (it cannot
+    // prove the rank wave-uniform): ~40 tiny basic blocks per tile that no scheduling pipeline crosses.
+    auto run = [&](auto ks_tag) {
+    constexpr int KSC = decltype(ks_tag)::value;
+    f32x16 pend0 = {0}, pend1 = {0};          // accumulator chains of tile T-1
+    float own[T::OWN], res_next[T::OWN];
+#pragma unroll
+    for (int o = 0; o < T::OWN; ++o) own[o] = res_next[o] = 0.f;
+    int tcount = 0, xpar = 0;
+    constexpr int DU1 = 1, DU2 = T::TPU == 1 ? 2 : 1;  // units back of tiles T-1 (when tt == 0) and T-2
+    auto finish_pending = [&](char* xb) {  // pair 0: sum of the chains; exchange slices out, own slice kept
+      const f32x16 sum = pend0 + pend1;
+      if (T::KSPLIT > 1) {
+#pragma unroll
+        for (int r = 0; r < T::KSPLIT; ++r) {
+          if (r == KSC) continue;
+          const int dwave = T::WG_TYPES == 1 || KIND == IC_UP ? r * T::NCT + ct : r;
+          const int slot = KSC < r ? KSC : KSC - 1;
+          float* dst = reinterpret_cast<float*>(xb + dwave * T::XWAVE + slot * T::OWN * 256);
+#pragma unroll
+          for (int o = 0; o < T::OWN; ++o) dst[o * 64 + lane] = sum[r * T::OWN + o];
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < T::OWN; ++o) own[o] = sum[KSC * T::OWN + o];
+    };
+    auto gather_result = [&](const char* xb) {  // pair 7 (behind the barrier): ordered sum over the ranks
+      const float* src = reinterpret_cast<const float*>(xb + wave * T::XWAVE);
+#pragma unroll
+      for (int o = 0; o < T::OWN; ++o) {
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < T::KSPLIT; ++r) {
+          if (r == KSC) {
+            v += own[o];
+          } else {
+            const int slot = r < KSC ? r : r - 1;
+            v += src[(slot * T::OWN + o) * 64 + lane];
+          }
+        }
+        res_next[o] = v;
+      }
+    };
+    for (long long u = u0; u < u1; ++u) {
+      const int cur = (int)((u - u0) & 1);
+      const char* const abuf = lds + cur * T::BUF;
+      char* const nbuf = lds + (cur ^ 1) * T::BUF;
+      const f32x4* const src2 = unit_src(u + 2);
+      float* const outp_cur = g.out + u * OUT_UNIT;
+      const float* const srcp_cur = HAS_SRC ? g.act_src + u * OUT_UNIT : nullptr;
+#pragma unroll
+      for (int tt = 0; tt < T::TPU; ++tt) {
+        const int ptt1 = (tt + T::TPU - 1) % T::TPU;          // tile-in-unit index of tile T-1
+        const int ptt2 = (tt + 2 * T::TPU - 2) % T::TPU;      // ... of tile T-2 (== tt for TPU 1 and 2)
+        // rows of tile T-2; before there is one: the rows of THIS tile, which its real epilogue overwrites two tiles later
+        // (same lane, same address, program order), with weight 0 in the column sums
+        const bool valid2 = tcount >= 2;
+        float* const outp_e = valid2 ? outp_cur - DU2 * OUT_UNIT : outp_cur;
+        const float validf = valid2 ? 1.f : 0.f;
+        // mask of tile T-1 (consumed during tile T+1); before there is one: any readable rows
+        const float* const srcp_1 = !HAS_SRC ? nullptr : ((tt > 0 || tcount == 0) ? srcp_cur : srcp_cur - DU1 * OUT_UNIT);
+        char* const xb = xbase + xpar * T::XBUF;
+        const char* const next_buf = (tt + 1 < T::TPU) ? abuf : nbuf;
+        const int ntt = (tt + 1) % T::TPU;
+        f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+        for (int pr = 0; pr < 8; ++pr) {
+          bf16x8 a_nxt[2][3];
+          if (pr < 7) read_pair(a_nxt, abuf, tt, pr + 1);
+          if (pr == 0) finish_pending(xb);
+          if (tt == 0 && pr < 7) {  // conversion of the next unit: complete before the barrier behind pair 6
+            if (T::NF4 >= 8) {
+              constexpr int PER = T::NF4 / 8;
+#pragma unroll
+              for (int k = 0; k < (pr == 6 ? 2 * PER : PER); ++k) {
+                write_f4(nbuf, pr * PER + k);
+                raw[pr * PER + k] = src2[(pr * PER + k) * 256];
+              }
+            } else if (pr % (8 / T::NF4) == 0) {
+              write_f4(nbuf, pr / (8 / T::NF4));
+              raw[pr / (8 / T::NF4)] = src2[(pr / (8 / T::NF4)) * 256];
+            }
+          }
+#pragma unroll
+          for (int o = 0; o < T::OWN; ++o) {
+            if (o * 8 / T::OWN != pr) continue;
+            if (HAS_SRC) msk_cur[o] = srcp_1[obase + out_off(ptt1, o, 0)];
+            epilogue_row(outp_e, ptt2, o, validf);
+          }
+          constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {2, 1, 0, 1, 0, 0};  // small terms first
+          const int q0 = (2 * pr) / T::CHUNKS, c0 = (2 * pr) % T::CHUNKS;
+          const int q1 = (2 * pr + 1) / T::CHUNKS, c1 = (2 * pr + 1) % T::CHUNKS;
+#pragma unroll
+          for (int m = 0; m < 6; ++m) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][PA[m]], Bw[q0][c0][PB[m]], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][PA[m]], Bw[q1][c1][PB[m]], acc1, 0, 0, 0);
+          }
+          if (pr == 7) {  // behind the barrier: first fragments of the next tile, result of tile T-1
+            read_pair(a_nxt, next_buf, ntt, 0);
+            gather_result(xb);
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) a_cur[h][pc] = a_nxt[h][pc];
+          if (MVK_IC_SCHED > 0) {  // "1 MFMA, N others" (see the one-tile-latency loop)
+#pragma unroll
+            for (int m = 0; m < 12; ++m) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x496, MVK_IC_SCHED > 0 ? MVK_IC_SCHED : 1, 0);
+            }
+          }
+          if (pr == 6 && (T::KSPLIT > 1 || tt == T::TPU - 1)) __syncthreads();
+        }
+        pend0 = acc0;
+        pend1 = acc1;
+#pragma unroll
+        for (int o = 0; o < T::OWN; ++o) {
+          res_prev[o] = res_next[o];
+          msk_prev[o] = msk_cur[o];
+        }
+        xpar ^= 1;
+        ++tcount;
+      }
+    }
+    if (u0 < u1) {
+      // drain 1: finish the last tile (N-1), epilogue of tile N-2, masks of tile N-1
+      const long long ul = u1 - 1;
+      char* const xb = xbase + xpar * T::XBUF;
+      finish_pending(xb);
+      {
+        constexpr int tl2 = T::TPU == 1 ? 0 : T::TPU - 2;  // tile-in-unit index of tile N-2
+        const bool valid2 = tcount >= 2;
+        const long long u2 = T::TPU == 1 ? ul - 1 : ul;
+        float* const outp_e = g.out + (valid2 ? u2 : ul) * OUT_UNIT;
+        const float* const srcp_1 = HAS_SRC ? g.act_src + ul * OUT_UNIT : nullptr;
+#pragma unroll
+        for (int o = 0; o < T::OWN; ++o) {
+          if (HAS_SRC) msk_cur[o] = srcp_1[obase + out_off(T::TPU - 1, o, 0)];
+          epilogue_row(outp_e, valid2 ? tl2 : T::TPU - 1, o, valid2 ? 1.f : 0.f);
+        }
+      }
+      if (T::KSPLIT > 1) __syncthreads();
+      gather_result(xb);
+      // drain 2: epilogue of the last tile
+#pragma unroll
+      for (int o = 0; o < T::OWN; ++o) {
+        res_prev[o] = res_next[o];
+        msk_prev[o] = msk_cur[o];
+      }
+      float* const outp_last = g.out + ul * OUT_UNIT;
+#pragma unroll
+      for (int o = 0; o < T::OWN; ++o) epilogue_row(outp_last, T::TPU - 1, o, 1.f);
+    }
+    };
+    const int ks_u = __builtin_amdgcn_readfirstlane(ks);
+    if (T::KSPLIT == 1 || ks_u == 0) run(std::integral_constant<int, 0>{});
+    else if (T::KSPLIT > 1 && ks_u == 1) run(std::integral_constant<int, (T::KSPLIT > 1 ? 1 : 0)>{});
+    else if (T::KSPLIT > 2 && ks_u == 2) run(std::integral_constant<int, (T::KSPLIT > 2 ? 2 : 0)>{});
+    else if (T::KSPLIT > 3) run(std::integral_constant<int, (T::KSPLIT > 3 ? 3 : 0)>{});
+  } else {
   bool first = true;
   int xpar = 0;
   for (long long u = u0; u < u1; ++u) {
@@ -334,9 +530,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) a_cur[h][pc] = a_nxt[h][pc];
         }
-#ifndef MVK_IC_SCHED
-#define MVK_IC_SCHED (HS == 8 ? 5 : 6)
-#endif
         // One wave per SIMD: the ~28 idle issue cycles behind an MFMA hide about five single-issue instructions, a cluster
         // of MFMAs hides none — and hipcc clusters the 12 MFMAs of a k-step pair (108 of 191 MFMA-to-MFMA gaps empty,
         // the VALU / LDS / memory work in bursts of 7-20 between the clusters).  Ask the scheduler for the pipeline
@@ -431,6 +624,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int o = 0; o < T::OWN; ++o) epilogue_row(outp_last, T::TPU - 1, o, 1.f);
   }
 
+  }
   if (g.colsum_part) {  // fixed-order sum over the waves that share a column tile
     csum += __shfl_xor(csum, 32, 64);
     if (kg == 0) csred[wave * 32 + col] = csum;
@@ -467,20 +661,17 @@ template <int KIND, int HS, int CIN, int COUT>
 static int imgconv_launch(const ImgConvArgs& a, int* part_rows, hipStream_t s) {
   using T = ICfg<KIND, HS, CIN, COUT>;
   static bool attr_done = false;
-  auto kern = a.act_src ? imgconv_kernel<KIND, HS, CIN, COUT, true> : imgconv_kernel<KIND, HS, CIN, COUT, false>;
+  // MVK_IMGCONV_PIPE=0: the one-tile-latency main loop (A/B; results are bit-identical)
+  static const bool pipe = !(getenv("MVK_IMGCONV_PIPE") && atoi(getenv("MVK_IMGCONV_PIPE")) == 0);
+  auto kern = a.act_src ? (pipe ? imgconv_kernel<KIND, HS, CIN, COUT, true, true> : imgconv_kernel<KIND, HS, CIN, COUT, true, false>)
+                        : (pipe ? imgconv_kernel<KIND, HS, CIN, COUT, false, true> : imgconv_kernel<KIND, HS, CIN, COUT, false, false>);
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(imgconv_kernel<KIND, HS, CIN, COUT, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess)
-      return MVK_ELAUNCH;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(imgconv_kernel<KIND, HS, CIN, COUT, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess)
-      return MVK_ELAUNCH;
-    attr_done = true;
-  }
-  if (false) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            T::LDS_BYTES) != hipSuccess)
-      return MVK_ELAUNCH;
+    const void* all[4] = {reinterpret_cast<const void*>(imgconv_kernel<KIND, HS, CIN, COUT, true, true>),
+                          reinterpret_cast<const void*>(imgconv_kernel<KIND, HS, CIN, COUT, true, false>),
+                          reinterpret_cast<const void*>(imgconv_kernel<KIND, HS, CIN, COUT, false, true>),
+                          reinterpret_cast<const void*>(imgconv_kernel<KIND, HS, CIN, COUT, false, false>)};
+    for (const void* f : all)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return MVK_ELAUNCH;
     attr_done = true;
   }
   const int grid = 256;
