@@ -164,7 +164,11 @@ __global__ __launch_bounds__(NT) void small_up_fwd_kernel(const float* __restric
 // kernel lacks (measured with whole images: matrix pipe 42 % busy, 47 % of the wave cycles waiting to issue).
 // UACT / VACT >= 0: the activations are compile-time constants (sigmoid image, ReLU input map: the SVHN decoder); the
 // run-time codes cost a compare / select chain per element in a kernel that is bound by instruction issue.
-template <int CU, int CV, int NT, int PU, int OCC, int UACT, int VACT>
+// DENSE (whole 16x16 -> 32x32 images, NT = 256): the halo ring of the gradient tile is zero padding that never changes, so it is
+// zeroed once and a thread only ever stages INTERIOR elements — CU * 1024 of them = CU float4 per thread, read from the
+// contiguous NCHW image with 16-byte loads, channel = float4 index (no per-element geometry, masks or guards: the generic
+// path spends 14 4-byte loads x 2 tensors and ~25 compare / select / exec-mask instructions per element on them).
+template <int CU, int CV, int NT, int PU, int OCC, int UACT, int VACT, bool DENSE>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void small_up_bwd_kernel(const float* __restrict__ dU, const float* __restrict__ Uout,
                                                            int u_act_rt, const float* __restrict__ V, int v_act_rt,
                                                            const float* __restrict__ Wref, float* __restrict__ dV,
@@ -199,6 +203,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
   }
   for (int p = tid; p < P; p += NT) posoff[p] = (2 * (p / w)) * DW + 2 * (p % w);
   const bool active = wave * WP < P;
+  if (DENSE)
+    for (int i = tid; i < CU * DH * DW; i += NT) Ds[i] = 0.f;  // the halo stays zero for the whole launch
+  f32x4 qdu[CU], quo[CU];
+  float dblq[CU];
+#pragma unroll
+  for (int c = 0; c < CU; ++c) dblq[c] = 0.f;
+  const int dbase = ((tid >> 3) + 1) * 34 + (tid & 7) * 4 + 1;  // DENSE: tile offset of this thread's 4 pixels (row tid/8)
 
   f32x4 accw[C::NTV][CU];
 #pragma unroll
@@ -239,6 +250,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
     const int r2 = 2 * (int)(unit & (units - 1)) * hu;  // first output row of the unit
     const float* du = dU + img * CU * H2 * W2;
     const float* uo = Uout + img * CU * H2 * W2;
+    if (DENSE) {
+#pragma unroll
+      for (int k = 0; k < CU; ++k) {
+        qdu[k] = reinterpret_cast<const f32x4*>(du)[tid + k * NT];
+        quo[k] = reinterpret_cast<const f32x4*>(uo)[tid + k * NT];
+      }
+    } else
 #pragma unroll
     for (int u = 0; u < ND; ++u) {
       const int oh = r2 + (tinfo[u] & 255) - 1;
@@ -251,7 +269,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       const int idx = tid + u * NT;
-      pv[u] = src[idx < n4 ? idx : n4 - 1];
+      pv[u] = src[(DENSE || idx < n4) ? idx : n4 - 1];
     }
   };
   if ((long long)blockIdx.x < nunits) prefetch(blockIdx.x);
@@ -259,6 +277,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
     __syncthreads();  // previous unit's tiles are no longer read
     // --- stage dUpre with halo (sigmoid' applied here), bias-gradient partials, and the V tile
     const int r2s = 2 * (int)(unit & (units - 1)) * hu;  // first output row of the unit being staged
+    if (DENSE) {
+      if (!(abl & 16)) {
+#pragma unroll
+        for (int k = 0; k < CU; ++k)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = qdu[k][e] * mvk_act_grad_from_out(quo[k][e], u_act);
+            Ds[k * 34 * 34 + dbase + e] = v;
+            dblq[k] += v;
+          }
+      }
+    } else
 #pragma unroll
     for (int u = 0; u < ND; ++u) {
       const int idx = tid + u * NT;
@@ -274,14 +304,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       const int idx = tid + u * NT;
-      if (idx < n4 && !(abl & 32)) {
+      if ((DENSE || idx < n4) && !(abl & 32)) {
         const int pos = idx / (CV / 4), q = idx - pos * (CV / 4);
         *reinterpret_cast<f32x4*>(Vs + pos * C::VS + 4 * q) = pv[u];
       }
     }
     __syncthreads();
     if (unit + gridDim.x < nunits && !(abl & 8)) prefetch(unit + gridDim.x);
-    if (!active) continue;
+    if (!DENSE && !active) continue;
     // --- backward data: dV[pos][cv] = sum_{k=(cu,kh,kw)} dUpre[cu][2i-1+kh][2j-1+kw] * W[cv][k]
     f32x4 acc[MT][C::NTV];
 #pragma unroll
@@ -370,6 +400,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
   float dbl[CU];
 #pragma unroll
   for (int c = 0; c < CU; ++c) dbl[c] = 0.f;
+  if (DENSE) {
+#pragma unroll
+    for (int c = 0; c < CU; ++c) dbl[c] = dblq[c];
+  } else
 #pragma unroll
   for (int u = 0; u < ND; ++u)
 #pragma unroll
@@ -588,10 +622,15 @@ static int launch_bwd(const float* dU, const float* Uout, int u_act, const float
   const size_t lds = bwd_lds<CU, CV>(h / units, w);
   constexpr int NT = MVK_SMALL_BWD_THREADS;
   if (lds > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_bwd_kernel<CU, CV, NT, 256, 2, -1, -1>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_bwd_kernel<CU, CV, NT, 256, 2, -1, -1, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(
-        reinterpret_cast<const void*>(small_up_bwd_kernel<CU, CV, NT, 256, 2, MVK_ACT_SIGMOID, MVK_ACT_RELU>),
+        reinterpret_cast<const void*>(small_up_bwd_kernel<CU, CV, NT, 256, 2, MVK_ACT_SIGMOID, MVK_ACT_RELU, false>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_bwd_kernel<CU, CV, NT, 256, 2, -1, -1, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(
+        reinterpret_cast<const void*>(small_up_bwd_kernel<CU, CV, NT, 256, 2, MVK_ACT_SIGMOID, MVK_ACT_RELU, true>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   // algorithmic bytes: image gradient + image read once, the saved input map read once, its gradient written once
@@ -604,18 +643,23 @@ static int launch_bwd(const float* dU, const float* Uout, int u_act, const float
 #else
   constexpr int abl_bits = 0;
 #endif
-#define MVK_SUB_LAUNCH(PU_, OCC_, UA_, VA_, UNITS_)                                                                          \
-  hipLaunchKernelGGL((small_up_bwd_kernel<CU, CV, NT, PU_, OCC_, UA_, VA_>), dim3(grid), dim3(NT), lds, s, dU, Uout, u_act, V, \
-                     v_act, Wref, dV, ws, n, h, w, (UNITS_) | abl_bits, prof)
+#define MVK_SUB_LAUNCH(PU_, OCC_, UA_, VA_, UNITS_, DENSE_)                                                               \
+  hipLaunchKernelGGL((small_up_bwd_kernel<CU, CV, NT, PU_, OCC_, UA_, VA_, DENSE_>), dim3(grid), dim3(NT), lds, s, dU, Uout, \
+                     u_act, V, v_act, Wref, dV, ws, n, h, w, (UNITS_) | abl_bits, prof)
+  static const int dense_env = getenv("MVK_SMALL_BWD_DENSE") ? atoi(getenv("MVK_SMALL_BWD_DENSE")) : 1;  // A/B switch
+  const bool dense = dense_env && h == 16 && w == 16 && NT == 256 && mvk_aligned16(dU) && mvk_aligned16(Uout);
   if (units == 2 && occ_env == 4) {
-    if (spec) MVK_SUB_LAUNCH(128, 4, MVK_ACT_SIGMOID, MVK_ACT_RELU, 2);
-    else MVK_SUB_LAUNCH(128, 4, -1, -1, 2);
+    if (spec) MVK_SUB_LAUNCH(128, 4, MVK_ACT_SIGMOID, MVK_ACT_RELU, 2, false);
+    else MVK_SUB_LAUNCH(128, 4, -1, -1, 2, false);
   } else if (units == 2) {
-    if (spec) MVK_SUB_LAUNCH(128, 3, MVK_ACT_SIGMOID, MVK_ACT_RELU, 2);
-    else MVK_SUB_LAUNCH(128, 3, -1, -1, 2);
+    if (spec) MVK_SUB_LAUNCH(128, 3, MVK_ACT_SIGMOID, MVK_ACT_RELU, 2, false);
+    else MVK_SUB_LAUNCH(128, 3, -1, -1, 2, false);
+  } else if (dense) {
+    if (spec) MVK_SUB_LAUNCH(256, 2, MVK_ACT_SIGMOID, MVK_ACT_RELU, 1, true);
+    else MVK_SUB_LAUNCH(256, 2, -1, -1, 1, true);
   } else {
-    if (spec) MVK_SUB_LAUNCH(256, 2, MVK_ACT_SIGMOID, MVK_ACT_RELU, 1);
-    else MVK_SUB_LAUNCH(256, 2, -1, -1, 1);
+    if (spec) MVK_SUB_LAUNCH(256, 2, MVK_ACT_SIGMOID, MVK_ACT_RELU, 1, false);
+    else MVK_SUB_LAUNCH(256, 2, -1, -1, 1, false);
   }
 #undef MVK_SUB_LAUNCH
   MVK_CHECK_LAUNCH();

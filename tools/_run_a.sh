@@ -1,3 +1,2 @@
-timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -E "^E  |FAILED|passed|failed" | head -10
-for i in 1 2 3; do timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 | python -c "
-import json,sys;d=json.loads(sys.stdin.read());print(d['value'],d['ms_per_step'],d['roofline_mfma']['achieved'],d['roofline_mfma']['us_per_step'])"; done
+timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "svhn or small or conv" 2>&1 | tail -1
+for v in "MVK_SMALL_BWD_DENSE=0" "MVK_SMALL_BWD_DENSE=1" "MVK_SMALL_BWD_DENSE=0" "MVK_SMALL_BWD_DENSE=1"; do echo -n "$v  "; env $v python tools/smallup_probe.py 5120 7 | grep bwd | cut -c1-45; done
