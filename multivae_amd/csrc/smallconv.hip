@@ -43,7 +43,8 @@ struct SmallCfg {
 // ---------------------------------------------------------------------------------------------------------
 // forward: U[n,Cu,2h,2w] = act(convT(V[n,h,w,Cv]) + b)
 // ---------------------------------------------------------------------------------------------------------
-template <int CU, int CV, int NT>
+// DENSE: every per-element guard is a compile-time fact (16x16 inputs, the tile sizes divide the workgroup evenly)
+template <int CU, int CV, int NT, bool DENSE>
 __global__ __launch_bounds__(NT) void small_up_fwd_kernel(const float* __restrict__ V, const float* __restrict__ Wref,
                                                            const float* __restrict__ bias, float* __restrict__ U, int n,
                                                            int h, int w, int act, mvk_prof_slot* prof) {
@@ -65,10 +66,10 @@ __global__ __launch_bounds__(NT) void small_up_fwd_kernel(const float* __restric
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       const int idx = tid + u * NT;
-      pre[u] = src[idx < n4 ? idx : n4 - 1];  // clamped: unconditional loads keep pre[] in registers
+      pre[u] = src[(DENSE || idx < n4) ? idx : n4 - 1];  // clamped: unconditional loads keep pre[] in registers
     }
   };
-  const bool active = wave * WP < P;
+  const bool active = DENSE || wave * WP < P;
   const int H2 = 2 * h, W2 = 2 * w;
   const int per_img = CU * H2 * W2;
   // Output geometry is the same for every image: this thread's outputs o = tid + 256 t and, for each, the LDS
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(NT) void small_up_fwd_kernel(const float* __restric
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       const int idx = tid + u * NT;
-      if (idx < n4) {
+      if (DENSE || idx < n4) {
         const int pos = idx / (CV / 4), q = idx - pos * (CV / 4);
         *reinterpret_cast<f32x4*>(buf + pos * C::VS + 4 * q) = pre[u];
       }
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(NT) void small_up_fwd_kernel(const float* __restric
 #pragma unroll
     for (int t = 0; t < NO; ++t) {
       const int o = tid + t * NT;
-      if (o < per_img) {
+      if (DENSE || o < per_img) {
         const float sum = ((buf[tap[t][0]] + buf[tap[t][1]]) + (buf[tap[t][2]] + buf[tap[t][3]])) + bia[t];
         out[o] = mvk_act(sum, act);
       }
@@ -590,13 +591,21 @@ static int launch_fwd(const float* V, const float* Wref, const float* bias, floa
                       hipStream_t s) {
   const size_t lds = fwd_lds<CU, CV>(h * w);
   constexpr int NT = MVK_SMALL_FWD_THREADS;
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_fwd_kernel<CU, CV, NT>),
+  if (lds > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_fwd_kernel<CU, CV, NT, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_fwd_kernel<CU, CV, NT, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
   const int grid = n < 512 ? n : 512;  // persistent: 2 workgroups per CU, each loops over images with prefetch
   // algorithmic bytes: the input map read once, the image written once
   mvk_prof_slot* prof = mvk::prof_next(5, 4.0 * n * h * w * (CV + 4.0 * CU));
-  hipLaunchKernelGGL((small_up_fwd_kernel<CU, CV, NT>), dim3(grid), dim3(NT), lds, s, V, Wref, bias, U, n, h, w, act, prof);
+  // dense: 256 positions = one 16-row tile per wave, CV / 4 * 256 float4 and CU * 1024 outputs divide the workgroup evenly
+  const bool dense = h == 16 && w == 16 && NT == 1024 && (256 * CV / 4) % NT == 0 && (CU * 1024) % NT == 0;
+  if (dense)
+    hipLaunchKernelGGL((small_up_fwd_kernel<CU, CV, NT, true>), dim3(grid), dim3(NT), lds, s, V, Wref, bias, U, n, h, w, act, prof);
+  else
+    hipLaunchKernelGGL((small_up_fwd_kernel<CU, CV, NT, false>), dim3(grid), dim3(NT), lds, s, V, Wref, bias, U, n, h, w, act, prof);
   MVK_CHECK_LAUNCH();
   mvk::prof_fold(prof, s);
   return MVK_OK;
