@@ -10,7 +10,7 @@ for c in cfg3 cfg3k1 cfg2 cfg5 cfg4; do
   timeout 900 python bench.py --config $c --steps 20 --warmup 5 2> $OUT/bench_$c.err | tail -1 > $OUT/bench_$c.json
 done
 timeout 600 python bench.py --config cfg2 --family laplace_with_softmax --loss dreg_looser --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_cfg2_laplace_dreg.json
-timeout 900 python bench.py --config cfg4 --batch 128 --no-graph --steps 5 --warmup 2 --no-cpu-baseline 2> $OUT/bench_cfg4_b128_eager.err | grep '^{' | tail -1 > $OUT/bench_cfg4_b128_eager.json
+timeout 900 python bench.py --config cfg4 --batch 64 --no-graph --steps 5 --warmup 2 --no-cpu-baseline 2> $OUT/bench_cfg4_b64_eager.err | grep "^{" | tail -1 > $OUT/bench_cfg4_b64_eager.json
 # 3. trainer loop throughput
 timeout 300 python tools/trainer_bench.py cfg3 5 2>/dev/null | tail -1 > $OUT/trainer_cfg3.json
 timeout 300 python tools/trainer_bench.py cfg1 4 2>/dev/null | tail -1 > $OUT/trainer_cfg1.json

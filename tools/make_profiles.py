@@ -28,7 +28,7 @@ line = json_line(f"{SRC}/bench_under_rocprof.log")
 open(f"{DST}/{TAG}_bench_under_rocprof.json", "w").write(json.dumps(line, indent=1) + "\n")
 # 2. bench lines of every configuration
 with open(f"{DST}/{TAG}_bench_lines.jsonl", "w") as f:
-    for c in ("cfg3", "cfg3k1", "cfg2", "cfg2_laplace_dreg", "cfg5", "cfg4", "cfg4_b128_eager", "force_dist"):
+    for c in ("cfg3", "cfg3k1", "cfg2", "cfg2_laplace_dreg", "cfg5", "cfg4", "cfg4_b64_eager", "force_dist"):
         p = f"{SRC}/bench_{c}.json"
         d = json_line(p) if os.path.exists(p) else None
         if d:
@@ -83,10 +83,14 @@ with open(f"{DST}/{TAG}_pmc_mfma.md", "w") as f:
     for r in der:
         f.write(f"| {r[0]} | {r[1]:.1f} | {r[2] / 1e3:.0f} k | {r[3]:.2f} | {100 * r[4]:.0f} % | {100 * r[5]:.0f} % | {100 * r[6]:.0f} % | "
                 f"{100 * r[7]:.0f} % | {r[8]:.1f} | {r[9]:.0f} |\n")
-    f.write("\nReading: the matrix pipe is busy 46-69 % of the wave's cycles; the clock under this load is 1.7-1.9 GHz (not the 2.4 GHz of the\n"
-            "data sheet), so the practical ceiling of a 21.47-GFLOP launch is 122.9 k cycles / 1.8 GHz = 68 us, not 51 us.  `issue-stalled`\n"
+    lo, hi = min(r[4] for r in der), max(r[4] for r in der)
+    clo, chi = min(r[3] for r in der), max(r[3] for r in der)
+    f.write(f"\nReading: the matrix pipe is busy {100 * lo:.0f}-{100 * hi:.0f} % of the wave's cycles; the clock under this load is "
+            f"{clo:.2f}-{chi:.2f} GHz (not the 2.4 GHz of the\ndata sheet), so the practical ceiling of a 21.47-GFLOP launch is 122.9 k "
+            f"cycles / {0.5 * (clo + chi):.2f} GHz = {122.9 / (0.5 * (clo + chi)):.0f} us, not 51 us.  `issue-stalled`\n"
             "is mostly the in-order wave waiting for the matrix pipe (natural when MFMA-bound); `parked` is LDS / global data not there yet\n"
-            "or the per-tile barrier of the kernels whose waves split the taps (down: 23-26 %, up with 2 k-halves: 20 %).\n")
+            "or the barrier of the kernels whose waves split the taps.  Start of round 2 (before the scheduling pipeline, the AGPR-resident\n"
+            "weights and the two-tile-latency loop): 100 / 135 / 109 / 116 / 141 / 128 us, matrix pipe 46-70 % busy.\n")
 
 # 5. HBM traffic
 fs, ws = parse(f"{SRC}/pmc_FETCH_SIZE.txt"), parse(f"{SRC}/pmc_WRITE_SIZE.txt")
@@ -96,10 +100,10 @@ with open(f"{DST}/{TAG}_pmc_hbm.md", "w") as f:
             "FETCH_SIZE is doubled (gfx950 reports half of the bytes of wide coalesced reads, MI355X_MICROARCH.md HBM section; calibrated\n"
             "on small_up_fwd_kernel, whose only input is the 167.8 MB tensor g3); WRITE_SIZE as reported.  Counter unit: KB.\n\n"
             "| kernel | us | read MB (2 x FETCH) | written MB | algorithmic MB | ratio |\n|---|---:|---:|---:|---:|---:|\n")
-    alg = {"recon_nll_kernel<1, true>": 165.84, "small_up_fwd_kernel<3, 32, 1024>": 167.77 + 62.91,
-           "small_up_bwd_kernel<3, 32, 256>": 62.91 * 2 + 167.77 * 2,
-           "mvk::imgconv_kernel<0, 8, 64, 32, false>": 83.89 + 167.77, "mvk::imgconv_kernel<0, 4, 128, 64, false>": 41.94 + 83.89,
-           "mvk::imgconv_kernel<1, 8, 32, 64, true>": 167.77 + 83.89 * 2, "mvk::imgconv_kernel<1, 4, 64, 128, true>": 83.89 + 41.94 * 2,
+    alg = {"recon_nll_kernel<1, true>": 165.84, "small_up_fwd_kernel<3, 32, 1024, true>": 167.77 + 62.91,
+           "small_up_bwd_kernel<3, 32, 256, 256, 2, 2, 1, true>": 62.91 * 2 + 167.77 * 2,
+           "mvk::imgconv_kernel<0, 8, 64, 32, false, true>": 83.89 + 167.77, "mvk::imgconv_kernel<0, 4, 128, 64, false, true>": 41.94 + 83.89,
+           "mvk::imgconv_kernel<1, 8, 32, 64, true, true>": 167.77 + 83.89 * 2, "mvk::imgconv_kernel<1, 4, 64, 128, true, true>": 83.89 + 41.94 * 2,
            "mvk::imgwgrad_kernel<8, 32, 64>": 167.77 + 83.89 + 33.55, "mvk::imgwgrad_kernel<4, 64, 128>": 83.89 + 41.94 + 33.55}
     for k, a in alg.items():
         if k in fs and k in ws:
