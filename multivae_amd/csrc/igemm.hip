@@ -683,6 +683,9 @@ static int launch_with_colsum(GemmDesc& d, int zdim, float* db, float* ws, int64
 using namespace mvk;
 
 namespace mvk {
+// skinny.hip: few-row linear layer (a workgroup per 16 x 16 output tile, its waves split K): 1 = shape not covered
+int heads_launch(const float* X, const float* W0, const float* b0, float* Y0, const float* W1, const float* b1, float* Y1,
+                 int M, int N, int K, long long w_sk, long long w_sn, int act, hipStream_t s);
 // skinny.hip: short-reduction linear layer (K <= 32): 1 = shape not covered
 int smallk_fwd(const float* X, const float* W, long long w_sk, long long w_sn, const float* bias, int bias_mod, int act,
                float* Y, int M, int N, int K, hipStream_t s);
@@ -725,6 +728,13 @@ int mvk_linear_fwd(const float* X, const float* W, const float* b, float* Y, int
   if (!X || !W || !Y || M < 0 || N <= 0 || K <= 0) return MVK_EINVAL;
   if (K <= 32) {
     const int rc = smallk_fwd(X, W, 1, K, b, N, act, Y, M, N, K, mvk_stream(stream));
+    if (rc != 1) return rc;
+  }
+  // a few hundred rows (the encoders' hidden layers at the training batch): too few 128-row tiles for the tiled engine,
+  // which then splits K and needs a second launch to reduce (47 us for 512 x 784 -> 400); one 16 x 16 tile per workgroup
+  static const int fewrows = getenv("MVK_FEWROWS") ? atoi(getenv("MVK_FEWROWS")) : 1024;
+  if (M <= fewrows && K >= 64 && (long long)N * K <= (1 << 21)) {
+    const int rc = heads_launch(X, W, b, Y, nullptr, nullptr, nullptr, M, N, K, 1, K, act, mvk_stream(stream));
     if (rc != 1) return rc;
   }
   GemmDesc d{};

@@ -18,7 +18,7 @@ struct HeadsArgs {
   const float* W[2];
   const float* b[2];
   float* Y[2];
-  int M, N, K, tiles_per_head;
+  int M, N, K, tiles_per_head, act, wvec;  // wvec: 16-byte weight loads (w_sk == 1, rows and bases 16-byte aligned)
   long long w_sk, w_sn;  // W(k, n) = W[k * w_sk + n * w_sn]
 };
 
@@ -46,8 +46,14 @@ __global__ __launch_bounds__(NW * 64) void heads_fwd_kernel(const HeadsArgs g) {
     if (k < k1) {  // K % 4 == 0 and k1 % 4 == 0: a float4 is entirely inside or outside
       a = *reinterpret_cast<const f32x4*>(xrow + k);
       if (nok) {
+        if (g.wvec) {  // torch Linear rows: 4 consecutive k
+          const f32x4 t = *reinterpret_cast<const f32x4*>(wcol + k);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = wcol[(long long)(k + j) * g.w_sk];
+          for (int j = 0; j < 4; ++j) b[j] = t[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b[j] = wcol[(long long)(k + j) * g.w_sk];
+        }
       }
     }
 #pragma unroll
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(NW * 64) void heads_fwd_kernel(const HeadsArgs g) {
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; w += 4) t += (red[w][o] + red[w + 1][o]) + (red[w + 2][o] + red[w + 3][o]);
-      g.Y[head][(long long)m * N + n] = t + bias;
+      g.Y[head][(long long)m * N + n] = mvk_act(t + bias, g.act);
     }
   }
 }
@@ -76,8 +82,9 @@ __global__ __launch_bounds__(NW * 64) void heads_fwd_kernel(const HeadsArgs g) {
 namespace mvk {
 // Y_h = X W_h + b_h for 1 or 2 narrow heads; 1 = shape not covered
 int heads_launch(const float* X, const float* W0, const float* b0, float* Y0, const float* W1, const float* b1, float* Y1,
-                 int M, int N, int K, long long w_sk, long long w_sn, hipStream_t s) {
-  if (N > 32 || N < 1 || K % 4 != 0 || K < 4 || !mvk_aligned16(X) || M < 1) return 1;
+                 int M, int N, int K, long long w_sk, long long w_sn, int act, hipStream_t s) {
+  if ((W1 && N > 32) || N < 1 || K % 4 != 0 || K < 4 || !mvk_aligned16(X) || M < 1) return 1;
+  const int wvec = w_sk == 1 && (w_sn & 3) == 0 && mvk_aligned16(W0) && (!W1 || mvk_aligned16(W1));
   HeadsArgs a{};
   a.X = X;
   a.W[0] = W0;
@@ -90,6 +97,8 @@ int heads_launch(const float* X, const float* W0, const float* b0, float* Y0, co
   a.N = N;
   a.K = K;
   a.tiles_per_head = (N + 15) / 16;
+  a.act = act;
+  a.wvec = wvec;
   a.w_sk = w_sk;
   a.w_sn = w_sn;
   const int heads = W1 ? 2 : 1;
@@ -109,7 +118,7 @@ extern "C" int mvk_heads_fwd(const float* X, const float* W0, const float* b0, f
   if (M == 0) return MVK_OK;
   if (!X || !W0 || !Y0 || (W1 && !Y1) || M < 0 || N <= 0 || N > 32 || K <= 0 || K % 4 != 0 || !mvk_aligned16(X))
     return MVK_EINVAL;
-  const int rc = mvk::heads_launch(X, W0, b0, Y0, W1, b1, Y1, M, N, K, w_sk, w_sn, mvk_stream(stream));
+  const int rc = mvk::heads_launch(X, W0, b0, Y0, W1, b1, Y1, M, N, K, w_sk, w_sn, MVK_ACT_NONE, mvk_stream(stream));
   return rc == 1 ? MVK_EINVAL : rc;
 }
 

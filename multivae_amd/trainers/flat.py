@@ -11,22 +11,31 @@ from .. import kernels
 
 
 class FlatParams:
+    ALIGN = 64  # floats
+
     def __init__(self, model: torch.nn.Module):
         self.all_params = list(model.parameters())  # torch.optim indexes its state by position in this list
         self.params = [p for p in self.all_params if p.requires_grad]
         if not self.params:
             raise ValueError("model has no trainable parameters")
         dev = self.params[0].device
-        n = sum(p.numel() for p in self.params)
-        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
-        off = 0
+        # Every parameter starts on a 256-byte boundary of the buffer.  Densely packed, ONE 3-element bias (the image layer
+        # of the SVHN decoder) leaves every parameter behind it 12 bytes off a 16-byte boundary, and the kernels' 16-byte
+        # weight loads (`mvk_aligned16` checks in the C layer) silently fall back to their scalar paths for all of them
+        # (in `model.parameters()` order that was every encoder of the MnistSvhn models).  The padding stays zero: zero
+        # gradient, zero Adam update; the all-reduce carries it along (< 0.1 % of the buffer).
+        self.offsets, off = [], 0
         for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        n = off
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p, off in zip(self.params, self.offsets):
             k = p.numel()
             self.flat[off : off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off : off + k].view(p.shape)
             p.grad = self.grad[off : off + k].view(p.shape)
-            off += k
         self.numel = n
 
     def zero_grad(self):
@@ -46,14 +55,17 @@ class FlatParams:
                 return
 
     def _reattach(self):
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             k = p.numel()
             view = self.grad[off : off + k].view(p.shape)
             if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
                 view.add_(p.grad)
             p.grad = view
-            off += k
+
+    def dense(self, buf):
+        """The parameter slices of a buffer laid out like `flat` / `grad`, concatenated without the alignment padding
+        (the order of `model.parameters()`)."""
+        return torch.cat([buf[off : off + p.numel()] for p, off in zip(self.params, self.offsets)])
 
     def all_reduce(self, group=None):
         """ONE collective over the whole gradient buffer (sum); the 1/world_size is folded into Adam."""
@@ -112,8 +124,8 @@ class FusedAdam(torch.optim.Optimizer):
         `step` / `exp_avg` / `exp_avg_sq` (/ `max_exp_avg_sq`) keyed by the parameter's position in
         `model.parameters()`, one param group."""
         pos = {id(p): i for i, p in enumerate(self.flat.all_params)}
-        state, off = {}, 0
-        for p in self.flat.params:
+        state = {}
+        for p, off in zip(self.flat.params, self.flat.offsets):
             k = p.numel()
             if self.step_count > 0:  # torch creates the state lazily at the first step
                 st = {"step": torch.tensor(float(self.step_count)),
@@ -122,7 +134,6 @@ class FusedAdam(torch.optim.Optimizer):
                 if self.vmax is not None:
                     st["max_exp_avg_sq"] = self.vmax[off:off + k].view(p.shape).clone()
                 state[pos[id(p)]] = st
-            off += k
         g = self._g()
         group = dict(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"],
                      amsgrad=self.amsgrad, maximize=False, foreach=None, capturable=False, differentiable=False,
@@ -152,8 +163,8 @@ class FusedAdam(torch.optim.Optimizer):
         self.v.zero_()
         if self.vmax is not None:
             self.vmax.zero_()
-        steps, off = set(), 0
-        for p in self.flat.params:
+        steps = set()
+        for p, off in zip(self.flat.params, self.flat.offsets):
             k = p.numel()
             st = sd["state"].get(pos[id(p)])
             if st is not None:
@@ -162,7 +173,6 @@ class FusedAdam(torch.optim.Optimizer):
                 if self.vmax is not None and "max_exp_avg_sq" in st:
                     self.vmax[off:off + k].copy_(st["max_exp_avg_sq"].reshape(-1))
                 steps.add(int(float(st["step"])))
-            off += k
         if len(steps) > 1:
             raise ValueError(f"parameters with different step counts {sorted(steps)}: not representable by one fused step")
         self.step_count = steps.pop() if steps else 0

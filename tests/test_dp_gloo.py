@@ -58,7 +58,7 @@ def _worker(rank, world, port, ret):
             p.grad.add_(grads[k])  # what the HIP backward does: accumulate into the flat-buffer views
         flat.all_reduce()
         flat.grad.mul_(1.0 / world)
-        ret[rank] = dict(flat=flat.grad.clone(), params=flat.flat.clone(), idx=idx, eps=eps, sd=sd_np)
+        ret[rank] = dict(flat=flat.dense(flat.grad).clone(), params=flat.dense(flat.flat).clone(), idx=idx, eps=eps, sd=sd_np)
     finally:
         dist.destroy_process_group()
 

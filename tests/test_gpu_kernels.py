@@ -1142,3 +1142,21 @@ def test_short_reduction_linear_matches_float64(M, N, K, tb, act, bias_mod):
     if tb and bias_mod == N:  # the same through mvk_linear_fwd (torch Linear layout)
         got2 = K_.linear_fwd(x.to(d), wd, b.to(d), code)
         assert torch.equal(got2, got)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(512, 400, 784, "relu"), (512, 400, 400, "relu"), (37, 50, 64, "none"), (1000, 17, 128, "sigmoid")])
+def test_few_row_linear_matches_float64(M, N, K, act):
+    """mvk_linear_fwd with <= 1024 rows: one 16 x 16 output tile per workgroup, K split over its waves (skinny.hip), instead
+    of a split-K launch of the tiled engine plus its reduce; vs float64."""
+    from multivae_amd import kernels as K_
+
+    d = dev()
+    gen = g(M + N + K)
+    x = torch.randn(M, K, generator=gen)
+    w = torch.randn(N, K, generator=gen) / K ** 0.5
+    b = torch.randn(N, generator=gen)
+    code = dict(none=K_.NONE, relu=K_.RELU, sigmoid=K_.SIGMOID)[act]
+    ref = x.double() @ w.double().t() + b.double()
+    ref = dict(none=lambda t: t, relu=torch.relu, sigmoid=torch.sigmoid)[act](ref)
+    got = K_.linear_fwd(x.to(d), w.to(d), b.to(d), code)
+    close_elementwise(got, ref.float(), "few-row linear", rtol=3e-6, atol_frac=3e-6)

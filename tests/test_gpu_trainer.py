@@ -135,7 +135,7 @@ def _run_steps(d, steps, graphed, branch_streams=True, B=64, K=3, L=8):
             opt.step()
             losses.append(float(out.loss.detach()))
         torch.cuda.synchronize()
-        return losses, flat.flat.detach().cpu().clone()
+        return losses, flat.dense(flat.flat.detach()).cpu().clone()
     finally:
         kernels.BRANCH_STREAMS = old
 
@@ -200,11 +200,9 @@ def test_deferred_reductions_match_immediate_finishes():
     l2, g2 = run(True)
     assert l0 == l1 == l2
     assert torch.equal(g1, g2), "deferred finishes are not reproducible"
-    off = 0
-    for name, p in model.named_parameters():  # FlatParams lays the gradients out in this order
+    for (name, p), off in zip(model.named_parameters(), flat.offsets):  # FlatParams lays the gradients out in this order
         n = p.numel()
         a, b = g1[off:off + n], g0[off:off + n]
-        off += n
         scale = float(b.abs().max().clamp_min(1e-30))
         assert float((a - b).abs().max()) <= 2e-6 * scale, (name, float((a - b).abs().max()), scale)
 

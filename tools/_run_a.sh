@@ -1,2 +1,3 @@
-OUT=gpurun_out/r02; mkdir -p $OUT
-timeout 900 python bench.py --config cfg4 --batch 64 --no-graph --steps 5 --warmup 2 --no-cpu-baseline 2> $OUT/bench_cfg4_b64_eager.err | grep "^{" | tail -1 > $OUT/bench_cfg4_b64_eager.json; cut -c1-260 $OUT/bench_cfg4_b64_eager.json
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -E "^E  |FAILED|passed|failed" | head -10
+for i in 1 2 3; do timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 | python -c "
+import json,sys;d=json.loads(sys.stdin.read());print(d['value'],d['ms_per_step'])"; done
