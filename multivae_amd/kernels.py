@@ -146,6 +146,47 @@ def _tensors_of(obj):
             yield from _tensors_of(v)
 
 
+# Weight / bias gradients of a launch-latency-bound backward chain (the encoders at the training batch: ~20 launches of
+# 5-30 us each) are leaves: on their own stream they could run beside the backward-data chain instead of inside it.
+# MEASURED (MoPoE MnistSvhn step, hipGraph replay): 1.435 ms with the SVHN encoder's leaves on a third stream vs 1.385 ms
+# without — every fork / join edge between streams of a captured graph costs more than the ~90 us of leaf work it moves
+# off the chain (third result of this kind).  Off unless MVK_LEAF_STREAM=1.
+LEAF_STREAM = os.environ.get("MVK_LEAF_STREAM", "0") == "1"
+
+
+class LeafStream:
+    """lf = LeafStream(device); `with lf:` enqueues the enclosed launches on the leaf stream, ordered behind everything
+    the current stream holds at that point; `lf.join()` orders the current stream behind the leaf stream (call it before
+    the node returns: tensors the leaf launches read may be freed afterwards).  A no-op on the CPU or with
+    MVK_LEAF_STREAM=0."""
+
+    def __init__(self, device, index=31):
+        self.on = LEAF_STREAM and device.type == "cuda"
+        self.device = device
+        self.st = _side_stream(device, index) if self.on else None
+        self._ctx = None
+        self.used = False
+
+    def __enter__(self):
+        if self.on:
+            cur = torch.cuda.current_stream(self.device)
+            self.st.wait_event(cur.record_event())
+            self._ctx = torch.cuda.stream(self.st)
+            self._ctx.__enter__()
+            self.used = True
+        return self
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+            self._ctx = None
+        return False
+
+    def join(self):
+        if self.on and self.used:
+            torch.cuda.current_stream(self.device).wait_stream(self.st)
+
+
 def run_branches(names, fn, device):
     """{m: fn(m)} with every branch but the first on its own stream; joined before returning."""
     names = list(names)
@@ -592,23 +633,29 @@ class SVHNEncoderFn(Function):
         # heads
         tw1, dwc1 = _grad_target(wc1)
         tw2, dwc2 = _grad_target(wc2)
-        ws = _ws(x)
-        call("mvk_flatten_wgrad", ptr(h3f), ptr(dmu), ptr(tw1), B, ch[3], L, ptr(ws), ws.numel(), stream_ptr())
-        call("mvk_flatten_wgrad", ptr(h3f), ptr(dlv), ptr(tw2), B, ch[3], L, ptr(ws), ws.numel(), stream_ptr())
-        dbc1, dbc2 = colsum(dmu, bc1), colsum(dlv, bc2)
+        lf = LeafStream(x.device)  # the weight / bias gradients run beside the backward-data chain
+        with lf:
+            ws = _ws(x)
+            call("mvk_flatten_wgrad", ptr(h3f), ptr(dmu), ptr(tw1), B, ch[3], L, ptr(ws), ws.numel(), stream_ptr())
+            call("mvk_flatten_wgrad", ptr(h3f), ptr(dlv), ptr(tw2), B, ch[3], L, ptr(ws), ws.numel(), stream_ptr())
+            dbc1, dbc2 = colsum(dmu, bc1), colsum(dlv, bc2)
         # d h3 (pre-activation): dmu Wd1^T + dlv Wd2^T, ReLU'(h3) fused
         dh3 = gemm(dmu, wdc1, B, Kf, L, tb=True, c_act_src=h3f, c_act=RELU)
         gemm(dlv, wdc2, B, Kf, L, tb=True, c_act_src=h3f, c_act=RELU, out=dh3, accumulate=True)
         dh3 = dh3.view(B, H // 8, W // 8, ch[3])
-        dw2 = conv_wgrad(h2, dh3, w2, B, H // 8, W // 8, ch[2], ch[3])
-        db2 = colsum(dh3.view(-1, ch[3]), b2)
+        with lf:
+            dw2 = conv_wgrad(h2, dh3, w2, B, H // 8, W // 8, ch[2], ch[3])
+            db2 = colsum(dh3.view(-1, ch[3]), b2)
         # each backward-data launch also emits the bias gradient of the layer it lands in (column sums of its output)
         dh2, db1 = conv_up(dh3, wu2, None, B, H // 8, W // 8, ch[2], ch[3], u_act_src=h2, u_act=RELU, out_bias=b1,
                            frag=ctx.frags[1])
-        dw1 = conv_wgrad(h1, dh2, w1, B, H // 4, W // 4, ch[1], ch[2])
+        with lf:
+            dw1 = conv_wgrad(h1, dh2, w1, B, H // 4, W // 4, ch[1], ch[2])
         dh1, db0 = conv_up(dh2, wu1, None, B, H // 4, W // 4, ch[1], ch[2], u_act_src=h1, u_act=RELU, out_bias=b0,
                            frag=ctx.frags[0])
-        dw0 = conv_wgrad(x, dh1, w0, B, H // 2, W // 2, ch[0], ch[1], u_nchw=True)
+        with lf:
+            dw0 = conv_wgrad(x, dh1, w0, B, H // 2, W // 2, ch[0], ch[1], u_nchw=True)
+        lf.join()
         dx = None
         if ctx.needs_input_grad[0]:
             raise _lib.MvkError("gradient w.r.t. the encoder input image is not implemented")
