@@ -26,6 +26,13 @@
 #define MVK_SMALL_BWD_THREADS 256
 #endif
 
+#ifdef MVK_SUPROF
+__device__ unsigned long long* g_su_dbg = nullptr;
+extern "C" int mvk_smallup_debug_buffer(unsigned long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_su_dbg), &p, sizeof(p)) == hipSuccess ? 0 : -2;
+}
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -274,8 +281,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
     }
   };
   if ((long long)blockIdx.x < nunits) prefetch(blockIdx.x);
+#ifdef MVK_SUPROF  // tools/smallup_phase.sh: per-wave cycle counters
+  unsigned long long su_t[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long su_t0 = __builtin_readcyclecounter();
+#define SU_T(i) { const unsigned long long n_ = __builtin_readcyclecounter(); su_t[i] += n_ - su_last; su_last = n_; }
+#else
+#define SU_T(i)
+#endif
   for (long long unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+#ifdef MVK_SUPROF
+    unsigned long long su_last = __builtin_readcyclecounter();
+#endif
     __syncthreads();  // previous unit's tiles are no longer read
+    SU_T(0)
     // --- stage dUpre with halo (sigmoid' applied here), bias-gradient partials, and the V tile
     const int r2s = 2 * (int)(unit & (units - 1)) * hu;  // first output row of the unit being staged
     if (DENSE) {
@@ -310,8 +328,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
         *reinterpret_cast<f32x4*>(Vs + pos * C::VS + 4 * q) = pv[u];
       }
     }
+    SU_T(1)
     __syncthreads();
+    SU_T(0)
     if (unit + gridDim.x < nunits && !(abl & 8)) prefetch(unit + gridDim.x);
+    SU_T(2)
     if (!DENSE && !active) continue;
     // --- backward data: dV[pos][cv] = sum_{k=(cu,kh,kw)} dUpre[cu][2i-1+kh][2j-1+kw] * W[cv][k]
     f32x4 acc[MT][C::NTV];
@@ -337,6 +358,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
         for (int b = 0; b < C::NTV; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[b], av[a], acc[a][b], 0, 0, 0);  // transposed tile
     }
+    SU_T(3)
     if (!(abl & 64)) {
       // operands swapped: this lane holds dV[pos = a*16 + l15][cv = b*16 + 4*lq .. +3] -> 16-byte mask reads and stores
       const long long img = unit >> (units - 1);
@@ -357,6 +379,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
           if (!(abl & 4)) *reinterpret_cast<f32x4*>(dv + pos * CV + cv) = g;
         }
     }
+    SU_T(4)
     // --- backward weight: dW[cv][k] += sum_pos V[pos][cv] * dUpre(gathered)[pos][k]; this wave's WP positions
 #pragma unroll 2
     for (int ks = 0; ks < ((abl & 2) ? 1 : WP / 4); ++ks) {
@@ -373,7 +396,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
         for (int b = 0; b < CU; ++b)
           accw[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], accw[a][b], 0, 0, 0);
     }
+    SU_T(5)
   }
+#ifdef MVK_SUPROF
+  if (g_su_dbg && lane == 0) {
+    unsigned long long* o = g_su_dbg + (blockIdx.x * NW + wave) * 8;
+    o[0] = __builtin_readcyclecounter() - su_t0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[1 + i] = su_t[i];
+  }
+#endif
   // --- cross-wave reduction of the weight / bias partials, one slab per workgroup
   __syncthreads();
   float* red = smem;  // [4][CV*NC] — reuses Wt/Ds/Vs (needs 4*CV*NC floats); waves 4.. add into the slab of wave-4
