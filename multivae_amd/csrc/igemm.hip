@@ -688,7 +688,8 @@ int heads_launch(const float* X, const float* W0, const float* b0, float* Y0, co
                  int M, int N, int K, long long w_sk, long long w_sn, int act, hipStream_t s);
 // skinny.hip: short-reduction linear layer (K <= 32): 1 = shape not covered
 int smallk_fwd(const float* X, const float* W, long long w_sk, long long w_sn, const float* bias, int bias_mod, int act,
-               float* Y, int M, int N, int K, hipStream_t s);
+               float* Y, int M, int N, int K, hipStream_t s, const float* mask_src = nullptr, int mask_act = 0,
+               int accumulate = 0);
 // imgconv.hip: register-stationary-weight kernels for the 4x4/stride-2 layer pairs (1 = shape not covered)
 int imgconv_up(const float* V, const float* Wup, const void* wfrag, const float* bias, float* U, int n, int h, int w, int Cu,
                int Cv, int act, const float* u_act_src, int u_act, float* colsum_part, int* part_rows, hipStream_t s);
@@ -768,6 +769,11 @@ int mvk_linear_bwd_data(const float* dY, const float* W, float* dX, int M, int N
   d.N = K;
   d.K = N;
   hipStream_t s = mvk_stream(stream);
+  static const int smallk_bwd = getenv("MVK_SMALLK_BWD") ? atoi(getenv("MVK_SMALLK_BWD")) : 0;  // measured +10 us per step on the heads' backward-data: off
+  if (smallk_bwd && N <= 32 && !y_out && !colsum_acc) {  // backward-data out of a narrow layer (the encoder heads)
+    const int rc = smallk_fwd(dY, W, K, 1, nullptr, 1, MVK_ACT_NONE, dX, M, K, N, s, prev_out, prev_act, accumulate);
+    if (rc != 1) return rc;
+  }
   if (!colsum_acc) return launch_auto(d, ws, ws_floats, s);
   // bias gradient of the previous layer = column sums of dX: fused into the epilogue unless the launch splits K
   const long long tiles = (long long)((d.M + 127) / 128) * ((d.N + 63) / 64);
@@ -848,8 +854,10 @@ int mvk_gemm(const float* A, const float* B, float* C, int M, int N, int K, int 
              int bias_mod, int act, int accumulate, const float* a_act_src, int a_act, const float* c_act_src,
              int c_act, float* ws, int64_t ws_floats, void* stream) {
   if (!A || !B || !C || M < 0 || N <= 0 || K <= 0) return MVK_EINVAL;
-  if (K <= 32 && !ta && !accumulate && !a_act_src && !c_act_src && M > 0) {
-    const int rc = smallk_fwd(A, B, tb ? 1 : N, tb ? K : 1, bias, bias_mod, act, C, M, N, K, mvk_stream(stream));
+  static const int smallk_bwd = getenv("MVK_SMALLK_BWD") ? atoi(getenv("MVK_SMALLK_BWD")) : 0;  // measured +10 us per step on the heads' backward-data: off
+  if (K <= 32 && !ta && !a_act_src && M > 0 && (smallk_bwd || (!accumulate && !c_act_src))) {
+    const int rc = smallk_fwd(A, B, tb ? 1 : N, tb ? K : 1, bias, bias_mod, act, C, M, N, K, mvk_stream(stream), c_act_src,
+                              c_act, accumulate);
     if (rc != 1) return rc;
   }
   GemmDesc d{};

@@ -139,6 +139,8 @@ struct SmallKArgs {
   float* Y;
   int M, N, K, bias_mod, act;
   long long w_sk, w_sn;  // W(k, n) = W[k * w_sk + n * w_sn]
+  const float* mask_src;  // optional [M][N]: the result is multiplied by act'(mask_src) (backward-data into a hidden layer)
+  int mask_act, accumulate;
 };
 
 template <int K4>  // ceil(K / 4)
@@ -196,7 +198,18 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const SmallKArgs g) {
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = mvk_act(acc[j], g.act);
-    *reinterpret_cast<f32x4*>(g.Y + (long long)(m0 + r) * g.N + n) = acc;
+    f32x4* const dst = reinterpret_cast<f32x4*>(g.Y + (long long)(m0 + r) * g.N + n);
+    if (g.mask_src) {
+      const f32x4 ms = *reinterpret_cast<const f32x4*>(g.mask_src + (long long)(m0 + r) * g.N + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] *= mvk_act_grad_from_out(ms[j], g.mask_act);
+    }
+    if (g.accumulate) {
+      const f32x4 old = *dst;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += old[j];
+    }
+    *dst = acc;
   }
 }
 
@@ -205,10 +218,11 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const SmallKArgs g) {
 namespace mvk {
 // 1: shape not covered (the caller continues with the tiled engine)
 int smallk_fwd(const float* X, const float* W, long long w_sk, long long w_sn, const float* bias, int bias_mod, int act,
-               float* Y, int M, int N, int K, hipStream_t s) {
+               float* Y, int M, int N, int K, hipStream_t s, const float* mask_src, int mask_act, int accumulate) {
   static const int off = getenv("MVK_SMALLK") ? atoi(getenv("MVK_SMALLK")) == 0 : 0;
-  if (off || K > 32 || K < 1 || N % 4 != 0 || N < 4 || !mvk_aligned16(Y) || M < 1) return 1;
-  SmallKArgs a{X, W, bias, Y, M, N, K, bias_mod > 0 ? bias_mod : 1, act, w_sk, w_sn};
+  if (off || K > 32 || K < 1 || N % 4 != 0 || N < 4 || !mvk_aligned16(Y) || M < 1 || (mask_src && !mvk_aligned16(mask_src)))
+    return 1;
+  SmallKArgs a{X, W, bias, Y, M, N, K, bias_mod > 0 ? bias_mod : 1, act, w_sk, w_sn, mask_src, mask_act, accumulate};
   const int CT = N / 4, ctb = CT < 256 ? CT : 256;
   const dim3 grid((M + 7) / 8, (CT + ctb - 1) / ctb);
   switch ((K + 3) / 4) {
