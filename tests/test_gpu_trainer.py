@@ -207,6 +207,41 @@ def test_deferred_reductions_match_immediate_finishes():
         assert float((a - b).abs().max()) <= 2e-6 * scale, (name, float((a - b).abs().max()), scale)
 
 
+def test_deferred_reductions_fall_back_when_the_arena_is_full():
+    """A 1 MB arena holds a few of the ~30 partial-result regions of a step: the producers that do not fit finish
+    immediately (their own launch), the others are queued — same gradients as with the full arena."""
+    from multivae_amd import kernels
+    from multivae_amd.data.datasets.base import DatasetOutput
+    from multivae_amd.trainers import FlatParams
+
+    d = torch.device("cuda:0")
+    B, K, L = 256, 10, 20
+    model = _mnist_svhn_mopoe(d, K=K, L=L)
+    flat = FlatParams(model)
+    g = torch.Generator().manual_seed(12)
+    inputs = DatasetOutput(data=dict(mnist=torch.rand(B, 1, 28, 28, generator=g).to(d),
+                                     svhn=torch.rand(B, 3, 32, 32, generator=g).to(d)))
+    eps = torch.randn(K, B, L, generator=g).to(d)
+
+    def run():
+        flat.zero_grad()
+        with kernels.deferred_reductions(flat):
+            out = model(inputs, noise=eps)
+            out.loss.backward()
+        torch.cuda.synchronize()
+        return flat.grad.detach().clone()
+
+    full = run()
+    saved = kernels._ARENA.get(d)
+    kernels._ARENA[d] = torch.empty(1 << 18, dtype=torch.float32, device=d)
+    try:
+        small = run()
+    finally:
+        kernels._ARENA[d] = saved
+    scale = float(full.abs().max())
+    assert float((small - full).abs().max()) <= 2e-6 * scale
+
+
 @pytest.mark.parametrize("model_name", ["MoPoE", "JMVAE", "MVAE"])
 def test_trainer_with_hip_graph(tmp_path, model_name):
     """BaseTrainerConfig.use_hip_graph: every batch shape gets one captured graph (the full batches and the short last

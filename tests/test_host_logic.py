@@ -333,3 +333,37 @@ def test_auto_model_and_auto_config(tmp_path):
         json.dump(d, f)
     with pytest.raises(NameError):
         AutoModel.load_from_folder(str(tmp_path / "mopoe"))
+
+
+def test_flat_params_align_every_parameter_and_keep_the_optimizer_layout():
+    """FlatParams: every parameter (and its gradient) starts on a 256-byte boundary of the flat buffer — with dense packing a
+    3-element bias pushes everything behind it off the 16-byte alignment the kernels' vector loads need —, the padding stays
+    zero, `dense()` strips it, and the fused Adam's state_dict is still keyed / shaped like torch.optim.Adam's."""
+    from multivae_amd.trainers import FlatParams, FusedAdam
+
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 7), torch.nn.Linear(7, 2))  # odd sizes: 15, 3, 21, 7, 14, 2
+    ref = [p.detach().clone() for p in model.parameters()]
+    flat = FlatParams(model)
+    assert len(flat.offsets) == 6 and flat.numel == 6 * FlatParams.ALIGN
+    for p, r, off in zip(model.parameters(), ref, flat.offsets):
+        assert off % FlatParams.ALIGN == 0
+        assert (p.data_ptr() - flat.flat.data_ptr()) == 4 * off and (p.grad.data_ptr() - flat.grad.data_ptr()) == 4 * off
+        assert torch.equal(p.detach(), r)
+    assert torch.equal(flat.dense(flat.flat), torch.cat([r.reshape(-1) for r in ref]))
+    mask = torch.ones(flat.numel, dtype=torch.bool)
+    for p, off in zip(flat.params, flat.offsets):
+        mask[off:off + p.numel()] = False
+    assert float(flat.flat[mask].abs().sum()) == 0.0  # padding
+    opt = FusedAdam(flat, lr=1e-3)
+    opt.step_count = 3  # as if three steps had run (the kernel itself needs the GPU)
+    opt.m.copy_(torch.arange(flat.numel, dtype=torch.float32))
+    sd = opt.state_dict()
+    tref = torch.optim.Adam(model.parameters(), lr=1e-3)
+    assert sd["param_groups"][0]["params"] == tref.state_dict()["param_groups"][0]["params"]
+    for i, (p, off) in enumerate(zip(flat.params, flat.offsets)):
+        assert sd["state"][i]["exp_avg"].shape == p.shape
+        assert torch.equal(sd["state"][i]["exp_avg"].reshape(-1), torch.arange(off, off + p.numel(), dtype=torch.float32))
+    opt2 = FusedAdam(FlatParams(torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 7), torch.nn.Linear(7, 2))), lr=1e-3)
+    opt2.load_state_dict(sd)
+    assert opt2.step_count == 3 and torch.equal(opt2.flat.dense(opt2.m), flat.dense(opt.m))
