@@ -709,7 +709,13 @@ struct WCfg {
   static constexpr int KS = SU * PIX / 16;                       // 16-pixel k-steps per unit
   static constexpr int UROWS_IMG = SPLIT_KH ? HS * AW : 4 * PIX; // staged input rows per image (one row per (i, x))
   static constexpr int UROWS = SU * UROWS_IMG, VROWS = SU * PIX;
-  static constexpr int PAD = SPLIT_KH ? 16 : 0;
+#ifndef MVK_IW_PAD_A
+#define MVK_IW_PAD_A 32  // tools/imgwgrad_pad.sh: 16 -> 112.8 us, 32 ... 72 -> 102-107 us (64 <-> 128 channels, n = 5120)
+#endif
+#ifndef MVK_IW_PAD_B
+#define MVK_IW_PAD_B 0
+#endif
+  static constexpr int PAD = SPLIT_KH ? MVK_IW_PAD_A : MVK_IW_PAD_B;  // row padding (bytes) of the LDS images
   static constexpr int SUB = CU * 2 + PAD, SVB = CV * 2 + PAD;   // bytes per LDS row
   static constexpr int PLANE_U = (UROWS + 1) * SUB, PLANE_V = VROWS * SVB;
   static constexpr int OFF_V = 3 * PLANE_U;

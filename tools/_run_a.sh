@@ -1,1 +1,1 @@
-timeout 600 python -m pytest tests/test_gpu_trainer.py -x -q -m gpu -k "deferred" 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "imgconv or conv or svhn" 2>&1 | tail -1
