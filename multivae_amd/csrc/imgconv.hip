@@ -372,6 +372,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const char* const next_buf = (tt + 1 < T::TPU) ? abuf : nbuf;
         const int ntt = (tt + 1) % T::TPU;
         f32x16 acc0 = {0}, acc1 = {0};
+#ifdef MVK_ICPROF
+        const unsigned long long ic_k0 = IC_CLK();
+#endif
 #pragma unroll
         for (int pr = 0; pr < 8; ++pr) {
           bf16x8 a_nxt[2][3];
@@ -419,8 +422,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               __builtin_amdgcn_sched_group_barrier(0x496, MVK_IC_SCHED > 0 ? MVK_IC_SCHED : 1, 0);
             }
           }
+#ifdef MVK_ICPROF
+          if (pr == 6) {
+            const unsigned long long ic_b0 = IC_CLK();
+            ic_k += ic_b0 - ic_k0;
+            if (T::KSPLIT > 1 || tt == T::TPU - 1) __syncthreads();
+            ic_tend = IC_CLK();
+            ic_bar += ic_tend - ic_b0;
+          }
+#else
           if (pr == 6 && (T::KSPLIT > 1 || tt == T::TPU - 1)) __syncthreads();
+#endif
         }
+#ifdef MVK_ICPROF
+        ic_post += IC_CLK() - ic_tend;  // pair 7
+#endif
         pend0 = acc0;
         pend1 = acc1;
 #pragma unroll

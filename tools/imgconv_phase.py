@@ -37,8 +37,8 @@ for h, Cu, Cv in [(8, 32, 64), (4, 64, 128)]:
         tot, bar, kl = t[..., 0], t[..., 1], t[..., 2]
         raw3 = buf.view(256, 4, 4)[..., 3].cpu()
         pre, post = (raw3 >> 32).double(), (raw3 & 0xffffffff).double()
-        print(f"   after k-loop -> barrier (add, exchange write) {100 * (pre / tot).mean():.1f} % | barrier -> end of tile (first fragments, "
-              f"exchange read) {100 * (post / tot).mean():.1f} %")
+        print(f"   one-tile-latency loop: after k-loop -> barrier {100 * (pre / tot).mean():.1f} % | barrier -> end of tile "
+              f"{100 * (post / tot).mean():.1f} %   (two-tile-latency loop: 'k-loops' = pairs 0-6, second figure = pair 7)")
         print(f"h={h} {name}: cycles/wave mean {tot.mean():.0f} max {tot.max():.0f} | barrier wait mean {100 * (bar / tot).mean():.1f} % "
               f"(per wave of a workgroup: {[round(float(x), 1) for x in (100 * bar / tot).mean(0)]}) | k-loops {100 * (kl / tot).mean():.1f} % "
               f"| rest {100 * ((tot - bar - kl) / tot).mean():.1f} %  | MFMA floor 122880 = {100 * 122880 / tot.mean():.0f} %")
