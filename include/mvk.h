@@ -382,6 +382,12 @@ int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h
 int mvk_conv3x3(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout,
                 int act, const float* y_act_src, int y_src_act, float* colsum_acc, float* ws, int64_t ws_floats,
                 void* stream);
+/* The same launch with a residual in the epilogue: Y = res + res_alpha * (act(conv(X) + bias) * src_act'(y_act_src)) —
+ * `xs + 0.1 * conv2(...)` of the ResNet blocks (models/nn/cub.py:274-280) and `d_block_input + d_shortcut` of their backward
+ * pass in one pass over the output. */
+int mvk_conv3x3_res(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin,
+                    int Cout, int act, const float* y_act_src, int y_src_act, const float* res, float res_alpha,
+                    float* ws, int64_t ws_floats, void* stream);
 int mvk_conv3x3_wgrad(const float* X, const float* dY, float* dWref, int n, int H, int W, int Cin, int Cout,
                       float* ws, int64_t ws_floats, void* stream);
 /* nn.AvgPool2d(3, stride=2, padding=1) (count_include_pad: every window divides by 9) and nn.Upsample(scale_factor=2)

@@ -683,6 +683,13 @@ static int launch_with_colsum(GemmDesc& d, int zdim, float* db, float* ws, int64
 using namespace mvk;
 
 namespace mvk {
+// conv3small.hip: 3x3 convolutions with an image (<= 4 channels) on one side: 1 = shape not covered
+int conv3_smallcin(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
+                   const float* mask_src, int mask_act, hipStream_t s);
+int conv3_smallcout(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
+                    const float* mask_src, int mask_act, hipStream_t s);
+int conv3_small_wgrad(const float* X, const float* dY, float* slab, long long slab_floats, int n, int H, int W, int Cin, int Cout,
+                      int* nz, hipStream_t s);
 // skinny.hip: few-row linear layer (a workgroup per 16 x 16 output tile, its waves split K): 1 = shape not covered
 int heads_launch(const float* X, const float* W0, const float* b0, float* Y0, const float* W1, const float* b1, float* Y1,
                  int M, int N, int K, long long w_sk, long long w_sn, int act, hipStream_t s);
@@ -993,10 +1000,22 @@ int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U
 // ---- 3x3 / stride 1 / pad 1 convolution on NHWC activations (ResNet blocks) --------------------------------------
 // Y[n,H,W,Cout] = act(conv3x3(X[n,H,W,Cin]) + b) (* src_act'(y_act_src));  Wp[(kh*3+kw)*Cin + ci][co].
 // The same launch is the backward-data pass when it is fed the output gradient and the flipped / transposed pack.
-int mvk_conv3x3(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout,
-                int act, const float* y_act_src, int y_src_act, float* colsum_acc, float* ws, int64_t ws_floats,
-                void* stream) {
+static int conv3x3_any(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout,
+                       int act, const float* y_act_src, int y_src_act, float* colsum_acc, const float* res, float res_alpha,
+                       float* ws, int64_t ws_floats, void* stream) {
   if (!X || !Wp || !Y || n < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return MVK_EINVAL;
+  if (n > 0 && Cin <= 4 && !res) {  // the image-consuming layer (or the backward-data pass of the image-producing one)
+    const int rc = conv3_smallcin(X, Wp, bias, Y, n, H, W, Cin, Cout, act, y_act_src, y_src_act, mvk_stream(stream));
+    if (rc == MVK_OK && colsum_acc)
+      return colsum(Y, nullptr, 0, n * H * W, Cout, colsum_acc, ws, ws_floats, mvk_stream(stream));
+    if (rc != 1) return rc;
+  }
+  if (n > 0 && Cout <= 4 && !res) {  // the image-producing layer
+    const int rc = conv3_smallcout(X, Wp, bias, Y, n, H, W, Cin, Cout, act, y_act_src, y_src_act, mvk_stream(stream));
+    if (rc == MVK_OK && colsum_acc)
+      return colsum(Y, nullptr, 0, n * H * W, Cout, colsum_acc, ws, ws_floats, mvk_stream(stream));
+    if (rc != 1) return rc;
+  }
   GemmDesc d{};
   d.a = AOperand{};
   d.a.p = X;
@@ -1018,16 +1037,47 @@ int mvk_conv3x3(const float* X, const float* Wp, const float* bias, float* Y, in
   d.e.act = act;
   d.e.act_src = y_act_src;
   d.e.src_act = y_src_act;
+  d.e.res = res;
+  d.e.res_alpha = res_alpha;
   d.M = n * H * W;
   d.N = Cout;
   d.K = 9 * Cin;
+  if (res && colsum_acc && !epilogue_vec_ok(d.e, d.N)) return MVK_EINVAL;  // the sums would include the residual
   return launch_with_colsum(d, 1, colsum_acc, ws, ws_floats, Y, (long long)n * H * W, mvk_stream(stream));
+}
+
+int mvk_conv3x3(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout,
+                int act, const float* y_act_src, int y_src_act, float* colsum_acc, float* ws, int64_t ws_floats,
+                void* stream) {
+  return conv3x3_any(X, Wp, bias, Y, n, H, W, Cin, Cout, act, y_act_src, y_src_act, colsum_acc, nullptr, 0.f, ws, ws_floats,
+                     stream);
+}
+
+// Y = res + res_alpha * (act(conv3x3(X) + b) * src_act'(y_act_src)): the residual sum of a ResNet block in the
+// convolution's epilogue (res may alias nothing the launch reads through X)
+int mvk_conv3x3_res(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout,
+                    int act, const float* y_act_src, int y_src_act, const float* res, float res_alpha, float* ws,
+                    int64_t ws_floats, void* stream) {
+  if (!res) return MVK_EINVAL;
+  return conv3x3_any(X, Wp, bias, Y, n, H, W, Cin, Cout, act, y_act_src, y_src_act, nullptr, res, res_alpha, ws, ws_floats,
+                     stream);
 }
 
 // dWref[Cout][Cin][3][3] += sum_pos X(gathered) dY
 int mvk_conv3x3_wgrad(const float* X, const float* dY, float* dWref, int n, int H, int W, int Cin, int Cout, float* ws,
                       int64_t ws_floats, void* stream) {
   if (!X || !dY || !dWref || n < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return MVK_EINVAL;
+  if (n > 0 && (Cin <= 4 || Cout <= 4)) {  // an image on one side: per-workgroup slabs in dWref order + ordered finish
+    const long long total = 9ll * Cin * Cout;
+    float* dslab = defer_scratch(dWref, 1024 * total, mvk_stream(stream));
+    int nz = 0;
+    const int rc = conv3_small_wgrad(X, dY, dslab ? dslab : ws, dslab ? 1024 * total : ws_floats, n, H, W, Cin, Cout, &nz,
+                                     mvk_stream(stream));
+    if (rc == MVK_OK)
+      return dslab ? defer_push_plain(dWref, dslab, total, nz, total, mvk_stream(stream))
+                   : colsum_finish_any(ws, nz, (int)total, dWref, mvk_stream(stream));
+    if (rc != 1) return rc;
+  }
   GemmDesc d{};
   d.a = AOperand{};
   d.a.p = X;

@@ -59,7 +59,10 @@ struct Epilogue {
   int taps;        // E_CONVREF: window size of the reference weight layout (0 = 16)
   float* ws;       // Z_SPLITK: if set, raw partial tiles go to ws[z][m][n] and splitk_reduce_kernel finishes
   float* colsum_part;  // optional: per-workgroup column sums of the stored values -> colsum_part[(z*gridDim.x + bx)*N + n]
-};                     // (vectorised epilogue only; the host finishes them with an ordered reduce: bias gradients)
+                       // (vectorised epilogue only; the host finishes them with an ordered reduce: bias gradients)
+  const float* res;    // optional residual: out = res[out offset] + res_alpha * (value after activation / mask)
+  float res_alpha;     // (the column sums are those of the value BEFORE the residual)
+};
 
 struct GemmDesc {
   AOperand a;
@@ -155,7 +158,7 @@ __device__ __forceinline__ bool gather_off(const AOperand& a, const Pos& ps, int
 __host__ __device__ inline bool epilogue_vec_ok(const Epilogue& E, int N) {
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
   return !E.ws && !E.atomic && (E.kind == E_ROWMAJOR || E.kind == E_UP) && (N % 4 == 0) && al16(E.out) &&
-         (!E.act_src || al16(E.act_src)) && (E.kind == E_UP ? (E.Cu % 4 == 0) : (E.ld % 4 == 0)) &&
+         (!E.act_src || al16(E.act_src)) && (!E.res || al16(E.res)) && (E.kind == E_UP ? (E.Cu % 4 == 0) : (E.ld % 4 == 0)) &&
          (!E.bias || (E.bias_mod % 4 == 0 && al16(E.bias)));
 }
 
@@ -222,6 +225,7 @@ __device__ __forceinline__ void run_epilogue(const GemmDesc& d, f32x16 (&acc)[T:
           }
           v = mvk_act(v + bias_v, E.act);
           if (E.act_src) v *= mvk_act_grad_from_out(E.act_src[off], E.src_act);
+          if (E.res) v = fmaf(E.res_alpha, v, E.res[off]);
           if (E.atomic)
             atomicAdd(E.out + off, v);
           else
@@ -301,11 +305,18 @@ __device__ __forceinline__ bool run_epilogue_vec(const GemmDesc& d, f32x16 (&acc
             v.z *= mvk_act_grad_from_out(y.z, E.src_act);
             v.w *= mvk_act_grad_from_out(y.w, E.src_act);
           }
-          *reinterpret_cast<float4*>(E.out + off) = v;
           csum.x += v.x;
           csum.y += v.y;
           csum.z += v.z;
           csum.w += v.w;
+          if (E.res) {
+            const float4 rr = *reinterpret_cast<const float4*>(E.res + off);
+            v.x = fmaf(E.res_alpha, v.x, rr.x);
+            v.y = fmaf(E.res_alpha, v.y, rr.y);
+            v.z = fmaf(E.res_alpha, v.z, rr.z);
+            v.w = fmaf(E.res_alpha, v.w, rr.w);
+          }
+          *reinterpret_cast<float4*>(E.out + off) = v;
         }
       }
     }
@@ -827,6 +838,7 @@ __device__ __forceinline__ void splitk_store(const Epilogue& E, int N, long long
   if (E.bias) v += E.bias[n % E.bias_mod];
   v = mvk_act(v, E.act);
   if (E.act_src) v *= mvk_act_grad_from_out(E.act_src[off], E.src_act);
+  if (E.res) v = fmaf(E.res_alpha, v, E.res[off]);
   if (E.atomic)
     E.out[off] += v;  // "accumulate" semantics; every element is owned by exactly one thread
   else

@@ -126,6 +126,19 @@ __global__ void act_bwd_kernel(float* __restrict__ dY, const float* __restrict__
   for (; i < n; i += stride) dY[i] *= mvk_act_grad_from_out(Y[i], act);
 }
 
+__global__ __launch_bounds__(256) void act_bwd4_kernel(float4* __restrict__ dY, const float4* __restrict__ Y, long long n4,
+                                                       int act) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 g = dY[i];
+  const float4 y = Y[i];
+  g.x *= mvk_act_grad_from_out(y.x, act);
+  g.y *= mvk_act_grad_from_out(y.y, act);
+  g.z *= mvk_act_grad_from_out(y.z, act);
+  g.w *= mvk_act_grad_from_out(y.w, act);
+  dY[i] = g;
+}
+
 __global__ void scale_kernel(float* __restrict__ buf, long long n, const float* __restrict__ g) {
   float s = *g;
   if (s == 1.0f) return;
@@ -419,7 +432,11 @@ int mvk_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, v
 int mvk_act_bwd(float* dY, const float* Y, int64_t n, int act, void* stream) {
   if (!dY || !Y) return MVK_EINVAL;
   if (n == 0) return MVK_OK;
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, mvk_stream(stream), dY, Y, (long long)n, act);
+  if (n % 4 == 0 && mvk_aligned16(dY) && mvk_aligned16(Y))
+    hipLaunchKernelGGL(act_bwd4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, mvk_stream(stream),
+                       reinterpret_cast<float4*>(dY), reinterpret_cast<const float4*>(Y), (long long)(n / 4), act);
+  else
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, mvk_stream(stream), dY, Y, (long long)n, act);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }
@@ -575,6 +592,31 @@ int mvk_bf3_to_f32(const void* planes, int64_t n, float* x, void* stream) {
 // ---------------------------------------------------------------------------------------------------------
 namespace {
 
+// V floats per lane (V = 4: 16-byte accesses when C % 4 == 0 and the tensors are 16-byte aligned); C below is in units of V
+template <int V>
+struct VecT {
+  float v[V];
+};
+template <int V>
+__device__ __forceinline__ VecT<V> vload(const float* p) {
+  VecT<V> r;
+  if (V == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    r.v[0] = t.x, r.v[1 % V] = t.y, r.v[2 % V] = t.z, r.v[3 % V] = t.w;
+  } else {
+    r.v[0] = *p;
+  }
+  return r;
+}
+template <int V>
+__device__ __forceinline__ void vstore(float* p, const VecT<V>& r) {
+  if (V == 4)
+    *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1 % V], r.v[2 % V], r.v[3 % V]);
+  else
+    *p = r.v[0];
+}
+
+template <int V>
 __global__ __launch_bounds__(256) void avgpool3s2_fwd_kernel(const float* __restrict__ x, int n, int H, int W, int C,
                                                              float* __restrict__ y) {
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;  // floor((H + 2 - 3) / 2) + 1
@@ -586,7 +628,9 @@ __global__ __launch_bounds__(256) void avgpool3s2_fwd_kernel(const float* __rest
   t /= OW;
   const int oh = (int)(t % OH);
   const long long b = t / OH;
-  float s = 0.f;
+  VecT<V> s;
+#pragma unroll
+  for (int e = 0; e < V; ++e) s.v[e] = 0.f;
 #pragma unroll
   for (int kh = 0; kh < 3; ++kh) {
     const int h = 2 * oh - 1 + kh;
@@ -595,13 +639,18 @@ __global__ __launch_bounds__(256) void avgpool3s2_fwd_kernel(const float* __rest
     for (int kw = 0; kw < 3; ++kw) {
       const int w = 2 * ow - 1 + kw;
       if (w < 0 || w >= W) continue;
-      s += x[((b * H + h) * W + w) * C + c];
+      const VecT<V> t4 = vload<V>(x + (((b * H + h) * W + w) * C + c) * V);
+#pragma unroll
+      for (int e = 0; e < V; ++e) s.v[e] += t4.v[e];
     }
   }
-  y[i] = s * (1.0f / 9.0f);
+#pragma unroll
+  for (int e = 0; e < V; ++e) s.v[e] *= (1.0f / 9.0f);
+  vstore<V>(y + i * V, s);
 }
 
 // dx[b,h,w,c] = (1/9) sum over the output windows that contain (h,w)
+template <int V>
 __global__ __launch_bounds__(256) void avgpool3s2_bwd_kernel(const float* __restrict__ dy, int n, int H, int W, int C,
                                                              float* __restrict__ dx) {
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;
@@ -613,17 +662,24 @@ __global__ __launch_bounds__(256) void avgpool3s2_bwd_kernel(const float* __rest
   t /= W;
   const int h = (int)(t % H);
   const long long b = t / H;
-  float s = 0.f;
+  VecT<V> s;
+#pragma unroll
+  for (int e = 0; e < V; ++e) s.v[e] = 0.f;
   for (int oh = h / 2; oh <= (h + 1) / 2; ++oh) {  // windows rows 2*oh-1 .. 2*oh+1
     if (oh >= OH) continue;
     for (int ow = w / 2; ow <= (w + 1) / 2; ++ow) {
       if (ow >= OW) continue;
-      s += dy[((b * OH + oh) * OW + ow) * C + c];
+      const VecT<V> t4 = vload<V>(dy + (((b * OH + oh) * OW + ow) * C + c) * V);
+#pragma unroll
+      for (int e = 0; e < V; ++e) s.v[e] += t4.v[e];
     }
   }
-  dx[i] = s * (1.0f / 9.0f);
+#pragma unroll
+  for (int e = 0; e < V; ++e) s.v[e] *= (1.0f / 9.0f);
+  vstore<V>(dx + i * V, s);
 }
 
+template <int V>
 __global__ __launch_bounds__(256) void upsample2_fwd_kernel(const float* __restrict__ x, int n, int H, int W, int C,
                                                             float* __restrict__ y) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -634,9 +690,10 @@ __global__ __launch_bounds__(256) void upsample2_fwd_kernel(const float* __restr
   t /= 2 * W;
   const int oh = (int)(t % (2 * H));
   const long long b = t / (2 * H);
-  y[i] = x[((b * H + (oh >> 1)) * W + (ow >> 1)) * C + c];
+  vstore<V>(y + i * V, vload<V>(x + (((b * H + (oh >> 1)) * W + (ow >> 1)) * C + c) * V));
 }
 
+template <int V>
 __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restrict__ dy, int n, int H, int W, int C,
                                                             float* __restrict__ dx) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -647,8 +704,13 @@ __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restr
   t /= W;
   const int h = (int)(t % H);
   const long long b = t / H;
-  const float* p = dy + ((b * 2 * H + 2 * h) * 2 * W + 2 * w) * C + c;
-  dx[i] = (p[0] + p[C]) + (p[(long long)2 * W * C] + p[(long long)2 * W * C + C]);
+  const float* p = dy + (((b * 2 * H + 2 * h) * 2 * W + 2 * w) * C + c) * V;
+  const long long rowf = (long long)2 * W * C * V;
+  const VecT<V> p00 = vload<V>(p), p01 = vload<V>(p + C * V), p10 = vload<V>(p + rowf), p11 = vload<V>(p + rowf + C * V);
+  VecT<V> s;
+#pragma unroll
+  for (int e = 0; e < V; ++e) s.v[e] = (p00.v[e] + p01.v[e]) + (p10.v[e] + p11.v[e]);
+  vstore<V>(dx + i * V, s);
 }
 
 __global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, float a, const float* __restrict__ y,
@@ -657,46 +719,81 @@ __global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x,
   if (i >= n) return;
   out[i] = mvk_act(a * (x ? x[i] : 0.f) + b * (y ? y[i] : 0.f), act);
 }
+
+// 16 bytes per lane (n4 = n / 4 quads; x, y, out 16-byte aligned)
+__global__ __launch_bounds__(256) void axpby4_kernel(const float4* __restrict__ x, float a, const float4* __restrict__ y,
+                                                     float b, long long n4, int act, float4* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 xv = x ? x[i] : z, yv = y ? y[i] : z;
+  float4 r;
+  r.x = mvk_act(a * xv.x + b * yv.x, act);
+  r.y = mvk_act(a * xv.y + b * yv.y, act);
+  r.z = mvk_act(a * xv.z + b * yv.z, act);
+  r.w = mvk_act(a * xv.w + b * yv.w, act);
+  out[i] = r;
+}
 }  // namespace
 
 extern "C" {
 
 int mvk_avgpool3s2_fwd(const float* x, float* y, int n, int H, int W, int C, void* stream) {
   if (!x || !y || n < 0 || H <= 0 || W <= 0 || C <= 0) return MVK_EINVAL;
-  const long long total = (long long)n * ((H + 1) / 2) * ((W + 1) / 2) * C;
+  const bool v4 = (C % 4 == 0) && mvk_aligned16(x) && mvk_aligned16(y);
+  const int Cq = v4 ? C / 4 : C;
+  const long long total = (long long)n * ((H + 1) / 2) * ((W + 1) / 2) * Cq;
   if (total == 0) return MVK_OK;
-  hipLaunchKernelGGL(avgpool3s2_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mvk_stream(stream), x,
-                     n, H, W, C, y);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (v4)
+    hipLaunchKernelGGL(avgpool3s2_fwd_kernel<4>, grid, dim3(256), 0, mvk_stream(stream), x, n, H, W, Cq, y);
+  else
+    hipLaunchKernelGGL(avgpool3s2_fwd_kernel<1>, grid, dim3(256), 0, mvk_stream(stream), x, n, H, W, Cq, y);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }
 
 int mvk_avgpool3s2_bwd(const float* dy, float* dx, int n, int H, int W, int C, void* stream) {
   if (!dy || !dx || n < 0 || H <= 0 || W <= 0 || C <= 0) return MVK_EINVAL;
-  const long long total = (long long)n * H * W * C;
+  const bool v4 = (C % 4 == 0) && mvk_aligned16(dy) && mvk_aligned16(dx);
+  const int Cq = v4 ? C / 4 : C;
+  const long long total = (long long)n * H * W * Cq;
   if (total == 0) return MVK_OK;
-  hipLaunchKernelGGL(avgpool3s2_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mvk_stream(stream), dy,
-                     n, H, W, C, dx);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (v4)
+    hipLaunchKernelGGL(avgpool3s2_bwd_kernel<4>, grid, dim3(256), 0, mvk_stream(stream), dy, n, H, W, Cq, dx);
+  else
+    hipLaunchKernelGGL(avgpool3s2_bwd_kernel<1>, grid, dim3(256), 0, mvk_stream(stream), dy, n, H, W, Cq, dx);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }
 
 int mvk_upsample2_fwd(const float* x, float* y, int n, int H, int W, int C, void* stream) {
   if (!x || !y || n < 0 || H <= 0 || W <= 0 || C <= 0) return MVK_EINVAL;
-  const long long total = (long long)n * 4 * H * W * C;
+  const bool v4 = (C % 4 == 0) && mvk_aligned16(x) && mvk_aligned16(y);
+  const int Cq = v4 ? C / 4 : C;
+  const long long total = (long long)n * 4 * H * W * Cq;
   if (total == 0) return MVK_OK;
-  hipLaunchKernelGGL(upsample2_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mvk_stream(stream), x, n,
-                     H, W, C, y);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (v4)
+    hipLaunchKernelGGL(upsample2_fwd_kernel<4>, grid, dim3(256), 0, mvk_stream(stream), x, n, H, W, Cq, y);
+  else
+    hipLaunchKernelGGL(upsample2_fwd_kernel<1>, grid, dim3(256), 0, mvk_stream(stream), x, n, H, W, Cq, y);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }
 
 int mvk_upsample2_bwd(const float* dy, float* dx, int n, int H, int W, int C, void* stream) {
   if (!dy || !dx || n < 0 || H <= 0 || W <= 0 || C <= 0) return MVK_EINVAL;
-  const long long total = (long long)n * H * W * C;
+  const bool v4 = (C % 4 == 0) && mvk_aligned16(dy) && mvk_aligned16(dx);
+  const int Cq = v4 ? C / 4 : C;
+  const long long total = (long long)n * H * W * Cq;
   if (total == 0) return MVK_OK;
-  hipLaunchKernelGGL(upsample2_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mvk_stream(stream), dy,
-                     n, H, W, C, dx);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (v4)
+    hipLaunchKernelGGL(upsample2_bwd_kernel<4>, grid, dim3(256), 0, mvk_stream(stream), dy, n, H, W, Cq, dx);
+  else
+    hipLaunchKernelGGL(upsample2_bwd_kernel<1>, grid, dim3(256), 0, mvk_stream(stream), dy, n, H, W, Cq, dx);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }
@@ -704,8 +801,13 @@ int mvk_upsample2_bwd(const float* dy, float* dx, int n, int H, int W, int C, vo
 int mvk_axpby(const float* x, float a, const float* y, float b, int64_t n, int act, float* out, void* stream) {
   if (!out || n < 0 || (!x && !y)) return MVK_EINVAL;
   if (n == 0) return MVK_OK;
-  hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, mvk_stream(stream), x, a, y, b,
-                     (long long)n, act, out);
+  if (n % 4 == 0 && mvk_aligned16(out) && (!x || mvk_aligned16(x)) && (!y || mvk_aligned16(y)))
+    hipLaunchKernelGGL(axpby4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, mvk_stream(stream),
+                       reinterpret_cast<const float4*>(x), a, reinterpret_cast<const float4*>(y), b, (long long)(n / 4), act,
+                       reinterpret_cast<float4*>(out));
+  else
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, mvk_stream(stream), x, a, y, b,
+                       (long long)n, act, out);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }

@@ -384,12 +384,19 @@ def conv_up(V, wup, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src=Non
 LEAKY = ACT["leaky_relu_0.2"]
 
 
-def conv3x3(X, wpack, bias, n, H, W, Cin, Cout, act=NONE, y_act_src=None, y_src_act=NONE, out_bias=None):
+def conv3x3(X, wpack, bias, n, H, W, Cin, Cout, act=NONE, y_act_src=None, y_src_act=NONE, out_bias=None, res=None,
+            res_alpha=1.0):
     """3x3/1/1 convolution on NHWC (forward with the forward pack; backward data with the backward pack and Cin/Cout
     swapped, y_act_src = the activation whose derivative multiplies the result, out_bias = the bias whose gradient is
-    the channel sum of the result)."""
+    the channel sum of the result, res: the result becomes res + res_alpha * result in the same pass)."""
     Y = _new((n, H, W, Cout), X)
     ws = _ws(X)
+    if res is not None:
+        if out_bias is not None:
+            raise _lib.MvkError("conv3x3: a residual and a fused bias gradient are exclusive")
+        call("mvk_conv3x3_res", ptr(X), ptr(wpack), ptr(bias), ptr(Y), n, H, W, Cin, Cout, act, ptr(y_act_src), y_src_act,
+             ptr(res), float(res_alpha), ptr(ws), ws.numel(), stream_ptr())
+        return Y
     tb, rb = _bias_target(out_bias)
     call("mvk_conv3x3", ptr(X), ptr(wpack), ptr(bias), ptr(Y), n, H, W, Cin, Cout, act, ptr(y_act_src), y_src_act,
          ptr(tb), ptr(ws), ws.numel(), stream_ptr())
@@ -787,9 +794,12 @@ class ResnetStackFn(Function):
                 else:
                     a0 = axpby(h, 1.0, None, 0.0, act=LEAKY)
                     a1 = conv3x3(a0, packs[iw1][0], b1, n, H, W, C, Chid, act=LEAKY)
-                    y2 = conv3x3(a1, packs[iw2][0], b2, n, H, W, Chid, Cout, act=NONE)
+                    y2 = None  # the block's sum is formed in conv2's epilogue; backward does not need conv2's output
                 xs = h if isc is None else linear_fwd(h.view(-1, C), params[isc].view(Cout, C), None, NONE).view(n, H, W, Cout)
-                out = axpby(xs, 1.0, y2, 0.1)
+                if y2 is None:
+                    out = conv3x3(a1, packs[iw2][0], b2, n, H, W, Chid, Cout, act=NONE, res=xs, res_alpha=0.1)
+                else:
+                    out = axpby(xs, 1.0, y2, 0.1)
                 tape.append((h, a0, a1, y2, (H, W, C, Chid, Cout)))
                 h, C = out, Cout
             elif op[0] == "pool":
@@ -855,14 +865,12 @@ class ResnetStackFn(Function):
                     if grads[isc] is not None:
                         grads[isc] = grads[isc].view(params[isc].shape)
                 if not first or need_dx:
+                    # the shortcut's gradient first, the convolution path adds itself to it in its epilogue
+                    gsc = gout if isc is None else linear_bwd_data(gout.view(-1, Cout), params[isc].view(Cout, C)).view(n, H, W, C)
                     if order_ == "post":
-                        dx = conv3x3(d1, packs[iw1][1], None, n, H, W, Chid, C)
+                        dx = conv3x3(d1, packs[iw1][1], None, n, H, W, Chid, C, res=gsc)
                     else:  # through the leading LeakyReLU: multiply by lrelu'(x) = lrelu'(a0)
-                        dx = conv3x3(d1, packs[iw1][1], None, n, H, W, Chid, C, y_act_src=a0, y_src_act=LEAKY)
-                    if isc is None:
-                        axpby(dx, 1.0, gout, 1.0, out=dx)
-                    else:
-                        linear_bwd_data(gout.view(-1, Cout), params[isc].view(Cout, C), out=dx.view(-1, C), accumulate=True)
+                        dx = conv3x3(d1, packs[iw1][1], None, n, H, W, Chid, C, y_act_src=a0, y_src_act=LEAKY, res=gsc)
                     g = dx
             elif op[0] == "pool":
                 H, W, C = rec

@@ -699,7 +699,8 @@ def test_jmvae_posterior(K, M, B, L, Kk):
 
 
 @pytest.mark.parametrize("n,H,W,Cin,Cout", [(3, 7, 7, 64, 128), (2, 14, 14, 128, 64), (5, 28, 28, 3, 64), (2, 28, 28, 64, 3),
-                                          (40, 16, 16, 64, 64)])
+                                          (40, 16, 16, 64, 64), (3, 64, 64, 3, 64), (3, 64, 64, 64, 3), (2, 13, 11, 3, 32),
+                                          (2, 13, 19, 32, 3), (1, 9, 40, 1, 16), (1, 9, 40, 16, 1)])
 def test_conv3x3_fwd_bwd(K, n, H, W, Cin, Cout):
     """mvk_conv3x3 / mvk_conv3x3_wgrad (+ kind-2 weight pack) vs F.conv2d(3, 1, 1) + LeakyReLU(0.2): forward, backward
     data with the fused activation derivative and bias-gradient column sums, backward weight in the reference layout."""
@@ -729,6 +730,28 @@ def test_conv3x3_fwd_bwd(K, n, H, W, Cin, Cout):
     wparam.grad = torch.zeros_like(wparam)
     K.conv3x3_wgrad(X, dpre, wparam, n, H, W, Cin, Cout)
     close(wparam.grad, w.grad, what="conv3x3 backward weight")
+
+
+@pytest.mark.parametrize("n,H,W,Cin,Cout", [(3, 7, 7, 64, 128), (2, 16, 16, 128, 64), (1, 5, 9, 6, 10), (2, 8, 8, 3, 64)])
+def test_conv3x3_residual_epilogue(K, n, H, W, Cin, Cout):
+    """mvk_conv3x3_res: res + alpha * (conv (+ bias, activation) * act'(mask source)) in the convolution's epilogue — the
+    block sum `x_s + 0.1 * dx` of models/nn/cub.py:274-280 and the gradient sum of its backward pass."""
+    gen = g(37)
+    d = dev()
+    x = torch.randn(n, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) / (3 * Cin ** 0.5)
+    b = 0.1 * torch.randn(Cout, generator=gen)
+    res = torch.randn(n, Cout, H, W, generator=gen)
+    src = torch.randn(n, Cout, H, W, generator=gen)
+    nhwc = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(d)
+    (wf, _), = K.pack_weights([(w.to(d), "c3", True, True)])
+    conv = F.conv2d(x, w, b, 1, 1)
+    Y = K.conv3x3(nhwc(x), wf, b.to(d), n, H, W, Cin, Cout, act=K.NONE, res=nhwc(res), res_alpha=0.1)
+    close(Y, nhwc(res + 0.1 * conv), what="res + 0.1 * conv")
+    Y = K.conv3x3(nhwc(x), wf, b.to(d), n, H, W, Cin, Cout, act=K.LEAKY, y_act_src=nhwc(src), y_src_act=K.LEAKY, res=nhwc(res))
+    close(Y, nhwc(res + F.leaky_relu(conv, 0.2) * torch.where(src > 0, 1.0, 0.2)), what="res + act(conv) * mask")
+    with pytest.raises(Exception):
+        K.conv3x3(nhwc(x), wf, None, n, H, W, Cin, Cout, res=nhwc(res), out_bias=torch.zeros(Cout, device=d))
 
 
 @pytest.mark.parametrize("n,H,W,C", [(3, 28, 28, 64), (2, 7, 7, 20), (4, 14, 14, 128), (2, 5, 9, 3)])
