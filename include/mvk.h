@@ -487,6 +487,18 @@ int mvk_adam_step_amsgrad(float* p, const float* g, float* m, float* v, float* v
 int mvk_heads_fwd(const float* X, const float* W0, const float* b0, float* Y0, const float* W1, const float* b1,
                   float* Y1, int M, int N, int K, int64_t w_sk, int64_t w_sn, void* stream);
 
+/* Their backward in ONE launch (6 launches on the GEMM engine before: 2 weight gradients, 2 bias column sums, 2
+ * backward-data products):  dX[m][k] = (sum_h sum_n dY_h[m][n] W_h(k, n)) * x_act'(X[m][k])  (x_act from the OUTPUT value
+ * X; dX may be NULL),  dW_h += dY_h^T X  stored at dW_h[n * K + k], or at dW_h[n * K + (k % flat_c) * (K / flat_c) +
+ * k / flat_c] when flat_c > 0 (k = (tap, c) of an NHWC map -> the [L][C][4][4] layout of the Conv2d heads),
+ * db_h += column sums of dY_h (may be NULL),  dbprev += column sums of dX (may be NULL: the bias gradient of the layer that
+ * produced X; K entries, or flat_c channel sums when flat_c > 0).  Per 128-row group a workgroup writes partial sums to slabs (the deferred arena of mvk_defer_begin when the
+ * target lies in the flat gradient buffer, else `ws`: (2 N K + 2 N + K) * ceil(M / 128) floats at most); the groups are
+ * added in order: deterministic.  N <= 32, K % 16 == 0, X / dX 16-byte aligned. */
+int mvk_heads_bwd(const float* X, int x_act, const float* dY0, const float* dY1, const float* W0, const float* W1,
+                  int64_t w_sk, int64_t w_sn, int flat_c, float* dX, float* dW0, float* dW1, float* db0, float* db1,
+                  float* dbprev, int M, int N, int K, float* ws, int64_t ws_floats, void* stream);
+
 /* Deferred leaf reductions.  Parameter gradients are leaves of the backward pass (reference: autograd accumulates them
  * into `.grad`, nothing reads them before `optimizer.step()`, trainers/base/base_trainer.py:405-420), so the ordered
  * finishes that complete them - split-K slabs of the weight-gradient GEMMs, per-workgroup column sums of the bias

@@ -91,6 +91,7 @@ PROTOTYPES = {
     "mvk_nhwc_to_nchw": [_p, _p, _i, _i, _i, _i, _p],
     "mvk_adam_step": [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _d, _p],
     "mvk_heads_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _i64, _p],
+    "mvk_heads_bwd": [_p, _i, _p, _p, _p, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _i64, _p],
     "mvk_defer_begin": [_p, _i64, _p, _i64],
     "mvk_defer_flush": [_p],
     "mvk_defer_end": [_p],
@@ -207,6 +208,7 @@ GEMM_FLOPS = {
     "mvk_unflatten_wgrad": lambda a: 2.0 * a[3] * a[4] * 16 * a[5],
     "mvk_flatten_wgrad": lambda a: 2.0 * a[3] * 16 * a[4] * a[5],
     "mvk_heads_fwd": lambda a: 2.0 * (2 if a[4] and a[4].value else 1) * a[7] * a[8] * a[9],
+    "mvk_heads_bwd": lambda a: 4.0 * a[15] * a[16] * a[17] * (2 if a[3] else 1),
 }
 COUNT_FLOPS = None
 

@@ -693,6 +693,10 @@ int conv3_small_wgrad(const float* X, const float* dY, float* slab, long long sl
 // skinny.hip: few-row linear layer (a workgroup per 16 x 16 output tile, its waves split K): 1 = shape not covered
 int heads_launch(const float* X, const float* W0, const float* b0, float* Y0, const float* W1, const float* b1, float* Y1,
                  int M, int N, int K, long long w_sk, long long w_sn, int act, hipStream_t s);
+// skinny.hip: backward of 1 or 2 narrow heads in one launch (slabs per 128-row group); 1 = shape not covered
+int heads_bwd_launch(const float* X, int x_act, const float* dY0, const float* dY1, const float* W0, const float* W1,
+                     long long w_sk, long long w_sn, int flat_c, float* dX, float* wslab0, float* wslab1, float* bslab0,
+                     float* bslab1, float* pslab, int M, int N, int K, int* nz, hipStream_t s);
 // skinny.hip: short-reduction linear layer (K <= 32): 1 = shape not covered
 int smallk_fwd(const float* X, const float* W, long long w_sk, long long w_sn, const float* bias, int bias_mod, int act,
                float* Y, int M, int N, int K, hipStream_t s, const float* mask_src = nullptr, int mask_act = 0,
@@ -1172,6 +1176,54 @@ int mvk_unflatten_wgrad(const float* Z, const float* dY, float* dWref, int n, in
   d.N = 16 * Cout;
   d.K = n;
   return launch_splitk(d, ws, ws_floats, 512, mvk_stream(stream));
+}
+
+// Backward of the (embedding, log-covariance) heads in one launch + the ordered finishes of its row-group slabs.
+int mvk_heads_bwd(const float* X, int x_act, const float* dY0, const float* dY1, const float* W0, const float* W1,
+                  int64_t w_sk, int64_t w_sn, int flat_c, float* dX, float* dW0, float* dW1, float* db0, float* db1,
+                  float* dbprev, int M, int N, int K, float* ws, int64_t ws_floats, void* stream) {
+  if (M == 0) return MVK_OK;
+  if (!X || !dY0 || !W0 || !dW0 || (dY1 && (!W1 || !dW1)) || M < 0 || N <= 0 || K <= 0) return MVK_EINVAL;
+  hipStream_t s = mvk_stream(stream);
+  const int nh = dY1 ? 2 : 1, rgs = (M + 127) / 128;
+  const long long wtot = (long long)N * K;
+  // slab regions: the deferred arena where the target is part of the flat gradient buffer, else the caller's workspace
+  float* outs[5] = {dW0, dW1, db0, db1, dbprev};
+  // with flat_c the layer below is a convolution: its bias gradient has flat_c channels, and the [rg][K] slab of column
+  // sums IS [rg * taps][flat_c] partial rows
+  const int pc = flat_c > 0 ? flat_c : K, prow = K / pc;
+  if (flat_c > 0 && K % flat_c != 0) return MVK_EINVAL;
+  const long long cnt[5] = {wtot, wtot, N, N, pc};
+  float* slab[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool deferred[5] = {false, false, false, false, false};
+  float* dummy = nullptr;  // bias slabs are always written by the kernel: without a target they go to the workspace
+  long long ws_used = 0;
+  for (int i = 0; i < 5; ++i) {
+    const bool head1 = (i == 1 || i == 3);
+    if (head1 && nh == 1) continue;
+    if (i == 4 && !dbprev) continue;
+    const long long need = (cnt[i] * rgs * (i == 4 ? prow : 1) + 3) & ~3LL;
+    if (outs[i]) slab[i] = defer_scratch(outs[i], need, s);
+    deferred[i] = slab[i] != nullptr;
+    if (!slab[i]) {
+      if (!ws || ws_used + need > ws_floats) return MVK_EINVAL;
+      slab[i] = ws + ws_used;
+      ws_used += need;
+    }
+  }
+  (void)dummy;
+  int nz = 0;
+  const int rc = heads_bwd_launch(X, x_act, dY0, dY1, W0, W1, w_sk, w_sn, flat_c, dX, slab[0], slab[1], slab[2], slab[3],
+                                  slab[4], M, N, K, &nz, s);
+  if (rc != MVK_OK) return rc == 1 ? MVK_EINVAL : rc;
+  for (int i = 0; i < 5; ++i) {
+    if (!slab[i] || !outs[i]) continue;
+    const int nrows = nz * (i == 4 ? prow : 1);
+    const int r = deferred[i] ? defer_push_plain(outs[i], slab[i], cnt[i], nrows, cnt[i], s)
+                              : colsum_finish_any(slab[i], nrows, (int)cnt[i], outs[i], s);
+    if (r != MVK_OK) return r;
+  }
+  return MVK_OK;
 }
 
 // dWref[cv][cu][4][4] += H[n,(tap,cu)]^T dY[n,cv]  (Conv2d(C,L,4,2,0) heads on a 4x4 input)

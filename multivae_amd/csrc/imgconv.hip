@@ -950,7 +950,10 @@ static int imgwgrad_launch(const ImgWgradArgs& a, int* nz, hipStream_t s) {
       return MVK_ELAUNCH;
     attr_done = true;
   }
-  const int grid = 256;
+  // MVK_IMGWGRAD_GRID: fewer workgroups than compute units leave room for launches of other streams (a workgroup owns a
+  // whole compute unit's registers)
+  static const int grid_env = getenv("MVK_IMGWGRAD_GRID") ? atoi(getenv("MVK_IMGWGRAD_GRID")) : 256;
+  const int grid = (grid_env >= T::WG_TYPES && grid_env <= 256) ? grid_env / T::WG_TYPES * T::WG_TYPES : 256;
   *nz = grid / T::WG_TYPES;
   ImgWgradArgs ap = a;
   ap.prof = prof_next(4, 2.0 * a.n * HS * HS * 16.0 * CU * CV);

@@ -77,6 +77,109 @@ __global__ __launch_bounds__(NW * 64) void heads_fwd_kernel(const HeadsArgs g) {
   }
 }
 
+
+// ---- backward of the heads in ONE launch -----------------------------------------------------------------------------------
+// Six launches of the tiled engine before (two weight gradients with their split-K finishes, two bias column sums, two
+// backward-data GEMMs accumulating into one buffer) in the launch-latency-bound encoder backward.  A workgroup owns
+// HB_KC = 16 columns k of X and HB_MR = 128 rows m:
+//   dX[m][k]      = (sum_h sum_n dY_h[m][n] W_h(n, k)) * act'(X[m][k])                   (exact fp32 FMA chains, fixed order)
+//   wslab_h[rg][.] = sum over its rows of dY_h[m][n] X[m][k]      (rows in order; the RG row groups are added by the caller's
+//   bslab_h[rg][n] = sum over its rows of dY_h[m][n]               ordered finish: deterministic)
+//   pslab[rg][k]   = sum over its rows of dX[m][k]                 (the bias gradient of the layer that produced X)
+constexpr int HB_KC = 16, HB_MR = 128, HB_XS = 20;
+struct HeadsBwdArgs {
+  const float* X;
+  const float* dY[2];
+  const float* W[2];
+  float* dX;
+  float* wslab[2];
+  float* bslab[2];
+  float* pslab;
+  int M, N, K, nh, x_act, flat_c;
+  long long w_sk, w_sn;  // W_h(n, k) = W_h[n * w_sn + k * w_sk]
+};
+
+__global__ __launch_bounds__(256) void heads_bwd_kernel(const HeadsBwdArgs g) {
+  __shared__ __attribute__((aligned(16))) float dYs[HB_MR * 65];
+  __shared__ __attribute__((aligned(16))) float Ws[64 * HB_KC];
+  __shared__ __attribute__((aligned(16))) float Xs[HB_MR * HB_XS];
+  __shared__ __attribute__((aligned(16))) float Ds[HB_MR * HB_XS];
+  const int tid = threadIdx.x, N = g.N, K = g.K, NN = g.nh * N, NNP = NN | 1;
+  const int k0 = blockIdx.x * HB_KC, rg = blockIdx.y, r0 = rg * HB_MR;
+  const int rows = min(HB_MR, g.M - r0);
+  for (int i = tid; i < HB_MR * NN; i += 256) {
+    const int m = i / NN, c = i - m * NN, h = c / N, n = c - h * N;
+    dYs[m * NNP + c] = m < rows ? g.dY[h][(long long)(r0 + m) * N + n] : 0.f;
+  }
+  for (int i = tid; i < NN * HB_KC; i += 256) {
+    const int c = i / HB_KC, kk = i % HB_KC, h = c / N, n = c - h * N;
+    Ws[i] = g.W[h][(long long)n * g.w_sn + (long long)(k0 + kk) * g.w_sk];
+  }
+  for (int i = tid; i < HB_MR * (HB_KC / 4); i += 256) {
+    const int m = i / (HB_KC / 4), q = i % (HB_KC / 4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (m < rows) v = *reinterpret_cast<const f32x4*>(g.X + (long long)(r0 + m) * K + k0 + 4 * q);
+    *reinterpret_cast<f32x4*>(Xs + m * HB_XS + 4 * q) = v;
+  }
+  __syncthreads();
+  {  // backward data: thread = (row, half of the 16 columns)
+    const int m = tid >> 1, kh = (tid & 1) * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int c = 0; c < NN; ++c) {
+      const float dy = dYs[m * NNP + c];
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(Ws + c * HB_KC + kh);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(Ws + c * HB_KC + kh + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[e] = fmaf(dy, w0[e], acc[e]);
+        acc[4 + e] = fmaf(dy, w1[e], acc[4 + e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      acc[e] *= mvk_act_grad_from_out(Xs[m * HB_XS + kh + e], g.x_act);
+      Ds[m * HB_XS + kh + e] = acc[e];
+    }
+    if (m < rows && g.dX) {
+      float* o = g.dX + (long long)(r0 + m) * K + k0 + kh;
+      *reinterpret_cast<f32x4*>(o) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+      *reinterpret_cast<f32x4*>(o + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+    }
+  }
+  if (tid < NN * (HB_KC / 4)) {  // weight gradients: thread = (head column, 4 columns of X)
+    const int c = tid / (HB_KC / 4), q = tid % (HB_KC / 4), h = c / N, n = c - h * N;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < rows; ++m) {
+      const float dy = dYs[m * NNP + c];
+      const f32x4 x = *reinterpret_cast<const f32x4*>(Xs + m * HB_XS + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = fmaf(dy, x[e], acc[e]);
+    }
+    float* slab = g.wslab[h] + (long long)rg * N * K + (long long)n * K;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + 4 * q + e;
+      slab[g.flat_c > 0 ? (k % g.flat_c) * (K / g.flat_c) + k / g.flat_c : k] = acc[e];
+    }
+  }
+  if (blockIdx.x == 0 && tid >= 192 && tid - 192 < NN) {  // bias gradients of the heads (the last wave: idle above)
+    const int c = tid - 192, h = c / N, n = c - h * N;
+    float t = 0.f;
+    for (int m = 0; m < rows; ++m) t += dYs[m * NNP + c];
+    g.bslab[h][rg * N + n] = t;
+  }
+  if (g.pslab) {
+    __syncthreads();
+    if (tid < HB_KC) {
+      float t = 0.f;
+      for (int m = 0; m < rows; ++m) t += Ds[m * HB_XS + tid];
+      g.pslab[(long long)rg * K + k0 + tid] = t;
+    }
+  }
+}
+
 }  // namespace
 
 namespace mvk {
@@ -109,6 +212,42 @@ int heads_launch(const float* X, const float* W0, const float* b0, float* Y0, co
   else
     hipLaunchKernelGGL(heads_fwd_kernel<4>, grid, dim3(256), 0, s, a);
   MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+// slabs: wslab_h [rg][N * K] (in the layout of dW_h), bslab_h [rg][N], pslab [rg][K] (optional) with rg = ceil(M / 128)
+// row groups (*nz); 1 = shape not covered
+int heads_bwd_launch(const float* X, int x_act, const float* dY0, const float* dY1, const float* W0, const float* W1,
+                     long long w_sk, long long w_sn, int flat_c, float* dX, float* wslab0, float* wslab1, float* bslab0,
+                     float* bslab1, float* pslab, int M, int N, int K, int* nz, hipStream_t s) {
+  const int nh = dY1 ? 2 : 1;
+  if (M < 1 || N < 1 || N > 32 || K % HB_KC != 0 || K < HB_KC || !mvk_aligned16(X) || (dX && !mvk_aligned16(dX))) return 1;
+  if (flat_c > 0 && K % flat_c != 0) return 1;
+  const int rgs = (M + HB_MR - 1) / HB_MR;
+  if (rgs > 64) return 1;
+  HeadsBwdArgs a{};
+  a.X = X;
+  a.dY[0] = dY0;
+  a.dY[1] = dY1;
+  a.W[0] = W0;
+  a.W[1] = W1;
+  a.dX = dX;
+  a.wslab[0] = wslab0;
+  a.wslab[1] = wslab1;
+  a.bslab[0] = bslab0;
+  a.bslab[1] = bslab1;
+  a.pslab = pslab;
+  a.M = M;
+  a.N = N;
+  a.K = K;
+  a.nh = nh;
+  a.x_act = x_act;
+  a.flat_c = flat_c;
+  a.w_sk = w_sk;
+  a.w_sn = w_sn;
+  hipLaunchKernelGGL(heads_bwd_kernel, dim3(K / HB_KC, rgs), dim3(256), 0, s, a);
+  MVK_CHECK_LAUNCH();
+  *nz = rgs;
   return MVK_OK;
 }
 }  // namespace mvk

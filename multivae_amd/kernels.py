@@ -81,6 +81,45 @@ DEFER_ARENA_FLOATS = int(os.environ.get("MVK_DEFER_MB", "512")) * (1 << 18)
 _ARENA = {}
 
 
+_DEFER_ACTIVE = set()  # devices inside deferred_reductions
+_LATE_USED = {}  # device -> the late-leaf stream, if anything was enqueued on it since mvk_defer_begin
+# MVK_LATE_LEAVES=1: the weight gradients of the large decoder (two ~100 us launches that fill the chip) are enqueued AFTER
+# its backward-data chain, on a stream that is joined only where the deferred finishes run: they execute beside the
+# launch-latency-bound encoder backward (the ~300 us tail of the step in which the chip is mostly idle) instead of in
+# front of it.
+# MEASURED (headline step, same box, two pairs): 1.347 / 1.336 ms without vs 1.320 / 1.315 ms with; a smaller grid for the
+# weight-gradient kernels (MVK_IMGWGRAD_GRID=224 / 192 / 128: compute units left free for the chain) does not help
+# (1.331 / 1.348 / 1.414 ms).  MVK_LATE_LEAVES=0 disables.
+LATE_LEAVES = os.environ.get("MVK_LATE_LEAVES", "1") != "0"
+
+
+class late_leaves:
+    """with late_leaves(device, *tensors_read): the enclosed launches go to the late-leaf stream, ordered behind what the
+    current stream holds now; nothing waits for them until deferred_reductions ends.  Outside deferred_reductions (or with
+    MVK_LATE_LEAVES=0, or on the CPU) the launches stay on the current stream."""
+
+    def __init__(self, device, *reads):
+        self.on = LATE_LEAVES and device.type == "cuda" and device in _DEFER_ACTIVE
+        self.device, self.reads, self._ctx = device, reads, None
+
+    def __enter__(self):
+        if self.on:
+            st = _side_stream(self.device, 30)
+            st.wait_event(torch.cuda.current_stream(self.device).record_event())
+            for t in self.reads:
+                t.record_stream(st)
+            _LATE_USED[self.device] = st
+            self._ctx = torch.cuda.stream(st)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+            self._ctx = None
+        return False
+
+
 class deferred_reductions:
     """with deferred_reductions(flat): forward + backward.  On exit the queued finishes run on the current stream; the
     gradient buffer is complete after that (before: NOT).  A no-op on CPU tensors or with MVK_DEFER=0."""
@@ -98,10 +137,16 @@ class deferred_reductions:
                 arena = torch.empty(DEFER_ARENA_FLOATS, dtype=torch.float32, device=dev)
                 _ARENA[dev] = arena
             call("mvk_defer_begin", ptr(arena), arena.numel(), ptr(self.grad), self.grad.numel())
+            _DEFER_ACTIVE.add(dev)
         return self
 
     def __exit__(self, et, ev, tb):
         if self.on:
+            dev = self.grad.device
+            _DEFER_ACTIVE.discard(dev)
+            st = _LATE_USED.pop(dev, None)
+            if st is not None:  # the late leaves (below) end here
+                torch.cuda.current_stream(dev).wait_stream(st)
             call("mvk_defer_end", stream_ptr())
         return False
 
@@ -289,6 +334,31 @@ def heads_fwd(h2, w_mu, b_mu, w_lv, b_lv, N, w_sk, w_sn):
     call("mvk_heads_fwd", ptr(h2), ptr(w_mu), ptr(b_mu), ptr(mu), ptr(w_lv), ptr(b_lv), ptr(lv), M, N, K, w_sk, w_sn,
          stream_ptr())
     return mu, lv
+
+
+HEADS_BWD = os.environ.get("MVK_HEADS_BWD", "1") != "0"  # A/B switch: the heads' backward in one launch
+
+
+def heads_bwd(x, x_act, dys, ws_, bs, w_sk, w_sn, flat_c=0, want_dx=True, prev_bias=None, dw_params=None):
+    """Backward of 1 or 2 narrow heads that read x [M,K] (mvk_heads_bwd).  dys: gradients [M,N]; ws_: the weights as the
+    kernel reads them (W(k, n) = W[k * w_sk + n * w_sn]); dw_params: the parameters whose .grad receives dY^T x (default:
+    ws_); bs: bias parameters (or None).  Returns None when the shape is not covered, else
+    (dx or None, [grad for autograd per weight], [grad per bias], grad for prev_bias)."""
+    M, K = x.shape
+    N = dys[0].shape[1]
+    if not HEADS_BWD or N > 32 or K % 16 != 0 or len(dys) > 2 or M < 1 or (M + 127) // 128 > 64:
+        return None
+    dw_params = ws_ if dw_params is None else dw_params
+    tw, rw = zip(*[_grad_target(p) for p in dw_params])
+    tb, rb = zip(*[_grad_target(b) if b is not None else (None, None) for b in bs])
+    tp, rp = _grad_target(prev_bias) if prev_bias is not None else (None, None)
+    dx = _new((M, K), x) if want_dx else None
+    two = len(dys) == 2
+    ws = _ws(x)
+    call("mvk_heads_bwd", ptr(x), x_act, ptr(dys[0]), ptr(dys[1]) if two else None, ptr(ws_[0]), ptr(ws_[1]) if two else None,
+         w_sk, w_sn, flat_c, ptr(dx), ptr(tw[0]), ptr(tw[1]) if two else None, ptr(tb[0]), ptr(tb[1]) if two else None,
+         ptr(tp), M, N, K, ptr(ws), ws.numel(), stream_ptr())
+    return dx, list(rw), list(rb), rp
 
 
 def colsum(dy2, b, y_out=None, y_act=NONE):
@@ -544,7 +614,17 @@ class MLPHeadsFn(Function):
         prev_src, prev_act = (h, RELU) if n > 0 else (None, NONE)
         need_dx = ctx.needs_input_grad[0]
         dh = None
-        for j in range(nh):
+        fused = None
+        if nh <= 2 and (n > 0 or need_dx):
+            # every head in one launch; with hidden layers it also emits the last hidden layer's bias gradient
+            hw = [params[2 * (n + j)] for j in range(nh)]
+            fused = heads_bwd(h, prev_act, [_c(d) for d in douts[:nh]], hw, [params[2 * (n + j) + 1] for j in range(nh)],
+                              1, h.shape[1], prev_bias=params[2 * n - 1] if n > 0 else None)
+        if fused is not None:
+            dh, gw, gb, gprev = fused
+            for j in range(nh):
+                grads[2 * (n + j)], grads[2 * (n + j) + 1] = gw[j], gb[j]
+        for j in range(nh if fused is None else 0):
             w, b = params[2 * (n + j)], params[2 * (n + j) + 1]
             dy = _c(douts[j])
             grads[2 * (n + j)], grads[2 * (n + j) + 1] = linear_bwd_weight(dy, h, w, b)
@@ -555,7 +635,11 @@ class MLPHeadsFn(Function):
                     linear_bwd_data(dy, w, prev_out=prev_src, prev_act=prev_act, out=dh, accumulate=True)
         for i in range(n - 1, -1, -1):
             w, inp = params[2 * i], acts[i]
-            grads[2 * i], grads[2 * i + 1] = linear_bwd_weight(dh, inp, w, params[2 * i + 1])
+            if fused is not None and i == n - 1:  # its bias gradient came with the heads' launch
+                grads[2 * i], _ = linear_bwd_weight(dh, inp, w, None)
+                grads[2 * i + 1] = gprev
+            else:
+                grads[2 * i], grads[2 * i + 1] = linear_bwd_weight(dh, inp, w, params[2 * i + 1])
             if i > 0:
                 dh = linear_bwd_data(dh, w, prev_out=acts[i], prev_act=RELU)
             elif need_dx:
@@ -638,22 +722,28 @@ class SVHNEncoderFn(Function):
         dmu, dlv = _c(dmu).view(B, L), _c(dlv).view(B, L)
         Kf = 16 * ch[3]
         h3f = h3.view(B, Kf)
-        # heads
-        tw1, dwc1 = _grad_target(wc1)
-        tw2, dwc2 = _grad_target(wc2)
+        # heads: both weight gradients (in the Conv2d layout), both bias gradients, d h3 (pre-activation: dmu Wd1^T + dlv Wd2^T
+        # with ReLU'(h3)) and its channel sums (the bias gradient of the layer below) in one launch
         lf = LeafStream(x.device)  # the weight / bias gradients run beside the backward-data chain
-        with lf:
-            ws = _ws(x)
-            call("mvk_flatten_wgrad", ptr(h3f), ptr(dmu), ptr(tw1), B, ch[3], L, ptr(ws), ws.numel(), stream_ptr())
-            call("mvk_flatten_wgrad", ptr(h3f), ptr(dlv), ptr(tw2), B, ch[3], L, ptr(ws), ws.numel(), stream_ptr())
-            dbc1, dbc2 = colsum(dmu, bc1), colsum(dlv, bc2)
-        # d h3 (pre-activation): dmu Wd1^T + dlv Wd2^T, ReLU'(h3) fused
-        dh3 = gemm(dmu, wdc1, B, Kf, L, tb=True, c_act_src=h3f, c_act=RELU)
-        gemm(dlv, wdc2, B, Kf, L, tb=True, c_act_src=h3f, c_act=RELU, out=dh3, accumulate=True)
+        fused = heads_bwd(h3f, RELU, [dmu, dlv], [wdc1, wdc2], [bc1, bc2], L, 1, flat_c=ch[3], prev_bias=b2,
+                          dw_params=[wc1, wc2]) if (H // 8, W // 8) == (4, 4) else None
+        if fused is not None:
+            dh3, (dwc1, dwc2), (dbc1, dbc2), db2 = fused
+        else:
+            tw1, dwc1 = _grad_target(wc1)
+            tw2, dwc2 = _grad_target(wc2)
+            with lf:
+                ws = _ws(x)
+                call("mvk_flatten_wgrad", ptr(h3f), ptr(dmu), ptr(tw1), B, ch[3], L, ptr(ws), ws.numel(), stream_ptr())
+                call("mvk_flatten_wgrad", ptr(h3f), ptr(dlv), ptr(tw2), B, ch[3], L, ptr(ws), ws.numel(), stream_ptr())
+                dbc1, dbc2 = colsum(dmu, bc1), colsum(dlv, bc2)
+            dh3 = gemm(dmu, wdc1, B, Kf, L, tb=True, c_act_src=h3f, c_act=RELU)
+            gemm(dlv, wdc2, B, Kf, L, tb=True, c_act_src=h3f, c_act=RELU, out=dh3, accumulate=True)
         dh3 = dh3.view(B, H // 8, W // 8, ch[3])
         with lf:
             dw2 = conv_wgrad(h2, dh3, w2, B, H // 8, W // 8, ch[2], ch[3])
-            db2 = colsum(dh3.view(-1, ch[3]), b2)
+            if fused is None:
+                db2 = colsum(dh3.view(-1, ch[3]), b2)
         # each backward-data launch also emits the bias gradient of the layer it lands in (column sums of its output)
         dh2, db1 = conv_up(dh3, wu2, None, B, H // 8, W // 8, ch[2], ch[3], u_act_src=h2, u_act=RELU, out_bias=b1,
                            frag=ctx.frags[1])
@@ -723,19 +813,35 @@ class SVHNDecoderFn(Function):
                  stream_ptr())
             dg3 = conv_down(dout, wd3, None, n, 16, 16, C4, C3, NONE, u_nchw=True, u_act_src=out, u_act=SIGMOID,
                             v_act_src=g3, v_act=RELU)
-        dw2 = conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2)
+        late = late_leaves(z2.device, dg3, g2, g1, z2)
+        if not late.on:
+            dw2 = conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2)
         if not ctx.small:
             db2 = colsum(dg3.view(-1, C3), b2)
         dg2, db1 = conv_down(dg3, wd2, None, n, 8, 8, C3, C2, NONE, v_act_src=g2, v_act=RELU, out_bias=b1,
                              frag=ctx.frags[1])
-        dw1 = conv_wgrad(dg2, g1, w1, n, 4, 4, C2, C1)
+        if not late.on:
+            dw1 = conv_wgrad(dg2, g1, w1, n, 4, 4, C2, C1)
         dg1, db0 = conv_down(dg2, wd1, None, n, 4, 4, C2, C1, NONE, v_act_src=g1, v_act=RELU, out_bias=b0,
                              frag=ctx.frags[0])
         dg1f = dg1.view(n, 16 * C1)
         tw0, dw0 = _grad_target(w0)
+        dz = None
+        if late.on:  # the backward-data chain first, then the weight gradients beside whatever follows it
+            if ctx.needs_input_grad[0]:
+                dz = gemm(dg1f, wp0, n, L, 16 * C1, tb=True).view(ctx.z_shape)
+            dg2.record_stream(_side_stream(z2.device, 30))
+            dg1.record_stream(_side_stream(z2.device, 30))
+            with late:
+                dw2 = conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2)
+                dw1 = conv_wgrad(dg2, g1, w1, n, 4, 4, C2, C1)
+                ws = _ws(z2)
+                call("mvk_unflatten_wgrad", ptr(z2), ptr(dg1f), ptr(tw0), n, L, C1, ptr(ws), ws.numel(), stream_ptr())
+            if dw0 is not None or dw1 is not None or dw2 is not None:  # a gradient autograd itself accumulates: join now
+                torch.cuda.current_stream(z2.device).wait_stream(_side_stream(z2.device, 30))
+            return dz, dw0, db0, dw1, db1, dw2, db2, dw3, db3
         ws = _ws(z2)
         call("mvk_unflatten_wgrad", ptr(z2), ptr(dg1f), ptr(tw0), n, L, C1, ptr(ws), ws.numel(), stream_ptr())
-        dz = None
         if ctx.needs_input_grad[0]:
             dz = gemm(dg1f, wp0, n, L, 16 * C1, tb=True).view(ctx.z_shape)
         return dz, dw0, db0, dw1, db1, dw2, db2, dw3, db3

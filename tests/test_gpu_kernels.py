@@ -1140,6 +1140,60 @@ def test_heads_fwd_matches_float64(M, N, K, layout):
         close_elementwise(got.cpu(), ref, "heads_fwd", rtol=2e-6, atol_frac=2e-6)
 
 
+@pytest.mark.parametrize("M,N,K,layout,nh,flat_c,deferred", [(512, 20, 2048, "kn", 2, 128, True), (512, 20, 512, "nk", 2, 0, True),
+                                                            (130, 17, 48, "nk", 2, 0, False), (1, 32, 64, "kn", 1, 4, False),
+                                                            (300, 5, 16, "nk", 1, 0, True), (512, 20, 2048, "kn", 2, 128, False)])
+def test_heads_bwd_matches_float64(M, N, K, layout, nh, flat_c, deferred):
+    """mvk_heads_bwd: the backward of the encoder heads in one launch (backward data with the activation mask, both weight
+    gradients — in the Conv2d [L][C][4][4] layout with flat_c —, both bias gradients and the bias gradient of the layer
+    below) vs float64; targets inside the flat gradient buffer (deferred finish) and plain tensors (workspace finish); the
+    gradients ACCUMULATE into their targets."""
+    from multivae_amd import kernels as K_
+
+    DEV = dev()
+    gen = g(M * 5 + N + K)
+    x = torch.relu(torch.randn(M, K, generator=gen))
+    w = [torch.randn(N, K, generator=gen) / K ** 0.5 for _ in range(nh)]
+    dy = [torch.randn(M, N, generator=gen) for _ in range(nh)]
+    wd = [(wi if layout == "nk" else wi.t().contiguous()).to(DEV) for wi in w]
+    sk, sn = (1, K) if layout == "nk" else (N, 1)
+    # parameters with gradients: views of one flat buffer (so that the deferred path takes them) or plain tensors
+    sizes = [N * K] * nh + [N] * nh + [flat_c if flat_c else K]  # the layer below: Linear (K units) or Conv2d (flat_c channels)
+    flat = torch.zeros(sum((n + 63) // 64 * 64 for n in sizes), device=DEV)
+    flat.grad = torch.full_like(flat, 0.5)  # the launch must ADD to what is there
+    params, off = [], 0
+    for i, n in enumerate(sizes):
+        p_ = flat[off:off + n].view((N, K) if i < nh else (n,)).detach().requires_grad_(True)
+        p_.grad = flat.grad[off:off + n].view(p_.shape)
+        params.append(p_)
+        off += (n + 63) // 64 * 64
+    wpar, bpar, prev = params[:nh], params[nh:2 * nh], params[2 * nh]
+    xd = x.to(DEV)
+    dyd = [t.to(DEV) for t in dy]
+
+    def run():
+        return K_.heads_bwd(xd, K_.RELU, dyd, wd, bpar, sk, sn, flat_c=flat_c, prev_bias=prev, dw_params=wpar)
+
+    if deferred:
+        with K_.deferred_reductions(flat):
+            out = run()
+    else:
+        out = run()
+    assert out is not None
+    dx, gw, gb, gp = out
+    assert all(t is None for t in gw + gb + [gp])  # accumulated straight into .grad
+    dx_ref = sum(d.double() @ wi.double() for d, wi in zip(dy, w)) * (x > 0).double()
+    close_elementwise(dx.cpu(), dx_ref.float(), "heads_bwd dx", rtol=2e-6, atol_frac=2e-6)
+    for h in range(nh):
+        ref = dy[h].double().t() @ x.double()  # [N][K], k = (tap, c) when flat_c
+        if flat_c:
+            ref = ref.view(N, K // flat_c, flat_c).permute(0, 2, 1).reshape(N, K)
+        close_elementwise(wpar[h].grad.cpu() - 0.5, ref.float(), "heads_bwd dW", rtol=4e-6, atol_frac=4e-6)
+        close_elementwise(bpar[h].grad.cpu() - 0.5, dy[h].double().sum(0).float(), "heads_bwd db", rtol=4e-6, atol_frac=4e-6)
+    prev_ref = dx_ref.view(M, K // flat_c, flat_c).sum((0, 1)) if flat_c else dx_ref.sum(0)
+    close_elementwise(prev.grad.cpu() - 0.5, prev_ref.float(), "heads_bwd d(previous bias)", rtol=4e-6, atol_frac=4e-6)
+
+
 @pytest.mark.parametrize("M,N,K,tb,act,bias_mod", [(5120, 2048, 20, False, "relu", 128), (5120, 400, 20, True, "relu", 400),
                                                    (37, 8, 5, True, "none", 8), (9, 1028, 32, False, "sigmoid", 4),
                                                    (1, 4, 1, False, "none", 0), (600, 64, 13, True, "leaky", 64)])
