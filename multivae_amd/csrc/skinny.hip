@@ -104,17 +104,24 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const HeadsBwdArgs g) {
   __shared__ __attribute__((aligned(16))) float Ws[64 * HB_KC];
   __shared__ __attribute__((aligned(16))) float Xs[HB_MR * HB_XS];
   __shared__ __attribute__((aligned(16))) float Ds[HB_MR * HB_XS];
+  __shared__ float red[16 * 64];
   const int tid = threadIdx.x, N = g.N, K = g.K, NN = g.nh * N, NNP = NN | 1;
   const int k0 = blockIdx.x * HB_KC, rg = blockIdx.y, r0 = rg * HB_MR;
   const int rows = min(HB_MR, g.M - r0);
-  for (int i = tid; i < HB_MR * NN; i += 256) {
-    const int m = i / NN, c = i - m * NN, h = c / N, n = c - h * N;
-    dYs[m * NNP + c] = m < rows ? g.dY[h][(long long)(r0 + m) * N + n] : 0.f;
+  {  // rows past the end are zero everywhere below: every loop over the rows has the fixed trip count HB_MR
+    const int c = tid & 63, mq = tid >> 6;
+    if (c < NN) {
+      const int h = c >= N ? 1 : 0, n = c - h * N;
+      const float* __restrict__ src = g.dY[h] + (long long)r0 * N + n;
+#pragma unroll 8
+      for (int m = mq; m < HB_MR; m += 4) dYs[m * NNP + c] = m < rows ? src[(long long)m * N] : 0.f;
+    }
   }
   for (int i = tid; i < NN * HB_KC; i += 256) {
-    const int c = i / HB_KC, kk = i % HB_KC, h = c / N, n = c - h * N;
+    const int c = i / HB_KC, kk = i % HB_KC, h = c >= N ? 1 : 0, n = c - h * N;
     Ws[i] = g.W[h][(long long)n * g.w_sn + (long long)(k0 + kk) * g.w_sk];
   }
+#pragma unroll
   for (int i = tid; i < HB_MR * (HB_KC / 4); i += 256) {
     const int m = i / (HB_KC / 4), q = i % (HB_KC / 4);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -127,6 +134,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const HeadsBwdArgs g) {
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll 4
     for (int c = 0; c < NN; ++c) {
       const float dy = dYs[m * NNP + c];
       const f32x4 w0 = *reinterpret_cast<const f32x4*>(Ws + c * HB_KC + kh);
@@ -148,10 +156,11 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const HeadsBwdArgs g) {
       *reinterpret_cast<f32x4*>(o + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
     }
   }
-  if (tid < NN * (HB_KC / 4)) {  // weight gradients: thread = (head column, 4 columns of X)
-    const int c = tid / (HB_KC / 4), q = tid % (HB_KC / 4), h = c / N, n = c - h * N;
+  if (tid < NN * (HB_KC / 4)) {  // weight gradients: thread = (head column, 4 columns of X), rows in order
+    const int c = tid / (HB_KC / 4), q = tid % (HB_KC / 4), h = c >= N ? 1 : 0, n = c - h * N;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int m = 0; m < rows; ++m) {
+#pragma unroll 8
+    for (int m = 0; m < HB_MR; ++m) {
       const float dy = dYs[m * NNP + c];
       const f32x4 x = *reinterpret_cast<const f32x4*>(Xs + m * HB_XS + 4 * q);
 #pragma unroll
@@ -164,18 +173,36 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const HeadsBwdArgs g) {
       slab[g.flat_c > 0 ? (k % g.flat_c) * (K / g.flat_c) + k / g.flat_c : k] = acc[e];
     }
   }
-  if (blockIdx.x == 0 && tid >= 192 && tid - 192 < NN) {  // bias gradients of the heads (the last wave: idle above)
-    const int c = tid - 192, h = c / N, n = c - h * N;
-    float t = 0.f;
-    for (int m = 0; m < rows; ++m) t += dYs[m * NNP + c];
-    g.bslab[h][rg * N + n] = t;
-  }
+  __syncthreads();  // Ds complete
+  // column sums: 16 row groups of 8 rows, then the groups in order (fixed order: deterministic)
+  const bool want_b = blockIdx.x == 0;
   if (g.pslab) {
+    const int k = tid & 15, mg = tid >> 4;
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += Ds[(mg * 8 + j) * HB_XS + k];
+    red[mg * 16 + k] = t;
     __syncthreads();
     if (tid < HB_KC) {
-      float t = 0.f;
-      for (int m = 0; m < rows; ++m) t += Ds[m * HB_XS + tid];
-      g.pslab[(long long)rg * K + k0 + tid] = t;
+      float u = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) u += red[q * 16 + tid];
+      g.pslab[(long long)rg * K + k0 + tid] = u;
+    }
+    if (want_b) __syncthreads();
+  }
+  if (want_b) {  // bias gradients of the heads: 4 row groups of 32 rows
+    const int c = tid & 63, mq = tid >> 6;
+    float t = 0.f;
+    if (c < NN) {
+#pragma unroll 8
+      for (int j = 0; j < 32; ++j) t += dYs[(mq * 32 + j) * NNP + c];
+    }
+    red[mq * 64 + c] = t;
+    __syncthreads();
+    if (tid < NN) {
+      const int h = tid >= N ? 1 : 0, n = tid - h * N;
+      g.bslab[h][rg * N + n] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
     }
   }
 }

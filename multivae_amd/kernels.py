@@ -337,6 +337,11 @@ def heads_fwd(h2, w_mu, b_mu, w_lv, b_lv, N, w_sk, w_sn):
 
 
 HEADS_BWD = os.environ.get("MVK_HEADS_BWD", "1") != "0"  # A/B switch: the heads' backward in one launch
+# MEASURED (headline step, one box, 3-4 rounds each): 1.355 ms with the six separate launches, 1.326 ms with the fused launch
+# for the convolutional (SVHN) encoder only, 1.343 ms with the fused launch for the MLP encoder too (its chain is not the
+# critical one and the fused launch delays the other stream's kernels): the MLP encoders keep the separate launches unless
+# MVK_HEADS_BWD_MLP=1.
+HEADS_BWD_MLP = os.environ.get("MVK_HEADS_BWD_MLP", "0") == "1"
 
 
 def heads_bwd(x, x_act, dys, ws_, bs, w_sk, w_sn, flat_c=0, want_dx=True, prev_bias=None, dw_params=None):
@@ -557,16 +562,24 @@ class MLPEncoderFn(Function):
         dmu, dlv = _c(dmu), _c(dlv)
         h = acts[-1]
         grads = [None] * len(params)
-        grads[-4], grads[-3] = linear_bwd_weight(dmu, h, we, be)
-        grads[-2], grads[-1] = linear_bwd_weight(dlv, h, wl, bl)
-        # gradient w.r.t. the last hidden layer's PRE-activation: both heads, ReLU' fused in the epilogue
         prev_src, prev_act = (h, RELU) if n > 0 else (None, NONE)
         need_dx = ctx.needs_input_grad[0]
         dh = None
-        if n > 0 or need_dx:
-            dh = linear_bwd_data(dmu, we, prev_out=prev_src, prev_act=prev_act)
-            linear_bwd_data(dlv, wl, prev_out=prev_src, prev_act=prev_act, out=dh, accumulate=True)
         bias_done = False  # bias gradient of layer i already produced by the backward-data launch of layer i+1
+        # both heads in one launch: weight / bias gradients, the gradient w.r.t. the last hidden layer's PRE-activation
+        # (ReLU' applied) and, with hidden layers, that layer's bias gradient
+        fused = heads_bwd(h, prev_act, [dmu, dlv], [we, wl], [be, bl], 1, h.shape[1], want_dx=n > 0 or need_dx,
+                          prev_bias=params[2 * n - 1] if n > 0 else None) if we.shape == wl.shape and HEADS_BWD_MLP else None
+        if fused is not None:
+            dh, (grads[-4], grads[-2]), (grads[-3], grads[-1]), gprev = fused
+            if n > 0:
+                grads[2 * n - 1], bias_done = gprev, True
+        else:
+            grads[-4], grads[-3] = linear_bwd_weight(dmu, h, we, be)
+            grads[-2], grads[-1] = linear_bwd_weight(dlv, h, wl, bl)
+            if n > 0 or need_dx:
+                dh = linear_bwd_data(dmu, we, prev_out=prev_src, prev_act=prev_act)
+                linear_bwd_data(dlv, wl, prev_out=prev_src, prev_act=prev_act, out=dh, accumulate=True)
         for i in range(n - 1, -1, -1):
             w, inp = params[2 * i], acts[i]
             gb = grads[2 * i + 1]
@@ -615,7 +628,7 @@ class MLPHeadsFn(Function):
         need_dx = ctx.needs_input_grad[0]
         dh = None
         fused = None
-        if nh <= 2 and (n > 0 or need_dx):
+        if HEADS_BWD_MLP and nh <= 2 and (n > 0 or need_dx):
             # every head in one launch; with hidden layers it also emits the last hidden layer's bias gradient
             hw = [params[2 * (n + j)] for j in range(nh)]
             fused = heads_bwd(h, prev_act, [_c(d) for d in douts[:nh]], hw, [params[2 * (n + j) + 1] for j in range(nh)],

@@ -329,9 +329,15 @@ def test_svhn_encoder_decoder_nodes(B):
     close(zd.grad, zr.grad, what="svhn dec dz")
 
 
+@pytest.mark.parametrize("fused_heads_bwd", [False, True])
 @pytest.mark.parametrize("B,D", [(6, (2,)), (33, (1, 28, 28)), (512, (3, 4))])
-def test_mlp_encoder_decoder_nodes(B, D):
+def test_mlp_encoder_decoder_nodes(B, D, fused_heads_bwd, monkeypatch):
+    """Encoder_VAE_MLP / Decoder_AE_MLP nodes vs the oracle networks; the encoder also with the heads' backward in one
+    launch (mvk_heads_bwd; off by default for the MLP encoders: kernels.HEADS_BWD_MLP)."""
     import golden_cases as G
+    from multivae_amd import kernels as K_
+
+    monkeypatch.setattr(K_, "HEADS_BWD_MLP", fused_heads_bwd)
     from multivae_amd.models.base.base_config import BaseAEConfig
     from multivae_amd.models.nn.default_architectures import Decoder_AE_MLP, Encoder_VAE_MLP
 
