@@ -358,14 +358,16 @@ def main():
         from multivae_amd.trainers import GraphedStep
 
         try:
-            graphed = GraphedStep(model, flat, inputs, noise=torch.zeros_like(draw(gen)) if draw is not None else None,
+            # noise=None: the model draws its reparameterisation noise itself, inside the captured graph (as it does under
+            # BaseTrainer and in the reference's forward), instead of a host-side draw + one more copy per step
+            graphed = GraphedStep(model, flat, inputs, noise=None,
                                   capture_error_mode="thread_local" if use_dist else "global", **fkw)
         except Exception as e:  # capture is an optimisation, not a requirement
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graphed = None
 
     def graph_step():
-        out = graphed(inputs, draw(gen) if draw is not None else None)
+        out = graphed(inputs)  # copies the batch into the captured buffers, replays
         if use_dist:
             flat.all_reduce()
         opt.step(grad_scale=grad_scale)
@@ -401,12 +403,12 @@ def main():
         step2 = eager_step
         if graphed is not None:
             try:
-                g2 = GraphedStep(model, flat, inputs, noise=torch.zeros_like(draw(gen)) if draw is not None else None,
+                g2 = GraphedStep(model, flat, inputs, noise=None,
                                  capture_error_mode="thread_local" if use_dist else "global", **fkw)
                 prof.stop()  # the captured launches keep their records; nothing else is stamped from here on
 
                 def step2():
-                    o = g2(inputs, draw(gen) if draw is not None else None)
+                    o = g2(inputs)
                     if use_dist:
                         flat.all_reduce()
                     opt.step(grad_scale=grad_scale)
