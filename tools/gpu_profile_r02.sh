@@ -11,6 +11,12 @@ for c in cfg3 cfg3k1 cfg2 cfg5 cfg4; do
 done
 timeout 600 python bench.py --config cfg2 --family laplace_with_softmax --loss dreg_looser --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_cfg2_laplace_dreg.json
 timeout 900 python bench.py --config cfg4 --batch 64 --no-graph --steps 5 --warmup 2 --no-cpu-baseline 2> $OUT/bench_cfg4_b64_eager.err | grep "^{" | tail -1 > $OUT/bench_cfg4_b64_eager.json
+# 2b. kernel traces of the other configurations (per-kernel shares; the JSON lines above are the unprofiled ones)
+for c in cfg5 cfg4 cfg2; do
+  rocprofv3 --kernel-trace --stats -d $OUT/trace_$c -o t -- python bench.py --config $c --steps 10 --warmup 3 --no-cpu-baseline > $OUT/trace_$c.log 2>&1
+  python tools/rocpd_summary.py $(find $OUT/trace_$c -name "*_results.db" | head -1) > $OUT/${c}_kernel_stats.md 2>/dev/null
+  rm -rf $OUT/trace_$c
+done
 # 3. trainer loop throughput
 timeout 300 python tools/trainer_bench.py cfg3 5 2>/dev/null | tail -1 > $OUT/trainer_cfg3.json
 timeout 300 python tools/trainer_bench.py cfg1 4 2>/dev/null | tail -1 > $OUT/trainer_cfg1.json

@@ -34,6 +34,10 @@ with open(f"{DST}/{TAG}_bench_lines.jsonl", "w") as f:
         if d:
             d["_run"] = c
             f.write(json.dumps(d) + "\n")
+for c in ("cfg5", "cfg4", "cfg2"):  # kernel traces of the other configurations
+    p = f"{SRC}/{c}_kernel_stats.md"
+    if os.path.exists(p) and os.path.getsize(p) > 0:
+        open(f"{DST}/{TAG}_{c}_kernel_stats.md", "w").write(open(p).read())
 # 3. trainer throughput
 tr = [json_line(f"{SRC}/trainer_{c}.json") for c in ("cfg3", "cfg1")]
 open(f"{DST}/{TAG}_trainer_throughput.json", "w").write(json.dumps([t for t in tr if t], indent=1) + "\n")
