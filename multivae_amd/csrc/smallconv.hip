@@ -11,6 +11,7 @@
 // exactly once.  v_mfma_f32_16x16x4_f32: exact fp32.
 #include <cstdlib>
 
+#include "bf3.hpp"
 #include "common.hpp"
 
 #ifndef MVK_SMALL_FWD_THREADS
@@ -35,7 +36,7 @@ extern "C" int mvk_smallup_debug_buffer(unsigned long long* p) {
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+using mvk::f32x4;
 
 template <int CU, int CV>
 struct SmallCfg {
@@ -159,6 +160,141 @@ __global__ __launch_bounds__(NT) void small_up_fwd_kernel(const float* __restric
       }
     }
     __syncthreads();  // the column matrix is overwritten by the next image's V tile
+  }
+  mvk_prof_end(prof);
+}
+
+// The same forward for 16x16 inputs with Cv = 32 on the bf16 matrix cores: the column-matrix GEMM (M = 256, N = 16 Cu, K = 32) is
+// 44 % of the fp32 kernel's time in v_mfma_f32_16x16x4_f32 alone (3072 of ~7000 cycles per image and SIMD).  Here V is split into
+// three bf16 pieces while it is staged (x = x0 + x1 + x2, bf3.hpp; planes [pos][32 k] of 64-byte rows, 16-byte k-octet o of row r at
+// o ^ ((r >> 1) & 3): conflict-free ds_write_b64 staging and ds_read_b128 fragments), the weights once per workgroup, and a product
+// is the 6 piece products of order <= 2 on v_mfma_f32_16x16x32_bf16 — ONE instruction covers the whole K: 6 x 16 cycles per
+// 16 x 16 tile instead of 8 x 32, fp32-level error (same scheme and error bound as the tiled engine, igemm_bf.hpp).
+// Everything around the GEMM (prefetch, column matrix in LDS, output gather, activation) is the fp32 kernel's.
+template <int CU, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT / 128))) void small_up_fwd_bf_kernel(const float* __restrict__ V, const float* __restrict__ Wref,
+                                                              const float* __restrict__ bias, float* __restrict__ U, int n,
+                                                              int act, mvk_prof_slot* prof) {
+  mvk_prof_begin(prof);
+  using mvk::bf16x8;
+  using mvk::u32x2;
+  constexpr int CV = 32, NC = 16 * CU, CS = NC + 1, P = 256, h = 16, w = 16;
+  constexpr int WP = P / (NT / 64), MT = WP / 16;
+  constexpr int PLANE = P * 64, WPLANE = NC * 64;  // bytes per piece plane
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* Wb = reinterpret_cast<char*>(smem);  // 3 x [NC][32 k] bf16
+  float* buf = smem + 3 * WPLANE / 4;       // 3 x [P][32 k] bf16, later the column matrix [P][CS] (+ the zero word)
+  char* Vb = reinterpret_cast<char*>(buf);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+  for (int i = tid; i < NC * 16; i += NT) {  // weight pieces: column nn, k = 2 kp, 2 kp + 1
+    const int nn = i >> 4, kp = i & 15;
+    unsigned p0, p1, p2;
+    mvk::bf3_split(Wref[(2 * kp) * NC + nn], Wref[(2 * kp + 1) * NC + nn], p0, p1, p2);
+    const int off = nn * 64 + (((kp >> 2) ^ ((nn >> 1) & 3)) << 4) + (kp & 3) * 4;
+    *reinterpret_cast<unsigned*>(Wb + off) = p0;
+    *reinterpret_cast<unsigned*>(Wb + WPLANE + off) = p1;
+    *reinterpret_cast<unsigned*>(Wb + 2 * WPLANE + off) = p2;
+  }
+  constexpr int NV = P * CV / 4 / NT;
+  static_assert((P * CV / 4) % NT == 0 && (CU * 1024) % NT == 0 && MT >= 1, "workgroup size");
+  f32x4 pre[NV];
+  auto prefetch = [&](long long img) __attribute__((always_inline)) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(V + img * P * CV);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) pre[u] = src[tid + u * NT];
+  };
+  constexpr int H2 = 2 * h, W2 = 2 * w, per_img = CU * H2 * W2;
+  constexpr int NO = per_img / NT;
+  constexpr int zidx = P * CS;  // one float past the column matrix (and past the piece planes), kept at 0
+  static_assert(3 * PLANE <= zidx * 4, "the zero word must survive the staging");
+  int tap[NO][4];
+  float bia[NO];
+#pragma unroll
+  for (int t = 0; t < NO; ++t) {
+    const int o = tid + t * NT;
+    const int cu = o / (H2 * W2);
+    const int rem = o - cu * (H2 * W2);
+    const int oh = rem / W2, ow = rem - oh * W2;
+    const int ph = oh & 1, pw = ow & 1, i0 = oh >> 1, j0 = ow >> 1;
+    bia[t] = bias ? bias[cu] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int ih = i0 + ph - a, kh = (1 - ph) + 2 * a;
+        const int iw = j0 + pw - b, kw = (1 - pw) + 2 * b;
+        const bool ok = ih >= 0 && ih < h && iw >= 0 && iw < w;
+        tap[t][a * 2 + b] = ok ? (ih * w + iw) * CS + cu * 16 + kh * 4 + kw : zidx;
+      }
+  }
+  if (tid == 0) buf[zidx] = 0.f;
+  // fragment addresses (bytes inside a plane)
+  int aoff[MT], boff[CU];
+#pragma unroll
+  for (int a = 0; a < MT; ++a) {
+    const int r = wave * WP + a * 16 + l15;
+    aoff[a] = r * 64 + ((lq ^ ((r >> 1) & 3)) << 4);
+  }
+#pragma unroll
+  for (int b = 0; b < CU; ++b) {
+    const int c = b * 16 + l15;
+    boff[b] = c * 64 + ((lq ^ ((c >> 1) & 3)) << 4);
+  }
+  long long img = blockIdx.x;
+  if (img < n) prefetch(img);
+  for (; img < n; img += gridDim.x) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int idx = tid + u * NT;
+      const int pos = idx >> 3, q = idx & 7;
+      unsigned a0, a1, a2, b0, b1, b2;
+      mvk::bf3_split(pre[u][0], pre[u][1], a0, a1, a2);
+      mvk::bf3_split(pre[u][2], pre[u][3], b0, b1, b2);
+      const int off = pos * 64 + (((q >> 1) ^ ((pos >> 1) & 3)) << 4) + (q & 1) * 8;
+      *reinterpret_cast<u32x2*>(Vb + off) = u32x2{a0, b0};
+      *reinterpret_cast<u32x2*>(Vb + PLANE + off) = u32x2{a1, b1};
+      *reinterpret_cast<u32x2*>(Vb + 2 * PLANE + off) = u32x2{a2, b2};
+    }
+    __syncthreads();
+    if (img + gridDim.x < n) prefetch(img + gridDim.x);
+    f32x4 acc[MT][CU];
+    {
+      bf16x8 af[MT][3];
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) af[a][p] = *reinterpret_cast<const bf16x8*>(Vb + p * PLANE + aoff[a]);
+      constexpr int PA[6] = {0, 1, 2, 0, 1, 0};  // smallest terms first
+      constexpr int PB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+      for (int b = 0; b < CU; ++b) {  // one column tile's weight pieces at a time (64 registers per lane at 8 waves per SIMD)
+        bf16x8 bfr[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bfr[p] = *reinterpret_cast<const bf16x8*>(Wb + p * WPLANE + boff[b]);
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+          f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < 6; ++t) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][PA[t]], bfr[PB[t]], c, 0, 0, 0);
+          acc[a][b] = c;
+        }
+      }
+    }
+    __syncthreads();  // every wave is done with the piece planes
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < CU; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) buf[(wave * WP + a * 16 + lq * 4 + r) * CS + b * 16 + l15] = acc[a][b][r];
+    __syncthreads();
+    float* out = U + img * per_img;
+#pragma unroll
+    for (int t = 0; t < NO; ++t) {
+      const float sum = ((buf[tap[t][0]] + buf[tap[t][1]]) + (buf[tap[t][2]] + buf[tap[t][3]])) + bia[t];
+      out[tid + t * NT] = mvk_act(sum, act);
+    }
+    __syncthreads();  // the column matrix is overwritten by the next image's pieces
   }
   mvk_prof_end(prof);
 }
@@ -634,6 +770,20 @@ static int launch_fwd(const float* V, const float* Wref, const float* bias, floa
   mvk_prof_slot* prof = mvk::prof_next(5, 4.0 * n * h * w * (CV + 4.0 * CU));
   // dense: 256 positions = one 16-row tile per wave, CV / 4 * 256 float4 and CU * 1024 outputs divide the workgroup evenly
   const bool dense = h == 16 && w == 16 && NT == 1024 && (256 * CV / 4) % NT == 0 && (CU * 1024) % NT == 0;
+  // MVK_SMALL_FWD_BF=0: the exact-fp32 matrix instructions for every shape; =512: the split kernel with 512-thread workgroups
+  static const int bf = getenv("MVK_SMALL_FWD_BF") ? atoi(getenv("MVK_SMALL_FWD_BF")) : 1024;
+  if constexpr (CV == 32 && CU == 3) {
+    if (h == 16 && w == 16 && bf > 0) {
+      const size_t blds = 3 * (16 * CU) * 64 + (256 * (16 * CU + 1) + 4) * sizeof(float);
+      if (bf == 512)
+        hipLaunchKernelGGL((small_up_fwd_bf_kernel<CU, 512>), dim3(grid), dim3(512), blds, s, V, Wref, bias, U, n, act, prof);
+      else
+        hipLaunchKernelGGL((small_up_fwd_bf_kernel<CU, 1024>), dim3(grid), dim3(1024), blds, s, V, Wref, bias, U, n, act, prof);
+      MVK_CHECK_LAUNCH();
+      mvk::prof_fold(prof, s);
+      return MVK_OK;
+    }
+  }
   if (dense)
     hipLaunchKernelGGL((small_up_fwd_kernel<CU, CV, NT, true>), dim3(grid), dim3(NT), lds, s, V, Wref, bias, U, n, h, w, act, prof);
   else
