@@ -609,6 +609,281 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The same backward for the SVHN decoder's shape (16x16 inputs, Cv = 32, sigmoid image, ReLU input map) on the bf16 matrix cores.
+// The fp32 kernel above spends 55 % of a wave's time in its two v_mfma_f32_16x16x4_f32 loops.  Here the im2col'd gradient
+// dC[pos][k = (cu,kh,kw)] is materialised once per image as three bf16 piece planes (x = x0 + x1 + x2, bf3.hpp) and feeds BOTH GEMMs:
+//   backward data    dV[pos][cv] = sum_k dC[pos][k] W[cv][k]   rows of dC are k-contiguous: 16-byte fragments (K = 48 padded to 64
+//                                                               with zero weight pieces), weights as pieces in registers;
+//   backward weight  dW[cv][k]  += sum_pos V[pos][cv] dC[pos][k]  the reduction index is the position, both operands are stored
+//                                                               [pos][channel]: gfx950's transposing LDS read (ds_read_b64_tr_b16)
+//                                                               delivers them k-contiguous, as in imgwgrad_kernel (imgconv.hip).
+// 6 products of order <= 2 on v_mfma_f32_16x16x32_bf16: 42 MFMAs of 16 cycles per wave and image instead of 192 of 32.
+// One 1024-thread workgroup per CU (134 KB of LDS): wave w owns positions [16 w, 16 w + 16) of the backward-data GEMM and
+// (k-step w >> 1, channel tile w & 1) of the weight gradient; three barriers per image; the next image's tiles are in flight in
+// registers meanwhile.
+typedef __bf16 su_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mvk::bf16x8 su_tr_pair(const char* p0, const char* p1) {
+  typedef __attribute__((address_space(3))) su_bf16x4* lp;
+  const su_bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p0));
+  const su_bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p1));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int CU, int NT, int UNITS>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(UNITS * NT / 256, UNITS * NT / 256))) void small_up_bwd_bf_kernel(
+    const float* __restrict__ dU, const float* __restrict__ Uout, const float* __restrict__ V, const float* __restrict__ Wref,
+    float* __restrict__ dV, float* __restrict__ partial, int n, mvk_prof_slot* prof) {
+  mvk_prof_begin(prof);
+  using mvk::bf16x8;
+  using mvk::f32x2;
+  using mvk::u32x2;
+  using mvk::u32x4;
+  // UNITS = 2: a work unit is HALF an image (input rows [8 half, 8 half + 8)); its gradient tile carries the neighbouring half's
+  // two rows as halo.  69 KB of LDS and 256 threads: two workgroups per CU whose phases overlap, and a grid of 512 that packs
+  // beside the other stream's kernels (one 134 KB workgroup per CU is 14 % faster alone but made the training step SLOWER).
+  constexpr int CV = 32, NC = 16 * CU, P = 256 / UNITS, NW = NT / 64, HU = 16 / UNITS;
+  constexpr int KS = P / 32;                   // 32-position k-steps of the weight gradient
+  constexpr int MT = (P / 16) / NW;            // position tiles per wave (backward data)
+  constexpr int CT = 2 * KS / NW;              // channel tiles per wave (weight gradient: wave = k-step x channel-tile group)
+  constexpr int ROWS = UNITS == 1 ? 32 : 2 * HU + 2;  // gradient rows a unit stages (UNITS = 1: the zero halo rows are never written)
+  constexpr int DH = 2 * HU + 2;
+  constexpr int NS = (CU * ROWS * 8 + NT - 1) / NT;   // gradient float4 per staging thread
+  constexpr int NVQ = P * CV / 4 / NT;         // V float4 per thread
+  constexpr int NB = CU * 4 * P / NT;          // im2col items per thread
+  constexpr int DSF = CU * DH * 34;            // floats: [CU][DH][34] pre-activation gradient with halo
+  constexpr int VPL = P * 64, CPL = P * 96;    // bytes per piece plane: V [pos][32 cv], dC [pos][48 k]
+  constexpr int OFF_V = ((DSF * 4 + 15) / 16) * 16, OFF_C = OFF_V + 3 * VPL;
+  static_assert(CU == 3 && MT >= 1 && CT >= 1 && MT * NW * 16 == P && KS * (2 / CT) == NW, "wave split");
+  static_assert(KS * CV * NC * 4 <= 3 * VPL + 3 * CPL && CV * P * 4 <= 3 * VPL + 3 * CPL, "reduction scratch");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ds = smem;
+  char* lds = reinterpret_cast<char*>(smem);
+  char* Vp = lds + OFF_V;
+  char* Cp = lds + OFF_C;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+  for (int i = tid; i < DSF; i += NT) Ds[i] = 0.f;  // the halo columns (and, for whole images, rows) stay zero for the whole launch
+  // weight pieces of the backward-data GEMM: lane (cv = 16 b + l15, k-octet 4 s + lq); octets 6, 7 are the zero padding of K
+  bf16x8 wf[2][2][3];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int o = 4 * s2 + lq;
+      unsigned pc[3][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+      if (o < NC / 8) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(Wref + (b * 16 + l15) * NC + 8 * o);
+        const f32x4 x = src[0], y = src[1];
+        mvk::bf3_split(x[0], x[1], pc[0][0], pc[1][0], pc[2][0]);
+        mvk::bf3_split(x[2], x[3], pc[0][1], pc[1][1], pc[2][1]);
+        mvk::bf3_split(y[0], y[1], pc[0][2], pc[1][2], pc[2][2]);
+        mvk::bf3_split(y[2], y[3], pc[0][3], pc[1][3], pc[2][3]);
+      }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wf[b][s2][p] = __builtin_bit_cast(bf16x8, u32x4{pc[p][0], pc[p][1], pc[p][2], pc[p][3]});
+    }
+  f32x4 accw[CT][CU];
+#pragma unroll
+  for (int a = 0; a < CT; ++a)
+#pragma unroll
+    for (int b = 0; b < CU; ++b) accw[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 dbv[MT][2];
+#pragma unroll
+  for (int a = 0; a < MT; ++a) dbv[a][0] = dbv[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // staging slot u of this thread: float4 f = tid + u NT of the unit's gradient rows = (channel, staged row yy, column quad)
+  float dblq[NS];
+  int dbase[NS], dsrc[NS], dyy[NS], dch[NS];
+  f32x4 qdu[NS], quo[NS], pv[NVQ];
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    const int f = tid + u * NT;
+    const int fc = f < CU * ROWS * 8 ? f : 0;
+    dch[u] = fc / (ROWS * 8);
+    dyy[u] = (fc % (ROWS * 8)) >> 3;
+    dblq[u] = 0.f;
+    dbase[u] = dch[u] * DH * 34 + (dyy[u] + (UNITS == 1 ? 1 : 0)) * 34 + (f & 7) * 4 + 1;
+    dsrc[u] = dch[u] * 256 + (f & 7);  // float4 index of (channel, row 0, quad); + 8 per image row
+    qdu[u] = quo[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const long long nunits = (long long)n * UNITS;
+  auto prefetch = [&](long long unit) __attribute__((always_inline)) {
+    const long long img = unit / UNITS;
+    const int half = (int)(unit % UNITS);
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int oy = UNITS == 1 ? dyy[u] : 2 * HU * half - 1 + dyy[u];  // image gradient row of this slot
+      if (tid + u * NT < CU * ROWS * 8 && oy >= 0 && oy < 32) {
+        qdu[u] = reinterpret_cast<const f32x4*>(dU + img * (CU * 1024))[dsrc[u] + 8 * oy];
+        quo[u] = reinterpret_cast<const f32x4*>(Uout + img * (CU * 1024))[dsrc[u] + 8 * oy];
+      } else {
+        qdu[u] = f32x4{0.f, 0.f, 0.f, 0.f};  // rows outside the image: zero padding
+      }
+    }
+    const f32x4* src = reinterpret_cast<const f32x4*>(V + img * (256 * CV) + half * (P * CV));
+#pragma unroll
+    for (int u = 0; u < NVQ; ++u) pv[u] = src[tid + u * NT];
+  };
+  // fragment addresses
+  int caddr[MT][2];  // backward data: position tile MT wave + a, this lane's position row, k-octet 4 s + lq
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int o = 4 * s2 + lq;
+      // padding octets: any finite data (their weight pieces are 0)
+      caddr[a][s2] = ((wave * MT + a) * 16 + l15) * 96 + (o < NC / 8 ? o : NC / 8 - 1) * 16;
+    }
+  const int kst = wave / (2 / CT), ct0 = (wave % (2 / CT)) * CT;   // weight gradient: k-step, first channel tile
+  const int wrow = 32 * kst + 8 * lq + (l15 >> 2);                  // first of this lane's two rows (+ 4)
+  const int vaddr = wrow * 64 + (ct0 * 16 + 4 * (l15 & 3)) * 2;
+  const int waddr = wrow * 96 + (4 * (l15 & 3)) * 2;
+  constexpr int PA[6] = {0, 1, 2, 0, 1, 0};  // smallest terms first
+  constexpr int PB[6] = {2, 1, 0, 1, 0, 0};
+  long long unit = blockIdx.x;
+  if (unit < nunits) prefetch(unit);
+  for (; unit < nunits; unit += gridDim.x) {
+    __syncthreads();  // the previous unit's planes are no longer read
+#pragma unroll
+    for (int u = 0; u < NS; ++u)
+      if (tid + u * NT < CU * ROWS * 8) {
+        const bool own = UNITS == 1 || (dyy[u] >= 1 && dyy[u] <= 2 * HU);  // halo rows belong to the other half's bias sum
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = qdu[u][e] * (quo[u][e] * (1.f - quo[u][e]));  // sigmoid'
+          Ds[dbase[u] + e] = v;
+          dblq[u] += own ? v : 0.f;
+        }
+      }
+#pragma unroll
+    for (int u = 0; u < NVQ; ++u) {
+      const int idx = tid + u * NT;
+      unsigned a0, a1, a2, b0, b1, b2;
+      mvk::bf3_split(pv[u][0], pv[u][1], a0, a1, a2);
+      mvk::bf3_split(pv[u][2], pv[u][3], b0, b1, b2);
+      const int off = (idx >> 3) * 64 + (idx & 7) * 8;
+      *reinterpret_cast<u32x2*>(Vp + off) = u32x2{a0, b0};
+      *reinterpret_cast<u32x2*>(Vp + VPL + off) = u32x2{a1, b1};
+      *reinterpret_cast<u32x2*>(Vp + 2 * VPL + off) = u32x2{a2, b2};
+    }
+    __syncthreads();
+    if (unit + gridDim.x < nunits) prefetch(unit + gridDim.x);
+    // im2col pieces: item (g = 4 cu + kh, pos): dC[pos][8 bytes at k = 4 g] = the 4 kw taps of gradient row 2 i - 1 + kh
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      const int id = tid + t * NT, g = id / P, pos = id % P;
+      const float* src = Ds + (g >> 2) * (DH * 34) + (2 * (pos >> 4) + (g & 3)) * 34 + 2 * (pos & 15);
+      const f32x2 x = *reinterpret_cast<const f32x2*>(src), y = *reinterpret_cast<const f32x2*>(src + 2);
+      unsigned a0, a1, a2, b0, b1, b2;
+      mvk::bf3_split(x[0], x[1], a0, a1, a2);
+      mvk::bf3_split(y[0], y[1], b0, b1, b2);
+      const int off = pos * 96 + g * 8;
+      *reinterpret_cast<u32x2*>(Cp + off) = u32x2{a0, b0};
+      *reinterpret_cast<u32x2*>(Cp + CPL + off) = u32x2{a1, b1};
+      *reinterpret_cast<u32x2*>(Cp + 2 * CPL + off) = u32x2{a2, b2};
+    }
+    __syncthreads();
+    // --- backward data (transposed tile: rows = channels, columns = positions) + ReLU mask + channel sums
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+      f32x4 c2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 cf[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) cf[p] = *reinterpret_cast<const bf16x8*>(Cp + p * CPL + caddr[a][s2]);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int t = 0; t < 6; ++t) c2[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b][s2][PA[t]], cf[PB[t]], c2[b], 0, 0, 0);
+      }
+      const int dpos = (wave * MT + a) * 16 + l15;
+      float* dv = dV + (unit / UNITS) * (256 * CV) + (int)(unit % UNITS) * (P * CV) + dpos * CV;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int cv = b * 16 + lq * 4;
+        const u32x2 vb = *reinterpret_cast<const u32x2*>(Vp + dpos * 64 + cv * 2);  // leading pieces of V: same sign, zero iff V = 0
+        const unsigned hv[4] = {vb[0] << 16, vb[0] & 0xffff0000u, vb[1] << 16, vb[1] & 0xffff0000u};
+        f32x4 gq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          gq[r] = __uint_as_float(hv[r]) > 0.f ? c2[b][r] : 0.f;
+          dbv[a][b][r] += gq[r];
+        }
+        *reinterpret_cast<f32x4*>(dv + cv) = gq;
+      }
+    }
+    // --- backward weight: this wave's 32 positions (k-step), CT channel tiles, all CU column tiles
+    {
+      bf16x8 va[CT][3];
+#pragma unroll
+      for (int a = 0; a < CT; ++a)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) va[a][p] = su_tr_pair(Vp + p * VPL + vaddr + a * 32, Vp + p * VPL + vaddr + a * 32 + 4 * 64);
+#pragma unroll
+      for (int b = 0; b < CU; ++b) {
+        bf16x8 cb[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) cb[p] = su_tr_pair(Cp + p * CPL + waddr + b * 32, Cp + p * CPL + waddr + b * 32 + 4 * 96);
+#pragma unroll
+        for (int a = 0; a < CT; ++a)
+#pragma unroll
+          for (int t = 0; t < 6; ++t)
+            accw[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[a][PA[t]], cb[PB[t]], accw[a][b], 0, 0, 0);
+      }
+    }
+  }
+  // --- one slab per workgroup: the 8 k-step partials of every weight-gradient tile in order, bias partials, channel sums of dV
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(Vp);  // [KS][CV * NC]
+#pragma unroll
+  for (int a = 0; a < CT; ++a)
+#pragma unroll
+    for (int b = 0; b < CU; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        red[kst * (CV * NC) + ((ct0 + a) * 16 + lq * 4 + r) * NC + b * 16 + l15] = accw[a][b][r];
+  __syncthreads();
+  float* slab = partial + (long long)blockIdx.x * (CV * NC + CU + CV);
+  for (int i = tid; i < CV * NC; i += NT) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < KS; ++q) t += red[q * (CV * NC) + i];
+    slab[i] = t;
+  }
+  __syncthreads();
+  // bias partials: per channel, the waves in order
+#pragma unroll
+  for (int c = 0; c < CU; ++c) {
+    float v = 0.f;
+#pragma unroll
+    for (int u = 0; u < NS; ++u) v += dch[u] == c ? dblq[u] : 0.f;
+    const float sdb = wave_sum(v);
+    if (lane == 0) red[c * NW + wave] = sdb;
+  }
+  __syncthreads();
+  if (tid < CU) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) t += red[tid * NW + q];
+    slab[CV * NC + tid] = t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(b * 16 + lq * 4 + r) * P + (wave * MT + a) * 16 + l15] = dbv[a][b][r];
+  __syncthreads();
+  if (tid < CV) {
+    float t = 0.f;
+#pragma unroll 8
+    for (int q = 0; q < P; ++q) t += red[tid * P + q];
+    slab[CV * NC + CU + tid] = t;
+  }
+  mvk_prof_end(prof);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // forward of the image-CONSUMING layer: V[n,h,w,Cv] = act(conv4s2(U[n,Cu,2h,2w]) + b), Cu <= 4 (svhn.py:13-15 first
 // Conv2d).  Same tile algebra as the backward-data part above (the gradient of the image-producing ConvTranspose IS this
 // convolution): the NCHW image with a zero halo is staged in LDS with coalesced loads (persistent workgroups, next
@@ -804,12 +1079,55 @@ static int launch_bwd(const float* dU, const float* Uout, int u_act, const float
   static const int units_env = getenv("MVK_SMALL_BWD_UNITS") ? atoi(getenv("MVK_SMALL_BWD_UNITS")) : 1;
   const int units = (h == 16 && w == 16 && units_env == 2) ? 2 : 1;
   const long long nunits = (long long)n * units;
-  const int gmax = units == 2 ? 1024 : 512;
-  int grid = nunits < gmax ? (int)nunits : gmax;
+  // MVK_SMALL_BWD_BF (read per call: tests switch it): 0 / unset = the exact-fp32 kernel; 512 / 1024 = the split-bf16 kernel on
+  // whole images, one workgroup of that many threads per CU; any other value = half-image units, 256 threads, two workgroups
+  // per CU.  OFF by default: alone the 512-thread variant is 14 % faster (110 vs 128 us at n = 5120) but the training step gets
+  // SLOWER with it (1.342 vs 1.322 ms): the step is throughput-bound over both modality streams, and a workgroup that owns its
+  // CU (134 KB of LDS) locks the other stream's kernels out where the fp32 kernel leaves them LDS and issue slots.
+  const char* bf_str = getenv("MVK_SMALL_BWD_BF");
+  const int bf_env = bf_str ? atoi(bf_str) : 0;
+  const bool bf = bf_env && CU == 3 && CV == 32 && h == 16 && w == 16 && units_env != 2 && u_act == MVK_ACT_SIGMOID &&
+                  v_act == MVK_ACT_RELU && mvk_aligned16(dU) && mvk_aligned16(Uout) && mvk_aligned16(V) && mvk_aligned16(dV) &&
+                  mvk_aligned16(Wref);
+  const bool bf_whole = bf && (bf_env == 512 || bf_env == 1024);  // whole images, one workgroup per CU
+  const int gmax = bf ? (bf_whole ? 256 : 512) : (units == 2 ? 1024 : 512);
+  const long long bf_units = bf && !bf_whole ? 2ll * n : nunits;
+  int grid = bf_units < gmax ? (int)bf_units : gmax;
   float* dslab = (mvk::defer_free(db) && mvk::defer_free(db_v)) ? mvk::defer_scratch(dWref, (long long)grid * slab, s) : nullptr;
   if (dslab) ws = dslab;
   else if ((int64_t)grid * slab > ws_floats) grid = (int)(ws_floats / slab);
   if (grid < 1) return MVK_EINVAL;
+  if constexpr (CU == 3 && CV == 32) {
+    if (bf) {
+      constexpr int BLDS = ((CU * 34 * 34 * 4 + 15) / 16) * 16 + 3 * 256 * 64 + 3 * 256 * 96;
+      constexpr int BLDS2 = ((CU * 18 * 34 * 4 + 15) / 16) * 16 + 3 * 128 * 64 + 3 * 128 * 96;
+      mvk_prof_slot* prof = mvk::prof_next(6, 4.0 * n * h * w * (2.0 * CV + 8.0 * CU));
+#define MVK_SUBF_LAUNCH(NT_, UN_, LDS_)                                                                                        \
+  do {                                                                                                                         \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_bwd_bf_kernel<CU, NT_, UN_>),                             \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_);                                               \
+    hipLaunchKernelGGL((small_up_bwd_bf_kernel<CU, NT_, UN_>), dim3(grid), dim3(NT_), LDS_, s, dU, Uout, V, Wref, dV, ws, n,   \
+                       prof);                                                                                                  \
+  } while (0)
+      if (bf_env == 1024) MVK_SUBF_LAUNCH(1024, 1, BLDS);
+      else if (bf_env == 512) MVK_SUBF_LAUNCH(512, 1, BLDS);
+      else MVK_SUBF_LAUNCH(256, 2, BLDS2);
+#undef MVK_SUBF_LAUNCH
+      MVK_CHECK_LAUNCH();
+      mvk::prof_fold(prof, s);
+      const int total = CV * C::NC + CU + CV;
+      if (dslab) {
+        int rc = mvk::defer_push_plain(dWref, dslab, CV * C::NC, grid, total, s);
+        if (rc == MVK_OK && db) rc = mvk::defer_push_plain(db, dslab + CV * C::NC, CU, grid, total, s);
+        if (rc == MVK_OK && db_v) rc = mvk::defer_push_plain(db_v, dslab + CV * C::NC + CU, CV, grid, total, s);
+        return rc;
+      }
+      hipLaunchKernelGGL(small_up_bwd_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, s, ws, grid, CV * C::NC, CU, CV,
+                         dWref, db, db_v);
+      MVK_CHECK_LAUNCH();
+      return MVK_OK;
+    }
+  }
   const size_t lds = bwd_lds<CU, CV>(h / units, w);
   constexpr int NT = MVK_SMALL_BWD_THREADS;
   if (lds > 64 * 1024) {
