@@ -609,18 +609,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// The same backward for the SVHN decoder's shape (16x16 inputs, Cv = 32, sigmoid image, ReLU input map) on the bf16 matrix cores.
-// The fp32 kernel above spends 55 % of a wave's time in its two v_mfma_f32_16x16x4_f32 loops.  Here the im2col'd gradient
-// dC[pos][k = (cu,kh,kw)] is materialised once per image as three bf16 piece planes (x = x0 + x1 + x2, bf3.hpp) and feeds BOTH GEMMs:
-//   backward data    dV[pos][cv] = sum_k dC[pos][k] W[cv][k]   rows of dC are k-contiguous: 16-byte fragments (K = 48 padded to 64
-//                                                               with zero weight pieces), weights as pieces in registers;
-//   backward weight  dW[cv][k]  += sum_pos V[pos][cv] dC[pos][k]  the reduction index is the position, both operands are stored
-//                                                               [pos][channel]: gfx950's transposing LDS read (ds_read_b64_tr_b16)
-//                                                               delivers them k-contiguous, as in imgwgrad_kernel (imgconv.hip).
-// 6 products of order <= 2 on v_mfma_f32_16x16x32_bf16: 42 MFMAs of 16 cycles per wave and image instead of 192 of 32.
-// One 1024-thread workgroup per CU (134 KB of LDS): wave w owns positions [16 w, 16 w + 16) of the backward-data GEMM and
-// (k-step w >> 1, channel tile w & 1) of the weight gradient; three barriers per image; the next image's tiles are in flight in
-// registers meanwhile.
 typedef __bf16 su_bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ mvk::bf16x8 su_tr_pair(const char* p0, const char* p1) {
   typedef __attribute__((address_space(3))) su_bf16x4* lp;
@@ -629,132 +617,135 @@ __device__ __forceinline__ mvk::bf16x8 su_tr_pair(const char* p0, const char* p1
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int CU, int NT, int UNITS>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(UNITS * NT / 256, UNITS * NT / 256))) void small_up_bwd_bf_kernel(
+// The backward for the SVHN decoder's shape (16x16 inputs, Cv = 32, sigmoid image, ReLU input map) on the bf16 matrix cores.
+// The fp32 kernel above spends 55 % of a wave's time in its two v_mfma_f32_16x16x4_f32 loops; here both GEMMs take 6 products of
+// order <= 2 of bf16 pieces (x = x0 + x1 + x2, bf3.hpp) on v_mfma_f32_16x16x32_bf16: 192 MFMAs of 16 cycles per wave and image
+// instead of 192 of 32, fp32-level error.  The weight gradient reduces over positions while both of its operands are stored
+// [position][channel]: gfx950's transposing LDS read (ds_read_b64_tr_b16) delivers them k-contiguous, as in imgwgrad_kernel.
+// NO im2col: the gradient image is staged pixel-major into four PARITY planes
+// Dp[y' & 1][x' & 1][y' >> 1][x' >> 1][4 channels (3 + a zero)] (y' = y + 1, x' = x + 1: 17 x 17 entries of 8 bytes per plane, zero
+// halo), so the 3 channels of a tap are one 8-byte piece and K is ordered k' = 4 tap + channel (64 with the zero channel):
+//   backward data    the k-octet (taps 2 o, 2 o + 1) of a position is two 8-byte reads from two parity planes;
+//   backward weight  the transposing read takes per-lane addresses: lane (row, piece) reads the piece of tap 4 b + piece at
+//                    its position's (parity, shifted) entry — the im2col matrix is never written.
+// 76 KB of LDS, 256 threads: two workgroups per CU like the fp32 kernel.
+template <int CU>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void small_up_bwd_bf_kernel(
     const float* __restrict__ dU, const float* __restrict__ Uout, const float* __restrict__ V, const float* __restrict__ Wref,
     float* __restrict__ dV, float* __restrict__ partial, int n, mvk_prof_slot* prof) {
   mvk_prof_begin(prof);
   using mvk::bf16x8;
-  using mvk::f32x2;
   using mvk::u32x2;
   using mvk::u32x4;
-  // UNITS = 2: a work unit is HALF an image (input rows [8 half, 8 half + 8)); its gradient tile carries the neighbouring half's
-  // two rows as halo.  69 KB of LDS and 256 threads: two workgroups per CU whose phases overlap, and a grid of 512 that packs
-  // beside the other stream's kernels (one 134 KB workgroup per CU is 14 % faster alone but made the training step SLOWER).
-  constexpr int CV = 32, NC = 16 * CU, P = 256 / UNITS, NW = NT / 64, HU = 16 / UNITS;
-  constexpr int KS = P / 32;                   // 32-position k-steps of the weight gradient
-  constexpr int MT = (P / 16) / NW;            // position tiles per wave (backward data)
-  constexpr int CT = 2 * KS / NW;              // channel tiles per wave (weight gradient: wave = k-step x channel-tile group)
-  constexpr int ROWS = UNITS == 1 ? 32 : 2 * HU + 2;  // gradient rows a unit stages (UNITS = 1: the zero halo rows are never written)
-  constexpr int DH = 2 * HU + 2;
-  constexpr int NS = (CU * ROWS * 8 + NT - 1) / NT;   // gradient float4 per staging thread
-  constexpr int NVQ = P * CV / 4 / NT;         // V float4 per thread
-  constexpr int NB = CU * 4 * P / NT;          // im2col items per thread
-  constexpr int DSF = CU * DH * 34;            // floats: [CU][DH][34] pre-activation gradient with halo
-  constexpr int VPL = P * 64, CPL = P * 96;    // bytes per piece plane: V [pos][32 cv], dC [pos][48 k]
-  constexpr int OFF_V = ((DSF * 4 + 15) / 16) * 16, OFF_C = OFF_V + 3 * VPL;
-  static_assert(CU == 3 && MT >= 1 && CT >= 1 && MT * NW * 16 == P && KS * (2 / CT) == NW, "wave split");
-  static_assert(KS * CV * NC * 4 <= 3 * VPL + 3 * CPL && CV * P * 4 <= 3 * VPL + 3 * CPL, "reduction scratch");
+  static_assert(CU == 3, "three image channels + one zero channel per 8-byte piece");
+  constexpr int CV = 32, NC = 16 * CU, P = 256, NT = 256, NW = 4, MT = 4;
+  constexpr int PL1 = 289 * 8;        // bytes of one parity plane (17 x 17 pieces)
+  constexpr int PLD = 4 * PL1;        // bytes of one bf16 piece plane of the gradient
+  constexpr int VPL = P * 64;         // bytes of one piece plane of V [pos][32 cv]
+  constexpr int OFF_V = 3 * PLD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ds = smem;
-  char* lds = reinterpret_cast<char*>(smem);
-  char* Vp = lds + OFF_V;
-  char* Cp = lds + OFF_C;
+  char* Dp = reinterpret_cast<char*>(smem);
+  char* Vp = Dp + OFF_V;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
-  for (int i = tid; i < DSF; i += NT) Ds[i] = 0.f;  // the halo columns (and, for whole images, rows) stay zero for the whole launch
-  // weight pieces of the backward-data GEMM: lane (cv = 16 b + l15, k-octet 4 s + lq); octets 6, 7 are the zero padding of K
+  for (int i = tid; i < OFF_V / 4; i += NT) smem[i] = 0.f;  // the halo entries stay zero for the whole launch
+  // weight pieces of the backward-data GEMM: lane (cv = 16 b + l15, k'-octet o = 4 s + lq = taps 2 o, 2 o + 1 x 4 channels)
   bf16x8 wf[2][2][3];
 #pragma unroll
   for (int b = 0; b < 2; ++b)
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       const int o = 4 * s2 + lq;
-      unsigned pc[3][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-      if (o < NC / 8) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(Wref + (b * 16 + l15) * NC + 8 * o);
-        const f32x4 x = src[0], y = src[1];
-        mvk::bf3_split(x[0], x[1], pc[0][0], pc[1][0], pc[2][0]);
-        mvk::bf3_split(x[2], x[3], pc[0][1], pc[1][1], pc[2][1]);
-        mvk::bf3_split(y[0], y[1], pc[0][2], pc[1][2], pc[2][2]);
-        mvk::bf3_split(y[2], y[3], pc[0][3], pc[1][3], pc[2][3]);
+      const float* wr = Wref + (b * 16 + l15) * NC + 2 * o;  // + 16 ch + tt
+      unsigned pc[3][4];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        mvk::bf3_split(wr[tt], wr[16 + tt], pc[0][2 * tt], pc[1][2 * tt], pc[2][2 * tt]);
+        mvk::bf3_split(wr[32 + tt], 0.f, pc[0][2 * tt + 1], pc[1][2 * tt + 1], pc[2][2 * tt + 1]);
       }
 #pragma unroll
       for (int p = 0; p < 3; ++p) wf[b][s2][p] = __builtin_bit_cast(bf16x8, u32x4{pc[p][0], pc[p][1], pc[p][2], pc[p][3]});
     }
-  f32x4 accw[CT][CU];
+  f32x4 accw[2][4];
 #pragma unroll
-  for (int a = 0; a < CT; ++a)
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < CU; ++b) accw[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < 4; ++b) accw[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 dbv[MT][2];
 #pragma unroll
   for (int a = 0; a < MT; ++a) dbv[a][0] = dbv[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // staging slot u of this thread: float4 f = tid + u NT of the unit's gradient rows = (channel, staged row yy, column quad)
-  float dblq[NS];
-  int dbase[NS], dsrc[NS], dyy[NS], dch[NS];
-  f32x4 qdu[NS], quo[NS], pv[NVQ];
+  float dblq[CU] = {0.f, 0.f, 0.f};
+  // staging: this thread's 4 pixels (row tid >> 3, columns 4 (tid & 7) ..) of every channel -> their parity-plane pieces
+  int dst[4];
 #pragma unroll
-  for (int u = 0; u < NS; ++u) {
-    const int f = tid + u * NT;
-    const int fc = f < CU * ROWS * 8 ? f : 0;
-    dch[u] = fc / (ROWS * 8);
-    dyy[u] = (fc % (ROWS * 8)) >> 3;
-    dblq[u] = 0.f;
-    dbase[u] = dch[u] * DH * 34 + (dyy[u] + (UNITS == 1 ? 1 : 0)) * 34 + (f & 7) * 4 + 1;
-    dsrc[u] = dch[u] * 256 + (f & 7);  // float4 index of (channel, row 0, quad); + 8 per image row
-    qdu[u] = quo[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int e = 0; e < 4; ++e) {
+    const int yp = (tid >> 3) + 1, xp = (tid & 7) * 4 + e + 1;
+    dst[e] = (((yp & 1) * 2 + (xp & 1)) * 289 + (yp >> 1) * 17 + (xp >> 1)) * 8;
   }
-  const long long nunits = (long long)n * UNITS;
-  auto prefetch = [&](long long unit) __attribute__((always_inline)) {
-    const long long img = unit / UNITS;
-    const int half = (int)(unit % UNITS);
-#pragma unroll
-    for (int u = 0; u < NS; ++u) {
-      const int oy = UNITS == 1 ? dyy[u] : 2 * HU * half - 1 + dyy[u];  // image gradient row of this slot
-      if (tid + u * NT < CU * ROWS * 8 && oy >= 0 && oy < 32) {
-        qdu[u] = reinterpret_cast<const f32x4*>(dU + img * (CU * 1024))[dsrc[u] + 8 * oy];
-        quo[u] = reinterpret_cast<const f32x4*>(Uout + img * (CU * 1024))[dsrc[u] + 8 * oy];
-      } else {
-        qdu[u] = f32x4{0.f, 0.f, 0.f, 0.f};  // rows outside the image: zero padding
-      }
+  f32x4 qdu[CU], quo[CU], pv[8];
+  // (the 14 loads of the next image go out in ONE burst right behind the staging: spread over the backward-data tiles they
+  // arrive too late — staging then waits 38 % of the wave's cycles for them, 136 us instead of 110)
+  auto prefetch_part = [&](long long img, int part) __attribute__((always_inline)) {
+    if (part < CU) {
+      qdu[part] = reinterpret_cast<const f32x4*>(dU + img * (CU * 1024))[tid + part * NT];
+      quo[part] = reinterpret_cast<const f32x4*>(Uout + img * (CU * 1024))[tid + part * NT];
     }
-    const f32x4* src = reinterpret_cast<const f32x4*>(V + img * (256 * CV) + half * (P * CV));
-#pragma unroll
-    for (int u = 0; u < NVQ; ++u) pv[u] = src[tid + u * NT];
+    const f32x4* src = reinterpret_cast<const f32x4*>(V + img * (P * CV));
+    pv[2 * part] = src[tid + (2 * part) * NT];
+    pv[2 * part + 1] = src[tid + (2 * part + 1) * NT];
   };
-  // fragment addresses
-  int caddr[MT][2];  // backward data: position tile MT wave + a, this lane's position row, k-octet 4 s + lq
+  auto prefetch = [&](long long img) __attribute__((always_inline)) {
+#pragma unroll
+    for (int part = 0; part < 4; ++part) prefetch_part(img, part);
+  };
+  // entry of tap (kh, kw) for input position (i, j): parity (kh & 1, kw & 1), entry (i + (kh >> 1), j + (kw >> 1))
+  auto dentry = [](int pos, int tap) {
+    const int i = pos >> 4, j = pos & 15, kh = tap >> 2, kw = tap & 3;
+    return ((((kh & 1) * 2 + (kw & 1)) * 289) + (i + (kh >> 1)) * 17 + j + (kw >> 1)) * 8;
+  };
+  int daddr[MT][2];  // backward data: first tap of this lane's octet (the second: the next parity plane, + PL1)
 #pragma unroll
   for (int a = 0; a < MT; ++a)
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const int o = 4 * s2 + lq;
-      // padding octets: any finite data (their weight pieces are 0)
-      caddr[a][s2] = ((wave * MT + a) * 16 + l15) * 96 + (o < NC / 8 ? o : NC / 8 - 1) * 16;
-    }
-  const int kst = wave / (2 / CT), ct0 = (wave % (2 / CT)) * CT;   // weight gradient: k-step, first channel tile
-  const int wrow = 32 * kst + 8 * lq + (l15 >> 2);                  // first of this lane's two rows (+ 4)
-  const int vaddr = wrow * 64 + (ct0 * 16 + 4 * (l15 & 3)) * 2;
-  const int waddr = wrow * 96 + (4 * (l15 & 3)) * 2;
+    for (int s2 = 0; s2 < 2; ++s2) daddr[a][s2] = dentry((wave * MT + a) * 16 + l15, 2 * (4 * s2 + lq));
+  int vaddr[2], waddr[2][4];  // weight gradient: k-steps 2 wave, 2 wave + 1; rows 8 lq + (l15 >> 2) (+ 4), piece l15 & 3
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int pos0 = 32 * (2 * wave + ks) + 8 * lq + (l15 >> 2);
+    vaddr[ks] = pos0 * 64 + (4 * (l15 & 3)) * 2;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) waddr[ks][b] = dentry(pos0, 4 * b + (l15 & 3));
+  }
   constexpr int PA[6] = {0, 1, 2, 0, 1, 0};  // smallest terms first
   constexpr int PB[6] = {2, 1, 0, 1, 0, 0};
-  long long unit = blockIdx.x;
-  if (unit < nunits) prefetch(unit);
-  for (; unit < nunits; unit += gridDim.x) {
-    __syncthreads();  // the previous unit's planes are no longer read
+  long long img = blockIdx.x;
+  if (img < n) prefetch(img);
+#ifdef MVK_SUPROF  // tools/smallup_phase.sh: per-wave cycle counters
+  unsigned long long su_t[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long su_t0 = __builtin_readcyclecounter();
+#endif
+  for (; img < n; img += gridDim.x) {
+#ifdef MVK_SUPROF
+    unsigned long long su_last = __builtin_readcyclecounter();
+#endif
+    __syncthreads();  // the previous image's planes are no longer read
+    SU_T(0)
 #pragma unroll
-    for (int u = 0; u < NS; ++u)
-      if (tid + u * NT < CU * ROWS * 8) {
-        const bool own = UNITS == 1 || (dyy[u] >= 1 && dyy[u] <= 2 * HU);  // halo rows belong to the other half's bias sum
+    for (int e = 0; e < 4; ++e) {
+      float v[CU];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = qdu[u][e] * (quo[u][e] * (1.f - quo[u][e]));  // sigmoid'
-          Ds[dbase[u] + e] = v;
-          dblq[u] += own ? v : 0.f;
-        }
+      for (int c = 0; c < CU; ++c) {
+        v[c] = qdu[c][e] * (quo[c][e] * (1.f - quo[c][e]));  // sigmoid'
+        dblq[c] += v[c];
       }
+      unsigned a0, a1, a2, b0, b1, b2;
+      mvk::bf3_split(v[0], v[1], a0, a1, a2);
+      mvk::bf3_split(v[2], 0.f, b0, b1, b2);
+      *reinterpret_cast<u32x2*>(Dp + dst[e]) = u32x2{a0, b0};
+      *reinterpret_cast<u32x2*>(Dp + PLD + dst[e]) = u32x2{a1, b1};
+      *reinterpret_cast<u32x2*>(Dp + 2 * PLD + dst[e]) = u32x2{a2, b2};
+    }
 #pragma unroll
-    for (int u = 0; u < NVQ; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const int idx = tid + u * NT;
       unsigned a0, a1, a2, b0, b1, b2;
       mvk::bf3_split(pv[u][0], pv[u][1], a0, a1, a2);
@@ -764,23 +755,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(UNITS * NT /
       *reinterpret_cast<u32x2*>(Vp + VPL + off) = u32x2{a1, b1};
       *reinterpret_cast<u32x2*>(Vp + 2 * VPL + off) = u32x2{a2, b2};
     }
+    SU_T(1)
     __syncthreads();
-    if (unit + gridDim.x < nunits) prefetch(unit + gridDim.x);
-    // im2col pieces: item (g = 4 cu + kh, pos): dC[pos][8 bytes at k = 4 g] = the 4 kw taps of gradient row 2 i - 1 + kh
-#pragma unroll
-    for (int t = 0; t < NB; ++t) {
-      const int id = tid + t * NT, g = id / P, pos = id % P;
-      const float* src = Ds + (g >> 2) * (DH * 34) + (2 * (pos >> 4) + (g & 3)) * 34 + 2 * (pos & 15);
-      const f32x2 x = *reinterpret_cast<const f32x2*>(src), y = *reinterpret_cast<const f32x2*>(src + 2);
-      unsigned a0, a1, a2, b0, b1, b2;
-      mvk::bf3_split(x[0], x[1], a0, a1, a2);
-      mvk::bf3_split(y[0], y[1], b0, b1, b2);
-      const int off = pos * 96 + g * 8;
-      *reinterpret_cast<u32x2*>(Cp + off) = u32x2{a0, b0};
-      *reinterpret_cast<u32x2*>(Cp + CPL + off) = u32x2{a1, b1};
-      *reinterpret_cast<u32x2*>(Cp + 2 * CPL + off) = u32x2{a2, b2};
-    }
-    __syncthreads();
+    SU_T(0)
+    if (img + gridDim.x < n) prefetch(img + gridDim.x);
+    SU_T(2)
     // --- backward data (transposed tile: rows = channels, columns = positions) + ReLU mask + channel sums
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
@@ -789,14 +768,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(UNITS * NT /
       for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8 cf[3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) cf[p] = *reinterpret_cast<const bf16x8*>(Cp + p * CPL + caddr[a][s2]);
+        for (int p = 0; p < 3; ++p) {
+          const u32x2 t0 = *reinterpret_cast<const u32x2*>(Dp + p * PLD + daddr[a][s2]);
+          const u32x2 t1 = *reinterpret_cast<const u32x2*>(Dp + p * PLD + daddr[a][s2] + PL1);
+          cf[p] = __builtin_bit_cast(bf16x8, u32x4{t0[0], t0[1], t1[0], t1[1]});
+        }
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
           for (int t = 0; t < 6; ++t) c2[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b][s2][PA[t]], cf[PB[t]], c2[b], 0, 0, 0);
       }
       const int dpos = (wave * MT + a) * 16 + l15;
-      float* dv = dV + (unit / UNITS) * (256 * CV) + (int)(unit % UNITS) * (P * CV) + dpos * CV;
+      float* dv = dV + img * (P * CV) + dpos * CV;
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         const int cv = b * 16 + lq * 4;
@@ -811,61 +794,60 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(UNITS * NT /
         *reinterpret_cast<f32x4*>(dv + cv) = gq;
       }
     }
-    // --- backward weight: this wave's 32 positions (k-step), CT channel tiles, all CU column tiles
-    {
-      bf16x8 va[CT][3];
+    SU_T(3)
+    // --- backward weight: this wave's two 32-position k-steps, both channel tiles, the four (4 taps x 4 channels) column tiles
 #pragma unroll
-      for (int a = 0; a < CT; ++a)
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 va[2][3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) va[a][p] = su_tr_pair(Vp + p * VPL + vaddr + a * 32, Vp + p * VPL + vaddr + a * 32 + 4 * 64);
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < CU; ++b) {
+        for (int p = 0; p < 3; ++p) va[a][p] = su_tr_pair(Vp + p * VPL + vaddr[ks] + a * 32, Vp + p * VPL + vaddr[ks] + a * 32 + 4 * 64);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
         bf16x8 cb[3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) cb[p] = su_tr_pair(Cp + p * CPL + waddr + b * 32, Cp + p * CPL + waddr + b * 32 + 4 * 96);
+        for (int p = 0; p < 3; ++p) cb[p] = su_tr_pair(Dp + p * PLD + waddr[ks][b], Dp + p * PLD + waddr[ks][b] + 4 * 8);
 #pragma unroll
-        for (int a = 0; a < CT; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
           for (int t = 0; t < 6; ++t)
             accw[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[a][PA[t]], cb[PB[t]], accw[a][b], 0, 0, 0);
       }
     }
+    SU_T(5)
   }
-  // --- one slab per workgroup: the 8 k-step partials of every weight-gradient tile in order, bias partials, channel sums of dV
+#ifdef MVK_SUPROF
+  if (g_su_dbg && lane == 0) {
+    unsigned long long* o = g_su_dbg + (blockIdx.x * NW + wave) * 8;
+    o[0] = __builtin_readcyclecounter() - su_t0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[1 + i] = su_t[i];
+  }
+#endif
+  // --- one slab per workgroup: the waves' weight-gradient partials in order, bias partials, channel sums of dV
   __syncthreads();
-  float* red = reinterpret_cast<float*>(Vp);  // [KS][CV * NC]
+  float* red = reinterpret_cast<float*>(Vp);  // [NW][CV][64 columns k' = 4 tap + channel]
 #pragma unroll
-  for (int a = 0; a < CT; ++a)
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < CU; ++b)
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        red[kst * (CV * NC) + ((ct0 + a) * 16 + lq * 4 + r) * NC + b * 16 + l15] = accw[a][b][r];
+      for (int r = 0; r < 4; ++r) red[wave * (CV * 64) + (a * 16 + lq * 4 + r) * 64 + b * 16 + l15] = accw[a][b][r];
   __syncthreads();
   float* slab = partial + (long long)blockIdx.x * (CV * NC + CU + CV);
   for (int i = tid; i < CV * NC; i += NT) {
-    float t = 0.f;
-#pragma unroll
-    for (int q = 0; q < KS; ++q) t += red[q * (CV * NC) + i];
-    slab[i] = t;
+    const int cv = i / NC, k = i - cv * NC, src = cv * 64 + (k & 15) * 4 + (k >> 4);  // k = 16 channel + tap
+    slab[i] = ((red[src] + red[CV * 64 + src]) + red[2 * CV * 64 + src]) + red[3 * CV * 64 + src];
   }
   __syncthreads();
-  // bias partials: per channel, the waves in order
 #pragma unroll
   for (int c = 0; c < CU; ++c) {
-    float v = 0.f;
-#pragma unroll
-    for (int u = 0; u < NS; ++u) v += dch[u] == c ? dblq[u] : 0.f;
-    const float sdb = wave_sum(v);
+    const float sdb = wave_sum(dblq[c]);
     if (lane == 0) red[c * NW + wave] = sdb;
   }
   __syncthreads();
-  if (tid < CU) {
-    float t = 0.f;
-#pragma unroll
-    for (int q = 0; q < NW; ++q) t += red[tid * NW + q];
-    slab[CV * NC + tid] = t;
-  }
+  if (tid < CU) slab[CV * NC + tid] = ((red[tid * NW] + red[tid * NW + 1]) + red[tid * NW + 2]) + red[tid * NW + 3];
   __syncthreads();
 #pragma unroll
   for (int a = 0; a < MT; ++a)
@@ -874,10 +856,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(UNITS * NT /
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[(b * 16 + lq * 4 + r) * P + (wave * MT + a) * 16 + l15] = dbv[a][b][r];
   __syncthreads();
-  if (tid < CV) {
+  {  // 8 threads per channel sum 32 positions each, then the 8 partial sums in order
+    const int cv = tid >> 3, seg = tid & 7;
     float t = 0.f;
 #pragma unroll 8
-    for (int q = 0; q < P; ++q) t += red[tid * P + q];
+    for (int q = 0; q < 32; ++q) t += red[cv * P + seg * 32 + q];
+    red[CV * P + tid] = t;
+  }
+  __syncthreads();
+  if (tid < CV) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[CV * P + tid * 8 + q];
     slab[CV * NC + CU + tid] = t;
   }
   mvk_prof_end(prof);
@@ -1079,40 +1069,25 @@ static int launch_bwd(const float* dU, const float* Uout, int u_act, const float
   static const int units_env = getenv("MVK_SMALL_BWD_UNITS") ? atoi(getenv("MVK_SMALL_BWD_UNITS")) : 1;
   const int units = (h == 16 && w == 16 && units_env == 2) ? 2 : 1;
   const long long nunits = (long long)n * units;
-  // MVK_SMALL_BWD_BF (read per call: tests switch it): 0 / unset = the exact-fp32 kernel; 512 / 1024 = the split-bf16 kernel on
-  // whole images, one workgroup of that many threads per CU; any other value = half-image units, 256 threads, two workgroups
-  // per CU.  OFF by default: alone the 512-thread variant is 14 % faster (110 vs 128 us at n = 5120) but the training step gets
-  // SLOWER with it (1.342 vs 1.322 ms): the step is throughput-bound over both modality streams, and a workgroup that owns its
-  // CU (134 KB of LDS) locks the other stream's kernels out where the fp32 kernel leaves them LDS and issue slots.
+  // MVK_SMALL_BWD_BF=0 (read per call: tests switch it): the exact-fp32 kernel for every shape.  Default: the split-bf16 kernel at
+  // the SVHN decoder's shape — 128 -> 110 us alone at n = 5120, -13 us per training step (three A/B pairs on one box).
   const char* bf_str = getenv("MVK_SMALL_BWD_BF");
-  const int bf_env = bf_str ? atoi(bf_str) : 0;
-  const bool bf = bf_env && CU == 3 && CV == 32 && h == 16 && w == 16 && units_env != 2 && u_act == MVK_ACT_SIGMOID &&
-                  v_act == MVK_ACT_RELU && mvk_aligned16(dU) && mvk_aligned16(Uout) && mvk_aligned16(V) && mvk_aligned16(dV) &&
-                  mvk_aligned16(Wref);
-  const bool bf_whole = bf && (bf_env == 512 || bf_env == 1024);  // whole images, one workgroup per CU
-  const int gmax = bf ? (bf_whole ? 256 : 512) : (units == 2 ? 1024 : 512);
-  const long long bf_units = bf && !bf_whole ? 2ll * n : nunits;
-  int grid = bf_units < gmax ? (int)bf_units : gmax;
+  const bool bf = (!bf_str || atoi(bf_str) != 0) && CU == 3 && CV == 32 && h == 16 && w == 16 && units_env != 2 &&
+                  u_act == MVK_ACT_SIGMOID && v_act == MVK_ACT_RELU && mvk_aligned16(dU) && mvk_aligned16(Uout) &&
+                  mvk_aligned16(V) && mvk_aligned16(dV) && mvk_aligned16(Wref);
+  const int gmax = units == 2 ? 1024 : 512;
+  int grid = nunits < gmax ? (int)nunits : gmax;
   float* dslab = (mvk::defer_free(db) && mvk::defer_free(db_v)) ? mvk::defer_scratch(dWref, (long long)grid * slab, s) : nullptr;
   if (dslab) ws = dslab;
   else if ((int64_t)grid * slab > ws_floats) grid = (int)(ws_floats / slab);
   if (grid < 1) return MVK_EINVAL;
   if constexpr (CU == 3 && CV == 32) {
     if (bf) {
-      constexpr int BLDS = ((CU * 34 * 34 * 4 + 15) / 16) * 16 + 3 * 256 * 64 + 3 * 256 * 96;
-      constexpr int BLDS2 = ((CU * 18 * 34 * 4 + 15) / 16) * 16 + 3 * 128 * 64 + 3 * 128 * 96;
       mvk_prof_slot* prof = mvk::prof_next(6, 4.0 * n * h * w * (2.0 * CV + 8.0 * CU));
-#define MVK_SUBF_LAUNCH(NT_, UN_, LDS_)                                                                                        \
-  do {                                                                                                                         \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_bwd_bf_kernel<CU, NT_, UN_>),                             \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_);                                               \
-    hipLaunchKernelGGL((small_up_bwd_bf_kernel<CU, NT_, UN_>), dim3(grid), dim3(NT_), LDS_, s, dU, Uout, V, Wref, dV, ws, n,   \
-                       prof);                                                                                                  \
-  } while (0)
-      if (bf_env == 1024) MVK_SUBF_LAUNCH(1024, 1, BLDS);
-      else if (bf_env == 512) MVK_SUBF_LAUNCH(512, 1, BLDS);
-      else MVK_SUBF_LAUNCH(256, 2, BLDS2);
-#undef MVK_SUBF_LAUNCH
+      constexpr int BLDS = 3 * 4 * 289 * 8 + 3 * 256 * 64;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_bwd_bf_kernel<CU>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, BLDS);
+      hipLaunchKernelGGL((small_up_bwd_bf_kernel<CU>), dim3(grid), dim3(256), BLDS, s, dU, Uout, V, Wref, dV, ws, n, prof);
       MVK_CHECK_LAUNCH();
       mvk::prof_fold(prof, s);
       const int total = CV * C::NC + CU + CV;

@@ -599,11 +599,11 @@ def test_adam_amsgrad_matches_torch(K):
     close(vd, opt.state[ref]["exp_avg_sq"], rtol=1e-6, what="exp_avg_sq")
 
 
-@pytest.mark.parametrize("bwd_bf", ["0", "512", "1"])
+@pytest.mark.parametrize("bwd_bf", ["0", "1"])
 @pytest.mark.parametrize("n,h,w,Cu,Cv", [(3, 16, 16, 3, 32), (700, 16, 16, 3, 32), (5, 8, 8, 1, 16), (2, 16, 8, 4, 64)])
 def test_small_up_fwd_bwd(K, n, h, w, Cu, Cv, bwd_bf, monkeypatch):
     """The per-image MFMA kernels of the image-producing layer (smallconv.hip) against torch CPU.  bwd_bf: the backward on the
-    exact-fp32 matrix instructions (default) / the split-bf16 variants (whole images, half-image units; 16x16x3x32 only)."""
+    exact-fp32 matrix instructions / the split-bf16 kernel (default at the SVHN decoder's shape 16x16x3x32)."""
     from multivae_amd import _lib
     from multivae_amd._lib import call, ptr, stream_ptr
 
