@@ -397,6 +397,13 @@ int mvk_avgpool3s2_bwd(const float* dy, float* dx, int n, int H, int W, int C, v
 int mvk_upsample2_fwd(const float* x, float* y, int n, int H, int W, int C, void* stream);
 int mvk_upsample2_bwd(const float* dy, float* dx, int n, int H, int W, int C, void* stream);
 int mvk_axpby(const float* x, float a, const float* y, float b, int64_t n, int act, float* out, void* stream);
+
+/* Noise drawn with the generator state in device memory (the reparameterisation noise of models/base/base_utils.py:129-160
+ * `rsample_from_gaussian` and of every `rsample` on the path; the reference calls torch's generator).  state: 3 x uint64
+ * {seed, offset, arrival ticket} owned by the caller, advanced by the launch itself — a captured training step draws fresh
+ * noise at every replay with no host-issued launch in front of it.  Philox4x32-10, counter = offset + index / 4; uniform = 0:
+ * N(0, 1) by Box-Muller; uniform = 1: U[lo, hi).  The values depend only on (seed, offset, index). */
+int mvk_device_rng(float* out, int64_t n, uint64_t* state, int uniform, float lo, float hi, void* stream);
 /* Direct kernel for the 3-channel image-producing layer: U[n,Cu,2h,2w] (NCHW) = act(convT(V) + b), Cu <= 4,
  * reading the reference weight tensor directly (models/nn/svhn.py:58-60). */
 int mvk_conv4s2_up_nchw_small(const float* V, const float* Wref, const float* bias, float* U, int n, int h,

@@ -798,6 +798,86 @@ int mvk_upsample2_bwd(const float* dy, float* dx, int n, int H, int W, int C, vo
   return MVK_OK;
 }
 
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// Noise with the generator state in DEVICE memory: a hipGraph replay of a training step draws fresh noise without the
+// two host-issued fill launches per replay that torch's graph-safe generator needs (seed / offset tensors).
+// Philox4x32-10 (counter = offset + thread index, key = seed), 4 values per thread; normal: Box-Muller.
+// state[0] = seed, state[1] = offset (in threads), state[2] = arrival ticket.  Every workgroup reads the offset, then takes
+// a ticket; the last one to arrive advances the offset by the launch's thread count and resets the ticket — the values
+// depend only on (seed, offset, index): deterministic, and consecutive launches on a stream never overlap.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+  const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+  const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1;
+  const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+  c[0] = n0, c[1] = n1, c[2] = n2, c[3] = n3;
+}
+
+__global__ __launch_bounds__(256) void device_rng_kernel(float* __restrict__ out, long long n, unsigned long long* __restrict__ st,
+                                                         int uniform, float lo, float hi) {
+  const unsigned long long seed = st[0], off = st[1];
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long ctr = off + (unsigned long long)idx;
+  unsigned c[4] = {(unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u};
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  float v[4];
+  if (uniform) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = lo + (float)(c[e] >> 8) * (1.0f / 16777216.0f) * (hi - lo);  // [lo, hi)
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+      const float u1 = (float)((c[e] >> 8) + 1u) * (1.0f / 16777216.0f);  // (0, 1]
+      const float u2 = (float)(c[e + 1] >> 8) * (1.0f / 16777216.0f);     // [0, 1)
+      const float r = sqrtf(-2.0f * logf(u1));
+      float sn, cs;
+      sincosf(6.28318530717958647692f * u2, &sn, &cs);
+      v[e] = r * cs;
+      v[e + 1] = r * sn;
+    }
+  }
+  const long long o = idx * 4;
+  if (o + 3 < n && mvk_dev_aligned16(out)) {
+    *reinterpret_cast<float4*>(out + o) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (o + e < n) out[o + e] = v[e];
+  }
+  __syncthreads();  // every thread of this workgroup has read the offset
+  if (threadIdx.x == 0) {
+    __threadfence();
+    unsigned* ticket = reinterpret_cast<unsigned*>(st + 2);
+    if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+      st[1] = off + (unsigned long long)gridDim.x * 256ull;
+      *ticket = 0u;
+      __threadfence();
+    }
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int mvk_device_rng(float* out, int64_t n, uint64_t* state, int uniform, float lo, float hi, void* stream) {
+  if (!out || !state || n < 0) return MVK_EINVAL;
+  if (n == 0) return MVK_OK;
+  const long long threads = (n + 3) / 4;
+  hipLaunchKernelGGL(device_rng_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, mvk_stream(stream), out,
+                     (long long)n, reinterpret_cast<unsigned long long*>(state), uniform, lo, hi);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
 int mvk_axpby(const float* x, float a, const float* y, float b, int64_t n, int act, float* out, void* stream) {
   if (!out || n < 0 || (!x && !y)) return MVK_EINVAL;
   if (n == 0) return MVK_OK;

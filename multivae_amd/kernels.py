@@ -509,6 +509,41 @@ def upsample2_bwd(dy, n, H, W, C):
     return dx
 
 
+# ---- noise with the generator state in device memory (mvk_device_rng) -------------------------------------------------
+# MVK_DEVICE_RNG=0: draw from torch's generator instead (two extra host-issued fill launches per hipGraph replay).
+DEVICE_RNG = os.environ.get("MVK_DEVICE_RNG", "1") != "0"
+_RNG = {}  # device -> [state tensor (3 x int64: seed, offset, ticket), torch seed it was built from, breadcrumb offset]
+
+
+def _rng_state(device):
+    """The device-resident generator state, tied to torch's CUDA generator of that device: (re)built from its seed whenever
+    torch was re-seeded since the last draw.  A re-seed is seen as a changed seed or an offset that went backwards — every
+    draw leaves a breadcrumb by advancing torch's (host-side) offset, so `torch.manual_seed(s)` twice with the same s and
+    nothing drawn from torch in between is still noticed.  Not consulted while a stream is capturing (a captured step
+    keeps the state it was captured with; the launches inside the graph advance it)."""
+    ent = _RNG.get(device)
+    if ent is not None and torch.cuda.is_current_stream_capturing():
+        return ent[0]
+    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+    seed, off = gen.initial_seed(), gen.get_offset()
+    if ent is None or ent[1] != seed or off < ent[2]:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.MvkError("the device generator state must exist before a graph capture starts (run one eager step)")
+        st = torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, off // 4, 0], dtype=torch.int64, device=device)
+        ent = [st, seed, off]
+        _RNG[device] = ent
+    ent[2] = off + 4
+    gen.set_offset(ent[2])
+    return ent[0]
+
+
+def device_randn(shape, device, uniform=False, lo=0.0, hi=1.0):
+    """N(0, 1) (or U[lo, hi)) noise of `shape` from the device-resident generator."""
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    call("mvk_device_rng", ptr(out), out.numel(), ptr(_rng_state(device)), 1 if uniform else 0, float(lo), float(hi), stream_ptr())
+    return out
+
+
 def axpby(x, a, y, b, act=NONE, out=None):
     ref = x if x is not None else y
     out = torch.empty_like(ref) if out is None else out

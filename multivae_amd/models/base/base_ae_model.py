@@ -295,8 +295,11 @@ class BaseMultiVAE(BaseModel):
             if tuple(noise.shape) != tuple(shape):
                 raise ValueError(f"noise has shape {tuple(noise.shape)}, expected {tuple(shape)}")
             return noise.to(device=device, dtype=torch.float32).contiguous()
+        device = torch.device(device)
+        lo = torch.finfo(torch.float32).eps - 1.0
+        if device.type == "cuda" and kernels.DEVICE_RNG:  # generator state in device memory: graph replays need no host launch
+            return kernels.device_randn(tuple(shape), device, uniform=uniform, lo=lo, hi=1.0)
         if uniform:
-            lo = torch.finfo(torch.float32).eps - 1.0
             return torch.empty(shape, device=device, dtype=torch.float32).uniform_(lo, 1.0)
         return torch.randn(shape, device=device, dtype=torch.float32)
 

@@ -766,6 +766,44 @@ def test_conv3x3_residual_epilogue(K, n, H, W, Cin, Cout):
         K.conv3x3(nhwc(x), wf, None, n, H, W, Cin, Cout, res=nhwc(res), out_bias=torch.zeros(Cout, device=d))
 
 
+def test_device_rng(K):
+    """mvk_device_rng: N(0, 1) / U[lo, hi) noise whose generator state lives in device memory.  Moments and tails, the tie to
+    torch's seed (re-seeding restarts the sequence, also with the same seed), and a captured launch that draws fresh noise at
+    every replay and continues the eager sequence."""
+    d = dev()
+    torch.manual_seed(1234)
+    x = K.device_randn((1 << 20,), d)
+    assert abs(float(x.mean())) < 5e-3 and abs(float(x.var()) - 1.0) < 1e-2
+    assert abs(float((x ** 3).mean())) < 2e-2 and abs(float((x ** 4).mean()) - 3.0) < 5e-2
+    assert 0.002 < float((x.abs() > 3).float().mean()) < 0.0034 and float(x.abs().max()) < 6.5
+    y = K.device_randn((1 << 20,), d)
+    assert abs(float((x * y).mean())) < 5e-3 and not torch.equal(x, y)  # the next draw is a new, uncorrelated block
+    u = K.device_randn((3, 1001), d, uniform=True, lo=-1.0 + 1.2e-7, hi=1.0)  # ragged size: scalar tail stores
+    assert float(u.min()) >= -1.0 + 1.2e-7 and float(u.max()) < 1.0 and abs(float(u.mean())) < 0.05
+    torch.manual_seed(1234)
+    x2, y2 = K.device_randn((1 << 20,), d), K.device_randn((1 << 20,), d)
+    assert torch.equal(x, x2) and torch.equal(y, y2)
+    torch.manual_seed(99)
+    assert not torch.equal(K.device_randn((1 << 20,), d), x)
+    # a captured draw: every replay continues the sequence an eager run would produce
+    torch.manual_seed(7)
+    ref = [K.device_randn((5, 512, 20), d) for _ in range(4)]
+    torch.manual_seed(7)
+    first = K.device_randn((5, 512, 20), d)  # the state exists before the capture starts
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        g_ = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_, stream=st):
+            z = K.device_randn((5, 512, 20), d)
+    torch.cuda.current_stream().wait_stream(st)
+    assert torch.equal(first, ref[0])
+    for i in (1, 2, 3):
+        g_.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(z, ref[i]), f"replay {i}"
+
+
 @pytest.mark.parametrize("n,H,W,C", [(3, 28, 28, 64), (2, 7, 7, 20), (4, 14, 14, 128), (2, 5, 9, 3)])
 def test_avgpool_upsample_axpby(K, n, H, W, C):
     """nn.AvgPool2d(3, 2, 1), nn.Upsample(scale_factor=2) forward / backward and the residual combination on NHWC."""
