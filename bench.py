@@ -331,7 +331,8 @@ def main():
     flat = FlatParams(model)
     if use_dist:
         flat.broadcast(0)  # C1: one parameter broadcast
-    opt = FusedAdam(flat, **w["adam"])
+    # the update clears the gradients it consumes (MVK_ADAM_ZERO=0: a separate zero_grad pass per step, for A/B)
+    opt = FusedAdam(flat, zero_grad_in_step=os.environ.get("MVK_ADAM_ZERO", "1") != "0", **w["adam"])
     inputs = DatasetOutput(data=w["data"])
     gen = torch.Generator(device=device).manual_seed(1000 + rank)
     grad_scale = 1.0 / world
@@ -351,7 +352,7 @@ def main():
         opt.step(grad_scale=grad_scale)
         return out
 
-    # zero_grad + forward + backward replayed as ONE hipGraph launch (the host needs about as long to enqueue the
+    # forward + backward replayed as ONE hipGraph launch (the host needs about as long to enqueue the
     # launches of a step as the GPU needs to run them); all-reduce and the fused Adam launch stay outside.
     graphed = None
     if not args.no_graph:

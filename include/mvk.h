@@ -484,6 +484,11 @@ int mvk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, doubl
  * mvk_adam_step.  lr is a host scalar per call, so learning-rate schedulers (base_trainer_config.py:60) cost nothing. */
 int mvk_adam_step_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1,
                           double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream);
+/* The same update (vmax = NULL: plain Adam) that also CLEARS the gradient buffer as it consumes it when zero_grad != 0: the next
+ * step's `optimizer.zero_grad()` (base_trainer.py:350) needs no pass over the buffer and no launch. */
+int mvk_adam_step_fused(float* p, float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1,
+                        double beta2, double eps, double weight_decay, int step, double grad_scale, int zero_grad,
+                        void* stream);
 
 /* The encoder heads in ONE launch: Y_h[m][n] = sum_k X[m][k] W_h(k, n) + b_h[n] for h = 0 (and 1 when W1 != NULL),
  * n < N <= 32, W_h(k, n) = W_h[k * w_sk + n * w_sn] (a torch Linear weight [N][K]: w_sk = 1, w_sn = K; the packed

@@ -97,6 +97,7 @@ PROTOTYPES = {
     "mvk_defer_flush": [_p],
     "mvk_defer_end": [_p],
     "mvk_adam_step_amsgrad": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _d, _p],
+    "mvk_adam_step_fused": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _d, _i, _p],
     "mvk_mmvae_std_fwd": [_p, _i, _i, _i, _p, _p],
     "mvk_mmvae_std_bwd": [_p, _p, _p, _i, _i, _i, _p, _p],
     "mvk_mmvae_latent_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p],

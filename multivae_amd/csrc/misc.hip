@@ -218,27 +218,57 @@ __global__ __launch_bounds__(256) void up_nchw_small_kernel(const float* __restr
 }
 
 // ---- Adam on flat buffers (torch.optim.Adam single-tensor rule, amsgrad=False) -----------------------------
+struct AdamScalars {
+  float step_size, omb1, b2, omb2, eps, wd, bc2_sqrt, gscale;
+};
+// one element of the update; vmx = the amsgrad running maximum (read and updated only when AMSGRAD)
 template <bool AMSGRAD>
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, float* __restrict__ vmax, long long n, float step_size, float omb1,
-                            float b2, float omb2, float eps, float wd, float bc2_sqrt, float gscale) {
+__device__ __forceinline__ void adam_one(float& pi, float gi, float& mi, float& vi, float& vmx, const AdamScalars& a) {
+  gi *= a.gscale;
+  if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
+  mi = mi + (gi - mi) * a.omb1;            // exp_avg.lerp_(grad, 1 - beta1), weight < 0.5 branch
+  vi = fmaf(a.omb2, gi * gi, vi * a.b2);   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+  float vd = vi;
+  if (AMSGRAD) {  // max_exp_avg_sq = max(max_exp_avg_sq, exp_avg_sq); the denominator uses the running maximum
+    vd = fmaxf(vmx, vi);
+    vmx = vd;
+  }
+  const float denom = sqrtf(vd) / a.bc2_sqrt + a.eps;
+  pi = pi - a.step_size * (mi / denom);
+}
+
+// ZERO: the gradient is cleared as it is consumed (the next step's zero_grad pass and its launch disappear)
+template <bool AMSGRAD, bool ZERO>
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            float* __restrict__ vmax, long long n, const AdamScalars a) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
-    float gi = g[i] * gscale;
-    float pi = p[i];
-    if (wd != 0.f) gi = fmaf(wd, pi, gi);
-    float mi = m[i] + (gi - m[i]) * omb1;  // exp_avg.lerp_(grad, 1 - beta1), weight < 0.5 branch
-    float vi = fmaf(omb2, gi * gi, v[i] * b2);  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
-    m[i] = mi;
-    v[i] = vi;
-    if (AMSGRAD) {  // max_exp_avg_sq = max(max_exp_avg_sq, exp_avg_sq); the denominator uses the running maximum
-      vi = fmaxf(vmax[i], vi);
-      vmax[i] = vi;
-    }
-    float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = pi - step_size * (mi / denom);
+    float pi = p[i], mi = m[i], vi = v[i], vmx = AMSGRAD ? vmax[i] : 0.f;
+    adam_one<AMSGRAD>(pi, g[i], mi, vi, vmx, a);
+    p[i] = pi, m[i] = mi, v[i] = vi;
+    if (AMSGRAD) vmax[i] = vmx;
+    if (ZERO) g[i] = 0.f;
   }
+}
+
+// 16 bytes per lane and tensor (n4 = n / 4; all buffers 16-byte aligned)
+template <bool AMSGRAD, bool ZERO>
+__global__ __launch_bounds__(256) void adam4_kernel(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
+                                                    float4* __restrict__ v, float4* __restrict__ vmax, long long n4,
+                                                    const AdamScalars a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 pi = p[i], mi = m[i], vi = v[i];
+  const float4 gi = g[i];
+  float4 vx = AMSGRAD ? vmax[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  adam_one<AMSGRAD>(pi.x, gi.x, mi.x, vi.x, vx.x, a);
+  adam_one<AMSGRAD>(pi.y, gi.y, mi.y, vi.y, vx.y, a);
+  adam_one<AMSGRAD>(pi.z, gi.z, mi.z, vi.z, vx.z, a);
+  adam_one<AMSGRAD>(pi.w, gi.w, mi.w, vi.w, vx.w, a);
+  p[i] = pi, m[i] = mi, v[i] = vi;
+  if (AMSGRAD) vmax[i] = vx;
+  if (ZERO) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // ---- scalar assembly ----------------------------------------------------------------------------------------
@@ -484,23 +514,40 @@ int mvk_conv4s2_up_nchw_small(const float* V, const float* Wref, const float* bi
   return MVK_OK;
 }
 
-int mvk_adam_step_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1,
-                          double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream) {
+int mvk_adam_step_fused(float* p, float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1, double beta2,
+                        double eps, double weight_decay, int step, double grad_scale, int zero_grad, void* stream) {
   if (!p || !g || !m || !v || step < 1) return MVK_EINVAL;
   if (n == 0) return MVK_OK;
   // scalar arithmetic in double like the Python side of torch.optim.Adam, cast once
-  double bc1 = 1.0 - pow(beta1, (double)step);
-  double bc2 = 1.0 - pow(beta2, (double)step);
-  if (vmax)
-    hipLaunchKernelGGL(adam_kernel<true>, dim3(grid_for(n, 256)), dim3(256), 0, mvk_stream(stream), p, g, m, v, vmax,
-                       (long long)n, (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
-                       (float)eps, (float)weight_decay, (float)sqrt(bc2), (float)grad_scale);
-  else
-    hipLaunchKernelGGL(adam_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, mvk_stream(stream), p, g, m, v, vmax,
-                       (long long)n, (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
-                       (float)eps, (float)weight_decay, (float)sqrt(bc2), (float)grad_scale);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const AdamScalars a{(float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                      (float)eps,        (float)weight_decay,  (float)sqrt(bc2), (float)grad_scale};
+  hipStream_t s = mvk_stream(stream);
+  const bool v4 = n % 4 == 0 && mvk_aligned16(p) && mvk_aligned16(g) && mvk_aligned16(m) && mvk_aligned16(v) &&
+                  (!vmax || mvk_aligned16(vmax));
+#define MVK_ADAM_LAUNCH(AMS_, Z_)                                                                                              \
+  do {                                                                                                                         \
+    if (v4)                                                                                                                    \
+      hipLaunchKernelGGL((adam4_kernel<AMS_, Z_>), dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s,                     \
+                         reinterpret_cast<float4*>(p), reinterpret_cast<float4*>(g), reinterpret_cast<float4*>(m),             \
+                         reinterpret_cast<float4*>(v), reinterpret_cast<float4*>(vmax), (long long)(n / 4), a);                \
+    else                                                                                                                       \
+      hipLaunchKernelGGL((adam_kernel<AMS_, Z_>), dim3(grid_for(n, 256)), dim3(256), 0, s, p, g, m, v, vmax, (long long)n, a); \
+  } while (0)
+  if (vmax && zero_grad) MVK_ADAM_LAUNCH(true, true);
+  else if (vmax) MVK_ADAM_LAUNCH(true, false);
+  else if (zero_grad) MVK_ADAM_LAUNCH(false, true);
+  else MVK_ADAM_LAUNCH(false, false);
+#undef MVK_ADAM_LAUNCH
   MVK_CHECK_LAUNCH();
   return MVK_OK;
+}
+
+int mvk_adam_step_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1,
+                          double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream) {
+  return mvk_adam_step_fused(p, const_cast<float*>(g), m, v, vmax, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, 0,
+                             stream);
 }
 
 int mvk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,

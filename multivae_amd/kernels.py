@@ -1364,10 +1364,12 @@ class MVAEPosteriorFn(Function):
         return (None, None, None, None, *dmu, *dlv)
 
 
-def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0, vmax=None):
-    """torch.optim.Adam on flat buffers, one launch; vmax = the amsgrad running maximum of exp_avg_sq (or None)."""
-    call("mvk_adam_step_amsgrad", ptr(p), ptr(g), ptr(m), ptr(v), ptr(vmax), p.numel(), lr, beta1, beta2, eps,
-         weight_decay, step, grad_scale, stream_ptr())
+def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0, vmax=None,
+              zero_grad=False):
+    """torch.optim.Adam on flat buffers, one launch; vmax = the amsgrad running maximum of exp_avg_sq (or None);
+    zero_grad: g is cleared as it is consumed."""
+    call("mvk_adam_step_fused", ptr(p), ptr(g), ptr(m), ptr(v), ptr(vmax), p.numel(), lr, beta1, beta2, eps,
+         weight_decay, step, grad_scale, 1 if zero_grad else 0, stream_ptr())
 
 
 # =====================================================================================================

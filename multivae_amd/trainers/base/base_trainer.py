@@ -245,7 +245,8 @@ class BaseTrainer:
         if fused_ok:  # amsgrad and every torch lr scheduler stay on the one-launch path
             self.optimizer = FusedAdam(self.flat, lr=cfg.learning_rate, betas=tuple(params.get("betas", (0.9, 0.999))),
                                        eps=params.get("eps", 1e-8), weight_decay=params.get("weight_decay", 0.0),
-                                       amsgrad=params.get("amsgrad", False))
+                                       amsgrad=params.get("amsgrad", False),
+                                       zero_grad_in_step=True)  # every step here is zero_grad -> backward -> step
         else:
             import torch.optim as optim
 

@@ -37,9 +37,16 @@ class FlatParams:
             p.data = self.flat[off : off + k].view(p.shape)
             p.grad = self.grad[off : off + k].view(p.shape)
         self.numel = n
+        # set by FusedAdam(zero_grad_in_step=True) after a step that cleared the buffer while consuming it; the next
+        # zero_grad() then costs nothing.  Whoever writes gradients in between WITHOUT calling zero_grad() first
+        # (nobody in BaseTrainer / bench.py) must reset it.
+        self.grads_zero = False
 
     def zero_grad(self):
-        self.grad.zero_()
+        if self.grads_zero:
+            self.grads_zero = False  # a backward pass follows
+        else:
+            self.grad.zero_()
         for p in self.params:  # re-attach views if something replaced .grad
             if p.grad is None or p.grad.data_ptr() < self.grad.data_ptr() or \
                     p.grad.data_ptr() >= self.grad.data_ptr() + 4 * self.numel:
@@ -86,8 +93,13 @@ class FusedAdam(torch.optim.Optimizer):
     learning rate is a host scalar handed to the kernel at every step) and `state_dict()` / `load_state_dict()` speak
     the layout of `torch.optim.Adam(model.parameters())` — what the reference writes to / reads from `optimizer.pt`."""
 
-    def __init__(self, flat: FlatParams, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False):
+    def __init__(self, flat: FlatParams, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False,
+                 zero_grad_in_step=False):
+        """zero_grad_in_step: the update clears the gradient buffer as it reads it, and the `zero_grad()` of the next step
+        becomes free (one launch and one pass over the buffer less per step).  For loops of the form zero_grad -> backward
+        -> step (BaseTrainer, bench.py): a gradient written after `step()` and before the next `zero_grad()` would survive."""
         self.flat = flat
+        self.zero_grad_in_step = bool(zero_grad_in_step)
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=bool(amsgrad))
         super().__init__(flat.all_params, defaults)
         self.m = torch.zeros_like(flat.flat)
@@ -115,7 +127,8 @@ class FusedAdam(torch.optim.Optimizer):
         g = self._g()
         kernels.adam_step(self.flat.flat, self.flat.grad, self.m, self.v, self.step_count, float(g["lr"]),
                           float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
-                          grad_scale, vmax=self.vmax)
+                          grad_scale, vmax=self.vmax, zero_grad=self.zero_grad_in_step)
+        self.flat.grads_zero = self.zero_grad_in_step
         return loss
 
     def state_dict(self):

@@ -1,9 +1,10 @@
 """hipGraph replay of the fixed-shape part of a training step.
 
 One step of the models here is ~100 short kernel launches driven from Python (ctypes + autograd): the host needs
-about as long to enqueue them as the GPU needs to run them.  `GraphedStep` captures zero_grad + forward + backward
+about as long to enqueue them as the GPU needs to run them.  `GraphedStep` captures forward + backward
 once (torch.cuda.CUDAGraph == hipGraph on ROCm, including the fork/join of the modality-branch streams) and
-replays it with one launch per step.  The gradient all-reduce and the fused Adam kernel stay outside the graph, so
+replays it with one launch per step; `zero_grad` runs in front of the replay and costs nothing when the optimizer cleared
+the gradients while consuming them (`FusedAdam(zero_grad_in_step=True)`).  The gradient all-reduce and the fused Adam kernel stay outside the graph, so
 the distributed step is: copy batch -> replay -> all_reduce(flat.grad) -> adam.
 
 Capture needs static shapes and addresses: the batch and the noise are copied into buffers owned by this object;
@@ -40,6 +41,7 @@ class GraphedStep:
             side.wait_stream(cur)
             with torch.cuda.stream(side):  # eager warm-up: fills every cache (scratch, packed masks, autotuned paths)
                 for _ in range(max(int(warmup), 1)):
+                    self.flat.zero_grad()
                     self._body()
             cur.wait_stream(side)
             torch.cuda.synchronize(dev)
@@ -61,7 +63,6 @@ class GraphedStep:
         return noise.detach().clone()
 
     def _body(self):
-        self.flat.zero_grad()
         kw = dict(self.fwd_kwargs)
         if self.noise is not None:
             kw["noise"] = self.noise
@@ -92,5 +93,6 @@ class GraphedStep:
                     self.noise[k].copy_(v, non_blocking=True)
             elif noise is not self.noise:
                 self.noise.copy_(noise, non_blocking=True)
+        self.flat.zero_grad()  # free after FusedAdam(zero_grad_in_step=True).step()
         self.graph.replay()
         return self.out

@@ -577,6 +577,30 @@ def test_adam_matches_oracle(K):
     close(vd, v, rtol=1e-6, what="adam v")
 
 
+@pytest.mark.parametrize("amsgrad", [False, True])
+def test_adam_vector_path_and_fused_zero_grad(K, amsgrad):
+    """mvk_adam_step_fused: the 16-byte path (n % 4 == 0, aligned buffers) against the scalar path (an unaligned view of the
+    same data), and zero_grad clears the gradient as it is consumed."""
+    gen = g(12)
+    n = 4 * 25001
+    d = dev()
+    base = [torch.randn(n + 1, generator=gen).to(d) for _ in range(2)] + [torch.rand(n + 1, generator=gen).to(d) for _ in range(2)]
+    gr = torch.randn(n + 1, generator=gen).to(d)
+    vec = [t[:n].clone() for t in base]         # aligned, n % 4 == 0: float4 kernel
+    sca = [t.clone()[1:] for t in base]         # 4 bytes off a 16-byte boundary: scalar kernel
+    for t, s_ in zip(vec, sca):
+        s_.copy_(t)
+    gv, gs_ = gr[:n].clone(), gr.clone()[1:]
+    gs_.copy_(gv)
+    K.adam_step(vec[0], gv, vec[1], vec[2], 3, 1e-3, 0.9, 0.99, 1e-8, 0.01, grad_scale=0.5, vmax=vec[3] if amsgrad else None,
+                zero_grad=True)
+    K.adam_step(sca[0], gs_, sca[1], sca[2], 3, 1e-3, 0.9, 0.99, 1e-8, 0.01, grad_scale=0.5, vmax=sca[3] if amsgrad else None,
+                zero_grad=False)
+    for a_, b_, nm in zip(vec, sca, ("p", "m", "v", "vmax")):
+        close(a_, b_, rtol=1e-6, what=nm)  # (not bit-equal: the two kernels contract / divide in a different order)
+    assert float(gv.abs().max()) == 0.0 and torch.equal(gs_, gr[:n])
+
+
 def test_adam_amsgrad_matches_torch(K):
     """mvk_adam_step_amsgrad against torch.optim.Adam(amsgrad=True) on the CPU (the reference's MMVAE+ setting,
     examples/mmvae_plus/mmnist.py:61-62) over 4 steps with weight decay and a changing learning rate."""
