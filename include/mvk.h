@@ -354,7 +354,7 @@ int mvk_pack_conv4s2_weight(const float* Wref, int Cv, int Cu, float* Wdown, int
  * <= 0 means Cv); kind 1: as mvk_pack_unflatten_weight with Cv = Cin, Cu = Cout, destination in Wup; kind 2: 3x3
  * convolution weight Wref[Cv = Cout][Cu = Cin][3][3] -> Wdown[(tap*Cu + cu)][cv] (forward operand of mvk_conv3x3) and/or
  * Wup[((8-tap)*Cv + cv)][cu] (its backward-data operand: flipped window, channels swapped). */
-#define MVK_PACK_MAX 8
+#define MVK_PACK_MAX 16
 typedef struct mvk_pack_desc {
   const float* Wref;
   float* Wdown;

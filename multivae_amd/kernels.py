@@ -392,7 +392,69 @@ def wfrag(w):
     return getattr(w, "mvk_frag", None)
 
 
+PACK_MAX = 16  # MVK_PACK_MAX descriptors per launch
+# MVK_PREPACK=0: every network packs its own weights when it runs (one launch per network and forward pass)
+PREPACK = os.environ.get("MVK_PREPACK", "1") != "0"
+_PACK_SCOPE = None
+
+
+class pack_scope:
+    """with pack_scope(model): ONE weight-pack launch for the whole forward pass.  The first `pack_weights` call inside the
+    scope also packs what every other sub-module of `model` announces through `pack_jobs()` (the decoder's pack used to sit on
+    the critical chain between the posterior and the first decoder layer); later calls find their packs in the scope's cache.
+    The cache dies with the scope: nothing packed here outlives the forward pass (the weights change at the next optimizer step)."""
+
+    def __init__(self, model):
+        self.model, self.own = model, False
+
+    def __enter__(self):
+        global _PACK_SCOPE
+        if PREPACK and _PACK_SCOPE is None:
+            _PACK_SCOPE = {"model": self.model, "cache": {}, "done": False}
+            self.own = True
+        return self
+
+    def __exit__(self, *exc):
+        global _PACK_SCOPE
+        if self.own:
+            _PACK_SCOPE = None
+        return False
+
+
+def _job_key(job):
+    return (job[0].data_ptr(), tuple(job[0].shape)) + tuple(job[1:])
+
+
 def pack_weights(jobs):
+    """`_pack_launch(jobs)`, or inside a pack_scope: from the scope's cache / together with every announced job of the model."""
+    sc = _PACK_SCOPE
+    if sc is None:
+        return _pack_launch(jobs)
+    keys = [_job_key(j) for j in jobs]
+    cache = sc["cache"]
+    if all(k in cache for k in keys):
+        return [cache[k] for k in keys]
+    todo, tkeys = list(jobs), list(keys)
+    if not sc["done"]:
+        sc["done"] = True
+        for mod in sc["model"].modules():
+            announce = getattr(mod, "pack_jobs", None)
+            if announce is None:
+                continue
+            for j in announce():
+                k = _job_key(j)
+                if k not in tkeys and k not in cache and j[0].device == jobs[0][0].device and len(todo) < PACK_MAX:
+                    todo.append(j)
+                    tkeys.append(k)
+    outs = []
+    for i0 in range(0, len(todo), PACK_MAX):
+        outs += _pack_launch(todo[i0:i0 + PACK_MAX])
+    for k, o in zip(tkeys, outs):
+        cache[k] = o
+    return outs[:len(jobs)]
+
+
+def _pack_launch(jobs):
     """All weight packs of a network in ONE launch.  jobs: list of (wref, want_down, want_up) for 4x4/stride-2
     layers ([Cv][Cu][4][4] -> (Wdown [16*Cu, Cv], Wup [4, 4*Cv, Cu])) or (wref, "unflatten") for the 1x1-spatial
     transposed convolution ([Cin][Cout][4][4] -> [Cin, 16*Cout]).  Returns the packed tensors in job order."""
@@ -925,8 +987,8 @@ class ResnetStackFn(Function):
                     packs[i] = None
                     jobs.append((params[i], "c3", True, True))
                     order.append(i)
-        for i0 in range(0, len(jobs), 8):  # MVK_PACK_MAX descriptors per launch
-            for i, pk in zip(order[i0:i0 + 8], pack_weights(jobs[i0:i0 + 8])):
+        for i0 in range(0, len(jobs), PACK_MAX):
+            for i, pk in zip(order[i0:i0 + PACK_MAX], pack_weights(jobs[i0:i0 + PACK_MAX])):
                 packs[i] = pk
         h = x
         for op in program:

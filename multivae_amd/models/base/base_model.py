@@ -21,6 +21,13 @@ class BaseModel(nn.Module):
     def forward(self, inputs, **kwargs):
         raise NotImplementedError()
 
+    def __call__(self, *args, **kwargs):
+        # one weight-pack launch for the whole forward pass (kernels.pack_scope; a no-op on the CPU oracle-less paths)
+        from ... import kernels
+
+        with kernels.pack_scope(self):
+            return super().__call__(*args, **kwargs)
+
     def update(self):
         pass
 

@@ -25,6 +25,12 @@ class Encoder_VAE_SVHN(BaseEncoder):
         self.c1 = nn.Conv2d(self.fBase * 4, self.latent_dim, 4, 2, 0)
         self.c2 = nn.Conv2d(self.fBase * 4, self.latent_dim, 4, 2, 0)
 
+    def pack_jobs(self):
+        """The weight packs SVHNEncoderFn asks for (kernels.pack_scope: one pack launch per forward pass of the model)."""
+        e = self.enc
+        return [(e[0].weight, True, False), (e[2].weight, True, True), (e[4].weight, True, True),
+                (self.c1.weight, True, False), (self.c2.weight, True, False)]
+
     def forward(self, x: torch.Tensor):
         e = self.enc
         mu, lv = kernels.SVHNEncoderFn.apply(x, e[0].weight, e[0].bias, e[2].weight, e[2].bias, e[4].weight,
@@ -45,6 +51,11 @@ class Decoder_VAE_SVHN(BaseDecoder):
             nn.ConvTranspose2d(self.fBase * 2, self.fBase, 4, 2, 1, bias=True), nn.ReLU(True),
             nn.ConvTranspose2d(self.fBase, self.nb_channels, 4, 2, 1, bias=True), nn.Sigmoid(),
         )
+
+    def pack_jobs(self):
+        """The weight packs SVHNDecoderFn asks for (kernels.pack_scope)."""
+        d = self.dec
+        return [(d[0].weight, "unflatten"), (d[2].weight, True, True), (d[4].weight, True, True), (d[6].weight, True, False)]
 
     def forward(self, z: torch.Tensor):
         d = self.dec
