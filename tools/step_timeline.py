@@ -17,7 +17,7 @@ qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols
 sel = f", d.{qcol}" if qcol else ", 0"
 rows = c.execute(f"select s.display_name, d.start, d.end, d.grid_size_x, d.grid_size_y, d.grid_size_z, "
                  f"d.workgroup_size_x{sel} from {kd} d join {ks} s on d.kernel_id=s.id order by d.start").fetchall()
-ends = [i for i, r in enumerate(rows) if "adam_kernel" in r[0]]
+ends = [i for i, r in enumerate(rows) if ("adam_kernel" in r[0] or "adam4_kernel" in r[0])]
 if which < 0:
     which += len(ends)
 lo, hi = ends[which - 1] + 1, ends[which] + 1
