@@ -335,6 +335,7 @@ def main():
     opt = FusedAdam(flat, zero_grad_in_step=os.environ.get("MVK_ADAM_ZERO", "1") != "0", **w["adam"])
     inputs = DatasetOutput(data=w["data"])
     gen = torch.Generator(device=device).manual_seed(1000 + rank)
+    torch.cuda.manual_seed(1000 + rank)  # the model draws its noise from the device generator: another stream per rank
     grad_scale = 1.0 / world
     draw = w["noise"]
     fkw = w["fwd_kwargs"]
