@@ -347,7 +347,7 @@ def main():
         opt.zero_grad()
         with kernels.deferred_reductions(flat):
             out = model(inputs, **kw)
-            out.loss.backward()
+            out.loss.backward(gradient=kernels.unit_seed(out.loss))
         if use_dist:
             flat.all_reduce()  # C2: ONE all-reduce of the flat gradient buffer
         opt.step(grad_scale=grad_scale)

@@ -173,6 +173,8 @@ typedef struct mvk_term_desc {
   int64_t period;
   float coef;
   float lossw;
+  float* gfill; /* optional: gfill[0..n) = coef * lossw, the gradient of the loss w.r.t. this term's rows for an upstream
+                 * gradient of 1 (terms that enter the loss as a plain weighted row sum: the KL rows) */
 } mvk_term_desc;
 int mvk_reduce_terms(const mvk_term_desc* terms, int n_terms, float loss_sum_scale, float* out, float* loss_out,
                      void* stream);

@@ -40,7 +40,7 @@ class SeedDesc(C.Structure):  # mvk_seed_desc
 
 
 class TermDesc(C.Structure):
-    _fields_ = [("v", _p), ("mask", _p), ("n", _i64), ("period", _i64), ("coef", _f), ("lossw", _f)]
+    _fields_ = [("v", _p), ("mask", _p), ("n", _i64), ("period", _i64), ("coef", _f), ("lossw", _f), ("gfill", _p)]
 
 
 # name -> argtypes (restype is always int); mirrors include/mvk.h one for one

@@ -1233,6 +1233,32 @@ class JMVAEPosteriorFn(Function):
 # =====================================================================================================
 # Fused reconstruction NLL + scalar assembly (single autograd node producing the loss)
 # =====================================================================================================
+_UNIT_SEEDS = {}  # data_ptr -> tensor (kept alive): backward seeds known to hold exactly 1
+
+
+def unit_seed(like):
+    """A ones tensor shaped like the loss `like`, registered as THE unit backward seed of its device: pass it as
+    `loss.backward(gradient=...)` and ReconLossFn.backward needs no launch (autograd's own default seed is a fresh tensor
+    whose value the host cannot know without a synchronisation)."""
+    key = (like.device, tuple(like.shape))
+    t = _UNIT_SEEDS.get(key)
+    if t is None:
+        t = torch.ones_like(like)
+        _UNIT_SEEDS[key] = t
+        _UNIT_SEEDS[t.data_ptr()] = t
+    return t
+
+
+UNIT_SEED = os.environ.get("MVK_UNIT_SEED", "1") != "0"  # 0: always launch the seed kernel (A/B)
+
+
+def is_unit_seed(g):
+    if not UNIT_SEED:
+        return False
+    t = _UNIT_SEEDS.get(g.data_ptr())
+    return t is not None and t.shape == g.shape and t.device == g.device
+
+
 class ReconLossFn(Function):
     """loss = sum_i lossw_i * coef_i * sum_{k,b} mask_i[b] rows_i[k,b] + sum_j lossw_j * coef_j * sum(extra_j).
 
@@ -1310,6 +1336,9 @@ class ReconLossFn(Function):
             t.period, t.coef, t.lossw = B, spec["coef"][i], spec["lossw"][i]
         ti = n_rec
         extra_grad = []  # (byte offset, numel, coefficient) per chunk of every extra tensor
+        # the gradients of the extra tensors for an upstream gradient of 1 are constants: mvk_reduce_terms writes them
+        # (backward then launches nothing when its upstream gradient is the unit seed)
+        dextras = [torch.empty_like(e) if ctx.needs_input_grad[2 + n_mod + j] else None for j, e in enumerate(extras)]
         for j, e in enumerate(extras):
             ns = splits[j]
             chunk = e.numel() // ns
@@ -1319,12 +1348,14 @@ class ReconLossFn(Function):
                 cc = cj[c] if isinstance(cj, (list, tuple)) else cj
                 t.v, t.n, t.mask, t.period = e.data_ptr() + 4 * c * chunk, chunk, None, 1
                 t.coef, t.lossw = cc, spec["extra_lossw"][j]
+                t.gfill = dextras[j].data_ptr() + 4 * c * chunk if dextras[j] is not None else None
                 extra_grad.append((j, 4 * c * chunk, chunk, cc * spec["extra_lossw"][j]))
                 ti += 1
         out = _new((n_terms + 2,), ref)
         loss = _new((), ref)
         call("mvk_reduce_terms", terms, n_terms, spec["loss_sum_scale"], ptr(out), ptr(loss), stream_ptr())
         ctx.drecons = drecons
+        ctx.dextras = dextras
         ctx.extra_shapes = [e.shape for e in extras]
         ctx.extra_grad = extra_grad
         ctx.rows = rows  # keep alive: metrics / debugging
@@ -1337,9 +1368,13 @@ class ReconLossFn(Function):
     def backward(ctx, gloss, gout):
         if gloss is None:  # only the (non-differentiable) terms were used
             return (None, None) + (None,) * (len(ctx.drecons) + len(ctx.extra_shapes))
-        gloss = _c(gloss.reshape(1))
         grads = list(ctx.drecons)
-        extras = [_new(shape, gloss) for shape in ctx.extra_shapes]
+        if is_unit_seed(gloss):  # d loss = 1 exactly: every gradient below was written by the forward launches
+            extras = list(ctx.dextras)
+            ctx.drecons = ctx.dextras = None
+            return (None, None, *grads, *extras)
+        gloss = _c(gloss.reshape(1))
+        extras = [d if d is not None else _new(shape, gloss) for d, shape in zip(ctx.dextras, ctx.extra_shapes)]
         jobs = [(g.data_ptr(), g.numel(), 1.0, 0) for g in ctx.drecons if g is not None]
         jobs += [(extras[j].data_ptr() + off, n, c, 1) for j, off, n, c in ctx.extra_grad]
         for i0 in range(0, len(jobs), 12):  # MVK_SEED_MAX buffers per launch: normally ONE launch
@@ -1348,7 +1383,7 @@ class ReconLossFn(Function):
             for d, (p, n, c, fill) in zip(descs, chunk):
                 d.buf, d.n, d.coef, d.fill = p, n, float(c), fill
             call("mvk_loss_backward_seed", descs, len(chunk), ptr(gloss), stream_ptr())
-        ctx.drecons = None
+        ctx.drecons = ctx.dextras = None
         return (None, None, *grads, *extras)
 
 

@@ -318,7 +318,8 @@ class BaseTrainer:
             # allocate gradients OUTSIDE the buffer the all-reduce below exchanges
             self.flat.zero_grad()
             with kernels.deferred_reductions(self.flat):  # one launch finishes every weight / bias gradient
-                loss.backward()
+                # the registered unit seed (cuda): the loss node's backward then needs no launch (kernels.unit_seed)
+                loss.backward(gradient=kernels.unit_seed(loss) if loss.is_cuda else None)
             if not isinstance(self.optimizer, FusedAdam):
                 self.flat.ensure_attached()
         if isinstance(self.optimizer, FusedAdam):

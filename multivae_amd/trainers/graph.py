@@ -68,9 +68,8 @@ class GraphedStep:
             kw["noise"] = self.noise
         with kernels.deferred_reductions(self.flat):
             out = self.model(self.inputs, **kw)
-            if self._seed is None or self._seed.shape != out.loss.shape:
-                self._seed = torch.ones_like(out.loss)  # the backward seed, filled once (not one launch per replay)
-            out.loss.backward(gradient=self._seed)
+            # the registered unit seed: filled once (not one launch per replay), and ReconLossFn.backward launches nothing
+            out.loss.backward(gradient=kernels.unit_seed(out.loss))
         return out
 
     def matches(self, inputs):

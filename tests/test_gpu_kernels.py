@@ -994,6 +994,14 @@ def test_reduce_terms_handles_more_than_sixteen_terms(K):
     close(out[:n], exp, rtol=1e-6, what="terms")
     close(loss, 2.0 * exp.sum(), rtol=1e-6, what="loss")
     close(out[n + 1], 6.0 * exp.sum(), rtol=1e-6, what="loss_sum")
+    # gfill: the constant row gradients coef * lossw of the terms that ask for them, written by the same launch
+    gbuf = [torch.full((i + 1,), -7.0, device=d) for i in range(n)]
+    for i, t in enumerate(terms):
+        t.gfill = gbuf[i].data_ptr() if i % 3 == 0 else None
+    call("mvk_reduce_terms", terms, n, 3.0, ptr(out), ptr(loss), stream_ptr())
+    close(out[:n], exp, rtol=1e-6, what="terms (second launch)")
+    for i in range(n):
+        assert float(gbuf[i].min()) == float(gbuf[i].max()) == (1.0 if i % 3 == 0 else -7.0), i
 
 
 @pytest.mark.parametrize("Kk,B,L", [(1, 7, 3), (4, 9, 70)])
