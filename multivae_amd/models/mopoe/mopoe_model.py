@@ -6,6 +6,7 @@ subset selection, reparameterisation over K samples, all-subset KL) -> M decoder
 reconstruction-NLL kernel (+ d loss / d recon in the same pass) -> ONE scalar assembly kernel.
 """
 import math
+import os
 from itertools import chain, combinations
 from typing import Union
 
@@ -15,6 +16,9 @@ from ... import kernels
 from ..base import BaseMultiVAE
 from ..base.base_utils import ModelOutput
 from .mopoe_config import MoPoEConfig
+
+
+_EARLY_NOISE = os.environ.get("MVK_EARLY_NOISE", "1") != "0"  # 0: draw the noise behind the encoders (A/B)
 
 
 class MoPoE(BaseMultiVAE):
@@ -95,13 +99,32 @@ class MoPoE(BaseMultiVAE):
         return filt
 
     # -- forward -----------------------------------------------------------------------------------------
-    def modality_encode(self, inputs, **kwargs):
+    def modality_encode(self, inputs, side_work=None, **kwargs):
+        """side_work: a callable run at the head of the LAST branch (a side stream whose encoder is the short one when the
+        branches are ordered longest first): launches that do not depend on the encoders ride there for free."""
         names = self._branch_order(inputs)
-        enc = kernels.run_branches(names, lambda m: self.encoders[m](inputs.data[m]), inputs.data[names[0]].device)
+
+        def run(m):
+            if side_work is not None and len(names) > 1 and m == names[-1]:
+                side_work()
+            return self.encoders[m](inputs.data[m])
+
+        enc = kernels.run_branches(names, run, inputs.data[names[0]].device)
         return {m: enc[m] for m in self.encoders.keys()}
 
     def _posterior(self, inputs, K, noise=None, choice=None, want_stats=False):
-        enc = self.modality_encode(inputs)
+        early = {}
+        x0 = next(iter(inputs.data.values()))
+        if noise is None and x0.is_cuda and kernels.DEVICE_RNG and kernels.BRANCH_STREAMS and len(self.encoders) > 1 \
+                and x0.dim() > 1 and _EARLY_NOISE:
+            # the noise does not depend on the encoders: its launch rides at the head of the short encoder's branch stream
+            # instead of sitting between the encoders and the posterior kernel on the main one
+            shape = (K, x0.shape[0], self.latent_dim)
+            enc = self.modality_encode(inputs, side_work=lambda: early.setdefault("eps", self._noise(shape, x0.device)))
+            if "eps" in early:  # allocated on the side stream, consumed on this one (behind the join of run_branches)
+                early["eps"].record_stream(torch.cuda.current_stream(x0.device))
+        else:
+            enc = self.modality_encode(inputs)
         first = enc[self._poe_order[0]].embedding
         mus = [enc[m].embedding for m in self._poe_order]
         lvs = [enc[m].log_covariance for m in self._poe_order]
@@ -122,7 +145,9 @@ class MoPoE(BaseMultiVAE):
             sel = choice_idx.to(torch.int32).contiguous()
         else:
             sel = self._row_range_selection(B, device)
-        eps = self._noise((K, B, L), device, noise)
+        eps = early.get("eps")
+        if eps is None or tuple(eps.shape) != (K, B, L):
+            eps = self._noise((K, B, L), device, noise)
         outs = kernels.MoPoEPosteriorFn.apply(eps, self._subset_masks(device), sel, weights, want_stats, *mus, *lvs)
         return enc, outs, (B, L, device, weights)
 
