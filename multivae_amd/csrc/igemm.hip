@@ -116,9 +116,10 @@ static int defer_flush_locked(hipStream_t s, bool last) {
     DeferTable T{};
     unsigned blocks = 0;
     for (size_t i = i0; i < g_defer.items.size() && i < i0 + DEFER_BATCH; ++i) {
-      DeferItem& it = T.it[T.n++];
-      it = g_defer.items[i];
+      DeferItem it = g_defer.items[i];
+      if (it.e.res || it.e.colsum_part) return MVK_EINVAL;  // not representable in the packed item (never queued)
       it.blk0 = blocks;
+      T.it[T.n++] = defer_compact(it);
       const int per = (256 >> it.zl_bits) * (it.vec4 ? 4 : 1);
       blocks += (unsigned)(((long long)it.M * it.N + per - 1) / per);
     }

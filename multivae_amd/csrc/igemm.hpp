@@ -924,21 +924,50 @@ struct DeferItem {
   int vec4;     // 16-byte loads, 4 elements per thread
   int zl_bits;  // 3 or 5: 8 or 32 z-lanes
 };
-constexpr int DEFER_BATCH = 24;
+// What the finish needs of an item, packed: 40 of them fit the 4 KB kernel-argument limit (the headline step queues ~35: one
+// launch instead of two back to back at the very end of the step)
+struct DeferItemC {
+  float* out;
+  const float* ws;
+  const float* bias;
+  const float* act_src;
+  long long ld, zstride;
+  int M, N, nz;
+  unsigned blk0;
+  int Cu, bias_mod;
+  short kind, act, src_act, taps;
+  unsigned char atomic, vec4, zl_bits, pad;
+};
+constexpr int DEFER_BATCH = 40;
 struct DeferTable {
   int n;
-  DeferItem it[DEFER_BATCH];
+  DeferItemC it[DEFER_BATCH];
 };
+static_assert(sizeof(DeferTable) <= 4096, "kernel-argument limit");
+inline DeferItemC defer_compact(const DeferItem& d) {
+  DeferItemC c{};
+  c.out = d.e.out, c.ws = d.e.ws, c.bias = d.e.bias, c.act_src = d.e.act_src;
+  c.ld = d.e.ld, c.zstride = d.zstride;
+  c.M = d.M, c.N = d.N, c.nz = d.nz, c.blk0 = d.blk0;
+  c.Cu = d.e.Cu, c.bias_mod = d.e.bias_mod;
+  c.kind = (short)d.e.kind, c.act = (short)d.e.act, c.src_act = (short)d.e.src_act, c.taps = (short)d.e.taps;
+  c.atomic = (unsigned char)d.e.atomic, c.vec4 = (unsigned char)d.vec4, c.zl_bits = (unsigned char)d.zl_bits;
+  return c;
+}
 __global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const DeferTable T) {
   __shared__ float red[32 * 33];  // [ZL][EL * V + 1]: (8, 129) or (32, 33) at most
   int i = 0;
   for (int j = 1; j < T.n; ++j)
     if (blockIdx.x >= T.it[j].blk0) i = j;
-  const DeferItem& it = T.it[i];
+  const DeferItemC& it = T.it[i];
+  Epilogue E{};
+  E.out = it.out, E.ws = const_cast<float*>(it.ws), E.bias = it.bias, E.act_src = it.act_src;
+  E.ld = it.ld, E.Cu = it.Cu, E.bias_mod = it.bias_mod;
+  E.kind = it.kind, E.act = it.act, E.src_act = it.src_act, E.taps = it.taps, E.atomic = it.atomic;
   if (it.vec4)
-    splitk_reduce_bodyv<4>(it.e, it.M, it.N, it.nz, it.zstride, blockIdx.x - it.blk0, it.zl_bits, red);
+    splitk_reduce_bodyv<4>(E, it.M, it.N, it.nz, it.zstride, blockIdx.x - it.blk0, it.zl_bits, red);
   else
-    splitk_reduce_bodyv<1>(it.e, it.M, it.N, it.nz, it.zstride, blockIdx.x - it.blk0, it.zl_bits, red);
+    splitk_reduce_bodyv<1>(E, it.M, it.N, it.nz, it.zstride, blockIdx.x - it.blk0, it.zl_bits, red);
 }
 
 // what the launcher chose (needed to finish fused column sums): rows of one tile; 0 = generic kernel
