@@ -82,7 +82,7 @@ _ARENA = {}
 
 
 _DEFER_ACTIVE = set()  # devices inside deferred_reductions
-_LATE_USED = {}  # device -> the late-leaf stream, if anything was enqueued on it since mvk_defer_begin
+_LATE_USED = {}  # device -> streams that hold late leaves / partial flushes since mvk_defer_begin (joined at its end)
 # MVK_LATE_LEAVES=1: the weight gradients of the large decoder (two ~100 us launches that fill the chip) are enqueued AFTER
 # its backward-data chain, on a stream that is joined only where the deferred finishes run: they execute beside the
 # launch-latency-bound encoder backward (the ~300 us tail of the step in which the chip is mostly idle) instead of in
@@ -108,7 +108,7 @@ class late_leaves:
             st.wait_event(torch.cuda.current_stream(self.device).record_event())
             for t in self.reads:
                 t.record_stream(st)
-            _LATE_USED[self.device] = st
+            _LATE_USED.setdefault(self.device, []).append(st)
             self._ctx = torch.cuda.stream(st)
             self._ctx.__enter__()
         return self
@@ -144,11 +144,31 @@ class deferred_reductions:
         if self.on:
             dev = self.grad.device
             _DEFER_ACTIVE.discard(dev)
-            st = _LATE_USED.pop(dev, None)
-            if st is not None:  # the late leaves (below) end here
-                torch.cuda.current_stream(dev).wait_stream(st)
+            cur = torch.cuda.current_stream(dev)
+            for st in dict.fromkeys(_LATE_USED.pop(dev, ())):  # the late leaves (below) and sibling flushes end here
+                if st != cur:
+                    cur.wait_stream(st)
             call("mvk_defer_end", stream_ptr())
         return False
+
+
+# MVK_FLUSH_SIBLING=1: when the LAST backward node of the step starts (the convolutional encoder: ~140 us of launch-latency-bound
+# chain on its own stream), everything queued so far is finished on the other branch stream, which is idle by then, instead of
+# in one launch behind the chain.
+FLUSH_SIBLING = os.environ.get("MVK_FLUSH_SIBLING", "1") != "0"
+_BRANCH_SET = {}  # device -> the streams of the last run_branches call (main first)
+
+
+def defer_flush_sibling(device):
+    if not (FLUSH_SIBLING and DEFER) or device.type != "cuda" or device not in _DEFER_ACTIVE:
+        return
+    cur = torch.cuda.current_stream(device)
+    sib = next((st for st in _BRANCH_SET.get(device, ()) if st != cur), None)
+    if sib is None or _lib.load().mvk_defer_pending() == 0:
+        return
+    with torch.cuda.stream(sib):
+        call("mvk_defer_flush", stream_ptr())
+    _LATE_USED.setdefault(device, []).append(sib)
 
 
 def defer_flush_side(device):
@@ -239,6 +259,7 @@ def run_branches(names, fn, device):
     if not BRANCH_STREAMS or len(names) < 2 or device.type != "cuda":
         return {m: fn(m) for m in names}
     main = torch.cuda.current_stream(device)
+    _BRANCH_SET[device] = [main] + [_side_stream(device, i) for i in range(1, len(names))]
     fork = main.record_event()
     # The first branch stays on the caller's stream and is enqueued FIRST: autograd runs backward nodes in reverse
     # creation order, so the side branches' backward is enqueued (and, in a captured graph, ordered) before the long
@@ -832,6 +853,7 @@ class SVHNEncoderFn(Function):
         dmu, dlv = _c(dmu).view(B, L), _c(dlv).view(B, L)
         Kf = 16 * ch[3]
         h3f = h3.view(B, Kf)
+        defer_flush_sibling(x.device)
         # heads: both weight gradients (in the Conv2d layout), both bias gradients, d h3 (pre-activation: dmu Wd1^T + dlv Wd2^T
         # with ReLU'(h3)) and its channel sums (the bias gradient of the layer below) in one launch
         lf = LeafStream(x.device)  # the weight / bias gradients run beside the backward-data chain
