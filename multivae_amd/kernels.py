@@ -360,9 +360,10 @@ def heads_fwd(h2, w_mu, b_mu, w_lv, b_lv, N, w_sk, w_sn):
 HEADS_BWD = os.environ.get("MVK_HEADS_BWD", "1") != "0"  # A/B switch: the heads' backward in one launch
 # MEASURED (headline step, one box, 3-4 rounds each): 1.355 ms with the six separate launches, 1.326 ms with the fused launch
 # for the convolutional (SVHN) encoder only, 1.343 ms with the fused launch for the MLP encoder too (its chain is not the
-# critical one and the fused launch delays the other stream's kernels): the MLP encoders keep the separate launches unless
-# MVK_HEADS_BWD_MLP=1.
-HEADS_BWD_MLP = os.environ.get("MVK_HEADS_BWD_MLP", "0") == "1"
+# critical one and the fused launch delays the other stream's kernels).  RE-MEASURED at the end of round 2, with the partial
+# finish on the sibling stream and a replayed graph that now spreads over three hardware queues: 1.2480 ms with the fused launch
+# for the MLP encoder too vs 1.2569 ms without (four same-box pairs) — on by default now, MVK_HEADS_BWD_MLP=0 disables.
+HEADS_BWD_MLP = os.environ.get("MVK_HEADS_BWD_MLP", "1") != "0"
 
 
 def heads_bwd(x, x_act, dys, ws_, bs, w_sk, w_sn, flat_c=0, want_dx=True, prev_bias=None, dw_params=None):

@@ -333,7 +333,7 @@ def test_svhn_encoder_decoder_nodes(B):
 @pytest.mark.parametrize("B,D", [(6, (2,)), (33, (1, 28, 28)), (512, (3, 4))])
 def test_mlp_encoder_decoder_nodes(B, D, fused_heads_bwd, monkeypatch):
     """Encoder_VAE_MLP / Decoder_AE_MLP nodes vs the oracle networks; the encoder also with the heads' backward in one
-    launch (mvk_heads_bwd; off by default for the MLP encoders: kernels.HEADS_BWD_MLP)."""
+    launch (mvk_heads_bwd; kernels.HEADS_BWD_MLP switches it for the MLP encoders)."""
     import golden_cases as G
     from multivae_amd import kernels as K_
 
