@@ -499,7 +499,10 @@ def main():
               "step_achieved": round(step_flops / (ms * 1e-3) / 1e12, 2),
               "step_frac": round(step_flops / (ms * 1e-3) / 1e12 / MFMA_F32_TFLOPS, 4),
               "note": "fp32 products on the split-bf16 engine (6 bf16 MFMAs each): peak = the fp32-input MFMA rate, "
-                      "peak_split_bf16 = 2500 / 6; step_* = every GEMM-shaped FLOP of the step / ms_per_step"}
+                      "peak_split_bf16 = 2500 / 6; step_* = every GEMM-shaped FLOP of the step / ms_per_step; "
+                      "achieved / us_per_step of the named kernels are IN-STEP durations: the launches share the chip with "
+                      "the other modality's stream and the late weight gradients (alone: 98-113 us per launch, "
+                      "tools/imgconv_probe.py, DESIGN.md section 6)"}
         if conv:
             ach = conv["work"] / conv["seconds"] / 1e12
             mf.update({"kernel": "imgconv_kernel / imgwgrad_kernel (register-stationary 4x4/stride-2 convolutions)",
