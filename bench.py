@@ -112,7 +112,8 @@ def build_workload(name, args, device, rank):
                     attributes=(torch.rand(B, 40, generator=g) > 0.5).float().to(device))
         w.update(model=M.JMVAE(cfg, enc, dec), data=data, B=B, K=K, fwd_kwargs=dict(epoch=20),
                  metric="train samples/sec (ELBO step) JMVAE CelebA-shaped 64x64 + attributes",
-                 text=f"JMVAE CelebA-shaped (3x64x64 image: CUB ResNet enc/dec, 40 binary attributes: MLP), latent {L}, "
+                 text=f"JMVAE CelebA-shaped (3x64x64 image: CUB ResNet enc/dec, all 40 binary CelebA attributes "
+                      f"(reference data/datasets/celeba.py:18; not the 18-attribute subset): MLP), latent {L}, "
                       f"per-device batch {B}, Adam lr 1e-3, fwd+ELBO+bwd+optimizer")
     else:
         raise SystemExit(f"unknown --config {name}")
@@ -278,6 +279,23 @@ class DeviceProfiler:
         return out
 
 
+def measured_copy_gbs(device, mb=512, reps=20):
+    """Device-to-device copy bandwidth (read + write bytes per second) of a `mb`-MB fp32 buffer, HIP events around `reps`
+    copies: the measured denominator SURVEY.md section 8(d) asks for beside the 8.0 TB/s nominal one."""
+    n = mb * (1 << 20) // 4
+    src = torch.empty(n, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * 4 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def summarise(recs, kinds, boundary_s=0.0):
     """Duration per launch = first workgroup in -> first instruction of the one-wave kernel queued behind it (what
     rocprofv3's begin -> end of the dispatch shows, within ~1 %); `busy_avg_us` takes one calibrated kernel boundary off."""
@@ -382,14 +400,20 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    # per-step device times inside the timed region: one event record per step on the step's stream (no sync, ~1 us of
+    # host time each); the median is reported beside the mean that `value` is computed from
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         out = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     loss = float(out.loss.detach())
     if loss != loss:
         raise ArithmeticError("NaN detected in train loss")
@@ -456,6 +480,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms, 4),
+            "ms_per_step_median": round(per_step_ms[len(per_step_ms) // 2], 4),
+            "ms_per_step_min_max": [round(per_step_ms[0], 4), round(per_step_ms[-1], 4)],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -469,17 +495,22 @@ def main():
         nll = summarise(recs, {"recon_nll"}, boundary)
         if nll:
             ev = [s.elapsed_time(e) * 1e-3 for s, e in events]
-            traffic = None
+            traffic, traffic_meta = None, {}
             tf = os.path.join(ROOT, "profiles", "recon_nll_traffic.json")
             if args.config == "cfg3" and os.path.exists(tf):
                 with open(tf) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
+                    traffic_meta = json.load(f)
+                traffic = traffic_meta.get("hbm_bytes_per_launch")
             ach = nll["work"] / nll["seconds"] / 1e9
+            copy_gbs = measured_copy_gbs(device)
             res["roofline"] = {
                 "kernel": "recon_nll_kernel<vec,fwd> (fused reconstruction NLL + d_recon, all modalities, one launch)",
                 "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/recon_nll_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
+                "traffic_source": ("profiles/recon_nll_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                   "command by tools/gpu_profile.sh (counters cannot be read from inside the process); "
+                                   f"measured at commit {traffic_meta.get('commit', 'unrecorded')}") if traffic else None,
+                "measured_copy_GBs": round(copy_gbs, 1), "frac_vs_measured_copy": round(ach / copy_gbs, 4),
                 "algorithmic_bytes": nll["work"] / nll["launches"], "avg_launch_us": round(nll["avg_us"], 2),
                 "launches_timed": nll["launches"],
                 "first_in_last_out_us": round(nll["inner_avg_us"], 2),
@@ -493,21 +524,24 @@ def main():
                 "instrumented_ms_per_step": round(ms_instr, 4),
                 "hip_event_pair_us": round(1e6 * sum(ev) / len(ev), 2) if ev else None}
         conv = summarise(recs, {"imgconv_up", "imgconv_down", "imgconv_wgrad"}, boundary)
-        mf = {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F32_TFLOPS,
-              "peak_split_bf16": round(MFMA_BF16_TFLOPS / 6, 1),
+        SPLIT_PEAK = MFMA_BF16_TFLOPS / 6
+        mf = {"bound": "mfma", "unit": "TFLOP/s", "peak": round(SPLIT_PEAK, 1),
+              "peak_fp32_input_mfma": MFMA_F32_TFLOPS,
               "step_gemm_gflop": round(step_flops / 1e9, 2),
               "step_achieved": round(step_flops / (ms * 1e-3) / 1e12, 2),
-              "step_frac": round(step_flops / (ms * 1e-3) / 1e12 / MFMA_F32_TFLOPS, 4),
-              "note": "fp32 products on the split-bf16 engine (6 bf16 MFMAs each): peak = the fp32-input MFMA rate, "
-                      "peak_split_bf16 = 2500 / 6; step_* = every GEMM-shaped FLOP of the step / ms_per_step; "
+              "step_frac": round(step_flops / (ms * 1e-3) / 1e12 / SPLIT_PEAK, 4),
+              "step_frac_vs_fp32_input_mfma": round(step_flops / (ms * 1e-3) / 1e12 / MFMA_F32_TFLOPS, 4),
+              "note": "fp32 products on the split-bf16 engine (6 bf16 MFMAs each): peak = 2500 / 6 TFLOP/s of fp32 work, the "
+                      "ceiling of the pipes the work runs on (frac); the fp32-input MFMA rate is kept as a second "
+                      "denominator (*_vs_fp32_input_mfma); step_* = every GEMM-shaped FLOP of the step / ms_per_step; "
                       "achieved / us_per_step of the named kernels are IN-STEP durations: the launches share the chip with "
                       "the other modality's stream and the late weight gradients (alone: 98-113 us per launch, "
                       "tools/imgconv_probe.py, DESIGN.md section 6)"}
         if conv:
             ach = conv["work"] / conv["seconds"] / 1e12
             mf.update({"kernel": "imgconv_kernel / imgwgrad_kernel (register-stationary 4x4/stride-2 convolutions)",
-                       "achieved": round(ach, 1), "frac": round(ach / MFMA_F32_TFLOPS, 4),
-                       "frac_split_bf16": round(ach / (MFMA_BF16_TFLOPS / 6), 4),
+                       "achieved": round(ach, 1), "frac": round(ach / SPLIT_PEAK, 4),
+                       "frac_vs_fp32_input_mfma": round(ach / MFMA_F32_TFLOPS, 4),
                        "gflop_per_step": round(conv["work"] / args.steps / 1e9, 2),
                        "us_per_step": round(1e6 * conv["seconds"] / args.steps, 1), "launches_timed": conv["launches"]})
         res["roofline_mfma"] = mf

@@ -13,7 +13,16 @@
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it; calls are re-entrant per stream;
  *   - return value: 0 = MVK_OK, <0 = error (MVK_EINVAL bad argument, MVK_ELAUNCH launch failure);
  *   - noise is always an input buffer: results never depend on an RNG stream;
- *   - gradient outputs documented "+=" are ACCUMULATED (atomicAdd split-K): zero them first if needed.
+ *   - gradient outputs documented "+=" are ACCUMULATED into the caller's buffer: zero it first if needed.  Every
+ *     reduction is deterministic: split-K slices, column-sum partials and per-workgroup weight-gradient slabs are
+ *     written to caller-owned scratch and added in a fixed order (an entry point that is given no scratch falls back
+ *     to fp32 atomicAdd, the only non-reproducible path);
+ *   - there is no hidden global state, with TWO documented exceptions, both explicit begin / end pairs that the host
+ *     owns and that are per device: (1) mvk_defer_begin / mvk_defer_flush / mvk_defer_end — between begin and end the
+ *     ordered finishes of leaf gradients that target the registered flat gradient buffer are queued in a caller-owned
+ *     arena and run as one launch at flush; (2) mvk_prof_enable / mvk_prof_disable — device-timestamp records of
+ *     the launches in between are written to a caller-owned buffer.  Neither survives its end call; with neither
+ *     active every entry point is a pure function of its arguments.
  */
 #ifndef MVK_H
 #define MVK_H

@@ -9,6 +9,14 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def tune(name, default):
+    """Experiment switches (the MVK_* A/B knobs of DESIGN.md section 9) are honoured only under MVK_TUNE=1: a process without it
+    runs ONE configuration, the shipped one."""
+    return os.environ.get(name, default) if os.environ.get("MVK_TUNE") == "1" else default
+
+
 LIB_PATH = os.environ.get("MVK_LIB_PATH") or os.path.join(_HERE, "libmvk.so")  # MVK_LIB_PATH: A/B builds (tools/)
 
 MVK_OK = 0

@@ -15,6 +15,15 @@
 
 static inline hipStream_t mvk_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Experiment switches (the MVK_* A/B knobs of DESIGN.md section 9) are read only when MVK_TUNE=1 is set: a process without it
+// runs ONE configuration, the shipped one.  (MVK_ENGINE, the documented and tested engine selector, is read directly.)
+#include <cstdlib>
+#include <cstring>
+static inline const char* mvk_tune(const char* name) {
+  static const bool on = getenv("MVK_TUNE") && strcmp(getenv("MVK_TUNE"), "1") == 0;
+  return on ? getenv(name) : nullptr;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

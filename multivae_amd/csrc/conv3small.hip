@@ -240,7 +240,7 @@ namespace mvk {
 // 1: shape not covered (the caller continues with the GEMM engine)
 int conv3_smallcin(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
                    const float* mask_src, int mask_act, hipStream_t s) {
-  static const int off = getenv("MVK_CONV3SMALL") ? atoi(getenv("MVK_CONV3SMALL")) == 0 : 0;
+  static const int off = mvk_tune("MVK_CONV3SMALL") ? atoi(mvk_tune("MVK_CONV3SMALL")) == 0 : 0;
   if (off || Cin < 1 || Cin > 4 || Cout % 4 != 0 || Cout < 4 || Cout > 1024 || W > 256 || n < 1) return 1;
   if (!mvk_aligned16(Wp) || !mvk_aligned16(Y) || (bias && !mvk_aligned16(bias)) || (mask_src && !mvk_aligned16(mask_src))) return 1;
   C3Args a{X, Wp, bias, Y, mask_src, n, H, W, Cin, Cout, act, mask_act};
@@ -260,7 +260,7 @@ int conv3_smallcin(const float* X, const float* Wp, const float* bias, float* Y,
 // 1: shape not covered
 int conv3_smallcout(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
                     const float* mask_src, int mask_act, hipStream_t s) {
-  static const int off = getenv("MVK_CONV3SMALL") ? atoi(getenv("MVK_CONV3SMALL")) == 0 : 0;
+  static const int off = mvk_tune("MVK_CONV3SMALL") ? atoi(mvk_tune("MVK_CONV3SMALL")) == 0 : 0;
   if (off || Cout < 1 || Cout > 4 || Cin % 16 != 0 || Cin < 16 || Cin > 256 || n < 1 || !mvk_aligned16(X)) return 1;
   C3Args a{X, Wp, bias, Y, mask_src, n, H, W, Cin, Cout, act, mask_act};
   const int tcols = (W + C3_TC - 1) / C3_TC, trows = (H + C3_TR - 1) / C3_TR;
@@ -287,7 +287,7 @@ int conv3_smallcout(const float* X, const float* Wp, const float* bias, float* Y
 // slab: [*nz][9 * Cin * Cout] partial gradients already in dWref order; 1: shape not covered
 int conv3_small_wgrad(const float* X, const float* dY, float* slab, long long slab_floats, int n, int H, int W, int Cin, int Cout,
                       int* nz, hipStream_t s) {
-  static const int off = getenv("MVK_CONV3SMALL") ? atoi(getenv("MVK_CONV3SMALL")) == 0 : 0;
+  static const int off = mvk_tune("MVK_CONV3SMALL") ? atoi(mvk_tune("MVK_CONV3SMALL")) == 0 : 0;
   const bool in_small = Cin <= 4, out_small = Cout <= 4;
   if (off || n < 1 || (!in_small && !out_small) || W > 256) return 1;
   const int CS = in_small ? Cin : Cout, CB = in_small ? Cout : Cin;

@@ -421,7 +421,7 @@ __device__ __forceinline__ void recon_vec_body(const mvk_recon_desc& d, int B, i
 static int recon_max_chunk() {
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("MVK_RECON_CHUNK");
+    const char* e = mvk_tune("MVK_RECON_CHUNK");
     v = e ? atoi(e) : KC;
     if (v < 1) v = 1;
     if (v > KC) v = KC;

@@ -59,7 +59,7 @@ static int defer_push(const Epilogue& e, int M, int N, int nz, long long zstride
   it.nz = nz;
   it.zstride = zstride;
   it.vec4 = ((long long)M * N) % 4 == 0 && zstride % 4 == 0 && mvk_aligned16(e.ws);
-  static const int zl_env = getenv("MVK_DEFER_ZL") ? atoi(getenv("MVK_DEFER_ZL")) : 5;  // z-lanes of long reductions (A/B)
+  static const int zl_env = mvk_tune("MVK_DEFER_ZL") ? atoi(mvk_tune("MVK_DEFER_ZL")) : 5;  // z-lanes of long reductions (A/B)
   it.zl_bits = nz > 64 ? zl_env : 3;
   g_defer.items.push_back(it);
   return MVK_OK;
@@ -220,7 +220,7 @@ static int launch_bf_tile(const GemmDesc& d, int zdim, hipStream_t s, int amode,
 static int bf_min_blocks() {  // smallest grid that still goes to the split engine (MVK_BF_MIN_BLOCKS overrides)
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("MVK_BF_MIN_BLOCKS");
+    const char* e = mvk_tune("MVK_BF_MIN_BLOCKS");
     v = e ? atoi(e) : 256;  // measured on the MnistSvhn step: 160-256 best, 384 and < 100 1-2 % slower
   }
   return v;
@@ -345,8 +345,8 @@ int launch_igemm(const GemmDesc& d_in, int zdim, hipStream_t s, LaunchInfo* info
 static int splitk_target(int t) {
   static int t1024 = -1, t512 = -1;
   if (t1024 < 0) {
-    const char* a = getenv("MVK_SPLITK_TARGET_1024");
-    const char* b = getenv("MVK_SPLITK_TARGET_512");
+    const char* a = mvk_tune("MVK_SPLITK_TARGET_1024");
+    const char* b = mvk_tune("MVK_SPLITK_TARGET_512");
     t1024 = a ? atoi(a) : 768;  // one full wave of 3 workgroups per CU (A/B in the step: 1.955 vs 1.969 ms at 1024)
     t512 = b ? atoi(b) : 512;
   }
@@ -715,7 +715,7 @@ int imgconv_wgrad(const float* U, const float* V, float* slab, long long slab_fl
 static int imgconv_min_images() {
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("MVK_IMGCONV");
+    const char* e = mvk_tune("MVK_IMGCONV");
     v = e ? atoi(e) : 256;
     if (v == 0) v = 1 << 30;
   }
@@ -745,7 +745,7 @@ int mvk_linear_fwd(const float* X, const float* W, const float* b, float* Y, int
   }
   // a few hundred rows (the encoders' hidden layers at the training batch): too few 128-row tiles for the tiled engine,
   // which then splits K and needs a second launch to reduce (47 us for 512 x 784 -> 400); one 16 x 16 tile per workgroup
-  static const int fewrows = getenv("MVK_FEWROWS") ? atoi(getenv("MVK_FEWROWS")) : 1024;
+  static const int fewrows = mvk_tune("MVK_FEWROWS") ? atoi(mvk_tune("MVK_FEWROWS")) : 1024;
   if (M <= fewrows && K >= 64 && (long long)N * K <= (1 << 21)) {
     const int rc = heads_launch(X, W, b, Y, nullptr, nullptr, nullptr, M, N, K, 1, K, act, mvk_stream(stream));
     if (rc != 1) return rc;
@@ -781,7 +781,7 @@ int mvk_linear_bwd_data(const float* dY, const float* W, float* dX, int M, int N
   d.N = K;
   d.K = N;
   hipStream_t s = mvk_stream(stream);
-  static const int smallk_bwd = getenv("MVK_SMALLK_BWD") ? atoi(getenv("MVK_SMALLK_BWD")) : 0;  // measured +10 us per step on the heads' backward-data: off
+  static const int smallk_bwd = mvk_tune("MVK_SMALLK_BWD") ? atoi(mvk_tune("MVK_SMALLK_BWD")) : 0;  // measured +10 us per step on the heads' backward-data: off
   if (smallk_bwd && N <= 32 && !y_out && !colsum_acc) {  // backward-data out of a narrow layer (the encoder heads)
     const int rc = smallk_fwd(dY, W, K, 1, nullptr, 1, MVK_ACT_NONE, dX, M, K, N, s, prev_out, prev_act, accumulate);
     if (rc != 1) return rc;
@@ -866,7 +866,7 @@ int mvk_gemm(const float* A, const float* B, float* C, int M, int N, int K, int 
              int bias_mod, int act, int accumulate, const float* a_act_src, int a_act, const float* c_act_src,
              int c_act, float* ws, int64_t ws_floats, void* stream) {
   if (!A || !B || !C || M < 0 || N <= 0 || K <= 0) return MVK_EINVAL;
-  static const int smallk_bwd = getenv("MVK_SMALLK_BWD") ? atoi(getenv("MVK_SMALLK_BWD")) : 0;  // measured +10 us per step on the heads' backward-data: off
+  static const int smallk_bwd = mvk_tune("MVK_SMALLK_BWD") ? atoi(mvk_tune("MVK_SMALLK_BWD")) : 0;  // measured +10 us per step on the heads' backward-data: off
   if (K <= 32 && !ta && !a_act_src && M > 0 && (smallk_bwd || (!accumulate && !c_act_src))) {
     const int rc = smallk_fwd(A, B, tb ? 1 : N, tb ? K : 1, bias, bias_mod, act, C, M, N, K, mvk_stream(stream), c_act_src,
                               c_act, accumulate);

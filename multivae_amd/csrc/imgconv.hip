@@ -678,7 +678,7 @@ static int imgconv_launch(const ImgConvArgs& a, int* part_rows, hipStream_t s) {
   using T = ICfg<KIND, HS, CIN, COUT>;
   static bool attr_done = false;
   // MVK_IMGCONV_PIPE=0: the one-tile-latency main loop (A/B; results are bit-identical)
-  static const bool pipe = !(getenv("MVK_IMGCONV_PIPE") && atoi(getenv("MVK_IMGCONV_PIPE")) == 0);
+  static const bool pipe = !(mvk_tune("MVK_IMGCONV_PIPE") && atoi(mvk_tune("MVK_IMGCONV_PIPE")) == 0);
   auto kern = a.act_src ? (pipe ? imgconv_kernel<KIND, HS, CIN, COUT, true, true> : imgconv_kernel<KIND, HS, CIN, COUT, true, false>)
                         : (pipe ? imgconv_kernel<KIND, HS, CIN, COUT, false, true> : imgconv_kernel<KIND, HS, CIN, COUT, false, false>);
   if (!attr_done) {
@@ -952,7 +952,7 @@ static int imgwgrad_launch(const ImgWgradArgs& a, int* nz, hipStream_t s) {
   }
   // MVK_IMGWGRAD_GRID: fewer workgroups than compute units leave room for launches of other streams (a workgroup owns a
   // whole compute unit's registers)
-  static const int grid_env = getenv("MVK_IMGWGRAD_GRID") ? atoi(getenv("MVK_IMGWGRAD_GRID")) : 256;
+  static const int grid_env = mvk_tune("MVK_IMGWGRAD_GRID") ? atoi(mvk_tune("MVK_IMGWGRAD_GRID")) : 256;
   const int grid = (grid_env >= T::WG_TYPES && grid_env <= 256) ? grid_env / T::WG_TYPES * T::WG_TYPES : 256;
   *nz = grid / T::WG_TYPES;
   ImgWgradArgs ap = a;

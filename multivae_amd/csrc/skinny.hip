@@ -233,7 +233,7 @@ int heads_launch(const float* X, const float* W0, const float* b0, float* Y0, co
   a.w_sn = w_sn;
   const int heads = W1 ? 2 : 1;
   const dim3 grid((M + 15) / 16, heads * a.tiles_per_head);
-  static const int nw_env = getenv("MVK_HEADS_WAVES") ? atoi(getenv("MVK_HEADS_WAVES")) : 0;  // A/B switch
+  static const int nw_env = mvk_tune("MVK_HEADS_WAVES") ? atoi(mvk_tune("MVK_HEADS_WAVES")) : 0;  // A/B switch
   if (nw_env ? nw_env == 16 : K >= 1024)
     hipLaunchKernelGGL(heads_fwd_kernel<16>, grid, dim3(1024), 0, s, a);
   else
@@ -385,7 +385,7 @@ namespace mvk {
 // 1: shape not covered (the caller continues with the tiled engine)
 int smallk_fwd(const float* X, const float* W, long long w_sk, long long w_sn, const float* bias, int bias_mod, int act,
                float* Y, int M, int N, int K, hipStream_t s, const float* mask_src, int mask_act, int accumulate) {
-  static const int off = getenv("MVK_SMALLK") ? atoi(getenv("MVK_SMALLK")) == 0 : 0;
+  static const int off = mvk_tune("MVK_SMALLK") ? atoi(mvk_tune("MVK_SMALLK")) == 0 : 0;
   if (off || K > 32 || K < 1 || N % 4 != 0 || N < 4 || !mvk_aligned16(Y) || M < 1 || (mask_src && !mvk_aligned16(mask_src)))
     return 1;
   SmallKArgs a{X, W, bias, Y, M, N, K, bias_mod > 0 ? bias_mod : 1, act, w_sk, w_sn, mask_src, mask_act, accumulate};

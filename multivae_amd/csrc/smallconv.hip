@@ -1036,7 +1036,7 @@ static int launch_fwd(const float* V, const float* Wref, const float* bias, floa
   // dense: 256 positions = one 16-row tile per wave, CV / 4 * 256 float4 and CU * 1024 outputs divide the workgroup evenly
   const bool dense = h == 16 && w == 16 && NT == 1024 && (256 * CV / 4) % NT == 0 && (CU * 1024) % NT == 0;
   // MVK_SMALL_FWD_BF=0: the exact-fp32 matrix instructions for every shape; =512: the split kernel with 512-thread workgroups
-  static const int bf = getenv("MVK_SMALL_FWD_BF") ? atoi(getenv("MVK_SMALL_FWD_BF")) : 1024;
+  static const int bf = mvk_tune("MVK_SMALL_FWD_BF") ? atoi(mvk_tune("MVK_SMALL_FWD_BF")) : 1024;
   if constexpr (CV == 32 && CU == 3) {
     if (h == 16 && w == 16 && bf > 0) {
       const size_t blds = 3 * (16 * CU) * 64 + (256 * (16 * CU + 1) + 4) * sizeof(float);
@@ -1066,12 +1066,12 @@ static int launch_bwd(const float* dU, const float* Uout, int u_act, const float
   const int slab = CV * C::NC + CU + CV;
   // MVK_SMALL_BWD_UNITS=2: half-image work units for 16x16 inputs (3 workgroups per CU instead of 2).  Measured at
   // n = 5120: 142.7 us vs 146.0 us alone, 162-166 us vs 137-139 us inside the MoPoE step (same step time): off by default.
-  static const int units_env = getenv("MVK_SMALL_BWD_UNITS") ? atoi(getenv("MVK_SMALL_BWD_UNITS")) : 1;
+  static const int units_env = mvk_tune("MVK_SMALL_BWD_UNITS") ? atoi(mvk_tune("MVK_SMALL_BWD_UNITS")) : 1;
   const int units = (h == 16 && w == 16 && units_env == 2) ? 2 : 1;
   const long long nunits = (long long)n * units;
   // MVK_SMALL_BWD_BF=0 (read per call: tests switch it): the exact-fp32 kernel for every shape.  Default: the split-bf16 kernel at
   // the SVHN decoder's shape — 128 -> 110 us alone at n = 5120, -13 us per training step (three A/B pairs on one box).
-  const char* bf_str = getenv("MVK_SMALL_BWD_BF");
+  const char* bf_str = mvk_tune("MVK_SMALL_BWD_BF");
   const bool bf = (!bf_str || atoi(bf_str) != 0) && CU == 3 && CV == 32 && h == 16 && w == 16 && units_env != 2 &&
                   u_act == MVK_ACT_SIGMOID && v_act == MVK_ACT_RELU && mvk_aligned16(dU) && mvk_aligned16(Uout) &&
                   mvk_aligned16(V) && mvk_aligned16(dV) && mvk_aligned16(Wref);
@@ -1119,18 +1119,18 @@ static int launch_bwd(const float* dU, const float* Uout, int u_act, const float
   }
   // algorithmic bytes: image gradient + image read once, the saved input map read once, its gradient written once
   mvk_prof_slot* prof = mvk::prof_next(6, 4.0 * n * h * w * (2.0 * CV + 8.0 * CU));
-  static const int occ_env = getenv("MVK_SMALL_BWD_OCC") ? atoi(getenv("MVK_SMALL_BWD_OCC")) : 3;
+  static const int occ_env = mvk_tune("MVK_SMALL_BWD_OCC") ? atoi(mvk_tune("MVK_SMALL_BWD_OCC")) : 3;
   const bool spec = u_act == MVK_ACT_SIGMOID && v_act == MVK_ACT_RELU;
 #ifdef MVK_ABLATE
-  const int abl_bits = ((getenv("MVK_ABLATE") ? atoi(getenv("MVK_ABLATE")) : 0) << 8) |
-                       ((getenv("MVK_DEPHASE") ? atoi(getenv("MVK_DEPHASE")) : 0) << 16);
+  const int abl_bits = ((mvk_tune("MVK_ABLATE") ? atoi(mvk_tune("MVK_ABLATE")) : 0) << 8) |
+                       ((mvk_tune("MVK_DEPHASE") ? atoi(mvk_tune("MVK_DEPHASE")) : 0) << 16);
 #else
   constexpr int abl_bits = 0;
 #endif
 #define MVK_SUB_LAUNCH(PU_, OCC_, UA_, VA_, UNITS_, DENSE_)                                                               \
   hipLaunchKernelGGL((small_up_bwd_kernel<CU, CV, NT, PU_, OCC_, UA_, VA_, DENSE_>), dim3(grid), dim3(NT), lds, s, dU, Uout, \
                      u_act, V, v_act, Wref, dV, ws, n, h, w, (UNITS_) | abl_bits, prof)
-  static const int dense_env = getenv("MVK_SMALL_BWD_DENSE") ? atoi(getenv("MVK_SMALL_BWD_DENSE")) : 1;  // A/B switch
+  static const int dense_env = mvk_tune("MVK_SMALL_BWD_DENSE") ? atoi(mvk_tune("MVK_SMALL_BWD_DENSE")) : 1;  // A/B switch
   const bool dense = dense_env && h == 16 && w == 16 && NT == 256 && mvk_aligned16(dU) && mvk_aligned16(Uout);
   if (units == 2 && occ_env == 4) {
     if (spec) MVK_SUB_LAUNCH(128, 4, MVK_ACT_SIGMOID, MVK_ACT_RELU, 2, false);

@@ -95,15 +95,19 @@ class MnistSvhn(MultimodalBaseDataset):
         return True
 
     def rand_match_on_idx(self, l1, idx1, l2, idx2, max_d=10000):
-        _idx1, _idx2 = [], []
-        for l in l1.unique():  # both sets hold the same labels
-            l_idx1, l_idx2 = idx1[l1 == l], idx2[l2 == l]
-            n = min(l_idx1.size(0), l_idx2.size(0), max_d)
-            l_idx1, l_idx2 = l_idx1[:n], l_idx2[:n]
-            for _ in range(self.data_mul):
-                _idx1.append(l_idx1[torch.randperm(n)])
-                _idx2.append(l_idx2[torch.randperm(n)])
-        return torch.cat(_idx1), torch.cat(_idx2)
+        """Pair the two sample sets digit by digit (reference `mnist_svhn.py:100-115`; pinned against the reference's own
+        output by tests/golden/pairing_mnist_svhn.npz).  `l1 / l2` are the sorted labels, `idx1 / idx2` the matching
+        sample positions.  For every digit the first `min(count_1, count_2, max_d)` candidates of each set are kept and
+        shuffled `data_mul` times; the global torch generator is consumed in the order (digit, round, set 1, set 2), which is
+        what makes the index files of the reference reproducible."""
+        picked = ([], [])
+        for digit in torch.unique(l1):  # sorted; both sets hold every digit
+            cand = (idx1[l1 == digit], idx2[l2 == digit])
+            keep = min(cand[0].numel(), cand[1].numel(), max_d)
+            for _round in range(self.data_mul):
+                for side in (0, 1):
+                    picked[side].append(cand[side][:keep][torch.randperm(keep)])
+        return torch.cat(picked[0]), torch.cat(picked[1])
 
     def create_pairing(self, mnist_labels, svhn_labels, max_d=10000):
         logger.info(f"Creating indices in {self.path_to_idx}")

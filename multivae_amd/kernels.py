@@ -72,11 +72,11 @@ def _ws(like):
 # Weight / bias gradients are leaves: between `deferred_reductions(flat)` and its exit the ordered finishes of every
 # gradient that accumulates into the flat buffer (split-K slabs, column-sum partials, convolution weight-gradient slabs)
 # are queued and run in ONE launch at exit instead of one small launch each in the middle of the backward chain.
-DEFER = os.environ.get("MVK_DEFER", "1") != "0"
+DEFER = _lib.tune("MVK_DEFER", "1") != "0"
 # MVK_DEFER_SIDE=1: flush the decoders' finishes on a side stream when the posterior backward starts.  Measured on the
 # headline step: 1.528 ms vs 1.50 ms with one flush at the end (the streaming finish kernel delays every launch of the
 # latency-bound encoder backward it runs beside): off.
-DEFER_SIDE = os.environ.get("MVK_DEFER_SIDE", "0") == "1"
+DEFER_SIDE = _lib.tune("MVK_DEFER_SIDE", "0") == "1"
 DEFER_ARENA_FLOATS = int(os.environ.get("MVK_DEFER_MB", "512")) * (1 << 18)
 _ARENA = {}
 
@@ -90,7 +90,7 @@ _LATE_USED = {}  # device -> streams that hold late leaves / partial flushes sin
 # MEASURED (headline step, same box, two pairs): 1.347 / 1.336 ms without vs 1.320 / 1.315 ms with; a smaller grid for the
 # weight-gradient kernels (MVK_IMGWGRAD_GRID=224 / 192 / 128: compute units left free for the chain) does not help
 # (1.331 / 1.348 / 1.414 ms).  MVK_LATE_LEAVES=0 disables.
-LATE_LEAVES = os.environ.get("MVK_LATE_LEAVES", "1") != "0"
+LATE_LEAVES = _lib.tune("MVK_LATE_LEAVES", "1") != "0"
 
 
 class late_leaves:
@@ -155,7 +155,7 @@ class deferred_reductions:
 # MVK_FLUSH_SIBLING=1: when the LAST backward node of the step starts (the convolutional encoder: ~140 us of launch-latency-bound
 # chain on its own stream), everything queued so far is finished on the other branch stream, which is idle by then, instead of
 # in one launch behind the chain.
-FLUSH_SIBLING = os.environ.get("MVK_FLUSH_SIBLING", "1") != "0"
+FLUSH_SIBLING = _lib.tune("MVK_FLUSH_SIBLING", "1") != "0"
 _BRANCH_SET = {}  # device -> the streams of the last run_branches call (main first)
 
 
@@ -187,7 +187,7 @@ def defer_flush_side(device):
 # reconstruction loss) joins them.  The small-modality branch is a string of short, launch-latency-bound
 # kernels; on its own stream it runs beside the large modality's convolutions instead of in front of them.
 # Autograd replays each node's backward on the stream its forward ran on, so the backward overlaps too.
-BRANCH_STREAMS = os.environ.get("MVK_BRANCH_STREAMS", "1") != "0"
+BRANCH_STREAMS = _lib.tune("MVK_BRANCH_STREAMS", "1") != "0"
 _SIDE = {}
 
 
@@ -196,7 +196,7 @@ def _side_stream(device, i):
     st = _SIDE.get(key)
     if st is None:
         # default priority: a priority -1 side stream costs +75 % step time (1.38 -> 2.4 ms, re-measured in round 2: MVK_SIDE_PRIO)
-        st = torch.cuda.Stream(device=device, priority=int(os.environ.get("MVK_SIDE_PRIO", "0")))
+        st = torch.cuda.Stream(device=device, priority=int(_lib.tune("MVK_SIDE_PRIO", "0")))
         _SIDE[key] = st
     return st
 
@@ -217,7 +217,7 @@ def _tensors_of(obj):
 # MEASURED (MoPoE MnistSvhn step, hipGraph replay): 1.435 ms with the SVHN encoder's leaves on a third stream vs 1.385 ms
 # without — every fork / join edge between streams of a captured graph costs more than the ~90 us of leaf work it moves
 # off the chain (third result of this kind).  Off unless MVK_LEAF_STREAM=1.
-LEAF_STREAM = os.environ.get("MVK_LEAF_STREAM", "0") == "1"
+LEAF_STREAM = _lib.tune("MVK_LEAF_STREAM", "0") == "1"
 
 
 class LeafStream:
@@ -357,13 +357,13 @@ def heads_fwd(h2, w_mu, b_mu, w_lv, b_lv, N, w_sk, w_sn):
     return mu, lv
 
 
-HEADS_BWD = os.environ.get("MVK_HEADS_BWD", "1") != "0"  # A/B switch: the heads' backward in one launch
+HEADS_BWD = _lib.tune("MVK_HEADS_BWD", "1") != "0"  # A/B switch: the heads' backward in one launch
 # MEASURED (headline step, one box, 3-4 rounds each): 1.355 ms with the six separate launches, 1.326 ms with the fused launch
 # for the convolutional (SVHN) encoder only, 1.343 ms with the fused launch for the MLP encoder too (its chain is not the
 # critical one and the fused launch delays the other stream's kernels).  RE-MEASURED at the end of round 2, with the partial
 # finish on the sibling stream and a replayed graph that now spreads over three hardware queues: 1.2480 ms with the fused launch
 # for the MLP encoder too vs 1.2569 ms without (four same-box pairs) — on by default now, MVK_HEADS_BWD_MLP=0 disables.
-HEADS_BWD_MLP = os.environ.get("MVK_HEADS_BWD_MLP", "1") != "0"
+HEADS_BWD_MLP = _lib.tune("MVK_HEADS_BWD_MLP", "1") != "0"
 
 
 def heads_bwd(x, x_act, dys, ws_, bs, w_sk, w_sn, flat_c=0, want_dx=True, prev_bias=None, dw_params=None):
@@ -416,7 +416,7 @@ def wfrag(w):
 
 PACK_MAX = 16  # MVK_PACK_MAX descriptors per launch
 # MVK_PREPACK=0: every network packs its own weights when it runs (one launch per network and forward pass)
-PREPACK = os.environ.get("MVK_PREPACK", "1") != "0"
+PREPACK = _lib.tune("MVK_PREPACK", "1") != "0"
 _PACK_SCOPE = None
 
 
@@ -595,16 +595,22 @@ def upsample2_bwd(dy, n, H, W, C):
 
 # ---- noise with the generator state in device memory (mvk_device_rng) -------------------------------------------------
 # MVK_DEVICE_RNG=0: draw from torch's generator instead (two extra host-issued fill launches per hipGraph replay).
-DEVICE_RNG = os.environ.get("MVK_DEVICE_RNG", "1") != "0"
+DEVICE_RNG = _lib.tune("MVK_DEVICE_RNG", "1") != "0"
 _RNG = {}  # device -> [state tensor (3 x int64: seed, offset, ticket), torch seed it was built from, breadcrumb offset]
 
 
 def _rng_state(device):
-    """The device-resident generator state, tied to torch's CUDA generator of that device: (re)built from its seed whenever
+    """The device-resident generator state, tied to torch's CUDA generator of that device: re-seeded from its seed whenever
     torch was re-seeded since the last draw.  A re-seed is seen as a changed seed or an offset that went backwards — every
     draw leaves a breadcrumb by advancing torch's (host-side) offset, so `torch.manual_seed(s)` twice with the same s and
-    nothing drawn from torch in between is still noticed.  Not consulted while a stream is capturing (a captured step
-    keeps the state it was captured with; the launches inside the graph advance it)."""
+    nothing drawn from torch in between is still noticed.  Not consulted while a stream is capturing (the launches inside
+    a graph advance the state they find).
+
+    The state tensor is allocated ONCE per device and re-seeded IN PLACE (a stream-ordered copy): a captured GraphedStep has
+    its raw pointer baked into its mvk_device_rng launches, so the tensor must never be replaced — and a re-seed then also
+    reaches every existing graph.  Draws must be stream-ordered with respect to each other (the {offset, ticket} protocol of
+    device_rng_kernel serialises nothing): every caller in the package draws on the step's main stream or on a branch
+    stream between that stream's fork and join."""
     ent = _RNG.get(device)
     if ent is not None and torch.cuda.is_current_stream_capturing():
         return ent[0]
@@ -613,9 +619,12 @@ def _rng_state(device):
     if ent is None or ent[1] != seed or off < ent[2]:
         if torch.cuda.is_current_stream_capturing():
             raise _lib.MvkError("the device generator state must exist before a graph capture starts (run one eager step)")
-        st = torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, off // 4, 0], dtype=torch.int64, device=device)
-        ent = [st, seed, off]
-        _RNG[device] = ent
+        fresh = torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, off // 4, 0], dtype=torch.int64)
+        if ent is None:
+            ent = [torch.empty(3, dtype=torch.int64, device=device), seed, off]
+            _RNG[device] = ent
+        ent[0].copy_(fresh)  # pageable host source: the copy has read `fresh` when it returns; ordered on the current stream
+        ent[1], ent[2] = seed, off
     ent[2] = off + 4
     gen.set_offset(ent[2])
     return ent[0]
@@ -1272,7 +1281,7 @@ def unit_seed(like):
     return t
 
 
-UNIT_SEED = os.environ.get("MVK_UNIT_SEED", "1") != "0"  # 0: always launch the seed kernel (A/B)
+UNIT_SEED = _lib.tune("MVK_UNIT_SEED", "1") != "0"  # 0: always launch the seed kernel (A/B)
 
 
 def is_unit_seed(g):

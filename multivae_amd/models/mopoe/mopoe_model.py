@@ -12,13 +12,13 @@ from typing import Union
 
 import torch
 
-from ... import kernels
+from ... import _lib, kernels
 from ..base import BaseMultiVAE
 from ..base.base_utils import ModelOutput
 from .mopoe_config import MoPoEConfig
 
 
-_EARLY_NOISE = os.environ.get("MVK_EARLY_NOISE", "1") != "0"  # 0: draw the noise behind the encoders (A/B)
+_EARLY_NOISE = _lib.tune("MVK_EARLY_NOISE", "1") != "0"  # 0: draw the noise behind the encoders (A/B)
 
 
 class MoPoE(BaseMultiVAE):

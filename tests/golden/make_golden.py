@@ -101,6 +101,37 @@ def cmp_grads(tag, gref, gor):
     assert worst < 5e-5, tag
 
 
+
+class lrelu_margin:
+    """Records, for every LeakyReLU site evaluated inside the block (nn.LeakyReLU and F.leaky_relu both end in
+    torch.nn.functional.leaky_relu), the smallest |pre-activation| relative to the site's largest one, and the number of
+    units within 1e-6 of zero.  A unit below the fp32 noise of the forward pass (~1e-8 ... 1e-7 of the largest entry) takes
+    the other slope under any change of summation order: the network-level goldens are generated from seeds that keep every
+    unit above `MARGIN`; the assembled cases have 1e7 ... 2e8 units and no such seed exists."""
+
+    MARGIN = 3e-7
+
+    def __enter__(self):
+        import torch.nn.functional as F
+
+        self.F, self.orig, self.rel_min, self.units, self.near = F, F.leaky_relu, 1.0, 0, 0
+
+        def rec(x, *a, **k):
+            ax = x.detach().abs()
+            self.rel_min = min(self.rel_min, float(ax.min() / ax.max()))
+            self.units += ax.numel()
+            self.near += int((ax < 1e-6).sum())
+            return self.orig(x, *a, **k)
+
+        F.leaky_relu = rec
+        return self
+
+    def __exit__(self, *exc):
+        self.F.leaky_relu = self.orig
+        print(f"  LeakyReLU units {self.units}, within 1e-6 of zero: {self.near}, smallest |pre| / max |pre| = {self.rel_min:.3e}")
+        return False
+
+
 # ---------------------------------------------------------------------------------------------------
 TINY_DIMS = dict(mod1=(2,), mod2=(3,), mod3=(4,), mod4=(4,))  # tests/test_mopoe.py:23-43 shapes
 TINY_L = 5
@@ -613,11 +644,13 @@ def resnet_mmnist_case(name, *, B, K, private_dim, shared_dim, seed):
     z = t(P.uniform((K, B, L), seed + 3, -1.0, 1.0)).requires_grad_(True)
     pe = [t(P.uniform((B, d), seed + 10 + i, -1.0, 1.0)) for i, d in enumerate((shared_dim, shared_dim, private_dim, private_dim))]
     pd = t(P.uniform((K, B, 3, 28, 28), seed + 20, -1.0, 1.0))
-    eo = enc(x)
+    with lrelu_margin() as lm:
+        eo = enc(x)
+        rec = dec(z).reconstruction
+    assert lm.rel_min >= lm.MARGIN, "pick a seed that keeps every LeakyReLU unit away from zero (tools: seed search)"
     outs = [eo.embedding, eo.log_covariance, eo.style_embedding, eo.style_log_covariance]
     le = sum((o * p).sum() for o, p in zip(outs, pe))
     le.backward()
-    rec = dec(z).reconstruction
     ld = (rec * pd).sum()
     ld.backward()
     oe, od = oracle_sd(esd), oracle_sd(dsd)
@@ -637,7 +670,8 @@ def resnet_mmnist_case(name, *, B, K, private_dim, shared_dim, seed):
                   dz=z.grad.detach())
     arrays.update(grad_stats({"enc." + k: p.grad for k, p in enc.named_parameters()}))
     arrays.update(grad_stats({"dec." + k: p.grad for k, p in dec.named_parameters()}))
-    save(name, dict(model="ResnetMMNIST", B=B, K=K, private_dim=private_dim, shared_dim=shared_dim, seed=seed), arrays)
+    save(name, dict(model="ResnetMMNIST", B=B, K=K, private_dim=private_dim, shared_dim=shared_dim, seed=seed,
+                    lrelu_rel_margin=lm.rel_min, lrelu_units=lm.units), arrays)
 
 
 def resnet_cub_case(name, *, B, L, seed):
@@ -654,10 +688,12 @@ def resnet_cub_case(name, *, B, L, seed):
     z = t(P.uniform((B, L), seed + 3, -1.0, 1.0)).requires_grad_(True)
     pe = [t(P.uniform((B, L), seed + 10 + i, -1.0, 1.0)) for i in range(2)]
     pd = t(P.uniform((B, 3, 64, 64), seed + 20, -1.0, 1.0))
-    eo = enc(x)
+    with lrelu_margin() as lm:
+        eo = enc(x)
+        rec = dec(z).reconstruction
+    assert lm.rel_min >= lm.MARGIN, "pick a seed that keeps every LeakyReLU unit away from zero (tools: seed search)"
     outs = [eo.embedding, eo.log_covariance]
     sum((o * p).sum() for o, p in zip(outs, pe)).backward()
-    rec = dec(z).reconstruction
     (rec * pd).sum().backward()
     oe, od = oracle_sd(esd), oracle_sd(dsd)
     oo = nets.cub_resnet_encoder(oe, "", x)
@@ -674,7 +710,7 @@ def resnet_cub_case(name, *, B, L, seed):
                   recon_sample=rec.detach().reshape(-1)[P.hash_indices(rec.numel(), 512, 78)], dz=z.grad.detach())
     arrays.update(grad_stats({"enc." + k: p.grad for k, p in enc.named_parameters()}))
     arrays.update(grad_stats({"dec." + k: p.grad for k, p in dec.named_parameters()}))
-    save(name, dict(model="ResnetCUB", B=B, L=L, seed=seed), arrays)
+    save(name, dict(model="ResnetCUB", B=B, L=L, seed=seed, lrelu_rel_margin=lm.rel_min, lrelu_units=lm.units), arrays)
 
 
 def mmvaeplus_resnet_case(name, *, M, B, K, S, L, loss, beta, scale, seed):
@@ -811,8 +847,9 @@ def assembled_main():
 
 
 def resnet_main():
-    resnet_mmnist_case("resnet_mmnist_nets", B=3, K=2, private_dim=4, shared_dim=6, seed=601)
-    resnet_cub_case("resnet_cub_nets", B=2, L=12, seed=602)
+    # seeds: the best of 60 / 40 tried by tools/golden_seed_search.py (largest LeakyReLU margin)
+    resnet_mmnist_case("resnet_mmnist_nets", B=3, K=2, private_dim=4, shared_dim=6, seed=625)
+    resnet_cub_case("resnet_cub_nets", B=2, L=12, seed=618)
 
 
 def jmvae_main():

@@ -120,3 +120,27 @@ def check_grads(arrays, named_grads, rtol=2e-4, atol_frac=2e-5):
         assert (err <= tol).all(), (name, float(err.max()), float(tol.min()))
         worst = max(worst, float((err / (np.abs(arrays["gval/" + name]) + scale)).max()))
     return worst
+
+
+def check_flip_aware(ref, got, what, rtol=1e-4, outlier_frac=5e-3, outlier_floor=9, worst=2e-2, median=1e-5):
+    """Gradient of a LeakyReLU ResNet stack against the fp32 oracle / the reference golden.
+
+    In fp32 a unit whose pre-activation is ~1e-8 takes the other slope as soon as ANY kernel upstream sums in another
+    order; the reference networks have ~10 units per million below 1e-6 (tests/golden/make_golden.py prints the count), so
+    at the assembled sizes (1e7 ... 2e8 units) no choice of inputs avoids them.  A flipped unit changes the 9 Cin entries
+    of the weight gradient it feeds and the patch of the gradient map around it; everything else moves at the 1e-7 level.
+    The check is therefore a statement about the DISTRIBUTION of the elementwise error relative to the tensor's largest
+    entry: all but `outlier_frac` of the entries (at least `outlier_floor`) within `rtol`, the median within `median`, the
+    worst entry within `worst`.  A real error of the gradient arithmetic at the 1e-4 ... 1e-2 level moves most entries
+    and fails the first two bounds (the previous test bounded only the worst entry at 1e-2 and a median at 5e-4)."""
+    r = torch.as_tensor(np.asarray(ref)).double().reshape(-1)
+    g_ = got.detach().double().cpu().reshape(-1)
+    assert r.numel() == g_.numel(), what
+    scale = float(r.abs().max().clamp_min(1e-30))
+    err = (g_ - r).abs() / scale
+    n_out = int((err > rtol).sum())
+    allowed = max(outlier_floor, int(outlier_frac * err.numel()))
+    assert n_out <= allowed, f"{what}: {n_out} of {err.numel()} entries off by > {rtol} of max (allowed {allowed}); worst {float(err.max()):.3e}"
+    assert float(err.median()) <= median, f"{what}: median err {float(err.median()):.3e} of max"
+    assert float(err.max()) <= worst, f"{what}: worst err {float(err.max()):.3e} of max"
+    return n_out

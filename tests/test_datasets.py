@@ -94,6 +94,25 @@ def test_mnist_svhn_pairing_and_items(tmp_path):
         MnistSvhn(root, split="valid")
 
 
+def test_mnist_svhn_pairing_matches_reference_fixture():
+    """`rand_match_on_idx` against index vectors produced by the REFERENCE's own function under the same torch seed
+    (tests/golden/make_pairing_golden.py; mnist_svhn.py:100-115): same pairs in the same order."""
+    import json
+    import types
+
+    import golden_cases as G
+    from multivae_amd.data.datasets import MnistSvhn
+
+    z = np.load(os.path.join(G.GOLDEN, "pairing_mnist_svhn.npz"))
+    for c in json.loads(bytes(z["cfg_json"]).decode()):
+        lab = lambda n, seed: torch.from_numpy((G.P.hash_uniform(n, seed) * 10).astype(np.int64) % 10)
+        l1, i1 = lab(c["n1"], c["seed"]).sort()
+        l2, i2 = lab(c["n2"], c["seed"] + 100).sort()
+        torch.manual_seed(c["seed"])
+        r1, r2 = MnistSvhn.rand_match_on_idx(types.SimpleNamespace(data_mul=c["data_mul"]), l1, i1, l2, i2, max_d=c["max_d"])
+        assert np.array_equal(r1.numpy(), z[c["name"] + "/idx1"]) and np.array_equal(r2.numpy(), z[c["name"] + "/idx2"]), c
+
+
 @pytest.mark.gpu
 def test_trainer_on_the_example_datasets(tmp_path):
     """One epoch of BaseTrainer on both loaders through the device-resident batch iterator: MMVAE+ on PolyMNIST-shaped data

@@ -20,7 +20,7 @@ def rel(a, b):
     return float((a - b).abs().max() / a.abs().max().clamp_min(1e-30))
 
 
-ELEMENTWISE = re.compile(r"^(z\b|zs|z |kld|kl\b|joint|mus|logvars|mu\b|lv\b|lw\b|u |w |us|ws|lws|rows)")
+ELEMENTWISE = re.compile(r"^(subset |selected )?(z\b|zs|z |kld|kl\b|joint|mus|logvars|mu\b|lv\b|lw\b|u |w |us|ws|lws|rows)")
 
 
 def check(a, b, what, rtol=RTOL):
@@ -360,22 +360,6 @@ def test_mmvaeplus_encode_paths():
         MMVAEPlus(MMVAEPlusConfig(n_modalities=3, latent_dim=6, input_dims=dims))  # modalities_specific_dim missing
 
 
-def check_flip_tolerant(ref, got, what, rtol_max=2e-2, rtol_median=2e-3):
-    """Gradients of a LeakyReLU stack in fp32: a unit with a ~1e-8 pre-activation takes the other slope when ANY kernel
-    upstream sums in another order, which moves the gradients around it by up to ~1e-2 of the tensor's largest entry while
-    most entries move far less (test_assembled_configs.MASK_FLIP_RTOL: measured, incl. the fp32 oracle
-    against its own float64 run; with MVK_SMALLK=0, i.e. the previous kernel for the first Linear layer, this very test
-    passes at 1e-4).  Bias gradients are cancelling sums over all positions: one unit is ~1e-3 of their largest entry
-    (measured on resnet.2.conv_layers.0.bias).  The flipped unit itself shows in the weight gradient of the layer it feeds: resnet.2.conv_layers.2.weight has
-    typical entries at 1e-7 and one 3x3 patch at 1.2e-2.  Hence: median error <= 2e-3 of the largest entry, worst <= 2e-2."""
-    r = torch.as_tensor(np.asarray(ref)).double().reshape(-1)
-    g_ = got.detach().double().cpu().reshape(-1)
-    scale = float(r.abs().max().clamp_min(1e-30))
-    err = (g_ - r).abs() / scale
-    assert float(err.median()) <= rtol_median, f"{what}: median err {float(err.median()):.3e} of max"
-    assert float(err.max()) <= rtol_max, f"{what}: worst err {float(err.max()):.3e} of max"
-
-
 def test_resnet_mmnist_nets_golden():
     """EncoderResnetMMNIST / DecoderResnetMMNIST on the HIP kernels (3x3 convolutions, pooling, upsampling, residuals,
     one autograd node per stack) vs the reference golden and the oracle's full gradients."""
@@ -400,10 +384,12 @@ def test_resnet_mmnist_nets_golden():
     assert rec.shape == (cfg["K"], cfg["B"], 3, 28, 28)
     check(a["recon_sample"], rec.reshape(-1)[torch.as_tensor(G.P.hash_indices(rec.numel(), 512, 77), device=d)], "recon")
     (rec * pdec.to(d)).sum().backward()
-    # the gradient w.r.t. the latent passes every LeakyReLU of the stack: one unit whose pre-activation is ~1e-8 takes the
-    # other branch when a kernel sums in another order (fp32 on any device, cf. test_assembled_configs.MASK_FLIP_RTOL);
-    # measured 1.2e-4 of the largest entry between two exact-fp32 kernels for the first Linear layer
-    check(a["dz"], zz.grad, "grad dz", rtol=3e-4)  # 16 entries, all downstream of every unit: 1.2e-4 measured
+    # The golden's seed was picked for its LeakyReLU margin (tests/golden/make_golden.py `lrelu_margin`: no unit of the
+    # reference's forward pass within 3e-7 of its site's largest pre-activation, cfg["lrelu_rel_margin"]), so no unit takes the
+    # other slope under a different summation order and every gradient is checked entry by entry at 1e-4 (round 2 needed a
+    # flip-tolerant 2e-2 bound on the decoder here).
+    assert cfg["lrelu_rel_margin"] >= 3e-7
+    check(a["dz"], zz.grad, "grad dz")
     # full gradients vs the oracle
     oe = {k: G.t(v).clone().requires_grad_(True) for k, v in esd.items()}
     od = {k: G.t(v).clone().requires_grad_(True) for k, v in dsd.items()}
@@ -414,9 +400,8 @@ def test_resnet_mmnist_nets_golden():
     for k, v in list(oe.items()) + []:
         check(v.grad.numpy(), mg["enc." + k], "grad enc." + k)
     for k, v in od.items():
-        check_flip_tolerant(v.grad.numpy(), mg["dec." + k], "grad dec." + k)
-    G.check_grads(a, {k: v for k, v in mg.items() if k.startswith("enc.")}, rtol=5 * RTOL, atol_frac=RTOL)
-    G.check_grads(a, {k: v for k, v in mg.items() if k.startswith("dec.")}, rtol=1e-2, atol_frac=5e-2)  # flip-tolerant
+        check(v.grad.numpy(), mg["dec." + k], "grad dec." + k)
+    G.check_grads(a, mg, rtol=5 * RTOL, atol_frac=RTOL)
     assert dec(zz[0].detach()).reconstruction.shape == (cfg["B"], 3, 28, 28)  # 2-D latent input
 
 
@@ -428,6 +413,7 @@ def test_resnet_cub_nets_golden():
     from multivae_amd.models.nn.cub import CUB_Resnet_Decoder, CUB_Resnet_Encoder
 
     cfg, a, esd, dsd, x, z, pe, pdec = resnet_cub_case()
+    assert cfg["lrelu_rel_margin"] >= 3e-7  # seed picked for its LeakyReLU margin: entry-by-entry 1e-4 below
     d = torch.device("cuda:0")
     enc, dec = CUB_Resnet_Encoder(cfg["L"]), CUB_Resnet_Decoder(cfg["L"])
     enc.load_state_dict({k: G.t(v) for k, v in esd.items()})

@@ -826,6 +826,16 @@ def test_device_rng(K):
         g_.replay()
         torch.cuda.synchronize()
         assert torch.equal(z, ref[i]), f"replay {i}"
+    # a re-seed after the capture re-seeds the SAME state tensor in place: the existing graph keeps a valid
+    # pointer and picks the new seed up at its next replay
+    state_ptr = K._rng_state(d).data_ptr()
+    torch.manual_seed(7)
+    again = K.device_randn((5, 512, 20), d)  # eager draw: notices the re-seed
+    assert K._rng_state(d).data_ptr() == state_ptr
+    assert torch.equal(again, ref[0])
+    g_.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(z, ref[1]), "replay after an in-place re-seed"
 
 
 @pytest.mark.parametrize("n,H,W,C", [(3, 28, 28, 64), (2, 7, 7, 20), (4, 14, 14, 128), (2, 5, 9, 3)])

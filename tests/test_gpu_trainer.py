@@ -522,3 +522,110 @@ def test_rccl_path_on_one_gpu_matches_the_plain_step(tmp_path):
         outs.append(json.loads(line))
     assert outs[0]["config"]["final_loss"] == pytest.approx(outs[1]["config"]["final_loss"], rel=1e-6)
     assert outs[1]["n_gpus"] == 1
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# The REAL distributed step with world_size 2: two processes on cuda:0, gloo all-reducing the CUDA
+# gradient buffer, BaseTrainer with FusedAdam + hipGraph replay (thread-local capture) on MoPoE MnistSvhn.
+# Reference semantics: base_trainer.py:92-117 (DDP average), :198-211 (DistributedSampler without set_epoch), :748 (epoch loss
+# over the full dataset length); MoPoE's row-range subset selection is per local shard (mopoe_model.py:444-455).
+# ------------------------------------------------------------------------------------------------------------------------
+_DP = dict(n=256, bs=32, epochs=2, K=2, L=8, lr=1e-3, seed=11)
+
+
+def _dp_dataset():
+    from multivae_amd.data.datasets.base import MultimodalBaseDataset
+
+    n = _DP["n"]
+    return MultimodalBaseDataset(data=dict(mnist=G.t(G.P.uniform((n, 1, 28, 28), 9001)), svhn=G.t(G.P.uniform((n, 3, 32, 32), 9002))))
+
+
+def _dp_worker(rank, world, port, ret, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from multivae_amd.trainers import BaseTrainer, BaseTrainerConfig, FusedAdam
+    from multivae_amd.trainers.flat import FlatParams
+
+    d = torch.device("cuda:0")
+    model = _mnist_svhn_mopoe(d, K=_DP["K"], L=_DP["L"], seed=100 + rank)  # different weights per rank: rank 0's are broadcast
+    calls = []
+    orig = FlatParams.all_reduce
+    FlatParams.all_reduce = lambda self, group=None: (calls.append(1), orig(self, group))[1]
+    cfg = BaseTrainerConfig(output_dir=outdir, per_device_train_batch_size=_DP["bs"], num_epochs=_DP["epochs"],
+                            learning_rate=_DP["lr"], optimizer_cls="Adam", use_fused_adam=True, use_hip_graph=True,
+                            dist_backend="gloo", world_size=world, rank=rank, local_rank=0, seed=_DP["seed"], steps_saving=None)
+    tr = BaseTrainer(model, _dp_dataset(), training_config=cfg)
+    hist = tr.train()
+    torch.cuda.synchronize()
+    assert isinstance(tr.optimizer, FusedAdam)
+    graphs = [g for g in tr.__dict__.get("_graphs", {}).values() if g is not None]
+    ret[rank] = dict(params=tr.flat.dense(tr.flat.flat).cpu(), loss=[h["train_epoch_loss"] for h in hist], allreduce=len(calls),
+                     steps=tr.optimizer.step_count, graphs=len(graphs))
+
+
+@pytest.mark.timeout(900)
+def test_distributed_step_two_ranks_on_one_gpu(tmp_path):
+    """world_size 2 on ONE GPU: GraphedStep (thread-local capture) -> flat.all_reduce() (gloo on the CUDA buffer) ->
+    FusedAdam.step(grad_scale = 1 / W).  The ranks end bit-identical; they equal a single-process replay in which every step's
+    gradient is the mean over the ranks of the per-shard gradients (each shard through MoPoE on its own, i.e. with its
+    own row-range subset selection) — the noise of step t is draw number `warmup + t` of the device generator after
+    `set_seed` (the eager warm-up passes of the capture consume the first ones), identical on both ranks as under the
+    reference's DDP (every rank seeds alike); the epoch loss is the local sum over the FULL dataset length; flat.grad is
+    all-reduced exactly once per step."""
+    import inspect
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from multivae_amd import kernels
+    from multivae_amd.data.datasets.base import DatasetOutput
+    from multivae_amd.trainers import FlatParams, FusedAdam
+    from multivae_amd.trainers.base import shard_indices
+    from multivae_amd.trainers.base.base_trainer import set_seed
+    from multivae_amd.trainers.graph import GraphedStep
+
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp_worker, args=(world, port, ret, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = ret[0], ret[1]
+    n, bs, epochs, K, L = _DP["n"], _DP["bs"], _DP["epochs"], _DP["K"], _DP["L"]
+    steps = epochs * (n // world // bs)
+    assert r0["steps"] == r1["steps"] == steps
+    assert r0["allreduce"] == r1["allreduce"] == steps, "ONE all-reduce of the flat gradient buffer per step"
+    assert r0["graphs"] == r1["graphs"] == 1, "the steps ran through the captured hipGraph"
+    assert torch.equal(r0["params"], r1["params"]), "ranks diverged"
+
+    # single-process replay on this GPU
+    d = torch.device("cuda:0")
+    model = _mnist_svhn_mopoe(d, K=K, L=L, seed=100)
+    flat = FlatParams(model)
+    opt = FusedAdam(flat, lr=_DP["lr"], zero_grad_in_step=True)
+    ds = _dp_dataset()
+    data = {m: v.to(d) for m, v in ds.data.items()}
+    set_seed(_DP["seed"])
+    warm = inspect.signature(GraphedStep.__init__).parameters["warmup"].default
+    for _ in range(warm):
+        kernels.device_randn((K, bs, L), d)
+    losses = {r: [] for r in range(world)}
+    for epoch in range(epochs):
+        idx = [shard_indices(n, world, r).to(d) for r in range(world)]  # no set_epoch: the same permutation every epoch
+        ep = {r: 0.0 for r in range(world)}
+        for b in range(n // world // bs):
+            eps = kernels.device_randn((K, bs, L), d)
+            flat.zero_grad()
+            for r in range(world):
+                sel = idx[r][b * bs:(b + 1) * bs]
+                out = model(DatasetOutput(data={m: v.index_select(0, sel) for m, v in data.items()}), noise=eps)
+                out.loss.backward()  # accumulates into the flat buffer: sum over the ranks
+                ep[r] += float(out.loss_sum)
+            opt.step(grad_scale=1.0 / world)
+        for r in range(world):
+            losses[r].append(ep[r] / n)
+    ref = flat.dense(flat.flat).cpu()
+    err = float((r0["params"] - ref).abs().max())
+    assert err <= 2e-6, f"distributed parameters differ from the replay by {err:.3e} after {steps} Adam steps of {_DP['lr']}"
+    for r, got in ((0, r0["loss"]), (1, r1["loss"])):
+        assert got == pytest.approx(losses[r], rel=1e-5), (r, got, losses[r])

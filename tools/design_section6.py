@@ -39,7 +39,7 @@ t = f"""| configuration (`bench.py --config`) | samples/s, 1 GPU | ms/step | GEM
 k = f"""| headline step, per kernel class (`profiles/r02_kernel_stats.md`, `r02_step_timeline.txt`) | |
 |---|---|
 | fused reconstruction-NLL kernel | **{r3['avg_launch_us']:.1f} µs → {f(r3['achieved'])} GB/s algorithmic = {r3['frac']:.2f} of the 8 TB/s HBM peak** (bench line, device timestamps; {r3['frac_minus_kernel_boundary']:.2f} after one kernel boundary; rocprofv3 average of the same command: {nll_roc:.1f} µs); traffic 166.9 MB vs 165.8 MB algorithmic (ratio 1.006) |
-| six register-stationary convolution launches (21.47 GFLOP each) | {m3['us_per_step']:.0f} µs per step → **{m3['achieved']:.0f} TFLOP/s = {m3['frac_split_bf16']:.2f} of 416.7** ({m3['frac']:.2f} x the fp32-input MFMA rate); alone: 98-113 µs each, matrix pipe 61-77 % busy at 1.63-1.77 GHz (`r02_pmc_mfma.md`) |
+| six register-stationary convolution launches (21.47 GFLOP each) | {m3['us_per_step']:.0f} µs per step → **{m3['achieved']:.0f} TFLOP/s = {m3['frac']:.2f} of 416.7** ({m3['frac_vs_fp32_input_mfma']:.2f} x the fp32-input MFMA rate); alone: 98-113 µs each, matrix pipe 61-77 % busy at 1.63-1.77 GHz (`r02_pmc_mfma.md`) |
 | image-layer kernels | fwd {im['image_layer_fwd']['avg_launch_us']:.0f} µs ({im['image_layer_fwd']['frac']:.2f} of HBM), bwd {im['image_layer_bwd']['avg_launch_us']:.0f} µs ({im['image_layer_bwd']['frac']:.2f}) |
 | dispatches per step | {disp} (2 batch copies in front of the graph; the noise comes from the device-resident generator inside it) — 103 at the start of the round, 94 in round 1; helper launches (`splitk_reduce*`, `colsum*`, `act_bwd_colsum`) {100 * helpk / tot:.0f} % of kernel time (17 % in round 1) |
 | MVK_FORCE_DIST=1 (RCCL all-reduce of the 6.2 MB flat buffer on one GPU) | {L['force_dist']['ms_per_step']:.3f} ms/step (+{100 * (L['force_dist']['ms_per_step'] / c3['ms_per_step'] - 1):.1f} %) |
