@@ -1,0 +1,492 @@
+// Register-stationary-weight kernels for the 3x3 / stride-1 / pad-1 convolutions of the ResNet blocks
+// (reference: models/nn/mmnist.py:214-252 ResnetBlock, models/nn/cub.py:250-293 ResnetBlock; the layers of
+// EncoderResnetMMNIST / DecoderResnetMMNIST / CUB_Resnet_Encoder / CUB_Resnet_Decoder with 64 or 128 input channels).
+//
+// Same data flow as imgconv.hip, re-derived for a 3x3 window on maps of ANY size:
+//
+//   * one workgroup per CU, 4 waves, one wave per SIMD, up to 512 registers per lane; every wave keeps an
+//     [18 k-steps x 16 k][32 n] slice of the layer's GEMM weight W[(tap, ci)][co] as three bf16 pieces in 216 registers of
+//     the accumulator half (AGPRs) for the whole launch: 64 input channels -> 2 waves share a 32-column tile (9 taps x 4
+//     channel chunks = 36 k-steps), 128 input channels -> 4 waves; wider outputs take more workgroup types;
+//   * THE IMAGES ARE ONE STREAM OF POSITIONS.  Every image is laid out with one zero column on the right of each row and
+//     one zero row below it: position p = (img (H+1) + y) (W+1) + x.  The zero column is the right halo of its row AND the
+//     left halo of the next one, the zero row the bottom halo of its image AND the top halo of the next — so tap (dy, dx) of
+//     output position p is input position p + dy (W+1) + dx for every p, with no validity test, and a 32-row GEMM tile is
+//     32 consecutive positions whatever W is (the outputs computed at the zero positions, 1.5 % of a 64x64 map, 23 % of a
+//     7x7 one, are dropped).  A workgroup walks its share of the stream once: the positions live in an LDS ring
+//     (slot = p mod RING, one slot = the three bf16 piece rows of all channels + 16 bytes of padding: conflict-free
+//     ds_read_b128 fragments), chunk T+D+1 is converted while tile T is multiplied;
+//   * a table of 32 pixel indices per chunk (or -1 for the zero positions), computed incrementally by 32 lanes and
+//     published through LDS, drives the staging loads, the mask / residual loads and the stores, so nothing in the main
+//     loop divides or branches per element;
+//   * the main loop is the two-tile-latency pipeline of imgconv_kernel: tile T carries the accumulator sum + exchange of
+//     tile T-1, the epilogue of tile T-2, the conversion of chunk T+D+1 and ONE barrier; the epilogue fuses bias,
+//     LeakyReLU / ReLU, the activation derivative of the layer the result lands in, the residual sum of the block
+//     (res + alpha * result) and the bias-gradient column sums.
+#include <cstdlib>
+#include <type_traits>
+
+#include "bf3.hpp"
+
+#ifndef MVK_C3_SCHED
+#define MVK_C3_SCHED 4  // "others" per MFMA of the scheduling pipeline (0 = hipcc's own order)
+#endif
+
+namespace mvk {
+
+struct C3Args {
+  const float* X;        // input [n][H][W][CIN] (NHWC)
+  const float* Wp;       // fp32 GEMM pack W[(tap * CIN + ci)][COUT] (mvk_pack_weights kind c3)
+  const float* bias;     // [COUT] or null
+  float* Y;              // output [n][H][W][COUT]
+  const float* act_src;  // tensor of the output's shape whose activation derivative multiplies the result, or null
+  const float* res;      // residual of the output's shape: Y = res + res_alpha * result, or null
+  float* colsum_part;    // [workers][COUT] per-workgroup column sums of the result (before the residual), or null
+  float* trash;          // >= 64 floats: where the stores of dropped rows go (no branch in the epilogue)
+  int n, H, W;
+  float aslope, mslope;  // negative-side slopes of the output activation (1 = none) and of the mask (src_act)
+  float res_alpha;
+  int ring;              // LDS ring length in positions (multiple of 32, >= 32 (2 D + 2))
+  int D;                 // reach of the window in 32-position chunks: ceil((W + 2) / 32)
+  int tiles;             // ceil(n (H+1) (W+1) / 32)
+  mvk_prof_slot* prof;
+};
+
+template <int CIN, int COUT>
+struct C3Cfg {
+  static constexpr int CHUNKS = CIN / 16;            // 16-channel k-steps per tap
+  static constexpr int KALL = 9 * CHUNKS;            // k-steps of one output element
+  static constexpr int KPW = 18;                     // k-steps per wave = 216 weight registers
+  static constexpr int KSPLIT = KALL / KPW;          // waves sharing one 32-column tile: 2 (64 channels), 4 (128)
+  static constexpr int NCT = COUT / 32;
+  static constexpr int ROLES = NCT * KSPLIT;
+  static constexpr int WG_TYPES = ROLES / 4;
+  static constexpr int S = 6 * CIN + 16;             // bytes per ring slot: 3 pieces x CIN bf16 + pad ((S / 16) odd)
+  static constexpr int NF4 = CIN / 32;               // float4 staging units per thread and chunk
+  static constexpr int OWN = 16 / KSPLIT;            // accumulator registers (output rows per lane) a wave finishes
+  static constexpr int XWAVE = (KSPLIT - 1) * OWN * 64 * 4;
+  static constexpr int XBUF = 4 * XWAVE;
+  static constexpr int PTAB_INTS = 16 * 32;
+  static_assert(KALL % KPW == 0 && ROLES % 4 == 0 && 4 % KSPLIT == 0, "roles");
+  static_assert((S / 16) % 2 == 1, "odd 16-byte stride: conflict-free fragments");
+  __host__ __device__ static constexpr int lds_bytes(int ring) { return ring * S + 2 * XBUF + PTAB_INTS * 4 + 4 * 32 * 4; }
+};
+
+__device__ __forceinline__ bf16x8 c3_pack8(const unsigned (&d)[4]) {
+  u32x4 v = {d[0], d[1], d[2], d[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int CIN, int COUT, bool HAS_SRC, bool HAS_RES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void c3rs_kernel(const C3Args g) {
+  using T = C3Cfg<CIN, COUT>;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  mvk_prof_begin(g.prof);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, kg = lane >> 5;
+  const int wgtype = blockIdx.x % T::WG_TYPES;
+  const int worker = blockIdx.x / T::WG_TYPES, workers = gridDim.x / T::WG_TYPES;
+  const int role = wgtype * 4 + wave;
+  const int ct = role / T::KSPLIT, ks = role % T::KSPLIT;
+  const int ncol = ct * 32 + col;
+
+  // ---- weights: 18 k-steps x 3 pieces, resident for the whole launch ------------------------------------------------------
+  bf16x8 Bw[T::KPW][3];
+#pragma unroll
+  for (int i = 0; i < T::KPW; ++i) {
+    const int gk = ks * T::KPW + i;
+    const long long rowbase = (long long)(gk / T::CHUNKS) * CIN + (gk % T::CHUNKS) * 16 + kg * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = g.Wp[(rowbase + e) * COUT + ncol];
+    unsigned p[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bf3_split(v[2 * e], v[2 * e + 1], p[0][e], p[1][e], p[2][e]);
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) Bw[i][pc] = c3_pack8(p[pc]);
+  }
+  // AGPR citizens (see imgconv_kernel): MFMA reads its B operand from a[...] directly, no v_accvgpr_read per use
+#pragma unroll
+  for (int i = 0; i < T::KPW; ++i)
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+      bf16x8 t = Bw[i][pc];
+      asm volatile("" : "=a"(Bw[i][pc]) : "0"(t));
+    }
+
+  // ---- LDS ---------------------------------------------------------------------------------------------------------------
+  const int RING = g.ring, NCH = RING / 32;
+  char* const ringp = lds;
+  char* const xbase = lds + RING * T::S;
+  int* const ptab = reinterpret_cast<int*>(xbase + 2 * T::XBUF);
+  float* const csred = reinterpret_cast<float*>(ptab + T::PTAB_INTS);
+
+  const int H = g.H, W = g.W, W1 = W + 1, H1 = H + 1, PB = W1 * H1;
+  const int dx32 = 32 % W1, dv32 = 32 / W1;
+  const int D = g.D;
+  const int T0 = (int)((long long)g.tiles * worker / workers), T1 = (int)((long long)g.tiles * (worker + 1) / workers);
+  const int NT = T1 - T0;
+
+  // pixel-index table: entry [c & 15][l] = pixel index of position 32 c + l, or -1 (zero column / zero row / outside)
+  int pimg, pv, px;
+  {
+    const int p0 = 32 * (T0 - D) + col + PB;  // >= 0: PB >= 32 D for every supported shape (checked by the launcher)
+    pimg = p0 / PB - 1;
+    const int rem = p0 % PB;
+    pv = rem / W1;
+    px = rem % W1;
+  }
+  int cnext = T0 - D;
+  auto ptab_store = [&]() {
+    const bool ok = pimg >= 0 && pimg < g.n && pv < H && px < W;
+    const int val = ok ? (pimg * H + pv) * W + px : -1;
+    if (wave == 0 && kg == 0) ptab[(cnext & 15) * 32 + col] = val;
+    ++cnext;
+    px += dx32;
+    pv += dv32;
+    if (px >= W1) {
+      px -= W1;
+      pv += 1;
+    }
+    if (pv >= H1) {
+      pv -= H1;
+      pimg += 1;
+    }
+  };
+
+  // staging: float4 unit f = tid + k * 256 of a chunk's [32 positions][CIN] block
+  int soff[T::NF4], spos[T::NF4], sc4[T::NF4];
+#pragma unroll
+  for (int k = 0; k < T::NF4; ++k) {
+    const int f = tid + k * 256;
+    spos[k] = f / (CIN / 4);
+    sc4[k] = (f % (CIN / 4)) * 4;
+    soff[k] = spos[k] * T::S + (f % (CIN / 4)) * 8;
+  }
+  f32x4 raw[T::NF4];
+  auto load_unit = [&](int c, int k) {
+    const int pix = ptab[(c & 15) * 32 + spos[k]];
+    const f32x4 v = *reinterpret_cast<const f32x4*>(g.X + (long long)(pix < 0 ? 0 : pix) * CIN + sc4[k]);
+    raw[k] = pix < 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
+  };
+  auto write_unit = [&](int wbase, int k) {  // wbase = byte offset of the chunk's first slot
+    unsigned a0, a1, a2, b0, b1, b2;
+    bf3_split(raw[k][0], raw[k][1], a0, a1, a2);
+    bf3_split(raw[k][2], raw[k][3], b0, b1, b2);
+    char* d = ringp + wbase + soff[k];
+    *reinterpret_cast<u32x2*>(d) = u32x2{a0, b0};
+    *reinterpret_cast<u32x2*>(d + 2 * CIN) = u32x2{a1, b1};
+    *reinterpret_cast<u32x2*>(d + 4 * CIN) = u32x2{a2, b2};
+  };
+  auto chunk_slot = [&](int c) { return (((c % NCH) + NCH) % NCH) * 32 * T::S; };
+
+  // ---- prologue: table entries T0-D .. T0+D+2, chunks T0-D .. T0+D in the ring, chunk T0+D+1 in registers ---------------
+  if (NT > 0) {
+    for (int c = T0 - D; c <= T0 + D + 2; ++c) ptab_store();
+  }
+  __syncthreads();
+  if (NT > 0) {
+    for (int c = T0 - D; c <= T0 + D; ++c) {
+      const int wb = chunk_slot(c);
+#pragma unroll
+      for (int k = 0; k < T::NF4; ++k) load_unit(c, k);
+#pragma unroll
+      for (int k = 0; k < T::NF4; ++k) write_unit(wb, k);
+    }
+#pragma unroll
+    for (int k = 0; k < T::NF4; ++k) load_unit(T0 + D + 1, k);
+  }
+  __syncthreads();
+
+  const float bias = g.bias ? g.bias[ncol] : 0.f;
+  const float aslope = g.aslope, mslope = g.mslope, alpha = g.res_alpha;
+  float csum = 0.f;
+
+  // ---- main loop, instantiated per tap-split rank (every "is this my slice" test is a compile-time fact) ----------------
+  auto run = [&](auto ks_tag) {
+    constexpr int KSC = decltype(ks_tag)::value;
+    constexpr int TAP_LO = (KSC * T::KPW) / T::CHUNKS, TAP_HI = (KSC * T::KPW + T::KPW - 1) / T::CHUNKS;
+    constexpr int NTAPW = TAP_HI - TAP_LO + 1;
+    int delta[NTAPW];
+#pragma unroll
+    for (int j = 0; j < NTAPW; ++j) {
+      const int tap = TAP_LO + j;
+      delta[j] = (tap / 3 - 1) * W1 + (tap % 3 - 1) + RING;
+    }
+    auto frag_base = [&](int (&ab)[NTAPW], int tb) {  // byte offsets of this lane's A rows of the tile whose first slot is tb
+#pragma unroll
+      for (int j = 0; j < NTAPW; ++j) {
+        unsigned s = (unsigned)(tb + col + delta[j]);
+        s = min(s, s - (unsigned)RING);
+        s = min(s, s - (unsigned)RING);
+        ab[j] = (int)s * T::S + kg * 16;
+      }
+    };
+    auto read_pair = [&](bf16x8 (&dst)[2][3], const int (&ab)[NTAPW], int pr) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int gk = KSC * T::KPW + 2 * pr + h;
+        const int j = gk / T::CHUNKS - TAP_LO, c = gk % T::CHUNKS;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+          dst[h][pc] = *reinterpret_cast<const bf16x8*>(ringp + ab[j] + pc * 2 * CIN + c * 32);
+      }
+    };
+    // rows of the 32 x 32 tile this lane finishes: accumulator registers [KSC * OWN, KSC * OWN + OWN)
+    int rrow[T::OWN];
+#pragma unroll
+    for (int o = 0; o < T::OWN; ++o) {
+      const int r = KSC * T::OWN + o;
+      rrow[o] = (r & 3) + 8 * (r >> 2) + 4 * kg;
+    }
+    const int wgrp = (wave / T::KSPLIT) * T::KSPLIT;  // first wave of this wave's column-tile group
+
+    f32x16 pend0 = {0}, pend1 = {0};
+    float own[T::OWN], res_next[T::OWN], res_prev[T::OWN], msk_prev[T::OWN], msk_cur[T::OWN], rr_prev[T::OWN], rr_cur[T::OWN];
+    int pix_prev[T::OWN], pix_cur[T::OWN];
+#pragma unroll
+    for (int o = 0; o < T::OWN; ++o) {
+      own[o] = res_next[o] = res_prev[o] = msk_prev[o] = msk_cur[o] = rr_prev[o] = rr_cur[o] = 0.f;
+      pix_prev[o] = pix_cur[o] = -1;
+    }
+    auto finish_pending = [&](char* xb) {
+      const f32x16 sum = pend0 + pend1;
+#pragma unroll
+      for (int r = 0; r < T::KSPLIT; ++r) {
+        if (r == KSC) continue;
+        const int slot = KSC < r ? KSC : KSC - 1;
+        float* dst = reinterpret_cast<float*>(xb + (wgrp + r) * T::XWAVE + slot * T::OWN * 256);
+#pragma unroll
+        for (int o = 0; o < T::OWN; ++o) dst[o * 64 + lane] = sum[r * T::OWN + o];
+      }
+#pragma unroll
+      for (int o = 0; o < T::OWN; ++o) own[o] = sum[KSC * T::OWN + o];
+    };
+    auto gather_result = [&](const char* xb) {  // ordered sum over the ranks: deterministic
+      const float* src = reinterpret_cast<const float*>(xb + wave * T::XWAVE);
+#pragma unroll
+      for (int o = 0; o < T::OWN; ++o) {
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < T::KSPLIT; ++r) {
+          if (r == KSC) {
+            v += own[o];
+          } else {
+            const int slot = r < KSC ? r : r - 1;
+            v += src[(slot * T::OWN + o) * 64 + lane];
+          }
+        }
+        res_next[o] = v;
+      }
+    };
+    auto fetch_row = [&](int tabrow, int o) {  // pixel index of row o of the tile whose table row is tabrow (+ mask / residual)
+      const int pix = ptab[tabrow * 32 + rrow[o]];
+      pix_cur[o] = pix;
+      const long long off = (long long)(pix < 0 ? 0 : pix) * COUT + ncol;
+      if (HAS_SRC) msk_cur[o] = g.act_src[off];
+      if (HAS_RES) rr_cur[o] = g.res[off];
+    };
+    auto epilogue_row = [&](int o, bool valid) {
+      float v = res_prev[o] + bias;
+      v = v > 0.f ? v : v * aslope;
+      if (HAS_SRC) v = msk_prev[o] > 0.f ? v : v * mslope;
+      const int pix = valid ? pix_prev[o] : -1;
+      csum += pix < 0 ? 0.f : v;
+      if (HAS_RES) v = fmaf(alpha, v, rr_prev[o]);
+      float* dst = pix < 0 ? g.trash + lane : g.Y + (long long)pix * COUT + ncol;
+      *dst = v;
+    };
+    auto rotate = [&]() {
+#pragma unroll
+      for (int o = 0; o < T::OWN; ++o) {
+        res_prev[o] = res_next[o];
+        msk_prev[o] = msk_cur[o];
+        rr_prev[o] = rr_cur[o];
+        pix_prev[o] = pix_cur[o];
+      }
+    };
+
+    int tb = (int)(((long long)32 * T0) % RING);       // first ring slot of tile T
+    int wch = (((T0 + D + 1) % NCH) + NCH) % NCH;       // ring chunk that chunk T+D+1 goes to
+    int xpar = 0;
+    int ab_cur[NTAPW], ab_nxt[NTAPW];
+    bf16x8 a_cur[2][3];
+    if (NT > 0) {
+      frag_base(ab_cur, tb);
+      read_pair(a_cur, ab_cur, 0);
+    }
+    for (int t = 0; t < NT; ++t) {
+      const int Tt = T0 + t;
+      const bool valid2 = t >= 2;
+      char* const xb = xbase + xpar * T::XBUF;
+      const int wbase = wch * 32 * T::S;
+      const int tabrow1 = (Tt - 1) & 15;
+      int tbn = tb + 32;
+      tbn = tbn >= RING ? tbn - RING : tbn;
+      f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+      for (int pr = 0; pr < 9; ++pr) {
+        bf16x8 a_nxt[2][3];
+        if (pr < 8) read_pair(a_nxt, ab_cur, pr + 1);
+        if (pr == 0) finish_pending(xb);
+        if (pr == 1) ptab_store();               // table row of chunk Tt + D + 3 (staging loads of the next tile)
+        if (pr == 2) frag_base(ab_nxt, tbn);
+        // conversion of chunk Tt+D+1 (loaded one tile ago) + the loads of chunk Tt+D+2: done before the barrier behind pair 7
+        if (pr < 7 && pr % (T::NF4 == 2 ? 3 : 2) == 0 && pr / (T::NF4 == 2 ? 3 : 2) < T::NF4) {
+          constexpr int STEP = T::NF4 == 2 ? 3 : 2;
+          write_unit(wbase, pr / STEP);
+          load_unit(Tt + D + 2, pr / STEP);
+        }
+#pragma unroll
+        for (int o = 0; o < T::OWN; ++o) {
+          if (o * 9 / T::OWN != pr) continue;
+          fetch_row(tabrow1, o);                  // tile Tt-1: consumed two tiles later
+          epilogue_row(o, valid2);                // tile Tt-2
+        }
+        constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB_[6] = {2, 1, 0, 1, 0, 0};  // small terms first
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][PA[m]], Bw[2 * pr][PB_[m]], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][PA[m]], Bw[2 * pr + 1][PB_[m]], acc1, 0, 0, 0);
+        }
+        if (pr == 8) {  // behind the barrier: first fragments of the next tile, result of tile Tt-1
+          read_pair(a_nxt, ab_nxt, 0);
+          gather_result(xb);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) a_cur[h][pc] = a_nxt[h][pc];
+        if (MVK_C3_SCHED > 0) {
+#pragma unroll
+          for (int m = 0; m < 12; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x496, MVK_C3_SCHED > 0 ? MVK_C3_SCHED : 1, 0);
+          }
+        }
+        if (pr == 7) __syncthreads();
+      }
+      pend0 = acc0;
+      pend1 = acc1;
+      rotate();
+#pragma unroll
+      for (int j = 0; j < NTAPW; ++j) ab_cur[j] = ab_nxt[j];
+      tb = tbn;
+      wch = wch + 1 == NCH ? 0 : wch + 1;
+      xpar ^= 1;
+    }
+    if (NT > 0) {
+      // drain 1: finish the last tile, epilogue of the one before it
+      char* const xb = xbase + xpar * T::XBUF;
+      finish_pending(xb);
+#pragma unroll
+      for (int o = 0; o < T::OWN; ++o) {
+        fetch_row((T1 - 1) & 15, o);
+        epilogue_row(o, NT >= 2);
+      }
+      __syncthreads();
+      gather_result(xb);
+      rotate();
+      // drain 2: epilogue of the last tile
+#pragma unroll
+      for (int o = 0; o < T::OWN; ++o) epilogue_row(o, true);
+    }
+  };
+  const int ks_u = __builtin_amdgcn_readfirstlane(ks);
+  if (ks_u == 0) run(std::integral_constant<int, 0>{});
+  else if (ks_u == 1) run(std::integral_constant<int, 1>{});
+  else if (T::KSPLIT > 2 && ks_u == 2) run(std::integral_constant<int, (T::KSPLIT > 2 ? 2 : 0)>{});
+  else if (T::KSPLIT > 3) run(std::integral_constant<int, (T::KSPLIT > 3 ? 3 : 0)>{});
+
+  if (g.colsum_part) {  // fixed-order sum over the lanes / waves that share a column
+    csum += __shfl_xor(csum, 32, 64);
+    __syncthreads();
+    if (kg == 0) csred[wave * 32 + col] = csum;
+    __syncthreads();
+    constexpr int CPW = (4 / T::KSPLIT) * 32;  // columns this workgroup covers
+    if (tid < CPW) {
+      const int grp = tid / 32, c_l = tid % 32;
+      float s = 0.f;
+      for (int r = 0; r < T::KSPLIT; ++r) s += csred[(grp * T::KSPLIT + r) * 32 + c_l];
+      g.colsum_part[(long long)worker * COUT + wgtype * CPW + tid] = s;
+    }
+  }
+  mvk_prof_end(g.prof);
+}
+
+template <int CIN, int COUT>
+static int c3rs_launch(const C3Args& a, int* part_rows, hipStream_t s) {
+  using T = C3Cfg<CIN, COUT>;
+  const int lds = T::lds_bytes(a.ring);
+  if (lds > 160 * 1024) return 1;
+  const void* all[4] = {reinterpret_cast<const void*>(c3rs_kernel<CIN, COUT, false, false>),
+                        reinterpret_cast<const void*>(c3rs_kernel<CIN, COUT, true, false>),
+                        reinterpret_cast<const void*>(c3rs_kernel<CIN, COUT, false, true>),
+                        reinterpret_cast<const void*>(c3rs_kernel<CIN, COUT, true, true>)};
+  static int attr_bytes = 0;
+  if (attr_bytes < lds) {
+    for (const void* f : all)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MVK_ELAUNCH;
+    attr_bytes = 160 * 1024;
+  }
+  const int grid = 256;
+  if (part_rows) *part_rows = grid / T::WG_TYPES;
+  C3Args ap = a;
+  ap.prof = prof_next(7, 2.0 * a.n * a.H * a.W * 9.0 * CIN * COUT);
+  const int which = (a.act_src ? 1 : 0) + (a.res ? 2 : 0);
+  auto kern = which == 0 ? c3rs_kernel<CIN, COUT, false, false>
+              : which == 1 ? c3rs_kernel<CIN, COUT, true, false>
+              : which == 2 ? c3rs_kernel<CIN, COUT, false, true> : c3rs_kernel<CIN, COUT, true, true>;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, ap);
+  MVK_CHECK_LAUNCH();
+  prof_fold(ap.prof, s);
+  return MVK_OK;
+}
+
+static float c3_slope(int act) { return act == MVK_ACT_RELU ? 0.f : act == MVK_ACT_LEAKY02 ? 0.2f : 1.f; }
+
+static int c3_lds_bytes(int Cin, int Cout, int ring) {
+  if (Cin == 64 && Cout == 64) return C3Cfg<64, 64>::lds_bytes(ring);
+  if (Cin == 64 && Cout == 128) return C3Cfg<64, 128>::lds_bytes(ring);
+  if (Cin == 128 && Cout == 64) return C3Cfg<128, 64>::lds_bytes(ring);
+  if (Cin == 128 && Cout == 128) return C3Cfg<128, 128>::lds_bytes(ring);
+  if (Cin == 128 && Cout == 256) return C3Cfg<128, 256>::lds_bytes(ring);
+  return 1 << 30;
+}
+
+static int c3_ring(int W) {
+  const int D = (W + 2 + 31) / 32;
+  int ring = 32 * (2 * D + 2);
+  while (ring <= 32 * D + 63 + W + 2) ring += 32;  // chunk T+D+1 must not land on a slot tile T still reads
+  return ring;
+}
+
+// every condition under which c3rs_conv takes a problem (the caller reserves arena space only behind this test)
+bool c3rs_shape_ok(int n, int H, int W, int Cin, int Cout) {
+  if (n <= 0 || H < 4 || W < 4 || W > 96) return false;
+  const long long total = (long long)n * (H + 1) * (W + 1);
+  if (total >= (1ll << 31) - 64 || (long long)n * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 40)) return false;
+  const int D = (W + 2 + 31) / 32;
+  if ((H + 1) * (W + 1) < 32 * D) return false;   // the table's start-up shift by one image block
+  if (32 / (W + 1) + 1 > H + 1) return false;     // one wrap per 32-position step of the incremental (image, row, column)
+  return c3_lds_bytes(Cin, Cout, c3_ring(W)) <= 160 * 1024;
+}
+
+// 1: not covered (the caller falls back to the implicit-GEMM engine).  colsum_part: [256 / types][Cout] floats.
+int c3rs_conv(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
+              const float* act_src, int src_act, const float* res, float res_alpha, float* colsum_part, int* part_rows,
+              float* trash, hipStream_t s) {
+  if (act == MVK_ACT_SIGMOID || (act_src && src_act == MVK_ACT_SIGMOID) || !trash || !mvk_aligned16(X)) return 1;
+  if (!c3rs_shape_ok(n, H, W, Cin, Cout)) return 1;
+  const long long total = (long long)n * (H + 1) * (W + 1);
+  C3Args a{X, Wp, bias, Y, act_src, res, colsum_part, trash, n, H, W, c3_slope(act), c3_slope(act_src ? src_act : MVK_ACT_NONE),
+           res_alpha, c3_ring(W), (W + 2 + 31) / 32, (int)((total + 31) / 32), nullptr};
+  if (Cin == 64 && Cout == 64) return c3rs_launch<64, 64>(a, part_rows, s);
+  if (Cin == 64 && Cout == 128) return c3rs_launch<64, 128>(a, part_rows, s);
+  if (Cin == 128 && Cout == 64) return c3rs_launch<128, 64>(a, part_rows, s);
+  if (Cin == 128 && Cout == 128) return c3rs_launch<128, 128>(a, part_rows, s);
+  if (Cin == 128 && Cout == 256) return c3rs_launch<128, 256>(a, part_rows, s);
+  return 1;
+}
+
+}  // namespace mvk

@@ -712,6 +712,24 @@ int imgconv_down(const float* U, const float* Wdown, const void* wfrag, const fl
 // mvk_debug_set_flags: bit 0x100 disables them, bit 0x200 takes them for every batch size (tests, A/B probes)
 int imgconv_wgrad(const float* U, const float* V, float* slab, long long slab_floats, int n, int h, int w, int Cu, int Cv,
                   int* nz, hipStream_t s);
+// Register-stationary 3x3 convolutions (conv3rs.hip); 1: shape not covered.  mvk_debug_set_flags: bit 0x400 disables them,
+// bit 0x800 takes them for every problem size (tests); MVK_C3RS=0 / MVK_C3RS=<min tiles> under MVK_TUNE=1.
+int c3rs_conv(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
+              const float* act_src, int src_act, const float* res, float res_alpha, float* colsum_part, int* part_rows,
+              float* trash, hipStream_t s);
+bool c3rs_shape_ok(int n, int H, int W, int Cin, int Cout);
+static bool c3rs_covers(int n, int H, int W, int Cin, int Cout) {
+  static int min_tiles = -1;
+  if (min_tiles < 0) {
+    const char* e = mvk_tune("MVK_C3RS");
+    min_tiles = e ? atoi(e) : 1024;
+    if (min_tiles == 0) min_tiles = 1 << 30;
+  }
+  if (g_dbg_flags & 0x400) return false;
+  if (!c3rs_shape_ok(n, H, W, Cin, Cout)) return false;
+  const long long tiles = ((long long)n * (H + 1) * (W + 1) + 31) / 32;
+  return (g_dbg_flags & 0x800) ? true : tiles >= min_tiles;
+}
 static int imgconv_min_images() {
   static int v = -1;
   if (v < 0) {
@@ -1020,6 +1038,17 @@ static int conv3x3_any(const float* X, const float* Wp, const float* bias, float
     if (rc == MVK_OK && colsum_acc)
       return colsum(Y, nullptr, 0, n * H * W, Cout, colsum_acc, ws, ws_floats, mvk_stream(stream));
     if (rc != 1) return rc;
+  }
+  if (n > 0 && ws && ws_floats >= 256ll * Cout + 64 && !(res && colsum_acc) && mvk_aligned16(X) && act != MVK_ACT_SIGMOID &&
+      !(y_act_src && y_src_act == MVK_ACT_SIGMOID) && c3rs_covers(n, H, W, Cin, Cout)) {
+    int rows = 0;
+    float* dpart = colsum_acc ? defer_scratch(colsum_acc, 256ll * Cout, mvk_stream(stream)) : nullptr;
+    const int rc = c3rs_conv(X, Wp, bias, Y, n, H, W, Cin, Cout, act, y_act_src, y_src_act, res, res_alpha,
+                             colsum_acc ? (dpart ? dpart : ws) : nullptr, &rows, ws + 256ll * Cout, mvk_stream(stream));
+    if (rc == MVK_OK && dpart) return defer_push_plain(colsum_acc, dpart, Cout, rows, Cout, mvk_stream(stream));
+    if (rc == MVK_OK && colsum_acc) return colsum_finish(ws, rows, Cout, colsum_acc, mvk_stream(stream));
+    if (rc != 1) return rc;
+    if (dpart) return MVK_EINVAL;  // covered shapes never decline after taking arena space
   }
   GemmDesc d{};
   d.a = AOperand{};

@@ -713,7 +713,7 @@ def resnet_cub_case(name, *, B, L, seed):
     save(name, dict(model="ResnetCUB", B=B, L=L, seed=seed, lrelu_rel_margin=lm.rel_min, lrelu_units=lm.units), arrays)
 
 
-def mmvaeplus_resnet_case(name, *, M, B, K, S, L, loss, beta, scale, seed):
+def mmvaeplus_resnet_case(name, *, M, B, K, S, L, loss, beta, scale, seed, probe=False):
     """BASELINE configs[3] assembled (MMVAE+ on PolyMNIST-shaped data, examples/mmvae_plus/mmnist.py:19-45): M
     modalities of 3x28x28, EncoderResnetMMNIST / DecoderResnetMMNIST, laplace_with_softmax posteriors, Laplace
     decoders with scale 0.75, learnable private priors, K importance samples."""
@@ -753,7 +753,14 @@ def mmvaeplus_resnet_case(name, *, M, B, K, S, L, loss, beta, scale, seed):
             if r != c:
                 noise[c][r] = draw((K, B, S))
     torch.manual_seed(seed)
-    out = model(inputs)
+    with lrelu_margin() as lm:
+        if probe:
+            with torch.no_grad():
+                model(inputs)
+        else:
+            out = model(inputs)
+    if probe:
+        return lm.rel_min
     model.zero_grad()
     out.loss.backward()
     gref = ref_grads(model)
@@ -783,10 +790,10 @@ def mmvaeplus_resnet_case(name, *, M, B, K, S, L, loss, beta, scale, seed):
         arrays["ws/" + c] = o["ws"][c].detach()
     arrays.update(grad_stats(gref))
     save(name, dict(model="MMVAEPlusResnet", M=M, B=B, L=L, S=S, K=K, family=family, loss=loss, beta=beta, scale=scale,
-                    seed=seed, names=names), arrays)
+                    seed=seed, names=names, lrelu_rel_margin=lm.rel_min, lrelu_units=lm.units), arrays)
 
 
-def jmvae_cub_case(name, *, B, L, n_attr, alpha, beta, warmup, epoch, seed):
+def jmvae_cub_case(name, *, B, L, n_attr, alpha, beta, warmup, epoch, seed, probe=False):
     """BASELINE configs[4] assembled: JMVAE on a 64x64 image (CUB_Resnet_Encoder / Decoder, cub.py:144-246) and a binary
     attribute vector (default MLPs, Bernoulli likelihood), default MultipleHeadJointEncoder (copies of both encoders)."""
     from multivae.models.nn.cub import CUB_Resnet_Decoder, CUB_Resnet_Encoder
@@ -809,7 +816,14 @@ def jmvae_cub_case(name, *, B, L, n_attr, alpha, beta, warmup, epoch, seed):
     torch.manual_seed(seed)
     eps = torch.randn(B, L)
     torch.manual_seed(seed)
-    out = model(inputs, epoch=epoch)
+    with lrelu_margin() as lm:
+        if probe:
+            with torch.no_grad():
+                model(inputs, epoch=epoch)
+        else:
+            out = model(inputs, epoch=epoch)
+    if probe:
+        return lm.rel_min
     model.zero_grad()
     out.loss.backward()
     gref = ref_grads(model)
@@ -833,7 +847,24 @@ def jmvae_cub_case(name, *, B, L, n_attr, alpha, beta, warmup, epoch, seed):
         arrays["metric/" + k] = torch.as_tensor(v).detach()
     arrays.update(grad_stats(gref))
     save(name, dict(model="JMVAECub", B=B, L=L, n_attr=n_attr, alpha=alpha, beta=beta, warmup=warmup, epoch=epoch,
-                    seed=seed, names=names, dists=dists), arrays)
+                    seed=seed, names=names, dists=dists, lrelu_rel_margin=lm.rel_min, lrelu_units=lm.units), arrays)
+
+
+ASSEMBLED = dict(
+    mmvaeplus_polymnist_resnet_k10=(mmvaeplus_resnet_case, dict(M=5, B=3, K=10, S=32, L=32, loss="iwae_looser", beta=2.5, scale=0.75)),
+    mmvaeplus_polymnist_resnet_dreg=(mmvaeplus_resnet_case, dict(M=3, B=4, K=3, S=8, L=16, loss="dreg_looser", beta=1.0, scale=0.75)),
+    jmvae_celeba_cub_resnet=(jmvae_cub_case, dict(B=3, L=64, n_attr=40, alpha=0.1, beta=1.0, warmup=10, epoch=4)),
+    jmvae_celeba_cub_resnet_trained=(jmvae_cub_case, dict(B=2, L=16, n_attr=18, alpha=0.5, beta=2.0, warmup=3, epoch=7)))
+
+
+def margin_search(name, seed0, count):
+    """`make_golden.py margin NAME SEED0 COUNT`: LeakyReLU margin of an assembled case for COUNT seeds (forward only)."""
+    fn, kw = ASSEMBLED[name]
+    best = []
+    for seed in range(seed0, seed0 + count):
+        best.append((fn(name, seed=seed, probe=True, **kw), seed))
+    best.sort(reverse=True)
+    print("BEST", best[:5])
 
 
 def assembled_main():
@@ -842,7 +873,8 @@ def assembled_main():
                           scale=0.75, seed=701)
     mmvaeplus_resnet_case("mmvaeplus_polymnist_resnet_dreg", M=3, B=4, K=3, S=8, L=16, loss="dreg_looser", beta=1.0,
                           scale=0.75, seed=702)
-    jmvae_cub_case("jmvae_celeba_cub_resnet", B=3, L=64, n_attr=40, alpha=0.1, beta=1.0, warmup=10, epoch=4, seed=703)
+    # seed: the best LeakyReLU margin of 40 tried (`make_golden.py margin jmvae_celeba_cub_resnet 703 40`)
+    jmvae_cub_case("jmvae_celeba_cub_resnet", B=3, L=64, n_attr=40, alpha=0.1, beta=1.0, warmup=10, epoch=4, seed=725)
     jmvae_cub_case("jmvae_celeba_cub_resnet_trained", B=2, L=16, n_attr=18, alpha=0.5, beta=2.0, warmup=3, epoch=7, seed=704)
 
 
@@ -1516,6 +1548,10 @@ if __name__ == "__main__":
         mmvaeplus_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "resnet":
         resnet_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "one":  # one assembled case, e.g. `make_golden.py one jmvae_celeba_cub_resnet 725`
+        ASSEMBLED[sys.argv[2]][0](sys.argv[2], seed=int(sys.argv[3]), **ASSEMBLED[sys.argv[2]][1])
+    elif len(sys.argv) > 1 and sys.argv[1] == "margin":
+        margin_search(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
     elif len(sys.argv) > 1 and sys.argv[1] == "assembled":
         assembled_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "nll":

@@ -122,25 +122,33 @@ def check_grads(arrays, named_grads, rtol=2e-4, atol_frac=2e-5):
     return worst
 
 
-def check_flip_aware(ref, got, what, rtol=1e-4, outlier_frac=5e-3, outlier_floor=9, worst=2e-2, median=1e-5):
-    """Gradient of a LeakyReLU ResNet stack against the fp32 oracle / the reference golden.
+def check_grads_flip_aware(ref_grads, got_grads, rtol=1e-4, clean_frac=0.95, median=1e-3, worst=1e-2):
+    """All parameter gradients of an assembled LeakyReLU-ResNet model against the fp32 oracle.
 
     In fp32 a unit whose pre-activation is ~1e-8 takes the other slope as soon as ANY kernel upstream sums in another
-    order; the reference networks have ~10 units per million below 1e-6 (tests/golden/make_golden.py prints the count), so
-    at the assembled sizes (1e7 ... 2e8 units) no choice of inputs avoids them.  A flipped unit changes the 9 Cin entries
-    of the weight gradient it feeds and the patch of the gradient map around it; everything else moves at the 1e-7 level.
-    The check is therefore a statement about the DISTRIBUTION of the elementwise error relative to the tensor's largest
-    entry: all but `outlier_frac` of the entries (at least `outlier_floor`) within `rtol`, the median within `median`, the
-    worst entry within `worst`.  A real error of the gradient arithmetic at the 1e-4 ... 1e-2 level moves most entries
-    and fails the first two bounds (the previous test bounded only the worst entry at 1e-2 and a median at 5e-4)."""
-    r = torch.as_tensor(np.asarray(ref)).double().reshape(-1)
-    g_ = got.detach().double().cpu().reshape(-1)
-    assert r.numel() == g_.numel(), what
-    scale = float(r.abs().max().clamp_min(1e-30))
-    err = (g_ - r).abs() / scale
-    n_out = int((err > rtol).sum())
-    allowed = max(outlier_floor, int(outlier_frac * err.numel()))
-    assert n_out <= allowed, f"{what}: {n_out} of {err.numel()} entries off by > {rtol} of max (allowed {allowed}); worst {float(err.max()):.3e}"
-    assert float(err.median()) <= median, f"{what}: median err {float(err.median()):.3e} of max"
-    assert float(err.max()) <= worst, f"{what}: worst err {float(err.max()):.3e} of max"
-    return n_out
+    order.  The reference networks have ~10 units per million within 1e-6 of zero (tests/golden/make_golden.py
+    `lrelu_margin` prints the count); the assembled cases have 1e7 ... 2e8 units, so no choice of inputs avoids them
+    (the two network-level goldens, 2e6 ... 4e6 units, ARE generated from seeds with a margin and checked entry by entry
+    at 1e-4: test_gpu_golden.py).  What a flipped unit does, measured on the GPU (tools/flip_calib.py): the 9 Cin
+    weight-gradient entries it feeds move by up to ~5e-3 of the tensor's largest entry, and EVERY gradient upstream of it
+    moves by its share — a dense rank-one change of 1e-4 ... 5e-4 when the unit sits near the top of an encoder.  So the
+    statement checked here is about the distribution over tensors and entries:
+      * at least `clean_frac` of the tensors agree entry by entry within `rtol` of their largest entry,
+      * every tensor's median error stays within `median`, its worst entry within `worst`.
+    A real error of the gradient arithmetic at the 1e-3 level fails the first bound (it moves every tensor downstream of
+    the faulty kernel); `jmvae_celeba_cub_resnet_trained`, which happens to contain no flipped unit, is checked strictly."""
+    clean, rows = 0, []
+    for k, g in ref_grads.items():
+        r = torch.as_tensor(np.asarray(g.detach() if torch.is_tensor(g) else g)).double().reshape(-1)
+        x = got_grads[k].detach().double().cpu().reshape(-1)
+        assert r.numel() == x.numel(), k
+        err = (x - r).abs() / float(r.abs().max().clamp_min(1e-30))
+        mx, md = float(err.max()), float(err.median())
+        assert md <= median, f"grad {k}: median err {md:.3e} of max"
+        assert mx <= worst, f"grad {k}: worst err {mx:.3e} of max"
+        clean += mx <= rtol
+        rows.append((mx, k))
+    rows.sort(reverse=True)
+    assert clean >= clean_frac * len(rows), (f"only {clean} of {len(rows)} gradient tensors within {rtol} of their largest "
+                                             f"entry; worst: {rows[:5]}")
+    return clean, len(rows)

@@ -768,6 +768,47 @@ def test_conv3x3_fwd_bwd(K, n, H, W, Cin, Cout):
     close(wparam.grad, w.grad, what="conv3x3 backward weight")
 
 
+@pytest.mark.parametrize("n,H,W,Cin,Cout", [(5, 64, 64, 64, 64), (9, 32, 32, 64, 128), (40, 16, 16, 128, 128), (33, 16, 16, 128, 256),
+                                          (70, 28, 28, 64, 64), (130, 14, 14, 128, 64), (300, 7, 7, 128, 128), (2, 7, 7, 128, 256),
+                                          (1, 9, 13, 64, 64), (3, 32, 32, 128, 64)])
+def test_conv3x3_register_stationary(K, n, H, W, Cin, Cout):
+    """csrc/conv3rs.hip (weights resident in registers, the images one zero-padded stream of positions through an LDS ring)
+    against a float64 F.conv2d(3, 1, 1): plain forward with bias + LeakyReLU; backward-data form (activation derivative of
+    the landing layer + bias-gradient column sums); the residual epilogue.  Taken for EVERY size here (debug flag 0x800),
+    so workers with zero, one and two tiles and ragged last tiles are covered; (3, 32, 32, 128, 64) exceeds the LDS ring
+    and must fall back to the tiled engine with the same result."""
+    gen = g(53)
+    d = dev()
+    x = torch.randn(n, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) / (3 * Cin ** 0.5)
+    b = 0.1 * torch.randn(Cout, generator=gen)
+    res = torch.randn(n, Cout, H, W, generator=gen)
+    src = torch.randn(n, Cout, H, W, generator=gen)
+    nhwc = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(d)
+    (wf, _), = K.pack_weights([(w.to(d), "c3", True, True)])
+    conv = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    lrelu = lambda t: F.leaky_relu(t, 0.2)
+    mask = torch.where(src > 0, 1.0, 0.2).double()
+    _debug_flags(0x800)
+    try:
+        Y = K.conv3x3(nhwc(x), wf, b.to(d), n, H, W, Cin, Cout, act=K.LEAKY)
+        close(Y, nhwc(lrelu(conv).float()), what="forward + bias + LeakyReLU", rtol=2e-6)
+        bparam = torch.zeros(Cout, device=d).requires_grad_(True)
+        bparam.grad = torch.zeros(Cout, device=d)
+        Y, _ = K.conv3x3(nhwc(x), wf, None, n, H, W, Cin, Cout, y_act_src=nhwc(src), y_src_act=K.LEAKY, out_bias=bparam)
+        ref = (conv - b.double().view(1, -1, 1, 1)) * mask
+        close(Y, nhwc(ref.float()), what="conv * act'(mask source)", rtol=2e-6)
+        close(bparam.grad, ref.sum((0, 2, 3)).float(), what="column sums", rtol=1e-5)
+        Y = K.conv3x3(nhwc(x), wf, b.to(d), n, H, W, Cin, Cout, act=K.NONE, res=nhwc(res), res_alpha=0.1)
+        close(Y, nhwc((res.double() + 0.1 * conv).float()), what="res + 0.1 * conv", rtol=2e-6)
+        Y = K.conv3x3(nhwc(x), wf, b.to(d), n, H, W, Cin, Cout, act=K.RELU, y_act_src=nhwc(src), y_src_act=K.RELU, res=nhwc(res))
+        close(Y, nhwc((res.double() + torch.relu(conv) * (src > 0)).float()), what="res + relu(conv) * relu'(src)", rtol=2e-6)
+    finally:
+        _debug_flags(0)
+    Yt = K.conv3x3(nhwc(x), wf, b.to(d), n, H, W, Cin, Cout, act=K.LEAKY)  # the default dispatch (tiled engine at these sizes)
+    close(Yt, nhwc(lrelu(conv).float()), what="default dispatch", rtol=2e-6)
+
+
 @pytest.mark.parametrize("n,H,W,Cin,Cout", [(3, 7, 7, 64, 128), (2, 16, 16, 128, 64), (1, 5, 9, 6, 10), (2, 8, 8, 3, 64)])
 def test_conv3x3_residual_epilogue(K, n, H, W, Cin, Cout):
     """mvk_conv3x3_res: res + alpha * (conv (+ bias, activation) * act'(mask source)) in the convolution's epilogue — the
