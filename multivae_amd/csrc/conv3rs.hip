@@ -163,16 +163,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     sc4[k] = (f % (CIN / 4)) * 4;
     soff[k] = spos[k] * T::S + (f % (CIN / 4)) * 8;
   }
+  // A loaded value is first touched ONE TILE after its load was issued (the zero positions are selected at conversion
+  // time, not at load time): with one wave per SIMD a wait on a fresh load stalls the matrix pipe for a memory latency.
   f32x4 raw[T::NF4];
-  auto load_unit = [&](int c, int k) {
-    const int pix = ptab[(c & 15) * 32 + spos[k]];
-    const f32x4 v = *reinterpret_cast<const f32x4*>(g.X + (long long)(pix < 0 ? 0 : pix) * CIN + sc4[k]);
-    raw[k] = pix < 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
+  int rawpix[T::NF4];
+  auto unit_pix = [&](int c, int k) { return ptab[(c & 15) * 32 + spos[k]]; };
+  auto load_unit_at = [&](int pix, int k) {
+    rawpix[k] = pix;
+    raw[k] = *reinterpret_cast<const f32x4*>(g.X + (long long)(pix < 0 ? 0 : pix) * CIN + sc4[k]);
   };
+  auto load_unit = [&](int c, int k) { load_unit_at(unit_pix(c, k), k); };
   auto write_unit = [&](int wbase, int k) {  // wbase = byte offset of the chunk's first slot
+    const bool z = rawpix[k] < 0;
+    const float r0 = z ? 0.f : raw[k][0], r1 = z ? 0.f : raw[k][1], r2 = z ? 0.f : raw[k][2], r3 = z ? 0.f : raw[k][3];
     unsigned a0, a1, a2, b0, b1, b2;
-    bf3_split(raw[k][0], raw[k][1], a0, a1, a2);
-    bf3_split(raw[k][2], raw[k][3], b0, b1, b2);
+    bf3_split(r0, r1, a0, a1, a2);
+    bf3_split(r2, r3, b0, b1, b2);
     char* d = ringp + wbase + soff[k];
     *reinterpret_cast<u32x2*>(d) = u32x2{a0, b0};
     *reinterpret_cast<u32x2*>(d + 2 * CIN) = u32x2{a1, b1};
@@ -242,12 +248,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int wgrp = (wave / T::KSPLIT) * T::KSPLIT;  // first wave of this wave's column-tile group
 
     f32x16 pend0 = {0}, pend1 = {0};
-    float own[T::OWN], res_next[T::OWN], res_prev[T::OWN], msk_prev[T::OWN], msk_cur[T::OWN], rr_prev[T::OWN], rr_cur[T::OWN];
-    int pix_prev[T::OWN], pix_cur[T::OWN];
+    // msk / rr / pix of a tile are fetched (global loads) while the NEXT tile is multiplied and consumed one tile after
+    // that: two register sets indexed by the compile-time parity of the tile, no copy between them (hipcc hoists a copy
+    // "prev = cur" to the last use of prev, i.e. right behind the load, and waits there for the memory latency)
+    float own[T::OWN], res_next[T::OWN], res_prev[T::OWN], msk[2][T::OWN], rr[2][T::OWN];
+    int pix[2][T::OWN];
 #pragma unroll
     for (int o = 0; o < T::OWN; ++o) {
-      own[o] = res_next[o] = res_prev[o] = msk_prev[o] = msk_cur[o] = rr_prev[o] = rr_cur[o] = 0.f;
-      pix_prev[o] = pix_cur[o] = -1;
+      own[o] = res_next[o] = res_prev[o] = 0.f;
+      msk[0][o] = msk[1][o] = rr[0][o] = rr[1][o] = 0.f;
+      pix[0][o] = pix[1][o] = -1;
     }
     auto finish_pending = [&](char* xb) {
       const f32x16 sum = pend0 + pend1;
@@ -279,69 +289,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         res_next[o] = v;
       }
     };
-    auto fetch_row = [&](int tabrow, int o) {  // pixel index of row o of the tile whose table row is tabrow (+ mask / residual)
-      const int pix = ptab[tabrow * 32 + rrow[o]];
-      pix_cur[o] = pix;
-      const long long off = (long long)(pix < 0 ? 0 : pix) * COUT + ncol;
-      if (HAS_SRC) msk_cur[o] = g.act_src[off];
-      if (HAS_RES) rr_cur[o] = g.res[off];
+    auto fetch_pix = [&](int P, int tabrow) {  // pixel indices of this lane's rows of the tile whose table row is tabrow
+#pragma unroll
+      for (int o = 0; o < T::OWN; ++o) pix[P][o] = ptab[tabrow * 32 + rrow[o]];
     };
-    auto epilogue_row = [&](int o, bool valid) {
+    auto fetch_row = [&](int P, int o) {  // mask / residual of row o (issued one tile before they are consumed)
+      const long long off = (long long)(pix[P][o] < 0 ? 0 : pix[P][o]) * COUT + ncol;
+      if (HAS_SRC) msk[P][o] = g.act_src[off];
+      if (HAS_RES) rr[P][o] = g.res[off];
+    };
+    auto epilogue_row = [&](int Q, int o, bool valid) {  // Q: the parity whose fetch belongs to the tile in res_prev
       float v = res_prev[o] + bias;
       v = v > 0.f ? v : v * aslope;
-      if (HAS_SRC) v = msk_prev[o] > 0.f ? v : v * mslope;
-      const int pix = valid ? pix_prev[o] : -1;
-      csum += pix < 0 ? 0.f : v;
-      if (HAS_RES) v = fmaf(alpha, v, rr_prev[o]);
-      float* dst = pix < 0 ? g.trash + lane : g.Y + (long long)pix * COUT + ncol;
+      if (HAS_SRC) v = msk[Q][o] > 0.f ? v : v * mslope;
+      const int px_ = valid ? pix[Q][o] : -1;
+      csum += px_ < 0 ? 0.f : v;
+      if (HAS_RES) v = fmaf(alpha, v, rr[Q][o]);
+      float* dst = px_ < 0 ? g.trash + lane : g.Y + (long long)px_ * COUT + ncol;
       *dst = v;
     };
     auto rotate = [&]() {
 #pragma unroll
-      for (int o = 0; o < T::OWN; ++o) {
-        res_prev[o] = res_next[o];
-        msk_prev[o] = msk_cur[o];
-        rr_prev[o] = rr_cur[o];
-        pix_prev[o] = pix_cur[o];
-      }
+      for (int o = 0; o < T::OWN; ++o) res_prev[o] = res_next[o];
     };
 
     int tb = (int)(((long long)32 * T0) % RING);       // first ring slot of tile T
     int wch = (((T0 + D + 1) % NCH) + NCH) % NCH;       // ring chunk that chunk T+D+1 goes to
-    int xpar = 0;
     int ab_cur[NTAPW], ab_nxt[NTAPW];
     bf16x8 a_cur[2][3];
     if (NT > 0) {
       frag_base(ab_cur, tb);
       read_pair(a_cur, ab_cur, 0);
     }
-    for (int t = 0; t < NT; ++t) {
+    auto tile = [&](auto par_tag, int t) {
+      constexpr int P = decltype(par_tag)::value;
       const int Tt = T0 + t;
       const bool valid2 = t >= 2;
-      char* const xb = xbase + xpar * T::XBUF;
+      char* const xb = xbase + P * T::XBUF;
       const int wbase = wch * 32 * T::S;
-      const int tabrow1 = (Tt - 1) & 15;
       int tbn = tb + 32;
       tbn = tbn >= RING ? tbn - RING : tbn;
       f32x16 acc0 = {0}, acc1 = {0};
+      int upix[T::NF4];
 #pragma unroll
       for (int pr = 0; pr < 9; ++pr) {
         bf16x8 a_nxt[2][3];
         if (pr < 8) read_pair(a_nxt, ab_cur, pr + 1);
-        if (pr == 0) finish_pending(xb);
+        if (pr == 0) {
+          finish_pending(xb);
+          fetch_pix(P, (Tt - 1) & 15);            // table rows published by the previous barrier: ONE wait per tile
+#pragma unroll
+          for (int k = 0; k < T::NF4; ++k) upix[k] = unit_pix(Tt + D + 2, k);
+        }
         if (pr == 1) ptab_store();               // table row of chunk Tt + D + 3 (staging loads of the next tile)
         if (pr == 2) frag_base(ab_nxt, tbn);
         // conversion of chunk Tt+D+1 (loaded one tile ago) + the loads of chunk Tt+D+2: done before the barrier behind pair 7
-        if (pr < 7 && pr % (T::NF4 == 2 ? 3 : 2) == 0 && pr / (T::NF4 == 2 ? 3 : 2) < T::NF4) {
+        {
           constexpr int STEP = T::NF4 == 2 ? 3 : 2;
-          write_unit(wbase, pr / STEP);
-          load_unit(Tt + D + 2, pr / STEP);
+          if (pr >= 1 && pr <= 7 && (pr - 1) % STEP == 0 && (pr - 1) / STEP < T::NF4) {
+            write_unit(wbase, (pr - 1) / STEP);
+            load_unit_at(upix[(pr - 1) / STEP], (pr - 1) / STEP);
+          }
         }
 #pragma unroll
         for (int o = 0; o < T::OWN; ++o) {
-          if (o * 9 / T::OWN != pr) continue;
-          fetch_row(tabrow1, o);                  // tile Tt-1: consumed two tiles later
-          epilogue_row(o, valid2);                // tile Tt-2
+          if (o * 8 / T::OWN + 1 != pr) continue;
+          fetch_row(P, o);                        // tile Tt-1: consumed two tiles later
+          epilogue_row(P ^ 1, o, valid2);         // tile Tt-2
         }
         constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB_[6] = {2, 1, 0, 1, 0, 0};  // small terms first
 #pragma unroll
@@ -373,23 +387,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int j = 0; j < NTAPW; ++j) ab_cur[j] = ab_nxt[j];
       tb = tbn;
       wch = wch + 1 == NCH ? 0 : wch + 1;
-      xpar ^= 1;
-    }
-    if (NT > 0) {
+    };
+    auto drain = [&](auto par_tag) {
+      constexpr int P = decltype(par_tag)::value;  // parity of the (virtual) tile NT
       // drain 1: finish the last tile, epilogue of the one before it
-      char* const xb = xbase + xpar * T::XBUF;
+      char* const xb = xbase + P * T::XBUF;
       finish_pending(xb);
+      fetch_pix(P, (T1 - 1) & 15);
 #pragma unroll
       for (int o = 0; o < T::OWN; ++o) {
-        fetch_row((T1 - 1) & 15, o);
-        epilogue_row(o, NT >= 2);
+        fetch_row(P, o);
+        epilogue_row(P ^ 1, o, NT >= 2);
       }
       __syncthreads();
       gather_result(xb);
       rotate();
       // drain 2: epilogue of the last tile
 #pragma unroll
-      for (int o = 0; o < T::OWN; ++o) epilogue_row(o, true);
+      for (int o = 0; o < T::OWN; ++o) epilogue_row(P, o, true);
+    };
+    std::integral_constant<int, 0> par0;
+    std::integral_constant<int, 1> par1;
+    for (int t = 0; t < NT; t += 2) {
+      tile(par0, t);
+      if (t + 1 < NT) tile(par1, t + 1);
+    }
+    if (NT > 0) {
+      if (NT & 1) drain(par1);
+      else drain(par0);
     }
   };
   const int ks_u = __builtin_amdgcn_readfirstlane(ks);
