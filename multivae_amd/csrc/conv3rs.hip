@@ -470,6 +470,305 @@ static int c3rs_launch(const C3Args& a, int* part_rows, hipStream_t s) {
 
 static float c3_slope(int act) { return act == MVK_ACT_RELU ? 0.f : act == MVK_ACT_LEAKY02 ? 0.2f : 1.f; }
 
+// =====================================================================================================================
+// Weight gradient of the same layers:  dW[co][ci][kh][kw] += sum_p dY[p][co] X[p + (kh-1)(W+1) + (kw-1)][ci]
+// =====================================================================================================================
+// OUTPUT-stationary, on the same position stream: the reduction index of this GEMM is the position, and with the zero
+// column / zero row in the stream (dY is staged with zeros there too) every tap is again a plain shift.  A workgroup type
+// owns a [9 taps][64 ci][64 co] block of the gradient, wave (h, c) of it the nine 32 x 32 tiles [tap][32 ci][32 co] in 144
+// accumulator registers for the whole launch; Cin / 64 x Cout / 64 workgroup types cover a layer, each staging only its 64
+// input and 64 output channels.  X lives in the ring of the forward kernel (three bf16 piece rows per slot), dY in two
+// 32-position buffers; both operands are position-major in LDS, i.e. transposed for the matrix cores, and are read with
+// ds_read_b64_tr_b16 (imgwgrad_kernel) at per-lane slot addresses.  Per 32 positions a wave issues 2 k-steps x 3 kernel
+// rows x 18 MFMAs (three accumulator chains interleaved); the A fragments of the next kernel row are read one row ahead.
+// Every workgroup writes its block as one slab; the slabs are added in a fixed order (convref_reduce, deferred).
+struct C3WArgs {
+  const float* X;   // [n][H][W][Cin]
+  const float* dY;  // [n][H][W][Cout]
+  float* slab;      // [workers][9 Cin][Cout]
+  int n, H, W, Cin, Cout;
+  int ring, D, tiles;
+  mvk_prof_slot* prof;
+};
+
+#ifndef MVK_C3W_PAD
+#define MVK_C3W_PAD 16
+#endif
+#ifndef MVK_C3W_SCHED
+#define MVK_C3W_SCHED 4
+#endif
+constexpr int C3W_S = 6 * 64 + MVK_C3W_PAD;  // bytes per slot: 3 pieces x 64 channels bf16 + pad
+static int c3w_lds_bytes(int ring) { return (ring + 64) * C3W_S + 16 * 32 * 4; }
+
+typedef __bf16 c3_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 c3_tr_pair(const char* p0, const char* p1) {
+  typedef __attribute__((address_space(3))) c3_bf16x4* lp;
+  const c3_bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p0));
+  const c3_bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p1));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void c3wg_kernel(const C3WArgs g) {
+  constexpr int S = C3W_S;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  mvk_prof_begin(g.prof);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, kg = lane >> 5;
+  const int cit = g.Cin / 64, types = cit * (g.Cout / 64);
+  const int wgtype = blockIdx.x % types;
+  const int worker = blockIdx.x / types, workers = gridDim.x / types;
+  const int ci0 = (wgtype % cit) * 64, co0 = (wgtype / cit) * 64;
+  const int h = wave & 1, c = wave >> 1;  // this wave's 32-channel tiles of the block
+
+  const int RING = g.ring, NCH = RING / 32;
+  char* const ringp = lds;
+  char* const dyp = lds + RING * S;  // two 32-slot buffers
+  int* const ptab = reinterpret_cast<int*>(dyp + 64 * S);
+
+  const int H = g.H, W = g.W, W1 = W + 1, H1 = H + 1, PB = W1 * H1;
+  const int dx32 = 32 % W1, dv32 = 32 / W1;
+  const int D = g.D;
+  const int T0 = (int)((long long)g.tiles * worker / workers), T1 = (int)((long long)g.tiles * (worker + 1) / workers);
+  const int NT = T1 - T0;
+
+  int pimg, pv, px;
+  {
+    const int p0 = 32 * (T0 - D) + col + PB;
+    pimg = p0 / PB - 1;
+    const int rem = p0 % PB;
+    pv = rem / W1;
+    px = rem % W1;
+  }
+  int cnext = T0 - D;
+  auto ptab_store = [&]() {
+    const bool ok = pimg >= 0 && pimg < g.n && pv < H && px < W;
+    const int val = ok ? (pimg * H + pv) * W + px : -1;
+    if (wave == 0 && kg == 0) ptab[(cnext & 15) * 32 + col] = val;
+    ++cnext;
+    px += dx32;
+    pv += dv32;
+    if (px >= W1) {
+      px -= W1;
+      pv += 1;
+    }
+    if (pv >= H1) {
+      pv -= H1;
+      pimg += 1;
+    }
+  };
+
+  // staging: units 0,1 = the X chunk, units 2,3 = the dY chunk; float4 unit f = tid + k * 256 of a [32 positions][64] block
+  int soff[2], spos[2], sc4[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int f = tid + k * 256;
+    spos[k] = f / 16;
+    sc4[k] = (f % 16) * 4;
+    soff[k] = spos[k] * S + (f % 16) * 8;
+  }
+  f32x4 raw[4];
+  int rawpix[4];
+  auto unit_pix = [&](int chunk, int k) { return ptab[(chunk & 15) * 32 + spos[k & 1]]; };
+  auto load_unit_at = [&](int pix, int k) {
+    rawpix[k] = pix;
+    const long long pc = pix < 0 ? 0 : pix;
+    raw[k] = k < 2 ? *reinterpret_cast<const f32x4*>(g.X + pc * g.Cin + ci0 + sc4[k & 1])
+                   : *reinterpret_cast<const f32x4*>(g.dY + pc * g.Cout + co0 + sc4[k & 1]);
+  };
+  auto write_unit = [&](char* base, int k) {  // base: first slot of the chunk (ring) / of the buffer (dY)
+    const bool z = rawpix[k] < 0;
+    const float r0 = z ? 0.f : raw[k][0], r1 = z ? 0.f : raw[k][1], r2 = z ? 0.f : raw[k][2], r3 = z ? 0.f : raw[k][3];
+    unsigned a0, a1, a2, b0, b1, b2;
+    bf3_split(r0, r1, a0, a1, a2);
+    bf3_split(r2, r3, b0, b1, b2);
+    char* d = base + soff[k & 1];
+    *reinterpret_cast<u32x2*>(d) = u32x2{a0, b0};
+    *reinterpret_cast<u32x2*>(d + 128) = u32x2{a1, b1};
+    *reinterpret_cast<u32x2*>(d + 256) = u32x2{a2, b2};
+  };
+  auto chunk_slot = [&](int ch) { return (((ch % NCH) + NCH) % NCH) * 32 * S; };
+
+  // ---- prologue -------------------------------------------------------------------------------------------------------------
+  if (NT > 0) {
+    for (int ch = T0 - D; ch <= T0 + D + 2; ++ch) ptab_store();
+  }
+  __syncthreads();
+  if (NT > 0) {
+    for (int ch = T0 - D; ch <= T0 + D; ++ch) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) load_unit_at(unit_pix(ch, k), k);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) write_unit(ringp + chunk_slot(ch), k);
+    }
+#pragma unroll
+    for (int k = 2; k < 4; ++k) load_unit_at(unit_pix(T0, k), k);
+#pragma unroll
+    for (int k = 2; k < 4; ++k) write_unit(dyp, k);  // tile T0 -> buffer 0
+#pragma unroll
+    for (int k = 0; k < 2; ++k) load_unit_at(unit_pix(T0 + D + 1, k), k);
+#pragma unroll
+    for (int k = 2; k < 4; ++k) load_unit_at(unit_pix(T0 + 1, k), k);
+  }
+  __syncthreads();
+
+  // transposing-read geometry (imgwgrad_kernel): 16-lane group gq reads [4 positions][16 channels]; lane lp supplies position
+  // (lp >> 2), channels 4 (lp & 3) .. +3 and receives channel lp of the block, positions 0..3
+  const int gq = lane >> 4, lp = lane & 15;
+  const int kbase = 8 * (gq >> 1) + (lp >> 2);
+  const int cch = 16 * (gq & 1) + 4 * (lp & 3);
+  const int a_ch = (h * 32 + cch) * 2, b_ch = (c * 32 + cch) * 2;
+  int boff[2][2];  // dY fragment addresses inside a buffer: [k-step][4-position half]
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) boff[s][t] = (s * 16 + kbase + 4 * t) * S + b_ch;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) acc[j] = f32x16{0};
+
+  int tb = (int)(((long long)32 * T0) % RING);
+  int wch = (((T0 + D + 1) % NCH) + NCH) % NCH;
+
+  // fragment addresses of one kernel row (dy) of k-step s of the tile whose first slot is tbv: [dx][4-position half]
+  auto row_addr = [&](int (&ad)[3][2], int tbv, int s, int dy) {
+    unsigned q = (unsigned)(tbv + s * 16 + kbase + dy * W1 - 1 + RING);
+    q = min(q, q - (unsigned)RING);
+    q = min(q, q - (unsigned)RING);
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        unsigned r = q + dx + 4 * t;
+        r = min(r, r - (unsigned)RING);
+        ad[dx][t] = (int)r * S + a_ch;
+      }
+  };
+  auto read_row = [&](bf16x8 (&A)[3][3], const int (&ad)[3][2]) {
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) A[dx][pc] = c3_tr_pair(ringp + ad[dx][0] + pc * 128, ringp + ad[dx][1] + pc * 128);
+  };
+  auto read_b = [&](bf16x8 (&B)[2][3], const char* buf) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) B[s][pc] = c3_tr_pair(buf + boff[s][0] + pc * 128, buf + boff[s][1] + pc * 128);
+  };
+
+  bf16x8 A_cur[3][3], Bf[2][3];
+  int ad[3][2];
+  if (NT > 0) {
+    row_addr(ad, tb, 0, -1);
+    read_row(A_cur, ad);
+    read_b(Bf, dyp);
+  }
+  for (int t = 0; t < NT; ++t) {
+    const int Tt = T0 + t;
+    const char* const nbuf_r = dyp + ((t + 1) & 1) * 32 * S;
+    char* const nbuf_w = dyp + ((t + 1) & 1) * 32 * S;
+    char* const xw = ringp + wch * 32 * S;
+    int tbn = tb + 32;
+    tbn = tbn >= RING ? tbn - RING : tbn;
+    int upix[4];
+#pragma unroll
+    for (int step = 0; step < 6; ++step) {  // (k-step, kernel row)
+      const int s = step / 3, grp = step % 3;
+      bf16x8 A_nxt[3][3];
+      if (step < 5) {
+        row_addr(ad, tb, (step + 1) / 3, (step + 1) % 3 - 1);
+        read_row(A_nxt, ad);
+      }
+      if (step == 0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) upix[k] = unit_pix(Tt + D + 2, k);
+#pragma unroll
+        for (int k = 2; k < 4; ++k) upix[k] = unit_pix(Tt + 2, k);
+      }
+      if (step == 1) ptab_store();  // table row of chunk Tt + D + 3
+      if (step >= 1 && step <= 4) {  // conversion of X chunk Tt+D+1 / dY tile Tt+1 (loaded one tile ago), next loads
+        const int k = step - 1;
+        write_unit(k < 2 ? xw : nbuf_w, k);
+        load_unit_at(upix[k], k);
+      }
+      constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB_[6] = {2, 1, 0, 1, 0, 0};  // small terms first
+#pragma unroll
+      for (int m = 0; m < 6; ++m)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+          acc[grp * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_cur[dx][PA[m]], Bf[s][PB_[m]], acc[grp * 3 + dx], 0, 0, 0);
+      if (MVK_C3W_SCHED > 0) {
+#pragma unroll
+        for (int m = 0; m < 18; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x496, MVK_C3W_SCHED > 0 ? MVK_C3W_SCHED : 1, 0);
+        }
+      }
+      if (step < 5) {
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) A_cur[dx][pc] = A_nxt[dx][pc];
+      }
+    }
+    __syncthreads();
+    row_addr(ad, tbn, 0, -1);
+    read_row(A_cur, ad);
+    read_b(Bf, nbuf_r);
+    tb = tbn;
+    wch = wch + 1 == NCH ? 0 : wch + 1;
+  }
+
+  // partial gradient of this workgroup: slab[worker][(tap * Cin + ci)][co]
+  float* const slab = g.slab + (long long)worker * 9 * g.Cin * g.Cout;
+#pragma unroll
+  for (int j = 0; j < 9; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = ci0 + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+      slab[((long long)j * g.Cin + ci) * g.Cout + co0 + c * 32 + col] = acc[j][r];
+    }
+  mvk_prof_end(g.prof);
+}
+
+static int c3_ring(int W);
+bool c3rs_wgrad_ok(int n, int H, int W, int Cin, int Cout) {
+  if (n <= 0 || H < 4 || W < 4 || W > 96 || Cin % 64 != 0 || Cout % 64 != 0 || Cin > 256 || Cout > 256) return false;
+  const int types = (Cin / 64) * (Cout / 64);
+  if (types > 16) return false;
+  const long long total = (long long)n * (H + 1) * (W + 1);
+  if (total >= (1ll << 31) - 64 || (long long)n * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 40)) return false;
+  const int D = (W + 2 + 31) / 32;
+  if ((H + 1) * (W + 1) < 32 * D || 32 / (W + 1) + 1 > H + 1) return false;
+  return c3w_lds_bytes(c3_ring(W)) <= 160 * 1024;
+}
+
+// slab: [*nz][9 Cin][Cout] partial gradients (needs (256 / types) * 9 Cin Cout floats); 1: not covered
+int c3rs_wgrad(const float* X, const float* dY, float* slab, long long slab_floats, int n, int H, int W, int Cin, int Cout,
+               int* nz, hipStream_t s) {
+  if (!c3rs_wgrad_ok(n, H, W, Cin, Cout) || !mvk_aligned16(X) || !mvk_aligned16(dY)) return 1;
+  const int types = (Cin / 64) * (Cout / 64);
+  const int grid = 256 / types * types, workers = grid / types;
+  if (slab_floats < (long long)workers * 9 * Cin * Cout) return 1;
+  const int ring = c3_ring(W), lds = c3w_lds_bytes(ring);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(c3wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return MVK_ELAUNCH;
+    attr_done = true;
+  }
+  const long long total = (long long)n * (H + 1) * (W + 1);
+  C3WArgs a{X, dY, slab, n, H, W, Cin, Cout, ring, (W + 2 + 31) / 32, (int)((total + 31) / 32), nullptr};
+  a.prof = prof_next(8, 2.0 * n * H * W * 9.0 * Cin * Cout);
+  *nz = workers;
+  hipLaunchKernelGGL(c3wg_kernel, dim3(grid), dim3(256), lds, s, a);
+  MVK_CHECK_LAUNCH();
+  prof_fold(a.prof, s);
+  return MVK_OK;
+}
+
 static int c3_lds_bytes(int Cin, int Cout, int ring) {
   if (Cin == 64 && Cout == 64) return C3Cfg<64, 64>::lds_bytes(ring);
   if (Cin == 64 && Cout == 128) return C3Cfg<64, 128>::lds_bytes(ring);

@@ -718,6 +718,11 @@ int c3rs_conv(const float* X, const float* Wp, const float* bias, float* Y, int 
               const float* act_src, int src_act, const float* res, float res_alpha, float* colsum_part, int* part_rows,
               float* trash, hipStream_t s);
 bool c3rs_shape_ok(int n, int H, int W, int Cin, int Cout);
+bool c3rs_wgrad_ok(int n, int H, int W, int Cin, int Cout);
+int c3rs_wgrad(const float* X, const float* dY, float* slab, long long slab_floats, int n, int H, int W, int Cin, int Cout,
+               int* nz, hipStream_t s);
+int convref_reduce(const float* slab, int nz, int Cu, int Cv, int taps, float* dWref, hipStream_t s, bool deferred);
+static bool c3rs_wgrad_covers(int n, int H, int W, int Cin, int Cout);
 static bool c3rs_covers(int n, int H, int W, int Cin, int Cout) {
   static int min_tiles = -1;
   if (min_tiles < 0) {
@@ -729,6 +734,11 @@ static bool c3rs_covers(int n, int H, int W, int Cin, int Cout) {
   if (!c3rs_shape_ok(n, H, W, Cin, Cout)) return false;
   const long long tiles = ((long long)n * (H + 1) * (W + 1) + 31) / 32;
   return (g_dbg_flags & 0x800) ? true : tiles >= min_tiles;
+}
+static bool c3rs_wgrad_covers(int n, int H, int W, int Cin, int Cout) {
+  if ((g_dbg_flags & 0x400) || !c3rs_wgrad_ok(n, H, W, Cin, Cout)) return false;
+  if (g_dbg_flags & 0x800) return true;
+  return c3rs_covers(n, H, W, 64, 64);  // the same size threshold as the forward kernels
 }
 static int imgconv_min_images() {
   static int v = -1;
@@ -1111,6 +1121,17 @@ int mvk_conv3x3_wgrad(const float* X, const float* dY, float* dWref, int n, int 
       return dslab ? defer_push_plain(dWref, dslab, total, nz, total, mvk_stream(stream))
                    : colsum_finish_any(ws, nz, (int)total, dWref, mvk_stream(stream));
     if (rc != 1) return rc;
+  }
+  if (n > 0 && mvk_aligned16(X) && mvk_aligned16(dY) && c3rs_wgrad_covers(n, H, W, Cin, Cout)) {
+    const int types = (Cin / 64) * (Cout / 64), workers = 256 / types;
+    const long long slab_floats = (long long)workers * 9 * Cin * Cout;
+    float* dslab = defer_scratch(dWref, slab_floats, mvk_stream(stream));
+    if (dslab || (ws && ws_floats >= slab_floats && mvk_aligned16(ws))) {
+      int nz = 0;
+      const int rc = c3rs_wgrad(X, dY, dslab ? dslab : ws, slab_floats, n, H, W, Cin, Cout, &nz, mvk_stream(stream));
+      if (rc == MVK_OK) return convref_reduce(dslab ? dslab : ws, nz, Cin, Cout, 9, dWref, mvk_stream(stream), dslab != nullptr);
+      return rc == 1 ? MVK_EINVAL : rc;  // covered shapes never decline
+    }
   }
   GemmDesc d{};
   d.a = AOperand{};
