@@ -42,7 +42,8 @@ struct C3Args {
   const float* act_src;  // tensor of the output's shape whose activation derivative multiplies the result, or null
   const float* res;      // residual of the output's shape: Y = res + res_alpha * result, or null
   float* colsum_part;    // [workers][COUT] per-workgroup column sums of the result (before the residual), or null
-  float* trash;          // >= 64 floats: where the stores of dropped rows go (no branch in the epilogue)
+  float* trash;          // unused (dropped rows are out-of-range buffer stores)
+  unsigned xbytes, ybytes;  // sizes of X and of Y / act_src / res in bytes (< 2^32 - 4096): buffer bounds
   int n, H, W;
   float aslope, mslope;  // negative-side slopes of the output activation (1 = none) and of the mask (src_act)
   float res_alpha;
@@ -67,6 +68,7 @@ struct C3Cfg {
   static constexpr int XWAVE = (KSPLIT - 1) * OWN * 64 * 4;
   static constexpr int XBUF = 4 * XWAVE;
   static constexpr int PTAB_INTS = 16 * 32;
+  static constexpr int MAXD = CIN == 64 ? 3 : 1;     // largest window reach (chunks) whose ring fits the LDS (W <= 94 / W <= 30)
   static_assert(KALL % KPW == 0 && ROLES % 4 == 0 && 4 % KSPLIT == 0, "roles");
   static_assert((S / 16) % 2 == 1, "odd 16-byte stride: conflict-free fragments");
   __host__ __device__ static constexpr int lds_bytes(int ring) { return ring * S + 2 * XBUF + PTAB_INTS * 4 + 4 * 32 * 4; }
@@ -165,17 +167,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   // A loaded value is first touched ONE TILE after its load was issued (the zero positions are selected at conversion
   // time, not at load time): with one wave per SIMD a wait on a fresh load stalls the matrix pipe for a memory latency.
+  // Every global access is a raw buffer operation with a 32-bit byte offset: pixel index -1 (a zero position, or a row that
+  // must not be stored) gives an offset beyond the buffer's size, where loads return 0 and stores are dropped — no
+  // selects, no 64-bit address arithmetic and no branches in the loop.
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)g.X, 0, (int)g.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)g.Y, 0, (int)g.ybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsM =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_SRC ? g.act_src : g.Y), 0, (int)g.ybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_RES ? g.res : g.Y), 0, (int)g.ybytes, 0x00020000);
   f32x4 raw[T::NF4];
-  int rawpix[T::NF4];
   auto unit_pix = [&](int c, int k) { return ptab[(c & 15) * 32 + spos[k]]; };
   auto load_unit_at = [&](int pix, int k) {
-    rawpix[k] = pix;
-    raw[k] = *reinterpret_cast<const f32x4*>(g.X + (long long)(pix < 0 ? 0 : pix) * CIN + sc4[k]);
+    raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (unsigned)pix * (CIN * 4u) + sc4[k] * 4u, 0, 0));
   };
   auto load_unit = [&](int c, int k) { load_unit_at(unit_pix(c, k), k); };
-  auto write_unit = [&](int wbase, int k) {  // wbase = byte offset of the chunk's first slot
-    const bool z = rawpix[k] < 0;
-    const float r0 = z ? 0.f : raw[k][0], r1 = z ? 0.f : raw[k][1], r2 = z ? 0.f : raw[k][2], r3 = z ? 0.f : raw[k][3];
+  auto write_vals = [&](int wbase, int k, const f32x4& v) {  // wbase = byte offset of the chunk's first slot
+    const float r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3];
     unsigned a0, a1, a2, b0, b1, b2;
     bf3_split(r0, r1, a0, a1, a2);
     bf3_split(r2, r3, b0, b1, b2);
@@ -184,6 +191,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     *reinterpret_cast<u32x2*>(d + 2 * CIN) = u32x2{a1, b1};
     *reinterpret_cast<u32x2*>(d + 4 * CIN) = u32x2{a2, b2};
   };
+  auto write_unit = [&](int wbase, int k) { write_vals(wbase, k, raw[k]); };
   auto chunk_slot = [&](int c) { return (((c % NCH) + NCH) % NCH) * 32 * T::S; };
 
   // ---- prologue: table entries T0-D .. T0+D+2, chunks T0-D .. T0+D in the ring, chunk T0+D+1 in registers ---------------
@@ -191,19 +199,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int c = T0 - D; c <= T0 + D + 2; ++c) ptab_store();
   }
   __syncthreads();
-  if (NT > 0) {
-    for (int c = T0 - D; c <= T0 + D; ++c) {
-      const int wb = chunk_slot(c);
+  if (NT > 0) {  // all loads of the 2 D + 1 start-up chunks in flight at once (one memory latency, not 2 D + 1)
+    constexpr int MAXCH = T::MAXD * 2 + 1;
+    f32x4 praw[MAXCH][T::NF4];
 #pragma unroll
-      for (int k = 0; k < T::NF4; ++k) load_unit(c, k);
+    for (int u = 0; u < MAXCH; ++u)
+      if (u < 2 * D + 1) {
 #pragma unroll
-      for (int k = 0; k < T::NF4; ++k) write_unit(wb, k);
-    }
+        for (int k = 0; k < T::NF4; ++k)
+          praw[u][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                     rsX, (unsigned)unit_pix(T0 - D + u, k) * (CIN * 4u) + sc4[k] * 4u, 0, 0));
+      }
 #pragma unroll
     for (int k = 0; k < T::NF4; ++k) load_unit(T0 + D + 1, k);
+#pragma unroll
+    for (int u = 0; u < MAXCH; ++u)
+      if (u < 2 * D + 1) {
+        const int wb = chunk_slot(T0 - D + u);
+#pragma unroll
+        for (int k = 0; k < T::NF4; ++k) write_vals(wb, k, praw[u][k]);
+      }
   }
   __syncthreads();
 
+  // column sums (the bias gradient of the layer below) exist in the backward-data form only: mask, no residual
+  constexpr bool WITH_CSUM = HAS_SRC && !HAS_RES;
   const float bias = g.bias ? g.bias[ncol] : 0.f;
   const float aslope = g.aslope, mslope = g.mslope, alpha = g.res_alpha;
   float csum = 0.f;
@@ -217,15 +237,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int j = 0; j < NTAPW; ++j) {
       const int tap = TAP_LO + j;
-      delta[j] = (tap / 3 - 1) * W1 + (tap % 3 - 1) + RING;
+      delta[j] = ((tap / 3 - 1) * W1 + (tap % 3 - 1) + RING) * T::S;  // bytes: slot * S is never multiplied in the loop
     }
-    auto frag_base = [&](int (&ab)[NTAPW], int tb) {  // byte offsets of this lane's A rows of the tile whose first slot is tb
+    const unsigned RINGB = (unsigned)RING * T::S;
+    const int colB = col * T::S;
+    auto frag_base = [&](int (&ab)[NTAPW], int tb) {  // byte offsets of this lane's A rows of the tile whose first slot is at byte tb
 #pragma unroll
       for (int j = 0; j < NTAPW; ++j) {
-        unsigned s = (unsigned)(tb + col + delta[j]);
-        s = min(s, s - (unsigned)RING);
-        s = min(s, s - (unsigned)RING);
-        ab[j] = (int)s * T::S + kg * 16;
+        unsigned s = (unsigned)(tb + colB + delta[j]);
+        s = min(s, s - RINGB);
+        s = min(s, s - RINGB);
+        ab[j] = (int)s + kg * 16;
       }
     };
     auto read_pair = [&](bf16x8 (&dst)[2][3], const int (&ab)[NTAPW], int pr) {
@@ -294,26 +316,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int o = 0; o < T::OWN; ++o) pix[P][o] = ptab[tabrow * 32 + rrow[o]];
     };
     auto fetch_row = [&](int P, int o) {  // mask / residual of row o (issued one tile before they are consumed)
-      const long long off = (long long)(pix[P][o] < 0 ? 0 : pix[P][o]) * COUT + ncol;
-      if (HAS_SRC) msk[P][o] = g.act_src[off];
-      if (HAS_RES) rr[P][o] = g.res[off];
+      const unsigned off = (unsigned)pix[P][o] * (COUT * 4u) + ncol * 4u;
+      if (HAS_SRC) msk[P][o] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsM, off, 0, 0));
+      if (HAS_RES) rr[P][o] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, off, 0, 0));
     };
     auto epilogue_row = [&](int Q, int o, bool valid) {  // Q: the parity whose fetch belongs to the tile in res_prev
       float v = res_prev[o] + bias;
       v = v > 0.f ? v : v * aslope;
       if (HAS_SRC) v = msk[Q][o] > 0.f ? v : v * mslope;
       const int px_ = valid ? pix[Q][o] : -1;
-      csum += px_ < 0 ? 0.f : v;
+      if (WITH_CSUM) csum += px_ < 0 ? 0.f : v;
       if (HAS_RES) v = fmaf(alpha, v, rr[Q][o]);
-      float* dst = px_ < 0 ? g.trash + lane : g.Y + (long long)px_ * COUT + ncol;
-      *dst = v;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY, (unsigned)px_ * (COUT * 4u) + ncol * 4u, 0, 0);
     };
     auto rotate = [&]() {
 #pragma unroll
       for (int o = 0; o < T::OWN; ++o) res_prev[o] = res_next[o];
     };
 
-    int tb = (int)(((long long)32 * T0) % RING);       // first ring slot of tile T
+    int tb = (int)(((long long)32 * T0) % RING) * T::S;  // first ring slot of tile T, in bytes
     int wch = (((T0 + D + 1) % NCH) + NCH) % NCH;       // ring chunk that chunk T+D+1 goes to
     int ab_cur[NTAPW], ab_nxt[NTAPW];
     bf16x8 a_cur[2][3];
@@ -327,8 +348,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const bool valid2 = t >= 2;
       char* const xb = xbase + P * T::XBUF;
       const int wbase = wch * 32 * T::S;
-      int tbn = tb + 32;
-      tbn = tbn >= RING ? tbn - RING : tbn;
+      int tbn = tb + 32 * T::S;
+      tbn = tbn >= (int)RINGB ? tbn - (int)RINGB : tbn;
       f32x16 acc0 = {0}, acc1 = {0};
       int upix[T::NF4];
 #pragma unroll
@@ -423,7 +444,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   else if (T::KSPLIT > 2 && ks_u == 2) run(std::integral_constant<int, (T::KSPLIT > 2 ? 2 : 0)>{});
   else if (T::KSPLIT > 3) run(std::integral_constant<int, (T::KSPLIT > 3 ? 3 : 0)>{});
 
-  if (g.colsum_part) {  // fixed-order sum over the lanes / waves that share a column
+  if (WITH_CSUM && g.colsum_part) {  // fixed-order sum over the lanes / waves that share a column
     csum += __shfl_xor(csum, 32, 64);
     __syncthreads();
     if (kg == 0) csred[wave * 32 + col] = csum;
@@ -488,6 +509,7 @@ struct C3WArgs {
   float* slab;      // [workers][9 Cin][Cout]
   int n, H, W, Cin, Cout;
   int ring, D, tiles;
+  unsigned xbytes, ybytes;  // sizes of X / dY in bytes (< 2^32 - 8192)
   mvk_prof_slot* prof;
 };
 
@@ -566,18 +588,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     sc4[k] = (f % 16) * 4;
     soff[k] = spos[k] * S + (f % 16) * 8;
   }
+  // raw buffer loads with 32-bit byte offsets: pixel index -1 (a zero position) is out of range and reads as 0
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)g.X, 0, (int)g.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)g.dY, 0, (int)g.ybytes, 0x00020000);
+  const unsigned xrow = g.Cin * 4u, yrow = g.Cout * 4u;
+  const unsigned xcol[2] = {(ci0 + sc4[0]) * 4u, (ci0 + sc4[1]) * 4u}, ycol[2] = {(co0 + sc4[0]) * 4u, (co0 + sc4[1]) * 4u};
   f32x4 raw[4];
-  int rawpix[4];
   auto unit_pix = [&](int chunk, int k) { return ptab[(chunk & 15) * 32 + spos[k & 1]]; };
-  auto load_unit_at = [&](int pix, int k) {
-    rawpix[k] = pix;
-    const long long pc = pix < 0 ? 0 : pix;
-    raw[k] = k < 2 ? *reinterpret_cast<const f32x4*>(g.X + pc * g.Cin + ci0 + sc4[k & 1])
-                   : *reinterpret_cast<const f32x4*>(g.dY + pc * g.Cout + co0 + sc4[k & 1]);
+  auto load_x = [&](int pix, int k) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (unsigned)pix * xrow + xcol[k & 1], 0, 0));
   };
-  auto write_unit = [&](char* base, int k) {  // base: first slot of the chunk (ring) / of the buffer (dY)
-    const bool z = rawpix[k] < 0;
-    const float r0 = z ? 0.f : raw[k][0], r1 = z ? 0.f : raw[k][1], r2 = z ? 0.f : raw[k][2], r3 = z ? 0.f : raw[k][3];
+  auto load_unit_at = [&](int pix, int k) {
+    raw[k] = k < 2 ? load_x(pix, k)
+                   : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsD, (unsigned)pix * yrow + ycol[k & 1], 0, 0));
+  };
+  auto write_vals = [&](char* base, int k, const f32x4& v) {  // base: first slot of the chunk (ring) / buffer (dY)
+    const float r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3];
     unsigned a0, a1, a2, b0, b1, b2;
     bf3_split(r0, r1, a0, a1, a2);
     bf3_split(r2, r3, b0, b1, b2);
@@ -586,6 +612,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     *reinterpret_cast<u32x2*>(d + 128) = u32x2{a1, b1};
     *reinterpret_cast<u32x2*>(d + 256) = u32x2{a2, b2};
   };
+  auto write_unit = [&](char* base, int k) { write_vals(base, k, raw[k]); };
   auto chunk_slot = [&](int ch) { return (((ch % NCH) + NCH) % NCH) * 32 * S; };
 
   // ---- prologue -------------------------------------------------------------------------------------------------------------
@@ -593,15 +620,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int ch = T0 - D; ch <= T0 + D + 2; ++ch) ptab_store();
   }
   __syncthreads();
-  if (NT > 0) {
-    for (int ch = T0 - D; ch <= T0 + D; ++ch) {
+  if (NT > 0) {  // all start-up loads in flight at once
+    f32x4 praw[7][2];
 #pragma unroll
-      for (int k = 0; k < 2; ++k) load_unit_at(unit_pix(ch, k), k);
+    for (int u = 0; u < 7; ++u)
+      if (u < 2 * D + 1) {
 #pragma unroll
-      for (int k = 0; k < 2; ++k) write_unit(ringp + chunk_slot(ch), k);
-    }
+        for (int k = 0; k < 2; ++k) praw[u][k] = load_x(unit_pix(T0 - D + u, k), k);
+      }
 #pragma unroll
     for (int k = 2; k < 4; ++k) load_unit_at(unit_pix(T0, k), k);
+#pragma unroll
+    for (int u = 0; u < 7; ++u)
+      if (u < 2 * D + 1) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) write_vals(ringp + chunk_slot(T0 - D + u), k, praw[u][k]);
+      }
 #pragma unroll
     for (int k = 2; k < 4; ++k) write_unit(dyp, k);  // tile T0 -> buffer 0
 #pragma unroll
@@ -627,21 +661,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int j = 0; j < 9; ++j) acc[j] = f32x16{0};
 
-  int tb = (int)(((long long)32 * T0) % RING);
+  int tb = (int)(((long long)32 * T0) % RING) * S;  // first slot of tile T, in bytes
   int wch = (((T0 + D + 1) % NCH) + NCH) % NCH;
 
   // fragment addresses of one kernel row (dy) of k-step s of the tile whose first slot is tbv: [dx][4-position half]
-  auto row_addr = [&](int (&ad)[3][2], int tbv, int s, int dy) {
-    unsigned q = (unsigned)(tbv + s * 16 + kbase + dy * W1 - 1 + RING);
-    q = min(q, q - (unsigned)RING);
-    q = min(q, q - (unsigned)RING);
+  // (all in BYTES: slot * S never multiplied in the loop)
+  const unsigned RINGB = (unsigned)RING * S;
+  const int laneB = kbase * S + (int)RINGB;
+  auto row_addr = [&](int (&ad)[3][2], int tbv, int s, int dy) {  // tbv: first slot of the tile, in bytes
+    unsigned q = (unsigned)(tbv + laneB + (s * 16 + dy * W1 - 1) * S);
+    q = min(q, q - RINGB);
+    q = min(q, q - RINGB);
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        unsigned r = q + dx + 4 * t;
-        r = min(r, r - (unsigned)RING);
-        ad[dx][t] = (int)r * S + a_ch;
+        unsigned r = q + (dx + 4 * t) * S;
+        r = min(r, r - RINGB);
+        ad[dx][t] = (int)r + a_ch;
       }
   };
   auto read_row = [&](bf16x8 (&A)[3][3], const int (&ad)[3][2]) {
@@ -669,8 +706,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const char* const nbuf_r = dyp + ((t + 1) & 1) * 32 * S;
     char* const nbuf_w = dyp + ((t + 1) & 1) * 32 * S;
     char* const xw = ringp + wch * 32 * S;
-    int tbn = tb + 32;
-    tbn = tbn >= RING ? tbn - RING : tbn;
+    int tbn = tb + 32 * S;
+    tbn = tbn >= (int)RINGB ? tbn - (int)RINGB : tbn;
     int upix[4];
 #pragma unroll
     for (int step = 0; step < 6; ++step) {  // (k-step, kernel row)
@@ -738,9 +775,9 @@ bool c3rs_wgrad_ok(int n, int H, int W, int Cin, int Cout) {
   const int types = (Cin / 64) * (Cout / 64);
   if (types > 16) return false;
   const long long total = (long long)n * (H + 1) * (W + 1);
-  if (total >= (1ll << 31) - 64 || (long long)n * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 40)) return false;
+  if (total >= (1ll << 31) - 64 || (long long)n * H * W * (Cin > Cout ? Cin : Cout) * 4 >= (1ll << 32) - 8192) return false;
   const int D = (W + 2 + 31) / 32;
-  if ((H + 1) * (W + 1) < 32 * D || 32 / (W + 1) + 1 > H + 1) return false;
+  if ((H + 1) * (W + 1) < 32 * D || 32 / (W + 1) + 1 > H + 1 || D > 3) return false;
   return c3w_lds_bytes(c3_ring(W)) <= 160 * 1024;
 }
 
@@ -760,7 +797,8 @@ int c3rs_wgrad(const float* X, const float* dY, float* slab, long long slab_floa
     attr_done = true;
   }
   const long long total = (long long)n * (H + 1) * (W + 1);
-  C3WArgs a{X, dY, slab, n, H, W, Cin, Cout, ring, (W + 2 + 31) / 32, (int)((total + 31) / 32), nullptr};
+  C3WArgs a{X, dY, slab, n, H, W, Cin, Cout, ring, (W + 2 + 31) / 32, (int)((total + 31) / 32),
+            (unsigned)((long long)n * H * W * Cin * 4), (unsigned)((long long)n * H * W * Cout * 4), nullptr};
   a.prof = prof_next(8, 2.0 * n * H * W * 9.0 * Cin * Cout);
   *nz = workers;
   hipLaunchKernelGGL(c3wg_kernel, dim3(grid), dim3(256), lds, s, a);
@@ -789,9 +827,11 @@ static int c3_ring(int W) {
 bool c3rs_shape_ok(int n, int H, int W, int Cin, int Cout) {
   if (n <= 0 || H < 4 || W < 4 || W > 96) return false;
   const long long total = (long long)n * (H + 1) * (W + 1);
-  if (total >= (1ll << 31) - 64 || (long long)n * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 40)) return false;
+  // 32-bit byte offsets into X / Y; offset (unsigned)(-1) * 4 C must stay out of range
+  if (total >= (1ll << 31) - 64 || (long long)n * H * W * (Cin > Cout ? Cin : Cout) * 4 >= (1ll << 32) - 8192) return false;
   const int D = (W + 2 + 31) / 32;
   if ((H + 1) * (W + 1) < 32 * D) return false;   // the table's start-up shift by one image block
+  if (D > (Cin == 64 ? 3 : 1)) return false;      // C3Cfg::MAXD
   if (32 / (W + 1) + 1 > H + 1) return false;     // one wrap per 32-position step of the incremental (image, row, column)
   return c3_lds_bytes(Cin, Cout, c3_ring(W)) <= 160 * 1024;
 }
@@ -800,16 +840,20 @@ bool c3rs_shape_ok(int n, int H, int W, int Cin, int Cout) {
 int c3rs_conv(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
               const float* act_src, int src_act, const float* res, float res_alpha, float* colsum_part, int* part_rows,
               float* trash, hipStream_t s) {
-  if (act == MVK_ACT_SIGMOID || (act_src && src_act == MVK_ACT_SIGMOID) || !trash || !mvk_aligned16(X)) return 1;
+  if (act == MVK_ACT_SIGMOID || (act_src && src_act == MVK_ACT_SIGMOID) || !mvk_aligned16(X)) return 1;
+  if (colsum_part && (!act_src || res)) return 1;  // column sums: backward-data form only (WITH_CSUM)
   if (!c3rs_shape_ok(n, H, W, Cin, Cout)) return 1;
   const long long total = (long long)n * (H + 1) * (W + 1);
-  C3Args a{X, Wp, bias, Y, act_src, res, colsum_part, trash, n, H, W, c3_slope(act), c3_slope(act_src ? src_act : MVK_ACT_NONE),
+  C3Args a{X, Wp, bias, Y, act_src, res, colsum_part, trash, (unsigned)((long long)n * H * W * Cin * 4),
+           (unsigned)((long long)n * H * W * Cout * 4), n, H, W, c3_slope(act), c3_slope(act_src ? src_act : MVK_ACT_NONE),
            res_alpha, c3_ring(W), (W + 2 + 31) / 32, (int)((total + 31) / 32), nullptr};
   if (Cin == 64 && Cout == 64) return c3rs_launch<64, 64>(a, part_rows, s);
+#ifndef MVK_C3_PROBE_ONLY  // variant builds of tools/conv3_variants.sh: one instantiation, short compiles
   if (Cin == 64 && Cout == 128) return c3rs_launch<64, 128>(a, part_rows, s);
   if (Cin == 128 && Cout == 64) return c3rs_launch<128, 64>(a, part_rows, s);
   if (Cin == 128 && Cout == 128) return c3rs_launch<128, 128>(a, part_rows, s);
   if (Cin == 128 && Cout == 256) return c3rs_launch<128, 256>(a, part_rows, s);
+#endif
   return 1;
 }
 

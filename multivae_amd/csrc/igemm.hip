@@ -1050,7 +1050,7 @@ static int conv3x3_any(const float* X, const float* Wp, const float* bias, float
     if (rc != 1) return rc;
   }
   if (n > 0 && ws && ws_floats >= 256ll * Cout + 64 && !(res && colsum_acc) && mvk_aligned16(X) && act != MVK_ACT_SIGMOID &&
-      !(y_act_src && y_src_act == MVK_ACT_SIGMOID) && c3rs_covers(n, H, W, Cin, Cout)) {
+      !(y_act_src && y_src_act == MVK_ACT_SIGMOID) && (!colsum_acc || y_act_src) && c3rs_covers(n, H, W, Cin, Cout)) {
     int rows = 0;
     float* dpart = colsum_acc ? defer_scratch(colsum_acc, 256ll * Cout, mvk_stream(stream)) : nullptr;
     const int rc = c3rs_conv(X, Wp, bias, Y, n, H, W, Cin, Cout, act, y_act_src, y_src_act, res, res_alpha,

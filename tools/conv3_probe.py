@@ -15,7 +15,10 @@ d = torch.device("cuda:0")
 lib = _lib.load()
 lib.mvk_debug_set_flags.argtypes = [ctypes.c_int]
 which = sys.argv[1] if len(sys.argv) > 1 else "cfg5"
-if which == "cfg5":
+if which == "one":  # the 64 -> 64 channel layers only (variant builds of tools/conv3_variants.sh)
+    n = 128
+    shapes = [(64, 64, 64), (32, 64, 64)]
+elif which == "cfg5":
     n = 128
     shapes = [(64, 64, 64), (32, 64, 64), (32, 64, 128), (32, 128, 64), (16, 128, 128), (16, 128, 256), (16, 256, 128)]
 else:
