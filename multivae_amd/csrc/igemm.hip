@@ -727,7 +727,7 @@ static bool c3rs_covers(int n, int H, int W, int Cin, int Cout) {
   static int min_tiles = -1;
   if (min_tiles < 0) {
     const char* e = mvk_tune("MVK_C3RS");
-    min_tiles = e ? atoi(e) : 1024;
+    min_tiles = e ? atoi(e) : 200;  // ~1 tile per worker: 15 us of start-up beat the tiled engine on a 50-us problem
     if (min_tiles == 0) min_tiles = 1 << 30;
   }
   if (g_dbg_flags & 0x400) return false;

@@ -114,15 +114,19 @@ class MMVAEPlus(BaseMultiVAE):
                                          *mus, *sds)
         mod_prior_std = {r: self._log_var_to_std(self.logvars_priors[r]) for r in mods}
 
-        def decode_all(r):  # every conditioning modality's latent through decoder r
-            outs = []
+        def decode_all(r):  # every conditioning modality's latent through decoder r: ONE pass over the M * K * B stacked rows
+            zins = []
             for ci, c in enumerate(mods):
                 if r == c:
                     zin = zs[ci]
                 else:
                     zin = kernels.MMVAEPlusCrossLatentFn.apply(zs[ci], mod_prior_std[r], cross_noise[(c, r)], L, family)
-                outs.append(self.decoders[r](zin.reshape(-1, D)).reconstruction)
-            return outs
+                zins.append(zin.reshape(-1, D))
+            # (the reference decodes every (conditioning, target) pair on its own, mmvaePlus_model.py:172-186: M^2 decoder passes
+            # of K * B rows; the rows are independent, so M passes of M * K * B rows give the same reconstructions with 1 / M of
+            # the launches and M times longer weight-gradient reductions per launch)
+            rec = self.decoders[r](torch.cat(zins, dim=0)).reconstruction
+            return list(rec.view(M, K * B, *rec.shape[1:]).unbind(0))
 
         dec = kernels.run_branches(self._branch_order(inputs, mods), decode_all, device)
         recons = [dec[r][c] for c in range(M) for r in mods]
