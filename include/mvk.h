@@ -401,6 +401,21 @@ int mvk_conv3x3_res(const float* X, const float* Wp, const float* bias, float* Y
                     float* ws, int64_t ws_floats, void* stream);
 int mvk_conv3x3_wgrad(const float* X, const float* dY, float* dWref, int n, int H, int W, int Cin, int Cout,
                       float* ws, int64_t ws_floats, void* stream);
+/* Fused forms of the three launches above, taken only by the register-stationary kernels (csrc/conv3rs.hip); they fold the
+ * elementwise passes of a ResnetBlock (models/nn/cub.py:274-280 `x_s + 0.1 * conv_1(actvn(conv_0(actvn(x))))`, mmnist.py:229-246)
+ * into the convolutions on either side:
+ *   mvk_conv3x3_fused_ok   1 when both fused launches take this problem (ask first: they return MVK_EINVAL otherwise)
+ *   mvk_conv3x3_f          Y = [res + res_alpha *] (act(pre_scale * conv(x_act(X)) + bias) * src_act'(y_act_src)): x_act is the
+ *                          activation of the layer that produced X, applied while X is staged (the activated tensor is never
+ *                          written); res may be NULL; colsum_acc as in mvk_conv3x3 (backward-data form, exclusive with res)
+ *   mvk_conv3x3_wgrad_f    dWref += dy_scale * sum_pos x_act(X)(gathered) dY and, when db != NULL, db[Cout] += dy_scale * sum_pos dY
+ *                          (the bias gradient without a pass of its own; dy_scale = the 0.1 of the residual branch) */
+int mvk_conv3x3_fused_ok(int n, int H, int W, int Cin, int Cout);
+int mvk_conv3x3_f(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout,
+                  int act, const float* y_act_src, int y_src_act, const float* res, float res_alpha, float* colsum_acc,
+                  int x_act, float pre_scale, float* ws, int64_t ws_floats, void* stream);
+int mvk_conv3x3_wgrad_f(const float* X, const float* dY, float* dWref, float* db, int n, int H, int W, int Cin, int Cout,
+                        int x_act, float dy_scale, float* ws, int64_t ws_floats, void* stream);
 /* nn.AvgPool2d(3, stride=2, padding=1) (count_include_pad: every window divides by 9) and nn.Upsample(scale_factor=2)
  * (nearest) on NHWC tensors, forward and backward; out = act(a*x + b*y) (x or y may be NULL). */
 int mvk_avgpool3s2_fwd(const float* x, float* y, int n, int H, int W, int C, void* stream);

@@ -82,6 +82,8 @@ PROTOTYPES = {
     "mvk_conv3x3": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i64, _p],
     "mvk_conv3x3_res": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _f, _p, _i64, _p],
     "mvk_conv3x3_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i64, _p],
+    "mvk_conv3x3_f": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _f, _p, _i, _f, _p, _i64, _p],
+    "mvk_conv3x3_wgrad_f": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _i64, _p],
     "mvk_avgpool3s2_fwd": [_p, _p, _i, _i, _i, _i, _p],
     "mvk_avgpool3s2_bwd": [_p, _p, _i, _i, _i, _i, _p],
     "mvk_upsample2_fwd": [_p, _p, _i, _i, _i, _i, _p],
@@ -151,6 +153,8 @@ def load(path=None):
         fn.restype = C.c_int
     lib.mvk_conv4s2_small_up_supported.argtypes = [_i, _i, _i, _i]
     lib.mvk_conv4s2_small_up_supported.restype = C.c_int
+    lib.mvk_conv3x3_fused_ok.argtypes = [_i, _i, _i, _i, _i]
+    lib.mvk_conv3x3_fused_ok.restype = C.c_int
     lib.mvk_defer_pending.argtypes = []
     lib.mvk_defer_pending.restype = C.c_int
     lib.mvk_prof_enable.argtypes = [_p, _i, _p, _p]
@@ -211,6 +215,8 @@ GEMM_FLOPS = {
     "mvk_conv3x3": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
     "mvk_conv3x3_res": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
     "mvk_conv3x3_wgrad": lambda a: 2.0 * a[3] * a[4] * a[5] * 9 * a[6] * a[7],
+    "mvk_conv3x3_f": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
+    "mvk_conv3x3_wgrad_f": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
     "mvk_conv4s2_up_nchw_small": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
     "mvk_conv4s2_small_up_fwd": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
     "mvk_conv4s2_small_down_fwd": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],

@@ -47,6 +47,8 @@ struct C3Args {
   int n, H, W;
   float aslope, mslope;  // negative-side slopes of the output activation (1 = none) and of the mask (src_act)
   float res_alpha;
+  float islope;          // negative-side slope of the activation applied to X while it is staged (1 = none)
+  float pre_scale;       // the convolution sum is multiplied by this before the bias (1 = none)
   int ring;              // LDS ring length in positions (multiple of 32, >= 32 (2 D + 2))
   int D;                 // reach of the window in 32-position chunks: ceil((W + 2) / 32)
   int tiles;             // ceil(n (H+1) (W+1) / 32)
@@ -181,8 +183,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (unsigned)pix * (CIN * 4u) + sc4[k] * 4u, 0, 0));
   };
   auto load_unit = [&](int c, int k) { load_unit_at(unit_pix(c, k), k); };
+  const float islope = g.islope;
   auto write_vals = [&](int wbase, int k, const f32x4& v) {  // wbase = byte offset of the chunk's first slot
-    const float r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3];
+    // the activation of the layer that produced X, applied on the way into LDS (X is then stored before its activation)
+    const float r0 = v[0] > 0.f ? v[0] : v[0] * islope, r1 = v[1] > 0.f ? v[1] : v[1] * islope;
+    const float r2 = v[2] > 0.f ? v[2] : v[2] * islope, r3 = v[3] > 0.f ? v[3] : v[3] * islope;
     unsigned a0, a1, a2, b0, b1, b2;
     bf3_split(r0, r1, a0, a1, a2);
     bf3_split(r2, r3, b0, b1, b2);
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // column sums (the bias gradient of the layer below) exist in the backward-data form only: mask, no residual
   constexpr bool WITH_CSUM = HAS_SRC && !HAS_RES;
   const float bias = g.bias ? g.bias[ncol] : 0.f;
-  const float aslope = g.aslope, mslope = g.mslope, alpha = g.res_alpha;
+  const float aslope = g.aslope, mslope = g.mslope, alpha = g.res_alpha, pre_scale = g.pre_scale;
   float csum = 0.f;
 
   // ---- main loop, instantiated per tap-split rank (every "is this my slice" test is a compile-time fact) ----------------
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if (HAS_RES) rr[P][o] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, off, 0, 0));
     };
     auto epilogue_row = [&](int Q, int o, bool valid) {  // Q: the parity whose fetch belongs to the tile in res_prev
-      float v = res_prev[o] + bias;
+      float v = fmaf(res_prev[o], pre_scale, bias);
       v = v > 0.f ? v : v * aslope;
       if (HAS_SRC) v = msk[Q][o] > 0.f ? v : v * mslope;
       const int px_ = valid ? pix[Q][o] : -1;
@@ -507,6 +512,9 @@ struct C3WArgs {
   const float* X;   // [n][H][W][Cin]
   const float* dY;  // [n][H][W][Cout]
   float* slab;      // [workers][9 Cin][Cout]
+  float* dbpart;    // [workers][Cout] column sums of dY (x dy_scale): the bias gradient, or null
+  float islope;     // negative-side slope of the activation applied to X while it is staged (1 = none)
+  float dy_scale;   // both results are multiplied by this (the 0.1 of a ResNet block's residual branch)
   int n, H, W, Cin, Cout;
   int ring, D, tiles;
   unsigned xbytes, ybytes;  // sizes of X / dY in bytes (< 2^32 - 8192)
@@ -602,8 +610,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     raw[k] = k < 2 ? load_x(pix, k)
                    : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsD, (unsigned)pix * yrow + ycol[k & 1], 0, 0));
   };
-  auto write_vals = [&](char* base, int k, const f32x4& v) {  // base: first slot of the chunk (ring) / buffer (dY)
-    const float r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3];
+  const float islope = g.islope;
+  f32x4 dysum[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // this thread's 4 channels of dY, summed over its positions
+  auto write_vals = [&](char* base, int k, const f32x4& v, float mine = 1.f) {  // base: first slot of the chunk (ring) / buffer (dY)
+    float r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3];
+    if (k < 2) {  // X: the activation of the layer that produced it, applied on the way into LDS
+      r0 = r0 > 0.f ? r0 : r0 * islope;
+      r1 = r1 > 0.f ? r1 : r1 * islope;
+      r2 = r2 > 0.f ? r2 : r2 * islope;
+      r3 = r3 > 0.f ? r3 : r3 * islope;
+    } else {  // mine = 0: the tile behind this workgroup's range (staged by the last iteration, summed by its owner)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dysum[k & 1][e] = fmaf(v[e], mine, dysum[k & 1][e]);
+    }
     unsigned a0, a1, a2, b0, b1, b2;
     bf3_split(r0, r1, a0, a1, a2);
     bf3_split(r2, r3, b0, b1, b2);
@@ -612,7 +631,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     *reinterpret_cast<u32x2*>(d + 128) = u32x2{a1, b1};
     *reinterpret_cast<u32x2*>(d + 256) = u32x2{a2, b2};
   };
-  auto write_unit = [&](char* base, int k) { write_vals(base, k, raw[k]); };
+  auto write_unit = [&](char* base, int k, float mine = 1.f) { write_vals(base, k, raw[k], mine); };
   auto chunk_slot = [&](int ch) { return (((ch % NCH) + NCH) % NCH) * 32 * S; };
 
   // ---- prologue -------------------------------------------------------------------------------------------------------------
@@ -726,7 +745,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if (step == 1) ptab_store();  // table row of chunk Tt + D + 3
       if (step >= 1 && step <= 4) {  // conversion of X chunk Tt+D+1 / dY tile Tt+1 (loaded one tile ago), next loads
         const int k = step - 1;
-        write_unit(k < 2 ? xw : nbuf_w, k);
+        write_unit(k < 2 ? xw : nbuf_w, k, t + 1 < NT ? 1.f : 0.f);
         load_unit_at(upix[k], k);
       }
       constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB_[6] = {2, 1, 0, 1, 0, 0};  // small terms first
@@ -764,8 +783,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ci = ci0 + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-      slab[((long long)j * g.Cin + ci) * g.Cout + co0 + c * 32 + col] = acc[j][r];
+      slab[((long long)j * g.Cin + ci) * g.Cout + co0 + c * 32 + col] = acc[j][r] * g.dy_scale;
     }
+  if (g.dbpart && ci0 == 0) {  // bias gradient: column sums of dY, added in a fixed order (thread groups of equal channels)
+    float* const red = reinterpret_cast<float*>(lds);  // the ring is dead behind the last barrier of the loop
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(red + tid * 4) = dysum[0] + dysum[1];
+    __syncthreads();
+    if (tid < 64) {
+      float sum = 0.f;
+      for (int j = 0; j < 16; ++j) sum += red[(j * 16 + (tid >> 2)) * 4 + (tid & 3)];
+      g.dbpart[(long long)worker * g.Cout + co0 + tid] = sum * g.dy_scale;
+    }
+  }
   mvk_prof_end(g.prof);
 }
 
@@ -782,8 +812,9 @@ bool c3rs_wgrad_ok(int n, int H, int W, int Cin, int Cout) {
 }
 
 // slab: [*nz][9 Cin][Cout] partial gradients (needs (256 / types) * 9 Cin Cout floats); 1: not covered
-int c3rs_wgrad(const float* X, const float* dY, float* slab, long long slab_floats, int n, int H, int W, int Cin, int Cout,
-               int* nz, hipStream_t s) {
+int c3rs_wgrad(const float* X, const float* dY, float* slab, long long slab_floats, float* dbpart, int x_act, float dy_scale,
+               int n, int H, int W, int Cin, int Cout, int* nz, hipStream_t s) {
+  if (x_act == MVK_ACT_SIGMOID) return 1;
   if (!c3rs_wgrad_ok(n, H, W, Cin, Cout) || !mvk_aligned16(X) || !mvk_aligned16(dY)) return 1;
   const int types = (Cin / 64) * (Cout / 64);
   const int grid = 256 / types * types, workers = grid / types;
@@ -797,7 +828,7 @@ int c3rs_wgrad(const float* X, const float* dY, float* slab, long long slab_floa
     attr_done = true;
   }
   const long long total = (long long)n * (H + 1) * (W + 1);
-  C3WArgs a{X, dY, slab, n, H, W, Cin, Cout, ring, (W + 2 + 31) / 32, (int)((total + 31) / 32),
+  C3WArgs a{X, dY, slab, dbpart, c3_slope(x_act), dy_scale, n, H, W, Cin, Cout, ring, (W + 2 + 31) / 32, (int)((total + 31) / 32),
             (unsigned)((long long)n * H * W * Cin * 4), (unsigned)((long long)n * H * W * Cout * 4), nullptr};
   a.prof = prof_next(8, 2.0 * n * H * W * 9.0 * Cin * Cout);
   *nz = workers;
@@ -839,14 +870,14 @@ bool c3rs_shape_ok(int n, int H, int W, int Cin, int Cout) {
 // 1: not covered (the caller falls back to the implicit-GEMM engine).  colsum_part: [256 / types][Cout] floats.
 int c3rs_conv(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
               const float* act_src, int src_act, const float* res, float res_alpha, float* colsum_part, int* part_rows,
-              float* trash, hipStream_t s) {
-  if (act == MVK_ACT_SIGMOID || (act_src && src_act == MVK_ACT_SIGMOID) || !mvk_aligned16(X)) return 1;
+              float* trash, int x_act, float pre_scale, hipStream_t s) {
+  if (act == MVK_ACT_SIGMOID || (act_src && src_act == MVK_ACT_SIGMOID) || x_act == MVK_ACT_SIGMOID || !mvk_aligned16(X)) return 1;
   if (colsum_part && (!act_src || res)) return 1;  // column sums: backward-data form only (WITH_CSUM)
   if (!c3rs_shape_ok(n, H, W, Cin, Cout)) return 1;
   const long long total = (long long)n * (H + 1) * (W + 1);
   C3Args a{X, Wp, bias, Y, act_src, res, colsum_part, trash, (unsigned)((long long)n * H * W * Cin * 4),
            (unsigned)((long long)n * H * W * Cout * 4), n, H, W, c3_slope(act), c3_slope(act_src ? src_act : MVK_ACT_NONE),
-           res_alpha, c3_ring(W), (W + 2 + 31) / 32, (int)((total + 31) / 32), nullptr};
+           res_alpha, c3_slope(x_act), pre_scale, c3_ring(W), (W + 2 + 31) / 32, (int)((total + 31) / 32), nullptr};
   if (Cin == 64 && Cout == 64) return c3rs_launch<64, 64>(a, part_rows, s);
 #ifndef MVK_C3_PROBE_ONLY  // variant builds of tools/conv3_variants.sh: one instantiation, short compiles
   if (Cin == 64 && Cout == 128) return c3rs_launch<64, 128>(a, part_rows, s);

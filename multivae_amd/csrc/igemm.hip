@@ -716,11 +716,11 @@ int imgconv_wgrad(const float* U, const float* V, float* slab, long long slab_fl
 // bit 0x800 takes them for every problem size (tests); MVK_C3RS=0 / MVK_C3RS=<min tiles> under MVK_TUNE=1.
 int c3rs_conv(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
               const float* act_src, int src_act, const float* res, float res_alpha, float* colsum_part, int* part_rows,
-              float* trash, hipStream_t s);
+              float* trash, int x_act, float pre_scale, hipStream_t s);
 bool c3rs_shape_ok(int n, int H, int W, int Cin, int Cout);
 bool c3rs_wgrad_ok(int n, int H, int W, int Cin, int Cout);
-int c3rs_wgrad(const float* X, const float* dY, float* slab, long long slab_floats, int n, int H, int W, int Cin, int Cout,
-               int* nz, hipStream_t s);
+int c3rs_wgrad(const float* X, const float* dY, float* slab, long long slab_floats, float* dbpart, int x_act, float dy_scale,
+               int n, int H, int W, int Cin, int Cout, int* nz, hipStream_t s);
 int convref_reduce(const float* slab, int nz, int Cu, int Cv, int taps, float* dWref, hipStream_t s, bool deferred);
 static bool c3rs_wgrad_covers(int n, int H, int W, int Cin, int Cout);
 static bool c3rs_covers(int n, int H, int W, int Cin, int Cout) {
@@ -1035,8 +1035,12 @@ int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U
 // The same launch is the backward-data pass when it is fed the output gradient and the flipped / transposed pack.
 static int conv3x3_any(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout,
                        int act, const float* y_act_src, int y_src_act, float* colsum_acc, const float* res, float res_alpha,
-                       float* ws, int64_t ws_floats, void* stream) {
+                       float* ws, int64_t ws_floats, void* stream, int x_act = MVK_ACT_NONE, float pre_scale = 1.f) {
+  const bool fused = x_act != MVK_ACT_NONE || pre_scale != 1.f;  // forms only the register-stationary kernels take
   if (!X || !Wp || !Y || n < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return MVK_EINVAL;
+  if (fused && !(n > 0 && ws && ws_floats >= 256ll * Cout + 64 && !(res && colsum_acc) && mvk_aligned16(X) &&
+                 (!colsum_acc || y_act_src) && c3rs_covers(n, H, W, Cin, Cout)))
+    return MVK_EINVAL;  // ask mvk_conv3x3_fused_ok first
   if (n > 0 && Cin <= 4 && !res) {  // the image-consuming layer (or the backward-data pass of the image-producing one)
     const int rc = conv3_smallcin(X, Wp, bias, Y, n, H, W, Cin, Cout, act, y_act_src, y_src_act, mvk_stream(stream));
     if (rc == MVK_OK && colsum_acc)
@@ -1054,7 +1058,8 @@ static int conv3x3_any(const float* X, const float* Wp, const float* bias, float
     int rows = 0;
     float* dpart = colsum_acc ? defer_scratch(colsum_acc, 256ll * Cout, mvk_stream(stream)) : nullptr;
     const int rc = c3rs_conv(X, Wp, bias, Y, n, H, W, Cin, Cout, act, y_act_src, y_src_act, res, res_alpha,
-                             colsum_acc ? (dpart ? dpart : ws) : nullptr, &rows, ws + 256ll * Cout, mvk_stream(stream));
+                             colsum_acc ? (dpart ? dpart : ws) : nullptr, &rows, ws + 256ll * Cout, x_act, pre_scale,
+                             mvk_stream(stream));
     if (rc == MVK_OK && dpart) return defer_push_plain(colsum_acc, dpart, Cout, rows, Cout, mvk_stream(stream));
     if (rc == MVK_OK && colsum_acc) return colsum_finish(ws, rows, Cout, colsum_acc, mvk_stream(stream));
     if (rc != 1) return rc;
@@ -1107,9 +1112,37 @@ int mvk_conv3x3_res(const float* X, const float* Wp, const float* bias, float* Y
                      stream);
 }
 
+// 1 when the fused forms mvk_conv3x3_f / mvk_conv3x3_wgrad_f take this problem (the register-stationary kernels cover both)
+int mvk_conv3x3_fused_ok(int n, int H, int W, int Cin, int Cout) {
+  return n > 0 && c3rs_covers(n, H, W, Cin, Cout) && c3rs_wgrad_covers(n, H, W, Cin, Cout) ? 1 : 0;
+}
+
+// Y = [res + res_alpha *] (act(pre_scale * conv(x_act(X)) + bias) * src_act'(y_act_src)); colsum_acc as in mvk_conv3x3
+int mvk_conv3x3_f(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
+                  const float* y_act_src, int y_src_act, const float* res, float res_alpha, float* colsum_acc, int x_act,
+                  float pre_scale, float* ws, int64_t ws_floats, void* stream) {
+  return conv3x3_any(X, Wp, bias, Y, n, H, W, Cin, Cout, act, y_act_src, y_src_act, colsum_acc, res, res_alpha, ws, ws_floats,
+                     stream, x_act, pre_scale);
+}
+
+static int conv3x3_wgrad_any(const float* X, const float* dY, float* dWref, float* db, int x_act, float dy_scale, int n, int H,
+                             int W, int Cin, int Cout, float* ws, int64_t ws_floats, void* stream);
+
+// dWref[Cout][Cin][3][3] += dy_scale * sum_pos x_act(X)(gathered) dY;  db[Cout] += dy_scale * sum_pos dY (db may be null)
+int mvk_conv3x3_wgrad_f(const float* X, const float* dY, float* dWref, float* db, int n, int H, int W, int Cin, int Cout,
+                        int x_act, float dy_scale, float* ws, int64_t ws_floats, void* stream) {
+  if (!mvk_conv3x3_fused_ok(n, H, W, Cin, Cout)) return MVK_EINVAL;
+  return conv3x3_wgrad_any(X, dY, dWref, db, x_act, dy_scale, n, H, W, Cin, Cout, ws, ws_floats, stream);
+}
+
 // dWref[Cout][Cin][3][3] += sum_pos X(gathered) dY
 int mvk_conv3x3_wgrad(const float* X, const float* dY, float* dWref, int n, int H, int W, int Cin, int Cout, float* ws,
                       int64_t ws_floats, void* stream) {
+  return conv3x3_wgrad_any(X, dY, dWref, nullptr, MVK_ACT_NONE, 1.f, n, H, W, Cin, Cout, ws, ws_floats, stream);
+}
+
+static int conv3x3_wgrad_any(const float* X, const float* dY, float* dWref, float* db, int x_act, float dy_scale, int n, int H,
+                             int W, int Cin, int Cout, float* ws, int64_t ws_floats, void* stream) {
   if (!X || !dY || !dWref || n < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return MVK_EINVAL;
   if (n > 0 && (Cin <= 4 || Cout <= 4)) {  // an image on one side: per-workgroup slabs in dWref order + ordered finish
     const long long total = 9ll * Cin * Cout;
@@ -1124,15 +1157,26 @@ int mvk_conv3x3_wgrad(const float* X, const float* dY, float* dWref, int n, int 
   }
   if (n > 0 && mvk_aligned16(X) && mvk_aligned16(dY) && c3rs_wgrad_covers(n, H, W, Cin, Cout)) {
     const int types = (Cin / 64) * (Cout / 64), workers = 256 / types;
-    const long long slab_floats = (long long)workers * 9 * Cin * Cout;
+    const long long slab_floats = (long long)workers * 9 * Cin * Cout, db_floats = db ? ((long long)workers * Cout + 3) & ~3ll : 0;
     float* dslab = defer_scratch(dWref, slab_floats, mvk_stream(stream));
-    if (dslab || (ws && ws_floats >= slab_floats && mvk_aligned16(ws))) {
+    float* dbslab = db ? defer_scratch(db, db_floats, mvk_stream(stream)) : nullptr;
+    const long long ws_need = (dslab ? 0 : slab_floats) + ((db && !dbslab) ? db_floats : 0);
+    if (ws_need == 0 || (ws && ws_floats >= ws_need && mvk_aligned16(ws))) {
+      float* wslab = dslab ? dslab : ws;
+      float* bslab = !db ? nullptr : (dbslab ? dbslab : ws + (dslab ? 0 : slab_floats));
       int nz = 0;
-      const int rc = c3rs_wgrad(X, dY, dslab ? dslab : ws, slab_floats, n, H, W, Cin, Cout, &nz, mvk_stream(stream));
-      if (rc == MVK_OK) return convref_reduce(dslab ? dslab : ws, nz, Cin, Cout, 9, dWref, mvk_stream(stream), dslab != nullptr);
-      return rc == 1 ? MVK_EINVAL : rc;  // covered shapes never decline
+      const int rc = c3rs_wgrad(X, dY, wslab, slab_floats, bslab, x_act, dy_scale, n, H, W, Cin, Cout, &nz, mvk_stream(stream));
+      if (rc != MVK_OK) return rc == 1 ? MVK_EINVAL : rc;  // covered shapes never decline
+      if (db) {
+        const int r = dbslab ? defer_push_plain(db, dbslab, Cout, nz, Cout, mvk_stream(stream))
+                             : colsum_finish_any(bslab, nz, Cout, db, mvk_stream(stream));
+        if (r != MVK_OK) return r;
+      }
+      return convref_reduce(wslab, nz, Cin, Cout, 9, dWref, mvk_stream(stream), dslab != nullptr);
     }
+    if (dslab || dbslab) return MVK_EINVAL;
   }
+  if (db || x_act != MVK_ACT_NONE || dy_scale != 1.f) return MVK_EINVAL;  // fused forms: register-stationary kernel only
   GemmDesc d{};
   d.a = AOperand{};
   d.a.p = X;

@@ -569,6 +569,33 @@ def conv3x3_wgrad(X, dY, wparam, n, H, W, Cin, Cout):
     return rw
 
 
+def conv3x3_fused_ok(n, H, W, Cin, Cout):
+    """True when mvk_conv3x3_f / mvk_conv3x3_wgrad_f (the register-stationary kernels) take this problem: the elementwise
+    passes of a ResnetBlock are then folded into the convolutions (ResnetStackFn)."""
+    return bool(_lib.load().mvk_conv3x3_fused_ok(n, H, W, Cin, Cout))
+
+
+def conv3x3_f(X, wpack, bias, n, H, W, Cin, Cout, act=NONE, y_act_src=None, y_src_act=NONE, res=None, res_alpha=1.0,
+              out_bias=None, x_act=NONE, pre_scale=1.0):
+    """Y = [res + res_alpha *] (act(pre_scale * conv(x_act(X)) + bias) * y_src_act'(y_act_src)); out_bias as in conv3x3."""
+    Y = _new((n, H, W, Cout), X)
+    ws = _ws(X)
+    tb, rb = _bias_target(out_bias)
+    call("mvk_conv3x3_f", ptr(X), ptr(wpack), ptr(bias), ptr(Y), n, H, W, Cin, Cout, act, ptr(y_act_src), y_src_act, ptr(res),
+         float(res_alpha), ptr(tb), x_act, float(pre_scale), ptr(ws), ws.numel(), stream_ptr())
+    return Y if out_bias is None else (Y, rb)
+
+
+def conv3x3_wgrad_f(X, dY, wparam, bparam, n, H, W, Cin, Cout, x_act=NONE, dy_scale=1.0):
+    """dW += dy_scale * sum x_act(X) (x) dY and (bparam given) db += dy_scale * sum dY, one launch.  -> (dW ref, db ref)"""
+    dw, rw = _grad_target(wparam)
+    tb, rb = _bias_target(bparam)
+    ws = _ws(X)
+    call("mvk_conv3x3_wgrad_f", ptr(X), ptr(dY), ptr(dw), ptr(tb), n, H, W, Cin, Cout, x_act, float(dy_scale), ptr(ws),
+         ws.numel(), stream_ptr())
+    return rw, rb
+
+
 def avgpool(x, n, H, W, C):
     y = _new((n, (H + 1) // 2, (W + 1) // 2, C), x)
     call("mvk_avgpool3s2_fwd", ptr(x), ptr(y), n, H, W, C, stream_ptr())
@@ -1035,10 +1062,18 @@ class ResnetStackFn(Function):
                 Chid, Cout = params[iw1].shape[0], params[iw2].shape[0]
                 b1 = params[ib1] if ib1 is not None else None
                 b2 = params[ib2] if ib2 is not None else None
+                # fused forms (register-stationary kernels): the leading LeakyReLU of a pre-activation block is applied while
+                # conv1 stages its input (a0 is never written) and the backward pass folds the 0.1 and the bias gradients
+                fused = (conv3x3_fused_ok(n, H, W, C, Chid) and conv3x3_fused_ok(n, H, W, Chid, Cout)
+                         and conv3x3_fused_ok(n, H, W, Cout, Chid))  # conv1, conv2 and conv2's backward-data launch
                 if order_ == "post":
                     a0 = h
                     a1 = conv3x3(a0, packs[iw1][0], b1, n, H, W, C, Chid, act=LEAKY)
                     y2 = conv3x3(a1, packs[iw2][0], b2, n, H, W, Chid, Cout, act=LEAKY)
+                elif fused:
+                    a0 = None
+                    a1 = conv3x3_f(h, packs[iw1][0], b1, n, H, W, C, Chid, act=LEAKY, x_act=LEAKY)
+                    y2 = None
                 else:
                     a0 = axpby(h, 1.0, None, 0.0, act=LEAKY)
                     a1 = conv3x3(a0, packs[iw1][0], b1, n, H, W, C, Chid, act=LEAKY)
@@ -1048,7 +1083,7 @@ class ResnetStackFn(Function):
                     out = conv3x3(a1, packs[iw2][0], b2, n, H, W, Chid, Cout, act=NONE, res=xs, res_alpha=0.1)
                 else:
                     out = axpby(xs, 1.0, y2, 0.1)
-                tape.append((h, a0, a1, y2, (H, W, C, Chid, Cout)))
+                tape.append((h, a0, a1, y2, (H, W, C, Chid, Cout), fused))
                 h, C = out, Cout
             elif op[0] == "pool":
                 y = avgpool(h, n, H, W, C)
@@ -1093,21 +1128,43 @@ class ResnetStackFn(Function):
                     g = conv3x3(dpre, packs[iw][1], None, n, H, W, Cout, C)
             elif op[0] == "block":
                 _, order_, iw1, ib1, iw2, ib2, isc = op
-                xin, a0, a1, y2, (H, W, C, Chid, Cout) = rec
+                xin, a0, a1, y2, (H, W, C, Chid, Cout), fused = rec
                 gout = g
-                d2 = axpby(gout, 0.1, None, 0.0)  # gradient w.r.t. y2
-                if order_ == "post":
-                    call("mvk_act_bwd", ptr(d2), ptr(y2), d2.numel(), LEAKY, stream_ptr())
-                grads[iw2] = conv3x3_wgrad(a1, d2, params[iw2], n, H, W, Chid, Cout)
-                if ib2 is not None:
-                    grads[ib2] = colsum(d2.view(-1, Cout), params[ib2])
-                # backward data of conv2 with lrelu'(a1) fused; its channel sums are conv1's bias gradient
-                if ib1 is not None:
-                    d1, grads[ib1] = conv3x3(d2, packs[iw2][1], None, n, H, W, Cout, Chid, y_act_src=a1, y_src_act=LEAKY,
-                                             out_bias=params[ib1])
+                if fused and order_ == "pre":
+                    # d2 = 0.1 * gout is never formed: the 0.1 rides on the weight / bias gradient and on the backward-data
+                    # sum; a0 = lrelu(x) is re-applied while the weight-gradient kernel stages x
+                    grads[iw2], gb2 = conv3x3_wgrad_f(a1, gout, params[iw2], params[ib2] if ib2 is not None else None, n, H, W,
+                                                      Chid, Cout, dy_scale=0.1)
+                    if ib2 is not None:
+                        grads[ib2] = gb2
+                    if ib1 is not None:
+                        d1, grads[ib1] = conv3x3_f(gout, packs[iw2][1], None, n, H, W, Cout, Chid, y_act_src=a1,
+                                                   y_src_act=LEAKY, out_bias=params[ib1], pre_scale=0.1)
+                    else:
+                        d1 = conv3x3_f(gout, packs[iw2][1], None, n, H, W, Cout, Chid, y_act_src=a1, y_src_act=LEAKY,
+                                       pre_scale=0.1)
+                    grads[iw1], _ = conv3x3_wgrad_f(xin, d1, params[iw1], None, n, H, W, C, Chid, x_act=LEAKY)
+                    a0 = xin  # sign(lrelu(x)) == sign(x): the mask source of dx below
                 else:
-                    d1 = conv3x3(d2, packs[iw2][1], None, n, H, W, Cout, Chid, y_act_src=a1, y_src_act=LEAKY)
-                grads[iw1] = conv3x3_wgrad(a0, d1, params[iw1], n, H, W, C, Chid)
+                    d2 = axpby(gout, 0.1, None, 0.0)  # gradient w.r.t. y2
+                    if order_ == "post":
+                        call("mvk_act_bwd", ptr(d2), ptr(y2), d2.numel(), LEAKY, stream_ptr())
+                    if fused:  # bias gradient with the weight gradient
+                        grads[iw2], gb2 = conv3x3_wgrad_f(a1, d2, params[iw2], params[ib2] if ib2 is not None else None, n, H,
+                                                          W, Chid, Cout)
+                        if ib2 is not None:
+                            grads[ib2] = gb2
+                    else:
+                        grads[iw2] = conv3x3_wgrad(a1, d2, params[iw2], n, H, W, Chid, Cout)
+                        if ib2 is not None:
+                            grads[ib2] = colsum(d2.view(-1, Cout), params[ib2])
+                    # backward data of conv2 with lrelu'(a1) fused; its channel sums are conv1's bias gradient
+                    if ib1 is not None:
+                        d1, grads[ib1] = conv3x3(d2, packs[iw2][1], None, n, H, W, Cout, Chid, y_act_src=a1, y_src_act=LEAKY,
+                                                 out_bias=params[ib1])
+                    else:
+                        d1 = conv3x3(d2, packs[iw2][1], None, n, H, W, Cout, Chid, y_act_src=a1, y_src_act=LEAKY)
+                    grads[iw1] = conv3x3_wgrad(a0, d1, params[iw1], n, H, W, C, Chid)
                 if isc is not None:
                     grads[isc], _ = linear_bwd_weight(gout.view(-1, Cout), xin.view(-1, C), params[isc].view(Cout, C), None)
                     if grads[isc] is not None:

@@ -153,7 +153,7 @@ def model_grads(model):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", MMVAEPLUS_RESNET_CASES)
-def test_mmvaeplus_resnet_golden_gpu(name):
+def test_mmvaeplus_resnet_golden_gpu(name, conv3_engine):
     from multivae_amd.data.datasets.base import DatasetOutput
 
     cfg, a = G.load_case(name)
@@ -185,9 +185,23 @@ def test_mmvaeplus_resnet_golden_gpu(name):
     G.check_grads(a, mg, rtol=5e-2, atol_frac=1e-2)  # 48 sampled entries + sums per tensor of the REFERENCE's gradients
 
 
+@pytest.fixture(params=["default dispatch", "register-stationary kernels"])
+def conv3_engine(request):
+    """As in test_gpu_golden.py: the size-based dispatch, then conv3rs.hip + the fused ResnetBlock forms for every size."""
+    import ctypes
+
+    from multivae_amd import _lib
+
+    lib = _lib.load()
+    lib.mvk_debug_set_flags.argtypes = [ctypes.c_int]
+    lib.mvk_debug_set_flags(0x800 if request.param != "default dispatch" else 0)
+    yield request.param
+    lib.mvk_debug_set_flags(0)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", JMVAE_CUB_CASES)
-def test_jmvae_cub_golden_gpu(name):
+def test_jmvae_cub_golden_gpu(name, conv3_engine):
     from multivae_amd.data.datasets.base import DatasetOutput
 
     cfg, a = G.load_case(name)

@@ -360,7 +360,22 @@ def test_mmvaeplus_encode_paths():
         MMVAEPlus(MMVAEPlusConfig(n_modalities=3, latent_dim=6, input_dims=dims))  # modalities_specific_dim missing
 
 
-def test_resnet_mmnist_nets_golden():
+@pytest.fixture(params=["default dispatch", "register-stationary kernels"])
+def conv3_engine(request):
+    """The ResNet goldens run twice: with the size-based dispatch (the tiled engine at these batch sizes) and with the
+    register-stationary 3x3 kernels + the fused ResnetBlock forms taken for every size (mvk_debug_set_flags 0x800)."""
+    import ctypes
+
+    from multivae_amd import _lib
+
+    lib = _lib.load()
+    lib.mvk_debug_set_flags.argtypes = [ctypes.c_int]
+    lib.mvk_debug_set_flags(0x800 if request.param != "default dispatch" else 0)
+    yield request.param
+    lib.mvk_debug_set_flags(0)
+
+
+def test_resnet_mmnist_nets_golden(conv3_engine):
     """EncoderResnetMMNIST / DecoderResnetMMNIST on the HIP kernels (3x3 convolutions, pooling, upsampling, residuals,
     one autograd node per stack) vs the reference golden and the oracle's full gradients."""
     from test_oracle_golden import resnet_case
@@ -405,7 +420,7 @@ def test_resnet_mmnist_nets_golden():
     assert dec(zz[0].detach()).reconstruction.shape == (cfg["B"], 3, 28, 28)  # 2-D latent input
 
 
-def test_resnet_cub_nets_golden():
+def test_resnet_cub_nets_golden(conv3_engine):
     """CUB_Resnet_Encoder / Decoder (64x64 images, pre-activation blocks, lrelu before the heads / the image conv) on the
     HIP kernels vs the reference golden and the oracle's full gradients; 3-D latents decode too."""
     from test_oracle_golden import resnet_cub_case

@@ -818,6 +818,56 @@ def test_conv3x3_register_stationary(K, n, H, W, Cin, Cout):
     close(Yt, nhwc(lrelu(conv).float()), what="default dispatch", rtol=3e-6)
 
 
+@pytest.mark.parametrize("n,H,W,Cin,Cout", [(3, 32, 32, 64, 64), (15, 16, 16, 128, 128), (20, 14, 14, 64, 128), (3, 7, 7, 128, 64)])
+def test_conv3x3_fused_forms(K, n, H, W, Cin, Cout):
+    """mvk_conv3x3_f / mvk_conv3x3_wgrad_f (csrc/conv3rs.hip): the activation of the producing layer applied while X is staged,
+    the 0.1 of the residual branch on the convolution sum / on both gradients, the bias gradient out of the weight-gradient
+    launch — against float64 torch.  Outside the covered problems the entry points refuse (MVK_EINVAL) instead of guessing."""
+    from multivae_amd import _lib
+
+    gen = g(59)
+    d = dev()
+    x = torch.randn(n, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) / (3 * Cin ** 0.5)
+    b = 0.1 * torch.randn(Cout, generator=gen)
+    res = torch.randn(n, Cout, H, W, generator=gen)
+    src = torch.randn(n, Cout, H, W, generator=gen)
+    dy = torch.randn(n, Cout, H, W, generator=gen)
+    nhwc = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(d)
+    (wf, _), = K.pack_weights([(w.to(d), "c3", True, True)])
+    assert not K.conv3x3_fused_ok(n, H, W, Cin, Cout)  # too small for the default dispatch
+    with pytest.raises(_lib.MvkError):
+        K.conv3x3_f(nhwc(x), wf, None, n, H, W, Cin, Cout, x_act=K.LEAKY)
+    _debug_flags(0x800)
+    try:
+        assert K.conv3x3_fused_ok(n, H, W, Cin, Cout)
+        ax = F.leaky_relu(x.double(), 0.2)
+        conv = F.conv2d(ax, w.double(), None, 1, 1)
+        Y = K.conv3x3_f(nhwc(x), wf, b.to(d), n, H, W, Cin, Cout, act=K.LEAKY, x_act=K.LEAKY)
+        close(Y, nhwc(F.leaky_relu(conv + b.double().view(1, -1, 1, 1), 0.2).float()), what="lrelu(conv(lrelu(x)) + b)", rtol=3e-6)
+        bparam = torch.zeros(Cout, device=d).requires_grad_(True)
+        bparam.grad = torch.zeros(Cout, device=d)
+        Y, _ = K.conv3x3_f(nhwc(x), wf, None, n, H, W, Cin, Cout, y_act_src=nhwc(src), y_src_act=K.LEAKY, out_bias=bparam,
+                           pre_scale=0.1)
+        ref = 0.1 * F.conv2d(x.double(), w.double(), None, 1, 1) * torch.where(src > 0, 1.0, 0.2).double()
+        close(Y, nhwc(ref.float()), what="0.1 * conv * act'(src)", rtol=3e-6)
+        close(bparam.grad, ref.sum((0, 2, 3)).float(), what="column sums", rtol=1e-5)
+        Y = K.conv3x3_f(nhwc(x), wf, b.to(d), n, H, W, Cin, Cout, res=nhwc(res), res_alpha=0.1, x_act=K.LEAKY)
+        close(Y, nhwc((res.double() + 0.1 * (conv + b.double().view(1, -1, 1, 1))).float()), what="res + 0.1 conv(lrelu(x))", rtol=3e-6)
+        w64 = w.double().requires_grad_(True)
+        F.conv2d(ax, w64, None, 1, 1).backward(0.1 * dy.double())
+        wparam = w.to(d).clone().requires_grad_(True)
+        wparam.grad = torch.zeros_like(wparam)
+        bparam.grad.zero_()
+        K.conv3x3_wgrad_f(nhwc(x), nhwc(dy), wparam, bparam, n, H, W, Cin, Cout, x_act=K.LEAKY, dy_scale=0.1)
+        close(wparam.grad, w64.grad.float(), what="0.1 * weight gradient with lrelu(x)", rtol=3e-6)
+        close(bparam.grad, (0.1 * dy.double().sum((0, 2, 3))).float(), what="bias gradient", rtol=1e-5)
+        K.conv3x3_wgrad_f(nhwc(x), nhwc(dy), wparam, None, n, H, W, Cin, Cout, x_act=K.LEAKY, dy_scale=0.1)
+        close(wparam.grad, 2 * w64.grad.float(), what="accumulates", rtol=3e-6)
+    finally:
+        _debug_flags(0)
+
+
 @pytest.mark.parametrize("n,H,W,Cin,Cout", [(3, 7, 7, 64, 128), (2, 16, 16, 128, 64), (1, 5, 9, 6, 10), (2, 8, 8, 3, 64)])
 def test_conv3x3_residual_epilogue(K, n, H, W, Cin, Cout):
     """mvk_conv3x3_res: res + alpha * (conv (+ bias, activation) * act'(mask source)) in the convolution's epilogue — the
