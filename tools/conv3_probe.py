@@ -15,6 +15,23 @@ d = torch.device("cuda:0")
 lib = _lib.load()
 lib.mvk_debug_set_flags.argtypes = [ctypes.c_int]
 which = sys.argv[1] if len(sys.argv) > 1 else "cfg5"
+if which == "prof":  # a few launches per kernel NAME (one shape each) for the counter passes of tools/conv3_pmc.sh
+    # kernel -> GFLOP per launch: tools/make_profiles.py C3_GFLOP
+    for n_, H_, Ci_, Co_, wg_ in [(128, 64, 64, 64, True), (128, 32, 64, 128, False), (128, 16, 128, 128, False),
+                                  (128, 16, 128, 256, False), (1600, 14, 128, 64, False)]:
+        x = torch.randn(n_, H_, H_, Ci_, device=d)
+        w = torch.randn(Co_, Ci_, 3, 3, device=d) / (3 * Ci_ ** 0.5)
+        b = torch.randn(Co_, device=d)
+        src = torch.randn(n_, H_, H_, Co_, device=d)
+        (wf, wb), = K.pack_weights([(w, "c3", True, True)])
+        wparam = w.clone().requires_grad_(True)
+        wparam.grad = torch.zeros_like(wparam)
+        for _ in range(5):
+            K.conv3x3(x, wf, b, n_, H_, H_, Ci_, Co_, act=K.LEAKY, y_act_src=src, y_src_act=K.LEAKY)
+            if wg_:
+                K.conv3x3_wgrad(x, src, wparam, n_, H_, H_, Ci_, Co_)
+        torch.cuda.synchronize()
+    sys.exit(0)
 if which == "one":  # the 64 -> 64 channel layers only (variant builds of tools/conv3_variants.sh)
     n = 128
     shapes = [(64, 64, 64), (32, 64, 64)]

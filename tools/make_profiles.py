@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/<TAG>/ (written by tools/gpu_profile_r02.sh on the GPU box) -> the tracked summaries under profiles/.
+"""gpurun_out/<TAG>/ (written by tools/gpu_profile_r0N.sh on the GPU box) -> the tracked summaries under profiles/.
 usage: python tools/make_profiles.py [TAG]"""
 import json
 import os
@@ -7,7 +7,9 @@ import re
 import subprocess
 import sys
 
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+ROUND = TAG[1:3].lstrip("0") or "0"
+COMMIT = open(f"gpurun_out/{TAG}/commit.txt").read().strip() if os.path.exists(f"gpurun_out/{TAG}/commit.txt") else "unrecorded"
 SRC, DST = f"gpurun_out/{TAG}", "profiles"
 run = lambda *a: subprocess.run([sys.executable, *a], capture_output=True, text=True).stdout
 
@@ -28,7 +30,7 @@ line = json_line(f"{SRC}/bench_under_rocprof.log")
 open(f"{DST}/{TAG}_bench_under_rocprof.json", "w").write(json.dumps(line, indent=1) + "\n")
 # 2. bench lines of every configuration
 with open(f"{DST}/{TAG}_bench_lines.jsonl", "w") as f:
-    for c in ("cfg3", "cfg3k1", "cfg2", "cfg2_laplace_dreg", "cfg5", "cfg4", "cfg4_b64_eager", "force_dist"):
+    for c in ("cfg3", "cfg3k1", "cfg2", "cfg2_laplace_dreg", "cfg5", "cfg4", "cfg4_b64_eager", "cfg4_b64", "force_dist"):
         p = f"{SRC}/bench_{c}.json"
         d = json_line(p) if os.path.exists(p) else None
         if d:
@@ -59,7 +61,7 @@ def parse(path):
 
 ctr = parse(f"{SRC}/pmc_conv.txt")
 with open(f"{DST}/{TAG}_pmc_mfma.md", "w") as f:
-    f.write(f"# Round 2 - SQ / LDS counters of the register-stationary convolution kernels (rocprofv3 --pmc, kernel-trace only)\n\n"
+    f.write(f"# Round {ROUND} - SQ / LDS counters of the register-stationary convolution kernels (rocprofv3 --pmc, kernel-trace only)\n\n"
             "Command (MI355X, tools/imgconv_pmc.sh = two PMC passes of `python tools/imgconv_probe.py prof new`: 5 launches of every\n"
             "kernel at the headline batch, n = 5120 images = K 10 x B 512):\n\n"
             "    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace ...\n"
@@ -96,10 +98,46 @@ with open(f"{DST}/{TAG}_pmc_mfma.md", "w") as f:
             "or the barrier of the kernels whose waves split the taps.  Start of round 2 (before the scheduling pipeline, the AGPR-resident\n"
             "weights and the two-tile-latency loop): 100 / 135 / 109 / 116 / 141 / 128 us, matrix pipe 46-70 % busy.\n")
 
+# 4b. the register-stationary 3x3 kernels (tools/conv3_pmc.sh: one shape per kernel name)
+C3_GFLOP = {"mvk::c3rs_kernel<64, 64, true, false>": (38.65, "64 -> 64 @64x64, n = 128"),
+            "mvk::c3rs_kernel<64, 128, true, false>": (19.33, "64 -> 128 @32x32, n = 128"),
+            "mvk::c3rs_kernel<128, 128, true, false>": (9.66, "128 -> 128 @16x16, n = 128"),
+            "mvk::c3rs_kernel<128, 256, true, false>": (19.33, "128 -> 256 @16x16, n = 128"),
+            "mvk::c3rs_kernel<128, 64, true, false>": (46.24, "128 -> 64 @14x14, n = 1600"),
+            "mvk::c3wg_kernel": (38.65, "weight gradient 64 x 64 @64x64, n = 128")}
+p3 = f"{SRC}/pmc_conv3.txt"
+if os.path.exists(p3):
+    c3 = parse(p3)
+    with open(f"{DST}/{TAG}_pmc_conv3.md", "w") as f:
+        f.write(f"# Round {ROUND} - SQ / LDS counters of the register-stationary 3x3 convolution kernels (csrc/conv3rs.hip)\n\n"
+                "Command (MI355X, tools/conv3_pmc.sh = two rocprofv3 --pmc passes, kernel-trace only, of `python tools/conv3_probe.py prof`:\n"
+                "5 launches per kernel name, one layer shape each; backward-data form = mask + column sums in the epilogue).\n"
+                "Counters per launch in millions (SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles); 1024 waves per launch.\n\n"
+                "| kernel | layer | us | GFLOP | TFLOP/s | cycles per wave | clock GHz | matrix pipe busy | issuing | issue-stalled | parked | VALU per MFMA | LDS bank-conflict share |\n"
+                "|---|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|\n")
+        for k, v in c3.items():
+            if "SQ_INSTS_MFMA" not in v or v["SQ_INSTS_MFMA"] == 0 or k not in C3_GFLOP:
+                continue
+            gf, what = C3_GFLOP[k]
+            cyc = v["SQ_WAVE_CYCLES"] * 4e6 / 1024
+            busy = v["SQ_VALU_MFMA_BUSY_CYCLES"] * 1e6 / 1024 / cyc
+            f.write(f"| {k} | {what} | {v['dur']:.1f} | {gf:.1f} | {gf / v['dur'] * 1e3:.0f} | {cyc / 1e3:.0f} k | {cyc / v['dur'] / 1e3:.2f} | "
+                    f"{100 * busy:.0f} % | {100 * v['SQ_ACTIVE_INST_ANY'] / v['SQ_WAVE_CYCLES']:.0f} % | "
+                    f"{100 * v['SQ_WAIT_INST_ANY'] / v['SQ_WAVE_CYCLES']:.0f} % | {100 * v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES']:.0f} % | "
+                    f"{v['SQ_INSTS_VALU'] / v['SQ_INSTS_MFMA']:.1f} | "
+                    f"{100 * v.get('SQ_LDS_BANK_CONFLICT', 0) / max(v.get('SQ_LDS_IDX_ACTIVE', 1), 1e-9):.0f} % |\n")
+        for c in ("cfg5", "cfg4"):
+            pp = f"{SRC}/conv3_probe_{c}.txt"
+            if os.path.exists(pp):
+                f.write(f"\nIsolated launches, `python tools/conv3_probe.py {c}` (HIP events around 10 launches incl. the Python call; tiled = the\n"
+                        "implicit-GEMM engine, debug flag 0x400; the weight-gradient time includes the ordered finish of its slabs):\n\n")
+                f.write("".join(ln for ln in open(pp) if ln.startswith("|") or ln.startswith("cfg")))
+    print(open(f"{DST}/{TAG}_pmc_conv3.md").read())
+
 # 5. HBM traffic
 fs, ws = parse(f"{SRC}/pmc_FETCH_SIZE.txt"), parse(f"{SRC}/pmc_WRITE_SIZE.txt")
 with open(f"{DST}/{TAG}_pmc_hbm.md", "w") as f:
-    f.write(f"# Round 2 - HBM traffic counters (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, kernel-trace only)\n\n"
+    f.write(f"# Round {ROUND} - HBM traffic counters (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, kernel-trace only)\n\n"
             "Command: `rocprofv3 --pmc <C> --kernel-trace -d ... -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline` (MoPoE MnistSvhn K=10 B=512).\n"
             "FETCH_SIZE is doubled (gfx950 reports half of the bytes of wide coalesced reads, MI355X_MICROARCH.md HBM section; calibrated\n"
             "on small_up_fwd_kernel, whose only input is the 167.8 MB tensor g3); WRITE_SIZE as reported.  Counter unit: KB.\n\n"
@@ -120,8 +158,9 @@ k = "recon_nll_kernel<1, true>"
 if k in fs and k in ws:
     rd, wr = int(2 * fs[k]["FETCH_SIZE"] * 1e6 * 1024), int(ws[k]["WRITE_SIZE"] * 1e6 * 1024)
     json.dump({"kernel": k, "workload": "MoPoE MnistSvhn K=10 B=512 (both modalities in one launch), bench.py default config",
-               "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), MI355X, round 2 "
-                         f"(tools/gpu_profile_r02.sh); summary profiles/{TAG}_pmc_hbm.md",
+               "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), MI355X, round {ROUND} "
+                         f"(tools/gpu_profile_{TAG}.sh); summary profiles/{TAG}_pmc_hbm.md",
+               "commit": COMMIT,
                "FETCH_SIZE_KB_avg": fs[k]["FETCH_SIZE"] * 1e6, "WRITE_SIZE_KB_avg": ws[k]["WRITE_SIZE"] * 1e6,
                "correction": "gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide coalesced read (MI355X_MICROARCH.md): doubled; "
                              "WRITE_SIZE as reported",
