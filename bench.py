@@ -490,6 +490,7 @@ def main():
             "config": {"workload": w["text"] + (", 1 RCCL all-reduce/step" if world > 1 else ""),
                        "baseline_config": args.config, "global_batch": world * B, "K": K, "parallelism": f"dp{world}",
                        "final_loss": round(loss, 4),
+                       "peak_device_memory_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
                        "launch": "hipGraph replay (fwd+bwd) + all-reduce + Adam" if graphed is not None else "eager"},
         }
         nll = summarise(recs, {"recon_nll"}, boundary)

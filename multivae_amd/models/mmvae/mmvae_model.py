@@ -72,9 +72,16 @@ class MMVAE(BaseMultiVAE):
         prior_std = self.log_var_to_std(self.prior_log_var)
         zs = kernels.MMVAELatentFn.apply(state, noises, masks, self.prior_mean.detach(), family, int(dreg), prior_std,
                                          *mus, *sds)
-        flats = [zs[c].reshape(-1, L) for c in range(M)]  # (K*B, L) like the reference (:127)
-        dec = kernels.run_branches(self._branch_order(inputs, mods),
-                                   lambda r: [self.decoders[r](flats[c]).reconstruction for c in range(M)], device)
+        # The reference decodes every (conditioning, target) pair on its own (:127: M^2 decoder passes of K * B rows); the
+        # rows are independent, so every decoder runs ONCE over the M * K * B stacked rows (the same reconstructions from
+        # 1 / M of the launches).
+        zall = torch.cat([zs[c].reshape(-1, L) for c in range(M)], dim=0) if M > 1 else zs[0].reshape(-1, L)
+
+        def decode_all(r):
+            rec = self.decoders[r](zall).reconstruction
+            return list(rec.view(M, K * B, *rec.shape[1:]).unbind(0))
+
+        dec = kernels.run_branches(self._branch_order(inputs, mods), decode_all, device)
         recons = [dec[r][c] for c in range(M) for r in mods]
         spec = self._recon_spec(mods, inputs.data, inputs.masks if masks is not None else None, K, B)
         loss = kernels.MMVAEObjectiveFn.apply(state, spec, M, dreg, *recons)
