@@ -31,6 +31,9 @@
 #ifndef MVK_C3_SCHED
 #define MVK_C3_SCHED 4  // "others" per MFMA of the scheduling pipeline (0 = hipcc's own order)
 #endif
+#ifndef MVK_C3_BAR
+#define MVK_C3_BAR 7    // the pair behind which the tile's barrier sits (6: one more pair of cover for what follows it)
+#endif
 
 namespace mvk {
 
@@ -372,9 +375,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // conversion of chunk Tt+D+1 (loaded one tile ago) + the loads of chunk Tt+D+2: done before the barrier behind pair 7
         {
           constexpr int STEP = T::NF4 == 2 ? 3 : 2;
-          if (pr >= 1 && pr <= 7 && (pr - 1) % STEP == 0 && (pr - 1) / STEP < T::NF4) {
-            write_unit(wbase, (pr - 1) / STEP);
-            load_unit_at(upix[(pr - 1) / STEP], (pr - 1) / STEP);
+          constexpr int FIRST = MVK_C3_BAR == 7 ? 1 : 0;  // the last conversion sits in front of the barrier
+          if (pr >= FIRST && pr <= MVK_C3_BAR && (pr - FIRST) % STEP == 0 && (pr - FIRST) / STEP < T::NF4) {
+            write_unit(wbase, (pr - FIRST) / STEP);
+            load_unit_at(upix[(pr - FIRST) / STEP], (pr - FIRST) / STEP);
           }
         }
 #pragma unroll
@@ -389,10 +393,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][PA[m]], Bw[2 * pr][PB_[m]], acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][PA[m]], Bw[2 * pr + 1][PB_[m]], acc1, 0, 0, 0);
         }
-        if (pr == 8) {  // behind the barrier: first fragments of the next tile, result of tile Tt-1
-          read_pair(a_nxt, ab_nxt, 0);
-          gather_result(xb);
-        }
+        if (pr == MVK_C3_BAR + 1) gather_result(xb);  // behind the barrier: result of tile Tt-1
+        if (pr == 8) read_pair(a_nxt, ab_nxt, 0);     // first fragments of the next tile
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_sched_group_barrier(0x496, MVK_C3_SCHED > 0 ? MVK_C3_SCHED : 1, 0);
           }
         }
-        if (pr == 7) __syncthreads();
+        if (pr == MVK_C3_BAR) __syncthreads();
       }
       pend0 = acc0;
       pend1 = acc1;
