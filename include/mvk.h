@@ -556,6 +556,9 @@ int mvk_heads_bwd(const float* X, int x_act, const float* dY0, const float* dY1,
 int mvk_defer_begin(float* arena, int64_t arena_floats, const float* grad, int64_t grad_floats);
 int mvk_defer_flush(void* stream);
 int mvk_defer_end(void* stream);
+/* Arena floats asked for since the last mvk_defer_begin, granted or declined for lack of room: the host sizes the arena
+ * from it (multivae_amd/kernels.py grows its arena between steps instead of reserving a fixed 512 MB). */
+int64_t mvk_defer_wanted(void);
 int mvk_defer_pending(void);
 
 /* Device-timestamp profiler (bench.py's roofline objects).  device_slots: nslots records of MVK_PROF_SLOT_U64 = 520

@@ -155,6 +155,8 @@ def load(path=None):
     lib.mvk_conv4s2_small_up_supported.restype = C.c_int
     lib.mvk_conv3x3_fused_ok.argtypes = [_i, _i, _i, _i, _i]
     lib.mvk_conv3x3_fused_ok.restype = C.c_int
+    lib.mvk_defer_wanted.argtypes = []
+    lib.mvk_defer_wanted.restype = C.c_int64
     lib.mvk_defer_pending.argtypes = []
     lib.mvk_defer_pending.restype = C.c_int
     lib.mvk_prof_enable.argtypes = [_p, _i, _p, _p]

@@ -11,6 +11,7 @@ struct DeferState {
   bool active = false;
   float* arena = nullptr;
   long long cap = 0, used = 0;
+  long long wanted = 0;  // floats asked for since mvk_defer_begin, granted or not (mvk_defer_wanted: arena sizing)
   const char* g0 = nullptr;
   const char* g1 = nullptr;
   std::vector<DeferItem> items;
@@ -34,6 +35,7 @@ float* defer_scratch(const void* out, long long floats, hipStream_t s) {
   for (const DeferItem& it : g_defer.items)
     if (it.e.out == out) return nullptr;
   const long long need = (floats + 63) & ~63LL;  // 256-byte aligned regions
+  g_defer.wanted += need;
   if (g_defer.used + need > g_defer.cap) return nullptr;
   float* p = g_defer.arena + g_defer.used;
   g_defer.used += need;
@@ -88,6 +90,7 @@ extern "C" int mvk_defer_begin(float* arena, int64_t arena_floats, const float* 
   g_defer.arena = arena;
   g_defer.cap = arena_floats;
   g_defer.used = 0;
+  g_defer.wanted = 0;
   g_defer.g0 = reinterpret_cast<const char*>(grad);
   g_defer.g1 = g_defer.g0 + sizeof(float) * (size_t)grad_floats;
   g_defer.streams.clear();
@@ -146,6 +149,11 @@ extern "C" int mvk_defer_end(void* stream) {
   const int rc = defer_flush_locked(mvk_stream(stream), true);
   mvk::g_defer.active = false;
   return rc;
+}
+
+extern "C" int64_t mvk_defer_wanted(void) {
+  std::lock_guard<std::mutex> lock(mvk::g_defer.mu);
+  return (int64_t)mvk::g_defer.wanted;
 }
 
 extern "C" int mvk_defer_pending(void) {

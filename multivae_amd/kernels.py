@@ -77,8 +77,14 @@ DEFER = _lib.tune("MVK_DEFER", "1") != "0"
 # headline step: 1.528 ms vs 1.50 ms with one flush at the end (the streaming finish kernel delays every launch of the
 # latency-bound encoder backward it runs beside): off.
 DEFER_SIDE = _lib.tune("MVK_DEFER_SIDE", "0") == "1"
-DEFER_ARENA_FLOATS = int(os.environ.get("MVK_DEFER_MB", "512")) * (1 << 18)
+# The arena starts at 64 MB and grows between steps to what the last step asked for (mvk_defer_wanted), up to MVK_DEFER_MB
+# (default 1024): an MLP model keeps 64 MB, the MnistSvhn models settle at ~200 MB, the ResNet configurations at the cap
+# (a fixed 512 MB per device was wasteful for small models and too small for cfg5).  Grown only outside a stream
+# capture; a replaced arena stays alive (a captured graph may hold its address).
+DEFER_ARENA_CAP_FLOATS = int(os.environ.get("MVK_DEFER_MB", "1024")) * (1 << 18)
+DEFER_ARENA_START_FLOATS = min(64 * (1 << 18), DEFER_ARENA_CAP_FLOATS)
 _ARENA = {}
+_ARENA_RETIRED = []
 
 
 _DEFER_ACTIVE = set()  # devices inside deferred_reductions
@@ -134,7 +140,7 @@ class deferred_reductions:
             dev = self.grad.device
             arena = _ARENA.get(dev)
             if arena is None:
-                arena = torch.empty(DEFER_ARENA_FLOATS, dtype=torch.float32, device=dev)
+                arena = torch.empty(DEFER_ARENA_START_FLOATS, dtype=torch.float32, device=dev)
                 _ARENA[dev] = arena
             call("mvk_defer_begin", ptr(arena), arena.numel(), ptr(self.grad), self.grad.numel())
             _DEFER_ACTIVE.add(dev)
@@ -149,6 +155,11 @@ class deferred_reductions:
                 if st != cur:
                     cur.wait_stream(st)
             call("mvk_defer_end", stream_ptr())
+            wanted = int(_lib.load().mvk_defer_wanted())
+            arena = _ARENA[dev]
+            if wanted > arena.numel() and arena.numel() < DEFER_ARENA_CAP_FLOATS and not torch.cuda.is_current_stream_capturing():
+                _ARENA_RETIRED.append(arena)
+                _ARENA[dev] = torch.empty(min(DEFER_ARENA_CAP_FLOATS, wanted + wanted // 8), dtype=torch.float32, device=dev)
         return False
 
 
@@ -382,6 +393,11 @@ def heads_bwd(x, x_act, dys, ws_, bs, w_sk, w_sn, flat_c=0, want_dx=True, prev_b
     dx = _new((M, K), x) if want_dx else None
     two = len(dys) == 2
     ws = _ws(x)
+    # slabs of the launch: N * K * ceil(M / 128) floats per head + the bias rows; what does not fit the deferred arena must fit
+    # the per-stream scratch, else the separate launches take over (the C side declines with MVK_EINVAL)
+    rgs = (M + 127) // 128
+    if (len(dys) * (N * K + N) + K) * rgs + 64 > ws.numel():
+        return None
     call("mvk_heads_bwd", ptr(x), x_act, ptr(dys[0]), ptr(dys[1]) if two else None, ptr(ws_[0]), ptr(ws_[1]) if two else None,
          w_sk, w_sn, flat_c, ptr(dx), ptr(tw[0]), ptr(tw[1]) if two else None, ptr(tb[0]), ptr(tb[1]) if two else None,
          ptr(tp), M, N, K, ptr(ws), ws.numel(), stream_ptr())

@@ -246,11 +246,19 @@ class BaseTrainer:
             self.optimizer = FusedAdam(self.flat, lr=cfg.learning_rate, betas=tuple(params.get("betas", (0.9, 0.999))),
                                        eps=params.get("eps", 1e-8), weight_decay=params.get("weight_decay", 0.0),
                                        amsgrad=params.get("amsgrad", False),
-                                       zero_grad_in_step=True)  # every step here is zero_grad -> backward -> step
+                                       zero_grad_in_step=self._fused_zero_grad())
         else:
             import torch.optim as optim
 
             self.optimizer = getattr(optim, cfg.optimizer_cls)(self.model.parameters(), lr=cfg.learning_rate, **params)
+
+    def _fused_zero_grad(self):
+        """Every step here is zero_grad -> backward -> step, so the optimizer launch may clear the gradients it consumes;
+        user callbacks could write gradients in between: then only when the configuration asks for it."""
+        want = self.training_config.fused_zero_grad
+        if want is None:
+            want = all(type(cb) is TrainingCallback for cb in self.callbacks)
+        return bool(want)
 
     def set_scheduler(self):
         cfg = self.training_config

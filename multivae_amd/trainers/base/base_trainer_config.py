@@ -40,9 +40,13 @@ class BaseTrainerConfig(BaseConfig):
     use_fused_adam: bool = True     # optimizer_cls == "Adam": one mvk_adam_step launch over the flat buffer
     sync_every_step: bool = False   # True reproduces the reference's per-step `.item()` host sync
     use_hip_graph: bool = False     # replay zero_grad+forward+backward of full-size batches as ONE hipGraph launch
+    # the fused Adam launch clears the gradients it consumes and the next zero_grad() is a flag test.  Correct for the loop
+    # zero_grad -> backward -> step of this trainer; a callback that writes gradients between step() and the next
+    # zero_grad() would see them survive, so None (default) = on only while no user callback is installed
+    fused_zero_grad: Union[bool, None] = None
 
     # the reference's BaseTrainerConfig.from_json_file rejects unknown fields: the extension fields go to a side file
-    _EXTENSION_FIELDS = ("use_fused_adam", "sync_every_step", "use_hip_graph")
+    _EXTENSION_FIELDS = ("use_fused_adam", "sync_every_step", "use_hip_graph", "fused_zero_grad")
 
     def save_json(self, dir_path, filename):
         """`<filename>.json` holds exactly the reference's fields (loads in either trainer); the multivae_amd switches

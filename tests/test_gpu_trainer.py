@@ -180,14 +180,14 @@ def test_deferred_reductions_match_immediate_finishes():
                                      svhn=torch.rand(B, 3, 32, 32, generator=g).to(d)))
     eps = torch.randn(K, B, L, generator=g).to(d)
 
-    def run(deferred):
+    def run(deferred, settled=True):
         flat.zero_grad()
         if deferred:
             with kernels.deferred_reductions(flat) as ctx:
                 assert ctx.on
                 out = model(inputs, noise=eps)
                 out.loss.backward()
-                assert _lib.load().mvk_defer_pending() >= 10  # the finishes are queued, not run
+                assert _lib.load().mvk_defer_pending() >= (10 if settled else 1)  # the finishes are queued, not run
         else:
             out = model(inputs, noise=eps)
             out.loss.backward()
@@ -196,6 +196,7 @@ def test_deferred_reductions_match_immediate_finishes():
         return float(out.loss.detach()), flat.grad.detach().clone()
 
     l0, g0 = run(False)
+    run(True, settled=False)  # the arena grows to what the step asks for (kernels.deferred_reductions): which finishes are queued settles here
     l1, g1 = run(True)
     l2, g2 = run(True)
     assert l0 == l1 == l2
