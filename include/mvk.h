@@ -423,6 +423,12 @@ int mvk_avgpool3s2_bwd(const float* dy, float* dx, int n, int H, int W, int C, v
 int mvk_upsample2_fwd(const float* x, float* y, int n, int H, int W, int C, void* stream);
 int mvk_upsample2_bwd(const float* dy, float* dx, int n, int H, int W, int C, void* stream);
 int mvk_axpby(const float* x, float a, const float* y, float b, int64_t n, int act, float* out, void* stream);
+/* y[b][c][r] = act(x[b][r][c]) * dact'(msrc[b][r][c]) (msrc may be NULL; the derivative is taken through the OUTPUT of dact,
+ * as everywhere here): the NCHW flatten in front of `fc_mu / fc_logvar` of the ResNet encoders fused with their last activation
+ * (models/nn/cub.py:190-195, mmnist.py:300-306), the un-flatten behind `fc` of the decoders (cub.py:232-240), and their
+ * backward passes — x, msrc: [batch][rows][cols], y: [batch][cols][rows]; batch <= 65535. */
+int mvk_transpose_act(const float* x, float* y, int batch, int rows, int cols, int act, const float* msrc, int dact,
+                      void* stream);
 
 /* Noise drawn with the generator state in device memory (the reparameterisation noise of models/base/base_utils.py:129-160
  * `rsample_from_gaussian` and of every `rsample` on the path; the reference calls torch's generator).  state: 3 x uint64

@@ -867,6 +867,49 @@ int mvk_upsample2_bwd(const float* dy, float* dx, int n, int H, int W, int C, vo
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------------------
+// Batched transpose with a fused activation / activation derivative: the flatten of the ResNet encoders
+// (`out.view(batch, nf0 * s0 * s0)` on an NCHW tensor, models/nn/cub.py:190-195, mmnist.py:300-306) and the `view(-1, nf0,
+// s0, s0)` of the decoders (cub.py:232-240), whose convolutional stacks run NHWC here:
+//   y[b][c][r] = act(x[b][r][c]) * dact'(msrc[b][r][c])      x, msrc: [batch][rows][cols], y: [batch][cols][rows]
+// One pass (32 x 32 tiles through LDS, 128-byte rows on both sides) instead of an activation pass + a strided copy.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void transpose_act_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int cols,
+                                                            int act, const float* __restrict__ msrc, int dact) {
+  __shared__ float tile[32][33];
+  const long long base = (long long)blockIdx.z * rows * cols;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    float v = 0.f;
+    if (r < rows && c < cols) {
+      v = mvk_act(x[base + (long long)r * cols + c], act);
+      if (msrc) v *= mvk_act_grad_from_out(msrc[base + (long long)r * cols + c], dact);
+    }
+    tile[ty + 8 * i][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (r < rows && c < cols) y[base + (long long)c * rows + r] = tile[tx][ty + 8 * i];
+  }
+}
+}  // namespace
+
+extern "C" int mvk_transpose_act(const float* x, float* y, int batch, int rows, int cols, int act, const float* msrc, int dact,
+                                 void* stream) {
+  if (!x || !y || batch < 0 || rows <= 0 || cols <= 0 || batch > 65535) return MVK_EINVAL;
+  if (batch == 0) return MVK_OK;
+  hipLaunchKernelGGL(transpose_act_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, batch), dim3(256), 0, mvk_stream(stream), x, y,
+                     rows, cols, act, msrc, dact);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Noise with the generator state in DEVICE memory: a hipGraph replay of a training step draws fresh noise without the
 // two host-issued fill launches per replay that torch's graph-safe generator needs (seed / offset tensors).
 // Philox4x32-10 (counter = offset + thread index, key = seed), 4 values per thread; normal: Box-Muller.

@@ -680,6 +680,44 @@ def device_randn(shape, device, uniform=False, lo=0.0, hi=1.0):
     return out
 
 
+class TransposeActFn(Function):
+    """y[b, c, r] = act(x[b, r, c]): NHWC <-> NCHW-flattened in ONE pass with the activation in front of the flatten
+    (mvk_transpose_act); backward = the transposed gradient times act'(y)."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        x = _c(x)
+        b, r, c = x.shape
+        y = _new((b, c, r), x)
+        call("mvk_transpose_act", ptr(x), ptr(y), b, r, c, act, None, NONE, stream_ptr())
+        ctx.act = act
+        if act != NONE:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dy = _c(dy)
+        b, c, r = dy.shape
+        dx = _new((b, r, c), dy)
+        y = ctx.saved_tensors[0] if ctx.act != NONE else None
+        call("mvk_transpose_act", ptr(dy), ptr(dx), b, c, r, NONE, ptr(y), ctx.act, stream_ptr())
+        return dx, None
+
+
+def nhwc_to_flat_nchw(h, act=NONE):
+    """[n, H, W, C] (NHWC) -> [n, C * H * W] in the reference's NCHW flatten order, with `act` applied on the way."""
+    n, H, W, C = h.shape
+    return TransposeActFn.apply(h.reshape(n, H * W, C), act).reshape(n, C * H * W)
+
+
+def flat_nchw_to_nhwc(flat, C, H, W):
+    """[n, C * H * W] (NCHW order) -> [n, H, W, C]."""
+    n = flat.shape[0]
+    return TransposeActFn.apply(flat.reshape(n, C, H * W), NONE).reshape(n, H, W, C)
+
+
 def axpby(x, a, y, b, act=NONE, out=None):
     ref = x if x is not None else y
     out = torch.empty_like(ref) if out is None else out

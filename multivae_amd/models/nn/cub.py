@@ -57,9 +57,9 @@ class CUB_Resnet_Encoder(BaseEncoder):
         prog, params = [], []
         _add_conv(prog, params, self.conv_img, kernels.NONE)
         _add_sequential(prog, params, self.resnet)
-        prog.append(("act", kernels.LEAKY))  # fc_mu(actvn(out)), fc_logvar(actvn(out))
         h = kernels.ResnetStackFn.apply(x.permute(0, 2, 3, 1).contiguous(), prog, *params)
-        flat = h.permute(0, 3, 1, 2).reshape(h.shape[0], self.nf0 * self.s0 * self.s0)
+        # fc_mu(actvn(out)), fc_logvar(actvn(out)): the activation and the NCHW flatten in one pass
+        flat = kernels.nhwc_to_flat_nchw(h, kernels.LEAKY)
         mu, lv = kernels.MLPHeadsFn.apply(flat, 2, self.fc_mu.weight, self.fc_mu.bias, self.fc_logvar.weight,
                                           self.fc_logvar.bias)
         return ModelOutput(embedding=mu, log_covariance=lv)
@@ -93,7 +93,7 @@ class CUB_Resnet_Decoder(BaseDecoder):
         # K-sample models can decode [K, B, L] as with every other in-package decoder
         z2 = z.reshape(-1, z.shape[-1])
         (h,) = kernels.MLPHeadsFn.apply(z2, 1, self.fc.weight, self.fc.bias)
-        h = h.view(-1, self.nf0, self.s0, self.s0).permute(0, 2, 3, 1)
+        h = kernels.flat_nchw_to_nhwc(h, self.nf0, self.s0, self.s0)
         prog, params = [], []
         _add_sequential(prog, params, self.resnet)
         prog.append(("act", kernels.LEAKY))

@@ -116,7 +116,7 @@ class EncoderResnetMMNIST(BaseEncoder):
         _add_conv(prog, params, conv_img, kernels.NONE)
         _add_sequential(prog, params, resnet)
         h = kernels.ResnetStackFn.apply(x_nhwc, prog, *params)  # [B, 7, 7, nf0]
-        flat = h.permute(0, 3, 1, 2).reshape(h.shape[0], self.nf0 * self.s0 * self.s0)  # the reference flattens NCHW
+        flat = kernels.nhwc_to_flat_nchw(h)  # the reference flattens NCHW
         return kernels.MLPHeadsFn.apply(flat, 2, fc_mu.weight, fc_mu.bias, fc_lv.weight, fc_lv.bias)
 
     def forward(self, x):
@@ -155,7 +155,7 @@ class DecoderResnetMMNIST(BaseDecoder):
     def forward(self, z):
         z2 = z.reshape(-1, z.shape[-1])
         (h,) = kernels.MLPHeadsFn.apply(z2, 1, self.fc.weight, self.fc.bias)  # [N, nf0*7*7] in NCHW order
-        h = h.view(-1, self.nf0, self.s0, self.s0).permute(0, 2, 3, 1)
+        h = kernels.flat_nchw_to_nhwc(h, self.nf0, self.s0, self.s0)
         prog, params = [], []
         _add_sequential(prog, params, self.resnet)
         _add_conv(prog, params, self.conv_img[0], kernels.LEAKY)

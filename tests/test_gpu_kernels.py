@@ -938,6 +938,30 @@ def test_device_rng(K):
     assert torch.equal(z, ref[1]), "replay after an in-place re-seed"
 
 
+@pytest.mark.parametrize("n,H,W,C", [(5, 16, 16, 256), (3, 7, 7, 256), (2, 5, 9, 3), (1, 1, 1, 1)])
+def test_transpose_act(K, n, H, W, C):
+    """mvk_transpose_act: the NCHW flatten of an NHWC map with LeakyReLU in the same pass, its inverse, and both backward
+    passes (the ResNet encoders' `fc(actvn(out).view(batch, -1))`, the decoders' `fc(z).view(-1, nf0, s0, s0)`)."""
+    gen = g(61)
+    d = dev()
+    h = torch.randn(n, H, W, C, generator=gen)
+    hd = h.to(d).requires_grad_(True)
+    flat = K.nhwc_to_flat_nchw(hd, K.LEAKY)
+    ref = F.leaky_relu(h, 0.2).permute(0, 3, 1, 2).reshape(n, C * H * W)
+    assert torch.equal(flat.cpu(), ref)
+    gflat = torch.randn(n, C * H * W, generator=gen)
+    flat.backward(gflat.to(d))
+    href = h.clone().requires_grad_(True)
+    F.leaky_relu(href, 0.2).permute(0, 3, 1, 2).reshape(n, C * H * W).backward(gflat)
+    close(hd.grad, href.grad, what="flatten backward", rtol=1e-6)
+    fd = ref.to(d).requires_grad_(True)
+    back = K.flat_nchw_to_nhwc(fd, C, H, W)
+    assert torch.equal(back.cpu(), ref.view(n, C, H, W).permute(0, 2, 3, 1))
+    gb = torch.randn(n, H, W, C, generator=gen)
+    back.backward(gb.to(d))
+    assert torch.equal(fd.grad.cpu(), gb.permute(0, 3, 1, 2).reshape(n, C * H * W))
+
+
 @pytest.mark.parametrize("n,H,W,C", [(3, 28, 28, 64), (2, 7, 7, 20), (4, 14, 14, 128), (2, 5, 9, 3)])
 def test_avgpool_upsample_axpby(K, n, H, W, C):
     """nn.AvgPool2d(3, 2, 1), nn.Upsample(scale_factor=2) forward / backward and the residual combination on NHWC."""
