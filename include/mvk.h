@@ -459,6 +459,19 @@ int mvk_conv4s2_small_up_fwd(const float* V, const float* Wref, const float* bia
 int mvk_conv4s2_small_up_bwd(const float* dU, const float* Uout, int u_act, const float* V, int v_act,
                              const float* Wref, float* dV, float* dWref, float* db, float* db_v, float* ws,
                              int64_t ws_floats, int n, int h, int w, int Cu, int Cv, void* stream);
+/* The fused decoder tail (round 3, opt-in for the in-package Decoder_VAE_SVHN, models/nn/svhn.py:52-70): the image-producing
+ * layer scores its output against the data by a Normal(scale) likelihood (models/base/base_utils.py:62-87, mopoe_model.py:192-199)
+ * in its own epilogue — rows[n] = -log p(x | image) summed over the image (what mvk_recon_nll_fwd produces from the image),
+ * dpre[n,Cu,2h,2w] = d rows / d pre-activation stored where the image would be; X: [xrows][Cu * 4 h w] targets, image i is scored
+ * against X[i % xrows] (the K samples of a data point share it).  mvk_conv4s2_small_up_bwd_pre is the layer's backward for that
+ * buffer: dpre * rowscale[n] (d loss / d rows; NULL = 1) replaces dU * u_act'(Uout), the image is not read.  3 of the 5 passes over
+ * the [K B, 3, 32, 32] tensor disappear.  Only where mvk_conv4s2_small_up_nll_supported returns 1 (16x16x32 -> 3x32x32). */
+int mvk_conv4s2_small_up_nll_supported(int h, int w, int Cu, int Cv);
+int mvk_conv4s2_small_up_fwd_nll(const float* V, const float* Wref, const float* bias, const float* X, int xrows, float scale,
+                                 float* dpre, float* rows, int n, int h, int w, int Cu, int Cv, int act, void* stream);
+int mvk_conv4s2_small_up_bwd_pre(const float* dpre, const float* rowscale, const float* V, int v_act, const float* Wref,
+                                 float* dV, float* dWref, float* db, float* db_v, float* ws, int64_t ws_floats, int n, int h,
+                                 int w, int Cu, int Cv, void* stream);
 
 /* 1x1-spatial layers:
  *   unflatten  Y[n,(tap,co)] = act(z[n,Cin] Wp + b[co]), Wp[ci][tap*Cout+co] = Wref[ci][co][tap]

@@ -79,6 +79,8 @@ PROTOTYPES = {
     "mvk_loss_backward_seed": [C.POINTER(SeedDesc), _i, _p, _p],
     "mvk_f32_to_bf3": [_p, _i64, _p, _p],
     "mvk_bf3_to_f32": [_p, _i64, _p, _p],
+    "mvk_conv4s2_small_up_fwd_nll": [_p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "mvk_conv4s2_small_up_bwd_pre": [_p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p],
     "mvk_conv3x3": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i64, _p],
     "mvk_conv3x3_res": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _f, _p, _i64, _p],
     "mvk_conv3x3_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i64, _p],
@@ -154,6 +156,8 @@ def load(path=None):
         fn.restype = C.c_int
     lib.mvk_conv4s2_small_up_supported.argtypes = [_i, _i, _i, _i]
     lib.mvk_conv4s2_small_up_supported.restype = C.c_int
+    lib.mvk_conv4s2_small_up_nll_supported.argtypes = [_i, _i, _i, _i]
+    lib.mvk_conv4s2_small_up_nll_supported.restype = C.c_int
     lib.mvk_conv3x3_fused_ok.argtypes = [_i, _i, _i, _i, _i]
     lib.mvk_conv3x3_fused_ok.restype = C.c_int
     lib.mvk_defer_wanted.argtypes = []
@@ -230,6 +234,29 @@ GEMM_FLOPS = {
     "mvk_heads_bwd": lambda a: 4.0 * a[15] * a[16] * a[17] * (2 if a[3] else 1),
 }
 COUNT_FLOPS = None
+
+
+_HIP = None
+
+
+def new_stream(device):
+    """A dedicated HIP stream wrapped as a torch stream.  `torch.cuda.Stream()` hands out the 32 streams of a per-device pool
+    round-robin: in a long-lived process two `Stream` objects created far apart are the SAME hipStream_t, and which of the
+    package's cached side streams alias torch's capture stream (or each other) depends on how many streams the process made
+    before — a captured step whose fork / join edges fold onto one stream crashed hipGraphLaunch
+    (hip::Graph::UpdateStreams) for one particular test order.  Streams made here are outside that pool."""
+    global _HIP
+    if _HIP is None:
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        _HIP = C.CDLL(cand if os.path.exists(cand) else "libamdhip64.so")
+        _HIP.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+        _HIP.hipStreamCreateWithFlags.restype = C.c_int
+    h = C.c_void_p()
+    with torch.cuda.device(device):
+        rc = _HIP.hipStreamCreateWithFlags(C.byref(h), 1)  # hipStreamNonBlocking
+    if rc != 0 or not h.value:
+        raise MvkError(f"hipStreamCreateWithFlags failed ({rc})")
+    return torch.cuda.ExternalStream(h.value, device=device)
 
 
 def call(name, *args):

@@ -171,10 +171,20 @@ __global__ __launch_bounds__(NT) void small_up_fwd_kernel(const float* __restric
 // is the 6 piece products of order <= 2 on v_mfma_f32_16x16x32_bf16 — ONE instruction covers the whole K: 6 x 16 cycles per
 // 16 x 16 tile instead of 8 x 32, fp32-level error (same scheme and error bound as the tiled engine, igemm_bf.hpp).
 // Everything around the GEMM (prefetch, column matrix in LDS, output gather, activation) is the fp32 kernel's.
-template <int CU, int NT>
+// FUSED TAIL (X != nullptr; round 3): the layer is the last one of a decoder whose output is scored against the data by a Normal
+// likelihood (models/base/base_utils.py:62-87 `set_decoder_dist`, mopoe_model.py:192-199).  The workgroup that holds a whole
+// reconstructed image then scores it in its epilogue: rows[img] = sum_d (r_d - x_d)^2 / (2 s^2) + D (log s + 1/2 log 2 pi) (fixed
+// summation order: lanes, waves) and U receives d rows[img] / d pre-activation = (r - x) / s^2 * act'(r) instead of the image
+// — the reconstruction and its gradient never travel to HBM and back (3 of the 5 passes over the [K B, 3, 32, 32] tensor gone).
+// X: [xrows][CU * 1024] targets, image img is scored against row img % xrows (the K samples of a data point share it).
+// (NLL is a template argument: the plain kernel sits exactly at its 64-register budget of 8 waves per SIMD, and the tail's
+// few extra live values made BOTH paths spill when it was a run-time branch: 47 -> 54 us for the plain forward.)
+template <int CU, int NT, bool NLL = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT / 128))) void small_up_fwd_bf_kernel(const float* __restrict__ V, const float* __restrict__ Wref,
                                                               const float* __restrict__ bias, float* __restrict__ U, int n,
-                                                              int act, mvk_prof_slot* prof) {
+                                                              int act, mvk_prof_slot* prof, const float* __restrict__ X = nullptr,
+                                                              int xrows = 1, float inv_s2 = 1.f, float lconst = 0.f,
+                                                              float* __restrict__ rows = nullptr) {
   mvk_prof_begin(prof);
   using mvk::bf16x8;
   using mvk::u32x2;
@@ -257,6 +267,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
     }
     __syncthreads();
     if (img + gridDim.x < n) prefetch(img + gridDim.x);
+    float xv[NO];  // fused tail: this thread's target pixels, loaded here and first touched behind the GEMM
+    if (NLL) {
+      const float* xt = X + (img % xrows) * per_img;
+#pragma unroll
+      for (int t = 0; t < NO; ++t) xv[t] = xt[tid + t * NT];
+    }
     f32x4 acc[MT][CU];
     {
       bf16x8 af[MT][3];
@@ -289,12 +305,30 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
         for (int r = 0; r < 4; ++r) buf[(wave * WP + a * 16 + lq * 4 + r) * CS + b * 16 + l15] = acc[a][b][r];
     __syncthreads();
     float* out = U + img * per_img;
+    if (NLL) {
+      float part = 0.f;
 #pragma unroll
-    for (int t = 0; t < NO; ++t) {
-      const float sum = ((buf[tap[t][0]] + buf[tap[t][1]]) + (buf[tap[t][2]] + buf[tap[t][3]])) + bia[t];
-      out[tid + t * NT] = mvk_act(sum, act);
+      for (int t = 0; t < NO; ++t) {
+        const float sum = ((buf[tap[t][0]] + buf[tap[t][1]]) + (buf[tap[t][2]] + buf[tap[t][3]])) + bia[t];
+        const float r = mvk_act(sum, act), dlt = r - xv[t];
+        part = fmaf(0.5f * inv_s2 * dlt, dlt, part);
+        out[tid + t * NT] = dlt * inv_s2 * mvk_act_grad_from_out(r, act);
+      }
+      part = wave_sum(part);
+      if (lane == 0) buf[zidx + 1 + wave] = part;
+    } else {
+#pragma unroll
+      for (int t = 0; t < NO; ++t) {
+        const float sum = ((buf[tap[t][0]] + buf[tap[t][1]]) + (buf[tap[t][2]] + buf[tap[t][3]])) + bia[t];
+        out[tid + t * NT] = mvk_act(sum, act);
+      }
     }
     __syncthreads();  // the column matrix is overwritten by the next image's pieces
+    if (NLL && tid == 0) {  // the wave partials are rewritten three barriers from now at the earliest
+      float tot = 0.f;
+      for (int wv = 0; wv < NT / 64; ++wv) tot += buf[zidx + 1 + wv];
+      rows[img] = tot + lconst;
+    }
   }
   mvk_prof_end(prof);
 }
@@ -629,10 +663,13 @@ __device__ __forceinline__ mvk::bf16x8 su_tr_pair(const char* p0, const char* p1
 //   backward weight  the transposing read takes per-lane addresses: lane (row, piece) reads the piece of tap 4 b + piece at
 //                    its position's (parity, shifted) entry — the im2col matrix is never written.
 // 76 KB of LDS, 256 threads: two workgroups per CU like the fp32 kernel.
-template <int CU>
+// PRE (round 3, the fused tail of small_up_fwd_bf_kernel): dU already is the gradient with respect to the layer's pre-activation
+// per unit of its image's score; it is multiplied by rowscale[img] (the gradient of the loss with respect to that score) while it is
+// staged, and the layer's output is not read at all.
+template <int CU, bool PRE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void small_up_bwd_bf_kernel(
     const float* __restrict__ dU, const float* __restrict__ Uout, const float* __restrict__ V, const float* __restrict__ Wref,
-    float* __restrict__ dV, float* __restrict__ partial, int n, mvk_prof_slot* prof) {
+    float* __restrict__ dV, float* __restrict__ partial, int n, mvk_prof_slot* prof, const float* __restrict__ rowscale = nullptr) {
   mvk_prof_begin(prof);
   using mvk::bf16x8;
   using mvk::u32x2;
@@ -682,13 +719,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     dst[e] = (((yp & 1) * 2 + (xp & 1)) * 289 + (yp >> 1) * 17 + (xp >> 1)) * 8;
   }
   f32x4 qdu[CU], quo[CU], pv[8];
+  float rs_next = 1.f;
   // (the 14 loads of the next image go out in ONE burst right behind the staging: spread over the backward-data tiles they
   // arrive too late — staging then waits 38 % of the wave's cycles for them, 136 us instead of 110)
   auto prefetch_part = [&](long long img, int part) __attribute__((always_inline)) {
     if (part < CU) {
       qdu[part] = reinterpret_cast<const f32x4*>(dU + img * (CU * 1024))[tid + part * NT];
-      quo[part] = reinterpret_cast<const f32x4*>(Uout + img * (CU * 1024))[tid + part * NT];
+      if (!PRE) quo[part] = reinterpret_cast<const f32x4*>(Uout + img * (CU * 1024))[tid + part * NT];
     }
+    if (PRE && part == 0) rs_next = rowscale ? rowscale[img] : 1.f;
     const f32x4* src = reinterpret_cast<const f32x4*>(V + img * (P * CV));
     pv[2 * part] = src[tid + (2 * part) * NT];
     pv[2 * part + 1] = src[tid + (2 * part + 1) * NT];
@@ -734,7 +773,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       float v[CU];
 #pragma unroll
       for (int c = 0; c < CU; ++c) {
-        v[c] = qdu[c][e] * (quo[c][e] * (1.f - quo[c][e]));  // sigmoid'
+        v[c] = PRE ? qdu[c][e] * rs_next : qdu[c][e] * (quo[c][e] * (1.f - quo[c][e]));  // sigmoid'
         dblq[c] += v[c];
       }
       unsigned a0, a1, a2, b0, b1, b2;
@@ -1021,7 +1060,7 @@ static bool supported(int h, int w, int Cu, int Cv) {
 
 template <int CU, int CV>
 static int launch_fwd(const float* V, const float* Wref, const float* bias, float* U, int n, int h, int w, int act,
-                      hipStream_t s) {
+                      hipStream_t s, const float* X = nullptr, int xrows = 1, float scale = 1.f, float* rows = nullptr) {
   const size_t lds = fwd_lds<CU, CV>(h * w);
   constexpr int NT = MVK_SMALL_FWD_THREADS;
   if (lds > 64 * 1024) {
@@ -1039,8 +1078,17 @@ static int launch_fwd(const float* V, const float* Wref, const float* bias, floa
   static const int bf = mvk_tune("MVK_SMALL_FWD_BF") ? atoi(mvk_tune("MVK_SMALL_FWD_BF")) : 1024;
   if constexpr (CV == 32 && CU == 3) {
     if (h == 16 && w == 16 && bf > 0) {
-      const size_t blds = 3 * (16 * CU) * 64 + (256 * (16 * CU + 1) + 4) * sizeof(float);
-      if (bf == 512)
+      const size_t blds = 3 * (16 * CU) * 64 + (256 * (16 * CU + 1) + 24) * sizeof(float);  // + zero word + 16 wave partials
+      const float inv_s2 = 1.f / (scale * scale), lconst = (float)(CU * 1024) * (logf(scale) + 0.91893853320467274178f);
+      // fused tail: 512-thread workgroups (4 waves per SIMD, 128 registers) — at 1024 threads it spills; MVK_SMALL_NLL_NT=1024 for A/B
+      static const int nll_nt = mvk_tune("MVK_SMALL_NLL_NT") ? atoi(mvk_tune("MVK_SMALL_NLL_NT")) : 512;
+      if (X && nll_nt == 1024)
+        hipLaunchKernelGGL((small_up_fwd_bf_kernel<CU, 1024, true>), dim3(grid), dim3(1024), blds, s, V, Wref, bias, U, n, act,
+                           prof, X, xrows, inv_s2, lconst, rows);
+      else if (X)
+        hipLaunchKernelGGL((small_up_fwd_bf_kernel<CU, 512, true>), dim3(grid), dim3(512), blds, s, V, Wref, bias, U, n, act,
+                           prof, X, xrows, inv_s2, lconst, rows);
+      else if (bf == 512)
         hipLaunchKernelGGL((small_up_fwd_bf_kernel<CU, 512>), dim3(grid), dim3(512), blds, s, V, Wref, bias, U, n, act, prof);
       else
         hipLaunchKernelGGL((small_up_fwd_bf_kernel<CU, 1024>), dim3(grid), dim3(1024), blds, s, V, Wref, bias, U, n, act, prof);
@@ -1049,6 +1097,7 @@ static int launch_fwd(const float* V, const float* Wref, const float* bias, floa
       return MVK_OK;
     }
   }
+  if (X) return MVK_EINVAL;  // the fused tail lives in the split-bf16 kernel only (mvk_conv4s2_small_up_nll_supported)
   if (dense)
     hipLaunchKernelGGL((small_up_fwd_kernel<CU, CV, NT, true>), dim3(grid), dim3(NT), lds, s, V, Wref, bias, U, n, h, w, act, prof);
   else
@@ -1061,7 +1110,7 @@ static int launch_fwd(const float* V, const float* Wref, const float* bias, floa
 template <int CU, int CV>
 static int launch_bwd(const float* dU, const float* Uout, int u_act, const float* V, int v_act, const float* Wref,
                       float* dV, float* dWref, float* db, float* db_v, float* ws, int64_t ws_floats, int n, int h,
-                      int w, hipStream_t s) {
+                      int w, hipStream_t s, bool pre = false, const float* rowscale = nullptr) {
   using C = SmallCfg<CU, CV>;
   const int slab = CV * C::NC + CU + CV;
   // MVK_SMALL_BWD_UNITS=2: half-image work units for 16x16 inputs (3 workgroups per CU instead of 2).  Measured at
@@ -1073,8 +1122,9 @@ static int launch_bwd(const float* dU, const float* Uout, int u_act, const float
   // the SVHN decoder's shape — 128 -> 110 us alone at n = 5120, -13 us per training step (three A/B pairs on one box).
   const char* bf_str = mvk_tune("MVK_SMALL_BWD_BF");
   const bool bf = (!bf_str || atoi(bf_str) != 0) && CU == 3 && CV == 32 && h == 16 && w == 16 && units_env != 2 &&
-                  u_act == MVK_ACT_SIGMOID && v_act == MVK_ACT_RELU && mvk_aligned16(dU) && mvk_aligned16(Uout) &&
-                  mvk_aligned16(V) && mvk_aligned16(dV) && mvk_aligned16(Wref);
+                  (pre || u_act == MVK_ACT_SIGMOID) && v_act == MVK_ACT_RELU && mvk_aligned16(dU) &&
+                  (pre || mvk_aligned16(Uout)) && mvk_aligned16(V) && mvk_aligned16(dV) && mvk_aligned16(Wref);
+  if (pre && !bf) return MVK_EINVAL;  // the pre-activation form lives in the split-bf16 kernel only
   const int gmax = units == 2 ? 1024 : 512;
   int grid = nunits < gmax ? (int)nunits : gmax;
   float* dslab = (mvk::defer_free(db) && mvk::defer_free(db_v)) ? mvk::defer_scratch(dWref, (long long)grid * slab, s) : nullptr;
@@ -1085,9 +1135,16 @@ static int launch_bwd(const float* dU, const float* Uout, int u_act, const float
     if (bf) {
       mvk_prof_slot* prof = mvk::prof_next(6, 4.0 * n * h * w * (2.0 * CV + 8.0 * CU));
       constexpr int BLDS = 3 * 4 * 289 * 8 + 3 * 256 * 64;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_bwd_bf_kernel<CU>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_bwd_bf_kernel<CU, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, BLDS);
-      hipLaunchKernelGGL((small_up_bwd_bf_kernel<CU>), dim3(grid), dim3(256), BLDS, s, dU, Uout, V, Wref, dV, ws, n, prof);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_bwd_bf_kernel<CU, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, BLDS);
+      if (pre)
+        hipLaunchKernelGGL((small_up_bwd_bf_kernel<CU, true>), dim3(grid), dim3(256), BLDS, s, dU, Uout, V, Wref, dV, ws, n, prof,
+                           rowscale);
+      else
+        hipLaunchKernelGGL((small_up_bwd_bf_kernel<CU, false>), dim3(grid), dim3(256), BLDS, s, dU, Uout, V, Wref, dV, ws, n, prof,
+                           rowscale);
       MVK_CHECK_LAUNCH();
       mvk::prof_fold(prof, s);
       const int total = CV * C::NC + CU + CV;
@@ -1203,6 +1260,33 @@ int mvk_conv4s2_small_up_fwd(const float* V, const float* Wref, const float* bia
   if (n == 0) return MVK_OK;
   hipStream_t s = mvk_stream(stream);
   MVK_SMALL_DISPATCH(launch_fwd, V, Wref, bias, U, n, h, w, act, s)
+}
+
+/* The fused decoder tail (round 3): the last layer of Decoder_VAE_SVHN (models/nn/svhn.py:52-70) scored against the data by a
+ * Normal(scale) likelihood in its own epilogue.  rows[n] = -log p(x | image) summed over the image (the row sums
+ * mvk_recon_nll_fwd produces), dpre = d rows / d pre-activation, stored where the image would be.  X: [xrows][Cu * 4 h w]; image i is
+ * scored against X[i % xrows].  Only where mvk_conv4s2_small_up_nll_supported says so (16x16 x 32 channels -> 3 x 32x32). */
+int mvk_conv4s2_small_up_nll_supported(int h, int w, int Cu, int Cv) { return h == 16 && w == 16 && Cu == 3 && Cv == 32 ? 1 : 0; }
+
+int mvk_conv4s2_small_up_fwd_nll(const float* V, const float* Wref, const float* bias, const float* X, int xrows, float scale,
+                                 float* dpre, float* rows, int n, int h, int w, int Cu, int Cv, int act, void* stream) {
+  if (!V || !Wref || !X || !dpre || !rows || n < 0 || xrows <= 0 || !(scale > 0.f) || !mvk_aligned16(V) ||
+      !mvk_conv4s2_small_up_nll_supported(h, w, Cu, Cv))
+    return MVK_EINVAL;
+  if (n == 0) return MVK_OK;
+  return launch_fwd<3, 32>(V, Wref, bias, dpre, n, h, w, act, mvk_stream(stream), X, xrows, scale, rows);
+}
+
+/* Its backward: dpre (from mvk_conv4s2_small_up_fwd_nll) times rowscale[n] (d loss / d rows; NULL = 1) through the layer. */
+int mvk_conv4s2_small_up_bwd_pre(const float* dpre, const float* rowscale, const float* V, int v_act, const float* Wref, float* dV,
+                                 float* dWref, float* db, float* db_v, float* ws, int64_t ws_floats, int n, int h, int w, int Cu,
+                                 int Cv, void* stream) {
+  if (!dpre || !V || !Wref || !dV || !dWref || !ws || n < 0 || !mvk_aligned16(V) ||
+      !mvk_conv4s2_small_up_nll_supported(h, w, Cu, Cv))
+    return MVK_EINVAL;
+  if (n == 0) return MVK_OK;
+  return launch_bwd<3, 32>(dpre, nullptr, MVK_ACT_NONE, V, v_act, Wref, dV, dWref, db, db_v, ws, ws_floats, n, h, w,
+                           mvk_stream(stream), true, rowscale);
 }
 
 int mvk_conv4s2_small_down_fwd(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w,

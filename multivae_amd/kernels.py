@@ -206,8 +206,8 @@ def _side_stream(device, i):
     key = (device, i)
     st = _SIDE.get(key)
     if st is None:
-        # default priority: a priority -1 side stream costs +75 % step time (1.38 -> 2.4 ms, re-measured in round 2: MVK_SIDE_PRIO)
-        st = torch.cuda.Stream(device=device, priority=int(_lib.tune("MVK_SIDE_PRIO", "0")))
+        # default priority: a priority -1 side stream costs +75 % step time (1.38 -> 2.4 ms, measured in round 2)
+        st = _lib.new_stream(device)  # dedicated: never one of torch's 32 pooled streams (see _lib.new_stream)
         _SIDE[key] = st
     return st
 
@@ -987,7 +987,11 @@ class SVHNDecoderFn(Function):
     """z[...,L] -> ConvT(4,1,0)+ReLU -> 2x ConvT(4,2,1)+ReLU -> ConvT(4,2,1)+Sigmoid -> [...,C,32,32] NCHW."""
 
     @staticmethod
-    def forward(ctx, z, w0, b0, w1, b1, w2, b2, w3, b3):
+    def forward(ctx, z, w0, b0, w1, b1, w2, b2, w3, b3, nll_x=None, nll_scale=1.0):
+        """nll_x [B, C, 32, 32] given: the FUSED TAIL — the last layer scores its image against nll_x[row % B] by a
+        Normal(nll_scale) likelihood in its epilogue (mvk_conv4s2_small_up_fwd_nll) and the node returns the NLL row sums
+        [*z.shape[:-1]] instead of the images; the buffer that would hold the images holds d rows / d pre-activation for the
+        backward pass.  The caller checks `svhn_fused_tail_ok` first."""
         L = w0.shape[0]
         z2 = _c(z.reshape(-1, L))
         n = z2.shape[0]
@@ -1000,7 +1004,12 @@ class SVHNDecoderFn(Function):
         g3 = conv_up(g2, wu2, b2, n, 8, 8, C3, C2, RELU)  # [n,16,16,C3]
         out = _new((n, C4, 32, 32), z2)
         small = bool(_lib.load().mvk_conv4s2_small_up_supported(16, 16, C4, C3))
-        if small:  # per-image MFMA column-matrix kernel (smallconv.hip)
+        ctx.fused = nll_x is not None
+        if ctx.fused:
+            rows = _new((n,), z2)
+            call("mvk_conv4s2_small_up_fwd_nll", ptr(g3), ptr(w3), ptr(b3), ptr(nll_x), nll_x.shape[0], float(nll_scale), ptr(out),
+                 ptr(rows), n, 16, 16, C4, C3, SIGMOID, stream_ptr())
+        elif small:  # per-image MFMA column-matrix kernel (smallconv.hip)
             call("mvk_conv4s2_small_up_fwd", ptr(g3), ptr(w3), ptr(b3), ptr(out), n, 16, 16, C4, C3, SIGMOID,
                  stream_ptr())
         else:
@@ -1011,6 +1020,8 @@ class SVHNDecoderFn(Function):
         ctx.save_for_backward(z2, g1, g2, g3, out, wp0, wd1, wd2, wd3, w0, b0, w1, b1, w2, b2, w3, b3)
         ctx.dims = (n, L, C1, C2, C3, C4)
         ctx.z_shape = z.shape
+        if ctx.fused:
+            return rows.view(*z.shape[:-1])
         return out.view(*z.shape[:-1], C4, 32, 32)
 
     @staticmethod
@@ -1018,9 +1029,21 @@ class SVHNDecoderFn(Function):
     def backward(ctx, dout):
         z2, g1, g2, g3, out, wp0, wd1, wd2, wd3, w0, b0, w1, b1, w2, b2, w3, b3 = ctx.saved_tensors
         n, L, C1, C2, C3, C4 = ctx.dims
-        dout = _c(dout).view(out.shape)
+        if ctx.fused:  # dout = d loss / d rows [n]; `out` holds d rows / d pre-activation
+            drows = _c(dout).reshape(-1)
+            tw3, dw3 = _grad_target(w3)
+            tb3, db3 = _grad_target(b3)
+            dg3 = _new((n, 16, 16, C3), z2)
+            ws = _ws(z2)
+            tb2, db2 = _grad_target(b2)
+            call("mvk_conv4s2_small_up_bwd_pre", ptr(out), ptr(drows), ptr(g3), RELU, ptr(w3), ptr(dg3), ptr(tw3), ptr(tb3),
+                 ptr(tb2), ptr(ws), ws.numel(), n, 16, 16, C4, C3, stream_ptr())
+        else:
+            dout = _c(dout).view(out.shape)
         # last layer: dpre = dout * out(1-out) applied while loading
-        if ctx.small:  # backward-data + backward-weight + bias gradient in ONE pass over dout / out / g3
+        if ctx.fused:
+            pass
+        elif ctx.small:  # backward-data + backward-weight + bias gradient in ONE pass over dout / out / g3
             tw3, dw3 = _grad_target(w3)
             tb3, db3 = _grad_target(b3)
             dg3 = _new((n, 16, 16, C3), z2)
@@ -1039,7 +1062,7 @@ class SVHNDecoderFn(Function):
         late = late_leaves(z2.device, dg3, g2, g1, z2)
         if not late.on:
             dw2 = conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2)
-        if not ctx.small:
+        if not ctx.small and not ctx.fused:
             db2 = colsum(dg3.view(-1, C3), b2)
         dg2, db1 = conv_down(dg3, wd2, None, n, 8, 8, C3, C2, NONE, v_act_src=g2, v_act=RELU, out_bias=b1,
                              frag=ctx.frags[1])
@@ -1062,12 +1085,17 @@ class SVHNDecoderFn(Function):
                 call("mvk_unflatten_wgrad", ptr(z2), ptr(dg1f), ptr(tw0), n, L, C1, ptr(ws), ws.numel(), stream_ptr())
             if dw0 is not None or dw1 is not None or dw2 is not None:  # a gradient autograd itself accumulates: join now
                 torch.cuda.current_stream(z2.device).wait_stream(_side_stream(z2.device, 30))
-            return dz, dw0, db0, dw1, db1, dw2, db2, dw3, db3
+            return dz, dw0, db0, dw1, db1, dw2, db2, dw3, db3, None, None
         ws = _ws(z2)
         call("mvk_unflatten_wgrad", ptr(z2), ptr(dg1f), ptr(tw0), n, L, C1, ptr(ws), ws.numel(), stream_ptr())
         if ctx.needs_input_grad[0]:
             dz = gemm(dg1f, wp0, n, L, 16 * C1, tb=True).view(ctx.z_shape)
-        return dz, dw0, db0, dw1, db1, dw2, db2, dw3, db3
+        return dz, dw0, db0, dw1, db1, dw2, db2, dw3, db3, None, None
+
+
+def svhn_fused_tail_ok(C4, C3):
+    """The fused decoder tail of SVHNDecoderFn exists for this image layer (mvk_conv4s2_small_up_nll_supported)."""
+    return bool(_lib.load().mvk_conv4s2_small_up_nll_supported(16, 16, C4, C3))
 
 
 # =====================================================================================================

@@ -33,6 +33,9 @@ class MoPoE(BaseMultiVAE):
             list_subsets = self.all_subsets()
         self.set_subsets(list_subsets)
         self._sel_cache = {}
+        # decoders that can score their own output (`reconstruction_nll`, e.g. Decoder_VAE_SVHN) do so in the epilogue of their
+        # last layer; False = always decode + the generic likelihood kernel (A/B, and what every user-written decoder gets)
+        self.fused_decoder_tail = _lib.tune("MVK_FUSED_TAIL", "1") != "0"
         if self.multiple_latent_spaces:  # default multi-latent MLPs (mopoe_model.py:58-75)
             from ..nn.default_architectures import BaseDictDecodersMultiLatents, BaseDictEncoders_MultiLatents
 
@@ -183,29 +186,47 @@ class MoPoE(BaseMultiVAE):
                 style_kl.append(kl)
                 zw = torch.cat([z, w], dim=-1)
                 z_ins[m] = zw[0] if K == 1 else zw
-            decode = lambda m: self.decoders[m](z_ins[m]).reconstruction
+            z_of = lambda m: z_ins[m]
         else:
-            decode = lambda m: self.decoders[m](z_in).reconstruction
+            z_of = lambda m: z_in
+
+        # Opt-in fused decoder tail (round 3): an in-package decoder that can score its own output (`reconstruction_nll`:
+        # Decoder_VAE_SVHN with a Normal likelihood) returns the NLL row sums [K, B] instead of the images; the reconstruction
+        # term of that modality is then a plain sum of rows.  Complete data only; user decoders, other likelihoods and
+        # evaluation (no grad) take the generic path below.
+        normal = kernels.DIST["normal"]
+
+        def decode(m):
+            dec = self.decoders[m]
+            if self.fused_decoder_tail and masks is None and self.recon_dists[m][0] == normal and hasattr(dec, "reconstruction_nll"):
+                rows = dec.reconstruction_nll(z_of(m), inputs.data[m], "normal", self.recon_dists[m][1])
+                if rows is not None:
+                    return ("rows", rows)
+            return ("rec", dec(z_of(m)).reconstruction)
+
         rec = kernels.run_branches(self._branch_order(inputs), decode, device)
-        recons = [rec[m] for m in names]
-        spec = self._recon_spec(names, inputs.data, masks, K, B)
-        M = len(names)
+        plain = [m for m in names if rec[m][0] == "rec"]
+        fused = [m for m in names if rec[m][0] == "rows"]
+        recons = [rec[m][1] for m in plain]
+        spec = self._recon_spec(plain, inputs.data, masks, K, B)
+        M, S, Fz = len(plain), len(style_kl), len(fused)
         beta = float(self.model_config.beta)
-        spec.update(coef=[1.0 / (K * B)] * M, lossw=[1.0] * M, extra_coef=[1.0 / B] * (1 + len(style_kl)),
-                    extra_lossw=[beta] + [beta * float(self.model_config.beta_style)] * len(style_kl),
+        spec.update(coef=[1.0 / (K * B)] * M, lossw=[1.0] * M,
+                    extra_coef=[1.0 / B] * (1 + S) + [float(self.rescale_factors[m]) / (K * B) for m in fused],
+                    extra_lossw=[beta] + [beta * float(self.model_config.beta_style)] * S + [1.0] * Fz,
                     loss_sum_scale=float(B))
         if style_kl and masks is not None:  # style_kld *= mask (:217-218), still averaged over the whole batch
             style_kl = [kl * masks[m].to(kl.dtype) for kl, m in zip(style_kl, names)]
-        loss, terms = kernels.ReconLossFn.apply(spec, M, *recons, kld_rows, *style_kl)
+        loss, terms = kernels.ReconLossFn.apply(spec, M, *recons, kld_rows, *style_kl, *[rec[m][1] for m in fused])
         jd = terms[M]
         if style_kl:
             # `kld = results["joint_divergence"]` is updated in place by `kld += style_kld.mean() * beta_style`
             # (:164, :221): the reference's metric includes the style terms
-            jd = jd + float(self.model_config.beta_style) * terms[M + 1:M + 1 + len(style_kl)].sum()
+            jd = jd + float(self.model_config.beta_style) * terms[M + 1:M + 1 + S].sum()
         metrics = {"joint_divergence": jd}
-        for i, m in enumerate(names):
-            metrics["recon_" + m] = terms[i]
-        n_terms = M + 1 + len(style_kl)
+        for m in names:
+            metrics["recon_" + m] = terms[plain.index(m)] if m in plain else terms[M + 1 + S + fused.index(m)]
+        n_terms = M + 1 + S + Fz
         return ModelOutput(loss=loss, loss_sum=terms[n_terms + 1], metrics=metrics)
 
     def inference(self, inputs, **kwargs):

@@ -37,7 +37,7 @@ class GraphedStep:
         prof = kernels.PROFILE.pop("recon_nll", None)  # host-timed events cannot be recorded into a graph
         try:
             cur = torch.cuda.current_stream(dev)
-            side = torch.cuda.Stream(device=dev)
+            side = kernels._side_stream(dev, 62)  # a dedicated stream (not one of torch's pooled ones: _lib.new_stream)
             side.wait_stream(cur)
             with torch.cuda.stream(side):  # eager warm-up: fills every cache (scratch, packed masks, autotuned paths)
                 for _ in range(max(int(warmup), 1)):

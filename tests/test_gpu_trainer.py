@@ -162,6 +162,46 @@ def test_graph_replay_matches_eager():
     _same_training(_run_steps(d, 5, graphed=False), _run_steps(d, 5, graphed=True))
 
 
+@pytest.mark.parametrize("K,B", [(3, 16), (1, 24), (10, 64)])
+def test_fused_decoder_tail_matches_the_generic_path(K, B):
+    """MoPoE MnistSvhn with the SVHN decoder scoring its own output (Decoder_VAE_SVHN.reconstruction_nll: Normal NLL row sums and
+    d rows / d pre-activation out of the last layer's epilogue, mvk_conv4s2_small_up_fwd_nll / _bwd_pre) against the same model
+    decoding the images and running the generic likelihood kernel: loss, every metric, every gradient."""
+    from multivae_amd.data.datasets.base import DatasetOutput
+    from multivae_amd.trainers import FlatParams
+
+    d = torch.device("cuda:0")
+    L = 8
+    model = _mnist_svhn_mopoe(d, K=K, L=L, seed=5)
+    model.model_config.uses_likelihood_rescaling = True
+    model.rescale_factors = dict(mnist=3072 / 784, svhn=1.0)
+    flat = FlatParams(model)
+    g = torch.Generator().manual_seed(21)
+    inputs = DatasetOutput(data=dict(mnist=torch.rand(B, 1, 28, 28, generator=g).to(d), svhn=torch.rand(B, 3, 32, 32, generator=g).to(d)))
+    eps = torch.randn(K, B, L, generator=g).to(d)
+    res = {}
+    for fused in (True, False):
+        model.fused_decoder_tail = fused
+        flat.zero_grad()
+        out = model(inputs, noise=eps)
+        out.loss.backward()
+        torch.cuda.synchronize()
+        res[fused] = (float(out.loss), {k: float(v) for k, v in out.metrics.items()}, flat.grad.detach().clone())
+    lf, mf, gf = res[True]
+    lp, mp, gp = res[False]
+    assert abs(lf - lp) <= 1e-6 * abs(lp), (lf, lp)
+    for k in mp:
+        assert abs(mf[k] - mp[k]) <= 1e-6 * abs(mp[k]) + 1e-12, (k, mf[k], mp[k])
+    for (name, p), off in zip(model.named_parameters(), flat.offsets):
+        n = p.numel()
+        a, b = gf[off:off + n], gp[off:off + n]
+        scale = float(b.abs().max().clamp_min(1e-30))
+        assert float((a - b).abs().max()) <= 3e-6 * scale, (name, float((a - b).abs().max()), scale)
+    with torch.no_grad():  # evaluation never takes the fused tail (it has no gradient to prepare)
+        model.fused_decoder_tail = True
+        assert abs(float(model(inputs, noise=eps).loss) - lp) <= 1e-6 * abs(lp)
+
+
 def test_deferred_reductions_match_immediate_finishes():
     """kernels.deferred_reductions (mvk_defer_begin / _end): every ordered finish of a weight / bias gradient queued and
     run in one launch at the end of the backward pass vs one launch each behind its producer.  Same partial results, a

@@ -21,7 +21,8 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/mvk.h but not exported by libmvk.so"
-    bound = set(_lib.PROTOTYPES) | {"mvk_splitk_workspace_floats", "mvk_conv4s2_small_up_supported", "mvk_imgconv_frag_bytes",
+    bound = set(_lib.PROTOTYPES) | {"mvk_splitk_workspace_floats", "mvk_conv4s2_small_up_supported", "mvk_conv4s2_small_up_nll_supported",
+                                    "mvk_imgconv_frag_bytes",
                                     "mvk_debug_set_phase_buffer", "mvk_debug_set_flags",  # void hooks, bound ad hoc
                                     "mvk_prof_enable", "mvk_prof_count", "mvk_prof_clock_khz", "mvk_prof_calibrate",
                                     "mvk_defer_pending", "mvk_defer_wanted", "mvk_conv3x3_fused_ok"}
