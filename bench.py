@@ -493,11 +493,16 @@ def main():
                        "peak_device_memory_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
                        "launch": "hipGraph replay (fwd+bwd) + all-reduce + Adam" if graphed is not None else "eager"},
         }
-        nll = summarise(recs, {"recon_nll"}, boundary)
+        nll_generic = summarise(recs, {"recon_nll"}, boundary)
+        imgf = summarise(recs, {"image_layer_fwd"}, boundary)
+        # With the fused decoder tail (round 3) the large modality's reconstruction NLL lives in the epilogue of its decoder's last
+        # layer: THAT launch is the fused reconstruction-NLL kernel now, the generic kernel only scores the small modality
+        fused_tail = bool(nll_generic and imgf and nll_generic["work"] / nll_generic["launches"] < 0.5 * imgf["work"] / imgf["launches"])
+        nll = imgf if fused_tail else nll_generic
         if nll:
             ev = [s.elapsed_time(e) * 1e-3 for s, e in events]
             traffic, traffic_meta = None, {}
-            tf = os.path.join(ROOT, "profiles", "recon_nll_traffic.json")
+            tf = os.path.join(ROOT, "profiles", "fused_tail_traffic.json" if fused_tail else "recon_nll_traffic.json")
             if args.config == "cfg3" and os.path.exists(tf):
                 with open(tf) as f:
                     traffic_meta = json.load(f)
@@ -505,10 +510,13 @@ def main():
             ach = nll["work"] / nll["seconds"] / 1e9
             copy_gbs = measured_copy_gbs(device)
             res["roofline"] = {
-                "kernel": "recon_nll_kernel<vec,fwd> (fused reconstruction NLL + d_recon, all modalities, one launch)",
+                "kernel": ("small_up_fwd_bf_kernel<3, 512, NLL> (decoder tail + reconstruction NLL + d NLL / d pre-activation of the "
+                           "svhn modality in one launch: reads the 16x16x32 input map and the targets, writes the gradient; the "
+                           "image and d_recon of SURVEY 8(d)'s byte count are never written)") if fused_tail else
+                          "recon_nll_kernel<vec,fwd> (fused reconstruction NLL + d_recon, all modalities, one launch)",
                 "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": ("profiles/recon_nll_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                "traffic_source": (("profiles/fused_tail_traffic.json" if fused_tail else "profiles/recon_nll_traffic.json") + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                    "command by tools/gpu_profile.sh (counters cannot be read from inside the process); "
                                    f"measured at commit {traffic_meta.get('commit', 'unrecorded')}") if traffic else None,
                 "measured_copy_GBs": round(copy_gbs, 1), "frac_vs_measured_copy": round(ach / copy_gbs, 4),
@@ -523,7 +531,14 @@ def main():
                           "`steps` replays of the instrumented step right after the timed region.  minus_kernel_boundary_us "
                           "takes off one dependent-kernel boundary calibrated in the same run",
                 "instrumented_ms_per_step": round(ms_instr, 4),
-                "hip_event_pair_us": round(1e6 * sum(ev) / len(ev), 2) if ev else None}
+                "hip_event_pair_us": round(1e6 * sum(ev) / len(ev), 2) if ev and not fused_tail else None}
+            if fused_tail:  # the generic likelihood kernel that is left (the small modality): 32 MB, latency-sized
+                g_ach = nll_generic["work"] / nll_generic["seconds"] / 1e9
+                res["roofline_generic_nll"] = {"kernel": "recon_nll_kernel<vec,fwd> (mnist only)", "bound": "hbm",
+                                               "achieved": round(g_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                               "frac": round(g_ach / HBM_PEAK_GBS, 4),
+                                               "algorithmic_bytes": nll_generic["work"] / nll_generic["launches"],
+                                               "avg_launch_us": round(nll_generic["avg_us"], 2)}
         conv = summarise(recs, {"imgconv_up", "imgconv_down", "imgconv_wgrad"}, boundary)
         SPLIT_PEAK = MFMA_BF16_TFLOPS / 6
         mf = {"bound": "mfma", "unit": "TFLOP/s", "peak": round(SPLIT_PEAK, 1),

@@ -1071,7 +1071,8 @@ static int launch_fwd(const float* V, const float* Wref, const float* bias, floa
   }
   const int grid = n < 512 ? n : 512;  // persistent: 2 workgroups per CU, each loops over images with prefetch
   // algorithmic bytes: the input map read once, the image written once
-  mvk_prof_slot* prof = mvk::prof_next(5, 4.0 * n * h * w * (CV + 4.0 * CU));
+  // (+ the target images of the fused tail, read once per data point)
+  mvk_prof_slot* prof = mvk::prof_next(5, 4.0 * n * h * w * (CV + 4.0 * CU) + (X ? 16.0 * xrows * h * w * CU : 0.0));
   // dense: 256 positions = one 16-row tile per wave, CV / 4 * 256 float4 and CU * 1024 outputs divide the workgroup evenly
   const bool dense = h == 16 && w == 16 && NT == 1024 && (256 * CV / 4) % NT == 0 && (CU * 1024) % NT == 0;
   // MVK_SMALL_FWD_BF=0: the exact-fp32 matrix instructions for every shape; =512: the split kernel with 512-thread workgroups

@@ -166,5 +166,15 @@ if k in fs and k in ws:
                              "WRITE_SIZE as reported",
                "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
                "algorithmic_bytes_per_launch": 165838848}, open(f"{DST}/recon_nll_traffic.json", "w"), indent=1)
+kf = next((kk for kk in fs if kk.startswith("small_up_fwd_bf_kernel") and kk in ws and "true" in kk), None)
+if kf:  # the fused decoder tail: the launch that carries the large modality's reconstruction NLL
+    rd, wr = int(2 * fs[kf]["FETCH_SIZE"] * 1e6 * 1024), int(ws[kf]["WRITE_SIZE"] * 1e6 * 1024)
+    json.dump({"kernel": kf, "workload": "MoPoE MnistSvhn K=10 B=512, bench.py default config (fused decoder tail on)",
+               "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), MI355X, round {ROUND} "
+                         f"(tools/gpu_profile_{TAG}.sh)", "commit": COMMIT,
+               "correction": "gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide coalesced read: doubled; WRITE_SIZE as reported",
+               "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
+               "algorithmic_bytes_per_launch": 4 * 5120 * 256 * 32 + 4 * 5120 * 3072 + 4 * 512 * 3072},
+              open(f"{DST}/fused_tail_traffic.json", "w"), indent=1)
 print(open(f"{DST}/{TAG}_pmc_mfma.md").read()[-2600:])
 print(open(f"{DST}/{TAG}_pmc_hbm.md").read()[-1800:])
