@@ -228,6 +228,8 @@ GEMM_FLOPS = {
     "mvk_conv4s2_small_up_fwd": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
     "mvk_conv4s2_small_down_fwd": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
     "mvk_conv4s2_small_up_bwd": lambda a: 2.0 * 2.0 * a[12] * a[13] * a[14] * 16 * a[15] * a[16],  # data + weight
+    "mvk_conv4s2_small_up_fwd_nll": lambda a: 2.0 * a[8] * a[9] * a[10] * 16 * a[11] * a[12],
+    "mvk_conv4s2_small_up_bwd_pre": lambda a: 2.0 * 2.0 * a[11] * a[12] * a[13] * 16 * a[14] * a[15],  # data + weight
     "mvk_unflatten_wgrad": lambda a: 2.0 * a[3] * a[4] * 16 * a[5],
     "mvk_flatten_wgrad": lambda a: 2.0 * a[3] * 16 * a[4] * a[5],
     "mvk_heads_fwd": lambda a: 2.0 * (2 if a[4] and a[4].value else 1) * a[7] * a[8] * a[9],
