@@ -329,7 +329,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if os.environ.get("MVK_BENCH_SAME_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: multivae_amd has no CPU compute path")
     torch.cuda.set_device(local_rank)
@@ -338,7 +338,9 @@ def main():
 
     use_dist = world > 1 or os.environ.get("MVK_FORCE_DIST") == "1"  # the latter exercises the RCCL path on 1 GPU
     if use_dist:
-        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)  # nccl == RCCL on ROCm
+        # nccl == RCCL on ROCm.  MVK_DIST_BACKEND=gloo: the control flow of the multi-rank run on ONE GPU (RCCL refuses two
+        # ranks on one device; tests/test_gpu_trainer.py runs bench.py that way with MVK_BENCH_SAME_GPU=1)
+        dist.init_process_group(os.environ.get("MVK_DIST_BACKEND", "nccl"), init_method="env://", world_size=world, rank=rank)
 
     from multivae_amd import _lib, kernels
     from multivae_amd.data.datasets.base import DatasetOutput
@@ -358,7 +360,7 @@ def main():
     draw = w["noise"]
     fkw = w["fwd_kwargs"]
 
-    def eager_step():
+    def eager_step(collective=True):
         kw = dict(fkw)
         if draw is not None:
             kw["noise"] = draw(gen)
@@ -366,7 +368,7 @@ def main():
         with kernels.deferred_reductions(flat):
             out = model(inputs, **kw)
             out.loss.backward(gradient=kernels.unit_seed(out.loss))
-        if use_dist:
+        if use_dist and collective:
             flat.all_reduce()  # C2: ONE all-reduce of the flat gradient buffer
         opt.step(grad_scale=grad_scale)
         return out
@@ -424,9 +426,10 @@ def main():
         # second graph: every replay accumulates into the records), `steps` replays right after the timed region.  The
         # stamps and the one-wave fold kernels behind the instrumented launches cost ~2 % of the step, which is why the
         # headline number above is measured without them.
+        # (rank 0 only: NO collective in here — the other ranks are already waiting in the all-reduce of the elapsed time below)
         prof = DeviceProfiler(device)
         prof.start()
-        step2 = eager_step
+        step2 = lambda: eager_step(collective=False)
         if graphed is not None:
             try:
                 g2 = GraphedStep(model, flat, inputs, noise=None,
@@ -435,8 +438,6 @@ def main():
 
                 def step2():
                     o = g2(inputs)
-                    if use_dist:
-                        flat.all_reduce()
                     opt.step(grad_scale=grad_scale)
                     return o
             except Exception as e:
@@ -456,12 +457,12 @@ def main():
         kernels.PROFILE["recon_nll"] = events
         kernels.PROFILE["presleep_cycles"] = 200_000  # ~0.1 ms GPU spin: the host enqueues the launch meanwhile
         for _ in range(3):
-            eager_step()
+            eager_step(collective=False)
         torch.cuda.synchronize()
         kernels.PROFILE.pop("recon_nll", None)
         kernels.PROFILE.pop("presleep_cycles", None)
         _lib.COUNT_FLOPS = [0.0]  # GEMM-shaped FLOP of one step (every mvk_linear / gemm / conv entry point)
-        eager_step()
+        eager_step(collective=False)
         torch.cuda.synchronize()
         step_flops, _lib.COUNT_FLOPS = _lib.COUNT_FLOPS[0], None
 

@@ -565,6 +565,31 @@ def test_rccl_path_on_one_gpu_matches_the_plain_step(tmp_path):
     assert outs[1]["n_gpus"] == 1
 
 
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_on_one_gpu():
+    """The driver's multi-GPU launch line (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) with N = 2
+    on ONE GPU (gloo instead of RCCL, both ranks on cuda:0): every rank runs the same collectives in the same order — rank 0's
+    profiling section issues none —, the line reports the whole-job rate and the weak-scaling fields."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MVK_DIST_BACKEND="gloo", MVK_BENCH_SAME_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "64"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 128
+    assert d["value"] == pytest.approx(2 * 64 * 4 / (d["ms_per_step"] * 4e-3), rel=1e-3)
+    assert "cpu_baseline" not in d and "roofline" in d
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # The REAL distributed step with world_size 2 (VERDICT r2 item 4): two processes on cuda:0, gloo all-reducing the CUDA
 # gradient buffer, BaseTrainer with FusedAdam + hipGraph replay (thread-local capture) on MoPoE MnistSvhn.
