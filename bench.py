@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 MFMA_F32_TFLOPS = 157.3    # fp32-input MFMA = the fp32 vector rate
 MFMA_BF16_TFLOPS = 2500.0  # dense bf16 MFMA; an fp32 product on the split-bf16 path costs 6 bf16 products
 PROF_KINDS = {1: "recon_nll", 2: "imgconv_up", 3: "imgconv_down", 4: "imgconv_wgrad", 5: "image_layer_fwd",
-              6: "image_layer_bwd"}
+              6: "image_layer_bwd", 7: "conv3_rs", 8: "conv3_wgrad"}
 
 
 # ---- workloads --------------------------------------------------------------------------------------------------------
@@ -296,6 +296,29 @@ def measured_copy_gbs(device, mb=512, reps=20):
     return 2.0 * 4 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def measured_mfma_tflops(device, target_us, random_operands=True):
+    """bf16 MFMA rate (TFLOP/s) a register-only loop sustains in launches of about `target_us` (mvk_probe_mfma_bf16: the pipe is
+    100 % busy; what varies is the clock the chip holds under that load) — the measured ceiling beside the data-sheet one."""
+    from multivae_amd import _lib
+
+    out = torch.empty(65536, dtype=torch.float32, device=device)
+    per_iter = 256 * 4 * 64 * 32768.0  # FLOP of one loop iteration of the whole launch
+    iters = max(8, int(target_us * 1e-6 * 1.6e15 / per_iter))
+
+    def run(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            _lib.call("mvk_probe_mfma_bf16", _lib.ptr(out), iters, 1 if random_operands else 0, _lib.stream_ptr())
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    run(5)
+    sec = run(20)
+    return per_iter * iters / sec / 1e12, sec * 1e6
+
+
 def summarise(recs, kinds, boundary_s=0.0):
     """Duration per launch = first workgroup in -> first instruction of the one-wave kernel queued behind it (what
     rocprofv3's begin -> end of the dispatch shows, within ~1 %); `busy_avg_us` takes one calibrated kernel boundary off."""
@@ -540,7 +563,8 @@ def main():
                                                "frac": round(g_ach / HBM_PEAK_GBS, 4),
                                                "algorithmic_bytes": nll_generic["work"] / nll_generic["launches"],
                                                "avg_launch_us": round(nll_generic["avg_us"], 2)}
-        conv = summarise(recs, {"imgconv_up", "imgconv_down", "imgconv_wgrad"}, boundary)
+        conv = summarise(recs, {"imgconv_up", "imgconv_down", "imgconv_wgrad", "conv3_rs", "conv3_wgrad"}, boundary)
+        conv3 = summarise(recs, {"conv3_rs", "conv3_wgrad"}, boundary) is not None
         SPLIT_PEAK = MFMA_BF16_TFLOPS / 6
         mf = {"bound": "mfma", "unit": "TFLOP/s", "peak": round(SPLIT_PEAK, 1),
               "peak_fp32_input_mfma": MFMA_F32_TFLOPS,
@@ -556,7 +580,15 @@ def main():
                       "tools/imgconv_probe.py, DESIGN.md section 6)"}
         if conv:
             ach = conv["work"] / conv["seconds"] / 1e12
-            mf.update({"kernel": "imgconv_kernel / imgwgrad_kernel (register-stationary 4x4/stride-2 convolutions)",
+            m_tf, m_us = measured_mfma_tflops(device, 1e6 * conv["seconds"] / conv["launches"])
+            mf.update({"measured_sustained_bf16": round(m_tf, 1), "measured_sustained_fp32_equiv": round(m_tf / 6, 1),
+                       "measured_launch_us": round(m_us, 1),
+                       "frac_vs_measured_sustained": round(ach / (m_tf / 6), 4),
+                       "measured_note": "register-only v_mfma_f32_32x32x16_bf16 loop with hashed operand values in launches of the "
+                                        "named kernels' length (mvk_probe_mfma_bf16): pipe 100 % busy, clock as sustained under "
+                                        "that load — the power-limited ceiling of this chip for real operand data"})
+            mf.update({"kernel": ("c3rs_kernel / c3wg_kernel (register-stationary 3x3 convolutions of the ResNet blocks)" if conv3 else
+                                  "imgconv_kernel / imgwgrad_kernel (register-stationary 4x4/stride-2 convolutions)"),
                        "achieved": round(ach, 1), "frac": round(ach / SPLIT_PEAK, 4),
                        "frac_vs_fp32_input_mfma": round(ach / MFMA_F32_TFLOPS, 4),
                        "gflop_per_step": round(conv["work"] / args.steps / 1e9, 2),

@@ -423,6 +423,11 @@ int mvk_avgpool3s2_bwd(const float* dy, float* dx, int n, int H, int W, int C, v
 int mvk_upsample2_fwd(const float* x, float* y, int n, int H, int W, int C, void* stream);
 int mvk_upsample2_bwd(const float* dy, float* dx, int n, int H, int W, int C, void* stream);
 int mvk_axpby(const float* x, float a, const float* y, float b, int64_t n, int act, float* out, void* stream);
+/* Measurement aid of bench.py (not on the training path): one launch of a register-only loop of v_mfma_f32_32x32x16_bf16 — 256
+ * workgroups, one wave per SIMD, 4 accumulator chains, 64 * iters MFMAs per chain — with hashed operand values (random_operands = 1)
+ * or constants (0).  Timed by the caller, it gives the matrix-pipe rate the chip SUSTAINS for a launch of that length; with
+ * realistic operands that is 1.4-1.9 PFLOP/s, not the 2.5 of the data sheet (power-limited clock).  out: >= 65536 floats. */
+int mvk_probe_mfma_bf16(float* out, int iters, int random_operands, void* stream);
 /* y[b][c][r] = act(x[b][r][c]) * dact'(msrc[b][r][c]) (msrc may be NULL; the derivative is taken through the OUTPUT of dact,
  * as everywhere here): the NCHW flatten in front of `fc_mu / fc_logvar` of the ResNet encoders fused with their last activation
  * (models/nn/cub.py:190-195, mmnist.py:300-306), the un-flatten behind `fc` of the decoders (cub.py:232-240), and their

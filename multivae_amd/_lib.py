@@ -92,6 +92,7 @@ PROTOTYPES = {
     "mvk_upsample2_bwd": [_p, _p, _i, _i, _i, _i, _p],
     "mvk_axpby": [_p, _f, _p, _f, _i64, _i, _p, _p],
     "mvk_transpose_act": [_p, _p, _i, _i, _i, _i, _p, _i, _p],
+    "mvk_probe_mfma_bf16": [_p, _i, _i, _p],
     "mvk_device_rng": [_p, _i64, _p, _i, _f, _f, _p],
     "mvk_conv4s2_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _p],
     "mvk_conv4s2_up_nchw_small": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],

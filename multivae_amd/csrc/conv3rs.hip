@@ -45,7 +45,6 @@ struct C3Args {
   const float* act_src;  // tensor of the output's shape whose activation derivative multiplies the result, or null
   const float* res;      // residual of the output's shape: Y = res + res_alpha * result, or null
   float* colsum_part;    // [workers][COUT] per-workgroup column sums of the result (before the residual), or null
-  float* trash;          // unused (dropped rows are out-of-range buffer stores)
   unsigned xbytes, ybytes;  // sizes of X and of Y / act_src / res in bytes (< 2^32 - 4096): buffer bounds
   int n, H, W;
   float aslope, mslope;  // negative-side slopes of the output activation (1 = none) and of the mask (src_act)
@@ -733,10 +732,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int step = 0; step < 6; ++step) {  // (k-step, kernel row)
       const int s = step / 3, grp = step % 3;
-      bf16x8 A_nxt[3][3];
+      bf16x8 A_nxt[3][3], B_nxt[2][3];
       if (step < 5) {
         row_addr(ad, tb, (step + 1) / 3, (step + 1) % 3 - 1);
         read_row(A_nxt, ad);
+      } else {  // behind the barrier (end of step 4): the first fragments of the NEXT tile, covered by this step's 18 MFMAs
+        row_addr(ad, tbn, 0, -1);
+        read_row(A_nxt, ad);
+        read_b(B_nxt, nbuf_r);
       }
       if (step == 0) {
 #pragma unroll
@@ -763,17 +766,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           __builtin_amdgcn_sched_group_barrier(0x496, MVK_C3W_SCHED > 0 ? MVK_C3W_SCHED : 1, 0);
         }
       }
-      if (step < 5) {
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
+      for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) A_cur[dx][pc] = A_nxt[dx][pc];
+        for (int pc = 0; pc < 3; ++pc) A_cur[dx][pc] = A_nxt[dx][pc];
+      if (step == 4) __syncthreads();  // the conversions of this tile (steps 1-4) are published; ONE barrier per tile
+      if (step == 5) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) Bf[s2][pc] = B_nxt[s2][pc];
       }
     }
-    __syncthreads();
-    row_addr(ad, tbn, 0, -1);
-    read_row(A_cur, ad);
-    read_b(Bf, nbuf_r);
     tb = tbn;
     wch = wch + 1 == NCH ? 0 : wch + 1;
   }
@@ -872,12 +876,12 @@ bool c3rs_shape_ok(int n, int H, int W, int Cin, int Cout) {
 // 1: not covered (the caller falls back to the implicit-GEMM engine).  colsum_part: [256 / types][Cout] floats.
 int c3rs_conv(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
               const float* act_src, int src_act, const float* res, float res_alpha, float* colsum_part, int* part_rows,
-              float* trash, int x_act, float pre_scale, hipStream_t s) {
+              int x_act, float pre_scale, hipStream_t s) {
   if (act == MVK_ACT_SIGMOID || (act_src && src_act == MVK_ACT_SIGMOID) || x_act == MVK_ACT_SIGMOID || !mvk_aligned16(X)) return 1;
   if (colsum_part && (!act_src || res)) return 1;  // column sums: backward-data form only (WITH_CSUM)
   if (!c3rs_shape_ok(n, H, W, Cin, Cout)) return 1;
   const long long total = (long long)n * (H + 1) * (W + 1);
-  C3Args a{X, Wp, bias, Y, act_src, res, colsum_part, trash, (unsigned)((long long)n * H * W * Cin * 4),
+  C3Args a{X, Wp, bias, Y, act_src, res, colsum_part, (unsigned)((long long)n * H * W * Cin * 4),
            (unsigned)((long long)n * H * W * Cout * 4), n, H, W, c3_slope(act), c3_slope(act_src ? src_act : MVK_ACT_NONE),
            res_alpha, c3_slope(x_act), pre_scale, c3_ring(W), (W + 2 + 31) / 32, (int)((total + 31) / 32), nullptr};
   if (Cin == 64 && Cout == 64) return c3rs_launch<64, 64>(a, part_rows, s);

@@ -724,7 +724,7 @@ int imgconv_wgrad(const float* U, const float* V, float* slab, long long slab_fl
 // bit 0x800 takes them for every problem size (tests); MVK_C3RS=0 / MVK_C3RS=<min tiles> under MVK_TUNE=1.
 int c3rs_conv(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
               const float* act_src, int src_act, const float* res, float res_alpha, float* colsum_part, int* part_rows,
-              float* trash, int x_act, float pre_scale, hipStream_t s);
+              int x_act, float pre_scale, hipStream_t s);
 bool c3rs_shape_ok(int n, int H, int W, int Cin, int Cout);
 bool c3rs_wgrad_ok(int n, int H, int W, int Cin, int Cout);
 int c3rs_wgrad(const float* X, const float* dY, float* slab, long long slab_floats, float* dbpart, int x_act, float dy_scale,
@@ -1046,7 +1046,7 @@ static int conv3x3_any(const float* X, const float* Wp, const float* bias, float
                        float* ws, int64_t ws_floats, void* stream, int x_act = MVK_ACT_NONE, float pre_scale = 1.f) {
   const bool fused = x_act != MVK_ACT_NONE || pre_scale != 1.f;  // forms only the register-stationary kernels take
   if (!X || !Wp || !Y || n < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return MVK_EINVAL;
-  if (fused && !(n > 0 && ws && ws_floats >= 256ll * Cout + 64 && !(res && colsum_acc) && mvk_aligned16(X) &&
+  if (fused && !(n > 0 && ws && ws_floats >= 256ll * Cout && !(res && colsum_acc) && mvk_aligned16(X) &&
                  (!colsum_acc || y_act_src) && c3rs_covers(n, H, W, Cin, Cout)))
     return MVK_EINVAL;  // ask mvk_conv3x3_fused_ok first
   if (n > 0 && Cin <= 4 && !res) {  // the image-consuming layer (or the backward-data pass of the image-producing one)
@@ -1061,13 +1061,12 @@ static int conv3x3_any(const float* X, const float* Wp, const float* bias, float
       return colsum(Y, nullptr, 0, n * H * W, Cout, colsum_acc, ws, ws_floats, mvk_stream(stream));
     if (rc != 1) return rc;
   }
-  if (n > 0 && ws && ws_floats >= 256ll * Cout + 64 && !(res && colsum_acc) && mvk_aligned16(X) && act != MVK_ACT_SIGMOID &&
+  if (n > 0 && ws && ws_floats >= 256ll * Cout && !(res && colsum_acc) && mvk_aligned16(X) && act != MVK_ACT_SIGMOID &&
       !(y_act_src && y_src_act == MVK_ACT_SIGMOID) && (!colsum_acc || y_act_src) && c3rs_covers(n, H, W, Cin, Cout)) {
     int rows = 0;
     float* dpart = colsum_acc ? defer_scratch(colsum_acc, 256ll * Cout, mvk_stream(stream)) : nullptr;
     const int rc = c3rs_conv(X, Wp, bias, Y, n, H, W, Cin, Cout, act, y_act_src, y_src_act, res, res_alpha,
-                             colsum_acc ? (dpart ? dpart : ws) : nullptr, &rows, ws + 256ll * Cout, x_act, pre_scale,
-                             mvk_stream(stream));
+                             colsum_acc ? (dpart ? dpart : ws) : nullptr, &rows, x_act, pre_scale, mvk_stream(stream));
     if (rc == MVK_OK && dpart) return defer_push_plain(colsum_acc, dpart, Cout, rows, Cout, mvk_stream(stream));
     if (rc == MVK_OK && colsum_acc) return colsum_finish(ws, rows, Cout, colsum_acc, mvk_stream(stream));
     if (rc != 1) return rc;

@@ -867,6 +867,57 @@ int mvk_upsample2_bwd(const float* dy, float* dx, int n, int H, int W, int C, vo
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------------------
+// Measured ceiling of the matrix pipes (bench.py `roofline_mfma.measured_*`): a register-only loop of
+// v_mfma_f32_32x32x16_bf16, one wave per SIMD, 256 workgroups, 4 accumulator chains, 64 iters MFMAs per chain, with a different
+// operand pair of hashed values per MFMA (random = 1) or two constants (random = 0).  The pipe is 100 % busy either way; with
+// realistic operand data the chip sustains 1.4-1.9 GHz instead of 2.1-2.4 (power): THAT is the ceiling a real MFMA-bound
+// kernel is measured against (profiles/r03_mfma_sustained.txt, tools/ubench/mfma_bf16_sustained.hip).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+typedef float probe_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 probe_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int probe_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void mfma_probe_kernel(float* out, int iters, int rnd, unsigned seed) {
+  probe_f32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  probe_bf16x8 av[8], bv[8];
+  for (int j = 0; j < 8; ++j) {
+    probe_u32x4 ua, ub;
+    for (int e = 0; e < 4; ++e) {
+      unsigned h = (seed + threadIdx.x * 2654435761u + j * 40503u + e * 9176u + blockIdx.x * 7919u) * 2246822519u;
+      h ^= h >> 15;
+      h *= 3266489917u;
+      h ^= h >> 13;
+      const unsigned lo = 0x3f80u | (h & 0x807fu), hi = 0x3f80u | ((h >> 16) & 0x807fu);  // +-[1, 2)
+      ua[e] = rnd ? (lo | (hi << 16)) : 0x3f803f80u;
+      ub[e] = rnd ? ((hi ^ 0x8000u) | (lo << 16)) : 0x3f003f00u;
+    }
+    av[j] = __builtin_bit_cast(probe_bf16x8, ua);
+    bv[j] = __builtin_bit_cast(probe_bf16x8, ub);
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[(u + i) & 7], bv[(u * 3 + i) & 7], acc[i], 0, 0, 0);
+  }
+  float s_ = 0.f;
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) s_ += acc[i][r];
+  out[blockIdx.x * 256 + threadIdx.x] = s_;
+}
+}  // namespace
+
+// out: 65536 floats (written, meaningless); one launch = 256 workgroups x 4 waves x iters x 64 MFMAs of 32768 FLOP
+extern "C" int mvk_probe_mfma_bf16(float* out, int iters, int random_operands, void* stream) {
+  if (!out || iters <= 0) return MVK_EINVAL;
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(256), dim3(256), 0, mvk_stream(stream), out, iters, random_operands, 12345u);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Batched transpose with a fused activation / activation derivative: the flatten of the ResNet encoders
 // (`out.view(batch, nf0 * s0 * s0)` on an NCHW tensor, models/nn/cub.py:190-195, mmnist.py:300-306) and the `view(-1, nf0,
 // s0, s0)` of the decoders (cub.py:232-240), whose convolutional stacks run NHWC here:

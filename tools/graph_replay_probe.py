@@ -1,3 +1,5 @@
+"""Capture + first replay of the full-size MoPoE step (the path that crashed in hip::Graph::UpdateStreams while side streams came from
+torch's round-robin pool).  python tools/graph_replay_probe.py {0|1: fused tail} {eager_first|direct}"""
 import sys, os
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import torch
