@@ -373,7 +373,9 @@ typedef struct mvk_pack_desc {
   int Cv, Cu, ld_down, col_off, kind;
   void* Fdown; /* kind 0, optional: the weights as bf16-piece MFMA fragments in the order the register-stationary */
   void* Fup;   /* convolution kernels (csrc/imgconv.hip) load them: [role][k-step 16][piece 3][lane 64][8 bf16],  */
-} mvk_pack_desc; /* mvk_imgconv_frag_bytes(Cu, Cv) bytes each; passed to mvk_conv4s2_down / _up as `wfrag` */
+               /* mvk_imgconv_frag_bytes(Cu, Cv) bytes each; passed to mvk_conv4s2_down / _up as `wfrag` */
+  float* amax; /* optional: receives max |Wref| (atomic max: must hold 0 before the launch) — the w_amax of mvk_conv3x3_s */
+} mvk_pack_desc;
 int64_t mvk_imgconv_frag_bytes(int Cu, int Cv); /* 0: this channel pair has no register-stationary kernel */
 int mvk_pack_weights(const mvk_pack_desc* jobs, int n, void* stream);
 int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w,
@@ -416,6 +418,21 @@ int mvk_conv3x3_f(const float* X, const float* Wp, const float* bias, float* Y, 
                   int x_act, float pre_scale, float* ws, int64_t ws_floats, void* stream);
 int mvk_conv3x3_wgrad_f(const float* X, const float* dY, float* dWref, float* db, int n, int H, int W, int Cin, int Cout,
                         int x_act, float dy_scale, float* ws, int64_t ws_floats, void* stream);
+/* Scaled-fp16 form of mvk_conv3x3_f: every fp32 product is 3 fp16 MFMAs (hi hi' + (hi lo' + lo hi') / 2048, error-corrected
+ * fp16 pairs after Ootomo & Yokota 2022; csrc/bf3.hpp states the error bound) instead of the 6 bf16 ones.  fp16 has a narrow
+ * exponent, so each operand tensor is scaled by a power of two taken from an UPPER BOUND of its largest magnitude:
+ *   x_amax, w_amax  device scalars >= max |X|, max |Wp| (finite inputs; a bound that is too small overflows to inf)
+ *   y_amax          optional: max |Y| of this launch lands here by atomic max (*y_amax must hold 0 before the launch) and
+ *                   can be the x_amax of the launch that consumes Y
+ * mvk_amax computes the bound of any tensor (same protocol: *out holds 0 or a lower bound to keep); mvk_pack_weights fills
+ * the `amax` slot of a descriptor.  mvk_conv3x3_scaled_ok: 1 when this form takes the problem (a superset of the shapes of
+ * mvk_conv3x3_fused_ok's forward side: 128 input channels reach maps up to 62 wide). */
+int mvk_amax(const float* x, int64_t n, float* out, void* stream);
+int mvk_conv3x3_scaled_ok(int n, int H, int W, int Cin, int Cout);
+int mvk_conv3x3_s(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout,
+                  int act, const float* y_act_src, int y_src_act, const float* res, float res_alpha, float* colsum_acc,
+                  int x_act, float pre_scale, const float* x_amax, const float* w_amax, float* y_amax, float* ws,
+                  int64_t ws_floats, void* stream);
 /* nn.AvgPool2d(3, stride=2, padding=1) (count_include_pad: every window divides by 9) and nn.Upsample(scale_factor=2)
  * (nearest) on NHWC tensors, forward and backward; out = act(a*x + b*y) (x or y may be NULL). */
 int mvk_avgpool3s2_fwd(const float* x, float* y, int n, int H, int W, int C, void* stream);

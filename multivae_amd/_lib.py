@@ -40,7 +40,8 @@ class ReconDesc(C.Structure):
 
 class PackDesc(C.Structure):  # mvk_pack_desc
     _fields_ = [("Wref", _p), ("Wdown", _p), ("Wup", _p), ("Cv", C.c_int32), ("Cu", C.c_int32),
-                ("ld_down", C.c_int32), ("col_off", C.c_int32), ("kind", C.c_int32), ("Fdown", _p), ("Fup", _p)]
+                ("ld_down", C.c_int32), ("col_off", C.c_int32), ("kind", C.c_int32), ("Fdown", _p), ("Fup", _p),
+                ("amax", _p)]
 
 
 class SeedDesc(C.Structure):  # mvk_seed_desc
@@ -86,6 +87,8 @@ PROTOTYPES = {
     "mvk_conv3x3_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i64, _p],
     "mvk_conv3x3_f": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _f, _p, _i, _f, _p, _i64, _p],
     "mvk_conv3x3_wgrad_f": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _i64, _p],
+    "mvk_conv3x3_s": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _f, _p, _i, _f, _p, _p, _p, _p, _i64, _p],
+    "mvk_amax": [_p, _i64, _p, _p],
     "mvk_avgpool3s2_fwd": [_p, _p, _i, _i, _i, _i, _p],
     "mvk_avgpool3s2_bwd": [_p, _p, _i, _i, _i, _i, _p],
     "mvk_upsample2_fwd": [_p, _p, _i, _i, _i, _i, _p],
@@ -161,6 +164,8 @@ def load(path=None):
     lib.mvk_conv4s2_small_up_nll_supported.restype = C.c_int
     lib.mvk_conv3x3_fused_ok.argtypes = [_i, _i, _i, _i, _i]
     lib.mvk_conv3x3_fused_ok.restype = C.c_int
+    lib.mvk_conv3x3_scaled_ok.argtypes = [_i, _i, _i, _i, _i]
+    lib.mvk_conv3x3_scaled_ok.restype = C.c_int
     lib.mvk_defer_wanted.argtypes = []
     lib.mvk_defer_wanted.restype = C.c_int64
     lib.mvk_defer_pending.argtypes = []
@@ -225,6 +230,7 @@ GEMM_FLOPS = {
     "mvk_conv3x3_wgrad": lambda a: 2.0 * a[3] * a[4] * a[5] * 9 * a[6] * a[7],
     "mvk_conv3x3_f": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
     "mvk_conv3x3_wgrad_f": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
+    "mvk_conv3x3_s": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
     "mvk_conv4s2_up_nchw_small": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
     "mvk_conv4s2_small_up_fwd": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
     "mvk_conv4s2_small_down_fwd": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],

@@ -27,4 +27,42 @@ __device__ __forceinline__ void bf3_split(float x, float y, unsigned& p0, unsign
   p2 = __builtin_bit_cast(unsigned, a2);
 }
 
+// ---- scaled fp16 pairs (2 pieces, 3 products): Ootomo & Yokota, "Recovering single precision accuracy from Tensor Cores
+// while surpassing the FP32 theoretical peak performance" (2022) --------------------------------------------------------------
+// x * s = hi + lo / 2048 with hi = fp16(x s), lo = fp16((x s - hi) 2048): |x s - (hi + lo / 2048)| <= 2^-23 |x s|, and the
+// product of two such pairs is hi hi' + (hi lo' + lo hi') / 2048 up to 2^-22 (the lo lo' term): three fp16 MFMAs instead of
+// the six bf16 ones, the two cross terms in an accumulator of their own.  fp16 has 5 exponent bits, so every operand
+// TENSOR carries a power-of-two scale s that puts its largest magnitude in [2^13, 2^14): an element then keeps full
+// precision down to 2^-28 of the tensor's maximum (hi and the pre-scaled lo are both normal fp16 numbers there) and degrades
+// gradually below that — an absolute error of 2^-39 of the maximum, nothing in a dot product that contains the maximum's
+// order of magnitude.  The scale needs an upper bound of max |x| BEFORE the operand is converted: the producers of the
+// tensors publish it (atomic max in their epilogues, `amax` arguments of the C-ABI), mvk_amax computes it for the others.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// power of two s with amax * s in [2^13, 2^14) (clamped to [2^-126, 2^126]: amax = 0 or denormal gives 2^126)
+__device__ __forceinline__ float f16_scale_of(float amax) {
+  const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+  int se = 267 - e;
+  se = se < 1 ? 1 : (se > 253 ? 253 : se);
+  return __uint_as_float((unsigned)se << 23);
+}
+__device__ __forceinline__ float f16_inv_scale(float s) { return __uint_as_float((254u << 23) - __float_as_uint(s)); }
+
+// two SCALED fp32 values -> (hi pair, lo pair), each dword = (low half: x, high half: y)
+__device__ __forceinline__ void f16_split(float x, float y, unsigned& hi, unsigned& lo) {
+  const f16x2 h = __builtin_convertvector(f32x2{x, y}, f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  const float rx = (x - (float)h[0]) * 2048.f, ry = (y - (float)h[1]) * 2048.f;
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{rx, ry}, f16x2));
+}
+
+// wave-wide maximum of a non-negative value, then one atomic per wave: the bit patterns of non-negative floats order like
+// unsigned integers (+inf above every finite value), *dst must hold 0 before the launch
+__device__ __forceinline__ void amax_publish(float v, float* dst) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(v));
+}
+
 }  // namespace mvk

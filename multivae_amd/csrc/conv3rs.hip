@@ -31,6 +31,14 @@
 #ifndef MVK_C3_SCHED
 #define MVK_C3_SCHED 4  // "others" per MFMA of the scheduling pipeline (0 = hipcc's own order)
 #endif
+#ifndef MVK_C3_SCHED2
+#define MVK_C3_SCHED2 2  // multiplier of MVK_C3_SCHED in the scaled-fp16 form (3 MFMAs per product instead of 6)
+#endif
+#ifndef MVK_C3_F16ACC
+// accumulators of the scaled-fp16 form: 2 = main + cross (dependent MFMAs on the same accumulator issue back to back),
+// 3 = one main + a cross per k-step of a pair, 4 = main + cross per k-step.  A/B (64 -> 64 @64x64, n = 128): 153 / 162 / 165 us
+#define MVK_C3_F16ACC 2
+#endif
 #ifndef MVK_C3_BAR
 #define MVK_C3_BAR 7    // the pair behind which the tile's barrier sits (6: one more pair of cover for what follows it)
 #endif
@@ -55,24 +63,30 @@ struct C3Args {
   int D;                 // reach of the window in 32-position chunks: ceil((W + 2) / 32)
   int tiles;             // ceil(n (H+1) (W+1) / 32)
   mvk_prof_slot* prof;
+  // scaled-fp16 form (NP = 2, bf3.hpp): upper bounds of max |X| and max |Wp| (device scalars, both required)
+  const float* x_amax;
+  const float* w_amax;
+  float* y_amax;         // either form, optional: max |Y| is published here (atomic max; must hold 0 before the launch)
 };
 
-template <int CIN, int COUT>
+// NP = pieces per operand element: 3 bf16 pieces (6 MFMAs per product) or 2 scaled fp16 pieces (3 MFMAs per product)
+template <int CIN, int COUT, int NP = 3>
 struct C3Cfg {
   static constexpr int CHUNKS = CIN / 16;            // 16-channel k-steps per tap
   static constexpr int KALL = 9 * CHUNKS;            // k-steps of one output element
-  static constexpr int KPW = 18;                     // k-steps per wave = 216 weight registers
+  static constexpr int KPW = 18;                     // k-steps per wave = 216 (NP = 3) / 144 (NP = 2) weight registers
   static constexpr int KSPLIT = KALL / KPW;          // waves sharing one 32-column tile: 2 (64 channels), 4 (128)
   static constexpr int NCT = COUT / 32;
   static constexpr int ROLES = NCT * KSPLIT;
   static constexpr int WG_TYPES = ROLES / 4;
-  static constexpr int S = 6 * CIN + 16;             // bytes per ring slot: 3 pieces x CIN bf16 + pad ((S / 16) odd)
+  static constexpr int S = 2 * NP * CIN + 16;        // bytes per ring slot: NP pieces x CIN halves + pad ((S / 16) odd)
   static constexpr int NF4 = CIN / 32;               // float4 staging units per thread and chunk
   static constexpr int OWN = 16 / KSPLIT;            // accumulator registers (output rows per lane) a wave finishes
   static constexpr int XWAVE = (KSPLIT - 1) * OWN * 64 * 4;
   static constexpr int XBUF = 4 * XWAVE;
   static constexpr int PTAB_INTS = 16 * 32;
-  static constexpr int MAXD = CIN == 64 ? 3 : 1;     // largest window reach (chunks) whose ring fits the LDS (W <= 94 / W <= 30)
+  // largest window reach (chunks) whose ring fits the LDS: 3 = W <= 94, 2 = W <= 62, 1 = W <= 30
+  static constexpr int MAXD = CIN == 64 ? 3 : (NP == 2 ? 2 : 1);
   static_assert(KALL % KPW == 0 && ROLES % 4 == 0 && 4 % KSPLIT == 0, "roles");
   static_assert((S / 16) % 2 == 1, "odd 16-byte stride: conflict-free fragments");
   __host__ __device__ static constexpr int lds_bytes(int ring) { return ring * S + 2 * XBUF + PTAB_INTS * 4 + 4 * 32 * 4; }
@@ -83,9 +97,13 @@ __device__ __forceinline__ bf16x8 c3_pack8(const unsigned (&d)[4]) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int CIN, int COUT, bool HAS_SRC, bool HAS_RES>
+template <int CIN, int COUT, bool HAS_SRC, bool HAS_RES, int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void c3rs_kernel(const C3Args g) {
-  using T = C3Cfg<CIN, COUT>;
+  using T = C3Cfg<CIN, COUT, NP>;
+  using frag = std::conditional_t<NP == 3, bf16x8, f16x8>;
+  // scaled-fp16 form: the operands are multiplied by sx / sw on their way into pieces, the result by 1 / (sx sw)
+  const float sx = NP == 2 ? f16_scale_of(*g.x_amax) : 1.f, sw = NP == 2 ? f16_scale_of(*g.w_amax) : 1.f;
+  const float inv_sx = f16_inv_scale(sx), inv_sw = f16_inv_scale(sw);
   extern __shared__ __attribute__((aligned(16))) char lds[];
   mvk_prof_begin(g.prof);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -96,8 +114,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int ct = role / T::KSPLIT, ks = role % T::KSPLIT;
   const int ncol = ct * 32 + col;
 
-  // ---- weights: 18 k-steps x 3 pieces, resident for the whole launch ------------------------------------------------------
-  bf16x8 Bw[T::KPW][3];
+  // ---- weights: 18 k-steps x NP pieces, resident for the whole launch -----------------------------------------------------
+  frag Bw[T::KPW][NP];
 #pragma unroll
   for (int i = 0; i < T::KPW; ++i) {
     const int gk = ks * T::KPW + i;
@@ -107,16 +125,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int e = 0; e < 8; ++e) v[e] = g.Wp[(rowbase + e) * COUT + ncol];
     unsigned p[3][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bf3_split(v[2 * e], v[2 * e + 1], p[0][e], p[1][e], p[2][e]);
+    for (int e = 0; e < 4; ++e) {
+      if constexpr (NP == 3) bf3_split(v[2 * e], v[2 * e + 1], p[0][e], p[1][e], p[2][e]);
+      else f16_split(v[2 * e] * sw, v[2 * e + 1] * sw, p[0][e], p[1][e]);
+    }
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) Bw[i][pc] = c3_pack8(p[pc]);
+    for (int pc = 0; pc < NP; ++pc) Bw[i][pc] = __builtin_bit_cast(frag, u32x4{p[pc][0], p[pc][1], p[pc][2], p[pc][3]});
   }
   // AGPR citizens (see imgconv_kernel): MFMA reads its B operand from a[...] directly, no v_accvgpr_read per use
 #pragma unroll
   for (int i = 0; i < T::KPW; ++i)
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) {
-      bf16x8 t = Bw[i][pc];
+    for (int pc = 0; pc < NP; ++pc) {
+      frag t = Bw[i][pc];
       asm volatile("" : "=a"(Bw[i][pc]) : "0"(t));
     }
 
@@ -185,18 +206,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (unsigned)pix * (CIN * 4u) + sc4[k] * 4u, 0, 0));
   };
   auto load_unit = [&](int c, int k) { load_unit_at(unit_pix(c, k), k); };
-  const float islope = g.islope;
+  const float islope = g.islope, sxn = sx * g.islope;
   auto write_vals = [&](int wbase, int k, const f32x4& v) {  // wbase = byte offset of the chunk's first slot
     // the activation of the layer that produced X, applied on the way into LDS (X is then stored before its activation)
-    const float r0 = v[0] > 0.f ? v[0] : v[0] * islope, r1 = v[1] > 0.f ? v[1] : v[1] * islope;
-    const float r2 = v[2] > 0.f ? v[2] : v[2] * islope, r3 = v[3] > 0.f ? v[3] : v[3] * islope;
-    unsigned a0, a1, a2, b0, b1, b2;
-    bf3_split(r0, r1, a0, a1, a2);
-    bf3_split(r2, r3, b0, b1, b2);
     char* d = ringp + wbase + soff[k];
-    *reinterpret_cast<u32x2*>(d) = u32x2{a0, b0};
-    *reinterpret_cast<u32x2*>(d + 2 * CIN) = u32x2{a1, b1};
-    *reinterpret_cast<u32x2*>(d + 4 * CIN) = u32x2{a2, b2};
+    if constexpr (NP == 3) {
+      const float r0 = v[0] > 0.f ? v[0] : v[0] * islope, r1 = v[1] > 0.f ? v[1] : v[1] * islope;
+      const float r2 = v[2] > 0.f ? v[2] : v[2] * islope, r3 = v[3] > 0.f ? v[3] : v[3] * islope;
+      unsigned a0, a1, a2, b0, b1, b2;
+      bf3_split(r0, r1, a0, a1, a2);
+      bf3_split(r2, r3, b0, b1, b2);
+      *reinterpret_cast<u32x2*>(d) = u32x2{a0, b0};
+      *reinterpret_cast<u32x2*>(d + 2 * CIN) = u32x2{a1, b1};
+      *reinterpret_cast<u32x2*>(d + 4 * CIN) = u32x2{a2, b2};
+    } else {  // the operand scale rides on the activation's two slopes
+      const float r0 = v[0] * (v[0] > 0.f ? sx : sxn), r1 = v[1] * (v[1] > 0.f ? sx : sxn);
+      const float r2 = v[2] * (v[2] > 0.f ? sx : sxn), r3 = v[3] * (v[3] > 0.f ? sx : sxn);
+      unsigned a0, a1, b0, b1;
+      f16_split(r0, r1, a0, a1);
+      f16_split(r2, r3, b0, b1);
+      *reinterpret_cast<u32x2*>(d) = u32x2{a0, b0};
+      *reinterpret_cast<u32x2*>(d + 2 * CIN) = u32x2{a1, b1};
+    }
   };
   auto write_unit = [&](int wbase, int k) { write_vals(wbase, k, raw[k]); };
   auto chunk_slot = [&](int c) { return (((c % NCH) + NCH) % NCH) * 32 * T::S; };
@@ -232,8 +263,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // column sums (the bias gradient of the layer below) exist in the backward-data form only: mask, no residual
   constexpr bool WITH_CSUM = HAS_SRC && !HAS_RES;
   const float bias = g.bias ? g.bias[ncol] : 0.f;
-  const float aslope = g.aslope, mslope = g.mslope, alpha = g.res_alpha, pre_scale = g.pre_scale;
-  float csum = 0.f;
+  const float aslope = g.aslope, mslope = g.mslope, alpha = g.res_alpha;
+  const float pre_scale = NP == 2 ? g.pre_scale * inv_sw : g.pre_scale;
+  float csum = 0.f, amax_l = 0.f;
 
   // ---- main loop, instantiated per tap-split rank (every "is this my slice" test is a compile-time fact) ----------------
   auto run = [&](auto ks_tag) {
@@ -257,14 +289,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         ab[j] = (int)s + kg * 16;
       }
     };
-    auto read_pair = [&](bf16x8 (&dst)[2][3], const int (&ab)[NTAPW], int pr) {
+    auto read_pair = [&](frag (&dst)[2][NP], const int (&ab)[NTAPW], int pr) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int gk = KSC * T::KPW + 2 * pr + h;
         const int j = gk / T::CHUNKS - TAP_LO, c = gk % T::CHUNKS;
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
-          dst[h][pc] = *reinterpret_cast<const bf16x8*>(ringp + ab[j] + pc * 2 * CIN + c * 32);
+        for (int pc = 0; pc < NP; ++pc)
+          dst[h][pc] = *reinterpret_cast<const frag*>(ringp + ab[j] + pc * 2 * CIN + c * 32);
       }
     };
     // rows of the 32 x 32 tile this lane finishes: accumulator registers [KSC * OWN, KSC * OWN + OWN)
@@ -276,7 +308,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     const int wgrp = (wave / T::KSPLIT) * T::KSPLIT;  // first wave of this wave's column-tile group
 
-    f32x16 pend0 = {0}, pend1 = {0};
+    // accumulators of a tile: NP = 3: one per k-step of a pair; NP = 2: main (hi hi') and cross (hi lo' + lo hi') per k-step
+    constexpr int NACC = NP == 3 ? 2 : MVK_C3_F16ACC;
+    f32x16 pend[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) pend[i] = f32x16{0};
     // msk / rr / pix of a tile are fetched (global loads) while the NEXT tile is multiplied and consumed one tile after
     // that: two register sets indexed by the compile-time parity of the tile, no copy between them (hipcc hoists a copy
     // "prev = cur" to the last use of prev, i.e. right behind the load, and waits there for the memory latency)
@@ -289,7 +325,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       pix[0][o] = pix[1][o] = -1;
     }
     auto finish_pending = [&](char* xb) {
-      const f32x16 sum = pend0 + pend1;
+      f32x16 sum;
+      if constexpr (NP == 3) {
+        sum = pend[0] + pend[1];
+      } else {
+        const f32x16 cross = NACC == 4 ? pend[2] + pend[3] : (NACC == 3 ? pend[1] + pend[2] : pend[1]);
+        sum = NACC == 4 ? pend[0] + pend[1] : pend[0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum[r] = fmaf(cross[r], 1.f / 2048.f, sum[r]);
+      }
 #pragma unroll
       for (int r = 0; r < T::KSPLIT; ++r) {
         if (r == KSC) continue;
@@ -328,12 +372,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if (HAS_RES) rr[P][o] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, off, 0, 0));
     };
     auto epilogue_row = [&](int Q, int o, bool valid) {  // Q: the parity whose fetch belongs to the tile in res_prev
-      float v = fmaf(res_prev[o], pre_scale, bias);
+      float v = fmaf(NP == 2 ? res_prev[o] * inv_sx : res_prev[o], pre_scale, bias);
       v = v > 0.f ? v : v * aslope;
       if (HAS_SRC) v = msk[Q][o] > 0.f ? v : v * mslope;
       const int px_ = valid ? pix[Q][o] : -1;
       if (WITH_CSUM) csum += px_ < 0 ? 0.f : v;
       if (HAS_RES) v = fmaf(alpha, v, rr[Q][o]);
+      amax_l = fmaxf(amax_l, px_ < 0 ? 0.f : fabsf(v));
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY, (unsigned)px_ * (COUT * 4u) + ncol * 4u, 0, 0);
     };
     auto rotate = [&]() {
@@ -344,7 +389,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int tb = (int)(((long long)32 * T0) % RING) * T::S;  // first ring slot of tile T, in bytes
     int wch = (((T0 + D + 1) % NCH) + NCH) % NCH;       // ring chunk that chunk T+D+1 goes to
     int ab_cur[NTAPW], ab_nxt[NTAPW];
-    bf16x8 a_cur[2][3];
+    frag a_cur[2][NP];
     if (NT > 0) {
       frag_base(ab_cur, tb);
       read_pair(a_cur, ab_cur, 0);
@@ -357,11 +402,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const int wbase = wch * 32 * T::S;
       int tbn = tb + 32 * T::S;
       tbn = tbn >= (int)RINGB ? tbn - (int)RINGB : tbn;
-      f32x16 acc0 = {0}, acc1 = {0};
+      f32x16 acc[NACC];
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i] = f32x16{0};
       int upix[T::NF4];
 #pragma unroll
       for (int pr = 0; pr < 9; ++pr) {
-        bf16x8 a_nxt[2][3];
+        frag a_nxt[2][NP];
         if (pr < 8) read_pair(a_nxt, ab_cur, pr + 1);
         if (pr == 0) {
           finish_pending(xb);
@@ -386,29 +433,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           fetch_row(P, o);                        // tile Tt-1: consumed two tiles later
           epilogue_row(P ^ 1, o, valid2);         // tile Tt-2
         }
-        constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB_[6] = {2, 1, 0, 1, 0, 0};  // small terms first
+        if constexpr (NP == 3) {
+          constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB_[6] = {2, 1, 0, 1, 0, 0};  // small terms first
 #pragma unroll
-        for (int m = 0; m < 6; ++m) {
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][PA[m]], Bw[2 * pr][PB_[m]], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][PA[m]], Bw[2 * pr + 1][PB_[m]], acc1, 0, 0, 0);
+          for (int m = 0; m < 6; ++m) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][PA[m]], Bw[2 * pr][PB_[m]], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][PA[m]], Bw[2 * pr + 1][PB_[m]], acc[1], 0, 0, 0);
+          }
+        } else {  // cross terms (pieces 0 x 1, 1 x 0) in accumulators 2 / 3, the main term in 0 / 1: no two neighbours depend
+          constexpr int M0 = 0, M1 = NACC == 4 ? 1 : 0, C0 = NACC == 4 ? 2 : 1, C1 = NACC == 4 ? 3 : (NACC == 3 ? 2 : 1);
+          acc[C0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0][0], Bw[2 * pr][1], acc[C0], 0, 0, 0);
+          acc[M0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0][0], Bw[2 * pr][0], acc[M0], 0, 0, 0);
+          acc[C1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1][0], Bw[2 * pr + 1][1], acc[C1], 0, 0, 0);
+          acc[M1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1][0], Bw[2 * pr + 1][0], acc[M1], 0, 0, 0);
+          acc[C0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0][1], Bw[2 * pr][0], acc[C0], 0, 0, 0);
+          acc[C1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1][1], Bw[2 * pr + 1][0], acc[C1], 0, 0, 0);
         }
         if (pr == MVK_C3_BAR + 1) gather_result(xb);  // behind the barrier: result of tile Tt-1
         if (pr == 8) read_pair(a_nxt, ab_nxt, 0);     // first fragments of the next tile
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) a_cur[h][pc] = a_nxt[h][pc];
-        if (MVK_C3_SCHED > 0) {
+          for (int pc = 0; pc < NP; ++pc) a_cur[h][pc] = a_nxt[h][pc];
+        if (MVK_C3_SCHED > 0) {  // the same "other" work per pair behind half as many MFMAs in the fp16 form
+          constexpr int OTHERS = (MVK_C3_SCHED > 0 ? MVK_C3_SCHED : 1) * (NP == 3 ? 1 : MVK_C3_SCHED2);
 #pragma unroll
-          for (int m = 0; m < 12; ++m) {
+          for (int m = 0; m < 4 * NP; ++m) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x496, MVK_C3_SCHED > 0 ? MVK_C3_SCHED : 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x496, OTHERS, 0);
           }
         }
         if (pr == MVK_C3_BAR) __syncthreads();
       }
-      pend0 = acc0;
-      pend1 = acc1;
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) pend[i] = acc[i];
       rotate();
 #pragma unroll
       for (int j = 0; j < NTAPW; ++j) ab_cur[j] = ab_nxt[j];
@@ -450,6 +508,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   else if (T::KSPLIT > 2 && ks_u == 2) run(std::integral_constant<int, (T::KSPLIT > 2 ? 2 : 0)>{});
   else if (T::KSPLIT > 3) run(std::integral_constant<int, (T::KSPLIT > 3 ? 3 : 0)>{});
 
+  if (g.y_amax) amax_publish(amax_l, g.y_amax);
   if (WITH_CSUM && g.colsum_part) {  // fixed-order sum over the lanes / waves that share a column
     csum += __shfl_xor(csum, 32, 64);
     __syncthreads();
@@ -466,15 +525,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   mvk_prof_end(g.prof);
 }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, int NP>
 static int c3rs_launch(const C3Args& a, int* part_rows, hipStream_t s) {
-  using T = C3Cfg<CIN, COUT>;
+  using T = C3Cfg<CIN, COUT, NP>;
   const int lds = T::lds_bytes(a.ring);
   if (lds > 160 * 1024) return 1;
-  const void* all[4] = {reinterpret_cast<const void*>(c3rs_kernel<CIN, COUT, false, false>),
-                        reinterpret_cast<const void*>(c3rs_kernel<CIN, COUT, true, false>),
-                        reinterpret_cast<const void*>(c3rs_kernel<CIN, COUT, false, true>),
-                        reinterpret_cast<const void*>(c3rs_kernel<CIN, COUT, true, true>)};
+  const void* all[4] = {reinterpret_cast<const void*>(c3rs_kernel<CIN, COUT, false, false, NP>),
+                        reinterpret_cast<const void*>(c3rs_kernel<CIN, COUT, true, false, NP>),
+                        reinterpret_cast<const void*>(c3rs_kernel<CIN, COUT, false, true, NP>),
+                        reinterpret_cast<const void*>(c3rs_kernel<CIN, COUT, true, true, NP>)};
   static int attr_bytes = 0;
   if (attr_bytes < lds) {
     for (const void* f : all)
@@ -486,9 +545,9 @@ static int c3rs_launch(const C3Args& a, int* part_rows, hipStream_t s) {
   C3Args ap = a;
   ap.prof = prof_next(7, 2.0 * a.n * a.H * a.W * 9.0 * CIN * COUT);
   const int which = (a.act_src ? 1 : 0) + (a.res ? 2 : 0);
-  auto kern = which == 0 ? c3rs_kernel<CIN, COUT, false, false>
-              : which == 1 ? c3rs_kernel<CIN, COUT, true, false>
-              : which == 2 ? c3rs_kernel<CIN, COUT, false, true> : c3rs_kernel<CIN, COUT, true, true>;
+  auto kern = which == 0 ? c3rs_kernel<CIN, COUT, false, false, NP>
+              : which == 1 ? c3rs_kernel<CIN, COUT, true, false, NP>
+              : which == 2 ? c3rs_kernel<CIN, COUT, false, true, NP> : c3rs_kernel<CIN, COUT, true, true, NP>;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, ap);
   MVK_CHECK_LAUNCH();
   prof_fold(ap.prof, s);
@@ -844,7 +903,15 @@ int c3rs_wgrad(const float* X, const float* dY, float* slab, long long slab_floa
   return MVK_OK;
 }
 
-static int c3_lds_bytes(int Cin, int Cout, int ring) {
+static int c3_lds_bytes(int Cin, int Cout, int ring, int np) {
+  if (np == 2) {
+    if (Cin == 64 && Cout == 64) return C3Cfg<64, 64, 2>::lds_bytes(ring);
+    if (Cin == 64 && Cout == 128) return C3Cfg<64, 128, 2>::lds_bytes(ring);
+    if (Cin == 128 && Cout == 64) return C3Cfg<128, 64, 2>::lds_bytes(ring);
+    if (Cin == 128 && Cout == 128) return C3Cfg<128, 128, 2>::lds_bytes(ring);
+    if (Cin == 128 && Cout == 256) return C3Cfg<128, 256, 2>::lds_bytes(ring);
+    return 1 << 30;
+  }
   if (Cin == 64 && Cout == 64) return C3Cfg<64, 64>::lds_bytes(ring);
   if (Cin == 64 && Cout == 128) return C3Cfg<64, 128>::lds_bytes(ring);
   if (Cin == 128 && Cout == 64) return C3Cfg<128, 64>::lds_bytes(ring);
@@ -861,35 +928,48 @@ static int c3_ring(int W) {
 }
 
 // every condition under which c3rs_conv takes a problem (the caller reserves arena space only behind this test)
-bool c3rs_shape_ok(int n, int H, int W, int Cin, int Cout) {
+// np: 3 = bf16 pieces, 2 = scaled fp16 pieces (smaller ring slots: 128 input channels reach maps up to 62 wide)
+bool c3rs_shape_ok(int n, int H, int W, int Cin, int Cout, int np) {
   if (n <= 0 || H < 4 || W < 4 || W > 96) return false;
   const long long total = (long long)n * (H + 1) * (W + 1);
   // 32-bit byte offsets into X / Y; offset (unsigned)(-1) * 4 C must stay out of range
   if (total >= (1ll << 31) - 64 || (long long)n * H * W * (Cin > Cout ? Cin : Cout) * 4 >= (1ll << 32) - 8192) return false;
   const int D = (W + 2 + 31) / 32;
   if ((H + 1) * (W + 1) < 32 * D) return false;   // the table's start-up shift by one image block
-  if (D > (Cin == 64 ? 3 : 1)) return false;      // C3Cfg::MAXD
+  if (D > (Cin == 64 ? 3 : (np == 2 ? 2 : 1))) return false;  // C3Cfg::MAXD
   if (32 / (W + 1) + 1 > H + 1) return false;     // one wrap per 32-position step of the incremental (image, row, column)
-  return c3_lds_bytes(Cin, Cout, c3_ring(W)) <= 160 * 1024;
+  return c3_lds_bytes(Cin, Cout, c3_ring(W), np) <= 160 * 1024;
 }
 
 // 1: not covered (the caller falls back to the implicit-GEMM engine).  colsum_part: [256 / types][Cout] floats.
 int c3rs_conv(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
               const float* act_src, int src_act, const float* res, float res_alpha, float* colsum_part, int* part_rows,
-              int x_act, float pre_scale, hipStream_t s) {
+              int x_act, float pre_scale, const float* x_amax, const float* w_amax, float* y_amax, hipStream_t s) {
   if (act == MVK_ACT_SIGMOID || (act_src && src_act == MVK_ACT_SIGMOID) || x_act == MVK_ACT_SIGMOID || !mvk_aligned16(X)) return 1;
   if (colsum_part && (!act_src || res)) return 1;  // column sums: backward-data form only (WITH_CSUM)
-  if (!c3rs_shape_ok(n, H, W, Cin, Cout)) return 1;
+  const bool f16 = x_amax && w_amax;
+  if (!c3rs_shape_ok(n, H, W, Cin, Cout, f16 ? 2 : 3)) return 1;
   const long long total = (long long)n * (H + 1) * (W + 1);
   C3Args a{X, Wp, bias, Y, act_src, res, colsum_part, (unsigned)((long long)n * H * W * Cin * 4),
            (unsigned)((long long)n * H * W * Cout * 4), n, H, W, c3_slope(act), c3_slope(act_src ? src_act : MVK_ACT_NONE),
-           res_alpha, c3_slope(x_act), pre_scale, c3_ring(W), (W + 2 + 31) / 32, (int)((total + 31) / 32), nullptr};
-  if (Cin == 64 && Cout == 64) return c3rs_launch<64, 64>(a, part_rows, s);
+           res_alpha, c3_slope(x_act), pre_scale, c3_ring(W), (W + 2 + 31) / 32, (int)((total + 31) / 32), nullptr,
+           x_amax, w_amax, y_amax};
+  if (f16) {
+    if (Cin == 64 && Cout == 64) return c3rs_launch<64, 64, 2>(a, part_rows, s);
 #ifndef MVK_C3_PROBE_ONLY  // variant builds of tools/conv3_variants.sh: one instantiation, short compiles
-  if (Cin == 64 && Cout == 128) return c3rs_launch<64, 128>(a, part_rows, s);
-  if (Cin == 128 && Cout == 64) return c3rs_launch<128, 64>(a, part_rows, s);
-  if (Cin == 128 && Cout == 128) return c3rs_launch<128, 128>(a, part_rows, s);
-  if (Cin == 128 && Cout == 256) return c3rs_launch<128, 256>(a, part_rows, s);
+    if (Cin == 64 && Cout == 128) return c3rs_launch<64, 128, 2>(a, part_rows, s);
+    if (Cin == 128 && Cout == 64) return c3rs_launch<128, 64, 2>(a, part_rows, s);
+    if (Cin == 128 && Cout == 128) return c3rs_launch<128, 128, 2>(a, part_rows, s);
+    if (Cin == 128 && Cout == 256) return c3rs_launch<128, 256, 2>(a, part_rows, s);
+#endif
+    return 1;
+  }
+  if (Cin == 64 && Cout == 64) return c3rs_launch<64, 64, 3>(a, part_rows, s);
+#ifndef MVK_C3_PROBE_ONLY
+  if (Cin == 64 && Cout == 128) return c3rs_launch<64, 128, 3>(a, part_rows, s);
+  if (Cin == 128 && Cout == 64) return c3rs_launch<128, 64, 3>(a, part_rows, s);
+  if (Cin == 128 && Cout == 128) return c3rs_launch<128, 128, 3>(a, part_rows, s);
+  if (Cin == 128 && Cout == 256) return c3rs_launch<128, 256, 3>(a, part_rows, s);
 #endif
   return 1;
 }

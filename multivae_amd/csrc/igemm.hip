@@ -724,14 +724,14 @@ int imgconv_wgrad(const float* U, const float* V, float* slab, long long slab_fl
 // bit 0x800 takes them for every problem size (tests); MVK_C3RS=0 / MVK_C3RS=<min tiles> under MVK_TUNE=1.
 int c3rs_conv(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
               const float* act_src, int src_act, const float* res, float res_alpha, float* colsum_part, int* part_rows,
-              int x_act, float pre_scale, hipStream_t s);
-bool c3rs_shape_ok(int n, int H, int W, int Cin, int Cout);
+              int x_act, float pre_scale, const float* x_amax, const float* w_amax, float* y_amax, hipStream_t s);
+bool c3rs_shape_ok(int n, int H, int W, int Cin, int Cout, int np);
 bool c3rs_wgrad_ok(int n, int H, int W, int Cin, int Cout);
 int c3rs_wgrad(const float* X, const float* dY, float* slab, long long slab_floats, float* dbpart, int x_act, float dy_scale,
                int n, int H, int W, int Cin, int Cout, int* nz, hipStream_t s);
 int convref_reduce(const float* slab, int nz, int Cu, int Cv, int taps, float* dWref, hipStream_t s, bool deferred);
 static bool c3rs_wgrad_covers(int n, int H, int W, int Cin, int Cout);
-static bool c3rs_covers(int n, int H, int W, int Cin, int Cout) {
+static bool c3rs_covers(int n, int H, int W, int Cin, int Cout, int np = 3) {
   static int min_tiles = -1;
   if (min_tiles < 0) {
     const char* e = mvk_tune("MVK_C3RS");
@@ -739,7 +739,7 @@ static bool c3rs_covers(int n, int H, int W, int Cin, int Cout) {
     if (min_tiles == 0) min_tiles = 1 << 30;
   }
   if (g_dbg_flags & 0x400) return false;
-  if (!c3rs_shape_ok(n, H, W, Cin, Cout)) return false;
+  if (!c3rs_shape_ok(n, H, W, Cin, Cout, np)) return false;
   const long long tiles = ((long long)n * (H + 1) * (W + 1) + 31) / 32;
   return (g_dbg_flags & 0x800) ? true : tiles >= min_tiles;
 }
@@ -1043,12 +1043,15 @@ int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U
 // The same launch is the backward-data pass when it is fed the output gradient and the flipped / transposed pack.
 static int conv3x3_any(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout,
                        int act, const float* y_act_src, int y_src_act, float* colsum_acc, const float* res, float res_alpha,
-                       float* ws, int64_t ws_floats, void* stream, int x_act = MVK_ACT_NONE, float pre_scale = 1.f) {
-  const bool fused = x_act != MVK_ACT_NONE || pre_scale != 1.f;  // forms only the register-stationary kernels take
-  if (!X || !Wp || !Y || n < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return MVK_EINVAL;
+                       float* ws, int64_t ws_floats, void* stream, int x_act = MVK_ACT_NONE, float pre_scale = 1.f,
+                       const float* x_amax = nullptr, const float* w_amax = nullptr, float* y_amax = nullptr) {
+  // forms only the register-stationary kernels take
+  const bool fused = x_act != MVK_ACT_NONE || pre_scale != 1.f || x_amax || w_amax || y_amax;
+  const int np = x_amax && w_amax ? 2 : 3;
+  if (!X || !Wp || !Y || n < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (!x_amax != !w_amax)) return MVK_EINVAL;
   if (fused && !(n > 0 && ws && ws_floats >= 256ll * Cout && !(res && colsum_acc) && mvk_aligned16(X) &&
-                 (!colsum_acc || y_act_src) && c3rs_covers(n, H, W, Cin, Cout)))
-    return MVK_EINVAL;  // ask mvk_conv3x3_fused_ok first
+                 (!colsum_acc || y_act_src) && c3rs_covers(n, H, W, Cin, Cout, np)))
+    return MVK_EINVAL;  // ask mvk_conv3x3_fused_ok / mvk_conv3x3_scaled_ok first
   if (n > 0 && Cin <= 4 && !res) {  // the image-consuming layer (or the backward-data pass of the image-producing one)
     const int rc = conv3_smallcin(X, Wp, bias, Y, n, H, W, Cin, Cout, act, y_act_src, y_src_act, mvk_stream(stream));
     if (rc == MVK_OK && colsum_acc)
@@ -1062,11 +1065,12 @@ static int conv3x3_any(const float* X, const float* Wp, const float* bias, float
     if (rc != 1) return rc;
   }
   if (n > 0 && ws && ws_floats >= 256ll * Cout && !(res && colsum_acc) && mvk_aligned16(X) && act != MVK_ACT_SIGMOID &&
-      !(y_act_src && y_src_act == MVK_ACT_SIGMOID) && (!colsum_acc || y_act_src) && c3rs_covers(n, H, W, Cin, Cout)) {
+      !(y_act_src && y_src_act == MVK_ACT_SIGMOID) && (!colsum_acc || y_act_src) && c3rs_covers(n, H, W, Cin, Cout, np)) {
     int rows = 0;
     float* dpart = colsum_acc ? defer_scratch(colsum_acc, 256ll * Cout, mvk_stream(stream)) : nullptr;
     const int rc = c3rs_conv(X, Wp, bias, Y, n, H, W, Cin, Cout, act, y_act_src, y_src_act, res, res_alpha,
-                             colsum_acc ? (dpart ? dpart : ws) : nullptr, &rows, x_act, pre_scale, mvk_stream(stream));
+                             colsum_acc ? (dpart ? dpart : ws) : nullptr, &rows, x_act, pre_scale, x_amax, w_amax, y_amax,
+                             mvk_stream(stream));
     if (rc == MVK_OK && dpart) return defer_push_plain(colsum_acc, dpart, Cout, rows, Cout, mvk_stream(stream));
     if (rc == MVK_OK && colsum_acc) return colsum_finish(ws, rows, Cout, colsum_acc, mvk_stream(stream));
     if (rc != 1) return rc;
@@ -1130,6 +1134,19 @@ int mvk_conv3x3_f(const float* X, const float* Wp, const float* bias, float* Y, 
                   float pre_scale, float* ws, int64_t ws_floats, void* stream) {
   return conv3x3_any(X, Wp, bias, Y, n, H, W, Cin, Cout, act, y_act_src, y_src_act, colsum_acc, res, res_alpha, ws, ws_floats,
                      stream, x_act, pre_scale);
+}
+
+// The scaled-fp16 form of mvk_conv3x3_f (3 MFMAs per product instead of 6, csrc/bf3.hpp): x_amax / w_amax = device scalars
+// holding upper bounds of max |X| and max |Wp| (mvk_amax, the `amax` slot of mvk_pack_weights, or the y_amax of the launch
+// that produced X); y_amax (optional) receives max |Y| by atomic max and must hold 0 before the launch.
+int mvk_conv3x3_scaled_ok(int n, int H, int W, int Cin, int Cout) { return n > 0 && c3rs_covers(n, H, W, Cin, Cout, 2) ? 1 : 0; }
+int mvk_conv3x3_s(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
+                  const float* y_act_src, int y_src_act, const float* res, float res_alpha, float* colsum_acc, int x_act,
+                  float pre_scale, const float* x_amax, const float* w_amax, float* y_amax, float* ws, int64_t ws_floats,
+                  void* stream) {
+  if (!x_amax || !w_amax) return MVK_EINVAL;
+  return conv3x3_any(X, Wp, bias, Y, n, H, W, Cin, Cout, act, y_act_src, y_src_act, colsum_acc, res, res_alpha, ws, ws_floats,
+                     stream, x_act, pre_scale, x_amax, w_amax, y_amax);
 }
 
 static int conv3x3_wgrad_any(const float* X, const float* dY, float* dWref, float* db, int x_act, float dy_scale, int n, int H,

@@ -34,22 +34,27 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs jobs) {
   const mvk_pack_desc& d = jobs.j[blockIdx.y];
   if (d.kind == 2) {  // 3x3: Wref[cv][cu][3][3] -> Wdown[(tap*Cu + cu)][cv] (forward), Wup[((8-tap)*Cv + cv)][cu] (bwd data)
     const int total9 = d.Cv * d.Cu * 9;
+    float m = 0.f;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total9; idx += gridDim.x * 256) {
       const int tap = idx % 9;
       const int cu = (idx / 9) % d.Cu;
       const int cv = (idx / 9) / d.Cu;
       const float v = d.Wref[idx];
+      m = fmaxf(m, fabsf(v));
       if (d.Wdown) d.Wdown[(long long)(tap * d.Cu + cu) * d.ld_down + d.col_off + cv] = v;
       if (d.Wup) d.Wup[(long long)((8 - tap) * d.Cv + cv) * d.Cu + cu] = v;
     }
+    if (d.amax) mvk::amax_publish(m, d.amax);  // the weight's scale for the scaled-fp16 kernels (bf3.hpp)
     return;
   }
   const int total = d.Cv * d.Cu * 16;
+  float wmax = 0.f;
   for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
     const int tap = idx & 15;
     const int cu = (idx >> 4) % d.Cu;
     const int cv = (idx >> 4) / d.Cu;
     const float v = d.Wref[idx];
+    wmax = fmaxf(wmax, fabsf(v));
     if (d.kind == 1) {
       d.Wup[(long long)cv * 16 * d.Cu + tap * d.Cu + cu] = v;
       continue;
@@ -85,6 +90,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs jobs) {
       }
     }
   }
+  if (d.amax) mvk::amax_publish(wmax, d.amax);
 }
 
 // Wref[ci][co][tap] -> Wp[ci][tap*Cout + co]
@@ -913,6 +919,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 extern "C" int mvk_probe_mfma_bf16(float* out, int iters, int random_operands, void* stream) {
   if (!out || iters <= 0) return MVK_EINVAL;
   hipLaunchKernelGGL(mfma_probe_kernel, dim3(256), dim3(256), 0, mvk_stream(stream), out, iters, random_operands, 12345u);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// max |x| of a tensor: the operand scale of the scaled-fp16 kernels (csrc/bf3.hpp) for tensors whose producer does not
+// publish it.  *out must hold 0 (or a lower bound that is to be kept) before the launch.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long n, float* out) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const long long n4 = n / 4, stride = (long long)gridDim.x * 256;
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const v4 v = reinterpret_cast<const v4*>(x)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) m = fmaxf(m, fabsf(x[4 * n4 + threadIdx.x]));
+  mvk::amax_publish(m, out);
+}
+}  // namespace
+
+extern "C" int mvk_amax(const float* x, int64_t n, float* out, void* stream) {
+  if (!x || !out || n < 0 || !mvk_aligned16(x)) return MVK_EINVAL;
+  if (n == 0) return MVK_OK;
+  long long blocks = (n / 4 + 256 * 8 - 1) / (256 * 8);
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, mvk_stream(stream), x, (long long)n, out);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }

@@ -498,6 +498,9 @@ def _pack_launch(jobs):
     transposed convolution ([Cin][Cout][4][4] -> [Cin, 16*Cout]).  Returns the packed tensors in job order."""
     descs = (PackDesc * len(jobs))()
     outs = []
+    am = None
+    if C3_F16 and any(job[1] == "c3" for job in jobs):  # max |W| per 3x3 weight: the operand scale of mvk_conv3x3_s
+        am = torch.zeros(len(jobs), dtype=torch.float32, device=jobs[0][0].device)
     for i, job in enumerate(jobs):
         wref = job[0]
         Cv, Cu = wref.shape[0], wref.shape[1]
@@ -513,6 +516,11 @@ def _pack_launch(jobs):
             d.kind = 2
             d.Wdown = wf.data_ptr() if wf is not None else None
             d.Wup = wb.data_ptr() if wb is not None else None
+            if am is not None:
+                d.amax = am[i:i + 1].data_ptr()
+                for t in (wf, wb):
+                    if t is not None:
+                        t.mvk_amax = am[i:i + 1]
             outs.append((wf, wb))
         else:
             wd = _new((16 * Cu, Cv), wref) if job[1] else None
@@ -599,6 +607,50 @@ def conv3x3_f(X, wpack, bias, n, H, W, Cin, Cout, act=NONE, y_act_src=None, y_sr
     tb, rb = _bias_target(out_bias)
     call("mvk_conv3x3_f", ptr(X), ptr(wpack), ptr(bias), ptr(Y), n, H, W, Cin, Cout, act, ptr(y_act_src), y_src_act, ptr(res),
          float(res_alpha), ptr(tb), x_act, float(pre_scale), ptr(ws), ws.numel(), stream_ptr())
+    return Y if out_bias is None else (Y, rb)
+
+
+# ---- scaled-fp16 form of the register-stationary 3x3 kernels (csrc/bf3.hpp: 3 MFMAs per product instead of 6) --------------
+# MVK_C3_F16=0 (under MVK_TUNE=1) keeps every 3x3 convolution on the bf16-piece kernels.
+C3_F16 = _lib.tune("MVK_C3_F16", "1") != "0"
+
+
+class AmaxPool:
+    """Zeroed device scalars for the `amax` protocol (one fill launch per pool): a launch publishes max |Y| into a slot by
+    atomic max, the launch that consumes Y takes its operand scale from it.  A slot is used by ONE producer."""
+
+    def __init__(self, like, slots):
+        self.t = torch.zeros(slots, dtype=torch.float32, device=like.device)
+        self.i = 0
+
+    def take(self):
+        if self.i >= self.t.numel():
+            self.t, self.i = torch.zeros_like(self.t), 0
+        self.i += 1
+        return self.t[self.i - 1:self.i]
+
+
+def amax_of(x, slot):
+    """slot <- max(slot, max |x|) (mvk_amax); returns the slot."""
+    call("mvk_amax", ptr(x), x.numel(), ptr(slot), stream_ptr())
+    return slot
+
+
+def conv3x3_scaled_ok(n, H, W, Cin, Cout):
+    """True when mvk_conv3x3_s takes this problem."""
+    return C3_F16 and bool(_lib.load().mvk_conv3x3_scaled_ok(n, H, W, Cin, Cout))
+
+
+def conv3x3_s(X, wpack, bias, n, H, W, Cin, Cout, x_amax, w_amax, y_amax=None, act=NONE, y_act_src=None, y_src_act=NONE,
+              res=None, res_alpha=1.0, out_bias=None, x_act=NONE, pre_scale=1.0):
+    """conv3x3_f on scaled fp16 pairs: x_amax / w_amax = device scalars bounding max |X| / max |wpack|, y_amax (optional,
+    zeroed) receives max |Y|."""
+    Y = _new((n, H, W, Cout), X)
+    ws = _ws(X)
+    tb, rb = _bias_target(out_bias)
+    call("mvk_conv3x3_s", ptr(X), ptr(wpack), ptr(bias), ptr(Y), n, H, W, Cin, Cout, act, ptr(y_act_src), y_src_act, ptr(res),
+         float(res_alpha), ptr(tb), x_act, float(pre_scale), ptr(x_amax), ptr(w_amax), ptr(y_amax), ptr(ws), ws.numel(),
+         stream_ptr())
     return Y if out_bias is None else (Y, rb)
 
 
@@ -1101,6 +1153,23 @@ def svhn_fused_tail_ok(C4, C3):
 # =====================================================================================================
 # ResNet stacks (models/nn/mmnist.py:214-366, models/nn/cub.py:144-293), NHWC activations
 # =====================================================================================================
+def _rs_conv(pool, X, xam, wpack, bias, n, H, W, Cin, Cout, **kw):
+    """One 3x3 convolution of a ResNet stack -> (result of conv3x3 / conv3x3_f, amax slot of Y or None).  With a pool (the
+    scaled-fp16 form is on) and a covered shape the launch is mvk_conv3x3_s: xam = the slot that bounds max |X| (None: it is
+    computed here), the weight's bound came with its pack, and max |Y| lands in a fresh slot for the consumer of Y."""
+    w_am = getattr(wpack, "mvk_amax", None)
+    if (pool is not None and w_am is not None and kw.get("act", NONE) != SIGMOID and kw.get("y_src_act", NONE) != SIGMOID
+            and conv3x3_scaled_ok(n, H, W, Cin, Cout)):
+        xam = xam if xam is not None else amax_of(X, pool.take())
+        yam = pool.take()
+        return conv3x3_s(X, wpack, bias, n, H, W, Cin, Cout, xam, w_am, yam, **kw), yam
+    if kw.get("x_act", NONE) != NONE or kw.get("pre_scale", 1.0) != 1.0:
+        return conv3x3_f(X, wpack, bias, n, H, W, Cin, Cout, **kw), None
+    kw.pop("x_act", None)
+    kw.pop("pre_scale", None)
+    return conv3x3(X, wpack, bias, n, H, W, Cin, Cout, **kw), None
+
+
 class ResnetStackFn(Function):
     """x [n,H,W,C] NHWC -> a static program of layers -> y NHWC, one autograd node.
 
@@ -1132,13 +1201,16 @@ class ResnetStackFn(Function):
             for i, pk in zip(order[i0:i0 + PACK_MAX], pack_weights(jobs[i0:i0 + PACK_MAX])):
                 packs[i] = pk
         h = x
+        # scaled-fp16 form: ham = the slot that bounds max |h| (None: unknown, computed on demand)
+        pool = AmaxPool(x, 4 * len(program) + 4) if C3_F16 else None
+        ham = None
         for op in program:
             if op[0] == "conv":
                 _, iw, ib, act = op
                 Cout = params[iw].shape[0]
-                y = conv3x3(h, packs[iw][0], params[ib] if ib is not None else None, n, H, W, C, Cout, act=act)
+                y, yam = _rs_conv(pool, h, ham, packs[iw][0], params[ib] if ib is not None else None, n, H, W, C, Cout, act=act)
                 tape.append((h, y, (H, W, C, Cout)))
-                h, C = y, Cout
+                h, C, ham = y, Cout, yam
             elif op[0] == "block":
                 _, order_, iw1, ib1, iw2, ib2, isc = op
                 Chid, Cout = params[iw1].shape[0], params[iw2].shape[0]
@@ -1148,27 +1220,28 @@ class ResnetStackFn(Function):
                 # conv1 stages its input (a0 is never written) and the backward pass folds the 0.1 and the bias gradients
                 fused = (conv3x3_fused_ok(n, H, W, C, Chid) and conv3x3_fused_ok(n, H, W, Chid, Cout)
                          and conv3x3_fused_ok(n, H, W, Cout, Chid))  # conv1, conv2 and conv2's backward-data launch
+                oam = None
                 if order_ == "post":
                     a0 = h
-                    a1 = conv3x3(a0, packs[iw1][0], b1, n, H, W, C, Chid, act=LEAKY)
-                    y2 = conv3x3(a1, packs[iw2][0], b2, n, H, W, Chid, Cout, act=LEAKY)
+                    a1, a1am = _rs_conv(pool, a0, ham, packs[iw1][0], b1, n, H, W, C, Chid, act=LEAKY)
+                    y2, _ = _rs_conv(pool, a1, a1am, packs[iw2][0], b2, n, H, W, Chid, Cout, act=LEAKY)
                 elif fused:
                     a0 = None
-                    a1 = conv3x3_f(h, packs[iw1][0], b1, n, H, W, C, Chid, act=LEAKY, x_act=LEAKY)
+                    a1, a1am = _rs_conv(pool, h, ham, packs[iw1][0], b1, n, H, W, C, Chid, act=LEAKY, x_act=LEAKY)
                     y2 = None
                 else:
                     a0 = axpby(h, 1.0, None, 0.0, act=LEAKY)
-                    a1 = conv3x3(a0, packs[iw1][0], b1, n, H, W, C, Chid, act=LEAKY)
+                    a1, a1am = _rs_conv(pool, a0, ham, packs[iw1][0], b1, n, H, W, C, Chid, act=LEAKY)
                     y2 = None  # the block's sum is formed in conv2's epilogue; backward does not need conv2's output
                 xs = h if isc is None else linear_fwd(h.view(-1, C), params[isc].view(Cout, C), None, NONE).view(n, H, W, Cout)
                 if y2 is None:
-                    out = conv3x3(a1, packs[iw2][0], b2, n, H, W, Chid, Cout, act=NONE, res=xs, res_alpha=0.1)
+                    out, oam = _rs_conv(pool, a1, a1am, packs[iw2][0], b2, n, H, W, Chid, Cout, act=NONE, res=xs, res_alpha=0.1)
                 else:
                     out = axpby(xs, 1.0, y2, 0.1)
                 tape.append((h, a0, a1, y2, (H, W, C, Chid, Cout), fused))
-                h, C = out, Cout
+                h, C, ham = out, Cout, oam
             elif op[0] == "pool":
-                y = avgpool(h, n, H, W, C)
+                y = avgpool(h, n, H, W, C)  # an average, a copy, a (leaky) ReLU: max |h| still bounds the result
                 tape.append((H, W, C))
                 h, H, W = y, (H + 1) // 2, (W + 1) // 2
             elif op[0] == "up":
@@ -1179,6 +1252,7 @@ class ResnetStackFn(Function):
                 y = axpby(h, 1.0, None, 0.0, act=op[1])
                 tape.append((y,))
                 h = y
+                ham = ham if op[1] in (LEAKY, RELU) else None
             else:
                 raise _lib.MvkError(f"unknown ResNet op {op[0]!r}")
         ctx.tape, ctx.packs, ctx.program, ctx.n = tape, packs, program, n
@@ -1193,6 +1267,8 @@ class ResnetStackFn(Function):
         grads = [None] * len(params)
         g = _c(dout)
         need_dx = ctx.needs_input_grad[0]
+        pool = AmaxPool(g, 4 * len(ctx.program) + 4) if C3_F16 else None
+        gam = None  # the slot that bounds max |g| (None: unknown)
         for li in range(len(ctx.program) - 1, -1, -1):
             op, rec = ctx.program[li], ctx.tape[li]
             first = li == 0
@@ -1206,8 +1282,8 @@ class ResnetStackFn(Function):
                 grads[iw] = conv3x3_wgrad(xin, dpre, params[iw], n, H, W, C, Cout)
                 if ib is not None:
                     grads[ib] = colsum(dpre.view(-1, Cout), params[ib])
-                if not first or need_dx:
-                    g = conv3x3(dpre, packs[iw][1], None, n, H, W, Cout, C)
+                if not first or need_dx:  # |dpre| <= |g|: the activation derivatives are at most 1
+                    g, gam = _rs_conv(pool, dpre, gam if act in (NONE, LEAKY, RELU) else None, packs[iw][1], None, n, H, W, Cout, C)
             elif op[0] == "block":
                 _, order_, iw1, ib1, iw2, ib2, isc = op
                 xin, a0, a1, y2, (H, W, C, Chid, Cout), fused = rec
@@ -1220,15 +1296,15 @@ class ResnetStackFn(Function):
                     if ib2 is not None:
                         grads[ib2] = gb2
                     if ib1 is not None:
-                        d1, grads[ib1] = conv3x3_f(gout, packs[iw2][1], None, n, H, W, Cout, Chid, y_act_src=a1,
-                                                   y_src_act=LEAKY, out_bias=params[ib1], pre_scale=0.1)
+                        (d1, grads[ib1]), d1am = _rs_conv(pool, gout, gam, packs[iw2][1], None, n, H, W, Cout, Chid, y_act_src=a1,
+                                                          y_src_act=LEAKY, out_bias=params[ib1], pre_scale=0.1)
                     else:
-                        d1 = conv3x3_f(gout, packs[iw2][1], None, n, H, W, Cout, Chid, y_act_src=a1, y_src_act=LEAKY,
-                                       pre_scale=0.1)
+                        d1, d1am = _rs_conv(pool, gout, gam, packs[iw2][1], None, n, H, W, Cout, Chid, y_act_src=a1,
+                                            y_src_act=LEAKY, pre_scale=0.1)
                     grads[iw1], _ = conv3x3_wgrad_f(xin, d1, params[iw1], None, n, H, W, C, Chid, x_act=LEAKY)
                     a0 = xin  # sign(lrelu(x)) == sign(x): the mask source of dx below
                 else:
-                    d2 = axpby(gout, 0.1, None, 0.0)  # gradient w.r.t. y2
+                    d2 = axpby(gout, 0.1, None, 0.0)  # gradient w.r.t. y2 (max |gout| bounds it, LeakyReLU' included)
                     if order_ == "post":
                         call("mvk_act_bwd", ptr(d2), ptr(y2), d2.numel(), LEAKY, stream_ptr())
                     if fused:  # bias gradient with the weight gradient
@@ -1242,10 +1318,10 @@ class ResnetStackFn(Function):
                             grads[ib2] = colsum(d2.view(-1, Cout), params[ib2])
                     # backward data of conv2 with lrelu'(a1) fused; its channel sums are conv1's bias gradient
                     if ib1 is not None:
-                        d1, grads[ib1] = conv3x3(d2, packs[iw2][1], None, n, H, W, Cout, Chid, y_act_src=a1, y_src_act=LEAKY,
-                                                 out_bias=params[ib1])
+                        (d1, grads[ib1]), d1am = _rs_conv(pool, d2, gam, packs[iw2][1], None, n, H, W, Cout, Chid, y_act_src=a1,
+                                                          y_src_act=LEAKY, out_bias=params[ib1])
                     else:
-                        d1 = conv3x3(d2, packs[iw2][1], None, n, H, W, Cout, Chid, y_act_src=a1, y_src_act=LEAKY)
+                        d1, d1am = _rs_conv(pool, d2, gam, packs[iw2][1], None, n, H, W, Cout, Chid, y_act_src=a1, y_src_act=LEAKY)
                     grads[iw1] = conv3x3_wgrad(a0, d1, params[iw1], n, H, W, C, Chid)
                 if isc is not None:
                     grads[isc], _ = linear_bwd_weight(gout.view(-1, Cout), xin.view(-1, C), params[isc].view(Cout, C), None)
@@ -1255,19 +1331,21 @@ class ResnetStackFn(Function):
                     # the shortcut's gradient first, the convolution path adds itself to it in its epilogue
                     gsc = gout if isc is None else linear_bwd_data(gout.view(-1, Cout), params[isc].view(Cout, C)).view(n, H, W, C)
                     if order_ == "post":
-                        dx = conv3x3(d1, packs[iw1][1], None, n, H, W, Chid, C, res=gsc)
+                        dx, gam = _rs_conv(pool, d1, d1am, packs[iw1][1], None, n, H, W, Chid, C, res=gsc)
                     else:  # through the leading LeakyReLU: multiply by lrelu'(x) = lrelu'(a0)
-                        dx = conv3x3(d1, packs[iw1][1], None, n, H, W, Chid, C, y_act_src=a0, y_src_act=LEAKY, res=gsc)
+                        dx, gam = _rs_conv(pool, d1, d1am, packs[iw1][1], None, n, H, W, Chid, C, y_act_src=a0, y_src_act=LEAKY,
+                                           res=gsc)
                     g = dx
             elif op[0] == "pool":
                 H, W, C = rec
-                g = avgpool_bwd(g, n, H, W, C)
+                g = avgpool_bwd(g, n, H, W, C)  # every input position collects at most 4 window shares of 1/9: the bound holds
             elif op[0] == "act":
                 g = g.clone() if g is dout else g
                 call("mvk_act_bwd", ptr(g), ptr(rec[0]), g.numel(), op[1], stream_ptr())
             else:
                 H, W, C = rec
                 g = upsample2_bwd(g, n, H, W, C)
+                gam = None  # sums of 4
         return (g if need_dx else None, None, *grads)
 
 

@@ -818,6 +818,80 @@ def test_conv3x3_register_stationary(K, n, H, W, Cin, Cout):
     close(Yt, nhwc(lrelu(conv).float()), what="default dispatch", rtol=3e-6)
 
 
+@pytest.mark.parametrize("n,H,W,Cin,Cout", [(5, 64, 64, 64, 64), (9, 32, 32, 64, 128), (40, 16, 16, 128, 128), (33, 16, 16, 128, 256),
+                                          (70, 28, 28, 64, 64), (130, 14, 14, 128, 64), (2, 7, 7, 128, 256), (1, 9, 13, 64, 64),
+                                          (3, 32, 32, 128, 64), (2, 62, 50, 128, 128)])
+@pytest.mark.parametrize("spread", [0.0, 3.0])
+def test_conv3x3_scaled_fp16(K, n, H, W, Cin, Cout, spread):
+    """mvk_conv3x3_s (csrc/conv3rs.hip, NP = 2): every product is 3 fp16 MFMAs on scaled (hi, lo) pairs instead of 6 bf16
+    ones.  Same float64 reference and the SAME tolerance as the bf16-piece kernels (test_conv3x3_register_stationary), on
+    unit-scale data and on data whose images / weight rows spread over e^(+-3 sigma) ~ 8 orders of magnitude; the operand
+    scales come from mvk_amax / the pack launch, and max |Y| as published by the launch is exact."""
+    gen = g(61)
+    d = dev()
+    x = torch.randn(n, Cin, H, W, generator=gen) * torch.exp(spread * torch.randn(n, 1, 1, 1, generator=gen)) * 3.7
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) / (3 * Cin ** 0.5) * torch.exp(spread * torch.randn(Cout, 1, 1, 1, generator=gen))
+    b = 0.1 * torch.randn(Cout, generator=gen)
+    res = torch.randn(n, Cout, H, W, generator=gen)
+    src = torch.randn(n, Cout, H, W, generator=gen)
+    nhwc = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(d)
+    (wf, wb), = K.pack_weights([(w.to(d), "c3", True, True)])
+    assert float(wf.mvk_amax) == float(w.abs().max()) and wb.mvk_amax.data_ptr() == wf.mvk_amax.data_ptr()
+    pool = K.AmaxPool(wf, 8)
+    X = nhwc(x)
+    xam = K.amax_of(X, pool.take())
+    assert float(xam) == float(x.abs().max())
+    ax = F.leaky_relu(x.double(), 0.2)
+    conv = F.conv2d(ax, w.double(), None, 1, 1)
+    bb = b.double().view(1, -1, 1, 1)
+    _debug_flags(0x800)
+    try:
+        assert K.conv3x3_scaled_ok(n, H, W, Cin, Cout)
+        yam = pool.take()
+        Y = K.conv3x3_s(X, wf, b.to(d), n, H, W, Cin, Cout, xam, wf.mvk_amax, yam, act=K.LEAKY, x_act=K.LEAKY)
+        close(Y, nhwc(F.leaky_relu(conv + bb, 0.2).float()), what="lrelu(conv(lrelu(x)) + b)", rtol=3e-6)
+        assert float(yam) == float(Y.abs().max()), "published max |Y|"
+        bparam = torch.zeros(Cout, device=d).requires_grad_(True)
+        bparam.grad = torch.zeros(Cout, device=d)
+        mask = torch.where(src > 0, 1.0, 0.2).double()
+        yam = pool.take()
+        Y, _ = K.conv3x3_s(X, wf, None, n, H, W, Cin, Cout, xam, wf.mvk_amax, yam, y_act_src=nhwc(src), y_src_act=K.LEAKY,
+                           out_bias=bparam, x_act=K.LEAKY, pre_scale=0.1)
+        ref = 0.1 * conv * mask
+        close(Y, nhwc(ref.float()), what="0.1 conv * act'(mask source)", rtol=3e-6)
+        close(bparam.grad, ref.sum((0, 2, 3)).float(), what="column sums", rtol=1e-5)
+        assert float(yam) == float(Y.abs().max())
+        plain = F.conv2d(x.double(), w.double(), None, 1, 1)
+        Y = K.conv3x3_s(X, wf, b.to(d), n, H, W, Cin, Cout, xam, wf.mvk_amax, act=K.NONE, res=nhwc(res), res_alpha=0.1)
+        close(Y, nhwc((res.double() + 0.1 * (plain + bb)).float()), what="res + 0.1 * conv", rtol=3e-6)
+        yam = pool.take()
+        Y = K.conv3x3_s(X, wf, b.to(d), n, H, W, Cin, Cout, xam, wf.mvk_amax, yam, act=K.RELU, y_act_src=nhwc(src),
+                        y_src_act=K.RELU, res=nhwc(res))
+        close(Y, nhwc((res.double() + torch.relu(plain + bb) * (src > 0)).float()), what="res + relu(conv) * relu'(src)", rtol=3e-6)
+        assert float(yam) == float(Y.abs().max())
+        # a bound that is merely an upper bound (here 1000 x too large) costs range, not precision
+        loose = (xam * 1000.0).contiguous()
+        Y = K.conv3x3_s(X, wf, None, n, H, W, Cin, Cout, loose, wf.mvk_amax)
+        close(Y, nhwc(plain.float()), what="loose bound", rtol=3e-6)
+    finally:
+        _debug_flags(0)
+
+
+def test_amax_kernel(K):
+    """mvk_amax: max |x| by atomic max into a slot that keeps what it held; odd lengths, zeros, infinities."""
+    d = dev()
+    gen = g(67)
+    for nel in (1, 3, 4, 1023, 4096 * 257 + 2):
+        x = torch.randn(nel, generator=gen).to(d)
+        pool = K.AmaxPool(x, 2)
+        assert float(K.amax_of(x, pool.take())) == float(x.abs().max())
+    slot = torch.full((1,), 7.5, device=d)
+    assert float(K.amax_of(torch.zeros(100, device=d), slot)) == 7.5
+    x = torch.randn(1000, generator=gen).to(d)
+    x[77] = float("-inf")
+    assert float(K.amax_of(x, torch.zeros(1, device=d))) == float("inf")
+
+
 @pytest.mark.parametrize("n,H,W,Cin,Cout", [(3, 32, 32, 64, 64), (15, 16, 16, 128, 128), (20, 14, 14, 64, 128), (3, 7, 7, 128, 64)])
 def test_conv3x3_fused_forms(K, n, H, W, Cin, Cout):
     """mvk_conv3x3_f / mvk_conv3x3_wgrad_f (csrc/conv3rs.hip): the activation of the producing layer applied while X is staged,

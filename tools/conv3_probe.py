@@ -26,11 +26,56 @@ if which == "prof":  # a few launches per kernel NAME (one shape each) for the c
         (wf, wb), = K.pack_weights([(w, "c3", True, True)])
         wparam = w.clone().requires_grad_(True)
         wparam.grad = torch.zeros_like(wparam)
+        pool = K.AmaxPool(x, 16)
+        xam = K.amax_of(x, pool.take())
         for _ in range(5):
             K.conv3x3(x, wf, b, n_, H_, H_, Ci_, Co_, act=K.LEAKY, y_act_src=src, y_src_act=K.LEAKY)
+            K.conv3x3_s(x, wf, b, n_, H_, H_, Ci_, Co_, xam, wf.mvk_amax, pool.take(), act=K.LEAKY, y_act_src=src, y_src_act=K.LEAKY)
             if wg_:
                 K.conv3x3_wgrad(x, src, wparam, n_, H_, H_, Ci_, Co_)
         torch.cuda.synchronize()
+    sys.exit(0)
+if which in ("f16", "f16cfg4", "f16one"):  # bf16-piece kernels vs the scaled-fp16 form (mvk_conv3x3_s): time, error against float64
+    n = 1600 if which == "f16cfg4" else 128
+    shapes = ([(64, 64, 64), (32, 64, 64), (32, 64, 128), (32, 128, 64), (16, 128, 128), (16, 128, 256)] if which == "f16"
+              else [(64, 64, 64), (63, 64, 64)] if which == "f16one"  # variant builds (tools/conv3_variants.sh): 64 -> 64 only
+              else [(28, 64, 64), (14, 64, 64), (14, 64, 128), (14, 128, 64), (7, 128, 128), (7, 128, 256)])
+
+    def t_us(fn, reps=10):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+
+    print(f"{which}: n = {n}; masked backward-data form (mask + column sums); err = max |y - f64| / max |f64| on 2 images")
+    print("| H | Cin | Cout | GFLOP | bf16x3 us | TF/s | err | fp16x2 us | TF/s | err | amax us |")
+    for H, Cin, Cout in shapes:
+        x = torch.randn(n, H, H, Cin, device=d)
+        w = torch.randn(Cout, Cin, 3, 3, device=d) / (3 * Cin ** 0.5)
+        src = torch.randn(n, H, H, Cout, device=d)
+        (wf, wb), = K.pack_weights([(w, "c3", True, True)])
+        bparam = torch.zeros(Cout, device=d).requires_grad_(True)
+        bparam.grad = torch.zeros(Cout, device=d)
+        pool = K.AmaxPool(x, 64)
+        xam = K.amax_of(x, pool.take())
+        gf = 2.0 * n * H * H * 9 * Cin * Cout / 1e9
+        ref = torch.nn.functional.conv2d(x[:2].permute(0, 3, 1, 2).double(), w.double(), None, 1, 1).permute(0, 2, 3, 1)
+        ref = ref * torch.where(src[:2] > 0, 1.0, 0.2).double()
+        err = lambda y: float((y[:2].double() - ref).abs().max() / ref.abs().max())
+        f3 = lambda: K.conv3x3_f(x, wf, None, n, H, H, Cin, Cout, y_act_src=src, y_src_act=K.LEAKY, out_bias=bparam)[0]
+        f2 = lambda: K.conv3x3_s(x, wf, None, n, H, H, Cin, Cout, xam, wf.mvk_amax, pool.take(), y_act_src=src,
+                                 y_src_act=K.LEAKY, out_bias=bparam)[0]
+        ok3 = K.conv3x3_fused_ok(n, H, H, Cin, Cout)
+        t3, e3 = (t_us(f3), err(f3())) if ok3 else (float("nan"), float("nan"))
+        t2, e2 = t_us(f2), err(f2())
+        ta = t_us(lambda: K.amax_of(x, pool.take()))
+        print(f"| {H} | {Cin} | {Cout} | {gf:.1f} | {t3:.0f} | {gf / t3 * 1e3:.0f} | {e3:.1e} | {t2:.0f} | {gf / t2 * 1e3:.0f} | {e2:.1e} | {ta:.0f} |")
     sys.exit(0)
 if which == "one":  # the 64 -> 64 channel layers only (variant builds of tools/conv3_variants.sh)
     n = 128
