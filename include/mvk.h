@@ -433,6 +433,12 @@ int mvk_conv3x3_s(const float* X, const float* Wp, const float* bias, float* Y, 
                   int act, const float* y_act_src, int y_src_act, const float* res, float res_alpha, float* colsum_acc,
                   int x_act, float pre_scale, const float* x_amax, const float* w_amax, float* y_amax, float* ws,
                   int64_t ws_floats, void* stream);
+/* mvk_conv3x3_wgrad_f on scaled fp16 pairs (one accumulator per tap tile: the 2^11 between main and cross terms sits in a
+ * third piece of dY, csrc/conv3rs.hip); x_amax / dy_amax: device scalars >= max |X| / max |dY|. */
+int mvk_conv3x3_wgrad_scaled_ok(int n, int H, int W, int Cin, int Cout);
+int mvk_conv3x3_wgrad_s(const float* X, const float* dY, float* dWref, float* db, int n, int H, int W, int Cin, int Cout,
+                        int x_act, float dy_scale, const float* x_amax, const float* dy_amax, float* ws, int64_t ws_floats,
+                        void* stream);
 /* nn.AvgPool2d(3, stride=2, padding=1) (count_include_pad: every window divides by 9) and nn.Upsample(scale_factor=2)
  * (nearest) on NHWC tensors, forward and backward; out = act(a*x + b*y) (x or y may be NULL). */
 int mvk_avgpool3s2_fwd(const float* x, float* y, int n, int H, int W, int C, void* stream);

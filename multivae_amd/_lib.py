@@ -89,6 +89,7 @@ PROTOTYPES = {
     "mvk_conv3x3_wgrad_f": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _i64, _p],
     "mvk_conv3x3_s": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _f, _p, _i, _f, _p, _p, _p, _p, _i64, _p],
     "mvk_amax": [_p, _i64, _p, _p],
+    "mvk_conv3x3_wgrad_s": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _i64, _p],
     "mvk_avgpool3s2_fwd": [_p, _p, _i, _i, _i, _i, _p],
     "mvk_avgpool3s2_bwd": [_p, _p, _i, _i, _i, _i, _p],
     "mvk_upsample2_fwd": [_p, _p, _i, _i, _i, _i, _p],
@@ -166,6 +167,8 @@ def load(path=None):
     lib.mvk_conv3x3_fused_ok.restype = C.c_int
     lib.mvk_conv3x3_scaled_ok.argtypes = [_i, _i, _i, _i, _i]
     lib.mvk_conv3x3_scaled_ok.restype = C.c_int
+    lib.mvk_conv3x3_wgrad_scaled_ok.argtypes = [_i, _i, _i, _i, _i]
+    lib.mvk_conv3x3_wgrad_scaled_ok.restype = C.c_int
     lib.mvk_defer_wanted.argtypes = []
     lib.mvk_defer_wanted.restype = C.c_int64
     lib.mvk_defer_pending.argtypes = []
@@ -231,6 +234,7 @@ GEMM_FLOPS = {
     "mvk_conv3x3_f": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
     "mvk_conv3x3_wgrad_f": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
     "mvk_conv3x3_s": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
+    "mvk_conv3x3_wgrad_s": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
     "mvk_conv4s2_up_nchw_small": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
     "mvk_conv4s2_small_up_fwd": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
     "mvk_conv4s2_small_down_fwd": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],

@@ -39,11 +39,26 @@
 // 3 = one main + a cross per k-step of a pair, 4 = main + cross per k-step.  A/B (64 -> 64 @64x64, n = 128): 153 / 162 / 165 us
 #define MVK_C3_F16ACC 2
 #endif
+#ifndef MVK_C3_DIST
+// scaled-fp16 form: pairs of k-steps the A fragments are read ahead of their MFMAs (1 or 2).  A/B: 151 vs 167 us — the LDS
+// latency was not what the loop waits for, and 2 moves the barrier one pair up
+#define MVK_C3_DIST 1
+#endif
+#ifndef MVK_C3_NW2
+// waves per workgroup of the scaled-fp16 form: 4 = one per SIMD, 8 = two per SIMD with 72 weight registers each (twice the
+// tap split: 4 / 8 waves share a column tile).  A/B (64 -> 64 @64x64, n = 128, masked form): 157 vs 158 us, plain 129 vs 139 us
+// — what the second wave covers, the wider exchange and the 8-wave barrier (19 % of the cycles) take back.
+#define MVK_C3_NW2 4
+#endif
 #ifndef MVK_C3_BAR
 #define MVK_C3_BAR 7    // the pair behind which the tile's barrier sits (6: one more pair of cover for what follows it)
 #endif
 
 namespace mvk {
+
+#ifdef MVK_C3PROF  // tools/conv3_phase.py: per-wave cycle counters (total, waiting at the tile barrier)
+__device__ unsigned long long* g_c3_dbg = nullptr;
+#endif
 
 struct C3Args {
   const float* X;        // input [n][H][W][CIN] (NHWC)
@@ -74,22 +89,28 @@ template <int CIN, int COUT, int NP = 3>
 struct C3Cfg {
   static constexpr int CHUNKS = CIN / 16;            // 16-channel k-steps per tap
   static constexpr int KALL = 9 * CHUNKS;            // k-steps of one output element
-  static constexpr int KPW = 18;                     // k-steps per wave = 216 (NP = 3) / 144 (NP = 2) weight registers
-  static constexpr int KSPLIT = KALL / KPW;          // waves sharing one 32-column tile: 2 (64 channels), 4 (128)
+  // The bf16 form needs 216 weight registers per wave: ONE wave per SIMD, every latency covered by software pipelining.  The
+  // fp16 form has half the MFMAs (1730 cycles per tile) to hide the same staging / exchange / epilogue work behind, and that
+  // work alone takes 3260 cycles per tile (tools/conv3_phase.py, subtraction builds): the loop is bound by it, not by the
+  // matrix pipe.  MVK_C3_NW2 = 8 runs two waves per SIMD with 72 weight registers each; it measured no faster (see above).
+  static constexpr int NW = NP == 2 ? MVK_C3_NW2 : 4;  // waves per workgroup
+  static constexpr int KPW = 72 / NW;                // k-steps per wave: 18 = 216 (NP = 3) / 144 (NP = 2) weight registers, 9 = 72
+  static constexpr int HPP = KPW / 9;                // k-steps per loop iteration ("pair")
+  static constexpr int KSPLIT = KALL / KPW;          // waves sharing one 32-column tile
   static constexpr int NCT = COUT / 32;
   static constexpr int ROLES = NCT * KSPLIT;
-  static constexpr int WG_TYPES = ROLES / 4;
+  static constexpr int WG_TYPES = ROLES / NW;
   static constexpr int S = 2 * NP * CIN + 16;        // bytes per ring slot: NP pieces x CIN halves + pad ((S / 16) odd)
-  static constexpr int NF4 = CIN / 32;               // float4 staging units per thread and chunk
+  static constexpr int NF4 = CIN / (8 * NW);         // float4 staging units per thread and chunk
   static constexpr int OWN = 16 / KSPLIT;            // accumulator registers (output rows per lane) a wave finishes
   static constexpr int XWAVE = (KSPLIT - 1) * OWN * 64 * 4;
-  static constexpr int XBUF = 4 * XWAVE;
+  static constexpr int XBUF = NW * XWAVE;
   static constexpr int PTAB_INTS = 16 * 32;
   // largest window reach (chunks) whose ring fits the LDS: 3 = W <= 94, 2 = W <= 62, 1 = W <= 30
   static constexpr int MAXD = CIN == 64 ? 3 : (NP == 2 ? 2 : 1);
-  static_assert(KALL % KPW == 0 && ROLES % 4 == 0 && 4 % KSPLIT == 0, "roles");
+  static_assert(KALL % KPW == 0 && ROLES % NW == 0 && NW % KSPLIT == 0 && KPW % 9 == 0 && NF4 >= 1, "roles");
   static_assert((S / 16) % 2 == 1, "odd 16-byte stride: conflict-free fragments");
-  __host__ __device__ static constexpr int lds_bytes(int ring) { return ring * S + 2 * XBUF + PTAB_INTS * 4 + 4 * 32 * 4; }
+  __host__ __device__ static constexpr int lds_bytes(int ring) { return ring * S + 2 * XBUF + PTAB_INTS * 4 + NW * 32 * 4; }
 };
 
 __device__ __forceinline__ bf16x8 c3_pack8(const unsigned (&d)[4]) {
@@ -98,7 +119,7 @@ __device__ __forceinline__ bf16x8 c3_pack8(const unsigned (&d)[4]) {
 }
 
 template <int CIN, int COUT, bool HAS_SRC, bool HAS_RES, int NP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void c3rs_kernel(const C3Args g) {
+__device__ __forceinline__ void c3rs_body(const C3Args& g) {
   using T = C3Cfg<CIN, COUT, NP>;
   using frag = std::conditional_t<NP == 3, bf16x8, f16x8>;
   // scaled-fp16 form: the operands are multiplied by sx / sw on their way into pieces, the result by 1 / (sx sw)
@@ -110,7 +131,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int col = lane & 31, kg = lane >> 5;
   const int wgtype = blockIdx.x % T::WG_TYPES;
   const int worker = blockIdx.x / T::WG_TYPES, workers = gridDim.x / T::WG_TYPES;
-  const int role = wgtype * 4 + wave;
+  const int role = wgtype * T::NW + wave;
   const int ct = role / T::KSPLIT, ks = role % T::KSPLIT;
   const int ncol = ct * 32 + col;
 
@@ -185,7 +206,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   int soff[T::NF4], spos[T::NF4], sc4[T::NF4];
 #pragma unroll
   for (int k = 0; k < T::NF4; ++k) {
-    const int f = tid + k * 256;
+    const int f = tid + k * (T::NW * 64);
     spos[k] = f / (CIN / 4);
     sc4[k] = (f % (CIN / 4)) * 4;
     soff[k] = spos[k] * T::S + (f % (CIN / 4)) * 8;
@@ -263,6 +284,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // column sums (the bias gradient of the layer below) exist in the backward-data form only: mask, no residual
   constexpr bool WITH_CSUM = HAS_SRC && !HAS_RES;
   const float bias = g.bias ? g.bias[ncol] : 0.f;
+#ifdef MVK_C3PROF
+  const unsigned long long c3_t0 = __builtin_readcyclecounter();
+  unsigned long long c3_bar = 0;
+#endif
   const float aslope = g.aslope, mslope = g.mslope, alpha = g.res_alpha;
   const float pre_scale = NP == 2 ? g.pre_scale * inv_sw : g.pre_scale;
   float csum = 0.f, amax_l = 0.f;
@@ -289,10 +314,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         ab[j] = (int)s + kg * 16;
       }
     };
-    auto read_pair = [&](frag (&dst)[2][NP], const int (&ab)[NTAPW], int pr) {
+    auto read_pair = [&](frag (&dst)[T::HPP][NP], const int (&ab)[NTAPW], int pr) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int gk = KSC * T::KPW + 2 * pr + h;
+      for (int h = 0; h < T::HPP; ++h) {
+        const int gk = KSC * T::KPW + T::HPP * pr + h;
         const int j = gk / T::CHUNKS - TAP_LO, c = gk % T::CHUNKS;
 #pragma unroll
         for (int pc = 0; pc < NP; ++pc)
@@ -329,8 +354,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if constexpr (NP == 3) {
         sum = pend[0] + pend[1];
       } else {
-        const f32x16 cross = NACC == 4 ? pend[2] + pend[3] : (NACC == 3 ? pend[1] + pend[2] : pend[1]);
-        sum = NACC == 4 ? pend[0] + pend[1] : pend[0];
+        f32x16 cross;
+        if constexpr (NACC == 4) {
+          cross = pend[2] + pend[3];
+          sum = pend[0] + pend[1];
+        } else if constexpr (NACC == 3) {
+          cross = pend[1] + pend[2];
+          sum = pend[0];
+        } else {
+          cross = pend[1];
+          sum = pend[0];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) sum[r] = fmaf(cross[r], 1.f / 2048.f, sum[r]);
       }
@@ -389,10 +423,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int tb = (int)(((long long)32 * T0) % RING) * T::S;  // first ring slot of tile T, in bytes
     int wch = (((T0 + D + 1) % NCH) + NCH) % NCH;       // ring chunk that chunk T+D+1 goes to
     int ab_cur[NTAPW], ab_nxt[NTAPW];
-    frag a_cur[2][NP];
+    // A fragments are read DIST pairs ahead of their MFMAs (the bf16 form's 12 MFMAs per pair cover one burst of LDS reads of
+    // the four waves; the 6 of the fp16 form do not): set (pr + 9 P) % NSET holds pair pr of a tile of parity P
+    constexpr int DIST = NP == 2 ? MVK_C3_DIST : 1, NSET = DIST + 1;
+    // the barrier that publishes chunk T+D+1 must sit in front of the first read of tile T+1's fragments
+    constexpr int BAR = MVK_C3_BAR < 9 - DIST ? MVK_C3_BAR : 8 - DIST;
+    static_assert(18 % NSET == 0 && DIST >= 1, "the set of a pair must depend on the tile's parity only");
+    frag a_q[NSET][T::HPP][NP];
     if (NT > 0) {
       frag_base(ab_cur, tb);
-      read_pair(a_cur, ab_cur, 0);
+#pragma unroll
+      for (int dd = 0; dd < DIST; ++dd) read_pair(a_q[dd], ab_cur, dd);
     }
     auto tile = [&](auto par_tag, int t) {
       constexpr int P = decltype(par_tag)::value;
@@ -408,10 +449,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       int upix[T::NF4];
 #pragma unroll
       for (int pr = 0; pr < 9; ++pr) {
-        frag a_nxt[2][NP];
-        if (pr < 8) read_pair(a_nxt, ab_cur, pr + 1);
+#ifndef MVK_C3X_NOFRAG  // MVK_C3X_*: subtraction experiments of tools/conv3_phase.py (timing only: the results are wrong)
+        if (pr + DIST <= 8) read_pair(a_q[(pr + DIST + 9 * P) % NSET], ab_cur, pr + DIST);
+        else read_pair(a_q[(pr + DIST + 9 * P) % NSET], ab_nxt, pr + DIST - 9);  // behind the barrier: the next tile's first pairs
+#endif
+        frag(&a_cur)[T::HPP][NP] = a_q[(pr + 9 * P) % NSET];
         if (pr == 0) {
+#ifndef MVK_C3X_NOXCHG
           finish_pending(xb);
+#endif
           fetch_pix(P, (Tt - 1) & 15);            // table rows published by the previous barrier: ONE wait per tile
 #pragma unroll
           for (int k = 0; k < T::NF4; ++k) upix[k] = unit_pix(Tt + D + 2, k);
@@ -421,18 +467,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // conversion of chunk Tt+D+1 (loaded one tile ago) + the loads of chunk Tt+D+2: done before the barrier behind pair 7
         {
           constexpr int STEP = T::NF4 == 2 ? 3 : 2;
-          constexpr int FIRST = MVK_C3_BAR == 7 ? 1 : 0;  // the last conversion sits in front of the barrier
-          if (pr >= FIRST && pr <= MVK_C3_BAR && (pr - FIRST) % STEP == 0 && (pr - FIRST) / STEP < T::NF4) {
+          constexpr int FIRST = BAR == 7 ? 1 : 0;  // the last conversion sits in front of the barrier
+#ifndef MVK_C3X_NOSTAGE
+          if (pr >= FIRST && pr <= BAR && (pr - FIRST) % STEP == 0 && (pr - FIRST) / STEP < T::NF4) {
             write_unit(wbase, (pr - FIRST) / STEP);
             load_unit_at(upix[(pr - FIRST) / STEP], (pr - FIRST) / STEP);
           }
+#endif
         }
 #pragma unroll
         for (int o = 0; o < T::OWN; ++o) {
           if (o * 8 / T::OWN + 1 != pr) continue;
+#ifndef MVK_C3X_NOEPI
           fetch_row(P, o);                        // tile Tt-1: consumed two tiles later
           epilogue_row(P ^ 1, o, valid2);         // tile Tt-2
+#endif
         }
+#ifndef MVK_C3X_NOMFMA
         if constexpr (NP == 3) {
           constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB_[6] = {2, 1, 0, 1, 0, 0};  // small terms first
 #pragma unroll
@@ -440,7 +491,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][PA[m]], Bw[2 * pr][PB_[m]], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][PA[m]], Bw[2 * pr + 1][PB_[m]], acc[1], 0, 0, 0);
           }
-        } else {  // cross terms (pieces 0 x 1, 1 x 0) in accumulators 2 / 3, the main term in 0 / 1: no two neighbours depend
+        } else if constexpr (T::HPP == 1) {  // one k-step per iteration (two waves per SIMD): main, cross
+          static_assert(NACC == 2, "two accumulators");
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0][0], Bw[pr][1], acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0][0], Bw[pr][0], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0][1], Bw[pr][0], acc[1], 0, 0, 0);
+        } else {  // cross terms (pieces 0 x 1, 1 x 0) and the main term in accumulators of their own
           constexpr int M0 = 0, M1 = NACC == 4 ? 1 : 0, C0 = NACC == 4 ? 2 : 1, C1 = NACC == 4 ? 3 : (NACC == 3 ? 2 : 1);
           acc[C0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0][0], Bw[2 * pr][1], acc[C0], 0, 0, 0);
           acc[M0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0][0], Bw[2 * pr][0], acc[M0], 0, 0, 0);
@@ -449,13 +505,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           acc[C0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0][1], Bw[2 * pr][0], acc[C0], 0, 0, 0);
           acc[C1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1][1], Bw[2 * pr + 1][0], acc[C1], 0, 0, 0);
         }
-        if (pr == MVK_C3_BAR + 1) gather_result(xb);  // behind the barrier: result of tile Tt-1
-        if (pr == 8) read_pair(a_nxt, ab_nxt, 0);     // first fragments of the next tile
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int pc = 0; pc < NP; ++pc) a_cur[h][pc] = a_nxt[h][pc];
-        if (MVK_C3_SCHED > 0) {  // the same "other" work per pair behind half as many MFMAs in the fp16 form
+#else
+        acc[0][pr] += __builtin_bit_cast(f32x4, a_cur[0][0])[0] + __builtin_bit_cast(f32x4, a_cur[T::HPP - 1][NP - 1])[1];
+#endif
+#ifndef MVK_C3X_NOXCHG
+        if (pr == BAR + 1) gather_result(xb);  // behind the barrier: result of tile Tt-1
+#endif
+        if (MVK_C3_SCHED > 0 && T::NW == 4) {  // the same "other" work per pair behind half as many MFMAs in the fp16 form
           constexpr int OTHERS = (MVK_C3_SCHED > 0 ? MVK_C3_SCHED : 1) * (NP == 3 ? 1 : MVK_C3_SCHED2);
 #pragma unroll
           for (int m = 0; m < 4 * NP; ++m) {
@@ -463,7 +519,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_sched_group_barrier(0x496, OTHERS, 0);
           }
         }
-        if (pr == MVK_C3_BAR) __syncthreads();
+#ifdef MVK_C3PROF
+        if (pr == BAR) {
+          const unsigned long long b0 = __builtin_readcyclecounter();
+          __syncthreads();
+          c3_bar += __builtin_readcyclecounter() - b0;
+        }
+#else
+        if (pr == BAR) __syncthreads();
+#endif
       }
 #pragma unroll
       for (int i = 0; i < NACC; ++i) pend[i] = acc[i];
@@ -506,15 +570,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (ks_u == 0) run(std::integral_constant<int, 0>{});
   else if (ks_u == 1) run(std::integral_constant<int, 1>{});
   else if (T::KSPLIT > 2 && ks_u == 2) run(std::integral_constant<int, (T::KSPLIT > 2 ? 2 : 0)>{});
-  else if (T::KSPLIT > 3) run(std::integral_constant<int, (T::KSPLIT > 3 ? 3 : 0)>{});
+  else if (T::KSPLIT > 3 && ks_u == 3) run(std::integral_constant<int, (T::KSPLIT > 3 ? 3 : 0)>{});
+  else if (T::KSPLIT > 4 && ks_u == 4) run(std::integral_constant<int, (T::KSPLIT > 4 ? 4 : 0)>{});
+  else if (T::KSPLIT > 5 && ks_u == 5) run(std::integral_constant<int, (T::KSPLIT > 5 ? 5 : 0)>{});
+  else if (T::KSPLIT > 6 && ks_u == 6) run(std::integral_constant<int, (T::KSPLIT > 6 ? 6 : 0)>{});
+  else if (T::KSPLIT > 7) run(std::integral_constant<int, (T::KSPLIT > 7 ? 7 : 0)>{});
 
+#ifdef MVK_C3PROF
+  if (g_c3_dbg && lane == 0) {
+    unsigned long long* o = g_c3_dbg + (blockIdx.x * 4 + wave) * 2;
+    o[0] = __builtin_readcyclecounter() - c3_t0;
+    o[1] = c3_bar;
+  }
+#endif
   if (g.y_amax) amax_publish(amax_l, g.y_amax);
   if (WITH_CSUM && g.colsum_part) {  // fixed-order sum over the lanes / waves that share a column
     csum += __shfl_xor(csum, 32, 64);
     __syncthreads();
     if (kg == 0) csred[wave * 32 + col] = csum;
     __syncthreads();
-    constexpr int CPW = (4 / T::KSPLIT) * 32;  // columns this workgroup covers
+    constexpr int CPW = (T::NW / T::KSPLIT) * 32;  // columns this workgroup covers
     if (tid < CPW) {
       const int grp = tid / 32, c_l = tid % 32;
       float s = 0.f;
@@ -525,15 +600,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   mvk_prof_end(g.prof);
 }
 
+// one wave per SIMD (up to 512 registers per lane) / two waves per SIMD (256)
+template <int CIN, int COUT, bool HAS_SRC, bool HAS_RES, int NP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void c3rs_kernel(const C3Args g) {
+  static_assert(C3Cfg<CIN, COUT, NP>::NW == 4, "four waves");
+  c3rs_body<CIN, COUT, HAS_SRC, HAS_RES, NP>(g);
+}
+template <int CIN, int COUT, bool HAS_SRC, bool HAS_RES, int NP>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void c3rs_kernel8(const C3Args g) {
+  static_assert(C3Cfg<CIN, COUT, NP>::NW == 8, "eight waves");
+  c3rs_body<CIN, COUT, HAS_SRC, HAS_RES, NP>(g);
+}
+template <int CIN, int COUT, bool HAS_SRC, bool HAS_RES, int NP>
+static const void* c3rs_entry() {
+  if constexpr (C3Cfg<CIN, COUT, NP>::NW == 8) return reinterpret_cast<const void*>(c3rs_kernel8<CIN, COUT, HAS_SRC, HAS_RES, NP>);
+  else return reinterpret_cast<const void*>(c3rs_kernel<CIN, COUT, HAS_SRC, HAS_RES, NP>);
+}
+
 template <int CIN, int COUT, int NP>
 static int c3rs_launch(const C3Args& a, int* part_rows, hipStream_t s) {
   using T = C3Cfg<CIN, COUT, NP>;
   const int lds = T::lds_bytes(a.ring);
   if (lds > 160 * 1024) return 1;
-  const void* all[4] = {reinterpret_cast<const void*>(c3rs_kernel<CIN, COUT, false, false, NP>),
-                        reinterpret_cast<const void*>(c3rs_kernel<CIN, COUT, true, false, NP>),
-                        reinterpret_cast<const void*>(c3rs_kernel<CIN, COUT, false, true, NP>),
-                        reinterpret_cast<const void*>(c3rs_kernel<CIN, COUT, true, true, NP>)};
+  const void* all[4] = {c3rs_entry<CIN, COUT, false, false, NP>(), c3rs_entry<CIN, COUT, true, false, NP>(),
+                        c3rs_entry<CIN, COUT, false, true, NP>(), c3rs_entry<CIN, COUT, true, true, NP>()};
   static int attr_bytes = 0;
   if (attr_bytes < lds) {
     for (const void* f : all)
@@ -545,10 +635,8 @@ static int c3rs_launch(const C3Args& a, int* part_rows, hipStream_t s) {
   C3Args ap = a;
   ap.prof = prof_next(7, 2.0 * a.n * a.H * a.W * 9.0 * CIN * COUT);
   const int which = (a.act_src ? 1 : 0) + (a.res ? 2 : 0);
-  auto kern = which == 0 ? c3rs_kernel<CIN, COUT, false, false, NP>
-              : which == 1 ? c3rs_kernel<CIN, COUT, true, false, NP>
-              : which == 2 ? c3rs_kernel<CIN, COUT, false, true, NP> : c3rs_kernel<CIN, COUT, true, true, NP>;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, ap);
+  void* kargs[1] = {&ap};
+  if (hipLaunchKernel(all[which], dim3(grid), dim3(T::NW * 64), kargs, lds, s) != hipSuccess) return MVK_ELAUNCH;
   MVK_CHECK_LAUNCH();
   prof_fold(ap.prof, s);
   return MVK_OK;
@@ -579,6 +667,8 @@ struct C3WArgs {
   int ring, D, tiles;
   unsigned xbytes, ybytes;  // sizes of X / dY in bytes (< 2^32 - 8192)
   mvk_prof_slot* prof;
+  const float* x_amax;  // scaled-fp16 form (NP = 2): upper bounds of max |X| and max |dY| (device scalars)
+  const float* y_amax;
 };
 
 #ifndef MVK_C3W_PAD
@@ -591,15 +681,36 @@ constexpr int C3W_S = 6 * 64 + MVK_C3W_PAD;  // bytes per slot: 3 pieces x 64 ch
 static int c3w_lds_bytes(int ring) { return (ring + 64) * C3W_S + 16 * 32 * 4; }
 
 typedef __bf16 c3_bf16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 c3_tr_pair(const char* p0, const char* p1) {
-  typedef __attribute__((address_space(3))) c3_bf16x4* lp;
-  const c3_bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p0));
-  const c3_bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p1));
-  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+typedef _Float16 c3_f16x4 __attribute__((ext_vector_type(4)));
+template <typename F>
+__device__ __forceinline__ F c3_tr_pair(const char* p0, const char* p1) {
+  if constexpr (std::is_same<F, bf16x8>::value) {
+    typedef __attribute__((address_space(3))) c3_bf16x4* lp;
+    const c3_bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p0));
+    const c3_bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p1));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  } else {
+    typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+    typedef __attribute__((address_space(3))) h4* lp;
+    const c3_f16x4 lo = __builtin_bit_cast(c3_f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(p0)));
+    const c3_f16x4 hi = __builtin_bit_cast(c3_f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(p1)));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
 }
 
+// NP = 3: bf16 pieces, 6 MFMAs per product.  NP = 2: scaled fp16 (bf3.hpp) with ONE accumulator per tile — the nine tap tiles
+// leave no registers for a second one, so the 2^11 between the main and the cross terms sits in the operands instead:
+//   X  (scale sx, max in [2^13, 2^14)):  xh = fp16(x sx), xl = fp16((x sx - xh) 2^11)
+//   dY (scale sy, max in [2^3, 2^4)):    yH = fp16(y sy 2^11), yl = fp16(y sy 2^11 - yH), yh = fp16(y sy)
+//   acc += xh yH + xh yl + xl yh  =  2^11 sx sy x y (1 + O(2^-22))                       (three fp16 MFMAs, small terms first)
+// dY keeps full precision down to 2^-29 of its maximum (yH and yl are normal fp16 numbers there), X down to 2^-28.
+template <int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void c3wg_kernel(const C3WArgs g) {
   constexpr int S = C3W_S;
+  constexpr int NPA = NP, NPB = 3;  // planes of a slot: X has NP pieces, dY three in both forms
+  using frag = std::conditional_t<NP == 3, bf16x8, f16x8>;
+  const float sx = NP == 2 ? f16_scale_of(*g.x_amax) : 1.f;
+  const float sy = NP == 2 ? f16_scale_of(*g.y_amax) * (1.f / 1024.f) : 1.f;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   mvk_prof_begin(g.prof);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -670,26 +781,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     raw[k] = k < 2 ? load_x(pix, k)
                    : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsD, (unsigned)pix * yrow + ycol[k & 1], 0, 0));
   };
-  const float islope = g.islope;
+  const float islope = g.islope, sxn = sx * g.islope, sy11 = sy * 2048.f;
   f32x4 dysum[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // this thread's 4 channels of dY, summed over its positions
   auto write_vals = [&](char* base, int k, const f32x4& v, float mine = 1.f) {  // base: first slot of the chunk (ring) / buffer (dY)
     float r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3];
-    if (k < 2) {  // X: the activation of the layer that produced it, applied on the way into LDS
-      r0 = r0 > 0.f ? r0 : r0 * islope;
-      r1 = r1 > 0.f ? r1 : r1 * islope;
-      r2 = r2 > 0.f ? r2 : r2 * islope;
-      r3 = r3 > 0.f ? r3 : r3 * islope;
-    } else {  // mine = 0: the tile behind this workgroup's range (staged by the last iteration, summed by its owner)
+    char* d = base + soff[k & 1];
+    if (k >= 2) {  // mine = 0: the tile behind this workgroup's range (staged by the last iteration, summed by its owner)
 #pragma unroll
       for (int e = 0; e < 4; ++e) dysum[k & 1][e] = fmaf(v[e], mine, dysum[k & 1][e]);
     }
-    unsigned a0, a1, a2, b0, b1, b2;
-    bf3_split(r0, r1, a0, a1, a2);
-    bf3_split(r2, r3, b0, b1, b2);
-    char* d = base + soff[k & 1];
-    *reinterpret_cast<u32x2*>(d) = u32x2{a0, b0};
-    *reinterpret_cast<u32x2*>(d + 128) = u32x2{a1, b1};
-    *reinterpret_cast<u32x2*>(d + 256) = u32x2{a2, b2};
+    if constexpr (NP == 3) {
+      if (k < 2) {  // X: the activation of the layer that produced it, applied on the way into LDS
+        r0 = r0 > 0.f ? r0 : r0 * islope;
+        r1 = r1 > 0.f ? r1 : r1 * islope;
+        r2 = r2 > 0.f ? r2 : r2 * islope;
+        r3 = r3 > 0.f ? r3 : r3 * islope;
+      }
+      unsigned a0, a1, a2, b0, b1, b2;
+      bf3_split(r0, r1, a0, a1, a2);
+      bf3_split(r2, r3, b0, b1, b2);
+      *reinterpret_cast<u32x2*>(d) = u32x2{a0, b0};
+      *reinterpret_cast<u32x2*>(d + 128) = u32x2{a1, b1};
+      *reinterpret_cast<u32x2*>(d + 256) = u32x2{a2, b2};
+    } else if (k < 2) {  // X: (xh, xl), the scale on the activation's two slopes
+      r0 *= r0 > 0.f ? sx : sxn;
+      r1 *= r1 > 0.f ? sx : sxn;
+      r2 *= r2 > 0.f ? sx : sxn;
+      r3 *= r3 > 0.f ? sx : sxn;
+      unsigned a0, a1, b0, b1;
+      f16_split(r0, r1, a0, a1);
+      f16_split(r2, r3, b0, b1);
+      *reinterpret_cast<u32x2*>(d) = u32x2{a0, b0};
+      *reinterpret_cast<u32x2*>(d + 128) = u32x2{a1, b1};
+    } else {  // dY: planes (yh, yH, yl)
+      const f16x2 h01 = __builtin_convertvector(f32x2{r0 * sy, r1 * sy}, f16x2), h23 = __builtin_convertvector(f32x2{r2 * sy, r3 * sy}, f16x2);
+      const float q0 = r0 * sy11, q1 = r1 * sy11, q2 = r2 * sy11, q3 = r3 * sy11;
+      const f16x2 H01 = __builtin_convertvector(f32x2{q0, q1}, f16x2), H23 = __builtin_convertvector(f32x2{q2, q3}, f16x2);
+      const f16x2 l01 = __builtin_convertvector(f32x2{q0 - (float)H01[0], q1 - (float)H01[1]}, f16x2);
+      const f16x2 l23 = __builtin_convertvector(f32x2{q2 - (float)H23[0], q3 - (float)H23[1]}, f16x2);
+      *reinterpret_cast<u32x2*>(d) = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+      *reinterpret_cast<u32x2*>(d + 128) = u32x2{__builtin_bit_cast(unsigned, H01), __builtin_bit_cast(unsigned, H23)};
+      *reinterpret_cast<u32x2*>(d + 256) = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+    }
   };
   auto write_unit = [&](char* base, int k, float mine = 1.f) { write_vals(base, k, raw[k], mine); };
   auto chunk_slot = [&](int ch) { return (((ch % NCH) + NCH) % NCH) * 32 * S; };
@@ -760,20 +893,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         ad[dx][t] = (int)r + a_ch;
       }
   };
-  auto read_row = [&](bf16x8 (&A)[3][3], const int (&ad)[3][2]) {
+  auto read_row = [&](frag (&A)[3][NPA], const int (&ad)[3][2]) {
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) A[dx][pc] = c3_tr_pair(ringp + ad[dx][0] + pc * 128, ringp + ad[dx][1] + pc * 128);
+      for (int pc = 0; pc < NPA; ++pc) A[dx][pc] = c3_tr_pair<frag>(ringp + ad[dx][0] + pc * 128, ringp + ad[dx][1] + pc * 128);
   };
-  auto read_b = [&](bf16x8 (&B)[2][3], const char* buf) {
+  auto read_b = [&](frag (&B)[2][NPB], const char* buf) {
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) B[s][pc] = c3_tr_pair(buf + boff[s][0] + pc * 128, buf + boff[s][1] + pc * 128);
+      for (int pc = 0; pc < NPB; ++pc) B[s][pc] = c3_tr_pair<frag>(buf + boff[s][0] + pc * 128, buf + boff[s][1] + pc * 128);
   };
 
-  bf16x8 A_cur[3][3], Bf[2][3];
+  frag A_cur[3][NPA], Bf[2][NPB];
   int ad[3][2];
   if (NT > 0) {
     row_addr(ad, tb, 0, -1);
@@ -791,7 +924,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int step = 0; step < 6; ++step) {  // (k-step, kernel row)
       const int s = step / 3, grp = step % 3;
-      bf16x8 A_nxt[3][3], B_nxt[2][3];
+      frag A_nxt[3][NPA], B_nxt[2][NPB];
       if (step < 5) {
         row_addr(ad, tb, (step + 1) / 3, (step + 1) % 3 - 1);
         read_row(A_nxt, ad);
@@ -812,15 +945,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         write_unit(k < 2 ? xw : nbuf_w, k, t + 1 < NT ? 1.f : 0.f);
         load_unit_at(upix[k], k);
       }
-      constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB_[6] = {2, 1, 0, 1, 0, 0};  // small terms first
+      if constexpr (NP == 3) {
+        constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB_[6] = {2, 1, 0, 1, 0, 0};  // small terms first
 #pragma unroll
-      for (int m = 0; m < 6; ++m)
+        for (int m = 0; m < 6; ++m)
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
-          acc[grp * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_cur[dx][PA[m]], Bf[s][PB_[m]], acc[grp * 3 + dx], 0, 0, 0);
+          for (int dx = 0; dx < 3; ++dx)
+            acc[grp * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_cur[dx][PA[m]], Bf[s][PB_[m]], acc[grp * 3 + dx], 0, 0, 0);
+      } else {
+        constexpr int PA[3] = {1, 0, 0}, PB_[3] = {0, 2, 1};  // xl yh, xh yl, xh yH
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+            acc[grp * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_cur[dx][PA[m]], Bf[s][PB_[m]], acc[grp * 3 + dx], 0, 0, 0);
+      }
       if (MVK_C3W_SCHED > 0) {
 #pragma unroll
-        for (int m = 0; m < 18; ++m) {
+        for (int m = 0; m < 6 * NP; ++m) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x496, MVK_C3W_SCHED > 0 ? MVK_C3W_SCHED : 1, 0);
         }
@@ -828,13 +970,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) A_cur[dx][pc] = A_nxt[dx][pc];
+        for (int pc = 0; pc < NPA; ++pc) A_cur[dx][pc] = A_nxt[dx][pc];
       if (step == 4) __syncthreads();  // the conversions of this tile (steps 1-4) are published; ONE barrier per tile
       if (step == 5) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) Bf[s2][pc] = B_nxt[s2][pc];
+          for (int pc = 0; pc < NPB; ++pc) Bf[s2][pc] = B_nxt[s2][pc];
       }
     }
     tb = tbn;
@@ -843,12 +985,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   // partial gradient of this workgroup: slab[worker][(tap * Cin + ci)][co]
   float* const slab = g.slab + (long long)worker * 9 * g.Cin * g.Cout;
+  const float out_a = NP == 2 ? f16_inv_scale(sx) : 1.f, out_b = NP == 2 ? f16_inv_scale(sy) * (1.f / 2048.f) * g.dy_scale : g.dy_scale;
 #pragma unroll
   for (int j = 0; j < 9; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ci = ci0 + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-      slab[((long long)j * g.Cin + ci) * g.Cout + co0 + c * 32 + col] = acc[j][r] * g.dy_scale;
+      slab[((long long)j * g.Cin + ci) * g.Cout + co0 + c * 32 + col] = NP == 2 ? acc[j][r] * out_a * out_b : acc[j][r] * out_b;
     }
   if (g.dbpart && ci0 == 0) {  // bias gradient: column sums of dY, added in a fixed order (thread groups of equal channels)
     float* const red = reinterpret_cast<float*>(lds);  // the ring is dead behind the last barrier of the loop
@@ -878,7 +1021,7 @@ bool c3rs_wgrad_ok(int n, int H, int W, int Cin, int Cout) {
 
 // slab: [*nz][9 Cin][Cout] partial gradients (needs (256 / types) * 9 Cin Cout floats); 1: not covered
 int c3rs_wgrad(const float* X, const float* dY, float* slab, long long slab_floats, float* dbpart, int x_act, float dy_scale,
-               int n, int H, int W, int Cin, int Cout, int* nz, hipStream_t s) {
+               int n, int H, int W, int Cin, int Cout, int* nz, const float* x_amax, const float* y_amax, hipStream_t s) {
   if (x_act == MVK_ACT_SIGMOID) return 1;
   if (!c3rs_wgrad_ok(n, H, W, Cin, Cout) || !mvk_aligned16(X) || !mvk_aligned16(dY)) return 1;
   const int types = (Cin / 64) * (Cout / 64);
@@ -887,17 +1030,17 @@ int c3rs_wgrad(const float* X, const float* dY, float* slab, long long slab_floa
   const int ring = c3_ring(W), lds = c3w_lds_bytes(ring);
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(c3wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      return MVK_ELAUNCH;
+    for (const void* f : {reinterpret_cast<const void*>(c3wg_kernel<3>), reinterpret_cast<const void*>(c3wg_kernel<2>)})
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MVK_ELAUNCH;
     attr_done = true;
   }
   const long long total = (long long)n * (H + 1) * (W + 1);
   C3WArgs a{X, dY, slab, dbpart, c3_slope(x_act), dy_scale, n, H, W, Cin, Cout, ring, (W + 2 + 31) / 32, (int)((total + 31) / 32),
-            (unsigned)((long long)n * H * W * Cin * 4), (unsigned)((long long)n * H * W * Cout * 4), nullptr};
+            (unsigned)((long long)n * H * W * Cin * 4), (unsigned)((long long)n * H * W * Cout * 4), nullptr, x_amax, y_amax};
   a.prof = prof_next(8, 2.0 * n * H * W * 9.0 * Cin * Cout);
   *nz = workers;
-  hipLaunchKernelGGL(c3wg_kernel, dim3(grid), dim3(256), lds, s, a);
+  if (x_amax && y_amax) hipLaunchKernelGGL(c3wg_kernel<2>, dim3(grid), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(c3wg_kernel<3>, dim3(grid), dim3(256), lds, s, a);
   MVK_CHECK_LAUNCH();
   prof_fold(a.prof, s);
   return MVK_OK;
@@ -973,5 +1116,11 @@ int c3rs_conv(const float* X, const float* Wp, const float* bias, float* Y, int 
 #endif
   return 1;
 }
+
+#ifdef MVK_C3PROF
+extern "C" int mvk_c3_debug_buffer(unsigned long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_c3_dbg), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 }  // namespace mvk

@@ -728,7 +728,7 @@ int c3rs_conv(const float* X, const float* Wp, const float* bias, float* Y, int 
 bool c3rs_shape_ok(int n, int H, int W, int Cin, int Cout, int np);
 bool c3rs_wgrad_ok(int n, int H, int W, int Cin, int Cout);
 int c3rs_wgrad(const float* X, const float* dY, float* slab, long long slab_floats, float* dbpart, int x_act, float dy_scale,
-               int n, int H, int W, int Cin, int Cout, int* nz, hipStream_t s);
+               int n, int H, int W, int Cin, int Cout, int* nz, const float* x_amax, const float* y_amax, hipStream_t s);
 int convref_reduce(const float* slab, int nz, int Cu, int Cv, int taps, float* dWref, hipStream_t s, bool deferred);
 static bool c3rs_wgrad_covers(int n, int H, int W, int Cin, int Cout);
 static bool c3rs_covers(int n, int H, int W, int Cin, int Cout, int np = 3) {
@@ -1150,7 +1150,19 @@ int mvk_conv3x3_s(const float* X, const float* Wp, const float* bias, float* Y, 
 }
 
 static int conv3x3_wgrad_any(const float* X, const float* dY, float* dWref, float* db, int x_act, float dy_scale, int n, int H,
-                             int W, int Cin, int Cout, float* ws, int64_t ws_floats, void* stream);
+                             int W, int Cin, int Cout, float* ws, int64_t ws_floats, void* stream,
+                             const float* x_amax = nullptr, const float* dy_amax = nullptr);
+
+// scaled-fp16 form of mvk_conv3x3_wgrad_f (3 MFMAs per product; x_amax / dy_amax as in mvk_conv3x3_s)
+int mvk_conv3x3_wgrad_scaled_ok(int n, int H, int W, int Cin, int Cout) {
+  return n > 0 && c3rs_wgrad_covers(n, H, W, Cin, Cout) ? 1 : 0;
+}
+int mvk_conv3x3_wgrad_s(const float* X, const float* dY, float* dWref, float* db, int n, int H, int W, int Cin, int Cout,
+                        int x_act, float dy_scale, const float* x_amax, const float* dy_amax, float* ws, int64_t ws_floats,
+                        void* stream) {
+  if (!x_amax || !dy_amax || !mvk_conv3x3_wgrad_scaled_ok(n, H, W, Cin, Cout)) return MVK_EINVAL;
+  return conv3x3_wgrad_any(X, dY, dWref, db, x_act, dy_scale, n, H, W, Cin, Cout, ws, ws_floats, stream, x_amax, dy_amax);
+}
 
 // dWref[Cout][Cin][3][3] += dy_scale * sum_pos x_act(X)(gathered) dY;  db[Cout] += dy_scale * sum_pos dY (db may be null)
 int mvk_conv3x3_wgrad_f(const float* X, const float* dY, float* dWref, float* db, int n, int H, int W, int Cin, int Cout,
@@ -1166,7 +1178,8 @@ int mvk_conv3x3_wgrad(const float* X, const float* dY, float* dWref, int n, int 
 }
 
 static int conv3x3_wgrad_any(const float* X, const float* dY, float* dWref, float* db, int x_act, float dy_scale, int n, int H,
-                             int W, int Cin, int Cout, float* ws, int64_t ws_floats, void* stream) {
+                             int W, int Cin, int Cout, float* ws, int64_t ws_floats, void* stream, const float* x_amax,
+                             const float* dy_amax) {
   if (!X || !dY || !dWref || n < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return MVK_EINVAL;
   if (n > 0 && (Cin <= 4 || Cout <= 4)) {  // an image on one side: per-workgroup slabs in dWref order + ordered finish
     const long long total = 9ll * Cin * Cout;
@@ -1189,7 +1202,8 @@ static int conv3x3_wgrad_any(const float* X, const float* dY, float* dWref, floa
       float* wslab = dslab ? dslab : ws;
       float* bslab = !db ? nullptr : (dbslab ? dbslab : ws + (dslab ? 0 : slab_floats));
       int nz = 0;
-      const int rc = c3rs_wgrad(X, dY, wslab, slab_floats, bslab, x_act, dy_scale, n, H, W, Cin, Cout, &nz, mvk_stream(stream));
+      const int rc = c3rs_wgrad(X, dY, wslab, slab_floats, bslab, x_act, dy_scale, n, H, W, Cin, Cout, &nz, x_amax, dy_amax,
+                                mvk_stream(stream));
       if (rc != MVK_OK) return rc == 1 ? MVK_EINVAL : rc;  // covered shapes never decline
       if (db) {
         const int r = dbslab ? defer_push_plain(db, dbslab, Cout, nz, Cout, mvk_stream(stream))
@@ -1200,7 +1214,7 @@ static int conv3x3_wgrad_any(const float* X, const float* dY, float* dWref, floa
     }
     if (dslab || dbslab) return MVK_EINVAL;
   }
-  if (db || x_act != MVK_ACT_NONE || dy_scale != 1.f) return MVK_EINVAL;  // fused forms: register-stationary kernel only
+  if (db || x_act != MVK_ACT_NONE || dy_scale != 1.f || x_amax || dy_amax) return MVK_EINVAL;  // fused forms: register-stationary kernel only
   GemmDesc d{};
   d.a = AOperand{};
   d.a.p = X;

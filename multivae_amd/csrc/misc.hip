@@ -932,7 +932,18 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
   typedef float v4 __attribute__((ext_vector_type(4)));
   const long long n4 = n / 4, stride = (long long)gridDim.x * 256;
   float m = 0.f;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+  // a workgroup walks 16-KB tiles: four independent, neighbouring 16-byte loads in flight per thread
+  const long long tiles = n4 / 1024;
+  for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const v4* p = reinterpret_cast<const v4*>(x) + t * 1024 + threadIdx.x;
+    const v4 a = p[0], b = p[256], c = p[512], d = p[768];
+    const float ma = fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3])));
+    const float mb = fmaxf(fmaxf(fabsf(b[0]), fabsf(b[1])), fmaxf(fabsf(b[2]), fabsf(b[3])));
+    const float mc = fmaxf(fmaxf(fabsf(c[0]), fabsf(c[1])), fmaxf(fabsf(c[2]), fabsf(c[3])));
+    const float md = fmaxf(fmaxf(fabsf(d[0]), fabsf(d[1])), fmaxf(fabsf(d[2]), fabsf(d[3])));
+    m = fmaxf(m, fmaxf(fmaxf(ma, mb), fmaxf(mc, md)));
+  }
+  for (long long i = tiles * 1024 + (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     const v4 v = reinterpret_cast<const v4*>(x)[i];
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
   }
@@ -944,8 +955,8 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
 extern "C" int mvk_amax(const float* x, int64_t n, float* out, void* stream) {
   if (!x || !out || n < 0 || !mvk_aligned16(x)) return MVK_EINVAL;
   if (n == 0) return MVK_OK;
-  long long blocks = (n / 4 + 256 * 8 - 1) / (256 * 8);
-  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  long long blocks = (n / 4 + 1023) / 1024;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
   hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, mvk_stream(stream), x, (long long)n, out);
   MVK_CHECK_LAUNCH();
   return MVK_OK;

@@ -654,6 +654,21 @@ def conv3x3_s(X, wpack, bias, n, H, W, Cin, Cout, x_amax, w_amax, y_amax=None, a
     return Y if out_bias is None else (Y, rb)
 
 
+def conv3x3_wgrad_scaled_ok(n, H, W, Cin, Cout):
+    """True when mvk_conv3x3_wgrad_s takes this problem."""
+    return C3_F16 and bool(_lib.load().mvk_conv3x3_wgrad_scaled_ok(n, H, W, Cin, Cout))
+
+
+def conv3x3_wgrad_s(X, dY, wparam, bparam, n, H, W, Cin, Cout, x_amax, dy_amax, x_act=NONE, dy_scale=1.0):
+    """conv3x3_wgrad_f on scaled fp16 pairs; x_amax / dy_amax: device scalars bounding max |X| / max |dY|."""
+    dw, rw = _grad_target(wparam)
+    tb, rb = _bias_target(bparam)
+    ws = _ws(X)
+    call("mvk_conv3x3_wgrad_s", ptr(X), ptr(dY), ptr(dw), ptr(tb), n, H, W, Cin, Cout, x_act, float(dy_scale), ptr(x_amax),
+         ptr(dy_amax), ptr(ws), ws.numel(), stream_ptr())
+    return rw, rb
+
+
 def conv3x3_wgrad_f(X, dY, wparam, bparam, n, H, W, Cin, Cout, x_act=NONE, dy_scale=1.0):
     """dW += dy_scale * sum x_act(X) (x) dY and (bparam given) db += dy_scale * sum dY, one launch.  -> (dW ref, db ref)"""
     dw, rw = _grad_target(wparam)
@@ -1170,6 +1185,22 @@ def _rs_conv(pool, X, xam, wpack, bias, n, H, W, Cin, Cout, **kw):
     return conv3x3(X, wpack, bias, n, H, W, Cin, Cout, **kw), None
 
 
+def _rs_wgrad(pool, X, xam, dY, dyam, wparam, bparam, n, H, W, Cin, Cout, x_act=NONE, dy_scale=1.0, fused=False):
+    """Weight (and bias) gradient of one 3x3 convolution of a ResNet stack -> (dW ref, db ref or None).  With a pool and a
+    covered shape: mvk_conv3x3_wgrad_s (xam / dyam = slots bounding max |X| / max |dY|, computed here when unknown); else the
+    bf16-piece launch (fused: bias gradient, x_act and dy_scale in it) or the plain one + a column-sum pass."""
+    if pool is not None and conv3x3_wgrad_scaled_ok(n, H, W, Cin, Cout):
+        xam = xam if xam is not None else amax_of(X, pool.take())
+        dyam = dyam if dyam is not None else amax_of(dY, pool.take())
+        return conv3x3_wgrad_s(X, dY, wparam, bparam, n, H, W, Cin, Cout, xam, dyam, x_act=x_act, dy_scale=dy_scale)
+    if fused:
+        return conv3x3_wgrad_f(X, dY, wparam, bparam, n, H, W, Cin, Cout, x_act=x_act, dy_scale=dy_scale)
+    if x_act != NONE or dy_scale != 1.0:
+        raise _lib.MvkError("_rs_wgrad: x_act / dy_scale need the fused launch")
+    rw = conv3x3_wgrad(X, dY, wparam, n, H, W, Cin, Cout)
+    return rw, (colsum(dY.view(-1, Cout), bparam) if bparam is not None else None)
+
+
 class ResnetStackFn(Function):
     """x [n,H,W,C] NHWC -> a static program of layers -> y NHWC, one autograd node.
 
@@ -1209,7 +1240,7 @@ class ResnetStackFn(Function):
                 _, iw, ib, act = op
                 Cout = params[iw].shape[0]
                 y, yam = _rs_conv(pool, h, ham, packs[iw][0], params[ib] if ib is not None else None, n, H, W, C, Cout, act=act)
-                tape.append((h, y, (H, W, C, Cout)))
+                tape.append((h, y, (H, W, C, Cout), ham))
                 h, C, ham = y, Cout, yam
             elif op[0] == "block":
                 _, order_, iw1, ib1, iw2, ib2, isc = op
@@ -1238,7 +1269,7 @@ class ResnetStackFn(Function):
                     out, oam = _rs_conv(pool, a1, a1am, packs[iw2][0], b2, n, H, W, Chid, Cout, act=NONE, res=xs, res_alpha=0.1)
                 else:
                     out = axpby(xs, 1.0, y2, 0.1)
-                tape.append((h, a0, a1, y2, (H, W, C, Chid, Cout), fused))
+                tape.append((h, a0, a1, y2, (H, W, C, Chid, Cout), fused, ham, a1am))
                 h, C, ham = out, Cout, oam
             elif op[0] == "pool":
                 y = avgpool(h, n, H, W, C)  # an average, a copy, a (leaky) ReLU: max |h| still bounds the result
@@ -1274,25 +1305,29 @@ class ResnetStackFn(Function):
             first = li == 0
             if op[0] == "conv":
                 _, iw, ib, act = op
-                xin, y, (H, W, C, Cout) = rec
+                xin, y, (H, W, C, Cout), xam = rec
                 dpre = g
                 if act != NONE:
                     dpre = g.clone() if g is dout else g
                     call("mvk_act_bwd", ptr(dpre), ptr(y), dpre.numel(), act, stream_ptr())
-                grads[iw] = conv3x3_wgrad(xin, dpre, params[iw], n, H, W, C, Cout)
+                gam = gam if act in (NONE, LEAKY, RELU) else None  # |dpre| <= |g|: these derivatives are at most 1
+                grads[iw], gb = _rs_wgrad(pool, xin, xam, dpre, gam, params[iw], params[ib] if ib is not None else None, n, H, W,
+                                          C, Cout)
                 if ib is not None:
-                    grads[ib] = colsum(dpre.view(-1, Cout), params[ib])
-                if not first or need_dx:  # |dpre| <= |g|: the activation derivatives are at most 1
-                    g, gam = _rs_conv(pool, dpre, gam if act in (NONE, LEAKY, RELU) else None, packs[iw][1], None, n, H, W, Cout, C)
+                    grads[ib] = gb
+                if not first or need_dx:
+                    g, gam = _rs_conv(pool, dpre, gam, packs[iw][1], None, n, H, W, Cout, C)
             elif op[0] == "block":
                 _, order_, iw1, ib1, iw2, ib2, isc = op
-                xin, a0, a1, y2, (H, W, C, Chid, Cout), fused = rec
+                xin, a0, a1, y2, (H, W, C, Chid, Cout), fused, xam, a1am = rec
                 gout = g
+                if gam is None and pool is not None:
+                    gam = amax_of(gout, pool.take())  # three launches below take it
                 if fused and order_ == "pre":
                     # d2 = 0.1 * gout is never formed: the 0.1 rides on the weight / bias gradient and on the backward-data
                     # sum; a0 = lrelu(x) is re-applied while the weight-gradient kernel stages x
-                    grads[iw2], gb2 = conv3x3_wgrad_f(a1, gout, params[iw2], params[ib2] if ib2 is not None else None, n, H, W,
-                                                      Chid, Cout, dy_scale=0.1)
+                    grads[iw2], gb2 = _rs_wgrad(pool, a1, a1am, gout, gam, params[iw2], params[ib2] if ib2 is not None else None,
+                                                n, H, W, Chid, Cout, dy_scale=0.1, fused=True)
                     if ib2 is not None:
                         grads[ib2] = gb2
                     if ib1 is not None:
@@ -1301,28 +1336,23 @@ class ResnetStackFn(Function):
                     else:
                         d1, d1am = _rs_conv(pool, gout, gam, packs[iw2][1], None, n, H, W, Cout, Chid, y_act_src=a1,
                                             y_src_act=LEAKY, pre_scale=0.1)
-                    grads[iw1], _ = conv3x3_wgrad_f(xin, d1, params[iw1], None, n, H, W, C, Chid, x_act=LEAKY)
+                    grads[iw1], _ = _rs_wgrad(pool, xin, xam, d1, d1am, params[iw1], None, n, H, W, C, Chid, x_act=LEAKY, fused=True)
                     a0 = xin  # sign(lrelu(x)) == sign(x): the mask source of dx below
                 else:
                     d2 = axpby(gout, 0.1, None, 0.0)  # gradient w.r.t. y2 (max |gout| bounds it, LeakyReLU' included)
                     if order_ == "post":
                         call("mvk_act_bwd", ptr(d2), ptr(y2), d2.numel(), LEAKY, stream_ptr())
-                    if fused:  # bias gradient with the weight gradient
-                        grads[iw2], gb2 = conv3x3_wgrad_f(a1, d2, params[iw2], params[ib2] if ib2 is not None else None, n, H,
-                                                          W, Chid, Cout)
-                        if ib2 is not None:
-                            grads[ib2] = gb2
-                    else:
-                        grads[iw2] = conv3x3_wgrad(a1, d2, params[iw2], n, H, W, Chid, Cout)
-                        if ib2 is not None:
-                            grads[ib2] = colsum(d2.view(-1, Cout), params[ib2])
+                    grads[iw2], gb2 = _rs_wgrad(pool, a1, a1am, d2, gam, params[iw2], params[ib2] if ib2 is not None else None, n, H,
+                                                W, Chid, Cout, fused=fused)  # fused: bias gradient with the weight gradient
+                    if ib2 is not None:
+                        grads[ib2] = gb2
                     # backward data of conv2 with lrelu'(a1) fused; its channel sums are conv1's bias gradient
                     if ib1 is not None:
                         (d1, grads[ib1]), d1am = _rs_conv(pool, d2, gam, packs[iw2][1], None, n, H, W, Cout, Chid, y_act_src=a1,
                                                           y_src_act=LEAKY, out_bias=params[ib1])
                     else:
                         d1, d1am = _rs_conv(pool, d2, gam, packs[iw2][1], None, n, H, W, Cout, Chid, y_act_src=a1, y_src_act=LEAKY)
-                    grads[iw1] = conv3x3_wgrad(a0, d1, params[iw1], n, H, W, C, Chid)
+                    grads[iw1], _ = _rs_wgrad(pool, a0, xam, d1, d1am, params[iw1], None, n, H, W, C, Chid)
                 if isc is not None:
                     grads[isc], _ = linear_bwd_weight(gout.view(-1, Cout), xin.view(-1, C), params[isc].view(Cout, C), None)
                     if grads[isc] is not None:

@@ -873,6 +873,24 @@ def test_conv3x3_scaled_fp16(K, n, H, W, Cin, Cout, spread):
         loose = (xam * 1000.0).contiguous()
         Y = K.conv3x3_s(X, wf, None, n, H, W, Cin, Cout, loose, wf.mvk_amax)
         close(Y, nhwc(plain.float()), what="loose bound", rtol=3e-6)
+        # weight gradient (c3wg_kernel<2>: one accumulator per tap tile, dY carries the 2^11 in a third piece) with the
+        # activation of X applied while staging, the 0.1 of the residual branch and the bias gradient in the launch
+        if K.conv3x3_wgrad_scaled_ok(n, H, W, Cin, Cout):
+            dy = src * torch.exp(spread * torch.randn(n, 1, 1, 1, generator=g(62)))
+            w64 = w.double().requires_grad_(True)
+            F.conv2d(ax, w64, None, 1, 1).backward(0.1 * dy.double())
+            wparam = w.to(d).clone().requires_grad_(True)
+            wparam.grad = torch.zeros_like(wparam)
+            bp = torch.zeros(Cout, device=d).requires_grad_(True)
+            bp.grad = torch.zeros(Cout, device=d)
+            dY = nhwc(dy)
+            dyam = K.amax_of(dY, pool.take())
+            K.conv3x3_wgrad_s(X, dY, wparam, bp, n, H, W, Cin, Cout, xam, dyam, x_act=K.LEAKY, dy_scale=0.1)
+            close(wparam.grad, w64.grad.float(), what="weight gradient", rtol=3e-6)
+            close(bp.grad, 0.1 * dy.double().sum((0, 2, 3)).float(), what="bias gradient", rtol=1e-5)
+            K.conv3x3_wgrad_s(X, dY, wparam, None, n, H, W, Cin, Cout, (xam * 64.0).contiguous(), (dyam * 3.0).contiguous(),
+                              x_act=K.LEAKY, dy_scale=0.1)
+            close(wparam.grad, 2 * w64.grad.float(), what="weight gradient accumulates (loose bounds)", rtol=3e-6)
     finally:
         _debug_flags(0)
 
