@@ -57,12 +57,22 @@ __device__ __forceinline__ void f16_split(float x, float y, unsigned& hi, unsign
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{rx, ry}, f16x2));
 }
 
-// wave-wide maximum of a non-negative value, then one atomic per wave: the bit patterns of non-negative floats order like
-// unsigned integers (+inf above every finite value), *dst must hold 0 before the launch
-__device__ __forceinline__ void amax_publish(float v, float* dst) {
+// workgroup-wide maximum of a non-negative value (wave shuffles, then `red[waves]` in LDS), then ONE atomic per workgroup: the
+// bit patterns of non-negative floats order like unsigned integers (+inf above every finite value); *dst must hold 0 (or a
+// bound to keep) before the launch.  Atomics on one address serialise at ~10 ns each: one per wave of a 2048-workgroup launch
+// was 80 us.  Every thread of the workgroup must call it (it synchronises).
+__device__ __forceinline__ void amax_publish(float v, float* dst, float* red) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(v));
+  const int wave = threadIdx.x >> 6, waves = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = red[0];
+    for (int i = 1; i < waves; ++i) m = fmaxf(m, red[i]);
+    atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(m));
+  }
 }
 
 }  // namespace mvk

@@ -583,7 +583,7 @@ __device__ __forceinline__ void c3rs_body(const C3Args& g) {
     o[1] = c3_bar;
   }
 #endif
-  if (g.y_amax) amax_publish(amax_l, g.y_amax);
+  if (g.y_amax) amax_publish(amax_l, g.y_amax, csred);  // uniform branch; csred is free until the column sums below
   if (WITH_CSUM && g.colsum_part) {  // fixed-order sum over the lanes / waves that share a column
     csum += __shfl_xor(csum, 32, 64);
     __syncthreads();

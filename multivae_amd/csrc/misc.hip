@@ -31,6 +31,7 @@ struct PackJobs {
   mvk_pack_desc j[MVK_PACK_MAX];
 };
 __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs jobs) {
+  __shared__ float amax_red[4];
   const mvk_pack_desc& d = jobs.j[blockIdx.y];
   if (d.kind == 2) {  // 3x3: Wref[cv][cu][3][3] -> Wdown[(tap*Cu + cu)][cv] (forward), Wup[((8-tap)*Cv + cv)][cu] (bwd data)
     const int total9 = d.Cv * d.Cu * 9;
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs jobs) {
       if (d.Wdown) d.Wdown[(long long)(tap * d.Cu + cu) * d.ld_down + d.col_off + cv] = v;
       if (d.Wup) d.Wup[(long long)((8 - tap) * d.Cv + cv) * d.Cu + cu] = v;
     }
-    if (d.amax) mvk::amax_publish(m, d.amax);  // the weight's scale for the scaled-fp16 kernels (bf3.hpp)
+    if (d.amax) mvk::amax_publish(m, d.amax, amax_red);  // the weight's scale for the scaled-fp16 kernels (bf3.hpp)
     return;
   }
   const int total = d.Cv * d.Cu * 16;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs jobs) {
       }
     }
   }
-  if (d.amax) mvk::amax_publish(wmax, d.amax);
+  if (d.amax) mvk::amax_publish(wmax, d.amax, amax_red);
 }
 
 // Wref[ci][co][tap] -> Wp[ci][tap*Cout + co]
@@ -948,7 +949,8 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
   }
   if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) m = fmaxf(m, fabsf(x[4 * n4 + threadIdx.x]));
-  mvk::amax_publish(m, out);
+  __shared__ float red[4];
+  mvk::amax_publish(m, out, red);
 }
 }  // namespace
 
@@ -956,7 +958,7 @@ extern "C" int mvk_amax(const float* x, int64_t n, float* out, void* stream) {
   if (!x || !out || n < 0 || !mvk_aligned16(x)) return MVK_EINVAL;
   if (n == 0) return MVK_OK;
   long long blocks = (n / 4 + 1023) / 1024;
-  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
   hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, mvk_stream(stream), x, (long long)n, out);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
