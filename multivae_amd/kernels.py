@@ -1247,6 +1247,8 @@ class ResnetStackFn(Function):
                 Chid, Cout = params[iw1].shape[0], params[iw2].shape[0]
                 b1 = params[ib1] if ib1 is not None else None
                 b2 = params[ib2] if ib2 is not None else None
+                if pool is not None and ham is None and conv3x3_scaled_ok(n, H, W, C, Chid):
+                    ham = amax_of(h, pool.take())  # once: conv1 now, the weight gradient of conv1 in the backward pass
                 # fused forms (register-stationary kernels): the leading LeakyReLU of a pre-activation block is applied while
                 # conv1 stages its input (a0 is never written) and the backward pass folds the 0.1 and the bias gradients
                 fused = (conv3x3_fused_ok(n, H, W, C, Chid) and conv3x3_fused_ok(n, H, W, Chid, Cout)
