@@ -27,12 +27,13 @@ if which == "prof":  # a few launches per kernel NAME (one shape each) for the c
         wparam = w.clone().requires_grad_(True)
         wparam.grad = torch.zeros_like(wparam)
         pool = K.AmaxPool(x, 16)
-        xam = K.amax_of(x, pool.take())
+        xam, sam = K.amax_of(x, pool.take()), K.amax_of(src, pool.take())
         for _ in range(5):
             K.conv3x3(x, wf, b, n_, H_, H_, Ci_, Co_, act=K.LEAKY, y_act_src=src, y_src_act=K.LEAKY)
             K.conv3x3_s(x, wf, b, n_, H_, H_, Ci_, Co_, xam, wf.mvk_amax, pool.take(), act=K.LEAKY, y_act_src=src, y_src_act=K.LEAKY)
             if wg_:
                 K.conv3x3_wgrad(x, src, wparam, n_, H_, H_, Ci_, Co_)
+                K.conv3x3_wgrad_s(x, src, wparam, None, n_, H_, H_, Ci_, Co_, xam, sam)
         torch.cuda.synchronize()
     sys.exit(0)
 if which in ("f16", "f16cfg4", "f16one"):  # bf16-piece kernels vs the scaled-fp16 form (mvk_conv3x3_s): time, error against float64

@@ -27,6 +27,12 @@ bash tools/imgconv_pmc.sh $OUT/pmc_conv new > $OUT/pmc_conv.txt 2>&1
 bash tools/conv3_pmc.sh $OUT/pmc_conv3 > $OUT/pmc_conv3.txt 2>&1
 python tools/conv3_probe.py cfg5 > $OUT/conv3_probe_cfg5.txt 2>&1
 python tools/conv3_probe.py cfg4 > $OUT/conv3_probe_cfg4.txt 2>&1
+python tools/conv3_probe.py f16 > $OUT/conv3_probe_f16.txt 2>&1
+python tools/conv3_probe.py f16cfg4 > $OUT/conv3_probe_f16cfg4.txt 2>&1
+# 4c. the ResNet configurations with the 3x3 kernels on bf16 pieces (A/B of the scaled-fp16 form)
+for c in cfg5 cfg4; do
+  MVK_TUNE=1 MVK_C3_F16=0 timeout 900 python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep "^{" | tail -1 > $OUT/bench_${c}_bf16x3.json
+done
 # 5. HBM traffic counters of the headline step (separate passes)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace -d $OUT/pmc_$c -o p -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline > $OUT/pmc_$c.log 2>&1

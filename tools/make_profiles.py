@@ -30,7 +30,7 @@ line = json_line(f"{SRC}/bench_under_rocprof.log")
 open(f"{DST}/{TAG}_bench_under_rocprof.json", "w").write(json.dumps(line, indent=1) + "\n")
 # 2. bench lines of every configuration
 with open(f"{DST}/{TAG}_bench_lines.jsonl", "w") as f:
-    for c in ("cfg3", "cfg3k1", "cfg2", "cfg2_laplace_dreg", "cfg5", "cfg4", "cfg4_b64_eager", "cfg4_b64", "force_dist"):
+    for c in ("cfg3", "cfg3k1", "cfg2", "cfg2_laplace_dreg", "cfg5", "cfg5_bf16x3", "cfg4", "cfg4_bf16x3", "cfg4_b64_eager", "cfg4_b64", "force_dist"):
         p = f"{SRC}/bench_{c}.json"
         d = json_line(p) if os.path.exists(p) else None
         if d:
@@ -99,12 +99,15 @@ with open(f"{DST}/{TAG}_pmc_mfma.md", "w") as f:
             "weights and the two-tile-latency loop): 100 / 135 / 109 / 116 / 141 / 128 us, matrix pipe 46-70 % busy.\n")
 
 # 4b. the register-stationary 3x3 kernels (tools/conv3_pmc.sh: one shape per kernel name)
-C3_GFLOP = {"mvk::c3rs_kernel<64, 64, true, false>": (38.65, "64 -> 64 @64x64, n = 128"),
-            "mvk::c3rs_kernel<64, 128, true, false>": (19.33, "64 -> 128 @32x32, n = 128"),
-            "mvk::c3rs_kernel<128, 128, true, false>": (9.66, "128 -> 128 @16x16, n = 128"),
-            "mvk::c3rs_kernel<128, 256, true, false>": (19.33, "128 -> 256 @16x16, n = 128"),
-            "mvk::c3rs_kernel<128, 64, true, false>": (46.24, "128 -> 64 @14x14, n = 1600"),
-            "mvk::c3wg_kernel": (38.65, "weight gradient 64 x 64 @64x64, n = 128")}
+C3_SHAPES = {"64, 64": (38.65, "64 -> 64 @64x64, n = 128"), "64, 128": (19.33, "64 -> 128 @32x32, n = 128"),
+             "128, 128": (9.66, "128 -> 128 @16x16, n = 128"), "128, 256": (19.33, "128 -> 256 @16x16, n = 128"),
+             "128, 64": (46.24, "128 -> 64 @14x14, n = 1600")}
+C3_GFLOP = {}
+for cc, (gf_, what_) in C3_SHAPES.items():  # NP = 3: bf16 pieces (6 MFMAs per product), NP = 2: scaled fp16 pairs (3)
+    C3_GFLOP[f"mvk::c3rs_kernel<{cc}, true, false, 3>"] = (gf_, what_ + ", bf16x3")
+    C3_GFLOP[f"mvk::c3rs_kernel<{cc}, true, false, 2>"] = (gf_, what_ + ", fp16x2")
+C3_GFLOP["mvk::c3wg_kernel<3>"] = (38.65, "weight gradient 64 x 64 @64x64, n = 128, bf16x3")
+C3_GFLOP["mvk::c3wg_kernel<2>"] = (38.65, "weight gradient 64 x 64 @64x64, n = 128, fp16x2")
 p3 = f"{SRC}/pmc_conv3.txt"
 if os.path.exists(p3):
     c3 = parse(p3)
@@ -126,6 +129,13 @@ if os.path.exists(p3):
                     f"{100 * v['SQ_WAIT_INST_ANY'] / v['SQ_WAVE_CYCLES']:.0f} % | {100 * v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES']:.0f} % | "
                     f"{v['SQ_INSTS_VALU'] / v['SQ_INSTS_MFMA']:.1f} | "
                     f"{100 * v.get('SQ_LDS_BANK_CONFLICT', 0) / max(v.get('SQ_LDS_IDX_ACTIVE', 1), 1e-9):.0f} % |\n")
+        for c, title in (("f16", "cfg5 shapes, n = 128"), ("f16cfg4", "cfg4 shapes, n = 1600")):
+            pp = f"{SRC}/conv3_probe_{c}.txt"
+            if os.path.exists(pp):
+                f.write(f"\nbf16-piece kernels vs the scaled-fp16 form, `python tools/conv3_probe.py {c}` ({title}; HIP events around 10 launches\n"
+                        "incl. the Python call — launches under ~60 us are bound by the host here, the kernel-trace numbers above are the\n"
+                        "device times; err = max |y - float64| / max |float64| on two images):\n\n")
+                f.write("".join(ln for ln in open(pp) if ln.startswith("|") or ln.startswith("    weight")))
         for c in ("cfg5", "cfg4"):
             pp = f"{SRC}/conv3_probe_{c}.txt"
             if os.path.exists(pp):
