@@ -77,13 +77,14 @@ if which in ("f16", "f16cfg4", "f16one"):  # bf16-piece kernels vs the scaled-fp
         t2, e2 = t_us(f2), err(f2())
         slot_ = torch.zeros(1, device=d)
         ta = t_us(lambda: K.amax_of(x, slot_), reps=50)
+        wline = ""
         wparam = w.clone().requires_grad_(True)
         wparam.grad = torch.zeros_like(wparam)
         dyam = K.amax_of(src, pool.take())
         if K.conv3x3_fused_ok(n, H, H, Cin, Cout):
             w3 = t_us(lambda: K.conv3x3_wgrad_f(x, src, wparam, bparam, n, H, H, Cin, Cout, x_act=K.LEAKY, dy_scale=0.1))
             w2 = t_us(lambda: K.conv3x3_wgrad_s(x, src, wparam, bparam, n, H, H, Cin, Cout, xam, dyam, x_act=K.LEAKY, dy_scale=0.1))
-            print(f"    weight gradient (incl. ordered finish): bf16x3 {w3:.0f} us, fp16x2 {w2:.0f} us")
+            wline = f"    weight gradient of the row above (incl. ordered finish): bf16x3 {w3:.0f} us, fp16x2 {w2:.0f} us"
         if which == "f16one":  # plain forward form (no mask loads) and a cache-resident batch: is the loop waiting for memory?
             p3 = t_us(lambda: K.conv3x3_f(x, wf, None, n, H, H, Cin, Cout, pre_scale=0.5))
             p2 = t_us(lambda: K.conv3x3_s(x, wf, None, n, H, H, Cin, Cout, xam, wf.mvk_amax, pool.take()))
@@ -96,6 +97,8 @@ if which in ("f16", "f16cfg4", "f16one"):  # bf16-piece kernels vs the scaled-fp
             lib.mvk_debug_set_flags(0)
             print(f"    plain forward: bf16x3 {p3:.0f} us, fp16x2 {p2:.0f} us;  n = {nn} masked: bf16x3 {q3:.0f} us, fp16x2 {q2:.0f} us")
         print(f"| {H} | {Cin} | {Cout} | {gf:.1f} | {t3:.0f} | {gf / t3 * 1e3:.0f} | {e3:.1e} | {t2:.0f} | {gf / t2 * 1e3:.0f} | {e2:.1e} | {ta:.0f} |")
+        if wline:
+            print(wline)
     sys.exit(0)
 if which == "one":  # the 64 -> 64 channel layers only (variant builds of tools/conv3_variants.sh)
     n = 128
