@@ -385,6 +385,26 @@ int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, floa
 int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U, int n, int h, int w, int Cu,
                    int Cv, int act, int u_nchw, const float* u_act_src, int u_act, float* colsum_acc, float* ws,
                    int64_t ws_floats, int fmt, const void* wfrag, void* stream);
+/* The two launches above on the register-stationary kernels (csrc/imgconv.hip) with the amax protocol of mvk_conv3x3_s: x_amax
+ * + w_amax (both or neither) select the scaled-fp16 form (3 fp16 MFMAs per product instead of 6 bf16 ones; the weights are
+ * converted in the kernel from the fp32 pack Wdown / Wup, whose max |w| the `amax` slot of mvk_pack_weights delivers), y_amax
+ * (optional, zeroed) receives max |result| for the launch that consumes it.  NHWC tensors, no fused input activation.
+ * mvk_conv4s2_scaled_ok: 1 when the layer pair and the batch are covered (else both return MVK_EINVAL). */
+/* Two producers of the SVHN decoder that publish the maximum of what they write (so that the layer behind them can take the
+ * scaled-fp16 form without a pass over the tensor): the short-reduction first layer and the fused-tail backward of the image
+ * layer.  Same arguments as mvk_gemm (ta = 0, no fused operand activations) / mvk_conv4s2_small_up_bwd_pre. */
+int mvk_gemm_smallk_amax(const float* A, const float* B, float* C, int M, int N, int K, int tb, const float* bias, int bias_mod,
+                         int act, float* y_amax, void* stream);
+int mvk_conv4s2_small_up_bwd_pre_y(const float* dpre, const float* rowscale, const float* V, int v_act, const float* Wref,
+                                   float* dV, float* dWref, float* db, float* db_v, float* ws, int64_t ws_floats, int n, int h,
+                                   int w, int Cu, int Cv, float* dv_amax, void* stream);
+int mvk_conv4s2_scaled_ok(int n, int h, int w, int Cu, int Cv);
+int mvk_conv4s2_down_s(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w, int Cu, int Cv,
+                       int act, const float* v_act_src, int v_act, float* colsum_acc, const float* x_amax,
+                       const float* w_amax, float* y_amax, float* ws, int64_t ws_floats, const void* wfrag, void* stream);
+int mvk_conv4s2_up_s(const float* V, const float* Wup, const float* bias, float* U, int n, int h, int w, int Cu, int Cv,
+                     int act, const float* u_act_src, int u_act, float* colsum_acc, const float* x_amax, const float* w_amax,
+                     float* y_amax, float* ws, int64_t ws_floats, const void* wfrag, void* stream);
 int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv,
                       int u_nchw, const float* u_act_src, int u_act, float* ws, int64_t ws_floats, void* stream);
 

@@ -89,6 +89,10 @@ PROTOTYPES = {
     "mvk_conv3x3_wgrad_f": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _i64, _p],
     "mvk_conv3x3_s": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _f, _p, _i, _f, _p, _p, _p, _p, _i64, _p],
     "mvk_amax": [_p, _i64, _p, _p],
+    "mvk_gemm_smallk_amax": [_p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p],
+    "mvk_conv4s2_small_up_bwd_pre_y": [_p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p, _p],
+    "mvk_conv4s2_down_s": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _i64, _p, _p],
+    "mvk_conv4s2_up_s": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _i64, _p, _p],
     "mvk_conv3x3_wgrad_s": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _i64, _p],
     "mvk_avgpool3s2_fwd": [_p, _p, _i, _i, _i, _i, _p],
     "mvk_avgpool3s2_bwd": [_p, _p, _i, _i, _i, _i, _p],
@@ -169,6 +173,8 @@ def load(path=None):
     lib.mvk_conv3x3_scaled_ok.restype = C.c_int
     lib.mvk_conv3x3_wgrad_scaled_ok.argtypes = [_i, _i, _i, _i, _i]
     lib.mvk_conv3x3_wgrad_scaled_ok.restype = C.c_int
+    lib.mvk_conv4s2_scaled_ok.argtypes = [_i, _i, _i, _i, _i]
+    lib.mvk_conv4s2_scaled_ok.restype = C.c_int
     lib.mvk_defer_wanted.argtypes = []
     lib.mvk_defer_wanted.restype = C.c_int64
     lib.mvk_defer_pending.argtypes = []
@@ -234,6 +240,8 @@ GEMM_FLOPS = {
     "mvk_conv3x3_f": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
     "mvk_conv3x3_wgrad_f": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
     "mvk_conv3x3_s": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
+    "mvk_conv4s2_down_s": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
+    "mvk_conv4s2_up_s": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
     "mvk_conv3x3_wgrad_s": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
     "mvk_conv4s2_up_nchw_small": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
     "mvk_conv4s2_small_up_fwd": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
@@ -241,6 +249,8 @@ GEMM_FLOPS = {
     "mvk_conv4s2_small_up_bwd": lambda a: 2.0 * 2.0 * a[12] * a[13] * a[14] * 16 * a[15] * a[16],  # data + weight
     "mvk_conv4s2_small_up_fwd_nll": lambda a: 2.0 * a[8] * a[9] * a[10] * 16 * a[11] * a[12],
     "mvk_conv4s2_small_up_bwd_pre": lambda a: 2.0 * 2.0 * a[11] * a[12] * a[13] * 16 * a[14] * a[15],  # data + weight
+    "mvk_conv4s2_small_up_bwd_pre_y": lambda a: 2.0 * 2.0 * a[11] * a[12] * a[13] * 16 * a[14] * a[15],
+    "mvk_gemm_smallk_amax": lambda a: 2.0 * a[3] * a[4] * a[5],
     "mvk_unflatten_wgrad": lambda a: 2.0 * a[3] * a[4] * 16 * a[5],
     "mvk_flatten_wgrad": lambda a: 2.0 * a[3] * 16 * a[4] * a[5],
     "mvk_heads_fwd": lambda a: 2.0 * (2 if a[4] and a[4].value else 1) * a[7] * a[8] * a[9],

@@ -709,13 +709,14 @@ int heads_bwd_launch(const float* X, int x_act, const float* dY0, const float* d
 // skinny.hip: short-reduction linear layer (K <= 32): 1 = shape not covered
 int smallk_fwd(const float* X, const float* W, long long w_sk, long long w_sn, const float* bias, int bias_mod, int act,
                float* Y, int M, int N, int K, hipStream_t s, const float* mask_src = nullptr, int mask_act = 0,
-               int accumulate = 0);
+               int accumulate = 0, float* y_amax = nullptr);
 // imgconv.hip: register-stationary-weight kernels for the 4x4/stride-2 layer pairs (1 = shape not covered)
 int imgconv_up(const float* V, const float* Wup, const void* wfrag, const float* bias, float* U, int n, int h, int w, int Cu,
-               int Cv, int act, const float* u_act_src, int u_act, float* colsum_part, int* part_rows, hipStream_t s);
+               int Cv, int act, const float* u_act_src, int u_act, float* colsum_part, int* part_rows, const float* x_amax,
+               const float* w_amax, float* y_amax, hipStream_t s);
 int imgconv_down(const float* U, const float* Wdown, const void* wfrag, const float* bias, float* V, int n, int h, int w,
                  int Cu, int Cv, int act, const float* v_act_src, int v_act, float* colsum_part, int* part_rows,
-                 hipStream_t s);
+                 const float* x_amax, const float* w_amax, float* y_amax, hipStream_t s);
 // MVK_IMGCONV=0 disables the kernels, MVK_IMGCONV=<n> sets the smallest batch that takes them (default 256 images);
 // mvk_debug_set_flags: bit 0x100 disables them, bit 0x200 takes them for every batch size (tests, A/B probes)
 int imgconv_wgrad(const float* U, const float* V, float* slab, long long slab_floats, int n, int h, int w, int Cu, int Cv,
@@ -932,14 +933,29 @@ int mvk_gemm(const float* A, const float* B, float* C, int M, int N, int K, int 
   return launch_auto(d, ws, ws_floats, mvk_stream(stream));
 }
 
+// C = act(A B + bias) for a short reduction (K <= 32: the first layer of a decoder) with the published maximum of the result
+// (the amax protocol of mvk_conv3x3_s): y_amax receives max |C| by atomic max and must hold 0 before the launch.
+// B(k, n) = B[k * N + n] (tb = 0) or B[n * K + k] (tb = 1).  MVK_EINVAL for shapes the short-reduction kernel does not take.
+int mvk_gemm_smallk_amax(const float* A, const float* B, float* C, int M, int N, int K, int tb, const float* bias, int bias_mod,
+                         int act, float* y_amax, void* stream) {
+  if (!A || !B || !C || !y_amax || M < 0 || N <= 0 || K <= 0 || K > 32) return MVK_EINVAL;
+  if (M == 0) return MVK_OK;
+  const int rc = smallk_fwd(A, B, tb ? 1 : N, tb ? K : 1, bias, bias_mod, act, C, M, N, K, mvk_stream(stream), nullptr, 0, 0, y_amax);
+  return rc == 1 ? MVK_EINVAL : rc;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // 4x4 / stride 2 / pad 1 pair
 // ---------------------------------------------------------------------------------------------------------
-int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w, int Cu,
-                     int Cv, int act, int u_nchw, const float* u_act_src, int u_act, const float* v_act_src,
-                     int v_act, float* colsum_acc, float* ws, int64_t ws_floats, int fmt, const void* wfrag, void* stream) {
+static bool imgconv_pair(int h, int w, int Cu, int Cv) { return h == w && ((h == 8 && Cu == 32 && Cv == 64) || (h == 4 && Cu == 64 && Cv == 128)); }
+
+static int conv4s2_down_impl(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w, int Cu,
+                             int Cv, int act, int u_nchw, const float* u_act_src, int u_act, const float* v_act_src,
+                             int v_act, float* colsum_acc, float* ws, int64_t ws_floats, int fmt, const void* wfrag,
+                             const float* x_amax, const float* w_amax, float* y_amax, void* stream) {
   if (n == 0) return MVK_OK;  // empty batch: nothing to launch (torch hands out NULL for empty tensors)
-  if (!U || !Wdown || !V || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0) return MVK_EINVAL;
+  if (!U || !Wdown || !V || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0 || (!x_amax != !w_amax)) return MVK_EINVAL;
+  const bool wants_rs = x_amax || y_amax;  // forms only the register-stationary kernels take
   if ((fmt & ~MVK_FMT_IN_BF3) || ((fmt & MVK_FMT_IN_BF3) && (u_nchw || u_act_src))) return MVK_EINVAL;
   if (u_nchw && !u_act_src && !v_act_src && !colsum_acc) {  // the network-input layer
     if (mvk_conv4s2_small_up_supported(h, w, Cu, Cv))
@@ -952,11 +968,12 @@ int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, floa
     float* dpart = colsum_acc ? defer_scratch(colsum_acc, 256 * (long long)Cv, mvk_stream(stream)) : nullptr;
     float* cpart = dpart ? dpart : ws;
     const int rc = imgconv_down(U, Wdown, wfrag, bias, V, n, h, w, Cu, Cv, act, v_act_src, v_act, colsum_acc ? cpart : nullptr,
-                                &rows, mvk_stream(stream));
+                                &rows, x_amax, w_amax, y_amax, mvk_stream(stream));
     if (rc == MVK_OK && dpart) return defer_push_plain(colsum_acc, dpart, Cv, rows, Cv, mvk_stream(stream));
     if (rc == MVK_OK && colsum_acc) return colsum_finish(ws, rows, Cv, colsum_acc, mvk_stream(stream));
     if (rc != 1) return rc;
   }
+  if (wants_rs) return MVK_EINVAL;  // ask mvk_conv4s2_scaled_ok first
   GemmDesc d{};
   d.a = AOperand{};
   d.a.p = U;
@@ -986,11 +1003,37 @@ int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, floa
   return launch_with_colsum(d, 1, colsum_acc, ws, ws_floats, V, (long long)n * h * w, mvk_stream(stream));
 }
 
-int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U, int n, int h, int w, int Cu,
-                   int Cv, int act, int u_nchw, const float* u_act_src, int u_act, float* colsum_acc, float* ws,
-                   int64_t ws_floats, int fmt, const void* wfrag, void* stream) {
+int mvk_conv4s2_down(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w, int Cu,
+                     int Cv, int act, int u_nchw, const float* u_act_src, int u_act, const float* v_act_src,
+                     int v_act, float* colsum_acc, float* ws, int64_t ws_floats, int fmt, const void* wfrag, void* stream) {
+  return conv4s2_down_impl(U, Wdown, bias, V, n, h, w, Cu, Cv, act, u_nchw, u_act_src, u_act, v_act_src, v_act, colsum_acc, ws,
+                           ws_floats, fmt, wfrag, nullptr, nullptr, nullptr, stream);
+}
+
+// 1 when mvk_conv4s2_down_s / mvk_conv4s2_up_s take this layer at this batch (the register-stationary kernels cover it)
+int mvk_conv4s2_scaled_ok(int n, int h, int w, int Cu, int Cv) {
+  return n >= imgconv_min_images() && imgconv_pair(h, w, Cu, Cv) && (h != 4 || n % 2 == 0) ? 1 : 0;
+}
+
+// mvk_conv4s2_down on the register-stationary kernels with the amax protocol of mvk_conv3x3_s: x_amax + w_amax (both or
+// neither) select the scaled-fp16 form (3 MFMAs per product; the weights are converted in the kernel from the fp32 pack),
+// y_amax (optional) receives max |V|.  NHWC input, no fused input activation; MVK_EINVAL where mvk_conv4s2_scaled_ok says 0.
+int mvk_conv4s2_down_s(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w, int Cu, int Cv,
+                       int act, const float* v_act_src, int v_act, float* colsum_acc, const float* x_amax, const float* w_amax,
+                       float* y_amax, float* ws, int64_t ws_floats, const void* wfrag, void* stream) {
+  if (!mvk_conv4s2_scaled_ok(n, h, w, Cu, Cv) || (!x_amax && !y_amax)) return MVK_EINVAL;
+  return conv4s2_down_impl(U, Wdown, bias, V, n, h, w, Cu, Cv, act, 0, nullptr, MVK_ACT_NONE, v_act_src, v_act, colsum_acc, ws,
+                           ws_floats, 0, wfrag, x_amax, w_amax, y_amax, stream);
+}
+
+static int conv4s2_up_impl(const float* V, const float* Wup, const float* bias, float* U, int n, int h, int w, int Cu,
+                           int Cv, int act, int u_nchw, const float* u_act_src, int u_act, float* colsum_acc, float* ws,
+                           int64_t ws_floats, int fmt, const void* wfrag, const float* x_amax, const float* w_amax,
+                           float* y_amax, void* stream) {
   if (n == 0) return MVK_OK;  // empty batch: nothing to launch (torch hands out NULL for empty tensors)
-  if (!V || !Wup || !U || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0 || (colsum_acc && u_nchw)) return MVK_EINVAL;
+  if (!V || !Wup || !U || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0 || (colsum_acc && u_nchw) || (!x_amax != !w_amax))
+    return MVK_EINVAL;
+  const bool wants_rs = x_amax || y_amax;
   if (fmt & ~MVK_FMT_IN_BF3) return MVK_EINVAL;
   if (!u_nchw && fmt == 0 && n >= imgconv_min_images() && imgconv_act_ok(act) && imgconv_act_ok(u_act) &&
       (!colsum_acc || (ws && ws_floats >= 256 * (int64_t)Cu)) && mvk_aligned16(V)) {
@@ -998,11 +1041,12 @@ int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U
     float* dpart = colsum_acc ? defer_scratch(colsum_acc, 256 * (long long)Cu, mvk_stream(stream)) : nullptr;
     float* cpart = dpart ? dpart : ws;
     const int rc = imgconv_up(V, Wup, wfrag, bias, U, n, h, w, Cu, Cv, act, u_act_src, u_act, colsum_acc ? cpart : nullptr,
-                              &rows, mvk_stream(stream));
+                              &rows, x_amax, w_amax, y_amax, mvk_stream(stream));
     if (rc == MVK_OK && dpart) return defer_push_plain(colsum_acc, dpart, Cu, rows, Cu, mvk_stream(stream));
     if (rc == MVK_OK && colsum_acc) return colsum_finish(ws, rows, Cu, colsum_acc, mvk_stream(stream));
     if (rc != 1) return rc;
   }
+  if (wants_rs) return MVK_EINVAL;
   GemmDesc d{};
   d.a = AOperand{};
   d.a.p = V;
@@ -1036,6 +1080,22 @@ int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U
   d.K = 4 * Cv;
   d.zmode = Z_PARITY;
   return launch_with_colsum(d, 4, colsum_acc, ws, ws_floats, U, (long long)n * 4 * h * w, mvk_stream(stream));
+}
+
+int mvk_conv4s2_up(const float* V, const float* Wup, const float* bias, float* U, int n, int h, int w, int Cu,
+                   int Cv, int act, int u_nchw, const float* u_act_src, int u_act, float* colsum_acc, float* ws,
+                   int64_t ws_floats, int fmt, const void* wfrag, void* stream) {
+  return conv4s2_up_impl(V, Wup, bias, U, n, h, w, Cu, Cv, act, u_nchw, u_act_src, u_act, colsum_acc, ws, ws_floats, fmt, wfrag,
+                         nullptr, nullptr, nullptr, stream);
+}
+
+// mvk_conv4s2_up with the amax protocol (see mvk_conv4s2_down_s); NHWC output
+int mvk_conv4s2_up_s(const float* V, const float* Wup, const float* bias, float* U, int n, int h, int w, int Cu, int Cv, int act,
+                     const float* u_act_src, int u_act, float* colsum_acc, const float* x_amax, const float* w_amax,
+                     float* y_amax, float* ws, int64_t ws_floats, const void* wfrag, void* stream) {
+  if (!mvk_conv4s2_scaled_ok(n, h, w, Cu, Cv) || (!x_amax && !y_amax)) return MVK_EINVAL;
+  return conv4s2_up_impl(V, Wup, bias, U, n, h, w, Cu, Cv, act, 0, u_act_src, u_act, colsum_acc, ws, ws_floats, 0, wfrag, x_amax,
+                         w_amax, y_amax, stream);
 }
 
 // ---- 3x3 / stride 1 / pad 1 convolution on NHWC activations (ResNet blocks) --------------------------------------

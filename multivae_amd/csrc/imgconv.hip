@@ -55,9 +55,15 @@ struct ImgConvArgs {
   int n;                 // images
   int act, src_act;
   mvk_prof_slot* prof;   // device-timestamp record of this launch (null: profiler off)
+  // scaled-fp16 form (NP = 2, bf3.hpp): device scalars bounding max |A| and max |Wp| (both required); either form: max |out|
+  // is published into y_amax (atomic max; must hold 0 before the launch) when it is given
+  const float* x_amax;
+  const float* w_amax;
+  float* y_amax;
 };
 
-template <int KIND, int HS, int CIN, int COUT>
+// NP = pieces per operand element: 3 bf16 pieces (6 MFMAs per product) or 2 scaled fp16 pieces (3 MFMAs per product)
+template <int KIND, int HS, int CIN, int COUT, int NP = 3>
 struct ICfg {
   static constexpr int PIX = HS * HS;                          // output rows per image (per parity class for UP)
   static constexpr int APIX = KIND == IC_UP ? PIX : 4 * PIX;   // input pixels per image
@@ -90,7 +96,7 @@ struct ICfg {
   __host__ __device__ static constexpr int pix_off(int img, int y, int x) {
     return img * IMGB + y * LINEB + (XPERM ? (x & 1) * (AW / 2) + (x >> 1) : x) * S;
   }
-  static constexpr int BUF = 3 * PLANE;
+  static constexpr int BUF = NP * PLANE;
   static constexpr int NF4 = AROWS * CIN / 4 / 256;            // float4 units per thread per stage unit
   static constexpr int OWN = 16 / KSPLIT;                      // accumulator registers a wave finishes
   static constexpr int XWAVE = (KSPLIT - 1) * OWN * 64 * 4;    // exchange bytes received per wave
@@ -107,9 +113,14 @@ __device__ __forceinline__ bf16x8 ic_pack8(const unsigned (&d)[4]) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int KIND, int HS, int CIN, int COUT, bool HAS_SRC, bool PIPE>
+template <int KIND, int HS, int CIN, int COUT, bool HAS_SRC, bool PIPE, int NP = 3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void imgconv_kernel(const ImgConvArgs g) {
-  using T = ICfg<KIND, HS, CIN, COUT>;
+  using T = ICfg<KIND, HS, CIN, COUT, NP>;
+  static_assert(NP == 3 || PIPE, "the scaled-fp16 form exists for the two-tile-latency loop only");
+  using frag = std::conditional_t<NP == 3, bf16x8, f16x8>;
+  // scaled-fp16 form: the operands are multiplied by sx / sw on their way into pieces, the result by 1 / (sx sw)
+  const float sx = NP == 2 ? f16_scale_of(*g.x_amax) : 1.f, sw = NP == 2 ? f16_scale_of(*g.w_amax) : 1.f;
+  const float inv_s = NP == 2 ? f16_inv_scale(sx) * f16_inv_scale(sw) : 1.f;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   mvk_prof_begin(g.prof);
 #ifdef MVK_ICPROF
@@ -139,15 +150,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int ncol = ct * 32 + col;
 
   // ---- weights: 16 k-steps x 3 pieces, resident for the whole launch ---------------------------------------------
-  bf16x8 Bw[T::NTAPS][T::CHUNKS][3];
-  if (g.wfrag) {  // 48 coalesced 16-byte loads per lane
+  frag Bw[T::NTAPS][T::CHUNKS][NP];
+  if (NP == 3 && g.wfrag) {  // 48 coalesced 16-byte loads per lane
     const bf16x8* f = reinterpret_cast<const bf16x8*>(g.wfrag) + (long long)(wgtype * 4 + wave) * 16 * 3 * 64 + lane;
 #pragma unroll
     for (int q = 0; q < T::NTAPS; ++q)
 #pragma unroll
       for (int c = 0; c < T::CHUNKS; ++c)
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) Bw[q][c][pc] = f[((q * T::CHUNKS + c) * 3 + pc) * 64];
+        for (int pc = 0; pc < 3; ++pc) Bw[q][c][pc < NP ? pc : 0] = __builtin_bit_cast(frag, f[((q * T::CHUNKS + c) * 3 + pc) * 64]);
   } else
 #pragma unroll
   for (int q = 0; q < T::NTAPS; ++q) {
@@ -160,9 +171,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int e = 0; e < 8; ++e) v[e] = g.Wp[(rowbase + c * 16 + kg * 8 + e) * COUT + ncol];
       unsigned p[3][4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) bf3_split(v[2 * e], v[2 * e + 1], p[0][e], p[1][e], p[2][e]);
+      for (int e = 0; e < 4; ++e) {
+        if constexpr (NP == 3) bf3_split(v[2 * e], v[2 * e + 1], p[0][e], p[1][e], p[2][e]);
+        else f16_split(v[2 * e] * sw, v[2 * e + 1] * sw, p[0][e], p[1][e]);
+      }
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) Bw[q][c][pc] = ic_pack8(p[pc]);
+      for (int pc = 0; pc < NP; ++pc) Bw[q][c][pc] = __builtin_bit_cast(frag, u32x4{p[pc][0], p[pc][1], p[pc][2], p[pc][3]});
     }
   }
 
@@ -176,8 +190,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int c = 0; c < T::CHUNKS; ++c)
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) {
-        bf16x8 t = Bw[q][c][pc];
+      for (int pc = 0; pc < NP; ++pc) {
+        frag t = Bw[q][c][pc];
         asm volatile("" : "=a"(Bw[q][c][pc]) : "0"(t));
       }
 
@@ -185,9 +199,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   char* const xbase = lds + 2 * T::BUF;
   float* const csred = reinterpret_cast<float*>(lds + 2 * T::BUF + 2 * T::XBUF);
   // zero rows (at ZOFF of every plane of both buffers)
-  for (int i = tid; i < 2 * 3 * (T::S / 4); i += 256) {
+  for (int i = tid; i < 2 * NP * (T::S / 4); i += 256) {
     const int pl = i / (T::S / 4), w = i % (T::S / 4);
-    *reinterpret_cast<unsigned*>(lds + (pl / 3) * T::BUF + (pl % 3) * T::PLANE + T::ZOFF + w * 4) = 0u;
+    *reinterpret_cast<unsigned*>(lds + (pl / NP) * T::BUF + (pl % NP) * T::PLANE + T::ZOFF + w * 4) = 0u;
   }
   // A-fragment byte offsets of this lane, per (tile of the unit, tap of this wave): row * S + kg * 16
   int aoff[T::TPU][T::NTAPS];
@@ -235,7 +249,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const float bias = g.bias ? g.bias[ncol] : 0.f;
   const float act_lo = g.act == MVK_ACT_RELU ? 0.f : -__builtin_inff();
   const float src_lo = g.src_act == MVK_ACT_RELU ? 0.f : -__builtin_inff();
-  float csum = 0.f;
+  float csum = 0.f, amax_l = 0.f;
 
   const long long units = g.n / T::SU;
   const long long u0 = units * worker / workers, u1 = units * (worker + 1) / workers;
@@ -246,12 +260,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     return reinterpret_cast<const f32x4*>(g.A + uc * IN_UNIT) + tid;
   };
   auto write_f4 = [&](char* buf, int k) {
-    unsigned a0, a1, a2, b0, b1, b2;
-    bf3_split(raw[k][0], raw[k][1], a0, a1, a2);
-    bf3_split(raw[k][2], raw[k][3], b0, b1, b2);
-    *reinterpret_cast<u32x2*>(buf + soff[k]) = u32x2{a0, b0};
-    *reinterpret_cast<u32x2*>(buf + T::PLANE + soff[k]) = u32x2{a1, b1};
-    *reinterpret_cast<u32x2*>(buf + 2 * T::PLANE + soff[k]) = u32x2{a2, b2};
+    if constexpr (NP == 3) {
+      unsigned a0, a1, a2, b0, b1, b2;
+      bf3_split(raw[k][0], raw[k][1], a0, a1, a2);
+      bf3_split(raw[k][2], raw[k][3], b0, b1, b2);
+      *reinterpret_cast<u32x2*>(buf + soff[k]) = u32x2{a0, b0};
+      *reinterpret_cast<u32x2*>(buf + T::PLANE + soff[k]) = u32x2{a1, b1};
+      *reinterpret_cast<u32x2*>(buf + 2 * T::PLANE + soff[k]) = u32x2{a2, b2};
+    } else {
+      unsigned a0, a1, b0, b1;
+      f16_split(raw[k][0] * sx, raw[k][1] * sx, a0, a1);
+      f16_split(raw[k][2] * sx, raw[k][3] * sx, b0, b1);
+      *reinterpret_cast<u32x2*>(buf + soff[k]) = u32x2{a0, b0};
+      *reinterpret_cast<u32x2*>(buf + T::PLANE + soff[k]) = u32x2{a1, b1};
+    }
   };
 
   if (u0 < u1) {
@@ -273,13 +295,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   //   * the loads of the activation-derivative source of tile t (consumed one tile later),
   //   * the epilogue of tile t-1 (bias, activation, mask, store, column sums).
   // After the k-loop: accumulator exchange (waves that split the taps), ONE barrier, first fragments of tile t+1.
-  auto read_pair = [&](bf16x8 (&dst)[2][3], const char* buf, int tt, int pr) {
+  auto read_pair = [&](frag (&dst)[2][NP], const char* buf, int tt, int pr) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int q = (2 * pr + h) / T::CHUNKS, c = (2 * pr + h) % T::CHUNKS;
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc)
-        dst[h][pc] = *reinterpret_cast<const bf16x8*>(buf + aoff[tt][q] + pc * T::PLANE + c * 32);
+      for (int pc = 0; pc < NP; ++pc)
+        dst[h][pc] = *reinterpret_cast<const frag*>(buf + aoff[tt][q] + pc * T::PLANE + c * 32);
     }
   };
   float res_prev[T::OWN], msk_prev[T::OWN], msk_cur[T::OWN];
@@ -287,14 +309,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int o = 0; o < T::OWN; ++o) res_prev[o] = msk_prev[o] = msk_cur[o] = 0.f;
   auto epilogue_row = [&](float* outp, int ptt, int o, float validf) {
     const int off = obase + out_off(ptt, o, 0);
-    float v = fmaxf(res_prev[o] + bias, act_lo);          // NONE / RELU
+    float v = fmaxf((NP == 2 ? res_prev[o] * inv_s : res_prev[o]) + bias, act_lo);          // NONE / RELU
     if (HAS_SRC) v = (msk_prev[o] > src_lo) ? v : 0.f;    // x ReLU'(y) of the layer the result lands in (or x 1)
     outp[off] = v;
     csum = fmaf(v, validf, csum);
+    amax_l = fmaxf(amax_l, fabsf(v) * validf);
   };
-  bf16x8 a_cur[2][3];
+  frag a_cur[2][NP];
   if (u0 < u1) read_pair(a_cur, lds, 0, 0);
-  if (PIPE) {
+  if constexpr (PIPE) {
     // ---- main loop, two-tile latency (default) --------------------------------------------------------------------
     // With one barrier at the END of every tile the waves spend a third of their cycles between k-loops (measured with
     // the in-kernel counters of tools/imgconv_phase.sh: accumulator read-out + exchange writes before the barrier, first
@@ -311,14 +334,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // prove the rank wave-uniform): ~40 tiny basic blocks per tile that no scheduling pipeline crosses.
     auto run = [&](auto ks_tag) {
     constexpr int KSC = decltype(ks_tag)::value;
-    f32x16 pend0 = {0}, pend1 = {0};          // accumulator chains of tile T-1
+    // accumulator chains of tile T-1 (NP = 3: one per k-step of a pair; NP = 2: main hi hi' and cross hi lo' + lo hi')
+    f32x16 pend0 = {0}, pend1 = {0};
     float own[T::OWN], res_next[T::OWN];
 #pragma unroll
     for (int o = 0; o < T::OWN; ++o) own[o] = res_next[o] = 0.f;
     int tcount = 0, xpar = 0;
     constexpr int DU1 = 1, DU2 = T::TPU == 1 ? 2 : 1;  // units back of tiles T-1 (when tt == 0) and T-2
     auto finish_pending = [&](char* xb) {  // pair 0: sum of the chains; exchange slices out, own slice kept
-      const f32x16 sum = pend0 + pend1;
+      f32x16 sum;
+      if constexpr (NP == 3) {
+        sum = pend0 + pend1;
+      } else {
+        sum = pend0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum[r] = fmaf(pend1[r], 1.f / 2048.f, sum[r]);
+      }
       if (T::KSPLIT > 1) {
 #pragma unroll
         for (int r = 0; r < T::KSPLIT; ++r) {
@@ -377,7 +408,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 #pragma unroll
         for (int pr = 0; pr < 8; ++pr) {
-          bf16x8 a_nxt[2][3];
+          frag a_nxt[2][NP];
           if (pr < 7) read_pair(a_nxt, abuf, tt, pr + 1);
           if (pr == 0) finish_pending(xb);
           if (tt == 0 && pr < 7) {  // conversion of the next unit: complete before the barrier behind pair 6
@@ -399,13 +430,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (HAS_SRC) msk_cur[o] = srcp_1[obase + out_off(ptt1, o, 0)];
             epilogue_row(outp_e, ptt2, o, validf);
           }
-          constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {2, 1, 0, 1, 0, 0};  // small terms first
           const int q0 = (2 * pr) / T::CHUNKS, c0 = (2 * pr) % T::CHUNKS;
           const int q1 = (2 * pr + 1) / T::CHUNKS, c1 = (2 * pr + 1) % T::CHUNKS;
+          if constexpr (NP == 3) {
+            constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {2, 1, 0, 1, 0, 0};  // small terms first
 #pragma unroll
-          for (int m = 0; m < 6; ++m) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][PA[m]], Bw[q0][c0][PB[m]], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][PA[m]], Bw[q1][c1][PB[m]], acc1, 0, 0, 0);
+            for (int m = 0; m < 6; ++m) {
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][PA[m]], Bw[q0][c0][PB[m]], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][PA[m]], Bw[q1][c1][PB[m]], acc1, 0, 0, 0);
+            }
+          } else {  // acc0 = main, acc1 = cross (dependent MFMAs on one accumulator issue back to back)
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0][0], Bw[q0][c0][1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0][0], Bw[q0][c0][0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1][0], Bw[q1][c1][1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1][0], Bw[q1][c1][0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0][1], Bw[q0][c0][0], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1][1], Bw[q1][c1][0], acc1, 0, 0, 0);
           }
           if (pr == 7) {  // behind the barrier: first fragments of the next tile, result of tile T-1
             read_pair(a_nxt, next_buf, ntt, 0);
@@ -414,12 +454,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) a_cur[h][pc] = a_nxt[h][pc];
+            for (int pc = 0; pc < NP; ++pc) a_cur[h][pc] = a_nxt[h][pc];
           if (MVK_IC_SCHED > 0) {  // "1 MFMA, N others" (see the one-tile-latency loop)
 #pragma unroll
-            for (int m = 0; m < 12; ++m) {
+            for (int m = 0; m < 4 * NP; ++m) {
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-              __builtin_amdgcn_sched_group_barrier(0x496, MVK_IC_SCHED > 0 ? MVK_IC_SCHED : 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x496, (MVK_IC_SCHED > 0 ? MVK_IC_SCHED : 1) * (NP == 3 ? 1 : 2), 0);
             }
           }
 #ifdef MVK_ICPROF
@@ -641,6 +681,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 
   }
+  if (g.y_amax) {  // uniform branch; csred is free until the column sums below
+    amax_publish(amax_l, g.y_amax, csred);
+    __syncthreads();
+  }
   if (g.colsum_part) {  // fixed-order sum over the waves that share a column tile
     csum += __shfl_xor(csum, 32, 64);
     if (kg == 0) csred[wave * 32 + col] = csum;
@@ -673,9 +717,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   mvk_prof_end(g.prof);
 }
 
+// scaled-fp16 form (two-tile-latency loop only)
+template <int KIND, int HS, int CIN, int COUT>
+static int imgconv_launch_f16(const ImgConvArgs& a, int* part_rows, hipStream_t s) {
+  using T = ICfg<KIND, HS, CIN, COUT, 2>;
+  static bool attr_done = false;
+  auto kern = a.act_src ? imgconv_kernel<KIND, HS, CIN, COUT, true, true, 2> : imgconv_kernel<KIND, HS, CIN, COUT, false, true, 2>;
+  if (!attr_done) {
+    const void* all[2] = {reinterpret_cast<const void*>(imgconv_kernel<KIND, HS, CIN, COUT, true, true, 2>),
+                          reinterpret_cast<const void*>(imgconv_kernel<KIND, HS, CIN, COUT, false, true, 2>)};
+    for (const void* f : all)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return MVK_ELAUNCH;
+    attr_done = true;
+  }
+  const int grid = 256;
+  if (part_rows) *part_rows = (KIND == IC_DOWN && T::WG_TYPES > 1) ? grid / T::WG_TYPES : grid;
+  ImgConvArgs ap = a;
+  ap.prof = prof_next(KIND == IC_UP ? 2 : 3, 2.0 * a.n * HS * HS * 16.0 * CIN * COUT);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), T::LDS_BYTES, s, ap);
+  MVK_CHECK_LAUNCH();
+  prof_fold(ap.prof, s);
+  return MVK_OK;
+}
+
 template <int KIND, int HS, int CIN, int COUT>
 static int imgconv_launch(const ImgConvArgs& a, int* part_rows, hipStream_t s) {
   using T = ICfg<KIND, HS, CIN, COUT>;
+  if (a.x_amax && a.w_amax) return imgconv_launch_f16<KIND, HS, CIN, COUT>(a, part_rows, s);
   static bool attr_done = false;
   // MVK_IMGCONV_PIPE=0: the one-tile-latency main loop (A/B; results are bit-identical)
   static const bool pipe = !(mvk_tune("MVK_IMGCONV_PIPE") && atoi(mvk_tune("MVK_IMGCONV_PIPE")) == 0);
@@ -976,9 +1044,10 @@ int imgconv_wgrad(const float* U, const float* V, float* slab, long long slab_fl
 
 // 1: shape not covered (the caller falls back to the implicit-GEMM engine)
 int imgconv_up(const float* V, const float* Wup, const void* wfrag, const float* bias, float* U, int n, int h, int w, int Cu,
-               int Cv, int act, const float* u_act_src, int u_act, float* colsum_part, int* part_rows, hipStream_t s) {
+               int Cv, int act, const float* u_act_src, int u_act, float* colsum_part, int* part_rows, const float* x_amax,
+               const float* w_amax, float* y_amax, hipStream_t s) {
   if (h != w) return 1;
-  ImgConvArgs a{V, Wup, wfrag, bias, U, u_act_src, colsum_part, n, act, u_act, nullptr};
+  ImgConvArgs a{V, Wup, wfrag, bias, U, u_act_src, colsum_part, n, act, u_act, nullptr, x_amax, w_amax, y_amax};
   if (h == 8 && Cv == 64 && Cu == 32) return imgconv_launch<IC_UP, 8, 64, 32>(a, part_rows, s);
   if (h == 4 && Cv == 128 && Cu == 64 && n % 2 == 0) return imgconv_launch<IC_UP, 4, 128, 64>(a, part_rows, s);
   return 1;
@@ -986,9 +1055,9 @@ int imgconv_up(const float* V, const float* Wup, const void* wfrag, const float*
 
 int imgconv_down(const float* U, const float* Wdown, const void* wfrag, const float* bias, float* V, int n, int h, int w,
                  int Cu, int Cv, int act, const float* v_act_src, int v_act, float* colsum_part, int* part_rows,
-                 hipStream_t s) {
+                 const float* x_amax, const float* w_amax, float* y_amax, hipStream_t s) {
   if (h != w) return 1;
-  ImgConvArgs a{U, Wdown, wfrag, bias, V, v_act_src, colsum_part, n, act, v_act, nullptr};
+  ImgConvArgs a{U, Wdown, wfrag, bias, V, v_act_src, colsum_part, n, act, v_act, nullptr, x_amax, w_amax, y_amax};
   if (h == 8 && Cu == 32 && Cv == 64) return imgconv_launch<IC_DOWN, 8, 32, 64>(a, part_rows, s);
   if (h == 4 && Cu == 64 && Cv == 128 && n % 2 == 0) return imgconv_launch<IC_DOWN, 4, 64, 128>(a, part_rows, s);
   return 1;

@@ -7,7 +7,7 @@
 // added in a fixed order through LDS (deterministic).
 #include <cstdlib>
 
-#include "common.hpp"
+#include "bf3.hpp"
 
 namespace {
 
@@ -307,6 +307,7 @@ struct SmallKArgs {
   long long w_sk, w_sn;  // W(k, n) = W[k * w_sk + n * w_sn]
   const float* mask_src;  // optional [M][N]: the result is multiplied by act'(mask_src) (backward-data into a hidden layer)
   int mask_act, accumulate;
+  float* y_amax;          // optional: max |Y| is published here (atomic max, one per workgroup; must hold 0 before the launch)
 };
 
 template <int K4>  // ceil(K / 4)
@@ -351,7 +352,8 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const SmallKArgs g) {
     xs[r][k] = (m0 + r < g.M && k < g.K) ? g.X[(long long)(m0 + r) * g.K + k] : 0.f;
   }
   __syncthreads();
-  if (!active) return;
+  float amax_l = 0.f;
+  if (active)
   for (int r = rg; r < R && m0 + r < g.M; r += rgn) {
     f32x4 acc = b4;
 #pragma unroll
@@ -376,7 +378,9 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const SmallKArgs g) {
       for (int j = 0; j < 4; ++j) acc[j] += old[j];
     }
     *dst = acc;
+    amax_l = fmaxf(fmaxf(amax_l, fmaxf(fabsf(acc[0]), fabsf(acc[1]))), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
   }
+  if (g.y_amax) mvk::amax_publish(amax_l, g.y_amax, &xs[0][0]);  // uniform; xs is dead (amax_publish synchronises first)
 }
 
 }  // namespace
@@ -384,11 +388,11 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const SmallKArgs g) {
 namespace mvk {
 // 1: shape not covered (the caller continues with the tiled engine)
 int smallk_fwd(const float* X, const float* W, long long w_sk, long long w_sn, const float* bias, int bias_mod, int act,
-               float* Y, int M, int N, int K, hipStream_t s, const float* mask_src, int mask_act, int accumulate) {
+               float* Y, int M, int N, int K, hipStream_t s, const float* mask_src, int mask_act, int accumulate, float* y_amax) {
   static const int off = mvk_tune("MVK_SMALLK") ? atoi(mvk_tune("MVK_SMALLK")) == 0 : 0;
   if (off || K > 32 || K < 1 || N % 4 != 0 || N < 4 || !mvk_aligned16(Y) || M < 1 || (mask_src && !mvk_aligned16(mask_src)))
     return 1;
-  SmallKArgs a{X, W, bias, Y, M, N, K, bias_mod > 0 ? bias_mod : 1, act, w_sk, w_sn, mask_src, mask_act, accumulate};
+  SmallKArgs a{X, W, bias, Y, M, N, K, bias_mod > 0 ? bias_mod : 1, act, w_sk, w_sn, mask_src, mask_act, accumulate, y_amax};
   const int CT = N / 4, ctb = CT < 256 ? CT : 256;
   const dim3 grid((M + 7) / 8, (CT + ctb - 1) / ctb);
   switch ((K + 3) / 4) {

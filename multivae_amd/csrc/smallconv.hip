@@ -669,8 +669,10 @@ __device__ __forceinline__ mvk::bf16x8 su_tr_pair(const char* p0, const char* p1
 template <int CU, bool PRE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void small_up_bwd_bf_kernel(
     const float* __restrict__ dU, const float* __restrict__ Uout, const float* __restrict__ V, const float* __restrict__ Wref,
-    float* __restrict__ dV, float* __restrict__ partial, int n, mvk_prof_slot* prof, const float* __restrict__ rowscale = nullptr) {
+    float* __restrict__ dV, float* __restrict__ partial, int n, mvk_prof_slot* prof, const float* __restrict__ rowscale = nullptr,
+    float* dv_amax = nullptr) {
   mvk_prof_begin(prof);
+  float amax_l = 0.f;  // max |dV| of this thread's stores (published at the end when dv_amax is given)
   using mvk::bf16x8;
   using mvk::u32x2;
   using mvk::u32x4;
@@ -830,6 +832,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           gq[r] = __uint_as_float(hv[r]) > 0.f ? c2[b][r] : 0.f;
           dbv[a][b][r] += gq[r];
         }
+        amax_l = fmaxf(fmaxf(amax_l, fmaxf(fabsf(gq[0]), fabsf(gq[1]))), fmaxf(fabsf(gq[2]), fabsf(gq[3])));
         *reinterpret_cast<f32x4*>(dv + cv) = gq;
       }
     }
@@ -909,6 +912,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int q = 0; q < 8; ++q) t += red[CV * P + tid * 8 + q];
     slab[CV * NC + CU + tid] = t;
   }
+  if (dv_amax) mvk::amax_publish(amax_l, dv_amax, red);  // uniform branch; synchronises before it touches red
   mvk_prof_end(prof);
 }
 
@@ -1111,7 +1115,7 @@ static int launch_fwd(const float* V, const float* Wref, const float* bias, floa
 template <int CU, int CV>
 static int launch_bwd(const float* dU, const float* Uout, int u_act, const float* V, int v_act, const float* Wref,
                       float* dV, float* dWref, float* db, float* db_v, float* ws, int64_t ws_floats, int n, int h,
-                      int w, hipStream_t s, bool pre = false, const float* rowscale = nullptr) {
+                      int w, hipStream_t s, bool pre = false, const float* rowscale = nullptr, float* dv_amax = nullptr) {
   using C = SmallCfg<CU, CV>;
   const int slab = CV * C::NC + CU + CV;
   // MVK_SMALL_BWD_UNITS=2: half-image work units for 16x16 inputs (3 workgroups per CU instead of 2).  Measured at
@@ -1125,7 +1129,7 @@ static int launch_bwd(const float* dU, const float* Uout, int u_act, const float
   const bool bf = (!bf_str || atoi(bf_str) != 0) && CU == 3 && CV == 32 && h == 16 && w == 16 && units_env != 2 &&
                   (pre || u_act == MVK_ACT_SIGMOID) && v_act == MVK_ACT_RELU && mvk_aligned16(dU) &&
                   (pre || mvk_aligned16(Uout)) && mvk_aligned16(V) && mvk_aligned16(dV) && mvk_aligned16(Wref);
-  if (pre && !bf) return MVK_EINVAL;  // the pre-activation form lives in the split-bf16 kernel only
+  if ((pre || dv_amax) && !bf) return MVK_EINVAL;  // the pre-activation form and the published maximum: split-bf16 kernel only
   const int gmax = units == 2 ? 1024 : 512;
   int grid = nunits < gmax ? (int)nunits : gmax;
   float* dslab = (mvk::defer_free(db) && mvk::defer_free(db_v)) ? mvk::defer_scratch(dWref, (long long)grid * slab, s) : nullptr;
@@ -1142,10 +1146,10 @@ static int launch_bwd(const float* dU, const float* Uout, int u_act, const float
                                 hipFuncAttributeMaxDynamicSharedMemorySize, BLDS);
       if (pre)
         hipLaunchKernelGGL((small_up_bwd_bf_kernel<CU, true>), dim3(grid), dim3(256), BLDS, s, dU, Uout, V, Wref, dV, ws, n, prof,
-                           rowscale);
+                           rowscale, dv_amax);
       else
         hipLaunchKernelGGL((small_up_bwd_bf_kernel<CU, false>), dim3(grid), dim3(256), BLDS, s, dU, Uout, V, Wref, dV, ws, n, prof,
-                           rowscale);
+                           rowscale, dv_amax);
       MVK_CHECK_LAUNCH();
       mvk::prof_fold(prof, s);
       const int total = CV * C::NC + CU + CV;
@@ -1288,6 +1292,18 @@ int mvk_conv4s2_small_up_bwd_pre(const float* dpre, const float* rowscale, const
   if (n == 0) return MVK_OK;
   return launch_bwd<3, 32>(dpre, nullptr, MVK_ACT_NONE, V, v_act, Wref, dV, dWref, db, db_v, ws, ws_floats, n, h, w,
                            mvk_stream(stream), true, rowscale);
+}
+
+// mvk_conv4s2_small_up_bwd_pre with the published maximum of dV (amax protocol: dv_amax must hold 0 before the launch)
+int mvk_conv4s2_small_up_bwd_pre_y(const float* dpre, const float* rowscale, const float* V, int v_act, const float* Wref,
+                                   float* dV, float* dWref, float* db, float* db_v, float* ws, int64_t ws_floats, int n, int h,
+                                   int w, int Cu, int Cv, float* dv_amax, void* stream) {
+  if (!dpre || !V || !Wref || !dV || !dWref || !ws || !dv_amax || n < 0 || !mvk_aligned16(V) ||
+      !mvk_conv4s2_small_up_nll_supported(h, w, Cu, Cv))
+    return MVK_EINVAL;
+  if (n == 0) return MVK_OK;
+  return launch_bwd<3, 32>(dpre, nullptr, MVK_ACT_NONE, V, v_act, Wref, dV, dWref, db, db_v, ws, ws_floats, n, h, w,
+                           mvk_stream(stream), true, rowscale, dv_amax);
 }
 
 int mvk_conv4s2_small_down_fwd(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w,

@@ -499,7 +499,8 @@ def _pack_launch(jobs):
     descs = (PackDesc * len(jobs))()
     outs = []
     am = None
-    if C3_F16 and any(job[1] == "c3" for job in jobs):  # max |W| per 3x3 weight: the operand scale of mvk_conv3x3_s
+    # max |W| per convolution weight: the operand scale of the scaled-fp16 launches (mvk_conv3x3_s, mvk_conv4s2_down_s / _up_s)
+    if (C3_F16 and any(job[1] == "c3" for job in jobs)) or (IMG_F16 and any(job[1] not in ("c3", "unflatten") for job in jobs)):
         am = torch.zeros(len(jobs), dtype=torch.float32, device=jobs[0][0].device)
     for i, job in enumerate(jobs):
         wref = job[0]
@@ -535,18 +536,36 @@ def _pack_launch(jobs):
             if wu is not None:
                 wu.mvk_frag = _frag(wref, Cu, Cv)
                 d.Fup = wu.mvk_frag.data_ptr() if wu.mvk_frag is not None else None
+            if am is not None:
+                d.amax = am[i:i + 1].data_ptr()
+                for t in (wd, wu):
+                    if t is not None:
+                        t.mvk_amax = am[i:i + 1]
             outs.append((wd, wu))
     call("mvk_pack_weights", descs, len(jobs), stream_ptr())
     return outs
 
 
+def conv4s2_scaled_ok(n, h, w, Cu, Cv):
+    """True when the `amax=` forms of conv_down / conv_up (mvk_conv4s2_down_s / _up_s) take this layer at this batch."""
+    return bool(_lib.load().mvk_conv4s2_scaled_ok(n, h, w, Cu, Cv))
+
+
 def conv_down(U, wdown, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src=None, u_act=NONE,
-              v_act_src=None, v_act=NONE, out_bias=None, in_bf3=False, frag=None):
+              v_act_src=None, v_act=NONE, out_bias=None, in_bf3=False, frag=None, amax=None):
     """out_bias: bias parameter whose gradient is the per-channel sum of the result (backward-data use): fused into
-    the launch; returns (V, grad for autograd) then."""
+    the launch; returns (V, grad for autograd) then.  amax = (x_amax, w_amax, y_amax): the amax protocol (mvk_conv4s2_down_s;
+    x and w bounds given = scaled fp16 pairs, y_amax = zeroed slot that receives max |V|)."""
     V = torch.empty((n, h, w, Cv), dtype=torch.float32, device=U.device)
     ws = _ws(V)
     tb, rb = _bias_target(out_bias)
+    if amax is not None:
+        if u_nchw or u_act_src is not None or in_bf3:
+            raise _lib.MvkError("conv_down: the amax form takes NHWC fp32 input without a fused input activation")
+        call("mvk_conv4s2_down_s", ptr(U), ptr(wdown), ptr(bias), ptr(V), n, h, w, Cu, Cv, act, ptr(v_act_src), v_act, ptr(tb),
+             ptr(amax[0]), ptr(amax[1]), ptr(amax[2]), ptr(ws), ws.numel(), ptr(frag if frag is not None else wfrag(wdown)),
+             stream_ptr())
+        return V if out_bias is None else (V, rb)
     call("mvk_conv4s2_down", ptr(U), ptr(wdown), ptr(bias), ptr(V), n, h, w, Cu, Cv, act, int(u_nchw),
          ptr(u_act_src), u_act, ptr(v_act_src), v_act, ptr(tb), ptr(ws), ws.numel(), FMT_IN_BF3 if in_bf3 else 0,
          ptr(frag if frag is not None else wfrag(wdown)), stream_ptr())
@@ -554,10 +573,17 @@ def conv_down(U, wdown, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src
 
 
 def conv_up(V, wup, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src=None, u_act=NONE, out_bias=None,
-            in_bf3=False, frag=None):
+            in_bf3=False, frag=None, amax=None):
     U = torch.empty((n, Cu, 2 * h, 2 * w) if u_nchw else (n, 2 * h, 2 * w, Cu), dtype=torch.float32, device=V.device)
     ws = _ws(U)
     tb, rb = _bias_target(out_bias)
+    if amax is not None:  # (x_amax, w_amax, y_amax): see conv_down
+        if u_nchw or in_bf3:
+            raise _lib.MvkError("conv_up: the amax form writes NHWC and reads fp32")
+        call("mvk_conv4s2_up_s", ptr(V), ptr(wup), ptr(bias), ptr(U), n, h, w, Cu, Cv, act, ptr(u_act_src), u_act, ptr(tb),
+             ptr(amax[0]), ptr(amax[1]), ptr(amax[2]), ptr(ws), ws.numel(), ptr(frag if frag is not None else wfrag(wup)),
+             stream_ptr())
+        return U if out_bias is None else (U, rb)
     call("mvk_conv4s2_up", ptr(V), ptr(wup), ptr(bias), ptr(U), n, h, w, Cu, Cv, act, int(u_nchw),
          ptr(u_act_src), u_act, ptr(tb), ptr(ws), ws.numel(), FMT_IN_BF3 if in_bf3 else 0,
          ptr(frag if frag is not None else wfrag(wup)), stream_ptr())
@@ -613,6 +639,8 @@ def conv3x3_f(X, wpack, bias, n, H, W, Cin, Cout, act=NONE, y_act_src=None, y_sr
 # ---- scaled-fp16 form of the register-stationary 3x3 kernels (csrc/bf3.hpp: 3 MFMAs per product instead of 6) --------------
 # MVK_C3_F16=0 (under MVK_TUNE=1) keeps every 3x3 convolution on the bf16-piece kernels.
 C3_F16 = _lib.tune("MVK_C3_F16", "1") != "0"
+# the same product form for the 4x4 / stride-2 layers of the SVHN decoder (csrc/imgconv.hip NP = 2); MVK_IMG_F16=0: bf16 pieces
+IMG_F16 = _lib.tune("MVK_IMG_F16", "1") != "0"
 
 
 class AmaxPool:
@@ -1066,9 +1094,28 @@ class SVHNDecoderFn(Function):
         # [L][C1] unflatten pack; [Cv=C1][Cu=C2]; [Cv=C2][Cu=C3]; [Cv=C3][Cu=C4] — one launch
         wp0, (wd1, wu1), (wd2, wu2), (wd3, _) = pack_weights(
             [(w0, "unflatten"), (w1, True, True), (w2, True, True), (w3, True, False)])
-        g1 = gemm(z2, wp0, n, 16 * C1, L, bias=b0, bias_mod=C1, act=RELU)  # [n,4,4,C1]
-        g2 = conv_up(g1, wu1, b1, n, 4, 4, C2, C1, RELU)  # [n,8,8,C2]
-        g3 = conv_up(g2, wu2, b2, n, 8, 8, C3, C2, RELU)  # [n,16,16,C3]
+        # scaled-fp16 form of the two 4x4/stride-2 layers (csrc/imgconv.hip NP = 2): every producer on the chain publishes the
+        # maximum of what it writes, the consumer scales by it (amax protocol; no pass over a tensor)
+        f16 = (IMG_F16 and conv4s2_scaled_ok(n, 4, 4, C2, C1) and conv4s2_scaled_ok(n, 8, 8, C3, C2)
+               and all(getattr(t, "mvk_amax", None) is not None for t in (wu1, wu2, wd1, wd2)))
+        ctx.f16 = f16
+        if f16:
+            pool = AmaxPool(z2, 4)
+            a1, a2 = pool.take(), pool.take()
+            if L <= 32 and (16 * C1) % 4 == 0:
+                g1 = _new((n, 16 * C1), z2)
+                call("mvk_gemm_smallk_amax", ptr(z2), ptr(wp0), ptr(g1), n, 16 * C1, L, 0, ptr(b0), C1, RELU, ptr(a1),
+                     stream_ptr())
+            else:
+                g1 = gemm(z2, wp0, n, 16 * C1, L, bias=b0, bias_mod=C1, act=RELU)
+                amax_of(g1, a1)
+            g2 = conv_up(g1, wu1, b1, n, 4, 4, C2, C1, RELU, amax=(a1, wu1.mvk_amax, a2))  # [n,8,8,C2]
+            g3 = conv_up(g2, wu2, b2, n, 8, 8, C3, C2, RELU, amax=(a2, wu2.mvk_amax, None))  # [n,16,16,C3]
+            ctx.wamax = (wd1.mvk_amax, wd2.mvk_amax)
+        else:
+            g1 = gemm(z2, wp0, n, 16 * C1, L, bias=b0, bias_mod=C1, act=RELU)  # [n,4,4,C1]
+            g2 = conv_up(g1, wu1, b1, n, 4, 4, C2, C1, RELU)  # [n,8,8,C2]
+            g3 = conv_up(g2, wu2, b2, n, 8, 8, C3, C2, RELU)  # [n,16,16,C3]
         out = _new((n, C4, 32, 32), z2)
         small = bool(_lib.load().mvk_conv4s2_small_up_supported(16, 16, C4, C3))
         ctx.fused = nll_x is not None
@@ -1103,8 +1150,14 @@ class SVHNDecoderFn(Function):
             dg3 = _new((n, 16, 16, C3), z2)
             ws = _ws(z2)
             tb2, db2 = _grad_target(b2)
-            call("mvk_conv4s2_small_up_bwd_pre", ptr(out), ptr(drows), ptr(g3), RELU, ptr(w3), ptr(dg3), ptr(tw3), ptr(tb3),
-                 ptr(tb2), ptr(ws), ws.numel(), n, 16, 16, C4, C3, stream_ptr())
+            if ctx.f16:
+                bpool = AmaxPool(z2, 4)
+                a_dg3 = bpool.take()
+                call("mvk_conv4s2_small_up_bwd_pre_y", ptr(out), ptr(drows), ptr(g3), RELU, ptr(w3), ptr(dg3), ptr(tw3), ptr(tb3),
+                     ptr(tb2), ptr(ws), ws.numel(), n, 16, 16, C4, C3, ptr(a_dg3), stream_ptr())
+            else:
+                call("mvk_conv4s2_small_up_bwd_pre", ptr(out), ptr(drows), ptr(g3), RELU, ptr(w3), ptr(dg3), ptr(tw3), ptr(tb3),
+                     ptr(tb2), ptr(ws), ws.numel(), n, 16, 16, C4, C3, stream_ptr())
         else:
             dout = _c(dout).view(out.shape)
         # last layer: dpre = dout * out(1-out) applied while loading
@@ -1131,12 +1184,19 @@ class SVHNDecoderFn(Function):
             dw2 = conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2)
         if not ctx.small and not ctx.fused:
             db2 = colsum(dg3.view(-1, C3), b2)
+        am2 = am1 = None
+        if ctx.f16:  # the bound of dg3 came with the fused-tail backward; without it the first launch stays on bf16 pieces
+            if not ctx.fused:
+                bpool, a_dg3 = AmaxPool(z2, 4), None
+            a_dg2 = bpool.take()
+            am2 = (a_dg3, ctx.wamax[1] if a_dg3 is not None else None, a_dg2)
+            am1 = (a_dg2, ctx.wamax[0], None)
         dg2, db1 = conv_down(dg3, wd2, None, n, 8, 8, C3, C2, NONE, v_act_src=g2, v_act=RELU, out_bias=b1,
-                             frag=ctx.frags[1])
+                             frag=ctx.frags[1], amax=am2)
         if not late.on:
             dw1 = conv_wgrad(dg2, g1, w1, n, 4, 4, C2, C1)
         dg1, db0 = conv_down(dg2, wd1, None, n, 4, 4, C2, C1, NONE, v_act_src=g1, v_act=RELU, out_bias=b0,
-                             frag=ctx.frags[0])
+                             frag=ctx.frags[0], amax=am1)
         dg1f = dg1.view(n, 16 * C1)
         tw0, dw0 = _grad_target(w0)
         dz = None

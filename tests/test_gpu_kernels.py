@@ -273,6 +273,62 @@ def test_imgconv_register_stationary_kernels(K, n, h, Cu, Cv):
     close(wg, Wr.grad, rtol=2e-6, what="imgconv wgrad")
 
 
+@pytest.mark.parametrize("n", [2, 130, 700])
+@pytest.mark.parametrize("h,Cu,Cv", [(8, 32, 64), (4, 64, 128)])
+@pytest.mark.parametrize("spread", [0.0, 3.0])
+def test_imgconv_scaled_fp16(K, n, h, Cu, Cv, spread):
+    """mvk_conv4s2_down_s / _up_s (csrc/imgconv.hip NP = 2): 3 fp16 MFMAs per product on scaled (hi, lo) pairs, weights
+    converted in the kernel from the fp32 pack with the maximum the pack launch published.  Same float64 reference and the
+    tolerance of test_imgconv_register_stationary_kernels, on unit-scale data and on data whose images spread over 8 orders of
+    magnitude; max |result| as published by the launch is exact; with y_amax alone the bf16-piece kernel publishes too."""
+    gen = g(h * 1000 + n + 7)
+    U = torch.randn(n, Cu, 2 * h, 2 * h, generator=gen) * torch.exp(spread * torch.randn(n, 1, 1, 1, generator=gen)) * 2.3
+    V = torch.randn(n, Cv, h, h, generator=gen) * torch.exp(spread * torch.randn(n, 1, 1, 1, generator=gen)) * 0.04
+    Wc = torch.randn(Cv, Cu, 4, 4, generator=gen) / math.sqrt(16 * Cu)
+    bu, bv = torch.randn(Cu, generator=gen), torch.randn(Cv, generator=gen)
+    Us, Vs = torch.randn(n, Cu, 2 * h, 2 * h, generator=gen), torch.randn(n, Cv, h, h, generator=gen)
+    d = dev()
+    wd, wu = K.pack_conv(Wc.to(d))
+    assert float(wd.mvk_amax) == float(Wc.abs().max()) and float(wu.mvk_amax) == float(Wc.abs().max())
+    pb_u, pb_v = torch.nn.Parameter(torch.zeros(Cu, device=d)), torch.nn.Parameter(torch.zeros(Cv, device=d))
+    Ud, Vd = nhwc(U).to(d), nhwc(V).to(d)
+    pool = K.AmaxPool(Ud, 16)
+    uam, vam = K.amax_of(Ud, pool.take()), K.amax_of(Vd, pool.take())
+    direct = K.DIRECT_GRAD
+    K.DIRECT_GRAD = False
+    _debug_flags(0x200)  # take the kernels for every batch size
+    try:
+        if h == 4 and n % 2:
+            assert not K.conv4s2_scaled_ok(n, h, h, Cu, Cv)
+            return
+        assert K.conv4s2_scaled_ok(n, h, h, Cu, Cv)
+        y1, y2, y3, y4, y5 = (pool.take() for _ in range(5))
+        up = K.conv_up(Vd, wu, bu.to(d), n, h, h, Cu, Cv, act=1, amax=(vam, wu.mvk_amax, y1))
+        up2, gb_u = K.conv_up(Vd, wu, None, n, h, h, Cu, Cv, u_act_src=nhwc(Us).to(d), u_act=1, out_bias=pb_u,
+                              amax=(vam, wu.mvk_amax, y2))
+        dn = K.conv_down(Ud, wd, bv.to(d), n, h, h, Cu, Cv, act=1, amax=(uam, wd.mvk_amax, y3))
+        dn2, gb_v = K.conv_down(Ud, wd, None, n, h, h, Cu, Cv, v_act_src=nhwc(Vs).to(d), v_act=1, out_bias=pb_v,
+                                amax=(uam, wd.mvk_amax, y4))
+        dn3 = K.conv_down(Ud, wd, bv.to(d), n, h, h, Cu, Cv, act=1, amax=(None, None, y5))  # bf16 pieces, publishing
+        torch.cuda.synchronize()
+    finally:
+        _debug_flags(0)
+        K.DIRECT_GRAD = direct
+    ref_up = F.conv_transpose2d(V.double(), Wc.double(), None, stride=2, padding=1)
+    ref_dn = F.conv2d(U.double(), Wc.double(), None, stride=2, padding=1)
+    close(nchw(up.cpu()), torch.relu(ref_up + bu.double().view(1, -1, 1, 1)), rtol=2e-6, what="imgconv up")
+    close(nchw(dn.cpu()), torch.relu(ref_dn + bv.double().view(1, -1, 1, 1)), rtol=2e-6, what="imgconv down")
+    close(nchw(dn3.cpu()), torch.relu(ref_dn + bv.double().view(1, -1, 1, 1)), rtol=2e-6, what="imgconv down, bf16 pieces")
+    ref_up2 = ref_up * (Us > 0)
+    ref_dn2 = ref_dn * (Vs > 0)
+    close(nchw(up2.cpu()), ref_up2, rtol=2e-6, what="imgconv up x mask")
+    close(nchw(dn2.cpu()), ref_dn2, rtol=2e-6, what="imgconv down x mask")
+    close(gb_u, ref_up2.sum((0, 2, 3)), rtol=1e-5, what="imgconv up column sums")
+    close(gb_v, ref_dn2.sum((0, 2, 3)), rtol=1e-5, what="imgconv down column sums")
+    for slot, t in ((y1, up), (y2, up2), (y3, dn), (y4, dn2), (y5, dn3)):
+        assert float(slot) == float(t.abs().max()), "published max |result|"
+
+
 # ------------------------------------------------------------------------------------------------------------
 # whole networks (single autograd nodes) against the oracle's functional networks
 # ------------------------------------------------------------------------------------------------------------
