@@ -399,6 +399,11 @@ int mvk_conv4s2_small_up_bwd_pre_y(const float* dpre, const float* rowscale, con
                                    float* dV, float* dWref, float* db, float* db_v, float* ws, int64_t ws_floats, int n, int h,
                                    int w, int Cu, int Cv, float* dv_amax, void* stream);
 int mvk_conv4s2_scaled_ok(int n, int h, int w, int Cu, int Cv);
+/* mvk_conv4s2_wgrad on scaled fp16 pairs (one accumulator per tile; V carries the 2^11 between main and cross terms in a third
+ * piece): u_amax / v_amax = device scalars >= max |U| / max |V|.  NHWC U, no fused activation. */
+int mvk_conv4s2_wgrad_scaled_ok(int n, int h, int w, int Cu, int Cv);
+int mvk_conv4s2_wgrad_s(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv, const float* u_amax,
+                        const float* v_amax, float* ws, int64_t ws_floats, void* stream);
 int mvk_conv4s2_down_s(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w, int Cu, int Cv,
                        int act, const float* v_act_src, int v_act, float* colsum_acc, const float* x_amax,
                        const float* w_amax, float* y_amax, float* ws, int64_t ws_floats, const void* wfrag, void* stream);

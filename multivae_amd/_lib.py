@@ -89,6 +89,7 @@ PROTOTYPES = {
     "mvk_conv3x3_wgrad_f": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _i64, _p],
     "mvk_conv3x3_s": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _f, _p, _i, _f, _p, _p, _p, _p, _i64, _p],
     "mvk_amax": [_p, _i64, _p, _p],
+    "mvk_conv4s2_wgrad_s": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i64, _p],
     "mvk_gemm_smallk_amax": [_p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p],
     "mvk_conv4s2_small_up_bwd_pre_y": [_p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p, _p],
     "mvk_conv4s2_down_s": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _i64, _p, _p],
@@ -175,6 +176,8 @@ def load(path=None):
     lib.mvk_conv3x3_wgrad_scaled_ok.restype = C.c_int
     lib.mvk_conv4s2_scaled_ok.argtypes = [_i, _i, _i, _i, _i]
     lib.mvk_conv4s2_scaled_ok.restype = C.c_int
+    lib.mvk_conv4s2_wgrad_scaled_ok.argtypes = [_i, _i, _i, _i, _i]
+    lib.mvk_conv4s2_wgrad_scaled_ok.restype = C.c_int
     lib.mvk_defer_wanted.argtypes = []
     lib.mvk_defer_wanted.restype = C.c_int64
     lib.mvk_defer_pending.argtypes = []
@@ -241,6 +244,7 @@ GEMM_FLOPS = {
     "mvk_conv3x3_wgrad_f": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
     "mvk_conv3x3_s": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
     "mvk_conv4s2_down_s": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
+    "mvk_conv4s2_wgrad_s": lambda a: 2.0 * a[3] * a[4] * a[5] * 16 * a[6] * a[7],
     "mvk_conv4s2_up_s": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
     "mvk_conv3x3_wgrad_s": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
     "mvk_conv4s2_up_nchw_small": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],

@@ -720,7 +720,7 @@ int imgconv_down(const float* U, const float* Wdown, const void* wfrag, const fl
 // MVK_IMGCONV=0 disables the kernels, MVK_IMGCONV=<n> sets the smallest batch that takes them (default 256 images);
 // mvk_debug_set_flags: bit 0x100 disables them, bit 0x200 takes them for every batch size (tests, A/B probes)
 int imgconv_wgrad(const float* U, const float* V, float* slab, long long slab_floats, int n, int h, int w, int Cu, int Cv,
-                  int* nz, hipStream_t s);
+                  int* nz, const float* u_amax, const float* v_amax, hipStream_t s);
 // Register-stationary 3x3 convolutions (conv3rs.hip); 1: shape not covered.  mvk_debug_set_flags: bit 0x400 disables them,
 // bit 0x800 takes them for every problem size (tests); MVK_C3RS=0 / MVK_C3RS=<min tiles> under MVK_TUNE=1.
 int c3rs_conv(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
@@ -1305,9 +1305,10 @@ static int conv3x3_wgrad_any(const float* X, const float* dY, float* dWref, floa
   return launch_splitk(d, ws, ws_floats, 1024, mvk_stream(stream));
 }
 
-int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv,
-                      int u_nchw, const float* u_act_src, int u_act, float* ws, int64_t ws_floats, void* stream) {
-  if (!U || !V || !dWref || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0) return MVK_EINVAL;
+static int conv4s2_wgrad_impl(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv,
+                              int u_nchw, const float* u_act_src, int u_act, float* ws, int64_t ws_floats,
+                              const float* u_amax, const float* v_amax, void* stream) {
+  if (!U || !V || !dWref || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0 || (!u_amax != !v_amax)) return MVK_EINVAL;
   if (u_nchw && !u_act_src && smallcin_supported(Cu, Cv)) {
     const int rc = smallcin_wgrad(U, V, dWref, n, h, w, Cu, Cv, ws, ws_floats, mvk_stream(stream));
     if (rc != 1) return rc;  // 1: scratch too small -> the implicit GEMM below
@@ -1317,11 +1318,12 @@ int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h
     int nz = 0;
     const long long slab_floats = 256ll * 16 * Cu * Cv;
     float* dslab = defer_scratch(dWref, slab_floats, mvk_stream(stream));
-    const int rc = imgconv_wgrad(U, V, dslab ? dslab : ws, dslab ? slab_floats : ws_floats, n, h, w, Cu, Cv, &nz,
-                                 mvk_stream(stream));
+    const int rc = imgconv_wgrad(U, V, dslab ? dslab : ws, dslab ? slab_floats : ws_floats, n, h, w, Cu, Cv, &nz, u_amax,
+                                 v_amax, mvk_stream(stream));
     if (rc == MVK_OK) return convref_reduce(dslab ? dslab : ws, nz, Cu, Cv, 16, dWref, mvk_stream(stream), dslab != nullptr);
     if (rc != 1) return rc;
   }
+  if (u_amax) return MVK_EINVAL;  // the scaled form exists in the register-stationary kernel only (mvk_conv4s2_wgrad_scaled_ok)
   GemmDesc d{};
   d.a = AOperand{};
   d.a.p = U;
@@ -1349,6 +1351,22 @@ int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h
   d.N = Cv;
   d.K = n * h * w;
   return launch_splitk(d, ws, ws_floats, 1024, mvk_stream(stream));
+}
+
+int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv,
+                      int u_nchw, const float* u_act_src, int u_act, float* ws, int64_t ws_floats, void* stream) {
+  return conv4s2_wgrad_impl(U, V, dWref, n, h, w, Cu, Cv, u_nchw, u_act_src, u_act, ws, ws_floats, nullptr, nullptr, stream);
+}
+
+// mvk_conv4s2_wgrad on scaled fp16 pairs (imgwgrad_kernel NP = 2: one accumulator per tile, V carries the 2^11 in a third
+// piece); u_amax / v_amax: device scalars >= max |U| / max |V|.  NHWC U, no fused activation.
+int mvk_conv4s2_wgrad_scaled_ok(int n, int h, int w, int Cu, int Cv) {
+  return n / 4 >= imgconv_min_images() && imgconv_pair(h, w, Cu, Cv) && (h != 4 || n % 2 == 0) ? 1 : 0;
+}
+int mvk_conv4s2_wgrad_s(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv, const float* u_amax,
+                        const float* v_amax, float* ws, int64_t ws_floats, void* stream) {
+  if (!u_amax || !v_amax || !ws || !mvk_conv4s2_wgrad_scaled_ok(n, h, w, Cu, Cv)) return MVK_EINVAL;
+  return conv4s2_wgrad_impl(U, V, dWref, n, h, w, Cu, Cv, 0, nullptr, MVK_ACT_NONE, ws, ws_floats, u_amax, v_amax, stream);
 }
 
 // dWref[ci][co][4][4] += z[n,ci]^T dY[n,(tap,co)]  (ConvTranspose2d(L,C,4,1,0) on a 1x1 input)

@@ -781,7 +781,10 @@ static int imgconv_launch(const ImgConvArgs& a, int* part_rows, hipStream_t s) {
 //     takes one kernel row per workgroup type, one tap per wave;
 //   * a workgroup walks its share of the images once, one s_barrier per stage unit, and writes its partial gradient
 //     as one slab; the slabs are summed in a fixed order (deterministic) into the reference layout.
-template <int HS, int CU, int CV>
+// NP = 3: bf16 pieces (U and V three planes each, 6 MFMAs per product).  NP = 2: scaled fp16 with ONE accumulator per tile
+// (the eight tiles leave no registers for a second one; see c3wg_kernel): U as (uh, ul) = 2 planes, V as (vh, vH, vl) = 3
+// planes, acc += uh vH + uh vl + ul vh = 2^11 su sv u v.
+template <int HS, int CU, int CV, int NP = 3>
 struct WCfg {
   static constexpr int PIX = HS * HS, AW = 2 * HS;
   static constexpr bool SPLIT_KH = (CU * CV > 32 * 64);          // one kernel row per workgroup type
@@ -802,8 +805,8 @@ struct WCfg {
   static constexpr int PAD = SPLIT_KH ? MVK_IW_PAD_A : MVK_IW_PAD_B;  // row padding (bytes) of the LDS images
   static constexpr int SUB = CU * 2 + PAD, SVB = CV * 2 + PAD;   // bytes per LDS row
   static constexpr int PLANE_U = (UROWS + 1) * SUB, PLANE_V = VROWS * SVB;
-  static constexpr int OFF_V = 3 * PLANE_U;
-  static constexpr int BUF = 3 * (PLANE_U + PLANE_V);
+  static constexpr int OFF_V = NP * PLANE_U;
+  static constexpr int BUF = NP * PLANE_U + 3 * PLANE_V;
   static constexpr int NFU = UROWS * CU / 4 / 256, NFV = VROWS * CV / 4 / 256;
   static constexpr int NF = NFU + NFV;
   static constexpr int LDS_BYTES = 2 * BUF;
@@ -815,11 +818,21 @@ struct WCfg {
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ bf16x8 ic_tr_pair(const char* p0, const char* p1) {
-  typedef __attribute__((address_space(3))) bf16x4* lp;
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p0));
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p1));
-  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+typedef _Float16 ic_f16x4 __attribute__((ext_vector_type(4)));
+template <typename F>
+__device__ __forceinline__ F ic_tr_pair(const char* p0, const char* p1) {
+  if constexpr (std::is_same<F, bf16x8>::value) {
+    typedef __attribute__((address_space(3))) bf16x4* lp;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p1));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  } else {
+    typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+    typedef __attribute__((address_space(3))) h4* lp;
+    const ic_f16x4 lo = __builtin_bit_cast(ic_f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(p0)));
+    const ic_f16x4 hi = __builtin_bit_cast(ic_f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(p1)));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
 }
 
 struct ImgWgradArgs {
@@ -828,11 +841,17 @@ struct ImgWgradArgs {
   float* slab;     // [workers][16 * CU][CV] partial gradients
   int n;
   mvk_prof_slot* prof;
+  const float* u_amax;  // scaled-fp16 form: device scalars bounding max |U| and max |V|
+  const float* v_amax;
 };
 
-template <int HS, int CU, int CV>
+template <int HS, int CU, int CV, int NP = 3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void imgwgrad_kernel(const ImgWgradArgs g) {
-  using T = WCfg<HS, CU, CV>;
+  using T = WCfg<HS, CU, CV, NP>;
+  using frag = std::conditional_t<NP == 3, bf16x8, f16x8>;
+  constexpr int NPU = NP, NPV = 3;  // planes of U / V
+  const float su = NP == 2 ? f16_scale_of(*g.u_amax) : 1.f;
+  const float sv = NP == 2 ? f16_scale_of(*g.v_amax) * (1.f / 1024.f) : 1.f, sv11 = sv * 2048.f;  // max |V| sv in [2^3, 2^4)
   extern __shared__ __attribute__((aligned(16))) char lds[];
   mvk_prof_begin(g.prof);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -840,10 +859,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int worker = blockIdx.x / T::WG_TYPES, workers = gridDim.x / T::WG_TYPES;
   const int kh = T::SPLIT_KH ? wgtype : wave;
 
-  // zero rows of the three U planes of both buffers
-  for (int i = tid; i < 2 * 3 * (T::SUB / 4); i += 256) {
+  // zero rows of the U planes of both buffers
+  for (int i = tid; i < 2 * NPU * (T::SUB / 4); i += 256) {
     const int pl = i / (T::SUB / 4), w = i % (T::SUB / 4);
-    *reinterpret_cast<unsigned*>(lds + (pl / 3) * T::BUF + (pl % 3) * T::PLANE_U + T::UROWS * T::SUB + w * 4) = 0u;
+    *reinterpret_cast<unsigned*>(lds + (pl / NPU) * T::BUF + (pl % NPU) * T::PLANE_U + T::UROWS * T::SUB + w * 4) = 0u;
   }
   // transposing-read addresses: 16-lane group gq reads [4 pixels][16 channels]; lane lp supplies pixel (lp >> 2),
   // channels 4 (lp & 3) .. +3 and receives channel lp of the block, pixels 0..3
@@ -902,13 +921,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     raw[k] = base[ssrc[k]];
   };
   auto write_f4 = [&](char* buf, int k) {
-    unsigned a0, a1, a2, b0, b1, b2;
-    bf3_split(raw[k][0], raw[k][1], a0, a1, a2);
-    bf3_split(raw[k][2], raw[k][3], b0, b1, b2);
     const int pl = k < T::NFU ? T::PLANE_U : T::PLANE_V;
-    *reinterpret_cast<u32x2*>(buf + sdst[k]) = u32x2{a0, b0};
-    *reinterpret_cast<u32x2*>(buf + pl + sdst[k]) = u32x2{a1, b1};
-    *reinterpret_cast<u32x2*>(buf + 2 * pl + sdst[k]) = u32x2{a2, b2};
+    if constexpr (NP == 3) {
+      unsigned a0, a1, a2, b0, b1, b2;
+      bf3_split(raw[k][0], raw[k][1], a0, a1, a2);
+      bf3_split(raw[k][2], raw[k][3], b0, b1, b2);
+      *reinterpret_cast<u32x2*>(buf + sdst[k]) = u32x2{a0, b0};
+      *reinterpret_cast<u32x2*>(buf + pl + sdst[k]) = u32x2{a1, b1};
+      *reinterpret_cast<u32x2*>(buf + 2 * pl + sdst[k]) = u32x2{a2, b2};
+    } else if (k < T::NFU) {  // U: (uh, ul)
+      unsigned a0, a1, b0, b1;
+      f16_split(raw[k][0] * su, raw[k][1] * su, a0, a1);
+      f16_split(raw[k][2] * su, raw[k][3] * su, b0, b1);
+      *reinterpret_cast<u32x2*>(buf + sdst[k]) = u32x2{a0, b0};
+      *reinterpret_cast<u32x2*>(buf + pl + sdst[k]) = u32x2{a1, b1};
+    } else {  // V: planes (vh, vH = fp16(v sv 2^11), vl = fp16(v sv 2^11 - vH))
+      const f32x4 r = raw[k];
+      const f16x2 h01 = __builtin_convertvector(f32x2{r[0] * sv, r[1] * sv}, f16x2), h23 = __builtin_convertvector(f32x2{r[2] * sv, r[3] * sv}, f16x2);
+      const float q0 = r[0] * sv11, q1 = r[1] * sv11, q2 = r[2] * sv11, q3 = r[3] * sv11;
+      const f16x2 H01 = __builtin_convertvector(f32x2{q0, q1}, f16x2), H23 = __builtin_convertvector(f32x2{q2, q3}, f16x2);
+      const f16x2 l01 = __builtin_convertvector(f32x2{q0 - (float)H01[0], q1 - (float)H01[1]}, f16x2);
+      const f16x2 l23 = __builtin_convertvector(f32x2{q2 - (float)H23[0], q3 - (float)H23[1]}, f16x2);
+      *reinterpret_cast<u32x2*>(buf + sdst[k]) = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+      *reinterpret_cast<u32x2*>(buf + pl + sdst[k]) = u32x2{__builtin_bit_cast(unsigned, H01), __builtin_bit_cast(unsigned, H23)};
+      *reinterpret_cast<u32x2*>(buf + 2 * pl + sdst[k]) = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+    }
   };
 
   f32x16 acc[T::MT][T::NT];
@@ -927,17 +964,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   __syncthreads();
 
-  bf16x8 Af[T::MT][3], Bf[T::NT][3];
-  auto read_frags = [&](bf16x8 (&A)[T::MT][3], bf16x8 (&B)[T::NT][3], const char* buf, int s) {
+  frag Af[T::MT][NPU], Bf[T::NT][NPV];
+  auto read_frags = [&](frag (&A)[T::MT][NPU], frag (&B)[T::NT][NPV], const char* buf, int s) {
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) {
 #pragma unroll
       for (int b = 0; b < T::NT; ++b)
-        B[b][pc] = ic_tr_pair(buf + vaddr[s][0] + pc * T::PLANE_V + b * 64, buf + vaddr[s][1] + pc * T::PLANE_V + b * 64);
+        B[b][pc] = ic_tr_pair<frag>(buf + vaddr[s][0] + pc * T::PLANE_V + b * 64, buf + vaddr[s][1] + pc * T::PLANE_V + b * 64);
+      if (pc < NPU) {
 #pragma unroll
-      for (int a = 0; a < T::MT; ++a) {
-        const int q = T::SPLIT_KH ? 0 : a, co = T::SPLIT_KH ? a * 64 : 0;
-        A[a][pc] = ic_tr_pair(buf + uaddr[s][0][q] + pc * T::PLANE_U + co, buf + uaddr[s][1][q] + pc * T::PLANE_U + co);
+        for (int a = 0; a < T::MT; ++a) {
+          const int q = T::SPLIT_KH ? 0 : a, co = T::SPLIT_KH ? a * 64 : 0;
+          A[a][pc] = ic_tr_pair<frag>(buf + uaddr[s][0][q] + pc * T::PLANE_U + co, buf + uaddr[s][1][q] + pc * T::PLANE_U + co);
+        }
       }
     }
   };
@@ -949,7 +988,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     char* const nbuf = lds + (cur ^ 1) * T::BUF;
 #pragma unroll
     for (int s = 0; s < T::KS; ++s) {
-      bf16x8 An[T::MT][3], Bn[T::NT][3];
+      frag An[T::MT][NPU], Bn[T::NT][NPV];
       if (s + 1 < T::KS) read_frags(An, Bn, abuf, s + 1);
       constexpr int PER = T::NF / T::KS;
 #pragma unroll
@@ -957,29 +996,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         write_f4(nbuf, k);
         load_f4(u + 2, k);
       }
-      constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {2, 1, 0, 1, 0, 0};  // small terms first
+      if constexpr (NP == 3) {
+        constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {2, 1, 0, 1, 0, 0};  // small terms first
 #pragma unroll
-      for (int m = 0; m < 6; ++m)
+        for (int m = 0; m < 6; ++m)
 #pragma unroll
-        for (int a = 0; a < T::MT; ++a)
+          for (int a = 0; a < T::MT; ++a)
 #pragma unroll
-          for (int b = 0; b < T::NT; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[a][PA[m]], Bf[b][PB[m]], acc[a][b], 0, 0, 0);
+            for (int b = 0; b < T::NT; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[a][PA[m]], Bf[b][PB[m]], acc[a][b], 0, 0, 0);
+      } else {
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 2, 1};  // ul vh, uh vl, uh vH
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+          for (int a = 0; a < T::MT; ++a)
+#pragma unroll
+            for (int b = 0; b < T::NT; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[a][PA[m]], Bf[b][PB[m]], acc[a][b], 0, 0, 0);
+      }
 #ifndef MVK_IW_SCHED
 #define MVK_IW_SCHED 4
 #endif
       if (MVK_IW_SCHED > 0) {  // "1 MFMA, N others" instead of hipcc's MFMA clusters (see imgconv_kernel)
 #pragma unroll
-        for (int m = 0; m < 6 * T::MT * T::NT; ++m) {
+        for (int m = 0; m < 2 * NP * T::MT * T::NT; ++m) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x496, MVK_IW_SCHED > 0 ? MVK_IW_SCHED : 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x496, (MVK_IW_SCHED > 0 ? MVK_IW_SCHED : 1) * (NP == 3 ? 1 : 2), 0);
         }
       }
       if (s + 1 < T::KS) {
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) {
+          if (pc < NPU) {
 #pragma unroll
-          for (int a = 0; a < T::MT; ++a) Af[a][pc] = An[a][pc];
+            for (int a = 0; a < T::MT; ++a) Af[a][pc] = An[a][pc];
+          }
 #pragma unroll
           for (int b = 0; b < T::NT; ++b) Bf[b][pc] = Bn[b][pc];
         }
@@ -992,6 +1044,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // partial gradient of this workgroup: slab[worker][(tap * CU + cu)][cv]
   float* const slab = g.slab + (long long)worker * 16 * CU * CV;
   const int col = lane & 31, kg = lane >> 5;
+  const float oa = NP == 2 ? f16_inv_scale(su) : 1.f, ob = NP == 2 ? f16_inv_scale(sv) * (1.f / 2048.f) : 1.f;
 #pragma unroll
   for (int a = 0; a < T::MT; ++a) {
     const int kw = T::SPLIT_KH ? wave : a, cut = T::SPLIT_KH ? a : 0;
@@ -1001,17 +1054,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int cu = cut * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-        slab[(long long)(tap * CU + cu) * CV + b * 32 + col] = acc[a][b][r];
+        slab[(long long)(tap * CU + cu) * CV + b * 32 + col] = NP == 2 ? acc[a][b][r] * oa * ob : acc[a][b][r];
       }
   }
   mvk_prof_end(g.prof);
 }
 
+template <int HS, int CU, int CV, int NP>
+static int imgwgrad_launch_np(const ImgWgradArgs& a, int* nz, hipStream_t s);
 template <int HS, int CU, int CV>
 static int imgwgrad_launch(const ImgWgradArgs& a, int* nz, hipStream_t s) {
-  using T = WCfg<HS, CU, CV>;
+  return a.u_amax && a.v_amax ? imgwgrad_launch_np<HS, CU, CV, 2>(a, nz, s) : imgwgrad_launch_np<HS, CU, CV, 3>(a, nz, s);
+}
+template <int HS, int CU, int CV, int NP>
+static int imgwgrad_launch_np(const ImgWgradArgs& a, int* nz, hipStream_t s) {
+  using T = WCfg<HS, CU, CV, NP>;
   static bool attr_done = false;
-  auto kern = imgwgrad_kernel<HS, CU, CV>;
+  auto kern = imgwgrad_kernel<HS, CU, CV, NP>;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             T::LDS_BYTES) != hipSuccess)
@@ -1033,9 +1092,9 @@ static int imgwgrad_launch(const ImgWgradArgs& a, int* nz, hipStream_t s) {
 
 // slab: [*nz][16 Cu][Cv] partial gradients (needs 256 / types * 16 Cu Cv floats); 1: shape not covered
 int imgconv_wgrad(const float* U, const float* V, float* slab, long long slab_floats, int n, int h, int w, int Cu, int Cv,
-                  int* nz, hipStream_t s) {
+                  int* nz, const float* u_amax, const float* v_amax, hipStream_t s) {
   if (h != w) return 1;
-  ImgWgradArgs a{U, V, slab, n, nullptr};
+  ImgWgradArgs a{U, V, slab, n, nullptr, u_amax, v_amax};
   if (h == 8 && Cu == 32 && Cv == 64 && slab_floats >= 256ll * 16 * Cu * Cv) return imgwgrad_launch<8, 32, 64>(a, nz, s);
   if (h == 4 && Cu == 64 && Cv == 128 && n % 2 == 0 && slab_floats >= 64ll * 16 * Cu * Cv)
     return imgwgrad_launch<4, 64, 128>(a, nz, s);

@@ -820,9 +820,15 @@ def axpby(x, a, y, b, act=NONE, out=None):
     return out
 
 
-def conv_wgrad(U, V, wparam, n, h, w, Cu, Cv, u_nchw=False, u_act_src=None, u_act=NONE):
+def conv_wgrad(U, V, wparam, n, h, w, Cu, Cv, u_nchw=False, u_act_src=None, u_act=NONE, amax=None):
+    """amax = (u_amax, v_amax): the scaled-fp16 launch (mvk_conv4s2_wgrad_s) where mvk_conv4s2_wgrad_scaled_ok says so."""
     dw, rw = _grad_target(wparam)
     ws = _ws(V)
+    if (amax is not None and amax[0] is not None and amax[1] is not None and not u_nchw and u_act_src is None
+            and _lib.load().mvk_conv4s2_wgrad_scaled_ok(n, h, w, Cu, Cv)):
+        call("mvk_conv4s2_wgrad_s", ptr(U), ptr(V), ptr(dw), n, h, w, Cu, Cv, ptr(amax[0]), ptr(amax[1]), ptr(ws), ws.numel(),
+             stream_ptr())
+        return rw
     call("mvk_conv4s2_wgrad", ptr(U), ptr(V), ptr(dw), n, h, w, Cu, Cv, int(u_nchw), ptr(u_act_src), u_act,
          ptr(ws), ws.numel(), stream_ptr())
     return rw
@@ -1112,6 +1118,7 @@ class SVHNDecoderFn(Function):
             g2 = conv_up(g1, wu1, b1, n, 4, 4, C2, C1, RELU, amax=(a1, wu1.mvk_amax, a2))  # [n,8,8,C2]
             g3 = conv_up(g2, wu2, b2, n, 8, 8, C3, C2, RELU, amax=(a2, wu2.mvk_amax, None))  # [n,16,16,C3]
             ctx.wamax = (wd1.mvk_amax, wd2.mvk_amax)
+            ctx.gamax = (a1, a2)  # bounds of g1, g2: the V operands of the two weight gradients
         else:
             g1 = gemm(z2, wp0, n, 16 * C1, L, bias=b0, bias_mod=C1, act=RELU)  # [n,4,4,C1]
             g2 = conv_up(g1, wu1, b1, n, 4, 4, C2, C1, RELU)  # [n,8,8,C2]
@@ -1179,22 +1186,23 @@ class SVHNDecoderFn(Function):
                  stream_ptr())
             dg3 = conv_down(dout, wd3, None, n, 16, 16, C4, C3, NONE, u_nchw=True, u_act_src=out, u_act=SIGMOID,
                             v_act_src=g3, v_act=RELU)
-        late = late_leaves(z2.device, dg3, g2, g1, z2)
-        if not late.on:
-            dw2 = conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2)
-        if not ctx.small and not ctx.fused:
-            db2 = colsum(dg3.view(-1, C3), b2)
-        am2 = am1 = None
+        am2 = am1 = wam2 = wam1 = None
         if ctx.f16:  # the bound of dg3 came with the fused-tail backward; without it the first launch stays on bf16 pieces
             if not ctx.fused:
                 bpool, a_dg3 = AmaxPool(z2, 4), None
             a_dg2 = bpool.take()
             am2 = (a_dg3, ctx.wamax[1] if a_dg3 is not None else None, a_dg2)
             am1 = (a_dg2, ctx.wamax[0], None)
+            wam2, wam1 = (a_dg3, ctx.gamax[1]), (a_dg2, ctx.gamax[0])  # (max |U|, max |V|) of the two weight gradients
+        late = late_leaves(z2.device, dg3, g2, g1, z2)
+        if not late.on:
+            dw2 = conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2, amax=wam2)
+        if not ctx.small and not ctx.fused:
+            db2 = colsum(dg3.view(-1, C3), b2)
         dg2, db1 = conv_down(dg3, wd2, None, n, 8, 8, C3, C2, NONE, v_act_src=g2, v_act=RELU, out_bias=b1,
                              frag=ctx.frags[1], amax=am2)
         if not late.on:
-            dw1 = conv_wgrad(dg2, g1, w1, n, 4, 4, C2, C1)
+            dw1 = conv_wgrad(dg2, g1, w1, n, 4, 4, C2, C1, amax=wam1)
         dg1, db0 = conv_down(dg2, wd1, None, n, 4, 4, C2, C1, NONE, v_act_src=g1, v_act=RELU, out_bias=b0,
                              frag=ctx.frags[0], amax=am1)
         dg1f = dg1.view(n, 16 * C1)
@@ -1206,8 +1214,8 @@ class SVHNDecoderFn(Function):
             dg2.record_stream(_side_stream(z2.device, 30))
             dg1.record_stream(_side_stream(z2.device, 30))
             with late:
-                dw2 = conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2)
-                dw1 = conv_wgrad(dg2, g1, w1, n, 4, 4, C2, C1)
+                dw2 = conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2, amax=wam2)
+                dw1 = conv_wgrad(dg2, g1, w1, n, 4, 4, C2, C1, amax=wam1)
                 ws = _ws(z2)
                 call("mvk_unflatten_wgrad", ptr(z2), ptr(dg1f), ptr(tw0), n, L, C1, ptr(ws), ws.numel(), stream_ptr())
             if dw0 is not None or dw1 is not None or dw2 is not None:  # a gradient autograd itself accumulates: join now

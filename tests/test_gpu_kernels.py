@@ -310,6 +310,9 @@ def test_imgconv_scaled_fp16(K, n, h, Cu, Cv, spread):
         dn2, gb_v = K.conv_down(Ud, wd, None, n, h, h, Cu, Cv, v_act_src=nhwc(Vs).to(d), v_act=1, out_bias=pb_v,
                                 amax=(uam, wd.mvk_amax, y4))
         dn3 = K.conv_down(Ud, wd, bv.to(d), n, h, h, Cu, Cv, act=1, amax=(None, None, y5))  # bf16 pieces, publishing
+        wg = None
+        if n >= 4:  # imgwgrad_kernel NP = 2 (one accumulator per tile, V in three pieces); loose bounds on purpose
+            wg = K.conv_wgrad(Ud, Vd, Wc.to(d), n, h, h, Cu, Cv, amax=((uam * 3.0).contiguous(), (vam * 20.0).contiguous()))
         torch.cuda.synchronize()
     finally:
         _debug_flags(0)
@@ -327,6 +330,10 @@ def test_imgconv_scaled_fp16(K, n, h, Cu, Cv, spread):
     close(gb_v, ref_dn2.sum((0, 2, 3)), rtol=1e-5, what="imgconv down column sums")
     for slot, t in ((y1, up), (y2, up2), (y3, dn), (y4, dn2), (y5, dn3)):
         assert float(slot) == float(t.abs().max()), "published max |result|"
+    if wg is not None:
+        Wr = Wc.double().clone().requires_grad_()
+        (F.conv2d(U.double(), Wr, None, stride=2, padding=1) * V.double()).sum().backward()
+        close(wg, Wr.grad, rtol=2e-6, what="imgconv wgrad, scaled fp16")
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
                                     "mvk_imgconv_frag_bytes",
                                     "mvk_debug_set_phase_buffer", "mvk_debug_set_flags",  # void hooks, bound ad hoc
                                     "mvk_prof_enable", "mvk_prof_count", "mvk_prof_clock_khz", "mvk_prof_calibrate",
-                                    "mvk_defer_pending", "mvk_defer_wanted", "mvk_conv3x3_fused_ok", "mvk_conv3x3_scaled_ok", "mvk_conv3x3_wgrad_scaled_ok", "mvk_conv4s2_scaled_ok"}
+                                    "mvk_defer_pending", "mvk_defer_wanted", "mvk_conv3x3_fused_ok", "mvk_conv3x3_scaled_ok", "mvk_conv3x3_wgrad_scaled_ok", "mvk_conv4s2_scaled_ok", "mvk_conv4s2_wgrad_scaled_ok"}
     assert declared == bound, (declared - bound, bound - declared)
     assert lib.mvk_version() >= 100
 
