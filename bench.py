@@ -581,9 +581,11 @@ def main():
         if conv:
             ach = conv["work"] / conv["seconds"] / 1e12
             m_tf, m_us = measured_mfma_tflops(device, 1e6 * conv["seconds"] / conv["launches"])
-            # the 3x3 kernels of the ResNet configurations run the scaled-fp16 form (csrc/bf3.hpp): 3 fp16 MFMAs per fp32
+            # the register-stationary kernels run the scaled-fp16 form (csrc/bf3.hpp): 3 fp16 MFMAs per fp32
             # product instead of the 6 bf16 ones — their ceiling is 2500 / 3 (fp16 and bf16 MFMAs run at the same rate)
-            prods = 3 if (conv3 and kernels.C3_F16) else 6
+            # (the headline's six decoder launches at n = K B take the same form since the second half of round 3; the four
+            # encoder launches at n = B, 1/10 of the FLOPs, still use bf16 pieces)
+            prods = 3 if ((conv3 and kernels.C3_F16) or (not conv3 and kernels.IMG_F16)) else 6
             KPEAK = MFMA_BF16_TFLOPS / prods
             mf.update({"kernel_mfmas_per_fp32_product": prods, "kernel_peak": round(KPEAK, 1),
                        "measured_sustained_bf16": round(m_tf, 1), "measured_sustained_fp32_equiv": round(m_tf / prods, 1),

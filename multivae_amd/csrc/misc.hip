@@ -30,32 +30,38 @@ __global__ void pack_conv4s2_kernel(const float* __restrict__ Wref, int Cv, int 
 struct PackJobs {
   mvk_pack_desc j[MVK_PACK_MAX];
 };
+// max |Wref| of a descriptor (the weight's scale for the scaled-fp16 kernels, bf3.hpp): the first 8 workgroups of the descriptor
+// read the (L2-resident) weight once more and publish — 8 atomics per weight instead of one per workgroup of the launch (2304
+// same-address atomics made the 13-us launch 32 us)
+__device__ __forceinline__ void pack_amax(const mvk_pack_desc& d, int total, float* red) {
+  if (!d.amax || blockIdx.x >= 8) return;  // uniform per workgroup
+  float m = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += 8 * 256) m = fmaxf(m, fabsf(d.Wref[i]));
+  mvk::amax_publish(m, d.amax, red);
+}
+
 __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs jobs) {
   __shared__ float amax_red[4];
   const mvk_pack_desc& d = jobs.j[blockIdx.y];
   if (d.kind == 2) {  // 3x3: Wref[cv][cu][3][3] -> Wdown[(tap*Cu + cu)][cv] (forward), Wup[((8-tap)*Cv + cv)][cu] (bwd data)
     const int total9 = d.Cv * d.Cu * 9;
-    float m = 0.f;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total9; idx += gridDim.x * 256) {
       const int tap = idx % 9;
       const int cu = (idx / 9) % d.Cu;
       const int cv = (idx / 9) / d.Cu;
       const float v = d.Wref[idx];
-      m = fmaxf(m, fabsf(v));
       if (d.Wdown) d.Wdown[(long long)(tap * d.Cu + cu) * d.ld_down + d.col_off + cv] = v;
       if (d.Wup) d.Wup[(long long)((8 - tap) * d.Cv + cv) * d.Cu + cu] = v;
     }
-    if (d.amax) mvk::amax_publish(m, d.amax, amax_red);  // the weight's scale for the scaled-fp16 kernels (bf3.hpp)
+    pack_amax(d, total9, amax_red);
     return;
   }
   const int total = d.Cv * d.Cu * 16;
-  float wmax = 0.f;
   for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
     const int tap = idx & 15;
     const int cu = (idx >> 4) % d.Cu;
     const int cv = (idx >> 4) / d.Cu;
     const float v = d.Wref[idx];
-    wmax = fmaxf(wmax, fabsf(v));
     if (d.kind == 1) {
       d.Wup[(long long)cv * 16 * d.Cu + tap * d.Cu + cu] = v;
       continue;
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs jobs) {
       }
     }
   }
-  if (d.amax) mvk::amax_publish(wmax, d.amax, amax_red);
+  pack_amax(d, total, amax_red);
 }
 
 // Wref[ci][co][tap] -> Wp[ci][tap*Cout + co]
