@@ -501,7 +501,7 @@ def _pack_launch(jobs):
     am = None
     # max |W| per convolution weight: the operand scale of the scaled-fp16 launches (mvk_conv3x3_s, mvk_conv4s2_down_s / _up_s)
     if (C3_F16 and any(job[1] == "c3" for job in jobs)) or (IMG_F16 and any(job[1] not in ("c3", "unflatten") for job in jobs)):
-        am = torch.zeros(len(jobs), dtype=torch.float32, device=jobs[0][0].device)
+        am = _amax_slots(jobs[0][0], len(jobs), create=True)
     for i, job in enumerate(jobs):
         wref = job[0]
         Cv, Cu = wref.shape[0], wref.shape[1]
@@ -643,12 +643,27 @@ C3_F16 = _lib.tune("MVK_C3_F16", "1") != "0"
 IMG_F16 = _lib.tune("MVK_IMG_F16", "1") != "0"
 
 
+def _amax_slots(like, n, create=False):
+    """n zeroed device scalars.  Inside a pack_scope they are carved from ONE arena that the scope's pack launch creates in
+    front of itself (create=True): every stream that may read a pack is ordered behind that launch, hence behind the fill —
+    one fill per forward pass instead of one per pool, all of them on the step's critical chain."""
+    sc = _PACK_SCOPE
+    if sc is not None:
+        if create and sc.get("amax") is None:
+            sc["amax"], sc["amax_pos"] = torch.zeros(256, dtype=torch.float32, device=like.device), 0
+        ar = sc.get("amax")
+        if ar is not None and ar.device == like.device and sc["amax_pos"] + n <= ar.numel():
+            sc["amax_pos"] += n
+            return ar[sc["amax_pos"] - n:sc["amax_pos"]]
+    return torch.zeros(n, dtype=torch.float32, device=like.device)
+
+
 class AmaxPool:
     """Zeroed device scalars for the `amax` protocol (one fill launch per pool): a launch publishes max |Y| into a slot by
     atomic max, the launch that consumes Y takes its operand scale from it.  A slot is used by ONE producer."""
 
     def __init__(self, like, slots):
-        self.t = torch.zeros(slots, dtype=torch.float32, device=like.device)
+        self.t = _amax_slots(like, slots)
         self.i = 0
 
     def take(self):
@@ -1108,6 +1123,7 @@ class SVHNDecoderFn(Function):
         if f16:
             pool = AmaxPool(z2, 4)
             a1, a2 = pool.take(), pool.take()
+            ctx.bslots = (pool.take(), pool.take())  # the backward pass's two slots: no fill launch there
             if L <= 32 and (16 * C1) % 4 == 0:
                 g1 = _new((n, 16 * C1), z2)
                 call("mvk_gemm_smallk_amax", ptr(z2), ptr(wp0), ptr(g1), n, 16 * C1, L, 0, ptr(b0), C1, RELU, ptr(a1),
@@ -1158,8 +1174,7 @@ class SVHNDecoderFn(Function):
             ws = _ws(z2)
             tb2, db2 = _grad_target(b2)
             if ctx.f16:
-                bpool = AmaxPool(z2, 4)
-                a_dg3 = bpool.take()
+                a_dg3 = ctx.bslots[0]
                 call("mvk_conv4s2_small_up_bwd_pre_y", ptr(out), ptr(drows), ptr(g3), RELU, ptr(w3), ptr(dg3), ptr(tw3), ptr(tb3),
                      ptr(tb2), ptr(ws), ws.numel(), n, 16, 16, C4, C3, ptr(a_dg3), stream_ptr())
             else:
@@ -1189,8 +1204,8 @@ class SVHNDecoderFn(Function):
         am2 = am1 = wam2 = wam1 = None
         if ctx.f16:  # the bound of dg3 came with the fused-tail backward; without it the first launch stays on bf16 pieces
             if not ctx.fused:
-                bpool, a_dg3 = AmaxPool(z2, 4), None
-            a_dg2 = bpool.take()
+                a_dg3 = None
+            a_dg2 = ctx.bslots[1]
             am2 = (a_dg3, ctx.wamax[1] if a_dg3 is not None else None, a_dg2)
             am1 = (a_dg2, ctx.wamax[0], None)
             wam2, wam1 = (a_dg3, ctx.gamax[1]), (a_dg2, ctx.gamax[0])  # (max |U|, max |V|) of the two weight gradients
