@@ -121,10 +121,16 @@ def prof(which, n=5120, reps=5):
         wd, wu = K.pack_conv(Wc)
         pb = torch.nn.Parameter(torch.zeros(Cv, device=d))
         K.DIRECT_GRAD = False
+        pool = K.AmaxPool(Ud, 8)
+        uam, vam, y = K.amax_of(Ud, pool.take()), K.amax_of(Vd, pool.take()), pool.take()
         for _ in range(reps):
             K.conv_up(Vd, wu, bu, n, h, h, Cu, Cv, act=1)
             K.conv_down(Ud, wd, None, n, h, h, Cu, Cv, v_act_src=Vd, v_act=1, out_bias=pb)
             K.conv_wgrad(Ud, Vd, Wc, n, h, h, Cu, Cv)
+            if which == "new":  # the same launches on scaled fp16 pairs (NP = 2 kernels)
+                K.conv_up(Vd, wu, bu, n, h, h, Cu, Cv, act=1, amax=(vam, wu.mvk_amax, y))
+                K.conv_down(Ud, wd, None, n, h, h, Cu, Cv, v_act_src=Vd, v_act=1, out_bias=pb, amax=(uam, wd.mvk_amax, y))
+                K.conv_wgrad(Ud, Vd, Wc, n, h, h, Cu, Cv, amax=(uam, vam))
         torch.cuda.synchronize()
 
 

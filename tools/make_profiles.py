@@ -83,7 +83,8 @@ with open(f"{DST}/{TAG}_pmc_mfma.md", "w") as f:
                     v["SQ_ACTIVE_INST_ANY"] / v["SQ_WAVE_CYCLES"], v["SQ_WAIT_INST_ANY"] / v["SQ_WAVE_CYCLES"],
                     v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], v["SQ_INSTS_VALU"] / v["SQ_INSTS_MFMA"],
                     21.47 / v["dur"] * 1e3))
-    f.write("\nDerived (a launch is 21.47 GFLOP = 3.93 M v_mfma_f32_32x32x16_bf16 at 32 matrix-pipe cycles each = 122.9 k busy cycles per SIMD):\n\n"
+    f.write("\nDerived (a launch is 21.47 GFLOP = 3.93 M v_mfma_f32_32x32x16_bf16 at 32 matrix-pipe cycles each = 122.9 k busy cycles per SIMD;\n"
+            "the kernels whose last template argument is 2 are the scaled-fp16 form: 1.97 M v_mfma_f32_32x32x16_f16, 61.4 k busy cycles):\n\n"
             "| kernel | us | cycles per wave | clock GHz (cycles / duration) | matrix pipe busy | issuing | issue-stalled | parked (waitcnt / barrier) | VALU per MFMA | TFLOP/s (fp32-equivalent) |\n"
             "|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|\n")
     for r in der:
@@ -153,10 +154,16 @@ with open(f"{DST}/{TAG}_pmc_hbm.md", "w") as f:
             "on small_up_fwd_kernel, whose only input is the 167.8 MB tensor g3); WRITE_SIZE as reported.  Counter unit: KB.\n\n"
             "| kernel | us | read MB (2 x FETCH) | written MB | algorithmic MB | ratio |\n|---|---:|---:|---:|---:|---:|\n")
     alg = {"recon_nll_kernel<1, true>": 165.84, "small_up_fwd_kernel<3, 32, 1024, true>": 167.77 + 62.91,
-           "small_up_bwd_kernel<3, 32, 256, 256, 2, 2, 1, true>": 62.91 * 2 + 167.77 * 2,
-           "mvk::imgconv_kernel<0, 8, 64, 32, false, true>": 83.89 + 167.77, "mvk::imgconv_kernel<0, 4, 128, 64, false, true>": 41.94 + 83.89,
-           "mvk::imgconv_kernel<1, 8, 32, 64, true, true>": 167.77 + 83.89 * 2, "mvk::imgconv_kernel<1, 4, 64, 128, true, true>": 83.89 + 41.94 * 2,
-           "mvk::imgwgrad_kernel<8, 32, 64>": 167.77 + 83.89 + 33.55, "mvk::imgwgrad_kernel<4, 64, 128>": 83.89 + 41.94 + 33.55}
+           "small_up_fwd_bf_kernel<3, 512, true>": 167.77 + 6.29 + 62.91,
+           "small_up_bwd_bf_kernel<3, true>": 62.91 + 167.77 * 2,
+           "small_up_bwd_kernel<3, 32, 256, 256, 2, 2, 1, true>": 62.91 * 2 + 167.77 * 2}
+    for np_ in (3, 2):  # bf16 pieces / scaled fp16 pairs: the same algorithmic bytes
+        alg.update({f"mvk::imgconv_kernel<0, 8, 64, 32, false, true, {np_}>": 83.89 + 167.77,
+                    f"mvk::imgconv_kernel<0, 4, 128, 64, false, true, {np_}>": 41.94 + 83.89,
+                    f"mvk::imgconv_kernel<1, 8, 32, 64, true, true, {np_}>": 167.77 + 83.89 * 2,
+                    f"mvk::imgconv_kernel<1, 4, 64, 128, true, true, {np_}>": 83.89 + 41.94 * 2,
+                    f"mvk::imgwgrad_kernel<8, 32, 64, {np_}>": 167.77 + 83.89 + 33.55,
+                    f"mvk::imgwgrad_kernel<4, 64, 128, {np_}>": 83.89 + 41.94 + 33.55})
     for k, a in alg.items():
         if k in fs and k in ws:
             rd, wr = 2 * fs[k]["FETCH_SIZE"] * 1e6 * 1024 / 1e6, ws[k]["WRITE_SIZE"] * 1e6 * 1024 / 1e6
