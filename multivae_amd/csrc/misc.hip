@@ -30,14 +30,24 @@ __global__ void pack_conv4s2_kernel(const float* __restrict__ Wref, int Cv, int 
 struct PackJobs {
   mvk_pack_desc j[MVK_PACK_MAX];
 };
-// max |Wref| of a descriptor (the weight's scale for the scaled-fp16 kernels, bf3.hpp): the first 8 workgroups of the descriptor
-// read the (L2-resident) weight once more and publish — 8 atomics per weight instead of one per workgroup of the launch (2304
-// same-address atomics made the 13-us launch 32 us)
+// max |Wref| of a descriptor (the weight's scale for the scaled-fp16 kernels, bf3.hpp): the first 32 workgroups of the
+// descriptor read the (L2-resident) weight once more, eight independent loads in flight per thread, and publish — 32 atomics per
+// weight.  (One atomic per workgroup of the launch: 2304 on 9 addresses made the 13-us launch 32 us; 8 workgroups with one
+// load in flight at a time: 64 dependent L2 latencies, 32 us again.)
 __device__ __forceinline__ void pack_amax(const mvk_pack_desc& d, int total, float* red) {
-  if (!d.amax || blockIdx.x >= 8) return;  // uniform per workgroup
-  float m = 0.f;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += 8 * 256) m = fmaxf(m, fabsf(d.Wref[i]));
-  mvk::amax_publish(m, d.amax, red);
+  constexpr int NB = 32;
+  if (!d.amax || blockIdx.x >= NB) return;  // uniform per workgroup
+  float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int stride = NB * 256;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += 8 * stride) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = i + j * stride;
+      m[j] = fmaxf(m[j], k < total ? fabsf(d.Wref[k]) : 0.f);
+    }
+  }
+  const float mm = fmaxf(fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3])), fmaxf(fmaxf(m[4], m[5]), fmaxf(m[6], m[7])));
+  mvk::amax_publish(mm, d.amax, red);
 }
 
 __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs jobs) {

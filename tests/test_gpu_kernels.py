@@ -958,6 +958,41 @@ def test_conv3x3_scaled_fp16(K, n, H, W, Cin, Cout, spread):
         _debug_flags(0)
 
 
+def test_scaled_fp16_edge_values(K):
+    """The scaled-fp16 launches on degenerate operands: an all-zero tensor (bound 0: the scale clamps, the result is the bias),
+    a NaN (it does not enter the bound — fmax drops it — but reaches every output whose window holds it, and no other)."""
+    gen = g(71)
+    d = dev()
+    n, H, W, Cin, Cout = 3, 16, 16, 64, 64
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) / (3 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=gen)
+    (wf, _), = K.pack_weights([(w.to(d), "c3", True, True)])
+    pool = K.AmaxPool(wf, 8)
+    _debug_flags(0x800)
+    try:
+        X = torch.zeros(n, H, W, Cin, device=d)
+        xam = K.amax_of(X, pool.take())
+        assert float(xam) == 0.0
+        Y = K.conv3x3_s(X, wf, b.to(d), n, H, W, Cin, Cout, xam, wf.mvk_amax, pool.take())
+        assert torch.equal(Y.cpu(), b.view(1, 1, 1, -1).expand(n, H, W, Cout))
+        x = torch.randn(n, Cin, H, W, generator=gen)
+        X = x.permute(0, 2, 3, 1).contiguous().to(d)
+        X[1, 5, 7, 3] = float("nan")
+        xam = K.amax_of(X, pool.take())
+        assert float(xam) == float(x.abs().max()) or float(xam) < float(x.abs().max())  # the NaN is not the maximum
+        yam = pool.take()
+        Y = K.conv3x3_s(X, wf, None, n, H, W, Cin, Cout, xam, wf.mvk_amax, yam).cpu()
+        bad = torch.isnan(Y).any(-1)
+        want = torch.zeros(n, H, W, dtype=torch.bool)
+        want[1, 4:7, 6:9] = True
+        assert torch.equal(bad, want)
+        ref = F.conv2d(x.double(), w.double(), None, 1, 1).permute(0, 2, 3, 1)
+        ok = ~want
+        assert float((Y[ok].double() - ref[ok]).abs().max() / ref[ok].abs().max()) < 3e-6
+    finally:
+        _debug_flags(0)
+
+
 def test_amax_kernel(K):
     """mvk_amax: max |x| by atomic max into a slot that keeps what it held; odd lengths, zeros, infinities."""
     d = dev()
