@@ -515,7 +515,12 @@ def main():
                        "baseline_config": args.config, "global_batch": world * B, "K": K, "parallelism": f"dp{world}",
                        "final_loss": round(loss, 4),
                        "peak_device_memory_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
-                       "launch": "hipGraph replay (fwd+bwd) + all-reduce + Adam" if graphed is not None else "eager"},
+                       "launch": "hipGraph replay (fwd+bwd) + all-reduce + Adam" if graphed is not None else "eager",
+                       # how the fp32 GEMM / convolution products are formed (operands, results and accumulation are fp32; the
+                       # tests hold every form to the same float64-referenced tolerance)
+                       "fp32_product": ("register-stationary convolutions: 3 fp16 MFMAs on scaled (hi, lo) pairs"
+                                        if (kernels.IMG_F16 or kernels.C3_F16) else "6 bf16 MFMAs on three pieces")
+                                       + "; tiled engine: 6 bf16 MFMAs on three pieces; latency-sized layers: exact fp32 FMA / MFMA"},
         }
         nll_generic = summarise(recs, {"recon_nll"}, boundary)
         imgf = summarise(recs, {"image_layer_fwd"}, boundary)

@@ -154,6 +154,74 @@ __global__ __launch_bounds__(256) void conv3_smallcout_kernel(const C3Args g) {
 }
 
 
+// ---- many channels -> output image, on the vector ALU (end of round 3) ------------------------------------------------------
+// The MFMA version above uses 3 of the 16 columns of every v_mfma_f32_16x16x4_f32 and reads one B value from LDS per
+// instruction: 1101 us per launch at cfg4's decoder batch (1600 images of 28x28, 321 MB of input whose HBM time is 64 us), 164 us
+// at cfg5's.  Here a thread owns ONE output position and its CS <= 4 channels: 9 Cin CS FMAs in exact fp32, the input tile
+// (8 x 32 positions + halo) staged 16 channels at a time as [pixel][16 + 4 pad floats] (80-byte stride: conflict-free 16-byte
+// reads), the chunk's weights [tap][co][16] read as LDS broadcasts.  27 KB of LDS and ~40 registers: 5 workgroups per CU hide
+// the staging of one behind the FMAs of the others.
+constexpr int C3V_TR = 8, C3V_TC = 32, C3V_PS = 20;
+
+template <int CS>
+__global__ __launch_bounds__(256) void conv3_smallcout_v_kernel(const C3Args g) {
+  __shared__ __attribute__((aligned(16))) float xt[(C3V_TR + 2) * (C3V_TC + 2) * C3V_PS];
+  __shared__ __attribute__((aligned(16))) float wt[9 * CS * 16];
+  const int Cin = g.Cin, H = g.H, W = g.W;
+  const int tid = threadIdx.x, r = tid >> 5, c = tid & 31;
+  const int tcols = (W + C3V_TC - 1) / C3V_TC, trows = (H + C3V_TR - 1) / C3V_TR;
+  const int img = blockIdx.x / (tcols * trows), trem = blockIdx.x % (tcols * trows);
+  const int y0 = (trem / tcols) * C3V_TR, x0 = (trem % tcols) * C3V_TC;
+  const float* ximg = g.X + (long long)img * H * W * Cin;
+  float acc[CS];
+#pragma unroll
+  for (int co = 0; co < CS; ++co) acc[co] = 0.f;
+  for (int cb = 0; cb < Cin; cb += 16) {
+    if (cb) __syncthreads();  // the previous chunk's reads are done
+    for (int i = tid; i < (C3V_TR + 2) * (C3V_TC + 2) * 4; i += 256) {
+      const int pix = i >> 2, q = i & 3;
+      const int pr = pix / (C3V_TC + 2), px = pix - pr * (C3V_TC + 2);
+      const int yy = y0 + pr - 1, xx = x0 + px - 1;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = *reinterpret_cast<const f32x4*>(ximg + ((long long)yy * W + xx) * Cin + cb + 4 * q);
+      *reinterpret_cast<f32x4*>(xt + pix * C3V_PS + 4 * q) = v;
+    }
+    for (int i = tid; i < 9 * CS * 16; i += 256) {
+      const int tap = i / (CS * 16), co = (i >> 4) % CS, ch = i & 15;
+      wt[i] = g.Wp[(long long)(tap * Cin + cb + ch) * CS + co];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap - dy * 3;
+      const float* xp = xt + ((r + dy) * (C3V_TC + 2) + c + dx) * C3V_PS;
+      f32x4 x[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = *reinterpret_cast<const f32x4*>(xp + 4 * j);
+#pragma unroll
+      for (int co = 0; co < CS; ++co) {
+        const float* wp = wt + (tap * CS + co) * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp + 4 * j);  // the same address for the whole wave: a broadcast
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[co] = fmaf(x[j][e], w4[e], acc[co]);
+        }
+      }
+    }
+  }
+  const int yy = y0 + r, xx = x0 + c;
+  if (yy < H && xx < W) {
+    const long long o = (((long long)img * H + yy) * W + xx) * CS;
+#pragma unroll
+    for (int co = 0; co < CS; ++co) {
+      float v = mvk_act(acc[co] + (g.bias ? g.bias[co] : 0.f), g.act);
+      if (g.mask_src) v *= mvk_act_grad_from_out(g.mask_src[o + co], g.mask_act);
+      g.Y[o + co] = v;
+    }
+  }
+}
+
 // ---- weight gradient with an image on one side ---------------------------------------------------------------------------
 // slab[block][index in dWref] = sum over the block's positions of S[pos + sgn * off(tap)][cs] * B[pos][cb]:
 //   the image is the INPUT  (Cin = CS):  S = X,  B = dY, sgn = +1, dWref[cb][cs][tap]
@@ -263,6 +331,18 @@ int conv3_smallcout(const float* X, const float* Wp, const float* bias, float* Y
   static const int off = mvk_tune("MVK_CONV3SMALL") ? atoi(mvk_tune("MVK_CONV3SMALL")) == 0 : 0;
   if (off || Cout < 1 || Cout > 4 || Cin % 16 != 0 || Cin < 16 || Cin > 256 || n < 1 || !mvk_aligned16(X)) return 1;
   C3Args a{X, Wp, bias, Y, mask_src, n, H, W, Cin, Cout, act, mask_act};
+  static const int mfma = mvk_tune("MVK_SMALLCOUT_MFMA") ? atoi(mvk_tune("MVK_SMALLCOUT_MFMA")) : 0;  // A/B: the MFMA kernel
+  if (!mfma) {
+    const dim3 vgrid((unsigned)((long long)n * ((W + C3V_TC - 1) / C3V_TC) * ((H + C3V_TR - 1) / C3V_TR)));
+    switch (Cout) {
+      case 1: hipLaunchKernelGGL(conv3_smallcout_v_kernel<1>, vgrid, dim3(256), 0, s, a); break;
+      case 2: hipLaunchKernelGGL(conv3_smallcout_v_kernel<2>, vgrid, dim3(256), 0, s, a); break;
+      case 3: hipLaunchKernelGGL(conv3_smallcout_v_kernel<3>, vgrid, dim3(256), 0, s, a); break;
+      default: hipLaunchKernelGGL(conv3_smallcout_v_kernel<4>, vgrid, dim3(256), 0, s, a); break;
+    }
+    MVK_CHECK_LAUNCH();
+    return MVK_OK;
+  }
   const int tcols = (W + C3_TC - 1) / C3_TC, trows = (H + C3_TR - 1) / C3_TR;
   const size_t lds = ((size_t)(C3_TR + 2) * (C3_TC + 2) * (Cin + 4) + (size_t)9 * Cin * 4) * sizeof(float);
   const dim3 grid((unsigned)(n * tcols * trows));
