@@ -289,7 +289,7 @@ __device__ __forceinline__ void c3rs_body(const C3Args& g) {
   unsigned long long c3_bar = 0;
 #endif
   const float aslope = g.aslope, mslope = g.mslope, alpha = g.res_alpha;
-  const float pre_scale = NP == 2 ? g.pre_scale * inv_sw : g.pre_scale;
+  const float pre_scale = NP == 2 ? g.pre_scale * inv_sw * inv_sx : g.pre_scale;
   float csum = 0.f, amax_l = 0.f;
 
   // ---- main loop, instantiated per tap-split rank (every "is this my slice" test is a compile-time fact) ----------------
@@ -406,8 +406,8 @@ __device__ __forceinline__ void c3rs_body(const C3Args& g) {
       if (HAS_RES) rr[P][o] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, off, 0, 0));
     };
     auto epilogue_row = [&](int Q, int o, bool valid) {  // Q: the parity whose fetch belongs to the tile in res_prev
-      float v = fmaf(NP == 2 ? res_prev[o] * inv_sx : res_prev[o], pre_scale, bias);
-      v = v > 0.f ? v : v * aslope;
+      float v = fmaf(res_prev[o], pre_scale, bias);   // pre_scale carries 1 / (sx sw) in the scaled-fp16 form
+      v = fmaxf(v, v * aslope);                        // (leaky) ReLU / identity: 0 <= slope <= 1
       if (HAS_SRC) v = msk[Q][o] > 0.f ? v : v * mslope;
       const int px_ = valid ? pix[Q][o] : -1;
       if (WITH_CSUM) csum += px_ < 0 ? 0.f : v;
