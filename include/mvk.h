@@ -327,6 +327,9 @@ int mvk_nchw_channel_sum_acc(const float* dY, const float* y_out, int y_act, flo
                              float* ws, int64_t ws_floats, void* stream);
 /* In-place dY *= act'(Y) (sigmoid: y(1-y), relu: y>0). */
 int mvk_act_bwd(float* dY, const float* Y, int64_t n, int act, void* stream);
+/* out = a * g * act'(Y) in one pass (out may alias g): the gradient through `a * act(.)`, e.g. the 0.1 of a ResNet block's
+ * residual branch and the activation behind its second convolution (models/nn/mmnist.py:229-246). */
+int mvk_act_bwd_scaled(const float* g, float a, const float* Y, int act, float* out, int64_t n, void* stream);
 
 /* Row-major GEMM C[M,N] (+)= op(A) op(B) used for the packed 1x1-spatial layers:
  *   ta=0: A is [M,K]; ta=1: A is [K,M].  tb=0: B is [K,N]; tb=1: B is [N,K].

@@ -72,6 +72,7 @@ PROTOTYPES = {
     "mvk_colsum_acc": [_p, _p, _i, _p, _i, _i, _p, _i64, _p],
     "mvk_nchw_channel_sum_acc": [_p, _p, _i, _p, _i, _i, _i, _p, _i64, _p],
     "mvk_act_bwd": [_p, _p, _i64, _i, _p],
+    "mvk_act_bwd_scaled": [_p, _f, _p, _i, _p, _i64, _p],
     "mvk_gemm": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _i, _p, _i, _p, _i64, _p],
     "mvk_pack_conv4s2_weight": [_p, _i, _i, _p, _i, _i, _p, _p],
     "mvk_conv4s2_down": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i64, _i, _p, _p],

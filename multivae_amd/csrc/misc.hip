@@ -162,6 +162,24 @@ __global__ __launch_bounds__(256) void act_bwd4_kernel(float4* __restrict__ dY, 
   dY[i] = g;
 }
 
+// out = a * g * act'(Y): the gradient through `a * act(.)` in one pass (the 0.1 of a ResNet block's residual branch and the
+// LeakyReLU behind its second convolution: an axpby pass + an in-place act_bwd pass before)
+__global__ __launch_bounds__(256) void act_bwd_scaled_kernel(const float* __restrict__ g, float a, const float* __restrict__ Y,
+                                                             long long n, int act, float* __restrict__ out) {
+  const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 + 3 < n && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    const float4 gv = *reinterpret_cast<const float4*>(g + i4), y = *reinterpret_cast<const float4*>(Y + i4);
+    float4 r;
+    r.x = a * gv.x * mvk_act_grad_from_out(y.x, act);
+    r.y = a * gv.y * mvk_act_grad_from_out(y.y, act);
+    r.z = a * gv.z * mvk_act_grad_from_out(y.z, act);
+    r.w = a * gv.w * mvk_act_grad_from_out(y.w, act);
+    *reinterpret_cast<float4*>(out + i4) = r;
+  } else {
+    for (long long i = i4; i < n && i < i4 + 4; ++i) out[i] = a * g[i] * mvk_act_grad_from_out(Y[i], act);
+  }
+}
+
 __global__ void scale_kernel(float* __restrict__ buf, long long n, const float* __restrict__ g) {
   float s = *g;
   if (s == 1.0f) return;
@@ -509,6 +527,15 @@ int mvk_act_bwd(float* dY, const float* Y, int64_t n, int act, void* stream) {
                        reinterpret_cast<float4*>(dY), reinterpret_cast<const float4*>(Y), (long long)(n / 4), act);
   else
     hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, mvk_stream(stream), dY, Y, (long long)n, act);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_act_bwd_scaled(const float* g, float a, const float* Y, int act, float* out, int64_t n, void* stream) {
+  if (!g || !Y || !out || n < 0) return MVK_EINVAL;
+  if (n == 0) return MVK_OK;
+  hipLaunchKernelGGL(act_bwd_scaled_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, mvk_stream(stream), g, a, Y,
+                     (long long)n, act, out);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }

@@ -1338,11 +1338,11 @@ class ResnetStackFn(Function):
                 # conv1 stages its input (a0 is never written) and the backward pass folds the 0.1 and the bias gradients
                 fused = (conv3x3_fused_ok(n, H, W, C, Chid) and conv3x3_fused_ok(n, H, W, Chid, Cout)
                          and conv3x3_fused_ok(n, H, W, Cout, Chid))  # conv1, conv2 and conv2's backward-data launch
-                oam = None
+                oam = y2am = None
                 if order_ == "post":
                     a0 = h
                     a1, a1am = _rs_conv(pool, a0, ham, packs[iw1][0], b1, n, H, W, C, Chid, act=LEAKY)
-                    y2, _ = _rs_conv(pool, a1, a1am, packs[iw2][0], b2, n, H, W, Chid, Cout, act=LEAKY)
+                    y2, y2am = _rs_conv(pool, a1, a1am, packs[iw2][0], b2, n, H, W, Chid, Cout, act=LEAKY)
                 elif fused:
                     a0 = None
                     a1, a1am = _rs_conv(pool, h, ham, packs[iw1][0], b1, n, H, W, C, Chid, act=LEAKY, x_act=LEAKY)
@@ -1356,6 +1356,8 @@ class ResnetStackFn(Function):
                     out, oam = _rs_conv(pool, a1, a1am, packs[iw2][0], b2, n, H, W, Chid, Cout, act=NONE, res=xs, res_alpha=0.1)
                 else:
                     out = axpby(xs, 1.0, y2, 0.1)
+                    if isc is None and ham is not None and y2am is not None:
+                        oam = torch.add(ham, y2am, alpha=0.1)  # |xs + 0.1 y2| <= max |xs| + 0.1 max |y2|: no pass over `out`
                 tape.append((h, a0, a1, y2, (H, W, C, Chid, Cout), fused, ham, a1am))
                 h, C, ham = out, Cout, oam
             elif op[0] == "pool":
@@ -1426,9 +1428,11 @@ class ResnetStackFn(Function):
                     grads[iw1], _ = _rs_wgrad(pool, xin, xam, d1, d1am, params[iw1], None, n, H, W, C, Chid, x_act=LEAKY, fused=True)
                     a0 = xin  # sign(lrelu(x)) == sign(x): the mask source of dx below
                 else:
-                    d2 = axpby(gout, 0.1, None, 0.0)  # gradient w.r.t. y2 (max |gout| bounds it, LeakyReLU' included)
-                    if order_ == "post":
-                        call("mvk_act_bwd", ptr(d2), ptr(y2), d2.numel(), LEAKY, stream_ptr())
+                    if order_ == "post":  # gradient w.r.t. conv2's pre-activation: 0.1 * gout * lrelu'(y2), one pass
+                        d2 = _new(gout.shape, gout)
+                        call("mvk_act_bwd_scaled", ptr(gout), 0.1, ptr(y2), LEAKY, ptr(d2), d2.numel(), stream_ptr())
+                    else:
+                        d2 = axpby(gout, 0.1, None, 0.0)  # gradient w.r.t. y2 (max |gout| bounds it)
                     grads[iw2], gb2 = _rs_wgrad(pool, a1, a1am, d2, gam, params[iw2], params[ib2] if ib2 is not None else None, n, H,
                                                 W, Chid, Cout, fused=fused)  # fused: bias gradient with the weight gradient
                     if ib2 is not None:
