@@ -450,6 +450,13 @@ class pack_scope:
         if PREPACK and _PACK_SCOPE is None:
             _PACK_SCOPE = {"model": self.model, "cache": {}, "done": False}
             self.own = True
+            # the zeroed arena of the amax protocol (AmaxPool, the pack launches): filled HERE, on the caller's stream and in front
+            # of every fork of run_branches — a slot must be zero before ANY stream publishes into it, and the branch streams
+            # are ordered behind the fork only, not behind what the first branch enqueues
+            if C3_F16 or IMG_F16:
+                dev = next((p.device for p in self.model.parameters()), None)
+                if dev is not None and dev.type == "cuda":
+                    _PACK_SCOPE["amax"], _PACK_SCOPE["amax_pos"] = torch.zeros(512, dtype=torch.float32, device=dev), 0
         return self
 
     def __exit__(self, *exc):
@@ -644,13 +651,11 @@ IMG_F16 = _lib.tune("MVK_IMG_F16", "1") != "0"
 
 
 def _amax_slots(like, n, create=False):
-    """n zeroed device scalars.  Inside a pack_scope they are carved from ONE arena that the scope's pack launch creates in
-    front of itself (create=True): every stream that may read a pack is ordered behind that launch, hence behind the fill —
-    one fill per forward pass instead of one per pool, all of them on the step's critical chain."""
+    """n zeroed device scalars.  Inside a pack_scope they are carved from the ONE arena the scope filled when it was entered
+    (in front of every stream fork of the forward pass): one fill per forward pass instead of one per pool, all of them on
+    the step's critical chain.  Outside a scope (backward passes, PREPACK off): a fill on the current stream."""
     sc = _PACK_SCOPE
     if sc is not None:
-        if create and sc.get("amax") is None:
-            sc["amax"], sc["amax_pos"] = torch.zeros(256, dtype=torch.float32, device=like.device), 0
         ar = sc.get("amax")
         if ar is not None and ar.device == like.device and sc["amax_pos"] + n <= ar.numel():
             sc["amax_pos"] += n
