@@ -960,7 +960,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           for (int dx = 0; dx < 3; ++dx)
             acc[grp * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_cur[dx][PA[m]], Bf[s][PB_[m]], acc[grp * 3 + dx], 0, 0, 0);
       }
-      if (MVK_C3W_SCHED > 0) {
+      // the "1 MFMA, N others" directive pays in the bf16 form only: the fp16 form (half the MFMAs per step) measured 174-182 us
+      // with it and 158-166 us with hipcc's own order (64 x 64 @64x64, n = 128, incl. the finish); the bf16 form 214 vs 231
+      if (MVK_C3W_SCHED > 0 && NP == 3) {
 #pragma unroll
         for (int m = 0; m < 6 * NP; ++m) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
