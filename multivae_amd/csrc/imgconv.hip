@@ -35,6 +35,10 @@
 #define MVK_IC_SCHED (HS == 8 ? 5 : 4)  // "others" per MFMA of the scheduling pipeline in imgconv_kernel (0 = hipcc's own order)
 #endif
 
+#ifndef MVK_IC_SCHED2
+#define MVK_IC_SCHED2 2  // multiplier of MVK_IC_SCHED in the scaled-fp16 form (half the MFMAs per pair of k-steps)
+#endif
+
 namespace mvk {
 
 #ifdef MVK_ICPROF  // tools/imgconv_phase.py: per-wave cycle counters (total, waiting at the tile barrier, k-loops)
@@ -459,7 +463,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int m = 0; m < 4 * NP; ++m) {
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-              __builtin_amdgcn_sched_group_barrier(0x496, (MVK_IC_SCHED > 0 ? MVK_IC_SCHED : 1) * (NP == 3 ? 1 : 2), 0);
+              __builtin_amdgcn_sched_group_barrier(0x496, (MVK_IC_SCHED > 0 ? MVK_IC_SCHED : 1) * (NP == 3 ? 1 : MVK_IC_SCHED2), 0);
             }
           }
 #ifdef MVK_ICPROF
