@@ -993,6 +993,43 @@ def test_scaled_fp16_edge_values(K):
         _debug_flags(0)
 
 
+def test_scaled_entries_refuse_what_they_do_not_cover(K):
+    """The scaled-fp16 entry points never fall back silently: a shape / batch outside mvk_*_scaled_ok, or one operand bound
+    without the other, is MVK_EINVAL (the Python stub raises)."""
+    from multivae_amd import _lib
+
+    d = dev()
+    pool = K.AmaxPool(torch.zeros(1, device=d), 8)
+    one = torch.ones(1, device=d)
+    # 3x3: too small for the default dispatch (no debug flag), and a 256-channel input
+    n, H, Cin, Cout = 2, 8, 64, 64
+    x = torch.randn(n, H, H, Cin, device=d)
+    w = torch.randn(Cout, Cin, 3, 3, device=d) * 0.05
+    (wf, _), = K.pack_weights([(w, "c3", True, True)])
+    assert not K.conv3x3_scaled_ok(n, H, H, Cin, Cout)
+    with pytest.raises(_lib.MvkError):
+        K.conv3x3_s(x, wf, None, n, H, H, Cin, Cout, one, wf.mvk_amax, pool.take())
+    _debug_flags(0x800)
+    try:
+        assert not K.conv3x3_scaled_ok(n, H, H, 256, 64)
+        with pytest.raises(_lib.MvkError):  # one bound without the other
+            K.conv3x3_s(x, wf, None, n, H, H, Cin, Cout, one, None, pool.take())
+        wpar = w.clone().requires_grad_(True)
+        wpar.grad = torch.zeros_like(wpar)
+        with pytest.raises(_lib.MvkError):
+            K.conv3x3_wgrad_s(x, x, wpar, None, n, H, H, Cin, Cout, one, None)
+    finally:
+        _debug_flags(0)
+    # 4x4 / stride 2: a layer pair without a register-stationary kernel, and a batch below the threshold
+    assert not K.conv4s2_scaled_ok(5120, 8, 8, 16, 32)
+    assert not K.conv4s2_scaled_ok(8, 8, 8, 32, 64)
+    Wc = torch.randn(64, 32, 4, 4, device=d) * 0.05
+    wd, wu = K.pack_conv(Wc)
+    U = torch.randn(8, 16, 16, 32, device=d)
+    with pytest.raises(_lib.MvkError):
+        K.conv_down(U, wd, None, 8, 8, 8, 32, 64, amax=(one, wd.mvk_amax, pool.take()))
+
+
 def test_amax_kernel(K):
     """mvk_amax: max |x| by atomic max into a slot that keeps what it held; odd lengths, zeros, infinities."""
     d = dev()
