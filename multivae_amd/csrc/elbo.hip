@@ -120,11 +120,29 @@ __global__ __launch_bounds__(256) void mopoe_posterior_bwd_kernel(
     }
     // sum over k of dz and dz*eps for the selected subset
     float sdz = 0.f, sdze = 0.f;
-    for (int k = 0; k < K; ++k) {
-      const long long zo = ((long long)k * B + b) * L + l;
-      const float d = dz[zo];
-      sdz += d;
-      sdze += d * eps[zo];
+    {  // five samples' loads in flight at a time (one at a time = K dependent memory latencies at the head of the encoders'
+       // backward chain); the sums run in k order as before: bit-identical
+      const long long ks = (long long)B * L;
+      long long zo = (long long)b * L + l;
+      int k = 0;
+      for (; k + 5 <= K; k += 5, zo += 5 * ks) {
+        float d[5], e[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          d[j] = dz[zo + j * ks];
+          e[j] = eps[zo + j * ks];
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          sdz += d[j];
+          sdze += d[j] * e[j];
+        }
+      }
+      for (; k < K; ++k, zo += ks) {
+        const float d = dz[zo];
+        sdz += d;
+        sdze += d * eps[zo];
+      }
     }
     for (int s = 0; s < S; ++s) {
       const uint32_t bits = (uint32_t)subset_masks[s];
