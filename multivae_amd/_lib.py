@@ -11,9 +11,28 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+# MVK_* variables that are NOT experiment switches (read directly, with or without MVK_TUNE)
+_ALWAYS_READ = {"MVK_TUNE", "MVK_LIB_PATH", "MVK_DEFER_MB", "MVK_SYNC_DEBUG", "MVK_TRAINER_ALLOW_CPU", "MVK_CPU_THREADS",
+                "MVK_BENCH_SAME_GPU", "MVK_FORCE_DIST", "MVK_DIST_BACKEND", "MVK_ADAM_ZERO"}
+
+
+def _warn_ignored_switches():
+    if os.environ.get("MVK_TUNE") == "1":
+        return
+    ignored = sorted(k for k in os.environ if k.startswith("MVK_") and k not in _ALWAYS_READ)
+    if ignored:
+        import warnings
+
+        warnings.warn(f"{', '.join(ignored)} set without MVK_TUNE=1: experiment switches are ignored unless MVK_TUNE=1 "
+                      "(this process runs the shipped configuration)", RuntimeWarning, stacklevel=3)
+
+
+_warn_ignored_switches()
+
+
 def tune(name, default):
     """Experiment switches (the MVK_* A/B knobs of DESIGN.md section 9) are honoured only under MVK_TUNE=1: a process without it
-    runs ONE configuration, the shipped one."""
+    runs ONE configuration, the shipped one (and is told so once, at import, if it sets such a switch)."""
     return os.environ.get(name, default) if os.environ.get("MVK_TUNE") == "1" else default
 
 

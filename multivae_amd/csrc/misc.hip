@@ -1042,11 +1042,16 @@ __global__ __launch_bounds__(256) void transpose_act_kernel(const float* __restr
 
 extern "C" int mvk_transpose_act(const float* x, float* y, int batch, int rows, int cols, int act, const float* msrc, int dact,
                                  void* stream) {
-  if (!x || !y || batch < 0 || rows <= 0 || cols <= 0 || batch > 65535) return MVK_EINVAL;
+  if (!x || !y || batch < 0 || rows <= 0 || cols <= 0) return MVK_EINVAL;
   if (batch == 0) return MVK_OK;
-  hipLaunchKernelGGL(transpose_act_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, batch), dim3(256), 0, mvk_stream(stream), x, y,
-                     rows, cols, act, msrc, dact);
-  MVK_CHECK_LAUNCH();
+  // gridDim.z <= 65535: larger batches (the likelihood evaluators decode 65 536 rows per chunk) go in slices
+  const long long plane = (long long)rows * cols;
+  for (int b0 = 0; b0 < batch; b0 += 65535) {
+    const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+    hipLaunchKernelGGL(transpose_act_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, nb), dim3(256), 0, mvk_stream(stream),
+                       x + b0 * plane, y + b0 * plane, rows, cols, act, msrc ? msrc + b0 * plane : nullptr, dact);
+    MVK_CHECK_LAUNCH();
+  }
   return MVK_OK;
 }
 

@@ -85,6 +85,7 @@ DEFER_ARENA_CAP_FLOATS = int(os.environ.get("MVK_DEFER_MB", "1024")) * (1 << 18)
 DEFER_ARENA_START_FLOATS = min(64 * (1 << 18), DEFER_ARENA_CAP_FLOATS)
 _ARENA = {}
 _ARENA_RETIRED = []
+_ARENA_CAPTURED = set()  # data_ptr of every arena that was live during a stream capture
 
 
 _DEFER_ACTIVE = set()  # devices inside deferred_reductions
@@ -142,6 +143,8 @@ class deferred_reductions:
             if arena is None:
                 arena = torch.empty(DEFER_ARENA_START_FLOATS, dtype=torch.float32, device=dev)
                 _ARENA[dev] = arena
+            if torch.cuda.is_current_stream_capturing():
+                _ARENA_CAPTURED.add(arena.data_ptr())  # a hipGraph holds pointers into it: it must outlive the graph
             call("mvk_defer_begin", ptr(arena), arena.numel(), ptr(self.grad), self.grad.numel())
             _DEFER_ACTIVE.add(dev)
         return self
@@ -158,8 +161,12 @@ class deferred_reductions:
             wanted = int(_lib.load().mvk_defer_wanted())
             arena = _ARENA[dev]
             if wanted > arena.numel() and arena.numel() < DEFER_ARENA_CAP_FLOATS and not torch.cuda.is_current_stream_capturing():
-                _ARENA_RETIRED.append(arena)
-                _ARENA[dev] = torch.empty(min(DEFER_ARENA_CAP_FLOATS, wanted + wanted // 8), dtype=torch.float32, device=dev)
+                if arena.data_ptr() in _ARENA_CAPTURED:  # only an arena a captured graph points into is kept alive
+                    _ARENA_RETIRED.append(arena)
+                else:
+                    arena.record_stream(cur)  # the finish launch above still reads it: no reuse before that has run
+                grown = 1 << (wanted + wanted // 8 - 1).bit_length()  # powers of two: a creeping demand grows it log(n) times
+                _ARENA[dev] = torch.empty(min(DEFER_ARENA_CAP_FLOATS, grown), dtype=torch.float32, device=dev)
         return False
 
 
@@ -648,6 +655,9 @@ def conv3x3_f(X, wpack, bias, n, H, W, Cin, Cout, act=NONE, y_act_src=None, y_sr
 C3_F16 = _lib.tune("MVK_C3_F16", "1") != "0"
 # the same product form for the 4x4 / stride-2 layers of the SVHN decoder (csrc/imgconv.hip NP = 2); MVK_IMG_F16=0: bf16 pieces
 IMG_F16 = _lib.tune("MVK_IMG_F16", "1") != "0"
+# decoder rows from which SVHNDecoderFn takes that form (below, the in-kernel conversion of the weights costs what the cheaper
+# product saves); tests set 1 (with debug flag 0x200) so the small goldens meet these kernels too
+IMG_F16_MIN_ROWS = 1024
 
 
 def _amax_slots(like, n, create=False):
@@ -795,6 +805,16 @@ def device_randn(shape, device, uniform=False, lo=0.0, hi=1.0):
     return out
 
 
+# Test hook (tests/relu_sites.py): a list that receives (node, first weight, activation tensors) from the forward of every
+# network node, so a parity test can read which side of zero the HIP path put each ReLU / LeakyReLU unit on.  None = off (the default).
+TAPS = None
+
+
+def _tap(node, w, *acts):
+    if TAPS is not None:
+        TAPS.append((node, w, acts))
+
+
 class TransposeActFn(Function):
     """y[b, c, r] = act(x[b, r, c]): NHWC <-> NCHW-flattened in ONE pass with the activation in front of the flatten
     (mvk_transpose_act); backward = the transposed gradient times act'(y)."""
@@ -808,6 +828,7 @@ class TransposeActFn(Function):
         ctx.act = act
         if act != NONE:
             ctx.save_for_backward(y)
+            _tap("transpose_act", None, y)
         return y
 
     @staticmethod
@@ -878,6 +899,7 @@ class MLPEncoderFn(Function):
             mu = linear_fwd(h, we, be, NONE)
             lv = linear_fwd(h, wl, bl, NONE)
         ctx.save_for_backward(*acts, *params)
+        _tap("mlp_encoder", params[0], *acts[1:])
         ctx.n_layers = n_layers
         ctx.x_shape = x.shape
         return mu, lv
@@ -942,6 +964,7 @@ class MLPHeadsFn(Function):
         outs = tuple(linear_fwd(h, params[2 * (n_layers + j)], params[2 * (n_layers + j) + 1], NONE)
                      for j in range(n_heads))
         ctx.save_for_backward(*acts, *params)
+        _tap("mlp_heads", params[0], *acts[1:])
         ctx.n_layers, ctx.n_heads = n_layers, n_heads
         ctx.x_shape = x.shape
         return outs
@@ -1001,6 +1024,7 @@ class MLPDecoderFn(Function):
         h = linear_fwd(z2, w0, b0, RELU)
         out = linear_fwd(h, w1, b1, SIGMOID)
         ctx.save_for_backward(z2, h, out, w0, b0, w1, b1)
+        _tap("mlp_decoder", w0, h)
         ctx.z_shape = z.shape
         return out.view(*z.shape[:-1], *input_dim)
 
@@ -1053,6 +1077,7 @@ class SVHNEncoderFn(Function):
             mu = gemm(h3f, wdc1, B, L, Kf, bias=bc1, bias_mod=L)
             lv = gemm(h3f, wdc2, B, L, Kf, bias=bc2, bias_mod=L)
         ctx.save_for_backward(x, h1, h2, h3, wu1, wu2, wdc1, wdc2, w0, b0, w1, b1, w2, b2, wc1, bc1, wc2, bc2)
+        _tap("svhn_encoder", w0, h1, h2, h3)  # NHWC
         ctx.frags = (wfrag(wu1), wfrag(wu2))  # saved tensors come back without Python attributes
         ctx.dims = (B, H, W, chans, L)
         return mu, lv
@@ -1124,7 +1149,7 @@ class SVHNDecoderFn(Function):
         # maximum of what it writes, the consumer scales by it (amax protocol; no pass over a tensor)
         # (from 1024 images: below, the in-kernel conversion of the weights costs what the cheaper product saves — cfg2's decoder
         # batch of 512 measured 0.581 ms per step on bf16 pieces, 0.591 on fp16 pairs)
-        f16 = (IMG_F16 and n >= 1024 and conv4s2_scaled_ok(n, 4, 4, C2, C1) and conv4s2_scaled_ok(n, 8, 8, C3, C2)
+        f16 = (IMG_F16 and n >= IMG_F16_MIN_ROWS and conv4s2_scaled_ok(n, 4, 4, C2, C1) and conv4s2_scaled_ok(n, 8, 8, C3, C2)
                and all(getattr(t, "mvk_amax", None) is not None for t in (wu1, wu2, wd1, wd2)))
         ctx.f16 = f16
         if f16:
@@ -1162,6 +1187,7 @@ class SVHNDecoderFn(Function):
         ctx.small = small
         ctx.frags = (wfrag(wd1), wfrag(wd2))
         ctx.save_for_backward(z2, g1, g2, g3, out, wp0, wd1, wd2, wd3, w0, b0, w1, b1, w2, b2, w3, b3)
+        _tap("svhn_decoder", w0, g1.view(n, 4, 4, C1), g2, g3)  # NHWC
         ctx.dims = (n, L, C1, C2, C3, C4)
         ctx.z_shape = z.shape
         if ctx.fused:
@@ -1322,6 +1348,7 @@ class ResnetStackFn(Function):
             for i, pk in zip(order[i0:i0 + PACK_MAX], pack_weights(jobs[i0:i0 + PACK_MAX])):
                 packs[i] = pk
         h = x
+        sites = []  # sign sources of the activation sites in the reference's evaluation order (test hook, see TAPS)
         # scaled-fp16 form: ham = the slot that bounds max |h| (None: unknown, computed on demand)
         pool = AmaxPool(x, 4 * len(program) + 4) if C3_F16 else None
         ham = None
@@ -1331,6 +1358,8 @@ class ResnetStackFn(Function):
                 Cout = params[iw].shape[0]
                 y, yam = _rs_conv(pool, h, ham, packs[iw][0], params[ib] if ib is not None else None, n, H, W, C, Cout, act=act)
                 tape.append((h, y, (H, W, C, Cout), ham))
+                if act != NONE:
+                    sites.append(y)
                 h, C, ham = y, Cout, yam
             elif op[0] == "block":
                 _, order_, iw1, ib1, iw2, ib2, isc = op
@@ -1364,6 +1393,7 @@ class ResnetStackFn(Function):
                     if isc is None and ham is not None and y2am is not None:
                         oam = torch.add(ham, y2am, alpha=0.1)  # |xs + 0.1 y2| <= max |xs| + 0.1 max |y2|: no pass over `out`
                 tape.append((h, a0, a1, y2, (H, W, C, Chid, Cout), fused, ham, a1am))
+                sites += [a1, y2] if order_ == "post" else [h, a1]
                 h, C, ham = out, Cout, oam
             elif op[0] == "pool":
                 y = avgpool(h, n, H, W, C)  # an average, a copy, a (leaky) ReLU: max |h| still bounds the result
@@ -1376,12 +1406,14 @@ class ResnetStackFn(Function):
             elif op[0] == "act":
                 y = axpby(h, 1.0, None, 0.0, act=op[1])
                 tape.append((y,))
+                sites.append(y)
                 h = y
                 ham = ham if op[1] in (LEAKY, RELU) else None
             else:
                 raise _lib.MvkError(f"unknown ResNet op {op[0]!r}")
         ctx.tape, ctx.packs, ctx.program, ctx.n = tape, packs, program, n
         ctx.save_for_backward(*params)
+        _tap("resnet_stack", params[0] if params else None, *sites)
         return h
 
     @staticmethod

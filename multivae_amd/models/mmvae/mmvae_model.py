@@ -72,14 +72,18 @@ class MMVAE(BaseMultiVAE):
         prior_std = self.log_var_to_std(self.prior_log_var)
         zs = kernels.MMVAELatentFn.apply(state, noises, masks, self.prior_mean.detach(), family, int(dreg), prior_std,
                                          *mus, *sds)
-        # The reference decodes every (conditioning, target) pair on its own (:127: M^2 decoder passes of K * B rows); the
-        # rows are independent, so every decoder runs ONCE over the M * K * B stacked rows (the same reconstructions from
-        # 1 / M of the launches).
-        zall = torch.cat([zs[c].reshape(-1, L) for c in range(M)], dim=0) if M > 1 else zs[0].reshape(-1, L)
+        # The reference decodes every (conditioning, target) pair on its own (:127: M^2 decoder passes of K * B rows); a
+        # decoder that declares its rows independent (BaseDecoder.rows_independent: every in-package one) runs ONCE over the
+        # M * K * B stacked rows (the same reconstructions from 1 / M of the launches); any other decoder pair by pair.
+        zall = None
+        if any(getattr(self.decoders[r], "rows_independent", False) for r in mods):
+            zall = torch.cat([zs[c].reshape(-1, L) for c in range(M)], dim=0) if M > 1 else zs[0].reshape(-1, L)
 
         def decode_all(r):
+            if not getattr(self.decoders[r], "rows_independent", False):
+                return [self.decoders[r](zs[c].reshape(-1, L)).reconstruction for c in range(M)]
             rec = self.decoders[r](zall).reconstruction
-            return list(rec.view(M, K * B, *rec.shape[1:]).unbind(0))
+            return list(rec.reshape(M, K * B, *rec.shape[1:]).unbind(0))
 
         dec = kernels.run_branches(self._branch_order(inputs, mods), decode_all, device)
         recons = [dec[r][c] for c in range(M) for r in mods]

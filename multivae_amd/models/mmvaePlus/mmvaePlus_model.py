@@ -125,8 +125,12 @@ class MMVAEPlus(BaseMultiVAE):
             # (the reference decodes every (conditioning, target) pair on its own, mmvaePlus_model.py:172-186: M^2 decoder passes
             # of K * B rows; the rows are independent, so M passes of M * K * B rows give the same reconstructions with 1 / M of
             # the launches and M times longer weight-gradient reductions per launch)
+            # — for decoders that declare their rows independent (BaseDecoder.rows_independent: every in-package one); a
+            # user-written decoder is run pair by pair like in the reference
+            if not getattr(self.decoders[r], "rows_independent", False):
+                return [self.decoders[r](zin).reconstruction for zin in zins]
             rec = self.decoders[r](torch.cat(zins, dim=0)).reconstruction
-            return list(rec.view(M, K * B, *rec.shape[1:]).unbind(0))
+            return list(rec.reshape(M, K * B, *rec.shape[1:]).unbind(0))
 
         dec = kernels.run_branches(self._branch_order(inputs, mods), decode_all, device)
         recons = [dec[r][c] for c in range(M) for r in mods]

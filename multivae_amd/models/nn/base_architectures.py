@@ -13,6 +13,11 @@ class BaseEncoder(nn.Module):
 
 
 class BaseDecoder(nn.Module):
+    # True: forward treats the rows of z independently of one another (no batch statistics, no dropout / RNG, contiguous
+    # output), so MMVAE / MMVAE+ may decode the latents of all conditioning modalities in ONE stacked pass.  The in-package
+    # decoders say True; a user-written decoder keeps the reference's one pass per (conditioning, target) pair unless it does.
+    rows_independent = False
+
     def __init__(self):
         nn.Module.__init__(self)
 

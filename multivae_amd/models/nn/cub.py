@@ -67,6 +67,8 @@ class CUB_Resnet_Encoder(BaseEncoder):
 
 class CUB_Resnet_Decoder(BaseDecoder):
     """`cub.py:199-247`: fc -> [ResnetBlock, Upsample] x log2(64/s0) -> ResnetBlock -> conv_img(lrelu(.)) (logits)."""
+    rows_independent = True
+
 
     def __init__(self, latent_dim, s0=16, nfilter=64, nfilter_max=512, **kwargs):
         super().__init__()

@@ -44,6 +44,8 @@ class Encoder_VAE_MLP(BaseEncoder):
 
 class Decoder_AE_MLP(BaseDecoder):
     """Accepts any input shape (*, latent_dim); output is (*, *input_dim)."""
+    rows_independent = True
+
 
     def __init__(self, args):
         BaseDecoder.__init__(self)

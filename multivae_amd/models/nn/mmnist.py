@@ -133,6 +133,8 @@ class EncoderResnetMMNIST(BaseEncoder):
 class DecoderResnetMMNIST(BaseDecoder):
     """`mmnist.py:324-366`: fc -> [ResnetBlock, Upsample] x 2 -> ResnetBlock(64,64) -> Conv(64,3,3) + LeakyReLU(0.2).
     latent_dim is the total (shared + private) latent dimension."""
+    rows_independent = True
+
 
     def __init__(self, latent_dim):
         super().__init__()

@@ -40,6 +40,8 @@ class Encoder_VAE_SVHN(BaseEncoder):
 
 
 class Decoder_VAE_SVHN(BaseDecoder):
+    rows_independent = True
+
     def __init__(self, args):
         BaseDecoder.__init__(self)
         self.latent_dim = args.latent_dim
@@ -75,7 +77,9 @@ class Decoder_VAE_SVHN(BaseDecoder):
                 or not kernels.svhn_fused_tail_ok(d[6].weight.shape[1], d[6].weight.shape[0]):
             return None
         n = z.reshape(-1, z.shape[-1]).shape[0]
-        if n % x.shape[0] != 0:
+        # the kernel reads x as [x.shape[0], C, 32, 32] fp32 on z's device: anything else takes the generic path
+        if (tuple(x.shape[1:]) != (d[6].weight.shape[1], 32, 32) or not x.is_cuda or x.device != z.device
+                or x.shape[0] == 0 or n % x.shape[0] != 0):
             return None
         x = x.float().contiguous()
         return kernels.SVHNDecoderFn.apply(z, d[0].weight, d[0].bias, d[2].weight, d[2].bias, d[4].weight, d[4].bias,

@@ -4,7 +4,9 @@ import os
 from dataclasses import field
 from typing import Union
 
+import torch
 import torch.nn as nn
+import torch.optim.lr_scheduler  # noqa: F401  (resolved by name in __post_init__)
 from pydantic.dataclasses import dataclass
 
 from ...models.base.base_config import BaseConfig
@@ -75,54 +77,33 @@ class BaseTrainerConfig(BaseConfig):
                 d.update(json.load(f))
         return cls.from_dict(d)
 
+    # (field, environment variable, "unset" value, converter): torchrun's variables fill what the user left unset
+    _LAUNCHER_ENV = (("local_rank", "LOCAL_RANK", -1, int), ("world_size", "WORLD_SIZE", -1, int), ("rank", "RANK", -1, int),
+                     ("master_addr", "MASTER_ADDR", "localhost", str), ("master_port", "MASTER_PORT", "12345", str))
+
     def __post_init__(self):
+        """Same contract as the reference's configuration (trainers/base/base_trainer_config.py:77-152): a distributed field
+        left at its default takes the launcher's environment variable, the rendezvous address / port are exported for
+        `init_process_group`, and a misspelt optimizer / scheduler name (AttributeError) or an argument its constructor
+        rejects (TypeError) fails here, when the configuration is built, not in the middle of `train()`."""
         super().__post_init__()
-        env_local_rank = int(os.environ.get("LOCAL_RANK", -1))
-        if self.local_rank == -1 and env_local_rank != -1:
-            self.local_rank = env_local_rank
-        env_world_size = int(os.environ.get("WORLD_SIZE", -1))
-        if self.world_size == -1 and env_world_size != -1:
-            self.world_size = env_world_size
-        env_rank = int(os.environ.get("RANK", -1))
-        if self.rank == -1 and env_rank != -1:
-            self.rank = env_rank
-        env_master_addr = os.environ.get("MASTER_ADDR", "localhost")
-        if self.master_addr == "localhost" and env_master_addr != "localhost":
-            self.master_addr = env_master_addr
-        os.environ["MASTER_ADDR"] = self.master_addr
-        env_master_port = os.environ.get("MASTER_PORT", "12345")
-        if self.master_port == "12345" and env_master_port != "12345":
-            self.master_port = env_master_port
-        os.environ["MASTER_PORT"] = self.master_port
-
-        import torch.optim as optim
-
-        try:
-            optimizer_cls = getattr(optim, self.optimizer_cls)
-        except AttributeError:
-            raise AttributeError(f"Unable to import `{self.optimizer_cls}` optimizer from 'torch.optim'. "
-                                 "Check spelling and that it is part of 'torch.optim.Optimizers.'")
-        try:
-            optimizer = optimizer_cls(nn.Linear(2, 2).parameters(), lr=self.learning_rate,
-                                      **(self.optimizer_params or {}))
-        except TypeError as e:
-            raise TypeError("Error in optimizer's parameters. Check that the provided dict contains only "
-                            f"keys and values suitable for `{optimizer_cls}` optimizer. "
-                            f"Got {self.optimizer_params} as parameters.\n"
-                            f"Exception raised: {type(e)} with message: " + str(e)) from e
+        for attr, var, unset, conv in self._LAUNCHER_ENV:
+            if getattr(self, attr) == unset and var in os.environ:
+                setattr(self, attr, conv(os.environ[var]))
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = self.master_addr, self.master_port
+        probe = self._probe("optimizer", torch.optim, self.optimizer_cls, self.optimizer_params,
+                            lambda cls, kw: cls(nn.Linear(2, 2).parameters(), lr=self.learning_rate, **kw))
         if self.scheduler_cls is not None:
-            import torch.optim.lr_scheduler as schedulers
+            self._probe("scheduler", torch.optim.lr_scheduler, self.scheduler_cls, self.scheduler_params,
+                        lambda cls, kw: cls(probe, **kw))
 
-            try:
-                scheduler_cls = getattr(schedulers, self.scheduler_cls)
-            except AttributeError:
-                raise AttributeError(f"Unable to import `{self.scheduler_cls}` scheduler from "
-                                     "'torch.optim.lr_scheduler'. Check spelling and that it is part of "
-                                     "'torch.optim.lr_scheduler.'")
-            try:
-                scheduler_cls(optimizer, **(self.scheduler_params or {}))
-            except TypeError as e:
-                raise TypeError("Error in scheduler's parameters. Check that the provided dict contains only "
-                                f"keys and values suitable for `{scheduler_cls}` scheduler. "
-                                f"Got {self.scheduler_params} as parameters.\n"
-                                f"Exception raised: {type(e)} with message: " + str(e)) from e
+    @staticmethod
+    def _probe(kind, module, name, params, build):
+        """Resolve `name` in `module` and construct it once on a throw-away 2 x 2 layer."""
+        cls = getattr(module, name, None)
+        if cls is None:
+            raise AttributeError(f"{module.__name__} has no {kind} called `{name}`: check the spelling of `{kind}_cls`.")
+        try:
+            return build(cls, dict(params or {}))
+        except TypeError as err:
+            raise TypeError(f"`{kind}_params` = {params} does not fit {cls.__name__}: {err}") from err

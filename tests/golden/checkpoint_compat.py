@@ -104,13 +104,11 @@ def trainer_checkpoint():
         opt.load_state_dict(sd)
         assert opt.step_count == 6 and opt.lr == 1e-3 and opt.betas == (0.8, 0.95)
         ref_params = list(trainer._best_model.parameters())
-        off = 0
-        for p in flat.params:
+        for p, off in zip(flat.params, flat.offsets):  # parameters sit on 256-byte boundaries of the flat buffer
             i = [id(q) for q in flat.all_params].index(id(p))
             k = p.numel()
             assert torch.equal(opt.m[off:off + k], sd["state"][i]["exp_avg"].reshape(-1))
             assert torch.equal(opt.v[off:off + k], sd["state"][i]["exp_avg_sq"].reshape(-1))
-            off += k
         # and back: the fused Adam's state loads into the reference trainer's optimizer
         trainer.optimizer.load_state_dict(opt.state_dict())
         back = trainer.optimizer.state_dict()

@@ -186,8 +186,32 @@ def compare_grads(model, ograds, a, rtol=RTOL):
     return worst
 
 
+@pytest.fixture(params=["default dispatch", "register-stationary kernels"])
+def svhn_engine(request, monkeypatch):
+    """The size-based dispatch (tiled engine at the goldens' small batches), then csrc/imgconv.hip for every batch size
+    (mvk_debug_set_flags 0x200) with the scaled-fp16 product form of the SVHN decoder from the first row on: the kernels the
+    benchmark sizes dispatch to, on the small reference goldens."""
+    import ctypes
+
+    from multivae_amd import _lib, kernels
+
+    lib = _lib.load()
+    lib.mvk_debug_set_flags.argtypes = [ctypes.c_int]
+    if request.param != "default dispatch":
+        monkeypatch.setattr(kernels, "IMG_F16_MIN_ROWS", 1)
+        lib.mvk_debug_set_flags(0x200)
+    yield request.param
+    lib.mvk_debug_set_flags(0)
+
+
+def _engine_applies(name, engine):
+    if engine != "default dispatch" and "mnistsvhn" not in name:
+        pytest.skip("no SVHN network in this case")
+
+
 @pytest.mark.parametrize("name", G.MOPOE_CASES)
-def test_mopoe_golden(name):
+def test_mopoe_golden(name, svhn_engine):
+    _engine_applies(name, svhn_engine)
     cfg, a, dims, data, masks, sd_np, model, inputs, d = prep(name)
     kw = dict(noise=G.t(a["eps"]).to(d))
     if "choice" in a:
@@ -271,7 +295,8 @@ def test_jmvae_golden(name):
 
 
 @pytest.mark.parametrize("name", G.MMVAE_CASES)
-def test_mmvae_golden(name):
+def test_mmvae_golden(name, svhn_engine):
+    _engine_applies(name, svhn_engine)
     cfg, a, dims, data, masks, sd_np, model, inputs, d = prep(name)
     with torch.no_grad():
         model.prior_log_var.copy_(G.t(a["prior_log_var"]).to(d))
@@ -287,6 +312,123 @@ def test_mmvae_golden(name):
     # IWAE weights are exp(lw - lse) with |lw| ~ 4e3: one fp32 ulp of lw is 2.4e-4, so the weights (and the
     # gradients they scale) carry ~1e-4 relative noise in ANY fp32 evaluation order
     compare_grads(model, og, a, rtol=5e-4)
+
+
+# ---- BASELINE configs 3 and 2 at FULL size, on the dispatch the benchmark takes ----------------------------------------------
+def oracle_with_hip_decisions(cfg, dims, data, masks, sd_np, a, model, taps):
+    """The oracle's full gradients with the rectifier decisions of the HIP path on the ambiguous units (tests/relu_sites.py):
+    everything outside |pre| <= 2e-6 max|pre| is asserted to agree; -> (oracle output, gradients, ambiguous, flipped)."""
+    import relu_sites as RS
+
+    (o, og), n_amb, n_flip = RS.oracle_with_hip_decisions(lambda: oracle_full_grads(cfg, dims, data, masks, sd_np, a), model, taps)
+    return o, og, n_amb, n_flip
+
+
+def test_mopoe_fullsize_golden():
+    """BASELINE configs[2] at its per-device size (B = 512, K = 10) against the fixture generated from the real reference
+    (tests/golden/make_golden.py `fullsize_main`; mopoe_model.py:147-227, nn/svhn.py:7-70): the step runs on the DEFAULT
+    dispatch — scaled-fp16 register-stationary convolutions, fused decoder tail — eagerly and as a hipGraph replay.
+    Loss, metrics, posterior parameters at 1e-4; every gradient entry by entry at 1e-4 of the tensor's largest entry against
+    the oracle evaluated with the HIP path's decisions on the ~300 rectifier units within 2e-6 of zero."""
+    from multivae_amd import _lib, kernels
+    from multivae_amd.trainers import FlatParams, GraphedStep
+
+    name = "mopoe_mnistsvhn_k10_b512"
+    cfg, a, dims, data, masks, sd_np, model, inputs, d = prep(name)
+    n = cfg["K"] * cfg["B"]
+    # the shapes of this case are the ones the register-stationary scaled-fp16 kernels and the fused tail accept
+    assert kernels.IMG_F16 and kernels.conv4s2_scaled_ok(n, 4, 4, 64, 128) and kernels.conv4s2_scaled_ok(n, 8, 8, 32, 64)
+    assert kernels.svhn_fused_tail_ok(3, 32)
+    eps = G.t(a["eps"]).to(d)
+    kernels.TAPS = []
+    try:
+        out = model(inputs, noise=eps)
+        taps = kernels.TAPS
+    finally:
+        kernels.TAPS = None
+    check(a["loss"], out.loss, "loss")
+    check(a["loss_sum"], out.loss_sum, "loss_sum")
+    for k, v in out.metrics.items():
+        check(a["metric/" + k], v, k)
+    lat = model.inference(inputs, noise=eps)
+    check(a["mus"], lat["mus"], "subset mus")
+    check(a["logvars"], lat["logvars"], "subset logvars")
+    check(a["joint_mu"], lat["joint"][0], "joint mu")
+    check(a["joint_logvar"], lat["joint"][1], "joint logvar")
+    out.loss.backward()
+    o, og, n_amb, n_flip = oracle_with_hip_decisions(cfg, dims, data, masks, sd_np, a, model, taps)
+    print(f"{name}: {n_amb} rectifier units within 2e-6 of zero, {n_flip} decided the other way by the HIP path")
+    check(o["loss"].detach().numpy(), out.loss, "loss vs oracle")
+    compare_grads(model, og, a)
+    eager_loss = float(out.loss.detach())
+    # the same step as ONE hipGraph replay (what bench.py and BaseTrainer run)
+    flat = FlatParams(model)
+    gs = GraphedStep(model, flat, inputs, noise=eps)
+    out_g = gs(inputs, eps)
+    torch.cuda.synchronize()
+    assert float(out_g.loss.detach()) == eager_loss
+    compare_grads(model, og, a)
+
+
+def test_mmvae_fullsize_golden():
+    """BASELINE configs[1] at its size (MMVAE MnistSvhn, K = 1, B = 256, Normal / IWAE), as above."""
+    from multivae_amd import kernels
+
+    name = "mmvae_mnistsvhn_normal_iwae_k1_b256"
+    cfg, a, dims, data, masks, sd_np, model, inputs, d = prep(name)
+    with torch.no_grad():
+        model.prior_log_var.copy_(G.t(a["prior_log_var"]).to(d))
+    mods = cfg["names"]
+    noise = {m: G.t(a["noise/" + m]).to(d) for m in mods}
+    kernels.TAPS = []
+    try:
+        out = model(inputs, noise=noise, detailed_output=True)
+        taps = kernels.TAPS
+    finally:
+        kernels.TAPS = None
+    check(a["loss"], out.loss, "loss")
+    for m in mods:
+        check(a["zs/" + m], out.zss[m], "z " + m)
+        check(a["lws/" + m], out.lws[m], "lw " + m)
+    out.loss.backward()
+    o, og, n_amb, n_flip = oracle_with_hip_decisions(cfg, dims, data, masks, sd_np, a, model, taps)
+    print(f"{name}: {n_amb} rectifier units within 2e-6 of zero, {n_flip} decided the other way by the HIP path")
+    compare_grads(model, og, a)
+
+
+@pytest.mark.parametrize("name", ["mmvae_tiny_normal_iwae", "mmvaeplus_tiny_laplace_dreg"])
+def test_stacked_decoding_is_opt_in_per_decoder(name):
+    """MMVAE / MMVAE+ decode all conditioning modalities' latents in one stacked pass only through decoders that declare
+    `rows_independent` (every in-package one); any other decoder is run pair by pair like in the reference
+    (mmvae_model.py:127, mmvaePlus_model.py:172-186) — same loss and gradients, and a decoder with a non-contiguous output or
+    batch statistics keeps the reference's semantics."""
+    cfg, a, dims, data, masks, sd_np, model, inputs, d = prep(name)
+    mods = cfg["names"]
+    if cfg["model"] == "MMVAE":
+        noise = {m: G.t(a["noise/" + m]).to(d) for m in mods if ("noise/" + m) in a}
+    else:
+        mods = [m for m in mods if ("lws/" + m) in a]
+        noise = {c: {k.split("/")[2]: G.t(v).to(d) for k, v in a.items() if k.startswith(f"noise/{c}/")} for c in mods}
+    calls = []
+    for m, dec in model.decoders.items():
+        assert dec.rows_independent
+        dec.register_forward_hook(lambda mod, args, out, m=m: calls.append((m, args[0].reshape(-1, args[0].shape[-1]).shape[0])))
+    out = model(inputs, noise=noise)
+    out.loss.backward()
+    stacked_calls, calls[:] = list(calls), []
+    g_stacked = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    for dec in model.decoders.values():
+        dec.rows_independent = False
+    out2 = model(inputs, noise=noise)
+    out2.loss.backward()
+    M = len(noise)
+    assert len(stacked_calls) == len(model.decoders) and len(calls) == M * len(model.decoders), (stacked_calls, calls)
+    assert sum(n for _, n in stacked_calls) == sum(n for _, n in calls)
+    check(out.loss.detach().cpu().numpy(), out2.loss, "loss, pair by pair", rtol=1e-6)
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            check(g_stacked[k].cpu().numpy(), p.grad, "grad " + k, rtol=1e-5)
 
 
 def test_missing_modality_gives_exactly_zero_encoder_grads():

@@ -695,3 +695,19 @@ def test_distributed_step_two_ranks_on_one_gpu(tmp_path):
     assert err <= 2e-6, f"distributed parameters differ from the replay by {err:.3e} after {steps} Adam steps of {_DP['lr']}"
     for r, got in ((0, r0["loss"]), (1, r1["loss"])):
         assert got == pytest.approx(losses[r], rel=1e-5), (r, got, losses[r])
+
+
+def test_shipped_configuration_without_mvk_tune():
+    """The suite runs under MVK_TUNE=1 (tests/conftest.py) so that single tests can pick a secondary kernel; users ship
+    WITHOUT it (`mvk_tune()` returns nullptr, `_lib.tune()` the default).  The full-size reference goldens and a trainer run,
+    once more in a process where the switches are off."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MVK_TUNE="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_golden.py", "tests/test_gpu_trainer.py",
+                        "-k", "fullsize_golden or base_trainer_mvtcae_cfg1 or (mopoe_golden and mnistsvhn)"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout

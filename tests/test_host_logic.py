@@ -368,3 +368,17 @@ def test_flat_params_align_every_parameter_and_keep_the_optimizer_layout():
     opt2 = FusedAdam(FlatParams(torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 7), torch.nn.Linear(7, 2))), lr=1e-3)
     opt2.load_state_dict(sd)
     assert opt2.step_count == 3 and torch.equal(opt2.flat.dense(opt2.m), flat.dense(opt.m))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/multivae"), reason="needs the reference checkout (build container only)")
+def test_checkpoint_compat_script_against_the_real_reference():
+    """tests/golden/checkpoint_compat.py (folders written by either side load on the other side with identical
+    configuration fields, state_dict and Adam moments) runs green as committed — INTEGRATION.md cites it."""
+    import subprocess
+    import sys
+
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "checkpoint_compat.py")
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "optimizer state back OK" in r.stdout

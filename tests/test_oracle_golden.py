@@ -465,3 +465,45 @@ def test_dmvae_joint_nll(name):
                                        dists=cfg.get("dists"))
     close(a["nll"], nll)
     close(a["ll"], ll)
+
+
+def test_relu_site_recorder_and_forcing_reproduce_the_oracle():
+    """tests/relu_sites.py: recording the rectifier sites does not change the oracle, and forcing the oracle's OWN decisions
+    reproduces its loss and gradients bit for bit (the GPU parity tests force the HIP path's decisions on the units within
+    2e-6 of zero instead); a dictated decision takes effect in the network it belongs to and upstream of it, nowhere else."""
+    import relu_sites as RS
+
+    cfg, a = G.load_case("mopoe_mnistsvhn_k10")
+    dims, data, masks, sd_np = G.build_inputs(cfg)
+
+    def run():
+        sd = {k: G.t(v).clone().requires_grad_(True) for k, v in sd_np.items()}
+        enc_f, dec_f = nets.build_mnist_svhn(sd, cfg["L"])
+        td = {m: G.t(v) for m, v in data.items()}
+        e = {m: enc_f[m](td[m]) for m in cfg["names"]}
+        o = elbo.mopoe_forward(e, td, dec_f, G.t(a["eps"]), names=cfg["names"], beta=cfg["beta"],
+                               rescale=elbo.rescale_factors(dims, cfg["rescaling"]), dists=cfg["dists"], masks=None, choice=None)
+        o["loss"].backward()
+        return o["loss"].detach(), {k: v.grad.clone() for k, v in sd.items()}
+
+    loss0, g0 = run()
+    sites = RS.OracleSites()
+    with sites.record():
+        loss1, g1 = run()
+    assert torch.equal(loss0, loss1) and all(torch.equal(g0[k], g1[k]) for k in g0)
+    assert set(sites.pre) == {("encoders.mnist.", 0), ("encoders.mnist.", 1), ("encoders.svhn.", 0), ("encoders.svhn.", 1),
+                              ("encoders.svhn.", 2), ("decoders.mnist.", 0), ("decoders.svhn.", 0), ("decoders.svhn.", 1),
+                              ("decoders.svhn.", 2)}
+    own = {k: [p > 0 for p in v] for k, v in sites.pre.items()}
+    with sites.force(own):
+        loss2, g2 = run()
+    assert torch.equal(loss0, loss2) and all(torch.equal(g0[k], g2[k]) for k in g0)
+    # switch one active unit of the svhn decoder's second layer off: the other decoder keeps its gradients exactly
+    m = own[("decoders.svhn.", 1)][0]
+    idx = tuple(int(i) for i in torch.nonzero(m)[0])
+    m[idx] = False
+    with sites.force(own):
+        _, g3 = run()
+    assert torch.equal(g0["decoders.mnist.layers.1.0.weight"], g3["decoders.mnist.layers.1.0.weight"])
+    assert not torch.equal(g0["decoders.svhn.dec.2.weight"], g3["decoders.svhn.dec.2.weight"])
+    assert not torch.equal(g0["encoders.mnist.layers.0.0.weight"], g3["encoders.mnist.layers.0.0.weight"])
