@@ -187,9 +187,11 @@ def test_mmvaeplus_resnet_golden_gpu(name, conv3_engine):
     print(f"{name} [{conv3_engine}]: {n_amb} LeakyReLU units within 2e-6 of zero, {n_flip} decided the other way by the HIP path")
     check(o["loss"].detach(), out.loss, "loss vs oracle")
     mg = model_grads(model)
-    # K = 10 importance weights are exp(lw - lse) with |lw| ~ 3e3: 1e-4 relative noise in any fp32 evaluation order, hence
-    # 5e-4 for the IWAE gradients at K = 10 (as in test_gpu_golden.py's MMVAE K = 10 cases)
-    rtol = 5e-4 if cfg["K"] >= 10 else RTOL
+    # K > 1: the importance weights are exp(lw - lse) with |lw| ~ 3e3, one fp32 ulp of lw is 2.4e-4, so the weights (and the
+    # gradients they scale) carry ~1e-4 relative noise in ANY fp32 evaluation order — the CPU fp32 oracle itself is 4e-4 away
+    # from its own float64 evaluation on these cases (tools/repro_probe.py); hence 5e-4 for the IWAE / DReG gradients, as in
+    # test_gpu_golden.py's K > 1 cases (measured with the decisions reconciled: 1.1e-4 at K = 3)
+    rtol = 5e-4 if cfg["K"] > 1 else RTOL
     for k, g in og.items():
         check(g, mg[k], "grad " + k, rtol=rtol)
     if n_flip == 0:  # the fixture holds the REFERENCE's gradients, i.e. the reference's decisions

@@ -4,8 +4,10 @@ set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 echo "=== rocminfo"; rocminfo 2>/dev/null | grep -m2 -E "gfx950|Marketing" 
+echo "=== fullsize probe"
+timeout 600 python tools/fullsize_probe.py > gpurun_out/fullsize_probe.log 2>&1; tail -30 gpurun_out/fullsize_probe.log
 echo "=== pytest gpu"
-timeout 1500 python -m pytest tests -m gpu -q -x --timeout=600 2>&1 | tail -40 | tee gpurun_out/pytest_gpu.log
+timeout 2400 python -m pytest tests -m gpu -q --timeout=900 -rf -s 2>&1 > gpurun_out/pytest_gpu.log; tail -60 gpurun_out/pytest_gpu.log
 echo "=== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/smoke.log
 echo "=== bench"
