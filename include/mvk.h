@@ -528,6 +528,11 @@ int mvk_conv4s2_small_up_fwd_nll(const float* V, const float* Wref, const float*
 int mvk_conv4s2_small_up_bwd_pre(const float* dpre, const float* rowscale, const float* V, int v_act, const float* Wref,
                                  float* dV, float* dWref, float* db, float* db_v, float* ws, int64_t ws_floats, int n, int h,
                                  int w, int Cu, int Cv, void* stream);
+/* ..._fwd_nll with the stored gradient pre-multiplied by grad_weight (the weight the rows enter the loss with: a backward pass
+ * whose upstream row gradient is exactly that constant passes rowscale = NULL and reads no row gradient) */
+int mvk_conv4s2_small_up_fwd_nll_w(const float* V, const float* Wref, const float* bias, const float* X, int xrows, float scale,
+                                   float grad_weight, float* dpre, float* rows, int n, int h, int w, int Cu, int Cv, int act,
+                                   void* stream);
 
 /* 1x1-spatial layers:
  *   unflatten  Y[n,(tap,co)] = act(z[n,Cin] Wp + b[co]), Wp[ci][tap*Cout+co] = Wref[ci][co][tap]
@@ -635,6 +640,52 @@ int mvk_defer_end(void* stream);
  * from it (multivae_amd/kernels.py grows its arena between steps instead of reserving a fixed 512 MB). */
 int64_t mvk_defer_wanted(void);
 int mvk_defer_pending(void);
+
+/* Dense layers on pre-split fp16 pair planes (csrc/dense16.hip): the MLP decoder of the MnistSvhn models at the decoder batch
+ * (reference: models/nn/default_architectures.py:225-258 Decoder_AE_MLP; likelihood models/base/base_utils.py:62-87).
+ * A "planes" tensor [R][C] is two fp16 arrays hi, lo [R][C] with x s = hi + lo / 2048 (csrc/bf3.hpp); s is a power of two
+ * derived from a device scalar `bound` >= max |x| (activations, gradients: one per tensor) or kept per plane ROW as inv[r] = 1 / s_r
+ * (weights).  Every operand is split ONCE by its producer; the GEMM kernels move 16-byte pieces and issue three fp16 MFMAs per
+ * fp32 product with no conversion arithmetic in the loop.  C % 8 == 0, 16-byte aligned planes.
+ *   mvk_dense16_pack      W [N][K] (nn.Linear) -> planes [N][K] + nk_inv[N] (forward operand) and planes [K][N] + kn_inv[K]
+ *                         (backward-data operand), one launch per step
+ *   mvk_dense16_first     H planes [M][N] = act(Z [M][K] W^T + bias), K <= 32, N <= 1024 with 256 % (N / 4) == 0; *bound receives
+ *                         the a-priori bound max_n ||W[n]||_1 z_amax + max |bias| the planes are scaled by (z_amax: device scalar
+ *                         >= max |Z|, e.g. from mvk_amax)
+ *   mvk_dense16_fwd_nll   the output layer + its likelihood: r = sigmoid(H W^T + bias) scored against X[m % xrows] by Normal(scale);
+ *                         rows_part [mvk_dense16_fwd_nll_rows(N)][M] receives partial NLL row sums (their sum over the first axis
+ *                         is -log p(x | r) of the row), G planes [M][N] = grad_weight * d NLL / d pre-activation under the bound
+ *                         grad_weight (1 + x_amax) / (4 scale^2) written to *g_bound, colsum_part [mvk_dense16_colsum_rows(M)][N]
+ *                         (optional) the column sums of G per row tile (the bias gradient's partials).  Neither the reconstruction
+ *                         nor its gradient is written as an fp32 tensor.
+ *   mvk_dense16_bwd_data  dA [M][N] fp32 = (G [M][K] planes x W planes [N][K] (the [K][N]-orientation pack of the layer's weight))
+ *                         * ReLU'(mask) with mask_hi = the hi plane of the activation dA lands in (or NULL); db (optional) +=
+ *                         column sums of dA (deferred finish when db lies in the registered gradient buffer, else ws)
+ *   mvk_dense16_wgrad     dW [N][K] += G^T H over the M rows (both planes tensors; ordered finish of per-slice slabs: deferred,
+ *                         else ws of >= slices * N * K floats), db [N] += the rows of colsum_part in order
+ *   mvk_dense16_unsplit   planes -> fp32, optionally times rowf[m] * rowf_scale — rowf_tile > 0: rowf[(n / rowf_tile) M + m], one factor
+ *                         per column tile and row, the layout of rows_part — (tests; the general backward when the upstream
+ *                         row gradient is not the weight folded into G) */
+int mvk_dense16_ok(int M, int N, int K);
+int mvk_dense16_pack(const float* W, int N, int K, void* nk_hi, void* nk_lo, float* nk_inv, void* kn_hi, void* kn_lo,
+                     float* kn_inv, void* stream);
+int mvk_dense16_first(const float* Z, const float* W, const float* bias, const float* z_amax, void* hi, void* lo, float* bound,
+                      int M, int N, int K, int act, void* stream);
+int mvk_dense16_fwd_nll_rows(int N);
+int mvk_dense16_colsum_rows(int M);
+int mvk_dense16_fwd_nll(const void* h_hi, const void* h_lo, const float* h_bound, const void* w_hi, const void* w_lo,
+                        const float* w_inv, const float* bias, const float* X, int xrows, const float* x_amax, float scale,
+                        float grad_weight, void* g_hi, void* g_lo, float* g_bound, float* rows_part, float* colsum_part, int M,
+                        int N, int K, void* stream);
+int mvk_dense16_bwd_data(const void* g_hi, const void* g_lo, const float* g_bound, const void* wt_hi, const void* wt_lo,
+                         const float* wt_inv, const void* mask_hi, float* dA, float* db, float* ws, int64_t ws_floats, int M, int N,
+                         int K, void* stream);
+int mvk_dense16_wgrad(const void* g_hi, const void* g_lo, const float* g_bound, const void* h_hi, const void* h_lo,
+                      const float* h_bound, const float* colsum_part, int cs_rows, float* dW, float* db, float* ws,
+                      int64_t ws_floats, int M, int N, int K, void* stream);
+int mvk_dense16_unsplit(const void* hi, const void* lo, const float* bound, const float* rowf, float rowf_scale, int rowf_tile,
+                        int M, int N, float* out, void* stream);
+void mvk_dense16_debug(int flags); /* ablation switches of tools/dense16_probe.py (0 = the shipped kernels) */
 
 /* Device-timestamp profiler (bench.py's roofline objects).  device_slots: nslots records of MVK_PROF_SLOT_U64 = 520
  * uint64 each: [0] sum of durations (clock ticks, first workgroup in -> last workgroup out), [1] launches accumulated,

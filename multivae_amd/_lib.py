@@ -101,6 +101,7 @@ PROTOTYPES = {
     "mvk_f32_to_bf3": [_p, _i64, _p, _p],
     "mvk_bf3_to_f32": [_p, _i64, _p, _p],
     "mvk_conv4s2_small_up_fwd_nll": [_p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "mvk_conv4s2_small_up_fwd_nll_w": [_p, _p, _p, _p, _i, _f, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "mvk_conv4s2_small_up_bwd_pre": [_p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p],
     "mvk_conv3x3": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i64, _p],
     "mvk_conv3x3_res": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _f, _p, _i64, _p],
@@ -161,6 +162,12 @@ PROTOTYPES = {
     "mvk_kl_gauss_bwd": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p],
     "mvk_logprob_fwd": [_p, _p, _i64, _i64, _i, _f, _i, _f, _p, _p],
     "mvk_logprob_bwd": [_p, _p, _i64, _i64, _i, _f, _i, _f, _p, _p, _p],
+    "mvk_dense16_pack": [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p],
+    "mvk_dense16_first": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "mvk_dense16_fwd_nll": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _f, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "mvk_dense16_bwd_data": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _p],
+    "mvk_dense16_wgrad": [_p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i64, _i, _i, _i, _p],
+    "mvk_dense16_unsplit": [_p, _p, _p, _p, _f, _i, _i, _i, _p, _p],
 }
 
 _lib = None
@@ -212,6 +219,12 @@ def load(path=None):
     lib.mvk_prof_clock_khz.restype = C.c_int
     lib.mvk_imgconv_frag_bytes.argtypes = [_i, _i]
     lib.mvk_imgconv_frag_bytes.restype = C.c_int64
+    lib.mvk_dense16_ok.argtypes = [_i, _i, _i]
+    lib.mvk_dense16_ok.restype = C.c_int
+    lib.mvk_dense16_fwd_nll_rows.argtypes = [_i]
+    lib.mvk_dense16_fwd_nll_rows.restype = C.c_int
+    lib.mvk_dense16_colsum_rows.argtypes = [_i]
+    lib.mvk_dense16_colsum_rows.restype = C.c_int
     lib.mvk_splitk_workspace_floats.argtypes = [_i, _i, _i]
     lib.mvk_splitk_workspace_floats.restype = C.c_int64
     _lib = lib
@@ -272,6 +285,7 @@ GEMM_FLOPS = {
     "mvk_conv4s2_small_down_fwd": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
     "mvk_conv4s2_small_up_bwd": lambda a: 2.0 * 2.0 * a[12] * a[13] * a[14] * 16 * a[15] * a[16],  # data + weight
     "mvk_conv4s2_small_up_fwd_nll": lambda a: 2.0 * a[8] * a[9] * a[10] * 16 * a[11] * a[12],
+    "mvk_conv4s2_small_up_fwd_nll_w": lambda a: 2.0 * a[9] * a[10] * a[11] * 16 * a[12] * a[13],
     "mvk_conv4s2_small_up_bwd_pre": lambda a: 2.0 * 2.0 * a[11] * a[12] * a[13] * 16 * a[14] * a[15],  # data + weight
     "mvk_conv4s2_small_up_bwd_pre_y": lambda a: 2.0 * 2.0 * a[11] * a[12] * a[13] * 16 * a[14] * a[15],
     "mvk_gemm_smallk_amax": lambda a: 2.0 * a[3] * a[4] * a[5],
@@ -279,6 +293,10 @@ GEMM_FLOPS = {
     "mvk_flatten_wgrad": lambda a: 2.0 * a[3] * 16 * a[4] * a[5],
     "mvk_heads_fwd": lambda a: 2.0 * (2 if a[4] and a[4].value else 1) * a[7] * a[8] * a[9],
     "mvk_heads_bwd": lambda a: 4.0 * a[15] * a[16] * a[17] * (2 if a[3] else 1),
+    "mvk_dense16_first": lambda a: 2.0 * a[7] * a[8] * a[9],
+    "mvk_dense16_fwd_nll": lambda a: 2.0 * a[17] * a[18] * a[19],
+    "mvk_dense16_bwd_data": lambda a: 2.0 * a[11] * a[12] * a[13],
+    "mvk_dense16_wgrad": lambda a: 2.0 * a[12] * a[13] * a[14],
 }
 COUNT_FLOPS = None
 

@@ -184,7 +184,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
                                                               const float* __restrict__ bias, float* __restrict__ U, int n,
                                                               int act, mvk_prof_slot* prof, const float* __restrict__ X = nullptr,
                                                               int xrows = 1, float inv_s2 = 1.f, float lconst = 0.f,
-                                                              float* __restrict__ rows = nullptr) {
+                                                              float* __restrict__ rows = nullptr, float g_inv_s2 = 1.f) {
+  // g_inv_s2 = grad_weight / scale^2: the stored gradient carries the weight its row enters the loss with
   mvk_prof_begin(prof);
   using mvk::bf16x8;
   using mvk::u32x2;
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
         const float sum = ((buf[tap[t][0]] + buf[tap[t][1]]) + (buf[tap[t][2]] + buf[tap[t][3]])) + bia[t];
         const float r = mvk_act(sum, act), dlt = r - xv[t];
         part = fmaf(0.5f * inv_s2 * dlt, dlt, part);
-        out[tid + t * NT] = dlt * inv_s2 * mvk_act_grad_from_out(r, act);
+        out[tid + t * NT] = dlt * g_inv_s2 * mvk_act_grad_from_out(r, act);
       }
       part = wave_sum(part);
       if (lane == 0) buf[zidx + 1 + wave] = part;
@@ -1064,7 +1065,8 @@ static bool supported(int h, int w, int Cu, int Cv) {
 
 template <int CU, int CV>
 static int launch_fwd(const float* V, const float* Wref, const float* bias, float* U, int n, int h, int w, int act,
-                      hipStream_t s, const float* X = nullptr, int xrows = 1, float scale = 1.f, float* rows = nullptr) {
+                      hipStream_t s, const float* X = nullptr, int xrows = 1, float scale = 1.f, float* rows = nullptr,
+                      float grad_weight = 1.f) {
   const size_t lds = fwd_lds<CU, CV>(h * w);
   constexpr int NT = MVK_SMALL_FWD_THREADS;
   if (lds > 64 * 1024) {
@@ -1089,10 +1091,10 @@ static int launch_fwd(const float* V, const float* Wref, const float* bias, floa
       static const int nll_nt = mvk_tune("MVK_SMALL_NLL_NT") ? atoi(mvk_tune("MVK_SMALL_NLL_NT")) : 512;
       if (X && nll_nt == 1024)
         hipLaunchKernelGGL((small_up_fwd_bf_kernel<CU, 1024, true>), dim3(grid), dim3(1024), blds, s, V, Wref, bias, U, n, act,
-                           prof, X, xrows, inv_s2, lconst, rows);
+                           prof, X, xrows, inv_s2, lconst, rows, inv_s2 * grad_weight);
       else if (X)
         hipLaunchKernelGGL((small_up_fwd_bf_kernel<CU, 512, true>), dim3(grid), dim3(512), blds, s, V, Wref, bias, U, n, act,
-                           prof, X, xrows, inv_s2, lconst, rows);
+                           prof, X, xrows, inv_s2, lconst, rows, inv_s2 * grad_weight);
       else if (bf == 512)
         hipLaunchKernelGGL((small_up_fwd_bf_kernel<CU, 512>), dim3(grid), dim3(512), blds, s, V, Wref, bias, U, n, act, prof);
       else
@@ -1273,13 +1275,19 @@ int mvk_conv4s2_small_up_fwd(const float* V, const float* Wref, const float* bia
  * scored against X[i % xrows].  Only where mvk_conv4s2_small_up_nll_supported says so (16x16 x 32 channels -> 3 x 32x32). */
 int mvk_conv4s2_small_up_nll_supported(int h, int w, int Cu, int Cv) { return h == 16 && w == 16 && Cu == 3 && Cv == 32 ? 1 : 0; }
 
-int mvk_conv4s2_small_up_fwd_nll(const float* V, const float* Wref, const float* bias, const float* X, int xrows, float scale,
-                                 float* dpre, float* rows, int n, int h, int w, int Cu, int Cv, int act, void* stream) {
+int mvk_conv4s2_small_up_fwd_nll_w(const float* V, const float* Wref, const float* bias, const float* X, int xrows, float scale,
+                                   float grad_weight, float* dpre, float* rows, int n, int h, int w, int Cu, int Cv, int act,
+                                   void* stream) {
   if (!V || !Wref || !X || !dpre || !rows || n < 0 || xrows <= 0 || !(scale > 0.f) || !mvk_aligned16(V) ||
       !mvk_conv4s2_small_up_nll_supported(h, w, Cu, Cv))
     return MVK_EINVAL;
   if (n == 0) return MVK_OK;
-  return launch_fwd<3, 32>(V, Wref, bias, dpre, n, h, w, act, mvk_stream(stream), X, xrows, scale, rows);
+  return launch_fwd<3, 32>(V, Wref, bias, dpre, n, h, w, act, mvk_stream(stream), X, xrows, scale, rows, grad_weight);
+}
+
+int mvk_conv4s2_small_up_fwd_nll(const float* V, const float* Wref, const float* bias, const float* X, int xrows, float scale,
+                                 float* dpre, float* rows, int n, int h, int w, int Cu, int Cv, int act, void* stream) {
+  return mvk_conv4s2_small_up_fwd_nll_w(V, Wref, bias, X, xrows, scale, 1.f, dpre, rows, n, h, w, Cu, Cv, act, stream);
 }
 
 /* Its backward: dpre (from mvk_conv4s2_small_up_fwd_nll) times rowscale[n] (d loss / d rows; NULL = 1) through the layer. */

@@ -1014,23 +1014,117 @@ class MLPHeadsFn(Function):
         return (dx, None, *grads)
 
 
+# The MLP decoder at the decoder batch on pre-split fp16 pair planes (csrc/dense16.hip): MVK_DENSE16=0 keeps the tiled engine
+DENSE16 = _lib.tune("MVK_DENSE16", "1") != "0"
+DENSE16_MIN_ROWS = 1024  # below, the tiled engine's latency-sized tiles win (tests set 1 to meet the small goldens)
+
+
+def mlp_fused_tail_ok(n, L, H, D):
+    """MLPDecoderFn's fused tail (mvk_dense16_*) takes z [n, L] -> Linear(L, H) + ReLU -> Linear(H, D) + Sigmoid."""
+    return (DENSE16 and n >= DENSE16_MIN_ROWS and 4 <= L <= 32 and L % 4 == 0 and 16 <= H <= 1024 and H % 16 == 0
+            and 256 % (H // 4) == 0 and D % 8 == 0 and bool(_lib.load().mvk_dense16_ok(n, D, H)))
+
+
+def _planes(rows, cols, like):
+    """An fp16 pair-planes buffer [2][rows][cols] (hi, lo): the bytes of the fp32 tensor it replaces."""
+    t = torch.empty((2, rows, cols), dtype=torch.float16, device=like.device)
+    return t, t[0], t[1]
+
+
+def dense16_pack(w):
+    """Planes of a Linear weight [N][K] in both orientations + the per-row inverse scales; once per forward pass inside a
+    pack_scope (the cache dies with the scope: the weights change at the next optimizer step)."""
+    sc = _PACK_SCOPE
+    key = ("dense16", w.data_ptr(), tuple(w.shape))
+    if sc is not None and key in sc["cache"]:
+        return sc["cache"][key]
+    N, K = w.shape
+    nk, kn = _planes(N, K, w), _planes(K, N, w)
+    nk_inv, kn_inv = _new((N,), w), _new((K,), w)
+    call("mvk_dense16_pack", ptr(w), N, K, ptr(nk[1]), ptr(nk[2]), ptr(nk_inv), ptr(kn[1]), ptr(kn[2]), ptr(kn_inv), stream_ptr())
+    out = (nk, nk_inv, kn, kn_inv)
+    if sc is not None:
+        sc["cache"][key] = out
+    return out
+
+
+_CONST_GRADS = {}  # data_ptr -> (weakref of the tensor, numel, value): gradient buffers known to hold ONE constant
+
+
+def register_const_grad(t, value):
+    """ReconLossFn.backward: `t` was filled with `value` by the forward launch (the unit-seed path)."""
+    import weakref
+
+    _CONST_GRADS[t.data_ptr()] = (weakref.ref(t), t.numel(), float(value))
+
+
+def const_grad(t):
+    """The constant every element of the gradient tensor `t` holds, when a producer registered it (None otherwise: read it on
+    the device).  The registration dies with the tensor: a recycled address never matches."""
+    e = _CONST_GRADS.get(t.data_ptr())
+    if e is None:
+        return None
+    ref, numel, value = e
+    src = ref()
+    if src is None or numel != t.numel() or src.data_ptr() != t.data_ptr():
+        _CONST_GRADS.pop(t.data_ptr(), None)
+        return None
+    return value
+
+
 class MLPDecoderFn(Function):
-    """z[...,L] -> Linear+ReLU -> Linear+Sigmoid -> reshape(*z.shape[:-1], *input_dim)."""
+    """z[...,L] -> Linear+ReLU -> Linear+Sigmoid -> reshape(*z.shape[:-1], *input_dim).
+
+    nll_x [B, D] given: the FUSED TAIL on fp16 pair planes (csrc/dense16.hip; the caller checks `mlp_fused_tail_ok`) — the
+    output layer scores its rows against nll_x[row % B] by a Normal(nll_scale) likelihood in its epilogue and the node returns
+    PARTIAL NLL row sums [P, *z.shape[:-1]] (their sum over P is -log p(x | decoder(z)) per row) instead of the reconstruction;
+    what is kept for the backward pass is nll_weight * d NLL / d pre-activation as planes.  nll_weight = the weight the rows
+    are expected to enter the loss with (d loss / d rows): when the backward pass receives exactly that constant (const_grad)
+    nothing is rescaled; any other upstream gradient takes the general path (planes -> fp32 times the row factor)."""
 
     @staticmethod
-    def forward(ctx, z, w0, b0, w1, b1, input_dim):
+    def forward(ctx, z, w0, b0, w1, b1, input_dim, nll_x=None, nll_scale=1.0, nll_weight=1.0):
         L = w0.shape[1]
         z2 = _c(z.reshape(-1, L))
+        ctx.fused = nll_x is not None
+        ctx.z_shape = z.shape
+        if ctx.fused:
+            n, H, D = z2.shape[0], w0.shape[0], w1.shape[0]
+            nk, nk_inv, kn, kn_inv = dense16_pack(w1)
+            am = _amax_slots(z2, 2)
+            zam, xam = am[0:1], am[1:2]
+            call("mvk_amax", ptr(z2), z2.numel(), ptr(zam), stream_ptr())
+            call("mvk_amax", ptr(nll_x), nll_x.numel(), ptr(xam), stream_ptr())
+            hp = _planes(n, H, z2)
+            gp = _planes(n, D, z2)
+            bounds = _new((2,), z2)  # [bound of h, bound of G]
+            call("mvk_dense16_first", ptr(z2), ptr(w0), ptr(b0), ptr(zam), ptr(hp[1]), ptr(hp[2]), ptr(bounds[0:1]), n, H, L, RELU,
+                 stream_ptr())
+            lib = _lib.load()
+            P, CR = lib.mvk_dense16_fwd_nll_rows(D), lib.mvk_dense16_colsum_rows(n)
+            rows = _new((P, n), z2)
+            cs = _new((CR, D), z2)
+            call("mvk_dense16_fwd_nll", ptr(hp[1]), ptr(hp[2]), ptr(bounds[0:1]), ptr(nk[1]), ptr(nk[2]), ptr(nk_inv), ptr(b1),
+                 ptr(nll_x), nll_x.shape[0], ptr(xam), float(nll_scale), float(nll_weight), ptr(gp[1]), ptr(gp[2]),
+                 ptr(bounds[1:2]), ptr(rows), ptr(cs), n, D, H, stream_ptr())
+            ctx.save_for_backward(z2, hp[0], gp[0], bounds, kn[0], kn_inv, cs, w0, b0, w1, b1)
+            ctx.nll_weight = float(nll_weight)
+            if TAPS is not None:  # tests: the hidden activation as an fp32 tensor (the sign of h is the sign of its hi plane)
+                h = _new((n, H), z2)
+                call("mvk_dense16_unsplit", ptr(hp[1]), ptr(hp[2]), ptr(bounds[0:1]), None, 1.0, 0, n, H, ptr(h), stream_ptr())
+                _tap("mlp_decoder", w0, h)
+            return rows.view(P, *z.shape[:-1])
         h = linear_fwd(z2, w0, b0, RELU)
         out = linear_fwd(h, w1, b1, SIGMOID)
         ctx.save_for_backward(z2, h, out, w0, b0, w1, b1)
         _tap("mlp_decoder", w0, h)
-        ctx.z_shape = z.shape
         return out.view(*z.shape[:-1], *input_dim)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
+        if ctx.fused:
+            return MLPDecoderFn._backward_fused(ctx, dout)
         z2, h, out, w0, b0, w1, b1 = ctx.saved_tensors
         dout = _c(dout).view(out.shape)
         # pre-activation gradient of the output layer + its bias gradient in one pass; the two GEMMs then read it
@@ -1046,7 +1140,40 @@ class MLPDecoderFn(Function):
         dz = None
         if ctx.needs_input_grad[0]:
             dz = linear_bwd_data(dh, w0).view(ctx.z_shape)
-        return dz, dw0, db0, dw1, db1, None
+        return dz, dw0, db0, dw1, db1, None, None, None, None
+
+    @staticmethod
+    def _backward_fused(ctx, drows):
+        z2, hp, gp, bounds, kn, kn_inv, cs, w0, b0, w1, b1 = ctx.saved_tensors
+        n, H, D = z2.shape[0], w0.shape[0], w1.shape[0]
+        hb, gb = bounds[0:1], bounds[1:2]
+        c = const_grad(drows)
+        ws = _ws(z2)
+        if c is not None and c == ctx.nll_weight:
+            # the planes already hold d loss / d pre-activation: two GEMMs on planes, bias gradients out of their launches
+            tw1, dw1 = _grad_target(w1)
+            tb1, db1 = _grad_target(b1)
+            tb0, db0 = _grad_target(b0)
+            dh = _new((n, H), z2)
+            call("mvk_dense16_bwd_data", ptr(gp[0]), ptr(gp[1]), ptr(gb), ptr(kn[0]), ptr(kn[1]), ptr(kn_inv), ptr(hp[0]), ptr(dh),
+                 ptr(tb0), ptr(ws), ws.numel(), n, H, D, stream_ptr())
+            call("mvk_dense16_wgrad", ptr(gp[0]), ptr(gp[1]), ptr(gb), ptr(hp[0]), ptr(hp[1]), ptr(hb), ptr(cs), cs.shape[0], ptr(tw1),
+                 ptr(tb1), ptr(ws), ws.numel(), n, D, H, stream_ptr())
+        else:  # general upstream gradient: d pre = G * drows[column tile, row] / nll_weight as an fp32 tensor, then the tiled engine
+            drows = _c(drows).reshape(-1, n)
+            dpre = _new((n, D), z2)
+            h = _new((n, H), z2)
+            call("mvk_dense16_unsplit", ptr(gp[0]), ptr(gp[1]), ptr(gb), ptr(drows), 1.0 / ctx.nll_weight, 128, n, D, ptr(dpre),
+                 stream_ptr())
+            call("mvk_dense16_unsplit", ptr(hp[0]), ptr(hp[1]), ptr(hb), None, 1.0, 0, n, H, ptr(h), stream_ptr())
+            db1 = colsum(dpre, b1)
+            dw1, _ = linear_bwd_weight(dpre, h, w1, None)
+            dh, db0 = linear_bwd_data(dpre, w1, prev_out=h, prev_act=RELU, prev_bias=b0)
+        dw0, _ = linear_bwd_weight(dh, z2, w0, None)
+        dz = None
+        if ctx.needs_input_grad[0]:
+            dz = linear_bwd_data(dh, w0).view(ctx.z_shape)
+        return dz, dw0, db0, dw1, db1, None, None, None, None
 
 
 # =====================================================================================================
@@ -1133,7 +1260,7 @@ class SVHNDecoderFn(Function):
     """z[...,L] -> ConvT(4,1,0)+ReLU -> 2x ConvT(4,2,1)+ReLU -> ConvT(4,2,1)+Sigmoid -> [...,C,32,32] NCHW."""
 
     @staticmethod
-    def forward(ctx, z, w0, b0, w1, b1, w2, b2, w3, b3, nll_x=None, nll_scale=1.0):
+    def forward(ctx, z, w0, b0, w1, b1, w2, b2, w3, b3, nll_x=None, nll_scale=1.0, nll_weight=1.0):
         """nll_x [B, C, 32, 32] given: the FUSED TAIL — the last layer scores its image against nll_x[row % B] by a
         Normal(nll_scale) likelihood in its epilogue (mvk_conv4s2_small_up_fwd_nll) and the node returns the NLL row sums
         [*z.shape[:-1]] instead of the images; the buffer that would hold the images holds d rows / d pre-activation for the
@@ -1176,8 +1303,10 @@ class SVHNDecoderFn(Function):
         ctx.fused = nll_x is not None
         if ctx.fused:
             rows = _new((n,), z2)
-            call("mvk_conv4s2_small_up_fwd_nll", ptr(g3), ptr(w3), ptr(b3), ptr(nll_x), nll_x.shape[0], float(nll_scale), ptr(out),
-                 ptr(rows), n, 16, 16, C4, C3, SIGMOID, stream_ptr())
+            # the stored gradient is pre-multiplied by nll_weight, the weight the rows are expected to enter the loss with
+            ctx.nll_weight = float(nll_weight)
+            call("mvk_conv4s2_small_up_fwd_nll_w", ptr(g3), ptr(w3), ptr(b3), ptr(nll_x), nll_x.shape[0], float(nll_scale),
+                 float(nll_weight), ptr(out), ptr(rows), n, 16, 16, C4, C3, SIGMOID, stream_ptr())
         elif small:  # per-image MFMA column-matrix kernel (smallconv.hip)
             call("mvk_conv4s2_small_up_fwd", ptr(g3), ptr(w3), ptr(b3), ptr(out), n, 16, 16, C4, C3, SIGMOID,
                  stream_ptr())
@@ -1199,8 +1328,14 @@ class SVHNDecoderFn(Function):
     def backward(ctx, dout):
         z2, g1, g2, g3, out, wp0, wd1, wd2, wd3, w0, b0, w1, b1, w2, b2, w3, b3 = ctx.saved_tensors
         n, L, C1, C2, C3, C4 = ctx.dims
-        if ctx.fused:  # dout = d loss / d rows [n]; `out` holds d rows / d pre-activation
-            drows = _c(dout).reshape(-1)
+        if ctx.fused:  # dout = d loss / d rows [n]; `out` holds nll_weight * d rows / d pre-activation
+            c = const_grad(dout)
+            if c is not None and c == ctx.nll_weight:
+                drows = None  # exactly the weight folded into `out`: no row gradient is read (nor waited for)
+            else:
+                drows = _c(dout).reshape(-1)
+                if ctx.nll_weight != 1.0:
+                    drows = drows * (1.0 / ctx.nll_weight)
             tw3, dw3 = _grad_target(w3)
             tb3, db3 = _grad_target(b3)
             dg3 = _new((n, 16, 16, C3), z2)
@@ -1268,12 +1403,12 @@ class SVHNDecoderFn(Function):
                 call("mvk_unflatten_wgrad", ptr(z2), ptr(dg1f), ptr(tw0), n, L, C1, ptr(ws), ws.numel(), stream_ptr())
             if dw0 is not None or dw1 is not None or dw2 is not None:  # a gradient autograd itself accumulates: join now
                 torch.cuda.current_stream(z2.device).wait_stream(_side_stream(z2.device, 30))
-            return dz, dw0, db0, dw1, db1, dw2, db2, dw3, db3, None, None
+            return dz, dw0, db0, dw1, db1, dw2, db2, dw3, db3, None, None, None
         ws = _ws(z2)
         call("mvk_unflatten_wgrad", ptr(z2), ptr(dg1f), ptr(tw0), n, L, C1, ptr(ws), ws.numel(), stream_ptr())
         if ctx.needs_input_grad[0]:
             dz = gemm(dg1f, wp0, n, L, 16 * C1, tb=True).view(ctx.z_shape)
-        return dz, dw0, db0, dw1, db1, dw2, db2, dw3, db3, None, None
+        return dz, dw0, db0, dw1, db1, dw2, db2, dw3, db3, None, None, None
 
 
 def svhn_fused_tail_ok(C4, C3):
@@ -1778,6 +1913,14 @@ class ReconLossFn(Function):
         grads = list(ctx.drecons)
         if is_unit_seed(gloss):  # d loss = 1 exactly: every gradient below was written by the forward launches
             extras = list(ctx.dextras)
+            # a single-term extra tensor's gradient is ONE constant the host knows: a fused decoder tail whose stored gradient
+            # was pre-multiplied by it (MLPDecoderFn / SVHNDecoderFn `nll_weight`) then reads no row gradient at all
+            per = {}
+            for j, _off, _n, c in ctx.extra_grad:
+                per.setdefault(j, []).append(c)
+            for j, cs in per.items():
+                if extras[j] is not None and len(set(cs)) == 1:
+                    register_const_grad(extras[j], cs[0])
             ctx.drecons = ctx.dextras = None
             return (None, None, *grads, *extras)
         gloss = _c(gloss.reshape(1))

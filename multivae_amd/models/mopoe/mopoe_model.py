@@ -21,6 +21,22 @@ from .mopoe_config import MoPoEConfig
 _EARLY_NOISE = _lib.tune("MVK_EARLY_NOISE", "1") != "0"  # 0: draw the noise behind the encoders (A/B)
 
 
+_ROW_WEIGHT = {}
+
+
+def _takes_row_weight(dec):
+    """Whether a decoder's `reconstruction_nll` has the `row_weight` argument (in-package decoders; cached per class)."""
+    k = type(dec)
+    if k not in _ROW_WEIGHT:
+        import inspect
+
+        try:
+            _ROW_WEIGHT[k] = "row_weight" in inspect.signature(dec.reconstruction_nll).parameters
+        except (TypeError, ValueError):
+            _ROW_WEIGHT[k] = False
+    return _ROW_WEIGHT[k]
+
+
 class MoPoE(BaseMultiVAE):
     def __init__(self, model_config: MoPoEConfig, encoders: dict = None, decoders: dict = None):
         super().__init__(model_config, encoders, decoders)
@@ -199,7 +215,10 @@ class MoPoE(BaseMultiVAE):
         def decode(m):
             dec = self.decoders[m]
             if self.fused_decoder_tail and masks is None and self.recon_dists[m][0] == normal and hasattr(dec, "reconstruction_nll"):
-                rows = dec.reconstruction_nll(z_of(m), inputs.data[m], "normal", self.recon_dists[m][1])
+                kw = {}
+                if _takes_row_weight(dec):
+                    kw["row_weight"] = float(self.rescale_factors[m]) / (K * B)  # = extra_coef * extra_lossw of the term below
+                rows = dec.reconstruction_nll(z_of(m), inputs.data[m], "normal", self.recon_dists[m][1], **kw)
                 if rows is not None:
                     return ("rows", rows)
             return ("rec", dec(z_of(m)).reconstruction)

@@ -61,6 +61,26 @@ class Decoder_AE_MLP(BaseDecoder):
         out = kernels.MLPDecoderFn.apply(z, l0.weight, l0.bias, l1.weight, l1.bias, self.input_dim)
         return ModelOutput(reconstruction=out)
 
+    def reconstruction_nll(self, z: torch.Tensor, x: torch.Tensor, dist: str = "normal", scale: float = 1.0, row_weight=None):
+        """OPT-IN fast path for models that own the loss (MoPoE here; the contract of Decoder_VAE_SVHN.reconstruction_nll):
+        -log p(x | decoder(z)) under Normal(scale), computed in the epilogue of the output layer's GEMM on fp16 pair planes
+        (csrc/dense16.hip) so that neither the reconstruction nor its gradient travels through HBM as fp32.  Returns PARTIAL
+        row sums [P, *z.shape[:-1]] whose sum over P is the NLL of the row — a caller that only sums rows uses them as they
+        are —, or None when this decoder / likelihood / batch has no fused form (the caller then uses `forward` + the generic
+        likelihood kernel).  x: [B, *input_dim]; the rows of z are scored against x[row % B].  row_weight: the weight the rows
+        will enter the loss with (the expected d loss / d rows, e.g. rescale / (K B)): the stored gradient is pre-multiplied by
+        it, and a backward pass that receives exactly that constant rescales nothing."""
+        l0, l1 = self.layers[0][0], self.layers[1][0]
+        n = z.reshape(-1, z.shape[-1]).shape[0]
+        D = int(np.prod(self.input_dim))
+        if (dist != "normal" or not torch.is_grad_enabled() or z.shape[-1] != l0.weight.shape[1] or not x.is_cuda
+                or x.device != z.device or x.shape[0] == 0 or n % x.shape[0] != 0 or x[0].numel() != D
+                or not kernels.mlp_fused_tail_ok(n, l0.weight.shape[1], l0.weight.shape[0], D)):
+            return None
+        x2 = x.float().reshape(x.shape[0], D).contiguous()
+        return kernels.MLPDecoderFn.apply(z, l0.weight, l0.bias, l1.weight, l1.bias, self.input_dim, x2, float(scale),
+                                          1.0 if row_weight is None else float(row_weight))
+
 
 class Encoder_VAE_MLP_Style(BaseMultilatentEncoder):
     """`default_architectures.py:75-141`: Linear(prod D, 512)+ReLU and four linear heads, one autograd node."""

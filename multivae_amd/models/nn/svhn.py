@@ -65,13 +65,15 @@ class Decoder_VAE_SVHN(BaseDecoder):
                                           d[6].weight, d[6].bias)
         return ModelOutput(reconstruction=out)
 
-    def reconstruction_nll(self, z: torch.Tensor, x: torch.Tensor, dist: str = "normal", scale: float = 1.0):
+    def reconstruction_nll(self, z: torch.Tensor, x: torch.Tensor, dist: str = "normal", scale: float = 1.0, row_weight=None):
         """OPT-IN fast path for models that own the loss (MoPoE / MVTCAE here): -log p(x | decoder(z)) summed over the image,
         one value per latent row ([*z.shape[:-1]]), for a Normal(scale) likelihood — computed in the epilogue of the last
         ConvTranspose2d + Sigmoid, so neither the reconstruction nor its gradient travels through HBM (DESIGN.md section 4:
         `small_up_fwd_bf_kernel` fused tail).  Returns None when this decoder / likelihood has no fused form: the caller then
         uses `forward` + the generic likelihood kernel, as for every user-written decoder.  x: [B, C, 32, 32]; the rows of z are
-        scored against x[row % B] (K samples per data point)."""
+        scored against x[row % B] (K samples per data point).  row_weight: the weight the rows will enter the loss with (the
+        expected d loss / d rows): the stored gradient is pre-multiplied by it, and a backward pass that receives exactly that
+        constant reads no row gradient (Decoder_AE_MLP.reconstruction_nll has the same contract)."""
         d = self.dec
         if dist != "normal" or x.dim() != 4 or z.shape[-1] != self.latent_dim or not torch.is_grad_enabled() \
                 or not kernels.svhn_fused_tail_ok(d[6].weight.shape[1], d[6].weight.shape[0]):
@@ -83,4 +85,5 @@ class Decoder_VAE_SVHN(BaseDecoder):
             return None
         x = x.float().contiguous()
         return kernels.SVHNDecoderFn.apply(z, d[0].weight, d[0].bias, d[2].weight, d[2].bias, d[4].weight, d[4].bias,
-                                           d[6].weight, d[6].bias, x, float(scale))
+                                           d[6].weight, d[6].bias, x, float(scale),
+                                           1.0 if row_weight is None else float(row_weight))

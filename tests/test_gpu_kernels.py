@@ -1718,3 +1718,157 @@ def test_few_row_linear_matches_float64(M, N, K, act):
     ref = dict(none=lambda t: t, relu=torch.relu, sigmoid=torch.sigmoid)[act](ref)
     got = K_.linear_fwd(x.to(d), w.to(d), b.to(d), code)
     close_elementwise(got, ref.float(), "few-row linear", rtol=3e-6, atol_frac=3e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# csrc/dense16.hip: the MLP decoder on pre-split fp16 pair planes (reference: models/nn/default_architectures.py:225-258
+# Decoder_AE_MLP, likelihood models/base/base_utils.py:62-87) against float64 on the CPU
+# ---------------------------------------------------------------------------------------------------------------------
+from multivae_amd._lib import call, ptr, stream_ptr  # noqa: E402  (ctypes prototypes only: nothing is loaded at import)
+
+
+def _d16_planes(R, C_):
+    t = torch.empty(2, R, C_, dtype=torch.float16, device=dev())
+    return t[0], t[1]
+
+
+def _d16_unsplit(hi, lo, bound, R, C_):
+    out = torch.empty(R, C_, device=dev())
+    call("mvk_dense16_unsplit", ptr(hi), ptr(lo), ptr(bound), None, 1.0, 0, R, C_, ptr(out), stream_ptr())
+    return out
+
+
+@pytest.mark.parametrize("M,L,H,D,B,spread", [(1280, 20, 512, 784, 128, 0.0), (1048, 20, 512, 784, 131, 2.0), (384, 32, 256, 200, 384, 0.0),
+                                               (136, 8, 64, 72, 17, 1.0)])
+def test_dense16_chain_vs_float64(M, L, H, D, B, spread):
+    """mvk_dense16_pack / _first / _fwd_nll / _bwd_data / _wgrad / _unsplit: every stage against float64 at 3e-6 of the
+    tensor's maximum (the tolerance of the scaled-fp16 convolution tests), row tiles and column tiles that do not divide the
+    problem, a reduction length with a partial k-tile (K = 784, 200, 72), rows of very different magnitude (spread: a factor
+    10^(+-spread) per row of z and per row of W1), weights per plane row on their own scale."""
+    from multivae_amd import _lib as L_
+    lib = L_.load()
+    gen = g(11)
+    z = torch.randn(M, L, generator=gen) * torch.pow(10.0, (torch.rand(M, 1, generator=gen) - 0.5) * 2 * spread)
+    w0 = (torch.rand(H, L, generator=gen) - 0.5) * 2 / L ** 0.5
+    b0 = (torch.rand(H, generator=gen) - 0.5) * 2 / L ** 0.5
+    w1 = (torch.rand(D, H, generator=gen) - 0.5) * 2 / H ** 0.5 * torch.pow(10.0, (torch.rand(D, 1, generator=gen) - 0.5) * 2 * spread)
+    b1 = (torch.rand(D, generator=gen) - 0.5) * 2 / H ** 0.5
+    x = torch.rand(B, D, generator=gen) * 1.5 - 0.25
+    scale, gw = 0.75, 1.0 / M
+    zd, w0d, b0d, w1d, b1d, xd = (t.to(dev()) for t in (z, w0, b0, w1, b1, x))
+    # weight planes, both orientations, per-row scales
+    nk_hi, nk_lo = _d16_planes(D, H)
+    kn_hi, kn_lo = _d16_planes(H, D)
+    nk_inv, kn_inv = torch.empty(D, device=dev()), torch.empty(H, device=dev())
+    call("mvk_dense16_pack", ptr(w1d), D, H, ptr(nk_hi), ptr(nk_lo), ptr(nk_inv), ptr(kn_hi), ptr(kn_lo), ptr(kn_inv), stream_ptr())
+    w1r = (nk_hi.double() + nk_lo.double() / 2048) * nk_inv.double()[:, None]
+    w1t = (kn_hi.double() + kn_lo.double() / 2048) * kn_inv.double()[:, None]
+    keep = torch.ones(D, dtype=torch.bool)
+    close_per_slice(w1r, w1.double(), keep, 3e-7, "dense16 weight planes [N][K], every row on its own scale")
+    close_per_slice(w1t, w1.double().t().contiguous(), torch.ones(H, dtype=torch.bool), 3e-7, "dense16 weight planes [K][N]")
+    # first layer under the a-priori bound
+    zam, xam = torch.zeros(1, device=dev()), torch.zeros(1, device=dev())
+    call("mvk_amax", ptr(zd), zd.numel(), ptr(zam), stream_ptr())
+    call("mvk_amax", ptr(xd), xd.numel(), ptr(xam), stream_ptr())
+    h_hi, h_lo = _d16_planes(M, H)
+    bounds = torch.zeros(2, device=dev())
+    call("mvk_dense16_first", ptr(zd), ptr(w0d), ptr(b0d), ptr(zam), ptr(h_hi), ptr(h_lo), ptr(bounds[0:1]), M, H, L, 1, stream_ptr())
+    h64 = torch.relu(z.double() @ w0.double().t() + b0.double())
+    assert float(bounds[0]) >= float(h64.max())
+    close(_d16_unsplit(h_hi, h_lo, bounds[0:1], M, H), h64, 3e-6, "dense16 first layer")
+    # output layer + Normal NLL tail
+    g_hi, g_lo = _d16_planes(M, D)
+    P, CR = lib.mvk_dense16_fwd_nll_rows(D), lib.mvk_dense16_colsum_rows(M)
+    rows_part, cs = torch.zeros(P, M, device=dev()), torch.zeros(CR, D, device=dev())
+    call("mvk_dense16_fwd_nll", ptr(h_hi), ptr(h_lo), ptr(bounds[0:1]), ptr(nk_hi), ptr(nk_lo), ptr(nk_inv), ptr(b1d), ptr(xd), B,
+         ptr(xam), scale, gw, ptr(g_hi), ptr(g_lo), ptr(bounds[1:2]), ptr(rows_part), ptr(cs), M, D, H, stream_ptr())
+    r64 = torch.sigmoid(h64 @ w1.double().t() + b1.double())
+    xx = x.double()[torch.arange(M) % B]
+    rows64 = (0.5 * (r64 - xx) ** 2 / scale ** 2).sum(1) + D * (math.log(scale) + 0.918938533204672742)
+    g64 = gw * (r64 - xx) / scale ** 2 * r64 * (1 - r64)
+    assert float(bounds[1]) >= float(g64.abs().max())
+    G_ = _d16_unsplit(g_hi, g_lo, bounds[1:2], M, D)
+    # The tail is NOT linear in the GEMM: an error d_pre of the pre-activation moves G by |dG / d pre| d_pre <= gw / s^2 (1 + |x|) / 4
+    # d_pre, and d_pre is relative to sum_k |h_k w_k| (cancellation), not to |pre|.  Entry by entry: 1e-6 of that sum through the
+    # derivative bound + 3e-6 of the tensor's maximum (spread = 0: the second term alone covers it, as in the linear tests).
+    mag = h64 @ w1.double().abs().t() + b1.double().abs()
+    slack = 1e-6 * mag * gw / scale ** 2 * 0.25 * (1 + xx.abs())
+    exc = (G_.double().cpu() - g64).abs() - slack
+    assert float(exc.max()) <= 3e-6 * float(g64.abs().max()), ("dense16 d NLL / d pre-activation", float(exc.max()), float(g64.abs().max()))
+    rslack = (1e-6 * mag * (r64 - xx).abs() / scale ** 2 * 0.25).sum(1)
+    rexc = (rows_part.sum(0).double().cpu() - rows64).abs() - rslack
+    assert float(rexc.max()) <= 2e-6 * float(rows64.abs().max()), ("dense16 NLL rows", float(rexc.max()))
+    if spread == 0.0:
+        close(rows_part.sum(0), rows64, 2e-6, "dense16 NLL rows")
+        close(G_, g64, 3e-6, "dense16 d NLL / d pre-activation")
+    close(cs.sum(0), G_.double().cpu().sum(0), 3e-6, "dense16 column sums")
+    g64 = G_.double().cpu()  # the stages below are checked against what THIS gradient implies (each kernel on its own)
+    # backward data (ReLU mask from the hi plane of h) + bias gradient of the first layer
+    ws = torch.empty(max(CR * 2 * H, 64 * D * H) + 1024, device=dev())
+    dh, db0 = torch.empty(M, H, device=dev()), torch.zeros(H, device=dev())
+    call("mvk_dense16_bwd_data", ptr(g_hi), ptr(g_lo), ptr(bounds[1:2]), ptr(kn_hi), ptr(kn_lo), ptr(kn_inv), ptr(h_hi), ptr(dh), ptr(db0),
+         ptr(ws), ws.numel(), M, H, D, stream_ptr())
+    dh64 = (g64 @ w1.double()) * (h64 > 0)
+    close(dh, dh64, 3e-6, "dense16 backward data")
+    close(db0, dh64.sum(0), 3e-6, "dense16 db0")
+    # weight gradient (transposing LDS reads) + bias gradient from the forward's partials
+    dw1, db1 = torch.zeros(D, H, device=dev()), torch.zeros(D, device=dev())
+    call("mvk_dense16_wgrad", ptr(g_hi), ptr(g_lo), ptr(bounds[1:2]), ptr(h_hi), ptr(h_lo), ptr(bounds[0:1]), ptr(cs), CR, ptr(dw1),
+         ptr(db1), ptr(ws), ws.numel(), M, D, H, stream_ptr())
+    close(dw1, g64.t() @ h64, 3e-6, "dense16 weight gradient")
+    close(db1, g64.sum(0), 3e-6, "dense16 db1")
+    # planes -> fp32 with one factor per (column tile, row): the general backward path
+    rf = torch.rand(P, M, generator=gen) + 0.5
+    out = torch.empty(M, D, device=dev())
+    call("mvk_dense16_unsplit", ptr(g_hi), ptr(g_lo), ptr(bounds[1:2]), ptr(rf.to(dev())), 2.0, 128, M, D, ptr(out), stream_ptr())
+    fac = rf.double()[torch.arange(D) // 128].t() * 2.0  # [M, D]
+    close(out, g64 * fac, 3e-6, "dense16 unsplit with row factors")
+
+
+def test_mlp_decoder_fused_tail_matches_generic_path(monkeypatch):
+    """Decoder_AE_MLP.reconstruction_nll (planes + fused tail) against forward + the generic likelihood on the same inputs:
+    NLL rows, and every gradient for (a) the row weight the planes were built with (constant upstream gradient: the planes
+    path) and (b) an arbitrary upstream gradient per row (the general path through mvk_dense16_unsplit)."""
+    from multivae_amd import kernels
+    from multivae_amd.models.base.base_config import BaseAEConfig
+    from multivae_amd.models.nn.default_architectures import Decoder_AE_MLP
+
+    monkeypatch.setattr(kernels, "DENSE16_MIN_ROWS", 1)
+    torch.manual_seed(3)
+    K_, B, L = 3, 96, 20
+    dec = Decoder_AE_MLP(BaseAEConfig(latent_dim=L, input_dim=(1, 28, 28))).to(dev())
+    z = torch.randn(K_, B, L, device=dev(), requires_grad=True)
+    x = torch.rand(B, 1, 28, 28, device=dev())
+    scale, w = 0.75, 1.0 / (K_ * B)
+
+    def generic(up):
+        for p in dec.parameters():
+            p.grad = None
+        z.grad = None
+        rec = dec(z).reconstruction.reshape(K_, B, -1)
+        rows = (0.5 * (rec - x.reshape(1, B, -1)) ** 2 / scale ** 2).sum(-1) + 784 * (math.log(scale) + 0.918938533204672742)
+        (rows * up).sum().backward()
+        return rows.detach(), [p.grad.clone() for p in dec.parameters()], z.grad.clone()
+
+    def fused(up, const):
+        for p in dec.parameters():
+            p.grad = None
+        z.grad = None
+        part = dec.reconstruction_nll(z, x, "normal", scale, row_weight=w)
+        assert part is not None and part.shape[1:] == (K_, B)
+        if const:  # what ReconLossFn does on the unit-seed path: a registered constant gradient buffer
+            gbuf = torch.full_like(part, w)
+            kernels.register_const_grad(gbuf, w)
+            part.backward(gbuf)
+        else:
+            (part * up.unsqueeze(0)).sum().backward()
+        return part.detach().sum(0), [p.grad.clone() for p in dec.parameters()], z.grad.clone()
+
+    for const in (True, False):
+        up = torch.full((K_, B), w, device=dev()) if const else torch.rand(K_, B, device=dev()) * 2 * w
+        r0, g0, dz0 = generic(up)
+        r1, g1, dz1 = fused(up, const)
+        close(r1, r0, 2e-6, "fused MLP tail: NLL rows")
+        for a, b_, (nm, _) in zip(g1, g0, dec.named_parameters()):
+            close(a, b_, 1e-5, f"fused MLP tail ({'const' if const else 'general'}): d {nm}")
+        close(dz1, dz0, 1e-5, "fused MLP tail: dz")
