@@ -32,7 +32,24 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 MFMA_F32_TFLOPS = 157.3    # fp32-input MFMA = the fp32 vector rate
 MFMA_BF16_TFLOPS = 2500.0  # dense bf16 MFMA; an fp32 product on the split-bf16 path costs 6 bf16 products
 PROF_KINDS = {1: "recon_nll", 2: "imgconv_up", 3: "imgconv_down", 4: "imgconv_wgrad", 5: "image_layer_fwd",
-              6: "image_layer_bwd", 7: "conv3_rs", 8: "conv3_wgrad"}
+              6: "image_layer_bwd", 7: "conv3_rs", 8: "conv3_wgrad", 9: "dense16_fwd_nll", 10: "dense16_bwd", 11: "elbo_small"}
+
+
+def tracked_rocprof_avg_us(kernel):
+    """(avg us, file) of `kernel` in the newest tracked profiles/rNN_kernel_stats.md (the rocprofv3 --kernel-trace --stats summary
+    of this command), or None."""
+    import glob
+    import re
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_kernel_stats.md")), reverse=True):
+        for ln in open(path):
+            if ln.startswith("| ") and kernel in ln:
+                cols = [c.strip() for c in ln.strip().strip("|").split("|")]
+                try:
+                    return float(cols[3]), os.path.relpath(path, ROOT)
+                except (IndexError, ValueError):
+                    break
+    return None
 
 
 # ---- workloads --------------------------------------------------------------------------------------------------------
@@ -391,9 +408,10 @@ def main():
         with kernels.deferred_reductions(flat):
             out = model(inputs, **kw)
             out.loss.backward(gradient=kernels.unit_seed(out.loss))
+        scale = 1.0
         if use_dist and collective:
-            flat.all_reduce()  # C2: ONE all-reduce of the flat gradient buffer
-        opt.step(grad_scale=grad_scale)
+            scale = flat.all_reduce_mean()  # C2: ONE collective over the flat gradient buffer (mvk_allreduce_avg on RCCL)
+        opt.step(grad_scale=scale if (use_dist and collective) else grad_scale)
         return out
 
     # forward + backward replayed as ONE hipGraph launch (the host needs about as long to enqueue the
@@ -413,9 +431,7 @@ def main():
 
     def graph_step():
         out = graphed(inputs)  # copies the batch into the captured buffers, replays
-        if use_dist:
-            flat.all_reduce()
-        opt.step(grad_scale=grad_scale)
+        opt.step(grad_scale=flat.all_reduce_mean() if use_dist else 1.0)
         return out
 
     step = graph_step if graphed is not None else eager_step
@@ -509,7 +525,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (error-corrected 2xfp16 / 3xbf16 products, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": w["text"] + (", 1 RCCL all-reduce/step" if world > 1 else ""),
                        "baseline_config": args.config, "global_batch": world * B, "K": K, "parallelism": f"dp{world}",
@@ -520,13 +536,17 @@ def main():
                        # tests hold every form to the same float64-referenced tolerance)
                        "fp32_product": ("register-stationary convolutions: 3 fp16 MFMAs on scaled (hi, lo) pairs"
                                         if (kernels.IMG_F16 or kernels.C3_F16) else "6 bf16 MFMAs on three pieces")
+                                       + ("; MLP decoder at the decoder batch: 3 fp16 MFMAs on pre-split (hi, lo) planes"
+                                          if kernels.DENSE16 else "")
                                        + "; tiled engine: 6 bf16 MFMAs on three pieces; latency-sized layers: exact fp32 FMA / MFMA"},
         }
         nll_generic = summarise(recs, {"recon_nll"}, boundary)
         imgf = summarise(recs, {"image_layer_fwd"}, boundary)
         # With the fused decoder tail (round 3) the large modality's reconstruction NLL lives in the epilogue of its decoder's last
         # layer: THAT launch is the fused reconstruction-NLL kernel now, the generic kernel only scores the small modality
-        fused_tail = bool(nll_generic and imgf and nll_generic["work"] / nll_generic["launches"] < 0.5 * imgf["work"] / imgf["launches"])
+        # (round 4: the small modality's MLP decoder scores itself too — no generic launch is left in the headline step)
+        fused_tail = bool(imgf and imgf["work"] / imgf["launches"] > 2.0e8 and
+                          (nll_generic is None or nll_generic["work"] / nll_generic["launches"] < 0.5 * imgf["work"] / imgf["launches"]))
         nll = imgf if fused_tail else nll_generic
         if nll:
             ev = [s.elapsed_time(e) * 1e-3 for s, e in events]
@@ -536,6 +556,10 @@ def main():
                 with open(tf) as f:
                     traffic_meta = json.load(f)
                 traffic = traffic_meta.get("hbm_bytes_per_launch")
+            # the average of the SAME kernel in the tracked rocprofv3 summary of this command (profiles/: written by
+            # tools/make_profiles.py from `rocprofv3 --kernel-trace --stats -- python bench.py`): the second denominator
+            tracked_us = tracked_rocprof_avg_us("small_up_fwd_bf_kernel<3, 512, true>" if fused_tail else "recon_nll_kernel<1, true>") \
+                if args.config == "cfg3" else None
             ach = nll["work"] / nll["seconds"] / 1e9
             copy_gbs = measured_copy_gbs(device)
             res["roofline"] = {
@@ -545,6 +569,10 @@ def main():
                           "recon_nll_kernel<vec,fwd> (fused reconstruction NLL + d_recon, all modalities, one launch)",
                 "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac_is": "algorithmic bytes / (avg_launch_us measured in THIS run with device timestamps) / peak",
+                "tracked_rocprof_avg_us": tracked_us[0] if tracked_us else None,
+                "tracked_rocprof_file": tracked_us[1] if tracked_us else None,
+                "frac_tracked_rocprof": round(nll["work"] / nll["launches"] / (tracked_us[0] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if tracked_us else None,
                 "traffic_source": (("profiles/fused_tail_traffic.json" if fused_tail else "profiles/recon_nll_traffic.json") + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                    "command by tools/gpu_profile.sh (counters cannot be read from inside the process); "
                                    f"measured at commit {traffic_meta.get('commit', 'unrecorded')}") if traffic else None,
@@ -561,25 +589,40 @@ def main():
                           "takes off one dependent-kernel boundary calibrated in the same run",
                 "instrumented_ms_per_step": round(ms_instr, 4),
                 "hip_event_pair_us": round(1e6 * sum(ev) / len(ev), 2) if ev and not fused_tail else None}
-            if fused_tail:  # the generic likelihood kernel that is left (the small modality): 32 MB, latency-sized
+            if fused_tail and nll_generic:  # the generic likelihood kernel that is left (a modality without a fused tail)
                 g_ach = nll_generic["work"] / nll_generic["seconds"] / 1e9
                 res["roofline_generic_nll"] = {"kernel": "recon_nll_kernel<vec,fwd> (mnist only)", "bound": "hbm",
                                                "achieved": round(g_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                "frac": round(g_ach / HBM_PEAK_GBS, 4),
                                                "algorithmic_bytes": nll_generic["work"] / nll_generic["launches"],
                                                "avg_launch_us": round(nll_generic["avg_us"], 2)}
+        # The ELBO group of north_star ("fused MoPoE ELBO"): every launch between the decoders' last hidden activation and the
+        # gradient of their pre-activations + the posterior / KL kernels + the scalar assembly — minimal bytes of the group /
+        # the sum of its in-step launch durations (the members overlap other streams: a lower bound of what each achieves)
+        d16f = summarise(recs, {"dense16_fwd_nll"}, boundary)
+        small = summarise(recs, {"elbo_small"}, boundary)
+        members = [m for m in (imgf if fused_tail else None, nll_generic, d16f, small) if m]
+        if members and "roofline" in res:
+            gb = sum(m["work"] / m["launches"] * (m["launches"] / args.steps) for m in members)  # bytes per step
+            gus = sum(1e6 * m["seconds"] / args.steps for m in members)
+            res["roofline"]["elbo_group"] = {
+                "members": "fused svhn tail" + (" + generic recon_nll" if nll_generic else "") + (" + dense16 fwd_nll (mnist tail)" if d16f else "")
+                           + (" + mopoe_posterior fwd / bwd + reduce_terms" if small else ""),
+                "bytes_per_step": round(gb), "us_per_step": round(gus, 1), "achieved": round(gb / gus / 1e3, 1), "unit": "GB/s",
+                "frac": round(gb / gus / 1e3 / HBM_PEAK_GBS, 4),
+                "launches_per_step": round(sum(m["launches"] for m in members) / args.steps, 1)}
+        d16b = summarise(recs, {"dense16_bwd"}, boundary)
         conv = summarise(recs, {"imgconv_up", "imgconv_down", "imgconv_wgrad", "conv3_rs", "conv3_wgrad"}, boundary)
         conv3 = summarise(recs, {"conv3_rs", "conv3_wgrad"}, boundary) is not None
         SPLIT_PEAK = MFMA_BF16_TFLOPS / 6
         mf = {"bound": "mfma", "unit": "TFLOP/s", "peak": round(SPLIT_PEAK, 1),
-              "peak_fp32_input_mfma": MFMA_F32_TFLOPS,
               "step_gemm_gflop": round(step_flops / 1e9, 2),
               "step_achieved": round(step_flops / (ms * 1e-3) / 1e12, 2),
               "step_frac": round(step_flops / (ms * 1e-3) / 1e12 / SPLIT_PEAK, 4),
-              "step_frac_vs_fp32_input_mfma": round(step_flops / (ms * 1e-3) / 1e12 / MFMA_F32_TFLOPS, 4),
-              "note": "fp32 products on the split-bf16 engine (6 bf16 MFMAs each): peak = 2500 / 6 TFLOP/s of fp32 work, the "
-                      "ceiling of the pipes the work runs on (frac); the fp32-input MFMA rate is kept as a second "
-                      "denominator (*_vs_fp32_input_mfma); step_* = every GEMM-shaped FLOP of the step / ms_per_step; "
+              "step_frac_vs_3mfma_peak": round(step_flops / (ms * 1e-3) / 1e12 / (MFMA_BF16_TFLOPS / 3), 4),
+              "note": "peak = 2500 / 6 TFLOP/s of fp32 work for products formed from 6 bf16 MFMAs (tiled engine), 2500 / 3 for the "
+                      "3-fp16-MFMA form the large launches of the step run (kernel_peak, step_frac_vs_3mfma_peak: the denominator "
+                      "for a step whose FLOPs are almost all on that form); step_* = every GEMM-shaped FLOP of the step / ms_per_step; "
                       "achieved / us_per_step of the named kernels are IN-STEP durations: the launches share the chip with "
                       "the other modality's stream and the late weight gradients (alone: 98-113 us per launch, "
                       "tools/imgconv_probe.py, DESIGN.md section 6)"}
@@ -602,9 +645,13 @@ def main():
             mf.update({"kernel": ("c3rs_kernel / c3wg_kernel (register-stationary 3x3 convolutions of the ResNet blocks)" if conv3 else
                                   "imgconv_kernel / imgwgrad_kernel (register-stationary 4x4/stride-2 convolutions)"),
                        "achieved": round(ach, 1), "frac": round(ach / KPEAK, 4),
-                       "frac_vs_fp32_input_mfma": round(ach / MFMA_F32_TFLOPS, 4),
                        "gflop_per_step": round(conv["work"] / args.steps / 1e9, 2),
                        "us_per_step": round(1e6 * conv["seconds"] / args.steps, 1), "launches_timed": conv["launches"]})
+        if d16b:  # the MLP decoder's backward GEMMs on pre-split planes (3 fp16 MFMAs per product; the forward one is in elbo_group)
+            mf["dense16_bwd"] = {"kernel": "d16_nt_kernel<64, BWD> + d16_tn_kernel (MLP decoder backward data / weight gradient on fp16 pair planes)",
+                                 "achieved": round(d16b["work"] / d16b["seconds"] / 1e12, 1), "peak": round(MFMA_BF16_TFLOPS / 3, 1),
+                                 "frac": round(d16b["work"] / d16b["seconds"] / 1e12 / (MFMA_BF16_TFLOPS / 3), 4),
+                                 "us_per_step": round(1e6 * d16b["seconds"] / args.steps, 1)}
         res["roofline_mfma"] = mf
         img = {k: summarise(recs, {k}, boundary) for k in ("image_layer_fwd", "image_layer_bwd")}
         if any(img.values()):

@@ -641,6 +641,20 @@ int mvk_defer_end(void* stream);
 int64_t mvk_defer_wanted(void);
 int mvk_defer_pending(void);
 
+/* The collective of the data-parallel step (`allreduce_avg`; reference: the DDP wrapper of
+ * trainers/base/base_trainer.py:92-117 averages the gradients over the ranks, :350-361 then steps the optimizer).  One process
+ * per GPU; RCCL over xGMI, resolved at run time (dlopen: single-GPU processes never load it).
+ *   mvk_comm_unique_id   rank 0 makes a rendezvous id of mvk_comm_id_bytes() bytes and hands it to every rank (any channel)
+ *   mvk_comm_init        collective: every rank, same id, called with its own device current
+ *   mvk_allreduce_avg    buf[i] <- mean over ranks, in place, enqueued on `stream` (no host synchronisation); nseg > 1 issues
+ *                        nseg equal segments as one RCCL group
+ *   mvk_comm_destroy */
+int mvk_comm_id_bytes(void);
+int mvk_comm_unique_id(void* id);
+int mvk_comm_init(void** comm, int world, int rank, const void* id);
+int mvk_comm_destroy(void* comm);
+int mvk_allreduce_avg(float* buf, int64_t n, int nseg, void* comm, void* stream);
+
 /* Dense layers on pre-split fp16 pair planes (csrc/dense16.hip): the MLP decoder of the MnistSvhn models at the decoder batch
  * (reference: models/nn/default_architectures.py:225-258 Decoder_AE_MLP; likelihood models/base/base_utils.py:62-87).
  * A "planes" tensor [R][C] is two fp16 arrays hi, lo [R][C] with x s = hi + lo / 2048 (csrc/bf3.hpp); s is a power of two

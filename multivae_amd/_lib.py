@@ -162,6 +162,10 @@ PROTOTYPES = {
     "mvk_kl_gauss_bwd": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p],
     "mvk_logprob_fwd": [_p, _p, _i64, _i64, _i, _f, _i, _f, _p, _p],
     "mvk_logprob_bwd": [_p, _p, _i64, _i64, _i, _f, _i, _f, _p, _p, _p],
+    "mvk_comm_unique_id": [_p],
+    "mvk_comm_init": [C.POINTER(C.c_void_p), _i, _i, _p],
+    "mvk_comm_destroy": [_p],
+    "mvk_allreduce_avg": [_p, _i64, _i, _p, _p],
     "mvk_dense16_pack": [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "mvk_dense16_first": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "mvk_dense16_fwd_nll": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _f, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p],
@@ -219,6 +223,8 @@ def load(path=None):
     lib.mvk_prof_clock_khz.restype = C.c_int
     lib.mvk_imgconv_frag_bytes.argtypes = [_i, _i]
     lib.mvk_imgconv_frag_bytes.restype = C.c_int64
+    lib.mvk_comm_id_bytes.argtypes = []
+    lib.mvk_comm_id_bytes.restype = C.c_int
     lib.mvk_dense16_ok.argtypes = [_i, _i, _i]
     lib.mvk_dense16_ok.restype = C.c_int
     lib.mvk_dense16_fwd_nll_rows.argtypes = [_i]

@@ -99,3 +99,9 @@ __device__ __forceinline__ void mvk_prof_end(mvk_prof_slot* s) {
                 (unsigned long long)wall_clock64());
   }
 }
+// barrier-free exit stamp for kernels whose waves leave at different points (one atomic per wave)
+__device__ __forceinline__ void mvk_prof_end_wave(mvk_prof_slot* s) {
+  if (s && (threadIdx.x & 63) == 0)
+    atomicMax(&s->w[8 + 8 * MVK_PROF_ENTRIES + 8 * ((blockIdx.x + blockIdx.y + blockIdx.z) & (MVK_PROF_ENTRIES - 1))],
+              (unsigned long long)wall_clock64());
+}

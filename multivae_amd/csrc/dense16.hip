@@ -122,12 +122,10 @@ struct D16First {
   int M, N, K, act;
 };
 
-#ifndef D16_FIRST_ROWS
-#define D16_FIRST_ROWS 16
-#endif
-template <int K4>
+// R rows per workgroup: every workgroup loads all of W (40 KB at 512 x 20) first; the launcher picks R for ~256 workgroups
+template <int K4, int R>
 __global__ __launch_bounds__(256) void d16_first_kernel(const D16First g) {
-  constexpr int KP = K4 * 4, R = D16_FIRST_ROWS;  // rows per workgroup: every workgroup loads all of W (40 KB at 512 x 20) first
+  constexpr int KP = K4 * 4;
   __shared__ __attribute__((aligned(16))) float xs[R][KP];
   __shared__ float red[8];
   const int CT = g.N / 4;       // <= 256 column groups: thread = (column group, row group)
@@ -205,6 +203,9 @@ __global__ __launch_bounds__(256) void d16_first_kernel(const D16First g) {
 // LDS stages, one barrier per k-tile; the next tile's global loads are issued before the MFMAs of the current one.
 // ---------------------------------------------------------------------------------------------------------------------
 enum { D16_NLL = 0, D16_BWD = 1 };
+#ifndef D16_NT128_OCC
+#define D16_NT128_OCC 1  // workgroups per CU of the 128-row tile (its two register sets put it above 256 registers)
+#endif
 
 // 1 / (1 + e^-v) on the 1-ulp transcendental instructions: e^-v = 2^t (1 + tl ln 2) with -v log2(e) = t + tl carried as a
 // two-term product (the rounding of a plain -v * log2(e) alone is a relative error of |v| 2^-24 in the exponential)
@@ -236,16 +237,18 @@ struct D16Nt {
   // D16_BWD: out = C * (mask_hi > 0)
   const half_t* mask_hi;  // [M][N] hi plane of the activation the result lands in (ReLU), or null
   float* out;             // [M][N] fp32
+  mvk_prof_slot* prof;    // device-timestamp record (null: profiler off)
   int dbg;                // experiment switches (mvk_dense16_debug): 1 no global loads, 2 no MFMAs, 4 no LDS writes, 8 no epilogue
 };
 
 template <int BM, int EPI>
-__global__ __launch_bounds__(256, 2) void d16_nt_kernel(const D16Nt g) {
+__global__ __launch_bounds__(256, BM == 64 ? 2 : D16_NT128_OCC) void d16_nt_kernel(const D16Nt g) {
   constexpr int BN = 128, TM = BM / 64, TN = 2;
   constexpr int APL = BM * 64, BPL = BN * 64;  // bytes per plane tile
   constexpr int STAGE = 2 * APL + 2 * BPL;
   constexpr int NA = BM * 4 / 256, NB = BN * 4 / 256;  // 16-byte chunks per plane and thread
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  mvk_prof_begin(g.prof);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -271,32 +274,37 @@ __global__ __launch_bounds__(256, 2) void d16_nt_kernel(const D16Nt g) {
     b_g[u] = ((n0 + row) * K + oct * 8) * 2;
     b_kmax[u] = (n0 + row < g.N) ? K - oct * 8 : 0;
   }
-  u32x4 rah[NA], ral[NA], rbh[NB], rbl[NB];
+  // two register sets: a k-tile's loads are issued two iterations before its LDS write (one iteration = the MFMAs of one k-tile
+  // is shorter than the latency of an L2 miss: with one set every iteration waited for its loads)
+  struct Raw {
+    u32x4 ah[NA], al[NA], bh[NB], bl[NB];
+  };
+  Raw R0, R1;
   auto sel = [](bool ok, int off) { return __builtin_unpredictable(ok) ? off : 0x7fffffff; };  // out of range = zero fill
-  auto gload = [&](int k0) {
+  auto gload = [&](Raw& r, int k0) {
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
       const int off = sel(k0 < a_kmax[u], a_g[u] + k0 * 2);
-      rah[u] = __builtin_amdgcn_raw_buffer_load_b128(rsAh, off, 0, 0);
-      ral[u] = __builtin_amdgcn_raw_buffer_load_b128(rsAl, off, 0, 0);
+      r.ah[u] = __builtin_amdgcn_raw_buffer_load_b128(rsAh, off, 0, 0);
+      r.al[u] = __builtin_amdgcn_raw_buffer_load_b128(rsAl, off, 0, 0);
     }
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
       const int off = sel(k0 < b_kmax[u], b_g[u] + k0 * 2);
-      rbh[u] = __builtin_amdgcn_raw_buffer_load_b128(rsBh, off, 0, 0);
-      rbl[u] = __builtin_amdgcn_raw_buffer_load_b128(rsBl, off, 0, 0);
+      r.bh[u] = __builtin_amdgcn_raw_buffer_load_b128(rsBh, off, 0, 0);
+      r.bl[u] = __builtin_amdgcn_raw_buffer_load_b128(rsBl, off, 0, 0);
     }
   };
-  auto lwrite = [&](char* st) {
+  auto lwrite = [&](const Raw& r, char* st) {
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
-      *reinterpret_cast<u32x4*>(st + a_l[u]) = rah[u];
-      *reinterpret_cast<u32x4*>(st + APL + a_l[u]) = ral[u];
+      *reinterpret_cast<u32x4*>(st + a_l[u]) = r.ah[u];
+      *reinterpret_cast<u32x4*>(st + APL + a_l[u]) = r.al[u];
     }
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
-      *reinterpret_cast<u32x4*>(st + 2 * APL + b_l[u]) = rbh[u];
-      *reinterpret_cast<u32x4*>(st + 2 * APL + BPL + b_l[u]) = rbl[u];
+      *reinterpret_cast<u32x4*>(st + 2 * APL + b_l[u]) = r.bh[u];
+      *reinterpret_cast<u32x4*>(st + 2 * APL + BPL + b_l[u]) = r.bl[u];
     }
   };
 
@@ -351,23 +359,27 @@ __global__ __launch_bounds__(256, 2) void d16_nt_kernel(const D16Nt g) {
   const int nt = (K + 31) / 32;
   f16x8 FA[NF], FB[NF];
   const unsigned long long tk0 = (g.dbg & 16) ? __builtin_readcyclecounter() : 0ull;
-  gload(0);
-  lwrite(lds);
-  gload(32);
+  gload(R0, 0);
+  lwrite(R0, lds);
+  gload(R1, 32);
+  gload(R0, 64);
   __syncthreads();
   rfrag(FA, lds, 0);
-  for (int t = 0; t < nt; ++t) {
-    const char* cur = lds + (t & 1) * STAGE;
-    char* nxt = lds + ((t & 1) ^ 1) * STAGE;
-    lwrite(nxt);              // tile t+1 (its last readers passed the barrier of iteration t-1)
-    gload((t + 2) * 32);      // past the end of K: out of range, zero fill, no traffic
+  // one k-tile: LDS stage `cur` is multiplied; tile t+1 goes from `rw` to stage `nxt`, then tile t+3 is fetched into `rw`
+  auto ktile = [&](int t, const char* cur, char* nxt, Raw& rw) {
+    lwrite(rw, nxt);               // tile t+1 (the last readers of `nxt` passed the barrier of iteration t-1)
+    gload(rw, (t + 3) * 32);       // past the end of K: out of range, zero fill, no traffic
     rfrag(FB, cur, 1);
     mfmas(FA);
     D16_INTERLEAVE(2)
-    __syncthreads();          // tile t+1 is complete in `nxt`; every wave has its fragments of `cur`
+    __syncthreads();               // tile t+1 is complete in `nxt`; every wave has its fragments of `cur`
     rfrag(FA, nxt, 0);
     mfmas(FB);
     D16_INTERLEAVE(1)
+  };
+  for (int t = 0; t < nt; t += 2) {  // an odd nt runs one k-tile of zeros (zero-filled loads)
+    ktile(t, lds, lds + STAGE, R1);
+    ktile(t + 1, lds + STAGE, lds, R0);
   }
 
   const unsigned long long tk1 = (g.dbg & 16) ? __builtin_readcyclecounter() : 0ull;
@@ -501,6 +513,7 @@ __global__ __launch_bounds__(256, 2) void d16_nt_kernel(const D16Nt g) {
       g.colsum_part[(long long)blockIdx.x * g.N + n0 + tid] = s;
     }
   }
+  mvk_prof_end(g.prof);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -521,6 +534,7 @@ struct D16Tn {
   const float* colsum_part;  // [cs_rows][N] or null
   int cs_rows;
   float* db;              // [N], accumulated (+=)
+  mvk_prof_slot* prof;
 };
 
 __device__ __forceinline__ f16x8 d16_tr_pair(const char* p0, const char* p1) {
@@ -532,9 +546,10 @@ __device__ __forceinline__ f16x8 d16_tr_pair(const char* p0, const char* p1) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ __launch_bounds__(256, 2) void d16_tn_kernel(const D16Tn g) {
+__global__ __launch_bounds__(256, 1) void d16_tn_kernel(const D16Tn g) {
   constexpr int BJ = 128, BI = 128, ROWB = 256 + 64, PL = 32 * ROWB, STAGE = 4 * PL;
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  mvk_prof_begin(g.prof);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int wj = wave >> 1, wi = wave & 1;
   const int j0 = blockIdx.x * BJ, i0 = blockIdx.y * BI;
@@ -559,27 +574,30 @@ __global__ __launch_bounds__(256, 2) void d16_tn_kernel(const D16Tn g) {
     d_g[u] = ((mbeg + mr) * g.N + j0 + oct * 8) * 2;
     h_g[u] = ((mbeg + mr) * g.K + i0 + oct * 8) * 2;
   }
-  u32x4 rdh[2], rdl[2], rhh[2], rhl[2];
+  struct Raw {  // two register sets: loads run two k-tiles ahead of their LDS write (d16_nt_kernel)
+    u32x4 dh[2], dl[2], hh[2], hl[2];
+  };
+  Raw R0, R1;
   auto sel = [](bool ok, int off) { return __builtin_unpredictable(ok) ? off : 0x7fffffff; };
-  auto gload = [&](int t) {
+  auto gload = [&](Raw& r, int t) {
     const int mrow = mbeg + t * 32;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const bool rok = t < nt && mrow + ((tid + u * 256) >> 4) < g.M;
       const int od = sel(rok && d_ok[u], d_g[u] + t * 32 * g.N * 2), oh = sel(rok && h_ok[u], h_g[u] + t * 32 * g.K * 2);
-      rdh[u] = __builtin_amdgcn_raw_buffer_load_b128(rsDh, od, 0, 0);
-      rdl[u] = __builtin_amdgcn_raw_buffer_load_b128(rsDl, od, 0, 0);
-      rhh[u] = __builtin_amdgcn_raw_buffer_load_b128(rsHh, oh, 0, 0);
-      rhl[u] = __builtin_amdgcn_raw_buffer_load_b128(rsHl, oh, 0, 0);
+      r.dh[u] = __builtin_amdgcn_raw_buffer_load_b128(rsDh, od, 0, 0);
+      r.dl[u] = __builtin_amdgcn_raw_buffer_load_b128(rsDl, od, 0, 0);
+      r.hh[u] = __builtin_amdgcn_raw_buffer_load_b128(rsHh, oh, 0, 0);
+      r.hl[u] = __builtin_amdgcn_raw_buffer_load_b128(rsHl, oh, 0, 0);
     }
   };
-  auto lwrite = [&](char* st) {
+  auto lwrite = [&](const Raw& r, char* st) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      *reinterpret_cast<u32x4*>(st + s_l[u]) = rdh[u];
-      *reinterpret_cast<u32x4*>(st + PL + s_l[u]) = rdl[u];
-      *reinterpret_cast<u32x4*>(st + 2 * PL + s_l[u]) = rhh[u];
-      *reinterpret_cast<u32x4*>(st + 3 * PL + s_l[u]) = rhl[u];
+      *reinterpret_cast<u32x4*>(st + s_l[u]) = r.dh[u];
+      *reinterpret_cast<u32x4*>(st + PL + s_l[u]) = r.dl[u];
+      *reinterpret_cast<u32x4*>(st + 2 * PL + s_l[u]) = r.hh[u];
+      *reinterpret_cast<u32x4*>(st + 3 * PL + s_l[u]) = r.hl[u];
     }
   };
   // transposing-read addresses: 16-lane group gq reads [4 rows m][16 columns]; lane lp supplies row (lp >> 2), columns
@@ -602,38 +620,56 @@ __global__ __launch_bounds__(256, 2) void d16_tn_kernel(const D16Tn g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) accm[a][b][r] = accc[a][b][r] = 0.f;
 
-  gload(0);
-  lwrite(lds);
-  __syncthreads();
-  for (int t = 0; t < nt; ++t) {
-    const char* cur = lds + (t & 1) * STAGE;
-    char* nxt = lds + ((t & 1) ^ 1) * STAGE;
-    gload(t + 1);
+  // fragments of one 16-wide k-step: D hi [2], D lo [2], H hi [2], H lo [2]
+  auto rfrag = [&](f16x8 (&F)[8], const char* st, int ks) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      f16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        ah[a] = d16_tr_pair(cur + fa[a][ks], cur + fa[a][ks] + 4 * ROWB);
-        al[a] = d16_tr_pair(cur + PL + fa[a][ks], cur + PL + fa[a][ks] + 4 * ROWB);
-        bh[a] = d16_tr_pair(cur + fb[a][ks], cur + fb[a][ks] + 4 * ROWB);
-        bl[a] = d16_tr_pair(cur + PL + fb[a][ks], cur + PL + fb[a][ks] + 4 * ROWB);
-      }
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) accm[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], accm[a][b], 0, 0, 0);
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) accc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], accc[a][b], 0, 0, 0);
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) accc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], accc[a][b], 0, 0, 0);
+    for (int a = 0; a < 2; ++a) {
+      F[a] = d16_tr_pair(st + fa[a][ks], st + fa[a][ks] + 4 * ROWB);
+      F[2 + a] = d16_tr_pair(st + PL + fa[a][ks], st + PL + fa[a][ks] + 4 * ROWB);
+      F[4 + a] = d16_tr_pair(st + fb[a][ks], st + fb[a][ks] + 4 * ROWB);
+      F[6 + a] = d16_tr_pair(st + PL + fb[a][ks], st + PL + fb[a][ks] + 4 * ROWB);
     }
-    lwrite(nxt);
+  };
+  auto mfmas = [&](const f16x8 (&F)[8]) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) accm[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[a], F[4 + b], accm[a][b], 0, 0, 0);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) accc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[a], F[6 + b], accc[a][b], 0, 0, 0);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) accc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[2 + a], F[4 + b], accc[a][b], 0, 0, 0);
+  };
+#define D16_TN_INTERLEAVE(OTHERS)                           \
+  _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {       \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      \
+    __builtin_amdgcn_sched_group_barrier(0x496, OTHERS, 0); \
+  }
+  f16x8 FA[8], FB[8];
+  gload(R0, 0);
+  lwrite(R0, lds);
+  gload(R1, 1);
+  gload(R0, 2);
+  __syncthreads();
+  rfrag(FA, lds, 0);
+  auto ktile = [&](int t, const char* cur, char* nxt, Raw& rw) {  // the pipeline of d16_nt_kernel
+    lwrite(rw, nxt);
+    gload(rw, t + 3);
+    rfrag(FB, cur, 1);
+    mfmas(FA);
+    D16_TN_INTERLEAVE(3)
     __syncthreads();
+    rfrag(FA, nxt, 0);
+    mfmas(FB);
+    D16_TN_INTERLEAVE(2)
+  };
+  for (int t = 0; t < nt; t += 2) {  // an odd nt runs one k-tile of zeros
+    ktile(t, lds, lds + STAGE, R1);
+    ktile(t + 1, lds + STAGE, lds, R0);
   }
   const float inv = mvk::f16_inv_scale(mvk::f16_scale_of(*g.d_bound)) * mvk::f16_inv_scale(mvk::f16_scale_of(*g.h_bound));
   float* slab = g.slab + (long long)blockIdx.z * g.N * g.K;
@@ -653,6 +689,7 @@ __global__ __launch_bounds__(256, 2) void d16_tn_kernel(const D16Tn g) {
     for (int r = 0; r < g.cs_rows; ++r) s += g.colsum_part[(long long)r * g.N + j0 + tid];
     g.db[j0 + tid] += s;
   }
+  mvk_prof_end(g.prof);
 }
 
 // out[i] += sum_z part[z * stride + i], z in order (the finish of the slabs when no deferred-finish arena takes them)
@@ -723,24 +760,32 @@ int mvk_dense16_first(const float* Z, const float* W, const float* bias, const f
       256 % (N / 4) != 0 || !mvk_aligned16(W) || !mvk_aligned16(hi) || !mvk_aligned16(lo) || (bias && !mvk_aligned16(bias)))
     return MVK_EINVAL;
   D16First a{Z, W, bias, z_amax, (half_t*)hi, (half_t*)lo, bound, M, N, K, act};
-  const dim3 grid((M + D16_FIRST_ROWS - 1) / D16_FIRST_ROWS);
+  const int want = (M + 255) / 256;
+  const int R = want <= 8 ? 8 : (want <= 20 ? 20 : 40);
+  const dim3 grid((M + R - 1) / R);
   hipStream_t s = mvk_stream(stream);
+#define D16_FIRST_CASE(K4_)                                                                      \
+  case K4_:                                                                                      \
+    if (R == 8) hipLaunchKernelGGL((d16_first_kernel<K4_, 8>), grid, dim3(256), 0, s, a);        \
+    else if (R == 20) hipLaunchKernelGGL((d16_first_kernel<K4_, 20>), grid, dim3(256), 0, s, a); \
+    else hipLaunchKernelGGL((d16_first_kernel<K4_, 40>), grid, dim3(256), 0, s, a);              \
+    break;
   switch (K / 4) {
-    case 1: hipLaunchKernelGGL(d16_first_kernel<1>, grid, dim3(256), 0, s, a); break;
-    case 2: hipLaunchKernelGGL(d16_first_kernel<2>, grid, dim3(256), 0, s, a); break;
-    case 3: hipLaunchKernelGGL(d16_first_kernel<3>, grid, dim3(256), 0, s, a); break;
-    case 4: hipLaunchKernelGGL(d16_first_kernel<4>, grid, dim3(256), 0, s, a); break;
-    case 5: hipLaunchKernelGGL(d16_first_kernel<5>, grid, dim3(256), 0, s, a); break;
-    case 6: hipLaunchKernelGGL(d16_first_kernel<6>, grid, dim3(256), 0, s, a); break;
-    case 7: hipLaunchKernelGGL(d16_first_kernel<7>, grid, dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL(d16_first_kernel<8>, grid, dim3(256), 0, s, a); break;
+    D16_FIRST_CASE(1) D16_FIRST_CASE(2) D16_FIRST_CASE(3) D16_FIRST_CASE(4)
+    D16_FIRST_CASE(5) D16_FIRST_CASE(6) D16_FIRST_CASE(7) D16_FIRST_CASE(8)
   }
+#undef D16_FIRST_CASE
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }
 
+// row tile of the forward launch: 64 rows (two workgroups per CU overlap each other's epilogue) or 128 (MVK_D16_FWD_BM)
+static int d16_fwd_bm() {
+  static const int bm = mvk_tune("MVK_D16_FWD_BM") ? atoi(mvk_tune("MVK_D16_FWD_BM")) : 64;
+  return bm == 128 ? 128 : 64;
+}
 int mvk_dense16_fwd_nll_rows(int N) { return (N + 127) / 128; }
-int mvk_dense16_colsum_rows(int M) { return (M + 127) / 128; }
+int mvk_dense16_colsum_rows(int M) { return (M + d16_fwd_bm() - 1) / d16_fwd_bm(); }
 
 int mvk_dense16_fwd_nll(const void* h_hi, const void* h_lo, const float* h_bound, const void* w_hi, const void* w_lo,
                         const float* w_inv, const float* bias, const float* X, int xrows, const float* x_amax, float scale,
@@ -749,12 +794,13 @@ int mvk_dense16_fwd_nll(const void* h_hi, const void* h_lo, const float* h_bound
   if (!h_hi || !h_lo || !h_bound || !w_hi || !w_lo || !w_inv || !X || !x_amax || !g_hi || !g_lo || !g_bound || !rows_part ||
       xrows <= 0 || !(scale > 0.f) || !mvk_dense16_ok(M, N, K) || !mvk_aligned16(X) || !mvk_aligned16(g_hi) || !mvk_aligned16(g_lo))
     return MVK_EINVAL;
-  constexpr int LDS = 2 * 128 * (128 + 128);
+  constexpr int LDS128 = 2 * 128 * (128 + 128), LDS64 = 2 * 128 * (64 + 128);
   static bool attr = false;
   if (!attr) {
-    if (set_lds(d16_nt_kernel<128, D16_NLL>, LDS) != MVK_OK) return MVK_ELAUNCH;
+    if (set_lds(d16_nt_kernel<128, D16_NLL>, LDS128) != MVK_OK || set_lds(d16_nt_kernel<64, D16_NLL>, LDS64) != MVK_OK) return MVK_ELAUNCH;
     attr = true;
   }
+  const int BM = d16_fwd_bm();
   D16Nt a{};
   a.Ah = (const half_t*)h_hi, a.Al = (const half_t*)h_lo, a.Bh = (const half_t*)w_hi, a.Bl = (const half_t*)w_lo;
   a.a_bound = h_bound, a.b_inv = w_inv, a.M = M, a.N = N, a.K = K;
@@ -763,8 +809,14 @@ int mvk_dense16_fwd_nll(const void* h_hi, const void* h_lo, const float* h_bound
   a.row_const = (float)N * (logf(scale) + 0.918938533204672742f);
   a.Gh = (half_t*)g_hi, a.Gl = (half_t*)g_lo, a.g_bound = g_bound, a.rows_part = rows_part, a.colsum_part = colsum_part;
   a.dbg = g_d16_dbg;
-  hipLaunchKernelGGL((d16_nt_kernel<128, D16_NLL>), dim3((M + 127) / 128, (N + 127) / 128), dim3(256), LDS, mvk_stream(stream), a);
+  // profiler kind 9: the planes in (activation, weight), the targets, the gradient planes and the partial rows out
+  a.prof = mvk::prof_next(9, 4.0 * M * K + 4.0 * N * K + 4.0 * xrows * N + 4.0 * M * N + 4.0 * M * ((N + 127) / 128));
+  if (BM == 64)
+    hipLaunchKernelGGL((d16_nt_kernel<64, D16_NLL>), dim3((M + 63) / 64, (N + 127) / 128), dim3(256), LDS64, mvk_stream(stream), a);
+  else
+    hipLaunchKernelGGL((d16_nt_kernel<128, D16_NLL>), dim3((M + 127) / 128, (N + 127) / 128), dim3(256), LDS128, mvk_stream(stream), a);
   MVK_CHECK_LAUNCH();
+  mvk::prof_fold(a.prof, mvk_stream(stream));
   return MVK_OK;
 }
 
@@ -798,8 +850,10 @@ int mvk_dense16_bwd_data(const void* g_hi, const void* g_lo, const float* g_boun
   a.a_bound = g_bound, a.b_inv = wt_inv, a.M = M, a.N = N, a.K = K;
   a.mask_hi = (const half_t*)mask_hi, a.out = dA, a.colsum_part = part;
   a.dbg = g_d16_dbg;
+  a.prof = mvk::prof_next(10, 2.0 * M * N * K);  // kind 10: GEMM FLOP of the dense16 backward launches
   hipLaunchKernelGGL((d16_nt_kernel<BM, D16_BWD>), dim3(mt, (N + 127) / 128), dim3(256), LDS, s, a);
   MVK_CHECK_LAUNCH();
+  mvk::prof_fold(a.prof, s);
   if (db) {
     if (deferred) return mvk::defer_push_plain(db, part, N, mt, N, s);
     hipLaunchKernelGGL(d16_sum_kernel, dim3((N + 255) / 256), dim3(256), 0, s, db, part, (long long)N, mt, (long long)N);
@@ -835,9 +889,10 @@ int mvk_dense16_wgrad(const void* g_hi, const void* g_lo, const float* g_bound, 
     slab = ws;
   }
   D16Tn a{(const half_t*)g_hi, (const half_t*)g_lo, (const half_t*)h_hi, (const half_t*)h_lo, g_bound, h_bound, M, N, K, per, slab,
-          colsum_part, cs_rows, db};
+          colsum_part, cs_rows, db, mvk::prof_next(10, 2.0 * M * N * K)};
   hipLaunchKernelGGL(d16_tn_kernel, dim3(jt, it, S), dim3(256), LDS, s, a);
   MVK_CHECK_LAUNCH();
+  mvk::prof_fold(a.prof, s);
   if (deferred) return mvk::defer_push_plain(dW, slab, total, S, total, s);
   hipLaunchKernelGGL(d16_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dW, slab, total, S, total);
   MVK_CHECK_LAUNCH();

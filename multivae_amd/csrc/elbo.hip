@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256) void mopoe_posterior_fwd_kernel(
     const PtrTable pt, int M, const int32_t* __restrict__ subset_masks, int S, const int32_t* __restrict__ sel,
     const float* __restrict__ weights, const float* __restrict__ eps, int K, int B, int L, float* __restrict__ z,
     float* __restrict__ kld_rows, float* __restrict__ mus_out, float* __restrict__ lvs_out,
-    float* __restrict__ joint_mu, float* __restrict__ joint_lv) {
+    float* __restrict__ joint_mu, float* __restrict__ joint_lv, mvk_prof_slot* prof) {
+  mvk_prof_begin(prof);
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -89,12 +90,14 @@ __global__ __launch_bounds__(256) void mopoe_posterior_fwd_kernel(
   }
   kld_acc = wave_sum(kld_acc);
   if (lane == 0) kld_rows[b] = kld_acc;
+  mvk_prof_end_wave(prof);
 }
 
 __global__ __launch_bounds__(256) void mopoe_posterior_bwd_kernel(
     const PtrTable pt, const OutPtrTable ot, int M, const int32_t* __restrict__ subset_masks, int S,
     const int32_t* __restrict__ sel, const float* __restrict__ weights, const float* __restrict__ eps,
-    const float* __restrict__ dz, int K, int B, int L, const float* __restrict__ gkld_rows) {
+    const float* __restrict__ dz, int K, int B, int L, const float* __restrict__ gkld_rows, mvk_prof_slot* prof) {
+  mvk_prof_begin(prof);
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -185,6 +188,7 @@ __global__ __launch_bounds__(256) void mopoe_posterior_bwd_kernel(
       }
     }
   }
+  mvk_prof_end_wave(prof);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -921,9 +925,12 @@ int mvk_mopoe_posterior_fwd(const float* const* mu, const float* const* lv, int 
     pt.mu[m] = mu[m];
     pt.lv[m] = lv[m];
   }
+  // profiler kind 11: the latency-sized members of the ELBO group (bytes: encoder outputs in, noise in, samples out)
+  mvk_prof_slot* prof = mvk::prof_next(11, 4.0 * B * L * (2.0 * M + 2.0 * K) + 4.0 * B);
   hipLaunchKernelGGL(mopoe_posterior_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, mvk_stream(stream), pt, M,
-                     subset_masks, S, sel, weights, eps, K, B, L, z, kld_rows, mus_out, lvs_out, joint_mu, joint_lv);
+                     subset_masks, S, sel, weights, eps, K, B, L, z, kld_rows, mus_out, lvs_out, joint_mu, joint_lv, prof);
   MVK_CHECK_LAUNCH();
+  mvk::prof_fold(prof, mvk_stream(stream));
   return MVK_OK;
 }
 
@@ -943,9 +950,11 @@ int mvk_mopoe_posterior_bwd(const float* const* mu, const float* const* lv, int 
     ot.dmu[m] = dmu[m];
     ot.dlv[m] = dlv[m];
   }
+  mvk_prof_slot* prof = mvk::prof_next(11, 4.0 * B * L * (4.0 * M + 2.0 * K) + 4.0 * B);
   hipLaunchKernelGGL(mopoe_posterior_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, mvk_stream(stream), pt, ot, M,
-                     subset_masks, S, sel, weights, eps, dz, K, B, L, gkld_rows);
+                     subset_masks, S, sel, weights, eps, dz, K, B, L, gkld_rows, prof);
   MVK_CHECK_LAUNCH();
+  mvk::prof_fold(prof, mvk_stream(stream));
   return MVK_OK;
 }
 

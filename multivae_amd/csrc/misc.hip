@@ -325,7 +325,8 @@ struct TermTable {
 // gfill: where a term's gradient w.r.t. its rows is the constant coef * lossw (KL rows), it is written here, so that a
 // backward pass whose upstream gradient is known to be 1 launches nothing (ReconLossFn.backward).
 __global__ __launch_bounds__(1024) void reduce_terms_kernel(const TermTable tt, float* __restrict__ out,
-                                                            float* __restrict__ loss_out) {
+                                                            float* __restrict__ loss_out, mvk_prof_slot* prof) {
+  mvk_prof_begin(prof);
   __shared__ float red[MVK_MAX_TERMS][16];
   __shared__ float vals[MVK_MAX_TERMS];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -370,6 +371,7 @@ __global__ __launch_bounds__(1024) void reduce_terms_kernel(const TermTable tt, 
     out[tt.n + 1] = loss * tt.loss_sum_scale;
     if (loss_out) *loss_out = loss;
   }
+  mvk_prof_end(prof);
 }
 
 static int grid_for(long long n, int block, int cap = 2048) {
@@ -635,8 +637,12 @@ int mvk_reduce_terms(const mvk_term_desc* terms, int n_terms, float loss_sum_sca
   }
   tt.n = n_terms;
   tt.loss_sum_scale = loss_sum_scale;
-  hipLaunchKernelGGL(reduce_terms_kernel, dim3(1), dim3(1024), 0, mvk_stream(stream), tt, out, loss_out);
+  double bytes = 0.0;
+  for (int i = 0; i < n_terms; ++i) bytes += 4.0 * (double)terms[i].n * (terms[i].gfill ? 2.0 : 1.0);
+  mvk_prof_slot* prof = mvk::prof_next(11, bytes);
+  hipLaunchKernelGGL(reduce_terms_kernel, dim3(1), dim3(1024), 0, mvk_stream(stream), tt, out, loss_out, prof);
   MVK_CHECK_LAUNCH();
+  mvk::prof_fold(prof, mvk_stream(stream));
   return MVK_OK;
 }
 

@@ -310,9 +310,12 @@ struct SmallKArgs {
   float* y_amax;          // optional: max |Y| is published here (atomic max, one per workgroup; must hold 0 before the launch)
 };
 
-template <int K4>  // ceil(K / 4)
+// R rows per workgroup.  Every workgroup first loads its weight columns (40-80 KB at K = 20): with 8 rows the 1280 workgroups of
+// the decoder batch (M = 5120, N = 2048) read 100 MB of weights from L2 to write 42 MB of output (29 us); the launcher picks R
+// so that the grid is about one workgroup per compute unit (R = 40 there: 256 workgroups, 20 MB of weight reads).
+template <int K4, int R>  // K4 = ceil(K / 4)
 __global__ __launch_bounds__(256) void smallk_fwd_kernel(const SmallKArgs g) {
-  constexpr int KP = K4 * 4, R = 8;  // 8 rows per workgroup: >= 1000 workgroups at the decoder batch, 4-5 resident per CU
+  constexpr int KP = K4 * 4;
   __shared__ __attribute__((aligned(16))) float xs[R][KP];
   const int CT = g.N / 4;                    // float4 column groups
   const int ctb = CT < 256 ? CT : 256;       // column groups of this workgroup
@@ -394,17 +397,23 @@ int smallk_fwd(const float* X, const float* W, long long w_sk, long long w_sn, c
     return 1;
   SmallKArgs a{X, W, bias, Y, M, N, K, bias_mod > 0 ? bias_mod : 1, act, w_sk, w_sn, mask_src, mask_act, accumulate, y_amax};
   const int CT = N / 4, ctb = CT < 256 ? CT : 256;
-  const dim3 grid((M + 7) / 8, (CT + ctb - 1) / ctb);
-  switch ((K + 3) / 4) {
-    case 1: hipLaunchKernelGGL(smallk_fwd_kernel<1>, grid, dim3(256), 0, s, a); break;
-    case 2: hipLaunchKernelGGL(smallk_fwd_kernel<2>, grid, dim3(256), 0, s, a); break;
-    case 3: hipLaunchKernelGGL(smallk_fwd_kernel<3>, grid, dim3(256), 0, s, a); break;
-    case 4: hipLaunchKernelGGL(smallk_fwd_kernel<4>, grid, dim3(256), 0, s, a); break;
-    case 5: hipLaunchKernelGGL(smallk_fwd_kernel<5>, grid, dim3(256), 0, s, a); break;
-    case 6: hipLaunchKernelGGL(smallk_fwd_kernel<6>, grid, dim3(256), 0, s, a); break;
-    case 7: hipLaunchKernelGGL(smallk_fwd_kernel<7>, grid, dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL(smallk_fwd_kernel<8>, grid, dim3(256), 0, s, a); break;
+  const int gy = (CT + ctb - 1) / ctb;
+  static const int r_env = mvk_tune("MVK_SMALLK_ROWS") ? atoi(mvk_tune("MVK_SMALLK_ROWS")) : 0;
+  const long long want = r_env > 0 ? r_env : ((long long)M * gy + 255) / 256;  // rows per workgroup for ~256 workgroups
+  const int R = want <= 8 ? 8 : (want <= 16 ? 16 : (want <= 24 ? 24 : 40));
+  const dim3 grid((M + R - 1) / R, gy);
+#define MVK_SMALLK_CASE(K4_)                                                                                    \
+  case K4_:                                                                                                     \
+    if (R == 8) hipLaunchKernelGGL((smallk_fwd_kernel<K4_, 8>), grid, dim3(256), 0, s, a);                      \
+    else if (R == 16) hipLaunchKernelGGL((smallk_fwd_kernel<K4_, 16>), grid, dim3(256), 0, s, a);               \
+    else if (R == 24) hipLaunchKernelGGL((smallk_fwd_kernel<K4_, 24>), grid, dim3(256), 0, s, a);               \
+    else hipLaunchKernelGGL((smallk_fwd_kernel<K4_, 40>), grid, dim3(256), 0, s, a);                            \
+    break;
+  switch ((K + 3) / 4 > 8 ? 8 : (K + 3) / 4) {
+    MVK_SMALLK_CASE(1) MVK_SMALLK_CASE(2) MVK_SMALLK_CASE(3) MVK_SMALLK_CASE(4)
+    MVK_SMALLK_CASE(5) MVK_SMALLK_CASE(6) MVK_SMALLK_CASE(7) MVK_SMALLK_CASE(8)
   }
+#undef MVK_SMALLK_CASE
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }

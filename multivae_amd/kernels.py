@@ -127,6 +127,46 @@ class late_leaves:
         return False
 
 
+_LATE_CALLS = {}  # device -> closures run on the late-leaf stream when deferred_reductions ends (behind every other late leaf)
+# MVK_LATE_DENSE=0: the MLP decoder's weight gradients stay inside its backward chain
+LATE_DENSE = _lib.tune("MVK_LATE_DENSE", "1") != "0"
+
+
+def run_last(device, fn, *reads):
+    """Inside deferred_reductions: run fn() on the late-leaf stream AFTER everything else the backward pass puts there (the
+    enqueue itself is postponed to the end of the scope), i.e. in the launch-latency-bound tail of the step where the chip is
+    mostly idle, instead of beside the decoders' backward-data chains whose window is throughput-bound.  Returns False when
+    there is no such scope (the caller runs fn itself)."""
+    if not (LATE_LEAVES and LATE_DENSE) or device.type != "cuda" or device not in _DEFER_ACTIVE:
+        return False
+    _LATE_CALLS.setdefault(device, []).append((fn, reads))
+    return True
+
+
+_LATE_READY = {}
+
+
+def late_ready(device):
+    """Called on the main stream where every decoder's backward has been joined (the posterior's backward): the postponed
+    leaves of run_last may start behind this point."""
+    if device in _LATE_CALLS:
+        _LATE_READY[device] = torch.cuda.current_stream(device).record_event()
+
+
+_LOSS_EVENT = {}  # device -> event behind the loss assembly when it ran on the late-leaf stream (ReconLossFn, async_ok)
+# MVK_ASYNC_LOSS=0: the loss assembly stays on the caller's stream, between the last forward and the first backward launch
+ASYNC_LOSS = _lib.tune("MVK_ASYNC_LOSS", "1") != "0"
+
+
+def wait_loss(device):
+    """Order the current stream behind the loss assembly launch.  Every backward node that READS a gradient buffer the assembly
+    fills (the KL rows' gradients, a fused tail's row gradients on its general path) calls this first; nodes that take the
+    constant from `const_grad` do not wait for anything."""
+    ev = _LOSS_EVENT.get(device)
+    if ev is not None:
+        torch.cuda.current_stream(device).wait_event(ev)
+
+
 class deferred_reductions:
     """with deferred_reductions(flat): forward + backward.  On exit the queued finishes run on the current stream; the
     gradient buffer is complete after that (before: NOT).  A no-op on CPU tensors or with MVK_DEFER=0."""
@@ -152,7 +192,26 @@ class deferred_reductions:
     def __exit__(self, et, ev, tb):
         if self.on:
             dev = self.grad.device
+            late = _LATE_CALLS.pop(dev, ())
+            if late:  # postponed leaves: enqueued now, on the late-leaf stream, behind the other late leaves
+                # Ordered behind a MAIN-stream event (late_ready: recorded where the posterior's backward starts, i.e. behind the
+                # join of every decoder's backward), never behind the producer's branch stream itself: the partial flush on a branch
+                # stream waits for the late-leaf stream, a late-leaf stream that waited for that branch stream made the two
+                # "parallel capture streams" of each other and hip::Stream::EndCapture recursed until the stack overflowed; a
+                # stream of its own changed the queue assignment of the replayed graph (the encoders' backward chain landed
+                # behind the postponed launches: 1.10 -> 1.19 ms).
+                st = _side_stream(dev, 30)
+                ev = _LATE_READY.pop(dev, None)
+                st.wait_event(ev if ev is not None else torch.cuda.current_stream(dev).record_event())
+                _LATE_USED.setdefault(dev, []).append(st)
+                with torch.cuda.stream(st):
+                    for fn, reads in late:
+                        for t in reads:
+                            t.record_stream(st)
+                        fn()
             _DEFER_ACTIVE.discard(dev)
+            _LATE_READY.pop(dev, None)
+            _LOSS_EVENT.pop(dev, None)  # the late-leaf stream is joined below
             cur = torch.cuda.current_stream(dev)
             for st in dict.fromkeys(_LATE_USED.pop(dev, ())):  # the late leaves (below) and sibling flushes end here
                 if st != cur:
@@ -341,6 +400,13 @@ def _grad_target(p):
         return g, None
     z = _zeros(p.shape, p)
     return z, z
+
+
+def _is_direct(p):
+    """_grad_target(p) accumulates straight into p.grad (autograd gets None)."""
+    g = p.grad
+    return bool(DIRECT_GRAD and g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.shape == p.shape
+                and g.device == p.device)
 
 
 def linear_bwd_weight(dy, x2, w, b, y_out=None, y_act=NONE):
@@ -1048,6 +1114,19 @@ def dense16_pack(w):
     return out
 
 
+def dense16_xamax(x):
+    """Device scalar >= max |x| of a target batch, once per forward pass inside a pack_scope."""
+    sc = _PACK_SCOPE
+    key = ("dense16_xamax", x.data_ptr(), tuple(x.shape))
+    if sc is not None and key in sc["cache"]:
+        return sc["cache"][key]
+    slot = _amax_slots(x, 1)
+    call("mvk_amax", ptr(x), x.numel(), ptr(slot), stream_ptr())
+    if sc is not None:
+        sc["cache"][key] = slot
+    return slot
+
+
 _CONST_GRADS = {}  # data_ptr -> (weakref of the tensor, numel, value): gradient buffers known to hold ONE constant
 
 
@@ -1090,11 +1169,10 @@ class MLPDecoderFn(Function):
         ctx.z_shape = z.shape
         if ctx.fused:
             n, H, D = z2.shape[0], w0.shape[0], w1.shape[0]
-            nk, nk_inv, kn, kn_inv = dense16_pack(w1)
-            am = _amax_slots(z2, 2)
-            zam, xam = am[0:1], am[1:2]
+            nk, nk_inv, kn, kn_inv = dense16_pack(w1)  # both usually done already: Decoder_AE_MLP.early_work
+            xam = dense16_xamax(nll_x)
+            zam = _amax_slots(z2, 1)
             call("mvk_amax", ptr(z2), z2.numel(), ptr(zam), stream_ptr())
-            call("mvk_amax", ptr(nll_x), nll_x.numel(), ptr(xam), stream_ptr())
             hp = _planes(n, H, z2)
             gp = _planes(n, D, z2)
             bounds = _new((2,), z2)  # [bound of h, bound of G]
@@ -1157,9 +1235,17 @@ class MLPDecoderFn(Function):
             dh = _new((n, H), z2)
             call("mvk_dense16_bwd_data", ptr(gp[0]), ptr(gp[1]), ptr(gb), ptr(kn[0]), ptr(kn[1]), ptr(kn_inv), ptr(hp[0]), ptr(dh),
                  ptr(tb0), ptr(ws), ws.numel(), n, H, D, stream_ptr())
-            call("mvk_dense16_wgrad", ptr(gp[0]), ptr(gp[1]), ptr(gb), ptr(hp[0]), ptr(hp[1]), ptr(hb), ptr(cs), cs.shape[0], ptr(tw1),
-                 ptr(tb1), ptr(ws), ws.numel(), n, D, H, stream_ptr())
+
+            def wgrad1():
+                wsl = _ws(z2)
+                call("mvk_dense16_wgrad", ptr(gp[0]), ptr(gp[1]), ptr(gb), ptr(hp[0]), ptr(hp[1]), ptr(hb), ptr(cs), cs.shape[0],
+                     ptr(tw1), ptr(tb1), ptr(wsl), wsl.numel(), n, D, H, stream_ptr())
+
+            # a leaf: postponed into the tail of the step when its targets are views of the flat gradient buffer
+            if dw1 is not None or db1 is not None or not run_last(z2.device, wgrad1, gp, hp, cs, bounds):
+                wgrad1()
         else:  # general upstream gradient: d pre = G * drows[column tile, row] / nll_weight as an fp32 tensor, then the tiled engine
+            wait_loss(z2.device)
             drows = _c(drows).reshape(-1, n)
             dpre = _new((n, D), z2)
             h = _new((n, H), z2)
@@ -1169,10 +1255,12 @@ class MLPDecoderFn(Function):
             db1 = colsum(dpre, b1)
             dw1, _ = linear_bwd_weight(dpre, h, w1, None)
             dh, db0 = linear_bwd_data(dpre, w1, prev_out=h, prev_act=RELU, prev_bias=b0)
-        dw0, _ = linear_bwd_weight(dh, z2, w0, None)
         dz = None
         if ctx.needs_input_grad[0]:
             dz = linear_bwd_data(dh, w0).view(ctx.z_shape)
+        dw0 = None
+        if not _is_direct(w0) or not run_last(z2.device, lambda: linear_bwd_weight(dh, z2, w0, None), dh, z2):
+            dw0, _ = linear_bwd_weight(dh, z2, w0, None)
         return dz, dw0, db0, dw1, db1, None, None, None, None
 
 
@@ -1333,6 +1421,7 @@ class SVHNDecoderFn(Function):
             if c is not None and c == ctx.nll_weight:
                 drows = None  # exactly the weight folded into `out`: no row gradient is read (nor waited for)
             else:
+                wait_loss(dout.device)
                 drows = _c(dout).reshape(-1)
                 if ctx.nll_weight != 1.0:
                     drows = drows * (1.0 / ctx.nll_weight)
@@ -1678,6 +1767,8 @@ class MoPoEPosteriorFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dz, dkld_rows, *unused):
+        wait_loss(ctx.saved_tensors[0].device)  # the gradients of the KL rows come out of the loss assembly launch
+        late_ready(ctx.saved_tensors[0].device)
         saved = ctx.saved_tensors
         eps, subset_masks, sel = saved[:3]
         M = ctx.M
@@ -1719,6 +1810,8 @@ class MVTCAEPosteriorFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dz, djkl, dckl, *unused):
+        wait_loss(ctx.saved_tensors[0].device)  # the gradients of the KL rows come out of the loss assembly launch
+        late_ready(ctx.saved_tensors[0].device)
         saved = ctx.saved_tensors
         eps = saved[0]
         M = ctx.M
@@ -1756,6 +1849,8 @@ class JMVAEPosteriorFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dz, dkld, dljm):
+        wait_loss(ctx.saved_tensors[0].device)  # the gradients of the KL rows come out of the loss assembly launch
+        late_ready(ctx.saved_tensors[0].device)
         saved = ctx.saved_tensors
         eps, jmu, jlv = saved[:3]
         M = ctx.M
@@ -1895,7 +1990,20 @@ class ReconLossFn(Function):
                 ti += 1
         out = _new((n_terms + 2,), ref)
         loss = _new((), ref)
-        call("mvk_reduce_terms", terms, n_terms, spec["loss_sum_scale"], ptr(out), ptr(loss), stream_ptr())
+        # Every reconstruction term came from a fused decoder tail (n_rec == 0) and the model vouches for its backward nodes
+        # (spec["async_ok"]: they call wait_loss before reading a gradient this launch fills): the assembly is a leaf of the
+        # step — nothing on the backward chain needs the loss VALUE — so it runs on the late-leaf stream, joined where the
+        # deferred finishes run, instead of between the last forward and the first backward launch of the critical chain.
+        late = late_leaves(ref.device, *extras) if (ASYNC_LOSS and n_rec == 0 and spec.get("async_ok")) else None
+        if late is not None and late.on:
+            with late:
+                call("mvk_reduce_terms", terms, n_terms, spec["loss_sum_scale"], ptr(out), ptr(loss), stream_ptr())
+                st = torch.cuda.current_stream(ref.device)
+                _LOSS_EVENT[ref.device] = st.record_event()
+                for t in [out, loss] + [d for d in dextras if d is not None]:
+                    t.record_stream(st)
+        else:
+            call("mvk_reduce_terms", terms, n_terms, spec["loss_sum_scale"], ptr(out), ptr(loss), stream_ptr())
         ctx.drecons = drecons
         ctx.dextras = dextras
         ctx.extra_shapes = [e.shape for e in extras]
@@ -1923,6 +2031,7 @@ class ReconLossFn(Function):
                     register_const_grad(extras[j], cs[0])
             ctx.drecons = ctx.dextras = None
             return (None, None, *grads, *extras)
+        wait_loss(gloss.device)  # the seed launch below rewrites what the assembly launch filled
         gloss = _c(gloss.reshape(1))
         extras = [d if d is not None else _new(shape, gloss) for d, shape in zip(ctx.dextras, ctx.extra_shapes)]
         jobs = [(g.data_ptr(), g.numel(), 1.0, 0) for g in ctx.drecons if g is not None]
@@ -1953,6 +2062,8 @@ class GaussSampleKLFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dw, dkl):
+        wait_loss(ctx.saved_tensors[0].device)  # the gradients of the KL rows come out of the loss assembly launch
+        late_ready(ctx.saved_tensors[0].device)
         eps, mu, lv = ctx.saved_tensors
         K, B, L = eps.shape
         dw = _c(dw) if dw is not None else None

@@ -21,6 +21,7 @@ from .mopoe_config import MoPoEConfig
 _EARLY_NOISE = _lib.tune("MVK_EARLY_NOISE", "1") != "0"  # 0: draw the noise behind the encoders (A/B)
 
 
+_EARLY_DENSE = _lib.tune("MVK_EARLY_DENSE", "1") != "0"  # 0: the fused tails prepare their operands in their own chains (A/B)
 _ROW_WEIGHT = {}
 
 
@@ -139,7 +140,14 @@ class MoPoE(BaseMultiVAE):
             # the noise does not depend on the encoders: its launch rides at the head of the short encoder's branch stream
             # instead of sitting between the encoders and the posterior kernel on the main one
             shape = (K, x0.shape[0], self.latent_dim)
-            enc = self.modality_encode(inputs, side_work=lambda: early.setdefault("eps", self._noise(shape, x0.device)))
+            def side_work():
+                early.setdefault("eps", self._noise(shape, x0.device))
+                if self.fused_decoder_tail and _EARLY_DENSE and not hasattr(inputs, "masks") and self.training:
+                    for m, dec in self.decoders.items():  # z-independent preparation of the fused decoder tails
+                        if hasattr(dec, "early_work") and self.recon_dists[m][0] == kernels.DIST["normal"]:
+                            dec.early_work(inputs.data[m], K * x0.shape[0])
+
+            enc = self.modality_encode(inputs, side_work=side_work)
             if "eps" in early:  # allocated on the side stream, consumed on this one (behind the join of run_branches)
                 early["eps"].record_stream(torch.cuda.current_stream(x0.device))
         else:
@@ -233,7 +241,10 @@ class MoPoE(BaseMultiVAE):
         spec.update(coef=[1.0 / (K * B)] * M, lossw=[1.0] * M,
                     extra_coef=[1.0 / B] * (1 + S) + [float(self.rescale_factors[m]) / (K * B) for m in fused],
                     extra_lossw=[beta] + [beta * float(self.model_config.beta_style)] * S + [1.0] * Fz,
-                    loss_sum_scale=float(B))
+                    loss_sum_scale=float(B),
+                    # the backward nodes of every extra term (MoPoEPosteriorFn, GaussSampleKLFn, the fused tails) order themselves
+                    # behind the assembly launch where they read what it fills: it may run beside the backward chain
+                    async_ok=masks is None)
         if style_kl and masks is not None:  # style_kld *= mask (:217-218), still averaged over the whole batch
             style_kl = [kl * masks[m].to(kl.dtype) for kl, m in zip(style_kl, names)]
         loss, terms = kernels.ReconLossFn.apply(spec, M, *recons, kld_rows, *style_kl, *[rec[m][1] for m in fused])

@@ -61,6 +61,17 @@ class Decoder_AE_MLP(BaseDecoder):
         out = kernels.MLPDecoderFn.apply(z, l0.weight, l0.bias, l1.weight, l1.bias, self.input_dim)
         return ModelOutput(reconstruction=out)
 
+    def early_work(self, x: torch.Tensor, rows: int):
+        """What `reconstruction_nll` needs that does not depend on z — the fp16 pair planes of the output layer's weight and
+        the bound of the targets — launched where the caller has an idle stream (MoPoE: the head of the short encoder's
+        branch) instead of in the decoder's own chain.  A no-op when the fused tail would not take `rows` decoder rows."""
+        l0, l1 = self.layers[0][0], self.layers[1][0]
+        D = int(np.prod(self.input_dim))
+        if (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x[0].numel() == D and torch.is_grad_enabled()
+                and kernels.mlp_fused_tail_ok(rows, l0.weight.shape[1], l0.weight.shape[0], D)):
+            kernels.dense16_pack(l1.weight)
+            kernels.dense16_xamax(x.reshape(x.shape[0], D))
+
     def reconstruction_nll(self, z: torch.Tensor, x: torch.Tensor, dist: str = "normal", scale: float = 1.0, row_weight=None):
         """OPT-IN fast path for models that own the loss (MoPoE here; the contract of Decoder_VAE_SVHN.reconstruction_nll):
         -log p(x | decoder(z)) under Normal(scale), computed in the epilogue of the output layer's GEMM on fp16 pair planes

@@ -331,9 +331,9 @@ class BaseTrainer:
             if not isinstance(self.optimizer, FusedAdam):
                 self.flat.ensure_attached()
         if isinstance(self.optimizer, FusedAdam):
-            if self.distributed:
-                self.flat.all_reduce()  # C2: ONE sum all-reduce of the flat gradient buffer
-            self.optimizer.step(grad_scale=1.0 / self.world_size if self.distributed else 1.0)
+            # C2: ONE collective over the flat gradient buffer — mvk_allreduce_avg (RCCL) leaves the mean, a plain sum (gloo) the
+            # factor 1 / world_size for the optimizer launch
+            self.optimizer.step(grad_scale=self.flat.all_reduce_mean() if self.distributed else 1.0)
         else:
             if self.distributed:
                 self.flat.all_reduce()

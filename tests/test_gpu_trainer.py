@@ -614,8 +614,8 @@ def _dp_worker(rank, world, port, ret, outdir):
     d = torch.device("cuda:0")
     model = _mnist_svhn_mopoe(d, K=_DP["K"], L=_DP["L"], seed=100 + rank)  # different weights per rank: rank 0's are broadcast
     calls = []
-    orig = FlatParams.all_reduce
-    FlatParams.all_reduce = lambda self, group=None: (calls.append(1), orig(self, group))[1]
+    orig = FlatParams.all_reduce_mean
+    FlatParams.all_reduce_mean = lambda self, group=None: (calls.append(1), orig(self, group))[1]
     cfg = BaseTrainerConfig(output_dir=outdir, per_device_train_batch_size=_DP["bs"], num_epochs=_DP["epochs"],
                             learning_rate=_DP["lr"], optimizer_cls="Adam", use_fused_adam=True, use_hip_graph=True,
                             dist_backend="gloo", world_size=world, rank=rank, local_rank=0, seed=_DP["seed"], steps_saving=None)

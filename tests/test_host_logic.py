@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     bound = set(_lib.PROTOTYPES) | {"mvk_splitk_workspace_floats", "mvk_conv4s2_small_up_supported", "mvk_conv4s2_small_up_nll_supported",
                                     "mvk_imgconv_frag_bytes",
                                     "mvk_debug_set_phase_buffer", "mvk_debug_set_flags", "mvk_dense16_debug",  # void hooks, bound ad hoc
-                                    "mvk_dense16_ok", "mvk_dense16_fwd_nll_rows", "mvk_dense16_colsum_rows",
+                                    "mvk_dense16_ok", "mvk_dense16_fwd_nll_rows", "mvk_dense16_colsum_rows", "mvk_comm_id_bytes",
                                     "mvk_prof_enable", "mvk_prof_count", "mvk_prof_clock_khz", "mvk_prof_calibrate",
                                     "mvk_defer_pending", "mvk_defer_wanted", "mvk_conv3x3_fused_ok", "mvk_conv3x3_scaled_ok", "mvk_conv3x3_wgrad_scaled_ok", "mvk_conv4s2_scaled_ok", "mvk_conv4s2_wgrad_scaled_ok"}
     assert declared == bound, (declared - bound, bound - declared)
