@@ -71,7 +71,12 @@ __device__ __forceinline__ void amax_publish(float v, float* dst, float* red) {
   if (threadIdx.x == 0) {
     float m = red[0];
     for (int i = 1; i < waves; ++i) m = fmaxf(m, red[i]);
-    atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(m));
+    // Only a workgroup that would RAISE the published value issues the atomic: same-address atomics serialise at ~10 ns each
+    // (the 1280 workgroups of the decoder's first layer spent 12 of their 28 us there), a relaxed agent-scope load does not,
+    // and after the first few workgroups almost none exceeds what is already there.
+    unsigned* const d = reinterpret_cast<unsigned*>(dst);
+    const unsigned mu = __float_as_uint(m);
+    if (mu > __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(d, mu);
   }
 }
 

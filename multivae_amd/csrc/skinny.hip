@@ -312,7 +312,7 @@ struct SmallKArgs {
 
 // R rows per workgroup.  Every workgroup first loads its weight columns (40-80 KB at K = 20): with 8 rows the 1280 workgroups of
 // the decoder batch (M = 5120, N = 2048) read 100 MB of weights from L2 to write 42 MB of output (29 us); the launcher picks R
-// so that the grid is about one workgroup per compute unit (R = 40 there: 256 workgroups, 20 MB of weight reads).
+// 16 rows there (640 workgroups; the rest of the 28 us were 1280 same-address atomics of the published maximum: amax_publish).
 template <int K4, int R>  // K4 = ceil(K / 4)
 __global__ __launch_bounds__(256) void smallk_fwd_kernel(const SmallKArgs g) {
   constexpr int KP = K4 * 4;
@@ -400,7 +400,8 @@ int smallk_fwd(const float* X, const float* W, long long w_sk, long long w_sn, c
   const int gy = (CT + ctb - 1) / ctb;
   static const int r_env = mvk_tune("MVK_SMALLK_ROWS") ? atoi(mvk_tune("MVK_SMALLK_ROWS")) : 0;
   const long long want = r_env > 0 ? r_env : ((long long)M * gy + 255) / 256;  // rows per workgroup for ~256 workgroups
-  const int R = want <= 8 ? 8 : (want <= 16 ? 16 : (want <= 24 ? 24 : 40));
+  // measured at M = 5120, N = 2048, K = 20: 8 rows 19.2 us, 16 rows 18.0, 24 rows 20.4, 40 rows 28.8 (one wave per SIMD: latency-bound)
+  const int R = r_env > 0 ? (want <= 8 ? 8 : (want <= 16 ? 16 : (want <= 24 ? 24 : 40))) : (want <= 8 ? 8 : 16);
   const dim3 grid((M + R - 1) / R, gy);
 #define MVK_SMALLK_CASE(K4_)                                                                                    \
   case K4_:                                                                                                     \
