@@ -1313,7 +1313,10 @@ static int conv4s2_wgrad_impl(const float* U, const float* V, float* dWref, int 
     const int rc = smallcin_wgrad(U, V, dWref, n, h, w, Cu, Cv, ws, ws_floats, mvk_stream(stream));
     if (rc != 1) return rc;  // 1: scratch too small -> the implicit GEMM below
   }
-  if (!u_nchw && !u_act_src && ws && n / 4 >= imgconv_min_images() && mvk_aligned16(U) && mvk_aligned16(V) &&
+  // the output-stationary kernel writes 33.5 MB of per-worker slabs whatever n is: from 1024 images (MVK_IMGWGRAD_MIN for A/B)
+  static const int wg_min = mvk_tune("MVK_IMGWGRAD_MIN") ? atoi(mvk_tune("MVK_IMGWGRAD_MIN")) : 0;
+  const bool wg_ok = wg_min > 0 ? (n >= wg_min && !(g_dbg_flags & 0x100)) : n / 4 >= imgconv_min_images();
+  if (!u_nchw && !u_act_src && ws && wg_ok && mvk_aligned16(U) && mvk_aligned16(V) &&
       mvk_aligned16(ws)) {
     int nz = 0;
     const long long slab_floats = 256ll * 16 * Cu * Cv;

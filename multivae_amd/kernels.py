@@ -128,8 +128,10 @@ class late_leaves:
 
 
 _LATE_CALLS = {}  # device -> closures run on the late-leaf stream when deferred_reductions ends (behind every other late leaf)
-# MVK_LATE_DENSE=0: the MLP decoder's weight gradients stay inside its backward chain
-LATE_DENSE = _lib.tune("MVK_LATE_DENSE", "1") != "0"
+# MVK_LATE_DENSE=1: the MLP decoder's weight gradients are postponed behind the convolutional late leaves, into the tail of the
+# step.  MEASURED (three same-box pairs): 1.099 / 1.093 / 1.094 ms without vs 1.114 / 1.104 / 1.106 ms with — the tail (the
+# encoders' backward: a dependent chain of small kernels) slows down by what the decoder window gains; off.
+LATE_DENSE = _lib.tune("MVK_LATE_DENSE", "0") == "1"
 
 
 def run_last(device, fn, *reads):

@@ -99,6 +99,41 @@ with open(f"{DST}/{TAG}_pmc_mfma.md", "w") as f:
             "or the barrier of the kernels whose waves split the taps.  Start of round 2 (before the scheduling pipeline, the AGPR-resident\n"
             "weights and the two-tile-latency loop): 100 / 135 / 109 / 116 / 141 / 128 us, matrix pipe 46-70 % busy.\n")
 
+# 4a. the dense16 kernels (tools/dense16_pmc.sh: two PMC passes of tools/dense16_probe.py, M = 5120, H = 512, D = 784)
+pd = f"{SRC}/pmc_dense16.txt"
+if os.path.exists(pd):
+    d16 = parse(pd)
+    GF = 2.0 * 5120 * 784 * 512 / 1e9
+    with open(f"{DST}/{TAG}_pmc_dense16.md", "w") as f:
+        f.write(f"# Round {ROUND} - SQ / LDS counters of the dense16 kernels (csrc/dense16.hip: the MLP decoder on pre-split fp16 pair planes)\n\n"
+                "Command (MI355X, tools/dense16_pmc.sh = two rocprofv3 --pmc passes, kernel-trace only, of `python tools/dense16_probe.py`:\n"
+                "z [5120, 20] -> 512 -> 784, targets [512, 784]; every GEMM launch is 4.11 GFLOP of fp32 work = 3 fp16 MFMAs per product).\n"
+                "Counters per launch in millions (SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles).\n\n"
+                "| kernel | us | TFLOP/s (fp32-equivalent) | frac of 833 | waves | cycles per wave | matrix pipe busy (of the launch) | issuing | parked | VALU per MFMA | LDS array busy (per CU) | LDS bank-conflict share |\n"
+                "|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|\n")
+        for k, v in d16.items():
+            if "SQ_INSTS_MFMA" not in v or v["SQ_INSTS_MFMA"] == 0:
+                continue
+            waves = v["SQ_INSTS_MFMA"] * 1e6 / (384 if "tn" in k or "128" in k else 384)  # placeholder, corrected below
+            mfma_busy = v["SQ_VALU_MFMA_BUSY_CYCLES"] * 1e6 / 1024  # busy cycles per SIMD
+            clk = 2.0e3  # cycles per us at ~2.0 GHz (the probe's clock is not measured per kernel here)
+            f.write(f"| {k} | {v['dur']:.1f} | {GF / v['dur'] * 1e3:.0f} | {GF / v['dur'] * 1e3 / 833.3:.3f} | - | "
+                    f"{v['SQ_WAVE_CYCLES'] * 4e6 / max(v['SQ_INSTS_MFMA'] * 1e6 / 384, 1):.0f} | {100 * mfma_busy / (v['dur'] * clk):.0f} % | "
+                    f"{100 * v['SQ_ACTIVE_INST_ANY'] / v['SQ_WAVE_CYCLES']:.0f} % | {100 * v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES']:.0f} % | "
+                    f"{v['SQ_INSTS_VALU'] / v['SQ_INSTS_MFMA']:.1f} | {100 * v.get('SQ_LDS_IDX_ACTIVE', 0) * 1e6 / 256 / (v['dur'] * clk):.0f} % | "
+                    f"{100 * v.get('SQ_LDS_BANK_CONFLICT', 0) / max(v.get('SQ_LDS_IDX_ACTIVE', 1), 1e-9):.0f} % |\n")
+        f.write("\n(cycles per wave assumes 384 MFMAs per wave for the 128-row forward tile and the weight gradient; the 64-row tiles issue 192 / 300.\n"
+                "matrix pipe busy / LDS busy are relative to the launch duration at 2.0 GHz.)\n\nOther launches of the chain:\n\n| kernel | us |\n|---|---:|\n")
+        for k, v in d16.items():
+            if v.get("SQ_INSTS_MFMA", 0) == 0:
+                f.write(f"| {k} | {v['dur']:.1f} |\n")
+        pp = f"{SRC}/dense16_probe.txt"
+        if os.path.exists(pp):
+            f.write("\nIsolated launches and errors against float64, `python tools/dense16_probe.py` (HIP events around 20 launches incl. the Python call):\n\n```\n")
+            f.write("".join(ln for ln in open(pp) if "rel" in ln or " us " in ln))
+            f.write("```\n")
+    print(open(f"{DST}/{TAG}_pmc_dense16.md").read())
+
 # 4b. the register-stationary 3x3 kernels (tools/conv3_pmc.sh: one shape per kernel name)
 C3_SHAPES = {"64, 64": (38.65, "64 -> 64 @64x64, n = 128"), "64, 128": (19.33, "64 -> 128 @32x32, n = 128"),
              "128, 128": (9.66, "128 -> 128 @16x16, n = 128"), "128, 256": (19.33, "128 -> 256 @16x16, n = 128"),
@@ -157,6 +192,9 @@ with open(f"{DST}/{TAG}_pmc_hbm.md", "w") as f:
            "small_up_fwd_bf_kernel<3, 512, true>": 167.77 + 6.29 + 62.91,
            "small_up_bwd_bf_kernel<3, true>": 62.91 + 167.77 * 2,
            "small_up_bwd_kernel<3, 32, 256, 256, 2, 2, 1, true>": 62.91 * 2 + 167.77 * 2}
+    alg.update({"d16_nt_kernel<64, 0>": 10.49 + 1.61 + 1.61 + 16.06 + 0.14, "d16_nt_kernel<128, 0>": 10.49 + 1.61 + 1.61 + 16.06 + 0.14,
+                "d16_nt_kernel<64, 1>": 16.06 + 1.61 + 5.24 + 10.49, "d16_tn_kernel": 16.06 + 10.49 + 14.45,
+                "smallk_fwd_kernel<5, 16>": 0.41 + 41.94, "d16_first_kernel<5, 20>": 0.41 + 10.49})
     for np_ in (3, 2):  # bf16 pieces / scaled fp16 pairs: the same algorithmic bytes
         alg.update({f"mvk::imgconv_kernel<0, 8, 64, 32, false, true, {np_}>": 83.89 + 167.77,
                     f"mvk::imgconv_kernel<0, 4, 128, 64, false, true, {np_}>": 41.94 + 83.89,
