@@ -529,6 +529,7 @@ struct D16Tn {
   const float* d_bound;
   const float* h_bound;
   int M, N, K, mchunks;   // mchunks: 32-row chunks per z slice
+  int jt, it, S;          // column tiles of D / of H, z slices: the grid is 1-D (jt * it * S workgroups, XCD-aware mapping)
   float* slab;            // [gridDim.z][N][K]
   // bias gradient: workgroups (jt, 0, 0) add the forward's column-sum partials in order
   const float* colsum_part;  // [cs_rows][N] or null
@@ -552,8 +553,22 @@ __global__ __launch_bounds__(256, 1) void d16_tn_kernel(const D16Tn g) {
   mvk_prof_begin(g.prof);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int wj = wave >> 1, wi = wave & 1;
-  const int j0 = blockIdx.x * BJ, i0 = blockIdx.y * BI;
-  const int mbeg = blockIdx.z * g.mchunks * 32;
+  // Workgroup -> (tile, slice).  Consecutive workgroup ids go to the 8 XCDs round-robin, each with its own 4 MB L2: with
+  // S % 8 == 0 the slice index is the XCD index, so every tile of a slice (the same 32-row chunks of D and H: ~3 MB at
+  // S = 8) meets its operands in ONE L2.  (grid (jt, it, S): 146 MB of fabric reads for 26.5 MB of operands, r04_pmc_hbm.md.)
+  const int tiles = g.jt * g.it, L = blockIdx.x;
+  int tile, bz;
+  if (g.S % 8 == 0) {
+    const int q = L >> 3;
+    tile = q % tiles;
+    bz = (q / tiles) * 8 + (L & 7);
+  } else {
+    tile = L % tiles;
+    bz = L / tiles;
+  }
+  const int bx = tile % g.jt, by = tile / g.jt;
+  const int j0 = bx * BJ, i0 = by * BI;
+  const int mbeg = bz * g.mchunks * 32;
   int nt = (g.M - mbeg + 31) / 32;
   nt = nt < g.mchunks ? nt : g.mchunks;
   if (nt < 0) nt = 0;
@@ -672,7 +687,7 @@ __global__ __launch_bounds__(256, 1) void d16_tn_kernel(const D16Tn g) {
     ktile(t + 1, lds + STAGE, lds, R0);
   }
   const float inv = mvk::f16_inv_scale(mvk::f16_scale_of(*g.d_bound)) * mvk::f16_inv_scale(mvk::f16_scale_of(*g.h_bound));
-  float* slab = g.slab + (long long)blockIdx.z * g.N * g.K;
+  float* slab = g.slab + (long long)bz * g.N * g.K;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -684,7 +699,7 @@ __global__ __launch_bounds__(256, 1) void d16_tn_kernel(const D16Tn g) {
         if (j < g.N && i < g.K) slab[(long long)j * g.K + i] = fmaf(accc[a][b][r], 1.f / 2048.f, accm[a][b][r]) * inv;
       }
     }
-  if (g.colsum_part && blockIdx.y == 0 && blockIdx.z == 0 && tid < BJ && j0 + tid < g.N) {
+  if (g.colsum_part && by == 0 && bz == 0 && tid < BJ && j0 + tid < g.N) {
     float s = 0.f;
     for (int r = 0; r < g.cs_rows; ++r) s += g.colsum_part[(long long)r * g.N + j0 + tid];
     g.db[j0 + tid] += s;
@@ -877,10 +892,11 @@ int mvk_dense16_wgrad(const void* g_hi, const void* g_lo, const float* g_bound, 
   }
   const int jt = (N + 127) / 128, it = (K + 127) / 128;
   const int chunks = (M + 31) / 32;
-  int S = 256 / (jt * it);  // ~one workgroup per compute unit
+  int S = 256 / (jt * it);  // ~one workgroup per compute unit ...
   S = S < 1 ? 1 : (S > chunks ? chunks : S);
-  const int per = (chunks + S - 1) / S;
-  S = (chunks + per - 1) / per;
+  if (S >= 6 && chunks >= 8) S = S >= 12 && chunks >= 16 ? 16 : 8;  // ... in multiples of the 8 XCDs where that is close
+  int per = (chunks + S - 1) / S;
+  if (S % 8 != 0) S = (chunks + per - 1) / per;  // (a multiple of 8 keeps its empty tail slices: they write zero slabs)
   const long long total = (long long)N * K;
   float* slab = mvk::defer_scratch(dW, (long long)S * total, s);
   const bool deferred = slab != nullptr;
@@ -888,9 +904,9 @@ int mvk_dense16_wgrad(const void* g_hi, const void* g_lo, const float* g_bound, 
     if (!ws || ws_floats < (long long)S * total) return MVK_EINVAL;
     slab = ws;
   }
-  D16Tn a{(const half_t*)g_hi, (const half_t*)g_lo, (const half_t*)h_hi, (const half_t*)h_lo, g_bound, h_bound, M, N, K, per, slab,
-          colsum_part, cs_rows, db, mvk::prof_next(10, 2.0 * M * N * K)};
-  hipLaunchKernelGGL(d16_tn_kernel, dim3(jt, it, S), dim3(256), LDS, s, a);
+  D16Tn a{(const half_t*)g_hi, (const half_t*)g_lo, (const half_t*)h_hi, (const half_t*)h_lo, g_bound, h_bound, M, N, K, per, jt, it, S,
+          slab, colsum_part, cs_rows, db, mvk::prof_next(10, 2.0 * M * N * K)};
+  hipLaunchKernelGGL(d16_tn_kernel, dim3(jt * it * S), dim3(256), LDS, s, a);
   MVK_CHECK_LAUNCH();
   mvk::prof_fold(a.prof, s);
   if (deferred) return mvk::defer_push_plain(dW, slab, total, S, total, s);

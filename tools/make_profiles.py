@@ -109,21 +109,21 @@ if os.path.exists(pd):
                 "Command (MI355X, tools/dense16_pmc.sh = two rocprofv3 --pmc passes, kernel-trace only, of `python tools/dense16_probe.py`:\n"
                 "z [5120, 20] -> 512 -> 784, targets [512, 784]; every GEMM launch is 4.11 GFLOP of fp32 work = 3 fp16 MFMAs per product).\n"
                 "Counters per launch in millions (SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles).\n\n"
-                "| kernel | us | TFLOP/s (fp32-equivalent) | frac of 833 | waves | cycles per wave | matrix pipe busy (of the launch) | issuing | parked | VALU per MFMA | LDS array busy (per CU) | LDS bank-conflict share |\n"
-                "|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|\n")
+                "| kernel | us | TFLOP/s (fp32-equivalent) | frac of 833 | matrix pipe busy (of the launch) | issuing | parked | VALU per MFMA | LDS array busy (per CU) | LDS bank-conflict share |\n"
+                "|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|\n")
         for k, v in d16.items():
             if "SQ_INSTS_MFMA" not in v or v["SQ_INSTS_MFMA"] == 0:
                 continue
-            waves = v["SQ_INSTS_MFMA"] * 1e6 / (384 if "tn" in k or "128" in k else 384)  # placeholder, corrected below
             mfma_busy = v["SQ_VALU_MFMA_BUSY_CYCLES"] * 1e6 / 1024  # busy cycles per SIMD
             clk = 2.0e3  # cycles per us at ~2.0 GHz (the probe's clock is not measured per kernel here)
-            f.write(f"| {k} | {v['dur']:.1f} | {GF / v['dur'] * 1e3:.0f} | {GF / v['dur'] * 1e3 / 833.3:.3f} | - | "
-                    f"{v['SQ_WAVE_CYCLES'] * 4e6 / max(v['SQ_INSTS_MFMA'] * 1e6 / 384, 1):.0f} | {100 * mfma_busy / (v['dur'] * clk):.0f} % | "
+            f.write(f"| {k} | {v['dur']:.1f} | {GF / v['dur'] * 1e3:.0f} | {GF / v['dur'] * 1e3 / 833.3:.3f} | "
+                    f"{100 * mfma_busy / (v['dur'] * clk):.0f} % | "
                     f"{100 * v['SQ_ACTIVE_INST_ANY'] / v['SQ_WAVE_CYCLES']:.0f} % | {100 * v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES']:.0f} % | "
                     f"{v['SQ_INSTS_VALU'] / v['SQ_INSTS_MFMA']:.1f} | {100 * v.get('SQ_LDS_IDX_ACTIVE', 0) * 1e6 / 256 / (v['dur'] * clk):.0f} % | "
                     f"{100 * v.get('SQ_LDS_BANK_CONFLICT', 0) / max(v.get('SQ_LDS_IDX_ACTIVE', 1), 1e-9):.0f} % |\n")
-        f.write("\n(cycles per wave assumes 384 MFMAs per wave for the 128-row forward tile and the weight gradient; the 64-row tiles issue 192 / 300.\n"
-                "matrix pipe busy / LDS busy are relative to the launch duration at 2.0 GHz.)\n\nOther launches of the chain:\n\n| kernel | us |\n|---|---:|\n")
+        f.write("\n(matrix pipe busy / LDS busy: busy cycles per SIMD / per CU over the launch duration at 2.0 GHz; issuing / parked: share of the\n"
+                "waves' resident cycles.  Nothing is saturated: the launches are bound by the issue stalls of their global loads and LDS stores\n"
+                "in front of the MFMAs of an in-order wave, DESIGN.md section 9.)\n\nOther launches of the chain:\n\n| kernel | us |\n|---|---:|\n")
         for k, v in d16.items():
             if v.get("SQ_INSTS_MFMA", 0) == 0:
                 f.write(f"| {k} | {v['dur']:.1f} |\n")
