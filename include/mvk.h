@@ -509,6 +509,9 @@ int mvk_conv4s2_up_nchw_small(const float* V, const float* Wref, const float* bi
  * mvk_pack_conv4s2_weight.  Same support set as mvk_conv4s2_small_up_supported; mvk_conv4s2_down routes here. */
 int mvk_conv4s2_small_down_fwd(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w,
                                int Cu, int Cv, int act, void* stream);
+/* ... from the reference weight layout Wref[Cv][Cu][4][4]: the encoder's first kernel does not wait for mvk_pack_weights */
+int mvk_conv4s2_small_down_fwd_wref(const float* U, const float* Wref, const float* bias, float* V, int n, int h, int w,
+                                    int Cu, int Cv, int act, void* stream);
 int mvk_conv4s2_small_up_supported(int h, int w, int Cu, int Cv);
 int mvk_conv4s2_small_up_fwd(const float* V, const float* Wref, const float* bias, float* U, int n, int h, int w,
                              int Cu, int Cv, int act, void* stream);

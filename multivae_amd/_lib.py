@@ -128,6 +128,7 @@ PROTOTYPES = {
     "mvk_conv4s2_up_nchw_small": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "mvk_conv4s2_small_up_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "mvk_conv4s2_small_down_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "mvk_conv4s2_small_down_fwd_wref": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "mvk_conv4s2_small_up_bwd": [_p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p],
     "mvk_pack_unflatten_weight": [_p, _i, _i, _p, _p],
     "mvk_unflatten_wgrad": [_p, _p, _p, _i, _i, _i, _p, _i64, _p],
@@ -289,6 +290,7 @@ GEMM_FLOPS = {
     "mvk_conv4s2_up_nchw_small": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
     "mvk_conv4s2_small_up_fwd": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
     "mvk_conv4s2_small_down_fwd": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
+    "mvk_conv4s2_small_down_fwd_wref": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
     "mvk_conv4s2_small_up_bwd": lambda a: 2.0 * 2.0 * a[12] * a[13] * a[14] * 16 * a[15] * a[16],  # data + weight
     "mvk_conv4s2_small_up_fwd_nll": lambda a: 2.0 * a[8] * a[9] * a[10] * 16 * a[11] * a[12],
     "mvk_conv4s2_small_up_fwd_nll_w": lambda a: 2.0 * a[9] * a[10] * a[11] * 16 * a[12] * a[13],

@@ -927,7 +927,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <int CU, int CV, int NT>
 __global__ __launch_bounds__(NT) void small_down_fwd_kernel(const float* __restrict__ U, const float* __restrict__ Wdown,
                                                             const float* __restrict__ bias, float* __restrict__ V, int n,
-                                                            int h, int w, int act) {
+                                                            int h, int w, int act, int wref) {
+  // wref: Wdown is the layer's REFERENCE weight [Cv][Cu][4][4] (1536 floats at 3 -> 32 channels): the first kernel of the
+  // encoder then does not wait for the step's weight-pack launch, which runs beside it
   using C = SmallCfg<CU, CV>;
   constexpr int NW = NT / 64, WP = 256 / NW, MT = WP / 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -936,7 +938,10 @@ __global__ __launch_bounds__(NT) void small_down_fwd_kernel(const float* __restr
   float* Ds = Wt + C::NC * C::WT;                         // [CU][DH][DW] image with zero halo
   int* posoff = reinterpret_cast<int*>(Ds + ((CU * DH * DW + 3) & ~3));  // [P]: (2i)*DW + 2j
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
-  for (int i = tid; i < C::NC * CV; i += NT) Wt[(i / CV) * C::WT + (i % CV)] = Wdown[i];
+  for (int i = tid; i < C::NC * CV; i += NT) {  // i = k * CV + cv, k = tap * CU + cu
+    const int k = i / CV, cv = i % CV;
+    Wt[k * C::WT + cv] = wref ? Wdown[(cv * CU + k % CU) * 16 + k / CU] : Wdown[i];
+  }
   for (int p = tid; p < P; p += NT) posoff[p] = (2 * (p / w)) * DW + 2 * (p % w);
   const bool active = wave * WP < P;
   float bv0[C::NTV];
@@ -1227,13 +1232,13 @@ static int launch_bwd(const float* dU, const float* Uout, int u_act, const float
 
 template <int CU, int CV>
 static int launch_down_fwd(const float* U, const float* Wdown, const float* bias, float* V, int n, int h, int w, int act,
-                           hipStream_t s) {
+                           hipStream_t s, int wref) {
   using C = SmallCfg<CU, CV>;
   constexpr int NT = MVK_SMALL_DOWN_THREADS;
   const int P = h * w, DH = 2 * h + 2, DW = 2 * w + 2;
   const size_t lds = ((size_t)C::NC * C::WT + ((CU * DH * DW + 3) & ~3) + P) * sizeof(float);
   const int grid = n < 1024 ? n : 1024;  // persistent: up to 4 workgroups per CU, each loops over images with prefetch
-  hipLaunchKernelGGL((small_down_fwd_kernel<CU, CV, NT>), dim3(grid), dim3(NT), lds, s, U, Wdown, bias, V, n, h, w, act);
+  hipLaunchKernelGGL((small_down_fwd_kernel<CU, CV, NT>), dim3(grid), dim3(NT), lds, s, U, Wdown, bias, V, n, h, w, act, wref);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }
@@ -1319,7 +1324,16 @@ int mvk_conv4s2_small_down_fwd(const float* U, const float* Wdown, const float* 
   if (n == 0) return MVK_OK;
   if (!U || !Wdown || !V || n < 0 || !supported(h, w, Cu, Cv)) return MVK_EINVAL;
   hipStream_t s = mvk_stream(stream);
-  MVK_SMALL_DISPATCH(launch_down_fwd, U, Wdown, bias, V, n, h, w, act, s)
+  MVK_SMALL_DISPATCH(launch_down_fwd, U, Wdown, bias, V, n, h, w, act, s, 0)
+}
+
+/* the same layer from the REFERENCE weight layout Wref[Cv][Cu][4][4] (no weight pack in front of the encoder's first kernel) */
+int mvk_conv4s2_small_down_fwd_wref(const float* U, const float* Wref, const float* bias, float* V, int n, int h, int w,
+                                    int Cu, int Cv, int act, void* stream) {
+  if (n == 0) return MVK_OK;
+  if (!U || !Wref || !V || n < 0 || !supported(h, w, Cu, Cv)) return MVK_EINVAL;
+  hipStream_t s = mvk_stream(stream);
+  MVK_SMALL_DISPATCH(launch_down_fwd, U, Wref, bias, V, n, h, w, act, s, 1)
 }
 
 int mvk_conv4s2_small_up_bwd(const float* dU, const float* Uout, int u_act, const float* V, int v_act,

@@ -508,6 +508,11 @@ def wfrag(w):
 PACK_MAX = 16  # MVK_PACK_MAX descriptors per launch
 # MVK_PREPACK=0: every network packs its own weights when it runs (one launch per network and forward pass)
 PREPACK = _lib.tune("MVK_PREPACK", "1") != "0"
+# MVK_PACK_SIDE=1: the pack launch on the first branch stream, beside the image-consuming first convolution (which reads the
+# reference weight layout).  MEASURED (three same-box pairs): 1.074 / 1.079 / 1.074 ms without vs 1.137 / 1.130 / 1.131 ms with —
+# one more fork / join edge at the head of the captured graph costs three times the 20 us it takes off the chain (the fourth result
+# of this kind: DESIGN.md section 9).  Off.
+PACK_SIDE = _lib.tune("MVK_PACK_SIDE", "0") == "1"
 _PACK_SCOPE = None
 
 
@@ -528,11 +533,43 @@ class pack_scope:
             # the zeroed arena of the amax protocol (AmaxPool, the pack launches): filled HERE, on the caller's stream and in front
             # of every fork of run_branches — a slot must be zero before ANY stream publishes into it, and the branch streams
             # are ordered behind the fork only, not behind what the first branch enqueues
-            if C3_F16 or IMG_F16:
-                dev = next((p.device for p in self.model.parameters()), None)
-                if dev is not None and dev.type == "cuda":
-                    _PACK_SCOPE["amax"], _PACK_SCOPE["amax_pos"] = torch.zeros(512, dtype=torch.float32, device=dev), 0
+            dev = next((p.device for p in self.model.parameters()), None)
+            if (C3_F16 or IMG_F16) and dev is not None and dev.type == "cuda":
+                _PACK_SCOPE["amax"], _PACK_SCOPE["amax_pos"] = torch.zeros(512, dtype=torch.float32, device=dev), 0
+            if PACK_SIDE and BRANCH_STREAMS and dev is not None and dev.type == "cuda":
+                self._launch_beside(dev)
         return self
+
+    def _launch_beside(self, dev):
+        """The step's ONE weight-pack launch on the first branch stream, beside the first kernels of the forward pass (the image-
+        consuming first convolution reads the reference layout: `mvk_conv4s2_small_down_fwd_wref`), instead of in front of
+        them on the caller's stream: 20 us of the launch-latency-bound head of the step.  A stream that takes a pack out of the
+        cache orders itself behind the launch once (`pack_weights`)."""
+        sc = _PACK_SCOPE
+        jobs, keys = [], []
+        for mod in self.model.modules():
+            announce = getattr(mod, "pack_jobs", None)
+            if announce is None:
+                continue
+            for j in announce():
+                k = _job_key(j)
+                if k not in keys and j[0].device == dev:
+                    jobs.append(j)
+                    keys.append(k)
+        sc["done"] = True
+        if not jobs:
+            return
+        main = torch.cuda.current_stream(dev)
+        st = _side_stream(dev, 1)
+        st.wait_event(main.record_event())  # behind the optimizer step that wrote the weights, and the amax arena's fill
+        with torch.cuda.stream(st):
+            outs = []
+            for i0 in range(0, len(jobs), PACK_MAX):
+                outs += _pack_launch(jobs[i0:i0 + PACK_MAX])
+            sc["event"] = st.record_event()
+        sc["pack_stream"], sc["waited"] = st, {st.cuda_stream}
+        for k, o in zip(keys, outs):
+            sc["cache"][k] = o
 
     def __exit__(self, *exc):
         global _PACK_SCOPE
@@ -553,6 +590,16 @@ def pack_weights(jobs):
     keys = [_job_key(j) for j in jobs]
     cache = sc["cache"]
     if all(k in cache for k in keys):
+        ev = sc.get("event")
+        if ev is not None:  # packed on another stream (pack_scope._launch_beside): this stream waits for it once
+            cur = torch.cuda.current_stream(jobs[0][0].device)
+            if cur.cuda_stream not in sc["waited"]:
+                cur.wait_event(ev)
+                sc["waited"].add(cur.cuda_stream)
+                for t in _tensors_of([cache[k] for k in cache if not (isinstance(k, tuple) and k and k[0] in ("dense16", "dense16_xamax"))]):
+                    t.record_stream(cur)
+                    if getattr(t, "mvk_frag", None) is not None:
+                        t.mvk_frag.record_stream(cur)
         return [cache[k] for k in keys]
     todo, tkeys = list(jobs), list(keys)
     if not sc["done"]:
@@ -1278,9 +1325,17 @@ class SVHNEncoderFn(Function):
         B, C0, H, W = x.shape
         chans = [C0, w0.shape[0], w1.shape[0], w2.shape[0]]
         L = wc1.shape[0]
-        (wd0, _), (wd1, wu1), (wd2, wu2), (wdc1, _), (wdc2, _) = pack_weights(
-            [(w0, True, False), (w1, True, True), (w2, True, True), (wc1, True, False), (wc2, True, False)])
-        h1 = conv_down(x, wd0, b0, B, H // 2, W // 2, chans[0], chans[1], RELU, u_nchw=True)
+        if _lib.load().mvk_conv4s2_small_up_supported(H // 2, W // 2, chans[0], chans[1]):
+            # the image-consuming layer reads the reference weight layout: no pack in front of the encoder's first kernel
+            h1 = _new((B, H // 2, W // 2, chans[1]), x)
+            call("mvk_conv4s2_small_down_fwd_wref", ptr(x), ptr(w0), ptr(b0), ptr(h1), B, H // 2, W // 2, chans[0], chans[1], RELU,
+                 stream_ptr())
+            (wd1, wu1), (wd2, wu2), (wdc1, _), (wdc2, _) = pack_weights(
+                [(w1, True, True), (w2, True, True), (wc1, True, False), (wc2, True, False)])
+        else:
+            (wd0, _), (wd1, wu1), (wd2, wu2), (wdc1, _), (wdc2, _) = pack_weights(
+                [(w0, True, False), (w1, True, True), (w2, True, True), (wc1, True, False), (wc2, True, False)])
+            h1 = conv_down(x, wd0, b0, B, H // 2, W // 2, chans[0], chans[1], RELU, u_nchw=True)
         h2 = conv_down(h1, wd1, b1, B, H // 4, W // 4, chans[1], chans[2], RELU)
         h3 = conv_down(h2, wd2, b2, B, H // 8, W // 8, chans[2], chans[3], RELU)
         if (H // 8, W // 8) != (4, 4):

@@ -120,14 +120,15 @@ class MoPoE(BaseMultiVAE):
 
     # -- forward -----------------------------------------------------------------------------------------
     def modality_encode(self, inputs, side_work=None, **kwargs):
-        """side_work: a callable run at the head of the LAST branch (a side stream whose encoder is the short one when the
-        branches are ordered longest first): launches that do not depend on the encoders ride there for free."""
+        """side_work: a callable run on the LAST branch's stream (a side stream whose encoder is the short one when the branches
+        are ordered longest first), behind that encoder: launches that do not depend on the encoders ride there for free."""
         names = self._branch_order(inputs)
 
         def run(m):
+            out = self.encoders[m](inputs.data[m])
             if side_work is not None and len(names) > 1 and m == names[-1]:
-                side_work()
-            return self.encoders[m](inputs.data[m])
+                side_work()  # BEHIND the short encoder: its stream also carries the step's weight-pack launch (kernels.pack_scope)
+            return out
 
         enc = kernels.run_branches(names, run, inputs.data[names[0]].device)
         return {m: enc[m] for m in self.encoders.keys()}
