@@ -207,16 +207,8 @@ enum { D16_NLL = 0, D16_BWD = 1 };
 #define D16_NT128_OCC 1  // workgroups per CU of the 128-row tile (its two register sets put it above 256 registers)
 #endif
 
-// 1 / (1 + e^-v) on the 1-ulp transcendental instructions: e^-v = 2^t (1 + tl ln 2) with -v log2(e) = t + tl carried as a
-// two-term product (the rounding of a plain -v * log2(e) alone is a relative error of |v| 2^-24 in the exponential)
-__device__ __forceinline__ float d16_sigmoid(float v) {
-  constexpr float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f, LN2 = 0.693147180559945309f;
-  const float nv = -v, t = nv * L2E_HI;
-  const float tl = fmaf(nv, L2E_HI, -t) + nv * L2E_LO;
-  const float e0 = __builtin_amdgcn_exp2f(fminf(t, 126.f));  // 2^126 (1 + tl ln 2) is finite: sigmoid(-87) = 0 to fp32
-  const float e = fmaf(e0 * LN2, tl, e0);
-  return __builtin_amdgcn_rcpf(1.f + e);
-}
+// (mvk_fast_sigmoid: common.hpp)
+#define d16_sigmoid mvk_fast_sigmoid
 
 struct D16Nt {
   const half_t *Ah, *Al;  // [M][K]

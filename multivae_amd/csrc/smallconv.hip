@@ -311,7 +311,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
 #pragma unroll
       for (int t = 0; t < NO; ++t) {
         const float sum = ((buf[tap[t][0]] + buf[tap[t][1]]) + (buf[tap[t][2]] + buf[tap[t][3]])) + bia[t];
-        const float r = mvk_act(sum, act), dlt = r - xv[t];
+        // (the sigmoid on v_exp_f32 / v_rcp_f32 with a two-term exponent, 9 instructions instead of expf + an IEEE division)
+        const float r = act == MVK_ACT_SIGMOID ? mvk_fast_sigmoid(sum) : mvk_act(sum, act), dlt = r - xv[t];
         part = fmaf(0.5f * inv_s2 * dlt, dlt, part);
         out[tid + t * NT] = dlt * g_inv_s2 * mvk_act_grad_from_out(r, act);
       }

@@ -332,7 +332,29 @@ class LeafStream:
             torch.cuda.current_stream(self.device).wait_stream(self.st)
 
 
-def run_branches(names, fn, device):
+# The decoders' side branches are CREATED before the main one (run_branches(side_first=True)), so that autograd enqueues the main
+# branch's backward first and a side branch's backward can be ordered behind the main branch's HBM-bound tail kernel
+# (tail_bwd_done / wait_tail_bwd).  Two memory-heavy launches that share the chip are slower than the same two in a row:
+# small_up_bwd_bf_kernel took 139 us beside the MLP decoder's backward-data GEMM (95 us), 82 and 32 us alone.  MEASURED (three
+# same-box pairs): 1.087 / 1.080 / 1.095 ms -> 1.040 / 1.055 / 1.050 ms.  MVK_TAIL_FIRST=0: the round-3 order.
+TAIL_FIRST = _lib.tune("MVK_TAIL_FIRST", "1") != "0"
+_TAIL_EVENT = {}
+
+
+def tail_bwd_done(device):
+    """SVHNDecoderFn.backward, right behind its image-layer launch."""
+    if TAIL_FIRST and device in _DEFER_ACTIVE:
+        _TAIL_EVENT[device] = torch.cuda.current_stream(device).record_event()
+
+
+def wait_tail_bwd(device):
+    """A side branch's decoder backward: start behind the main branch's tail kernel when that one was enqueued first."""
+    ev = _TAIL_EVENT.pop(device, None)
+    if ev is not None:
+        torch.cuda.current_stream(device).wait_event(ev)
+
+
+def run_branches(names, fn, device, side_first=False):
     """{m: fn(m)} with every branch but the first on its own stream; joined before returning."""
     names = list(names)
     if not BRANCH_STREAMS or len(names) < 2 or device.type != "cuda":
@@ -343,7 +365,9 @@ def run_branches(names, fn, device):
     # The first branch stays on the caller's stream and is enqueued FIRST: autograd runs backward nodes in reverse
     # creation order, so the side branches' backward is enqueued (and, in a captured graph, ordered) before the long
     # backward of the main branch instead of behind it.
-    outs = {names[0]: fn(names[0])}
+    outs = {}
+    if not (side_first and TAIL_FIRST):
+        outs[names[0]] = fn(names[0])
     sides = []
     for i, m in enumerate(names[1:], start=1):
         st = _side_stream(device, i)
@@ -353,6 +377,8 @@ def run_branches(names, fn, device):
         for t in _tensors_of(outs[m]):
             t.record_stream(main)
         sides.append(st)
+    if names[0] not in outs:
+        outs[names[0]] = fn(names[0])
     for st in sides:
         main.wait_stream(st)
     return {m: outs[m] for m in names}
@@ -1272,6 +1298,7 @@ class MLPDecoderFn(Function):
     @staticmethod
     def _backward_fused(ctx, drows):
         z2, hp, gp, bounds, kn, kn_inv, cs, w0, b0, w1, b1 = ctx.saved_tensors
+        wait_tail_bwd(z2.device)
         n, H, D = z2.shape[0], w0.shape[0], w1.shape[0]
         hb, gb = bounds[0:1], bounds[1:2]
         c = const_grad(drows)
@@ -1284,6 +1311,8 @@ class MLPDecoderFn(Function):
             dh = _new((n, H), z2)
             call("mvk_dense16_bwd_data", ptr(gp[0]), ptr(gp[1]), ptr(gb), ptr(kn[0]), ptr(kn[1]), ptr(kn_inv), ptr(hp[0]), ptr(dh),
                  ptr(tb0), ptr(ws), ws.numel(), n, H, D, stream_ptr())
+            # the gradient of z first (the posterior's backward waits for it), the weight gradients — leaves — behind it
+            dz = linear_bwd_data(dh, w0).view(ctx.z_shape) if ctx.needs_input_grad[0] else None
 
             def wgrad1():
                 wsl = _ws(z2)
@@ -1293,6 +1322,10 @@ class MLPDecoderFn(Function):
             # a leaf: postponed into the tail of the step when its targets are views of the flat gradient buffer
             if dw1 is not None or db1 is not None or not run_last(z2.device, wgrad1, gp, hp, cs, bounds):
                 wgrad1()
+            dw0 = None
+            if not _is_direct(w0) or not run_last(z2.device, lambda: linear_bwd_weight(dh, z2, w0, None), dh, z2):
+                dw0, _ = linear_bwd_weight(dh, z2, w0, None)
+            return dz, dw0, db0, dw1, db1, None, None, None, None
         else:  # general upstream gradient: d pre = G * drows[column tile, row] / nll_weight as an fp32 tensor, then the tiled engine
             wait_loss(z2.device)
             drows = _c(drows).reshape(-1, n)
@@ -1491,6 +1524,7 @@ class SVHNDecoderFn(Function):
                 a_dg3 = ctx.bslots[0]
                 call("mvk_conv4s2_small_up_bwd_pre_y", ptr(out), ptr(drows), ptr(g3), RELU, ptr(w3), ptr(dg3), ptr(tw3), ptr(tb3),
                      ptr(tb2), ptr(ws), ws.numel(), n, 16, 16, C4, C3, ptr(a_dg3), stream_ptr())
+                tail_bwd_done(z2.device)
             else:
                 call("mvk_conv4s2_small_up_bwd_pre", ptr(out), ptr(drows), ptr(g3), RELU, ptr(w3), ptr(dg3), ptr(tw3), ptr(tb3),
                      ptr(tb2), ptr(ws), ws.numel(), n, 16, 16, C4, C3, stream_ptr())

@@ -232,7 +232,7 @@ class MoPoE(BaseMultiVAE):
                     return ("rows", rows)
             return ("rec", dec(z_of(m)).reconstruction)
 
-        rec = kernels.run_branches(self._branch_order(inputs), decode, device)
+        rec = kernels.run_branches(self._branch_order(inputs), decode, device, side_first=True)
         plain = [m for m in names if rec[m][0] == "rec"]
         fused = [m for m in names if rec[m][0] == "rows"]
         recons = [rec[m][1] for m in plain]
