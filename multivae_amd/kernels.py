@@ -354,6 +354,37 @@ def wait_tail_bwd(device):
         torch.cuda.current_stream(device).wait_event(ev)
 
 
+# A side branch's forward LAUNCHES may be postponed behind a point of the main branch's forward (its node is created first all the
+# same): the MLP decoder's GEMMs read ~200 MB through L2 / the fabric and slow the 128 <-> 64-channel convolution of the SVHN
+# decoder (4 workgroup types, 2-2.5x fabric traffic of its own) far more than its 64 <-> 32-channel one.  MEASURED (three same-box
+# pairs): 1.060 / 1.034 / 1.048 ms postponed behind the first convolution vs 1.047 / 1.051 / 1.042 ms launched where the node is
+# created — no difference in the forward pass; MVK_FWD_DEFER=1 enables it.
+FWD_DEFER = _lib.tune("MVK_FWD_DEFER", "0") == "1"
+_FWD_DEFERRED = {}  # device -> [(stream, closure)], only while run_branches(side_first=True) builds the side branches
+_FWD_DEFER_OPEN = set()
+
+
+def defer_forward(device, fn):
+    """Inside a side branch of run_branches(side_first=True): queue fn (launches only: every tensor is allocated already) until
+    the main branch calls flush_deferred_forward, or the branches are joined.  False: the caller launches now."""
+    if not FWD_DEFER or device not in _FWD_DEFER_OPEN or TAPS is not None:
+        return False
+    _FWD_DEFERRED.setdefault(device, []).append((torch.cuda.current_stream(device), fn))
+    return True
+
+
+def flush_deferred_forward(device):
+    """Main branch: the postponed side launches may start behind what this stream holds now."""
+    todo = _FWD_DEFERRED.pop(device, None)
+    if not todo:
+        return
+    ev = torch.cuda.current_stream(device).record_event()
+    for st, fn in todo:
+        st.wait_event(ev)
+        with torch.cuda.stream(st):
+            fn()
+
+
 def run_branches(names, fn, device, side_first=False):
     """{m: fn(m)} with every branch but the first on its own stream; joined before returning."""
     names = list(names)
@@ -368,6 +399,8 @@ def run_branches(names, fn, device, side_first=False):
     outs = {}
     if not (side_first and TAIL_FIRST):
         outs[names[0]] = fn(names[0])
+    else:
+        _FWD_DEFER_OPEN.add(device)
     sides = []
     for i, m in enumerate(names[1:], start=1):
         st = _side_stream(device, i)
@@ -378,7 +411,11 @@ def run_branches(names, fn, device, side_first=False):
             t.record_stream(main)
         sides.append(st)
     if names[0] not in outs:
-        outs[names[0]] = fn(names[0])
+        _FWD_DEFER_OPEN.discard(device)  # the main branch itself never defers
+        try:
+            outs[names[0]] = fn(names[0])
+        finally:
+            flush_deferred_forward(device)  # nobody asked for them earlier: now
     for st in sides:
         main.wait_stream(st)
     return {m: outs[m] for m in names}
@@ -1247,19 +1284,24 @@ class MLPDecoderFn(Function):
             nk, nk_inv, kn, kn_inv = dense16_pack(w1)  # both usually done already: Decoder_AE_MLP.early_work
             xam = dense16_xamax(nll_x)
             zam = _amax_slots(z2, 1)
-            call("mvk_amax", ptr(z2), z2.numel(), ptr(zam), stream_ptr())
             hp = _planes(n, H, z2)
             gp = _planes(n, D, z2)
             bounds = _new((2,), z2)  # [bound of h, bound of G]
-            call("mvk_dense16_first", ptr(z2), ptr(w0), ptr(b0), ptr(zam), ptr(hp[1]), ptr(hp[2]), ptr(bounds[0:1]), n, H, L, RELU,
-                 stream_ptr())
             lib = _lib.load()
             P, CR = lib.mvk_dense16_fwd_nll_rows(D), lib.mvk_dense16_colsum_rows(n)
             rows = _new((P, n), z2)
             cs = _new((CR, D), z2)
-            call("mvk_dense16_fwd_nll", ptr(hp[1]), ptr(hp[2]), ptr(bounds[0:1]), ptr(nk[1]), ptr(nk[2]), ptr(nk_inv), ptr(b1),
-                 ptr(nll_x), nll_x.shape[0], ptr(xam), float(nll_scale), float(nll_weight), ptr(gp[1]), ptr(gp[2]),
-                 ptr(bounds[1:2]), ptr(rows), ptr(cs), n, D, H, stream_ptr())
+
+            def launch():  # the three launches of the forward pass (possibly postponed: defer_forward)
+                call("mvk_amax", ptr(z2), z2.numel(), ptr(zam), stream_ptr())
+                call("mvk_dense16_first", ptr(z2), ptr(w0), ptr(b0), ptr(zam), ptr(hp[1]), ptr(hp[2]), ptr(bounds[0:1]), n, H, L,
+                     RELU, stream_ptr())
+                call("mvk_dense16_fwd_nll", ptr(hp[1]), ptr(hp[2]), ptr(bounds[0:1]), ptr(nk[1]), ptr(nk[2]), ptr(nk_inv), ptr(b1),
+                     ptr(nll_x), nll_x.shape[0], ptr(xam), float(nll_scale), float(nll_weight), ptr(gp[1]), ptr(gp[2]),
+                     ptr(bounds[1:2]), ptr(rows), ptr(cs), n, D, H, stream_ptr())
+
+            if not defer_forward(z2.device, launch):
+                launch()
             ctx.save_for_backward(z2, hp[0], gp[0], bounds, kn[0], kn_inv, cs, w0, b0, w1, b1)
             ctx.nll_weight = float(nll_weight)
             if TAPS is not None:  # tests: the hidden activation as an fp32 tensor (the sign of h is the sign of its hi plane)
@@ -1469,6 +1511,7 @@ class SVHNDecoderFn(Function):
                 g1 = gemm(z2, wp0, n, 16 * C1, L, bias=b0, bias_mod=C1, act=RELU)
                 amax_of(g1, a1)
             g2 = conv_up(g1, wu1, b1, n, 4, 4, C2, C1, RELU, amax=(a1, wu1.mvk_amax, a2))  # [n,8,8,C2]
+            flush_deferred_forward(z2.device)  # a side branch's postponed launches: beside the 64 -> 32 layer, not the 128 -> 64 one
             g3 = conv_up(g2, wu2, b2, n, 8, 8, C3, C2, RELU, amax=(a2, wu2.mvk_amax, None))  # [n,16,16,C3]
             ctx.wamax = (wd1.mvk_amax, wd2.mvk_amax)
             ctx.gamax = (a1, a2)  # bounds of g1, g2: the V operands of the two weight gradients
