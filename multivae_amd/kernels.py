@@ -134,12 +134,18 @@ _LATE_CALLS = {}  # device -> closures run on the late-leaf stream when deferred
 LATE_DENSE = _lib.tune("MVK_LATE_DENSE", "0") == "1"
 
 
-def run_last(device, fn, *reads):
+# Only the first layer's weight gradient (a split-K launch of 16 us alone, 50-60 us beside the convolutions) is postponed: autograd
+# orders the posterior's backward behind EVERYTHING the decoder's backward node enqueued on its stream, leaves included.
+# MEASURED (three same-box pairs): 1.046 / 1.050 / 1.039 -> 1.042 / 1.040 / 1.032 ms.  MVK_LATE_DW0=0: inside the node.
+LATE_DW0 = _lib.tune("MVK_LATE_DW0", "1") != "0"
+
+
+def run_last(device, fn, *reads, force=False):
     """Inside deferred_reductions: run fn() on the late-leaf stream AFTER everything else the backward pass puts there (the
     enqueue itself is postponed to the end of the scope), i.e. in the launch-latency-bound tail of the step where the chip is
     mostly idle, instead of beside the decoders' backward-data chains whose window is throughput-bound.  Returns False when
     there is no such scope (the caller runs fn itself)."""
-    if not (LATE_LEAVES and LATE_DENSE) or device.type != "cuda" or device not in _DEFER_ACTIVE:
+    if not (LATE_LEAVES and (LATE_DENSE or force)) or device.type != "cuda" or device not in _DEFER_ACTIVE:
         return False
     _LATE_CALLS.setdefault(device, []).append((fn, reads))
     return True
@@ -1365,7 +1371,7 @@ class MLPDecoderFn(Function):
             if dw1 is not None or db1 is not None or not run_last(z2.device, wgrad1, gp, hp, cs, bounds):
                 wgrad1()
             dw0 = None
-            if not _is_direct(w0) or not run_last(z2.device, lambda: linear_bwd_weight(dh, z2, w0, None), dh, z2):
+            if not _is_direct(w0) or not run_last(z2.device, lambda: linear_bwd_weight(dh, z2, w0, None), dh, z2, force=LATE_DW0):
                 dw0, _ = linear_bwd_weight(dh, z2, w0, None)
             return dz, dw0, db0, dw1, db1, None, None, None, None
         else:  # general upstream gradient: d pre = G * drows[column tile, row] / nll_weight as an fp32 tensor, then the tiled engine
