@@ -57,6 +57,72 @@ __device__ __forceinline__ void f16_split(float x, float y, unsigned& hi, unsign
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{rx, ry}, f16x2));
 }
 
+// The same split from UNSCALED values and a power-of-two scale, on the mixed-precision FMA instructions: v_fma_mixlo/hi_f16
+// round x s straight into one half of a register (x s is exact, so this is the fp16 the two-step conversion gives),
+// v_fma_mix_f32 reads that half back for the residual, and the 2^11 of the low piece rides on the third pair: 3 instructions
+// per element instead of 4 (scale, half a packed conversion, residual, 2^11, half a packed conversion) — bit-identical pieces.
+// The staging of the register-stationary kernels runs this 8-16 times per thread and tile in a loop whose budget is ~7 issue
+// slots per MFMA (one wave per SIMD).  _su: the scale (and the 2^11) in scalar registers; _sv: a per-lane scale.
+__device__ __forceinline__ void f16_split_su(float x, float y, float s, unsigned& hi, unsigned& lo) {
+#ifndef MVK_MIX
+  return f16_split(x * s, y * s, hi, lo);
+#endif
+  unsigned h, l;
+  float rx, ry;
+  const float k = 2048.f;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x), "s"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(y), "s"(s));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(rx) : "v"(x), "s"(s), "v"(h));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(ry) : "v"(y), "s"(s), "v"(h));
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(l) : "v"(rx), "s"(k));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(l) : "v"(ry), "s"(k));
+  hi = h;
+  lo = l;
+}
+__device__ __forceinline__ void f16_split_sv(float x, float y, float sx, float sy, unsigned& hi, unsigned& lo) {
+#ifndef MVK_MIX
+  return f16_split(x * sx, y * sy, hi, lo);
+#endif
+  unsigned h, l;
+  float rx, ry;
+  const float k = 2048.f;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x), "v"(sx));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(y), "v"(sy));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(rx) : "v"(x), "v"(sx), "v"(h));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(ry) : "v"(y), "v"(sy), "v"(h));
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(l) : "v"(rx), "s"(k));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(l) : "v"(ry), "s"(k));
+  hi = h;
+  lo = l;
+}
+
+// the three planes of a weight gradient's dY operand (h = fp16(y s), H = fp16(y s 2^11), l = fp16(y s 2^11 - H)) the same way:
+// 3 instructions per element instead of 4, bit-identical (y s and y s 2^11 are exact products)
+__device__ __forceinline__ void f16_split3_su(float x, float y, float s, float s11, unsigned& h, unsigned& H, unsigned& l) {
+#ifndef MVK_MIX
+  {
+    const f16x2 hh = __builtin_convertvector(f32x2{x * s, y * s}, f16x2);
+    const float q0 = x * s11, q1 = y * s11;
+    const f16x2 HH = __builtin_convertvector(f32x2{q0, q1}, f16x2);
+    const f16x2 ll = __builtin_convertvector(f32x2{q0 - (float)HH[0], q1 - (float)HH[1]}, f16x2);
+    h = __builtin_bit_cast(unsigned, hh);
+    H = __builtin_bit_cast(unsigned, HH);
+    l = __builtin_bit_cast(unsigned, ll);
+    return;
+  }
+#endif
+  unsigned a, b, c;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(a) : "v"(x), "s"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(a) : "v"(y), "s"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(b) : "v"(x), "s"(s11));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(b) : "v"(y), "s"(s11));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(c) : "v"(x), "s"(s11), "v"(b));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(c) : "v"(y), "s"(s11), "v"(b));
+  h = a;
+  H = b;
+  l = c;
+}
+
 // workgroup-wide maximum of a non-negative value (wave shuffles, then `red[waves]` in LDS), then ONE atomic per workgroup: the
 // bit patterns of non-negative floats order like unsigned integers (+inf above every finite value); *dst must hold 0 (or a
 // bound to keep) before the launch.  Atomics on one address serialise at ~10 ns each: one per wave of a 2048-workgroup launch

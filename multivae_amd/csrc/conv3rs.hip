@@ -28,6 +28,12 @@
 
 #include "bf3.hpp"
 
+#ifdef MVK_NO_RFL
+#define MVK_RFL(x) (x)
+#else
+#define MVK_RFL(x) __builtin_amdgcn_readfirstlane(x)
+#endif
+
 #ifndef MVK_C3_SCHED
 #define MVK_C3_SCHED 4  // "others" per MFMA of the scheduling pipeline (0 = hipcc's own order)
 #endif
@@ -172,7 +178,8 @@ __device__ __forceinline__ void c3rs_body(const C3Args& g) {
   const int H = g.H, W = g.W, W1 = W + 1, H1 = H + 1, PB = W1 * H1;
   const int dx32 = 32 % W1, dv32 = 32 / W1;
   const int D = g.D;
-  const int T0 = (int)((long long)g.tiles * worker / workers), T1 = (int)((long long)g.tiles * (worker + 1) / workers);
+  const int T0 = MVK_RFL((int)((long long)g.tiles * worker / workers));  // uniform trip count (see imgconv.hip)
+  const int T1 = MVK_RFL((int)((long long)g.tiles * (worker + 1) / workers));
   const int NT = T1 - T0;
 
   // pixel-index table: entry [c & 15][l] = pixel index of position 32 c + l, or -1 (zero column / zero row / outside)
@@ -241,11 +248,9 @@ __device__ __forceinline__ void c3rs_body(const C3Args& g) {
       *reinterpret_cast<u32x2*>(d + 2 * CIN) = u32x2{a1, b1};
       *reinterpret_cast<u32x2*>(d + 4 * CIN) = u32x2{a2, b2};
     } else {  // the operand scale rides on the activation's two slopes
-      const float r0 = v[0] * (v[0] > 0.f ? sx : sxn), r1 = v[1] * (v[1] > 0.f ? sx : sxn);
-      const float r2 = v[2] * (v[2] > 0.f ? sx : sxn), r3 = v[3] * (v[3] > 0.f ? sx : sxn);
       unsigned a0, a1, b0, b1;
-      f16_split(r0, r1, a0, a1);
-      f16_split(r2, r3, b0, b1);
+      f16_split_sv(v[0], v[1], v[0] > 0.f ? sx : sxn, v[1] > 0.f ? sx : sxn, a0, a1);
+      f16_split_sv(v[2], v[3], v[2] > 0.f ? sx : sxn, v[3] > 0.f ? sx : sxn, b0, b1);
       *reinterpret_cast<u32x2*>(d) = u32x2{a0, b0};
       *reinterpret_cast<u32x2*>(d + 2 * CIN) = u32x2{a1, b1};
     }
@@ -729,7 +734,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int H = g.H, W = g.W, W1 = W + 1, H1 = H + 1, PB = W1 * H1;
   const int dx32 = 32 % W1, dv32 = 32 / W1;
   const int D = g.D;
-  const int T0 = (int)((long long)g.tiles * worker / workers), T1 = (int)((long long)g.tiles * (worker + 1) / workers);
+  const int T0 = MVK_RFL((int)((long long)g.tiles * worker / workers));  // uniform trip count (see imgconv.hip)
+  const int T1 = MVK_RFL((int)((long long)g.tiles * (worker + 1) / workers));
   const int NT = T1 - T0;
 
   int pimg, pv, px;
@@ -804,24 +810,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       *reinterpret_cast<u32x2*>(d + 128) = u32x2{a1, b1};
       *reinterpret_cast<u32x2*>(d + 256) = u32x2{a2, b2};
     } else if (k < 2) {  // X: (xh, xl), the scale on the activation's two slopes
-      r0 *= r0 > 0.f ? sx : sxn;
-      r1 *= r1 > 0.f ? sx : sxn;
-      r2 *= r2 > 0.f ? sx : sxn;
-      r3 *= r3 > 0.f ? sx : sxn;
       unsigned a0, a1, b0, b1;
-      f16_split(r0, r1, a0, a1);
-      f16_split(r2, r3, b0, b1);
+      f16_split_sv(r0, r1, r0 > 0.f ? sx : sxn, r1 > 0.f ? sx : sxn, a0, a1);
+      f16_split_sv(r2, r3, r2 > 0.f ? sx : sxn, r3 > 0.f ? sx : sxn, b0, b1);
       *reinterpret_cast<u32x2*>(d) = u32x2{a0, b0};
       *reinterpret_cast<u32x2*>(d + 128) = u32x2{a1, b1};
     } else {  // dY: planes (yh, yH, yl)
-      const f16x2 h01 = __builtin_convertvector(f32x2{r0 * sy, r1 * sy}, f16x2), h23 = __builtin_convertvector(f32x2{r2 * sy, r3 * sy}, f16x2);
-      const float q0 = r0 * sy11, q1 = r1 * sy11, q2 = r2 * sy11, q3 = r3 * sy11;
-      const f16x2 H01 = __builtin_convertvector(f32x2{q0, q1}, f16x2), H23 = __builtin_convertvector(f32x2{q2, q3}, f16x2);
-      const f16x2 l01 = __builtin_convertvector(f32x2{q0 - (float)H01[0], q1 - (float)H01[1]}, f16x2);
-      const f16x2 l23 = __builtin_convertvector(f32x2{q2 - (float)H23[0], q3 - (float)H23[1]}, f16x2);
-      *reinterpret_cast<u32x2*>(d) = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
-      *reinterpret_cast<u32x2*>(d + 128) = u32x2{__builtin_bit_cast(unsigned, H01), __builtin_bit_cast(unsigned, H23)};
-      *reinterpret_cast<u32x2*>(d + 256) = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+      unsigned h01, H01, l01, h23, H23, l23;
+      f16_split3_su(r0, r1, sy, sy11, h01, H01, l01);
+      f16_split3_su(r2, r3, sy, sy11, h23, H23, l23);
+      *reinterpret_cast<u32x2*>(d) = u32x2{h01, h23};
+      *reinterpret_cast<u32x2*>(d + 128) = u32x2{H01, H23};
+      *reinterpret_cast<u32x2*>(d + 256) = u32x2{l01, l23};
     }
   };
   auto write_unit = [&](char* base, int k, float mine = 1.f) { write_vals(base, k, raw[k], mine); };

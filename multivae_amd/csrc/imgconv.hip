@@ -31,6 +31,15 @@
 
 #include "bf3.hpp"
 
+#ifndef MVK_IC_ABL
+#define MVK_IC_ABL 0  // subtraction builds (tools/ab_probe.sh): 1 = every input load from the worker's first unit (L2-resident), 2 = every store and mask load on the first unit
+#endif
+#ifdef MVK_NO_RFL
+#define MVK_RFL(x) (x)
+#else
+#define MVK_RFL(x) __builtin_amdgcn_readfirstlane(x)
+#endif
+
 #ifndef MVK_IC_SCHED
 #define MVK_IC_SCHED (HS == 8 ? 5 : 4)  // "others" per MFMA of the scheduling pipeline in imgconv_kernel (0 = hipcc's own order)
 #endif
@@ -133,8 +142,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, kg = lane >> 5;
-  const int wgtype = blockIdx.x % T::WG_TYPES;
-  const int worker = blockIdx.x / T::WG_TYPES, workers = gridDim.x / T::WG_TYPES;
+  // Workgroup types of one worker read the SAME images (each holds another slice of the weights).  Block b runs on XCD b % 8
+  // (observed placement; a speed choice only), and every XCD has its own L2: with type = b % WG_TYPES the four readers of an
+  // image sat on four XCDs and the input crossed the fabric 2.0-2.5 times (profiles/r04_pmc_hbm.md) in launches that move
+  // 250-420 MB in 60-80 us, i.e. run at the HBM rate.  Types of a worker on ONE XCD: slot = b / 8 on XCD b % 8, type = slot %
+  // WG_TYPES, so the four workgroups stream the same lines through one L2 at the same time.  Same unit ranges per worker.
+  int wgtype = blockIdx.x % T::WG_TYPES;
+  int worker = blockIdx.x / T::WG_TYPES;
+  const int workers = gridDim.x / T::WG_TYPES;
+#ifndef MVK_NO_XCDMAP
+  if (T::WG_TYPES > 1 && gridDim.x % (8 * T::WG_TYPES) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    wgtype = slot % T::WG_TYPES;
+    worker = xcd * (gridDim.x / (8 * T::WG_TYPES)) + slot / T::WG_TYPES;
+  }
+#endif
 
   // ---- role of this wave ----------------------------------------------------------------------------------
   int cls = 0, ct = 0, ks = 0;
@@ -256,11 +278,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   float csum = 0.f, amax_l = 0.f;
 
   const long long units = g.n / T::SU;
-  const long long u0 = units * worker / workers, u1 = units * (worker + 1) / workers;
+  // readfirstlane: the 64-bit division is emitted on the vector ALU, which makes the trip count of the unit loop 'divergent'
+  // for hipcc (exec-masked loop, every live-out accumulator read back per iteration: 32 v_accvgpr_read + a drain of the matrix pipe per tile)
+  const long long u0 = MVK_RFL((int)(units * worker / workers));
+  const long long u1 = MVK_RFL((int)(units * (worker + 1) / workers));
 
   f32x4 raw[T::NF4];
   auto unit_src = [&](long long u) {  // clamped: the tail re-reads the last unit instead of branching
-    const long long uc = u < u1 ? u : u1 - 1;
+    const long long uc = (MVK_IC_ABL & 1) ? u0 : (u < u1 ? u : u1 - 1);
     return reinterpret_cast<const f32x4*>(g.A + uc * IN_UNIT) + tid;
   };
   auto write_f4 = [&](char* buf, int k) {
@@ -273,8 +298,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       *reinterpret_cast<u32x2*>(buf + 2 * T::PLANE + soff[k]) = u32x2{a2, b2};
     } else {
       unsigned a0, a1, b0, b1;
-      f16_split(raw[k][0] * sx, raw[k][1] * sx, a0, a1);
-      f16_split(raw[k][2] * sx, raw[k][3] * sx, b0, b1);
+      f16_split_su(raw[k][0], raw[k][1], sx, a0, a1);
+      f16_split_su(raw[k][2], raw[k][3], sx, b0, b1);
       *reinterpret_cast<u32x2*>(buf + soff[k]) = u32x2{a0, b0};
       *reinterpret_cast<u32x2*>(buf + T::PLANE + soff[k]) = u32x2{a1, b1};
     }
@@ -319,8 +344,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     csum = fmaf(v, validf, csum);
     amax_l = fmaxf(amax_l, fabsf(v) * validf);
   };
-  frag a_cur[2][NP];
-  if (u0 < u1) read_pair(a_cur, lds, 0, 0);
+  // A fragments are read ahead of their MFMAs: one pair of k-steps in the bf16 form (12 MFMAs = 384 matrix-pipe cycles cover a
+  // ds_read_b128 under load), TWO pairs in the fp16 form, whose pair is 6 MFMAs = 192 cycles — less than the latency of an LDS
+  // read when the four waves of the workgroup issue their reads together (the LDS array is busy 8 cycles per b128 wave read,
+  // 16 reads per pair).  Subtraction builds (MVK_IC_ABL: all loads and stores on one L2-resident unit) run at 0.9 of the full
+  // kernel's time: the loop waits on neither HBM nor the instruction count (r04: -10 % instructions, same time).
+#ifndef MVK_IC_DEPTH2
+#define MVK_IC_DEPTH2 0  // measured: no gain alone (65-80 us either way), +3 % on the step
+#endif
+  constexpr bool D2 = NP == 2 && PIPE && MVK_IC_DEPTH2;
+  frag a_cur[2][NP], a_n1[2][NP];
+  if (u0 < u1) {
+    read_pair(a_cur, lds, 0, 0);
+    if (D2) read_pair(a_n1, lds, 0, 1);
+  }
   if constexpr (PIPE) {
     // ---- main loop, two-tile latency (default) --------------------------------------------------------------------
     // With one barrier at the END of every tile the waves spend a third of their cycles between k-loops (measured with
@@ -390,8 +427,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const char* const abuf = lds + cur * T::BUF;
       char* const nbuf = lds + (cur ^ 1) * T::BUF;
       const f32x4* const src2 = unit_src(u + 2);
-      float* const outp_cur = g.out + u * OUT_UNIT;
-      const float* const srcp_cur = HAS_SRC ? g.act_src + u * OUT_UNIT : nullptr;
+      float* const outp_cur = g.out + ((MVK_IC_ABL & 2) ? u0 + 2 : u) * OUT_UNIT;
+      const float* const srcp_cur = HAS_SRC ? g.act_src + ((MVK_IC_ABL & 2) ? u0 + 2 : u) * OUT_UNIT : nullptr;
 #pragma unroll
       for (int tt = 0; tt < T::TPU; ++tt) {
         const int ptt1 = (tt + T::TPU - 1) % T::TPU;          // tile-in-unit index of tile T-1
@@ -412,8 +449,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 #pragma unroll
         for (int pr = 0; pr < 8; ++pr) {
-          frag a_nxt[2][NP];
-          if (pr < 7) read_pair(a_nxt, abuf, tt, pr + 1);
+          frag a_nxt[2][NP];  // depth 1: pair pr + 1; depth 2: pair pr + 2 (a_n1 holds pair pr + 1)
+          if (D2) {
+            if (pr < 6) read_pair(a_nxt, abuf, tt, pr + 2);
+          } else if (pr < 7) {
+            read_pair(a_nxt, abuf, tt, pr + 1);
+          }
           if (pr == 0) finish_pending(xb);
           if (tt == 0 && pr < 7) {  // conversion of the next unit: complete before the barrier behind pair 6
             if (T::NF4 >= 8) {
@@ -452,13 +493,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1][1], Bw[q1][c1][0], acc1, 0, 0, 0);
           }
           if (pr == 7) {  // behind the barrier: first fragments of the next tile, result of tile T-1
-            read_pair(a_nxt, next_buf, ntt, 0);
+            if (D2) {
+              read_pair(a_n1, next_buf, ntt, 0);
+              read_pair(a_nxt, next_buf, ntt, 1);
+            } else {
+              read_pair(a_nxt, next_buf, ntt, 0);
+            }
             gather_result(xb);
           }
 #pragma unroll
           for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int pc = 0; pc < NP; ++pc) a_cur[h][pc] = a_nxt[h][pc];
+            for (int pc = 0; pc < NP; ++pc) {
+              if (D2) {
+                a_cur[h][pc] = a_n1[h][pc];
+                if (pr != 6) a_n1[h][pc] = a_nxt[h][pc];  // pair 6 reads nothing (pair 8 is the next tile's, behind the barrier)
+              } else {
+                a_cur[h][pc] = a_nxt[h][pc];
+              }
+            }
           if (MVK_IC_SCHED > 0) {  // "1 MFMA, N others" (see the one-tile-latency loop)
 #pragma unroll
             for (int m = 0; m < 4 * NP; ++m) {
@@ -706,7 +759,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int wct = KIND == IC_UP ? (wgtype * 4 + w) % T::NCT : w % T::NCT;
         if (wct == c_t) s += csred[w * 32 + c_l];
       }
-      g.colsum_part[(long long)blockIdx.x * COUT + tid] = s;
+      g.colsum_part[(long long)(worker * T::WG_TYPES + wgtype) * COUT + tid] = s;  // row = (worker, type), whatever block ran it
     }
   }
 #ifdef MVK_ICPROF
@@ -859,8 +912,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   extern __shared__ __attribute__((aligned(16))) char lds[];
   mvk_prof_begin(g.prof);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wgtype = blockIdx.x % T::WG_TYPES;
-  const int worker = blockIdx.x / T::WG_TYPES, workers = gridDim.x / T::WG_TYPES;
+  // Workgroup types of one worker read the SAME images (each holds another slice of the weights).  Block b runs on XCD b % 8
+  // (observed placement; a speed choice only), and every XCD has its own L2: with type = b % WG_TYPES the four readers of an
+  // image sat on four XCDs and the input crossed the fabric 2.0-2.5 times (profiles/r04_pmc_hbm.md) in launches that move
+  // 250-420 MB in 60-80 us, i.e. run at the HBM rate.  Types of a worker on ONE XCD: slot = b / 8 on XCD b % 8, type = slot %
+  // WG_TYPES, so the four workgroups stream the same lines through one L2 at the same time.  Same unit ranges per worker.
+  int wgtype = blockIdx.x % T::WG_TYPES;
+  int worker = blockIdx.x / T::WG_TYPES;
+  const int workers = gridDim.x / T::WG_TYPES;
+#ifndef MVK_NO_XCDMAP
+  if (T::WG_TYPES > 1 && gridDim.x % (8 * T::WG_TYPES) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    wgtype = slot % T::WG_TYPES;
+    worker = xcd * (gridDim.x / (8 * T::WG_TYPES)) + slot / T::WG_TYPES;
+  }
+#endif
   const int kh = T::SPLIT_KH ? wgtype : wave;
 
   // zero rows of the U planes of both buffers
@@ -916,10 +982,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr long long U_UNIT = (long long)T::SU * 4 * T::PIX * CU / 4, V_UNIT = (long long)T::SU * T::PIX * CV / 4;  // float4s
 
   const long long units = g.n / T::SU;
-  const long long u0 = units * worker / workers, u1 = units * (worker + 1) / workers;
+  // readfirstlane: the 64-bit division is emitted on the vector ALU, which makes the trip count of the unit loop 'divergent'
+  // for hipcc (exec-masked loop, every live-out accumulator read back per iteration: 32 v_accvgpr_read + a drain of the matrix pipe per tile)
+  const long long u0 = MVK_RFL((int)(units * worker / workers));
+  const long long u1 = MVK_RFL((int)(units * (worker + 1) / workers));
   f32x4 raw[T::NF];
   auto load_f4 = [&](long long u, int k) {
-    const long long uc = u < u1 ? u : u1 - 1;
+    const long long uc = (MVK_IC_ABL & 1) ? u0 : (u < u1 ? u : u1 - 1);
     const f32x4* base = k < T::NFU ? reinterpret_cast<const f32x4*>(g.U) + uc * U_UNIT
                                    : reinterpret_cast<const f32x4*>(g.V) + uc * V_UNIT;
     raw[k] = base[ssrc[k]];
@@ -935,20 +1004,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       *reinterpret_cast<u32x2*>(buf + 2 * pl + sdst[k]) = u32x2{a2, b2};
     } else if (k < T::NFU) {  // U: (uh, ul)
       unsigned a0, a1, b0, b1;
-      f16_split(raw[k][0] * su, raw[k][1] * su, a0, a1);
-      f16_split(raw[k][2] * su, raw[k][3] * su, b0, b1);
+      f16_split_su(raw[k][0], raw[k][1], su, a0, a1);
+      f16_split_su(raw[k][2], raw[k][3], su, b0, b1);
       *reinterpret_cast<u32x2*>(buf + sdst[k]) = u32x2{a0, b0};
       *reinterpret_cast<u32x2*>(buf + pl + sdst[k]) = u32x2{a1, b1};
     } else {  // V: planes (vh, vH = fp16(v sv 2^11), vl = fp16(v sv 2^11 - vH))
-      const f32x4 r = raw[k];
-      const f16x2 h01 = __builtin_convertvector(f32x2{r[0] * sv, r[1] * sv}, f16x2), h23 = __builtin_convertvector(f32x2{r[2] * sv, r[3] * sv}, f16x2);
-      const float q0 = r[0] * sv11, q1 = r[1] * sv11, q2 = r[2] * sv11, q3 = r[3] * sv11;
-      const f16x2 H01 = __builtin_convertvector(f32x2{q0, q1}, f16x2), H23 = __builtin_convertvector(f32x2{q2, q3}, f16x2);
-      const f16x2 l01 = __builtin_convertvector(f32x2{q0 - (float)H01[0], q1 - (float)H01[1]}, f16x2);
-      const f16x2 l23 = __builtin_convertvector(f32x2{q2 - (float)H23[0], q3 - (float)H23[1]}, f16x2);
-      *reinterpret_cast<u32x2*>(buf + sdst[k]) = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
-      *reinterpret_cast<u32x2*>(buf + pl + sdst[k]) = u32x2{__builtin_bit_cast(unsigned, H01), __builtin_bit_cast(unsigned, H23)};
-      *reinterpret_cast<u32x2*>(buf + 2 * pl + sdst[k]) = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+      unsigned h01, H01, l01, h23, H23, l23;
+      f16_split3_su(raw[k][0], raw[k][1], sv, sv11, h01, H01, l01);
+      f16_split3_su(raw[k][2], raw[k][3], sv, sv11, h23, H23, l23);
+      *reinterpret_cast<u32x2*>(buf + sdst[k]) = u32x2{h01, h23};
+      *reinterpret_cast<u32x2*>(buf + pl + sdst[k]) = u32x2{H01, H23};
+      *reinterpret_cast<u32x2*>(buf + 2 * pl + sdst[k]) = u32x2{l01, l23};
     }
   };
 

@@ -48,3 +48,7 @@ for h, Cu, Cv in [(8, 32, 64), (4, 64, 128)]:
         t2 = t_us(lambda: fn((xam, wp.mvk_amax, y)))
         t3y = t_us(lambda: fn((None, None, y)))
         print(f"| {Cu}<->{Cv} @{2 * h}<->{h} | {name} | {t3:.0f} | {t2:.0f} | {t3y:.0f} |")
+    K.DIRECT_GRAD = False
+    t3 = t_us(lambda: K.conv_wgrad(Ud, Vd, Wc, n, h, h, Cu, Cv))
+    t2 = t_us(lambda: K.conv_wgrad(Ud, Vd, Wc, n, h, h, Cu, Cv, amax=(uam, vam)))
+    print(f"| {Cu}<->{Cv} @{2 * h}<->{h} | weight gradient | {t3:.0f} | {t2:.0f} | |")
