@@ -313,7 +313,7 @@ def measured_copy_gbs(device, mb=512, reps=20):
     return 2.0 * 4 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def measured_mfma_tflops(device, target_us, random_operands=True):
+def measured_mfma_tflops(device, target_us, random_operands=True, f16=False):
     """bf16 MFMA rate (TFLOP/s) a register-only loop sustains in launches of about `target_us` (mvk_probe_mfma_bf16: the pipe is
     100 % busy; what varies is the clock the chip holds under that load) — the measured ceiling beside the data-sheet one."""
     from multivae_amd import _lib
@@ -326,7 +326,7 @@ def measured_mfma_tflops(device, target_us, random_operands=True):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            _lib.call("mvk_probe_mfma_bf16", _lib.ptr(out), iters, 1 if random_operands else 0, _lib.stream_ptr())
+            _lib.call("mvk_probe_mfma_bf16", _lib.ptr(out), iters, (2 if f16 else 1) if random_operands else 0, _lib.stream_ptr())
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / reps
@@ -635,6 +635,9 @@ def main():
             # encoder launches at n = B, 1/10 of the FLOPs, still use bf16 pieces)
             prods = 3 if ((conv3 and kernels.C3_F16) or (not conv3 and kernels.IMG_F16)) else 6
             KPEAK = MFMA_BF16_TFLOPS / prods
+            if prods == 3:  # the instruction the named kernels issue: the same loop on v_mfma_f32_32x32x16_f16
+                h_tf, h_us = measured_mfma_tflops(device, 1e6 * conv["seconds"] / conv["launches"], f16=True)
+                mf.update({"measured_sustained_f16": round(h_tf, 1), "frac_vs_measured_sustained_f16": round(ach / (h_tf / prods), 4)})
             mf.update({"kernel_mfmas_per_fp32_product": prods, "kernel_peak": round(KPEAK, 1),
                        "measured_sustained_bf16": round(m_tf, 1), "measured_sustained_fp32_equiv": round(m_tf / prods, 1),
                        "measured_launch_us": round(m_us, 1),

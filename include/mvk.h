@@ -476,7 +476,7 @@ int mvk_upsample2_bwd(const float* dy, float* dx, int n, int H, int W, int C, vo
 int mvk_axpby(const float* x, float a, const float* y, float b, int64_t n, int act, float* out, void* stream);
 /* Measurement aid of bench.py (not on the training path): one launch of a register-only loop of v_mfma_f32_32x32x16_bf16 — 256
  * workgroups, one wave per SIMD, 4 accumulator chains, 64 * iters MFMAs per chain — with hashed operand values (random_operands = 1)
- * or constants (0).  Timed by the caller, it gives the matrix-pipe rate the chip SUSTAINS for a launch of that length; with
+ * constants (0), or hashed fp16 values on v_mfma_f32_32x32x16_f16 (2: the scaled-fp16 kernels' instruction).  Timed by the caller, it gives the matrix-pipe rate the chip SUSTAINS for a launch of that length; with
  * realistic operands that is 1.4-1.9 PFLOP/s, not the 2.5 of the data sheet (power-limited clock).  out: >= 65536 floats. */
 int mvk_probe_mfma_bf16(float* out, int iters, int random_operands, void* stream);
 /* y[b][c][r] = act(x[b][r][c]) * dact'(msrc[b][r][c]) (msrc may be NULL; the derivative is taken through the OUTPUT of dact,
@@ -536,6 +536,16 @@ int mvk_conv4s2_small_up_bwd_pre(const float* dpre, const float* rowscale, const
 int mvk_conv4s2_small_up_fwd_nll_w(const float* V, const float* Wref, const float* bias, const float* X, int xrows, float scale,
                                    float grad_weight, float* dpre, float* rows, int n, int h, int w, int Cu, int Cv, int act,
                                    void* stream);
+/* The image-producing layer (plain and fused-tail form) on scaled fp16 pairs: v_amax = device scalar bounding max |V|, published by
+ * the launch that produced V (amax protocol above); the weight scale is derived in the kernel.  3 MFMAs per product, the weights as
+ * the A operand (one 16-byte column-matrix write per tile), the fast sigmoid.  Same reference layer (models/nn/svhn.py:59-60
+ * ConvTranspose2d(32, 3, 4, 2, 1) + Sigmoid) and likelihood (models/base/base_utils.py:62-87) as the entry points above; only
+ * where mvk_conv4s2_small_up_nll_supported returns 1. */
+int mvk_conv4s2_small_up_fwd_s(const float* V, const float* Wref, const float* bias, float* U, int n, int h, int w, int Cu, int Cv,
+                               int act, const float* v_amax, void* stream);
+int mvk_conv4s2_small_up_fwd_nll_s(const float* V, const float* Wref, const float* bias, const float* X, int xrows, float scale,
+                                   float grad_weight, float* dpre, float* rows, int n, int h, int w, int Cu, int Cv, int act,
+                                   const float* v_amax, void* stream);
 
 /* 1x1-spatial layers:
  *   unflatten  Y[n,(tap,co)] = act(z[n,Cin] Wp + b[co]), Wp[ci][tap*Cout+co] = Wref[ci][co][tap]

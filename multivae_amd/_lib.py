@@ -102,6 +102,8 @@ PROTOTYPES = {
     "mvk_bf3_to_f32": [_p, _i64, _p, _p],
     "mvk_conv4s2_small_up_fwd_nll": [_p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "mvk_conv4s2_small_up_fwd_nll_w": [_p, _p, _p, _p, _i, _f, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "mvk_conv4s2_small_up_fwd_nll_s": [_p, _p, _p, _p, _i, _f, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
+    "mvk_conv4s2_small_up_fwd_s": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "mvk_conv4s2_small_up_bwd_pre": [_p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p],
     "mvk_conv3x3": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i64, _p],
     "mvk_conv3x3_res": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _f, _p, _i64, _p],
@@ -294,6 +296,7 @@ GEMM_FLOPS = {
     "mvk_conv4s2_small_up_bwd": lambda a: 2.0 * 2.0 * a[12] * a[13] * a[14] * 16 * a[15] * a[16],  # data + weight
     "mvk_conv4s2_small_up_fwd_nll": lambda a: 2.0 * a[8] * a[9] * a[10] * 16 * a[11] * a[12],
     "mvk_conv4s2_small_up_fwd_nll_w": lambda a: 2.0 * a[9] * a[10] * a[11] * 16 * a[12] * a[13],
+    "mvk_conv4s2_small_up_fwd_nll_s": lambda a: 2.0 * a[9] * a[10] * a[11] * 16 * a[12] * a[13],
     "mvk_conv4s2_small_up_bwd_pre": lambda a: 2.0 * 2.0 * a[11] * a[12] * a[13] * 16 * a[14] * a[15],  # data + weight
     "mvk_conv4s2_small_up_bwd_pre_y": lambda a: 2.0 * 2.0 * a[11] * a[12] * a[13] * 16 * a[14] * a[15],
     "mvk_gemm_smallk_amax": lambda a: 2.0 * a[3] * a[4] * a[5],

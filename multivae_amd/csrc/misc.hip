@@ -947,11 +947,17 @@ typedef __bf16 probe_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int probe_u32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void mfma_probe_kernel(float* out, int iters, int rnd, unsigned seed) {
   probe_f32x16 acc[4];
+#pragma unroll
   for (int i = 0; i < 4; ++i)
+#pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   probe_bf16x8 av[8], bv[8];
+  // (every loop over the operand arrays is unrolled: a run-time index puts them in scratch memory, whose set-up was a fixed
+  // ~36 us per launch — the 80-us launches bench.py times read 1.09 PFLOP/s where the loop itself runs at 1.85)
+#pragma unroll
   for (int j = 0; j < 8; ++j) {
     probe_u32x4 ua, ub;
+#pragma unroll
     for (int e = 0; e < 4; ++e) {
       unsigned h = (seed + threadIdx.x * 2654435761u + j * 40503u + e * 9176u + blockIdx.x * 7919u) * 2246822519u;
       h ^= h >> 15;
@@ -964,6 +970,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     av[j] = __builtin_bit_cast(probe_bf16x8, ua);
     bv[j] = __builtin_bit_cast(probe_bf16x8, ub);
   }
+  if (rnd == 2) {  // the same loop on v_mfma_f32_32x32x16_f16 (the scaled-fp16 kernels' instruction): the hashed bits read as fp16
+    typedef _Float16 probe_f16x8 __attribute__((ext_vector_type(8)));
+    probe_f16x8 ah[8], bh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      probe_u32x4 ua = __builtin_bit_cast(probe_u32x4, av[j]), ub = __builtin_bit_cast(probe_u32x4, bv[j]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {  // +-[1, 2) with all ten mantissa bits hashed (a low piece has no quiet bits either)
+        ua[e] = (ua[e] & 0x83ff83ffu) | 0x3c003c00u | ((ua[e] >> 3) & 0x03800380u);
+        ub[e] = (ub[e] & 0x83ff83ffu) | 0x3c003c00u | ((ub[e] >> 3) & 0x03800380u);
+      }
+      ah[j] = __builtin_bit_cast(probe_f16x8, ua);
+      bh[j] = __builtin_bit_cast(probe_f16x8, ub);
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[(u + i) & 7], bh[(u * 3 + i) & 7], acc[i], 0, 0, 0);
+    }
+  } else
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int u = 0; u < 16; ++u)
@@ -971,13 +998,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[(u + i) & 7], bv[(u * 3 + i) & 7], acc[i], 0, 0, 0);
   }
   float s_ = 0.f;
+#pragma unroll
   for (int i = 0; i < 4; ++i)
+#pragma unroll
     for (int r = 0; r < 16; ++r) s_ += acc[i][r];
   out[blockIdx.x * 256 + threadIdx.x] = s_;
 }
 }  // namespace
 
 // out: 65536 floats (written, meaningless); one launch = 256 workgroups x 4 waves x iters x 64 MFMAs of 32768 FLOP
+// random_operands: 0 = two constants, 1 = hashed bf16 values, 2 = hashed fp16 values on v_mfma_f32_32x32x16_f16
 extern "C" int mvk_probe_mfma_bf16(float* out, int iters, int random_operands, void* stream) {
   if (!out || iters <= 0) return MVK_EINVAL;
   hipLaunchKernelGGL(mfma_probe_kernel, dim3(256), dim3(256), 0, mvk_stream(stream), out, iters, random_operands, 12345u);

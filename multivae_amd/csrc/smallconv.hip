@@ -34,6 +34,9 @@ extern "C" int mvk_smallup_debug_buffer(unsigned long long* p) {
 }
 #endif
 
+#ifndef MVK_SUF_ABL
+#define MVK_SUF_ABL 0  // subtraction builds of small_up_fwd_bf_kernel: 1 no piece split, 2 one MFMA per tile instead of six, 4 a quarter of the column-matrix writes, 8 one tap read instead of four, 16 no activation
+#endif
 namespace {
 
 using mvk::f32x4;
@@ -259,8 +262,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
       const int idx = tid + u * NT;
       const int pos = idx >> 3, q = idx & 7;
       unsigned a0, a1, a2, b0, b1, b2;
-      mvk::bf3_split(pre[u][0], pre[u][1], a0, a1, a2);
-      mvk::bf3_split(pre[u][2], pre[u][3], b0, b1, b2);
+      if (MVK_SUF_ABL & 1) {
+        a0 = a1 = __float_as_uint(pre[u][0]), a2 = __float_as_uint(pre[u][1]);
+        b0 = b1 = __float_as_uint(pre[u][2]), b2 = __float_as_uint(pre[u][3]);
+      } else {
+        mvk::bf3_split(pre[u][0], pre[u][1], a0, a1, a2);
+        mvk::bf3_split(pre[u][2], pre[u][3], b0, b1, b2);
+      }
       const int off = pos * 64 + (((q >> 1) ^ ((pos >> 1) & 3)) << 4) + (q & 1) * 8;
       *reinterpret_cast<u32x2*>(Vb + off) = u32x2{a0, b0};
       *reinterpret_cast<u32x2*>(Vb + PLANE + off) = u32x2{a1, b1};
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
         for (int a = 0; a < MT; ++a) {
           f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int t = 0; t < 6; ++t) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][PA[t]], bfr[PB[t]], c, 0, 0, 0);
+          for (int t = 0; t < ((MVK_SUF_ABL & 2) ? 1 : 6); ++t) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][PA[t]], bfr[PB[t]], c, 0, 0, 0);
           acc[a][b] = c;
         }
       }
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
 #pragma unroll
       for (int b = 0; b < CU; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) buf[(wave * WP + a * 16 + lq * 4 + r) * CS + b * 16 + l15] = acc[a][b][r];
+        for (int r = 0; r < ((MVK_SUF_ABL & 4) ? 1 : 4); ++r) buf[(wave * WP + a * 16 + lq * 4 + r) * CS + b * 16 + l15] = acc[a][b][r];
     __syncthreads();
     float* out = U + img * per_img;
     if (NLL) {
@@ -321,8 +329,185 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
     } else {
 #pragma unroll
       for (int t = 0; t < NO; ++t) {
+        const float sum = (MVK_SUF_ABL & 8) ? buf[tap[t][0]] + bia[t] : ((buf[tap[t][0]] + buf[tap[t][1]]) + (buf[tap[t][2]] + buf[tap[t][3]])) + bia[t];
+        out[tid + t * NT] = (MVK_SUF_ABL & 16) ? sum : mvk_act(sum, act);
+      }
+    }
+    __syncthreads();  // the column matrix is overwritten by the next image's pieces
+    if (NLL && tid == 0) {  // the wave partials are rewritten three barriers from now at the earliest
+      float tot = 0.f;
+      for (int wv = 0; wv < NT / 64; ++wv) tot += buf[zidx + 1 + wv];
+      rows[img] = tot + lconst;
+    }
+  }
+  mvk_prof_end(prof);
+}
+
+
+// The same forward on SCALED fp16 PAIRS with the operand roles swapped (round 4).  Subtraction builds of the kernel above at
+// n = 5120 (48.5 us alone, plain form): five of its six MFMAs per tile cost 7.7 us, three quarters of its column-matrix writes 4.4 us,
+// three of its four tap reads 3.1 us, the IEEE sigmoid 5.3 us, the piece split 1.4 us; everything off: 35.8 us = 6.4 TB/s, the
+// streaming skeleton.  Here:
+//   * V is split into (hi, lo) fp16 pairs under the bound its producer published (v_amax, bf3.hpp), W under its own maximum
+//     (computed once per workgroup): 3 MFMAs per tile instead of 6, two planes instead of three;
+//   * the weights are the A operand and the positions the B operand: D[nn][pos], a lane holds FOUR CONSECUTIVE columns nn of one
+//     position, i.e. one ds_write_b128 per tile into the column matrix (row stride 52 floats: conflict-free) instead of four
+//     ds_write_b32;
+//   * the fast sigmoid in both forms.
+// Same sums otherwise (tap order, bias, NLL tail, wave-ordered row sum).
+template <int CU, int NT, bool NLL = false>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT / 128))) void small_up_fwd_h_kernel(
+    const float* __restrict__ V, const float* __restrict__ Wref, const float* __restrict__ bias, float* __restrict__ U, int n, int act,
+    mvk_prof_slot* prof, const float* __restrict__ v_amax, const float* __restrict__ X = nullptr, int xrows = 1, float inv_s2 = 1.f,
+    float lconst = 0.f, float* __restrict__ rows = nullptr, float g_inv_s2 = 1.f) {
+  mvk_prof_begin(prof);
+  using mvk::f16x8;
+  using mvk::u32x2;
+  constexpr int CV = 32, NC = 16 * CU, CS = NC + 4, P = 256, h = 16, w = 16;
+  constexpr int WP = P / (NT / 64), MT = WP / 16;
+  constexpr int PLANE = P * 64, WPLANE = NC * 64;  // bytes per piece plane
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* Wb = reinterpret_cast<char*>(smem);  // 2 x [NC][32 k] fp16
+  float* buf = smem + 2 * WPLANE / 4;       // 2 x [P][32 k] fp16, later the column matrix [P][CS] (+ the zero word, wave partials)
+  char* Vb = reinterpret_cast<char*>(buf);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+  constexpr int zidx = P * CS;  // one float past the column matrix (and past the piece planes), kept at 0
+  static_assert(2 * PLANE <= zidx * 4, "the zero word must survive the staging");
+  // weight scale: max |W| over the NC * 32 weights (every thread visits its pairs twice: maximum, then split)
+  float wmax = 0.f;
+  for (int i = tid; i < NC * 16; i += NT) {
+    const int nn = i >> 4, kp = i & 15;
+    wmax = fmaxf(wmax, fmaxf(fabsf(Wref[(2 * kp) * NC + nn]), fabsf(Wref[(2 * kp + 1) * NC + nn])));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off, 64));
+  if (lane == 0) buf[zidx + 1 + wave] = wmax;
+  __syncthreads();
+  wmax = 0.f;
+  for (int wv = 0; wv < NT / 64; ++wv) wmax = fmaxf(wmax, buf[zidx + 1 + wv]);
+  const float sw = mvk::f16_scale_of(wmax), sv = mvk::f16_scale_of(*v_amax);
+  const float inv_s = mvk::f16_inv_scale(sw) * mvk::f16_inv_scale(sv);
+  __syncthreads();
+  for (int i = tid; i < NC * 16; i += NT) {  // weight pieces: column nn, k = 2 kp, 2 kp + 1
+    const int nn = i >> 4, kp = i & 15;
+    unsigned p0, p1;
+    mvk::f16_split(Wref[(2 * kp) * NC + nn] * sw, Wref[(2 * kp + 1) * NC + nn] * sw, p0, p1);
+    const int off = nn * 64 + (((kp >> 2) ^ ((nn >> 1) & 3)) << 4) + (kp & 3) * 4;
+    *reinterpret_cast<unsigned*>(Wb + off) = p0;
+    *reinterpret_cast<unsigned*>(Wb + WPLANE + off) = p1;
+  }
+  constexpr int NV = P * CV / 4 / NT;
+  static_assert((P * CV / 4) % NT == 0 && (CU * 1024) % NT == 0 && MT >= 1, "workgroup size");
+  f32x4 pre[NV];
+  auto prefetch = [&](long long img) __attribute__((always_inline)) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(V + img * P * CV);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) pre[u] = src[tid + u * NT];
+  };
+  constexpr int H2 = 2 * h, W2 = 2 * w, per_img = CU * H2 * W2;
+  constexpr int NO = per_img / NT;
+  int tap[NO][4];
+  float bia[NO];
+#pragma unroll
+  for (int t = 0; t < NO; ++t) {
+    const int o = tid + t * NT;
+    const int cu = o / (H2 * W2);
+    const int rem = o - cu * (H2 * W2);
+    const int oh = rem / W2, ow = rem - oh * W2;
+    const int ph = oh & 1, pw = ow & 1, i0 = oh >> 1, j0 = ow >> 1;
+    bia[t] = bias ? bias[cu] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int ih = i0 + ph - a, kh = (1 - ph) + 2 * a;
+        const int iw = j0 + pw - b, kw = (1 - pw) + 2 * b;
+        const bool ok = ih >= 0 && ih < h && iw >= 0 && iw < w;
+        tap[t][a * 2 + b] = ok ? (ih * w + iw) * CS + cu * 16 + kh * 4 + kw : zidx;
+      }
+  }
+  if (tid == 0) buf[zidx] = 0.f;
+  // fragment addresses (bytes inside a plane): positions = B operand, weights = A operand (both [row][32 k], k-octet lq)
+  int poff[MT], woff[CU];
+#pragma unroll
+  for (int a = 0; a < MT; ++a) {
+    const int r = wave * WP + a * 16 + l15;
+    poff[a] = r * 64 + ((lq ^ ((r >> 1) & 3)) << 4);
+  }
+#pragma unroll
+  for (int b = 0; b < CU; ++b) {
+    const int c = b * 16 + l15;
+    woff[b] = c * 64 + ((lq ^ ((c >> 1) & 3)) << 4);
+  }
+  long long img = blockIdx.x;
+  if (img < n) prefetch(img);
+  for (; img < n; img += gridDim.x) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int idx = tid + u * NT;
+      const int pos = idx >> 3, q = idx & 7;
+      unsigned a0, a1, b0, b1;
+      mvk::f16_split(pre[u][0] * sv, pre[u][1] * sv, a0, a1);
+      mvk::f16_split(pre[u][2] * sv, pre[u][3] * sv, b0, b1);
+      const int off = pos * 64 + (((q >> 1) ^ ((pos >> 1) & 3)) << 4) + (q & 1) * 8;
+      *reinterpret_cast<u32x2*>(Vb + off) = u32x2{a0, b0};
+      *reinterpret_cast<u32x2*>(Vb + PLANE + off) = u32x2{a1, b1};
+    }
+    __syncthreads();
+    if (img + gridDim.x < n) prefetch(img + gridDim.x);
+    float xv[NO];  // fused tail: this thread's target pixels, loaded here and first touched behind the GEMM
+    if (NLL) {
+      const float* xt = X + (img % xrows) * per_img;
+#pragma unroll
+      for (int t = 0; t < NO; ++t) xv[t] = xt[tid + t * NT];
+    }
+    f32x4 res[MT][CU];  // D[nn = b * 16 + 4 lq + r][pos = wave * WP + a * 16 + l15]
+    {
+      f16x8 pf[MT][2];
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) pf[a][p] = *reinterpret_cast<const f16x8*>(Vb + p * PLANE + poff[a]);
+#pragma unroll
+      for (int b = 0; b < CU; ++b) {
+        f16x8 wf[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) wf[p] = *reinterpret_cast<const f16x8*>(Wb + p * WPLANE + woff[b]);
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+          f32x4 cm = f32x4{0.f, 0.f, 0.f, 0.f}, cx = f32x4{0.f, 0.f, 0.f, 0.f};
+          cx = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0], pf[a][1], cx, 0, 0, 0);
+          cm = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0], pf[a][0], cm, 0, 0, 0);
+          cx = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1], pf[a][0], cx, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) res[a][b][r] = fmaf(cx[r], 1.f / 2048.f, cm[r]) * inv_s;
+        }
+      }
+    }
+    __syncthreads();  // every wave is done with the piece planes
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < CU; ++b)
+        *reinterpret_cast<f32x4*>(buf + (wave * WP + a * 16 + l15) * CS + b * 16 + 4 * lq) = res[a][b];
+    __syncthreads();
+    float* out = U + img * per_img;
+    if (NLL) {
+      float part = 0.f;
+#pragma unroll
+      for (int t = 0; t < NO; ++t) {
         const float sum = ((buf[tap[t][0]] + buf[tap[t][1]]) + (buf[tap[t][2]] + buf[tap[t][3]])) + bia[t];
-        out[tid + t * NT] = mvk_act(sum, act);
+        const float r = act == MVK_ACT_SIGMOID ? mvk_fast_sigmoid(sum) : mvk_act(sum, act), dlt = r - xv[t];
+        part = fmaf(0.5f * inv_s2 * dlt, dlt, part);
+        out[tid + t * NT] = dlt * g_inv_s2 * mvk_act_grad_from_out(r, act);
+      }
+      part = wave_sum(part);
+      if (lane == 0) buf[zidx + 1 + wave] = part;
+    } else {
+#pragma unroll
+      for (int t = 0; t < NO; ++t) {
+        const float sum = ((buf[tap[t][0]] + buf[tap[t][1]]) + (buf[tap[t][2]] + buf[tap[t][3]])) + bia[t];
+        out[tid + t * NT] = act == MVK_ACT_SIGMOID ? mvk_fast_sigmoid(sum) : mvk_act(sum, act);
       }
     }
     __syncthreads();  // the column matrix is overwritten by the next image's pieces
@@ -1072,7 +1257,7 @@ static bool supported(int h, int w, int Cu, int Cv) {
 template <int CU, int CV>
 static int launch_fwd(const float* V, const float* Wref, const float* bias, float* U, int n, int h, int w, int act,
                       hipStream_t s, const float* X = nullptr, int xrows = 1, float scale = 1.f, float* rows = nullptr,
-                      float grad_weight = 1.f) {
+                      float grad_weight = 1.f, const float* v_amax = nullptr) {
   const size_t lds = fwd_lds<CU, CV>(h * w);
   constexpr int NT = MVK_SMALL_FWD_THREADS;
   if (lds > 64 * 1024) {
@@ -1093,6 +1278,18 @@ static int launch_fwd(const float* V, const float* Wref, const float* bias, floa
     if (h == 16 && w == 16 && bf > 0) {
       const size_t blds = 3 * (16 * CU) * 64 + (256 * (16 * CU + 1) + 24) * sizeof(float);  // + zero word + 16 wave partials
       const float inv_s2 = 1.f / (scale * scale), lconst = (float)(CU * 1024) * (logf(scale) + 0.91893853320467274178f);
+      if (v_amax) {  // scaled fp16 pairs, weights as the A operand (small_up_fwd_h_kernel): 512-thread workgroups, 2 per CU
+        const size_t hlds = 2 * (16 * CU) * 64 + (256 * (16 * CU + 4) + 24) * sizeof(float);
+        if (X)
+          hipLaunchKernelGGL((small_up_fwd_h_kernel<CU, 512, true>), dim3(grid), dim3(512), hlds, s, V, Wref, bias, U, n, act, prof,
+                             v_amax, X, xrows, inv_s2, lconst, rows, inv_s2 * grad_weight);
+        else
+          hipLaunchKernelGGL((small_up_fwd_h_kernel<CU, 512, false>), dim3(grid), dim3(512), hlds, s, V, Wref, bias, U, n, act, prof,
+                             v_amax);
+        MVK_CHECK_LAUNCH();
+        mvk::prof_fold(prof, s);
+        return MVK_OK;
+      }
       // fused tail: 512-thread workgroups (4 waves per SIMD, 128 registers) — at 1024 threads it spills; MVK_SMALL_NLL_NT=1024 for A/B
       static const int nll_nt = mvk_tune("MVK_SMALL_NLL_NT") ? atoi(mvk_tune("MVK_SMALL_NLL_NT")) : 512;
       if (X && nll_nt == 1024)
@@ -1110,7 +1307,7 @@ static int launch_fwd(const float* V, const float* Wref, const float* bias, floa
       return MVK_OK;
     }
   }
-  if (X) return MVK_EINVAL;  // the fused tail lives in the split-bf16 kernel only (mvk_conv4s2_small_up_nll_supported)
+  if (X || v_amax) return MVK_EINVAL;  // the fused tail / the scaled form: 16x16x32 -> 3 channels only (mvk_conv4s2_small_up_nll_supported)
   if (dense)
     hipLaunchKernelGGL((small_up_fwd_kernel<CU, CV, NT, true>), dim3(grid), dim3(NT), lds, s, V, Wref, bias, U, n, h, w, act, prof);
   else
@@ -1289,6 +1486,26 @@ int mvk_conv4s2_small_up_fwd_nll_w(const float* V, const float* Wref, const floa
     return MVK_EINVAL;
   if (n == 0) return MVK_OK;
   return launch_fwd<3, 32>(V, Wref, bias, dpre, n, h, w, act, mvk_stream(stream), X, xrows, scale, rows, grad_weight);
+}
+
+/* The same two launches on scaled fp16 pairs (3 MFMAs per product, bf3.hpp): v_amax = device scalar bounding max |V| (published by
+ * the launch that produced V: amax protocol); where mvk_conv4s2_small_up_nll_supported says so. */
+int mvk_conv4s2_small_up_fwd_nll_s(const float* V, const float* Wref, const float* bias, const float* X, int xrows, float scale,
+                                   float grad_weight, float* dpre, float* rows, int n, int h, int w, int Cu, int Cv, int act,
+                                   const float* v_amax, void* stream) {
+  if (!V || !Wref || !X || !dpre || !rows || !v_amax || n < 0 || xrows <= 0 || !(scale > 0.f) || !mvk_aligned16(V) ||
+      !mvk_conv4s2_small_up_nll_supported(h, w, Cu, Cv))
+    return MVK_EINVAL;
+  if (n == 0) return MVK_OK;
+  return launch_fwd<3, 32>(V, Wref, bias, dpre, n, h, w, act, mvk_stream(stream), X, xrows, scale, rows, grad_weight, v_amax);
+}
+
+int mvk_conv4s2_small_up_fwd_s(const float* V, const float* Wref, const float* bias, float* U, int n, int h, int w, int Cu, int Cv,
+                               int act, const float* v_amax, void* stream) {
+  if (!V || !Wref || !U || !v_amax || n < 0 || !mvk_aligned16(V) || !mvk_conv4s2_small_up_nll_supported(h, w, Cu, Cv))
+    return MVK_EINVAL;
+  if (n == 0) return MVK_OK;
+  return launch_fwd<3, 32>(V, Wref, bias, U, n, h, w, act, mvk_stream(stream), nullptr, 1, 1.f, nullptr, 1.f, v_amax);
 }
 
 int mvk_conv4s2_small_up_fwd_nll(const float* V, const float* Wref, const float* bias, const float* X, int xrows, float scale,

@@ -1482,6 +1482,10 @@ class SVHNEncoderFn(Function):
         return dx, dw0, db0, dw1, db1, dw2, db2, dwc1, dbc1, dwc2, dbc2
 
 
+# MVK_TAIL_F16=0: the fused SVHN tail on bf16 pieces (small_up_fwd_bf_kernel) also where the scaled-fp16 chain runs
+TAIL_F16 = _lib.tune("MVK_TAIL_F16", "1") != "0"
+
+
 class SVHNDecoderFn(Function):
     """z[...,L] -> ConvT(4,1,0)+ReLU -> 2x ConvT(4,2,1)+ReLU -> ConvT(4,2,1)+Sigmoid -> [...,C,32,32] NCHW."""
 
@@ -1506,8 +1510,9 @@ class SVHNDecoderFn(Function):
                and all(getattr(t, "mvk_amax", None) is not None for t in (wu1, wu2, wd1, wd2)))
         ctx.f16 = f16
         if f16:
-            pool = AmaxPool(z2, 4)
+            pool = AmaxPool(z2, 5)
             a1, a2 = pool.take(), pool.take()
+            a3 = pool.take() if (TAIL_F16 and nll_x is not None) else None  # bound of g3 for the image layer's scaled form
             ctx.bslots = (pool.take(), pool.take())  # the backward pass's two slots: no fill launch there
             if L <= 32 and (16 * C1) % 4 == 0:
                 g1 = _new((n, 16 * C1), z2)
@@ -1518,10 +1523,11 @@ class SVHNDecoderFn(Function):
                 amax_of(g1, a1)
             g2 = conv_up(g1, wu1, b1, n, 4, 4, C2, C1, RELU, amax=(a1, wu1.mvk_amax, a2))  # [n,8,8,C2]
             flush_deferred_forward(z2.device)  # a side branch's postponed launches: beside the 64 -> 32 layer, not the 128 -> 64 one
-            g3 = conv_up(g2, wu2, b2, n, 8, 8, C3, C2, RELU, amax=(a2, wu2.mvk_amax, None))  # [n,16,16,C3]
+            g3 = conv_up(g2, wu2, b2, n, 8, 8, C3, C2, RELU, amax=(a2, wu2.mvk_amax, a3))  # [n,16,16,C3]
             ctx.wamax = (wd1.mvk_amax, wd2.mvk_amax)
             ctx.gamax = (a1, a2)  # bounds of g1, g2: the V operands of the two weight gradients
         else:
+            a3 = None
             g1 = gemm(z2, wp0, n, 16 * C1, L, bias=b0, bias_mod=C1, act=RELU)  # [n,4,4,C1]
             g2 = conv_up(g1, wu1, b1, n, 4, 4, C2, C1, RELU)  # [n,8,8,C2]
             g3 = conv_up(g2, wu2, b2, n, 8, 8, C3, C2, RELU)  # [n,16,16,C3]
@@ -1532,8 +1538,12 @@ class SVHNDecoderFn(Function):
             rows = _new((n,), z2)
             # the stored gradient is pre-multiplied by nll_weight, the weight the rows are expected to enter the loss with
             ctx.nll_weight = float(nll_weight)
-            call("mvk_conv4s2_small_up_fwd_nll_w", ptr(g3), ptr(w3), ptr(b3), ptr(nll_x), nll_x.shape[0], float(nll_scale),
-                 float(nll_weight), ptr(out), ptr(rows), n, 16, 16, C4, C3, SIGMOID, stream_ptr())
+            if a3 is not None:  # scaled fp16 pairs under the bound the 64 -> 32 launch published (small_up_fwd_h_kernel)
+                call("mvk_conv4s2_small_up_fwd_nll_s", ptr(g3), ptr(w3), ptr(b3), ptr(nll_x), nll_x.shape[0], float(nll_scale),
+                     float(nll_weight), ptr(out), ptr(rows), n, 16, 16, C4, C3, SIGMOID, ptr(a3), stream_ptr())
+            else:
+                call("mvk_conv4s2_small_up_fwd_nll_w", ptr(g3), ptr(w3), ptr(b3), ptr(nll_x), nll_x.shape[0], float(nll_scale),
+                     float(nll_weight), ptr(out), ptr(rows), n, 16, 16, C4, C3, SIGMOID, stream_ptr())
         elif small:  # per-image MFMA column-matrix kernel (smallconv.hip)
             call("mvk_conv4s2_small_up_fwd", ptr(g3), ptr(w3), ptr(b3), ptr(out), n, 16, 16, C4, C3, SIGMOID,
                  stream_ptr())

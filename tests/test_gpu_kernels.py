@@ -758,6 +758,58 @@ def test_small_up_fwd_bwd(K, n, h, w, Cu, Cv, bwd_bf, monkeypatch):
     close(db, br.grad, what="small up db")
 
 
+@pytest.mark.parametrize("n,xrows,spread", [(3, 3, 0.0), (700, 70, 0.0), (1030, 103, 3.0)])
+def test_small_up_fwd_scaled_fp16(K, n, xrows, spread):
+    """The image-producing layer on scaled fp16 pairs (small_up_fwd_h_kernel: 3 MFMAs per product, weights as the A operand, the
+    bound of V from an amax slot) against float64: the image, and the fused tail's Normal NLL row sums and d rows / d pre-activation
+    (reference: models/nn/svhn.py:59-60, models/base/base_utils.py:62-87).  spread: images whose magnitudes differ by 10^+-spread —
+    checked per image (a per-tensor scale must not cost the small images their precision)."""
+    from multivae_amd._lib import call, ptr, stream_ptr
+
+    h = w = 16
+    Cu, Cv = 3, 32
+    gen = g(n + 17)
+    V = torch.relu(torch.randn(n, Cv, h, w, generator=gen))
+    if spread:
+        V = V * (10.0 ** ((torch.rand(n, 1, 1, 1, generator=gen) * 2 - 1) * spread))
+    Wt = torch.randn(Cv, Cu, 4, 4, generator=gen) / math.sqrt(4 * Cv)
+    b = torch.randn(Cu, generator=gen)
+    X = torch.rand(xrows, Cu, 2 * h, 2 * w, generator=gen)
+    scale, gw = 0.75, 0.3
+    pre64 = F.conv_transpose2d(V.double(), Wt.double(), b.double(), stride=2, padding=1)
+    ref = torch.sigmoid(pre64)
+    d = dev()
+    Vd, Wd, bd, Xd = nhwc(V).to(d), Wt.to(d), b.to(d), X.to(d)
+    amax = torch.zeros(1, device=d)
+    K.amax_of(Vd, amax)
+    out = torch.empty(n, Cu, 2 * h, 2 * w, device=d)
+    call("mvk_conv4s2_small_up_fwd_s", ptr(Vd), ptr(Wd), ptr(bd), ptr(out), n, h, w, Cu, Cv, 2, ptr(amax), stream_ptr())
+    close(out, ref, what="scaled small up fwd")
+    # per image, on the pre-activations without the bias (act = none): every image within 3e-6 of ITS OWN largest entry
+    raw = torch.empty_like(out)
+    call("mvk_conv4s2_small_up_fwd_s", ptr(Vd), ptr(Wd), ptr(None), ptr(raw), n, h, w, Cu, Cv, 0, ptr(amax), stream_ptr())
+    raw64 = pre64 - b.double().view(1, Cu, 1, 1)
+    err = (raw.double().cpu() - raw64).abs().flatten(1).max(dim=1).values
+    den = raw64.abs().flatten(1).max(dim=1).values.clamp_min(1e-30)
+    assert float((err / den).max()) <= 3e-6, f"per-image rel err {float((err / den).max()):.3e}"
+    # fused tail: rows = sum (r - x)^2 / (2 s^2) + D (log s + 1/2 log 2 pi), dpre = gw (r - x) / s^2 r (1 - r)
+    xs = X.double()[torch.arange(n) % xrows]
+    rows_ref = ((ref - xs) ** 2).flatten(1).sum(1) / (2 * scale * scale) + Cu * 4 * h * w * (math.log(scale) + 0.5 * math.log(2 * math.pi))
+    dpre_ref = gw * (ref - xs) / (scale * scale) * ref * (1 - ref)
+    dpre, rows = torch.empty_like(out), torch.empty(n, device=d)
+    call("mvk_conv4s2_small_up_fwd_nll_s", ptr(Vd), ptr(Wd), ptr(bd), ptr(Xd), xrows, scale, gw, ptr(dpre), ptr(rows), n, h, w, Cu, Cv, 2,
+         ptr(amax), stream_ptr())
+    close(rows, rows_ref, rtol=2e-6, what="scaled fused tail rows")
+    # (with spread, an entry of a LARGE image whose sigmoid is not saturated carries that image's absolute pre-activation error,
+    # 4e-7 of the image's maximum, through a slope of order one: the per-image check above is the precision statement there)
+    close(dpre, dpre_ref, rtol=3e-6 if not spread else 2e-4, what="scaled fused tail dpre")
+    # and the unscaled fused tail agrees (same sums, other product form)
+    dpre2, rows2 = torch.empty_like(out), torch.empty(n, device=d)
+    call("mvk_conv4s2_small_up_fwd_nll_w", ptr(Vd), ptr(Wd), ptr(bd), ptr(Xd), xrows, scale, gw, ptr(dpre2), ptr(rows2), n, h, w, Cu, Cv, 2,
+         stream_ptr())
+    close(rows, rows2, rtol=2e-6, what="scaled vs bf16-piece tail rows")
+
+
 @pytest.mark.parametrize("M,N,Kd", [(40960, 128, 1024), (4096, 64, 2048), (65536, 32, 512), (8192, 64, 96)])
 def test_split_bf16_engine_has_fp32_accuracy(K, M, N, Kd):
     """The default GEMM engine (igemm_bf.hpp: every fp32 operand split into 3 bf16 pieces, 6 bf16 MFMAs per product)

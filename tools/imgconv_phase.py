@@ -26,13 +26,23 @@ for h, Cu, Cv in [(8, 32, 64), (4, 64, 128)]:
     bu = torch.randn(Cu, generator=gen).to(d)
     wd, wu = K.pack_conv(Wc)
     pb = torch.nn.Parameter(torch.zeros(Cv, device=d))
+    pool = K.AmaxPool(Ud, 8)
+    uam, vam, ya = K.amax_of(Ud, pool.take()), K.amax_of(Vd, pool.take()), pool.take()
     for name, fn in (("up  ", lambda: K.conv_up(Vd, wu, bu, n, h, h, Cu, Cv, act=1)),
-                     ("down", lambda: K.conv_down(Ud, wd, None, n, h, h, Cu, Cv, v_act_src=Vd, v_act=1, out_bias=pb))):
+                     ("down", lambda: K.conv_down(Ud, wd, None, n, h, h, Cu, Cv, v_act_src=Vd, v_act=1, out_bias=pb)),
+                     ("up   fp16", lambda: K.conv_up(Vd, wu, bu, n, h, h, Cu, Cv, act=1, amax=(vam, wu.mvk_amax, ya))),
+                     ("down fp16", lambda: K.conv_down(Ud, wd, None, n, h, h, Cu, Cv, v_act_src=Vd, v_act=1, out_bias=pb,
+                                                       amax=(uam, wd.mvk_amax, ya)))):
         fn()
         torch.cuda.synchronize()
         buf.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         fn()
+        e1.record()
         torch.cuda.synchronize()
+        print(f"-- {name}: {e0.elapsed_time(e1) * 1e3:.1f} us incl. launch; cycle counter rate = "
+              f"{buf.view(256, 4, 4)[..., 0].double().mean().item() / (e0.elapsed_time(e1) * 1e3) / 1e3:.2f} GHz (lower bound)")
         t = buf.view(256, 4, 4).double().cpu()
         tot, bar, kl = t[..., 0], t[..., 1], t[..., 2]
         raw3 = buf.view(256, 4, 4)[..., 3].cpu()
@@ -41,4 +51,4 @@ for h, Cu, Cv in [(8, 32, 64), (4, 64, 128)]:
               f"{100 * (post / tot).mean():.1f} %   (two-tile-latency loop: 'k-loops' = pairs 0-6, second figure = pair 7)")
         print(f"h={h} {name}: cycles/wave mean {tot.mean():.0f} max {tot.max():.0f} | barrier wait mean {100 * (bar / tot).mean():.1f} % "
               f"(per wave of a workgroup: {[round(float(x), 1) for x in (100 * bar / tot).mean(0)]}) | k-loops {100 * (kl / tot).mean():.1f} % "
-              f"| rest {100 * ((tot - bar - kl) / tot).mean():.1f} %  | MFMA floor 122880 = {100 * 122880 / tot.mean():.0f} %")
+              f"| rest {100 * ((tot - bar - kl) / tot).mean():.1f} %  | MFMA floor {61440 if 'fp16' in name else 122880} = {100 * (61440 if 'fp16' in name else 122880) / tot.mean():.0f} %")

@@ -33,7 +33,30 @@ def bwd():
          ws.numel(), n, h, h, Cu, Cv, stream_ptr())
 
 
-for name, f, mb in (("fwd", fwd, 4e-6 * n * h * h * (Cv + 4 * Cu)), ("bwd", bwd, 4e-6 * n * h * h * (2 * Cv + 8 * Cu))):
+amax = torch.zeros(1, device=d)
+K.amax_of(V, amax)
+X = torch.rand(n // 10, Cu, 2 * h, 2 * h, generator=g).to(d)
+rows = torch.empty(n, device=d)
+
+
+def fwd_s():  # scaled fp16 pairs (small_up_fwd_h_kernel)
+    call("mvk_conv4s2_small_up_fwd_s", ptr(V), ptr(W), ptr(b), ptr(U), n, h, h, Cu, Cv, K.SIGMOID, ptr(amax), stream_ptr())
+
+
+def nll():  # fused tail, bf16 pieces
+    call("mvk_conv4s2_small_up_fwd_nll_w", ptr(V), ptr(W), ptr(b), ptr(X), X.shape[0], 0.75, 1.0, ptr(U), ptr(rows), n, h, h, Cu, Cv,
+         K.SIGMOID, stream_ptr())
+
+
+def nll_s():  # fused tail, scaled fp16 pairs
+    call("mvk_conv4s2_small_up_fwd_nll_s", ptr(V), ptr(W), ptr(b), ptr(X), X.shape[0], 0.75, 1.0, ptr(U), ptr(rows), n, h, h, Cu, Cv,
+         K.SIGMOID, ptr(amax), stream_ptr())
+
+
+mb_f = 4e-6 * n * h * h * (Cv + 4 * Cu)
+mb_n = mb_f + 4e-6 * X.numel()
+for name, f, mb in (("fwd", fwd, mb_f), ("fwd_s", fwd_s, mb_f), ("nll", nll, mb_n), ("nll_s", nll_s, mb_n),
+                    ("bwd", bwd, 4e-6 * n * h * h * (2 * Cv + 8 * Cu))):
     f()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
@@ -43,5 +66,5 @@ for name, f, mb in (("fwd", fwd, 4e-6 * n * h * h * (Cv + 4 * Cu)), ("bwd", bwd,
         e.record()
     torch.cuda.synchronize()
     t = sorted(s.elapsed_time(e) * 1e3 for s, e in ev)
-    print(f"{name}: median {t[len(t) // 2]:.1f} us (min {t[0]:.1f}), {mb:.1f} MB -> {mb / t[len(t) // 2] * 1e-6 * 1e6 / 1e3:.2f} TB/s "
+    print(f"{name}: median {t[len(t) // 2]:.1f} us (min {t[0]:.1f}), {mb:.1f} MB -> {mb / t[len(t) // 2]:.2f} TB/s "
           f"= {mb / t[len(t) // 2] / 8e3 * 1e3:.3f} of 8 TB/s")
