@@ -353,6 +353,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define MVK_IC_DEPTH2 0  // measured: no gain alone (65-80 us either way), +3 % on the step
 #endif
   constexpr bool D2 = NP == 2 && PIPE && MVK_IC_DEPTH2;
+  // MVK_IC_DEPTH2 = 2: depth 2 AND the tile barrier one pair earlier (behind pair 5: every fragment of the tile has been read by
+  // then), so that the first fragments of the next tile are read behind the barrier with two pairs of MFMAs (384 cycles) in
+  // front of their first use instead of one; the conversion of the next unit is spread over pairs 0-5.
+  constexpr bool D2E = D2 && MVK_IC_DEPTH2 == 2;
+  constexpr int BP = D2E ? 5 : 6;  // the pair whose end holds the barrier
   frag a_cur[2][NP], a_n1[2][NP];
   if (u0 < u1) {
     read_pair(a_cur, lds, 0, 0);
@@ -452,10 +457,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           frag a_nxt[2][NP];  // depth 1: pair pr + 1; depth 2: pair pr + 2 (a_n1 holds pair pr + 1)
           if (D2) {
             if (pr < 6) read_pair(a_nxt, abuf, tt, pr + 2);
+            else if (D2E) read_pair(a_nxt, next_buf, ntt, pr - 6);  // behind the (earlier) barrier: pairs 0, 1 of the next tile
           } else if (pr < 7) {
             read_pair(a_nxt, abuf, tt, pr + 1);
           }
           if (pr == 0) finish_pending(xb);
+          if (D2E) {
+            if (tt == 0) {  // conversion of the next unit over pairs 0-5
+#pragma unroll
+              for (int k = 0; k < T::NF4; ++k) {
+                if (k * 6 / T::NF4 != pr) continue;
+                write_f4(nbuf, k);
+                raw[k] = src2[k * 256];
+              }
+            }
+          } else
           if (tt == 0 && pr < 7) {  // conversion of the next unit: complete before the barrier behind pair 6
             if (T::NF4 >= 8) {
               constexpr int PER = T::NF4 / 8;
@@ -493,7 +509,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1][1], Bw[q1][c1][0], acc1, 0, 0, 0);
           }
           if (pr == 7) {  // behind the barrier: first fragments of the next tile, result of tile T-1
-            if (D2) {
+            if (D2E) {
+            } else if (D2) {
               read_pair(a_n1, next_buf, ntt, 0);
               read_pair(a_nxt, next_buf, ntt, 1);
             } else {
@@ -507,7 +524,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int pc = 0; pc < NP; ++pc) {
               if (D2) {
                 a_cur[h][pc] = a_n1[h][pc];
-                if (pr != 6) a_n1[h][pc] = a_nxt[h][pc];  // pair 6 reads nothing (pair 8 is the next tile's, behind the barrier)
+                if (pr != 6 || D2E) a_n1[h][pc] = a_nxt[h][pc];  // depth 2, late barrier: pair 6 reads nothing (pair 8 is the next tile's)
               } else {
                 a_cur[h][pc] = a_nxt[h][pc];
               }
@@ -520,7 +537,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
           }
 #ifdef MVK_ICPROF
-          if (pr == 6) {
+          if (pr == BP) {
             const unsigned long long ic_b0 = IC_CLK();
             ic_k += ic_b0 - ic_k0;
             if (T::KSPLIT > 1 || tt == T::TPU - 1) __syncthreads();
@@ -528,7 +545,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             ic_bar += ic_tend - ic_b0;
           }
 #else
-          if (pr == 6 && (T::KSPLIT > 1 || tt == T::TPU - 1)) __syncthreads();
+          if (pr == BP && (T::KSPLIT > 1 || tt == T::TPU - 1)) __syncthreads();
 #endif
         }
 #ifdef MVK_ICPROF
