@@ -558,12 +558,14 @@ def main():
                 traffic = traffic_meta.get("hbm_bytes_per_launch")
             # the average of the SAME kernel in the tracked rocprofv3 summary of this command (profiles/: written by
             # tools/make_profiles.py from `rocprofv3 --kernel-trace --stats -- python bench.py`): the second denominator
-            tracked_us = tracked_rocprof_avg_us("small_up_fwd_bf_kernel<3, 512, true>" if fused_tail else "recon_nll_kernel<1, true>") \
-                if args.config == "cfg3" else None
+            tail_kernel = "small_up_fwd_h_kernel<3, 512, true>" if (kernels.TAIL_F16 and kernels.IMG_F16) else "small_up_fwd_bf_kernel<3, 512, true>"
+            tracked_us = (tracked_rocprof_avg_us(tail_kernel) or tracked_rocprof_avg_us("small_up_fwd_bf_kernel<3, 512, true>")) if fused_tail \
+                else tracked_rocprof_avg_us("recon_nll_kernel<1, true>")
+            tracked_us = tracked_us if args.config == "cfg3" else None
             ach = nll["work"] / nll["seconds"] / 1e9
             copy_gbs = measured_copy_gbs(device)
             res["roofline"] = {
-                "kernel": ("small_up_fwd_bf_kernel<3, 512, NLL> (decoder tail + reconstruction NLL + d NLL / d pre-activation of the "
+                "kernel": (tail_kernel + " (decoder tail + reconstruction NLL + d NLL / d pre-activation of the "
                            "svhn modality in one launch: reads the 16x16x32 input map and the targets, writes the gradient; the "
                            "image and d_recon of SURVEY 8(d)'s byte count are never written)") if fused_tail else
                           "recon_nll_kernel<vec,fwd> (fused reconstruction NLL + d_recon, all modalities, one launch)",

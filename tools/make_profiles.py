@@ -190,6 +190,7 @@ with open(f"{DST}/{TAG}_pmc_hbm.md", "w") as f:
             "| kernel | us | read MB (2 x FETCH) | written MB | algorithmic MB | ratio |\n|---|---:|---:|---:|---:|---:|\n")
     alg = {"recon_nll_kernel<1, true>": 165.84, "small_up_fwd_kernel<3, 32, 1024, true>": 167.77 + 62.91,
            "small_up_fwd_bf_kernel<3, 512, true>": 167.77 + 6.29 + 62.91,
+           "small_up_fwd_h_kernel<3, 512, true>": 167.77 + 6.29 + 62.91,
            "small_up_bwd_bf_kernel<3, true>": 62.91 + 167.77 * 2,
            "small_up_bwd_kernel<3, 32, 256, 256, 2, 2, 1, true>": 62.91 * 2 + 167.77 * 2}
     alg.update({"d16_nt_kernel<64, 0>": 10.49 + 1.61 + 1.61 + 16.06 + 0.14, "d16_nt_kernel<128, 0>": 10.49 + 1.61 + 1.61 + 16.06 + 0.14,
@@ -221,7 +222,7 @@ if k in fs and k in ws:
                              "WRITE_SIZE as reported",
                "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
                "algorithmic_bytes_per_launch": 165838848}, open(f"{DST}/recon_nll_traffic.json", "w"), indent=1)
-kf = next((kk for kk in fs if kk.startswith("small_up_fwd_bf_kernel") and kk in ws and "true" in kk), None)
+kf = next((kk for kk in fs if (kk.startswith("small_up_fwd_h_kernel") or kk.startswith("small_up_fwd_bf_kernel")) and kk in ws and "true" in kk), None)
 if kf:  # the fused decoder tail: the launch that carries the large modality's reconstruction NLL
     rd, wr = int(2 * fs[kf]["FETCH_SIZE"] * 1e6 * 1024), int(ws[kf]["WRITE_SIZE"] * 1e6 * 1024)
     json.dump({"kernel": kf, "workload": "MoPoE MnistSvhn K=10 B=512, bench.py default config (fused decoder tail on)",
