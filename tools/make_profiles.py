@@ -208,8 +208,10 @@ with open(f"{DST}/{TAG}_pmc_hbm.md", "w") as f:
             rd, wr = 2 * fs[k]["FETCH_SIZE"] * 1e6 * 1024 / 1e6, ws[k]["WRITE_SIZE"] * 1e6 * 1024 / 1e6
             f.write(f"| {k} | {fs[k]['dur']:.1f} | {rd:.1f} | {wr:.1f} | {a:.1f} | {(rd + wr) / a:.3f} |\n")
     f.write("\nThe register-stationary kernels with ONE workgroup type (64<->32 channels) read every image once (83.9 MB in, 167.8 MB\n"
-            "out for the forward); the 128<->64 pair (4 workgroup types) re-reads its input through L2 / MALL (2 x FETCH counts the\n"
-            "fabric requests: 169.5 MB for a 41.9 MB tensor read by 4 types).\n")
+            "out for the forward).  The 128<->64 pair has 4 workgroup types per worker, each reading the same images: until round 4\n"
+            "they sat on four XCDs (type = block % 4) and the input crossed the fabric 2.0-2.5 times (169.5 MB for a 41.9 MB tensor);\n"
+            "with the types of a worker on ONE XCD (slot = block / 8 on XCD block % 8, type = slot % 4) the ratio is 1.00-1.04.\n"
+            "d16_tn_kernel: slice index = XCD index (3.9x before).\n")
 k = "recon_nll_kernel<1, true>"
 if k in fs and k in ws:
     rd, wr = int(2 * fs[k]["FETCH_SIZE"] * 1e6 * 1024), int(ws[k]["WRITE_SIZE"] * 1e6 * 1024)
