@@ -131,19 +131,25 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const HeadsBwdArgs g) {
   __syncthreads();
   {  // backward data: thread = (row, half of the 16 columns)
     const int m = tid >> 1, kh = (tid & 1) * 8;
-    float acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    // (packed fp32 FMAs: the same chain per column in the same order, half the vector-ALU instructions)
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    f32x2_ pa[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll 4
     for (int c = 0; c < NN; ++c) {
       const float dy = dYs[m * NNP + c];
+      const f32x2_ dd = {dy, dy};
       const f32x4 w0 = *reinterpret_cast<const f32x4*>(Ws + c * HB_KC + kh);
       const f32x4 w1 = *reinterpret_cast<const f32x4*>(Ws + c * HB_KC + kh + 4);
+      pa[0] = __builtin_elementwise_fma(dd, f32x2_{w0[0], w0[1]}, pa[0]);
+      pa[1] = __builtin_elementwise_fma(dd, f32x2_{w0[2], w0[3]}, pa[1]);
+      pa[2] = __builtin_elementwise_fma(dd, f32x2_{w1[0], w1[1]}, pa[2]);
+      pa[3] = __builtin_elementwise_fma(dd, f32x2_{w1[2], w1[3]}, pa[3]);
+    }
+    float acc[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[e] = fmaf(dy, w0[e], acc[e]);
-        acc[4 + e] = fmaf(dy, w1[e], acc[4 + e]);
-      }
+    for (int e = 0; e < 4; ++e) {
+      acc[2 * e] = pa[e][0];
+      acc[2 * e + 1] = pa[e][1];
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -158,14 +164,17 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const HeadsBwdArgs g) {
   }
   if (tid < NN * (HB_KC / 4)) {  // weight gradients: thread = (head column, 4 columns of X), rows in order
     const int c = tid / (HB_KC / 4), q = tid % (HB_KC / 4), h = c >= N ? 1 : 0, n = c - h * N;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    f32x2_ g01 = {0.f, 0.f}, g23 = {0.f, 0.f};
 #pragma unroll 8
     for (int m = 0; m < HB_MR; ++m) {
       const float dy = dYs[m * NNP + c];
+      const f32x2_ dd = {dy, dy};
       const f32x4 x = *reinterpret_cast<const f32x4*>(Xs + m * HB_XS + 4 * q);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] = fmaf(dy, x[e], acc[e]);
+      g01 = __builtin_elementwise_fma(dd, f32x2_{x[0], x[1]}, g01);
+      g23 = __builtin_elementwise_fma(dd, f32x2_{x[2], x[3]}, g23);
     }
+    const f32x4 acc = {g01[0], g01[1], g23[0], g23[1]};
     float* slab = g.wslab[h] + (long long)rg * N * K + (long long)n * K;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -358,15 +367,21 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const SmallKArgs g) {
   float amax_l = 0.f;
   if (active)
   for (int r = rg; r < R && m0 + r < g.M; r += rgn) {
-    f32x4 acc = b4;
+    // packed fp32 FMAs (v_pk_fma_f32: two columns per instruction, the row's x broadcast to both halves): the same FMA chain per
+    // column in the same k order, half the vector-ALU instructions of a loop that is bound by them (80 FMAs per 16-byte store)
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    f32x2_ a01 = {b4[0], b4[1]}, a23 = {b4[2], b4[3]};
 #pragma unroll
     for (int q = 0; q < K4; ++q) {
       const f32x4 x = *reinterpret_cast<const f32x4*>(&xs[r][4 * q]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = fmaf(x[e], w[4 * q + e][j], acc[j]);
+      for (int e = 0; e < 4; ++e) {
+        const f32x2_ xx = {x[e], x[e]};
+        a01 = __builtin_elementwise_fma(xx, f32x2_{w[4 * q + e][0], w[4 * q + e][1]}, a01);
+        a23 = __builtin_elementwise_fma(xx, f32x2_{w[4 * q + e][2], w[4 * q + e][3]}, a23);
+      }
     }
+    f32x4 acc = {a01[0], a01[1], a23[0], a23[1]};
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = mvk_act(acc[j], g.act);
     f32x4* const dst = reinterpret_cast<f32x4*>(g.Y + (long long)(m0 + r) * g.N + n);
