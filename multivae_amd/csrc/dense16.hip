@@ -234,7 +234,12 @@ struct D16Nt {
 };
 
 template <int BM, int EPI>
-__global__ __launch_bounds__(256, BM == 64 ? 2 : D16_NT128_OCC) void d16_nt_kernel(const D16Nt g) {
+#ifndef D16_NT64_BWD_OCC
+#define D16_NT64_BWD_OCC 2  // occupancy bound of the 64-row backward-data form.  4 = at most 128 registers, so that a wave fits beside a
+// register-stationary one (imgconv DOWN forms hold 348-368 of a SIMD's 512 registers; this kernel's 173 do not fit and its launch
+// waits for theirs to end): measured, it DOES run beside them then — with 87 spilled registers, 227 us instead of 36, step +9 %.
+#endif
+__global__ __launch_bounds__(256, BM == 64 ? (EPI == 1 ? D16_NT64_BWD_OCC : 2) : D16_NT128_OCC) void d16_nt_kernel(const D16Nt g) {
   constexpr int BN = 128, TM = BM / 64, TN = 2;
   constexpr int APL = BM * 64, BPL = BN * 64;  // bytes per plane tile
   constexpr int STAGE = 2 * APL + 2 * BPL;
