@@ -276,6 +276,12 @@ __global__ __launch_bounds__(256, BM == 64 ? (EPI == 1 ? D16_NT64_BWD_OCC : 2) :
   struct Raw {
     u32x4 ah[NA], al[NA], bh[NB], bl[NB];
   };
+#ifndef D16_BWD_ONESET
+#define D16_BWD_ONESET 0  // 1: the 64-row backward-data form loads ONE k-tile ahead (one register set: 173 -> 149 registers, no spills).
+// It then fits beside imgconv<DOWN, 4, 64, 128> (352 + 152) and runs there: 106 -> 133 us while that launch goes 106 -> 130 us,
+// step +0.7 % (four same-box pairs).  Two MFMA-heavy kernels on one SIMD share a power-limited matrix pipe: co-residency is zero-sum.
+#endif
+  constexpr bool ONESET = BM == 64 && EPI == 1 && D16_BWD_ONESET;
   Raw R0, R1;
   auto sel = [](bool ok, int off) { return __builtin_unpredictable(ok) ? off : 0x7fffffff; };  // out of range = zero fill
   auto gload = [&](Raw& r, int k0) {
@@ -358,14 +364,18 @@ __global__ __launch_bounds__(256, BM == 64 ? (EPI == 1 ? D16_NT64_BWD_OCC : 2) :
   const unsigned long long tk0 = (g.dbg & 16) ? __builtin_readcyclecounter() : 0ull;
   gload(R0, 0);
   lwrite(R0, lds);
-  gload(R1, 32);
-  gload(R0, 64);
+  if (ONESET) {
+    gload(R0, 32);
+  } else {
+    gload(R1, 32);
+    gload(R0, 64);
+  }
   __syncthreads();
   rfrag(FA, lds, 0);
   // one k-tile: LDS stage `cur` is multiplied; tile t+1 goes from `rw` to stage `nxt`, then tile t+3 is fetched into `rw`
   auto ktile = [&](int t, const char* cur, char* nxt, Raw& rw) {
     lwrite(rw, nxt);               // tile t+1 (the last readers of `nxt` passed the barrier of iteration t-1)
-    gload(rw, (t + 3) * 32);       // past the end of K: out of range, zero fill, no traffic
+    gload(rw, (t + (ONESET ? 2 : 3)) * 32);  // past the end of K: out of range, zero fill, no traffic
     rfrag(FB, cur, 1);
     mfmas(FA);
     D16_INTERLEAVE(2)
@@ -375,7 +385,7 @@ __global__ __launch_bounds__(256, BM == 64 ? (EPI == 1 ? D16_NT64_BWD_OCC : 2) :
     D16_INTERLEAVE(1)
   };
   for (int t = 0; t < nt; t += 2) {  // an odd nt runs one k-tile of zeros (zero-filled loads)
-    ktile(t, lds, lds + STAGE, R1);
+    ktile(t, lds, lds + STAGE, ONESET ? R0 : R1);
     ktile(t + 1, lds + STAGE, lds, R0);
   }
 
