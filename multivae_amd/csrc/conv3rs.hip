@@ -135,8 +135,17 @@ __device__ __forceinline__ void c3rs_body(const C3Args& g) {
   mvk_prof_begin(g.prof);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, kg = lane >> 5;
-  const int wgtype = blockIdx.x % T::WG_TYPES;
-  const int worker = blockIdx.x / T::WG_TYPES, workers = gridDim.x / T::WG_TYPES;
+  // workgroup types of one worker read the same positions: all of them on ONE XCD (block b runs on XCD b % 8; imgconv.hip)
+  int wgtype = blockIdx.x % T::WG_TYPES;
+  int worker = blockIdx.x / T::WG_TYPES;
+  const int workers = gridDim.x / T::WG_TYPES;
+#ifndef MVK_NO_XCDMAP
+  if (T::WG_TYPES > 1 && gridDim.x % (8 * T::WG_TYPES) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    wgtype = slot % T::WG_TYPES;
+    worker = xcd * (gridDim.x / (8 * T::WG_TYPES)) + slot / T::WG_TYPES;
+  }
+#endif
   const int role = wgtype * T::NW + wave;
   const int ct = role / T::KSPLIT, ks = role % T::KSPLIT;
   const int ncol = ct * 32 + col;
@@ -721,8 +730,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, kg = lane >> 5;
   const int cit = g.Cin / 64, types = cit * (g.Cout / 64);
-  const int wgtype = blockIdx.x % types;
-  const int worker = blockIdx.x / types, workers = gridDim.x / types;
+  int wgtype = blockIdx.x % types;
+  int worker = blockIdx.x / types;
+  const int workers = gridDim.x / types;
+#ifndef MVK_NO_XCDMAP
+  if (types > 1 && gridDim.x % (8 * types) == 0) {  // the types of a worker on one XCD (imgconv.hip)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    wgtype = slot % types;
+    worker = xcd * (gridDim.x / (8 * types)) + slot / types;
+  }
+#endif
   const int ci0 = (wgtype % cit) * 64, co0 = (wgtype / cit) * 64;
   const int h = wave & 1, c = wave >> 1;  // this wave's 32-channel tiles of the block
 
