@@ -808,6 +808,13 @@ def test_small_up_fwd_scaled_fp16(K, n, xrows, spread):
     call("mvk_conv4s2_small_up_fwd_nll_w", ptr(Vd), ptr(Wd), ptr(bd), ptr(Xd), xrows, scale, gw, ptr(dpre2), ptr(rows2), n, h, w, Cu, Cv, 2,
          stream_ptr())
     close(rows, rows2, rtol=2e-6, what="scaled vs bf16-piece tail rows")
+    if n <= 8:  # edge values: an all-zero map under a zero bound (scale clamps, no NaN), then a bound far above the data
+        Z, zero = torch.zeros_like(Vd), torch.zeros(1, device=d)
+        call("mvk_conv4s2_small_up_fwd_s", ptr(Z), ptr(Wd), ptr(bd), ptr(out), n, h, w, Cu, Cv, 2, ptr(zero), stream_ptr())
+        close(out, torch.sigmoid(b.double()).view(1, Cu, 1, 1).expand(n, Cu, 2 * h, 2 * w), what="scaled small up fwd, zero map")
+        loose = amax * 1000.0  # a 1000x loose bound costs range, not precision
+        call("mvk_conv4s2_small_up_fwd_s", ptr(Vd), ptr(Wd), ptr(bd), ptr(out), n, h, w, Cu, Cv, 2, ptr(loose), stream_ptr())
+        close(out, ref, what="scaled small up fwd, loose bound")
 
 
 @pytest.mark.parametrize("M,N,Kd", [(40960, 128, 1024), (4096, 64, 2048), (65536, 32, 512), (8192, 64, 96)])
