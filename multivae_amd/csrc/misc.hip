@@ -67,6 +67,86 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs jobs) {
     return;
   }
   const int total = d.Cv * d.Cu * 16;
+#ifndef MVK_PACK_TILED
+#define MVK_PACK_TILED 1
+#endif
+  // Tiled form (round 4): the element-per-thread loop below reads coalesced and issues up to EIGHT scattered 2- / 4-byte stores per
+  // element (two fp32 packs + 2 x 3 bf16 fragment pieces: 3.2 M partial-line writes per launch, ~20 us at the head of every
+  // step).  Here a workgroup takes a tile of 8 cv x 8 cu x 16 taps through LDS and writes every destination in 16-byte pieces:
+  // 8 consecutive cv of a (tap, cu) are contiguous in Wdown and form one fragment chunk of Fup, 8 consecutive cu of a (tap, cv)
+  // are contiguous in Wup and form one chunk of Fdown — 1280 stores of 16 bytes per 1024 elements instead of 8192 small ones.
+  // Same values in the same places.
+  if (MVK_PACK_TILED && d.kind == 0 && d.Cu % 8 == 0 && d.Cv % 8 == 0 && d.ld_down % 4 == 0 && d.col_off % 4 == 0 &&
+      mvk_dev_aligned16(d.Wref) && (!d.Wdown || mvk_dev_aligned16(d.Wdown)) && (!d.Wup || mvk_dev_aligned16(d.Wup))) {
+    __shared__ __attribute__((aligned(16))) float T[8][8][16];  // [cv][cu][tap]
+    const int tcu = d.Cu / 8, ntiles = (d.Cv / 8) * tcu, t = threadIdx.x;
+    typedef float pf4 __attribute__((ext_vector_type(4)));
+    typedef unsigned pu4 __attribute__((ext_vector_type(4)));
+    float wmax = 0.f;  // max |Wref| over this workgroup's tiles: published once per workgroup (no second pass over the weight)
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const int cv0 = (tile / tcu) * 8, cu0 = (tile % tcu) * 8;
+      __syncthreads();  // the previous tile's readers are done
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = t + 256 * r, cvl = e >> 7, rem = e & 127;  // 128 contiguous floats per cv
+        const float v = d.Wref[((long long)(cv0 + cvl) * d.Cu + cu0) * 16 + rem];
+        (&T[0][0][0])[e] = v;
+        wmax = fmaxf(wmax, fabsf(v));
+      }
+      __syncthreads();
+      const int pair = t >> 1, half = t & 1, tap = pair >> 3, l8 = pair & 7;
+      const int kh = tap >> 2, kw = tap & 3, ph = 1 - (kh & 1), a = kh >> 1, pw = 1 - (kw & 1), b = kw >> 1;
+      if (d.Wdown) {  // (tap, cu = l8): cv0 + 4 half .. + 3
+        const pf4 v = {T[4 * half][l8][tap], T[4 * half + 1][l8][tap], T[4 * half + 2][l8][tap], T[4 * half + 3][l8][tap]};
+        *reinterpret_cast<pf4*>(d.Wdown + (long long)(tap * d.Cu + cu0 + l8) * d.ld_down + d.col_off + cv0 + 4 * half) = v;
+      }
+      if (d.Wup) {  // (tap, cv = l8): cu0 + 4 half .. + 3
+        const pf4 v = {T[l8][4 * half][tap], T[l8][4 * half + 1][tap], T[l8][4 * half + 2][tap], T[l8][4 * half + 3][tap]};
+        *reinterpret_cast<pf4*>(d.Wup + ((long long)(ph * 2 + pw) * 4 * d.Cv + (a * 2 + b) * d.Cv + cv0 + l8) * d.Cu + cu0 + 4 * half) = v;
+      }
+      if (t < 128 && d.Fdown) {  // item (tap, cv = l8'): the 8 cu of the tile = one 16-byte chunk per piece
+        const int tp = t >> 3, cvl = t & 7, cv = cv0 + cvl;
+        const int chunks = d.Cu / 16, ntaps = 16 / chunks, ksplit = 16 / ntaps, nct = d.Cv / 32;
+        const int ks = tp / ntaps, q = tp % ntaps, ct = cv / 32;
+        const int role = nct * ksplit <= 4 ? ks * nct + ct : ct * 4 + ks;
+        const int kk = q * chunks + cu0 / 16, lane = ((cu0 % 16) / 8) * 32 + cv % 32;
+        pu4 pc[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned p0, p1, p2;
+          mvk::bf3_split(T[cvl][2 * j][tp], T[cvl][2 * j + 1][tp], p0, p1, p2);
+          pc[0][j] = p0;
+          pc[1][j] = p1;
+          pc[2][j] = p2;
+        }
+        pu4* f = static_cast<pu4*>(d.Fdown);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) f[(((long long)role * 16 + kk) * 3 + p) * 64 + lane] = pc[p];
+      }
+      if (t >= 128 && d.Fup) {  // item (tap, cu): the 8 cv of the tile
+        const int i = t - 128, tp = i >> 3, cul = i & 7, cu = cu0 + cul;
+        const int kh2 = tp >> 2, kw2 = tp & 3, ph2 = 1 - (kh2 & 1), a2 = kh2 >> 1, pw2 = 1 - (kw2 & 1), b2 = kw2 >> 1;
+        const int chunks = d.Cv / 16, ntaps = 16 / chunks, ksplit = 4 / ntaps, nct = d.Cu / 32;
+        const int t4 = a2 * 2 + b2, ks = t4 / ntaps, q = t4 % ntaps, ct = cu / 32;
+        const int role = (ph2 * 2 + pw2) * (ksplit * nct) + ks * nct + ct;
+        const int kk = q * chunks + cv0 / 16, lane = ((cv0 % 16) / 8) * 32 + cu % 32;
+        pu4 pc[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned p0, p1, p2;
+          mvk::bf3_split(T[2 * j][cul][tp], T[2 * j + 1][cul][tp], p0, p1, p2);
+          pc[0][j] = p0;
+          pc[1][j] = p1;
+          pc[2][j] = p2;
+        }
+        pu4* f = static_cast<pu4*>(d.Fup);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) f[(((long long)role * 16 + kk) * 3 + p) * 64 + lane] = pc[p];
+      }
+    }
+    if (d.amax && blockIdx.x < ntiles) mvk::amax_publish(wmax, d.amax, amax_red);  // uniform per workgroup; <= ntiles atomics, most skipped
+    return;
+  }
   for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
     const int tap = idx & 15;
     const int cu = (idx >> 4) % d.Cu;
