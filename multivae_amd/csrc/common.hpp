@@ -30,6 +30,23 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// The same total without the LDS crossbar: four DPP steps sum every 16-lane row into each of its lanes (quad permutes, half-row and
+// row mirrors: register-to-register, no ds_bpermute), then the four rows are added in a fixed order from scalar reads.  __shfl_xor is
+// six DEPENDENT ds_bpermute_b32 (~700 cycles per call): per image in the fused decoder tail that was ~3 us of a 55-us launch.
+// Deterministic; the order differs from wave_sum's, so the two are not interchangeable where bit-identity between paths matters.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define MVK_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, false))
+  MVK_DPP_ADD(0xB1);   // quad_perm [1, 0, 3, 2]
+  MVK_DPP_ADD(0x4E);   // quad_perm [2, 3, 0, 1]
+  MVK_DPP_ADD(0x141);  // row_half_mirror
+  MVK_DPP_ADD(0x140);  // row_mirror
+#undef MVK_DPP_ADD
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));

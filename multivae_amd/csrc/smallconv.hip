@@ -324,7 +324,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
         part = fmaf(0.5f * inv_s2 * dlt, dlt, part);
         out[tid + t * NT] = dlt * g_inv_s2 * mvk_act_grad_from_out(r, act);
       }
-      part = wave_sum(part);
+      part = wave_sum_dpp(part);
       if (lane == 0) buf[zidx + 1 + wave] = part;
     } else {
 #pragma unroll
@@ -334,10 +334,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
       }
     }
     __syncthreads();  // the column matrix is overwritten by the next image's pieces
-    if (NLL && tid == 0) {  // the wave partials are rewritten three barriers from now at the earliest
-      float tot = 0.f;
-      for (int wv = 0; wv < NT / 64; ++wv) tot += buf[zidx + 1 + wv];
-      rows[img] = tot + lconst;
+    if (NLL && wave == 0) {  // the wave partials are rewritten three barriers from now at the earliest
+      float tot = lane < NT / 64 ? buf[zidx + 1 + lane] : 0.f;  // a fixed shuffle tree over the partials (small_up_fwd_h_kernel)
+#pragma unroll
+      for (int off = NT / 128; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
+      if (lane == 0) rows[img] = tot + lconst;
     }
   }
   mvk_prof_end(prof);
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
     if (NLL) {
       const float* xt = X + (img % xrows) * per_img;
 #pragma unroll
-      for (int t = 0; t < NO; ++t) xv[t] = xt[tid + t * NT];
+      for (int t = 0; t < NO; ++t) xv[t] = (MVK_SUF_ABL & 32) ? 0.25f : xt[tid + t * NT];
     }
     f32x4 res[MT][CU];  // D[nn = b * 16 + 4 lq + r][pos = wave * WP + a * 16 + l15]
     {
@@ -498,11 +499,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
       for (int t = 0; t < NO; ++t) {
         const float sum = ((buf[tap[t][0]] + buf[tap[t][1]]) + (buf[tap[t][2]] + buf[tap[t][3]])) + bia[t];
         const float r = act == MVK_ACT_SIGMOID ? mvk_fast_sigmoid(sum) : mvk_act(sum, act), dlt = r - xv[t];
-        part = fmaf(0.5f * inv_s2 * dlt, dlt, part);
+        if (!(MVK_SUF_ABL & 64)) part = fmaf(0.5f * inv_s2 * dlt, dlt, part);
         out[tid + t * NT] = dlt * g_inv_s2 * mvk_act_grad_from_out(r, act);
       }
-      part = wave_sum(part);
-      if (lane == 0) buf[zidx + 1 + wave] = part;
+      if (!(MVK_SUF_ABL & 64)) {
+        part = wave_sum_dpp(part);
+        if (lane == 0) buf[zidx + 1 + wave] = part;
+      }
     } else {
 #pragma unroll
       for (int t = 0; t < NO; ++t) {
@@ -511,10 +514,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
       }
     }
     __syncthreads();  // the column matrix is overwritten by the next image's pieces
-    if (NLL && tid == 0) {  // the wave partials are rewritten three barriers from now at the earliest
-      float tot = 0.f;
-      for (int wv = 0; wv < NT / 64; ++wv) tot += buf[zidx + 1 + wv];
-      rows[img] = tot + lconst;
+    if (NLL && wave == 0 && !(MVK_SUF_ABL & 64)) {  // the wave partials are rewritten three barriers from now at the earliest
+      // (one LDS latency + a fixed shuffle tree over the NT / 64 partials: a serial loop of dependent LDS reads in thread 0 held
+      // its wave back ~3 us per launch at the next barrier)
+      float tot = lane < NT / 64 ? buf[zidx + 1 + lane] : 0.f;
+#pragma unroll
+      for (int off = NT / 128; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
+      if (lane == 0) rows[img] = tot + lconst;
     }
   }
   mvk_prof_end(prof);
