@@ -99,7 +99,13 @@ struct HeadsBwdArgs {
   long long w_sk, w_sn;  // W_h(n, k) = W_h[n * w_sn + k * w_sk]
 };
 
+#ifndef MVK_CHAIN_PRIO
+#define MVK_CHAIN_PRIO 3  // wave priority of the latency-critical chain kernels (s_setprio; 0 = default)
+#endif
 __global__ __launch_bounds__(256) void heads_bwd_kernel(const HeadsBwdArgs g) {
+  // This launch heads the step's last dependent chain and runs beside the decoder's weight gradients (one 512-register MFMA wave
+  // per SIMD, all 256 CUs): 17 us alone, 60-90 us there.  A higher wave priority wins the SIMD's issue arbitration against that wave.
+  if (MVK_CHAIN_PRIO) __builtin_amdgcn_s_setprio(MVK_CHAIN_PRIO);
   __shared__ __attribute__((aligned(16))) float dYs[HB_MR * 65];
   __shared__ __attribute__((aligned(16))) float Ws[64 * HB_KC];
   __shared__ __attribute__((aligned(16))) float Xs[HB_MR * HB_XS];
