@@ -341,6 +341,13 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const SmallKArgs g) {
   const int n = (cg < CT ? cg : 0) * 4;
   const int m0 = blockIdx.x * R;
   f32x4 w[KP];  // w[k] = W(k, n .. n+3)
+#ifndef MVK_SK_ABL
+#define MVK_SK_ABL 0  // subtraction builds (tools/smallk_probe.py): 1 no weight loads, 2 no stores, 4 no FMA loop
+#endif
+  if (MVK_SK_ABL & 1) {
+#pragma unroll
+    for (int k = 0; k < KP; ++k) w[k] = f32x4{0.01f * k, 0.02f, 0.03f, 0.04f * threadIdx.x};
+  } else
   if (g.w_sn == 1 && (g.w_sk & 3) == 0 && mvk_dev_aligned16(g.W)) {  // [K][N] rows: one 16-byte load per k
 #pragma unroll
     for (int k = 0; k < KP; ++k)
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const SmallKArgs g) {
     typedef float f32x2_ __attribute__((ext_vector_type(2)));
     f32x2_ a01 = {b4[0], b4[1]}, a23 = {b4[2], b4[3]};
 #pragma unroll
-    for (int q = 0; q < K4; ++q) {
+    for (int q = 0; q < ((MVK_SK_ABL & 4) ? 1 : K4); ++q) {
       const f32x4 x = *reinterpret_cast<const f32x4*>(&xs[r][4 * q]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const SmallKArgs g) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] += old[j];
     }
-    *dst = acc;
+    if (!(MVK_SK_ABL & 2) || acc[0] == 123.456f) *dst = acc;
     amax_l = fmaxf(fmaxf(amax_l, fmaxf(fabsf(acc[0]), fabsf(acc[1]))), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
   }
   if (g.y_amax) mvk::amax_publish(amax_l, g.y_amax, &xs[0][0]);  // uniform; xs is dead (amax_publish synchronises first)

@@ -9,7 +9,7 @@ z = torch.randn(M, K, device=dev); w = torch.randn(K, N, device=dev) * 0.2; b = 
 y = torch.empty(M, N, device=dev); am = torch.zeros(1, device=dev)
 def run(amax):
     call("mvk_gemm_smallk_amax", ptr(z), ptr(w), ptr(y), M, N, K, 0, ptr(b), 128, 1, ptr(am) if amax else None, stream_ptr())
-for amax in (True,):
+for amax in (True, False):
     for _ in range(3): run(amax)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
