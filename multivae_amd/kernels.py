@@ -7,6 +7,7 @@ and the backward passes use the producer-epilogue fusion of the engine (a layer'
 multiplies by the previous layer's activation derivative and writes the pre-activation gradient directly).
 """
 import ctypes as C
+import math
 
 import os
 
@@ -164,6 +165,18 @@ def late_ready(device):
 _LOSS_EVENT = {}  # device -> event behind the loss assembly when it ran on the late-leaf stream (ReconLossFn, async_ok)
 # MVK_ASYNC_LOSS=0: the loss assembly stays on the caller's stream, between the last forward and the first backward launch
 ASYNC_LOSS = _lib.tune("MVK_ASYNC_LOSS", "1") != "0"
+
+
+def orders_behind_loss(rows):
+    """True when the backward node that produced `rows` (a fused decoder tail's NLL row sums) is one of this package's, i.e.
+    known to call wait_loss before it reads a row gradient the assembly launch fills.  A user decoder may implement
+    `reconstruction_nll` with ordinary autograd ops: its backward would read the row-gradient buffer with NO ordering against an
+    assembly launch on the late-leaf stream — in a captured graph a missing dependency, silently wrong gradients.
+    Models set spec["async_ok"] only when this holds for every fused term."""
+    fn = getattr(rows, "grad_fn", None)
+    if fn is None:
+        return not getattr(rows, "requires_grad", False)
+    return isinstance(fn, (MLPDecoderFn._backward_cls, SVHNDecoderFn._backward_cls))
 
 
 def wait_loss(device):
@@ -1269,6 +1282,14 @@ def const_grad(t):
     return value
 
 
+def _check_nll_weight(nll_x, nll_weight):
+    """The fused tails store nll_weight * d NLL / d pre-activation and divide by it on their general backward path: a zero or
+    non-finite weight has no such form (the decoders' `reconstruction_nll` return None for it and the caller takes the generic
+    likelihood kernel)."""
+    if nll_x is not None and not (math.isfinite(float(nll_weight)) and float(nll_weight) != 0.0):
+        raise _lib.MvkError(f"fused decoder tail: nll_weight must be finite and non-zero, got {nll_weight}")
+
+
 class MLPDecoderFn(Function):
     """z[...,L] -> Linear+ReLU -> Linear+Sigmoid -> reshape(*z.shape[:-1], *input_dim).
 
@@ -1281,6 +1302,7 @@ class MLPDecoderFn(Function):
 
     @staticmethod
     def forward(ctx, z, w0, b0, w1, b1, input_dim, nll_x=None, nll_scale=1.0, nll_weight=1.0):
+        _check_nll_weight(nll_x, nll_weight)
         L = w0.shape[1]
         z2 = _c(z.reshape(-1, L))
         ctx.fused = nll_x is not None
@@ -1495,6 +1517,7 @@ class SVHNDecoderFn(Function):
         Normal(nll_scale) likelihood in its epilogue (mvk_conv4s2_small_up_fwd_nll) and the node returns the NLL row sums
         [*z.shape[:-1]] instead of the images; the buffer that would hold the images holds d rows / d pre-activation for the
         backward pass.  The caller checks `svhn_fused_tail_ok` first."""
+        _check_nll_weight(nll_x, nll_weight)
         L = w0.shape[0]
         z2 = _c(z.reshape(-1, L))
         n = z2.shape[0]

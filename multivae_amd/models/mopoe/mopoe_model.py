@@ -245,7 +245,9 @@ class MoPoE(BaseMultiVAE):
                     loss_sum_scale=float(B),
                     # the backward nodes of every extra term (MoPoEPosteriorFn, GaussSampleKLFn, the fused tails) order themselves
                     # behind the assembly launch where they read what it fills: it may run beside the backward chain
-                    async_ok=masks is None)
+                    # — only when every fused term's node is one of the package's (kernels.orders_behind_loss): a user decoder's
+                    # `reconstruction_nll` built from plain autograd ops would read the row gradients unordered
+                    async_ok=masks is None and all(kernels.orders_behind_loss(rec[m][1]) for m in fused))
         if style_kl and masks is not None:  # style_kld *= mask (:217-218), still averaged over the whole batch
             style_kl = [kl * masks[m].to(kl.dtype) for kl, m in zip(style_kl, names)]
         loss, terms = kernels.ReconLossFn.apply(spec, M, *recons, kld_rows, *style_kl, *[rec[m][1] for m in fused])

@@ -5,6 +5,7 @@ The `nn.Linear` / `nn.Sequential` objects are parameter containers only (they gi
 `layers.0.0.weight`, `embedding.weight`, ... and the default initialisation); `forward` never calls them:
 the whole network is one autograd node (`kernels.MLPEncoderFn` / `kernels.MLPDecoderFn`).
 """
+import math
 from typing import List
 
 import numpy as np
@@ -88,7 +89,11 @@ class Decoder_AE_MLP(BaseDecoder):
                 or x.device != z.device or x.shape[0] == 0 or n % x.shape[0] != 0 or x[0].numel() != D
                 or not kernels.mlp_fused_tail_ok(n, l0.weight.shape[1], l0.weight.shape[0], D)):
             return None
+        if row_weight is not None and not (math.isfinite(float(row_weight)) and float(row_weight) != 0.0):
+            return None  # a zero / non-finite weight has no pre-multiplied gradient form (its bound would be 0): generic path
         x2 = x.float().reshape(x.shape[0], D).contiguous()
+        if x2.data_ptr() % 16:  # a view into a larger storage: the kernel reads the targets with 16-byte loads
+            x2 = x2.clone()
         return kernels.MLPDecoderFn.apply(z, l0.weight, l0.bias, l1.weight, l1.bias, self.input_dim, x2, float(scale),
                                           1.0 if row_weight is None else float(row_weight))
 

@@ -2,6 +2,8 @@
 (`multivae/models/nn/svhn.py:7-70`), computed by the implicit-GEMM fp32-MFMA kernels on NHWC activations.
 The `nn.Conv2d` / `nn.ConvTranspose2d` objects only hold the parameters (state_dict keys `enc.0.weight`,
 `c1.weight`, `dec.0.weight`, ...)."""
+import math
+
 import torch
 from torch import nn
 
@@ -85,7 +87,11 @@ class Decoder_VAE_SVHN(BaseDecoder):
         if (tuple(x.shape[1:]) != (d[6].weight.shape[1], 32, 32) or not x.is_cuda or x.device != z.device
                 or x.shape[0] == 0 or n % x.shape[0] != 0):
             return None
+        if row_weight is not None and not (math.isfinite(float(row_weight)) and float(row_weight) != 0.0):
+            return None  # no pre-multiplied gradient form for a zero / non-finite weight: generic path
         x = x.float().contiguous()
+        if x.data_ptr() % 16:
+            x = x.clone()
         return kernels.SVHNDecoderFn.apply(z, d[0].weight, d[0].bias, d[2].weight, d[2].bias, d[4].weight, d[4].bias,
                                            d[6].weight, d[6].bias, x, float(scale),
                                            1.0 if row_weight is None else float(row_weight))

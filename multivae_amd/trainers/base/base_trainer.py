@@ -472,6 +472,8 @@ class BaseTrainer:
         if self.is_main_process:
             self.save_model(self._best_model, dir_path=final_dir)
         if self.distributed:
+            if self.flat is not None:
+                self.flat.close()  # the RCCL communicator of mvk_allreduce_avg, before the process group it was built through
             dist.destroy_process_group()
         self.callback_handler.on_train_end(cfg)
         self.history = history

@@ -80,6 +80,8 @@ class FlatParams:
 
         dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
 
+    SEG_FLOATS = 1 << 19  # ~2 MB segments inside one RCCL group: 6.2 MB (MnistSvhn) = 3 segments, 96.6 MB (cfg5) = 46
+
     def all_reduce_mean(self, group=None):
         """ONE collective over the whole gradient buffer, the mean over the ranks — what the reference's DDP wrapper leaves in
         `.grad` (trainers/base/base_trainer.py:92-117).  Returns the factor the optimizer still has to apply (`grad_scale`):
@@ -93,14 +95,79 @@ class FlatParams:
         if comm is None:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
             return 1.0 / world
-        # segments of ~2 MB issued as one RCCL group: 6.2 MB for the MnistSvhn models = 3 segments, 96.6 MB at cfg5 = 46
-        nseg = max(1, min(64, (self.grad.numel() * 4 + (1 << 21) - 1) >> 21))
+        nseg = max(1, min(64, (self.grad.numel() + self.SEG_FLOATS - 1) // self.SEG_FLOATS))
         _lib.call("mvk_allreduce_avg", _lib.ptr(self.grad), self.grad.numel(), nseg, comm, _lib.stream_ptr())
         return 1.0
 
+    def all_reduce_mean_ranges(self, ranges, group=None):
+        """The same mean over the ranks for a list of disjoint (offset, count) ranges of the gradient buffer, on the CURRENT
+        stream (the overlapped step calls it twice: the ranges that are final early on the communication stream, the rest
+        behind the backward pass).  Same return value as all_reduce_mean; every rank must call it with the same ranges."""
+        import ctypes as C
+
+        import torch.distributed as dist
+
+        world = dist.get_world_size(group)
+        ranges = [(int(o), int(n)) for o, n in ranges if n > 0]
+        comm = self._rccl_comm(group)
+        if comm is None:
+            for o, n in ranges:
+                dist.all_reduce(self.grad[o:o + n], op=dist.ReduceOp.SUM, group=group)
+            return 1.0 / world
+        off = (C.c_int64 * len(ranges))(*[o for o, _ in ranges])
+        cnt = (C.c_int64 * len(ranges))(*[n for _, n in ranges])
+        _lib.call("mvk_allreduce_avg_ranges", _lib.ptr(self.grad), off, cnt, len(ranges), self.SEG_FLOATS, comm, _lib.stream_ptr())
+        return 1.0
+
+    def complement(self, ranges):
+        """The part of [0, numel) outside the given (offset, count) ranges, as sorted disjoint ranges."""
+        out, pos = [], 0
+        for o, n in sorted((int(o), int(n)) for o, n in ranges):
+            if o > pos:
+                out.append((pos, o - pos))
+            pos = max(pos, o + n)
+        if pos < self.numel:
+            out.append((pos, self.numel - pos))
+        return out
+
+    def ranges_of(self, params):
+        """(offset, padded count) of the given parameters inside the flat buffers, merged where adjacent (a module's parameters
+        are neighbours: one range).  Parameters that are not views of the buffer are ignored."""
+        pos = {id(p): (off, (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN) for p, off in zip(self.params, self.offsets)}
+        got = sorted(pos[id(p)] for p in params if id(p) in pos)
+        out = []
+        for o, n in got:
+            if out and out[-1][0] + out[-1][1] == o:
+                out[-1] = (out[-1][0], out[-1][1] + n)
+            else:
+                out.append((o, n))
+        return out
+
+    def world_size(self, group=None):
+        """The number of ranks the gradient collective runs over, as the COMMUNICATOR reports it (ncclCommCount) when the RCCL
+        path is in use, else the process group's size; 1 without a process group."""
+        import ctypes as C
+
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1
+        comm = self._rccl_comm(group)
+        if comm is None:
+            return dist.get_world_size(group)
+        w = C.c_int(0)
+        _lib.call("mvk_comm_size", comm, C.byref(w), None)
+        return int(w.value)
+
     def _rccl_comm(self, group=None):
         """The RCCL communicator behind mvk_allreduce_avg (created on first use: rank 0 draws the rendezvous id, the default
-        process group carries it to the other ranks), or None when the process group is not RCCL-backed."""
+        process group carries it to the other ranks), or None when the process group is not RCCL-backed.
+
+        Collective-safe: nothing here raises on ONE rank while the others wait.  Every rank first reports whether
+        RCCL resolves in its process (mvk_comm_available, no collective), rank 0 additionally whether it could draw the id; the
+        ranks agree (all_reduce MIN over the process group) before anyone enters ncclCommInitRank, agree again on its outcome,
+        and fall back to torch.distributed's all_reduce TOGETHER if any of them failed.  `_comm_checked` is set only behind
+        that agreement; the communicator is destroyed by close() (BaseTrainer at the end of train(), bench.py at exit)."""
         import os
 
         import torch.distributed as dist
@@ -109,24 +176,62 @@ class FlatParams:
             return None
         if getattr(self, "_comm_checked", False):
             return self._comm
-        self._comm_checked, self._comm = True, None
         if dist.get_backend() != "nccl":
+            self._comm_checked, self._comm = True, None
             return None
         import ctypes as C
+        import warnings
 
         lib = _lib.load()
+        ok = bool(lib.mvk_comm_available())
         nbytes = lib.mvk_comm_id_bytes()
         uid = (C.c_ubyte * nbytes)()
-        if dist.get_rank() == 0:
-            _lib.call("mvk_comm_unique_id", uid)
+        if ok and dist.get_rank() == 0:
+            ok = lib.mvk_comm_unique_id(uid) == _lib.MVK_OK
         box = [bytes(uid)]
-        dist.broadcast_object_list(box, src=0)
-        uid = (C.c_ubyte * nbytes).from_buffer_copy(box[0])
+        dist.broadcast_object_list(box, src=0)  # carried unconditionally: every rank takes part whatever its own `ok`
+
+        def agreed(flag):
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.grad.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+
         comm = C.c_void_p()
-        with torch.cuda.device(self.grad.device):
-            _lib.call("mvk_comm_init", C.byref(comm), dist.get_world_size(), dist.get_rank(), uid)
-        self._comm = comm
+        if agreed(ok):
+            uid = (C.c_ubyte * nbytes).from_buffer_copy(box[0])
+            with torch.cuda.device(self.grad.device):
+                ok = lib.mvk_comm_init(C.byref(comm), dist.get_world_size(), dist.get_rank(), uid) == _lib.MVK_OK
+            w = C.c_int(0)
+            ok = ok and lib.mvk_comm_size(comm, C.byref(w), None) == _lib.MVK_OK and w.value == dist.get_world_size()
+            if not agreed(ok):
+                if comm:
+                    lib.mvk_comm_destroy(comm)
+                comm = C.c_void_p()
+        if not comm:
+            warnings.warn("RCCL communicator for mvk_allreduce_avg could not be created on every rank: the gradient "
+                          "collective falls back to torch.distributed.all_reduce on all ranks", RuntimeWarning)
+            self._comm_checked, self._comm = True, None
+            return None
+        self._comm_checked, self._comm = True, comm
         return comm
+
+    def close(self):
+        """Destroy the RCCL communicator (the reference tears its process group down at the end of train(),
+        trainers/base/base_trainer.py:613-614).  Idempotent; the next collective would create a new one."""
+        comm = getattr(self, "_comm", None)
+        self._comm, self._comm_checked = None, False
+        if comm:
+            if self.grad.is_cuda:
+                torch.cuda.synchronize(self.grad.device)
+            _lib.load().mvk_comm_destroy(comm)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_comm", None):
+                _lib.load().mvk_comm_destroy(self._comm)
+                self._comm = None
+        except Exception:
+            pass
 
     def broadcast(self, src=0, group=None):
         import torch.distributed as dist

@@ -1931,3 +1931,53 @@ def test_mlp_decoder_fused_tail_matches_generic_path(monkeypatch):
         for a, b_, (nm, _) in zip(g1, g0, dec.named_parameters()):
             close(a, b_, 1e-5, f"fused MLP tail ({'const' if const else 'general'}): d {nm}")
         close(dz1, dz0, 1e-5, "fused MLP tail: dz")
+
+
+def test_integration_md_binding_runs_with_two_modalities():
+    """the reference-side binding INTEGRATION.md documents is EXECUTED — its code blocks, verbatim, against
+    libmvk.so — with two modalities (the descriptors travel as an array: a wrong struct stride shows up in the second one) and
+    compared with the oracle's restatement of recon_log_probs + row sums (base_utils.py:62-87, mopoe_model.py:186-208)."""
+    from multivae_amd import _lib
+    from test_host_logic import integration_md_python
+
+    code = integration_md_python().replace('C.CDLL("libmvk.so")', f'C.CDLL({_lib.LIB_PATH!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    gen = g(77)
+    Kk, B = 3, 13
+    d = dev()
+    shapes, dists, rescales = [(1, 28, 28), (3, 32, 32)], ["normal", "laplace"], [3.918, 1.0]
+    recons = [torch.randn(Kk, B, *s, generator=gen) for s in shapes]
+    xs = [torch.rand(B, *s, generator=gen) for s in shapes]
+    rows = ns["recon_nll_rows"]([r.to(d) for r in recons], [x.to(d) for x in xs], [_lib.DIST[n] for n in dists], rescales, Kk, B)
+    torch.cuda.synchronize()
+    assert len(rows) == 2
+    for r, x, n, rs, got in zip(recons, xs, dists, rescales, rows):
+        close(got, elbo._row_nll(n, r, x, rs, 1.0), what=f"INTEGRATION.md recon_nll_rows ({n})")
+    # the collective binding of the same document: one rank is a valid world (the W > 1 form needs W devices)
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        import os
+        import socket
+
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        made = True
+    else:
+        made = False
+    try:
+        comm = ns["make_comm"](0, 1)
+        buf = torch.randn(5000, generator=gen).to(d)
+        want = buf.clone()
+        ns["average_gradients"](buf, comm)
+        torch.cuda.synchronize()
+        assert torch.equal(buf, want)  # the mean over one rank
+        assert _lib.load().mvk_comm_destroy(comm) == 0
+    finally:
+        if made:
+            dist.destroy_process_group()

@@ -23,8 +23,8 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/mvk.h but not exported by libmvk.so"
     bound = set(_lib.PROTOTYPES) | {"mvk_splitk_workspace_floats", "mvk_conv4s2_small_up_supported", "mvk_conv4s2_small_up_nll_supported",
                                     "mvk_imgconv_frag_bytes",
-                                    "mvk_debug_set_phase_buffer", "mvk_debug_set_flags", "mvk_dense16_debug",  # void hooks, bound ad hoc
-                                    "mvk_dense16_ok", "mvk_dense16_fwd_nll_rows", "mvk_dense16_colsum_rows", "mvk_comm_id_bytes",
+                                    "mvk_debug_set_phase_buffer", "mvk_debug_set_flags", "mvk_dense16_debug", "mvk_dense16_debug_stamps",  # void hooks, bound ad hoc
+                                    "mvk_dense16_ok", "mvk_dense16_fwd_nll_rows", "mvk_dense16_colsum_rows", "mvk_comm_id_bytes", "mvk_comm_available",
                                     "mvk_prof_enable", "mvk_prof_count", "mvk_prof_clock_khz", "mvk_prof_calibrate",
                                     "mvk_defer_pending", "mvk_defer_wanted", "mvk_conv3x3_fused_ok", "mvk_conv3x3_scaled_ok", "mvk_conv3x3_wgrad_scaled_ok", "mvk_conv4s2_scaled_ok", "mvk_conv4s2_wgrad_scaled_ok"}
     assert declared == bound, (declared - bound, bound - declared)
@@ -42,6 +42,104 @@ def test_argument_counts_match_header():
         args = m.group(1).strip()
         n = 0 if args in ("", "void") else len(args.split(","))
         assert n == len(argtypes), (name, n, len(argtypes))
+
+
+def _header_struct_layouts(tmp_path):
+    """{struct name: (sizeof, [(field, offset, size), ...])} of every `typedef struct` in include/mvk.h, as gcc lays them out
+    (the header is compiled as C: the host ABI of hipcc's x86-64 side is the same)."""
+    import subprocess
+
+    text = open(os.path.join(ROOT, "include", "mvk.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    structs = {}
+    for m in re.finditer(r"typedef\s+struct\s+(\w+)\s*\{(.*?)\}\s*(\w+)\s*;", text, flags=re.S):
+        fields = []
+        for decl in m.group(2).split(";"):
+            decl = decl.strip()
+            if decl:
+                fields += [re.sub(r"\[.*\]", "", f).strip().lstrip("*").strip().split()[-1].lstrip("*") for f in decl.split(",")]
+        structs[m.group(3)] = fields
+    assert structs, "no structs parsed"
+    src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "mvk.h")}"', "int main(void){"]
+    for name, fields in structs.items():
+        src.append(f'printf("S {name} %zu\\n", sizeof({name}));')
+        for f in fields:
+            src.append(f'printf("F {name} {f} %zu %zu\\n", offsetof({name}, {f}), sizeof((({name}*)0)->{f}));')
+    src.append("return 0;}")
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-o", str(exe), str(c)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    res = {}
+    for ln in out.splitlines():
+        t = ln.split()
+        if t[0] == "S":
+            res[t[1]] = (int(t[2]), [])
+        else:
+            res[t[1]][1].append((t[2], int(t[3]), int(t[4])))
+    return res
+
+
+def _assert_layout(cls, want, what):
+    import ctypes as C
+
+    size, fields = want
+    assert C.sizeof(cls) == size, (what, C.sizeof(cls), size)
+    got = [(n, getattr(cls, n).offset, getattr(cls, n).size) for n, _ in cls._fields_]
+    assert got == fields, (what, got, fields)
+
+
+def integration_md_python():
+    """The Python code blocks of INTEGRATION.md section B (the binding a maintainer of the reference would add), joined."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    text = text[text.index("## B."):]
+    return "\n\n".join(re.findall(r"```python\n(.*?)```", text, flags=re.S))
+
+
+def test_struct_layouts_match_header(tmp_path):
+    """Descriptor tables cross the C ABI as ARRAYS: sizeof and every field offset of the ctypes mirrors — the package's and
+    the ones INTEGRATION.md documents — must be what a C compiler makes of include/mvk.h (the documented
+    ReconDesc had lost `n_classes`, stride 72 instead of 80)."""
+    from multivae_amd import _lib
+
+    want = _header_struct_layouts(tmp_path)
+    mirrors = {"mvk_recon_desc": _lib.ReconDesc, "mvk_term_desc": _lib.TermDesc, "mvk_seed_desc": _lib.SeedDesc,
+               "mvk_pack_desc": _lib.PackDesc}
+    assert set(want) == set(mirrors), (set(want) ^ set(mirrors))
+    for name, cls in mirrors.items():
+        _assert_layout(cls, want[name], f"_lib.{cls.__name__}")
+    assert want["mvk_recon_desc"][0] == 80
+    # the documented binding: execute the code blocks (they only define classes / functions and set prototypes)
+    code = integration_md_python().replace('C.CDLL("libmvk.so")', f'C.CDLL({_lib.LIB_PATH!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    documented = {"ReconDesc": "mvk_recon_desc", "TermDesc": "mvk_term_desc", "SeedDesc": "mvk_seed_desc", "PackDesc": "mvk_pack_desc"}
+    seen = [k for k in documented if k in ns]
+    assert "ReconDesc" in seen
+    for k in seen:
+        _assert_layout(ns[k], want[documented[k]], f"INTEGRATION.md {k}")
+    # and its prototypes have the header's argument counts
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mvk.h")).read(), flags=re.S)
+    lib = ns["_lib"]
+    for name in re.findall(r"_lib\.(mvk_\w+)\.argtypes", code) + re.findall(r'\("(mvk_\w+)",\s*\[', code):
+        m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", header, flags=re.S)
+        assert m, name
+        args = m.group(1).strip()
+        n = 0 if args in ("", "void") else len(args.split(","))
+        assert len(getattr(lib, name).argtypes) == n, (name, n)
+
+
+def test_bench_refuses_a_world_size_other_than_gpus():
+    """bench.py --gpus N under a launcher environment of another size exits with status 2 and prints no result line (the check
+    sits in front of everything that needs a GPU)."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29549")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 2 and not r.stdout.strip() and "WORLD_SIZE=2" in r.stderr, (r.returncode, r.stdout, r.stderr[-500:])
 
 
 def test_no_cpu_compute_path():

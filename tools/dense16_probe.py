@@ -145,10 +145,15 @@ timeit(lambda: call("mvk_dense16_pack", ptr(w1), D, Hd, ptr(nk_hi), ptr(nk_lo), 
 if os.environ.get("D16_ABLATE"):
     lib.mvk_dense16_debug.argtypes = [__import__("ctypes").c_int]
     lib.mvk_dense16_debug.restype = None
+    stamps = torch.zeros(4, device=gb.device)
+    lib.mvk_dense16_debug_stamps.argtypes = [__import__("ctypes").c_void_p]
+    lib.mvk_dense16_debug_stamps.restype = None
+    lib.mvk_dense16_debug_stamps(stamps.data_ptr())
     lib.mvk_dense16_debug(16)
     fwd()
     torch.cuda.synchronize()
-    print("cycle stamps [main, epilogue] of the first / last workgroup:", gb[1:5].tolist())
+    lib.mvk_dense16_debug_stamps(None)
+    print("cycle stamps [main, epilogue] of the first / last workgroup:", stamps.tolist())
     for flags in (0, 8):
         lib.mvk_dense16_debug(flags)
         timeit(fwd, f"fwd_nll dbg={flags}", fl)
