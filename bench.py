@@ -296,20 +296,33 @@ class DeviceProfiler:
         return out
 
 
-def measured_copy_gbs(device, mb=512, reps=20):
+def measured_copy_gbs(device, mb=512, reps=20, streaming=True):
     """Device-to-device copy bandwidth (read + write bytes per second) of a `mb`-MB fp32 buffer, HIP events around `reps`
-    copies: the measured denominator SURVEY.md section 8(d) asks for beside the 8.0 TB/s nominal one."""
+    copies: the measured denominator SURVEY.md section 8(d) asks for beside the 8.0 TB/s nominal one.  streaming=True: the
+    library's float4 nontemporal copy kernel (mvk_probe_stream_copy, the shape of kernel MI355X_MICROARCH.md quotes 6.29 TB/s
+    for); False: torch's copy_ (the probe of rounds 1-4: 4.7-5.5 TB/s, not a ceiling)."""
+    from multivae_amd import _lib
+
     n = mb * (1 << 20) // 4
     src = torch.empty(n, dtype=torch.float32, device=device).normal_()
     dst = torch.empty_like(src)
+
+    def copy():
+        if streaming:
+            _lib.call("mvk_probe_stream_copy", _lib.ptr(dst), _lib.ptr(src), n, _lib.stream_ptr())
+        else:
+            dst.copy_(src)
+
     for _ in range(3):
-        dst.copy_(src)
+        copy()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        dst.copy_(src)
+        copy()
     e1.record()
     torch.cuda.synchronize()
+    if streaming and not torch.equal(dst[-4096:], src[-4096:]):
+        raise RuntimeError("mvk_probe_stream_copy did not copy")
     return 2.0 * 4 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
@@ -457,15 +470,22 @@ def main():
         try:
             # noise=None: the model draws its reparameterisation noise itself, inside the captured graph (as it does under
             # BaseTrainer and in the reference's forward), instead of a host-side draw + one more copy per step
+            # single GPU: the fused Adam is the graph's last node (device-resident step / lr); data parallel: the graph carries
+            # the event the early part of the gradient collective waits for (MVK_OVERLAP=0: one collective behind the replay)
             graphed = GraphedStep(model, flat, inputs, noise=None,
-                                  capture_error_mode="thread_local" if use_dist else "global", **fkw)
+                                  capture_error_mode="thread_local" if use_dist else "global",
+                                  optimizer=None if (use_dist or _lib.tune("MVK_GRAPH_ADAM", "1") == "0") else opt,
+                                  overlap=use_dist and os.environ.get("MVK_OVERLAP", "1") != "0", **fkw)
         except Exception as e:  # capture is an optimisation, not a requirement
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graphed = None
 
     def graph_step():
         out = graphed(inputs)  # copies the batch into the captured buffers, replays
-        opt.step(grad_scale=flat.all_reduce_mean() if use_dist else 1.0)
+        if use_dist:
+            graphed.reduce_and_step(opt)  # C2: the gradient collective (early ranges beside the end of the backward pass), Adam
+        elif not graphed.includes_optimizer:
+            opt.step(grad_scale=1.0)
         return out
 
     step = graph_step if graphed is not None else eager_step
@@ -572,7 +592,12 @@ def main():
                                       else ("torch.distributed all_reduce (%s)" % dist.get_backend())) if use_dist else None,
                        "final_loss": round(loss, 4),
                        "peak_device_memory_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
-                       "launch": "hipGraph replay (fwd+bwd) + all-reduce + Adam" if graphed is not None else "eager",
+                       "launch": ("eager" if graphed is None else
+                                  "ONE hipGraph replay (fwd + bwd + Adam with device-resident step / lr)" if graphed.includes_optimizer else
+                                  ("hipGraph replay (fwd + bwd) || all-reduce of %d early + %d late ranges (%.1f + %.1f MB) + Adam" % (
+                                      len(graphed.early_ranges), len(graphed.late_ranges),
+                                      4e-6 * sum(n for _, n in graphed.early_ranges), 4e-6 * sum(n for _, n in graphed.late_ranges))
+                                   if graphed.early_ranges else "hipGraph replay (fwd + bwd) + all-reduce + Adam")),
                        # how the fp32 GEMM / convolution products are formed (operands, results and accumulation are fp32; the
                        # tests hold every form to the same float64-referenced tolerance)
                        "fp32_product": ("register-stationary convolutions: 3 fp16 MFMAs on scaled (hi, lo) pairs"
@@ -620,6 +645,9 @@ def main():
                                    "command by tools/gpu_profile.sh (counters cannot be read from inside the process); "
                                    f"measured at commit {traffic_meta.get('commit', 'unrecorded')}") if traffic else None,
                 "measured_copy_GBs": round(copy_gbs, 1), "frac_vs_measured_copy": round(ach / copy_gbs, 4),
+                "measured_copy_is": "float4 nontemporal streaming copy of 512 MB (mvk_probe_stream_copy), read + write bytes / time, "
+                                    "HIP events over 20 launches in this run; torch copy_ of the same buffers: "
+                                    f"{round(measured_copy_gbs(device, streaming=False), 1)} GB/s",
                 "algorithmic_bytes": nll["work"] / nll["launches"], "avg_launch_us": round(nll["avg_us"], 2),
                 "launches_timed": nll["launches"],
                 "first_in_last_out_us": round(nll["inner_avg_us"], 2),
@@ -648,7 +676,16 @@ def main():
         if members and "roofline" in res:
             gb = sum(m["work"] / m["launches"] * (m["launches"] / args.steps) for m in members)  # bytes per step
             gus = sum(1e6 * m["seconds"] / args.steps for m in members)
+            # SURVEY section 8(d)'s algorithmic bytes of the fused ELBO: 4 [B D (2K + 1) + B L (4M + 3K)] — recon read, x read,
+            # d_recon written, posterior / reparameterisation traffic (cfg3: 167.4 MB per step)
+            D_all = sum(int(v[0].numel()) for v in w["data"].values())
+            survey_bytes = 4.0 * (B * D_all * (2 * K + 1) + B * w["L"] * (4 * len(w["data"]) + 3 * K))
             res["roofline"]["elbo_group"] = {
+                "survey_8d_bytes_per_step": round(survey_bytes), "frac_vs_survey_8d_bytes": round(survey_bytes / gus / 1e3 / HBM_PEAK_GBS, 4),
+                "bound": "mixed: the svhn tail is HBM-bound (the `roofline` object above), the mnist tail lives in the epilogue of a "
+                         "GEMM launch (dense16 fwd_nll, MFMA work: roofline_mfma.dense16_*), the posterior kernels and the assembly "
+                         "are latency-sized — the group's fraction says how little of the ELBO's wall time is bandwidth, it is not "
+                         "a roofline of any one kernel",
                 "members": "fused svhn tail" + (" + generic recon_nll" if nll_generic else "") + (" + dense16 fwd_nll (mnist tail)" if d16f else "")
                            + (" + mopoe_posterior fwd / bwd + reduce_terms" if small else ""),
                 "bytes_per_step": round(gb), "us_per_step": round(gus, 1), "achieved": round(gb / gus / 1e3, 1), "unit": "GB/s",

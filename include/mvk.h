@@ -187,6 +187,14 @@ typedef struct mvk_term_desc {
 } mvk_term_desc;
 int mvk_reduce_terms(const mvk_term_desc* terms, int n_terms, float loss_sum_scale, float* out, float* loss_out,
                      void* stream);
+/* The same assembly on up to 16 workgroups (the one-workgroup form is latency-bound: 19 us alone for the 170 KB of row sums of
+ * the headline step).  ws: caller-owned scratch of >= MVK_REDUCE_TERMS_WS_FLOATS floats whose FIRST word is an arrival counter
+ * that must be 0 before the first launch and is 0 again after every launch; not shared between streams.  Every workgroup sums a
+ * fixed slice of every term, the last one to arrive adds the partials in workgroup order: deterministic.  ws == NULL (or too
+ * small, or no term longer than 4096 entries): exactly mvk_reduce_terms. */
+#define MVK_REDUCE_TERMS_WS_FLOATS (1 + 16 * MVK_MAX_TERMS)
+int mvk_reduce_terms_ws(const mvk_term_desc* terms, int n_terms, float loss_sum_scale, float* out, float* loss_out, float* ws,
+                        int64_t ws_floats, void* stream);
 
 /* buf[i] *= *gscale unless *gscale == 1 (no memory traffic in that case). */
 int mvk_scale_by_device_scalar(float* buf, int64_t n, const float* gscale, void* stream);
@@ -479,6 +487,9 @@ int mvk_axpby(const float* x, float a, const float* y, float b, int64_t n, int a
  * constants (0), or hashed fp16 values on v_mfma_f32_32x32x16_f16 (2: the scaled-fp16 kernels' instruction).  Timed by the caller, it gives the matrix-pipe rate the chip SUSTAINS for a launch of that length; with
  * realistic operands that is 1.4-1.9 PFLOP/s, not the 2.5 of the data sheet (power-limited clock).  out: >= 65536 floats. */
 int mvk_probe_mfma_bf16(float* out, int iters, int random_operands, void* stream);
+/* Measurement aid of bench.py: a float4 streaming copy of n floats (16-byte aligned, n % 4 == 0; nontemporal, four loads in
+ * flight per lane) — the measured HBM denominator beside the 8 TB/s of the data sheet. */
+int mvk_probe_stream_copy(float* dst, const float* src, int64_t n, void* stream);
 /* y[b][c][r] = act(x[b][r][c]) * dact'(msrc[b][r][c]) (msrc may be NULL; the derivative is taken through the OUTPUT of dact,
  * as everywhere here): the NCHW flatten in front of `fc_mu / fc_logvar` of the ResNet encoders fused with their last activation
  * (models/nn/cub.py:190-195, mmnist.py:300-306), the un-flatten behind `fc` of the decoders (cub.py:232-240), and their
@@ -608,6 +619,17 @@ int mvk_adam_step_amsgrad(float* p, const float* g, float* m, float* v, float* v
 int mvk_adam_step_fused(float* p, float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1,
                         double beta2, double eps, double weight_decay, int step, double grad_scale, int zero_grad,
                         void* stream);
+/* The optimizer inside a replayed hipGraph: the scalars of the update live in DEVICE memory.
+ *   state    8 doubles owned by the caller: lr, beta1, beta2, eps, weight_decay, grad_scale, step (updates applied so far), 0
+ *   scalars  8 floats (16-byte aligned) written by mvk_adam_prepare and read by mvk_adam_step_dev
+ * mvk_adam_prepare (one thread) advances state[6] by one and derives the bias-corrected step size etc. in double, exactly the
+ * arithmetic mvk_adam_step_fused does on the host; mvk_adam_step_dev is mvk_adam_step_fused with those scalars (buffers
+ * 16-byte aligned, n % 4 == 0: the flat buffers of trainers.FlatParams).  Captured once, replayed every step: a learning-rate
+ * scheduler (base_trainer_config.py:60) writes state[0] between replays; the pair is equivalent to one
+ * optimizer.step() of base_trainer.py:350-361. */
+int mvk_adam_prepare(double* state, float* scalars, void* stream);
+int mvk_adam_step_dev(float* p, float* g, float* m, float* v, float* vmax, int64_t n, const float* scalars, int zero_grad,
+                      void* stream);
 
 /* The encoder heads in ONE launch: Y_h[m][n] = sum_k X[m][k] W_h(k, n) + b_h[n] for h = 0 (and 1 when W1 != NULL),
  * n < N <= 32, W_h(k, n) = W_h[k * w_sk + n * w_sn] (a torch Linear weight [N][K]: w_sk = 1, w_sn = K; the packed

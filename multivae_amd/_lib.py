@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 # MVK_* variables that are NOT experiment switches (read directly, with or without MVK_TUNE)
 _ALWAYS_READ = {"MVK_TUNE", "MVK_LIB_PATH", "MVK_DEFER_MB", "MVK_SYNC_DEBUG", "MVK_TRAINER_ALLOW_CPU", "MVK_CPU_THREADS",
-                "MVK_BENCH_SAME_GPU", "MVK_FORCE_DIST", "MVK_DIST_BACKEND", "MVK_ADAM_ZERO", "MVK_RCCL", "MVK_BENCH_CHILD"}
+                "MVK_BENCH_SAME_GPU", "MVK_FORCE_DIST", "MVK_DIST_BACKEND", "MVK_ADAM_ZERO", "MVK_RCCL", "MVK_BENCH_CHILD", "MVK_OVERLAP"}
 
 
 def _warn_ignored_switches():
@@ -83,6 +83,7 @@ PROTOTYPES = {
     "mvk_recon_nll_fwd": [C.POINTER(ReconDesc), _i, _i, _i, _p],
     "mvk_recon_nll_bwd": [C.POINTER(ReconDesc), _i, _i, _i, _p],
     "mvk_reduce_terms": [C.POINTER(TermDesc), _i, _f, _p, _p, _p],
+    "mvk_reduce_terms_ws": [C.POINTER(TermDesc), _i, _f, _p, _p, _p, _i64, _p],
     "mvk_scale_by_device_scalar": [_p, _i64, _p, _p],
     "mvk_linear_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p, _i64, _p],
     "mvk_linear_bwd_data": [_p, _p, _p, _i, _i, _i, _p, _i, _p, _i, _i, _p, _p, _i64, _p],
@@ -125,6 +126,7 @@ PROTOTYPES = {
     "mvk_axpby": [_p, _f, _p, _f, _i64, _i, _p, _p],
     "mvk_transpose_act": [_p, _p, _i, _i, _i, _i, _p, _i, _p],
     "mvk_probe_mfma_bf16": [_p, _i, _i, _p],
+    "mvk_probe_stream_copy": [_p, _p, _i64, _p],
     "mvk_device_rng": [_p, _i64, _p, _i, _f, _f, _p],
     "mvk_conv4s2_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _p],
     "mvk_conv4s2_up_nchw_small": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
@@ -145,6 +147,8 @@ PROTOTYPES = {
     "mvk_defer_end": [_p],
     "mvk_adam_step_amsgrad": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _d, _p],
     "mvk_adam_step_fused": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _d, _i, _p],
+    "mvk_adam_prepare": [_p, _p, _p],
+    "mvk_adam_step_dev": [_p, _p, _p, _p, _p, _i64, _p, _i, _p],
     "mvk_mmvae_std_fwd": [_p, _i, _i, _i, _p, _p],
     "mvk_mmvae_std_bwd": [_p, _p, _p, _i, _i, _i, _p, _p],
     "mvk_mmvae_latent_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p],

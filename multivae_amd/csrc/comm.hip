@@ -156,12 +156,34 @@ int mvk_event_destroy(void* ev) {
   if (!ev) return MVK_OK;
   return hipEventDestroy(static_cast<hipEvent_t>(ev)) == hipSuccess ? MVK_OK : MVK_ELAUNCH;
 }
-/* external != 0: an event-record node when `stream` is capturing (a plain record otherwise) */
+/* external != 0: an event-record NODE when `stream` is capturing (a plain record otherwise).  The node is added to the graph
+ * being captured by hand — hipStreamGetCaptureInfo_v2 (graph + the stream's current dependency set), hipGraphAddEventRecordNode
+ * behind those dependencies, hipStreamUpdateCaptureDependencies so that the stream continues behind the node — because
+ * hipEventRecordWithFlags(hipEventRecordExternal) returns an error under torch's stream capture on the HIP 7.0 runtime torch
+ * ships (measured, tools/extevent_order_probe.py), and a failed call inside a capture invalidates it. */
 int mvk_event_record(void* ev, int external, void* stream) {
   if (!ev) return MVK_EINVAL;
-  hipError_t rc = external ? hipEventRecordWithFlags(static_cast<hipEvent_t>(ev), mvk_stream(stream), hipEventRecordExternal)
-                           : hipEventRecord(static_cast<hipEvent_t>(ev), mvk_stream(stream));
-  return rc == hipSuccess ? MVK_OK : MVK_ELAUNCH;
+  hipEvent_t e = static_cast<hipEvent_t>(ev);
+  hipStream_t s = mvk_stream(stream);
+  if (external) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    hipGraph_t graph = nullptr;
+    const hipGraphNode_t* deps = nullptr;
+    size_t ndeps = 0;
+    unsigned long long id = 0;
+    if (hipStreamGetCaptureInfo_v2(s, &st, &id, &graph, &deps, &ndeps) != hipSuccess) return MVK_ELAUNCH;
+    if (st == hipStreamCaptureStatusActive) {
+      hipGraphNode_t node = nullptr;
+      hipError_t rc = hipGraphAddEventRecordNode(&node, graph, deps, ndeps, e);
+      if (rc == hipSuccess) rc = hipStreamUpdateCaptureDependencies(s, &node, 1, hipStreamSetCaptureDependencies);
+      if (rc != hipSuccess) {
+        if (getenv("MVK_SYNC_DEBUG")) fprintf(stderr, "[mvk] external event node: %s\n", hipGetErrorString(rc));
+        return MVK_ELAUNCH;
+      }
+      return MVK_OK;
+    }
+  }
+  return hipEventRecord(e, s) == hipSuccess ? MVK_OK : MVK_ELAUNCH;
 }
 int mvk_stream_wait_event(void* stream, void* ev) {
   if (!ev) return MVK_EINVAL;

@@ -392,6 +392,49 @@ __global__ __launch_bounds__(256) void adam4_kernel(float4* __restrict__ p, floa
   if (ZERO) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// ---- the same update with its scalars in DEVICE memory (capturable: trainers/graph.py puts the optimizer into the hipGraph) ----
+// state (8 doubles, owned by the caller): [0] lr, [1] beta1, [2] beta2, [3] eps, [4] weight_decay, [5] grad_scale,
+// [6] step (the number of updates applied so far), [7] unused.  adam_prepare_kernel (one thread) advances the step and derives
+// the eight floats the update kernel needs — in double, like the host path and torch.optim.Adam's Python side — so a replayed
+// graph needs no host scalar: a learning-rate scheduler writes state[0], nothing else changes between replays.
+__global__ void adam_prepare_kernel(double* __restrict__ state, AdamScalars* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double lr = state[0], b1 = state[1], b2 = state[2];
+  const double step = state[6] + 1.0;
+  state[6] = step;
+  const double bc1 = 1.0 - pow(b1, step);
+  const double bc2 = 1.0 - pow(b2, step);
+  AdamScalars a;
+  a.step_size = (float)(lr / bc1);
+  a.omb1 = (float)(1.0 - b1);
+  a.b2 = (float)b2;
+  a.omb2 = (float)(1.0 - b2);
+  a.eps = (float)state[3];
+  a.wd = (float)state[4];
+  a.bc2_sqrt = (float)sqrt(bc2);
+  a.gscale = (float)state[5];
+  *out = a;
+}
+
+template <bool AMSGRAD, bool ZERO>
+__global__ __launch_bounds__(256) void adam4_dev_kernel(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
+                                                        float4* __restrict__ v, float4* __restrict__ vmax, long long n4,
+                                                        const AdamScalars* __restrict__ sc) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const AdamScalars a = *sc;  // uniform address: scalar loads
+  float4 pi = p[i], mi = m[i], vi = v[i];
+  const float4 gi = g[i];
+  float4 vx = AMSGRAD ? vmax[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  adam_one<AMSGRAD>(pi.x, gi.x, mi.x, vi.x, vx.x, a);
+  adam_one<AMSGRAD>(pi.y, gi.y, mi.y, vi.y, vx.y, a);
+  adam_one<AMSGRAD>(pi.z, gi.z, mi.z, vi.z, vx.z, a);
+  adam_one<AMSGRAD>(pi.w, gi.w, mi.w, vi.w, vx.w, a);
+  p[i] = pi, m[i] = mi, v[i] = vi;
+  if (AMSGRAD) vmax[i] = vx;
+  if (ZERO) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // ---- scalar assembly ----------------------------------------------------------------------------------------
 struct TermTable {
   mvk_term_desc t[MVK_MAX_TERMS];
@@ -404,12 +447,21 @@ struct TermTable {
 // term-by-term loop with a barrier per term, which cost ~1.5 us per term on the chain between forward and backward).
 // gfill: where a term's gradient w.r.t. its rows is the constant coef * lossw (KL rows), it is written here, so that a
 // backward pass whose upstream gradient is known to be 1 launches nothing (ReconLossFn.backward).
+#define MVK_TERMS_WG 16  // workgroups of the multi-workgroup form (include/mvk.h: MVK_REDUCE_TERMS_WS_FLOATS)
+
+// ws == null: ONE workgroup (gridDim.x == 1).  ws given: gridDim.x workgroups, workgroup g sums the g-th contiguous slice of
+// every term (slice = ceil(n / G) rounded up to 1024 entries), writes its per-term partials to ws[1 + g * MVK_MAX_TERMS + i],
+// takes a ticket (ws[0], an unsigned counter that is 0 between launches) and the LAST workgroup to arrive adds the partials in
+// workgroup order: the result does not depend on which workgroup that is.
 __global__ __launch_bounds__(1024) void reduce_terms_kernel(const TermTable tt, float* __restrict__ out,
-                                                            float* __restrict__ loss_out, mvk_prof_slot* prof) {
+                                                            float* __restrict__ loss_out, float* __restrict__ ws,
+                                                            mvk_prof_slot* prof) {
   mvk_prof_begin(prof);
   __shared__ float red[MVK_MAX_TERMS][16];
   __shared__ float vals[MVK_MAX_TERMS];
+  __shared__ unsigned ticket;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int G = gridDim.x, g = blockIdx.x;
   for (int i0 = 0; i0 < tt.n; i0 += 8) {
     float s[8];
 #pragma unroll
@@ -417,9 +469,11 @@ __global__ __launch_bounds__(1024) void reduce_terms_kernel(const TermTable tt, 
       s[u] = 0.f;
       if (i0 + u < tt.n) {
         const mvk_term_desc& t = tt.t[i0 + u];
+        const long long slice = ((t.n + G - 1) / G + 1023) & ~1023ll;
+        const long long lo = (long long)g * slice, hi = lo + slice < t.n ? lo + slice : t.n;
         // four loads in flight per thread (a term of 35840 rows was 35 dependent load latencies: 18 us for 160 KB)
-        long long j = threadIdx.x;
-        for (; j + 3 * 1024 < t.n; j += 4 * 1024) {
+        long long j = lo + threadIdx.x;
+        for (; j + 3 * 1024 < hi; j += 4 * 1024) {
           float v0 = t.v[j], v1 = t.v[j + 1024], v2 = t.v[j + 2048], v3 = t.v[j + 3072];
           if (t.mask) {
             v0 = t.mask[j % t.period] ? v0 : 0.f;
@@ -429,14 +483,14 @@ __global__ __launch_bounds__(1024) void reduce_terms_kernel(const TermTable tt, 
           }
           s[u] += (v0 + v1) + (v2 + v3);
         }
-        for (; j < t.n; j += 1024) {
+        for (; j < hi; j += 1024) {
           float v = t.v[j];
           if (t.mask) v = t.mask[j % t.period] ? v : 0.f;
           s[u] += v;
         }
         if (t.gfill) {
           const float gv = t.coef * t.lossw;
-          for (long long j = threadIdx.x; j < t.n; j += 1024) t.gfill[j] = gv;
+          for (long long j2 = lo + threadIdx.x; j2 < hi; j2 += 1024) t.gfill[j2] = gv;
         }
       }
     }
@@ -447,7 +501,30 @@ __global__ __launch_bounds__(1024) void reduce_terms_kernel(const TermTable tt, 
     }
   }
   __syncthreads();
-  if ((int)threadIdx.x < tt.n) {
+  if (ws) {  // publish this workgroup's partials; only the last arrival goes on
+    if ((int)threadIdx.x < tt.n) {
+      float tot = 0.f;
+      for (int wv = 0; wv < 16; ++wv) tot += red[threadIdx.x][wv];
+      __hip_atomic_store(ws + 1 + g * MVK_MAX_TERMS + threadIdx.x, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0)
+      ticket = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(ws), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (ticket != (unsigned)(G - 1)) {
+      mvk_prof_end(prof);
+      return;
+    }
+    __threadfence();
+    if ((int)threadIdx.x < tt.n) {
+      float tot = 0.f;
+      for (int q = 0; q < G; ++q)
+        tot += __hip_atomic_load(ws + 1 + q * MVK_MAX_TERMS + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      vals[threadIdx.x] = tot * tt.t[threadIdx.x].coef;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned*>(ws), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if ((int)threadIdx.x < tt.n) {
     float tot = 0.f;
     for (int wv = 0; wv < 16; ++wv) tot += red[threadIdx.x][wv];
     vals[threadIdx.x] = tot * tt.t[threadIdx.x].coef;
@@ -707,6 +784,34 @@ int mvk_adam_step_fused(float* p, float* g, float* m, float* v, float* vmax, int
   return MVK_OK;
 }
 
+int mvk_adam_prepare(double* state, float* scalars, void* stream) {
+  if (!state || !scalars || !mvk_aligned16(scalars)) return MVK_EINVAL;
+  hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, mvk_stream(stream), state, reinterpret_cast<AdamScalars*>(scalars));
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_adam_step_dev(float* p, float* g, float* m, float* v, float* vmax, int64_t n, const float* scalars, int zero_grad,
+                      void* stream) {
+  if (!p || !g || !m || !v || !scalars) return MVK_EINVAL;
+  if (n == 0) return MVK_OK;
+  if (n % 4 != 0 || !mvk_aligned16(p) || !mvk_aligned16(g) || !mvk_aligned16(m) || !mvk_aligned16(v) || (vmax && !mvk_aligned16(vmax)))
+    return MVK_EINVAL;  // flat buffers of trainers.FlatParams are padded to 64 floats and 256-byte aligned
+  hipStream_t s = mvk_stream(stream);
+  const AdamScalars* sc = reinterpret_cast<const AdamScalars*>(scalars);
+#define MVK_ADAM_DEV(AMS_, Z_)                                                                                              \
+  hipLaunchKernelGGL((adam4_dev_kernel<AMS_, Z_>), dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s,                  \
+                     reinterpret_cast<float4*>(p), reinterpret_cast<float4*>(g), reinterpret_cast<float4*>(m),              \
+                     reinterpret_cast<float4*>(v), reinterpret_cast<float4*>(vmax), (long long)(n / 4), sc)
+  if (vmax && zero_grad) MVK_ADAM_DEV(true, true);
+  else if (vmax) MVK_ADAM_DEV(true, false);
+  else if (zero_grad) MVK_ADAM_DEV(false, true);
+  else MVK_ADAM_DEV(false, false);
+#undef MVK_ADAM_DEV
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
 int mvk_adam_step_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1,
                           double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream) {
   return mvk_adam_step_fused(p, const_cast<float*>(g), m, v, vmax, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, 0,
@@ -718,24 +823,37 @@ int mvk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, doubl
   return mvk_adam_step_amsgrad(p, g, m, v, nullptr, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, stream);
 }
 
-int mvk_reduce_terms(const mvk_term_desc* terms, int n_terms, float loss_sum_scale, float* out, float* loss_out,
-                     void* stream) {
+int mvk_reduce_terms_ws(const mvk_term_desc* terms, int n_terms, float loss_sum_scale, float* out, float* loss_out, float* ws,
+                        int64_t ws_floats, void* stream) {
   if (!terms || !out || n_terms < 1 || n_terms > MVK_MAX_TERMS) return MVK_EINVAL;
   TermTable tt;
+  long long longest = 0;
   for (int i = 0; i < n_terms; ++i) {
     tt.t[i] = terms[i];
     if (!terms[i].v || terms[i].n < 0) return MVK_EINVAL;
     if (tt.t[i].period <= 0) tt.t[i].period = 1;
+    longest = terms[i].n > longest ? terms[i].n : longest;
   }
   tt.n = n_terms;
   tt.loss_sum_scale = loss_sum_scale;
   double bytes = 0.0;
   for (int i = 0; i < n_terms; ++i) bytes += 4.0 * (double)terms[i].n * (terms[i].gfill ? 2.0 : 1.0);
+  // several workgroups only where a term is long enough to give each of them a slice, and the caller lent the workspace
+  int G = 1;
+  if (ws && ws_floats >= MVK_REDUCE_TERMS_WS_FLOATS && longest > 4096) {
+    G = (int)((longest + 4095) / 4096);
+    if (G > MVK_TERMS_WG) G = MVK_TERMS_WG;
+  }
   mvk_prof_slot* prof = mvk::prof_next(11, bytes);
-  hipLaunchKernelGGL(reduce_terms_kernel, dim3(1), dim3(1024), 0, mvk_stream(stream), tt, out, loss_out, prof);
+  hipLaunchKernelGGL(reduce_terms_kernel, dim3(G), dim3(1024), 0, mvk_stream(stream), tt, out, loss_out, G > 1 ? ws : nullptr, prof);
   MVK_CHECK_LAUNCH();
   mvk::prof_fold(prof, mvk_stream(stream));
   return MVK_OK;
+}
+
+int mvk_reduce_terms(const mvk_term_desc* terms, int n_terms, float loss_sum_scale, float* out, float* loss_out,
+                     void* stream) {
+  return mvk_reduce_terms_ws(terms, n_terms, loss_sum_scale, out, loss_out, nullptr, 0, stream);
 }
 
 }  // extern "C"
@@ -1091,6 +1209,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 extern "C" int mvk_probe_mfma_bf16(float* out, int iters, int random_operands, void* stream) {
   if (!out || iters <= 0) return MVK_EINVAL;
   hipLaunchKernelGGL(mfma_probe_kernel, dim3(256), dim3(256), 0, mvk_stream(stream), out, iters, random_operands, 12345u);
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+// The measured HBM denominator of bench.py's roofline ("also report against a measured device-copy
+// bandwidth"): a float4 streaming copy — 16 bytes per lane, four independent nontemporal loads in flight per thread before the
+// first store, a grid of 8 workgroups per CU walking the buffer in grid-sized strides (every wave's four loads are four
+// consecutive 1-KB lines of one 4-KB run).  MI355X_MICROARCH.md quotes 6.29 TB/s (read + write bytes) for this shape of
+// kernel; torch's copy_ — the probe of rounds 1-4 — reached 4.7-5.5.
+namespace {
+__global__ __launch_bounds__(256) void stream_copy_kernel(const mvk::f32x4* __restrict__ src, mvk::f32x4* __restrict__ dst, long long n4) {
+  const long long stride = (long long)gridDim.x * 1024;  // float4 per grid sweep (4 per thread)
+  for (long long base = (long long)blockIdx.x * 1024 + threadIdx.x; base < n4; base += stride) {
+    mvk::f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (base + u * 256 < n4) v[u] = __builtin_nontemporal_load(src + base + u * 256);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (base + u * 256 < n4) __builtin_nontemporal_store(v[u], dst + base + u * 256);
+  }
+}
+}  // namespace
+
+// dst, src: 16-byte aligned, n a multiple of 4 floats.  One launch copies the whole buffer.
+extern "C" int mvk_probe_stream_copy(float* dst, const float* src, int64_t n, void* stream) {
+  if (!dst || !src || n <= 0 || (n & 3) || !mvk_aligned16(dst) || !mvk_aligned16(src)) return MVK_EINVAL;
+  const long long n4 = n / 4;
+  const int grid = (int)std::min<long long>((n4 + 1023) / 1024, 2048);
+  hipLaunchKernelGGL(stream_copy_kernel, dim3(grid), dim3(256), 0, mvk_stream(stream), reinterpret_cast<const mvk::f32x4*>(src),
+                     reinterpret_cast<mvk::f32x4*>(dst), n4);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }

@@ -141,7 +141,7 @@ LATE_DENSE = _lib.tune("MVK_LATE_DENSE", "0") == "1"
 LATE_DW0 = _lib.tune("MVK_LATE_DW0", "1") != "0"
 
 
-def run_last(device, fn, *reads, force=False):
+def run_last(device, fn, *reads, force=False, params=()):
     """Inside deferred_reductions: run fn() on the late-leaf stream AFTER everything else the backward pass puts there (the
     enqueue itself is postponed to the end of the scope), i.e. in the launch-latency-bound tail of the step where the chip is
     mostly idle, instead of beside the decoders' backward-data chains whose window is throughput-bound.  Returns False when
@@ -149,7 +149,46 @@ def run_last(device, fn, *reads, force=False):
     if not (LATE_LEAVES and (LATE_DENSE or force)) or device.type != "cuda" or device not in _DEFER_ACTIVE:
         return False
     _LATE_CALLS.setdefault(device, []).append((fn, reads))
+    op = _OVERLAP.get(device)
+    if op is not None:  # these gradients are written in the tail of the step: not part of the early collective
+        op.late_params.extend(params)
     return True
+
+
+# -----------------------------------------------------------------------------------------------------
+# where the backward pass says "this part of the gradient buffer is final" (overlapped data-parallel collective)
+# -----------------------------------------------------------------------------------------------------
+_OVERLAP = {}  # device -> OverlapPoint, while trainers.graph enqueues / captures a data-parallel step
+
+
+class OverlapPoint:
+    """The reference's DDP reduces gradient buckets while loss.backward() still runs (trainers/base/base_trainer.py:116-117,359).
+    Here the step is ONE replayed hipGraph, so the overlap needs a point INSIDE the graph that a stream OUTSIDE can wait for: an
+    external event-record node (mvk_event_record(ev, 1, stream)), placed where the finishes of everything but the last backward
+    node have run (defer_flush_sibling: the decoders', the posterior's and the short encoder's gradients are final there, the
+    long encoder's backward chain — ~300 us of the headline step — is still ahead).  `late_params` collects the parameters whose
+    gradients are NOT final at that point: the node that called defer_flush_sibling and every leaf postponed by run_last."""
+
+    def __init__(self, device):
+        self.device = device
+        self.event = C.c_void_p()
+        call("mvk_event_create", C.byref(self.event))
+        self.late_params = []
+        self.recorded = False
+
+    def begin(self):
+        self.late_params, self.recorded = [], False
+        _OVERLAP[self.device] = self
+
+    def end(self):
+        _OVERLAP.pop(self.device, None)
+
+    def __del__(self):
+        try:
+            if self.event:
+                _lib.load().mvk_event_destroy(self.event)
+        except Exception:
+            pass
 
 
 _LATE_READY = {}
@@ -257,7 +296,9 @@ FLUSH_SIBLING = _lib.tune("MVK_FLUSH_SIBLING", "1") != "0"
 _BRANCH_SET = {}  # device -> the streams of the last run_branches call (main first)
 
 
-def defer_flush_sibling(device):
+def defer_flush_sibling(device, node_params=()):
+    """node_params: the parameters of the backward node that calls this (the LAST one of the step): with an OverlapPoint open,
+    everything else's gradient is final behind the flush, and the point is recorded there."""
     if not (FLUSH_SIBLING and DEFER) or device.type != "cuda" or device not in _DEFER_ACTIVE:
         return
     cur = torch.cuda.current_stream(device)
@@ -266,6 +307,17 @@ def defer_flush_sibling(device):
         return
     with torch.cuda.stream(sib):
         call("mvk_defer_flush", stream_ptr())
+        op = _OVERLAP.get(device)
+        if op is not None and not op.recorded:
+            # the flush already waits for every stream a gradient producer RAN ON (csrc/igemm.hip defer_flush_locked); ordered
+            # explicitly behind the caller's stream and the late-leaf streams as well: a gradient written straight into the
+            # buffer by a launch that queued no finish would otherwise be unordered against the collective
+            for st in dict.fromkeys([cur] + list(_LATE_USED.get(device, ()))):
+                if st != sib:
+                    sib.wait_event(st.record_event())
+            call("mvk_event_record", op.event, 1, stream_ptr())
+            op.late_params.extend(node_params)
+            op.recorded = True
     _LATE_USED.setdefault(device, []).append(sib)
 
 
@@ -404,6 +456,22 @@ def flush_deferred_forward(device):
             fn()
 
 
+_PRELUDE = {}  # device -> closure with launches that depend on nothing of the step (run at the head of the first side branch)
+
+
+def set_prelude(device, fn):
+    """Launches that the step needs LATER and that depend on nothing it computes (the optimizer's scalar preparation inside a
+    captured step): enqueued at the head of the first side branch run_branches opens — a stream with slack, joined long before
+    the optimizer — instead of on the critical chain.  run_prelude(device) runs it where it is if no branch took it."""
+    _PRELUDE[device] = fn
+
+
+def run_prelude(device):
+    fn = _PRELUDE.pop(device, None)
+    if fn is not None:
+        fn()
+
+
 def run_branches(names, fn, device, side_first=False):
     """{m: fn(m)} with every branch but the first on its own stream; joined before returning."""
     names = list(names)
@@ -425,6 +493,7 @@ def run_branches(names, fn, device, side_first=False):
         st = _side_stream(device, i)
         st.wait_event(fork)
         with torch.cuda.stream(st):
+            run_prelude(device)
             outs[m] = fn(m)
         for t in _tensors_of(outs[m]):
             t.record_stream(main)
@@ -1390,10 +1459,10 @@ class MLPDecoderFn(Function):
                      ptr(tw1), ptr(tb1), ptr(wsl), wsl.numel(), n, D, H, stream_ptr())
 
             # a leaf: postponed into the tail of the step when its targets are views of the flat gradient buffer
-            if dw1 is not None or db1 is not None or not run_last(z2.device, wgrad1, gp, hp, cs, bounds):
+            if dw1 is not None or db1 is not None or not run_last(z2.device, wgrad1, gp, hp, cs, bounds, params=(w1, b1)):
                 wgrad1()
             dw0 = None
-            if not _is_direct(w0) or not run_last(z2.device, lambda: linear_bwd_weight(dh, z2, w0, None), dh, z2, force=LATE_DW0):
+            if not _is_direct(w0) or not run_last(z2.device, lambda: linear_bwd_weight(dh, z2, w0, None), dh, z2, force=LATE_DW0, params=(w0,)):
                 dw0, _ = linear_bwd_weight(dh, z2, w0, None)
             return dz, dw0, db0, dw1, db1, None, None, None, None
         else:  # general upstream gradient: d pre = G * drows[column tile, row] / nll_weight as an fp32 tensor, then the tiled engine
@@ -1411,7 +1480,7 @@ class MLPDecoderFn(Function):
         if ctx.needs_input_grad[0]:
             dz = linear_bwd_data(dh, w0).view(ctx.z_shape)
         dw0 = None
-        if not _is_direct(w0) or not run_last(z2.device, lambda: linear_bwd_weight(dh, z2, w0, None), dh, z2):
+        if not _is_direct(w0) or not run_last(z2.device, lambda: linear_bwd_weight(dh, z2, w0, None), dh, z2, params=(w0,)):
             dw0, _ = linear_bwd_weight(dh, z2, w0, None)
         return dz, dw0, db0, dw1, db1, None, None, None, None
 
@@ -1465,7 +1534,7 @@ class SVHNEncoderFn(Function):
         dmu, dlv = _c(dmu).view(B, L), _c(dlv).view(B, L)
         Kf = 16 * ch[3]
         h3f = h3.view(B, Kf)
-        defer_flush_sibling(x.device)
+        defer_flush_sibling(x.device, node_params=(w0, b0, w1, b1, w2, b2, wc1, bc1, wc2, bc2))
         # heads: both weight gradients (in the Conv2d layout), both bias gradients, d h3 (pre-activation: dmu Wd1^T + dlv Wd2^T
         # with ReLU'(h3)) and its channel sums (the bias gradient of the layer below) in one launch
         lf = LeafStream(x.device)  # the weight / bias gradients run beside the backward-data chain
@@ -2069,6 +2138,19 @@ def is_unit_seed(g):
     return t is not None and t.shape == g.shape and t.device == g.device
 
 
+_TERMS_WS = {}  # (device, stream) -> the arrival counter + partials of mvk_reduce_terms_ws (zero between launches)
+
+
+def _reduce_terms(terms, n_terms, loss_sum_scale, out, loss):
+    """The scalar assembly on the current stream, on several workgroups where a term is long (mvk_reduce_terms_ws)."""
+    key = (out.device, torch.cuda.current_stream(out.device).cuda_stream)
+    ws = _TERMS_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(1 + 16 * 64, dtype=torch.float32, device=out.device)  # MVK_REDUCE_TERMS_WS_FLOATS
+        _TERMS_WS[key] = ws
+    call("mvk_reduce_terms_ws", terms, n_terms, loss_sum_scale, ptr(out), ptr(loss), ptr(ws), ws.numel(), stream_ptr())
+
+
 class ReconLossFn(Function):
     """loss = sum_i lossw_i * coef_i * sum_{k,b} mask_i[b] rows_i[k,b] + sum_j lossw_j * coef_j * sum(extra_j).
 
@@ -2170,13 +2252,13 @@ class ReconLossFn(Function):
         late = late_leaves(ref.device, *extras) if (ASYNC_LOSS and n_rec == 0 and spec.get("async_ok")) else None
         if late is not None and late.on:
             with late:
-                call("mvk_reduce_terms", terms, n_terms, spec["loss_sum_scale"], ptr(out), ptr(loss), stream_ptr())
+                _reduce_terms(terms, n_terms, spec["loss_sum_scale"], out, loss)
                 st = torch.cuda.current_stream(ref.device)
                 _LOSS_EVENT[ref.device] = st.record_event()
                 for t in [out, loss] + [d for d in dextras if d is not None]:
                     t.record_stream(st)
         else:
-            call("mvk_reduce_terms", terms, n_terms, spec["loss_sum_scale"], ptr(out), ptr(loss), stream_ptr())
+            _reduce_terms(terms, n_terms, spec["loss_sum_scale"], out, loss)
         ctx.drecons = drecons
         ctx.dextras = dextras
         ctx.extra_shapes = [e.shape for e in extras]

@@ -359,12 +359,20 @@ class BaseTrainer:
         if gs is None and key not in graphs:
             try:
                 gs = GraphedStep(self.model, self.flat, inputs, noise=None,
-                                 capture_error_mode="thread_local" if self.distributed else "global", **fwd_kwargs)
+                                 capture_error_mode="thread_local" if self.distributed else "global",
+                                 optimizer=None if self.distributed else self.optimizer, overlap=self.distributed, **fwd_kwargs)
             except Exception as e:  # not capturable (host sync inside the model, ...): stay eager for this shape
                 logger.warning(f"hipGraph capture failed ({type(e).__name__}: {e}); running this batch shape eagerly")
                 gs = None
             graphs[key] = gs
-        return gs(inputs) if gs is not None else None
+        if gs is None:
+            return None
+        out = gs(inputs)
+        # what is left of the step: nothing (single GPU: the optimizer is the graph's last node), or the overlapped collective +
+        # Adam (data parallel)
+        self._graph_tail = (lambda: None) if gs.includes_optimizer else \
+            ((lambda: gs.reduce_and_step(self.optimizer)) if self.distributed else None)
+        return out
 
     def train_step(self, epoch: int):
         self.callback_handler.on_train_step_begin(training_config=self.training_config, train_loader=self.train_loader,
@@ -381,7 +389,11 @@ class BaseTrainer:
                               batch_ratio=batch_idx / n_batches, beta=beta_epoch)
             model_output = self._graphed_forward_backward(inputs, epoch, fwd_kwargs)
             if model_output is not None:  # gradients are already in the flat buffer
-                self._optimizers_step(model_output, backward_done=True)
+                tail = self.__dict__.pop("_graph_tail", None)
+                if tail is not None:
+                    tail()
+                else:
+                    self._optimizers_step(model_output, backward_done=True)
             else:
                 model_output = self.model(inputs, **fwd_kwargs)
                 self._optimizers_step(model_output)

@@ -259,6 +259,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.v = torch.zeros_like(flat.flat)
         self.vmax = torch.zeros_like(flat.flat) if amsgrad else None
         self.step_count = 0
+        self._dev_state = self._dev_scalars = self._dev_host = None  # the captured form (prepare_captured / step_captured)
 
     # the hyper-parameters live in the parameter group (schedulers write `lr` there)
     def _g(self):
@@ -283,6 +284,40 @@ class FusedAdam(torch.optim.Optimizer):
                           grad_scale, vmax=self.vmax, zero_grad=self.zero_grad_in_step)
         self.flat.grads_zero = self.zero_grad_in_step
         return loss
+
+    # -- the optimizer inside a replayed hipGraph (trainers/graph.py): scalars in device memory -------------------------
+    def sync_device_state(self, grad_scale=1.0):
+        """Before a replay: the device copy of (lr, betas, eps, weight_decay, grad_scale, step) is brought up to date — one
+        small copy when a scheduler changed the learning rate, an eager step() ran in between, or a state_dict was loaded;
+        nothing otherwise (the captured mvk_adam_prepare advances the step itself)."""
+        g = self._g()
+        want = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                float(grad_scale), float(self.step_count))
+        if self._dev_state is None:
+            dev = self.flat.flat.device
+            self._dev_state = torch.zeros(8, dtype=torch.float64, device=dev)
+            self._dev_scalars = torch.zeros(8, dtype=torch.float32, device=dev)
+        if want != self._dev_host:
+            self._dev_state.copy_(torch.tensor(list(want) + [0.0], dtype=torch.float64))
+            self._dev_host = want
+
+    def prepare_captured(self):
+        """mvk_adam_prepare on the current stream (inside a capture): step += 1, the update's scalars derived on the device."""
+        _lib.call("mvk_adam_prepare", _lib.ptr(self._dev_state), _lib.ptr(self._dev_scalars), _lib.stream_ptr())
+
+    def step_captured(self):
+        """mvk_adam_step_dev on the current stream (inside a capture, behind prepare_captured and the finished gradients)."""
+        f = self.flat
+        _lib.call("mvk_adam_step_dev", _lib.ptr(f.flat), _lib.ptr(f.grad), _lib.ptr(self.m), _lib.ptr(self.v), _lib.ptr(self.vmax),
+                  f.numel, _lib.ptr(self._dev_scalars), 1 if self.zero_grad_in_step else 0, _lib.stream_ptr())
+
+    def note_replayed_step(self):
+        """The host's mirror of what a replay of the captured pair did."""
+        self.step_count += 1
+        self._opt_called = True  # what torch's lr schedulers look for ("scheduler.step() before optimizer.step()")
+        if self._dev_host is not None:
+            self._dev_host = self._dev_host[:6] + (float(self.step_count),)
+        self.flat.grads_zero = self.zero_grad_in_step
 
     def state_dict(self):
         """The layout of `torch.optim.Adam(model.parameters()).state_dict()` (what the reference writes to

@@ -4,8 +4,18 @@ One step of the models here is ~100 short kernel launches driven from Python (ct
 about as long to enqueue them as the GPU needs to run them.  `GraphedStep` captures forward + backward
 once (torch.cuda.CUDAGraph == hipGraph on ROCm, including the fork/join of the modality-branch streams) and
 replays it with one launch per step; `zero_grad` runs in front of the replay and costs nothing when the optimizer cleared
-the gradients while consuming them (`FusedAdam(zero_grad_in_step=True)`).  The gradient all-reduce and the fused Adam kernel stay outside the graph, so
-the distributed step is: copy batch -> replay -> all_reduce(flat.grad) -> adam.
+the gradients while consuming them (`FusedAdam(zero_grad_in_step=True)`).
+
+Single GPU (`optimizer=` given): the fused Adam is INSIDE the graph — its scalars (step, lr, ...) live in device memory
+(mvk_adam_prepare / mvk_adam_step_dev), the preparation launch rides on a side branch, the update is the graph's last node:
+the step is copy batch -> ONE replay.
+
+Data parallel (`overlap=True`, one process per GPU): the collective stays outside the graph (RCCL launches are not captured), but
+it no longer waits for the whole backward pass: the graph carries an external event-record node where everything but the last
+encoder's gradients is final (kernels.OverlapPoint), `reduce_and_step` starts that part's all-reduce on a communication stream
+behind the event — beside the rest of the backward pass —, the remainder behind the replay, then Adam:
+copy batch -> replay || all-reduce(early ranges) -> all-reduce(late ranges) -> adam.  The reference's DDP overlaps its bucket
+reductions with loss.backward() the same way (trainers/base/base_trainer.py:116-117,359).
 
 Capture needs static shapes and addresses: the batch and the noise are copied into buffers owned by this object;
 a batch of another shape (the last one of an epoch) must go through the eager path.
@@ -19,11 +29,22 @@ from ..data.datasets.base import DatasetOutput
 
 
 class GraphedStep:
-    def __init__(self, model, flat, inputs, noise=None, warmup=3, capture_error_mode="global", **fwd_kwargs):
+    def __init__(self, model, flat, inputs, noise=None, warmup=3, capture_error_mode="global", optimizer=None, overlap=False,
+                 **fwd_kwargs):
+        """optimizer: a FusedAdam(zero_grad_in_step=True) to capture behind the backward pass (single-GPU steps; `includes_optimizer`
+        says whether it was).  overlap: record the point where the early part of the gradient buffer is final (data-parallel
+        steps; `reduce_and_step` uses it)."""
         dev = flat.flat.device
         if dev.type != "cuda":
             raise RuntimeError("GraphedStep needs a GPU")
         self.model, self.flat, self.fwd_kwargs = model, flat, fwd_kwargs
+        self.optimizer = optimizer if (optimizer is not None and getattr(optimizer, "zero_grad_in_step", False)
+                                       and hasattr(optimizer, "step_captured") and not overlap) else None
+        self.includes_optimizer = self.optimizer is not None
+        self.overlap_point = kernels.OverlapPoint(dev) if overlap else None
+        self.early_ranges = self.late_ranges = None
+        if self.optimizer is not None:
+            self.optimizer.sync_device_state()  # allocates the device scalars the captured launches point at
         self._seed = None
         self.data = {m: v.detach().clone() for m, v in inputs.data.items()}
         extra = {}
@@ -49,7 +70,11 @@ class GraphedStep:
             # (stream priorities were tried: capturing the main branch, or the side branches, on a priority -1 stream
             # makes the replayed step 3.0-3.1 ms instead of 1.9)
             with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
-                self.out = self._body()
+                self.out = self._body(capture=True)
+            op = self.overlap_point
+            if op is not None and op.recorded:
+                self.late_ranges = flat.ranges_of(op.late_params)
+                self.early_ranges = flat.complement(self.late_ranges)
         finally:
             if prof is not None:
                 kernels.PROFILE["recon_nll"] = prof
@@ -62,14 +87,28 @@ class GraphedStep:
             return {k: v.detach().clone() for k, v in noise.items()}
         return noise.detach().clone()
 
-    def _body(self):
+    def _body(self, capture=False):
         kw = dict(self.fwd_kwargs)
         if self.noise is not None:
             kw["noise"] = self.noise
-        with kernels.deferred_reductions(self.flat):
-            out = self.model(self.inputs, **kw)
-            # the registered unit seed: filled once (not one launch per replay), and ReconLossFn.backward launches nothing
-            out.loss.backward(gradient=kernels.unit_seed(out.loss))
+        dev = self.flat.flat.device
+        opt = self.optimizer if capture else None  # the eager warm-up passes must not move the parameters
+        if opt is not None:
+            kernels.set_prelude(dev, opt.prepare_captured)  # depends on nothing of the step: head of the first side branch
+        if self.overlap_point is not None:
+            self.overlap_point.begin()
+        try:
+            with kernels.deferred_reductions(self.flat):
+                out = self.model(self.inputs, **kw)
+                # the registered unit seed: filled once (not one launch per replay), and ReconLossFn.backward launches nothing
+                out.loss.backward(gradient=kernels.unit_seed(out.loss))
+            if opt is not None:
+                kernels.run_prelude(dev)  # no branch took it: here, in front of the update
+                opt.step_captured()
+        finally:
+            kernels._PRELUDE.pop(dev, None)
+            if self.overlap_point is not None:
+                self.overlap_point.end()
         return out
 
     def matches(self, inputs):
@@ -92,6 +131,29 @@ class GraphedStep:
                     self.noise[k].copy_(v, non_blocking=True)
             elif noise is not self.noise:
                 self.noise.copy_(noise, non_blocking=True)
+        if self.optimizer is not None:
+            self.optimizer.sync_device_state()  # a copy only when lr / step changed behind the graph's back
         self.flat.zero_grad()  # free after FusedAdam(zero_grad_in_step=True).step()
         self.graph.replay()
+        if self.optimizer is not None:
+            self.optimizer.note_replayed_step()
         return self.out
+
+    def reduce_and_step(self, optimizer):
+        """Data-parallel tail of a replayed step: the gradient collective (overlapped with the end of the backward pass when the
+        capture recorded an early point), then the optimizer.  Every rank calls it after every replay, with the same ranges in
+        the same order."""
+        flat, dev = self.flat, self.flat.flat.device
+        cur = torch.cuda.current_stream(dev)
+        if self.early_ranges and self.late_ranges:
+            comm = kernels._side_stream(dev, 61)
+            kernels.call("mvk_stream_wait_event", kernels.C.c_void_p(comm.cuda_stream), self.overlap_point.event)
+            with torch.cuda.stream(comm):
+                flat.all_reduce_mean_ranges(self.early_ranges)  # starts where the graph's event node fires
+            comm.wait_stream(cur)  # ... the rest only behind the whole replay
+            with torch.cuda.stream(comm):
+                scale = flat.all_reduce_mean_ranges(self.late_ranges)
+            cur.wait_stream(comm)
+        else:
+            scale = flat.all_reduce_mean()
+        optimizer.step(grad_scale=scale)

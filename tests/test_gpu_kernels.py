@@ -1462,6 +1462,56 @@ def test_reduce_terms_handles_more_than_sixteen_terms(K):
         assert float(gbuf[i].min()) == float(gbuf[i].max()) == (1.0 if i % 3 == 0 else -7.0), i
 
 
+def test_reduce_terms_on_several_workgroups_is_deterministic_and_exact():
+    """mvk_reduce_terms_ws: the headline's terms (KL rows 1536, SVHN rows 5120, MNIST partial rows 7 x 5120,
+    masked with a period) on up to 16 workgroups against a float64 sum; the same bits launch after launch (fixed slices, partials
+    added in workgroup order by whichever workgroup arrives last), the arrival counter back at 0, gfill complete; ragged lengths
+    around the 4096 / 1024-entry slice boundaries; and a workspace that is too small falls back to the one-workgroup launch."""
+    from multivae_amd._lib import TermDesc, call, ptr, stream_ptr
+
+    d = dev()
+    gen = g(5)
+    lens = [1536, 5120, 35840, 4097, 16 * 4096 + 1, 1023, 70001]
+    vals = [torch.randn(n, generator=gen).to(d) * (i + 1) for i, n in enumerate(lens)]
+    B = 512
+    mask = (torch.rand(B, generator=gen) > 0.3).to(d)
+    n = len(lens)
+    terms = (TermDesc * n)()
+    gbuf = [torch.full((m,), -7.0, device=d) for m in lens]
+    for i, t in enumerate(terms):
+        t.v, t.n, t.coef, t.lossw = vals[i].data_ptr(), lens[i], 0.25 + i, 1.5
+        t.mask, t.period = (mask.data_ptr(), B) if i in (1, 2) else (None, 1)
+        t.gfill = gbuf[i].data_ptr() if i % 2 == 0 else None
+    exp = []
+    for i, v in enumerate(vals):
+        v64 = v.double().cpu()
+        if i in (1, 2):
+            v64 = v64 * mask.cpu().double().repeat(lens[i] // B)
+        exp.append((0.25 + i) * float(v64.sum()))
+    exp = torch.tensor(exp, dtype=torch.float64)
+    ws = torch.zeros(1 + 16 * 64, device=d)
+    outs = []
+    for rep in range(5):
+        out = torch.empty(n + 2, device=d)
+        loss = torch.empty((), device=d)
+        call("mvk_reduce_terms_ws", terms, n, 3.0, ptr(out), ptr(loss), ptr(ws), ws.numel(), stream_ptr())
+        torch.cuda.synchronize()
+        assert ws[:1].view(torch.int32).item() == 0  # the arrival counter is left at zero
+        outs.append(out.clone())
+        scale = torch.tensor([(0.25 + i) * float(vals[i].double().abs().sum()) for i in range(n)], dtype=torch.float64)
+        assert bool(((out[:n].double().cpu() - exp).abs() <= 2e-6 * scale).all()), (out[:n], exp)
+        close(loss, 1.5 * exp.sum(), rtol=1e-5, what="loss")
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    for i in range(n):
+        assert float(gbuf[i].min()) == float(gbuf[i].max()) == ((0.25 + i) * 1.5 if i % 2 == 0 else -7.0), i
+    out1 = torch.empty(n + 2, device=d)
+    call("mvk_reduce_terms_ws", terms, n, 3.0, ptr(out1), None, ptr(ws), 16, stream_ptr())  # too small: one workgroup
+    out2 = torch.empty(n + 2, device=d)
+    call("mvk_reduce_terms", terms, n, 3.0, ptr(out2), None, stream_ptr())
+    assert torch.equal(out1, out2)
+    close(out1[:n], exp.float(), rtol=1e-5, what="one-workgroup terms")
+
+
 @pytest.mark.parametrize("Kk,B,L", [(1, 7, 3), (4, 9, 70)])
 def test_gauss_sample_kl(K, Kk, B, L):
     gen = g(51)

@@ -162,6 +162,56 @@ def test_graph_replay_matches_eager():
     _same_training(_run_steps(d, 5, graphed=False), _run_steps(d, 5, graphed=True))
 
 
+@pytest.mark.parametrize("amsgrad", [False, True])
+def test_optimizer_inside_the_graph_matches_the_host_scalar_step(amsgrad):
+    """the fused Adam as the LAST NODE of the replayed step (mvk_adam_prepare + mvk_adam_step_dev: step and
+    learning rate in device memory) against replay + FusedAdam.step() with host scalars (mvk_adam_step_fused) — same kernels,
+    same gradients, so the parameters agree to the last bits of the scalar arithmetic (device pow vs libm pow); the learning
+    rate changes mid-run (what a scheduler does, base_trainer_config.py:60), an eager host-scalar step is interleaved, and the
+    host's step counter / state_dict follow the replays."""
+    from multivae_amd.data.datasets.base import DatasetOutput
+    from multivae_amd.trainers import FlatParams, FusedAdam, GraphedStep
+
+    d = torch.device("cuda:0")
+    B, K, L = 64, 3, 8
+    g = torch.Generator().manual_seed(3)
+    inputs = DatasetOutput(data=dict(mnist=torch.rand(B, 1, 28, 28, generator=g).to(d), svhn=torch.rand(B, 3, 32, 32, generator=g).to(d)))
+    noise = [torch.randn(K, B, L, generator=g).to(d) for _ in range(7)]
+    res = []
+    for in_graph in (False, True):
+        model = _mnist_svhn_mopoe(d, K=K, L=L)
+        flat = FlatParams(model)
+        opt = FusedAdam(flat, lr=1e-3, amsgrad=amsgrad, zero_grad_in_step=True)
+        before = flat.dense(flat.flat).clone()
+        gs = GraphedStep(model, flat, inputs, noise=torch.zeros(K, B, L, device=d), optimizer=opt if in_graph else None)
+        assert gs.includes_optimizer == in_graph
+        assert torch.equal(before, flat.dense(flat.flat)), "warm-up and capture must not move the parameters"
+        losses = []
+        for i, eps in enumerate(noise):
+            if i == 3:
+                opt.lr = 3e-4  # a scheduler step
+            if i == 5:  # one eager step in between (the last, ragged batch of an epoch goes this way)
+                opt.zero_grad()
+                out = model(inputs, noise=eps)
+                out.loss.backward()
+                opt.step()
+            else:
+                out = gs(inputs, eps)
+                if not in_graph:
+                    opt.step()
+            losses.append(float(out.loss.detach()))
+        torch.cuda.synchronize()
+        assert opt.step_count == len(noise) and flat.grads_zero
+        sd = opt.state_dict()
+        assert float(sd["state"][0]["step"]) == len(noise) and sd["param_groups"][0]["lr"] == 3e-4
+        res.append((losses, flat.dense(flat.flat).cpu().clone(), flat.dense(opt.m).cpu().clone(), flat.dense(opt.v).cpu().clone()))
+    (l0, p0, m0, v0), (l1, p1, m1, v1) = res
+    assert l0 == pytest.approx(l1, rel=1e-6)
+    assert torch.allclose(m0, m1, rtol=1e-5, atol=1e-9) and torch.allclose(v0, v1, rtol=1e-5, atol=1e-12)
+    diff = (p0 - p1).abs()
+    assert float(diff.max()) <= 2e-6, float(diff.max())  # 7 steps of <= 1e-3: a ulp of the step size per step at most
+
+
 @pytest.mark.parametrize("K,B", [(3, 16), (1, 24), (10, 64)])
 def test_fused_decoder_tail_matches_the_generic_path(K, B):
     """MoPoE MnistSvhn with the SVHN decoder scoring its own output (Decoder_VAE_SVHN.reconstruction_nll: Normal NLL row sums and
@@ -640,9 +690,12 @@ def _dp_worker(rank, world, port, ret, outdir):
 
     d = torch.device("cuda:0")
     model = _mnist_svhn_mopoe(d, K=_DP["K"], L=_DP["L"], seed=100 + rank)  # different weights per rank: rank 0's are broadcast
-    calls = []
+    calls, range_calls = [], []
     orig = FlatParams.all_reduce_mean
     FlatParams.all_reduce_mean = lambda self, group=None: (calls.append(1), orig(self, group))[1]
+    orig_r = FlatParams.all_reduce_mean_ranges
+    FlatParams.all_reduce_mean_ranges = lambda self, ranges, group=None: (
+        range_calls.append((torch.cuda.current_stream().cuda_stream, [tuple(r) for r in ranges])), orig_r(self, ranges, group))[1]
     cfg = BaseTrainerConfig(output_dir=outdir, per_device_train_batch_size=_DP["bs"], num_epochs=_DP["epochs"],
                             learning_rate=_DP["lr"], optimizer_cls="Adam", use_fused_adam=True, use_hip_graph=True,
                             dist_backend="gloo", world_size=world, rank=rank, local_rank=0, seed=_DP["seed"], steps_saving=None)
@@ -651,14 +704,23 @@ def _dp_worker(rank, world, port, ret, outdir):
     torch.cuda.synchronize()
     assert isinstance(tr.optimizer, FusedAdam)
     graphs = [g for g in tr.__dict__.get("_graphs", {}).values() if g is not None]
+    # the overlapped collective: what the capture marked as final early / late, in parameter names
+    g0 = graphs[0]
+    late_names = sorted(k for k, p in model.named_parameters()
+                        if any(lo <= tr.flat.ranges_of([p])[0][0] < lo + n for lo, n in (g0.late_ranges or [])))
+    covered = sorted((g0.early_ranges or []) + (g0.late_ranges or []))
     ret[rank] = dict(params=tr.flat.dense(tr.flat.flat).cpu(), loss=[h["train_epoch_loss"] for h in hist], allreduce=len(calls),
-                     steps=tr.optimizer.step_count, graphs=len(graphs))
+                     steps=tr.optimizer.step_count, graphs=len(graphs), range_calls=len(range_calls),
+                     comm_streams=len({c[0] for c in range_calls}), main_stream=torch.cuda.current_stream().cuda_stream,
+                     streams_used=[c[0] for c in range_calls[:2]], late_names=late_names, covered=covered, numel=tr.flat.numel,
+                     first_two=[c[1] for c in range_calls[:2]], early=g0.early_ranges, late=g0.late_ranges)
 
 
 @pytest.mark.timeout(900)
 def test_distributed_step_two_ranks_on_one_gpu(tmp_path):
-    """world_size 2 on ONE GPU: GraphedStep (thread-local capture) -> flat.all_reduce() (gloo on the CUDA buffer) ->
-    FusedAdam.step(grad_scale = 1 / W).  The ranks end bit-identical; they equal a single-process replay in which every step's
+    """world_size 2 on ONE GPU: GraphedStep (thread-local capture, overlap point recorded) -> reduce_and_step: the early ranges'
+    all-reduce behind the graph's event node on the communication stream, the late ranges behind the replay (gloo on the CUDA
+    buffer), FusedAdam.step(grad_scale = 1 / W).  The ranks end bit-identical; they equal a single-process replay in which every step's
     gradient is the mean over the ranks of the per-shard gradients (each shard through MoPoE on its own, i.e. with its
     own row-range subset selection) — the noise of step t is draw number `warmup + t` of the device generator after
     `set_seed` (the eager warm-up passes of the capture consume the first ones), identical on both ranks as under the
@@ -687,7 +749,20 @@ def test_distributed_step_two_ranks_on_one_gpu(tmp_path):
     n, bs, epochs, K, L = _DP["n"], _DP["bs"], _DP["epochs"], _DP["K"], _DP["L"]
     steps = epochs * (n // world // bs)
     assert r0["steps"] == r1["steps"] == steps
-    assert r0["allreduce"] == r1["allreduce"] == steps, "ONE all-reduce of the flat gradient buffer per step"
+    # the collective of a step = the early ranges (behind the graph's external event node, beside the long encoder's backward
+    # chain) + the late ranges (behind the replay), on ONE communication stream that is not the step's; every element of the
+    # buffer exactly once
+    assert r0["allreduce"] == r1["allreduce"] == 0 and r0["range_calls"] == r1["range_calls"] == 2 * steps
+    assert r0["comm_streams"] == 1 and r0["streams_used"][0] != r0["main_stream"]
+    assert r0["first_two"] == [r0["early"], r0["late"]] and r0["early"] and r0["late"]
+    pos = 0
+    for o, n_ in r0["covered"]:
+        assert o == pos, "early and late ranges must tile the buffer"
+        pos = o + n_
+    assert pos == r0["numel"]
+    # late = the LAST backward node's parameters (the convolutional encoder) + the leaf postponed into the tail of the step
+    assert all(k.startswith("encoders.svhn.") or k == "decoders.mnist.layers.0.0.weight" for k in r0["late_names"]), r0["late_names"]
+    assert sum(k.startswith("encoders.svhn.") for k in r0["late_names"]) == 10 and r0["late_names"] == r1["late_names"]
     assert r0["graphs"] == r1["graphs"] == 1, "the steps ran through the captured hipGraph"
     assert torch.equal(r0["params"], r1["params"]), "ranks diverged"
 
