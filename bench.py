@@ -424,7 +424,13 @@ def main():
     import torch.distributed as dist
 
     use_dist = world > 1 or os.environ.get("MVK_FORCE_DIST") == "1"  # the latter exercises the RCCL path on 1 GPU
+    result_fd = 1
     if use_dist:
+        # RCCL prints a version banner ("RCCL version : ...", "Librccl path : ...") on STDOUT when a communicator comes and goes:
+        # everything the libraries write to fd 1 is sent to stderr, the ONE JSON line goes to the real stdout at the very end
+        sys.stdout.flush()
+        result_fd = os.dup(1)
+        os.dup2(2, 1)
         # nccl == RCCL on ROCm.  MVK_DIST_BACKEND=gloo: the control flow of the multi-rank run on ONE GPU (RCCL refuses two
         # ranks on one device; tests/test_gpu_trainer.py runs bench.py that way with MVK_BENCH_SAME_GPU=1)
         dist.init_process_group(os.environ.get("MVK_DIST_BACKEND", "nccl"), init_method="env://", world_size=world, rank=rank)
@@ -744,10 +750,15 @@ def main():
                                          "avg_launch_us": round(v["avg_us"], 2)} for k, v in img.items() if v}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(w, args.cpu_budget)
-        print(json.dumps(res), flush=True)
+        result_line = json.dumps(res)
+    else:
+        result_line = None
     if use_dist:
         flat.close()  # mvk_comm_destroy: the RCCL communicator goes before the process group it was built through
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if result_line is not None:
+        os.write(result_fd, (result_line + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -24,8 +24,13 @@ import os
 
 import torch
 
-from .. import kernels
+from .. import _lib, kernels
 from ..data.datasets.base import DatasetOutput
+
+
+# MVK_ADAM_PRELUDE=0: the optimizer's scalar preparation directly in front of the update (end of the chain) instead of at the
+# head of a side branch (A/B)
+_ADAM_PRELUDE = _lib.tune("MVK_ADAM_PRELUDE", "1") != "0"
 
 
 class GraphedStep:
@@ -93,7 +98,7 @@ class GraphedStep:
             kw["noise"] = self.noise
         dev = self.flat.flat.device
         opt = self.optimizer if capture else None  # the eager warm-up passes must not move the parameters
-        if opt is not None:
+        if opt is not None and _ADAM_PRELUDE:
             kernels.set_prelude(dev, opt.prepare_captured)  # depends on nothing of the step: head of the first side branch
         if self.overlap_point is not None:
             self.overlap_point.begin()
@@ -104,6 +109,8 @@ class GraphedStep:
                 out.loss.backward(gradient=kernels.unit_seed(out.loss))
             if opt is not None:
                 kernels.run_prelude(dev)  # no branch took it: here, in front of the update
+                if not _ADAM_PRELUDE:
+                    opt.prepare_captured()
                 opt.step_captured()
         finally:
             kernels._PRELUDE.pop(dev, None)
