@@ -476,12 +476,16 @@ def main():
         try:
             # noise=None: the model draws its reparameterisation noise itself, inside the captured graph (as it does under
             # BaseTrainer and in the reference's forward), instead of a host-side draw + one more copy per step
-            # single GPU: the fused Adam is the graph's last node (device-resident step / lr); data parallel: the graph carries
-            # the event the early part of the gradient collective waits for (MVK_OVERLAP=0: one collective behind the replay)
+            # Two forms of the step that were built, tested and MEASURED slower on one GPU stay opt-in:
+            #   MVK_GRAPH_ADAM=1  the fused Adam as the graph's last node (device-resident step / lr): +7 ... +10 us per step against
+            #                     the host-scalar launch behind the replay (four same-box pairs, profiles/r05_bench_lines.jsonl);
+            #   MVK_OVERLAP=1     the gradient collective in two parts, the first behind an external event node of the graph: the
+            #                     node alone costs the replayed step +65 us on one GPU (hipGraph re-partitions its queues around
+            #                     it), +100 us with the second collective launch.
             graphed = GraphedStep(model, flat, inputs, noise=None,
                                   capture_error_mode="thread_local" if use_dist else "global",
-                                  optimizer=None if (use_dist or _lib.tune("MVK_GRAPH_ADAM", "1") == "0") else opt,
-                                  overlap=use_dist and os.environ.get("MVK_OVERLAP", "1") != "0", **fkw)
+                                  optimizer=opt if (not use_dist and os.environ.get("MVK_GRAPH_ADAM", "0") == "1") else None,
+                                  overlap=use_dist and os.environ.get("MVK_OVERLAP", "0") in ("1", "2"), **fkw)
         except Exception as e:  # capture is an optimisation, not a requirement
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graphed = None

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 # MVK_* variables that are NOT experiment switches (read directly, with or without MVK_TUNE)
 _ALWAYS_READ = {"MVK_TUNE", "MVK_LIB_PATH", "MVK_DEFER_MB", "MVK_SYNC_DEBUG", "MVK_TRAINER_ALLOW_CPU", "MVK_CPU_THREADS",
-                "MVK_BENCH_SAME_GPU", "MVK_FORCE_DIST", "MVK_DIST_BACKEND", "MVK_ADAM_ZERO", "MVK_RCCL", "MVK_BENCH_CHILD", "MVK_OVERLAP"}
+                "MVK_BENCH_SAME_GPU", "MVK_FORCE_DIST", "MVK_DIST_BACKEND", "MVK_ADAM_ZERO", "MVK_RCCL", "MVK_BENCH_CHILD", "MVK_OVERLAP", "MVK_GRAPH_ADAM"}
 
 
 def _warn_ignored_switches():

@@ -356,6 +356,28 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
 //     ds_write_b32;
 //   * the fast sigmoid in both forms.
 // Same sums otherwise (tap order, bias, NLL tail, wave-ordered row sum).
+// Round 5 experiment switches of the kernel below (compile-time; tools/suh_variants.sh builds and times them; medians of the fused
+// tail alone over three interleaved rounds on one box, base 58.2 us: XFIRST 56.2, PAIR 55.6, WREG 54.0 (shipped), NT 57.5,
+// XFIRST + WREG 65.1 (!), XFIRST + WREG + PAIR 57.3, all four 61.1 — the combinations are worse than their parts: the kernel is
+// bound by how its four barrier phases of two resident workgroups interleave, not by any one instruction stream):
+//   MVK_SUH_XFIRST  the targets' loads are issued BEFORE the next image's prefetch: vmcnt counts in order, so waiting for a
+//                   load issued behind the prefetch is waiting for the prefetch as well
+//   MVK_SUH_PAIR    a thread owns PAIRS of horizontally adjacent pixels (8-byte target loads and gradient stores, one tap table
+//                   of 8 entries instead of 24: the channel is the unrolled index)
+//   MVK_SUH_WREG    the weight fragments stay in registers for the whole launch (24 VGPRs) instead of 6 ds_read_b128 per image
+//   MVK_SUH_NT      nontemporal loads of the input map (read once) and stores of the gradient (read ~300 us later)
+#ifndef MVK_SUH_XFIRST
+#define MVK_SUH_XFIRST 0
+#endif
+#ifndef MVK_SUH_PAIR
+#define MVK_SUH_PAIR 0
+#endif
+#ifndef MVK_SUH_WREG
+#define MVK_SUH_WREG 1  // measured (tools/suh_run.sh, n = 5120, three interleaved rounds): fused tail 58.2 -> 54.0 us, plain 48.8 -> 45.7
+#endif
+#ifndef MVK_SUH_NT
+#define MVK_SUH_NT 0
+#endif
 template <int CU, int NT, bool NLL = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT / 128))) void small_up_fwd_h_kernel(
     const float* __restrict__ V, const float* __restrict__ Wref, const float* __restrict__ bias, float* __restrict__ U, int n, int act,
@@ -364,6 +386,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
   mvk_prof_begin(prof);
   using mvk::f16x8;
   using mvk::u32x2;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   constexpr int CV = 32, NC = 16 * CU, CS = NC + 4, P = 256, h = 16, w = 16;
   constexpr int WP = P / (NT / 64), MT = WP / 16;
   constexpr int PLANE = P * 64, WPLANE = NC * 64;  // bytes per piece plane
@@ -403,20 +426,28 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
   auto prefetch = [&](long long img) __attribute__((always_inline)) {
     const f32x4* src = reinterpret_cast<const f32x4*>(V + img * P * CV);
 #pragma unroll
-    for (int u = 0; u < NV; ++u) pre[u] = src[tid + u * NT];
+    for (int u = 0; u < NV; ++u) pre[u] = MVK_SUH_NT ? __builtin_nontemporal_load(src + tid + u * NT) : src[tid + u * NT];
   };
   constexpr int H2 = 2 * h, W2 = 2 * w, per_img = CU * H2 * W2;
   constexpr int NO = per_img / NT;
-  int tap[NO][4];
+  // output -> (tap addresses in the column matrix, bias).  Plain mapping: output o = tid + t NT of the NCHW image.  PAIR mapping
+  // (NT = 512): thread = (output row tid >> 4, pixel pair tid & 15), the unrolled index is the channel: o = cu 1024 + 2 tid + e.
+  constexpr bool PAIR = MVK_SUH_PAIR && NT == 512 && H2 * W2 == 2 * NT;
+  constexpr int NTAP = PAIR ? 2 : NO;
+  int tap[NTAP][4];
   float bia[NO];
 #pragma unroll
   for (int t = 0; t < NO; ++t) {
-    const int o = tid + t * NT;
+    const int cu = PAIR ? t / 2 : (tid + t * NT) / (H2 * W2);
+    bia[t] = bias ? bias[cu] : 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+    const int o = PAIR ? 2 * tid + t : tid + t * NT;
     const int cu = o / (H2 * W2);
     const int rem = o - cu * (H2 * W2);
     const int oh = rem / W2, ow = rem - oh * W2;
     const int ph = oh & 1, pw = ow & 1, i0 = oh >> 1, j0 = ow >> 1;
-    bia[t] = bias ? bias[cu] : 0.f;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -427,7 +458,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
         tap[t][a * 2 + b] = ok ? (ih * w + iw) * CS + cu * 16 + kh * 4 + kw : zidx;
       }
   }
-  if (tid == 0) buf[zidx] = 0.f;
+  if (tid < 3) buf[zidx + 16 * tid] = 0.f;
   // fragment addresses (bytes inside a plane): positions = B operand, weights = A operand (both [row][32 k], k-octet lq)
   int poff[MT], woff[CU];
 #pragma unroll
@@ -440,6 +471,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
     const int c = b * 16 + l15;
     woff[b] = c * 64 + ((lq ^ ((c >> 1) & 3)) << 4);
   }
+#if MVK_SUH_WREG
+  __syncthreads();  // the weight planes are complete
+  f16x8 wreg[CU][2];
+#pragma unroll
+  for (int b = 0; b < CU; ++b)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) wreg[b][p] = *reinterpret_cast<const f16x8*>(Wb + p * WPLANE + woff[b]);
+#endif
   long long img = blockIdx.x;
   if (img < n) prefetch(img);
   for (; img < n; img += gridDim.x) {
@@ -455,13 +494,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
       *reinterpret_cast<u32x2*>(Vb + PLANE + off) = u32x2{a1, b1};
     }
     __syncthreads();
-    if (img + gridDim.x < n) prefetch(img + gridDim.x);
+    if (!MVK_SUH_XFIRST && img + gridDim.x < n) prefetch(img + gridDim.x);
     float xv[NO];  // fused tail: this thread's target pixels, loaded here and first touched behind the GEMM
     if (NLL) {
       const float* xt = X + (img % xrows) * per_img;
+      if (PAIR) {
 #pragma unroll
-      for (int t = 0; t < NO; ++t) xv[t] = (MVK_SUF_ABL & 32) ? 0.25f : xt[tid + t * NT];
+        for (int c = 0; c < NO / 2; ++c) {
+          const f32x2 v2 = reinterpret_cast<const f32x2*>(xt + c * H2 * W2)[tid];
+          xv[2 * c] = v2[0], xv[2 * c + 1] = v2[1];
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < NO; ++t) xv[t] = (MVK_SUF_ABL & 32) ? 0.25f : xt[tid + t * NT];
+      }
     }
+    if (MVK_SUH_XFIRST && img + gridDim.x < n) prefetch(img + gridDim.x);
     f32x4 res[MT][CU];  // D[nn = b * 16 + 4 lq + r][pos = wave * WP + a * 16 + l15]
     {
       f16x8 pf[MT][2];
@@ -473,7 +521,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
       for (int b = 0; b < CU; ++b) {
         f16x8 wf[2];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) wf[p] = *reinterpret_cast<const f16x8*>(Wb + p * WPLANE + woff[b]);
+        for (int p = 0; p < 2; ++p) {
+#if MVK_SUH_WREG
+          wf[p] = wreg[b][p];
+#else
+          wf[p] = *reinterpret_cast<const f16x8*>(Wb + p * WPLANE + woff[b]);
+#endif
+        }
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
           f32x4 cm = f32x4{0.f, 0.f, 0.f, 0.f}, cx = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -493,25 +547,46 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
         *reinterpret_cast<f32x4*>(buf + (wave * WP + a * 16 + l15) * CS + b * 16 + 4 * lq) = res[a][b];
     __syncthreads();
     float* out = U + img * per_img;
+    // output t of this thread: its four taps (fixed order), bias, activation
+    auto pixel = [&](int t) __attribute__((always_inline)) {
+      const int tt = PAIR ? (t & 1) : t, co = PAIR ? (t >> 1) * 16 : 0;  // PAIR: the channel is a column offset of the same taps
+      // (the zero word has a copy at zidx + 16 and zidx + 32: a border tap plus a channel offset still reads a zero)
+      const float sum = ((buf[tap[tt][0] + co] + buf[tap[tt][1] + co]) + (buf[tap[tt][2] + co] + buf[tap[tt][3] + co])) + bia[t];
+      return act == MVK_ACT_SIGMOID ? mvk_fast_sigmoid(sum) : mvk_act(sum, act);
+    };
     if (NLL) {
       float part = 0.f;
+      float gv[NO];
 #pragma unroll
       for (int t = 0; t < NO; ++t) {
-        const float sum = ((buf[tap[t][0]] + buf[tap[t][1]]) + (buf[tap[t][2]] + buf[tap[t][3]])) + bia[t];
-        const float r = act == MVK_ACT_SIGMOID ? mvk_fast_sigmoid(sum) : mvk_act(sum, act), dlt = r - xv[t];
+        const float r = pixel(t), dlt = r - xv[t];
         if (!(MVK_SUF_ABL & 64)) part = fmaf(0.5f * inv_s2 * dlt, dlt, part);
-        out[tid + t * NT] = dlt * g_inv_s2 * mvk_act_grad_from_out(r, act);
+        gv[t] = dlt * g_inv_s2 * mvk_act_grad_from_out(r, act);
+      }
+      if (PAIR) {
+#pragma unroll
+        for (int c = 0; c < NO / 2; ++c) {
+          f32x2* dst = reinterpret_cast<f32x2*>(out + c * H2 * W2) + tid;
+          if (MVK_SUH_NT) __builtin_nontemporal_store(f32x2{gv[2 * c], gv[2 * c + 1]}, dst);
+          else *dst = f32x2{gv[2 * c], gv[2 * c + 1]};
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < NO; ++t) {
+          if (MVK_SUH_NT) __builtin_nontemporal_store(gv[t], out + tid + t * NT);
+          else out[tid + t * NT] = gv[t];
+        }
       }
       if (!(MVK_SUF_ABL & 64)) {
         part = wave_sum_dpp(part);
         if (lane == 0) buf[zidx + 1 + wave] = part;
       }
+    } else if (PAIR) {
+#pragma unroll
+      for (int c = 0; c < NO / 2; ++c) reinterpret_cast<f32x2*>(out + c * H2 * W2)[tid] = f32x2{pixel(2 * c), pixel(2 * c + 1)};
     } else {
 #pragma unroll
-      for (int t = 0; t < NO; ++t) {
-        const float sum = ((buf[tap[t][0]] + buf[tap[t][1]]) + (buf[tap[t][2]] + buf[tap[t][3]])) + bia[t];
-        out[tid + t * NT] = act == MVK_ACT_SIGMOID ? mvk_fast_sigmoid(sum) : mvk_act(sum, act);
-      }
+      for (int t = 0; t < NO; ++t) out[tid + t * NT] = pixel(t);
     }
     __syncthreads();  // the column matrix is overwritten by the next image's pieces
     if (NLL && wave == 0 && !(MVK_SUF_ABL & 64)) {  // the wave partials are rewritten three barriers from now at the earliest
@@ -1285,7 +1360,7 @@ static int launch_fwd(const float* V, const float* Wref, const float* bias, floa
       const size_t blds = 3 * (16 * CU) * 64 + (256 * (16 * CU + 1) + 24) * sizeof(float);  // + zero word + 16 wave partials
       const float inv_s2 = 1.f / (scale * scale), lconst = (float)(CU * 1024) * (logf(scale) + 0.91893853320467274178f);
       if (v_amax) {  // scaled fp16 pairs, weights as the A operand (small_up_fwd_h_kernel): 512-thread workgroups, 2 per CU
-        const size_t hlds = 2 * (16 * CU) * 64 + (256 * (16 * CU + 4) + 24) * sizeof(float);
+        const size_t hlds = 2 * (16 * CU) * 64 + (256 * (16 * CU + 4) + 48) * sizeof(float);  // + zero words (zidx, +16, +32), wave partials
         if (X)
           hipLaunchKernelGGL((small_up_fwd_h_kernel<CU, 512, true>), dim3(grid), dim3(512), hlds, s, V, Wref, bias, U, n, act, prof,
                              v_amax, X, xrows, inv_s2, lconst, rows, inv_s2 * grad_weight);

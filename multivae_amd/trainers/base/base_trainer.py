@@ -349,6 +349,7 @@ class BaseTrainer:
             return None
         from ..graph import GraphedStep
 
+        cfg = self.training_config
         key_fn = getattr(self.model, "graph_key", None)
         model_key = key_fn(**fwd_kwargs) if key_fn else None
         if model_key is False:  # this step is not replayable (e.g. MVAE while its KL weight changes every batch)
@@ -360,7 +361,8 @@ class BaseTrainer:
             try:
                 gs = GraphedStep(self.model, self.flat, inputs, noise=None,
                                  capture_error_mode="thread_local" if self.distributed else "global",
-                                 optimizer=None if self.distributed else self.optimizer, overlap=self.distributed, **fwd_kwargs)
+                                 optimizer=self.optimizer if (cfg.graph_optimizer and not self.distributed) else None,
+                                 overlap=bool(cfg.overlap_collective and self.distributed), **fwd_kwargs)
             except Exception as e:  # not capturable (host sync inside the model, ...): stay eager for this shape
                 logger.warning(f"hipGraph capture failed ({type(e).__name__}: {e}); running this batch shape eagerly")
                 gs = None
@@ -371,7 +373,7 @@ class BaseTrainer:
         # what is left of the step: nothing (single GPU: the optimizer is the graph's last node), or the overlapped collective +
         # Adam (data parallel)
         self._graph_tail = (lambda: None) if gs.includes_optimizer else \
-            ((lambda: gs.reduce_and_step(self.optimizer)) if self.distributed else None)
+            ((lambda: gs.reduce_and_step(self.optimizer)) if (self.distributed and gs.early_ranges) else None)
         return out
 
     def train_step(self, epoch: int):

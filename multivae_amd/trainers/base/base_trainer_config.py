@@ -46,9 +46,16 @@ class BaseTrainerConfig(BaseConfig):
     # zero_grad -> backward -> step of this trainer; a callback that writes gradients between step() and the next
     # zero_grad() would see them survive, so None (default) = on only while no user callback is installed
     fused_zero_grad: Union[bool, None] = None
+    # with use_hip_graph: the fused Adam as the last node of the replayed graph (step and learning rate in device memory; single
+    # GPU), and the data-parallel gradient collective in two parts, the first started by an event node inside the graph beside
+    # the end of the backward pass.  Both are correct (tested) and both measured SLOWER on the MnistSvhn step (+7 us; +65 us for
+    # the event node alone): off by default, worth trying where the optimizer launch or the collective is a large part of the step
+    graph_optimizer: bool = False
+    overlap_collective: bool = False
 
     # the reference's BaseTrainerConfig.from_json_file rejects unknown fields: the extension fields go to a side file
-    _EXTENSION_FIELDS = ("use_fused_adam", "sync_every_step", "use_hip_graph", "fused_zero_grad")
+    _EXTENSION_FIELDS = ("use_fused_adam", "sync_every_step", "use_hip_graph", "fused_zero_grad", "graph_optimizer",
+                         "overlap_collective")
 
     def save_json(self, dir_path, filename):
         """`<filename>.json` holds exactly the reference's fields (loads in either trainer); the multivae_amd switches

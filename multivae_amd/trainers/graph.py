@@ -152,7 +152,7 @@ class GraphedStep:
         the same order."""
         flat, dev = self.flat, self.flat.flat.device
         cur = torch.cuda.current_stream(dev)
-        if self.early_ranges and self.late_ranges:
+        if self.early_ranges and self.late_ranges and os.environ.get("MVK_OVERLAP") != "2":  # 2: event node captured, serial collective (A/B)
             comm = kernels._side_stream(dev, 61)
             kernels.call("mvk_stream_wait_event", kernels.C.c_void_p(comm.cuda_stream), self.overlap_point.event)
             with torch.cuda.stream(comm):

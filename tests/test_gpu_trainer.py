@@ -333,8 +333,8 @@ def test_deferred_reductions_fall_back_when_the_arena_is_full():
     assert float((small - full).abs().max()) <= 2e-6 * scale
 
 
-@pytest.mark.parametrize("model_name", ["MoPoE", "JMVAE", "MVAE"])
-def test_trainer_with_hip_graph(tmp_path, model_name):
+@pytest.mark.parametrize("model_name,graph_opt", [("MoPoE", False), ("JMVAE", False), ("MVAE", False), ("MoPoE", True), ("JMVAE", True)])
+def test_trainer_with_hip_graph(tmp_path, model_name, graph_opt):
     """BaseTrainerConfig.use_hip_graph: every batch shape gets one captured graph (the full batches and the short last
     one; fresh noise on every replay through the registered default generator), JMVAE re-captures while its annealing
     factor changes.  The loss goes down like in the eager run of the same seed."""
@@ -354,9 +354,15 @@ def test_trainer_with_hip_graph(tmp_path, model_name):
         else:
             model = JMVAE(JMVAEConfig(n_modalities=2, latent_dim=12, input_dims=dims, warmup=2))
         cfg = BaseTrainerConfig(output_dir=str(tmp_path), per_device_train_batch_size=64, num_epochs=4,
-                                learning_rate=1e-3, use_hip_graph=use_graph)
+                                learning_rate=1e-3, use_hip_graph=use_graph, graph_optimizer=graph_opt and use_graph,
+                                scheduler_cls="StepLR" if graph_opt else None,
+                                scheduler_params=dict(step_size=2, gamma=0.5) if graph_opt else None)
         trainer = BaseTrainer(model, train_dataset=ds, training_config=cfg)
         hist = trainer.train()
+        if graph_opt:  # graph_optimizer: the optimizer is the last node of every captured graph; the scheduler still drives it
+            assert trainer.optimizer.step_count == 4 * 6 and trainer.optimizer.lr == pytest.approx(1e-3 * 0.25)
+            if use_graph:
+                assert all(g.includes_optimizer for g in trainer._graphs.values() if g is not None)
         metrics.append([{k: v for k, v in h.items() if k.startswith("train_") and k != "train_epoch_loss"} for h in hist])
         return [h["train_epoch_loss"] for h in hist], trainer
 
@@ -683,7 +689,7 @@ def _dp_dataset():
     return MultimodalBaseDataset(data=dict(mnist=G.t(G.P.uniform((n, 1, 28, 28), 9001)), svhn=G.t(G.P.uniform((n, 3, 32, 32), 9002))))
 
 
-def _dp_worker(rank, world, port, ret, outdir):
+def _dp_worker(rank, world, port, ret, outdir, overlap=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     from multivae_amd.trainers import BaseTrainer, BaseTrainerConfig, FusedAdam
     from multivae_amd.trainers.flat import FlatParams
@@ -698,7 +704,8 @@ def _dp_worker(rank, world, port, ret, outdir):
         range_calls.append((torch.cuda.current_stream().cuda_stream, [tuple(r) for r in ranges])), orig_r(self, ranges, group))[1]
     cfg = BaseTrainerConfig(output_dir=outdir, per_device_train_batch_size=_DP["bs"], num_epochs=_DP["epochs"],
                             learning_rate=_DP["lr"], optimizer_cls="Adam", use_fused_adam=True, use_hip_graph=True,
-                            dist_backend="gloo", world_size=world, rank=rank, local_rank=0, seed=_DP["seed"], steps_saving=None)
+                            dist_backend="gloo", world_size=world, rank=rank, local_rank=0, seed=_DP["seed"], steps_saving=None,
+                            overlap_collective=overlap)
     tr = BaseTrainer(model, _dp_dataset(), training_config=cfg)
     hist = tr.train()
     torch.cuda.synchronize()
@@ -717,7 +724,8 @@ def _dp_worker(rank, world, port, ret, outdir):
 
 
 @pytest.mark.timeout(900)
-def test_distributed_step_two_ranks_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_distributed_step_two_ranks_on_one_gpu(tmp_path, overlap):
     """world_size 2 on ONE GPU: GraphedStep (thread-local capture, overlap point recorded) -> reduce_and_step: the early ranges'
     all-reduce behind the graph's event node on the communication stream, the late ranges behind the replay (gloo on the CUDA
     buffer), FusedAdam.step(grad_scale = 1 / W).  The ranks end bit-identical; they equal a single-process replay in which every step's
@@ -744,7 +752,7 @@ def test_distributed_step_two_ranks_on_one_gpu(tmp_path):
         port = s.getsockname()[1]
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_dp_worker, args=(world, port, ret, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_dp_worker, args=(world, port, ret, str(tmp_path), overlap), nprocs=world, join=True)
     r0, r1 = ret[0], ret[1]
     n, bs, epochs, K, L = _DP["n"], _DP["bs"], _DP["epochs"], _DP["K"], _DP["L"]
     steps = epochs * (n // world // bs)
@@ -752,17 +760,20 @@ def test_distributed_step_two_ranks_on_one_gpu(tmp_path):
     # the collective of a step = the early ranges (behind the graph's external event node, beside the long encoder's backward
     # chain) + the late ranges (behind the replay), on ONE communication stream that is not the step's; every element of the
     # buffer exactly once
-    assert r0["allreduce"] == r1["allreduce"] == 0 and r0["range_calls"] == r1["range_calls"] == 2 * steps
-    assert r0["comm_streams"] == 1 and r0["streams_used"][0] != r0["main_stream"]
-    assert r0["first_two"] == [r0["early"], r0["late"]] and r0["early"] and r0["late"]
-    pos = 0
-    for o, n_ in r0["covered"]:
-        assert o == pos, "early and late ranges must tile the buffer"
-        pos = o + n_
-    assert pos == r0["numel"]
-    # late = the LAST backward node's parameters (the convolutional encoder) + the leaf postponed into the tail of the step
-    assert all(k.startswith("encoders.svhn.") or k == "decoders.mnist.layers.0.0.weight" for k in r0["late_names"]), r0["late_names"]
-    assert sum(k.startswith("encoders.svhn.") for k in r0["late_names"]) == 10 and r0["late_names"] == r1["late_names"]
+    if not overlap:  # the default: ONE all-reduce of the flat gradient buffer per step, behind the replay
+        assert r0["allreduce"] == r1["allreduce"] == steps and r0["range_calls"] == 0
+    else:
+        assert r0["allreduce"] == r1["allreduce"] == 0 and r0["range_calls"] == r1["range_calls"] == 2 * steps
+        assert r0["comm_streams"] == 1 and r0["streams_used"][0] != r0["main_stream"]
+        assert r0["first_two"] == [r0["early"], r0["late"]] and r0["early"] and r0["late"]
+        pos = 0
+        for o, n_ in r0["covered"]:
+            assert o == pos, "early and late ranges must tile the buffer"
+            pos = o + n_
+        assert pos == r0["numel"]
+        # late = the LAST backward node's parameters (the convolutional encoder) + the leaf postponed into the tail of the step
+        assert all(k.startswith("encoders.svhn.") or k == "decoders.mnist.layers.0.0.weight" for k in r0["late_names"]), r0["late_names"]
+        assert sum(k.startswith("encoders.svhn.") for k in r0["late_names"]) == 10 and r0["late_names"] == r1["late_names"]
     assert r0["graphs"] == r1["graphs"] == 1, "the steps ran through the captured hipGraph"
     assert torch.equal(r0["params"], r1["params"]), "ranks diverged"
 
