@@ -187,12 +187,12 @@ typedef struct mvk_term_desc {
 } mvk_term_desc;
 int mvk_reduce_terms(const mvk_term_desc* terms, int n_terms, float loss_sum_scale, float* out, float* loss_out,
                      void* stream);
-/* The same assembly on up to 16 workgroups (the one-workgroup form is latency-bound: 19 us alone for the 170 KB of row sums of
+/* The same assembly on up to 32 workgroups of 256 threads (the one-workgroup form is latency-bound: 19 us alone for the 170 KB of row sums of
  * the headline step).  ws: caller-owned scratch of >= MVK_REDUCE_TERMS_WS_FLOATS floats whose FIRST word is an arrival counter
  * that must be 0 before the first launch and is 0 again after every launch; not shared between streams.  Every workgroup sums a
  * fixed slice of every term, the last one to arrive adds the partials in workgroup order: deterministic.  ws == NULL (or too
  * small, or no term longer than 4096 entries): exactly mvk_reduce_terms. */
-#define MVK_REDUCE_TERMS_WS_FLOATS (1 + 16 * MVK_MAX_TERMS)
+#define MVK_REDUCE_TERMS_WS_FLOATS (1 + 32 * MVK_MAX_TERMS)
 int mvk_reduce_terms_ws(const mvk_term_desc* terms, int n_terms, float loss_sum_scale, float* out, float* loss_out, float* ws,
                         int64_t ws_floats, void* stream);
 

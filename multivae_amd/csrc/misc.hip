@@ -447,17 +447,18 @@ struct TermTable {
 // term-by-term loop with a barrier per term, which cost ~1.5 us per term on the chain between forward and backward).
 // gfill: where a term's gradient w.r.t. its rows is the constant coef * lossw (KL rows), it is written here, so that a
 // backward pass whose upstream gradient is known to be 1 launches nothing (ReconLossFn.backward).
-#define MVK_TERMS_WG 16  // workgroups of the multi-workgroup form (include/mvk.h: MVK_REDUCE_TERMS_WS_FLOATS)
+#define MVK_TERMS_WG 32  // workgroups of the multi-workgroup form (include/mvk.h: MVK_REDUCE_TERMS_WS_FLOATS)
 
 // ws == null: ONE workgroup (gridDim.x == 1).  ws given: gridDim.x workgroups, workgroup g sums the g-th contiguous slice of
 // every term (slice = ceil(n / G) rounded up to 1024 entries), writes its per-term partials to ws[1 + g * MVK_MAX_TERMS + i],
 // takes a ticket (ws[0], an unsigned counter that is 0 between launches) and the LAST workgroup to arrive adds the partials in
 // workgroup order: the result does not depend on which workgroup that is.
-__global__ __launch_bounds__(1024) void reduce_terms_kernel(const TermTable tt, float* __restrict__ out,
+template <int NT>
+__global__ __launch_bounds__(NT) void reduce_terms_kernel(const TermTable tt, float* __restrict__ out,
                                                             float* __restrict__ loss_out, float* __restrict__ ws,
                                                             mvk_prof_slot* prof) {
   mvk_prof_begin(prof);
-  __shared__ float red[MVK_MAX_TERMS][16];
+  __shared__ float red[MVK_MAX_TERMS][NT / 64];
   __shared__ float vals[MVK_MAX_TERMS];
   __shared__ unsigned ticket;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -469,28 +470,28 @@ __global__ __launch_bounds__(1024) void reduce_terms_kernel(const TermTable tt, 
       s[u] = 0.f;
       if (i0 + u < tt.n) {
         const mvk_term_desc& t = tt.t[i0 + u];
-        const long long slice = ((t.n + G - 1) / G + 1023) & ~1023ll;
+        const long long slice = ((t.n + G - 1) / G + NT - 1) / NT * NT;
         const long long lo = (long long)g * slice, hi = lo + slice < t.n ? lo + slice : t.n;
         // four loads in flight per thread (a term of 35840 rows was 35 dependent load latencies: 18 us for 160 KB)
         long long j = lo + threadIdx.x;
-        for (; j + 3 * 1024 < hi; j += 4 * 1024) {
-          float v0 = t.v[j], v1 = t.v[j + 1024], v2 = t.v[j + 2048], v3 = t.v[j + 3072];
+        for (; j + 3 * NT < hi; j += 4 * NT) {
+          float v0 = t.v[j], v1 = t.v[j + NT], v2 = t.v[j + 2 * NT], v3 = t.v[j + 3 * NT];
           if (t.mask) {
             v0 = t.mask[j % t.period] ? v0 : 0.f;
-            v1 = t.mask[(j + 1024) % t.period] ? v1 : 0.f;
-            v2 = t.mask[(j + 2048) % t.period] ? v2 : 0.f;
-            v3 = t.mask[(j + 3072) % t.period] ? v3 : 0.f;
+            v1 = t.mask[(j + NT) % t.period] ? v1 : 0.f;
+            v2 = t.mask[(j + 2 * NT) % t.period] ? v2 : 0.f;
+            v3 = t.mask[(j + 3 * NT) % t.period] ? v3 : 0.f;
           }
           s[u] += (v0 + v1) + (v2 + v3);
         }
-        for (; j < hi; j += 1024) {
+        for (; j < hi; j += NT) {
           float v = t.v[j];
           if (t.mask) v = t.mask[j % t.period] ? v : 0.f;
           s[u] += v;
         }
         if (t.gfill) {
           const float gv = t.coef * t.lossw;
-          for (long long j2 = lo + threadIdx.x; j2 < hi; j2 += 1024) t.gfill[j2] = gv;
+          for (long long j2 = lo + threadIdx.x; j2 < hi; j2 += NT) t.gfill[j2] = gv;
         }
       }
     }
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(1024) void reduce_terms_kernel(const TermTable tt, 
   if (ws) {  // publish this workgroup's partials; only the last arrival goes on
     if ((int)threadIdx.x < tt.n) {
       float tot = 0.f;
-      for (int wv = 0; wv < 16; ++wv) tot += red[threadIdx.x][wv];
+      for (int wv = 0; wv < NT / 64; ++wv) tot += red[threadIdx.x][wv];
       __hip_atomic_store(ws + 1 + g * MVK_MAX_TERMS + threadIdx.x, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __threadfence();
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(1024) void reduce_terms_kernel(const TermTable tt, 
     if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned*>(ws), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else if ((int)threadIdx.x < tt.n) {
     float tot = 0.f;
-    for (int wv = 0; wv < 16; ++wv) tot += red[threadIdx.x][wv];
+    for (int wv = 0; wv < NT / 64; ++wv) tot += red[threadIdx.x][wv];
     vals[threadIdx.x] = tot * tt.t[threadIdx.x].coef;
   }
   __syncthreads();
@@ -841,11 +842,14 @@ int mvk_reduce_terms_ws(const mvk_term_desc* terms, int n_terms, float loss_sum_
   // several workgroups only where a term is long enough to give each of them a slice, and the caller lent the workspace
   int G = 1;
   if (ws && ws_floats >= MVK_REDUCE_TERMS_WS_FLOATS && longest > 4096) {
-    G = (int)((longest + 4095) / 4096);
+    G = (int)((longest + 2047) / 2048);
     if (G > MVK_TERMS_WG) G = MVK_TERMS_WG;
   }
   mvk_prof_slot* prof = mvk::prof_next(11, bytes);
-  hipLaunchKernelGGL(reduce_terms_kernel, dim3(G), dim3(1024), 0, mvk_stream(stream), tt, out, loss_out, G > 1 ? ws : nullptr, prof);
+  if (G > 1)
+    hipLaunchKernelGGL(reduce_terms_kernel<256>, dim3(G), dim3(256), 0, mvk_stream(stream), tt, out, loss_out, ws, prof);
+  else
+    hipLaunchKernelGGL(reduce_terms_kernel<1024>, dim3(1), dim3(1024), 0, mvk_stream(stream), tt, out, loss_out, nullptr, prof);
   MVK_CHECK_LAUNCH();
   mvk::prof_fold(prof, mvk_stream(stream));
   return MVK_OK;

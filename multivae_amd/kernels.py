@@ -2146,7 +2146,7 @@ def _reduce_terms(terms, n_terms, loss_sum_scale, out, loss):
     key = (out.device, torch.cuda.current_stream(out.device).cuda_stream)
     ws = _TERMS_WS.get(key)
     if ws is None:
-        ws = torch.zeros(1 + 16 * 64, dtype=torch.float32, device=out.device)  # MVK_REDUCE_TERMS_WS_FLOATS
+        ws = torch.zeros(1 + 32 * 64, dtype=torch.float32, device=out.device)  # MVK_REDUCE_TERMS_WS_FLOATS
         _TERMS_WS[key] = ws
     call("mvk_reduce_terms_ws", terms, n_terms, loss_sum_scale, ptr(out), ptr(loss), ptr(ws), ws.numel(), stream_ptr())
 

@@ -120,12 +120,56 @@ def hip_signs(model, taps, sites):
     return out
 
 
+LAST = {}  # what the last reconcile() saw: units, ambiguous, flipped, {network prefix: flipped units}
+
+
+def record_counts(case, engine, path=None):
+    """Append the counts of the last reconcile() to gpurun_out/flip_counts.jsonl (the GPU box's scratch directory, merged back
+    by gpurun; tools/make_profiles.py turns it into the tracked profiles/rNN_flip_counts.json).  Returns the record."""
+    import json
+    import os
+
+    rec = dict(case=case, engine=engine, units=LAST.get("units", 0), ambiguous=LAST.get("ambiguous", 0),
+               flipped=LAST.get("flipped", 0), flipped_by_network=LAST.get("by_network", {}))
+    path = path or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "flip_counts.jsonl")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+    return rec
+
+
+def unreachable_by_flips(param_names, by_network=None):
+    """The parameters whose gradient NO flipped unit can reach.  A flipped unit changes the backward pass through itself: the
+    gradient of everything UPSTREAM of it in its own network (conservatively: the whole network), and — when it sits in a
+    decoder — of everything that produced the decoder's input (every encoder, the joint encoder, the learnable priors whose
+    samples the decoders read).  Decoders of other modalities, and every network when only encoders flipped, keep the
+    reference's gradients: those are compared with the fixture's samples (the REFERENCE's own decisions) whatever flipped."""
+    by_network = LAST.get("by_network", {}) if by_network is None else by_network
+    hit = [p for p, c in by_network.items() if c]
+    if not hit:
+        return list(param_names)
+    dec_flip = any(p.startswith("decoders.") for p in hit)
+    out = []
+    for k in param_names:
+        if any(k.startswith(p) for p in hit):
+            continue
+        if dec_flip and not k.startswith("decoders."):
+            continue
+        out.append(k)
+    return out
+
+
 def reconcile(model, taps, sites, tau=TAU):
     """-> (decisions for OracleSites.force, number of ambiguous units, number of them the HIP path decided the other way).
     Asserts agreement on every unit outside the ambiguous set."""
     hip = hip_signs(model, taps, sites)
     assert set(hip) == set(sites.pre), (sorted(set(hip) ^ set(sites.pre)))
     forced, n_amb, n_flip = {}, 0, 0
+    LAST.clear()
+    LAST.update(units=0, ambiguous=0, flipped=0, by_network={})
     for key, pres in sites.pre.items():
         flat = torch.cat([p.reshape(-1) for p in pres])
         gm = torch.cat([m.reshape(-1) for m in hip[key]])
@@ -136,12 +180,18 @@ def reconcile(model, taps, sites, tau=TAU):
         assert clear_bad == 0, f"{key}: {clear_bad} units away from zero rectified differently by the HIP path"
         n_amb += int(amb.sum())
         n_flip += int(((om != gm) & amb).sum())
+        LAST["units"] += flat.numel()
+        LAST["by_network"][key[0]] = LAST["by_network"].get(key[0], 0) + int(((om != gm) & amb).sum())
         full = torch.where(amb, gm, om)
         parts, at = [], 0
         for p in pres:
             parts.append(full[at:at + p.numel()].reshape(p.shape))
             at += p.numel()
         forced[key] = parts
+    LAST.update(ambiguous=n_amb, flipped=n_flip)
+    # the ambiguous band is what the module's header says it is: ~10 units per million within 1e-6 of zero (x 2 for tau = 2e-6,
+    # x 5 of margin); a HIP path that pushed many more units into it has a forward-pass problem, not a summation-order one
+    assert n_amb <= 100e-6 * LAST["units"] + 5, (n_amb, LAST["units"])
     return forced, n_amb, n_flip
 
 

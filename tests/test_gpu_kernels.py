@@ -1489,7 +1489,7 @@ def test_reduce_terms_on_several_workgroups_is_deterministic_and_exact():
             v64 = v64 * mask.cpu().double().repeat(lens[i] // B)
         exp.append((0.25 + i) * float(v64.sum()))
     exp = torch.tensor(exp, dtype=torch.float64)
-    ws = torch.zeros(1 + 16 * 64, device=d)
+    ws = torch.zeros(1 + 32 * 64, device=d)
     outs = []
     for rep in range(5):
         out = torch.empty(n + 2, device=d)
