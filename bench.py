@@ -607,7 +607,8 @@ def main():
                                   ("hipGraph replay (fwd + bwd) || all-reduce of %d early + %d late ranges (%.1f + %.1f MB) + Adam" % (
                                       len(graphed.early_ranges), len(graphed.late_ranges),
                                       4e-6 * sum(n for _, n in graphed.early_ranges), 4e-6 * sum(n for _, n in graphed.late_ranges))
-                                   if graphed.early_ranges else "hipGraph replay (fwd + bwd) + all-reduce + Adam")),
+                                   if graphed.early_ranges else ("hipGraph replay (fwd + bwd) + mvk_allreduce_avg + Adam" if use_dist else
+                                                                  "hipGraph replay (fwd + bwd) + Adam"))),
                        # how the fp32 GEMM / convolution products are formed (operands, results and accumulation are fp32; the
                        # tests hold every form to the same float64-referenced tolerance)
                        "fp32_product": ("register-stationary convolutions: 3 fp16 MFMAs on scaled (hi, lo) pairs"

@@ -240,7 +240,10 @@ template <int BM, int EPI>
 // register-stationary one (imgconv DOWN forms hold 348-368 of a SIMD's 512 registers; this kernel's 173 do not fit and its launch
 // waits for theirs to end): measured, it DOES run beside them then — with 87 spilled registers, 227 us instead of 36, step +9 %.
 #endif
-__global__ __launch_bounds__(256, BM == 64 ? (EPI == 1 ? D16_NT64_BWD_OCC : 2) : D16_NT128_OCC) void d16_nt_kernel(const D16Nt g) {
+#ifndef D16_NT64_FWD_OCC
+#define D16_NT64_FWD_OCC 2
+#endif
+__global__ __launch_bounds__(256, BM == 64 ? (EPI == 1 ? D16_NT64_BWD_OCC : D16_NT64_FWD_OCC) : D16_NT128_OCC) void d16_nt_kernel(const D16Nt g) {
   constexpr int BN = 128, TM = BM / 64, TN = 2;
   constexpr int APL = BM * 64, BPL = BN * 64;  // bytes per plane tile
   constexpr int STAGE = 2 * APL + 2 * BPL;
@@ -282,7 +285,10 @@ __global__ __launch_bounds__(256, BM == 64 ? (EPI == 1 ? D16_NT64_BWD_OCC : 2) :
 // It then fits beside imgconv<DOWN, 4, 64, 128> (352 + 152) and runs there: 106 -> 133 us while that launch goes 106 -> 130 us,
 // step +0.7 % (four same-box pairs).  Two MFMA-heavy kernels on one SIMD share a power-limited matrix pipe: co-residency is zero-sum.
 #endif
-  constexpr bool ONESET = BM == 64 && EPI == 1 && D16_BWD_ONESET;
+#ifndef D16_FWD_ONESET
+#define D16_FWD_ONESET 0  // the same for the 64-row forward form (fused tail)
+#endif
+  constexpr bool ONESET = BM == 64 && ((EPI == 1 && D16_BWD_ONESET) || (EPI == 0 && D16_FWD_ONESET));
   Raw R0, R1;
   auto sel = [](bool ok, int off) { return __builtin_unpredictable(ok) ? off : 0x7fffffff; };  // out of range = zero fill
   auto gload = [&](Raw& r, int k0) {
@@ -374,9 +380,20 @@ __global__ __launch_bounds__(256, BM == 64 ? (EPI == 1 ? D16_NT64_BWD_OCC : 2) :
   __syncthreads();
   rfrag(FA, lds, 0);
   // one k-tile: LDS stage `cur` is multiplied; tile t+1 goes from `rw` to stage `nxt`, then tile t+3 is fetched into `rw`
+#ifndef D16_ONEFRAG
+#define D16_ONEFRAG 0  // 1 (with ONESET): ONE fragment set, read where it is used — 24 registers less, for 4 waves per SIMD (A/B)
+#endif
   auto ktile = [&](int t, const char* cur, char* nxt, Raw& rw) {
     lwrite(rw, nxt);               // tile t+1 (the last readers of `nxt` passed the barrier of iteration t-1)
     gload(rw, (t + (ONESET ? 2 : 3)) * 32);  // past the end of K: out of range, zero fill, no traffic
+    if (D16_ONEFRAG && ONESET) {
+      rfrag(FA, cur, 0);
+      mfmas(FA);
+      rfrag(FA, cur, 1);
+      mfmas(FA);
+      __syncthreads();
+      return;
+    }
     rfrag(FB, cur, 1);
     mfmas(FA);
     D16_INTERLEAVE(2)

@@ -472,13 +472,26 @@ def run_prelude(device):
         fn()
 
 
+# MVK_BRANCH_MAX=n: at most n streams for the modality branches (the caller's + n - 1 side streams; branches beyond that share
+# the side streams round-robin, in order).  Five PolyMNIST stacks on five streams trample each other (cfg4: c3rs_kernel 188 us
+# average, 1326 us maximum); 0 = one stream per branch.
+BRANCH_MAX = int(_lib.tune("MVK_BRANCH_MAX", "0"))
+
+
+def _branch_stream(device, i, n):
+    """The stream of branch i (i >= 1) of n."""
+    if BRANCH_MAX >= 2 and n > BRANCH_MAX:
+        i = 1 + (i - 1) % (BRANCH_MAX - 1)
+    return _side_stream(device, i)
+
+
 def run_branches(names, fn, device, side_first=False):
     """{m: fn(m)} with every branch but the first on its own stream; joined before returning."""
     names = list(names)
     if not BRANCH_STREAMS or len(names) < 2 or device.type != "cuda":
         return {m: fn(m) for m in names}
     main = torch.cuda.current_stream(device)
-    _BRANCH_SET[device] = [main] + [_side_stream(device, i) for i in range(1, len(names))]
+    _BRANCH_SET[device] = [main] + list(dict.fromkeys(_branch_stream(device, i, len(names)) for i in range(1, len(names))))
     fork = main.record_event()
     # The first branch stays on the caller's stream and is enqueued FIRST: autograd runs backward nodes in reverse
     # creation order, so the side branches' backward is enqueued (and, in a captured graph, ordered) before the long
@@ -490,14 +503,15 @@ def run_branches(names, fn, device, side_first=False):
         _FWD_DEFER_OPEN.add(device)
     sides = []
     for i, m in enumerate(names[1:], start=1):
-        st = _side_stream(device, i)
-        st.wait_event(fork)
+        st = _branch_stream(device, i, len(names))
+        if st not in sides:
+            st.wait_event(fork)
+            sides.append(st)
         with torch.cuda.stream(st):
             run_prelude(device)
             outs[m] = fn(m)
         for t in _tensors_of(outs[m]):
             t.record_stream(main)
-        sides.append(st)
     if names[0] not in outs:
         _FWD_DEFER_OPEN.discard(device)  # the main branch itself never defers
         try:
