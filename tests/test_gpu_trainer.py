@@ -162,6 +162,67 @@ def test_graph_replay_matches_eager():
     _same_training(_run_steps(d, 5, graphed=False), _run_steps(d, 5, graphed=True))
 
 
+def test_user_decoder_with_autograd_reconstruction_nll_is_ordered_behind_the_loss_assembly():
+    """the fused-tail protocol is duck-typed — a USER decoder may implement `reconstruction_nll` with ordinary
+    autograd ops.  Its backward reads the row gradients the loss-assembly launch fills, so that launch must not move to the
+    late-leaf stream for it (in a captured graph: a missing dependency, silently wrong gradients).  `kernels.orders_behind_loss`
+    keeps `async_ok` off unless every fused term comes from one of the package's nodes: the gradients of such a model — eager and
+    replayed — equal the generic path's (forward + likelihood kernel)."""
+    import math
+
+    from multivae_amd import kernels
+    from multivae_amd.data.datasets.base import DatasetOutput
+    from multivae_amd.models.base.base_config import BaseAEConfig
+    from multivae_amd.models.nn.default_architectures import Decoder_AE_MLP
+    from multivae_amd.trainers import FlatParams, GraphedStep
+
+    class UserDecoder(Decoder_AE_MLP):
+        def reconstruction_nll(self, z, x, dist="normal", scale=1.0, row_weight=None):
+            rec = self.forward(z).reconstruction  # [K, B, *D] (the in-package forward node), then plain torch ops
+            d = (rec - x) / scale
+            n = x[0].numel()
+            return 0.5 * (d * d).flatten(2).sum(-1) + n * (math.log(scale) + 0.5 * math.log(2 * math.pi))
+
+    d = torch.device("cuda:0")
+    B, K, L = 64, 4, 8
+    g = torch.Generator().manual_seed(9)
+    inputs = DatasetOutput(data=dict(mnist=torch.rand(B, 1, 28, 28, generator=g).to(d), svhn=torch.rand(B, 3, 32, 32, generator=g).to(d)))
+    eps = torch.randn(K, B, L, generator=g).to(d)
+    seen = []
+    orig = kernels.orders_behind_loss
+    kernels.orders_behind_loss = lambda rows: (seen.append(orig(rows)), seen[-1])[1]
+    try:
+        res = {}
+        for mode in ("generic", "user eager", "user graph"):
+            model = _mnist_svhn_mopoe(d, K=K, L=L)
+            if mode != "generic":
+                ud = UserDecoder(BaseAEConfig(latent_dim=L, input_dim=(1, 28, 28))).to(d)
+                ud.load_state_dict(model.decoders["mnist"].state_dict())
+                model.decoders["mnist"] = ud
+            else:
+                model.fused_decoder_tail = False
+            flat = FlatParams(model)
+            if mode == "user graph":
+                gs = GraphedStep(model, flat, inputs, noise=torch.zeros(K, B, L, device=d))
+                out = gs(inputs, eps)
+            else:
+                flat.zero_grad()
+                with kernels.deferred_reductions(flat):
+                    out = model(inputs, noise=eps)
+                    out.loss.backward(gradient=kernels.unit_seed(out.loss))
+            torch.cuda.synchronize()
+            res[mode] = (float(out.loss), flat.dense(flat.grad).cpu().clone())
+    finally:
+        kernels.orders_behind_loss = orig
+    assert False in seen and True in seen  # the user decoder's rows were recognised as foreign, the SVHN tail's as the package's
+    ref_l, ref_g = res["generic"]
+    for mode in ("user eager", "user graph"):
+        l, gr = res[mode]
+        assert l == pytest.approx(ref_l, rel=1e-5), mode
+        err = float((gr - ref_g).abs().max() / ref_g.abs().max())
+        assert err <= 1e-4, (mode, err)
+
+
 @pytest.mark.parametrize("amsgrad", [False, True])
 def test_optimizer_inside_the_graph_matches_the_host_scalar_step(amsgrad):
     """the fused Adam as the LAST NODE of the replayed step (mvk_adam_prepare + mvk_adam_step_dev: step and
