@@ -464,6 +464,13 @@ int mvk_conv3x3_wgrad_f(const float* X, const float* dY, float* dWref, float* db
  * the `amax` slot of a descriptor.  mvk_conv3x3_scaled_ok: 1 when this form takes the problem (a superset of the shapes of
  * mvk_conv3x3_fused_ok's forward side: 128 input channels reach maps up to 62 wide). */
 int mvk_amax(const float* x, int64_t n, float* out, void* stream);
+/* mvk_conv3x3 with an image (Cin <= 4) on the input side that also publishes max |Y| into y_amax (atomic max, must hold 0):
+ * conv_img of the ResNet encoders (models/nn/mmnist.py:262, cub.py:160) and the backward-data pass of the decoders' conv_img —
+ * the stack behind it needs that bound for its scaled-fp16 launches and used to get it from a pass over Y (mvk_amax).
+ * MVK_EINVAL when the direct image kernel does not take the shape (the caller then uses mvk_conv3x3 + mvk_amax). */
+int mvk_conv3x3_y(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
+                  const float* y_act_src, int y_src_act, float* colsum_acc, float* y_amax, float* ws, int64_t ws_floats,
+                  void* stream);
 int mvk_conv3x3_scaled_ok(int n, int H, int W, int Cin, int Cout);
 int mvk_conv3x3_s(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout,
                   int act, const float* y_act_src, int y_src_act, const float* res, float res_alpha, float* colsum_acc,

@@ -107,6 +107,7 @@ PROTOTYPES = {
     "mvk_conv4s2_small_up_fwd_s": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "mvk_conv4s2_small_up_bwd_pre": [_p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p],
     "mvk_conv3x3": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i64, _p],
+    "mvk_conv3x3_y": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _i64, _p],
     "mvk_conv3x3_res": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _f, _p, _i64, _p],
     "mvk_conv3x3_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i64, _p],
     "mvk_conv3x3_f": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _f, _p, _i, _f, _p, _i64, _p],
@@ -292,6 +293,7 @@ GEMM_FLOPS = {
     "mvk_conv4s2_up": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
     "mvk_conv4s2_wgrad": lambda a: 2.0 * a[3] * a[4] * a[5] * 16 * a[6] * a[7],
     "mvk_conv3x3": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
+    "mvk_conv3x3_y": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
     "mvk_conv3x3_res": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
     "mvk_conv3x3_wgrad": lambda a: 2.0 * a[3] * a[4] * a[5] * 9 * a[6] * a[7],
     "mvk_conv3x3_f": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],

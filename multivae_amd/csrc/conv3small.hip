@@ -13,11 +13,12 @@
 //     slabs, ordered (deferred) finish into the reference layout.
 #include <cstdlib>
 
-#include "common.hpp"
+#include "bf3.hpp"  // amax_publish (the amax protocol), f32x4
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+using mvk::amax_publish;
+using mvk::f32x4;
 
 struct C3Args {
   const float* X;
@@ -26,6 +27,7 @@ struct C3Args {
   float* Y;
   const float* mask_src;  // optional tensor of Y's shape: the result is multiplied by mask_act'(mask_src)
   int n, H, W, Cin, Cout, act, mask_act;
+  float* y_amax;          // smallcin only, optional: receives max |Y| (atomic max; amax protocol)
 };
 
 constexpr int C3_RB = 8;  // image rows per workgroup
@@ -58,10 +60,11 @@ __global__ __launch_bounds__(256) void conv3_smallcin_kernel(const C3Args g) {
     xs[i] = (yy >= 0 && yy < H && xcol >= 0 && xcol < W) ? ximg[((long long)yy * W + xcol) * CS + c] : 0.f;
   }
   __syncthreads();
-  if (!active) return;
-  const int npos = rows * W;
+  if (!active && !g.y_amax) return;
+  const int npos = active ? rows * W : 0;
   float* yimg = g.Y + ((long long)img * H + y0) * W * Cout;
   const float* mimg = g.mask_src ? g.mask_src + ((long long)img * H + y0) * W * Cout : nullptr;
+  float ymax = 0.f;
   for (int p = pl; p < npos; p += PL) {
     const int r = p / W, x = p - r * W;
     f32x4 acc = b4;
@@ -83,6 +86,11 @@ __global__ __launch_bounds__(256) void conv3_smallcin_kernel(const C3Args g) {
       for (int j = 0; j < 4; ++j) acc[j] *= mvk_act_grad_from_out(ms[j], g.mask_act);
     }
     *reinterpret_cast<f32x4*>(yimg + (long long)p * Cout + 4 * cg) = acc;
+    ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(acc[0]), fabsf(acc[1]))), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
+  }
+  if (g.y_amax) {  // every thread of the workgroup (amax_publish synchronises); the staging tile is dead: its head is the scratch
+    __syncthreads();
+    amax_publish(ymax, g.y_amax, xs);
   }
 }
 
@@ -307,11 +315,11 @@ namespace mvk {
 
 // 1: shape not covered (the caller continues with the GEMM engine)
 int conv3_smallcin(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
-                   const float* mask_src, int mask_act, hipStream_t s) {
+                   const float* mask_src, int mask_act, hipStream_t s, float* y_amax) {
   static const int off = mvk_tune("MVK_CONV3SMALL") ? atoi(mvk_tune("MVK_CONV3SMALL")) == 0 : 0;
   if (off || Cin < 1 || Cin > 4 || Cout % 4 != 0 || Cout < 4 || Cout > 1024 || W > 256 || n < 1) return 1;
   if (!mvk_aligned16(Wp) || !mvk_aligned16(Y) || (bias && !mvk_aligned16(bias)) || (mask_src && !mvk_aligned16(mask_src))) return 1;
-  C3Args a{X, Wp, bias, Y, mask_src, n, H, W, Cin, Cout, act, mask_act};
+  C3Args a{X, Wp, bias, Y, mask_src, n, H, W, Cin, Cout, act, mask_act, y_amax};
   const int bands = (H + C3_RB - 1) / C3_RB;
   const size_t lds = (size_t)(C3_RB + 2) * (W + 2) * Cin * sizeof(float);
   const dim3 grid((unsigned)(n * bands));
@@ -330,7 +338,7 @@ int conv3_smallcout(const float* X, const float* Wp, const float* bias, float* Y
                     const float* mask_src, int mask_act, hipStream_t s) {
   static const int off = mvk_tune("MVK_CONV3SMALL") ? atoi(mvk_tune("MVK_CONV3SMALL")) == 0 : 0;
   if (off || Cout < 1 || Cout > 4 || Cin % 16 != 0 || Cin < 16 || Cin > 256 || n < 1 || !mvk_aligned16(X)) return 1;
-  C3Args a{X, Wp, bias, Y, mask_src, n, H, W, Cin, Cout, act, mask_act};
+  C3Args a{X, Wp, bias, Y, mask_src, n, H, W, Cin, Cout, act, mask_act, nullptr};
   static const int mfma = mvk_tune("MVK_SMALLCOUT_MFMA") ? atoi(mvk_tune("MVK_SMALLCOUT_MFMA")) : 0;  // A/B: the MFMA kernel
   if (!mfma) {
     const dim3 vgrid((unsigned)((long long)n * ((W + C3V_TC - 1) / C3V_TC) * ((H + C3V_TR - 1) / C3V_TR)));

@@ -694,7 +694,7 @@ using namespace mvk;
 namespace mvk {
 // conv3small.hip: 3x3 convolutions with an image (<= 4 channels) on one side: 1 = shape not covered
 int conv3_smallcin(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
-                   const float* mask_src, int mask_act, hipStream_t s);
+                   const float* mask_src, int mask_act, hipStream_t s, float* y_amax = nullptr);
 int conv3_smallcout(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
                     const float* mask_src, int mask_act, hipStream_t s);
 int conv3_small_wgrad(const float* X, const float* dY, float* slab, long long slab_floats, int n, int H, int W, int Cin, int Cout,
@@ -1106,18 +1106,21 @@ static int conv3x3_any(const float* X, const float* Wp, const float* bias, float
                        float* ws, int64_t ws_floats, void* stream, int x_act = MVK_ACT_NONE, float pre_scale = 1.f,
                        const float* x_amax = nullptr, const float* w_amax = nullptr, float* y_amax = nullptr) {
   // forms only the register-stationary kernels take
-  const bool fused = x_act != MVK_ACT_NONE || pre_scale != 1.f || x_amax || w_amax || y_amax;
+  // (y_amax alone with an image on the input side: the direct kernel of conv3small.hip publishes it, mvk_conv3x3_y)
+  const bool img_y = y_amax && !x_amax && !w_amax && Cin <= 4 && !res && x_act == MVK_ACT_NONE && pre_scale == 1.f;
+  const bool fused = !img_y && (x_act != MVK_ACT_NONE || pre_scale != 1.f || x_amax || w_amax || y_amax);
   const int np = x_amax && w_amax ? 2 : 3;
   if (!X || !Wp || !Y || n < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (!x_amax != !w_amax)) return MVK_EINVAL;
   if (fused && !(n > 0 && ws && ws_floats >= 256ll * Cout && !(res && colsum_acc) && mvk_aligned16(X) &&
                  (!colsum_acc || y_act_src) && c3rs_covers(n, H, W, Cin, Cout, np)))
     return MVK_EINVAL;  // ask mvk_conv3x3_fused_ok / mvk_conv3x3_scaled_ok first
   if (n > 0 && Cin <= 4 && !res) {  // the image-consuming layer (or the backward-data pass of the image-producing one)
-    const int rc = conv3_smallcin(X, Wp, bias, Y, n, H, W, Cin, Cout, act, y_act_src, y_src_act, mvk_stream(stream));
+    const int rc = conv3_smallcin(X, Wp, bias, Y, n, H, W, Cin, Cout, act, y_act_src, y_src_act, mvk_stream(stream), y_amax);
     if (rc == MVK_OK && colsum_acc)
       return colsum(Y, nullptr, 0, n * H * W, Cout, colsum_acc, ws, ws_floats, mvk_stream(stream));
     if (rc != 1) return rc;
   }
+  if (img_y) return MVK_EINVAL;  // mvk_conv3x3_y: only the direct image kernel publishes without the scaled operands
   if (n > 0 && Cout <= 4 && !res) {  // the image-producing layer
     const int rc = conv3_smallcout(X, Wp, bias, Y, n, H, W, Cin, Cout, act, y_act_src, y_src_act, mvk_stream(stream));
     if (rc == MVK_OK && colsum_acc)
@@ -1194,6 +1197,16 @@ int mvk_conv3x3_f(const float* X, const float* Wp, const float* bias, float* Y, 
                   float pre_scale, float* ws, int64_t ws_floats, void* stream) {
   return conv3x3_any(X, Wp, bias, Y, n, H, W, Cin, Cout, act, y_act_src, y_src_act, colsum_acc, res, res_alpha, ws, ws_floats,
                      stream, x_act, pre_scale);
+}
+
+// mvk_conv3x3 for an IMAGE on the input side (Cin <= 4: conv_img of the ResNet encoders, the backward-data pass of the decoders'
+// conv_img) that also publishes max |Y| (amax protocol): the stack behind it takes the scaled-fp16 form without a pass over Y.
+int mvk_conv3x3_y(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
+                  const float* y_act_src, int y_src_act, float* colsum_acc, float* y_amax, float* ws, int64_t ws_floats,
+                  void* stream) {
+  if (!y_amax || Cin > 4) return MVK_EINVAL;
+  return conv3x3_any(X, Wp, bias, Y, n, H, W, Cin, Cout, act, y_act_src, y_src_act, colsum_acc, nullptr, 0.f, ws, ws_floats, stream,
+                     MVK_ACT_NONE, 1.f, nullptr, nullptr, y_amax);
 }
 
 // The scaled-fp16 form of mvk_conv3x3_f (3 MFMAs per product instead of 6, csrc/bf3.hpp): x_amax / w_amax = device scalars

@@ -887,8 +887,12 @@ def conv_up(V, wup, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src=Non
 LEAKY = ACT["leaky_relu_0.2"]
 
 
+# MVK_C3_Y_AMAX=0: the image-side 3x3 launches do not publish max |Y| (an mvk_amax pass computes it where needed; A/B)
+C3_Y_AMAX = _lib.tune("MVK_C3_Y_AMAX", "1") != "0"
+
+
 def conv3x3(X, wpack, bias, n, H, W, Cin, Cout, act=NONE, y_act_src=None, y_src_act=NONE, out_bias=None, res=None,
-            res_alpha=1.0):
+            res_alpha=1.0, y_amax=None):
     """3x3/1/1 convolution on NHWC (forward with the forward pack; backward data with the backward pack and Cin/Cout
     swapped, y_act_src = the activation whose derivative multiplies the result, out_bias = the bias whose gradient is
     the channel sum of the result, res: the result becomes res + res_alpha * result in the same pass)."""
@@ -901,6 +905,10 @@ def conv3x3(X, wpack, bias, n, H, W, Cin, Cout, act=NONE, y_act_src=None, y_src_
              ptr(res), float(res_alpha), ptr(ws), ws.numel(), stream_ptr())
         return Y
     tb, rb = _bias_target(out_bias)
+    if y_amax is not None:  # image on the input side + published maximum (mvk_conv3x3_y; MvkError when the shape is not covered)
+        call("mvk_conv3x3_y", ptr(X), ptr(wpack), ptr(bias), ptr(Y), n, H, W, Cin, Cout, act, ptr(y_act_src), y_src_act,
+             ptr(tb), ptr(y_amax), ptr(ws), ws.numel(), stream_ptr())
+        return Y if out_bias is None else (Y, rb)
     call("mvk_conv3x3", ptr(X), ptr(wpack), ptr(bias), ptr(Y), n, H, W, Cin, Cout, act, ptr(y_act_src), y_src_act,
          ptr(tb), ptr(ws), ws.numel(), stream_ptr())
     return Y if out_bias is None else (Y, rb)
@@ -1778,6 +1786,14 @@ def _rs_conv(pool, X, xam, wpack, bias, n, H, W, Cin, Cout, **kw):
         return conv3x3_f(X, wpack, bias, n, H, W, Cin, Cout, **kw), None
     kw.pop("x_act", None)
     kw.pop("pre_scale", None)
+    if pool is not None and Cin <= 4 and Cout % 4 == 0 and kw.get("res") is None and C3_Y_AMAX:
+        # an image on the input side (conv_img of an encoder, the backward-data pass of a decoder's conv_img): the direct
+        # kernel publishes max |Y| itself — the stack behind it takes the scaled-fp16 form without an amax pass over Y
+        yam = pool.take()
+        try:
+            return conv3x3(X, wpack, bias, n, H, W, Cin, Cout, y_amax=yam, **kw), yam
+        except _lib.MvkError:
+            pass  # shape not covered by the direct kernel (MVK_EINVAL): the plain launch below
     return conv3x3(X, wpack, bias, n, H, W, Cin, Cout, **kw), None
 
 
@@ -2152,11 +2168,15 @@ def is_unit_seed(g):
     return t is not None and t.shape == g.shape and t.device == g.device
 
 
+TERMS_MULTI_WG = _lib.tune("MVK_TERMS_WS", "1") != "0"  # 0: the one-workgroup launch (A/B)
 _TERMS_WS = {}  # (device, stream) -> the arrival counter + partials of mvk_reduce_terms_ws (zero between launches)
 
 
 def _reduce_terms(terms, n_terms, loss_sum_scale, out, loss):
     """The scalar assembly on the current stream, on several workgroups where a term is long (mvk_reduce_terms_ws)."""
+    if not TERMS_MULTI_WG:
+        call("mvk_reduce_terms", terms, n_terms, loss_sum_scale, ptr(out), ptr(loss), stream_ptr())
+        return
     key = (out.device, torch.cuda.current_stream(out.device).cuda_stream)
     ws = _TERMS_WS.get(key)
     if ws is None:
@@ -2265,6 +2285,9 @@ class ReconLossFn(Function):
         # deferred finishes run, instead of between the last forward and the first backward launch of the critical chain.
         late = late_leaves(ref.device, *extras) if (ASYNC_LOSS and n_rec == 0 and spec.get("async_ok")) else None
         if late is not None and late.on:
+            # (postponing this launch behind the image layer's backward kernel — it competes with that kernel's persistent
+            # workgroups for CU slots at the head of the backward pass — was measured: +60 us per step, the ninth cross-stream
+            # edge inside the captured step that lost; profiles/NOTES_r05.md section 9)
             with late:
                 _reduce_terms(terms, n_terms, spec["loss_sum_scale"], out, loss)
                 st = torch.cuda.current_stream(ref.device)

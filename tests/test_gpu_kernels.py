@@ -923,6 +923,32 @@ def test_conv3x3_fwd_bwd(K, n, H, W, Cin, Cout):
     close(wparam.grad, w.grad, what="conv3x3 backward weight")
 
 
+@pytest.mark.parametrize("n,H,W,Cin,Cout", [(3, 64, 64, 3, 64), (7, 28, 28, 3, 64), (2, 9, 13, 1, 32), (5, 28, 28, 4, 128)])
+def test_conv3x3_image_side_publishes_its_maximum(K, n, H, W, Cin, Cout):
+    """mvk_conv3x3_y: the direct kernel for an image (Cin <= 4) on the input side (conv_img of the ResNet encoders, the backward
+    data of the decoders' conv_img) writes what mvk_conv3x3 writes — bit for bit, with and without the mask of a landing
+    activation — and publishes max |Y| into a zeroed slot (amax protocol): exactly the maximum of its result, ragged bands and
+    inactive threads included; a slot that already holds a larger bound keeps it."""
+    gen = g(57)
+    d = dev()
+    x = torch.randn(n, H, W, Cin, generator=gen).to(d)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=gen) / (3 * Cin ** 0.5)).to(d)
+    b = (0.1 * torch.randn(Cout, generator=gen)).to(d)
+    src = torch.randn(n, H, W, Cout, generator=gen).to(d)
+    (wf, _), = K.pack_weights([(w, "c3", True, True)])
+    for kw in (dict(act=K.LEAKY), dict(y_act_src=src, y_src_act=K.LEAKY)):
+        ref = K.conv3x3(x, wf, b, n, H, W, Cin, Cout, **kw)
+        slot = torch.zeros(1, device=d)
+        got = K.conv3x3(x, wf, b, n, H, W, Cin, Cout, y_amax=slot, **kw)
+        assert torch.equal(got, ref)
+        assert float(slot) == float(ref.abs().max())
+        big = torch.full((1,), 1e6, device=d)
+        K.conv3x3(x, wf, b, n, H, W, Cin, Cout, y_amax=big, **kw)
+        assert float(big) == 1e6
+    y64 = F.leaky_relu(F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), b.double().cpu(), 1, 1), 0.2)
+    close(K.conv3x3(x, wf, b, n, H, W, Cin, Cout, act=K.LEAKY, y_amax=torch.zeros(1, device=d)), y64.permute(0, 2, 3, 1), what="conv3x3_y vs float64")
+
+
 @pytest.mark.parametrize("n,H,W,Cin,Cout", [(5, 64, 64, 64, 64), (9, 32, 32, 64, 128), (40, 16, 16, 128, 128), (33, 16, 16, 128, 256),
                                           (70, 28, 28, 64, 64), (130, 14, 14, 128, 64), (300, 7, 7, 128, 128), (2, 7, 7, 128, 256),
                                           (1, 9, 13, 64, 64), (3, 32, 32, 128, 64), (20, 16, 16, 256, 128), (2, 14, 14, 256, 256)])

@@ -214,7 +214,10 @@ def test_user_decoder_with_autograd_reconstruction_nll_is_ordered_behind_the_los
             res[mode] = (float(out.loss), flat.dense(flat.grad).cpu().clone())
     finally:
         kernels.orders_behind_loss = orig
-    assert False in seen and True in seen  # the user decoder's rows were recognised as foreign, the SVHN tail's as the package's
+    assert seen and not any(seen)  # the user decoder's rows were recognised as foreign (it is asked first: all() stops there)
+    stock = _mnist_svhn_mopoe(d, K=K, L=L)  # ... and the package's own fused tails as its own
+    rows = stock.decoders["svhn"].reconstruction_nll(torch.randn(K, B, L, device=d, requires_grad=True), inputs.data["svhn"], "normal", 1.0)
+    assert rows is not None and kernels.orders_behind_loss(rows)
     ref_l, ref_g = res["generic"]
     for mode in ("user eager", "user graph"):
         l, gr = res[mode]
