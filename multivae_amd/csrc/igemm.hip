@@ -701,7 +701,8 @@ int conv3_small_wgrad(const float* X, const float* dY, float* slab, long long sl
                       int* nz, hipStream_t s);
 // skinny.hip: few-row linear layer (a workgroup per 16 x 16 output tile, its waves split K): 1 = shape not covered
 int heads_launch(const float* X, const float* W0, const float* b0, float* Y0, const float* W1, const float* b1, float* Y1,
-                 int M, int N, int K, long long w_sk, long long w_sn, int act, hipStream_t s);
+                 int M, int N, int K, long long w_sk, long long w_sn, int act, hipStream_t s, float* ws = nullptr,
+                 long long ws_floats = 0);
 // skinny.hip: backward of 1 or 2 narrow heads in one launch (slabs per 128-row group); 1 = shape not covered
 int heads_bwd_launch(const float* X, int x_act, const float* dY0, const float* dY1, const float* W0, const float* W1,
                      long long w_sk, long long w_sn, int flat_c, float* dX, float* wslab0, float* wslab1, float* bslab0,
@@ -783,8 +784,11 @@ int mvk_linear_fwd(const float* X, const float* W, const float* b, float* Y, int
   // a few hundred rows (the encoders' hidden layers at the training batch): too few 128-row tiles for the tiled engine,
   // which then splits K and needs a second launch to reduce (47 us for 512 x 784 -> 400); one 16 x 16 tile per workgroup
   static const int fewrows = mvk_tune("MVK_FEWROWS") ? atoi(mvk_tune("MVK_FEWROWS")) : 1024;
+  // (with scratch the kernel splits long reductions over workgroups: 32 rows x 12544 features, the heads of the PolyMNIST ResNet
+  // encoders, 57 -> ~10 us; the fat heads of the 64x64 ResNet encoder — 128 x 65536 -> 64, 4 M weights — measured SLOWER there
+  // than on the tiled engine, cfg5 8.40 vs 8.34 ms, so the size limit stays)
   if (M <= fewrows && K >= 64 && (long long)N * K <= (1 << 21)) {
-    const int rc = heads_launch(X, W, b, Y, nullptr, nullptr, nullptr, M, N, K, 1, K, act, mvk_stream(stream));
+    const int rc = heads_launch(X, W, b, Y, nullptr, nullptr, nullptr, M, N, K, 1, K, act, mvk_stream(stream), ws, ws_floats);
     if (rc != 1) return rc;
   }
   GemmDesc d{};

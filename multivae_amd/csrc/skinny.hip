@@ -20,6 +20,11 @@ struct HeadsArgs {
   float* Y[2];
   int M, N, K, tiles_per_head, act, wvec;  // wvec: 16-byte weight loads (w_sk == 1, rows and bases 16-byte aligned)
   long long w_sk, w_sn;  // W(k, n) = W[k * w_sk + n * w_sn]
+  // K split over gridDim.z workgroups (few output tiles, long reductions: the heads of the ResNet encoders, K = 12544 ... 65536
+  // from 32 ... 128 rows — four workgroups walked K = 12544 in 57 us, latency-bound): raw sums go to part[z][head][M][N],
+  // heads_finish_kernel adds the slices in order and applies bias + activation
+  float* part;
+  int kz;  // k range of a z slice (a multiple of 16)
 };
 
 template <int NW>  // waves per workgroup = K slices (4 for short reductions, 16 for K >= 1024: the loop is latency-bound)
@@ -30,8 +35,9 @@ __global__ __launch_bounds__(NW * 64) void heads_fwd_kernel(const HeadsArgs g) {
   const int m0 = blockIdx.x * 16;
   const float* __restrict__ W = g.W[head];
   const int K = g.K, N = g.N;
-  const int kw = ((K + 16 * NW - 1) / (16 * NW)) * 16;  // k range of a wave, a multiple of 16
-  const int k0 = wave * kw, k1 = min(K, k0 + kw);
+  const int kbeg = g.part ? (int)blockIdx.z * g.kz : 0, kend = g.part ? min(K, kbeg + g.kz) : K;
+  const int kw = ((kend - kbeg + 16 * NW - 1) / (16 * NW)) * 16;  // k range of a wave, a multiple of 16
+  const int k0 = kbeg + wave * kw, k1 = min(kend, k0 + kw);
   const int row = min(m0 + l15, g.M - 1);  // clamped: rows past M are computed and not stored
   const int n = n0 + l15;
   const bool nok = n < N;
@@ -72,11 +78,33 @@ __global__ __launch_bounds__(NW * 64) void heads_fwd_kernel(const HeadsArgs g) {
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; w += 4) t += (red[w][o] + red[w + 1][o]) + (red[w + 2][o] + red[w + 3][o]);
-      g.Y[head][(long long)m * N + n] = mvk_act(t + bias, g.act);
+      if (g.part)
+        g.part[(((long long)blockIdx.z * (gridDim.y / g.tiles_per_head) + head) * g.M + m) * N + n] = t;
+      else
+        g.Y[head][(long long)m * N + n] = mvk_act(t + bias, g.act);
     }
   }
 }
 
+
+// Y[head][m][n] = act(sum_z part[z][head][m][n] + b[head][n]), the slices in order (deterministic)
+__global__ __launch_bounds__(256) void heads_finish_kernel(const HeadsArgs g, int heads, int nz) {
+  const long long per = (long long)g.M * g.N;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= per * heads) return;
+  const int head = (int)(i / per);
+  const long long r = i - head * per;
+  const int n = (int)(r % g.N);
+  float t = 0.f;
+  int z = 0;
+  for (; z + 3 < nz; z += 4) {  // four loads in flight, added in z order
+    const float a0 = g.part[((long long)(z + 0) * heads + head) * per + r], a1 = g.part[((long long)(z + 1) * heads + head) * per + r];
+    const float a2 = g.part[((long long)(z + 2) * heads + head) * per + r], a3 = g.part[((long long)(z + 3) * heads + head) * per + r];
+    t = (((t + a0) + a1) + a2) + a3;
+  }
+  for (; z < nz; ++z) t += g.part[((long long)z * heads + head) * per + r];
+  g.Y[head][r] = mvk_act(t + (g.b[head] ? g.b[head][n] : 0.f), g.act);
+}
 
 // ---- backward of the heads in ONE launch -----------------------------------------------------------------------------------
 // Six launches of the tiled engine before (two weight gradients with their split-K finishes, two bias column sums, two
@@ -227,7 +255,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const HeadsBwdArgs g) {
 namespace mvk {
 // Y_h = X W_h + b_h for 1 or 2 narrow heads; 1 = shape not covered
 int heads_launch(const float* X, const float* W0, const float* b0, float* Y0, const float* W1, const float* b1, float* Y1,
-                 int M, int N, int K, long long w_sk, long long w_sn, int act, hipStream_t s) {
+                 int M, int N, int K, long long w_sk, long long w_sn, int act, hipStream_t s, float* ws, long long ws_floats) {
   if ((W1 && N > 32) || N < 1 || K % 4 != 0 || K < 4 || !mvk_aligned16(X) || M < 1) return 1;
   const int wvec = w_sk == 1 && (w_sn & 3) == 0 && mvk_aligned16(W0) && (!W1 || mvk_aligned16(W1));
   HeadsArgs a{};
@@ -247,8 +275,30 @@ int heads_launch(const float* X, const float* W0, const float* b0, float* Y0, co
   a.w_sk = w_sk;
   a.w_sn = w_sn;
   const int heads = W1 ? 2 : 1;
-  const dim3 grid((M + 15) / 16, heads * a.tiles_per_head);
+  dim3 grid((M + 15) / 16, heads * a.tiles_per_head);
   static const int nw_env = mvk_tune("MVK_HEADS_WAVES") ? atoi(mvk_tune("MVK_HEADS_WAVES")) : 0;  // A/B switch
+  // few tiles and a long reduction: split K over workgroups (MVK_HEADS_KSPLIT=0 switches it off)
+  static const int ksplit_on = mvk_tune("MVK_HEADS_KSPLIT") ? atoi(mvk_tune("MVK_HEADS_KSPLIT")) : 1;
+  const int tiles = (int)(grid.x * grid.y);
+  int nz = 1;
+  if (ksplit_on && ws && tiles <= 64 && K >= 2048) {
+    nz = K / 256;                                   // >= 256 k per slice: one pass of 16 waves x 16
+    const int cap = tiles >= 32 ? 64 : 128;         // ~2-4 k workgroups at most
+    if (nz > cap) nz = cap;
+    a.kz = ((K + nz - 1) / nz + 15) & ~15;
+    nz = (K + a.kz - 1) / a.kz;
+    if (nz < 2 || (long long)nz * heads * M * N > ws_floats) nz = 1;
+  }
+  if (nz > 1) {
+    a.part = ws;
+    grid.z = nz;
+    hipLaunchKernelGGL(heads_fwd_kernel<16>, grid, dim3(1024), 0, s, a);
+    MVK_CHECK_LAUNCH();
+    const long long total = (long long)heads * M * N;
+    hipLaunchKernelGGL(heads_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, heads, nz);
+    MVK_CHECK_LAUNCH();
+    return MVK_OK;
+  }
   if (nw_env ? nw_env == 16 : K >= 1024)
     hipLaunchKernelGGL(heads_fwd_kernel<16>, grid, dim3(1024), 0, s, a);
   else
@@ -299,7 +349,7 @@ extern "C" int mvk_heads_fwd(const float* X, const float* W0, const float* b0, f
   if (M == 0) return MVK_OK;
   if (!X || !W0 || !Y0 || (W1 && !Y1) || M < 0 || N <= 0 || N > 32 || K <= 0 || K % 4 != 0 || !mvk_aligned16(X))
     return MVK_EINVAL;
-  const int rc = mvk::heads_launch(X, W0, b0, Y0, W1, b1, Y1, M, N, K, w_sk, w_sn, MVK_ACT_NONE, mvk_stream(stream));
+  const int rc = mvk::heads_launch(X, W0, b0, Y0, W1, b1, Y1, M, N, K, w_sk, w_sn, MVK_ACT_NONE, mvk_stream(stream), nullptr, 0);
   return rc == 1 ? MVK_EINVAL : rc;
 }
 

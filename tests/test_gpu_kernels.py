@@ -116,6 +116,27 @@ def test_linear_fwd_bwd(K, M, N, K_, act):
     close(bd.grad - 1, br.grad, rtol=2e-4, what="direct-accumulated bias grad")
 
 
+@pytest.mark.parametrize("M,N,K_,act", [(32, 32, 12544, "none"), (128, 64, 16384, "none"), (20, 24, 4100, "relu"), (256, 32, 2048, "sigmoid")])
+def test_linear_fwd_few_rows_long_reduction(K, M, N, K_, act):
+    """mvk_linear_fwd where the output has a handful of 16 x 16 tiles and K is long (the heads of the ResNet encoders: 32 rows x
+    12544 features at cfg4): the reduction is split over workgroups, raw slices go to the caller's scratch
+    and heads_finish_kernel adds them in order with bias + activation.  Against float64 (exact-fp32 MFMA: 3e-6 of the largest
+    output), ragged K / M / N, and bit-identical launch to launch."""
+    gen = g(M + K_)
+    x = torch.randn(M, K_, generator=gen)
+    w = torch.randn(N, K_, generator=gen) / math.sqrt(K_)
+    b = torch.randn(N, generator=gen)
+    a = {"relu": 1, "sigmoid": 2, "none": 0}[act]
+    f = {"relu": torch.relu, "sigmoid": torch.sigmoid, "none": lambda t: t}[act]
+    y64 = f(F.linear(x.double(), w.double(), b.double()))
+    d = dev()
+    xd, wd, bd = x.to(d), w.to(d), b.to(d)
+    y = K.linear_fwd(xd, wd, bd, a)
+    err = float((y.double().cpu() - y64).abs().max() / y64.abs().max())
+    assert err <= 3e-6, err
+    assert torch.equal(y, K.linear_fwd(xd, wd, bd, a))
+
+
 def test_linear_bwd_data_fused_prev_act_and_accumulate(K):
     gen = g(3)
     M, N, K_ = 50, 24, 36
