@@ -912,7 +912,9 @@ def test_jmvae_posterior(K, M, B, L, Kk):
 
 @pytest.mark.parametrize("n,H,W,Cin,Cout", [(3, 7, 7, 64, 128), (2, 14, 14, 128, 64), (5, 28, 28, 3, 64), (2, 28, 28, 64, 3),
                                           (40, 16, 16, 64, 64), (3, 64, 64, 3, 64), (3, 64, 64, 64, 3), (2, 13, 11, 3, 32),
-                                          (2, 13, 19, 32, 3), (1, 9, 40, 1, 16), (1, 9, 40, 16, 1)])
+                                          (2, 13, 19, 32, 3), (1, 9, 40, 1, 16), (1, 9, 40, 16, 1),
+                                          # few positions, long reductions: the split-K route of the tiled engine (round 5)
+                                          (32, 7, 7, 128, 128), (8, 7, 7, 256, 128), (32, 7, 7, 128, 256)])
 def test_conv3x3_fwd_bwd(K, n, H, W, Cin, Cout):
     """mvk_conv3x3 / mvk_conv3x3_wgrad (+ kind-2 weight pack) vs F.conv2d(3, 1, 1) + LeakyReLU(0.2): forward, backward
     data with the fused activation derivative and bias-gradient column sums, backward weight in the reference layout."""
