@@ -564,6 +564,18 @@ int mvk_conv4s2_small_up_fwd_s(const float* V, const float* Wref, const float* b
 int mvk_conv4s2_small_up_fwd_nll_s(const float* V, const float* Wref, const float* bias, const float* X, int xrows, float scale,
                                    float grad_weight, float* dpre, float* rows, int n, int h, int w, int Cu, int Cv, int act,
                                    const float* v_amax, void* stream);
+/* The image layer's backward on scaled fp16 pairs (round 5; same reference lines as mvk_conv4s2_small_up_bwd_pre:
+ * models/nn/svhn.py:58-60 ConvTranspose2d(32, 3, 4, 2, 1) + Sigmoid under models/base/base_utils.py:62-87's log-probability).
+ * _fwd_nll_sy = _fwd_nll_s that also publishes an upper bound of max |dpre| into *dpre_amax (atomic max; must hold 0 before the
+ * launch; from the largest row sum: at most sqrt(Cu 4 h w) times the true maximum); _bwd_pre_s = _bwd_pre_y with the gradient
+ * image scaled under dpre_amax x max |rowscale| and V under v_amax (dv_amax may be NULL). */
+int mvk_conv4s2_small_up_fwd_nll_sy(const float* V, const float* Wref, const float* bias, const float* X, int xrows, float scale,
+                                    float grad_weight, float* dpre, float* rows, int n, int h, int w, int Cu, int Cv, int act,
+                                    const float* v_amax, float* dpre_amax, void* stream);
+int mvk_conv4s2_small_up_bwd_pre_s(const float* dpre, const float* rowscale, const float* V, int v_act, const float* Wref,
+                                   float* dV, float* dWref, float* db, float* db_v, float* ws, int64_t ws_floats, int n, int h,
+                                   int w, int Cu, int Cv, const float* dpre_amax, const float* v_amax, float* dv_amax,
+                                   void* stream);
 
 /* 1x1-spatial layers:
  *   unflatten  Y[n,(tap,co)] = act(z[n,Cin] Wp + b[co]), Wp[ci][tap*Cout+co] = Wref[ci][co][tap]

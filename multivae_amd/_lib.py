@@ -105,6 +105,8 @@ PROTOTYPES = {
     "mvk_conv4s2_small_up_fwd_nll_w": [_p, _p, _p, _p, _i, _f, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "mvk_conv4s2_small_up_fwd_nll_s": [_p, _p, _p, _p, _i, _f, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "mvk_conv4s2_small_up_fwd_s": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
+    "mvk_conv4s2_small_up_fwd_nll_sy": [_p, _p, _p, _p, _i, _f, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p],
+    "mvk_conv4s2_small_up_bwd_pre_s": [_p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     "mvk_conv4s2_small_up_bwd_pre": [_p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p],
     "mvk_conv3x3": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i64, _p],
     "mvk_conv3x3_y": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _i64, _p],
@@ -313,6 +315,8 @@ GEMM_FLOPS = {
     "mvk_conv4s2_small_up_fwd_nll_s": lambda a: 2.0 * a[9] * a[10] * a[11] * 16 * a[12] * a[13],
     "mvk_conv4s2_small_up_bwd_pre": lambda a: 2.0 * 2.0 * a[11] * a[12] * a[13] * 16 * a[14] * a[15],  # data + weight
     "mvk_conv4s2_small_up_bwd_pre_y": lambda a: 2.0 * 2.0 * a[11] * a[12] * a[13] * 16 * a[14] * a[15],
+    "mvk_conv4s2_small_up_fwd_nll_sy": lambda a: 2.0 * a[9] * a[10] * a[11] * 16 * a[12] * a[13],
+    "mvk_conv4s2_small_up_bwd_pre_s": lambda a: 2.0 * 2.0 * a[11] * a[12] * a[13] * 16 * a[14] * a[15],
     "mvk_gemm_smallk_amax": lambda a: 2.0 * a[3] * a[4] * a[5],
     "mvk_unflatten_wgrad": lambda a: 2.0 * a[3] * a[4] * 16 * a[5],
     "mvk_flatten_wgrad": lambda a: 2.0 * a[3] * 16 * a[4] * a[5],

@@ -127,9 +127,15 @@ __device__ __forceinline__ void f16_split3_su(float x, float y, float s, float s
 // bit patterns of non-negative floats order like unsigned integers (+inf above every finite value); *dst must hold 0 (or a
 // bound to keep) before the launch.  Atomics on one address serialise at ~10 ns each: one per wave of a 2048-workgroup launch
 // was 80 us.  Every thread of the workgroup must call it (it synchronises).
+// amax_publish_wave: v already is the maximum of its wave (wave-uniform) — no lane shuffles (their address registers would stay
+// live across a whole kernel that shuffled in its prologue).
+__device__ __forceinline__ void amax_publish_wave(float v, float* dst, float* red);
 __device__ __forceinline__ void amax_publish(float v, float* dst, float* red) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  amax_publish_wave(v, dst, red);
+}
+__device__ __forceinline__ void amax_publish_wave(float v, float* dst, float* red) {
   const int wave = threadIdx.x >> 6, waves = (blockDim.x + 63) >> 6;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[wave] = v;

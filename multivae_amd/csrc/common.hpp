@@ -47,6 +47,23 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
+// the maximum of a NON-NEGATIVE value over the wave as a wave-uniform bit pattern (non-negative floats order like unsigned
+// integers): the same register-to-register steps, four scalar reads, scalar maxima — a running maximum kept this way lives in a
+// scalar register (the fused decoder tail has no vector register to spare).
+__device__ __forceinline__ unsigned wave_max_dpp_bits(float v) {
+#define MVK_DPP_MAX(ctrl) v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, false)))
+  MVK_DPP_MAX(0xB1);
+  MVK_DPP_MAX(0x4E);
+  MVK_DPP_MAX(0x141);
+  MVK_DPP_MAX(0x140);
+#undef MVK_DPP_MAX
+  const int b = __builtin_bit_cast(int, v);
+  const unsigned r0 = (unsigned)__builtin_amdgcn_readlane(b, 0), r1 = (unsigned)__builtin_amdgcn_readlane(b, 16);
+  const unsigned r2 = (unsigned)__builtin_amdgcn_readlane(b, 32), r3 = (unsigned)__builtin_amdgcn_readlane(b, 48);
+  const unsigned m01 = r0 > r1 ? r0 : r1, m23 = r2 > r3 ? r2 : r3;
+  return m01 > m23 ? m01 : m23;
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));

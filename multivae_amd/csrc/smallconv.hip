@@ -382,8 +382,16 @@ template <int CU, int NT, bool NLL = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT / 128))) void small_up_fwd_h_kernel(
     const float* __restrict__ V, const float* __restrict__ Wref, const float* __restrict__ bias, float* __restrict__ U, int n, int act,
     mvk_prof_slot* prof, const float* __restrict__ v_amax, const float* __restrict__ X = nullptr, int xrows = 1, float inv_s2 = 1.f,
-    float lconst = 0.f, float* __restrict__ rows = nullptr, float g_inv_s2 = 1.f) {
+    float lconst = 0.f, float* __restrict__ rows = nullptr, float g_inv_s2 = 1.f, float* __restrict__ du_amax = nullptr) {
   mvk_prof_begin(prof);
+#ifndef MVK_SUH_GMAX
+// how the fused tail bounds max |stored gradient|: 0 = not at all (A/B), 1 = exact, per thread, 2 = exact, per wave and image,
+// 3 = from the largest row sum (wave 0 has it anyway): |g| <= |g_inv_s2| max act' sqrt(2 max_i tot_i / inv_s2), up to
+// sqrt(3072) = 55 times the true maximum (6 bits of fp16 range, no precision), no instruction outside wave 0
+#define MVK_SUH_GMAX 3
+#endif
+  float gmax = 0.f;       // ... of this thread (published at the end when du_amax is given)
+  unsigned gmax_u = 0u;   // ... of this wave, as bits (wave-uniform: a scalar register)
   using mvk::f16x8;
   using mvk::u32x2;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -563,6 +571,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
         if (!(MVK_SUF_ABL & 64)) part = fmaf(0.5f * inv_s2 * dlt, dlt, part);
         gv[t] = dlt * g_inv_s2 * mvk_act_grad_from_out(r, act);
       }
+      if (MVK_SUH_GMAX == 1) {
+#pragma unroll
+        for (int t = 0; t < NO; ++t) gmax = fmaxf(gmax, fabsf(gv[t]));
+      } else if (MVK_SUH_GMAX == 2) {
+        float gm = fabsf(gv[0]);
+#pragma unroll
+        for (int t = 1; t < NO; ++t) gm = fmaxf(gm, fabsf(gv[t]));
+        const unsigned gu = wave_max_dpp_bits(gm);
+        gmax_u = gu > gmax_u ? gu : gmax_u;
+      }
       if (PAIR) {
 #pragma unroll
         for (int c = 0; c < NO / 2; ++c) {
@@ -592,12 +610,28 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
     if (NLL && wave == 0 && !(MVK_SUF_ABL & 64)) {  // the wave partials are rewritten three barriers from now at the earliest
       // (one LDS latency + a fixed shuffle tree over the NT / 64 partials: a serial loop of dependent LDS reads in thread 0 held
       // its wave back ~3 us per launch at the next barrier)
-      float tot = lane < NT / 64 ? buf[zidx + 1 + lane] : 0.f;
+      unsigned ones = ~0u;
+      asm volatile("" : "+s"(ones));  // the lane index recomputed HERE (mbcnt of an opaque mask): kept live across the image loop it
+      const int ln = __builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));  // is the register hipcc spills
+      float tot = ln < NT / 64 ? buf[zidx + 1 + ln] : 0.f;
 #pragma unroll
       for (int off = NT / 128; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
       if (lane == 0) rows[img] = tot + lconst;
+      if (MVK_SUH_GMAX == 3) {
+        const unsigned tb = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(tot));  // a sum of squares: >= 0
+        gmax_u = tb > gmax_u ? tb : gmax_u;
+      }
     }
   }
+  if (MVK_SUH_GMAX == 3) {
+    if (NLL && du_amax && tid == 0) {  // one atomic per workgroup, only when it raises the published value (bf3.hpp)
+      const float cmax = act == MVK_ACT_SIGMOID ? 0.25f : 1.f;
+      const float bound = 1.001f * fabsf(g_inv_s2) * cmax * sqrtf(2.f * __uint_as_float(gmax_u) / inv_s2);
+      unsigned* const d = reinterpret_cast<unsigned*>(du_amax);
+      const unsigned mu = __float_as_uint(bound);
+      if (mu > __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(d, mu);
+    }
+  } else if (NLL && du_amax) mvk::amax_publish_wave(MVK_SUH_GMAX == 2 ? __uint_as_float(gmax_u) : __uint_as_float(wave_max_dpp_bits(gmax)), du_amax, buf + zidx + 1);  // uniform branch; the wave-partial words are free here
   mvk_prof_end(prof);
 }
 
@@ -1185,6 +1219,260 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The scaled-fp16 form of small_up_bwd_bf_kernel<CU, PRE = true> (bf3.hpp: x s = hi + lo / 2048, a product = hi hi' + (hi lo' +
+// lo hi') / 2048 in a main and a cross accumulator): 96 MFMAs per wave and image instead of 192, two piece planes instead of
+// three (51 KB of LDS).  Same data flow, same parity planes, same transposing reads.  The scales:
+//   gradient  s_d from du_amax x max |rowscale| — the fused tail publishes a bound of what it stores (amax protocol; from its
+//             largest row sum, MVK_SUH_GMAX), the largest row weight is found in the prologue (n floats, L2-resident).  ONE
+//             scale for the launch: the weight gradient accumulates over the images of a workgroup in registers;
+//   V         s_v from v_amax, the bound the 64 -> 32 launch published; weights: the workgroup computes max |W| itself.
+// The ReLU mask of dV comes from the pieces of V: V >= 0 by contract (v_act = ReLU), and V > 0 iff one of its two pieces is
+// non-zero down to 2^-49 of the tensor's maximum (hi alone would round 2^-39 of it to zero).
+typedef _Float16 su_f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mvk::f16x8 su_tr_pair_h(const char* p0, const char* p1) {
+  typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+  typedef __attribute__((address_space(3))) h4* lp;
+  const su_f16x4 lo = __builtin_bit_cast(su_f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(p0)));
+  const su_f16x4 hi = __builtin_bit_cast(su_f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(p1)));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int CU>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void small_up_bwd_h_kernel(
+    const float* __restrict__ dU, const float* __restrict__ V, const float* __restrict__ Wref, float* __restrict__ dV,
+    float* __restrict__ partial, int n, mvk_prof_slot* prof, const float* __restrict__ rowscale,
+    const float* __restrict__ du_amax, const float* __restrict__ v_amax, float* dv_amax) {
+  mvk_prof_begin(prof);
+  float amax_l = 0.f;  // max |dV| of this thread's stores (published at the end when dv_amax is given)
+  using mvk::f16x8;
+  using mvk::u32x2;
+  using mvk::u32x4;
+  static_assert(CU == 3, "three image channels + one zero channel per 8-byte piece");
+  constexpr int CV = 32, NC = 16 * CU, P = 256, NT = 256, NW = 4, MT = 4;
+  constexpr int PL1 = 289 * 8;        // bytes of one parity plane (17 x 17 pieces)
+  constexpr int PLD = 4 * PL1;        // bytes of one fp16 piece plane of the gradient
+  constexpr int VPL = P * 64;         // bytes of one piece plane of V [pos][32 cv]
+  constexpr int OFF_V = 2 * PLD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* Dp = reinterpret_cast<char*>(smem);
+  char* Vp = Dp + OFF_V;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+  for (int i = tid; i < OFF_V / 4; i += NT) smem[i] = 0.f;  // the halo entries stay zero for the whole launch
+  // ---- scales: max |W| and max |rowscale| of the launch (every workgroup finds the same two numbers)
+  float wmax = 0.f, rmax = rowscale ? 0.f : 1.f;
+  for (int i = tid; i < CV * NC; i += NT) wmax = fmaxf(wmax, fabsf(Wref[i]));
+  if (rowscale)
+    for (int i = tid; i < n; i += NT) rmax = fmaxf(rmax, fabsf(rowscale[i]));
+  wmax = __uint_as_float(wave_max_dpp_bits(wmax));  // (no lane shuffles: their address registers would stay live across the loop)
+  rmax = __uint_as_float(wave_max_dpp_bits(rmax));
+  {
+    float* sc = reinterpret_cast<float*>(Vp);  // read by everyone before the first staging barrier below
+    if (lane == 0) sc[2 * wave] = wmax, sc[2 * wave + 1] = rmax;
+    __syncthreads();
+    wmax = fmaxf(fmaxf(sc[0], sc[2]), fmaxf(sc[4], sc[6]));
+    rmax = fmaxf(fmaxf(sc[1], sc[3]), fmaxf(sc[5], sc[7]));
+  }
+  const float sw = mvk::f16_scale_of(wmax), sv = mvk::f16_scale_of(*v_amax), sd = mvk::f16_scale_of(*du_amax * rmax);
+  const float inv_dv = mvk::f16_inv_scale(sw) * mvk::f16_inv_scale(sd), inv_dw = mvk::f16_inv_scale(sv) * mvk::f16_inv_scale(sd);
+  // weight pieces of the backward-data GEMM: lane (cv = 16 b + l15, k'-octet o = 4 s + lq = taps 2 o, 2 o + 1 x 4 channels)
+  f16x8 wf[2][2][2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int o = 4 * s2 + lq;
+      const float* wr = Wref + (b * 16 + l15) * NC + 2 * o;  // + 16 ch + tt
+      unsigned pc[2][4];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        mvk::f16_split(wr[tt] * sw, wr[16 + tt] * sw, pc[0][2 * tt], pc[1][2 * tt]);
+        mvk::f16_split(wr[32 + tt] * sw, 0.f, pc[0][2 * tt + 1], pc[1][2 * tt + 1]);
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p) wf[b][s2][p] = __builtin_bit_cast(f16x8, u32x4{pc[p][0], pc[p][1], pc[p][2], pc[p][3]});
+    }
+  f32x4 accw[2][4], accx[2][4];  // weight gradient: main and cross terms
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) accw[a][b] = accx[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 dbv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // channel sums of dV: this lane's 4 + 4 channels
+  float dblq[CU] = {0.f, 0.f, 0.f};
+  // staging: this thread's 4 pixels (row tid >> 3, columns 4 (tid & 7) ..) of every channel -> their parity-plane pieces
+  int dst[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int yp = (tid >> 3) + 1, xp = (tid & 7) * 4 + e + 1;
+    dst[e] = (((yp & 1) * 2 + (xp & 1)) * 289 + (yp >> 1) * 17 + (xp >> 1)) * 8;
+  }
+  f32x4 qdu[CU], pv[8];
+  float rs_next = 1.f;
+  auto prefetch = [&](long long img) __attribute__((always_inline)) {  // one burst right behind the staging (see the bf16 form)
+#pragma unroll
+    for (int c = 0; c < CU; ++c) qdu[c] = reinterpret_cast<const f32x4*>(dU + img * (CU * 1024))[tid + c * NT];
+    rs_next = rowscale ? rowscale[img] : 1.f;
+    const f32x4* src = reinterpret_cast<const f32x4*>(V + img * (P * CV));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) pv[u] = src[tid + u * NT];
+  };
+  // entry of tap (kh, kw) for input position (i, j): parity (kh & 1, kw & 1), entry (i + (kh >> 1), j + (kw >> 1))
+  auto dentry = [](int pos, int tap) {
+    const int i = pos >> 4, j = pos & 15, kh = tap >> 2, kw = tap & 3;
+    return ((((kh & 1) * 2 + (kw & 1)) * 289) + (i + (kh >> 1)) * 17 + j + (kw >> 1)) * 8;
+  };
+  int daddr[MT][2];  // backward data: first tap of this lane's octet (the second: the next parity plane, + PL1)
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) daddr[a][s2] = dentry((wave * MT + a) * 16 + l15, 2 * (4 * s2 + lq));
+  int vaddr[2], waddr[2][4];  // weight gradient: k-steps 2 wave, 2 wave + 1; rows 8 lq + (l15 >> 2) (+ 4), piece l15 & 3
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int pos0 = 32 * (2 * wave + ks) + 8 * lq + (l15 >> 2);
+    vaddr[ks] = pos0 * 64 + (4 * (l15 & 3)) * 2;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) waddr[ks][b] = dentry(pos0, 4 * b + (l15 & 3));
+  }
+  long long img = blockIdx.x;
+  if (img < n) prefetch(img);
+  for (; img < n; img += gridDim.x) {
+    __syncthreads();  // the previous image's planes (first pass: the scale words) are no longer read
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v[CU];
+#pragma unroll
+      for (int c = 0; c < CU; ++c) {
+        v[c] = qdu[c][e] * rs_next;
+        dblq[c] += v[c];
+      }
+      unsigned a0, a1, b0, b1;
+      mvk::f16_split_su(v[0], v[1], sd, a0, a1);
+      mvk::f16_split_su(v[2], 0.f, sd, b0, b1);
+      *reinterpret_cast<u32x2*>(Dp + dst[e]) = u32x2{a0, b0};
+      *reinterpret_cast<u32x2*>(Dp + PLD + dst[e]) = u32x2{a1, b1};
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = tid + u * NT;
+      unsigned a0, a1, b0, b1;
+      mvk::f16_split_su(pv[u][0], pv[u][1], sv, a0, a1);
+      mvk::f16_split_su(pv[u][2], pv[u][3], sv, b0, b1);
+      const int off = (idx >> 3) * 64 + (idx & 7) * 8;
+      *reinterpret_cast<u32x2*>(Vp + off) = u32x2{a0, b0};
+      *reinterpret_cast<u32x2*>(Vp + VPL + off) = u32x2{a1, b1};
+    }
+    __syncthreads();
+    if (img + gridDim.x < n) prefetch(img + gridDim.x);
+    // --- backward data (transposed tile: rows = channels, columns = positions) + ReLU mask + channel sums
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+      f32x4 cm[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, cx[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        f16x8 cf[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const u32x2 t0 = *reinterpret_cast<const u32x2*>(Dp + p * PLD + daddr[a][s2]);
+          const u32x2 t1 = *reinterpret_cast<const u32x2*>(Dp + p * PLD + daddr[a][s2] + PL1);
+          cf[p] = __builtin_bit_cast(f16x8, u32x4{t0[0], t0[1], t1[0], t1[1]});
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          cx[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[b][s2][0], cf[1], cx[b], 0, 0, 0);
+          cm[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[b][s2][0], cf[0], cm[b], 0, 0, 0);
+          cx[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[b][s2][1], cf[0], cx[b], 0, 0, 0);
+        }
+      }
+      const int dpos = (wave * MT + a) * 16 + l15;
+      float* dv = dV + img * (P * CV) + dpos * CV;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int cv = b * 16 + lq * 4;
+        const u32x2 vh = *reinterpret_cast<const u32x2*>(Vp + dpos * 64 + cv * 2);
+        const u32x2 vl = *reinterpret_cast<const u32x2*>(Vp + VPL + dpos * 64 + cv * 2);
+        const unsigned m0 = vh[0] | vl[0], m1 = vh[1] | vl[1];
+        const bool on[4] = {(m0 & 0x7fffu) != 0u, (m0 & 0x7fff0000u) != 0u, (m1 & 0x7fffu) != 0u, (m1 & 0x7fff0000u) != 0u};
+        f32x4 gq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          gq[r] = on[r] ? fmaf(cx[b][r], 1.f / 2048.f, cm[b][r]) * inv_dv : 0.f;
+          dbv[b][r] += gq[r];
+        }
+        amax_l = fmaxf(fmaxf(amax_l, fmaxf(fabsf(gq[0]), fabsf(gq[1]))), fmaxf(fabsf(gq[2]), fabsf(gq[3])));
+        *reinterpret_cast<f32x4*>(dv + cv) = gq;
+      }
+    }
+    // --- backward weight: this wave's two 32-position k-steps, both channel tiles, the four (4 taps x 4 channels) column tiles
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 va[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) va[a][p] = su_tr_pair_h(Vp + p * VPL + vaddr[ks] + a * 32, Vp + p * VPL + vaddr[ks] + a * 32 + 4 * 64);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        f16x8 cb[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) cb[p] = su_tr_pair_h(Dp + p * PLD + waddr[ks][b], Dp + p * PLD + waddr[ks][b] + 4 * 8);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          accx[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va[a][0], cb[1], accx[a][b], 0, 0, 0);
+          accw[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va[a][0], cb[0], accw[a][b], 0, 0, 0);
+          accx[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va[a][1], cb[0], accx[a][b], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // --- one slab per workgroup: the waves' weight-gradient partials in order, bias partials, channel sums of dV
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(Vp);  // [NW][CV][64 columns k' = 4 tap + channel] = the two piece planes of V
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        red[wave * (CV * 64) + (a * 16 + lq * 4 + r) * 64 + b * 16 + l15] = fmaf(accx[a][b][r], 1.f / 2048.f, accw[a][b][r]) * inv_dw;
+  __syncthreads();
+  float* slab = partial + (long long)blockIdx.x * (CV * NC + CU + CV);
+  for (int i = tid; i < CV * NC; i += NT) {
+    const int cv = i / NC, k = i - cv * NC, src = cv * 64 + (k & 15) * 4 + (k >> 4);  // k = 16 channel + tap
+    slab[i] = ((red[src] + red[CV * 64 + src]) + red[2 * CV * 64 + src]) + red[3 * CV * 64 + src];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < CU; ++c) {
+    const float sdb = wave_sum(dblq[c]);
+    if (lane == 0) red[c * NW + wave] = sdb;
+  }
+  __syncthreads();
+  if (tid < CU) slab[CV * NC + tid] = ((red[tid * NW] + red[tid * NW + 1]) + red[tid * NW + 2]) + red[tid * NW + 3];
+  __syncthreads();
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(b * 16 + lq * 4 + r) * 64 + wave * 16 + l15] = dbv[b][r];
+  __syncthreads();
+  {  // 8 threads per channel sum 8 entries each, then the 8 partial sums in order
+    const int cv = tid >> 3, seg = tid & 7;
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[cv * 64 + seg * 8 + q];
+    red[CV * 64 + tid] = t;
+  }
+  __syncthreads();
+  if (tid < CV) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[CV * 64 + tid * 8 + q];
+    slab[CV * NC + CU + tid] = t;
+  }
+  if (dv_amax) mvk::amax_publish(amax_l, dv_amax, red);  // uniform branch; synchronises before it touches red
+  mvk_prof_end(prof);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // forward of the image-CONSUMING layer: V[n,h,w,Cv] = act(conv4s2(U[n,Cu,2h,2w]) + b), Cu <= 4 (svhn.py:13-15 first
 // Conv2d).  Same tile algebra as the backward-data part above (the gradient of the image-producing ConvTranspose IS this
 // convolution): the NCHW image with a zero halo is staged in LDS with coalesced loads (persistent workgroups, next
@@ -1338,7 +1626,7 @@ static bool supported(int h, int w, int Cu, int Cv) {
 template <int CU, int CV>
 static int launch_fwd(const float* V, const float* Wref, const float* bias, float* U, int n, int h, int w, int act,
                       hipStream_t s, const float* X = nullptr, int xrows = 1, float scale = 1.f, float* rows = nullptr,
-                      float grad_weight = 1.f, const float* v_amax = nullptr) {
+                      float grad_weight = 1.f, const float* v_amax = nullptr, float* du_amax = nullptr) {
   const size_t lds = fwd_lds<CU, CV>(h * w);
   constexpr int NT = MVK_SMALL_FWD_THREADS;
   if (lds > 64 * 1024) {
@@ -1363,7 +1651,7 @@ static int launch_fwd(const float* V, const float* Wref, const float* bias, floa
         const size_t hlds = 2 * (16 * CU) * 64 + (256 * (16 * CU + 4) + 48) * sizeof(float);  // + zero words (zidx, +16, +32), wave partials
         if (X)
           hipLaunchKernelGGL((small_up_fwd_h_kernel<CU, 512, true>), dim3(grid), dim3(512), hlds, s, V, Wref, bias, U, n, act, prof,
-                             v_amax, X, xrows, inv_s2, lconst, rows, inv_s2 * grad_weight);
+                             v_amax, X, xrows, inv_s2, lconst, rows, inv_s2 * grad_weight, du_amax);
         else
           hipLaunchKernelGGL((small_up_fwd_h_kernel<CU, 512, false>), dim3(grid), dim3(512), hlds, s, V, Wref, bias, U, n, act, prof,
                              v_amax);
@@ -1388,7 +1676,7 @@ static int launch_fwd(const float* V, const float* Wref, const float* bias, floa
       return MVK_OK;
     }
   }
-  if (X || v_amax) return MVK_EINVAL;  // the fused tail / the scaled form: 16x16x32 -> 3 channels only (mvk_conv4s2_small_up_nll_supported)
+  if (X || v_amax || du_amax) return MVK_EINVAL;  // the fused tail / the scaled form: 16x16x32 -> 3 channels only (mvk_conv4s2_small_up_nll_supported)
   if (dense)
     hipLaunchKernelGGL((small_up_fwd_kernel<CU, CV, NT, true>), dim3(grid), dim3(NT), lds, s, V, Wref, bias, U, n, h, w, act, prof);
   else
@@ -1401,7 +1689,8 @@ static int launch_fwd(const float* V, const float* Wref, const float* bias, floa
 template <int CU, int CV>
 static int launch_bwd(const float* dU, const float* Uout, int u_act, const float* V, int v_act, const float* Wref,
                       float* dV, float* dWref, float* db, float* db_v, float* ws, int64_t ws_floats, int n, int h,
-                      int w, hipStream_t s, bool pre = false, const float* rowscale = nullptr, float* dv_amax = nullptr) {
+                      int w, hipStream_t s, bool pre = false, const float* rowscale = nullptr, float* dv_amax = nullptr,
+                      const float* du_amax = nullptr, const float* v_amax = nullptr) {
   using C = SmallCfg<CU, CV>;
   const int slab = CV * C::NC + CU + CV;
   // MVK_SMALL_BWD_UNITS=2: half-image work units for 16x16 inputs (3 workgroups per CU instead of 2).  Measured at
@@ -1416,6 +1705,7 @@ static int launch_bwd(const float* dU, const float* Uout, int u_act, const float
                   (pre || u_act == MVK_ACT_SIGMOID) && v_act == MVK_ACT_RELU && mvk_aligned16(dU) &&
                   (pre || mvk_aligned16(Uout)) && mvk_aligned16(V) && mvk_aligned16(dV) && mvk_aligned16(Wref);
   if ((pre || dv_amax) && !bf) return MVK_EINVAL;  // the pre-activation form and the published maximum: split-bf16 kernel only
+  if ((du_amax || v_amax) && !(pre && du_amax && v_amax)) return MVK_EINVAL;  // the scaled-fp16 form: both bounds, pre-activation form
   const int gmax = units == 2 ? 1024 : 512;
   int grid = nunits < gmax ? (int)nunits : gmax;
   float* dslab = (mvk::defer_free(db) && mvk::defer_free(db_v)) ? mvk::defer_scratch(dWref, (long long)grid * slab, s) : nullptr;
@@ -1430,7 +1720,11 @@ static int launch_bwd(const float* dU, const float* Uout, int u_act, const float
                                 hipFuncAttributeMaxDynamicSharedMemorySize, BLDS);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_up_bwd_bf_kernel<CU, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, BLDS);
-      if (pre)
+      if (du_amax) {
+        constexpr int HLDS = 2 * 4 * 289 * 8 + 2 * 256 * 64;
+        hipLaunchKernelGGL((small_up_bwd_h_kernel<CU>), dim3(grid), dim3(256), HLDS, s, dU, V, Wref, dV, ws, n, prof, rowscale,
+                           du_amax, v_amax, dv_amax);
+      } else if (pre)
         hipLaunchKernelGGL((small_up_bwd_bf_kernel<CU, true>), dim3(grid), dim3(256), BLDS, s, dU, Uout, V, Wref, dV, ws, n, prof,
                            rowscale, dv_amax);
       else
@@ -1579,6 +1873,33 @@ int mvk_conv4s2_small_up_fwd_nll_s(const float* V, const float* Wref, const floa
     return MVK_EINVAL;
   if (n == 0) return MVK_OK;
   return launch_fwd<3, 32>(V, Wref, bias, dpre, n, h, w, act, mvk_stream(stream), X, xrows, scale, rows, grad_weight, v_amax);
+}
+
+/* mvk_conv4s2_small_up_fwd_nll_s that also publishes an upper bound of max |dpre| (amax protocol: *dpre_amax must hold 0 before
+ * the launch): what mvk_conv4s2_small_up_bwd_pre_s scales the gradient image by. */
+int mvk_conv4s2_small_up_fwd_nll_sy(const float* V, const float* Wref, const float* bias, const float* X, int xrows, float scale,
+                                    float grad_weight, float* dpre, float* rows, int n, int h, int w, int Cu, int Cv, int act,
+                                    const float* v_amax, float* dpre_amax, void* stream) {
+  if (!V || !Wref || !X || !dpre || !rows || !v_amax || !dpre_amax || n < 0 || xrows <= 0 || !(scale > 0.f) || !mvk_aligned16(V) ||
+      !mvk_conv4s2_small_up_nll_supported(h, w, Cu, Cv))
+    return MVK_EINVAL;
+  if (n == 0) return MVK_OK;
+  return launch_fwd<3, 32>(V, Wref, bias, dpre, n, h, w, act, mvk_stream(stream), X, xrows, scale, rows, grad_weight, v_amax,
+                           dpre_amax);
+}
+
+/* mvk_conv4s2_small_up_bwd_pre_y on scaled fp16 pairs (small_up_bwd_h_kernel): dpre_amax bounds max |dpre| (published by
+ * mvk_conv4s2_small_up_fwd_nll_sy), v_amax bounds max |V| (published by the launch that produced V); dv_amax may be NULL. */
+int mvk_conv4s2_small_up_bwd_pre_s(const float* dpre, const float* rowscale, const float* V, int v_act, const float* Wref,
+                                   float* dV, float* dWref, float* db, float* db_v, float* ws, int64_t ws_floats, int n, int h,
+                                   int w, int Cu, int Cv, const float* dpre_amax, const float* v_amax, float* dv_amax,
+                                   void* stream) {
+  if (!dpre || !V || !Wref || !dV || !dWref || !ws || !dpre_amax || !v_amax || n < 0 || !mvk_aligned16(V) ||
+      !mvk_conv4s2_small_up_nll_supported(h, w, Cu, Cv))
+    return MVK_EINVAL;
+  if (n == 0) return MVK_OK;
+  return launch_bwd<3, 32>(dpre, nullptr, MVK_ACT_NONE, V, v_act, Wref, dV, dWref, db, db_v, ws, ws_floats, n, h, w,
+                           mvk_stream(stream), true, rowscale, dv_amax, dpre_amax, v_amax);
 }
 
 int mvk_conv4s2_small_up_fwd_s(const float* V, const float* Wref, const float* bias, float* U, int n, int h, int w, int Cu, int Cv,

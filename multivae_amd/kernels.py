@@ -1597,6 +1597,8 @@ class SVHNEncoderFn(Function):
 
 # MVK_TAIL_F16=0: the fused SVHN tail on bf16 pieces (small_up_fwd_bf_kernel) also where the scaled-fp16 chain runs
 TAIL_F16 = _lib.tune("MVK_TAIL_F16", "1") != "0"
+# MVK_TAIL_BWD_F16=0: the image layer's backward stays on bf16 pieces (small_up_bwd_bf_kernel) where its forward runs the scaled form
+TAIL_BWD_F16 = _lib.tune("MVK_TAIL_BWD_F16", "1") != "0"
 
 
 class SVHNDecoderFn(Function):
@@ -1624,9 +1626,12 @@ class SVHNDecoderFn(Function):
                and all(getattr(t, "mvk_amax", None) is not None for t in (wu1, wu2, wd1, wd2)))
         ctx.f16 = f16
         if f16:
-            pool = AmaxPool(z2, 5)
+            pool = AmaxPool(z2, 6)
             a1, a2 = pool.take(), pool.take()
             a3 = pool.take() if (TAIL_F16 and nll_x is not None) else None  # bound of g3 for the image layer's scaled form
+            # bound of the fused tail's stored gradient: the image layer's backward scales it (small_up_bwd_h_kernel)
+            ctx.a_dpre = pool.take() if (a3 is not None and TAIL_BWD_F16) else None
+            ctx.a_g3 = a3
             ctx.bslots = (pool.take(), pool.take())  # the backward pass's two slots: no fill launch there
             if L <= 32 and (16 * C1) % 4 == 0:
                 g1 = _new((n, 16 * C1), z2)
@@ -1652,7 +1657,10 @@ class SVHNDecoderFn(Function):
             rows = _new((n,), z2)
             # the stored gradient is pre-multiplied by nll_weight, the weight the rows are expected to enter the loss with
             ctx.nll_weight = float(nll_weight)
-            if a3 is not None:  # scaled fp16 pairs under the bound the 64 -> 32 launch published (small_up_fwd_h_kernel)
+            if a3 is not None and ctx.a_dpre is not None:  # ... and the maximum of the stored gradient published for the backward
+                call("mvk_conv4s2_small_up_fwd_nll_sy", ptr(g3), ptr(w3), ptr(b3), ptr(nll_x), nll_x.shape[0], float(nll_scale),
+                     float(nll_weight), ptr(out), ptr(rows), n, 16, 16, C4, C3, SIGMOID, ptr(a3), ptr(ctx.a_dpre), stream_ptr())
+            elif a3 is not None:  # scaled fp16 pairs under the bound the 64 -> 32 launch published (small_up_fwd_h_kernel)
                 call("mvk_conv4s2_small_up_fwd_nll_s", ptr(g3), ptr(w3), ptr(b3), ptr(nll_x), nll_x.shape[0], float(nll_scale),
                      float(nll_weight), ptr(out), ptr(rows), n, 16, 16, C4, C3, SIGMOID, ptr(a3), stream_ptr())
             else:
@@ -1695,8 +1703,12 @@ class SVHNDecoderFn(Function):
             tb2, db2 = _grad_target(b2)
             if ctx.f16:
                 a_dg3 = ctx.bslots[0]
-                call("mvk_conv4s2_small_up_bwd_pre_y", ptr(out), ptr(drows), ptr(g3), RELU, ptr(w3), ptr(dg3), ptr(tw3), ptr(tb3),
-                     ptr(tb2), ptr(ws), ws.numel(), n, 16, 16, C4, C3, ptr(a_dg3), stream_ptr())
+                if ctx.a_dpre is not None:  # scaled fp16 pairs: the gradient under the published bound x max |drows|, g3 under its own
+                    call("mvk_conv4s2_small_up_bwd_pre_s", ptr(out), ptr(drows), ptr(g3), RELU, ptr(w3), ptr(dg3), ptr(tw3), ptr(tb3),
+                         ptr(tb2), ptr(ws), ws.numel(), n, 16, 16, C4, C3, ptr(ctx.a_dpre), ptr(ctx.a_g3), ptr(a_dg3), stream_ptr())
+                else:
+                    call("mvk_conv4s2_small_up_bwd_pre_y", ptr(out), ptr(drows), ptr(g3), RELU, ptr(w3), ptr(dg3), ptr(tw3), ptr(tb3),
+                         ptr(tb2), ptr(ws), ws.numel(), n, 16, 16, C4, C3, ptr(a_dg3), stream_ptr())
                 tail_bwd_done(z2.device)
             else:
                 call("mvk_conv4s2_small_up_bwd_pre", ptr(out), ptr(drows), ptr(g3), RELU, ptr(w3), ptr(dg3), ptr(tw3), ptr(tb3),

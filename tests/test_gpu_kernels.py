@@ -779,6 +779,76 @@ def test_small_up_fwd_bwd(K, n, h, w, Cu, Cv, bwd_bf, monkeypatch):
     close(db, br.grad, what="small up db")
 
 
+@pytest.mark.parametrize("n,rowscale,spread", [(3, False, 0.0), (700, True, 0.0), (1030, True, 1.0), (1030, False, 2.0)])
+def test_small_up_bwd_scaled_fp16(K, n, rowscale, spread):
+    """The image layer's backward on scaled fp16 pairs (small_up_bwd_h_kernel behind mvk_conv4s2_small_up_bwd_pre_s: 3 MFMAs per
+    product, the gradient image under the bound the fused tail publishes x max |rowscale|, V under its producer's bound) against
+    float64 autograd of ConvTranspose2d(32, 3, 4, 2, 1) (reference: models/nn/svhn.py:58-60): dV with the ReLU mask of V fused, its
+    channel sums, dW, db.  spread: images (and row weights) whose magnitudes differ by 10^+-spread — dV is checked per image on the
+    image's own scale.  The same launch on bf16 pieces (mvk_conv4s2_small_up_bwd_pre_y) must agree."""
+    from multivae_amd._lib import call, ptr, stream_ptr
+
+    h = w = 16
+    Cu, Cv = 3, 32
+    gen = g(n + 29)
+    V = torch.relu(torch.randn(n, Cv, h, w, generator=gen))
+    dpre = torch.randn(n, Cu, 2 * h, 2 * w, generator=gen) * 0.05
+    rs = None
+    if spread:
+        V = V * (10.0 ** ((torch.rand(n, 1, 1, 1, generator=gen) * 2 - 1) * spread))
+        dpre = dpre * (10.0 ** ((torch.rand(n, 1, 1, 1, generator=gen) * 2 - 1) * spread))
+    V[0, 0, 0, 0] = 1e-12 * float(V.max())  # positive, and its leading fp16 piece is zero: the mask must still pass it
+    if rowscale:
+        rs = torch.randn(n, generator=gen) * (10.0 ** ((torch.rand(n, generator=gen) * 2 - 1) * spread))
+        rs[n // 2] = 0.0  # a row that does not enter the loss
+    Wt = torch.randn(Cv, Cu, 4, 4, generator=gen) / math.sqrt(4 * Cv)
+    gimg = dpre.double() * (rs.double().view(n, 1, 1, 1) if rs is not None else 1.0)
+    V64, W64 = V.double().requires_grad_(), Wt.double().requires_grad_()
+    F.conv_transpose2d(V64, W64, None, stride=2, padding=1).backward(gimg)
+    mask = (V > 0).double()
+    dV_ref = V64.grad * mask
+    d = dev()
+    Vd, Wd, dpd = nhwc(V).to(d), Wt.to(d), dpre.to(d)
+    rsd = rs.to(d) if rs is not None else None
+    v_amax, du_amax = torch.zeros(1, device=d), torch.zeros(1, device=d)
+    K.amax_of(Vd, v_amax)
+    K.amax_of(dpd, du_amax)
+    ws = K._ws(Vd)
+
+    def run(entry, *bounds):
+        dV = torch.empty(n, h, w, Cv, device=d)
+        dW, db, dbv = torch.zeros_like(Wd), torch.zeros(Cu, device=d), torch.zeros(Cv, device=d)
+        dv_amax = torch.zeros(1, device=d)
+        call(entry, ptr(dpd), ptr(rsd), ptr(Vd), 1, ptr(Wd), ptr(dV), ptr(dW), ptr(db), ptr(dbv), ptr(ws), ws.numel(), n, h, w, Cu,
+             Cv, *[ptr(b_) for b_ in bounds], ptr(dv_amax), stream_ptr())
+        return dV, dW, db, dbv, dv_amax
+
+    dV, dW, db, dbv, dv_amax = run("mvk_conv4s2_small_up_bwd_pre_s", du_amax, v_amax)
+    close(nchw(dV.cpu()), dV_ref, rtol=3e-6, what="scaled small up dV (relu mask fused)")
+    # per image: full precision for images down to 1e-4 of the largest one (the bound max |dpre| x max |rowscale| may sit 10^2
+    # above the largest product; bf3.hpp: elements keep full precision down to 2^-28 of the bound)
+    imax = dV_ref.abs().flatten(1).max(dim=1).values
+    close_per_slice(nchw(dV.cpu()), dV_ref, imax >= 1e-4 * imax.max(), 3e-6, "scaled small up dV, per image")
+    assert bool((nchw(dV.cpu())[mask == 0] == 0).all()), "the ReLU mask of V"
+    assert float(dV[0, 0, 0, 0]) != 0.0 or float(dV_ref[0, 0, 0, 0]) == 0.0, "a tiny positive V lost its gradient"
+    close(dW, W64.grad, rtol=3e-6, what="scaled small up dW")
+    close(db, gimg.sum(dim=(0, 2, 3)), rtol=3e-6, what="scaled small up db")
+    close(dbv, dV_ref.sum(dim=(0, 2, 3)), rtol=3e-6, what="scaled small up channel sums of dV")
+    assert float(dv_amax) == float(dV.abs().max()), "published max |dV|"
+    dV2, dW2, db2, dbv2, _ = run("mvk_conv4s2_small_up_bwd_pre_y")
+    close(dV, dV2, rtol=3e-6, what="scaled vs bf16-piece dV")
+    close(dW, dW2, rtol=3e-6, what="scaled vs bf16-piece dW")
+    if n <= 8:  # bounds far above the data cost range, not precision; a zero gradient under a zero bound stays finite
+        dV3, dW3, _, _, _ = run("mvk_conv4s2_small_up_bwd_pre_s", du_amax * 1000.0, v_amax * 1000.0)
+        ref3 = dV_ref.clone()
+        ref3[0, :, 0, 0] = nchw(dV3.cpu())[0, :, 0, 0].double()  # (the 1e-12 entry of V is 2^-50 of THIS bound: below what the mask resolves)
+        close(nchw(dV3.cpu()), ref3, rtol=3e-6, what="scaled small up dV, loose bounds")
+        close(dW3, W64.grad, rtol=3e-6, what="scaled small up dW, loose bounds")
+        dpd.zero_()
+        dV4, dW4, db4, _, a4 = run("mvk_conv4s2_small_up_bwd_pre_s", torch.zeros(1, device=d), v_amax)
+        assert float(dV4.abs().max()) == 0.0 and float(dW4.abs().max()) == 0.0 and float(db4.abs().max()) == 0.0 and float(a4) == 0.0
+
+
 @pytest.mark.parametrize("n,xrows,spread", [(3, 3, 0.0), (700, 70, 0.0), (1030, 103, 3.0)])
 def test_small_up_fwd_scaled_fp16(K, n, xrows, spread):
     """The image-producing layer on scaled fp16 pairs (small_up_fwd_h_kernel: 3 MFMAs per product, weights as the A operand, the
@@ -829,6 +899,12 @@ def test_small_up_fwd_scaled_fp16(K, n, xrows, spread):
     call("mvk_conv4s2_small_up_fwd_nll_w", ptr(Vd), ptr(Wd), ptr(bd), ptr(Xd), xrows, scale, gw, ptr(dpre2), ptr(rows2), n, h, w, Cu, Cv, 2,
          stream_ptr())
     close(rows, rows2, rtol=2e-6, what="scaled vs bf16-piece tail rows")
+    # ... and publishes a bound of the gradient it stored (what the layer's backward scales by), same numbers
+    dpre3, rows3, pub = torch.empty_like(out), torch.empty(n, device=d), torch.zeros(1, device=d)
+    call("mvk_conv4s2_small_up_fwd_nll_sy", ptr(Vd), ptr(Wd), ptr(bd), ptr(Xd), xrows, scale, gw, ptr(dpre3), ptr(rows3), n, h, w, Cu, Cv,
+         2, ptr(amax), ptr(pub), stream_ptr())
+    assert torch.equal(dpre3, dpre) and torch.equal(rows3, rows)
+    assert float(dpre.abs().max()) <= float(pub) <= 64.0 * float(dpre.abs().max())  # a bound from the largest row sum (<= sqrt(3072) x)
     if n <= 8:  # edge values: an all-zero map under a zero bound (scale clamps, no NaN), then a bound far above the data
         Z, zero = torch.zeros_like(Vd), torch.zeros(1, device=d)
         call("mvk_conv4s2_small_up_fwd_s", ptr(Z), ptr(Wd), ptr(bd), ptr(out), n, h, w, Cu, Cv, 2, ptr(zero), stream_ptr())
