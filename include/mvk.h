@@ -476,6 +476,12 @@ int mvk_conv3x3_s(const float* X, const float* Wp, const float* bias, float* Y, 
                   int act, const float* y_act_src, int y_src_act, const float* res, float res_alpha, float* colsum_acc,
                   int x_act, float pre_scale, const float* x_amax, const float* w_amax, float* y_amax, float* ws,
                   int64_t ws_floats, void* stream);
+/* mvk_conv3x3_s in its residual form with a second store (round 5): Y <- res + res_alpha * a and y_pre <- a, a = act(conv + bias).
+ * The post-activation ResnetBlock of models/nn/mmnist.py:229-246 (x_s + 0.1 * lrelu(conv2(.))) keeps `a` for its backward pass:
+ * one launch instead of the convolution and an elementwise pass over three tensors.  Where mvk_conv3x3_scaled_ok says so. */
+int mvk_conv3x3_s2(const float* X, const float* Wp, const float* bias, float* Y, float* y_pre, int n, int H, int W, int Cin, int Cout,
+                   int act, const float* res, float res_alpha, const float* x_amax, const float* w_amax, float* y_amax, float* ws,
+                   int64_t ws_floats, void* stream);
 /* mvk_conv3x3_wgrad_f on scaled fp16 pairs (one accumulator per tap tile: the 2^11 between main and cross terms sits in a
  * third piece of dY, csrc/conv3rs.hip); x_amax / dy_amax: device scalars >= max |X| / max |dY|. */
 int mvk_conv3x3_wgrad_scaled_ok(int n, int H, int W, int Cin, int Cout);

@@ -88,6 +88,7 @@ struct C3Args {
   const float* x_amax;
   const float* w_amax;
   float* y_amax;         // either form, optional: max |Y| is published here (atomic max; must hold 0 before the launch)
+  float* Y2;             // scaled-fp16 residual form, optional: act(conv + bias), the value before res + res_alpha * (.)
 };
 
 // NP = pieces per operand element: 3 bf16 pieces (6 MFMAs per product) or 2 scaled fp16 pieces (3 MFMAs per product)
@@ -124,7 +125,7 @@ __device__ __forceinline__ bf16x8 c3_pack8(const unsigned (&d)[4]) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int CIN, int COUT, bool HAS_SRC, bool HAS_RES, int NP>
+template <int CIN, int COUT, bool HAS_SRC, bool HAS_RES, int NP, bool DUAL = false>
 __device__ __forceinline__ void c3rs_body(const C3Args& g) {
   using T = C3Cfg<CIN, COUT, NP>;
   using frag = std::conditional_t<NP == 3, bf16x8, f16x8>;
@@ -234,6 +235,9 @@ __device__ __forceinline__ void c3rs_body(const C3Args& g) {
   // selects, no 64-bit address arithmetic and no branches in the loop.
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)g.X, 0, (int)g.xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)g.Y, 0, (int)g.ybytes, 0x00020000);
+  // DUAL: the activations BEFORE the residual sum go to Y2 as well (a post-activation ResNet block keeps them for its backward)
+  static_assert(!DUAL || (HAS_RES && !HAS_SRC), "the second store exists for the forward residual form");
+  const __amdgpu_buffer_rsrc_t rsY2 = __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? g.Y2 : g.Y), 0, (int)g.ybytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsM =
       __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_SRC ? g.act_src : g.Y), 0, (int)g.ybytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_RES ? g.res : g.Y), 0, (int)g.ybytes, 0x00020000);
@@ -425,6 +429,7 @@ __device__ __forceinline__ void c3rs_body(const C3Args& g) {
       if (HAS_SRC) v = msk[Q][o] > 0.f ? v : v * mslope;
       const int px_ = valid ? pix[Q][o] : -1;
       if (WITH_CSUM) csum += px_ < 0 ? 0.f : v;
+      if (DUAL) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY2, (unsigned)px_ * (COUT * 4u) + ncol * 4u, 0, 0);
       if (HAS_RES) v = fmaf(alpha, v, rr[Q][o]);
       amax_l = fmaxf(amax_l, px_ < 0 ? 0.f : fabsf(v));
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY, (unsigned)px_ * (COUT * 4u) + ncol * 4u, 0, 0);
@@ -615,20 +620,20 @@ __device__ __forceinline__ void c3rs_body(const C3Args& g) {
 }
 
 // one wave per SIMD (up to 512 registers per lane) / two waves per SIMD (256)
-template <int CIN, int COUT, bool HAS_SRC, bool HAS_RES, int NP>
+template <int CIN, int COUT, bool HAS_SRC, bool HAS_RES, int NP, bool DUAL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void c3rs_kernel(const C3Args g) {
   static_assert(C3Cfg<CIN, COUT, NP>::NW == 4, "four waves");
-  c3rs_body<CIN, COUT, HAS_SRC, HAS_RES, NP>(g);
+  c3rs_body<CIN, COUT, HAS_SRC, HAS_RES, NP, DUAL>(g);
 }
-template <int CIN, int COUT, bool HAS_SRC, bool HAS_RES, int NP>
+template <int CIN, int COUT, bool HAS_SRC, bool HAS_RES, int NP, bool DUAL = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void c3rs_kernel8(const C3Args g) {
   static_assert(C3Cfg<CIN, COUT, NP>::NW == 8, "eight waves");
-  c3rs_body<CIN, COUT, HAS_SRC, HAS_RES, NP>(g);
+  c3rs_body<CIN, COUT, HAS_SRC, HAS_RES, NP, DUAL>(g);
 }
-template <int CIN, int COUT, bool HAS_SRC, bool HAS_RES, int NP>
+template <int CIN, int COUT, bool HAS_SRC, bool HAS_RES, int NP, bool DUAL = false>
 static const void* c3rs_entry() {
-  if constexpr (C3Cfg<CIN, COUT, NP>::NW == 8) return reinterpret_cast<const void*>(c3rs_kernel8<CIN, COUT, HAS_SRC, HAS_RES, NP>);
-  else return reinterpret_cast<const void*>(c3rs_kernel<CIN, COUT, HAS_SRC, HAS_RES, NP>);
+  if constexpr (C3Cfg<CIN, COUT, NP>::NW == 8) return reinterpret_cast<const void*>(c3rs_kernel8<CIN, COUT, HAS_SRC, HAS_RES, NP, DUAL>);
+  else return reinterpret_cast<const void*>(c3rs_kernel<CIN, COUT, HAS_SRC, HAS_RES, NP, DUAL>);
 }
 
 template <int CIN, int COUT, int NP>
@@ -636,8 +641,10 @@ static int c3rs_launch(const C3Args& a, int* part_rows, hipStream_t s) {
   using T = C3Cfg<CIN, COUT, NP>;
   const int lds = T::lds_bytes(a.ring);
   if (lds > 160 * 1024) return 1;
-  const void* all[4] = {c3rs_entry<CIN, COUT, false, false, NP>(), c3rs_entry<CIN, COUT, true, false, NP>(),
-                        c3rs_entry<CIN, COUT, false, true, NP>(), c3rs_entry<CIN, COUT, true, true, NP>()};
+  const void* all[5] = {c3rs_entry<CIN, COUT, false, false, NP>(), c3rs_entry<CIN, COUT, true, false, NP>(),
+                        c3rs_entry<CIN, COUT, false, true, NP>(), c3rs_entry<CIN, COUT, true, true, NP>(),
+                        c3rs_entry<CIN, COUT, false, true, NP, NP == 2>()};  // [4]: + the second store (scaled-fp16 form only)
+  if (a.Y2 && (NP != 2 || a.act_src || !a.res)) return 1;
   static int attr_bytes = 0;
   if (attr_bytes < lds) {
     for (const void* f : all)
@@ -648,7 +655,7 @@ static int c3rs_launch(const C3Args& a, int* part_rows, hipStream_t s) {
   if (part_rows) *part_rows = grid / T::WG_TYPES;
   C3Args ap = a;
   ap.prof = prof_next(7, 2.0 * a.n * a.H * a.W * 9.0 * CIN * COUT);
-  const int which = (a.act_src ? 1 : 0) + (a.res ? 2 : 0);
+  const int which = a.Y2 ? 4 : (a.act_src ? 1 : 0) + (a.res ? 2 : 0);
   void* kargs[1] = {&ap};
   if (hipLaunchKernel(all[which], dim3(grid), dim3(T::NW * 64), kargs, lds, s) != hipSuccess) return MVK_ELAUNCH;
   MVK_CHECK_LAUNCH();
@@ -1106,7 +1113,7 @@ bool c3rs_shape_ok(int n, int H, int W, int Cin, int Cout, int np) {
 // 1: not covered (the caller falls back to the implicit-GEMM engine).  colsum_part: [256 / types][Cout] floats.
 int c3rs_conv(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
               const float* act_src, int src_act, const float* res, float res_alpha, float* colsum_part, int* part_rows,
-              int x_act, float pre_scale, const float* x_amax, const float* w_amax, float* y_amax, hipStream_t s) {
+              int x_act, float pre_scale, const float* x_amax, const float* w_amax, float* y_amax, hipStream_t s, float* y_pre) {
   if (act == MVK_ACT_SIGMOID || (act_src && src_act == MVK_ACT_SIGMOID) || x_act == MVK_ACT_SIGMOID || !mvk_aligned16(X)) return 1;
   if (colsum_part && (!act_src || res)) return 1;  // column sums: backward-data form only (WITH_CSUM)
   const bool f16 = x_amax && w_amax;
@@ -1115,7 +1122,8 @@ int c3rs_conv(const float* X, const float* Wp, const float* bias, float* Y, int 
   C3Args a{X, Wp, bias, Y, act_src, res, colsum_part, (unsigned)((long long)n * H * W * Cin * 4),
            (unsigned)((long long)n * H * W * Cout * 4), n, H, W, c3_slope(act), c3_slope(act_src ? src_act : MVK_ACT_NONE),
            res_alpha, c3_slope(x_act), pre_scale, c3_ring(W), (W + 2 + 31) / 32, (int)((total + 31) / 32), nullptr,
-           x_amax, w_amax, y_amax};
+           x_amax, w_amax, y_amax, y_pre};
+  if (y_pre && !f16) return 1;
   if (f16) {
     if (Cin == 64 && Cout == 64) return c3rs_launch<64, 64, 2>(a, part_rows, s);
 #ifndef MVK_C3_PROBE_ONLY  // variant builds of tools/conv3_variants.sh: one instantiation, short compiles

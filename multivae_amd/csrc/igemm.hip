@@ -726,7 +726,8 @@ int imgconv_wgrad(const float* U, const float* V, float* slab, long long slab_fl
 // bit 0x800 takes them for every problem size (tests); MVK_C3RS=0 / MVK_C3RS=<min tiles> under MVK_TUNE=1.
 int c3rs_conv(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
               const float* act_src, int src_act, const float* res, float res_alpha, float* colsum_part, int* part_rows,
-              int x_act, float pre_scale, const float* x_amax, const float* w_amax, float* y_amax, hipStream_t s);
+              int x_act, float pre_scale, const float* x_amax, const float* w_amax, float* y_amax, hipStream_t s,
+              float* y_pre = nullptr);
 bool c3rs_shape_ok(int n, int H, int W, int Cin, int Cout, int np);
 bool c3rs_wgrad_ok(int n, int H, int W, int Cin, int Cout);
 int c3rs_wgrad(const float* X, const float* dY, float* slab, long long slab_floats, float* dbpart, int x_act, float dy_scale,
@@ -1108,11 +1109,13 @@ int mvk_conv4s2_up_s(const float* V, const float* Wup, const float* bias, float*
 static int conv3x3_any(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout,
                        int act, const float* y_act_src, int y_src_act, float* colsum_acc, const float* res, float res_alpha,
                        float* ws, int64_t ws_floats, void* stream, int x_act = MVK_ACT_NONE, float pre_scale = 1.f,
-                       const float* x_amax = nullptr, const float* w_amax = nullptr, float* y_amax = nullptr) {
+                       const float* x_amax = nullptr, const float* w_amax = nullptr, float* y_amax = nullptr,
+                       float* y_pre = nullptr) {
   // forms only the register-stationary kernels take
   // (y_amax alone with an image on the input side: the direct kernel of conv3small.hip publishes it, mvk_conv3x3_y)
   const bool img_y = y_amax && !x_amax && !w_amax && Cin <= 4 && !res && x_act == MVK_ACT_NONE && pre_scale == 1.f;
-  const bool fused = !img_y && (x_act != MVK_ACT_NONE || pre_scale != 1.f || x_amax || w_amax || y_amax);
+  const bool fused = !img_y && (x_act != MVK_ACT_NONE || pre_scale != 1.f || x_amax || w_amax || y_amax || y_pre);
+  if (y_pre && !(res && x_amax && w_amax && !y_act_src && !colsum_acc)) return MVK_EINVAL;  // the second store: scaled residual form
   const int np = x_amax && w_amax ? 2 : 3;
   if (!X || !Wp || !Y || n < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (!x_amax != !w_amax)) return MVK_EINVAL;
   if (fused && !(n > 0 && ws && ws_floats >= 256ll * Cout && !(res && colsum_acc) && mvk_aligned16(X) &&
@@ -1137,7 +1140,7 @@ static int conv3x3_any(const float* X, const float* Wp, const float* bias, float
     float* dpart = colsum_acc ? defer_scratch(colsum_acc, 256ll * Cout, mvk_stream(stream)) : nullptr;
     const int rc = c3rs_conv(X, Wp, bias, Y, n, H, W, Cin, Cout, act, y_act_src, y_src_act, res, res_alpha,
                              colsum_acc ? (dpart ? dpart : ws) : nullptr, &rows, x_act, pre_scale, x_amax, w_amax, y_amax,
-                             mvk_stream(stream));
+                             mvk_stream(stream), y_pre);
     if (rc == MVK_OK && dpart) return defer_push_plain(colsum_acc, dpart, Cout, rows, Cout, mvk_stream(stream));
     if (rc == MVK_OK && colsum_acc) return colsum_finish(ws, rows, Cout, colsum_acc, mvk_stream(stream));
     if (rc != 1) return rc;
@@ -1224,6 +1227,17 @@ int mvk_conv3x3_s(const float* X, const float* Wp, const float* bias, float* Y, 
   if (!x_amax || !w_amax) return MVK_EINVAL;
   return conv3x3_any(X, Wp, bias, Y, n, H, W, Cin, Cout, act, y_act_src, y_src_act, colsum_acc, res, res_alpha, ws, ws_floats,
                      stream, x_act, pre_scale, x_amax, w_amax, y_amax);
+}
+
+/* mvk_conv3x3_s in its residual form with a SECOND store: y_pre <- act(conv + bias) (what res + res_alpha * (.) is formed from).
+ * A post-activation ResNet block (models/nn/mmnist.py:229-246: x_s + 0.1 * lrelu(conv2(.))) keeps that tensor for its backward;
+ * one launch instead of a convolution and an elementwise pass over three tensors. */
+int mvk_conv3x3_s2(const float* X, const float* Wp, const float* bias, float* Y, float* y_pre, int n, int H, int W, int Cin, int Cout,
+                   int act, const float* res, float res_alpha, const float* x_amax, const float* w_amax, float* y_amax, float* ws,
+                   int64_t ws_floats, void* stream) {
+  if (!x_amax || !w_amax || !res || !y_pre || !mvk_conv3x3_scaled_ok(n, H, W, Cin, Cout)) return MVK_EINVAL;
+  return conv3x3_any(X, Wp, bias, Y, n, H, W, Cin, Cout, act, nullptr, MVK_ACT_NONE, nullptr, res, res_alpha, ws, ws_floats, stream,
+                     MVK_ACT_NONE, 1.f, x_amax, w_amax, y_amax, y_pre);
 }
 
 static int conv3x3_wgrad_any(const float* X, const float* dY, float* dWref, float* db, int x_act, float dy_scale, int n, int H,

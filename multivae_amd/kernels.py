@@ -1000,6 +1000,15 @@ def conv3x3_s(X, wpack, bias, n, H, W, Cin, Cout, x_amax, w_amax, y_amax=None, a
     return Y if out_bias is None else (Y, rb)
 
 
+def conv3x3_s2(X, wpack, bias, n, H, W, Cin, Cout, x_amax, w_amax, y_amax, act, res, res_alpha):
+    """conv3x3_s in its residual form with a second store -> (res + res_alpha * a, a), a = act(conv + bias)."""
+    Y, A = _new((n, H, W, Cout), X), _new((n, H, W, Cout), X)
+    ws = _ws(X)
+    call("mvk_conv3x3_s2", ptr(X), ptr(wpack), ptr(bias), ptr(Y), ptr(A), n, H, W, Cin, Cout, act, ptr(res), float(res_alpha),
+         ptr(x_amax), ptr(w_amax), ptr(y_amax), ptr(ws), ws.numel(), stream_ptr())
+    return Y, A
+
+
 def conv3x3_wgrad_scaled_ok(n, H, W, Cin, Cout):
     """True when mvk_conv3x3_wgrad_s takes this problem."""
     return C3_F16 and bool(_lib.load().mvk_conv3x3_wgrad_scaled_ok(n, H, W, Cin, Cout))
@@ -1597,6 +1606,8 @@ class SVHNEncoderFn(Function):
 
 # MVK_TAIL_F16=0: the fused SVHN tail on bf16 pieces (small_up_fwd_bf_kernel) also where the scaled-fp16 chain runs
 TAIL_F16 = _lib.tune("MVK_TAIL_F16", "1") != "0"
+# MVK_C3_DUAL=0: a post-activation ResNet block forms its sum in an elementwise pass behind conv2 (A/B of mvk_conv3x3_s2)
+C3_DUAL = _lib.tune("MVK_C3_DUAL", "1") != "0"
 # MVK_TAIL_BWD_F16=0: the image layer's backward stays on bf16 pieces (small_up_bwd_bf_kernel) where its forward runs the scaled form
 TAIL_BWD_F16 = _lib.tune("MVK_TAIL_BWD_F16", "1") != "0"
 
@@ -1881,10 +1892,20 @@ class ResnetStackFn(Function):
                 fused = (conv3x3_fused_ok(n, H, W, C, Chid) and conv3x3_fused_ok(n, H, W, Chid, Cout)
                          and conv3x3_fused_ok(n, H, W, Cout, Chid))  # conv1, conv2 and conv2's backward-data launch
                 oam = y2am = None
+                out = None
                 if order_ == "post":
                     a0 = h
                     a1, a1am = _rs_conv(pool, a0, ham, packs[iw1][0], b1, n, H, W, C, Chid, act=LEAKY)
-                    y2, y2am = _rs_conv(pool, a1, a1am, packs[iw2][0], b2, n, H, W, Chid, Cout, act=LEAKY)
+                    w2am = getattr(packs[iw2][0], "mvk_amax", None)
+                    if (C3_DUAL and pool is not None and a1am is not None and w2am is not None
+                            and conv3x3_scaled_ok(n, H, W, Chid, Cout)):
+                        # conv2, its LeakyReLU and the block's sum in one launch; y2 (the backward pass needs its signs) is the
+                        # launch's second store, max |out| its published bound
+                        xs = h if isc is None else linear_fwd(h.view(-1, C), params[isc].view(Cout, C), None, NONE).view(n, H, W, Cout)
+                        oam = pool.take()
+                        out, y2 = conv3x3_s2(a1, packs[iw2][0], b2, n, H, W, Chid, Cout, a1am, w2am, oam, LEAKY, xs, 0.1)
+                    else:
+                        y2, y2am = _rs_conv(pool, a1, a1am, packs[iw2][0], b2, n, H, W, Chid, Cout, act=LEAKY)
                 elif fused:
                     a0 = None
                     a1, a1am = _rs_conv(pool, h, ham, packs[iw1][0], b1, n, H, W, C, Chid, act=LEAKY, x_act=LEAKY)
@@ -1893,8 +1914,11 @@ class ResnetStackFn(Function):
                     a0 = axpby(h, 1.0, None, 0.0, act=LEAKY)
                     a1, a1am = _rs_conv(pool, a0, ham, packs[iw1][0], b1, n, H, W, C, Chid, act=LEAKY)
                     y2 = None  # the block's sum is formed in conv2's epilogue; backward does not need conv2's output
-                xs = h if isc is None else linear_fwd(h.view(-1, C), params[isc].view(Cout, C), None, NONE).view(n, H, W, Cout)
-                if y2 is None:
+                if out is None:
+                    xs = h if isc is None else linear_fwd(h.view(-1, C), params[isc].view(Cout, C), None, NONE).view(n, H, W, Cout)
+                if out is not None:
+                    pass
+                elif y2 is None:
                     out, oam = _rs_conv(pool, a1, a1am, packs[iw2][0], b2, n, H, W, Chid, Cout, act=NONE, res=xs, res_alpha=0.1)
                 else:
                     out = axpby(xs, 1.0, y2, 0.1)

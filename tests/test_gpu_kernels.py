@@ -1144,6 +1144,14 @@ def test_conv3x3_scaled_fp16(K, n, H, W, Cin, Cout, spread):
         plain = F.conv2d(x.double(), w.double(), None, 1, 1)
         Y = K.conv3x3_s(X, wf, b.to(d), n, H, W, Cin, Cout, xam, wf.mvk_amax, act=K.NONE, res=nhwc(res), res_alpha=0.1)
         close(Y, nhwc((res.double() + 0.1 * (plain + bb)).float()), what="res + 0.1 * conv", rtol=3e-6)
+        # the residual form with a second store (mvk_conv3x3_s2): Y = res + 0.1 a and a = lrelu(conv + b) from one launch — `a` is
+        # bit for bit what the plain launch stores, max |Y| is published
+        yam = pool.take()
+        Y, A = K.conv3x3_s2(X, wf, b.to(d), n, H, W, Cin, Cout, xam, wf.mvk_amax, yam, K.LEAKY, nhwc(res), 0.1)
+        A1 = K.conv3x3_s(X, wf, b.to(d), n, H, W, Cin, Cout, xam, wf.mvk_amax, act=K.LEAKY)
+        assert torch.equal(A, A1), "the second store of mvk_conv3x3_s2"
+        close(Y, nhwc((res.double() + 0.1 * F.leaky_relu(plain + bb, 0.2)).float()), what="res + 0.1 * lrelu(conv + b)", rtol=3e-6)
+        assert float(yam) == float(Y.abs().max())
         yam = pool.take()
         Y = K.conv3x3_s(X, wf, b.to(d), n, H, W, Cin, Cout, xam, wf.mvk_amax, yam, act=K.RELU, y_act_src=nhwc(src),
                         y_src_act=K.RELU, res=nhwc(res))
