@@ -15,6 +15,7 @@ timeout 600 python bench.py --config cfg2 --family laplace_with_softmax --loss d
 for c in cfg5 cfg4 cfg2; do
   rocprofv3 --kernel-trace --stats -d $OUT/trace_$c -o t -- python bench.py --config $c --steps 10 --warmup 3 --no-cpu-baseline > $OUT/trace_$c.log 2>&1
   python tools/rocpd_summary.py $(find $OUT/trace_$c -name "*_results.db" | head -1) > $OUT/${c}_kernel_stats.md 2>/dev/null
+  python tools/step_groups.py $(find $OUT/trace_$c -name "*_results.db" | head -1) 5 70 > $OUT/${c}_step_groups.md 2>/dev/null
   rm -rf $OUT/trace_$c
 done
 # 3. trainer loop throughput
@@ -54,6 +55,15 @@ for i in 1 2; do
 done
 for bm in 0 3 4; do
   MVK_TUNE=1 MVK_BRANCH_MAX=$bm timeout 600 python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | line > $OUT/bench_cfg4_branchmax$bm.json
+done
+# 7b. the image layer's backward on fp16 pairs / bf16 pieces; the post-activation blocks' one-launch sum / conv + axpby
+for i in 1 2 3; do
+  python bench.py --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | line > $OUT/bench_ab_tail_bwd_f16_$i.json
+  MVK_TUNE=1 MVK_TAIL_BWD_F16=0 python bench.py --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | line > $OUT/bench_ab_tail_bwd_bf16_$i.json
+done
+for i in 1 2; do
+  timeout 600 python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | line > $OUT/bench_ab_cfg4_dual_$i.json
+  MVK_TUNE=1 MVK_C3_DUAL=0 timeout 600 python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | line > $OUT/bench_ab_cfg4_axpby_$i.json
 done
 # 8. the assembled-configuration tests once more for the rectifier counts (gpurun_out/flip_counts.jsonl)
 rm -f gpurun_out/flip_counts.jsonl

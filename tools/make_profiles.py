@@ -36,10 +36,19 @@ with open(f"{DST}/{TAG}_bench_lines.jsonl", "w") as f:
         if d:
             d["_run"] = c
             f.write(json.dumps(d) + "\n")
+    import glob
+    for p in sorted(glob.glob(f"{SRC}/bench_ab_*.json") + glob.glob(f"{SRC}/bench_cfg4_branchmax*.json")):  # same-box A/B lines
+        d = json_line(p)
+        if d:
+            d["_run"] = os.path.basename(p)[len("bench_"):-len(".json")]
+            f.write(json.dumps(d) + "\n")
 for c in ("cfg5", "cfg4", "cfg2"):  # kernel traces of the other configurations
     p = f"{SRC}/{c}_kernel_stats.md"
     if os.path.exists(p) and os.path.getsize(p) > 0:
         open(f"{DST}/{TAG}_{c}_kernel_stats.md", "w").write(open(p).read())
+    p = f"{SRC}/{c}_step_groups.md"  # one step of the same trace by (kernel, grid): tools/step_groups.py
+    if os.path.exists(p) and os.path.getsize(p) > 0:
+        open(f"{DST}/{TAG}_{c}_step_groups.md", "w").write(open(p).read())
 # 3. trainer throughput
 tr = [json_line(f"{SRC}/trainer_{c}.json") for c in ("cfg3", "cfg1")]
 open(f"{DST}/{TAG}_trainer_throughput.json", "w").write(json.dumps([t for t in tr if t], indent=1) + "\n")
