@@ -21,7 +21,10 @@ from .mopoe_config import MoPoEConfig
 _EARLY_NOISE = _lib.tune("MVK_EARLY_NOISE", "1") != "0"  # 0: draw the noise behind the encoders (A/B)
 
 
-_EARLY_DENSE = _lib.tune("MVK_EARLY_DENSE", "1") != "0"  # 0: the fused tails prepare their operands in their own chains (A/B)
+# 1: the fused decoder tails' z-independent preparation (dense16 pack + target bound, 18 us) behind the short encoder instead of in
+# the decoder's own chain.  Off since round 5: the short encoder's branch had become the LONGER one (117 vs 109 us at the join in
+# front of the posterior); in the MLP decoder's chain the two launches sit in slack.  1.0205-1.0238 -> 1.0090-1.0148 ms, four pairs.
+_EARLY_DENSE = _lib.tune("MVK_EARLY_DENSE", "0") == "1"
 _ROW_WEIGHT = {}
 
 
