@@ -482,6 +482,13 @@ int mvk_conv3x3_s(const float* X, const float* Wp, const float* bias, float* Y, 
 int mvk_conv3x3_s2(const float* X, const float* Wp, const float* bias, float* Y, float* y_pre, int n, int H, int W, int Cin, int Cout,
                    int act, const float* res, float res_alpha, const float* x_amax, const float* w_amax, float* y_amax, float* ws,
                    int64_t ws_floats, void* stream);
+/* One launch of mvk_conv3x3_s over a SLICE of the layer's input channels (round 5): X [n][H][W][x_channels], the slice = Cin
+ * channels from x_off; Wp = the layer's whole pack [9 x_channels][Cout].  res_pre != 0: Y = act(conv + bias + res), `res` = the
+ * partial sum the other slice's launch left (act = none, no bias there).  The register-stationary kernels hold the weights of at
+ * most 128 input channels: a 256-channel layer (models/nn/mmnist.py:345-352, cub.py:233-240) is two such launches. */
+int mvk_conv3x3_s_part(const float* X, int x_channels, int x_off, const float* Wp, const float* bias, float* Y, int n, int H, int W,
+                       int Cin, int Cout, int act, const float* y_act_src, int y_src_act, const float* res, int res_pre, int x_act,
+                       float pre_scale, const float* x_amax, const float* w_amax, float* y_amax, void* stream);
 /* mvk_conv3x3_wgrad_f on scaled fp16 pairs (one accumulator per tap tile: the 2^11 between main and cross terms sits in a
  * third piece of dY, csrc/conv3rs.hip); x_amax / dy_amax: device scalars >= max |X| / max |dY|. */
 int mvk_conv3x3_wgrad_scaled_ok(int n, int H, int W, int Cin, int Cout);

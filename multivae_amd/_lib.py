@@ -116,6 +116,7 @@ PROTOTYPES = {
     "mvk_conv3x3_wgrad_f": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _i64, _p],
     "mvk_conv3x3_s": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _f, _p, _i, _f, _p, _p, _p, _p, _i64, _p],
     "mvk_conv3x3_s2": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _f, _p, _p, _p, _p, _i64, _p],
+    "mvk_conv3x3_s_part": [_p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _f, _p, _p, _p, _p],
     "mvk_amax": [_p, _i64, _p, _p],
     "mvk_conv4s2_wgrad_s": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i64, _p],
     "mvk_gemm_smallk_amax": [_p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p],
@@ -307,6 +308,7 @@ GEMM_FLOPS = {
     "mvk_conv4s2_up_s": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
     "mvk_conv3x3_wgrad_s": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
     "mvk_conv3x3_s2": lambda a: 2.0 * a[5] * a[6] * a[7] * 9 * a[8] * a[9],
+    "mvk_conv3x3_s_part": lambda a: 2.0 * a[6] * a[7] * a[8] * 9 * a[9] * a[10],
     "mvk_conv4s2_up_nchw_small": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
     "mvk_conv4s2_small_up_fwd": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
     "mvk_conv4s2_small_down_fwd": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],

@@ -89,6 +89,12 @@ struct C3Args {
   const float* w_amax;
   float* y_amax;         // either form, optional: max |Y| is published here (atomic max; must hold 0 before the launch)
   float* Y2;             // scaled-fp16 residual form, optional: act(conv + bias), the value before res + res_alpha * (.)
+  // a launch over a SLICE of the input channels (a 256-channel layer as two 128-channel launches, mvk_conv3x3_s_part): X points at
+  // the slice's first channel, Wp at its first row of tap 0
+  unsigned xpix_bytes;   // bytes between consecutive pixels of X (4 CIN for a whole tensor)
+  int wtap_rows;         // rows of Wp per tap (CIN for a whole tensor)
+  float res_pre;         // 1: the residual is added BEFORE the activation (Y = act(conv + bias + res): the partial sum of the
+                         // other slice), res_alpha unused; 0: Y = res + res_alpha * act(conv + bias)
 };
 
 // NP = pieces per operand element: 3 bf16 pieces (6 MFMAs per product) or 2 scaled fp16 pieces (3 MFMAs per product)
@@ -156,7 +162,7 @@ __device__ __forceinline__ void c3rs_body(const C3Args& g) {
 #pragma unroll
   for (int i = 0; i < T::KPW; ++i) {
     const int gk = ks * T::KPW + i;
-    const long long rowbase = (long long)(gk / T::CHUNKS) * CIN + (gk % T::CHUNKS) * 16 + kg * 8;
+    const long long rowbase = (long long)(gk / T::CHUNKS) * g.wtap_rows + (gk % T::CHUNKS) * 16 + kg * 8;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = g.Wp[(rowbase + e) * COUT + ncol];
@@ -241,10 +247,11 @@ __device__ __forceinline__ void c3rs_body(const C3Args& g) {
   const __amdgpu_buffer_rsrc_t rsM =
       __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_SRC ? g.act_src : g.Y), 0, (int)g.ybytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_RES ? g.res : g.Y), 0, (int)g.ybytes, 0x00020000);
+  const unsigned xpb = g.xpix_bytes;
   f32x4 raw[T::NF4];
   auto unit_pix = [&](int c, int k) { return ptab[(c & 15) * 32 + spos[k]]; };
   auto load_unit_at = [&](int pix, int k) {
-    raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (unsigned)pix * (CIN * 4u) + sc4[k] * 4u, 0, 0));
+    raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (unsigned)pix * xpb + sc4[k] * 4u, 0, 0));
   };
   auto load_unit = [&](int c, int k) { load_unit_at(unit_pix(c, k), k); };
   const float islope = g.islope, sxn = sx * g.islope;
@@ -285,7 +292,7 @@ __device__ __forceinline__ void c3rs_body(const C3Args& g) {
 #pragma unroll
         for (int k = 0; k < T::NF4; ++k)
           praw[u][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                     rsX, (unsigned)unit_pix(T0 - D + u, k) * (CIN * 4u) + sc4[k] * 4u, 0, 0));
+                                                     rsX, (unsigned)unit_pix(T0 - D + u, k) * xpb + sc4[k] * 4u, 0, 0));
       }
 #pragma unroll
     for (int k = 0; k < T::NF4; ++k) load_unit(T0 + D + 1, k);
@@ -306,7 +313,9 @@ __device__ __forceinline__ void c3rs_body(const C3Args& g) {
   const unsigned long long c3_t0 = __builtin_readcyclecounter();
   unsigned long long c3_bar = 0;
 #endif
-  const float aslope = g.aslope, mslope = g.mslope, alpha = g.res_alpha;
+  // residual before / behind the activation without a branch: v = a act(v0 + wpre rr) + wpost rr
+  const float aslope = g.aslope, mslope = g.mslope, alpha = g.res_pre != 0.f ? 1.f : g.res_alpha;
+  const float wpre = g.res_pre != 0.f ? 1.f : 0.f, wpost = 1.f - wpre;
   const float pre_scale = NP == 2 ? g.pre_scale * inv_sw * inv_sx : g.pre_scale;
   float csum = 0.f, amax_l = 0.f;
 
@@ -425,12 +434,13 @@ __device__ __forceinline__ void c3rs_body(const C3Args& g) {
     };
     auto epilogue_row = [&](int Q, int o, bool valid) {  // Q: the parity whose fetch belongs to the tile in res_prev
       float v = fmaf(res_prev[o], pre_scale, bias);   // pre_scale carries 1 / (sx sw) in the scaled-fp16 form
+      if (HAS_RES) v = fmaf(wpre, rr[Q][o], v);        // (the other channel slice's partial sum)
       v = fmaxf(v, v * aslope);                        // (leaky) ReLU / identity: 0 <= slope <= 1
       if (HAS_SRC) v = msk[Q][o] > 0.f ? v : v * mslope;
       const int px_ = valid ? pix[Q][o] : -1;
       if (WITH_CSUM) csum += px_ < 0 ? 0.f : v;
       if (DUAL) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY2, (unsigned)px_ * (COUT * 4u) + ncol * 4u, 0, 0);
-      if (HAS_RES) v = fmaf(alpha, v, rr[Q][o]);
+      if (HAS_RES) v = fmaf(alpha, v, wpost * rr[Q][o]);
       amax_l = fmaxf(amax_l, px_ < 0 ? 0.f : fabsf(v));
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY, (unsigned)px_ * (COUT * 4u) + ncol * 4u, 0, 0);
     };
@@ -1113,16 +1123,20 @@ bool c3rs_shape_ok(int n, int H, int W, int Cin, int Cout, int np) {
 // 1: not covered (the caller falls back to the implicit-GEMM engine).  colsum_part: [256 / types][Cout] floats.
 int c3rs_conv(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
               const float* act_src, int src_act, const float* res, float res_alpha, float* colsum_part, int* part_rows,
-              int x_act, float pre_scale, const float* x_amax, const float* w_amax, float* y_amax, hipStream_t s, float* y_pre) {
+              int x_act, float pre_scale, const float* x_amax, const float* w_amax, float* y_amax, hipStream_t s, float* y_pre,
+              int x_channels, int w_channels, int res_pre) {
+  // x_channels / w_channels (0 = Cin): channels per pixel of the tensor X is a slice of / input channels of the layer Wp belongs to
   if (act == MVK_ACT_SIGMOID || (act_src && src_act == MVK_ACT_SIGMOID) || x_act == MVK_ACT_SIGMOID || !mvk_aligned16(X)) return 1;
   if (colsum_part && (!act_src || res)) return 1;  // column sums: backward-data form only (WITH_CSUM)
   const bool f16 = x_amax && w_amax;
   if (!c3rs_shape_ok(n, H, W, Cin, Cout, f16 ? 2 : 3)) return 1;
   const long long total = (long long)n * (H + 1) * (W + 1);
-  C3Args a{X, Wp, bias, Y, act_src, res, colsum_part, (unsigned)((long long)n * H * W * Cin * 4),
+  const int xc = x_channels > 0 ? x_channels : Cin, wc = w_channels > 0 ? w_channels : Cin;
+  if (xc < Cin || wc < Cin || (res_pre && !res) || (long long)n * H * W * xc * 4 >= (1ll << 32) - 8192) return 1;
+  C3Args a{X, Wp, bias, Y, act_src, res, colsum_part, (unsigned)(((long long)n * H * W - 1) * xc * 4 + (long long)Cin * 4),
            (unsigned)((long long)n * H * W * Cout * 4), n, H, W, c3_slope(act), c3_slope(act_src ? src_act : MVK_ACT_NONE),
            res_alpha, c3_slope(x_act), pre_scale, c3_ring(W), (W + 2 + 31) / 32, (int)((total + 31) / 32), nullptr,
-           x_amax, w_amax, y_amax, y_pre};
+           x_amax, w_amax, y_amax, y_pre, (unsigned)(xc * 4), wc, res_pre ? 1.f : 0.f};
   if (y_pre && !f16) return 1;
   if (f16) {
     if (Cin == 64 && Cout == 64) return c3rs_launch<64, 64, 2>(a, part_rows, s);

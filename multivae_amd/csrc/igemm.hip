@@ -727,7 +727,7 @@ int imgconv_wgrad(const float* U, const float* V, float* slab, long long slab_fl
 int c3rs_conv(const float* X, const float* Wp, const float* bias, float* Y, int n, int H, int W, int Cin, int Cout, int act,
               const float* act_src, int src_act, const float* res, float res_alpha, float* colsum_part, int* part_rows,
               int x_act, float pre_scale, const float* x_amax, const float* w_amax, float* y_amax, hipStream_t s,
-              float* y_pre = nullptr);
+              float* y_pre = nullptr, int x_channels = 0, int w_channels = 0, int res_pre = 0);
 bool c3rs_shape_ok(int n, int H, int W, int Cin, int Cout, int np);
 bool c3rs_wgrad_ok(int n, int H, int W, int Cin, int Cout);
 int c3rs_wgrad(const float* X, const float* dY, float* slab, long long slab_floats, float* dbpart, int x_act, float dy_scale,
@@ -1238,6 +1238,22 @@ int mvk_conv3x3_s2(const float* X, const float* Wp, const float* bias, float* Y,
   if (!x_amax || !w_amax || !res || !y_pre || !mvk_conv3x3_scaled_ok(n, H, W, Cin, Cout)) return MVK_EINVAL;
   return conv3x3_any(X, Wp, bias, Y, n, H, W, Cin, Cout, act, nullptr, MVK_ACT_NONE, nullptr, res, res_alpha, ws, ws_floats, stream,
                      MVK_ACT_NONE, 1.f, x_amax, w_amax, y_amax, y_pre);
+}
+
+/* One launch of mvk_conv3x3_s over a SLICE of the layer's input channels: X [n][H][W][x_channels], the slice starts at channel
+ * x_off and has Cin channels; Wp is the layer's whole pack [9 x_channels][Cout].  res_pre != 0: Y = act(conv + bias + res) — `res`
+ * is the partial sum the other slice's launch left (act = none, no bias there).  A 256-channel layer (the register-stationary
+ * kernels hold at most 128 input channels' weights) = two such launches (models/nn/mmnist.py:345-352, cub.py:233-240). */
+int mvk_conv3x3_s_part(const float* X, int x_channels, int x_off, const float* Wp, const float* bias, float* Y, int n, int H, int W,
+                       int Cin, int Cout, int act, const float* y_act_src, int y_src_act, const float* res, int res_pre, int x_act,
+                       float pre_scale, const float* x_amax, const float* w_amax, float* y_amax, void* stream) {
+  if (!X || !Wp || !Y || !x_amax || !w_amax || n <= 0 || x_off < 0 || x_off + Cin > x_channels || x_off % 4 != 0 ||
+      (res_pre && !res) || (res && !res_pre) || !mvk_conv3x3_scaled_ok(n, H, W, Cin, Cout))
+    return MVK_EINVAL;
+  const int rc = c3rs_conv(X + x_off, Wp + (long long)x_off * Cout, bias, Y, n, H, W, Cin, Cout, act, y_act_src, y_src_act, res, 1.f,
+                           nullptr, nullptr, x_act, pre_scale, x_amax, w_amax, y_amax, mvk_stream(stream), nullptr, x_channels,
+                           x_channels, res_pre);
+  return rc == 1 ? MVK_EINVAL : rc;
 }
 
 static int conv3x3_wgrad_any(const float* X, const float* dY, float* dWref, float* db, int x_act, float dy_scale, int n, int H,

@@ -1009,6 +1009,20 @@ def conv3x3_s2(X, wpack, bias, n, H, W, Cin, Cout, x_amax, w_amax, y_amax, act, 
     return Y, A
 
 
+def conv3x3_s_split(X, wpack, bias, n, H, W, Cin, Cout, x_amax, w_amax, y_amax=None, act=NONE, y_act_src=None, y_src_act=NONE,
+                    out_bias=None, x_act=NONE, pre_scale=1.0):
+    """conv3x3_s for a layer with 256 input channels: two launches over 128-channel slices (mvk_conv3x3_s_part) — the first leaves
+    its partial sum, the second adds it in front of its bias / activation / mask and publishes max |Y|.  out_bias: the column
+    sums of Y (the bias gradient of the layer below) come from a pass of their own."""
+    half = Cin // 2
+    part, Y = _new((n, H, W, Cout), X), _new((n, H, W, Cout), X)
+    call("mvk_conv3x3_s_part", ptr(X), Cin, 0, ptr(wpack), None, ptr(part), n, H, W, half, Cout, NONE, None, NONE, None, 0, x_act,
+         float(pre_scale), ptr(x_amax), ptr(w_amax), None, stream_ptr())
+    call("mvk_conv3x3_s_part", ptr(X), Cin, half, ptr(wpack), ptr(bias), ptr(Y), n, H, W, half, Cout, act, ptr(y_act_src), y_src_act,
+         ptr(part), 1, x_act, float(pre_scale), ptr(x_amax), ptr(w_amax), ptr(y_amax), stream_ptr())
+    return Y if out_bias is None else (Y, colsum(Y.view(-1, Cout), out_bias))
+
+
 def conv3x3_wgrad_scaled_ok(n, H, W, Cin, Cout):
     """True when mvk_conv3x3_wgrad_s takes this problem."""
     return C3_F16 and bool(_lib.load().mvk_conv3x3_wgrad_scaled_ok(n, H, W, Cin, Cout))
@@ -1606,6 +1620,8 @@ class SVHNEncoderFn(Function):
 
 # MVK_TAIL_F16=0: the fused SVHN tail on bf16 pieces (small_up_fwd_bf_kernel) also where the scaled-fp16 chain runs
 TAIL_F16 = _lib.tune("MVK_TAIL_F16", "1") != "0"
+# MVK_C3_SPLIT256=0: 3x3 layers with 256 input channels stay on the tiled engine (A/B of mvk_conv3x3_s_part)
+C3_SPLIT256 = _lib.tune("MVK_C3_SPLIT256", "1") != "0"
 # MVK_C3_DUAL=0: a post-activation ResNet block forms its sum in an elementwise pass behind conv2 (A/B of mvk_conv3x3_s2)
 C3_DUAL = _lib.tune("MVK_C3_DUAL", "1") != "0"
 # MVK_TAIL_BWD_F16=0: the image layer's backward stays on bf16 pieces (small_up_bwd_bf_kernel) where its forward runs the scaled form
@@ -1805,6 +1821,13 @@ def _rs_conv(pool, X, xam, wpack, bias, n, H, W, Cin, Cout, **kw):
         xam = xam if xam is not None else amax_of(X, pool.take())
         yam = pool.take()
         return conv3x3_s(X, wpack, bias, n, H, W, Cin, Cout, xam, w_am, yam, **kw), yam
+    if (C3_SPLIT256 and pool is not None and w_am is not None and Cin == 256 and kw.get("res") is None
+            and kw.get("act", NONE) != SIGMOID and kw.get("y_src_act", NONE) != SIGMOID and conv3x3_scaled_ok(n, H, W, 128, Cout)):
+        # 256 input channels: more weights than a register-stationary wave holds — two launches over 128-channel slices
+        xam = xam if xam is not None else amax_of(X, pool.take())
+        yam = pool.take()
+        kw2 = {k: v for k, v in kw.items() if k not in ("res", "res_alpha")}
+        return conv3x3_s_split(X, wpack, bias, n, H, W, Cin, Cout, xam, w_am, yam, **kw2), yam
     if kw.get("x_act", NONE) != NONE or kw.get("pre_scale", 1.0) != 1.0:
         return conv3x3_f(X, wpack, bias, n, H, W, Cin, Cout, **kw), None
     kw.pop("x_act", None)

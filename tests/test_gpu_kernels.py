@@ -1098,6 +1098,56 @@ def test_conv3x3_register_stationary(K, n, H, W, Cin, Cout):
     close(Yt, nhwc(lrelu(conv).float()), what="default dispatch", rtol=3e-6)
 
 
+@pytest.mark.parametrize("n,H,W,Cout", [(40, 7, 7, 128), (9, 16, 16, 128), (3, 16, 16, 256), (5, 28, 20, 64)])
+@pytest.mark.parametrize("spread", [0.0, 2.0])
+def test_conv3x3_256_input_channels_as_two_slices(K, n, H, W, Cout, spread):
+    """A 3x3 layer with 256 input channels on the register-stationary kernels: two launches over 128-channel slices
+    (mvk_conv3x3_s_part; kernels.conv3x3_s_split), the second adding the first one's partial sum in front of its bias, activation and
+    mask.  Against float64 at the tolerance of the one-launch layers, in the forward form (input activation, bias, LeakyReLU) and
+    the backward-data form (0.1 conv x act'(mask source), column sums); max |Y| as published is exact; the tiled engine agrees."""
+    Cin = 256
+    gen = g(77)
+    d = dev()
+    x = torch.randn(n, Cin, H, W, generator=gen) * torch.exp(spread * torch.randn(n, 1, 1, 1, generator=gen)) * 2.1
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) / (3 * Cin ** 0.5) * torch.exp(spread * torch.randn(Cout, 1, 1, 1, generator=gen))
+    b = 0.1 * torch.randn(Cout, generator=gen)
+    src = torch.randn(n, Cout, H, W, generator=gen)
+    nhwc = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(d)
+    (wf, _), = K.pack_weights([(w.to(d), "c3", True, False)])
+    pool = K.AmaxPool(wf, 8)
+    X = nhwc(x)
+    xam = K.amax_of(X, pool.take())
+    ax = F.leaky_relu(x.double(), 0.2)
+    conv = F.conv2d(ax, w.double(), None, 1, 1)
+    bb = b.double().view(1, -1, 1, 1)
+    _debug_flags(0x800)
+    try:
+        assert K.conv3x3_scaled_ok(n, H, W, 128, Cout) and not K.conv3x3_scaled_ok(n, H, W, Cin, Cout)
+        yam = pool.take()
+        Y = K.conv3x3_s_split(X, wf, b.to(d), n, H, W, Cin, Cout, xam, wf.mvk_amax, yam, act=K.LEAKY, x_act=K.LEAKY)
+        close(Y, nhwc(F.leaky_relu(conv + bb, 0.2).float()), what="lrelu(conv(lrelu(x)) + b), 256 channels in two slices", rtol=3e-6)
+        assert float(yam) == float(Y.abs().max()), "published max |Y|"
+        bparam = torch.zeros(Cout, device=d).requires_grad_(True)
+        bparam.grad = torch.zeros(Cout, device=d)
+        mask = torch.where(src > 0, 1.0, 0.2).double()
+        yam = pool.take()
+        Y, _ = K.conv3x3_s_split(X, wf, None, n, H, W, Cin, Cout, xam, wf.mvk_amax, yam, y_act_src=nhwc(src), y_src_act=K.LEAKY,
+                                 out_bias=bparam, x_act=K.LEAKY, pre_scale=0.1)
+        ref = 0.1 * conv * mask
+        close(Y, nhwc(ref.float()), what="0.1 conv * act'(mask source), two slices", rtol=3e-6)
+        close(bparam.grad, ref.sum((0, 2, 3)).float(), what="column sums", rtol=1e-5)
+        assert float(yam) == float(Y.abs().max())
+        # the stack's dispatcher takes the same route and returns the published bound; the tiled engine agrees
+        Y1, am1 = K._rs_conv(pool, X, xam, wf, b.to(d), n, H, W, Cin, Cout, act=K.LEAKY)
+        plain = F.conv2d(x.double(), w.double(), None, 1, 1)
+        close(Y1, nhwc(F.leaky_relu(plain + bb, 0.2).float()), what="_rs_conv, 256 input channels", rtol=3e-6)
+        assert am1 is not None and float(am1) == float(Y1.abs().max())
+        Y2 = K.conv3x3(X, wf, b.to(d), n, H, W, Cin, Cout, act=K.LEAKY)
+        close(Y1, Y2, what="two slices vs tiled engine", rtol=3e-6)
+    finally:
+        _debug_flags(0)
+
+
 @pytest.mark.parametrize("n,H,W,Cin,Cout", [(5, 64, 64, 64, 64), (9, 32, 32, 64, 128), (40, 16, 16, 128, 128), (33, 16, 16, 128, 256),
                                           (70, 28, 28, 64, 64), (130, 14, 14, 128, 64), (2, 7, 7, 128, 256), (1, 9, 13, 64, 64),
                                           (3, 32, 32, 128, 64), (2, 62, 50, 128, 128)])
