@@ -174,7 +174,6 @@ constexpr int C3V_TR = 8, C3V_TC = 32, C3V_PS = 20;
 template <int CS>
 __global__ __launch_bounds__(256) void conv3_smallcout_v_kernel(const C3Args g) {
   __shared__ __attribute__((aligned(16))) float xt[(C3V_TR + 2) * (C3V_TC + 2) * C3V_PS];
-  __shared__ __attribute__((aligned(16))) float wt[9 * CS * 16];
   const int Cin = g.Cin, H = g.H, W = g.W;
   const int tid = threadIdx.x, r = tid >> 5, c = tid & 31;
   const int tcols = (W + C3V_TC - 1) / C3V_TC, trows = (H + C3V_TR - 1) / C3V_TR;
@@ -194,28 +193,23 @@ __global__ __launch_bounds__(256) void conv3_smallcout_v_kernel(const C3Args g) 
       if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = *reinterpret_cast<const f32x4*>(ximg + ((long long)yy * W + xx) * Cin + cb + 4 * q);
       *reinterpret_cast<f32x4*>(xt + pix * C3V_PS + 4 * q) = v;
     }
-    for (int i = tid; i < 9 * CS * 16; i += 256) {
-      const int tap = i / (CS * 16), co = (i >> 4) % CS, ch = i & 15;
-      wt[i] = g.Wp[(long long)(tap * Cin + cb + ch) * CS + co];
-    }
     __syncthreads();
+    // The chunk's weights are the same for every lane: SCALAR loads (16 CS consecutive floats of the pack per tap, a uniform
+    // address) feeding the FMAs as scalar operands.  As LDS broadcasts (round 3) they were 12 of the 16 ds_read_b128 per tap:
+    // 128 LDS clocks per wave and tap beside 192 clocks of FMAs, four SIMDs on one LDS — the kernel ran at a third of its FMA
+    // time.  Same sums in the same order.
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int dy = tap / 3, dx = tap - dy * 3;
       const float* xp = xt + ((r + dy) * (C3V_TC + 2) + c + dx) * C3V_PS;
+      const float* __restrict__ wp = g.Wp + (long long)(tap * Cin + cb) * CS;  // [16 channels][CS]
       f32x4 x[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) x[j] = *reinterpret_cast<const f32x4*>(xp + 4 * j);
 #pragma unroll
-      for (int co = 0; co < CS; ++co) {
-        const float* wp = wt + (tap * CS + co) * 16;
+      for (int co = 0; co < CS; ++co)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp + 4 * j);  // the same address for the whole wave: a broadcast
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[co] = fmaf(x[j][e], w4[e], acc[co]);
-        }
-      }
+        for (int ch = 0; ch < 16; ++ch) acc[co] = fmaf(x[ch >> 2][ch & 3], wp[ch * CS + co], acc[co]);
     }
   }
   const int yy = y0 + r, xx = x0 + c;
