@@ -271,6 +271,28 @@ __global__ __launch_bounds__(256) void conv3_small_wgrad_kernel(const C3WArgs g)
     }
     __syncthreads();
     const float* bimg = g.B + (((long long)img * H + y0) * W) * CB + 4 * cg;
+    if (W >= PG) {
+      // ONE loop over the band's rows x W positions (they are contiguous in B): with a loop per row a 28-wide map gives each position
+      // group 7 iterations — the 8-fold unrolled body never runs, the remainder loop keeps ONE 16-byte load in flight, and the kernel
+      // waited for memory latency (262 us at cfg4's decoder batch for 63 us of FMAs).  The row / column of a position are carried
+      // along (no division); the same sums in the same order when W is a multiple of the position groups.
+      const int npos = rows * W;
+      int x = pg, soffr = 0;  // soffr = r * TW (the staged rows carry a halo column on each side)
+#pragma unroll 8
+      for (int idx = pg; idx < npos; idx += PG) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bimg + (long long)idx * CB);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+          const float sv = st[soffr + x * CS + soff[j]];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(sv, b4[e], acc[j][e]);
+        }
+        x += PG;
+        const bool wrap = x >= W;
+        x = wrap ? x - W : x;
+        soffr = wrap ? soffr + TW : soffr;
+      }
+    } else
     for (int r = 0; r < rows; ++r) {
       const float* srow = st + r * TW;
       const float* brow = bimg + (long long)r * W * CB;
