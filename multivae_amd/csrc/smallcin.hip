@@ -64,71 +64,112 @@ __global__ __launch_bounds__(256) void smallcin_fwd_kernel(const float* __restri
 }
 
 // slab[block][(tap*C + c)][cv] = sum over the block's positions of window[k] * dV[pos][cv].
-// 256 threads = 16 k-groups (C consecutive k each) x 16 channel groups (Cv/16 channels each): C + Cv/16 LDS reads feed
-// C * Cv/16 FMAs per position.
+// The four waves split the staged positions; a lane owns a (2 C) x (Cv / 8) block of the gradient: 2 C + Cv / 8 floats read from
+// LDS (vector reads, 8-byte aligned) feed 2 C Cv / 8 FMAs per position, and the waves' partial blocks are added in a fixed order at
+// the end.  (Until round 5 a thread owned C x Cv / 16 entries and all 256 threads walked all positions: 5 scalar LDS reads per 6
+// FMAs at Cu = 3, Cv = 32 — the launch, the last compute kernel of the headline step's critical chain, was bound by the LDS
+// instruction rate: 26 us for 0.2 GFLOP.)
 template <int C, int NCV>
 __global__ __launch_bounds__(256) void smallcin_wgrad_kernel(const float* __restrict__ U, const float* __restrict__ dV,
                                                              float* __restrict__ slab, long long npos, int h, int w,
                                                              int pos_per_block) {
   constexpr int K = 16 * C, Cv = 16 * NCV;
   constexpr int PT = 64;                       // positions staged at a time
-  __shared__ __attribute__((aligned(16))) float xs[PT * (K + 1)];
-  __shared__ __attribute__((aligned(16))) float ds[PT * Cv];
+  constexpr int XS = K + 4;                    // row stride of the window matrix: 16-byte aligned rows
+  constexpr int KQ = 2 * C, CQ = 2 * NCV;      // a lane's block: KQ window entries x CQ channels
+  constexpr int STAGE = PT * XS + PT * Cv, RED = 3 * K * Cv;
+  __shared__ __attribute__((aligned(16))) float smem[STAGE > RED ? STAGE : RED];
+  float* const xs = smem;
+  float* const ds = smem + PT * XS;
   const long long p0 = (long long)blockIdx.x * pos_per_block;
-  const int kg = threadIdx.x >> 4, cg = threadIdx.x & 15;
-  float acc[C][NCV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kq = lane >> 3, cq = lane & 7;
+  float acc[KQ][CQ];
 #pragma unroll
-  for (int a = 0; a < C; ++a)
+  for (int a = 0; a < KQ; ++a)
 #pragma unroll
-    for (int b = 0; b < NCV; ++b) acc[a][b] = 0.f;
-  for (int s0 = 0; s0 < pos_per_block; s0 += PT) {
-    __syncthreads();
-    {  // stage PT windows (4 threads per position: one tap row each) and PT gradient rows
-      const int pl = threadIdx.x >> 2, kh = threadIdx.x & 3;
-      const long long pos = p0 + s0 + pl;
-      const bool pv = pos < npos && (s0 + pl) < pos_per_block;
-      const int j = pv ? (int)(pos % w) : 0;
-      const long long t = pv ? pos / w : 0;
-      const int i = (int)(t % h);
-      const long long img = t / h;
-      const int H = 2 * h, W = 2 * w;
-      const int hh = 2 * i - 1 + kh;
+    for (int b = 0; b < CQ; ++b) acc[a][b] = 0.f;
+  // Staging is a software pipeline: the global loads of tile t + 1 (a 4 x C window row per thread, PT Cv / 1024 gradient quads)
+  // are in flight while tile t is multiplied — four dependent rounds of "load, barrier, multiply, barrier" per workgroup were the
+  // launch's time (25 us for 0.2 GFLOP at the headline's encoder batch).
+  constexpr int ND = PT * Cv / 4 / 256;
+  static_assert(PT * Cv % 1024 == 0, "gradient quads divide over the workgroup");
+  float xr[4 * C];
+  float4 dr[ND];
+  const int pl = threadIdx.x >> 2, kh = threadIdx.x & 3;
+  auto fetch = [&](int s0) {
+    const long long pos = p0 + s0 + pl;
+    const bool pv = pos < npos && (s0 + pl) < pos_per_block;
+    const int j = pv ? (int)(pos % w) : 0;
+    const long long t = pv ? pos / w : 0;
+    const int i = (int)(t % h);
+    const long long img = t / h;
+    const int H = 2 * h, W = 2 * w;
+    const int hh = 2 * i - 1 + kh;
 #pragma unroll
-      for (int c = 0; c < C; ++c)
+    for (int c = 0; c < C; ++c)
 #pragma unroll
-        for (int kw = 0; kw < 4; ++kw) {
-          const int ww = 2 * j - 1 + kw;
-          const bool ok = pv && hh >= 0 && hh < H && ww >= 0 && ww < W;
-          xs[pl * (K + 1) + (kh * 4 + kw) * C + c] = ok ? U[((img * C + c) * H + hh) * (long long)W + ww] : 0.f;
-        }
-      for (int e = threadIdx.x; e < PT * Cv / 4; e += 256) {
-        const int pp = e / (Cv / 4);
-        const long long pos2 = p0 + s0 + pp;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pos2 < npos && (s0 + pp) < pos_per_block)
-          v = *reinterpret_cast<const float4*>(dV + pos2 * Cv + (e - pp * (Cv / 4)) * 4);
-        *reinterpret_cast<float4*>(ds + e * 4) = v;
+      for (int kw = 0; kw < 4; ++kw) {
+        const int ww = 2 * j - 1 + kw;
+        const bool ok = pv && hh >= 0 && hh < H && ww >= 0 && ww < W;
+        xr[kw * C + c] = ok ? U[((img * C + c) * H + hh) * (long long)W + ww] : 0.f;
       }
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int e = threadIdx.x + u * 256, pp = e / (Cv / 4);
+      const long long pos2 = p0 + s0 + pp;
+      dr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pos2 < npos && (s0 + pp) < pos_per_block)
+        dr[u] = *reinterpret_cast<const float4*>(dV + pos2 * Cv + (e - pp * (Cv / 4)) * 4);
     }
+  };
+  fetch(0);
+  for (int s0 = 0; s0 < pos_per_block; s0 += PT) {
+    __syncthreads();  // the previous tile's readers are done
+#pragma unroll
+    for (int q = 0; q < 4 * C; ++q) xs[pl * XS + kh * 4 * C + q] = xr[q];
+#pragma unroll
+    for (int u = 0; u < ND; ++u) *reinterpret_cast<float4*>(ds + (threadIdx.x + u * 256) * 4) = dr[u];
     __syncthreads();
+    if (s0 + PT < pos_per_block) fetch(s0 + PT);
 #pragma unroll 4
-    for (int pp = 0; pp < PT; ++pp) {
-      float xv[C], dv[NCV];
+    for (int pp = wave; pp < PT; pp += 4) {
+      float xv[KQ], dv[CQ];
+      typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-      for (int a = 0; a < C; ++a) xv[a] = xs[pp * (K + 1) + kg * C + a];
+      for (int a = 0; a < C; ++a) {
+        const f2 t = *reinterpret_cast<const f2*>(xs + pp * XS + kq * KQ + 2 * a);
+        xv[2 * a] = t[0], xv[2 * a + 1] = t[1];
+      }
 #pragma unroll
-      for (int b = 0; b < NCV; ++b) dv[b] = ds[pp * Cv + cg * NCV + b];
+      for (int b = 0; b < NCV; ++b) {
+        const f2 t = *reinterpret_cast<const f2*>(ds + pp * Cv + cq * CQ + 2 * b);
+        dv[2 * b] = t[0], dv[2 * b + 1] = t[1];
+      }
 #pragma unroll
-      for (int a = 0; a < C; ++a)
+      for (int a = 0; a < KQ; ++a)
 #pragma unroll
-        for (int b = 0; b < NCV; ++b) acc[a][b] = fmaf(xv[a], dv[b], acc[a][b]);
+        for (int b = 0; b < CQ; ++b) acc[a][b] = fmaf(xv[a], dv[b], acc[a][b]);
     }
   }
-  float* out = slab + (long long)blockIdx.x * (K * Cv);
+  // the four waves' partial blocks in a fixed order: waves 1..3 through LDS, wave 0 adds and stores
+  __syncthreads();
+  if (wave > 0) {
 #pragma unroll
-  for (int a = 0; a < C; ++a)
+    for (int a = 0; a < KQ; ++a)
 #pragma unroll
-    for (int b = 0; b < NCV; ++b) out[(kg * C + a) * Cv + cg * NCV + b] = acc[a][b];
+      for (int b = 0; b < CQ; ++b) smem[(wave - 1) * (K * Cv) + (kq * KQ + a) * Cv + cq * CQ + b] = acc[a][b];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* out = slab + (long long)blockIdx.x * (K * Cv);
+#pragma unroll
+    for (int a = 0; a < KQ; ++a)
+#pragma unroll
+      for (int b = 0; b < CQ; ++b) {
+        const int i = (kq * KQ + a) * Cv + cq * CQ + b;
+        out[i] = ((acc[a][b] + smem[i]) + smem[K * Cv + i]) + smem[2 * K * Cv + i];
+      }
+  }
 }
 
 bool smallcin_supported(int Cu, int Cv) { return Cu >= 1 && Cu <= SC_MAXC && (Cv == 16 || Cv == 32 || Cv == 64); }

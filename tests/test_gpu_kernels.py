@@ -190,7 +190,8 @@ def nchw(t):
 
 
 @pytest.mark.parametrize("n,h,w,Cu,Cv", [(3, 2, 3, 8, 12), (5, 4, 4, 64, 128), (4, 8, 8, 32, 64), (2, 16, 16, 4, 32),
-                                         (130, 4, 4, 16, 20)])
+                                         (130, 4, 4, 16, 20), (70, 16, 16, 3, 32), (5, 8, 6, 1, 16), (3, 16, 16, 3, 64),
+                                         (300, 16, 16, 2, 64)])
 def test_conv_down_up_wgrad(K, n, h, w, Cu, Cv):
     gen = g(n * 100 + h)
     U = torch.randn(n, Cu, 2 * h, 2 * w, generator=gen)
