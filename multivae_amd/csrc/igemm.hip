@@ -350,15 +350,26 @@ int launch_igemm(const GemmDesc& d_in, int zdim, hipStream_t s, LaunchInfo* info
 }
 
 // experiment hook: MVK_SPLITK_TARGET_1024 / _512 replace the two block targets of the split-K launches
+// SPLITK_C4 / SPLITK_LIN: the weight gradients of the 4x4/stride-2 convolutions / of the Linear layers (targets of their own since
+// round 5: MVK_SPLITK_TARGET_C4, MVK_SPLITK_TARGET_LIN)
+enum { SPLITK_C4 = 1025, SPLITK_LIN = 1026 };
 static int splitk_target(int t) {
-  static int t1024 = -1, t512 = -1;
+  static int t1024 = -1, t512 = -1, tc4 = -1, tlin = -1;
   if (t1024 < 0) {
     const char* a = mvk_tune("MVK_SPLITK_TARGET_1024");
     const char* b = mvk_tune("MVK_SPLITK_TARGET_512");
+    const char* c = mvk_tune("MVK_SPLITK_TARGET_C4");
+    const char* l = mvk_tune("MVK_SPLITK_TARGET_LIN");
     t1024 = a ? atoi(a) : 768;  // one full wave of 3 workgroups per CU (A/B in the step: 1.955 vs 1.969 ms at 1024)
     t512 = b ? atoi(b) : 512;
+    // 4x4/stride-2 weight gradients at the encoder batch sit on the step's last dependent chain, beside the ordered finish of the
+    // decoders' partial sums: 256 workgroups (16 tiles x 16 slices at 64 -> 128 channels, 4 x 64 at 32 -> 64) instead of 768 write a
+    // third of the partial tiles and leave the chip to their neighbours — headline 1.0005 -> 0.992 ms, MMVAE MnistSvhn 0.581 ->
+    // 0.548 ms (tools/gpu_r05_k2.sh / _m2.sh; 128 and 192 are slower again)
+    tc4 = c ? atoi(c) : 256;
+    tlin = l ? atoi(l) : t1024;
   }
-  return t == 1024 ? t1024 : (t == 512 ? t512 : t);
+  return t == 1024 ? t1024 : (t == 512 ? t512 : (t == SPLITK_C4 ? tc4 : (t == SPLITK_LIN ? tlin : t)));
 }
 
 int launch_splitk(GemmDesc& d, float* ws, long long ws_floats, int target_blocks, hipStream_t s) {
@@ -851,7 +862,7 @@ int mvk_linear_bwd_weight(const float* dY, const float* X, float* dW, float* db,
   d.M = N;
   d.N = K;
   d.K = M;
-  int rc = launch_splitk(d, ws, ws_floats, 1024, s);
+  int rc = launch_splitk(d, ws, ws_floats, SPLITK_LIN, s);
   if (rc) return rc;
   if (db) return colsum(dY, y_out, y_act, M, N, db, ws, ws_floats, s);
   return MVK_OK;
@@ -1400,7 +1411,7 @@ static int conv4s2_wgrad_impl(const float* U, const float* V, float* dWref, int 
   d.M = 16 * Cu;
   d.N = Cv;
   d.K = n * h * w;
-  return launch_splitk(d, ws, ws_floats, 1024, mvk_stream(stream));
+  return launch_splitk(d, ws, ws_floats, SPLITK_C4, mvk_stream(stream));
 }
 
 int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv,

@@ -6,8 +6,8 @@ line() { grep '^{' | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline())
 print('$1', d['value'], d['ms_per_step'], d['ms_per_step_median'])"; }
-for i in 1 2 3; do
-  for t in 768 256 384 512 1024; do
+for i in 1 2 3 4 5; do
+  for t in 768 256 128 192; do
     MVK_TUNE=1 MVK_SPLITK_TARGET_1024=$t timeout 600 python bench.py --steps 200 --warmup 20 --no-cpu-baseline 2>>$OUT/ab.err | line target_$t
   done
 done
