@@ -134,12 +134,16 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const HeadsBwdArgs g) {
   // This launch heads the step's last dependent chain and runs beside the decoder's weight gradients (one 512-register MFMA wave
   // per SIMD, all 256 CUs): 17 us alone, 60-90 us there.  A higher wave priority wins the SIMD's issue arbitration against that wave.
   if (MVK_CHAIN_PRIO) __builtin_amdgcn_s_setprio(MVK_CHAIN_PRIO);
-  __shared__ __attribute__((aligned(16))) float dYs[HB_MR * 65];
-  __shared__ __attribute__((aligned(16))) float Ws[64 * HB_KC];
-  __shared__ __attribute__((aligned(16))) float Xs[HB_MR * HB_XS];
-  __shared__ __attribute__((aligned(16))) float Ds[HB_MR * HB_XS];
-  __shared__ float red[16 * 64];
+  // LDS sized by the heads' width (dynamic): 48 KB for the 2 x 20 latents of the MnistSvhn encoders instead of a fixed 62 KB — the
+  // launch runs beside the decoder's weight gradients (95 / 112 KB of a CU's 160 KB): at 62 KB no workgroup of it fits beside the
+  // larger one
+  extern __shared__ __attribute__((aligned(16))) float hb_smem[];
   const int tid = threadIdx.x, N = g.N, K = g.K, NN = g.nh * N, NNP = NN | 1;
+  float* const dYs = hb_smem;                                  // [HB_MR][NNP]
+  float* const Ws = dYs + ((HB_MR * NNP + 3) & ~3);            // [NN][HB_KC]
+  float* const Xs = Ws + NN * HB_KC;                           // [HB_MR][HB_XS]
+  float* const Ds = Xs + HB_MR * HB_XS;                        // [HB_MR][HB_XS]
+  float* const red = Ds + HB_MR * HB_XS;                       // [16 * 64]
   const int k0 = blockIdx.x * HB_KC, rg = blockIdx.y, r0 = rg * HB_MR;
   const int rows = min(HB_MR, g.M - r0);
   {  // rows past the end are zero everywhere below: every loop over the rows has the fixed trip count HB_MR
@@ -337,7 +341,9 @@ int heads_bwd_launch(const float* X, int x_act, const float* dY0, const float* d
   a.flat_c = flat_c;
   a.w_sk = w_sk;
   a.w_sn = w_sn;
-  hipLaunchKernelGGL(heads_bwd_kernel, dim3(K / HB_KC, rgs), dim3(256), 0, s, a);
+  const int nn = nh * N;
+  const size_t lds = sizeof(float) * (size_t)(((HB_MR * (nn | 1) + 3) & ~3) + nn * HB_KC + 2 * HB_MR * HB_XS + 16 * 64);
+  hipLaunchKernelGGL(heads_bwd_kernel, dim3(K / HB_KC, rgs), dim3(256), lds, s, a);
   MVK_CHECK_LAUNCH();
   *nz = rgs;
   return MVK_OK;
