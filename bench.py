@@ -384,7 +384,8 @@ def self_launch(n):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of this node (default: WORLD_SIZE when a launcher started the process, else 1)")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg3k1", "cfg4", "cfg5"],
@@ -397,6 +398,11 @@ def main():
     ap.add_argument("--loss", default="iwae_looser", choices=["iwae_looser", "dreg_looser"], help="cfg2 objective")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every launch from Python instead of replaying a hipGraph")
+    ap.add_argument("--rotate", action="store_true",
+                    help="single GPU: the decoders' late weight gradients, their finishes and their share of Adam run at the head of "
+                         "the NEXT replay (GraphedStep(rotate=...); exact, bit-identical parameters; the timed region ends with the "
+                         "drain).  Built for VERDICT r5 item 1 and measured SLOWER on one MI355X (profiles/NOTES_r06.md section 2): opt-in")
+    ap.add_argument("--no-rotate", action="store_true", help=argparse.SUPPRESS)  # (the default; kept for the round's A/B scripts)
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -405,6 +411,8 @@ def main():
     #   no launcher environment and N > 1 -> this process becomes the launcher (torch.distributed.run, N ranks on 127.0.0.1);
     #   a launcher environment whose WORLD_SIZE differs from N -> exit status 2, nothing printed on stdout;
     #   the line's n_gpus is what the gradient collective's communicator reports (ncclCommCount), checked against N.
+    if args.gpus is None:  # `torchrun --nproc-per-node N bench.py` without --gpus reports the launcher's size
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -482,9 +490,14 @@ def main():
             #   MVK_OVERLAP=1     the gradient collective in two parts, the first behind an external event node of the graph: the
             #                     node alone costs the replayed step +65 us on one GPU (hipGraph re-partitions its queues around
             #                     it), +100 us with the second collective launch.
+            graph_adam = not use_dist and os.environ.get("MVK_GRAPH_ADAM", "0") == "1"
+            # Rotated step (single GPU, --rotate): the decoders' late weight gradients of step N, their finishes and their share of
+            # the update run at the head of replay N + 1, beside the encoders (exact: tests/test_gpu_trainer.py
+            # test_rotated_step_is_bit_identical); the timed region below ends with the drain of the last step.
+            rotate = (not use_dist and not graph_adam and args.rotate and not args.no_rotate and opt.zero_grad_in_step)
             graphed = GraphedStep(model, flat, inputs, noise=None,
                                   capture_error_mode="thread_local" if use_dist else "global",
-                                  optimizer=opt if (not use_dist and os.environ.get("MVK_GRAPH_ADAM", "0") == "1") else None,
+                                  optimizer=opt if graph_adam else None, rotate=opt if rotate else None,
                                   overlap=use_dist and os.environ.get("MVK_OVERLAP", "0") in ("1", "2"), **fkw)
         except Exception as e:  # capture is an optimisation, not a requirement
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
@@ -502,6 +515,32 @@ def main():
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
+    # Settling: the clock ramp of a freshly started process belongs outside the timed region by
+    # construction, not by the choice of --warmup.  Untimed groups of SETTLE_GROUP steps (device time of a group between two
+    # events) follow the W warm-up steps until two consecutive groups agree within 3 %, at most SETTLE_MAX groups; every rank
+    # runs the same number (the ranks agree on "settled" through an all-reduce), and the count goes into the line.
+    SETTLE_GROUP, SETTLE_MAX = 5, 10
+    settle_groups, prev_ms = 0, None
+    while settle_groups < SETTLE_MAX:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(SETTLE_GROUP):
+            out = step()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / SETTLE_GROUP
+        settle_groups += 1
+        settled = prev_ms is not None and abs(ms - prev_ms) <= 0.03 * min(ms, prev_ms)
+        if use_dist:
+            flag = torch.tensor([1 if settled else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            settled = bool(int(flag.item()))
+        prev_ms = ms
+        if settled:
+            break
+    if graphed is not None:
+        graphed.drain()
+    torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -512,6 +551,8 @@ def main():
     marks[0].record()
     for i in range(args.steps):
         out = step()
+        if i + 1 == args.steps and graphed is not None:
+            graphed.drain()  # rotated step: the last step's late leaves + their update belong to the timed region
         marks[i + 1].record()
     torch.cuda.synchronize()
     if use_dist:
@@ -535,7 +576,7 @@ def main():
         step2 = lambda: eager_step(collective=False)
         if graphed is not None:
             try:
-                g2 = GraphedStep(model, flat, inputs, noise=None,
+                g2 = GraphedStep(model, flat, inputs, noise=None, rotate=opt if (graphed.rotated) else None,
                                  capture_error_mode="thread_local" if use_dist else "global", **fkw)
                 prof.stop()  # the captured launches keep their records; nothing else is stamped from here on
 
@@ -551,6 +592,8 @@ def main():
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step2()
+        if graphed is not None and graphed.rotated:
+            g2.drain()
         torch.cuda.synchronize()
         ms_instr = 1e3 * (time.perf_counter() - t1) / args.steps
         prof.stop()
@@ -588,6 +631,7 @@ def main():
             "n_gpus": n_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
+            "settle_steps": settle_groups * SETTLE_GROUP,  # untimed, behind the warm-up: groups of 5 until two agree within 3 % (<= 50)
             "ms_per_step": round(ms, 4),
             "ms_per_step_median": round(per_step_ms[len(per_step_ms) // 2], 4),
             "ms_per_step_min_max": [round(per_step_ms[0], 4), round(per_step_ms[-1], 4)],
@@ -608,7 +652,12 @@ def main():
                                       len(graphed.early_ranges), len(graphed.late_ranges),
                                       4e-6 * sum(n for _, n in graphed.early_ranges), 4e-6 * sum(n for _, n in graphed.late_ranges))
                                    if graphed.early_ranges else ("hipGraph replay (fwd + bwd) + mvk_allreduce_avg + Adam" if use_dist else
-                                                                  "hipGraph replay (fwd + bwd) + Adam"))),
+                                                                  ("ROTATED hipGraph replay: [late weight gradients of the previous step + "
+                                                                   "their finishes + Adam over %.2f MB of decoder weights + their packs] beside "
+                                                                   "[encoders + posterior], then decoders + backward; Adam over the rest behind "
+                                                                   "the replay; the timed region ends with the drain of the last step"
+                                                                   % (4e-6 * sum(n for _, n in opt._rot_ranges)))
+                                                                  if graphed.rotated else "hipGraph replay (fwd + bwd) + Adam"))),
                        # how the fp32 GEMM / convolution products are formed (operands, results and accumulation are fp32; the
                        # tests hold every form to the same float64-referenced tolerance)
                        "fp32_product": ("register-stationary convolutions: 3 fp16 MFMAs on scaled (hi, lo) pairs"

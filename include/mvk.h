@@ -662,6 +662,16 @@ int mvk_adam_step_fused(float* p, float* g, float* m, float* v, float* vmax, int
 int mvk_adam_prepare(double* state, float* scalars, void* stream);
 int mvk_adam_step_dev(float* p, float* g, float* m, float* v, float* vmax, int64_t n, const float* scalars, int zero_grad,
                       void* stream);
+/* The rotated step (trainers/graph.py: the decoder's late weight gradients of step N are produced at the head of step N + 1, beside
+ * the encoders' forward pass).  optimizer.step() of base_trainer.py:350-361 is then TWO launches over disjoint ranges of the flat
+ * buffers with the SAME scalars: mvk_adam_step_pub — mvk_adam_step_fused over the range whose gradients are final when the
+ * step ends, which also leaves the update's scalars (step size, bias corrections, ...: 8 floats) in `publish` — and, inside the
+ * next replay and behind the late gradients, mvk_adam_step_dev over the other range reading `publish`.  Every parameter is
+ * updated exactly once per step and before it is next read.  n == 0 publishes only.  mvk_adam_identity writes the scalars
+ * under which mvk_adam_step_dev changes nothing (the state before the first step and after a drain). */
+int mvk_adam_step_pub(float* p, float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1, double beta2,
+                      double eps, double weight_decay, int step, double grad_scale, int zero_grad, float* publish, void* stream);
+int mvk_adam_identity(float* scalars, void* stream);
 
 /* The encoder heads in ONE launch: Y_h[m][n] = sum_k X[m][k] W_h(k, n) + b_h[n] for h = 0 (and 1 when W1 != NULL),
  * n < N <= 32, W_h(k, n) = W_h[k * w_sk + n * w_sn] (a torch Linear weight [N][K]: w_sk = 1, w_sn = K; the packed

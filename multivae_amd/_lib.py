@@ -153,6 +153,8 @@ PROTOTYPES = {
     "mvk_adam_step_amsgrad": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _d, _p],
     "mvk_adam_step_fused": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _d, _i, _p],
     "mvk_adam_prepare": [_p, _p, _p],
+    "mvk_adam_step_pub": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _d, _i, _p, _p],
+    "mvk_adam_identity": [_p, _p],
     "mvk_adam_step_dev": [_p, _p, _p, _p, _p, _i64, _p, _i, _p],
     "mvk_mmvae_std_fwd": [_p, _i, _i, _i, _p, _p],
     "mvk_mmvae_std_bwd": [_p, _p, _p, _i, _i, _i, _p, _p],

@@ -434,13 +434,15 @@ __device__ __forceinline__ void c3rs_body(const C3Args& g) {
     };
     auto epilogue_row = [&](int Q, int o, bool valid) {  // Q: the parity whose fetch belongs to the tile in res_prev
       float v = fmaf(res_prev[o], pre_scale, bias);   // pre_scale carries 1 / (sx sw) in the scaled-fp16 form
-      if (HAS_RES) v = fmaf(wpre, rr[Q][o], v);        // (the other channel slice's partial sum)
+      // (the other channel slice's partial sum; selected, not multiplied by 0, where it does not enter: a non-finite residual must
+      // not turn into NaN inside the activation's input — ADVICE r5; wpre / wpost are wave-uniform)
+      if (HAS_RES && wpre != 0.f) v = fmaf(wpre, rr[Q][o], v);
       v = fmaxf(v, v * aslope);                        // (leaky) ReLU / identity: 0 <= slope <= 1
       if (HAS_SRC) v = msk[Q][o] > 0.f ? v : v * mslope;
       const int px_ = valid ? pix[Q][o] : -1;
       if (WITH_CSUM) csum += px_ < 0 ? 0.f : v;
       if (DUAL) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY2, (unsigned)px_ * (COUT * 4u) + ncol * 4u, 0, 0);
-      if (HAS_RES) v = fmaf(alpha, v, wpost * rr[Q][o]);
+      if (HAS_RES) v = wpost != 0.f ? fmaf(alpha, v, wpost * rr[Q][o]) : alpha * v;
       amax_l = fmaxf(amax_l, px_ < 0 ? 0.f : fabsf(v));
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY, (unsigned)px_ * (COUT * 4u) + ncol * 4u, 0, 0);
     };

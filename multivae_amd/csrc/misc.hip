@@ -361,7 +361,8 @@ __device__ __forceinline__ void adam_one(float& pi, float gi, float& mi, float& 
 // ZERO: the gradient is cleared as it is consumed (the next step's zero_grad pass and its launch disappear)
 template <bool AMSGRAD, bool ZERO>
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            float* __restrict__ vmax, long long n, const AdamScalars a) {
+                            float* __restrict__ vmax, long long n, const AdamScalars a, AdamScalars* __restrict__ pub) {
+  if (pub && blockIdx.x == 0 && threadIdx.x == 0) *pub = a;  // mvk_adam_step_pub: the scalars of THIS update, for a later mvk_adam_step_dev
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
@@ -377,8 +378,9 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float*
 template <bool AMSGRAD, bool ZERO>
 __global__ __launch_bounds__(256) void adam4_kernel(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
                                                     float4* __restrict__ v, float4* __restrict__ vmax, long long n4,
-                                                    const AdamScalars a) {
+                                                    const AdamScalars a, AdamScalars* __restrict__ pub) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (pub && i == 0) *pub = a;
   if (i >= n4) return;
   float4 pi = p[i], mi = m[i], vi = v[i];
   const float4 gi = g[i];
@@ -755,16 +757,31 @@ int mvk_conv4s2_up_nchw_small(const float* V, const float* Wref, const float* bi
   return MVK_OK;
 }
 
-int mvk_adam_step_fused(float* p, float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1, double beta2,
-                        double eps, double weight_decay, int step, double grad_scale, int zero_grad, void* stream) {
-  if (!p || !g || !m || !v || step < 1) return MVK_EINVAL;
-  if (n == 0) return MVK_OK;
-  // scalar arithmetic in double like the Python side of torch.optim.Adam, cast once
+// the scalar arithmetic of one update: in double like the Python side of torch.optim.Adam, cast once
+static AdamScalars adam_scalars(double lr, double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale) {
   const double bc1 = 1.0 - pow(beta1, (double)step);
   const double bc2 = 1.0 - pow(beta2, (double)step);
-  const AdamScalars a{(float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
-                      (float)eps,        (float)weight_decay,  (float)sqrt(bc2), (float)grad_scale};
+  return AdamScalars{(float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                     (float)eps,        (float)weight_decay,  (float)sqrt(bc2), (float)grad_scale};
+}
+
+__global__ void adam_publish_kernel(AdamScalars* __restrict__ pub, const AdamScalars a) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *pub = a;
+}
+
+int mvk_adam_step_pub(float* p, float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1, double beta2,
+                      double eps, double weight_decay, int step, double grad_scale, int zero_grad, float* publish, void* stream) {
+  if (n < 0 || step < 1 || (n > 0 && (!p || !g || !m || !v)) || (publish && !mvk_aligned16(publish))) return MVK_EINVAL;
+  const AdamScalars a = adam_scalars(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
   hipStream_t s = mvk_stream(stream);
+  AdamScalars* pub = reinterpret_cast<AdamScalars*>(publish);
+  if (n == 0) {
+    if (pub) {
+      hipLaunchKernelGGL(adam_publish_kernel, dim3(1), dim3(64), 0, s, pub, a);
+      MVK_CHECK_LAUNCH();
+    }
+    return MVK_OK;
+  }
   const bool v4 = n % 4 == 0 && mvk_aligned16(p) && mvk_aligned16(g) && mvk_aligned16(m) && mvk_aligned16(v) &&
                   (!vmax || mvk_aligned16(vmax));
 #define MVK_ADAM_LAUNCH(AMS_, Z_)                                                                                              \
@@ -772,15 +789,33 @@ int mvk_adam_step_fused(float* p, float* g, float* m, float* v, float* vmax, int
     if (v4)                                                                                                                    \
       hipLaunchKernelGGL((adam4_kernel<AMS_, Z_>), dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s,                     \
                          reinterpret_cast<float4*>(p), reinterpret_cast<float4*>(g), reinterpret_cast<float4*>(m),             \
-                         reinterpret_cast<float4*>(v), reinterpret_cast<float4*>(vmax), (long long)(n / 4), a);                \
+                         reinterpret_cast<float4*>(v), reinterpret_cast<float4*>(vmax), (long long)(n / 4), a, pub);           \
     else                                                                                                                       \
-      hipLaunchKernelGGL((adam_kernel<AMS_, Z_>), dim3(grid_for(n, 256)), dim3(256), 0, s, p, g, m, v, vmax, (long long)n, a); \
+      hipLaunchKernelGGL((adam_kernel<AMS_, Z_>), dim3(grid_for(n, 256)), dim3(256), 0, s, p, g, m, v, vmax, (long long)n, a,  \
+                         pub);                                                                                                 \
   } while (0)
   if (vmax && zero_grad) MVK_ADAM_LAUNCH(true, true);
   else if (vmax) MVK_ADAM_LAUNCH(true, false);
   else if (zero_grad) MVK_ADAM_LAUNCH(false, true);
   else MVK_ADAM_LAUNCH(false, false);
 #undef MVK_ADAM_LAUNCH
+  MVK_CHECK_LAUNCH();
+  return MVK_OK;
+}
+
+int mvk_adam_step_fused(float* p, float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1, double beta2,
+                        double eps, double weight_decay, int step, double grad_scale, int zero_grad, void* stream) {
+  if (!p || !g || !m || !v || step < 1) return MVK_EINVAL;
+  return mvk_adam_step_pub(p, g, m, v, vmax, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, zero_grad, nullptr, stream);
+}
+
+// The scalars under which mvk_adam_step_dev changes NOTHING (p, m, v, vmax bit for bit; a finite gradient is consumed — and
+// cleared when zero_grad is set): step_size 0, 1 - beta1 = 0, beta2 = 1, 1 - beta2 = 0, eps 1, weight_decay 0, sqrt(bc2) 1,
+// grad_scale 0.  What a rotated step's update of the late leaves reads before the first step and after a drain.
+int mvk_adam_identity(float* scalars, void* stream) {
+  if (!scalars || !mvk_aligned16(scalars)) return MVK_EINVAL;
+  const AdamScalars a{0.f, 0.f, 1.f, 0.f, 1.f, 0.f, 1.f, 0.f};
+  hipLaunchKernelGGL(adam_publish_kernel, dim3(1), dim3(64), 0, mvk_stream(stream), reinterpret_cast<AdamScalars*>(scalars), a);
   MVK_CHECK_LAUNCH();
   return MVK_OK;
 }

@@ -139,6 +139,9 @@ LATE_DENSE = _lib.tune("MVK_LATE_DENSE", "0") == "1"
 # orders the posterior's backward behind EVERYTHING the decoder's backward node enqueued on its stream, leaves included.
 # MEASURED (three same-box pairs): 1.046 / 1.050 / 1.039 -> 1.042 / 1.040 / 1.032 ms.  MVK_LATE_DW0=0: inside the node.
 LATE_DW0 = _lib.tune("MVK_LATE_DW0", "1") != "0"
+# MVK_SKIP_LATE=1 (TIMING ONLY, wrong gradients): the SVHN decoder's late weight gradients are not launched at all — the bound of
+# what moving them out of the step's tail can gain (NOTES_r06 section 1)
+SKIP_LATE = _lib.tune("MVK_SKIP_LATE", "0") == "1"
 
 
 def run_last(device, fn, *reads, force=False, params=()):
@@ -189,6 +192,128 @@ class OverlapPoint:
                 _lib.load().mvk_event_destroy(self.event)
         except Exception:
             pass
+
+
+# -----------------------------------------------------------------------------------------------------
+# the rotated step: leaf gradients of step N at the head of step N + 1 (trainers/graph.py GraphedStep(rotate=True))
+# -----------------------------------------------------------------------------------------------------
+# The reference's loop is strictly sequential (trainers/base/base_trainer.py:350-361: zero_grad, forward, backward, step), but
+# nothing in its semantics ties a DECODER's weight gradients and their share of optimizer.step() of step N to anything before
+# that decoder's forward pass of step N + 1.  In a rotated step the decoders' weight-gradient launches (leaves of the backward
+# pass: nothing waits for them) are not enqueued by the backward pass; their closures are kept and run at the head of the
+# next step on a branch of their own — beside the encoders' forward pass and the posterior, the launch-latency-bound head of
+# the step in which the chip is mostly idle — followed by their ordered finishes, the Adam update of exactly those
+# parameters (mvk_adam_step_dev with the scalars the step's main update published: mvk_adam_step_pub) and the weight packs
+# that read them; the decoders' forward pass waits for that branch.  Every parameter is updated once per step, with the same
+# gradient and the same scalars, before it is next read: the parameters after N steps + a drain are bit for bit those of N
+# unrotated steps (tests/test_gpu_trainer.py).  What a leaf reads must survive into the next replay at a fixed address:
+# `Rotation.buf` hands out persistent buffers, `Rotation.slots` persistent amax slots (zeroed by the branch behind the leaves).
+# MVK_ROT_SVHN / MVK_ROT_MLP = 0: that decoder's leaves stay in the step they belong to (A/B).
+ROT_SVHN = _lib.tune("MVK_ROT_SVHN", "1") != "0"
+ROT_MLP = _lib.tune("MVK_ROT_MLP", "1") != "0"
+_ROTATE = {}  # device -> Rotation, while trainers.graph enqueues / captures a rotated step
+
+
+def rotation(device):
+    """The open Rotation of a device, or None."""
+    return _ROTATE.get(device) if _ROTATE else None
+
+
+class Rotation:
+    def __init__(self, device):
+        self.device = device
+        self.bufs = {}
+        self.amax = torch.zeros(64, dtype=torch.float32, device=device)
+        self.amax_pos = 0
+        self.leaves = []    # registered by the backward pass that is being enqueued: (closure, parameters, prepare)
+        self.pending = []   # those of the previous pass: what the head of the next one runs
+        self.cache = {}     # pack key -> what the head's `prepare` closures packed BEHIND the update of the rotated parameters
+        self.event = None
+        self.waited = set()
+        self.stream = _side_stream(device, 29)
+        self.open = False
+
+    def buf(self, name, shape, dtype=torch.float32):
+        """A buffer that keeps its address from pass to pass (and from replay to replay)."""
+        t = self.bufs.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            if t is not None and torch.cuda.is_current_stream_capturing():
+                raise _lib.MvkError(f"rotated step: buffer {name} changes shape inside a capture")
+            t = torch.zeros(tuple(shape), dtype=dtype, device=self.device)
+            self.bufs[name] = t
+        return t
+
+    def slots(self, n):
+        """n amax slots that are zero now and stay untouched until the head of the next step has run its leaves."""
+        if self.amax_pos + n > self.amax.numel():
+            raise _lib.MvkError("rotated step: out of amax slots")
+        self.amax_pos += n
+        return self.amax[self.amax_pos - n:self.amax_pos]
+
+    @property
+    def params(self):
+        """The parameters whose gradients (and update) are rotated, in registration order."""
+        out, seen = [], set()
+        for _, ps, _ in self.pending:
+            for q in ps:
+                if id(q) not in seen:
+                    seen.add(id(q))
+                    out.append(q)
+        return out
+
+    def push(self, fn, params, prepare=None):
+        self.leaves.append((fn, tuple(params), prepare))
+
+    def begin_step(self, update=None):
+        """Inside deferred_reductions, before the forward pass: the branch of the previous step's leaves.  update: the closure
+        that applies the optimizer to the rotated parameters (captured passes only; eager warm-up passes leave the parameters
+        alone)."""
+        cur = torch.cuda.current_stream(self.device)
+        st = self.stream
+        st.wait_event(cur.record_event())
+        self.cache, self.waited, self.open = {}, set(), True
+        with torch.cuda.stream(st):
+            for fn, _, _ in self.pending:
+                fn()
+            if self.pending:
+                call("mvk_defer_flush", stream_ptr())  # their ordered finishes: the gradients of the rotated parameters are final
+                if update is not None:
+                    update()
+            self.amax.zero_()  # the slots the leaves read are free for this step's producers
+            self.amax_pos = 0
+            for _, _, prepare in self.pending:
+                if prepare is not None:
+                    prepare(self)
+            self.event = st.record_event()
+        self.leaves = []
+        _ROTATE[self.device] = self
+
+    def wait(self):
+        """Order the current stream behind the head branch (whoever reads a rotated parameter, or a pack of one, calls this)."""
+        if not self.open or self.event is None:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream not in self.waited:
+            cur.wait_event(self.event)
+            self.waited.add(cur.cuda_stream)
+            for t in _tensors_of(list(self.cache.values())):  # allocated on the branch's stream, read on this one
+                t.record_stream(cur)
+                if getattr(t, "mvk_frag", None) is not None:
+                    t.mvk_frag.record_stream(cur)
+
+    def end_step(self):
+        """Behind the backward pass: the branch is joined (it is, transitively, when a decoder waited for it), the leaves the
+        backward pass registered become the next head's."""
+        _ROTATE.pop(self.device, None)
+        if self.open:
+            self.wait()
+            self.open = False
+        self.pending, self.leaves = self.leaves, []
+
+    def run_pending(self):
+        """The drain: the pending leaves on the current stream (inside deferred_reductions), no update, no packs."""
+        for fn, _, _ in self.pending:
+            fn()
 
 
 _LATE_READY = {}
@@ -312,12 +437,14 @@ def defer_flush_sibling(device, node_params=()):
             # the flush already waits for every stream a gradient producer RAN ON (csrc/igemm.hip defer_flush_locked); ordered
             # explicitly behind the caller's stream and the late-leaf streams as well: a gradient written straight into the
             # buffer by a launch that queued no finish would otherwise be unordered against the collective
-            for st in dict.fromkeys([cur] + list(_LATE_USED.get(device, ()))):
+            # (... and behind EVERY branch stream of the step, not only the caller's: a backward node of another branch
+            # that is enqueued already must have written its gradients before the collective reads them)
+            for st in dict.fromkeys([cur] + list(_BRANCH_SET.get(device, ())) + list(_LATE_USED.get(device, ()))):
                 if st != sib:
                     sib.wait_event(st.record_event())
             call("mvk_event_record", op.event, 1, stream_ptr())
             op.late_params.extend(node_params)
-            op.recorded = True
+            op.recorded = True  # from here on every gradient target handed out is late (_grad_target): whatever node asks
     _LATE_USED.setdefault(device, []).append(sib)
 
 
@@ -562,6 +689,12 @@ def _grad_target(p):
     and autograd gets None for this input (no zero-fill, no extra add kernel); otherwise a fresh zero buffer is
     returned to autograd as usual.  Both ways the visible semantics are `p.grad += dL/dp`."""
     g = p.grad
+    if _OVERLAP:
+        op = _OVERLAP.get(p.device)
+        if op is not None and op.recorded:
+            # ADVICE r5: a gradient produced behind the overlap point — by the node that recorded it or by ANY node enqueued
+            # later (a second SVHN-type encoder, an encoder on a side branch) — is not part of the early collective
+            op.late_params.append(p)
     if DIRECT_GRAD and g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.shape == p.shape \
             and g.device == p.device:
         return g, None
@@ -750,9 +883,13 @@ def _job_key(job):
 def pack_weights(jobs):
     """`_pack_launch(jobs)`, or inside a pack_scope: from the scope's cache / together with every announced job of the model."""
     sc = _PACK_SCOPE
+    keys = [_job_key(j) for j in jobs]
+    rot = rotation(jobs[0][0].device)
+    if rot is not None and rot.cache and all(k in rot.cache for k in keys):  # packed by the head branch of a rotated step
+        rot.wait()
+        return [rot.cache[k] for k in keys]
     if sc is None:
         return _pack_launch(jobs)
-    keys = [_job_key(j) for j in jobs]
     cache = sc["cache"]
     if all(k in cache for k in keys):
         ev = sc.get("event")
@@ -775,6 +912,8 @@ def pack_weights(jobs):
                 continue
             for j in announce():
                 k = _job_key(j)
+                if rot is not None and k in rot.cache:
+                    continue  # behind the rotated update of these weights, on the head branch
                 if k not in tkeys and k not in cache and j[0].device == jobs[0][0].device and len(todo) < PACK_MAX:
                     todo.append(j)
                     tkeys.append(k)
@@ -786,15 +925,16 @@ def pack_weights(jobs):
     return outs[:len(jobs)]
 
 
-def _pack_launch(jobs):
+def _pack_launch(jobs, am=None):
     """All weight packs of a network in ONE launch.  jobs: list of (wref, want_down, want_up) for 4x4/stride-2
     layers ([Cv][Cu][4][4] -> (Wdown [16*Cu, Cv], Wup [4, 4*Cv, Cu])) or (wref, "unflatten") for the 1x1-spatial
     transposed convolution ([Cin][Cout][4][4] -> [Cin, 16*Cout]).  Returns the packed tensors in job order."""
     descs = (PackDesc * len(jobs))()
     outs = []
-    am = None
     # max |W| per convolution weight: the operand scale of the scaled-fp16 launches (mvk_conv3x3_s, mvk_conv4s2_down_s / _up_s)
-    if (C3_F16 and any(job[1] == "c3" for job in jobs)) or (IMG_F16 and any(job[1] not in ("c3", "unflatten") for job in jobs)):
+    # (am given: zeroed slots of the caller's — the head branch of a rotated step packs outside the scope's arena)
+    if am is None and ((C3_F16 and any(job[1] == "c3" for job in jobs))
+                       or (IMG_F16 and any(job[1] not in ("c3", "unflatten") for job in jobs))):
         am = _amax_slots(jobs[0][0], len(jobs), create=True)
     for i, job in enumerate(jobs):
         wref = job[0]
@@ -846,11 +986,11 @@ def conv4s2_scaled_ok(n, h, w, Cu, Cv):
 
 
 def conv_down(U, wdown, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src=None, u_act=NONE,
-              v_act_src=None, v_act=NONE, out_bias=None, in_bf3=False, frag=None, amax=None):
+              v_act_src=None, v_act=NONE, out_bias=None, in_bf3=False, frag=None, amax=None, out=None):
     """out_bias: bias parameter whose gradient is the per-channel sum of the result (backward-data use): fused into
     the launch; returns (V, grad for autograd) then.  amax = (x_amax, w_amax, y_amax): the amax protocol (mvk_conv4s2_down_s;
-    x and w bounds given = scaled fp16 pairs, y_amax = zeroed slot that receives max |V|)."""
-    V = torch.empty((n, h, w, Cv), dtype=torch.float32, device=U.device)
+    x and w bounds given = scaled fp16 pairs, y_amax = zeroed slot that receives max |V|).  out: the buffer V is written to."""
+    V = out if out is not None else torch.empty((n, h, w, Cv), dtype=torch.float32, device=U.device)
     ws = _ws(V)
     tb, rb = _bias_target(out_bias)
     if amax is not None:
@@ -867,8 +1007,9 @@ def conv_down(U, wdown, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src
 
 
 def conv_up(V, wup, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src=None, u_act=NONE, out_bias=None,
-            in_bf3=False, frag=None, amax=None):
-    U = torch.empty((n, Cu, 2 * h, 2 * w) if u_nchw else (n, 2 * h, 2 * w, Cu), dtype=torch.float32, device=V.device)
+            in_bf3=False, frag=None, amax=None, out=None):
+    U = out if out is not None else torch.empty((n, Cu, 2 * h, 2 * w) if u_nchw else (n, 2 * h, 2 * w, Cu), dtype=torch.float32,
+                                                device=V.device)
     ws = _ws(U)
     tb, rb = _bias_target(out_bias)
     if amax is not None:  # (x_amax, w_amax, y_amax): see conv_down
@@ -1342,19 +1483,23 @@ def _planes(rows, cols, like):
     return t, t[0], t[1]
 
 
-def dense16_pack(w):
+def dense16_pack(w, raw=False):
     """Planes of a Linear weight [N][K] in both orientations + the per-row inverse scales; once per forward pass inside a
-    pack_scope (the cache dies with the scope: the weights change at the next optimizer step)."""
+    pack_scope (the cache dies with the scope: the weights change at the next optimizer step).  raw: launch here, no cache."""
     sc = _PACK_SCOPE
     key = ("dense16", w.data_ptr(), tuple(w.shape))
-    if sc is not None and key in sc["cache"]:
+    rot = rotation(w.device)
+    if not raw and rot is not None and key in rot.cache:  # packed by the head branch of a rotated step, behind w's update
+        rot.wait()
+        return rot.cache[key]
+    if not raw and sc is not None and key in sc["cache"]:
         return sc["cache"][key]
     N, K = w.shape
     nk, kn = _planes(N, K, w), _planes(K, N, w)
     nk_inv, kn_inv = _new((N,), w), _new((K,), w)
     call("mvk_dense16_pack", ptr(w), N, K, ptr(nk[1]), ptr(nk[2]), ptr(nk_inv), ptr(kn[1]), ptr(kn[2]), ptr(kn_inv), stream_ptr())
     out = (nk, nk_inv, kn, kn_inv)
-    if sc is not None:
+    if sc is not None and not raw:
         sc["cache"][key] = out
     return out
 
@@ -1423,16 +1568,35 @@ class MLPDecoderFn(Function):
         ctx.z_shape = z.shape
         if ctx.fused:
             n, H, D = z2.shape[0], w0.shape[0], w1.shape[0]
+            # rotated step (Rotation): the weight gradients of w1 / b1 / w0 run at the head of the NEXT step; what they read (z,
+            # the planes of h and of the stored gradient, their bounds, the column-sum partials; dh in backward) is persistent
+            rot = rotation(z2.device)
+            if rot is not None:
+                rot.wait()  # w0 is read as it is, w1 through planes packed behind its update
+            if not (ROT_MLP and rot is not None and LATE_LEAVES and z2.device in _DEFER_ACTIVE
+                    and all(_is_direct(t) for t in (w0, w1, b1))):
+                rot = None
+            ctx.rot = rot
+            rkey = ("mlp_dec", w0.data_ptr(), n)
             nk, nk_inv, kn, kn_inv = dense16_pack(w1)  # both usually done already: Decoder_AE_MLP.early_work
             xam = dense16_xamax(nll_x)
             zam = _amax_slots(z2, 1)
-            hp = _planes(n, H, z2)
-            gp = _planes(n, D, z2)
-            bounds = _new((2,), z2)  # [bound of h, bound of G]
             lib = _lib.load()
             P, CR = lib.mvk_dense16_fwd_nll_rows(D), lib.mvk_dense16_colsum_rows(n)
+            if rot is None:
+                hp = _planes(n, H, z2)
+                gp = _planes(n, D, z2)
+                bounds = _new((2,), z2)  # [bound of h, bound of G]
+                cs = _new((CR, D), z2)
+            else:
+                z2 = rot.buf(rkey + ("z",), z2.shape).copy_(z2)
+                hp = rot.buf(rkey + ("hp",), (2, n, H), torch.float16)
+                hp = (hp, hp[0], hp[1])
+                gp = rot.buf(rkey + ("gp",), (2, n, D), torch.float16)
+                gp = (gp, gp[0], gp[1])
+                bounds = rot.buf(rkey + ("bounds",), (2,))
+                cs = rot.buf(rkey + ("cs",), (CR, D))
             rows = _new((P, n), z2)
-            cs = _new((CR, D), z2)
 
             def launch():  # the three launches of the forward pass (possibly postponed: defer_forward)
                 call("mvk_amax", ptr(z2), z2.numel(), ptr(zam), stream_ptr())
@@ -1492,7 +1656,8 @@ class MLPDecoderFn(Function):
             tw1, dw1 = _grad_target(w1)
             tb1, db1 = _grad_target(b1)
             tb0, db0 = _grad_target(b0)
-            dh = _new((n, H), z2)
+            rot = ctx.rot if (ctx.rot is not None and rotation(z2.device) is ctx.rot and dw1 is None and db1 is None) else None
+            dh = _new((n, H), z2) if rot is None else rot.buf(("mlp_dec", w0.data_ptr(), n, "dh"), (n, H))
             call("mvk_dense16_bwd_data", ptr(gp[0]), ptr(gp[1]), ptr(gb), ptr(kn[0]), ptr(kn[1]), ptr(kn_inv), ptr(hp[0]), ptr(dh),
                  ptr(tb0), ptr(ws), ws.numel(), n, H, D, stream_ptr())
             # the gradient of z first (the posterior's backward waits for it), the weight gradients — leaves — behind it
@@ -1502,6 +1667,17 @@ class MLPDecoderFn(Function):
                 wsl = _ws(z2)
                 call("mvk_dense16_wgrad", ptr(gp[0]), ptr(gp[1]), ptr(gb), ptr(hp[0]), ptr(hp[1]), ptr(hb), ptr(cs), cs.shape[0],
                      ptr(tw1), ptr(tb1), ptr(wsl), wsl.numel(), n, D, H, stream_ptr())
+
+            if rot is not None:  # rotated step: both weight gradients are the head of the next step (Rotation.begin_step)
+                def leaves():
+                    wgrad1()
+                    linear_bwd_weight(dh, z2, w0, None)
+
+                def prepare(r):  # behind the update of w1: its planes for the next forward pass
+                    r.cache[("dense16", w1.data_ptr(), tuple(w1.shape))] = dense16_pack(w1, raw=True)
+
+                rot.push(leaves, (w1, b1, w0), prepare)
+                return dz, None, db0, None, None, None, None, None, None
 
             # a leaf: postponed into the tail of the step when its targets are views of the flat gradient buffer
             if dw1 is not None or db1 is not None or not run_last(z2.device, wgrad1, gp, hp, cs, bounds, params=(w1, b1)):
@@ -1652,22 +1828,37 @@ class SVHNDecoderFn(Function):
         f16 = (IMG_F16 and n >= IMG_F16_MIN_ROWS and conv4s2_scaled_ok(n, 4, 4, C2, C1) and conv4s2_scaled_ok(n, 8, 8, C3, C2)
                and all(getattr(t, "mvk_amax", None) is not None for t in (wu1, wu2, wd1, wd2)))
         ctx.f16 = f16
+        # rotated step (Rotation): the three weight gradients of w0 / w1 / w2 run at the head of the NEXT step — what they read
+        # (z, g1, g2 here; the three gradients in backward; the amax slots) lives in the rotation's persistent buffers
+        rot = rotation(z2.device)
+        if rot is not None:
+            rot.wait()  # w0 / w1 / w2 (and their packs above) are final behind the head branch
+        if not (ROT_SVHN and rot is not None and f16 and nll_x is not None and LATE_LEAVES and z2.device in _DEFER_ACTIVE
+                and all(_is_direct(t) for t in (w0, w1, w2))):
+            rot = None
+        ctx.rot = rot
+        rkey = ("svhn_dec", w0.data_ptr(), n)
+        if rot is not None:
+            z2 = rot.buf(rkey + ("z",), z2.shape).copy_(z2)
         if f16:
-            pool = AmaxPool(z2, 6)
+            pool = AmaxPool(z2, 6) if rot is None else AmaxPool.__new__(AmaxPool)
+            if rot is not None:
+                pool.t, pool.i = rot.slots(6), 0
             a1, a2 = pool.take(), pool.take()
             a3 = pool.take() if (TAIL_F16 and nll_x is not None) else None  # bound of g3 for the image layer's scaled form
             # bound of the fused tail's stored gradient: the image layer's backward scales it (small_up_bwd_h_kernel)
             ctx.a_dpre = pool.take() if (a3 is not None and TAIL_BWD_F16) else None
             ctx.a_g3 = a3
             ctx.bslots = (pool.take(), pool.take())  # the backward pass's two slots: no fill launch there
+            g1 = _new((n, 16 * C1), z2) if rot is None else rot.buf(rkey + ("g1",), (n, 16 * C1))
             if L <= 32 and (16 * C1) % 4 == 0:
-                g1 = _new((n, 16 * C1), z2)
                 call("mvk_gemm_smallk_amax", ptr(z2), ptr(wp0), ptr(g1), n, 16 * C1, L, 0, ptr(b0), C1, RELU, ptr(a1),
                      stream_ptr())
             else:
-                g1 = gemm(z2, wp0, n, 16 * C1, L, bias=b0, bias_mod=C1, act=RELU)
+                gemm(z2, wp0, n, 16 * C1, L, bias=b0, bias_mod=C1, act=RELU, out=g1)
                 amax_of(g1, a1)
-            g2 = conv_up(g1, wu1, b1, n, 4, 4, C2, C1, RELU, amax=(a1, wu1.mvk_amax, a2))  # [n,8,8,C2]
+            g2 = conv_up(g1, wu1, b1, n, 4, 4, C2, C1, RELU, amax=(a1, wu1.mvk_amax, a2),
+                         out=None if rot is None else rot.buf(rkey + ("g2",), (n, 8, 8, C2)))  # [n,8,8,C2]
             flush_deferred_forward(z2.device)  # a side branch's postponed launches: beside the 64 -> 32 layer, not the 128 -> 64 one
             g3 = conv_up(g2, wu2, b2, n, 8, 8, C3, C2, RELU, amax=(a2, wu2.mvk_amax, a3))  # [n,16,16,C3]
             ctx.wamax = (wd1.mvk_amax, wd2.mvk_amax)
@@ -1725,7 +1916,9 @@ class SVHNDecoderFn(Function):
                     drows = drows * (1.0 / ctx.nll_weight)
             tw3, dw3 = _grad_target(w3)
             tb3, db3 = _grad_target(b3)
-            dg3 = _new((n, 16, 16, C3), z2)
+            rot = ctx.rot if (ctx.rot is not None and rotation(z2.device) is ctx.rot) else None
+            rkey = ("svhn_dec", w0.data_ptr(), n)
+            dg3 = _new((n, 16, 16, C3), z2) if rot is None else rot.buf(rkey + ("dg3",), (n, 16, 16, C3))
             ws = _ws(z2)
             tb2, db2 = _grad_target(b2)
             if ctx.f16:
@@ -1769,28 +1962,50 @@ class SVHNDecoderFn(Function):
             am2 = (a_dg3, ctx.wamax[1] if a_dg3 is not None else None, a_dg2)
             am1 = (a_dg2, ctx.wamax[0], None)
             wam2, wam1 = (a_dg3, ctx.gamax[1]), (a_dg2, ctx.gamax[0])  # (max |U|, max |V|) of the two weight gradients
+        rot = ctx.rot if (ctx.fused and ctx.rot is not None and rotation(z2.device) is ctx.rot) else None
         late = late_leaves(z2.device, dg3, g2, g1, z2)
         if not late.on:
+            rot = None
             dw2 = conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2, amax=wam2)
         if not ctx.small and not ctx.fused:
             db2 = colsum(dg3.view(-1, C3), b2)
         dg2, db1 = conv_down(dg3, wd2, None, n, 8, 8, C3, C2, NONE, v_act_src=g2, v_act=RELU, out_bias=b1,
-                             frag=ctx.frags[1], amax=am2)
+                             frag=ctx.frags[1], amax=am2, out=None if rot is None else rot.buf(rkey + ("dg2",), (n, 8, 8, C2)))
         if not late.on:
             dw1 = conv_wgrad(dg2, g1, w1, n, 4, 4, C2, C1, amax=wam1)
         dg1, db0 = conv_down(dg2, wd1, None, n, 4, 4, C2, C1, NONE, v_act_src=g1, v_act=RELU, out_bias=b0,
-                             frag=ctx.frags[0], amax=am1)
+                             frag=ctx.frags[0], amax=am1, out=None if rot is None else rot.buf(rkey + ("dg1",), (n, 4, 4, C1)))
         dg1f = dg1.view(n, 16 * C1)
         tw0, dw0 = _grad_target(w0)
         dz = None
+        if rot is not None:  # rotated step: the three weight gradients are the head of the next step (Rotation.begin_step)
+            if ctx.needs_input_grad[0]:
+                dz = gemm(dg1f, wp0, n, L, 16 * C1, tb=True).view(ctx.z_shape)
+
+            def leaves():
+                conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2, amax=wam2)
+                conv_wgrad(dg2, g1, w1, n, 4, 4, C2, C1, amax=wam1)
+                wsl = _ws(z2)
+                call("mvk_unflatten_wgrad", ptr(z2), ptr(dg1f), ptr(_grad_target(w0)[0]), n, L, C1, ptr(wsl), wsl.numel(),
+                     stream_ptr())
+
+            def prepare(r):  # behind the update of w0 / w1 / w2: the packs the next forward pass asks for
+                jobs = [(w0, "unflatten"), (w1, True, True), (w2, True, True), (w3, True, False)]
+                for j, o in zip(jobs, _pack_launch(jobs, am=r.slots(len(jobs)))):
+                    r.cache[_job_key(j)] = o
+
+            rot.push(leaves, (w0, w1, w2), prepare)
+            return dz, None, db0, None, db1, None, db2, dw3, db3, None, None, None
         if late.on:  # the backward-data chain first, then the weight gradients beside whatever follows it
             if ctx.needs_input_grad[0]:
                 dz = gemm(dg1f, wp0, n, L, 16 * C1, tb=True).view(ctx.z_shape)
             dg2.record_stream(_side_stream(z2.device, 30))
             dg1.record_stream(_side_stream(z2.device, 30))
             with late:
-                dw2 = conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2, amax=wam2)
-                dw1 = conv_wgrad(dg2, g1, w1, n, 4, 4, C2, C1, amax=wam1)
+                dw2 = dw1 = None
+                if not SKIP_LATE:
+                    dw2 = conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2, amax=wam2)
+                    dw1 = conv_wgrad(dg2, g1, w1, n, 4, 4, C2, C1, amax=wam1)
                 ws = _ws(z2)
                 call("mvk_unflatten_wgrad", ptr(z2), ptr(dg1f), ptr(tw0), n, L, C1, ptr(ws), ws.numel(), stream_ptr())
             if dw0 is not None or dw1 is not None or dw2 is not None:  # a gradient autograd itself accumulates: join now
@@ -2239,9 +2454,24 @@ def _reduce_terms(terms, n_terms, loss_sum_scale, out, loss):
     key = (out.device, torch.cuda.current_stream(out.device).cuda_stream)
     ws = _TERMS_WS.get(key)
     if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            # a workspace made HERE would live in the capturing graph's private pool, zero-filled by a node of that
+            # graph only, and then be handed to every later capture through this cache.  The warm-up passes of GraphedStep run on
+            # another stream than the capture: inside a capture the launch takes the one-workgroup form, which needs no workspace
+            # (same sums in the same order per term; bit-identical results are tested for both forms)
+            call("mvk_reduce_terms", terms, n_terms, loss_sum_scale, ptr(out), ptr(loss), stream_ptr())
+            return
         ws = torch.zeros(1 + 32 * 64, dtype=torch.float32, device=out.device)  # MVK_REDUCE_TERMS_WS_FLOATS
         _TERMS_WS[key] = ws
     call("mvk_reduce_terms_ws", terms, n_terms, loss_sum_scale, ptr(out), ptr(loss), ptr(ws), ws.numel(), stream_ptr())
+
+
+def terms_workspace(device, stream):
+    """Make the assembly's workspace of (device, stream) now, outside any capture (trainers/graph.py: before torch.cuda.graph, for
+    the capture stream and the late-leaf stream the assembly may run on).  Eager memory, zeroed once, left zero by every launch."""
+    key = (device, stream.cuda_stream)
+    if key not in _TERMS_WS and TERMS_MULTI_WG:
+        _TERMS_WS[key] = torch.zeros(1 + 32 * 64, dtype=torch.float32, device=device)
 
 
 class ReconLossFn(Function):

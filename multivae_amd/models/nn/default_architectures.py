@@ -62,6 +62,12 @@ class Decoder_AE_MLP(BaseDecoder):
         out = kernels.MLPDecoderFn.apply(z, l0.weight, l0.bias, l1.weight, l1.bias, self.input_dim)
         return ModelOutput(reconstruction=out)
 
+    def late_leaf_params(self):
+        """The parameters whose gradients are leaves of the backward pass that a rotated step (kernels.Rotation) produces at the
+        head of the NEXT step: trainers.FlatParams keeps them together at the end of its buffers."""
+        l0, l1 = self.layers[0][0], self.layers[1][0]
+        return [l0.weight, l1.weight, l1.bias] if self.depth == 2 else []
+
     def early_work(self, x: torch.Tensor, rows: int):
         """What `reconstruction_nll` needs that does not depend on z — the fp16 pair planes of the output layer's weight and
         the bound of the targets — launched where the caller has an idle stream (MoPoE: the head of the short encoder's

@@ -63,6 +63,12 @@ class Decoder_VAE_SVHN(BaseDecoder):
         d = self.dec
         return [(d[0].weight, "unflatten"), (d[2].weight, True, True), (d[4].weight, True, True), (d[6].weight, True, False)]
 
+    def late_leaf_params(self):
+        """The weights whose gradients are leaves of the backward pass that a rotated step (kernels.Rotation) produces at the
+        head of the NEXT step: trainers.FlatParams keeps them together at the end of its buffers."""
+        d = self.dec
+        return [d[0].weight, d[2].weight, d[4].weight]
+
     def forward(self, z: torch.Tensor):
         d = self.dec
         out = kernels.SVHNDecoderFn.apply(z, d[0].weight, d[0].bias, d[2].weight, d[2].bias, d[4].weight, d[4].bias,

@@ -359,9 +359,13 @@ class BaseTrainer:
         gs = graphs.get(key)
         if gs is None and key not in graphs:
             try:
+                self._drain_rotation()  # a capture warms up with eager passes: nothing may be pending
+                in_graph = bool(cfg.graph_optimizer and not self.distributed)
+                rotate = bool(getattr(cfg, "rotate_step", False) and not self.distributed and not in_graph
+                              and getattr(self.optimizer, "zero_grad_in_step", False))
                 gs = GraphedStep(self.model, self.flat, inputs, noise=None,
                                  capture_error_mode="thread_local" if self.distributed else "global",
-                                 optimizer=self.optimizer if (cfg.graph_optimizer and not self.distributed) else None,
+                                 optimizer=self.optimizer if in_graph else None, rotate=self.optimizer if rotate else None,
                                  overlap=bool(cfg.overlap_collective and self.distributed), **fwd_kwargs)
             except Exception as e:  # not capturable (host sync inside the model, ...): stay eager for this shape
                 logger.warning(f"hipGraph capture failed ({type(e).__name__}: {e}); running this batch shape eagerly")
@@ -369,12 +373,24 @@ class BaseTrainer:
             graphs[key] = gs
         if gs is None:
             return None
+        if self.__dict__.get("_rot_pending") is not gs:
+            self._drain_rotation()  # another graph's (batch shape's) rotated update is pending: apply it first
         out = gs(inputs)
+        if gs.rotated:
+            self._rot_pending = gs
         # what is left of the step: nothing (single GPU: the optimizer is the graph's last node), or the overlapped collective +
         # Adam (data parallel)
         self._graph_tail = (lambda: None) if gs.includes_optimizer else \
             ((lambda: gs.reduce_and_step(self.optimizer)) if (self.distributed and gs.early_ranges) else None)
         return out
+
+    def _drain_rotation(self):
+        """Rotated steps (training_config.rotate_step): apply the update the last replay left pending — before an eager step,
+        a replay of another captured shape, and at the end of an epoch (evaluation, checkpoints and callbacks read the
+        parameters)."""
+        gs = self.__dict__.pop("_rot_pending", None)
+        if gs is not None:
+            gs.drain()
 
     def train_step(self, epoch: int):
         self.callback_handler.on_train_step_begin(training_config=self.training_config, train_loader=self.train_loader,
@@ -397,6 +413,7 @@ class BaseTrainer:
                 else:
                     self._optimizers_step(model_output, backward_done=True)
             else:
+                self._drain_rotation()
                 model_output = self.model(inputs, **fwd_kwargs)
                 self._optimizers_step(model_output)
             loss = model_output.loss_sum if hasattr(model_output, "loss_sum") else model_output.loss
@@ -409,6 +426,7 @@ class BaseTrainer:
             update_dict(epoch_model_metrics, {k: (v.detach() if torch.is_tensor(v) else v)
                                               for k, v in model_output.metrics.items()})
             self.callback_handler.on_train_step_end(training_config=cfg)
+        self._drain_rotation()
         self.model.update()
         if not sync:
             epoch_loss = float(epoch_loss.item())  # the one host sync of the epoch

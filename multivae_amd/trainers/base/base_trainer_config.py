@@ -52,10 +52,17 @@ class BaseTrainerConfig(BaseConfig):
     # the event node alone): off by default, worth trying where the optimizer launch or the collective is a large part of the step
     graph_optimizer: bool = False
     overlap_collective: bool = False
+    # with use_hip_graph, single GPU, FusedAdam(zero_grad_in_step): the ROTATED step (trainers/graph.py, kernels.Rotation) — the
+    # decoders' late weight gradients of step N, their finishes and their share of optimizer.step() run at the head of replay
+    # N + 1 beside the encoders' forward pass; the trainer drains what is pending before anything but another replay reads the
+    # parameters (eager steps of ragged batches, the end of an epoch: evaluation, checkpoints, callbacks).  Exact (parameters
+    # bit for bit those of the sequential loop, tested) and measured SLOWER on the MnistSvhn step on one MI355X (+2 % with the
+    # SVHN decoder's leaves, +7 % with both decoders': the leaves delay the encoders' chain by what they take): off by default
+    rotate_step: bool = False
 
     # the reference's BaseTrainerConfig.from_json_file rejects unknown fields: the extension fields go to a side file
     _EXTENSION_FIELDS = ("use_fused_adam", "sync_every_step", "use_hip_graph", "fused_zero_grad", "graph_optimizer",
-                         "overlap_collective")
+                         "overlap_collective", "rotate_step")
 
     def save_json(self, dir_path, filename):
         """`<filename>.json` holds exactly the reference's fields (loads in either trainer); the multivae_amd switches

@@ -18,16 +18,31 @@ class FlatParams:
         self.params = [p for p in self.all_params if p.requires_grad]
         if not self.params:
             raise ValueError("model has no trainable parameters")
+        # Parameters a module announces as `late_leaf_params()` (the decoders' weights whose gradients a rotated step produces
+        # at the head of the NEXT step: kernels.Rotation) sit together at the END of the buffers, so that the step's two
+        # optimizer launches (everything else / the rotated range) and the two halves of a data-parallel collective are one
+        # contiguous range each.  The layout inside the buffer is private: state dicts and `dense()` go by parameter.
+        late = []
+        for mod in model.modules():
+            announce = getattr(mod, "late_leaf_params", None)
+            if announce is not None:
+                late += [p for p in announce() if p.requires_grad]
+        late_ids = {id(p) for p in late}
         dev = self.params[0].device
         # Every parameter starts on a 256-byte boundary of the buffer.  Densely packed, ONE 3-element bias (the image layer
         # of the SVHN decoder) leaves every parameter behind it 12 bytes off a 16-byte boundary, and the kernels' 16-byte
         # weight loads (`mvk_aligned16` checks in the C layer) silently fall back to their scalar paths for all of them
         # (in `model.parameters()` order that was every encoder of the MnistSvhn models).  The padding stays zero: zero
         # gradient, zero Adam update; the all-reduce carries it along (< 0.1 % of the buffer).
-        self.offsets, off = [], 0
-        for p in self.params:
-            self.offsets.append(off)
-            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        # (`params` / `offsets` stay in model.parameters() order; only the offsets of the late-leaf parameters are at the end)
+        where, off = {}, 0
+        for group in (False, True):
+            for p in self.params:
+                if (id(p) in late_ids) == group:
+                    where[id(p)] = off
+                    off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.offsets = [where[id(p)] for p in self.params]
+        self.late_start = min([where[i] for i in late_ids], default=off)  # first float of the late-leaf parameters
         n = off
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -130,11 +145,22 @@ class FlatParams:
             out.append((pos, self.numel - pos))
         return out
 
-    def ranges_of(self, params):
+    def ranges_of(self, params, strict=False):
         """(offset, padded count) of the given parameters inside the flat buffers, merged where adjacent (a module's parameters
-        are neighbours: one range).  Parameters that are not views of the buffer are ignored."""
+        are neighbours: one range).  Parameters that are not views of the buffer are ignored — or, with strict=True, make the
+        result None (a LATE parameter that cannot be placed must not be classified as early by `complement`; the
+        caller then falls back to one collective over the whole buffer)."""
         pos = {id(p): (off, (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN) for p, off in zip(self.params, self.offsets)}
-        got = sorted(pos[id(p)] for p in params if id(p) in pos)
+        by_ptr = {p.data_ptr(): pos[id(p)] for p in self.params}
+        got = set()
+        for p in params:
+            e = pos.get(id(p)) or by_ptr.get(p.data_ptr())  # a detached / re-wrapped view of the same storage still counts
+            if e is None:
+                if strict:
+                    return None
+                continue
+            got.add(e)
+        got = sorted(got)
         out = []
         for o, n in got:
             if out and out[-1][0] + out[-1][1] == o:
@@ -260,6 +286,11 @@ class FusedAdam(torch.optim.Optimizer):
         self.vmax = torch.zeros_like(flat.flat) if amsgrad else None
         self.step_count = 0
         self._dev_state = self._dev_scalars = self._dev_host = None  # the captured form (prepare_captured / step_captured)
+        # the rotated form (trainers/graph.py GraphedStep(rotate=True)): ranges updated at the head of the NEXT replay
+        self._rot_ranges = None
+        self._rot_main = None
+        self._rot_scalars = None
+        self._rot_dirty = False
 
     # the hyper-parameters live in the parameter group (schedulers write `lr` there)
     def _g(self):
@@ -277,13 +308,67 @@ class FusedAdam(torch.optim.Optimizer):
 
     def step(self, closure=None, grad_scale=1.0):
         loss = closure() if closure is not None else None
+        if self._rot_dirty and not self._rot_armed:
+            raise RuntimeError("FusedAdam.step(): the rotated ranges of the previous replayed step are not updated yet — call "
+                               "GraphedStep.drain() before an eager step")
         self.step_count += 1
         g = self._g()
+        if self._rot_ranges is not None and self._rot_armed:
+            # behind a rotated replay: everything but the rotated ranges now, with the scalars left on the device for the update
+            # of the rotated ranges inside the next replay (or the drain)
+            f = self.flat
+            ranges = self._rot_main or [(0, 0)]
+            for i, (o, n) in enumerate(ranges):
+                _lib.call("mvk_adam_step_pub", _lib.ptr(f.flat[o:o + n]) if n else None, _lib.ptr(f.grad[o:o + n]) if n else None,
+                          _lib.ptr(self.m[o:o + n]) if n else None, _lib.ptr(self.v[o:o + n]) if n else None,
+                          _lib.ptr(self.vmax[o:o + n]) if (self.vmax is not None and n) else None, n, float(g["lr"]),
+                          float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self.step_count,
+                          float(grad_scale), 1 if self.zero_grad_in_step else 0,
+                          _lib.ptr(self._rot_scalars) if i == 0 else None, _lib.stream_ptr())
+            self._rot_dirty, self._rot_armed = True, False
+            self.flat.grads_zero = self.zero_grad_in_step
+            return loss
         kernels.adam_step(self.flat.flat, self.flat.grad, self.m, self.v, self.step_count, float(g["lr"]),
                           float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
                           grad_scale, vmax=self.vmax, zero_grad=self.zero_grad_in_step)
         self.flat.grads_zero = self.zero_grad_in_step
         return loss
+
+    # -- the rotated step (trainers/graph.py): the optimizer in two launches over disjoint ranges, same scalars ------------
+    _rot_armed = False
+
+    def set_rotation(self, ranges):
+        """ranges: (offset, count) of the parameters a rotated GraphedStep updates at the head of its NEXT replay (None: off).
+        step() behind a replay of that graph (`arm_rotation`) then covers the rest and publishes its scalars."""
+        if self._rot_dirty:
+            raise RuntimeError("FusedAdam.set_rotation(): drain the rotated step first")
+        if not ranges:
+            self._rot_ranges = self._rot_main = None
+            return
+        self._rot_ranges = [(int(o), int(n)) for o, n in ranges]
+        self._rot_main = self.flat.complement(self._rot_ranges)
+        if self._rot_scalars is None:
+            self._rot_scalars = torch.zeros(8, dtype=torch.float32, device=self.flat.flat.device)
+            _lib.call("mvk_adam_identity", _lib.ptr(self._rot_scalars), _lib.stream_ptr())
+
+    def arm_rotation(self):
+        """Called by the rotated GraphedStep behind every replay: the next step() is the main part of a rotated update."""
+        self._rot_armed = True
+
+    def rot_update(self):
+        """mvk_adam_step_dev over the rotated ranges with the published scalars, on the current stream (captured at the head of
+        the rotated graph behind the late gradients; eager in the drain).  Identity scalars (before the first step, after a
+        drain) change nothing."""
+        f = self.flat
+        for o, n in self._rot_ranges:
+            _lib.call("mvk_adam_step_dev", _lib.ptr(f.flat[o:o + n]), _lib.ptr(f.grad[o:o + n]), _lib.ptr(self.m[o:o + n]),
+                      _lib.ptr(self.v[o:o + n]), _lib.ptr(self.vmax[o:o + n]) if self.vmax is not None else None, n,
+                      _lib.ptr(self._rot_scalars), 1 if self.zero_grad_in_step else 0, _lib.stream_ptr())
+
+    def rot_drained(self):
+        """Behind an eager rot_update (the drain): the scalars become the identity again, every parameter has seen step_count updates."""
+        _lib.call("mvk_adam_identity", _lib.ptr(self._rot_scalars), _lib.stream_ptr())
+        self._rot_dirty = False
 
     # -- the optimizer inside a replayed hipGraph (trainers/graph.py): scalars in device memory -------------------------
     def sync_device_state(self, grad_scale=1.0):
@@ -324,6 +409,8 @@ class FusedAdam(torch.optim.Optimizer):
         `optimizer.pt`, base_trainer.py:790-793, and reads back in `resume_training`, :413-419): per-parameter
         `step` / `exp_avg` / `exp_avg_sq` (/ `max_exp_avg_sq`) keyed by the parameter's position in
         `model.parameters()`, one param group."""
+        if self._rot_dirty:
+            raise RuntimeError("FusedAdam.state_dict(): the rotated ranges lag one update behind — call GraphedStep.drain() first")
         pos = {id(p): i for i, p in enumerate(self.flat.all_params)}
         state = {}
         for p, off in zip(self.flat.params, self.flat.offsets):

@@ -17,6 +17,12 @@ behind the event — beside the rest of the backward pass —, the remainder beh
 copy batch -> replay || all-reduce(early ranges) -> all-reduce(late ranges) -> adam.  The reference's DDP overlaps its bucket
 reductions with loss.backward() the same way (trainers/base/base_trainer.py:116-117,359).
 
+Rotated (`rotate=optimizer`, single GPU): the decoders' weight-gradient leaves of step N, their finishes and their share of the
+optimizer run at the HEAD of replay N + 1 on a branch of their own, beside the encoders' forward pass (kernels.Rotation); the
+caller's optimizer.step() behind replay N covers everything else and leaves its scalars on the device for that branch.
+`drain()` applies what is pending (end of an epoch, before evaluation / a checkpoint / an eager step); parameters after N
+replays + drain are bit for bit those of N unrotated steps.
+
 Capture needs static shapes and addresses: the batch and the noise are copied into buffers owned by this object;
 a batch of another shape (the last one of an epoch) must go through the eager path.
 """
@@ -35,14 +41,20 @@ _ADAM_PRELUDE = _lib.tune("MVK_ADAM_PRELUDE", "1") != "0"
 
 class GraphedStep:
     def __init__(self, model, flat, inputs, noise=None, warmup=3, capture_error_mode="global", optimizer=None, overlap=False,
-                 **fwd_kwargs):
+                 rotate=None, **fwd_kwargs):
         """optimizer: a FusedAdam(zero_grad_in_step=True) to capture behind the backward pass (single-GPU steps; `includes_optimizer`
         says whether it was).  overlap: record the point where the early part of the gradient buffer is final (data-parallel
-        steps; `reduce_and_step` uses it)."""
+        steps; `reduce_and_step` uses it).  rotate: the FusedAdam the caller steps behind every replay — the decoders' late
+        leaves and their part of the update move to the head of the next replay (`rotated` says whether the model had any)."""
         dev = flat.flat.device
         if dev.type != "cuda":
             raise RuntimeError("GraphedStep needs a GPU")
         self.model, self.flat, self.fwd_kwargs = model, flat, fwd_kwargs
+        if rotate is not None and (optimizer is not None or overlap or not hasattr(rotate, "set_rotation")):
+            raise ValueError("GraphedStep(rotate=...) excludes optimizer= / overlap= and needs a trainers.FusedAdam")
+        self.rot_opt = rotate
+        self.rotation = kernels.Rotation(dev) if rotate is not None else None
+        self.rotated = False
         self.optimizer = optimizer if (optimizer is not None and getattr(optimizer, "zero_grad_in_step", False)
                                        and hasattr(optimizer, "step_captured") and not overlap) else None
         self.includes_optimizer = self.optimizer is not None
@@ -66,11 +78,22 @@ class GraphedStep:
             side = kernels._side_stream(dev, 62)  # a dedicated stream (not one of torch's pooled ones: _lib.new_stream)
             side.wait_stream(cur)
             with torch.cuda.stream(side):  # eager warm-up: fills every cache (scratch, packed masks, autotuned paths)
-                for _ in range(max(int(warmup), 1)):
+                for _ in range(max(int(warmup), 2 if self.rotation is not None else 1)):
                     self.flat.zero_grad()
                     self._body()
+                if self.rotation is not None:  # the leaves the last pass registered stay unapplied: warm-up moves no parameter
+                    self.flat.zero_grad()
             cur.wait_stream(side)
             torch.cuda.synchronize(dev)
+            if self.rotation is not None:
+                ranges = flat.ranges_of(self.rotation.params)
+                if ranges:
+                    self.rot_opt.set_rotation(ranges)
+                    self.rotated = True
+                else:  # nothing in this model registers rotatable leaves: an ordinary captured step
+                    self.rotation = None
+            for st in (cur, kernels._side_stream(dev, 30)):  # the loss assembly's workspace: eager memory, made outside the capture
+                kernels.terms_workspace(dev, st)
             self.graph = torch.cuda.CUDAGraph()
             # (stream priorities were tried: capturing the main branch, or the side branches, on a priority -1 stream
             # makes the replayed step 3.0-3.1 ms instead of 1.9)
@@ -78,8 +101,11 @@ class GraphedStep:
                 self.out = self._body(capture=True)
             op = self.overlap_point
             if op is not None and op.recorded:
-                self.late_ranges = flat.ranges_of(op.late_params)
-                self.early_ranges = flat.complement(self.late_ranges)
+                # strict: a late parameter that is not a view of the flat buffer leaves both None -> one collective behind the replay
+                self.late_ranges = flat.ranges_of(op.late_params, strict=True)
+                self.early_ranges = flat.complement(self.late_ranges) if self.late_ranges else None
+                if not self.early_ranges:
+                    self.early_ranges = self.late_ranges = None
         finally:
             if prof is not None:
                 kernels.PROFILE["recon_nll"] = prof
@@ -102,8 +128,11 @@ class GraphedStep:
             kernels.set_prelude(dev, opt.prepare_captured)  # depends on nothing of the step: head of the first side branch
         if self.overlap_point is not None:
             self.overlap_point.begin()
+        rot = self.rotation
         try:
             with kernels.deferred_reductions(self.flat):
+                if rot is not None:  # the head branch: the previous step's leaves, finishes, update, packs
+                    rot.begin_step(self.rot_opt.rot_update if (capture and self.rotated) else None)
                 out = self.model(self.inputs, **kw)
                 # the registered unit seed: filled once (not one launch per replay), and ReconLossFn.backward launches nothing
                 out.loss.backward(gradient=kernels.unit_seed(out.loss))
@@ -116,6 +145,8 @@ class GraphedStep:
             kernels._PRELUDE.pop(dev, None)
             if self.overlap_point is not None:
                 self.overlap_point.end()
+            if rot is not None:
+                rot.end_step()
         return out
 
     def matches(self, inputs):
@@ -144,7 +175,22 @@ class GraphedStep:
         self.graph.replay()
         if self.optimizer is not None:
             self.optimizer.note_replayed_step()
+        if self.rotated:
+            self.rot_opt.arm_rotation()  # the caller's optimizer.step() covers everything but the rotated ranges
         return self.out
+
+    def drain(self):
+        """Rotated steps only: apply what the last replay left pending — the late leaves of its step, their finishes and the
+        update of the rotated parameters — on the current stream.  Afterwards every parameter (and optimizer moment) has seen
+        the same number of updates; the next replay's head branch finds identity scalars and changes nothing.  Call it before
+        anything but another replay reads the parameters or the optimizer state (evaluation, checkpoint, eager step)."""
+        if not self.rotated or not self.rot_opt._rot_dirty:
+            return
+        with kernels.deferred_reductions(self.flat):
+            self.rotation.run_pending()
+        self.rot_opt.rot_update()
+        self.rot_opt.rot_drained()
+        self.flat.grads_zero = self.rot_opt.zero_grad_in_step
 
     def reduce_and_step(self, optimizer):
         """Data-parallel tail of a replayed step: the gradient collective (overlapped with the end of the backward pass when the

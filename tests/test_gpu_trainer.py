@@ -276,6 +276,80 @@ def test_optimizer_inside_the_graph_matches_the_host_scalar_step(amsgrad):
     assert float(diff.max()) <= 2e-6, float(diff.max())  # 7 steps of <= 1e-3: a ulp of the step size per step at most
 
 
+@pytest.mark.parametrize("amsgrad,which", [(False, "both"), (True, "both"), (False, "svhn"), (False, "mlp")])
+def test_rotated_step_is_bit_identical(amsgrad, which):
+    """GraphedStep(rotate=optimizer) — the decoders' late weight gradients of step N, their ordered finishes,
+    their share of Adam and the weight packs that read them run at the HEAD of replay N + 1 (kernels.Rotation), the caller's
+    optimizer.step() covers the rest and publishes its scalars (mvk_adam_step_pub / mvk_adam_step_dev).  Same noise, same
+    kernels, same scalars: after 7 steps + drain the parameters, both Adam moments (and max_exp_avg_sq) and every loss are
+    BIT FOR BIT those of the unrotated GraphedStep — with a learning-rate change mid-run, a drain + eager step in the middle
+    (the ragged last batch of an epoch), warm-up and capture moving nothing, and the optimizer refusing an eager step or a
+    state_dict while an update is pending.  Decoder rows = 128 x 10: the scaled-fp16 convolution chain and the MLP decoder's
+    fused tail (the two nodes that register rotatable leaves) take the batch."""
+    from multivae_amd import kernels
+    from multivae_amd.data.datasets.base import DatasetOutput
+    from multivae_amd.trainers import FlatParams, FusedAdam, GraphedStep
+
+    d = torch.device("cuda:0")
+    B, K, L = 128, 10, 20
+    g = torch.Generator().manual_seed(11)
+    inputs = DatasetOutput(data=dict(mnist=torch.rand(B, 1, 28, 28, generator=g).to(d), svhn=torch.rand(B, 3, 32, 32, generator=g).to(d)))
+    noise = [torch.randn(K, B, L, generator=g).to(d) for _ in range(7)]
+    old = kernels.ROT_SVHN, kernels.ROT_MLP
+    kernels.ROT_SVHN, kernels.ROT_MLP = which in ("both", "svhn"), which in ("both", "mlp")
+    res = []
+    try:
+        for rotate in (False, True):
+            model = _mnist_svhn_mopoe(d, K=K, L=L)
+            flat = FlatParams(model)
+            opt = FusedAdam(flat, lr=1e-3, amsgrad=amsgrad, zero_grad_in_step=True)
+            before = flat.dense(flat.flat).clone()
+            gs = GraphedStep(model, flat, inputs, noise=torch.zeros(K, B, L, device=d), rotate=opt if rotate else None)
+            assert gs.rotated == rotate
+            assert torch.equal(before, flat.dense(flat.flat)), "warm-up and capture must not move the parameters"
+            if rotate:
+                want = {"both": 6, "svhn": 3, "mlp": 3}[which]
+                assert len(gs.rotation.params) == want and len(opt._rot_ranges) == 1  # one contiguous range at the buffer's end
+                assert opt._rot_ranges[0][0] >= flat.late_start and (which == "mlp" or sum(opt._rot_ranges[0]) == flat.numel)
+            losses = []
+            for i, eps in enumerate(noise):
+                if i == 3:
+                    opt.lr = 3e-4  # a scheduler step
+                if i == 5:  # one eager step in between: the pending update first
+                    if rotate:
+                        with pytest.raises(RuntimeError):
+                            opt.state_dict()
+                        with pytest.raises(RuntimeError):
+                            opt.step()
+                    gs.drain()
+                    opt.zero_grad()
+                    with kernels.deferred_reductions(flat):
+                        out = model(inputs, noise=eps)
+                        out.loss.backward()
+                    opt.step()
+                else:
+                    out = gs(inputs, eps)
+                    opt.step()
+                losses.append(float(out.loss.detach()))
+            gs.drain()
+            gs.drain()  # idempotent
+            torch.cuda.synchronize()
+            assert opt.step_count == len(noise) and flat.grads_zero and float(flat.grad.abs().max()) == 0.0
+            sd = opt.state_dict()
+            assert float(sd["state"][0]["step"]) == len(noise)
+            res.append((losses, flat.dense(flat.flat).cpu().clone(), flat.dense(opt.m).cpu().clone(), flat.dense(opt.v).cpu().clone(),
+                        flat.dense(opt.vmax).cpu().clone() if amsgrad else None))
+    finally:
+        kernels.ROT_SVHN, kernels.ROT_MLP = old
+    (l0, p0, m0, v0, x0), (l1, p1, m1, v1, x1) = res
+    assert l0 == l1, (l0, l1)
+    assert torch.equal(p0, p1), float((p0 - p1).abs().max())
+    assert torch.equal(m0, m1) and torch.equal(v0, v1)
+    if amsgrad:
+        assert torch.equal(x0, x1)
+    assert float((p0 - before.cpu()).abs().max()) > 1e-3  # ... and the run did train
+
+
 @pytest.mark.parametrize("K,B", [(3, 16), (1, 24), (10, 64)])
 def test_fused_decoder_tail_matches_the_generic_path(K, B):
     """MoPoE MnistSvhn with the SVHN decoder scoring its own output (Decoder_VAE_SVHN.reconstruction_nll: Normal NLL row sums and
@@ -444,6 +518,36 @@ def test_trainer_with_hip_graph(tmp_path, model_name, graph_opt):
     assert all(np.isfinite(v) for v in graphed) and graphed[-1] < graphed[0]
     for a, b in zip(eager, graphed):  # same data order and initial weights, different noise stream
         assert abs(a - b) <= 0.05 * abs(a), (eager, graphed)
+
+
+def test_trainer_rotate_step_is_bit_identical(tmp_path):
+    """BaseTrainerConfig.rotate_step (the rotated GraphedStep under the trainer's loop): two epochs of three full batches + a ragged
+    one (captured as a graph of its own: the pending update of the other shape is drained first), a StepLR scheduler, a checkpoint
+    per epoch — the trainer drains before eager steps, shape changes and at the end of every epoch, so the final parameters and
+    optimizer moments are bit for bit those of the run without rotation (same seed: same data order, same device noise)."""
+    from multivae_amd.data.datasets.base import MultimodalBaseDataset
+    from multivae_amd.trainers import BaseTrainer, BaseTrainerConfig
+
+    d = torch.device("cuda:0")
+    res = []
+    for rotate in (False, True):
+        torch.manual_seed(0)
+        torch.cuda.manual_seed(0)
+        n = 128 * 3 + 112
+        ds = MultimodalBaseDataset(data=dict(mnist=torch.rand(n, 1, 28, 28), svhn=torch.rand(n, 3, 32, 32)))
+        model = _mnist_svhn_mopoe(d, K=10, L=20)
+        cfg = BaseTrainerConfig(output_dir=str(tmp_path / str(rotate)), per_device_train_batch_size=128, num_epochs=2,
+                                learning_rate=1e-3, use_hip_graph=True, rotate_step=rotate, steps_saving=1,
+                                scheduler_cls="StepLR", scheduler_params=dict(step_size=1, gamma=0.5))
+        trainer = BaseTrainer(model, train_dataset=ds, training_config=cfg)
+        hist = trainer.train()
+        graphs = [g for g in trainer._graphs.values() if g is not None]
+        assert len(graphs) == 2 and all(g.rotated == rotate for g in graphs)
+        assert trainer.optimizer.step_count == 8 and not trainer.optimizer._rot_dirty
+        res.append(([h["train_epoch_loss"] for h in hist], trainer.flat.dense(trainer.flat.flat).cpu().clone(),
+                    trainer.flat.dense(trainer.optimizer.m).cpu().clone(), trainer.flat.dense(trainer.optimizer.v).cpu().clone()))
+    (l0, p0, m0, v0), (l1, p1, m1, v1) = res
+    assert l0 == l1 and torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1), (l0, l1, float((p0 - p1).abs().max()))
 
 
 def test_cfg4_cfg5_architectures_take_training_steps():
