@@ -423,6 +423,14 @@ int mvk_conv4s2_up_s(const float* V, const float* Wup, const float* bias, float*
                      float* y_amax, float* ws, int64_t ws_floats, const void* wfrag, void* stream);
 int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv,
                       int u_nchw, const float* u_act_src, int u_act, float* ws, int64_t ws_floats, void* stream);
+/* Two of those in ONE launch: the weight gradients of two 4x4 / stride-2 layers of one network at the same batch (the two inner
+ * layers of Encoder_VAE_SVHN, models/nn/svhn.py:19-28, at the training batch, where each is a split-K GEMM of ~35 us on the
+ * step's last dependent chain).  Both problems' workgroups share one grid (igemm_bf_pair_kernel); slabs and ordered finishes are
+ * those of two separate mvk_conv4s2_wgrad launches (bit-identical gradients); shapes the pair launch does not cover run as two
+ * launches.  NHWC U, no fused activation.  */
+int mvk_conv4s2_wgrad_pair(const float* U0, const float* V0, float* dW0, int h0, int w0, int Cu0, int Cv0, const float* U1,
+                           const float* V1, float* dW1, int h1, int w1, int Cu1, int Cv1, int n, float* ws, int64_t ws_floats,
+                           void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution on NHWC activations — the ResNet blocks of models/nn/mmnist.py:214-366 and
  * models/nn/cub.py:144-293.  Y[n,H,W,Cout] = act(conv(X[n,H,W,Cin]) + bias) (* src_act'(y_act_src) elementwise), with

@@ -134,6 +134,7 @@ PROTOTYPES = {
     "mvk_probe_stream_copy": [_p, _p, _i64, _p],
     "mvk_device_rng": [_p, _i64, _p, _i, _f, _f, _p],
     "mvk_conv4s2_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _p],
+    "mvk_conv4s2_wgrad_pair": [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i64, _p],
     "mvk_conv4s2_up_nchw_small": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "mvk_conv4s2_small_up_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "mvk_conv4s2_small_down_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
@@ -298,6 +299,7 @@ GEMM_FLOPS = {
     "mvk_conv4s2_down": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
     "mvk_conv4s2_up": lambda a: 2.0 * a[4] * a[5] * a[6] * 16 * a[7] * a[8],
     "mvk_conv4s2_wgrad": lambda a: 2.0 * a[3] * a[4] * a[5] * 16 * a[6] * a[7],
+    "mvk_conv4s2_wgrad_pair": lambda a: 2.0 * a[14] * 16 * (a[3] * a[4] * a[5] * a[6] + a[10] * a[11] * a[12] * a[13]),
     "mvk_conv3x3": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
     "mvk_conv3x3_y": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],
     "mvk_conv3x3_res": lambda a: 2.0 * a[4] * a[5] * a[6] * 9 * a[7] * a[8],

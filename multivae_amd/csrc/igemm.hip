@@ -365,7 +365,7 @@ static int splitk_target(int t) {
     // 4x4/stride-2 weight gradients at the encoder batch sit on the step's last dependent chain, beside the ordered finish of the
     // decoders' partial sums: 256 workgroups (16 tiles x 16 slices at 64 -> 128 channels, 4 x 64 at 32 -> 64) instead of 768 write a
     // third of the partial tiles and leave the chip to their neighbours — headline 1.0005 -> 0.992 ms, MMVAE MnistSvhn 0.581 ->
-    // 0.548 ms (tools/gpu_r05_k2.sh / _m2.sh; 128 and 192 are slower again)
+    // 0.548 ms (tools/lab/r05/gpu_r05_k2.sh / _m2.sh; 128 and 192 are slower again)
     tc4 = c ? atoi(c) : 256;
     tlin = l ? atoi(l) : t1024;
   }
@@ -1363,28 +1363,9 @@ static int conv3x3_wgrad_any(const float* X, const float* dY, float* dWref, floa
   return launch_splitk(d, ws, ws_floats, 1024, mvk_stream(stream));
 }
 
-static int conv4s2_wgrad_impl(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv,
-                              int u_nchw, const float* u_act_src, int u_act, float* ws, int64_t ws_floats,
-                              const float* u_amax, const float* v_amax, void* stream) {
-  if (!U || !V || !dWref || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0 || (!u_amax != !v_amax)) return MVK_EINVAL;
-  if (u_nchw && !u_act_src && smallcin_supported(Cu, Cv)) {
-    const int rc = smallcin_wgrad(U, V, dWref, n, h, w, Cu, Cv, ws, ws_floats, mvk_stream(stream));
-    if (rc != 1) return rc;  // 1: scratch too small -> the implicit GEMM below
-  }
-  // the output-stationary kernel writes 33.5 MB of per-worker slabs whatever n is: from 1024 images (MVK_IMGWGRAD_MIN for A/B)
-  static const int wg_min = mvk_tune("MVK_IMGWGRAD_MIN") ? atoi(mvk_tune("MVK_IMGWGRAD_MIN")) : 0;
-  const bool wg_ok = wg_min > 0 ? (n >= wg_min && !(g_dbg_flags & 0x100)) : n / 4 >= imgconv_min_images();
-  if (!u_nchw && !u_act_src && ws && wg_ok && mvk_aligned16(U) && mvk_aligned16(V) &&
-      mvk_aligned16(ws)) {
-    int nz = 0;
-    const long long slab_floats = 256ll * 16 * Cu * Cv;
-    float* dslab = defer_scratch(dWref, slab_floats, mvk_stream(stream));
-    const int rc = imgconv_wgrad(U, V, dslab ? dslab : ws, dslab ? slab_floats : ws_floats, n, h, w, Cu, Cv, &nz, u_amax,
-                                 v_amax, mvk_stream(stream));
-    if (rc == MVK_OK) return convref_reduce(dslab ? dslab : ws, nz, Cu, Cv, 16, dWref, mvk_stream(stream), dslab != nullptr);
-    if (rc != 1) return rc;
-  }
-  if (u_amax) return MVK_EINVAL;  // the scaled form exists in the register-stationary kernel only (mvk_conv4s2_wgrad_scaled_ok)
+// the implicit GEMM of a 4x4 / stride-2 weight gradient: dWref[cv][cu][4][4] += sum over positions U(window)^T V
+static GemmDesc conv4s2_wgrad_desc(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv, int u_nchw,
+                                   const float* u_act_src, int u_act) {
   GemmDesc d{};
   d.a = AOperand{};
   d.a.p = U;
@@ -1411,7 +1392,85 @@ static int conv4s2_wgrad_impl(const float* U, const float* V, float* dWref, int 
   d.M = 16 * Cu;
   d.N = Cv;
   d.K = n * h * w;
+  return d;
+}
+
+static int conv4s2_wgrad_impl(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv,
+                              int u_nchw, const float* u_act_src, int u_act, float* ws, int64_t ws_floats,
+                              const float* u_amax, const float* v_amax, void* stream) {
+  if (!U || !V || !dWref || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0 || (!u_amax != !v_amax)) return MVK_EINVAL;
+  if (u_nchw && !u_act_src && smallcin_supported(Cu, Cv)) {
+    const int rc = smallcin_wgrad(U, V, dWref, n, h, w, Cu, Cv, ws, ws_floats, mvk_stream(stream));
+    if (rc != 1) return rc;  // 1: scratch too small -> the implicit GEMM below
+  }
+  // the output-stationary kernel writes 33.5 MB of per-worker slabs whatever n is: from 1024 images (MVK_IMGWGRAD_MIN for A/B)
+  static const int wg_min = mvk_tune("MVK_IMGWGRAD_MIN") ? atoi(mvk_tune("MVK_IMGWGRAD_MIN")) : 0;
+  const bool wg_ok = wg_min > 0 ? (n >= wg_min && !(g_dbg_flags & 0x100)) : n / 4 >= imgconv_min_images();
+  if (!u_nchw && !u_act_src && ws && wg_ok && mvk_aligned16(U) && mvk_aligned16(V) &&
+      mvk_aligned16(ws)) {
+    int nz = 0;
+    const long long slab_floats = 256ll * 16 * Cu * Cv;
+    float* dslab = defer_scratch(dWref, slab_floats, mvk_stream(stream));
+    const int rc = imgconv_wgrad(U, V, dslab ? dslab : ws, dslab ? slab_floats : ws_floats, n, h, w, Cu, Cv, &nz, u_amax,
+                                 v_amax, mvk_stream(stream));
+    if (rc == MVK_OK) return convref_reduce(dslab ? dslab : ws, nz, Cu, Cv, 16, dWref, mvk_stream(stream), dslab != nullptr);
+    if (rc != 1) return rc;
+  }
+  if (u_amax) return MVK_EINVAL;  // the scaled form exists in the register-stationary kernel only (mvk_conv4s2_wgrad_scaled_ok)
+  GemmDesc d = conv4s2_wgrad_desc(U, V, dWref, n, h, w, Cu, Cv, u_nchw, u_act_src, u_act);
   return launch_splitk(d, ws, ws_floats, SPLITK_C4, mvk_stream(stream));
+}
+
+// Two weight gradients of 4x4 / stride-2 layers at a small batch in ONE launch (igemm_bf_pair_kernel): both must take the
+// implicit-GEMM split-K path with the 128 x 64 split-bf16 tile and land in the deferred arena (their ordered finishes are queued
+// like those of two separate launches: same slabs, same sums, bit-identical gradients); anything else = two launches.
+int mvk_conv4s2_wgrad_pair(const float* U0, const float* V0, float* dW0, int h0, int w0, int Cu0, int Cv0, const float* U1,
+                           const float* V1, float* dW1, int h1, int w1, int Cu1, int Cv1, int n, float* ws, int64_t ws_floats,
+                           void* stream) {
+  if (!U0 || !V0 || !dW0 || !U1 || !V1 || !dW1 || n < 0) return MVK_EINVAL;
+  hipStream_t s = mvk_stream(stream);
+  static const bool off = mvk_tune("MVK_WGRAD_PAIR") && atoi(mvk_tune("MVK_WGRAD_PAIR")) == 0;  // A/B: two launches
+  GemmDesc d[2] = {conv4s2_wgrad_desc(U0, V0, dW0, n, h0, w0, Cu0, Cv0, 0, nullptr, MVK_ACT_NONE),
+                   conv4s2_wgrad_desc(U1, V1, dW1, n, h1, w1, Cu1, Cv1, 0, nullptr, MVK_ACT_NONE)};
+  int z[2] = {0, 0};
+  bool ok = !off && engine() == 1 && n > 0 && !(n / 4 >= imgconv_min_images());  // (large batches: the output-stationary kernel)
+  const long long lim = 1ll << 29;
+  for (int i = 0; i < 2 && ok; ++i) {
+    GemmDesc& g = d[i];
+    ok = g.a.vec4 && g.b.vec4 && !g.b.contig_k && g.N > 32 && g.N <= 128 && g.N % 64 == 0 &&
+         (long long)g.a.H * g.a.W * g.a.C * ((long long)g.K / (g.a.OH * g.a.OW) + 1) < lim && (long long)g.K * g.N < lim;
+    if (!ok) break;
+    const int tiles = ((g.M + 127) / 128) * ((g.N + 63) / 64), ktiles = (g.K + BK - 1) / BK;
+    int splits = splitk_target(SPLITK_C4) / tiles;
+    splits = splits < 1 ? 1 : (splits > ktiles ? ktiles : splits);
+    g.zmode = Z_SPLITK;
+    g.ksplit_tiles = (ktiles + splits - 1) / splits;
+    g.ksplit_tiles += g.ksplit_tiles & 1;
+    z[i] = (ktiles + g.ksplit_tiles - 1) / g.ksplit_tiles;
+    ok = z[i] > 1 && (long long)tiles * z[i] >= bf_min_blocks() && defer_free(g.e.out);
+  }
+  if (ok) {
+    float* slab0 = defer_scratch(d[0].e.out, (long long)z[0] * d[0].M * d[0].N, s);
+    float* slab1 = slab0 ? defer_scratch(d[1].e.out, (long long)z[1] * d[1].M * d[1].N, s) : nullptr;
+    if (slab0 && slab1) {
+      d[0].e.ws = slab0;
+      d[1].e.ws = slab1;
+      for (int i = 0; i < 2; ++i) d[i].dbg = g_dbg, d[i].dbg_flags = g_dbg_flags;
+      const unsigned gx0 = (d[0].M + 127) / 128, gy0 = (d[0].N + 63) / 64, gx1 = (d[1].M + 127) / 128, gy1 = (d[1].N + 63) / 64;
+      const unsigned n0 = gx0 * gy0 * z[0], n1 = gx1 * gy1 * z[1];
+      hipLaunchKernelGGL((igemm_bf_pair_kernel<128, 64, AM_COL, BM_N, false, 2>), dim3(n0 + n1), dim3(256), 0, s, d[0], d[1], n0,
+                         gx0, gy0, gx1, gy1);
+      MVK_CHECK_LAUNCH();
+      int rc = defer_push(d[0].e, d[0].M, d[0].N, z[0], (long long)d[0].M * d[0].N);
+      if (rc == MVK_OK) rc = defer_push(d[1].e, d[1].M, d[1].N, z[1], (long long)d[1].M * d[1].N);
+      return rc;
+    }
+    if (slab0) return MVK_EINVAL;  // (the arena took one region and not the other: cannot happen with a sized arena; never silently mix)
+  }
+  int rc = conv4s2_wgrad_impl(U0, V0, dW0, n, h0, w0, Cu0, Cv0, 0, nullptr, MVK_ACT_NONE, ws, ws_floats, nullptr, nullptr, stream);
+  if (rc == MVK_OK)
+    rc = conv4s2_wgrad_impl(U1, V1, dW1, n, h1, w1, Cu1, Cv1, 0, nullptr, MVK_ACT_NONE, ws, ws_floats, nullptr, nullptr, stream);
+  return rc;
 }
 
 int mvk_conv4s2_wgrad(const float* U, const float* V, float* dWref, int n, int h, int w, int Cu, int Cv,

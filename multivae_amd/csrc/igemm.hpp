@@ -165,7 +165,7 @@ __host__ __device__ inline bool epilogue_vec_ok(const Epilogue& E, int N) {
 // ---- shared epilogue -------------------------------------------------------------------------------------------
 template <class T>
 __device__ __forceinline__ void run_epilogue(const GemmDesc& d, f32x16 (&acc)[T::TM][T::TN], float* lds, int tid, int m0,
-                                             int n0, int wm, int wn, int l31, int lhi, int ph, int pw) {
+                                             int n0, int wm, int wn, int l31, int lhi, int ph, int pw, int bz = -1) {
   // ---------------- epilogue ----------------
   // The accumulators of one 32x32 MFMA tile are parked in LDS (one private column per thread, so no
   // barrier is needed) and consumed by a rolled loop: the address / activation code exists once instead of
@@ -173,7 +173,8 @@ __device__ __forceinline__ void run_epilogue(const GemmDesc& d, f32x16 (&acc)[T:
   const Epilogue& E = d.e;
   if (E.ws) {
     // split-K partial: plain coalesced stores of the raw accumulators into this slice's slab
-    float* slab = E.ws + (long long)blockIdx.z * d.M * d.N;
+    // (bz: the split-K slice when the caller's workgroup position is not its blockIdx — igemm_bf_pair_kernel)
+    float* slab = E.ws + (long long)(bz >= 0 ? (unsigned)bz : blockIdx.z) * d.M * d.N;
 #pragma unroll
     for (int a = 0; a < T::TM; ++a) {
 #pragma unroll

@@ -149,8 +149,10 @@ __device__ __forceinline__ void bf_write_pieces(char* base, const unsigned (&pc)
   }
 }
 
+// The kernel's body with the workgroup's position as arguments: igemm_bf_kernel passes its blockIdx, igemm_bf_pair_kernel (two
+// independent problems in ONE grid) the position inside the problem a workgroup belongs to.
 template <int BM, int BN, int AMODE, int BMODE, bool AACT, int DEPTH>
-__global__ __launch_bounds__(256, (BM * BN <= 128 * 32) ? MVK_BF_OCC_SMALL : ((BM * BN <= 128 * 64) ? 3 : 2)) void igemm_bf_kernel(const GemmDesc d) {
+__device__ __forceinline__ void igemm_bf_body(const GemmDesc& d, const unsigned bid_x, const unsigned bid_y, const unsigned bid_z) {
   using T = BfCfg<BM, BN>;
   constexpr int BKT = T::BKT;
   __shared__ __attribute__((aligned(16))) char lds_raw[T::LDS_BYTES];
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 32) ? MVK_BF_OCC_SMALL : ((B
   char* Bs = lds_raw + 3 * T::A_PIECE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / T::WAVES_N, wn = wave % T::WAVES_N;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int m0 = bid_x * BM, n0 = bid_y * BN;
   const int l31 = lane & 31, lhi = lane >> 5;
   const AOperand& A = d.a;
   const BOperand& B = d.b;
@@ -174,11 +176,11 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 32) ? MVK_BF_OCC_SMALL : ((B
   int kbeg = 0, kend = d.K;
   const float* bp = B.p;
   if (d.zmode == Z_PARITY) {
-    ph = blockIdx.z >> 1;
-    pw = blockIdx.z & 1;
-    bp += (long long)blockIdx.z * B.z_stride;
+    ph = bid_z >> 1;
+    pw = bid_z & 1;
+    bp += (long long)bid_z * B.z_stride;
   } else if (d.zmode == Z_SPLITK) {
-    kbeg = blockIdx.z * d.ksplit_tiles * BK;  // launch keeps ksplit_tiles (16-wide) a multiple of 2
+    kbeg = bid_z * d.ksplit_tiles * BK;  // launch keeps ksplit_tiles (16-wide) a multiple of 2
     const int e = kbeg + d.ksplit_tiles * BK;
     kend = e < kend ? e : kend;
     if (kbeg >= kend) return;
@@ -578,7 +580,28 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 32) ? MVK_BF_OCC_SMALL : ((B
 #endif
   float* lds = reinterpret_cast<float*>(lds_raw);
   if (run_epilogue_vec<T, BM, BN, T::LDS_BYTES / 4>(d, acc, lds, tid, m0, n0, wm, wn, l31, lhi, ph, pw)) return;
-  run_epilogue<T>(d, acc, lds, tid, m0, n0, wm, wn, l31, lhi, ph, pw);
+  run_epilogue<T>(d, acc, lds, tid, m0, n0, wm, wn, l31, lhi, ph, pw, (int)bid_z);
+}
+
+template <int BM, int BN, int AMODE, int BMODE, bool AACT, int DEPTH>
+__global__ __launch_bounds__(256, (BM * BN <= 128 * 32) ? MVK_BF_OCC_SMALL : ((BM * BN <= 128 * 64) ? 3 : 2)) void igemm_bf_kernel(const GemmDesc d) {
+  igemm_bf_body<BM, BN, AMODE, BMODE, AACT, DEPTH>(d, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Two independent split-K problems of the same kernel configuration in ONE launch (the two 4x4 / stride-2 weight gradients of the
+// convolutional encoder at the training batch: 256 workgroups each, two dependent launches of ~35 us on the step's last chain;
+// three workgroups fit a CU, so one grid of 512 runs them side by side).  grid.x = n0 + n1 workgroups; the first n0 belong to d0.
+template <int BM, int BN, int AMODE, int BMODE, bool AACT, int DEPTH>
+__global__ __launch_bounds__(256, (BM * BN <= 128 * 32) ? MVK_BF_OCC_SMALL : ((BM * BN <= 128 * 64) ? 3 : 2)) void igemm_bf_pair_kernel(
+    const GemmDesc d0, const GemmDesc d1, const unsigned n0, const unsigned gx0, const unsigned gy0, const unsigned gx1,
+    const unsigned gy1) {
+  unsigned b = blockIdx.x;
+  if (b < n0) {
+    igemm_bf_body<BM, BN, AMODE, BMODE, AACT, DEPTH>(d0, b % gx0, (b / gx0) % gy0, b / (gx0 * gy0));
+  } else {
+    b -= n0;
+    igemm_bf_body<BM, BN, AMODE, BMODE, AACT, DEPTH>(d1, b % gx1, (b / gx1) % gy1, b / (gx1 * gy1));
+  }
 }
 
 }  // namespace mvk

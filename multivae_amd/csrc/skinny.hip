@@ -434,8 +434,14 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const SmallKArgs g) {
   }
   __syncthreads();
   float amax_l = 0.f;
+#ifndef MVK_SK_UNROLL
+#define MVK_SK_UNROLL 1  // rows in flight per thread (a row is ONE dependent chain of K packed FMAs): 4 measured, no difference in the step
+// (0.9735 / 0.9757 / 0.9742 / 0.9795 against 0.9761 / 0.9736 / 0.9772 / 0.9783 ms, tools/gpu_r06_j.sh): the round-5 loop stays
+#endif
   if (active)
-  for (int r = rg; r < R && m0 + r < g.M; r += rgn) {
+#pragma unroll MVK_SK_UNROLL
+  for (int r = rg; r < R; r += rgn) {
+    if (m0 + r >= g.M) continue;
     // packed fp32 FMAs (v_pk_fma_f32: two columns per instruction, the row's x broadcast to both halves): the same FMA chain per
     // column in the same k order, half the vector-ALU instructions of a loop that is bound by them (80 FMAs per 16-byte store)
     typedef float f32x2_ __attribute__((ext_vector_type(2)));

@@ -208,10 +208,16 @@ class OverlapPoint:
 # gradient and the same scalars, before it is next read: the parameters after N steps + a drain are bit for bit those of N
 # unrotated steps (tests/test_gpu_trainer.py).  What a leaf reads must survive into the next replay at a fixed address:
 # `Rotation.buf` hands out persistent buffers, `Rotation.slots` persistent amax slots (zeroed by the branch behind the leaves).
-# MVK_ROT_SVHN / MVK_ROT_MLP = 0: that decoder's leaves stay in the step they belong to (A/B).
-ROT_SVHN = _lib.tune("MVK_ROT_SVHN", "1") != "0"
-ROT_MLP = _lib.tune("MVK_ROT_MLP", "1") != "0"
+# MVK_ROT_SVHN / MVK_ROT_MLP: 0 = that decoder's leaves stay in the step they belong to; 1 = all of its weight-gradient leaves are
+# rotated (the large, register-stationary launches too); 2 = only its FIRST layer's (a split-K GEMM of 10-25 us whose workgroups
+# fit beside anything: the kind of launch the head of the step has room for).
+ROT_SVHN = int(_lib.tune("MVK_ROT_SVHN", "1"))
+ROT_MLP = int(_lib.tune("MVK_ROT_MLP", "1"))
+# MVK_ROT_ARM=1: the head branch forks BEHIND the first launch of the forward pass (so that the main chain is the root chain that is
+# enqueued first); measured slower than forking in front of it (0.955 vs 0.948 ms, three pairs; unrotated 0.938): off
+ROT_ARM = _lib.tune("MVK_ROT_ARM", "0") != "0"
 _ROTATE = {}  # device -> Rotation, while trainers.graph enqueues / captures a rotated step
+_ROTATE_ARMED = {}  # device -> Rotation whose head branch starts behind the forward pass's first launch (Rotation.arm)
 
 
 def rotation(device):
@@ -264,10 +270,27 @@ class Rotation:
     def push(self, fn, params, prepare=None):
         self.leaves.append((fn, tuple(params), prepare))
 
+    def arm(self, update=None):
+        """Inside deferred_reductions, before the forward pass: begin_step(update) will run behind the FIRST launch of the
+        forward pass on the caller's stream (pack_scope's fill of the amax arena), not in front of it — in a captured graph the
+        root chain that is enqueued first gets the launching hardware queue, and that has to be the step's main chain (with the
+        head branch enqueued first the whole forward chain started ~20 us later: profiles/r06_rotated_small_step_timeline.txt)."""
+        self.armed = (update,)
+        _ROTATE_ARMED[self.device] = self
+
+    def begin_if_armed(self):
+        if self.armed is not None:
+            update, = self.armed
+            self.armed = None
+            _ROTATE_ARMED.pop(self.device, None)
+            self.begin_step(update)
+
+    armed = None
+
     def begin_step(self, update=None):
-        """Inside deferred_reductions, before the forward pass: the branch of the previous step's leaves.  update: the closure
-        that applies the optimizer to the rotated parameters (captured passes only; eager warm-up passes leave the parameters
-        alone)."""
+        """Inside deferred_reductions, at the head of the forward pass: the branch of the previous step's leaves.  update: the
+        closure that applies the optimizer to the rotated parameters (captured passes only; eager warm-up passes leave the
+        parameters alone)."""
         cur = torch.cuda.current_stream(self.device)
         st = self.stream
         st.wait_event(cur.record_event())
@@ -304,6 +327,7 @@ class Rotation:
     def end_step(self):
         """Behind the backward pass: the branch is joined (it is, transitively, when a decoder waited for it), the leaves the
         backward pass registered become the next head's."""
+        self.begin_if_armed()  # (a forward pass without a pack_scope never started it)
         _ROTATE.pop(self.device, None)
         if self.open:
             self.wait()
@@ -343,13 +367,39 @@ def orders_behind_loss(rows):
     return isinstance(fn, (MLPDecoderFn._backward_cls, SVHNDecoderFn._backward_cls))
 
 
+_LOSS_POSTPONED = {}  # device -> the assembly launch as a closure, while it waits among the postponed leaves (ReconLossFn, assembly_last)
+# MVK_ASSEMBLY_LAST=0: the assembly launch at the head of the backward pass on the late-leaf stream (the round-5 place; A/B)
+ASSEMBLY_LAST = _lib.tune("MVK_ASSEMBLY_LAST", "1") != "0"
+
+
 def wait_loss(device):
     """Order the current stream behind the loss assembly launch.  Every backward node that READS a gradient buffer the assembly
     fills (the KL rows' gradients, a fused tail's row gradients on its general path) calls this first; nodes that take the
-    constant from `const_grad` do not wait for anything."""
+    constant from `const_grad` do not wait for anything.  An assembly that was postponed to the end of the step (nobody was
+    expected to read what it fills) runs HERE, on the caller's stream, when somebody does."""
+    fn = _LOSS_POSTPONED.pop(device, None)
+    if fn is not None:
+        calls = _LATE_CALLS.get(device, [])
+        calls[:] = [c for c in calls if c[0] is not fn]
+        fn()
+        return
     ev = _LOSS_EVENT.get(device)
     if ev is not None:
         torch.cuda.current_stream(device).wait_event(ev)
+
+
+_CONST_ROWS = {}  # (device, n, value) -> a tensor of n floats holding `value` (made in an eager pass, kept: captured graphs read it)
+
+
+def const_rows(device, n, value):
+    key = (device, int(n), float(value))
+    t = _CONST_ROWS.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None  # never allocate a cached buffer inside a capture (it would live in that graph's pool)
+        t = torch.full((int(n),), float(value), dtype=torch.float32, device=device)
+        _CONST_ROWS[key] = t
+    return t
 
 
 class deferred_reductions:
@@ -397,6 +447,7 @@ class deferred_reductions:
             _DEFER_ACTIVE.discard(dev)
             _LATE_READY.pop(dev, None)
             _LOSS_EVENT.pop(dev, None)  # the late-leaf stream is joined below
+            _LOSS_POSTPONED.pop(dev, None)
             cur = torch.cuda.current_stream(dev)
             for st in dict.fromkeys(_LATE_USED.pop(dev, ())):  # the late leaves (below) and sibling flushes end here
                 if st != cur:
@@ -495,6 +546,8 @@ def _tensors_of(obj):
 # without — every fork / join edge between streams of a captured graph costs more than the ~90 us of leaf work it moves
 # off the chain (third result of this kind).  Off unless MVK_LEAF_STREAM=1.
 LEAF_STREAM = _lib.tune("MVK_LEAF_STREAM", "0") == "1"
+# MVK_WGRAD_PAIR=0: the convolutional encoder's two inner weight gradients as two launches inside the backward-data chain (A/B)
+WGRAD_PAIR = _lib.tune("MVK_WGRAD_PAIR", "1") != "0"
 
 
 class LeafStream:
@@ -836,6 +889,9 @@ class pack_scope:
                 _PACK_SCOPE["amax"], _PACK_SCOPE["amax_pos"] = torch.zeros(512, dtype=torch.float32, device=dev), 0
             if PACK_SIDE and BRANCH_STREAMS and dev is not None and dev.type == "cuda":
                 self._launch_beside(dev)
+        if _ROTATE_ARMED:  # a rotated step's head branch forks HERE, behind the first launch of the main chain
+            for r in list(_ROTATE_ARMED.values()):
+                r.begin_if_armed()
         return self
 
     def _launch_beside(self, dev):
@@ -885,9 +941,14 @@ def pack_weights(jobs):
     sc = _PACK_SCOPE
     keys = [_job_key(j) for j in jobs]
     rot = rotation(jobs[0][0].device)
-    if rot is not None and rot.cache and all(k in rot.cache for k in keys):  # packed by the head branch of a rotated step
-        rot.wait()
-        return [rot.cache[k] for k in keys]
+    if rot is not None and rot.cache:  # some (or all) of them packed by the head branch of a rotated step, behind their update
+        hit = [k in rot.cache for k in keys]
+        if any(hit):
+            rot.wait()
+            if all(hit):
+                return [rot.cache[k] for k in keys]
+            rest = iter(pack_weights([j for j, h in zip(jobs, hit) if not h]))
+            return [rot.cache[k] if h else next(rest) for k, h in zip(keys, hit)]
     if sc is None:
         return _pack_launch(jobs)
     cache = sc["cache"]
@@ -1576,7 +1637,13 @@ class MLPDecoderFn(Function):
             if not (ROT_MLP and rot is not None and LATE_LEAVES and z2.device in _DEFER_ACTIVE
                     and all(_is_direct(t) for t in (w0, w1, b1))):
                 rot = None
-            ctx.rot = rot
+            ctx.rot, ctx.rot_mode = rot, ROT_MLP
+            if rot is not None and ROT_MLP == 2:
+                # mode 2 rotates the first layer's gradient only: z at a fixed address (copied HERE, on this branch's stream: the
+                # late-leaf stream must never wait for a branch stream — hip::Stream::EndCapture recursion, see deferred_reductions)
+                z2 = rot.buf(("mlp_dec", w0.data_ptr(), z2.shape[0], "z"), z2.shape).copy_(z2)
+            if ROT_MLP != 1:
+                rot = None
             rkey = ("mlp_dec", w0.data_ptr(), n)
             nk, nk_inv, kn, kn_inv = dense16_pack(w1)  # both usually done already: Decoder_AE_MLP.early_work
             xam = dense16_xamax(nll_x)
@@ -1657,7 +1724,10 @@ class MLPDecoderFn(Function):
             tb1, db1 = _grad_target(b1)
             tb0, db0 = _grad_target(b0)
             rot = ctx.rot if (ctx.rot is not None and rotation(z2.device) is ctx.rot and dw1 is None and db1 is None) else None
+            rot0 = rot if (rot is not None and ctx.rot_mode == 2) else None
             dh = _new((n, H), z2) if rot is None else rot.buf(("mlp_dec", w0.data_ptr(), n, "dh"), (n, H))
+            if rot0 is not None:
+                rot = None
             call("mvk_dense16_bwd_data", ptr(gp[0]), ptr(gp[1]), ptr(gb), ptr(kn[0]), ptr(kn[1]), ptr(kn_inv), ptr(hp[0]), ptr(dh),
                  ptr(tb0), ptr(ws), ws.numel(), n, H, D, stream_ptr())
             # the gradient of z first (the posterior's backward waits for it), the weight gradients — leaves — behind it
@@ -1683,7 +1753,9 @@ class MLPDecoderFn(Function):
             if dw1 is not None or db1 is not None or not run_last(z2.device, wgrad1, gp, hp, cs, bounds, params=(w1, b1)):
                 wgrad1()
             dw0 = None
-            if not _is_direct(w0) or not run_last(z2.device, lambda: linear_bwd_weight(dh, z2, w0, None), dh, z2, force=LATE_DW0, params=(w0,)):
+            if rot0 is not None:  # mode 2: the first layer's weight gradient is the head of the next step (z2 is the fixed copy)
+                rot0.push(lambda: linear_bwd_weight(dh, z2, w0, None), (w0,), None)
+            elif not _is_direct(w0) or not run_last(z2.device, lambda: linear_bwd_weight(dh, z2, w0, None), dh, z2, force=LATE_DW0, params=(w0,)):
                 dw0, _ = linear_bwd_weight(dh, z2, w0, None)
             return dz, dw0, db0, dw1, db1, None, None, None, None
         else:  # general upstream gradient: d pre = G * drows[column tile, row] / nll_weight as an fp32 tensor, then the tiled engine
@@ -1774,17 +1846,31 @@ class SVHNEncoderFn(Function):
             dh3 = gemm(dmu, wdc1, B, Kf, L, tb=True, c_act_src=h3f, c_act=RELU)
             gemm(dlv, wdc2, B, Kf, L, tb=True, c_act_src=h3f, c_act=RELU, out=dh3, accumulate=True)
         dh3 = dh3.view(B, H // 8, W // 8, ch[3])
-        with lf:
-            dw2 = conv_wgrad(h2, dh3, w2, B, H // 8, W // 8, ch[2], ch[3])
-            if fused is None:
+        # The two inner layers' weight gradients as ONE launch behind both backward-data launches (mvk_conv4s2_wgrad_pair): at the
+        # training batch each is a split-K GEMM of 256 workgroups and ~35 us, and the four launches were one dependent chain
+        # (the step's last one).  Only where both targets are views of the flat gradient buffer inside deferred_reductions (the
+        # pair's slabs live in the arena) and the leaf stream is off.
+        pair = (WGRAD_PAIR and not lf.on and x.device in _DEFER_ACTIVE and _is_direct(w1) and _is_direct(w2)
+                and x.device.type == "cuda")
+        if not pair:
+            with lf:
+                dw2 = conv_wgrad(h2, dh3, w2, B, H // 8, W // 8, ch[2], ch[3])
+        if fused is None:
+            with lf:
                 db2 = colsum(dh3.view(-1, ch[3]), b2)
         # each backward-data launch also emits the bias gradient of the layer it lands in (column sums of its output)
         dh2, db1 = conv_up(dh3, wu2, None, B, H // 8, W // 8, ch[2], ch[3], u_act_src=h2, u_act=RELU, out_bias=b1,
                            frag=ctx.frags[1])
-        with lf:
-            dw1 = conv_wgrad(h1, dh2, w1, B, H // 4, W // 4, ch[1], ch[2])
+        if not pair:
+            with lf:
+                dw1 = conv_wgrad(h1, dh2, w1, B, H // 4, W // 4, ch[1], ch[2])
         dh1, db0 = conv_up(dh2, wu1, None, B, H // 4, W // 4, ch[1], ch[2], u_act_src=h1, u_act=RELU, out_bias=b0,
                            frag=ctx.frags[0])
+        if pair:
+            ws = _ws(x)
+            call("mvk_conv4s2_wgrad_pair", ptr(h2), ptr(dh3), ptr(_grad_target(w2)[0]), H // 8, W // 8, ch[2], ch[3],
+                 ptr(h1), ptr(dh2), ptr(_grad_target(w1)[0]), H // 4, W // 4, ch[1], ch[2], B, ptr(ws), ws.numel(), stream_ptr())
+            dw2 = dw1 = None
         with lf:
             dw0 = conv_wgrad(x, dh1, w0, B, H // 2, W // 2, ch[0], ch[1], u_nchw=True)
         lf.join()
@@ -1836,7 +1922,9 @@ class SVHNDecoderFn(Function):
         if not (ROT_SVHN and rot is not None and f16 and nll_x is not None and LATE_LEAVES and z2.device in _DEFER_ACTIVE
                 and all(_is_direct(t) for t in (w0, w1, w2))):
             rot = None
-        ctx.rot = rot
+        ctx.rot, ctx.rot_mode = rot, ROT_SVHN
+        if ROT_SVHN != 1:
+            rot = None  # mode 2 rotates the first layer's gradient only: nothing of the forward pass needs a fixed address
         rkey = ("svhn_dec", w0.data_ptr(), n)
         if rot is not None:
             z2 = rot.buf(rkey + ("z",), z2.shape).copy_(z2)
@@ -1916,7 +2004,7 @@ class SVHNDecoderFn(Function):
                     drows = drows * (1.0 / ctx.nll_weight)
             tw3, dw3 = _grad_target(w3)
             tb3, db3 = _grad_target(b3)
-            rot = ctx.rot if (ctx.rot is not None and rotation(z2.device) is ctx.rot) else None
+            rot = ctx.rot if (ctx.rot is not None and ctx.rot_mode == 1 and rotation(z2.device) is ctx.rot) else None
             rkey = ("svhn_dec", w0.data_ptr(), n)
             dg3 = _new((n, 16, 16, C3), z2) if rot is None else rot.buf(rkey + ("dg3",), (n, 16, 16, C3))
             ws = _ws(z2)
@@ -1963,9 +2051,12 @@ class SVHNDecoderFn(Function):
             am1 = (a_dg2, ctx.wamax[0], None)
             wam2, wam1 = (a_dg3, ctx.gamax[1]), (a_dg2, ctx.gamax[0])  # (max |U|, max |V|) of the two weight gradients
         rot = ctx.rot if (ctx.fused and ctx.rot is not None and rotation(z2.device) is ctx.rot) else None
+        rot0 = rot if (rot is not None and ctx.rot_mode == 2) else None  # mode 2: only the first layer's weight gradient
+        if rot0 is not None:
+            rot = None
         late = late_leaves(z2.device, dg3, g2, g1, z2)
         if not late.on:
-            rot = None
+            rot = rot0 = None
             dw2 = conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2, amax=wam2)
         if not ctx.small and not ctx.fused:
             db2 = colsum(dg3.view(-1, C3), b2)
@@ -1973,8 +2064,9 @@ class SVHNDecoderFn(Function):
                              frag=ctx.frags[1], amax=am2, out=None if rot is None else rot.buf(rkey + ("dg2",), (n, 8, 8, C2)))
         if not late.on:
             dw1 = conv_wgrad(dg2, g1, w1, n, 4, 4, C2, C1, amax=wam1)
-        dg1, db0 = conv_down(dg2, wd1, None, n, 4, 4, C2, C1, NONE, v_act_src=g1, v_act=RELU, out_bias=b0,
-                             frag=ctx.frags[0], amax=am1, out=None if rot is None else rot.buf(rkey + ("dg1",), (n, 4, 4, C1)))
+        rany = rot if rot is not None else rot0
+        dg1, db0 = conv_down(dg2, wd1, None, n, 4, 4, C2, C1, NONE, v_act_src=g1, v_act=RELU, out_bias=b0, frag=ctx.frags[0],
+                             amax=am1, out=None if rany is None else rany.buf(("svhn_dec", w0.data_ptr(), n, "dg1"), (n, 4, 4, C1)))
         dg1f = dg1.view(n, 16 * C1)
         tw0, dw0 = _grad_target(w0)
         dz = None
@@ -2006,8 +2098,24 @@ class SVHNDecoderFn(Function):
                 if not SKIP_LATE:
                     dw2 = conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2, amax=wam2)
                     dw1 = conv_wgrad(dg2, g1, w1, n, 4, 4, C2, C1, amax=wam1)
-                ws = _ws(z2)
-                call("mvk_unflatten_wgrad", ptr(z2), ptr(dg1f), ptr(tw0), n, L, C1, ptr(ws), ws.numel(), stream_ptr())
+                if rot0 is not None:
+                    # mode 2: the first layer's weight gradient (a split-K GEMM over z and dg1) is the head of the next step; z is
+                    # copied to a buffer with a fixed address HERE, on the late-leaf stream (off the backward chain)
+                    zp = rot0.buf(("svhn_dec", w0.data_ptr(), n, "z"), z2.shape).copy_(z2)
+
+                    def leaf0():
+                        wsl = _ws(zp)
+                        call("mvk_unflatten_wgrad", ptr(zp), ptr(dg1f), ptr(_grad_target(w0)[0]), n, L, C1, ptr(wsl), wsl.numel(),
+                             stream_ptr())
+
+                    def prepare0(r):  # behind the update of w0: its pack for the next forward pass
+                        job = (w0, "unflatten")
+                        r.cache[_job_key(job)] = _pack_launch([job])[0]
+
+                    rot0.push(leaf0, (w0,), prepare0)
+                else:
+                    ws = _ws(z2)
+                    call("mvk_unflatten_wgrad", ptr(z2), ptr(dg1f), ptr(tw0), n, L, C1, ptr(ws), ws.numel(), stream_ptr())
             if dw0 is not None or dw1 is not None or dw2 is not None:  # a gradient autograd itself accumulates: join now
                 torch.cuda.current_stream(z2.device).wait_stream(_side_stream(z2.device, 30))
             return dz, dw0, db0, dw1, db1, dw2, db2, dw3, db3, None, None, None
@@ -2313,15 +2421,22 @@ class MoPoEPosteriorFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dz, dkld_rows, *unused):
-        wait_loss(ctx.saved_tensors[0].device)  # the gradients of the KL rows come out of the loss assembly launch
-        late_ready(ctx.saved_tensors[0].device)
+        dev = ctx.saved_tensors[0].device
+        # the gradient of the KL rows: ONE constant the host knows when the loss node registered it (const_grad: the unit-seed
+        # path) — read from a kept buffer of that constant, and the assembly launch has no reader inside the step; else it comes
+        # out of the assembly launch, which this node then waits for (or runs, when it was postponed)
+        c = const_grad(dkld_rows) if dkld_rows is not None else None
+        gk = const_rows(dev, dkld_rows.numel(), c) if c is not None else None
+        if gk is None:
+            wait_loss(dev)
+            gk = _c(dkld_rows) if dkld_rows is not None else None
+        late_ready(dev)
         saved = ctx.saved_tensors
         eps, subset_masks, sel = saved[:3]
         M = ctx.M
         mus, lvs = saved[3 : 3 + M], saved[3 + M :]
         K, B, L = eps.shape
         dz = _c(dz) if dz is not None else torch.zeros_like(eps)
-        gk = _c(dkld_rows) if dkld_rows is not None else None
         dmus = [_new((B, L), eps) for _ in range(M)]
         dlvs = [_new((B, L), eps) for _ in range(M)]
         defer_flush_side(eps.device)  # the decoders are done: finish their gradients beside the encoder backward
@@ -2573,7 +2688,27 @@ class ReconLossFn(Function):
         # step — nothing on the backward chain needs the loss VALUE — so it runs on the late-leaf stream, joined where the
         # deferred finishes run, instead of between the last forward and the first backward launch of the critical chain.
         late = late_leaves(ref.device, *extras) if (ASYNC_LOSS and n_rec == 0 and spec.get("async_ok")) else None
-        if late is not None and late.on:
+        dev = ref.device
+        if late is not None and late.on and ASSEMBLY_LAST and spec.get("assembly_last") and dev in _DEFER_ACTIVE:
+            # The model vouches that NO backward node reads what this launch fills when the backward seed is the unit seed (its
+            # posterior node takes the KL rows' constant gradient from const_grad): the launch is enqueued with the postponed
+            # leaves at the end of the scope (run_last: the late-leaf stream, behind the large decoder's weight gradients) instead
+            # of at the head of the backward pass, where its 18 workgroups wait 50-80 us for slots beside the image layer's 512
+            # persistent workgroups — and delay them.  A node that does read (general seed, style latents) runs it first: wait_loss.
+            keep = [out, loss] + [d for d in dextras if d is not None]
+
+            def assemble():
+                _LOSS_POSTPONED.pop(dev, None)
+                _reduce_terms(terms, n_terms, spec["loss_sum_scale"], out, loss)
+                st = torch.cuda.current_stream(dev)
+                for t in keep:
+                    t.record_stream(st)
+
+            if run_last(dev, assemble, *extras, force=True):
+                _LOSS_POSTPONED[dev] = assemble
+            else:
+                assemble()
+        elif late is not None and late.on:
             # (postponing this launch behind the image layer's backward kernel — it competes with that kernel's persistent
             # workgroups for CU slots at the head of the backward pass — was measured: +60 us per step, the ninth cross-stream
             # edge inside the captured step that lost; profiles/NOTES_r05.md section 9)

@@ -250,7 +250,10 @@ class MoPoE(BaseMultiVAE):
                     # behind the assembly launch where they read what it fills: it may run beside the backward chain
                     # — only when every fused term's node is one of the package's (kernels.orders_behind_loss): a user decoder's
                     # `reconstruction_nll` built from plain autograd ops would read the row gradients unordered
-                    async_ok=masks is None and all(kernels.orders_behind_loss(rec[m][1]) for m in fused))
+                    async_ok=masks is None and all(kernels.orders_behind_loss(rec[m][1]) for m in fused),
+                    # ... and with the unit seed nothing reads what it fills: the posterior node takes the KL rows' constant
+                    # gradient from the host (kernels.const_grad), the fused tails theirs — the launch may run LAST
+                    assembly_last=masks is None and not style_kl)
         if style_kl and masks is not None:  # style_kld *= mask (:217-218), still averaged over the whole batch
             style_kl = [kl * masks[m].to(kl.dtype) for kl, m in zip(style_kl, names)]
         loss, terms = kernels.ReconLossFn.apply(spec, M, *recons, kld_rows, *style_kl, *[rec[m][1] for m in fused])

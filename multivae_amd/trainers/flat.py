@@ -22,12 +22,17 @@ class FlatParams:
         # at the head of the NEXT step: kernels.Rotation) sit together at the END of the buffers, so that the step's two
         # optimizer launches (everything else / the rotated range) and the two halves of a data-parallel collective are one
         # contiguous range each.  The layout inside the buffer is private: state dicts and `dense()` go by parameter.
-        late = []
+        late_first, late_rest = [], []  # per announcing module: its FIRST entry (by convention the first layer's weight, the
+        # one a rotation of the small leaves only moves) / the others; the first entries sit at the very end, together
         for mod in model.modules():
             announce = getattr(mod, "late_leaf_params", None)
             if announce is not None:
-                late += [p for p in announce() if p.requires_grad]
-        late_ids = {id(p) for p in late}
+                ps = [p for p in announce() if p.requires_grad]
+                late_first += ps[:1]
+                late_rest += ps[1:]
+        group = {id(p): 1 for p in late_rest}
+        group.update({id(p): 2 for p in late_first})
+        late_ids = set(group)
         dev = self.params[0].device
         # Every parameter starts on a 256-byte boundary of the buffer.  Densely packed, ONE 3-element bias (the image layer
         # of the SVHN decoder) leaves every parameter behind it 12 bytes off a 16-byte boundary, and the kernels' 16-byte
@@ -36,9 +41,9 @@ class FlatParams:
         # gradient, zero Adam update; the all-reduce carries it along (< 0.1 % of the buffer).
         # (`params` / `offsets` stay in model.parameters() order; only the offsets of the late-leaf parameters are at the end)
         where, off = {}, 0
-        for group in (False, True):
+        for g in (0, 1, 2):
             for p in self.params:
-                if (id(p) in late_ids) == group:
+                if group.get(id(p), 0) == g:
                     where[id(p)] = off
                     off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.offsets = [where[id(p)] for p in self.params]
@@ -110,7 +115,9 @@ class FlatParams:
         if comm is None:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
             return 1.0 / world
-        nseg = max(1, min(64, (self.grad.numel() + self.SEG_FLOATS - 1) // self.SEG_FLOATS))
+        # one call up to 8 MB (the MnistSvhn models' 6.2 MB): with one rank every segment is a launch of its own (RCCL's
+        # oneRankReduce, 5 us each: profiles/r06_dp1_timeline.txt), and a ring over xGMI pipelines a call of this size internally
+        nseg = 1 if self.grad.numel() <= 4 * self.SEG_FLOATS else max(1, min(64, (self.grad.numel() + self.SEG_FLOATS - 1) // self.SEG_FLOATS))
         _lib.call("mvk_allreduce_avg", _lib.ptr(self.grad), self.grad.numel(), nseg, comm, _lib.stream_ptr())
         return 1.0
 

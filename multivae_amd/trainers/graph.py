@@ -132,7 +132,7 @@ class GraphedStep:
         try:
             with kernels.deferred_reductions(self.flat):
                 if rot is not None:  # the head branch: the previous step's leaves, finishes, update, packs
-                    rot.begin_step(self.rot_opt.rot_update if (capture and self.rotated) else None)
+                    (rot.arm if kernels.ROT_ARM else rot.begin_step)(self.rot_opt.rot_update if (capture and self.rotated) else None)
                 out = self.model(self.inputs, **kw)
                 # the registered unit seed: filled once (not one launch per replay), and ReconLossFn.backward launches nothing
                 out.loss.backward(gradient=kernels.unit_seed(out.loss))

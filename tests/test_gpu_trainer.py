@@ -276,7 +276,7 @@ def test_optimizer_inside_the_graph_matches_the_host_scalar_step(amsgrad):
     assert float(diff.max()) <= 2e-6, float(diff.max())  # 7 steps of <= 1e-3: a ulp of the step size per step at most
 
 
-@pytest.mark.parametrize("amsgrad,which", [(False, "both"), (True, "both"), (False, "svhn"), (False, "mlp")])
+@pytest.mark.parametrize("amsgrad,which", [(False, "both"), (True, "both"), (False, "svhn"), (False, "mlp"), (False, "small"), (True, "small")])
 def test_rotated_step_is_bit_identical(amsgrad, which):
     """GraphedStep(rotate=optimizer) — the decoders' late weight gradients of step N, their ordered finishes,
     their share of Adam and the weight packs that read them run at the HEAD of replay N + 1 (kernels.Rotation), the caller's
@@ -296,7 +296,8 @@ def test_rotated_step_is_bit_identical(amsgrad, which):
     inputs = DatasetOutput(data=dict(mnist=torch.rand(B, 1, 28, 28, generator=g).to(d), svhn=torch.rand(B, 3, 32, 32, generator=g).to(d)))
     noise = [torch.randn(K, B, L, generator=g).to(d) for _ in range(7)]
     old = kernels.ROT_SVHN, kernels.ROT_MLP
-    kernels.ROT_SVHN, kernels.ROT_MLP = which in ("both", "svhn"), which in ("both", "mlp")
+    # which leaves are rotated: every weight-gradient leaf of both decoders / of one of them / only the two first-layer ones ("small")
+    kernels.ROT_SVHN, kernels.ROT_MLP = {"both": (1, 1), "svhn": (1, 0), "mlp": (0, 1), "small": (2, 2)}[which]
     res = []
     try:
         for rotate in (False, True):
@@ -308,9 +309,10 @@ def test_rotated_step_is_bit_identical(amsgrad, which):
             assert gs.rotated == rotate
             assert torch.equal(before, flat.dense(flat.flat)), "warm-up and capture must not move the parameters"
             if rotate:
-                want = {"both": 6, "svhn": 3, "mlp": 3}[which]
-                assert len(gs.rotation.params) == want and len(opt._rot_ranges) == 1  # one contiguous range at the buffer's end
-                assert opt._rot_ranges[0][0] >= flat.late_start and (which == "mlp" or sum(opt._rot_ranges[0]) == flat.numel)
+                want = {"both": 6, "svhn": 3, "mlp": 3, "small": 2}[which]
+                assert len(gs.rotation.params) == want and all(o >= flat.late_start for o, _ in opt._rot_ranges)
+                if which in ("both", "small"):  # one contiguous range at the very end of the buffer: two optimizer launches per step
+                    assert len(opt._rot_ranges) == 1 and sum(opt._rot_ranges[0]) == flat.numel
             losses = []
             for i, eps in enumerate(noise):
                 if i == 3:
