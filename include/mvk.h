@@ -351,6 +351,10 @@ int mvk_gemm(const float* A, const float* B, float* C, int M, int N, int K, int 
  * p1 = bf16(x - p0), p2 = bf16(x - p0 - p1) (round to nearest); stored as three planes of n bf16 values,
  * plane i at byte offset i * 2 * n.  A producer writes it once; every consuming GEMM saves the per-k-tile split. */
 #define MVK_FMT_IN_BF3 1
+/* mvk_conv4s2_up only: take the tiled engine (three resident workgroups of <= 128 registers per SIMD) even where the
+ * register-stationary kernel (one 512-register wave per SIMD) covers the shape — for a launch that has to run BESIDE such a
+ * kernel of another stream instead of behind it (the convolutional encoder's backward-data launches in the step's tail). */
+#define MVK_FMT_TILED 2
 int mvk_f32_to_bf3(const float* x, int64_t n, void* planes, void* stream);
 int mvk_bf3_to_f32(const void* planes, int64_t n, float* x, void* stream);
 

@@ -1050,7 +1050,7 @@ static int conv4s2_up_impl(const float* V, const float* Wup, const float* bias, 
   if (!V || !Wup || !U || n < 0 || h <= 0 || w <= 0 || Cu <= 0 || Cv <= 0 || (colsum_acc && u_nchw) || (!x_amax != !w_amax))
     return MVK_EINVAL;
   const bool wants_rs = x_amax || y_amax;
-  if (fmt & ~MVK_FMT_IN_BF3) return MVK_EINVAL;
+  if (fmt & ~(MVK_FMT_IN_BF3 | MVK_FMT_TILED)) return MVK_EINVAL;
   if (!u_nchw && fmt == 0 && n >= imgconv_min_images() && imgconv_act_ok(act) && imgconv_act_ok(u_act) &&
       (!colsum_acc || (ws && ws_floats >= 256 * (int64_t)Cu)) && mvk_aligned16(V)) {
     int rows = 0;
@@ -1465,7 +1465,16 @@ int mvk_conv4s2_wgrad_pair(const float* U0, const float* V0, float* dW0, int h0,
       if (rc == MVK_OK) rc = defer_push(d[1].e, d[1].M, d[1].N, z[1], (long long)d[1].M * d[1].N);
       return rc;
     }
-    if (slab0) return MVK_EINVAL;  // (the arena took one region and not the other: cannot happen with a sized arena; never silently mix)
+    if (slab0) {
+      // the arena (still growing in the first steps of a process) had room for the first region only: two launches, the first
+      // into the region it was granted, the second on whatever path mvk_conv4s2_wgrad takes without one
+      d[0].e.ws = slab0;
+      int rc = launch_igemm(d[0], z[0], s);
+      if (rc == MVK_OK) rc = defer_push(d[0].e, d[0].M, d[0].N, z[0], (long long)d[0].M * d[0].N);
+      if (rc == MVK_OK)
+        rc = conv4s2_wgrad_impl(U1, V1, dW1, n, h1, w1, Cu1, Cv1, 0, nullptr, MVK_ACT_NONE, ws, ws_floats, nullptr, nullptr, stream);
+      return rc;
+    }
   }
   int rc = conv4s2_wgrad_impl(U0, V0, dW0, n, h0, w0, Cu0, Cv0, 0, nullptr, MVK_ACT_NONE, ws, ws_floats, nullptr, nullptr, stream);
   if (rc == MVK_OK)

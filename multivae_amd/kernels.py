@@ -448,6 +448,7 @@ class deferred_reductions:
             _LATE_READY.pop(dev, None)
             _LOSS_EVENT.pop(dev, None)  # the late-leaf stream is joined below
             _LOSS_POSTPONED.pop(dev, None)
+            _BIG_LATE.discard(dev)
             cur = torch.cuda.current_stream(dev)
             for st in dict.fromkeys(_LATE_USED.pop(dev, ())):  # the late leaves (below) and sibling flushes end here
                 if st != cur:
@@ -548,6 +549,10 @@ def _tensors_of(obj):
 LEAF_STREAM = _lib.tune("MVK_LEAF_STREAM", "0") == "1"
 # MVK_WGRAD_PAIR=0: the convolutional encoder's two inner weight gradients as two launches inside the backward-data chain (A/B)
 WGRAD_PAIR = _lib.tune("MVK_WGRAD_PAIR", "1") != "0"
+# MVK_ENC_BWD_TILED (bit 0: the 64 <- 128 layer, bit 1: the 32 <- 64 layer): the convolutional encoder's backward-data launches on
+# the tiled engine when register-stationary late leaves of a decoder are in flight (big_late_leaves): a 512-register workgroup
+# waits for a CU those leaves have left, <= 128-register ones run beside them
+ENC_BWD_TILED = int(_lib.tune("MVK_ENC_BWD_TILED", "0"))
 
 
 class LeafStream:
@@ -610,7 +615,8 @@ def wait_tail_bwd(device):
 # decoder (4 workgroup types, 2-2.5x fabric traffic of its own) far more than its 64 <-> 32-channel one.  MEASURED (three same-box
 # pairs): 1.060 / 1.034 / 1.048 ms postponed behind the first convolution vs 1.047 / 1.051 / 1.042 ms launched where the node is
 # created — no difference in the forward pass; MVK_FWD_DEFER=1 enables it.
-FWD_DEFER = _lib.tune("MVK_FWD_DEFER", "0") == "1"
+FWD_DEFER_AT = int(_lib.tune("MVK_FWD_DEFER", "0"))  # 1: behind the 128 -> 64 layer; 2: behind the 64 -> 32 layer; 3: behind the fused tail
+FWD_DEFER = FWD_DEFER_AT > 0
 _FWD_DEFERRED = {}  # device -> [(stream, closure)], only while run_branches(side_first=True) builds the side branches
 _FWD_DEFER_OPEN = set()
 
@@ -800,7 +806,28 @@ HEADS_BWD = _lib.tune("MVK_HEADS_BWD", "1") != "0"  # A/B switch: the heads' bac
 # critical one and the fused launch delays the other stream's kernels).  RE-MEASURED at the end of round 2, with the partial
 # finish on the sibling stream and a replayed graph that now spreads over three hardware queues: 1.2480 ms with the fused launch
 # for the MLP encoder too vs 1.2569 ms without (four same-box pairs) — on by default now, MVK_HEADS_BWD_MLP=0 disables.
-HEADS_BWD_MLP = _lib.tune("MVK_HEADS_BWD_MLP", "1") != "0"
+# RE-MEASURED in round 6, with the loss assembly at the end of the step and the convolutional encoder's weight-gradient pair: at the
+# headline (K = 10: the large decoder's register-stationary weight gradients are late leaves of the tail, one 512-register wave
+# per SIMD on every CU) the six separate launches for the MLP encoder are ahead again — 0.9262 / 0.9299 / 0.9272 ms against
+# 0.9407 / 0.9370 / 0.9361 with the fused launch, second box 0.9565 / 0.9615 / 0.9606 against 0.9638 / 0.9713 / 0.9708, third
+# 0.9487 / 0.9558 / 0.9508 against 0.9574 / 0.9612 / 0.9587 (-0.9 %, nine alternating pairs: the fused launch's 128 x 4
+# workgroups with 48-62 KB of LDS wait for room beside those leaves) — while WITHOUT such leaves (decoder batch < 1024 rows:
+# MMVAE MnistSvhn 0.516 / 0.533 fused against 0.560 / 0.559, MoPoE at K = 1 0.509 / 0.521 against 0.537 / 0.540) the fused launch
+# wins by 5-8 %.  "auto" (default): fused unless a backward node of this scope enqueued register-stationary late leaves
+# (big_late_leaves); MVK_HEADS_BWD_MLP=0 / 1 force one form.
+_HEADS_BWD_MLP_MODE = _lib.tune("MVK_HEADS_BWD_MLP", "auto")
+_BIG_LATE = set()  # devices on which a backward node of the open deferred_reductions scope enqueued register-stationary late leaves
+
+
+def big_late_leaves(device):
+    _BIG_LATE.add(device)
+
+
+def heads_bwd_mlp(device):
+    """Whether an MLP encoder's heads take the one-launch backward now."""
+    if _HEADS_BWD_MLP_MODE in ("0", "1"):
+        return _HEADS_BWD_MLP_MODE == "1"
+    return device not in _BIG_LATE
 
 
 def heads_bwd(x, x_act, dys, ws_, bs, w_sk, w_sn, flat_c=0, want_dx=True, prev_bias=None, dw_params=None):
@@ -1067,8 +1094,11 @@ def conv_down(U, wdown, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src
     return V if out_bias is None else (V, rb)
 
 
+FMT_TILED = 2  # mvk.h MVK_FMT_TILED
+
+
 def conv_up(V, wup, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src=None, u_act=NONE, out_bias=None,
-            in_bf3=False, frag=None, amax=None, out=None):
+            in_bf3=False, frag=None, amax=None, out=None, tiled=False):
     U = out if out is not None else torch.empty((n, Cu, 2 * h, 2 * w) if u_nchw else (n, 2 * h, 2 * w, Cu), dtype=torch.float32,
                                                 device=V.device)
     ws = _ws(U)
@@ -1081,7 +1111,7 @@ def conv_up(V, wup, bias, n, h, w, Cu, Cv, act=NONE, u_nchw=False, u_act_src=Non
              stream_ptr())
         return U if out_bias is None else (U, rb)
     call("mvk_conv4s2_up", ptr(V), ptr(wup), ptr(bias), ptr(U), n, h, w, Cu, Cv, act, int(u_nchw),
-         ptr(u_act_src), u_act, ptr(tb), ptr(ws), ws.numel(), FMT_IN_BF3 if in_bf3 else 0,
+         ptr(u_act_src), u_act, ptr(tb), ptr(ws), ws.numel(), (FMT_IN_BF3 if in_bf3 else 0) | (FMT_TILED if tiled else 0),
          ptr(frag if frag is not None else wfrag(wup)), stream_ptr())
     return U if out_bias is None else (U, rb)
 
@@ -1434,7 +1464,7 @@ class MLPEncoderFn(Function):
         # both heads in one launch: weight / bias gradients, the gradient w.r.t. the last hidden layer's PRE-activation
         # (ReLU' applied) and, with hidden layers, that layer's bias gradient
         fused = heads_bwd(h, prev_act, [dmu, dlv], [we, wl], [be, bl], 1, h.shape[1], want_dx=n > 0 or need_dx,
-                          prev_bias=params[2 * n - 1] if n > 0 else None) if we.shape == wl.shape and HEADS_BWD_MLP else None
+                          prev_bias=params[2 * n - 1] if n > 0 else None) if we.shape == wl.shape and heads_bwd_mlp(h.device) else None
         if fused is not None:
             dh, (grads[-4], grads[-2]), (grads[-3], grads[-1]), gprev = fused
             if n > 0:
@@ -1494,7 +1524,7 @@ class MLPHeadsFn(Function):
         need_dx = ctx.needs_input_grad[0]
         dh = None
         fused = None
-        if HEADS_BWD_MLP and nh <= 2 and (n > 0 or need_dx):
+        if heads_bwd_mlp(h.device) and nh <= 2 and (n > 0 or need_dx):
             # every head in one launch; with hidden layers it also emits the last hidden layer's bias gradient
             hw = [params[2 * (n + j)] for j in range(nh)]
             fused = heads_bwd(h, prev_act, [_c(d) for d in douts[:nh]], hw, [params[2 * (n + j) + 1] for j in range(nh)],
@@ -1860,12 +1890,12 @@ class SVHNEncoderFn(Function):
                 db2 = colsum(dh3.view(-1, ch[3]), b2)
         # each backward-data launch also emits the bias gradient of the layer it lands in (column sums of its output)
         dh2, db1 = conv_up(dh3, wu2, None, B, H // 8, W // 8, ch[2], ch[3], u_act_src=h2, u_act=RELU, out_bias=b1,
-                           frag=ctx.frags[1])
+                           frag=ctx.frags[1], tiled=bool(ENC_BWD_TILED & 1) and x.device in _BIG_LATE)
         if not pair:
             with lf:
                 dw1 = conv_wgrad(h1, dh2, w1, B, H // 4, W // 4, ch[1], ch[2])
         dh1, db0 = conv_up(dh2, wu1, None, B, H // 4, W // 4, ch[1], ch[2], u_act_src=h1, u_act=RELU, out_bias=b0,
-                           frag=ctx.frags[0])
+                           frag=ctx.frags[0], tiled=bool(ENC_BWD_TILED & 2) and x.device in _BIG_LATE)
         if pair:
             ws = _ws(x)
             call("mvk_conv4s2_wgrad_pair", ptr(h2), ptr(dh3), ptr(_grad_target(w2)[0]), H // 8, W // 8, ch[2], ch[3],
@@ -1947,8 +1977,11 @@ class SVHNDecoderFn(Function):
                 amax_of(g1, a1)
             g2 = conv_up(g1, wu1, b1, n, 4, 4, C2, C1, RELU, amax=(a1, wu1.mvk_amax, a2),
                          out=None if rot is None else rot.buf(rkey + ("g2",), (n, 8, 8, C2)))  # [n,8,8,C2]
-            flush_deferred_forward(z2.device)  # a side branch's postponed launches: beside the 64 -> 32 layer, not the 128 -> 64 one
+            if FWD_DEFER_AT <= 1:
+                flush_deferred_forward(z2.device)  # a side branch's postponed launches: beside the 64 -> 32 layer, not the 128 -> 64 one
             g3 = conv_up(g2, wu2, b2, n, 8, 8, C3, C2, RELU, amax=(a2, wu2.mvk_amax, a3))  # [n,16,16,C3]
+            if FWD_DEFER_AT == 2:
+                flush_deferred_forward(z2.device)  # ... beside the fused tail (HBM-bound: the other resource)
             ctx.wamax = (wd1.mvk_amax, wd2.mvk_amax)
             ctx.gamax = (a1, a2)  # bounds of g1, g2: the V operands of the two weight gradients
         else:
@@ -2093,6 +2126,8 @@ class SVHNDecoderFn(Function):
                 dz = gemm(dg1f, wp0, n, L, 16 * C1, tb=True).view(ctx.z_shape)
             dg2.record_stream(_side_stream(z2.device, 30))
             dg1.record_stream(_side_stream(z2.device, 30))
+            if ctx.f16 and wam1 is not None:
+                big_late_leaves(z2.device)  # (what an MLP encoder's backward asks: heads_bwd_mlp)
             with late:
                 dw2 = dw1 = None
                 if not SKIP_LATE:

@@ -451,11 +451,11 @@ def test_svhn_encoder_decoder_nodes(B, svhn_engine):
 @pytest.mark.parametrize("B,D", [(6, (2,)), (33, (1, 28, 28)), (512, (3, 4))])
 def test_mlp_encoder_decoder_nodes(B, D, fused_heads_bwd, monkeypatch):
     """Encoder_VAE_MLP / Decoder_AE_MLP nodes vs the oracle networks; the encoder also with the heads' backward in one
-    launch (mvk_heads_bwd; kernels.HEADS_BWD_MLP switches it for the MLP encoders)."""
+    launch (mvk_heads_bwd; kernels.heads_bwd_mlp / MVK_HEADS_BWD_MLP decide for the MLP encoders)."""
     import golden_cases as G
     from multivae_amd import kernels as K_
 
-    monkeypatch.setattr(K_, "HEADS_BWD_MLP", fused_heads_bwd)
+    monkeypatch.setattr(K_, "_HEADS_BWD_MLP_MODE", "1" if fused_heads_bwd else "0")
     from multivae_amd.models.base.base_config import BaseAEConfig
     from multivae_amd.models.nn.default_architectures import Decoder_AE_MLP, Encoder_VAE_MLP
 

@@ -1,0 +1,15 @@
+#!/bin/bash
+# r06 m: combinations of the switches that moved in gpu_r06_l.sh
+set -u
+export TMPDIR=/tmp MVK_TUNE=1; OUT=gpurun_out/r06m; mkdir -p $OUT
+line() { grep '^{' | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline())
+print('$1', d['value'], d['ms_per_step'], d['ms_per_step_median'])"; }
+for i in 1 2 3; do
+  for e in "-" "MVK_HEADS_BWD_MLP=0" "MVK_HEADS_BWD_MLP=0 MVK_WGRAD_PAIR=0" "MVK_HEADS_BWD_MLP=0 MVK_FLUSH_SIBLING=0" "MVK_HEADS_BWD_MLP=0 MVK_LATE_DW0=0" "MVK_HEADS_BWD_MLP=0 MVK_WGRAD_PAIR=0 MVK_FLUSH_SIBLING=0 MVK_LATE_DW0=0" "MVK_HEADS_BWD=0" "MVK_IMGCONV=1024" "MVK_LATE_DENSE=1"; do
+    envs=""; [ "$e" != "-" ] && envs="$e"
+    env $envs timeout 600 python bench.py --steps 200 --warmup 20 --no-cpu-baseline 2>>$OUT/ab.err | line "[$e]" | tee -a $OUT/ab.txt
+  done
+done
+grep -v "amdgpu.ids" $OUT/ab.err | grep -i "capture failed" | sort | uniq -c

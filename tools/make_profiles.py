@@ -243,5 +243,20 @@ if kf:  # the fused decoder tail: the launch that carries the large modality's r
                "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
                "algorithmic_bytes_per_launch": 4 * 5120 * 256 * 32 + 4 * 5120 * 3072 + 4 * 512 * 3072},
               open(f"{DST}/fused_tail_traffic.json", "w"), indent=1)
+# 6. rectifier counts of the assembled-configuration goldens, float64 distances of the IWAE / DReG gradients (jsonl written by the tests)
+def jsonl(path):
+    return [json.loads(ln) for ln in open(path) if ln.strip()] if os.path.exists(path) else []
+
+
+fc = jsonl(f"{SRC}/flip_counts.jsonl")
+if fc:
+    what = json.load(open(f"{DST}/r05_flip_counts.json"))["what"] if os.path.exists(f"{DST}/r05_flip_counts.json") else ""
+    json.dump({"what": what, "commit": COMMIT, "cases": fc}, open(f"{DST}/{TAG}_flip_counts.json", "w"), indent=1)
+f64 = jsonl(f"{SRC}/iwae_float64.jsonl")
+if f64:
+    json.dump({"what": "IWAE / DReG gradients of the K >= 10 goldens (tests/test_gpu_golden.py::test_mmvae_golden / test_mmvaeplus_golden): "
+                       "largest per-tensor rel-to-max distance of the fp32 CPU oracle and of the HIP path from the FLOAT64 evaluation of "
+                       "the same oracle (tests/test_oracle_float64.py asserts the oracle's own distance on the CPU); the tests allow 5e-4",
+               "commit": COMMIT, "cases": f64}, open(f"{DST}/{TAG}_iwae_float64.json", "w"), indent=1)
 print(open(f"{DST}/{TAG}_pmc_mfma.md").read()[-2600:])
 print(open(f"{DST}/{TAG}_pmc_hbm.md").read()[-1800:])
