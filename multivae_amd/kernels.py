@@ -2083,6 +2083,10 @@ class SVHNDecoderFn(Function):
             am2 = (a_dg3, ctx.wamax[1] if a_dg3 is not None else None, a_dg2)
             am1 = (a_dg2, ctx.wamax[0], None)
             wam2, wam1 = (a_dg3, ctx.gamax[1]), (a_dg2, ctx.gamax[0])  # (max |U|, max |V|) of the two weight gradients
+        if ctx.f16 and wam1 is not None and LATE_LEAVES and z2.device in _DEFER_ACTIVE:
+            # register-stationary weight gradients are this step's late leaves (what an MLP encoder's backward asks: heads_bwd_mlp;
+            # a rotated step decides the same way, so that it launches exactly the kernels of the unrotated one)
+            big_late_leaves(z2.device)
         rot = ctx.rot if (ctx.fused and ctx.rot is not None and rotation(z2.device) is ctx.rot) else None
         rot0 = rot if (rot is not None and ctx.rot_mode == 2) else None  # mode 2: only the first layer's weight gradient
         if rot0 is not None:
@@ -2126,8 +2130,6 @@ class SVHNDecoderFn(Function):
                 dz = gemm(dg1f, wp0, n, L, 16 * C1, tb=True).view(ctx.z_shape)
             dg2.record_stream(_side_stream(z2.device, 30))
             dg1.record_stream(_side_stream(z2.device, 30))
-            if ctx.f16 and wam1 is not None:
-                big_late_leaves(z2.device)  # (what an MLP encoder's backward asks: heads_bwd_mlp)
             with late:
                 dw2 = dw1 = None
                 if not SKIP_LATE:
