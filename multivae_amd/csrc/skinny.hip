@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const SmallKArgs g) {
   float amax_l = 0.f;
 #ifndef MVK_SK_UNROLL
 #define MVK_SK_UNROLL 1  // rows in flight per thread (a row is ONE dependent chain of K packed FMAs): 4 measured, no difference in the step
-// (0.9735 / 0.9757 / 0.9742 / 0.9795 against 0.9761 / 0.9736 / 0.9772 / 0.9783 ms, tools/gpu_r06_j.sh): the round-5 loop stays
+// (0.9735 / 0.9757 / 0.9742 / 0.9795 against 0.9761 / 0.9736 / 0.9772 / 0.9783 ms, tools/lab/r06/gpu_r06_j.sh): the round-5 loop stays
 #endif
   if (active)
 #pragma unroll MVK_SK_UNROLL

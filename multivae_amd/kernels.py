@@ -144,6 +144,29 @@ LATE_DW0 = _lib.tune("MVK_LATE_DW0", "1") != "0"
 SKIP_LATE = _lib.tune("MVK_SKIP_LATE", "0") == "1"
 
 
+# MVK_LATE_GATE=1: the large decoder's register-stationary weight gradients (one 512-register wave per SIMD on every CU for ~150 us)
+# start only behind the convolutional encoder's LAST backward-data launch (late_gate): the encoder's own 512-register launches
+# cannot start on a CU that holds such a workgroup, its small-register ones (heads, split-K weight gradients) can run beside them
+LATE_GATE = _lib.tune("MVK_LATE_GATE", "0") == "1"
+_LATE_GATE_EV = {}  # device -> event recorded by late_gate (main stream)
+_LATE_GATED = {}    # device -> closures that wait for it
+
+
+def late_gate(device):
+    """SVHNEncoderFn.backward, behind its last backward-data launch (the caller's stream must be the step's main stream)."""
+    if LATE_GATE and device in _LATE_GATED:
+        _LATE_GATE_EV[device] = torch.cuda.current_stream(device).record_event()
+
+
+def run_gated(device, fn, *reads):
+    """Inside deferred_reductions: fn() on the late-leaf stream, enqueued at the end of the scope behind every other postponed
+    leaf and behind the late_gate event (when one was recorded).  False: the caller runs fn itself."""
+    if not (LATE_GATE and LATE_LEAVES) or device.type != "cuda" or device not in _DEFER_ACTIVE:
+        return False
+    _LATE_GATED.setdefault(device, []).append((fn, reads))
+    return True
+
+
 def run_last(device, fn, *reads, force=False, params=()):
     """Inside deferred_reductions: run fn() on the late-leaf stream AFTER everything else the backward pass puts there (the
     enqueue itself is postponed to the end of the scope), i.e. in the launch-latency-bound tail of the step where the chip is
@@ -427,8 +450,13 @@ class deferred_reductions:
     def __exit__(self, et, ev, tb):
         if self.on:
             dev = self.grad.device
-            late = _LATE_CALLS.pop(dev, ())
-            if late:  # postponed leaves: enqueued now, on the late-leaf stream, behind the other late leaves
+            late = list(_LATE_CALLS.pop(dev, ()))
+            gated = _LATE_GATED.pop(dev, ())
+            gate_ev = _LATE_GATE_EV.pop(dev, None)
+            if gated and gate_ev is None:
+                late += list(gated)  # nobody recorded the gate: ordinary postponed leaves
+                gated = ()
+            if late or gated:  # postponed leaves: enqueued now, on the late-leaf stream, behind the other late leaves
                 # Ordered behind a MAIN-stream event (late_ready: recorded where the posterior's backward starts, i.e. behind the
                 # join of every decoder's backward), never behind the producer's branch stream itself: the partial flush on a branch
                 # stream waits for the late-leaf stream, a late-leaf stream that waited for that branch stream made the two
@@ -444,11 +472,19 @@ class deferred_reductions:
                         for t in reads:
                             t.record_stream(st)
                         fn()
+                    if gated:
+                        st.wait_event(gate_ev)
+                        for fn, reads in gated:
+                            for t in reads:
+                                t.record_stream(st)
+                            fn()
             _DEFER_ACTIVE.discard(dev)
             _LATE_READY.pop(dev, None)
             _LOSS_EVENT.pop(dev, None)  # the late-leaf stream is joined below
             _LOSS_POSTPONED.pop(dev, None)
             _BIG_LATE.discard(dev)
+            _LATE_GATE_EV.pop(dev, None)
+            _LATE_GATED.pop(dev, None)
             cur = torch.cuda.current_stream(dev)
             for st in dict.fromkeys(_LATE_USED.pop(dev, ())):  # the late leaves (below) and sibling flushes end here
                 if st != cur:
@@ -1896,6 +1932,7 @@ class SVHNEncoderFn(Function):
                 dw1 = conv_wgrad(h1, dh2, w1, B, H // 4, W // 4, ch[1], ch[2])
         dh1, db0 = conv_up(dh2, wu1, None, B, H // 4, W // 4, ch[1], ch[2], u_act_src=h1, u_act=RELU, out_bias=b0,
                            frag=ctx.frags[0], tiled=bool(ENC_BWD_TILED & 2) and x.device in _BIG_LATE)
+        late_gate(x.device)  # the decoder's gated late leaves (MVK_LATE_GATE) may start: no 512-register launch of this chain is left
         if pair:
             ws = _ws(x)
             call("mvk_conv4s2_wgrad_pair", ptr(h2), ptr(dh3), ptr(_grad_target(w2)[0]), H // 8, W // 8, ch[2], ch[3],
@@ -2130,9 +2167,15 @@ class SVHNDecoderFn(Function):
                 dz = gemm(dg1f, wp0, n, L, 16 * C1, tb=True).view(ctx.z_shape)
             dg2.record_stream(_side_stream(z2.device, 30))
             dg1.record_stream(_side_stream(z2.device, 30))
+            def big_leaves():
+                conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2, amax=wam2)
+                conv_wgrad(dg2, g1, w1, n, 4, 4, C2, C1, amax=wam1)
+
+            gated_ok = (LATE_GATE and ctx.f16 and wam1 is not None and not SKIP_LATE and _is_direct(w1) and _is_direct(w2)
+                        and run_gated(z2.device, big_leaves, dg3, g2, dg2, g1))
             with late:
                 dw2 = dw1 = None
-                if not SKIP_LATE:
+                if not SKIP_LATE and not gated_ok:
                     dw2 = conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2, amax=wam2)
                     dw1 = conv_wgrad(dg2, g1, w1, n, 4, 4, C2, C1, amax=wam1)
                 if rot0 is not None:

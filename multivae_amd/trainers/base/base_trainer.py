@@ -132,11 +132,15 @@ class _BatchIterator:
     def __iter__(self):
         order = self._order()
         nb = len(self)
+        if self.fast:
+            # the epoch's whole order goes to the device ONCE: a per-batch `.to(device)` of a pageable host slice is a
+            # synchronous copy — the host then waits for every step it has enqueued and cannot run ahead of the device
+            # (round 6: the trainer's step was 1.06 ms around a 0.96 ms replay)
+            order_dev = (order if self.index_map is None else self.index_map[order]).to(self.device)
         for b in range(nb):
             idx = order[b * self.batch_size : (b + 1) * self.batch_size]
             if self.fast:
-                gi = idx if self.index_map is None else self.index_map[idx]
-                gi = gi.to(self.device)
+                gi = order_dev[b * self.batch_size : (b + 1) * self.batch_size]
                 out = {"data": {m: v.index_select(0, self.resample[m].index_select(0, gi) if m in self.resample else gi)
                                 for m, v in self.data.items()}}
                 if self.masks is not None:
