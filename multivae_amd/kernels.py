@@ -506,6 +506,8 @@ class deferred_reductions:
 # chain on its own stream), everything queued so far is finished on the other branch stream, which is idle by then, instead of
 # in one launch behind the chain.
 FLUSH_SIBLING = _lib.tune("MVK_FLUSH_SIBLING", "1") != "0"
+# MVK_FLUSH_ON_LATE=1: that partial flush on the late-leaf stream, directly behind the large decoder's late weight gradients (A/B)
+FLUSH_ON_LATE = _lib.tune("MVK_FLUSH_ON_LATE", "0") == "1"
 _BRANCH_SET = {}  # device -> the streams of the last run_branches call (main first)
 
 
@@ -516,6 +518,11 @@ def defer_flush_sibling(device, node_params=()):
         return
     cur = torch.cuda.current_stream(device)
     sib = next((st for st in _BRANCH_SET.get(device, ()) if st != cur), None)
+    if FLUSH_ON_LATE and device in _BIG_LATE and _OVERLAP.get(device) is None:
+        # the partial flush has to wait for the decoder's late weight gradients anyway (their slabs are most of what it adds): on
+        # THEIR stream it starts the moment they end — beside the encoders' backward-data launches — instead of behind the other
+        # encoder's whole backward chain on the sibling stream, where its 165 MB ran beside the last launches of the step's chain
+        sib = _side_stream(device, 30)
     if sib is None or _lib.load().mvk_defer_pending() == 0:
         return
     with torch.cuda.stream(sib):
