@@ -126,7 +126,12 @@ static int defer_flush_locked(hipStream_t s, bool last) {
       const int per = (256 >> it.zl_bits) * (it.vec4 ? 4 : 1);
       blocks += (unsigned)(((long long)it.M * it.N + per - 1) / per);
     }
-    hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3(blocks), dim3(256), 0, s, T);
+    // MVK_DEFER_FLUSH_GRID=n: a PARTIAL flush (it runs beside the step's chain) on at most n workgroups (A/B; 0 = one per index)
+    static const int part_grid = mvk_tune("MVK_DEFER_FLUSH_GRID") ? atoi(mvk_tune("MVK_DEFER_FLUSH_GRID")) : 0;
+    if (!last && part_grid > 0 && blocks > (unsigned)part_grid)
+      hipLaunchKernelGGL(splitk_reduce_batch_loop_kernel, dim3(part_grid), dim3(256), 0, s, T, blocks);
+    else
+      hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3(blocks), dim3(256), 0, s, T);
     if (hipGetLastError() != hipSuccess) rc = MVK_ELAUNCH;
   }
   g_defer.items.clear();

@@ -971,6 +971,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const DeferTab
     splitk_reduce_bodyv<1>(E, it.M, it.N, it.nz, it.zstride, blockIdx.x - it.blk0, it.zl_bits, red);
 }
 
+// The same launch with a bounded grid (a workgroup walks the table's workgroup indices grid by grid): for a PARTIAL flush that
+// runs beside the step's last dependent chain — 11 k short workgroups take every free CU slot from the launches it runs beside,
+// a few hundred long ones leave room (mvk_defer_flush; the final flush stays wide: it IS the chain).
+__global__ __launch_bounds__(256) void splitk_reduce_batch_loop_kernel(const DeferTable T, const unsigned total) {
+  __shared__ float red[32 * 33];
+  for (unsigned b = blockIdx.x; b < total; b += gridDim.x) {
+    int i = 0;
+    for (int j = 1; j < T.n; ++j)
+      if (b >= T.it[j].blk0) i = j;
+    const DeferItemC& it = T.it[i];
+    Epilogue E{};
+    E.out = it.out, E.ws = const_cast<float*>(it.ws), E.bias = it.bias, E.act_src = it.act_src;
+    E.ld = it.ld, E.Cu = it.Cu, E.bias_mod = it.bias_mod;
+    E.kind = it.kind, E.act = it.act, E.src_act = it.src_act, E.taps = it.taps, E.atomic = it.atomic;
+    if (it.vec4)
+      splitk_reduce_bodyv<4>(E, it.M, it.N, it.nz, it.zstride, b - it.blk0, it.zl_bits, red);
+    else
+      splitk_reduce_bodyv<1>(E, it.M, it.N, it.nz, it.zstride, b - it.blk0, it.zl_bits, red);
+    __syncthreads();  // `red` is reused by the next index
+  }
+}
+
 // what the launcher chose (needed to finish fused column sums): rows of one tile; 0 = generic kernel
 struct LaunchInfo {
   int bm;
