@@ -658,7 +658,8 @@ def wait_tail_bwd(device):
 # decoder (4 workgroup types, 2-2.5x fabric traffic of its own) far more than its 64 <-> 32-channel one.  MEASURED (three same-box
 # pairs): 1.060 / 1.034 / 1.048 ms postponed behind the first convolution vs 1.047 / 1.051 / 1.042 ms launched where the node is
 # created — no difference in the forward pass; MVK_FWD_DEFER=1 enables it.
-FWD_DEFER_AT = int(_lib.tune("MVK_FWD_DEFER", "0"))  # 1: behind the 128 -> 64 layer; 2: behind the 64 -> 32 layer; 3: behind the fused tail
+FWD_DEFER_AT = int(_lib.tune("MVK_FWD_DEFER", "0"))  # 1: behind the 128 -> 64 layer; 2: behind the 64 -> 32 layer; 3: behind the fused tail;
+# 4: behind the FIRST layer, the side branch's z-independent preparation included
 FWD_DEFER = FWD_DEFER_AT > 0
 _FWD_DEFERRED = {}  # device -> [(stream, closure)], only while run_branches(side_first=True) builds the side branches
 _FWD_DEFER_OPEN = set()
@@ -1617,7 +1618,7 @@ def _planes(rows, cols, like):
     return t, t[0], t[1]
 
 
-def dense16_pack(w, raw=False):
+def dense16_pack(w, raw=False, defer=None):
     """Planes of a Linear weight [N][K] in both orientations + the per-row inverse scales; once per forward pass inside a
     pack_scope (the cache dies with the scope: the weights change at the next optimizer step).  raw: launch here, no cache."""
     sc = _PACK_SCOPE
@@ -1631,21 +1632,31 @@ def dense16_pack(w, raw=False):
     N, K = w.shape
     nk, kn = _planes(N, K, w), _planes(K, N, w)
     nk_inv, kn_inv = _new((N,), w), _new((K,), w)
-    call("mvk_dense16_pack", ptr(w), N, K, ptr(nk[1]), ptr(nk[2]), ptr(nk_inv), ptr(kn[1]), ptr(kn[2]), ptr(kn_inv), stream_ptr())
+
+    def go():
+        call("mvk_dense16_pack", ptr(w), N, K, ptr(nk[1]), ptr(nk[2]), ptr(nk_inv), ptr(kn[1]), ptr(kn[2]), ptr(kn_inv), stream_ptr())
+
+    if defer is not None:
+        defer.append(go)  # (the caller launches it: MLPDecoderFn with MVK_FWD_DEFER=4)
+    else:
+        go()
     out = (nk, nk_inv, kn, kn_inv)
     if sc is not None and not raw:
         sc["cache"][key] = out
     return out
 
 
-def dense16_xamax(x):
+def dense16_xamax(x, defer=None):
     """Device scalar >= max |x| of a target batch, once per forward pass inside a pack_scope."""
     sc = _PACK_SCOPE
     key = ("dense16_xamax", x.data_ptr(), tuple(x.shape))
     if sc is not None and key in sc["cache"]:
         return sc["cache"][key]
     slot = _amax_slots(x, 1)
-    call("mvk_amax", ptr(x), x.numel(), ptr(slot), stream_ptr())
+    if defer is not None:
+        defer.append(lambda: call("mvk_amax", ptr(x), x.numel(), ptr(slot), stream_ptr()))
+    else:
+        call("mvk_amax", ptr(x), x.numel(), ptr(slot), stream_ptr())
     if sc is not None:
         sc["cache"][key] = slot
     return slot
@@ -1718,8 +1729,11 @@ class MLPDecoderFn(Function):
             if ROT_MLP != 1:
                 rot = None
             rkey = ("mlp_dec", w0.data_ptr(), n)
-            nk, nk_inv, kn, kn_inv = dense16_pack(w1)  # both usually done already: Decoder_AE_MLP.early_work
-            xam = dense16_xamax(nll_x)
+            # MVK_FWD_DEFER=4: this branch's z-independent preparation joins the postponed launches (flushed behind the large
+            # decoder's FIRST layer, the latency-sized launch on the step's chain these 30 us of launches otherwise run beside)
+            prep = [] if (FWD_DEFER_AT == 4 and z2.device in _FWD_DEFER_OPEN and TAPS is None) else None
+            nk, nk_inv, kn, kn_inv = dense16_pack(w1, defer=prep)  # both usually done already: Decoder_AE_MLP.early_work
+            xam = dense16_xamax(nll_x, defer=prep)
             zam = _amax_slots(z2, 1)
             lib = _lib.load()
             P, CR = lib.mvk_dense16_fwd_nll_rows(D), lib.mvk_dense16_colsum_rows(n)
@@ -1739,6 +1753,8 @@ class MLPDecoderFn(Function):
             rows = _new((P, n), z2)
 
             def launch():  # the three launches of the forward pass (possibly postponed: defer_forward)
+                for f in prep or ():
+                    f()
                 call("mvk_amax", ptr(z2), z2.numel(), ptr(zam), stream_ptr())
                 call("mvk_dense16_first", ptr(z2), ptr(w0), ptr(b0), ptr(zam), ptr(hp[1]), ptr(hp[2]), ptr(bounds[0:1]), n, H, L,
                      RELU, stream_ptr())
@@ -2019,6 +2035,8 @@ class SVHNDecoderFn(Function):
             else:
                 gemm(z2, wp0, n, 16 * C1, L, bias=b0, bias_mod=C1, act=RELU, out=g1)
                 amax_of(g1, a1)
+            if FWD_DEFER_AT == 4:
+                flush_deferred_forward(z2.device)  # a side branch's postponed launches: behind the first (latency-sized) layer
             g2 = conv_up(g1, wu1, b1, n, 4, 4, C2, C1, RELU, amax=(a1, wu1.mvk_amax, a2),
                          out=None if rot is None else rot.buf(rkey + ("g2",), (n, 8, 8, C2)))  # [n,8,8,C2]
             if FWD_DEFER_AT <= 1:
