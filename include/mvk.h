@@ -646,6 +646,17 @@ int mvk_logprob_fwd(const float* recon, const float* target, int64_t n, int64_t 
 int mvk_logprob_bwd(const float* recon, const float* target, int64_t n, int64_t n_target, int dist, float scale, int C,
                     float eps, const float* g, float* drecon, void* stream);
 
+/* Up to MVK_COPY_MAX device-to-device copies in one launch (dst, src 16-byte aligned, bytes a multiple of 16): the tensors of one
+ * collated batch (trainers/base/base_trainer.py:682-700: `inputs = set_inputs_to_device(inputs, device)`) into the input buffers a
+ * replayed step reads.  Host array of descriptors, copied into the launch. */
+#define MVK_COPY_MAX 8
+typedef struct {
+  void* dst;
+  const void* src;
+  int64_t bytes;
+} mvk_copy_desc;
+int mvk_copy_batch(const mvk_copy_desc* descs, int n, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Optimizer
  * ------------------------------------------------------------------------------------------------ */

@@ -63,6 +63,10 @@ class PackDesc(C.Structure):  # mvk_pack_desc
                 ("amax", _p)]
 
 
+class CopyDesc(C.Structure):  # mvk_copy_desc
+    _fields_ = [("dst", _p), ("src", _p), ("bytes", _i64)]
+
+
 class SeedDesc(C.Structure):  # mvk_seed_desc
     _fields_ = [("buf", _p), ("n", _i64), ("coef", _f), ("fill", C.c_int32)]
 
@@ -153,6 +157,7 @@ PROTOTYPES = {
     "mvk_defer_end": [_p],
     "mvk_adam_step_amsgrad": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _d, _p],
     "mvk_adam_step_fused": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _d, _i, _p],
+    "mvk_copy_batch": [C.POINTER(CopyDesc), _i, _p],
     "mvk_adam_prepare": [_p, _p, _p],
     "mvk_adam_step_pub": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _d, _i, _p, _p],
     "mvk_adam_identity": [_p, _p],

@@ -447,6 +447,37 @@ def test_svhn_encoder_decoder_nodes(B, svhn_engine):
     close(zd.grad, zr.grad, what="svhn dec dz")
 
 
+def test_copy_batch(K):
+    """mvk_copy_batch: up to 8 device-to-device copies in one launch (the modalities of a batch into a captured step's input
+    buffers): every byte arrives, neighbours are untouched, sizes that are not a multiple of a tile, an empty entry, and the
+    argument checks (misaligned pointer, odd byte count, too many entries)."""
+    import ctypes as C
+
+    from multivae_amd import _lib
+
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    shapes = [(512, 784), (512, 3, 32, 32), (7, 4), (0, 8), (4099,)]
+    srcs = [torch.randn(*sh, generator=g).to(d) for sh in shapes[:-1]] + [torch.randn(4 * 4099, generator=g).to(d)]
+    guard = 64
+    dsts = [torch.full((s.numel() + 2 * guard,), -7.0, device=d) for s in srcs]
+    descs = (_lib.CopyDesc * len(srcs))()
+    for e, dst, s in zip(descs, dsts, srcs):
+        e.dst, e.src, e.bytes = dst[guard:].data_ptr(), s.data_ptr(), 4 * s.numel()
+    _lib.call("mvk_copy_batch", descs, len(srcs), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    for dst, s in zip(dsts, srcs):
+        assert torch.equal(dst[guard:guard + s.numel()], s.reshape(-1))
+        assert bool((dst[:guard] == -7.0).all()) and bool((dst[guard + s.numel():] == -7.0).all())
+    lib = _lib.load()
+    bad = (_lib.CopyDesc * 1)()
+    bad[0].dst, bad[0].src, bad[0].bytes = dsts[0][guard + 1:].data_ptr(), srcs[0].data_ptr(), 64  # 4 bytes off a 16-byte boundary
+    assert lib.mvk_copy_batch(bad, 1, None) == -1
+    bad[0].dst, bad[0].bytes = dsts[0][guard:].data_ptr(), 60
+    assert lib.mvk_copy_batch(bad, 1, None) == -1
+    assert lib.mvk_copy_batch((_lib.CopyDesc * 9)(), 9, None) == -1 and lib.mvk_copy_batch(None, 0, None) == 0
+
+
 @pytest.mark.parametrize("fused_heads_bwd", [False, True])
 @pytest.mark.parametrize("B,D", [(6, (2,)), (33, (1, 28, 28)), (512, (3, 4))])
 def test_mlp_encoder_decoder_nodes(B, D, fused_heads_bwd, monkeypatch):
