@@ -276,6 +276,48 @@ def test_optimizer_inside_the_graph_matches_the_host_scalar_step(amsgrad):
     assert float(diff.max()) <= 2e-6, float(diff.max())  # 7 steps of <= 1e-3: a ulp of the step size per step at most
 
 
+@pytest.mark.parametrize("seed_kind", ["unit seed", "autograd's default seed"])
+def test_loss_assembly_postponed_to_the_end_of_the_step(seed_kind):
+    """Round 6: with the unit backward seed nothing inside the step reads what the loss assembly fills (the fused tails hold their
+    gradient pre-multiplied, the posterior node takes the KL rows' constant from the host), so MoPoE lets the launch run LAST
+    (`spec["assembly_last"]`, kernels.ASSEMBLY_LAST) — loss, every metric and the whole gradient buffer are bit for bit those of
+    the launch at the head of the backward pass; with autograd's own seed (a tensor whose value the host does not know) the
+    first reader runs the postponed launch itself (kernels.wait_loss) — same result."""
+    from multivae_amd import kernels
+    from multivae_amd.data.datasets.base import DatasetOutput
+    from multivae_amd.trainers import FlatParams
+
+    d = torch.device("cuda:0")
+    B, K, L = 128, 10, 20
+    g = torch.Generator().manual_seed(21)
+    inputs = DatasetOutput(data=dict(mnist=torch.rand(B, 1, 28, 28, generator=g).to(d), svhn=torch.rand(B, 3, 32, 32, generator=g).to(d)))
+    eps = torch.randn(K, B, L, generator=g).to(d)
+    old = kernels.ASSEMBLY_LAST
+    res, postponed = [], []
+    orig_run_last = kernels.run_last
+    try:
+        for last in (False, True):
+            kernels.ASSEMBLY_LAST = last
+            kernels.run_last = lambda dev, fn, *a, **k: (postponed.append((last, getattr(fn, "__name__", ""))), orig_run_last(dev, fn, *a, **k))[1]
+            model = _mnist_svhn_mopoe(d, K=K, L=L)
+            flat = FlatParams(model)
+            flat.zero_grad()
+            with kernels.deferred_reductions(flat):
+                out = model(inputs, noise=eps)
+                if seed_kind == "unit seed":
+                    out.loss.backward(gradient=kernels.unit_seed(out.loss))
+                else:
+                    out.loss.backward()
+            torch.cuda.synchronize()
+            res.append((float(out.loss.detach()), float(out.loss_sum.detach()), {k: float(v.detach()) for k, v in out.metrics.items()}, flat.grad.detach().clone()))
+    finally:
+        kernels.ASSEMBLY_LAST, kernels.run_last = old, orig_run_last
+    assert (True, "assemble") in postponed and (False, "assemble") not in postponed  # the launch WAS handed to the postponed leaves
+    (l0, s0, m0, g0), (l1, s1, m1, g1) = res
+    assert l0 == l1 and s0 == s1 and m0 == m1
+    assert torch.equal(g0, g1) and float(g0.abs().max()) > 0
+
+
 @pytest.mark.parametrize("amsgrad,which", [(False, "both"), (True, "both"), (False, "svhn"), (False, "mlp"), (False, "small"), (True, "small")])
 def test_rotated_step_is_bit_identical(amsgrad, which):
     """GraphedStep(rotate=optimizer) — the decoders' late weight gradients of step N, their ordered finishes,
