@@ -19,6 +19,9 @@ from .mopoe_config import MoPoEConfig
 
 
 _EARLY_NOISE = _lib.tune("MVK_EARLY_NOISE", "1") != "0"  # 0: draw the noise behind the encoders (A/B)
+# MVK_ENC_SIDE_FIRST=1: the short encoder's node is created FIRST, so that autograd enqueues the LONG encoder's backward first (its
+# launches are the step's last chain; A/B)
+_ENC_SIDE_FIRST = kernels._lib.tune("MVK_ENC_SIDE_FIRST", "0") == "1"
 
 
 # 1: the fused decoder tails' z-independent preparation (dense16 pack + target bound, 18 us) behind the short encoder instead of in
@@ -133,7 +136,7 @@ class MoPoE(BaseMultiVAE):
                 side_work()  # BEHIND the short encoder: its stream also carries the step's weight-pack launch (kernels.pack_scope)
             return out
 
-        enc = kernels.run_branches(names, run, inputs.data[names[0]].device)
+        enc = kernels.run_branches(names, run, inputs.data[names[0]].device, side_first=_ENC_SIDE_FIRST)
         return {m: enc[m] for m in self.encoders.keys()}
 
     def _posterior(self, inputs, K, noise=None, choice=None, want_stats=False):
