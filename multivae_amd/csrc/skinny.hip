@@ -87,6 +87,78 @@ __global__ __launch_bounds__(NW * 64) void heads_fwd_kernel(const HeadsArgs g) {
 }
 
 
+// ONE head of up to 32 outputs over MANY rows (the decoders' gradient into the latent at the decoder batch: 5120 rows, N = 20, K = 2048 /
+// 512 — until round 6 a split-K launch of the tiled engine plus its reduce, 23 + 27 us at the end of the decoder window's chains):
+// a workgroup owns 16 rows, its 4 waves split K, and every wave accumulates BOTH 16-column tiles, so X is read once (the
+// two-tile grid of heads_fwd_kernel read it twice).  Same exact-fp32 MFMA, same fixed summation order per output.
+__global__ __launch_bounds__(256) void narrow_fwd_kernel(const HeadsArgs g) {
+  __shared__ float red[4][2][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+  const int m0 = blockIdx.x * 16;
+  const float* __restrict__ W = g.W[0];
+  const int K = g.K, N = g.N;
+  const int kw = ((K + 63) / 64) * 16;  // k range of a wave, a multiple of 16
+  const int k0 = wave * kw, k1 = min(K, k0 + kw);
+  const int row = min(m0 + l15, g.M - 1);
+  const int n_0 = l15, n_1 = 16 + l15;
+  const bool ok0 = n_0 < N, ok1 = n_1 < N;
+  const float* __restrict__ xrow = g.X + (long long)row * K;
+  const float* __restrict__ w0 = W + (long long)(ok0 ? n_0 : 0) * g.w_sn;
+  const float* __restrict__ w1 = W + (long long)(ok1 ? n_1 : 0) * g.w_sn;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int kb = k0; kb < k1; kb += 16) {
+    const int k = kb + 4 * lq;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    float b0[4] = {0.f, 0.f, 0.f, 0.f}, b1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (k < k1) {
+      a = *reinterpret_cast<const f32x4*>(xrow + k);
+      if (g.wvec) {
+        if (ok0) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(w0 + k);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b0[j] = t[j];
+        }
+        if (ok1) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(w1 + k);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b1[j] = t[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (ok0) b0[j] = w0[(long long)(k + j) * g.w_sk];
+          if (ok1) b1[j] = w1[(long long)(k + j) * g.w_sk];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b0[j], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b1[j], acc1, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    red[wave][0][r * 64 + lane] = acc0[r];
+    red[wave][1][r * 64 + lane] = acc1[r];
+  }
+  __syncthreads();
+  if (wave > 1) return;  // wave 0 finishes the first column tile, wave 1 the second
+  const int n = wave * 16 + l15;
+  if (n >= N) return;
+  const float bias = g.b[0] ? g.b[0][n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = m0 + 4 * lq + r;
+    if (m < g.M) {
+      const int o = r * 64 + lane;
+      const float t = (red[0][wave][o] + red[1][wave][o]) + (red[2][wave][o] + red[3][wave][o]);
+      g.Y[0][(long long)m * N + n] = mvk_act(t + bias, g.act);
+    }
+  }
+}
+
 // Y[head][m][n] = act(sum_z part[z][head][m][n] + b[head][n]), the slices in order (deterministic)
 __global__ __launch_bounds__(256) void heads_finish_kernel(const HeadsArgs g, int heads, int nz) {
   const long long per = (long long)g.M * g.N;
@@ -292,6 +364,12 @@ int heads_launch(const float* X, const float* W0, const float* b0, float* Y0, co
     a.kz = ((K + nz - 1) / nz + 15) & ~15;
     nz = (K + a.kz - 1) / a.kz;
     if (nz < 2 || (long long)nz * heads * M * N > ws_floats) nz = 1;
+  }
+  static const int narrow_on = mvk_tune("MVK_NARROW_FWD") ? atoi(mvk_tune("MVK_NARROW_FWD")) : 1;  // A/B: 0 = the two-tile grid
+  if (narrow_on && heads == 1 && N > 16 && N <= 32 && M >= 1024) {  // many rows, one head: both column tiles in one workgroup
+    hipLaunchKernelGGL(narrow_fwd_kernel, dim3((M + 15) / 16), dim3(256), 0, s, a);
+    MVK_CHECK_LAUNCH();
+    return MVK_OK;
   }
   if (nz > 1) {
     a.part = ws;

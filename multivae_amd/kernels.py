@@ -844,6 +844,24 @@ def heads_fwd(h2, w_mu, b_mu, w_lv, b_lv, N, w_sk, w_sn):
     return mu, lv
 
 
+# MVK_NARROW_DZ=1: the decoders' gradient into the latent (N = L <= 32 outputs from K = 512 / 2048 over the decoder batch) as ONE
+# exact-fp32 launch that reads its input once (narrow_linear / narrow_fwd_kernel) instead of a split-K launch of the tiled engine +
+# its reduce.  MEASURED (four alternating pairs): 0.9382 / 0.9361 / 0.9307 / 0.9317 ms with, 0.9361 / 0.9288 / 0.9293 / 0.9271
+# without (+0.4 %): the launch takes 21.5 / 28.7 us in the step beside the last decoder launches, no less than the pair it
+# replaces (18.5 + 4.5 / 18.5 + 9).  Off.
+NARROW_DZ = _lib.tune("MVK_NARROW_DZ", "0") == "1"
+
+
+def narrow_linear(x2, w, M, N, K, w_sk, w_sn):
+    """y[M, N] = x2[M, K] W with W(k, n) = w[k * w_sk + n * w_sn], 16 < N <= 32, M >= 1024 rows: ONE launch that reads x2 once
+    (mvk_heads_fwd's one-head, many-rows form: narrow_fwd_kernel, exact fp32, fixed summation order).  None: not covered."""
+    if not NARROW_DZ or not (16 < N <= 32) or K % 4 != 0 or M < 1024 or x2.data_ptr() % 16 != 0 or not x2.is_cuda:
+        return None
+    y = _new((M, N), x2)
+    call("mvk_heads_fwd", ptr(x2), ptr(w), None, ptr(y), None, None, None, M, N, K, w_sk, w_sn, stream_ptr())
+    return y
+
+
 HEADS_BWD = _lib.tune("MVK_HEADS_BWD", "1") != "0"  # A/B switch: the heads' backward in one launch
 # MEASURED (headline step, one box, 3-4 rounds each): 1.355 ms with the six separate launches, 1.326 ms with the fused launch
 # for the convolutional (SVHN) encoder only, 1.343 ms with the fused launch for the MLP encoder too (its chain is not the
@@ -1820,7 +1838,10 @@ class MLPDecoderFn(Function):
             call("mvk_dense16_bwd_data", ptr(gp[0]), ptr(gp[1]), ptr(gb), ptr(kn[0]), ptr(kn[1]), ptr(kn_inv), ptr(hp[0]), ptr(dh),
                  ptr(tb0), ptr(ws), ws.numel(), n, H, D, stream_ptr())
             # the gradient of z first (the posterior's backward waits for it), the weight gradients — leaves — behind it
-            dz = linear_bwd_data(dh, w0).view(ctx.z_shape) if ctx.needs_input_grad[0] else None
+            dz = None
+            if ctx.needs_input_grad[0]:
+                dz = narrow_linear(dh, w0, n, w0.shape[1], H, w0.shape[1], 1)  # W(k = h, l) = w0[h][l]
+                dz = (dz if dz is not None else linear_bwd_data(dh, w0)).view(ctx.z_shape)
 
             def wgrad1():
                 wsl = _ws(z2)
@@ -2171,7 +2192,7 @@ class SVHNDecoderFn(Function):
         dz = None
         if rot is not None:  # rotated step: the three weight gradients are the head of the next step (Rotation.begin_step)
             if ctx.needs_input_grad[0]:
-                dz = gemm(dg1f, wp0, n, L, 16 * C1, tb=True).view(ctx.z_shape)
+                dz = _svhn_dz(dg1f, wp0, n, L, C1).view(ctx.z_shape)
 
             def leaves():
                 conv_wgrad(dg3, g2, w2, n, 8, 8, C3, C2, amax=wam2)
@@ -2189,7 +2210,7 @@ class SVHNDecoderFn(Function):
             return dz, None, db0, None, db1, None, db2, dw3, db3, None, None, None
         if late.on:  # the backward-data chain first, then the weight gradients beside whatever follows it
             if ctx.needs_input_grad[0]:
-                dz = gemm(dg1f, wp0, n, L, 16 * C1, tb=True).view(ctx.z_shape)
+                dz = _svhn_dz(dg1f, wp0, n, L, C1).view(ctx.z_shape)
             dg2.record_stream(_side_stream(z2.device, 30))
             dg1.record_stream(_side_stream(z2.device, 30))
             def big_leaves():
@@ -2227,8 +2248,14 @@ class SVHNDecoderFn(Function):
         ws = _ws(z2)
         call("mvk_unflatten_wgrad", ptr(z2), ptr(dg1f), ptr(tw0), n, L, C1, ptr(ws), ws.numel(), stream_ptr())
         if ctx.needs_input_grad[0]:
-            dz = gemm(dg1f, wp0, n, L, 16 * C1, tb=True).view(ctx.z_shape)
+            dz = _svhn_dz(dg1f, wp0, n, L, C1).view(ctx.z_shape)
         return dz, dw0, db0, dw1, db1, dw2, db2, dw3, db3, None, None, None
+
+
+def _svhn_dz(dg1f, wp0, n, L, C1):
+    """d z = d g1 W0^T of the SVHN decoder's first layer (wp0: the [L][16 C1] unflatten pack)."""
+    y = narrow_linear(dg1f, wp0, n, L, 16 * C1, 1, 16 * C1)
+    return y if y is not None else gemm(dg1f, wp0, n, L, 16 * C1, tb=True)
 
 
 def svhn_fused_tail_ok(C4, C3):
